@@ -1,0 +1,354 @@
+"""ctypes front-end for the oracle's C restatement (oracle/oar_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under oar_ocr_amd/ may import this module.
+
+Every helper mirrors one reference function; the citation (file:line under
+/root/reference) lives on the C function it calls.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB = None
+
+
+def build(force: bool = False) -> Path:
+    so = _HERE / "liboar_oracle.so"
+    src = _HERE / "oar_oracle.c"
+    if force or not so.exists() or (src.exists() and so.stat().st_mtime < src.stat().st_mtime):
+        subprocess.check_call(["make", "-C", str(_HERE), "-s", "liboar_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(str(build()))
+        L = _LIB
+        L.orc_find_contours.restype = C.c_void_p
+        L.orc_find_contours.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_contours_count.restype = C.c_long
+        L.orc_contours_count.argtypes = [C.c_void_p]
+        L.orc_contours_npts.restype = C.c_long
+        L.orc_contours_npts.argtypes = [C.c_void_p]
+        L.orc_contours_copy.argtypes = [C.c_void_p] * 5
+        L.orc_contours_free.argtypes = [C.c_void_p]
+        L.orc_box_score_fast.restype = C.c_float
+        L.orc_box_score_fast.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_unclip.restype = C.c_int
+        L.orc_unclip.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int]
+        L.orc_boxes_from_bitmap.restype = C.c_int
+        L.orc_boxes_from_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+                                            C.c_float, C.c_float, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_threshold_mask.argtypes = [C.c_void_p, C.c_long, C.c_float, C.c_void_p]
+        L.orc_argmax_rows.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_void_p]
+        L.orc_ctc_collapse.restype = C.c_int
+        L.orc_ctc_collapse.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_normalize_chw.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_normalize_hwc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_alpha_beta.argtypes = [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_normalize_crnn_chw.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_det_resize_dims.restype = C.c_int
+        L.orc_det_resize_dims.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_resize_triangle_rgb.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_convex_hull.restype = C.c_int
+        L.orc_convex_hull.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_mini_box_from_points.restype = C.c_int
+        L.orc_mini_box_from_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_simplify_chain.restype = C.c_int
+        L.orc_simplify_chain.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_sort_quad_boxes.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_crop_plan.restype = C.c_int
+        L.orc_crop_plan.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_crop_exec.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_bicubic_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
+        L.orc_rec_tensor_width.restype = C.c_int
+        L.orc_rec_tensor_width.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_perspective_transform.restype = C.c_int
+        L.orc_perspective_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_inverse3.restype = C.c_int
+        L.orc_inverse3.argtypes = [C.c_void_p, C.c_void_p]
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ---------------------------------------------------------------- normalize (a4)
+DB_MEAN = (0.485, 0.456, 0.406)
+DB_STD = (0.229, 0.224, 0.225)
+
+
+def alpha_beta(scale, mean, std):
+    a = np.zeros(3, np.float32)
+    b = np.zeros(3, np.float32)
+    lib().orc_alpha_beta(C.c_float(scale), _p(_f32(mean)), _p(_f32(std)), _p(a), _p(b))
+    return a, b
+
+
+def normalize(rgb: np.ndarray, alpha, beta, src=(0, 1, 2), layout="chw") -> np.ndarray:
+    """rgb: [H,W,3] u8.  Returns [3,H,W] (chw) or [H,W,3] (hwc) f32."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w, _ = rgb.shape
+    src_a = np.asarray(src, dtype=np.int32)
+    alpha, beta = _f32(alpha), _f32(beta)
+    if layout == "chw":
+        out = np.empty((3, h, w), np.float32)
+        lib().orc_normalize_chw(_p(rgb), w, h, _p(src_a), _p(alpha), _p(beta), _p(out))
+    else:
+        out = np.empty((h, w, 3), np.float32)
+        lib().orc_normalize_hwc(_p(rgb), w, h, _p(src_a), _p(alpha), _p(beta), _p(out))
+    return out
+
+
+def db_normalize(rgb: np.ndarray) -> np.ndarray:
+    """DB detector input: scale 1/255, ImageNet mean/std applied in OUTPUT (BGR) order
+    (models/detection/db.rs:404-415). Returns [3,H,W]."""
+    a, b = alpha_beta(np.float32(1.0) / np.float32(255.0), DB_MEAN, DB_STD)
+    return normalize(rgb, a, b, src=(2, 1, 0), layout="chw")
+
+
+def crnn_normalize(resized_rgb: np.ndarray, tensor_w: int) -> np.ndarray:
+    resized_rgb = np.ascontiguousarray(resized_rgb, dtype=np.uint8)
+    h, rw, _ = resized_rgb.shape
+    out = np.zeros((3, h, tensor_w), np.float32)
+    lib().orc_normalize_crnn_chw(_p(resized_rgb), rw, h, tensor_w, _p(out))
+    return out
+
+
+# ---------------------------------------------------------------- resize (a3, a16)
+def det_resize_dims(w, h, limit_side_len=960, limit_type="max", max_side_limit=4000):
+    lt = {"max": 0, "min": 1, "resize_long": 2}[limit_type]
+    hw = np.zeros(2, np.uint32)
+    ratios = np.zeros(2, np.float32)
+    need = lib().orc_det_resize_dims(w, h, limit_side_len, lt, max_side_limit, _p(hw), _p(ratios))
+    return bool(need), int(hw[0]), int(hw[1]), float(ratios[0]), float(ratios[1])
+
+
+def resize_triangle(rgb: np.ndarray, nw: int, nh: int) -> np.ndarray:
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w, _ = rgb.shape
+    out = np.empty((nh, nw, 3), np.uint8)
+    lib().orc_resize_triangle_rgb(_p(rgb), w, h, nw, nh, _p(out))
+    return out
+
+
+def det_preprocess(rgb: np.ndarray, limit_side_len=960, limit_type="max", max_side_limit=4000):
+    """resize_detection.rs:162-221 + db.rs normalize. Returns (tensor[3,H,W], (src_h, src_w))."""
+    h, w, _ = rgb.shape
+    img = rgb
+    if h + w < 64:  # image_padding
+        nw_, nh_ = max(w, 32), max(h, 32)
+        pad = np.zeros((nh_, nw_, 3), np.uint8)
+        pad[:h, :w] = rgb
+        img = pad
+    ih, iw, _ = img.shape
+    need, rh, rw, _, _ = det_resize_dims(iw, ih, limit_side_len, limit_type, max_side_limit)
+    if need:
+        img = resize_triangle(img, rw, rh)
+    return db_normalize(img), (h, w)
+
+
+def rec_tensor_width(sizes, img_h=48, img_w=320, max_img_w=3200):
+    ws = np.asarray([s[0] for s in sizes], np.int32)
+    hs = np.asarray([s[1] for s in sizes], np.int32)
+    rw = np.zeros(len(sizes), np.int32)
+    tw = lib().orc_rec_tensor_width(_p(ws), _p(hs), len(sizes), img_h, img_w, max_img_w, _p(rw))
+    return tw, rw
+
+
+def rec_preprocess(crops, img_h=48, img_w=320, max_img_w=3200) -> np.ndarray:
+    """models/recognition/crnn.rs:71-125. crops: list of [h,w,3] u8. Returns [n,3,img_h,Wt] f32."""
+    if not crops:
+        return np.zeros((0, 0, 0, 0), np.float32)
+    tw, rws = rec_tensor_width([(c.shape[1], c.shape[0]) for c in crops], img_h, img_w, max_img_w)
+    out = np.zeros((len(crops), 3, img_h, tw), np.float32)
+    for i, c in enumerate(crops):
+        r = resize_triangle(c, int(rws[i]), img_h)
+        out[i] = crnn_normalize(r, tw)
+    return out
+
+
+# ---------------------------------------------------------------- DB postprocess (a7..a12)
+def threshold_mask(pred: np.ndarray, thresh: float) -> np.ndarray:
+    pred = _f32(pred)
+    mask = np.empty(pred.shape, np.uint8)
+    lib().orc_threshold_mask(_p(pred), pred.size, C.c_float(thresh), _p(mask))
+    return mask
+
+
+def find_contours(mask: np.ndarray):
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    h, w = mask.shape
+    L = lib()
+    cs = L.orc_find_contours(_p(mask), w, h)
+    n, npts = L.orc_contours_count(cs), L.orc_contours_npts(cs)
+    offs = np.zeros(n + 1, np.int64)
+    pts = np.zeros((max(npts, 1), 2), np.int32)
+    bt = np.zeros(max(n, 1), np.int32)
+    par = np.zeros(max(n, 1), np.int32)
+    L.orc_contours_copy(cs, _p(offs), _p(pts), _p(bt), _p(par))
+    L.orc_contours_free(cs)
+    return [(pts[offs[i]:offs[i + 1]].copy(), int(bt[i]), int(par[i])) for i in range(n)]
+
+
+def box_score_fast(pred: np.ndarray, box: np.ndarray) -> float:
+    pred = _f32(pred)
+    box = _f32(box).reshape(-1, 2)
+    h, w = pred.shape
+    return float(lib().orc_box_score_fast(_p(pred), h, w, _p(box), box.shape[0]))
+
+
+def unclip(box: np.ndarray, ratio: float) -> np.ndarray:
+    box = _f32(box).reshape(-1, 2)
+    out = np.zeros((1024, 2), np.float32)
+    n = lib().orc_unclip(_p(box), box.shape[0], C.c_float(ratio), _p(out), 1024)
+    return out[:max(n, 0)].copy()
+
+
+def mini_box(points: np.ndarray):
+    pts = _f32(points).reshape(-1, 2)
+    out = np.zeros((4, 2), np.float32)
+    ms = C.c_float(0)
+    ok = lib().orc_mini_box_from_points(_p(pts), pts.shape[0], _p(out), C.byref(ms))
+    return (out, float(ms.value)) if ok else None
+
+
+def simplify_chain(points: np.ndarray) -> np.ndarray:
+    pts = _f32(points).reshape(-1, 2)
+    out = np.zeros_like(pts)
+    n = lib().orc_simplify_chain(_p(pts), pts.shape[0], _p(out))
+    return out[:n].copy()
+
+
+def convex_hull(points: np.ndarray) -> np.ndarray:
+    pts = _f32(points).reshape(-1, 2)
+    out = np.zeros_like(pts)
+    n = lib().orc_convex_hull(_p(pts), pts.shape[0], _p(out))
+    return out[:n].copy()
+
+
+def boxes_from_bitmap(pred, mask, dest_w, dest_h, box_thresh=0.6, unclip_ratio=1.5, max_candidates=1000, min_size=3.0):
+    pred = _f32(pred)
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    h, w = pred.shape
+    cap = max_candidates
+    boxes = np.zeros((cap, 4, 2), np.float32)
+    scores = np.zeros(cap, np.float32)
+    n = lib().orc_boxes_from_bitmap(_p(pred), _p(mask), h, w, dest_w, dest_h, C.c_float(box_thresh),
+                                    C.c_float(unclip_ratio), max_candidates, C.c_float(min_size), _p(boxes), _p(scores), cap)
+    return boxes[:n].copy(), scores[:n].copy()
+
+
+def db_postprocess(pred, src_h, src_w, thresh=0.3, box_thresh=0.6, unclip_ratio=1.5, max_candidates=1000):
+    """processors/db_postprocess.rs:134-183 (Quad / Fast / no dilation). pred: [H,W] f32."""
+    mask = threshold_mask(pred, thresh)
+    return boxes_from_bitmap(pred, mask, int(src_w), int(src_h), box_thresh, unclip_ratio, max_candidates)
+
+
+def sort_quad_boxes(boxes: np.ndarray) -> np.ndarray:
+    """Returns the permutation (processors/sorting.rs:35-84)."""
+    boxes = _f32(boxes).reshape(-1, 8)
+    order = np.zeros(boxes.shape[0], np.int32)
+    if boxes.shape[0]:
+        lib().orc_sort_quad_boxes(_p(boxes), boxes.shape[0], _p(order))
+    return order
+
+
+# ---------------------------------------------------------------- crop (a14)
+def rotate_crop(img: np.ndarray, box: np.ndarray):
+    """utils/transform.rs:76-191. Returns the crop [h,w,3] u8 or None when the reference errors."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w, _ = img.shape
+    box = _f32(box).reshape(4, 2)
+    plan = np.zeros(7, np.int32)
+    inv = np.zeros(9, np.float32)
+    mode = lib().orc_crop_plan(w, h, _p(box), _p(plan), _p(inv))
+    if mode == 0:
+        return None
+    out = np.empty((int(plan[5]), int(plan[4]), 3), np.uint8)
+    lib().orc_crop_exec(_p(img), w, h, mode, _p(plan), _p(inv), _p(out))
+    return out
+
+
+def bicubic_sample(img: np.ndarray, x: float, y: float) -> np.ndarray:
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w, _ = img.shape
+    out = np.zeros(3, np.uint8)
+    lib().orc_bicubic_sample(_p(img), w, h, C.c_float(x), C.c_float(y), _p(out))
+    return out
+
+
+# ---------------------------------------------------------------- CTC (a18, a19)
+def argmax_rows(probs: np.ndarray):
+    probs = _f32(probs)
+    v = probs.shape[-1]
+    rows = probs.size // v if v else 0
+    idx = np.zeros(rows, np.int64)
+    p = np.zeros(rows, np.float32)
+    lib().orc_argmax_rows(_p(probs), rows, v, _p(idx), _p(p))
+    return idx, p
+
+
+def read_dict_lines(text: str):
+    """decode.rs:120 + ocr.rs:277-291: one entry per line, first char only, empty lines vanish."""
+    return [ln[0] for ln in text.splitlines() if len(ln) > 0]
+
+
+def ctc_charset(dict_chars, use_space_char=True):
+    """decode.rs:391-421 (has_explicit_blank=false): ['\\0'] + chars + [' ']"""
+    chars = list(dict_chars)
+    if use_space_char:
+        chars.append(" ")
+    return ["\0"] + chars
+
+
+def ctc_decode(idx: np.ndarray, prob: np.ndarray, n: int, T: int, charset):
+    """decode.rs:505-614. Returns texts, scores, positions, cols, seq_lens."""
+    idx = np.ascontiguousarray(idx, np.int64).reshape(n, T) if n * T else np.zeros((0, 0), np.int64)
+    prob = _f32(prob).reshape(n, T) if n * T else np.zeros((0, 0), np.float32)
+    texts, scores, positions, cols, lens = [], [], [], [], []
+    if n == 0 or T == 0:
+        return texts, scores, positions, cols, lens
+    kc = np.zeros(T, np.int32)
+    ki = np.zeros(T, np.int64)
+    for b in range(n):
+        sc = C.c_float(0)
+        k = lib().orc_ctc_collapse(_p(idx[b]), _p(prob[b]), T, len(charset), _p(kc), _p(ki), C.byref(sc))
+        texts.append("".join(charset[int(i)] for i in ki[:k]))
+        scores.append(float(np.float32(sc.value)))
+        cols.append([int(c) for c in kc[:k]])
+        positions.append([float(np.float32(c) / np.float32(T)) for c in kc[:k]])
+        lens.append(T)
+    return texts, scores, positions, cols, lens
+
+
+# ---------------------------------------------------------------- host policy (a2, a21)
+def default_cpu_region_batch_size(model_name: str | None) -> int:
+    """src/oarocr/builder_utils.rs:111-125"""
+    return 16 if (model_name and "tiny" in model_name.lower()) else 4
+
+
+def resolve_device_batch_sizes(user_image, user_region, accelerated: bool, model_name):
+    """src/oarocr/builder_utils.rs:86-102"""
+    if accelerated:
+        return user_image, user_region
+    return (user_image if user_image is not None else 1,
+            user_region if user_region is not None else default_cpu_region_batch_size(model_name))
+
+
+def is_cjk(ch: str) -> bool:
+    c = ord(ch)
+    return (0x4E00 <= c <= 0x9FFF) or (0x3400 <= c <= 0x4DBF) or (0x3040 <= c <= 0x30FF) or (0xAC00 <= c <= 0xD7AF)

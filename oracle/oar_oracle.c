@@ -1,0 +1,851 @@
+/*
+ * oar_oracle.c -- CPU restatement ("oracle") of the oar-ocr det+rec hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oar_ocr_amd/ may link, import or call
+ * this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ *
+ * Every function restates one reference function and cites it as file:line relative
+ * to /root/reference.  The reference is Rust and cannot be compiled in this image
+ * (no cargo/rustc), so this restatement is pinned against the known-answer vectors
+ * transcribed from the reference's own inline tests (see
+ * tests/test_oracle_kat.py).  Third-party arithmetic that is NOT in the reference
+ * tree is restated from the published algorithm and is "parity unpinned":
+ *   - image 0.25.6   imageops::resize(.., FilterType::Triangle)    -> orc_resize_triangle_rgb
+ *   - imageproc 0.27 contours::find_contours (Suzuki-Abe)          -> orc_find_contours
+ *   - clipper2-rust 1.0.3 inflate_paths_d (Round join, precision 2)-> orc_unclip
+ *   - nalgebra 0.35  DMatrix::lu().solve / Matrix3::try_inverse     -> orc_perspective_transform
+ *
+ * Build: gcc -O2 -std=c11 -ffp-contract=off -fno-fast-math -fPIC -shared -o liboar_oracle.so oar_oracle.c -lm
+ * (-ffp-contract=off: the reference never fuses mul+add, simd.rs:11-14.)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define F32_EPS 1.1920929e-7f
+#define PI_F 3.14159265358979323846f
+#define PI_D 3.14159265358979323846
+
+typedef struct { float x, y; } pt_t;
+
+/* ------------------------------------------------------------------ helpers */
+static inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+/* Rust `as u32/usize` on f32: truncate toward zero, saturating, NaN -> 0 */
+static inline uint32_t f2u(float v) {
+    if (!(v > 0.0f)) return 0u;
+    if (v >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)v;
+}
+static inline int64_t d2i_round(double v) { return (int64_t)round(v); }
+
+/* f32::total_cmp key */
+static inline int32_t total_key(float f) {
+    int32_t i; memcpy(&i, &f, 4);
+    i ^= (int32_t)(((uint32_t)(i >> 31)) >> 1);
+    return i;
+}
+
+/* ============================================================ a4  normalize
+ * processors/simd.rs:87-104 (normalize_chw_scalar), :107-123 (normalize_hwc_scalar):
+ *   out[c*plane+p] = rgb[p*3+src[c]] as f32 * alpha[c] + beta[c]   (mul then add, no FMA)
+ */
+void orc_normalize_chw(const uint8_t* rgb, int w, int h, const int* src, const float* alpha,
+                       const float* beta, float* out) {
+    size_t plane = (size_t)w * h;
+    for (int c = 0; c < 3; ++c) {
+        float a = alpha[c], b = beta[c]; int sc = src[c];
+        float* dst = out + (size_t)c * plane;
+        for (size_t p = 0; p < plane; ++p) { float v = (float)rgb[p * 3 + sc] * a; dst[p] = v + b; }
+    }
+}
+void orc_normalize_hwc(const uint8_t* rgb, int w, int h, const int* src, const float* alpha,
+                       const float* beta, float* out) {
+    size_t plane = (size_t)w * h;
+    for (size_t p = 0; p < plane; ++p)
+        for (int c = 0; c < 3; ++c) { float v = (float)rgb[p * 3 + src[c]] * alpha[c]; out[p * 3 + c] = v + beta[c]; }
+}
+/* processors/normalization.rs:142-143: alpha = scale/std, beta = -mean/std (f32) */
+void orc_alpha_beta(float scale, const float* mean, const float* std_, float* alpha, float* beta) {
+    for (int i = 0; i < 3; ++i) { alpha[i] = scale / std_[i]; beta[i] = -mean[i] / std_[i]; }
+}
+
+/* ============================================================ a16 CRNN normalize
+ * processors/simd.rs:248-308: dst[c][y][x] = (rgb[(y*rw+x)*3 + (2-c)] / 255.0 - 0.5) / 0.5,
+ * columns >= resized_w keep their prior value (caller zero-fills).
+ */
+void orc_normalize_crnn_chw(const uint8_t* rgb, int resized_w, int img_h, int tensor_w, float* dst) {
+    size_t plane = (size_t)img_h * tensor_w;
+    static const int CRNN_SRC[3] = {2, 1, 0};
+    for (int c = 0; c < 3; ++c)
+        for (int y = 0; y < img_h; ++y)
+            for (int x = 0; x < resized_w; ++x) {
+                float v = (float)rgb[((size_t)y * resized_w + x) * 3 + CRNN_SRC[c]];
+                dst[c * plane + (size_t)y * tensor_w + x] = (v / 255.0f - 0.5f) / 0.5f;
+            }
+}
+
+/* ============================================================ a18 CTC argmax
+ * processors/simd.rs:128-133,190-205: max value; index = LAST index with v >= max.
+ * processors/decode.rs:452-501: one (index, prob) per (batch,time) row.
+ */
+void orc_argmax_rows(const float* data, long rows, long vocab, int64_t* idx, float* prob) {
+    for (long r = 0; r < rows; ++r) {
+        const float* row = data + (size_t)r * vocab;
+        if (vocab == 0) { idx[r] = 0; prob[r] = 0.0f; continue; }
+        float best = -INFINITY; for (long i = 0; i < vocab; ++i) if (row[i] > best) best = row[i];
+        long bi = 0; for (long i = 0; i < vocab; ++i) if (row[i] >= best) bi = i;
+        idx[r] = bi; prob[r] = best;
+    }
+}
+
+/* ============================================================ a19 CTC collapse
+ * processors/decode.rs:505-614: prev = blank(0); emit when idx!=0 && idx!=prev && idx<n_chars;
+ * prev = idx ALWAYS; score = sequential f32 sum / count (0 if none).
+ * Returns number kept; keep_cols[] = timesteps kept.
+ */
+int orc_ctc_collapse(const int64_t* idx, const float* prob, int T, int64_t n_chars, int* keep_cols,
+                     int64_t* keep_idx, float* score) {
+    int n = 0; int64_t prev = 0; float sum = 0.0f;
+    for (int t = 0; t < T; ++t) {
+        int64_t id = idx[t];
+        if (id != 0 && id != prev && id >= 0 && id < n_chars) { keep_cols[n] = t; keep_idx[n] = id; sum += prob[t]; ++n; }
+        prev = id;
+    }
+    *score = n ? sum / (float)n : 0.0f;
+    return n;
+}
+
+/* ============================================================ a7 threshold
+ * processors/db_postprocess.rs:185-221: mask = pred > thresh ? 255 : 0 (strict >)
+ */
+void orc_threshold_mask(const float* pred, long n, float thresh, uint8_t* mask) {
+    for (long i = 0; i < n; ++i) mask[i] = pred[i] > thresh ? 255 : 0;
+}
+
+/* ============================================================ a3 det resize dims
+ * processors/resize_detection.rs:243-319 (type0). limit_type: 0=Max 1=Min 2=ResizeLong.
+ * Returns 1 if a resize is needed; out_hw = {resize_h, resize_w}; ratios = {ratio_h, ratio_w}.
+ */
+int orc_det_resize_dims(uint32_t w, uint32_t h, uint32_t limit_side_len, int limit_type,
+                        uint32_t max_side_limit, uint32_t* out_hw, float* ratios) {
+    uint32_t mx = h > w ? h : w, mn = h < w ? h : w;
+    float ratio;
+    if (limit_type == 0) ratio = mx > limit_side_len ? (float)limit_side_len / (float)mx : 1.0f;
+    else if (limit_type == 1) ratio = mn < limit_side_len ? (float)limit_side_len / (float)mn : 1.0f;
+    else ratio = (float)limit_side_len / (float)mx;
+    uint32_t rh = f2u((float)h * ratio), rw = f2u((float)w * ratio);
+    uint32_t rmx = rh > rw ? rh : rw;
+    if (rmx > max_side_limit) {
+        float lr = (float)max_side_limit / (float)rmx;
+        rh = f2u((float)rh * lr); rw = f2u((float)rw * lr);
+    }
+    rh = (rh + 16) / 32 * 32; if (rh < 32) rh = 32;
+    rw = (rw + 16) / 32 * 32; if (rw < 32) rw = 32;
+    out_hw[0] = rh; out_hw[1] = rw;
+    if (rh == h && rw == w) { ratios[0] = 1.0f; ratios[1] = 1.0f; return 0; }
+    ratios[0] = (float)rh / (float)h; ratios[1] = (float)rw / (float)w;
+    return 1;
+}
+
+/* ============================================================ Triangle resize  [third-party: image 0.25.6]
+ * imageops::sample::{vertical_sample, horizontal_sample} with triangle_kernel, support 1.0.
+ * Vertical pass first into an f32 image (no rounding), then horizontal with clamp(0,255)+round.
+ * Same-size input is a plain copy.  Call sites: resize_detection.rs:314, crnn.rs:104-109.
+ */
+static inline float tri_kernel(float x) { float a = fabsf(x); return a < 1.0f ? 1.0f - a : 0.0f; }
+static inline int64_t clampi64(int64_t v, int64_t lo, int64_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+void orc_resize_triangle_rgb(const uint8_t* src, int w, int h, int nw, int nh, uint8_t* dst) {
+    if (w == 0 || h == 0) { memset(dst, 0, (size_t)nw * nh * 3); return; }
+    if (nw == w && nh == h) { memcpy(dst, src, (size_t)w * h * 3); return; }
+    float* tmp = (float*)malloc(sizeof(float) * (size_t)w * nh * 3);
+    float* ws = (float*)malloc(sizeof(float) * (size_t)((w > h ? w : h) + 4));
+    /* vertical */
+    {
+        float ratio = (float)h / (float)nh;
+        float sratio = ratio < 1.0f ? 1.0f : ratio;
+        float support = 1.0f * sratio;
+        for (int oy = 0; oy < nh; ++oy) {
+            float in = ((float)oy + 0.5f) * ratio;
+            int64_t left = clampi64((int64_t)floorf(in - support), 0, (int64_t)h - 1);
+            int64_t right = clampi64((int64_t)ceilf(in + support), left + 1, (int64_t)h);
+            in = in - 0.5f;
+            int n = 0; float sum = 0.0f;
+            for (int64_t i = left; i < right; ++i) { float wv = tri_kernel(((float)i - in) / sratio); ws[n++] = wv; sum += wv; }
+            for (int i = 0; i < n; ++i) ws[i] /= sum;
+            for (int x = 0; x < w; ++x) {
+                float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+                for (int i = 0; i < n; ++i) {
+                    const uint8_t* p = src + ((size_t)(left + i) * w + x) * 3;
+                    float wv = ws[i];
+                    t0 += (float)p[0] * wv; t1 += (float)p[1] * wv; t2 += (float)p[2] * wv;
+                }
+                float* o = tmp + ((size_t)oy * w + x) * 3; o[0] = t0; o[1] = t1; o[2] = t2;
+            }
+        }
+    }
+    /* horizontal */
+    {
+        float ratio = (float)w / (float)nw;
+        float sratio = ratio < 1.0f ? 1.0f : ratio;
+        float support = 1.0f * sratio;
+        for (int ox = 0; ox < nw; ++ox) {
+            float in = ((float)ox + 0.5f) * ratio;
+            int64_t left = clampi64((int64_t)floorf(in - support), 0, (int64_t)w - 1);
+            int64_t right = clampi64((int64_t)ceilf(in + support), left + 1, (int64_t)w);
+            in = in - 0.5f;
+            int n = 0; float sum = 0.0f;
+            for (int64_t i = left; i < right; ++i) { float wv = tri_kernel(((float)i - in) / sratio); ws[n++] = wv; sum += wv; }
+            for (int i = 0; i < n; ++i) ws[i] /= sum;
+            for (int y = 0; y < nh; ++y) {
+                float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+                for (int i = 0; i < n; ++i) {
+                    const float* p = tmp + ((size_t)y * w + (left + i)) * 3;
+                    float wv = ws[i];
+                    t0 += p[0] * wv; t1 += p[1] * wv; t2 += p[2] * wv;
+                }
+                uint8_t* o = dst + ((size_t)y * nw + ox) * 3;
+                o[0] = (uint8_t)roundf(clampf(t0, 0.0f, 255.0f));
+                o[1] = (uint8_t)roundf(clampf(t1, 0.0f, 255.0f));
+                o[2] = (uint8_t)roundf(clampf(t2, 0.0f, 255.0f));
+            }
+        }
+    }
+    free(tmp); free(ws);
+}
+
+/* ============================================================ a8 contours  [third-party: imageproc 0.27 find_contours]
+ * Suzuki-Abe border following; outer AND hole borders, raster discovery order.
+ * Call site: processors/db_bitmap.rs:100 (threshold 0: pixel > 0 is foreground).
+ * Output: CSR. offsets[n_contours+1], pts (x,y int32 pairs), border_type (0 outer, 1 hole), parent (-1 none).
+ */
+typedef struct {
+    int32_t* pts; size_t n_pts, cap_pts;
+    int64_t* offsets; int32_t* btype; int32_t* parent; size_t n, cap;
+} contour_set_t;
+
+static void cs_push_pt(contour_set_t* cs, int32_t x, int32_t y) {
+    if (cs->n_pts + 1 > cs->cap_pts) { cs->cap_pts = cs->cap_pts ? cs->cap_pts * 2 : 4096; cs->pts = (int32_t*)realloc(cs->pts, cs->cap_pts * 2 * sizeof(int32_t)); }
+    cs->pts[cs->n_pts * 2] = x; cs->pts[cs->n_pts * 2 + 1] = y; cs->n_pts++;
+}
+static void cs_push_contour(contour_set_t* cs, int btype, int parent) {
+    if (cs->n + 2 > cs->cap) {
+        cs->cap = cs->cap ? cs->cap * 2 : 256;
+        cs->offsets = (int64_t*)realloc(cs->offsets, (cs->cap + 1) * sizeof(int64_t));
+        cs->btype = (int32_t*)realloc(cs->btype, cs->cap * sizeof(int32_t));
+        cs->parent = (int32_t*)realloc(cs->parent, cs->cap * sizeof(int32_t));
+    }
+    cs->btype[cs->n] = btype; cs->parent[cs->n] = parent; cs->n++;
+    cs->offsets[cs->n] = (int64_t)cs->n_pts;
+}
+
+static const int DIFFS[8][2] = {{-1, 0}, {-1, -1}, {0, -1}, {1, -1}, {1, 0}, {1, 1}, {0, 1}, {-1, 1}};
+static inline int dir_index(int dx, int dy) { for (int i = 0; i < 8; ++i) if (DIFFS[i][0] == dx && DIFFS[i][1] == dy) return i; return -1; }
+
+contour_set_t* orc_find_contours(const uint8_t* mask, int width, int height) {
+    contour_set_t* cs = (contour_set_t*)calloc(1, sizeof(contour_set_t));
+    cs->cap = 256; cs->offsets = (int64_t*)malloc((cs->cap + 1) * sizeof(int64_t)); cs->offsets[0] = 0;
+    cs->btype = (int32_t*)malloc(cs->cap * sizeof(int32_t)); cs->parent = (int32_t*)malloc(cs->cap * sizeof(int32_t));
+    int32_t* iv = (int32_t*)malloc(sizeof(int32_t) * (size_t)width * height);
+    for (size_t i = 0; i < (size_t)width * height; ++i) iv[i] = mask[i] > 0 ? 1 : 0;
+#define AT(x, y) iv[(size_t)(y) * width + (x)]
+#define NONZERO(px, py) ((px) > -1 && (px) < width && (py) > -1 && (py) < height && AT(px, py) != 0)
+    int curr_border_num = 1;
+    for (int y = 0; y < height; ++y) {
+        int parent_border_num = 1;
+        for (int x = 0; x < width; ++x) {
+            if (AT(x, y) == 0) continue;
+            int have = 0, adjx = 0, adjy = 0, btype = 0;
+            if (AT(x, y) == 1 && x > 0 && AT(x - 1, y) == 0) { have = 1; adjx = x - 1; adjy = y; btype = 0; }
+            else if (AT(x, y) > 0 && x + 1 < width && AT(x + 1, y) == 0) {
+                if (AT(x, y) > 1) parent_border_num = AT(x, y);
+                have = 1; adjx = x + 1; adjy = y; btype = 1;
+            }
+            if (have) {
+                curr_border_num += 1;
+                int parent = -1;
+                if (parent_border_num > 1) {
+                    int pidx = parent_border_num - 2;
+                    int p_outer = cs->btype[pidx] == 0;
+                    if ((btype == 0) ^ p_outer) parent = pidx; else parent = cs->parent[pidx];
+                }
+                /* deque `diffs` rotated so that front == adj - curr; we keep a start offset instead */
+                int start = dir_index(adjx - x, adjy - y);
+                int found = 0, p1x = 0, p1y = 0;
+                for (int k = 0; k < 8; ++k) { /* clockwise from adj */
+                    int d = (start + k) & 7; int px = x + DIFFS[d][0], py = y + DIFFS[d][1];
+                    if (NONZERO(px, py)) { found = 1; p1x = px; p1y = py; break; }
+                }
+                if (found) {
+                    int p2x = p1x, p2y = p1y, p3x = x, p3y = y;
+                    for (;;) {
+                        cs_push_pt(cs, p3x, p3y);
+                        int front = dir_index(p2x - p3x, p2y - p3y);
+                        /* diffs.iter().rev(): last element first == (front+7), ..., front */
+                        int p4x = 0, p4y = 0, d4 = -1;
+                        for (int k = 7; k >= 0; --k) {
+                            int d = (front + k) & 7; int px = p3x + DIFFS[d][0], py = p3y + DIFFS[d][1];
+                            if (NONZERO(px, py)) { p4x = px; p4y = py; d4 = d; break; }
+                        }
+                        int is_right_edge = 0;
+                        for (int k = 7; k >= 0; --k) {
+                            int d = (front + k) & 7;
+                            if (d == d4) break;
+                            if (DIFFS[d][0] == 1 && DIFFS[d][1] == 0) { is_right_edge = 1; break; }
+                        }
+                        if (p3x + 1 == width || is_right_edge) AT(p3x, p3y) = -curr_border_num;
+                        else if (AT(p3x, p3y) == 1) AT(p3x, p3y) = curr_border_num;
+                        if (p4x == x && p4y == y && p3x == p1x && p3y == p1y) break;
+                        p2x = p3x; p2y = p3y; p3x = p4x; p3y = p4y;
+                    }
+                } else {
+                    cs_push_pt(cs, x, y);
+                    AT(x, y) = -curr_border_num;
+                }
+                cs_push_contour(cs, btype, parent);
+            }
+            if (AT(x, y) != 1) { int v = AT(x, y); parent_border_num = v < 0 ? -v : v; }
+        }
+    }
+#undef AT
+#undef NONZERO
+    free(iv);
+    return cs;
+}
+long orc_contours_count(const contour_set_t* cs) { return (long)cs->n; }
+long orc_contours_npts(const contour_set_t* cs) { return (long)cs->n_pts; }
+void orc_contours_copy(const contour_set_t* cs, int64_t* offsets, int32_t* pts, int32_t* btype, int32_t* parent) {
+    memcpy(offsets, cs->offsets, (cs->n + 1) * sizeof(int64_t));
+    memcpy(pts, cs->pts, cs->n_pts * 2 * sizeof(int32_t));
+    memcpy(btype, cs->btype, cs->n * sizeof(int32_t));
+    memcpy(parent, cs->parent, cs->n * sizeof(int32_t));
+}
+void orc_contours_free(contour_set_t* cs) { if (!cs) return; free(cs->pts); free(cs->offsets); free(cs->btype); free(cs->parent); free(cs); }
+
+/* ============================================================ a9 geometry
+ * processors/geometry.rs:226-271 Graham scan (lowest y then lowest x; atan2 total_cmp, tie dist^2; pop on cross<=0)
+ * processors/geometry.rs:310-441 min-area rect (first strictly smaller area wins; skip edge_len_sq < EPS)
+ */
+typedef struct { float cx, cy, w, h, angle; } mar_t;
+
+static int hull_cmp(const pt_t* a, const pt_t* b, pt_t s) {
+    float aa = atan2f(a->y - s.y, a->x - s.x), ab = atan2f(b->y - s.y, b->x - s.x);
+    int32_t ka = total_key(aa), kb = total_key(ab);
+    if (ka != kb) return ka < kb ? -1 : 1;
+    float da = (a->x - s.x) * (a->x - s.x) + (a->y - s.y) * (a->y - s.y);
+    float db = (b->x - s.x) * (b->x - s.x) + (b->y - s.y) * (b->y - s.y);
+    int32_t kda = total_key(da), kdb = total_key(db);
+    return kda < kdb ? -1 : (kda > kdb ? 1 : 0);
+}
+/* stable merge sort (Rust sort_by is stable) */
+static void msort_pts(pt_t* a, pt_t* tmp, int n, pt_t s) {
+    if (n < 2) return;
+    int m = n / 2; msort_pts(a, tmp, m, s); msort_pts(a + m, tmp, n - m, s);
+    int i = 0, j = m, k = 0;
+    while (i < m && j < n) { if (hull_cmp(&a[j], &a[i], s) < 0) tmp[k++] = a[j++]; else tmp[k++] = a[i++]; }
+    while (i < m) tmp[k++] = a[i++];
+    while (j < n) tmp[k++] = a[j++];
+    memcpy(a, tmp, sizeof(pt_t) * n);
+}
+static inline float cross3(pt_t p1, pt_t p2, pt_t p3) { return (p2.x - p1.x) * (p3.y - p1.y) - (p2.y - p1.y) * (p3.x - p1.x); }
+
+int orc_convex_hull(const pt_t* src, int n, pt_t* hull) {
+    if (n < 3) { memcpy(hull, src, sizeof(pt_t) * n); return n; }
+    pt_t* pts = (pt_t*)malloc(sizeof(pt_t) * n); pt_t* tmp = (pt_t*)malloc(sizeof(pt_t) * n);
+    memcpy(pts, src, sizeof(pt_t) * n);
+    int si = 0;
+    for (int i = 1; i < n; ++i) if (pts[i].y < pts[si].y || (pts[i].y == pts[si].y && pts[i].x < pts[si].x)) si = i;
+    pt_t t = pts[0]; pts[0] = pts[si]; pts[si] = t;
+    pt_t s = pts[0];
+    msort_pts(pts + 1, tmp, n - 1, s);
+    int hn = 0;
+    for (int i = 0; i < n; ++i) {
+        while (hn > 1 && cross3(hull[hn - 2], hull[hn - 1], pts[i]) <= 0.0f) hn--;
+        hull[hn++] = pts[i];
+    }
+    free(pts); free(tmp);
+    return hn;
+}
+
+mar_t orc_min_area_rect(const pt_t* src, int n) {
+    mar_t zero = {0, 0, 0, 0, 0};
+    if (n < 3) return zero;
+    pt_t* hp = (pt_t*)malloc(sizeof(pt_t) * n);
+    int hn = orc_convex_hull(src, n, hp);
+    if (hn < 3) {
+        float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+        for (int i = 0; i < n; ++i) {
+            if (src[i].x < mnx) mnx = src[i].x; if (src[i].x > mxx) mxx = src[i].x;
+            if (src[i].y < mny) mny = src[i].y; if (src[i].y > mxy) mxy = src[i].y;
+        }
+        free(hp);
+        if (!isfinite(mnx)) return zero;
+        mar_t r = {(mnx + mxx) * 0.5f, (mny + mxy) * 0.5f, mxx - mnx, mxy - mny, 0.0f};
+        return r;
+    }
+    float min_area = 3.40282347e+38f; mar_t best = zero;
+    for (int i = 0; i < hn; ++i) {
+        int j = (i + 1) % hn;
+        float ex = hp[j].x - hp[i].x, ey = hp[j].y - hp[i].y;
+        float el2 = ex * ex + ey * ey;
+        if (el2 < F32_EPS) continue;
+        float inv = 1.0f / sqrtf(el2);
+        float nx = ex * inv, ny = ey * inv, px = -ny, py = nx;
+        float hix = hp[i].x, hiy = hp[i].y;
+        float mnn = 3.40282347e+38f, mxn = -3.40282347e+38f, mnp = 3.40282347e+38f, mxp = -3.40282347e+38f;
+        for (int k = 0; k < hn; ++k) {
+            float dx = hp[k].x - hix, dy = hp[k].y - hiy;
+            float pn = nx * dx + ny * dy, pp = px * dx + py * dy;
+            if (pn < mnn) mnn = pn; if (pn > mxn) mxn = pn;
+            if (pp < mnp) mnp = pp; if (pp > mxp) mxp = pp;
+        }
+        float w = mxn - mnn, h = mxp - mnp, area = w * h;
+        if (area < min_area) {
+            min_area = area;
+            float cn = (mnn + mxn) * 0.5f, cp = (mnp + mxp) * 0.5f;
+            best.cx = hix + cn * nx + cp * px; best.cy = hiy + cn * ny + cp * py;
+            best.w = w; best.h = h; best.angle = atan2f(ny, nx) * 180.0f / PI_F;
+        }
+    }
+    free(hp);
+    return best;
+}
+
+/* processors/db_bitmap.rs:153-277: get_mini_boxes_from_points (box_points_without_reorder + paddlex order) */
+static int mini_box_from_points(const pt_t* pts, int n, pt_t out[4], float* min_side) {
+    if (n < 3) return 0;
+    mar_t r = orc_min_area_rect(pts, n);
+    float ms = r.w < r.h ? r.w : r.h;    /* f32::min */
+    if (!isfinite(ms) || ms <= 0.0f) return 0;
+    float ca = cosf(r.angle * PI_F / 180.0f), sa = sinf(r.angle * PI_F / 180.0f);
+    float w2 = r.w / 2.0f, h2 = r.h / 2.0f;
+    float cs[4][2] = {{-w2, -h2}, {w2, -h2}, {w2, h2}, {-w2, h2}};
+    pt_t raw[4];
+    for (int i = 0; i < 4; ++i) {
+        raw[i].x = cs[i][0] * ca - cs[i][1] * sa + r.cx;
+        raw[i].y = cs[i][0] * sa + cs[i][1] * ca + r.cy;
+    }
+    /* stable sort by x (partial_cmp) -- insertion sort is stable */
+    for (int i = 1; i < 4; ++i) { pt_t k = raw[i]; int j = i - 1; while (j >= 0 && raw[j].x > k.x) { raw[j + 1] = raw[j]; --j; } raw[j + 1] = k; }
+    int i1, i4, i2, i3;
+    if (raw[1].y > raw[0].y) { i1 = 0; i4 = 1; } else { i1 = 1; i4 = 0; }
+    if (raw[3].y > raw[2].y) { i2 = 2; i3 = 3; } else { i2 = 3; i3 = 2; }
+    out[0] = raw[i1]; out[1] = raw[i2]; out[2] = raw[i3]; out[3] = raw[i4];
+    *min_side = ms;
+    return 1;
+}
+int orc_mini_box_from_points(const pt_t* pts, int n, pt_t* out4, float* min_side) { return mini_box_from_points(pts, n, out4, min_side); }
+
+/* processors/db_bitmap.rs:207-239 simplify_chain_points */
+static inline int sign_step(float v) { return v > 0.0f ? 1 : (v < 0.0f ? -1 : 0); }
+int orc_simplify_chain(const pt_t* p, int n, pt_t* out) {
+    if (n <= 2) { memcpy(out, p, sizeof(pt_t) * n); return n; }
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        pt_t prev = p[(i + n - 1) % n], cur = p[i], next = p[(i + 1) % n];
+        int dpx = sign_step(cur.x - prev.x), dpy = sign_step(cur.y - prev.y);
+        int dnx = sign_step(next.x - cur.x), dny = sign_step(next.y - cur.y);
+        if (dpx != dnx || dpy != dny) out[m++] = cur;
+    }
+    if (m < 3) { memcpy(out, p, sizeof(pt_t) * n); return n; }
+    return m;
+}
+
+/* ============================================================ a10 box score
+ * processors/db_score.rs:34-134 + geometry.rs:1087-1164 (ScanlineBuffer::process_scanline).
+ * Both the serial (<8000 px) and the rayon (>=8000 px) branch reduce to: per row a sequential
+ * left-to-right f32 sum from 0.0, then a sequential sum of the row sums in row order.
+ */
+float orc_box_score_fast(const float* pred, int height, int width, const pt_t* box, int nb) {
+    float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+    if (nb == 0) { mnx = mny = mxx = mxy = 0.0f; }
+    for (int i = 0; i < nb; ++i) {
+        if (box[i].x < mnx) mnx = box[i].x; if (box[i].x > mxx) mxx = box[i].x;
+        if (box[i].y < mny) mny = box[i].y; if (box[i].y > mxy) mxy = box[i].y;
+    }
+    float fx0 = fminf(fmaxf(floorf(mnx), 0.0f), (float)width - 1.0f);
+    float fx1 = fminf(fmaxf(ceilf(mxx), 0.0f), (float)width - 1.0f);
+    float fy0 = fminf(fmaxf(floorf(mny), 0.0f), (float)height - 1.0f);
+    float fy1 = fminf(fmaxf(ceilf(mxy), 0.0f), (float)height - 1.0f);
+    size_t start_y = f2u(fy0), end_y = (size_t)f2u(fy1) + 1, start_x = f2u(fx0), end_x = (size_t)f2u(fx1) + 1;
+    float total = 0.0f; size_t pixels = 0;
+    float* xs = (float*)malloc(sizeof(float) * (nb + 2));
+    for (size_t yy = start_y; yy < end_y; ++yy) {
+        float y = (float)yy + 0.5f;
+        int ni = 0;
+        for (int i = 0; i < nb; ++i) {
+            int j = (i + 1) % nb; pt_t p1 = box[i], p2 = box[j];
+            if (((p1.y <= y && y < p2.y) || (p2.y <= y && y < p1.y)) && fabsf(p2.y - p1.y) > F32_EPS) {
+                float x = p1.x + (y - p1.y) * (p2.x - p1.x) / (p2.y - p1.y);
+                xs[ni++] = x;
+            }
+        }
+        for (int i = 1; i < ni; ++i) { float k = xs[i]; int j = i - 1; while (j >= 0 && xs[j] > k) { xs[j + 1] = xs[j]; --j; } xs[j + 1] = k; }
+        float line = 0.0f; size_t lp = 0;
+        size_t yi = f2u(y);
+        if (yi < (size_t)height) {
+            const float* row = pred + yi * (size_t)width;
+            for (int c = 0; c + 1 < ni; c += 2) {
+                size_t x1 = f2u(fmaxf(xs[c], (float)start_x));
+                size_t x2 = f2u(fminf(xs[c + 1], (float)end_x));
+                if (x1 < x2 && x1 >= start_x && x2 <= end_x) {
+                    size_t xe = x2 < (size_t)width ? x2 : (size_t)width;
+                    if (x1 < xe) { for (size_t x = x1; x < xe; ++x) line += row[x]; lp += xe - x1; }
+                }
+            }
+        }
+        total += line; pixels += lp;
+    }
+    free(xs);
+    return pixels > 0 ? total / (float)pixels : 0.0f;
+}
+
+/* ============================================================ a11 unclip  [third-party: clipper2-rust 1.0.3]
+ * processors/db_bitmap.rs:279-368.  f64 area (shoelace, Clipper2 `Area`), perimeter (hypot sum),
+ * delta = area*ratio/perimeter; inflate_paths_d(Round, Polygon, miter 2, precision 2, arc_tol 0).
+ * Restated: scale by 100 and round to int64; unit normals; per vertex Round join arcs
+ * (Clipper2 ClipperOffset::{BuildNormals,OffsetPoint,DoRound}; arc_tol = |delta|*0.002).
+ * The trailing Union pass of Clipper2 only re-orders/dedups the (convex) offset path; every
+ * consumer here takes the convex hull of the result, which is order independent.
+ * Returns number of points written to out (0 => dropped).
+ */
+typedef struct { int64_t x, y; } p64_t;
+typedef struct { double x, y; } pd_t;
+static inline pd_t unit_normal(p64_t a, p64_t b) {
+    pd_t r = {0.0, 0.0};
+    if (a.x == b.x && a.y == b.y) return r;
+    double dx = (double)(b.x - a.x), dy = (double)(b.y - a.y);
+    double inv = 1.0 / sqrt(dx * dx + dy * dy);
+    dx *= inv; dy *= inv;
+    r.x = dy; r.y = -dx; return r;
+}
+int orc_unclip(const pt_t* box, int nb, float unclip_ratio, pt_t* out, int out_cap) {
+    if (nb < 3) { for (int i = 0; i < nb && i < out_cap; ++i) out[i] = box[i]; return nb; }
+    pd_t* pd = (pd_t*)malloc(sizeof(pd_t) * nb);
+    for (int i = 0; i < nb; ++i) { pd[i].x = (double)box[i].x; pd[i].y = (double)box[i].y; }
+    /* clipper2 area(): a += (prev.y + cur.y) * (prev.x - cur.x); a*0.5 */
+    double a = 0.0; { int prev = nb - 1; for (int i = 0; i < nb; ++i) { a += (pd[prev].y + pd[i].y) * (pd[prev].x - pd[i].x); prev = i; } a *= 0.5; }
+    double area = fabs(a);
+    if (area <= 2.220446049250313e-16) { free(pd); return 0; }
+    double perim = 0.0;
+    for (int i = 1; i < nb; ++i) perim += hypot(pd[i].x - pd[i - 1].x, pd[i].y - pd[i - 1].y);
+    perim += hypot(pd[0].x - pd[nb - 1].x, pd[0].y - pd[nb - 1].y);
+    if (perim <= 2.220446049250313e-16) { free(pd); return 0; }
+    double delta = area * (double)unclip_ratio / perim;
+    if (fabs(delta) <= 2.220446049250313e-16) { free(pd); return 0; }
+
+    const double scale = 100.0;
+    p64_t* path = (p64_t*)malloc(sizeof(p64_t) * nb); int n = 0;
+    for (int i = 0; i < nb; ++i) { /* ScalePath + StripDuplicates */
+        p64_t q = {d2i_round(pd[i].x * scale), d2i_round(pd[i].y * scale)};
+        if (n > 0 && path[n - 1].x == q.x && path[n - 1].y == q.y) continue;
+        path[n++] = q;
+    }
+    while (n > 1 && path[n - 1].x == path[0].x && path[n - 1].y == path[0].y) n--;
+    free(pd);
+    int count = 0;
+    double d = delta * scale;
+    if (n < 3) { free(path); return 0; }
+    if (fabs(d) < 0.5) { /* Execute: tiny delta copies the path */
+        for (int i = 0; i < n && count < out_cap; ++i) { out[count].x = (float)((double)path[i].x / scale); out[count].y = (float)((double)path[i].y / scale); count++; }
+        free(path); return count;
+    }
+    /* group orientation */
+    double ai = 0.0; { int prev = n - 1; for (int i = 0; i < n; ++i) { ai += (double)(path[prev].y + path[i].y) * (double)(path[prev].x - path[i].x); prev = i; } ai *= 0.5; }
+    double gd = ai < 0 ? -d : d;
+    double absd = fabs(gd);
+    double arc_tol = absd * 0.002;
+    double steps360 = fmin(PI_D / acos(1.0 - arc_tol / absd), absd * PI_D);
+    double step_sin = sin(2.0 * PI_D / steps360), step_cos = cos(2.0 * PI_D / steps360);
+    if (gd < 0.0) step_sin = -step_sin;
+    double steps_per_rad = steps360 / (2.0 * PI_D);
+    pd_t* norms = (pd_t*)malloc(sizeof(pd_t) * n);
+    for (int i = 0; i < n; ++i) norms[i] = unit_normal(path[i], path[(i + 1) % n]);
+#define PUSH64(X, Y) do { if (count < out_cap) { int64_t xi = d2i_round(X), yi = d2i_round(Y); out[count].x = (float)((double)xi / scale); out[count].y = (float)((double)yi / scale); } count++; } while (0)
+    for (int j = 0, k = n - 1; j < n; k = j, ++j) {
+        if (path[j].x == path[k].x && path[j].y == path[k].y) continue;
+        /* Clipper2 CrossProduct(v1,v2) = v1.y*v2.x - v2.y*v1.x ; OffsetPoint uses (norms[j], norms[k]) */
+        double sin_a = norms[j].y * norms[k].x - norms[k].y * norms[j].x;
+        double cos_a = norms[j].x * norms[k].x + norms[j].y * norms[k].y;
+        if (sin_a > 1.0) sin_a = 1.0; else if (sin_a < -1.0) sin_a = -1.0;
+        double px = (double)path[j].x, py = (double)path[j].y;
+        if (cos_a > -0.999 && (sin_a * gd < 0)) { /* concave */
+            PUSH64(px + norms[k].x * gd, py + norms[k].y * gd);
+            PUSH64(px, py);
+            PUSH64(px + norms[j].x * gd, py + norms[j].y * gd);
+        } else { /* JoinType::Round -> DoRound */
+            double angle = atan2(sin_a, cos_a);
+            double ox = norms[k].x * gd, oy = norms[k].y * gd;
+            if (j == k) { ox = -ox; oy = -oy; }
+            PUSH64(px + ox, py + oy);
+            int steps = (int)ceil(steps_per_rad * fabs(angle));
+            for (int i = 1; i < steps; ++i) {
+                double nx2 = ox * step_cos - step_sin * oy, ny2 = ox * step_sin + oy * step_cos;
+                ox = nx2; oy = ny2;
+                PUSH64(px + ox, py + oy);
+            }
+            PUSH64(px + norms[j].x * gd, py + norms[j].y * gd);
+        }
+    }
+#undef PUSH64
+    free(norms); free(path);
+    if (count > out_cap) return -count; /* caller buffer too small */
+    /* db_bitmap.rs:355-361 drop duplicate closing point */
+    if (count > 1 && fabsf(out[0].x - out[count - 1].x) < F32_EPS && fabsf(out[0].y - out[count - 1].y) < F32_EPS) count--;
+    if (count < 3) return 0;
+    return count;
+}
+
+/* ============================================================ a8..a12 boxes_from_bitmap
+ * processors/db_bitmap.rs:84-150 (Quad, ScoreMode::Fast). dest = (src_w as u32, src_h as u32).
+ * Output boxes: 8 floats per box (x0,y0..x3,y3) + score; returns count.
+ */
+int orc_boxes_from_bitmap(const float* pred, const uint8_t* mask, int height, int width, uint32_t dest_w,
+                          uint32_t dest_h, float box_thresh, float unclip_ratio, int max_candidates,
+                          float min_size, float* out_boxes, float* out_scores, int out_cap) {
+    float wscale = (float)dest_w / (float)width, hscale = (float)dest_h / (float)height;
+    float dwf = (float)dest_w, dhf = (float)dest_h;
+    contour_set_t* cs = orc_find_contours(mask, width, height);
+    int nout = 0;
+    size_t ncont = cs->n; if ((size_t)max_candidates < ncont) ncont = (size_t)max_candidates;
+    for (size_t ci = 0; ci < ncont; ++ci) {
+        int np = (int)(cs->offsets[ci + 1] - cs->offsets[ci]);
+        const int32_t* ip = cs->pts + cs->offsets[ci] * 2;
+        pt_t* pts = (pt_t*)malloc(sizeof(pt_t) * (np > 0 ? np : 1));
+        pt_t* simp = (pt_t*)malloc(sizeof(pt_t) * (np > 0 ? np : 1));
+        for (int i = 0; i < np; ++i) { pts[i].x = (float)ip[i * 2]; pts[i].y = (float)ip[i * 2 + 1]; }
+        int ns = orc_simplify_chain(pts, np, simp);
+        pt_t mb[4]; float min_side = 0.0f; int ok;
+        if (ns >= 3) ok = mini_box_from_points(simp, ns, mb, &min_side); else ok = mini_box_from_points(pts, np, mb, &min_side);
+        free(pts); free(simp);
+        if (!ok) continue;
+        if (min_side < min_size) continue;
+        float score = orc_box_score_fast(pred, height, width, mb, 4);
+        if (score < box_thresh) continue;
+        pt_t un[512];
+        int nu = orc_unclip(mb, 4, unclip_ratio, un, 512);
+        if (nu <= 0) continue;
+        pt_t bp[4]; float sside = 0.0f;
+        if (!mini_box_from_points(un, nu, bp, &sside)) continue;
+        if (sside < min_size + 2.0f) continue;
+        if (nout < out_cap) {
+            for (int i = 0; i < 4; ++i) {
+                out_boxes[nout * 8 + i * 2] = clampf(roundf(bp[i].x * wscale), 0.0f, dwf);
+                out_boxes[nout * 8 + i * 2 + 1] = clampf(roundf(bp[i].y * hscale), 0.0f, dhf);
+            }
+            out_scores[nout] = score;
+        }
+        nout++;
+    }
+    orc_contours_free(cs);
+    return nout;
+}
+
+/* ============================================================ a13 sort_quad_boxes
+ * processors/sorting.rs:35-84. boxes: n x 8 floats. order_out: permutation (indices into input).
+ */
+static inline float box_ymin(const float* b) { float m = INFINITY; for (int i = 0; i < 4; ++i) if (b[i * 2 + 1] < m) m = b[i * 2 + 1]; return m; }
+static inline float box_xmin(const float* b) { float m = INFINITY; for (int i = 0; i < 4; ++i) if (b[i * 2] < m) m = b[i * 2]; return m; }
+void orc_sort_quad_boxes(const float* boxes, int n, int* order) {
+    for (int i = 0; i < n; ++i) order[i] = i;
+    /* stable insertion sort by (y_min, x_min) */
+    for (int i = 1; i < n; ++i) {
+        int k = order[i]; float ky = box_ymin(boxes + k * 8), kx = box_xmin(boxes + k * 8);
+        int j = i - 1;
+        while (j >= 0) {
+            int o = order[j]; float oy = box_ymin(boxes + o * 8), ox = box_xmin(boxes + o * 8);
+            int gt = (oy > ky) || (oy == ky && ox > kx);
+            if (!gt) break;
+            order[j + 1] = order[j]; --j;
+        }
+        order[j + 1] = k;
+    }
+    for (int i = 0; i + 1 < n; ++i) {
+        for (int j = i; j >= 0; --j) {
+            if (j + 1 >= n) break;
+            const float* c = boxes + order[j] * 8; const float* nx = boxes + order[j + 1] * 8;
+            if (fabsf(box_ymin(nx) - box_ymin(c)) < 10.0f && box_xmin(nx) < box_xmin(c)) { int t = order[j]; order[j] = order[j + 1]; order[j + 1] = t; }
+            else break;
+        }
+    }
+}
+
+/* ============================================================ a14 rotate-crop
+ * utils/transform.rs:76-191 get_rotate_crop_image; :212-283 get_perspective_transform
+ * [third-party nalgebra: 8x8 LU partial pivoting + Matrix3::try_inverse];
+ * :439-502 bicubic (A=-0.5, replicate, j-outer/i-inner/channel-innermost, round().clamp()).
+ */
+static int lu_solve8(float A[8][8], float b[8]) {
+    int perm_i[8], perm_p[8], np = 0;
+    for (int i = 0; i < 8; ++i) {
+        int piv = i; float mx = fabsf(A[i][i]);
+        for (int r = i + 1; r < 8; ++r) { float v = fabsf(A[r][i]); if (v > mx) { mx = v; piv = r; } }
+        float diag = A[piv][i];
+        if (diag == 0.0f) continue;
+        if (piv != i) {
+            perm_i[np] = i; perm_p[np] = piv; np++;
+            for (int c = 0; c < i; ++c) { float t = A[i][c]; A[i][c] = A[piv][c]; A[piv][c] = t; }
+            /* gauss_step_swap */
+            float inv = 1.0f / diag;
+            { float t = A[i][i]; A[i][i] = A[piv][i]; A[piv][i] = t; }
+            for (int r = i + 1; r < 8; ++r) A[r][i] *= inv;
+            for (int k = i + 1; k < 8; ++k) {
+                float t = A[i][k]; A[i][k] = A[piv][k]; A[piv][k] = t;
+                float pk = -A[i][k];
+                for (int r = i + 1; r < 8; ++r) A[r][k] = pk * A[r][i] + A[r][k];
+            }
+        } else {
+            float inv = 1.0f / diag;
+            for (int r = i + 1; r < 8; ++r) A[r][i] *= inv;
+            for (int k = i + 1; k < 8; ++k) {
+                float pk = -A[i][k];
+                for (int r = i + 1; r < 8; ++r) A[r][k] = pk * A[r][i] + A[r][k];
+            }
+        }
+    }
+    for (int s = 0; s < np; ++s) { float t = b[perm_i[s]]; b[perm_i[s]] = b[perm_p[s]]; b[perm_p[s]] = t; }
+    for (int i = 0; i < 7; ++i) { float coeff = -(b[i] / 1.0f); for (int r = i + 1; r < 8; ++r) b[r] = coeff * A[r][i] + b[r]; }
+    for (int i = 7; i >= 0; --i) {
+        float diag = A[i][i]; if (diag == 0.0f) return 0;
+        float coeff = b[i] / diag; b[i] = coeff;
+        float nc = -coeff;
+        for (int r = 0; r < i; ++r) b[r] = nc * A[r][i] + b[r];
+    }
+    return 1;
+}
+int orc_perspective_transform(const pt_t* src, const pt_t* dst, float* m9) {
+    float A[8][8]; float b[8];
+    for (int i = 0; i < 4; ++i) {
+        float sx = src[i].x, sy = src[i].y, dx = dst[i].x, dy = dst[i].y;
+        float r0[8] = {sx, sy, 1.0f, 0.0f, 0.0f, 0.0f, -sx * dx, -sy * dx};
+        float r1[8] = {0.0f, 0.0f, 0.0f, sx, sy, 1.0f, -sx * dy, -sy * dy};
+        memcpy(A[i * 2], r0, sizeof r0); memcpy(A[i * 2 + 1], r1, sizeof r1);
+        b[i * 2] = dx; b[i * 2 + 1] = dy;
+    }
+    if (!lu_solve8(A, b)) return 0;
+    for (int i = 0; i < 8; ++i) m9[i] = b[i];
+    m9[8] = 1.0f;
+    return 1;
+}
+int orc_inverse3(const float* m, float* o) {
+    float m11 = m[0], m12 = m[1], m13 = m[2], m21 = m[3], m22 = m[4], m23 = m[5], m31 = m[6], m32 = m[7], m33 = m[8];
+    float minor_m12_m23 = m22 * m33 - m32 * m23;
+    float minor_m11_m23 = m21 * m33 - m31 * m23;
+    float minor_m11_m22 = m21 * m32 - m31 * m22;
+    float det = m11 * minor_m12_m23 - m12 * minor_m11_m23 + m13 * minor_m11_m22;
+    if (det == 0.0f) return 0;
+    o[0] = minor_m12_m23 / det; o[1] = (m13 * m32 - m33 * m12) / det; o[2] = (m12 * m23 - m22 * m13) / det;
+    o[3] = -minor_m11_m23 / det; o[4] = (m11 * m33 - m31 * m13) / det; o[5] = (m13 * m21 - m23 * m11) / det;
+    o[6] = minor_m11_m22 / det; o[7] = (m12 * m31 - m32 * m11) / det; o[8] = (m11 * m22 - m21 * m12) / det;
+    return 1;
+}
+static inline float cubic_kernel(float t) {
+    const float A = -0.5f; float a = fabsf(t);
+    if (a <= 1.0f) return (A + 2.0f) * a * a * a - (A + 3.0f) * a * a + 1.0f;
+    else if (a < 2.0f) return A * a * a * a - 5.0f * A * a * a + 8.0f * A * a - 4.0f * A;
+    return 0.0f;
+}
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+void orc_bicubic_sample(const uint8_t* img, int w, int h, float x, float y, uint8_t* out3) {
+    int xi = (int)floorf(x), yi = (int)floorf(y);
+    float dx = x - (float)xi, dy = y - (float)yi;
+    float wx[4] = {cubic_kernel(dx + 1.0f), cubic_kernel(dx), cubic_kernel(dx - 1.0f), cubic_kernel(dx - 2.0f)};
+    float wy[4] = {cubic_kernel(dy + 1.0f), cubic_kernel(dy), cubic_kernel(dy - 1.0f), cubic_kernel(dy - 2.0f)};
+    size_t stride = (size_t)w * 3;
+    size_t cx[4], cy[4];
+    for (int i = 0; i < 4; ++i) { cx[i] = (size_t)clampi(xi - 1 + i, 0, w - 1) * 3; cy[i] = (size_t)clampi(yi - 1 + i, 0, h - 1) * stride; }
+    float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+    for (int j = 0; j < 4; ++j) for (int i = 0; i < 4; ++i) {
+        float wt = wx[i] * wy[j]; size_t idx = cy[j] + cx[i];
+        r0 += wt * (float)img[idx]; r1 += wt * (float)img[idx + 1]; r2 += wt * (float)img[idx + 2];
+    }
+    out3[0] = (uint8_t)clampf(roundf(r0), 0.0f, 255.0f);
+    out3[1] = (uint8_t)clampf(roundf(r1), 0.0f, 255.0f);
+    out3[2] = (uint8_t)clampf(roundf(r2), 0.0f, 255.0f);
+}
+static void rotate270(const uint8_t* src, int w, int h, uint8_t* dst) {
+    /* image::imageops::rotate270: out(y, w-1-x) = in(x, y); out dims (h, w) */
+    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+        const uint8_t* p = src + ((size_t)y * w + x) * 3;
+        uint8_t* q = dst + ((size_t)(w - 1 - x) * h + y) * 3;
+        q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
+    }
+}
+/* Plan only: returns 0 on failure (crop dropped); mode 1 = axis-aligned fast path, 2 = warp.
+ * plan: [left, top, crop_w, crop_h, out_w, out_h, rotate(0/1)], inv: 9 floats (mode 2). */
+int orc_crop_plan(int img_w, int img_h, const pt_t* box, int32_t* plan, float* inv) {
+    float mnx = INFINITY, mxx = -INFINITY, mny = INFINITY, mxy = -INFINITY;
+    for (int i = 0; i < 4; ++i) { mnx = fminf(mnx, box[i].x); mxx = fmaxf(mxx, box[i].x); mny = fminf(mny, box[i].y); mxy = fmaxf(mxy, box[i].y); }
+    uint32_t left = f2u(fmaxf(mnx, 0.0f)), top = f2u(fmaxf(mny, 0.0f));
+    uint32_t right = f2u(fminf(mxx, (float)img_w)), bottom = f2u(fminf(mxy, (float)img_h));
+    if (right <= left || bottom <= top) return 0;
+    uint32_t cw = right - left, ch = bottom - top;
+    pt_t s[4];
+    for (int i = 0; i < 4; ++i) { s[i].x = box[i].x - (float)left; s[i].y = box[i].y - (float)top; }
+    for (int i = 1; i < 4; ++i) { pt_t k = s[i]; int j = i - 1; while (j >= 0 && s[j].x > k.x) { s[j + 1] = s[j]; --j; } s[j + 1] = k; }
+    int ia = 0, id = 1, ib = 2, ic = 3;
+    if (s[1].y < s[0].y) { ia = 1; id = 0; }
+    if (s[3].y < s[2].y) { ib = 3; ic = 2; }
+    pt_t o[4] = {s[ia], s[ib], s[ic], s[id]};
+    plan[0] = (int32_t)left; plan[1] = (int32_t)top; plan[2] = (int32_t)cw; plan[3] = (int32_t)ch;
+    float fw = (float)cw, fh = (float)ch;
+    if (o[0].x == 0.0f && o[0].y == 0.0f && o[1].x == fw && o[1].y == 0.0f && o[2].x == fw && o[2].y == fh && o[3].x == 0.0f && o[3].y == fh) {
+        int rot = (float)ch >= (float)cw * 1.5f;
+        plan[4] = rot ? (int32_t)ch : (int32_t)cw; plan[5] = rot ? (int32_t)cw : (int32_t)ch; plan[6] = rot;
+        return 1;
+    }
+    float w1 = hypotf(o[0].x - o[1].x, o[0].y - o[1].y), w2 = hypotf(o[2].x - o[3].x, o[2].y - o[3].y);
+    uint32_t ow = f2u(roundf(fmaxf(w1, w2)));
+    float h1 = hypotf(o[0].x - o[3].x, o[0].y - o[3].y), h2 = hypotf(o[1].x - o[2].x, o[1].y - o[2].y);
+    uint32_t oh = f2u(roundf(fmaxf(h1, h2)));
+    if (ow == 0 || oh == 0) return 0;
+    pt_t std_[4] = {{0.0f, 0.0f}, {(float)ow, 0.0f}, {(float)ow, (float)oh}, {0.0f, (float)oh}};
+    float m[9];
+    if (!orc_perspective_transform(o, std_, m)) return 0;
+    if (!orc_inverse3(m, inv)) return 0;
+    int rot = (float)oh >= (float)ow * 1.5f;
+    plan[4] = rot ? (int32_t)oh : (int32_t)ow; plan[5] = rot ? (int32_t)ow : (int32_t)oh; plan[6] = rot;
+    return 2;
+}
+/* Executes a plan. out must hold plan[4]*plan[5]*3 bytes. */
+void orc_crop_exec(const uint8_t* img, int img_w, int img_h, int mode, const int32_t* plan, const float* inv, uint8_t* out) {
+    (void)img_h;
+    int left = plan[0], top = plan[1], cw = plan[2], ch = plan[3], rot = plan[6];
+    uint8_t* crop = (uint8_t*)malloc((size_t)cw * ch * 3);
+    for (int y = 0; y < ch; ++y) memcpy(crop + (size_t)y * cw * 3, img + ((size_t)(top + y) * img_w + left) * 3, (size_t)cw * 3);
+    if (mode == 1) {
+        if (rot) rotate270(crop, cw, ch, out); else memcpy(out, crop, (size_t)cw * ch * 3);
+        free(crop); return;
+    }
+    int ow = rot ? plan[5] : plan[4], oh = rot ? plan[4] : plan[5];
+    uint8_t* warped = rot ? (uint8_t*)malloc((size_t)ow * oh * 3) : out;
+    for (int dy = 0; dy < oh; ++dy) for (int dx = 0; dx < ow; ++dx) {
+        float fx = (float)dx, fy = (float)dy;
+        /* nalgebra gemv: y = col0*x0; y += col1*x1; y += col2*x2 */
+        float px = inv[0] * fx; px = inv[1] * fy + px; px = inv[2] * 1.0f + px;
+        float py = inv[3] * fx; py = inv[4] * fy + py; py = inv[5] * 1.0f + py;
+        float pz = inv[6] * fx; pz = inv[7] * fy + pz; pz = inv[8] * 1.0f + pz;
+        uint8_t* o = warped + ((size_t)dy * ow + dx) * 3;
+        if (fabsf(pz) > F32_EPS) orc_bicubic_sample(crop, cw, ch, px / pz, py / pz, o);
+        else { o[0] = crop[0]; o[1] = crop[1]; o[2] = crop[2]; }
+    }
+    if (rot) { rotate270(warped, ow, oh, out); free(warped); }
+    free(crop);
+}
+
+/* ============================================================ a16 rec batch geometry
+ * models/recognition/crnn.rs:80-103: max_wh = max(img_w/img_h, max_i w_i/h_i);
+ * Wt = min((img_h*max_wh) as usize, max_img_w); rw_i = min(ceil(img_h*w_i/h_i), Wt)
+ */
+int orc_rec_tensor_width(const int32_t* ws, const int32_t* hs, int n, int img_h, int img_w, int max_img_w, int32_t* resized_w) {
+    float max_wh = (float)img_w / (float)(img_h > 1 ? img_h : 1);
+    for (int i = 0; i < n; ++i) { float r = (float)ws[i] / (float)(hs[i] > 1 ? hs[i] : 1); if (r > max_wh) max_wh = r; } /* fold(acc.max(r)) */
+    uint32_t tw = f2u((float)img_h * max_wh); if (tw > (uint32_t)max_img_w) tw = (uint32_t)max_img_w;
+    for (int i = 0; i < n; ++i) {
+        float ratio = (float)ws[i] / (float)hs[i];
+        uint32_t rw = f2u(ceilf((float)img_h * ratio)); if (rw > tw) rw = tw;
+        resized_w[i] = (int32_t)rw;
+    }
+    return (int)tw;
+}
