@@ -1,0 +1,294 @@
+"""Synthetic PP-OCR-style ONNX graphs (random-init weights of the PP-OCR architecture family).
+
+The reference treats every model as an opaque `.onnx` with one f32 NCHW input named "x" and uses
+output[0] only (oar-ocr-core/src/models/detection/db.rs:388-390, recognition/crnn.rs:273-279).  The
+real files are not in this container, so bench/tests use graphs of the same
+topology family, sized to the byte sizes pinned in core/download/registry.rs:83-84
+(pp-ocrv6_tiny_det 1.78 MB ~ 0.44 M params; pp-ocrv6_tiny_rec 4.46 MB ~ 1.1 M params, V = 6906).
+
+Detector: PP-LCNetV3-style depthwise-separable backbone (strides 4/8/16/32) -> RSE-FPN-style neck
+(1x1 laterals, nearest x2 top-down adds, 3x3 smooth, concat at stride 4) -> DB head (3x3 conv, BN,
+ReLU, 2x ConvTranspose 2x2 s2, Sigmoid).  Recognizer: LCNetV3-style backbone with (2,1)/(1,2)
+strides (H 48 -> 1, W -> W/8), SVTR neck (2 global-attention blocks) and CTC Linear+Softmax head.
+
+Random weights give a meaningless probability map, so the detector carries one hand-set "ink" path:
+channel 0 of every layer on the stride-4 route propagates a blurred darkness signal (all other
+channels are random) and the last ConvTranspose reads it with a large gain.  The network therefore
+genuinely computes text-like blobs from a synthetic page -- nothing is injected after the forward.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .onnx_writer import GraphBuilder, node
+
+DB_MEAN = np.array([0.485, 0.456, 0.406], np.float32)
+DB_STD = np.array([0.229, 0.224, 0.225], np.float32)
+INK_AMPL = 12.0  # channel-0 amplitude for a fully dark neighbourhood
+
+
+class _Net:
+    def __init__(self, name, seed, opset=17, decomposed_hswish=True):
+        self.g = GraphBuilder(name, opset)
+        self.rng = np.random.default_rng(seed)
+        self.decomposed_hswish = decomposed_hswish
+
+    # ------------------------------------------------------------------ weights
+    def _w(self, shape, fan_in, gain=2.0):
+        return (self.rng.standard_normal(shape) * np.sqrt(gain / fan_in)).astype(np.float32)
+
+    def _b(self, n, scale=0.05):
+        return (self.rng.standard_normal(n) * scale).astype(np.float32)
+
+    # ------------------------------------------------------------------ activations
+    def act(self, x, kind):
+        g = self.g
+        if kind is None:
+            return x
+        if kind == "relu":
+            return g.op("Relu", [x])
+        if kind == "hswish":
+            if self.decomposed_hswish:
+                hs = g.op("HardSigmoid", [x], alpha=1.0 / 6.0, beta=0.5)
+                return g.op("Mul", [x, hs])
+            return g.op("HardSwish", [x])
+        if kind == "hsigmoid":
+            return g.op("HardSigmoid", [x], alpha=0.2, beta=0.5)
+        if kind == "sigmoid":
+            return g.op("Sigmoid", [x])
+        if kind == "swish":
+            s = g.op("Sigmoid", [x])
+            return g.op("Mul", [x, s])
+        raise ValueError(kind)
+
+    # ------------------------------------------------------------------ layers
+    def conv(self, x, cin, cout, k, stride=1, groups=1, act=None, ink=None, pad=None, bias=True, w=None, b=None):
+        """ink: None | 'pass' (out0 <- box-filter of in0) | 'zero' (out0 == 0) for the channel-0 ink path."""
+        kh, kw = (k, k) if isinstance(k, int) else k
+        sh, sw = (stride, stride) if isinstance(stride, int) else stride
+        if pad is None:
+            pad = (kh // 2, kw // 2)
+        cpg = cin // groups
+        if w is None:
+            w = self._w((cout, cpg, kh, kw), cpg * kh * kw)
+        if b is None:
+            b = self._b(cout)
+        if ink == "pass":
+            w[0] = 0.0
+            w[0, 0] = 1.0 / (kh * kw)
+            b[0] = 0.0
+        elif ink == "zero":
+            w[0] = 0.0
+            b[0] = 0.0
+        ins = [x, self.g.init(w)]
+        if bias:
+            ins.append(self.g.init(b, "b"))
+        y = self.g.op("Conv", ins, kernel_shape=[kh, kw], strides=[sh, sw], pads=[pad[0], pad[1], pad[0], pad[1]],
+                      group=groups, dilations=[1, 1])
+        return self.act(y, act)
+
+    def se(self, x, c, ink=False):
+        """SE block: GAP -> 1x1 -> ReLU -> 1x1 -> HardSigmoid(0.2, 0.5) -> Mul"""
+        g = self.g
+        r = max(c // 4, 8)
+        p = g.op("GlobalAveragePool", [x])
+        w1, b1 = self._w((r, c, 1, 1), c), self._b(r)
+        w2, b2 = self._w((c, r, 1, 1), r), self._b(c)
+        if ink:  # keep channel 0 unscaled: hard-sigmoid saturates at 1 for input >= 2.5
+            w2[0] = 0.0
+            b2[0] = 3.0
+        h = g.op("Conv", [p, g.init(w1), g.init(b1, "b")], kernel_shape=[1, 1], strides=[1, 1], pads=[0, 0, 0, 0], group=1, dilations=[1, 1])
+        h = g.op("Relu", [h])
+        h = g.op("Conv", [h, g.init(w2), g.init(b2, "b")], kernel_shape=[1, 1], strides=[1, 1], pads=[0, 0, 0, 0], group=1, dilations=[1, 1])
+        h = self.act(h, "hsigmoid")
+        return g.op("Mul", [x, h])
+
+    def ds_block(self, x, cin, cout, k, stride, use_se=False, ink=None, act="hswish"):
+        """DepthwiseSeparable: dw kxk (+act) [SE] pw 1x1 (+act)  (PP-LCNet)"""
+        x = self.conv(x, cin, cin, k, stride, groups=cin, act=act, ink=ink)
+        if use_se:
+            x = self.se(x, cin, ink=ink == "pass")
+        x = self.conv(x, cin, cout, 1, 1, act=act, ink=ink)
+        return x
+
+    def bn(self, x, c, ink=False):
+        g = self.g
+        gamma = (1.0 + 0.1 * self.rng.standard_normal(c)).astype(np.float32)
+        beta = (0.05 * self.rng.standard_normal(c)).astype(np.float32)
+        mean = (0.05 * self.rng.standard_normal(c)).astype(np.float32)
+        var = (1.0 + 0.1 * self.rng.random(c)).astype(np.float32)
+        if ink:
+            gamma[0], beta[0], mean[0], var[0] = 1.0, 0.0, 0.0, 1.0 - 1e-5
+        return g.op("BatchNormalization", [x, g.init(gamma), g.init(beta), g.init(mean), g.init(var)], epsilon=1e-5)
+
+    def conv_transpose2x2(self, x, cin, cout, ink_gain=None, ink_bias=0.0, noise=1.0):
+        """ConvTranspose 2x2 stride 2.  ink_gain: output channel 0 = ink_gain * in0 (+ noise-scaled random
+        contributions from the other input channels when cout == 1) + ink_bias."""
+        w = self._w((cin, cout, 2, 2), cin) * np.float32(noise)
+        b = self._b(cout)
+        if ink_gain is not None:
+            if cout > 1:
+                w[1:, 0] = 0.0          # out0 reads only in0
+            w[0, 0] = ink_gain
+            b[0] = ink_bias
+        return self.g.op("ConvTranspose", [x, self.g.init(w.astype(np.float32)), self.g.init(b, "b")], kernel_shape=[2, 2],
+                         strides=[2, 2], pads=[0, 0, 0, 0], group=1, dilations=[1, 1])
+
+
+def build_det(size="tiny", seed=0):
+    """DB text detector.  Returns (onnx_bytes, info)."""
+    cfg = {
+        #        stem  c2   c3   c4    c5   neck  p
+        "tiny": (16, 24, 32, 64, 128, 256, 64, 16),
+        "server": (32, 64, 128, 256, 512, 1024, 256, 64),
+    }[size]
+    stem, b2, c2, c3, c4, c5, nk, pc = cfg
+    n = _Net(f"synth_db_{size}", seed, decomposed_hswish=True)
+    g = n.g
+    g.add_input("x", ["N", 3, "H", "W"])
+    # stem: channel 0 = INK_AMPL * mean darkness of the 3x3 window (see module docstring)
+    w = n._w((stem, 3, 3, 3), 27)
+    b = n._b(stem)
+    # input plane c holds BGR[c] normalised with mean/std in OUTPUT order (db.rs:404-415)
+    for c in range(3):
+        w[0, c] = -INK_AMPL * DB_STD[c] / 27.0
+    b[0] = INK_AMPL * (1.0 - float(DB_MEAN.mean()))
+    x = n.conv("x", 3, stem, 3, 2, act="hswish", w=w, b=b)
+    x = n.ds_block(x, stem, b2, 3, 1, ink="pass")
+    x = n.ds_block(x, b2, c2, 3, 2, ink="pass")
+    f2 = n.ds_block(x, c2, c2, 3, 1, ink="pass")              # stride 4
+    x = n.ds_block(f2, c2, c3, 3, 2)
+    f3 = n.ds_block(x, c3, c3, 3, 1)                          # stride 8
+    x = n.ds_block(f3, c3, c4, 3, 2)
+    x = n.ds_block(x, c4, c4, 5, 1)
+    f4 = n.ds_block(x, c4, c4, 5, 1)                          # stride 16
+    x = n.ds_block(f4, c4, c5, 5, 2, use_se=True)
+    f5 = n.ds_block(x, c5, c5, 5, 1, use_se=True)             # stride 32
+    # neck
+    in5 = n.conv(f5, c5, nk, 1, ink="zero")
+    in4 = n.conv(f4, c4, nk, 1, ink="zero")
+    in3 = n.conv(f3, c3, nk, 1, ink="zero")
+    in2 = n.conv(f2, c2, nk, 1, ink="pass")
+
+    def up(t, s):
+        return g.op("Resize", [t, "", g.init(np.array([1, 1, s, s], np.float32), "scales")], mode="nearest",
+                    coordinate_transformation_mode="asymmetric", nearest_mode="floor")
+
+    out4 = g.op("Add", [in4, up(in5, 2)])
+    out3 = g.op("Add", [in3, up(out4, 2)])
+    out2 = g.op("Add", [in2, up(out3, 2)])
+    p5 = n.conv(in5, nk, pc, 3)
+    p4 = n.conv(out4, nk, pc, 3)
+    p3 = n.conv(out3, nk, pc, 3)
+    p2 = n.conv(out2, nk, pc, 3, ink="pass")
+    fuse = g.op("Concat", [up(p5, 8), up(p4, 4), up(p3, 2), p2], axis=1)
+    # head: the ink channel is concat index 3*pc
+    hc = pc
+    w = n._w((hc, 4 * pc, 3, 3), 4 * pc * 9)
+    b = n._b(hc)
+    w[0] = 0.0
+    w[0, 3 * pc] = 1.0 / 9.0
+    b[0] = 0.0
+    x = n.conv(fuse, 4 * pc, hc, 3, w=w, b=b, bias=True)
+    x = n.bn(x, hc, ink=True)
+    x = g.op("Relu", [x])
+    x = n.conv_transpose2x2(x, hc, hc, ink_gain=1.0)
+    x = n.bn(x, hc, ink=True)
+    x = g.op("Relu", [x])
+    x = n.conv_transpose2x2(x, hc, 1, ink_gain=2.0, ink_bias=-7.0, noise=0.01)
+    y = g.op("Sigmoid", [x])
+    g.nodes.append(node("Identity", [y], ["prob"]))
+    g.add_output("prob", ["N", 1, "H", "W"])
+    return g.model(), {"params": g.n_params, "size": size}
+
+
+def build_rec(size="tiny", vocab=6906, seed=1):
+    """CRNN/SVTR CTC recognizer: in [n,3,48,W] -> out [n, W/8, vocab] softmax probabilities."""
+    cfg = {
+        #        stem b2  b3  b4   b5   b6   svtr_dim heads out
+        "tiny": (16, 24, 48, 96, 192, 256, 64, 4, 64),
+        "server": (32, 64, 128, 256, 512, 768, 192, 6, 192),
+    }[size]
+    stem, b2, b3, b4, b5, b6, dim, heads, outc = cfg
+    n = _Net(f"synth_rec_{size}", seed, decomposed_hswish=False)
+    g = n.g
+    g.add_input("x", ["N", 3, 48, "W"])
+    x = n.conv("x", 3, stem, 3, 2, act="hswish")                       # 24 x W/2
+    x = n.ds_block(x, stem, b2, 3, 1)
+    x = n.ds_block(x, b2, b3, 3, 1)
+    x = n.ds_block(x, b3, b3, 3, 1)
+    x = n.ds_block(x, b3, b4, 3, (2, 1))                               # 12 x W/2
+    x = n.ds_block(x, b4, b4, 3, 1)
+    x = n.ds_block(x, b4, b5, 3, (1, 2))                               # 12 x W/4
+    x = n.ds_block(x, b5, b5, 5, 1)
+    x = n.ds_block(x, b5, b5, 5, 1)
+    x = n.ds_block(x, b5, b6, 5, (2, 1), use_se=True)                  # 6 x W/4
+    x = n.ds_block(x, b6, b6, 5, 1, use_se=True)
+    x = g.op("AveragePool", [x], kernel_shape=[6, 2], strides=[6, 2], pads=[0, 0, 0, 0])   # 1 x W/8
+    # SVTR neck (EncoderWithSVTR)
+    h = x
+    z = n.conv(x, b6, b6 // 8, (1, 3), act="swish", pad=(0, 1))
+    z = n.conv(z, b6 // 8, dim, 1, act="swish")
+    z = g.op("Squeeze", [z, g.init(np.array([2], np.int64), "axes")])   # [n, dim, T]
+    z = g.op("Transpose", [z], perm=[0, 2, 1])                           # [n, T, dim]
+    hd = dim // heads
+
+    def linear(t, cin, cout, gain=1.0):
+        w = n._w((cin, cout), cin, gain)
+        t = g.op("MatMul", [t, g.init(w)])
+        return g.op("Add", [t, g.init(n._b(cout), "b")])
+
+    def layernorm(t, c):
+        gamma = (1.0 + 0.1 * n.rng.standard_normal(c)).astype(np.float32)
+        beta = (0.05 * n.rng.standard_normal(c)).astype(np.float32)
+        return g.op("LayerNormalization", [t, g.init(gamma), g.init(beta)], axis=-1, epsilon=1e-5)
+
+    for _ in range(2):
+        y = layernorm(z, dim)
+        qkv = linear(y, dim, 3 * dim)
+        qkv = g.op("Reshape", [qkv, g.init(np.array([0, -1, 3, heads, hd], np.int64), "shape")])
+        qkv = g.op("Transpose", [qkv], perm=[2, 0, 3, 1, 4])            # [3, n, heads, T, hd]
+        q, k, v = g.op("Split", [qkv], n_out=3, axis=0)
+        ax0 = g.init(np.array([0], np.int64), "axes")
+        q = g.op("Squeeze", [q, ax0])
+        k = g.op("Squeeze", [k, ax0])
+        v = g.op("Squeeze", [v, ax0])
+        q = g.op("Mul", [q, g.init(np.array(hd ** -0.5, np.float32), "scale")])
+        kt = g.op("Transpose", [k], perm=[0, 1, 3, 2])
+        att = g.op("MatMul", [q, kt])                                    # [n, heads, T, T]
+        att = g.op("Softmax", [att], axis=-1)
+        o = g.op("MatMul", [att, v])                                     # [n, heads, T, hd]
+        o = g.op("Transpose", [o], perm=[0, 2, 1, 3])
+        o = g.op("Reshape", [o, g.init(np.array([0, -1, dim], np.int64), "shape")])
+        o = linear(o, dim, dim)
+        z = g.op("Add", [z, o])
+        y = layernorm(z, dim)
+        y = linear(y, dim, 2 * dim)
+        y = n.act(y, "swish")
+        y = linear(y, 2 * dim, dim)
+        z = g.op("Add", [z, y])
+    z = layernorm(z, dim)
+    z = g.op("Transpose", [z], perm=[0, 2, 1])                           # [n, dim, T]
+    z = g.op("Unsqueeze", [z, g.init(np.array([2], np.int64), "axes")])  # [n, dim, 1, T]
+    z = n.conv(z, dim, b6, 1, act="swish")
+    z = g.op("Concat", [h, z], axis=1)
+    z = n.conv(z, 2 * b6, b6 // 8, (1, 3), act="swish", pad=(0, 1))
+    z = n.conv(z, b6 // 8, outc, 1, act="swish")
+    z = g.op("Squeeze", [z, g.init(np.array([2], np.int64), "axes")])
+    z = g.op("Transpose", [z], perm=[0, 2, 1])                           # [n, T, outc]
+    logits = linear(z, outc, vocab, gain=float(outc) * 4.0)               # spread logits: distinct argmax
+    g.nodes.append(node("Softmax", [logits], ["probs"], axis=2))
+    g.add_output("probs", ["N", "T", vocab])
+    return g.model(), {"params": g.n_params, "size": size, "vocab": vocab}
+
+
+def synth_dict(n_chars=6904):
+    """A dictionary file body with n_chars distinct single-character lines (CJK block + ASCII)."""
+    chars = []
+    for c in range(0x21, 0x7F):
+        chars.append(chr(c))
+    c = 0x4E00
+    while len(chars) < n_chars:
+        chars.append(chr(c))
+        c += 1
+    return "\n".join(chars[:n_chars]) + "\n"
