@@ -1,0 +1,249 @@
+/*
+ * oar_mi355x.h -- C ABI of libOarMi355x.so: the MI355X-native (gfx950) drop-in for the det+rec hot path
+ * of GreatV/oar-ocr.  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * Every entry point cites the reference interface it replaces (file:line under the reference tree).
+ * Two seams are exported:
+ *   Seam A (narrow) -- replaces `OrtInfer` (oar-ocr-core/src/core/inference/ort_infer_execution.rs:121-306):
+ *       .onnx bytes in, f32 tensors in/out.
+ *   Seam B (wide)   -- replaces `ModelAdapter::execute` for text detection / recognition
+ *       (oar-ocr-core/src/core/traits/adapter.rs:42-81) and `OAROCR::predict` (src/oarocr/ocr.rs:518-659),
+ *       so pre/post-processing also runs on the GPU.
+ *
+ * Conventions: every function returns an oar_status (0 = ok); on failure a thread-local message is
+ * available through oar_last_error().  Nothing throws or aborts across the ABI.  Inputs are borrowed for
+ * the duration of the call only; outputs are library-allocated and released with the matching *_free.
+ * Handles may be used from any thread; calls on one handle serialise on an internal mutex (the reference
+ * serialises on `Mutex<Session>`, core/inference/mod.rs:31-37).
+ */
+#ifndef OAR_MI355X_H
+#define OAR_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    OAR_OK = 0,
+    OAR_INVALID_INPUT = 1,   /* OCRError::InvalidInput / validation_error        (core/errors/types.rs:112-214) */
+    OAR_MODEL_LOAD = 2,      /* OCRError::ModelLoad                                                             */
+    OAR_UNSUPPORTED_OP = 3,  /* graph contains an operator the engine does not implement                        */
+    OAR_SHAPE_MISMATCH = 4,  /* OCRError::Tensor                                                                */
+    OAR_DEVICE = 5,          /* HIP runtime failure / no gfx950 device (the library never falls back to CPU)    */
+    OAR_OOM = 6,
+    OAR_INTERNAL = 7
+} oar_status;
+
+/* Copies the calling thread's last error message (NUL terminated, truncated to cap). Returns its length. */
+size_t oar_last_error(char* buf, size_t cap);
+/* Library / device identification: "libOarMi355x <ver> gfx950 <device name> CUs=<n>". */
+size_t oar_version(char* buf, size_t cap);
+/* Number of visible HIP devices (0 => every create call fails with OAR_DEVICE). */
+int oar_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------ Seam A
+ * OrtInfer::new / from_config (core/inference/ort_infer_builders.rs:9-70) -> oar_engine_create
+ * OrtInfer::infer               (core/inference/ort_infer_execution.rs:121-219) -> oar_engine_run
+ * OrtInfer::input_name / primary_input_shape (core/inference/mod.rs:52-115) -> oar_engine_input_name
+ */
+typedef struct oar_engine oar_engine;
+
+typedef struct {
+    int32_t device_id;      /* HIP device ordinal                                                    */
+    int32_t use_hip_graph;  /* 1: capture each (shape-specialised) plan into a hipGraph and replay    */
+    int32_t profile;        /* 1: record hipEvents around kernels (see oar_prof_*)                   */
+    int32_t reserved;
+} oar_engine_cfg;
+
+typedef struct {
+    int32_t rank;
+    int64_t dims[8];
+    float* data;            /* host memory owned by the library; free with oar_tensor_free           */
+    char name[64];
+} oar_tensor;
+
+oar_status oar_engine_create(const uint8_t* onnx, size_t onnx_len, const oar_engine_cfg* cfg, oar_engine** out);
+void oar_engine_destroy(oar_engine* e);
+/* Name of the graph's first non-initializer input (DB/CRNN use "x": models/detection/db.rs:388-390). */
+oar_status oar_engine_input_name(const oar_engine* e, char* buf, size_t cap);
+/* One f32 input (row-major, ONNX/NCHW semantics), all graph outputs copied back to host.
+ * outs must have room for max_out entries; *n_out receives the count. */
+oar_status oar_engine_run(oar_engine* e, const float* input, const int64_t* dims, int32_t rank,
+                          oar_tensor* outs, int32_t max_out, int32_t* n_out);
+void oar_tensor_free(oar_tensor* t);
+/* Analytic cost of the plan for a given input shape (what roofline.achieved is computed from):
+ * flops = sum 2*MACs over conv/matmul steps; bytes = sum (activations in + out + weights once). */
+oar_status oar_engine_cost(oar_engine* e, const int64_t* dims, int32_t rank, double* flops, double* bytes,
+                           int32_t* n_kernels);
+
+/* ------------------------------------------------------------------------------------------------ Seam B: detection
+ * TextDetectionAdapter::execute (domain/adapters/text_detection_adapter.rs:36-79) -> DBModel::forward
+ * (models/detection/db.rs:281-335): resize (processors/resize_detection.rs:243-319) -> normalize
+ * (processors/normalization.rs:429-482) -> network -> DBPostProcess (processors/db_postprocess.rs:100-183).
+ */
+typedef struct oar_det oar_det;
+
+typedef struct {
+    int32_t device_id;
+    uint32_t limit_side_len;   /* default 960  (core/constants.rs:15)                                   */
+    int32_t limit_type;        /* 0 = Max, 1 = Min, 2 = ResizeLong (processors/types.rs LimitType)      */
+    uint32_t max_side_limit;   /* default 4000 (core/constants.rs:11)                                   */
+    uint32_t max_candidates;   /* default 1000 (processors/db_postprocess.rs:79)                        */
+    int32_t use_hip_graph;
+    int32_t profile;
+    int32_t host_threads;      /* worker threads for the serial contour/geometry stage (0 = hw conc.)   */
+} oar_det_cfg;
+
+/* CSR result: image i owns boxes [box_offsets[i], box_offsets[i+1]); each box is 4 points (x,y) f32 in
+ * original-image coordinates, contour discovery order (unsorted, as the adapter returns them). */
+typedef struct {
+    uint32_t n_images;
+    uint32_t n_boxes;
+    uint32_t* box_offsets;   /* n_images + 1 */
+    float* points;           /* n_boxes * 8  */
+    float* scores;           /* n_boxes      */
+} oar_det_result;
+
+oar_status oar_det_create(const uint8_t* onnx, size_t onnx_len, const oar_det_cfg* cfg, oar_det** out);
+void oar_det_destroy(oar_det* d);
+/* images: n tightly packed RGB8 (HWC) host buffers. thresh/box_thresh/unclip = TextDetectionConfig
+ * {score_threshold, box_threshold, unclip_ratio} (domain/tasks/text_detection.rs:34-66). */
+oar_status oar_det_run(oar_det* d, const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights,
+                       uint32_t n_images, float thresh, float box_thresh, float unclip_ratio, oar_det_result* out);
+void oar_det_result_free(oar_det_result* r);
+/* Test hook (parity of a7..a12 in isolation): run only DB post-processing on a host probability map. */
+oar_status oar_db_postprocess(const float* pred, uint32_t height, uint32_t width, uint32_t src_w, uint32_t src_h,
+                              float thresh, float box_thresh, float unclip_ratio, uint32_t max_candidates,
+                              oar_det_result* out);
+
+/* ------------------------------------------------------------------------------------------------ Seam B: recognition
+ * TextRecognitionAdapter::execute (domain/adapters/text_recognition_adapter.rs:35-111) -> CRNNModel::forward_refs
+ * (models/recognition/crnn.rs:247-293): resize+normalize (crnn.rs:71-125) -> network -> CTC argmax
+ * (processors/decode.rs:452-501).  The dictionary / string assembly stays on the caller's side exactly as
+ * decode.rs:505-614 (the result is the reference's CTCArgmaxOutput, decode.rs:28-33).
+ */
+typedef struct oar_rec oar_rec;
+
+typedef struct {
+    int32_t device_id;
+    uint32_t rec_image_shape[3];  /* default {3,48,320} (core/constants.rs:21)  */
+    uint32_t max_img_w;           /* default 3200       (core/constants.rs:8)   */
+    int32_t use_hip_graph;
+    int32_t profile;
+    int32_t reserved;
+} oar_rec_cfg;
+
+typedef struct {
+    uint32_t batch;
+    uint32_t seq_len;        /* T                              */
+    uint32_t vocab;          /* V (output last dim)            */
+    uint32_t tensor_width;   /* Wt the batch was padded to     */
+    int64_t* indices;        /* batch * T, argmax (last max index wins) */
+    float* probs;            /* batch * T, max probability      */
+} oar_rec_result;
+
+oar_status oar_rec_create(const uint8_t* onnx, size_t onnx_len, const oar_rec_cfg* cfg, oar_rec** out);
+void oar_rec_destroy(oar_rec* r);
+oar_status oar_rec_run(oar_rec* r, const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights,
+                       uint32_t n_crops, oar_rec_result* out);
+void oar_rec_result_free(oar_rec_result* r);
+
+/* ------------------------------------------------------------------------------------------------ Seam B: whole pipeline
+ * OAROCRBuilder::new(det, rec, dict)...build() (src/oarocr/ocr.rs:105,249-417) -> oar_ocr_create
+ * OAROCR::predict(Vec<RgbImage>)               (src/oarocr/ocr.rs:518-659)     -> oar_ocr_predict
+ * Everything between the u8 pages and the per-region (box, CTC indices, probs) stays in HBM:
+ * detect -> sort_quad_boxes (processors/sorting.rs:35-84) -> get_rotate_crop_image (utils/transform.rs:76-191)
+ * -> wh-ratio pooled recognition batches (ocr.rs:802-897) -> CTC argmax.
+ */
+typedef struct oar_ocr oar_ocr;
+
+typedef struct {
+    oar_det_cfg det;
+    oar_rec_cfg rec;
+    float det_thresh;          /* builder default 0.3 (src/oarocr/ocr.rs:319-366)           */
+    float det_box_thresh;      /* builder default 0.6                                         */
+    float det_unclip_ratio;    /* builder default 2.0; explicit TextDetectionConfig: 1.5      */
+    uint32_t image_batch_size; /* 0 => adapter recommended 8  (text_detection_adapter.rs:85-87)   */
+    uint32_t region_batch_size;/* 0 => adapter recommended 64 (text_recognition_adapter.rs:117-127) */
+    uint32_t max_pooled_crops; /* 0 => 4096 (src/oarocr/ocr.rs:603)                            */
+} oar_ocr_cfg;
+
+/* One entry per detected region, grouped per image in sorted (reading) order; regions whose crop failed
+ * are dropped like the reference does (ocr.rs:736-738). */
+typedef struct {
+    uint32_t n_images;
+    uint32_t n_regions;
+    uint32_t* region_offsets;  /* n_images + 1                                              */
+    float* points;             /* n_regions * 8, original-image coordinates                 */
+    float* det_scores;         /* n_regions (not part of OAROCRResult; kept for parity checks) */
+    uint32_t* crop_wh;         /* n_regions * 2 (w,h) of the rectified crop                 */
+    uint32_t* seq_len;         /* n_regions: T of the batch the region was recognised in    */
+    float* max_wh_ratio;       /* n_regions: chunk_max_wh_ratio (ocr.rs:828-831), for ctc_word_boxes */
+    uint64_t* ctc_offsets;     /* n_regions + 1 into ctc_indices / ctc_probs                */
+    int64_t* ctc_indices;
+    float* ctc_probs;
+} oar_ocr_result;
+
+oar_status oar_ocr_create(const uint8_t* det_onnx, size_t det_len, const uint8_t* rec_onnx, size_t rec_len,
+                          const oar_ocr_cfg* cfg, oar_ocr** out);
+void oar_ocr_destroy(oar_ocr* o);
+oar_status oar_ocr_predict(oar_ocr* o, const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights,
+                           uint32_t n_images, oar_ocr_result* out);
+/* Same, with the pages already resident in HBM (device pointers from oar_dev_alloc/oar_dev_upload). */
+oar_status oar_ocr_predict_device(oar_ocr* o, const uint8_t* const* d_rgb, const uint32_t* widths,
+                                  const uint32_t* heights, uint32_t n_images, oar_ocr_result* out);
+void oar_ocr_result_free(oar_ocr_result* r);
+
+/* ------------------------------------------------------------------------------------------------ device helpers */
+oar_status oar_dev_alloc(int32_t device_id, size_t bytes, void** out);
+oar_status oar_dev_upload(void* dst, const void* src, size_t bytes);
+oar_status oar_dev_download(void* dst, const void* src, size_t bytes);
+void oar_dev_free(void* p);
+oar_status oar_dev_synchronize(int32_t device_id);
+
+/* ------------------------------------------------------------------------------------------------ stand-alone kernels
+ * Exposed so each HIP kernel can be parity-tested against the oracle on identical input bits. Host in/out.
+ * a4  processors/simd.rs:28-45,87-123   */
+oar_status oar_k_normalize(const uint8_t* rgb, uint32_t w, uint32_t h, const int32_t src_channels[3],
+                           const float alpha[3], const float beta[3], int32_t hwc_layout, float* out);
+/* a16 processors/simd.rs:248-308 + image Triangle resize (models/recognition/crnn.rs:98-121) */
+oar_status oar_k_rec_preprocess(const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights,
+                                uint32_t n, uint32_t img_h, uint32_t img_w, uint32_t max_img_w,
+                                float* out_nchw, uint32_t* tensor_width);
+/* a3  image Triangle resize (processors/resize_detection.rs:314) */
+oar_status oar_k_resize_triangle(const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, uint8_t* out);
+/* a7  processors/db_postprocess.rs:185-221 */
+oar_status oar_k_threshold(const float* pred, size_t n, float thresh, uint8_t* mask);
+/* a18 processors/decode.rs:452-501 + simd.rs:72-81 */
+oar_status oar_k_ctc_argmax(const float* probs, size_t rows, size_t vocab, int64_t* idx, float* prob);
+/* a10 processors/db_score.rs:34-134: boxes = n_boxes * 8 floats */
+oar_status oar_k_box_scores(const float* pred, uint32_t height, uint32_t width, const float* boxes,
+                            uint32_t n_boxes, float* scores);
+/* a14 utils/transform.rs:76-191: returns crop dims through out_w/out_h (0,0 when the reference would error);
+ * out must hold at least cap bytes. */
+oar_status oar_k_rotate_crop(const uint8_t* rgb, uint32_t w, uint32_t h, const float box[8], uint8_t* out,
+                             size_t cap, uint32_t* out_w, uint32_t* out_h);
+
+/* ------------------------------------------------------------------------------------------------ profiling
+ * Per-kernel-class accumulators filled from hipEvents recorded on the engine's own stream while cfg.profile
+ * is set.  class_name e.g. "conv_igemm", "dwconv", "softmax".  alg_bytes / alg_flops are the algorithmic
+ * totals of the timed launches. */
+typedef struct {
+    char name[48];
+    uint64_t launches;
+    double total_ms;
+    double alg_bytes;
+    double alg_flops;
+} oar_prof_entry;
+void oar_prof_reset(void);
+void oar_prof_enable(int32_t on);
+/* Fills up to cap entries, sorted by total_ms descending; returns the number of classes. */
+int32_t oar_prof_snapshot(oar_prof_entry* entries, int32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OAR_MI355X_H */

@@ -1,0 +1,712 @@
+"""ctypes binding of libOarMi355x.so plus a thin Python mirror of the reference's user-facing API for the
+det+rec path (same names / argument meaning / error behaviour as the Rust reference):
+
+    OAROCRBuilder(det, rec, dict).image_batch_size(..)...build() -> OAROCR      src/oarocr/ocr.rs:105,249-417
+    OAROCR.predict(images) -> [OAROCRResult]                                    src/oarocr/ocr.rs:518-659
+    TextDetectionPredictor / TextRecognitionPredictor                           oar-ocr-core/src/predictors/*.rs
+    CTCLabelDecode.decode_argmax                                                processors/decode.rs:505-614
+
+All compute goes through the C ABI (include/oar_mi355x.h).  There is NO CPU fallback: loading fails loudly
+when the HIP library is missing, and every call fails with OCRError(code=OAR_DEVICE) when no GPU is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "lib" / "libOarMi355x.so"
+_lib = None
+
+OAR_OK, OAR_INVALID_INPUT, OAR_MODEL_LOAD, OAR_UNSUPPORTED_OP, OAR_SHAPE_MISMATCH, OAR_DEVICE, OAR_OOM, OAR_INTERNAL = range(8)
+
+
+class OCRError(RuntimeError):
+    """Mirror of `OCRError` (oar-ocr-core/src/core/errors/types.rs:112-214); `.code` is the oar_status."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[oar_status {code}] {message}")
+        self.code = code
+        self.message = message
+
+
+class EngineCfg(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("use_hip_graph", C.c_int32), ("profile", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Tensor(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("dims", C.c_int64 * 8), ("data", C.POINTER(C.c_float)), ("name", C.c_char * 64)]
+
+
+class DetCfg(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("limit_side_len", C.c_uint32), ("limit_type", C.c_int32), ("max_side_limit", C.c_uint32),
+                ("max_candidates", C.c_uint32), ("use_hip_graph", C.c_int32), ("profile", C.c_int32), ("host_threads", C.c_int32)]
+
+
+class DetResult(C.Structure):
+    _fields_ = [("n_images", C.c_uint32), ("n_boxes", C.c_uint32), ("box_offsets", C.POINTER(C.c_uint32)),
+                ("points", C.POINTER(C.c_float)), ("scores", C.POINTER(C.c_float))]
+
+
+class RecCfg(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("rec_image_shape", C.c_uint32 * 3), ("max_img_w", C.c_uint32), ("use_hip_graph", C.c_int32),
+                ("profile", C.c_int32), ("reserved", C.c_int32)]
+
+
+class RecResult(C.Structure):
+    _fields_ = [("batch", C.c_uint32), ("seq_len", C.c_uint32), ("vocab", C.c_uint32), ("tensor_width", C.c_uint32),
+                ("indices", C.POINTER(C.c_int64)), ("probs", C.POINTER(C.c_float))]
+
+
+class OcrCfg(C.Structure):
+    _fields_ = [("det", DetCfg), ("rec", RecCfg), ("det_thresh", C.c_float), ("det_box_thresh", C.c_float), ("det_unclip_ratio", C.c_float),
+                ("image_batch_size", C.c_uint32), ("region_batch_size", C.c_uint32), ("max_pooled_crops", C.c_uint32)]
+
+
+class OcrResult(C.Structure):
+    _fields_ = [("n_images", C.c_uint32), ("n_regions", C.c_uint32), ("region_offsets", C.POINTER(C.c_uint32)),
+                ("points", C.POINTER(C.c_float)), ("det_scores", C.POINTER(C.c_float)), ("crop_wh", C.POINTER(C.c_uint32)),
+                ("seq_len", C.POINTER(C.c_uint32)), ("max_wh_ratio", C.POINTER(C.c_float)), ("ctc_offsets", C.POINTER(C.c_uint64)),
+                ("ctc_indices", C.POINTER(C.c_int64)), ("ctc_probs", C.POINTER(C.c_float))]
+
+
+class ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double), ("alg_bytes", C.c_double), ("alg_flops", C.c_double)]
+
+
+EXPORTS = [
+    "oar_last_error", "oar_version", "oar_device_count", "oar_engine_create", "oar_engine_destroy", "oar_engine_input_name",
+    "oar_engine_run", "oar_tensor_free", "oar_engine_cost", "oar_det_create", "oar_det_destroy", "oar_det_run", "oar_det_result_free",
+    "oar_db_postprocess", "oar_rec_create", "oar_rec_destroy", "oar_rec_run", "oar_rec_result_free", "oar_ocr_create", "oar_ocr_destroy",
+    "oar_ocr_predict", "oar_ocr_predict_device", "oar_ocr_result_free", "oar_dev_alloc", "oar_dev_upload", "oar_dev_download",
+    "oar_dev_free", "oar_dev_synchronize", "oar_k_normalize", "oar_k_rec_preprocess", "oar_k_resize_triangle", "oar_k_threshold",
+    "oar_k_ctc_argmax", "oar_k_box_scores", "oar_k_rotate_crop", "oar_prof_reset", "oar_prof_enable", "oar_prof_snapshot",
+]
+
+
+def lib():
+    """Loads the HIP library. Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise OCRError(OAR_DEVICE, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                   "(the MI355X path has no CPU fallback)")
+    L = C.CDLL(str(LIB_PATH))
+    vp, u8pp, u32p, f32p = C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_float)
+    L.oar_last_error.restype = C.c_size_t
+    L.oar_last_error.argtypes = [C.c_char_p, C.c_size_t]
+    L.oar_version.restype = C.c_size_t
+    L.oar_version.argtypes = [C.c_char_p, C.c_size_t]
+    L.oar_device_count.restype = C.c_int
+    L.oar_engine_create.argtypes = [vp, C.c_size_t, C.POINTER(EngineCfg), C.POINTER(vp)]
+    L.oar_engine_destroy.argtypes = [vp]
+    L.oar_engine_destroy.restype = None
+    L.oar_engine_input_name.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.oar_engine_run.argtypes = [vp, vp, C.POINTER(C.c_int64), C.c_int32, C.POINTER(Tensor), C.c_int32, C.POINTER(C.c_int32)]
+    L.oar_tensor_free.argtypes = [C.POINTER(Tensor)]
+    L.oar_tensor_free.restype = None
+    L.oar_engine_cost.argtypes = [vp, C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    L.oar_det_create.argtypes = [vp, C.c_size_t, C.POINTER(DetCfg), C.POINTER(vp)]
+    L.oar_det_destroy.argtypes = [vp]
+    L.oar_det_destroy.restype = None
+    L.oar_det_run.argtypes = [vp, u8pp, u32p, u32p, C.c_uint32, C.c_float, C.c_float, C.c_float, C.POINTER(DetResult)]
+    L.oar_det_result_free.argtypes = [C.POINTER(DetResult)]
+    L.oar_det_result_free.restype = None
+    L.oar_db_postprocess.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_uint32, C.POINTER(DetResult)]
+    L.oar_rec_create.argtypes = [vp, C.c_size_t, C.POINTER(RecCfg), C.POINTER(vp)]
+    L.oar_rec_destroy.argtypes = [vp]
+    L.oar_rec_destroy.restype = None
+    L.oar_rec_run.argtypes = [vp, u8pp, u32p, u32p, C.c_uint32, C.POINTER(RecResult)]
+    L.oar_rec_result_free.argtypes = [C.POINTER(RecResult)]
+    L.oar_rec_result_free.restype = None
+    L.oar_ocr_create.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(OcrCfg), C.POINTER(vp)]
+    L.oar_ocr_destroy.argtypes = [vp]
+    L.oar_ocr_destroy.restype = None
+    L.oar_ocr_predict.argtypes = [vp, u8pp, u32p, u32p, C.c_uint32, C.POINTER(OcrResult)]
+    L.oar_ocr_predict_device.argtypes = [vp, u8pp, u32p, u32p, C.c_uint32, C.POINTER(OcrResult)]
+    L.oar_ocr_result_free.argtypes = [C.POINTER(OcrResult)]
+    L.oar_ocr_result_free.restype = None
+    L.oar_dev_alloc.argtypes = [C.c_int32, C.c_size_t, C.POINTER(vp)]
+    L.oar_dev_upload.argtypes = [vp, vp, C.c_size_t]
+    L.oar_dev_download.argtypes = [vp, vp, C.c_size_t]
+    L.oar_dev_free.argtypes = [vp]
+    L.oar_dev_free.restype = None
+    L.oar_dev_synchronize.argtypes = [C.c_int32]
+    L.oar_k_normalize.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), f32p, f32p, C.c_int32, vp]
+    L.oar_k_rec_preprocess.argtypes = [u8pp, u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, u32p]
+    L.oar_k_resize_triangle.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    L.oar_k_threshold.argtypes = [vp, C.c_size_t, C.c_float, vp]
+    L.oar_k_ctc_argmax.argtypes = [vp, C.c_size_t, C.c_size_t, vp, vp]
+    L.oar_k_box_scores.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp]
+    L.oar_k_rotate_crop.argtypes = [vp, C.c_uint32, C.c_uint32, f32p, vp, C.c_size_t, u32p, u32p]
+    L.oar_prof_reset.restype = None
+    L.oar_prof_enable.argtypes = [C.c_int32]
+    L.oar_prof_enable.restype = None
+    L.oar_prof_snapshot.argtypes = [C.POINTER(ProfEntry), C.c_int32]
+    L.oar_prof_snapshot.restype = C.c_int32
+    _lib = L
+    return L
+
+
+def _check(st: int):
+    if st != OAR_OK:
+        buf = C.create_string_buffer(4096)
+        lib().oar_last_error(buf, 4096)
+        raise OCRError(st, buf.value.decode(errors="replace"))
+
+
+def version() -> str:
+    buf = C.create_string_buffer(256)
+    lib().oar_version(buf, 256)
+    return buf.value.decode()
+
+
+def device_count() -> int:
+    return int(lib().oar_device_count())
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _img_arrays(images: Sequence[np.ndarray]):
+    imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+    for im in imgs:
+        if im.ndim != 3 or im.shape[2] != 3:
+            raise OCRError(OAR_INVALID_INPUT, "images must be HxWx3 uint8 (RgbImage)")
+    ptrs = (C.c_void_p * max(len(imgs), 1))(*[im.ctypes.data for im in imgs])
+    ws = (C.c_uint32 * max(len(imgs), 1))(*[im.shape[1] for im in imgs])
+    hs = (C.c_uint32 * max(len(imgs), 1))(*[im.shape[0] for im in imgs])
+    return imgs, ptrs, ws, hs
+
+
+# ------------------------------------------------------------------------------------------------ Seam A
+class OrtInfer:
+    """Drop-in for `OrtInfer` (core/inference/mod.rs:31-115): `.onnx` bytes in, f32 tensors in/out."""
+
+    def __init__(self, model: bytes, device_id: int = 0, profile: bool = False):
+        self._h = C.c_void_p()
+        cfg = EngineCfg(device_id, 0, int(profile), 0)
+        buf = (C.c_char * len(model)).from_buffer_copy(model)
+        _check(lib().oar_engine_create(C.cast(buf, C.c_void_p), len(model), C.byref(cfg), C.byref(self._h)))
+
+    def input_name(self) -> str:
+        buf = C.create_string_buffer(256)
+        _check(lib().oar_engine_input_name(self._h, buf, 256))
+        return buf.value.decode()
+
+    def infer(self, x: np.ndarray):
+        """Returns [(name, ndarray)] for every graph output (ort_infer_execution.rs:121-219)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        dims = (C.c_int64 * x.ndim)(*x.shape)
+        outs = (Tensor * 16)()
+        n = C.c_int32(0)
+        _check(lib().oar_engine_run(self._h, _p(x), dims, x.ndim, outs, 16, C.byref(n)))
+        res = []
+        for i in range(n.value):
+            t = outs[i]
+            shape = tuple(t.dims[k] for k in range(t.rank))
+            cnt = int(np.prod(shape)) if shape else 1
+            arr = np.ctypeslib.as_array(t.data, shape=(cnt,)).copy().reshape(shape)
+            res.append((t.name.decode(), arr))
+            lib().oar_tensor_free(C.byref(outs[i]))
+        return res
+
+    def cost(self, shape):
+        dims = (C.c_int64 * len(shape))(*shape)
+        fl, by, nk = C.c_double(0), C.c_double(0), C.c_int32(0)
+        _check(lib().oar_engine_cost(self._h, dims, len(shape), C.byref(fl), C.byref(by), C.byref(nk)))
+        return fl.value, by.value, nk.value
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.oar_engine_destroy(self._h)
+            self._h = None
+
+
+# ------------------------------------------------------------------------------------------------ host-side types
+@dataclass
+class TextDetectionConfig:
+    """domain/tasks/text_detection.rs:34-66"""
+    score_threshold: float = 0.3
+    box_threshold: float = 0.6
+    unclip_ratio: float = 1.5
+    max_candidates: int = 1000
+    limit_side_len: Optional[int] = None
+    limit_type: Optional[str] = None   # "max" | "min" | "resize_long"
+    max_side_len: Optional[int] = None
+
+    def validate(self):
+        for name, v, lo, hi in (("score_threshold", self.score_threshold, 0.0, 1.0), ("box_threshold", self.box_threshold, 0.0, 1.0)):
+            if not (lo <= v <= hi):
+                raise OCRError(OAR_INVALID_INPUT, f"{name} must be in [{lo}, {hi}]")
+        if self.unclip_ratio <= 0:
+            raise OCRError(OAR_INVALID_INPUT, "unclip_ratio must be > 0")
+        if self.max_candidates < 1:
+            raise OCRError(OAR_INVALID_INPUT, "max_candidates must be >= 1")
+
+
+@dataclass
+class Detection:
+    bbox: np.ndarray   # [4,2] f32
+    score: float
+
+
+@dataclass
+class TextRegion:
+    """domain/text_region.rs:10-41"""
+    bounding_box: np.ndarray
+    text: Optional[str]
+    confidence: Optional[float]
+    dt_poly: Optional[np.ndarray] = None
+    rec_poly: Optional[np.ndarray] = None
+    word_boxes: Optional[List[np.ndarray]] = None
+    det_score: float = 0.0
+    crop_wh: tuple = (0, 0)
+
+
+@dataclass
+class OAROCRResult:
+    """src/oarocr/result.rs:34-49"""
+    input_path: str
+    index: int
+    text_regions: List[TextRegion] = field(default_factory=list)
+    orientation_angle: Optional[float] = None
+
+
+def read_dict(text: str) -> List[str]:
+    """Dictionary file -> entries (src/oarocr/ocr.rs:277-291, decode.rs:120): first char of each non-empty line."""
+    return [ln[0] for ln in text.splitlines() if len(ln) > 0]
+
+
+class CTCLabelDecode:
+    """processors/decode.rs:391-421 (from_string_list, has_explicit_blank=false) and :505-614 (decode_argmax)."""
+
+    def __init__(self, character_list: Sequence[str], use_space_char: bool = True):
+        chars = [s[0] for s in character_list if len(s) > 0]
+        if use_space_char:
+            chars.append(" ")
+        self.character = ["\0"] + chars
+        self.blank_index = 0
+
+    def decode_argmax(self, indices: np.ndarray, probs: np.ndarray, batch: int, T: int, with_positions: bool = True):
+        texts, scores, positions, cols, lens = [], [], [], [], []
+        if batch == 0 or T == 0:
+            return texts, scores, positions, cols, lens
+        idx = np.asarray(indices, np.int64).reshape(batch, T)
+        pr = np.asarray(probs, np.float32).reshape(batch, T)
+        nchar = len(self.character)
+        for b in range(batch):
+            prev = self.blank_index
+            chars, kept, ts = [], [], []
+            for t in range(T):
+                i = int(idx[b, t])
+                if i != self.blank_index and i != prev and 0 <= i < nchar:
+                    chars.append(self.character[i])
+                    kept.append(pr[b, t])
+                    ts.append(t)
+                prev = i
+            s = np.float32(0.0)
+            for v in kept:                      # sequential f32 sum (decode.rs:531-535)
+                s = np.float32(s + v)
+            scores.append(float(s / np.float32(len(kept))) if kept else 0.0)
+            texts.append("".join(chars))
+            cols.append(ts)
+            positions.append([float(np.float32(t) / np.float32(T)) for t in ts])
+            lens.append(T)
+        return texts, scores, positions, cols, lens
+
+
+# ------------------------------------------------------------------------------------------------ adapters / predictors
+_LIMIT = {"max": 0, "min": 1, "resize_long": 2}
+
+
+class TextDetectionPredictor:
+    """predictors/text_detection.rs + domain/adapters/text_detection_adapter.rs:36-79"""
+
+    def __init__(self, model: bytes, config: Optional[TextDetectionConfig] = None, device_id: int = 0, limit_side_len: int = 960,
+                 limit_type: str = "max", max_side_limit: int = 4000, host_threads: int = 0, profile: bool = False):
+        self.config = config or TextDetectionConfig()
+        self.config.validate()
+        cfg = DetCfg(device_id, self.config.limit_side_len or limit_side_len, _LIMIT[self.config.limit_type or limit_type],
+                     self.config.max_side_len or max_side_limit, self.config.max_candidates, 0, int(profile), host_threads)
+        self._h = C.c_void_p()
+        buf = (C.c_char * len(model)).from_buffer_copy(model)
+        _check(lib().oar_det_create(C.cast(buf, C.c_void_p), len(model), C.byref(cfg), C.byref(self._h)))
+
+    @staticmethod
+    def recommended_batch_size() -> int:
+        return 8   # text_detection_adapter.rs:85-87
+
+    def predict(self, images: Sequence[np.ndarray], config: Optional[TextDetectionConfig] = None) -> List[List[Detection]]:
+        if len(images) == 0:
+            raise OCRError(OAR_INVALID_INPUT, "images must be a non-empty slice")   # predictors/core.rs:58-69 validate_input
+        c = config or self.config
+        imgs, ptrs, ws, hs = _img_arrays(images)
+        res = DetResult()
+        _check(lib().oar_det_run(self._h, ptrs, ws, hs, len(imgs), c.score_threshold, c.box_threshold, c.unclip_ratio, C.byref(res)))
+        out = _unpack_det(res)
+        lib().oar_det_result_free(C.byref(res))
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.oar_det_destroy(self._h)
+            self._h = None
+
+
+def _unpack_det(res: DetResult) -> List[List[Detection]]:
+    n, nb = res.n_images, res.n_boxes
+    offs = np.ctypeslib.as_array(res.box_offsets, shape=(n + 1,)).copy()
+    pts = np.ctypeslib.as_array(res.points, shape=(max(nb, 1) * 8,)).copy()[:nb * 8].reshape(nb, 4, 2)
+    sc = np.ctypeslib.as_array(res.scores, shape=(max(nb, 1),)).copy()[:nb]
+    return [[Detection(pts[k].copy(), float(sc[k])) for k in range(offs[i], offs[i + 1])] for i in range(n)]
+
+
+def db_postprocess(pred: np.ndarray, src_w: int, src_h: int, thresh=0.3, box_thresh=0.6, unclip_ratio=1.5, max_candidates=1000):
+    """Test hook: DB post-processing (a7..a12) on a host probability map through the HIP kernels."""
+    pred = np.ascontiguousarray(pred, np.float32)
+    h, w = pred.shape
+    res = DetResult()
+    _check(lib().oar_db_postprocess(_p(pred), h, w, src_w, src_h, thresh, box_thresh, unclip_ratio, max_candidates, C.byref(res)))
+    out = _unpack_det(res)[0]
+    lib().oar_det_result_free(C.byref(res))
+    return out
+
+
+@dataclass
+class TextRecognitionOutput:
+    """domain/tasks/text_recognition.rs:33-47"""
+    texts: List[str]
+    scores: List[float]
+    char_positions: List[List[float]]
+    char_col_indices: List[List[int]]
+    sequence_lengths: List[int]
+    indices: Optional[np.ndarray] = None
+    probs: Optional[np.ndarray] = None
+    tensor_width: int = 0
+
+
+class TextRecognitionPredictor:
+    """predictors/text_recognition.rs:33-106 + domain/adapters/text_recognition_adapter.rs:35-111"""
+
+    def __init__(self, model: bytes, character_list: Sequence[str], score_threshold: float = 0.0, device_id: int = 0,
+                 rec_image_shape=(3, 48, 320), max_img_w: int = 3200, profile: bool = False):
+        self.score_threshold = score_threshold
+        self.decoder = CTCLabelDecode(character_list, use_space_char=True)   # crnn.rs:384-385
+        cfg = RecCfg(device_id, (C.c_uint32 * 3)(*rec_image_shape), max_img_w, 0, int(profile), 0)
+        self._h = C.c_void_p()
+        buf = (C.c_char * len(model)).from_buffer_copy(model)
+        _check(lib().oar_rec_create(C.cast(buf, C.c_void_p), len(model), C.byref(cfg), C.byref(self._h)))
+
+    @staticmethod
+    def recommended_batch_size() -> int:
+        return 64  # text_recognition_adapter.rs:117-127
+
+    def predict(self, images: Sequence[np.ndarray]) -> TextRecognitionOutput:
+        if len(images) == 0:
+            raise OCRError(OAR_INVALID_INPUT, "images must be a non-empty slice")
+        imgs, ptrs, ws, hs = _img_arrays(images)
+        res = RecResult()
+        _check(lib().oar_rec_run(self._h, ptrs, ws, hs, len(imgs), C.byref(res)))
+        n, T = res.batch, res.seq_len
+        idx = np.ctypeslib.as_array(res.indices, shape=(max(n * T, 1),)).copy()[:n * T]
+        pr = np.ctypeslib.as_array(res.probs, shape=(max(n * T, 1),)).copy()[:n * T]
+        tw = res.tensor_width
+        lib().oar_rec_result_free(C.byref(res))
+        texts, scores, pos, cols, lens = self.decoder.decode_argmax(idx, pr, n, T)
+        for i, s in enumerate(scores):
+            if not (0.0 <= s <= 1.0):   # validate_output: domain/tasks/text_recognition.rs:114-120
+                raise OCRError(OAR_INVALID_INPUT, f"recognition score {s} outside [0,1]")
+            if not (s >= self.score_threshold):   # adapter filter keeps the slot (text_recognition_adapter.rs:70-102)
+                texts[i], pos[i], cols[i] = "", [], []
+        return TextRecognitionOutput(texts, scores, pos, cols, lens, idx.reshape(n, T), pr.reshape(n, T), tw)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.oar_rec_destroy(self._h)
+            self._h = None
+
+
+# ------------------------------------------------------------------------------------------------ pipeline
+def _is_cjk(ch: str) -> bool:
+    """src/oarocr/ocr.rs:1075-1082"""
+    u = ord(ch)
+    return (0x4E00 <= u <= 0x9FFF) or (0x3400 <= u <= 0x4DBF) or (0x20000 <= u <= 0x2A6DF) or (0x2A700 <= u <= 0x2B73F) or (0x2B740 <= u <= 0x2B81F)
+
+
+class OAROCRBuilder:
+    """src/oarocr/ocr.rs:105-417"""
+
+    def __init__(self, det_model: bytes, rec_model: bytes, character_dict: Sequence[str]):
+        self._det, self._rec, self._dict = det_model, rec_model, list(character_dict)
+        self._image_bs = None
+        self._region_bs = None
+        self._det_cfg: Optional[TextDetectionConfig] = None
+        self._score_thr = 0.0
+        self._device = 0
+        self._profile = False
+        self._host_threads = 0
+
+    def image_batch_size(self, n: int):
+        self._image_bs = n
+        return self
+
+    def region_batch_size(self, n: int):
+        self._region_bs = n
+        return self
+
+    def text_detection_config(self, cfg: TextDetectionConfig):
+        self._det_cfg = cfg
+        return self
+
+    def text_rec_score_threshold(self, t: float):
+        self._score_thr = t
+        return self
+
+    def device(self, device_id: int):
+        self._device = device_id
+        return self
+
+    def profile(self, on: bool = True):
+        self._profile = on
+        return self
+
+    def host_threads(self, n: int):
+        self._host_threads = n
+        return self
+
+    def build(self) -> "OAROCR":
+        for name, v in (("image_batch_size", self._image_bs), ("region_batch_size", self._region_bs)):
+            if v is not None and not (1 <= v <= 4096):   # ocr.rs:250-255,419-430
+                raise OCRError(OAR_INVALID_INPUT, f"{name} must be in 1..=4096")
+        if self._det_cfg is not None:
+            d = self._det_cfg
+            d.validate()
+            thresh, box_thresh, unclip, maxc = d.score_threshold, d.box_threshold, d.unclip_ratio, d.max_candidates
+            lsl, lt, msl = d.limit_side_len or 960, d.limit_type or "max", d.max_side_len or 4000
+        else:   # builder defaults (ocr.rs:319-366)
+            thresh, box_thresh, unclip, maxc, lsl, lt, msl = 0.3, 0.6, 2.0, 1000, 960, "max", 4000
+        cfg = OcrCfg()
+        cfg.det = DetCfg(self._device, lsl, _LIMIT[lt], msl, maxc, 0, int(self._profile), self._host_threads)
+        cfg.rec = RecCfg(self._device, (C.c_uint32 * 3)(3, 48, 320), 3200, 0, int(self._profile), 0)
+        cfg.det_thresh, cfg.det_box_thresh, cfg.det_unclip_ratio = thresh, box_thresh, unclip
+        cfg.image_batch_size = self._image_bs or 0      # accelerator: adapter defaults 8 / 64 (builder_utils.rs:86-102)
+        cfg.region_batch_size = self._region_bs or 0
+        cfg.max_pooled_crops = 0
+        return OAROCR(self._det, self._rec, self._dict, cfg, self._score_thr)
+
+
+class OAROCR:
+    def __init__(self, det: bytes, rec: bytes, character_dict, cfg: OcrCfg, score_threshold: float):
+        self.decoder = CTCLabelDecode(character_dict, use_space_char=True)
+        self.score_threshold = score_threshold
+        self.return_word_box = False
+        self._h = C.c_void_p()
+        b1 = (C.c_char * len(det)).from_buffer_copy(det)
+        b2 = (C.c_char * len(rec)).from_buffer_copy(rec)
+        _check(lib().oar_ocr_create(C.cast(b1, C.c_void_p), len(det), C.cast(b2, C.c_void_p), len(rec), C.byref(cfg), C.byref(self._h)))
+
+    def predict(self, images: Sequence[np.ndarray]) -> List[OAROCRResult]:
+        if len(images) == 0:
+            raise OCRError(OAR_INVALID_INPUT, "OCR Pipeline: images must be a non-empty slice")   # ocr.rs:525-532
+        imgs, ptrs, ws, hs = _img_arrays(images)
+        res = OcrResult()
+        _check(lib().oar_ocr_predict(self._h, ptrs, ws, hs, len(imgs), C.byref(res)))
+        out = self._assemble(res)
+        lib().oar_ocr_result_free(C.byref(res))
+        return out
+
+    def predict_device(self, dev_ptrs: Sequence[int], widths: Sequence[int], heights: Sequence[int], raw: bool = False):
+        """Pages already resident in HBM (pointers from DeviceBuffer). raw=True skips string assembly and returns
+        (n_regions, n_ctc) -- used by bench.py so the timed region is exactly the C-ABI call."""
+        n = len(dev_ptrs)
+        ptrs = (C.c_void_p * n)(*dev_ptrs)
+        ws = (C.c_uint32 * n)(*widths)
+        hs = (C.c_uint32 * n)(*heights)
+        res = OcrResult()
+        _check(lib().oar_ocr_predict_device(self._h, ptrs, ws, hs, n, C.byref(res)))
+        if raw:
+            r = (int(res.n_regions), int(res.ctc_offsets[res.n_regions]) if res.n_regions else 0)
+            lib().oar_ocr_result_free(C.byref(res))
+            return r
+        out = self._assemble(res)
+        lib().oar_ocr_result_free(C.byref(res))
+        return out
+
+    def _assemble(self, res: OcrResult) -> List[OAROCRResult]:
+        n, nr = res.n_images, res.n_regions
+        offs = np.ctypeslib.as_array(res.region_offsets, shape=(n + 1,)).copy()
+        if nr == 0:
+            return [OAROCRResult(f"image_{i}", i) for i in range(n)]
+        pts = np.ctypeslib.as_array(res.points, shape=(nr * 8,)).copy().reshape(nr, 4, 2)
+        dsc = np.ctypeslib.as_array(res.det_scores, shape=(nr,)).copy()
+        cwh = np.ctypeslib.as_array(res.crop_wh, shape=(nr * 2,)).copy().reshape(nr, 2)
+        sl = np.ctypeslib.as_array(res.seq_len, shape=(nr,)).copy()
+        mwh = np.ctypeslib.as_array(res.max_wh_ratio, shape=(nr,)).copy()
+        co = np.ctypeslib.as_array(res.ctc_offsets, shape=(nr + 1,)).copy()
+        nctc = int(co[nr])
+        ci = np.ctypeslib.as_array(res.ctc_indices, shape=(max(nctc, 1),)).copy()
+        cp = np.ctypeslib.as_array(res.ctc_probs, shape=(max(nctc, 1),)).copy()
+        results = []
+        for i in range(n):
+            regions = []
+            for k in range(offs[i], offs[i + 1]):
+                T = int(sl[k])
+                texts, scores, pos, cols, _ = self.decoder.decode_argmax(ci[co[k]:co[k + 1]], cp[co[k]:co[k + 1]], 1 if T else 0, T)
+                text, score = (texts[0], scores[0]) if texts else ("", 0.0)
+                col = cols[0] if cols else []
+                if not (score >= self.score_threshold):
+                    text, col = "", []
+                wb = None
+                if self.return_word_box and col and T > 0:
+                    wh = np.float32(cwh[k, 0]) / np.float32(max(int(cwh[k, 1]), 1))
+                    wb = ctc_word_boxes(pts[k], text, col, T, float(wh), float(mwh[k]))
+                regions.append(TextRegion(pts[k].copy(), text, score, pts[k].copy(), pts[k].copy(), wb, float(dsc[k]), (int(cwh[k, 0]), int(cwh[k, 1]))))
+            results.append(OAROCRResult(f"image_{i}", i, regions))
+        return results
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.oar_ocr_destroy(self._h)
+            self._h = None
+
+
+def ctc_word_boxes(line_bbox: np.ndarray, text: str, col_indices, seq_len: int, wh_ratio: float, max_wh_ratio: float):
+    """src/oarocr/ocr.rs:949-1020 (f32 arithmetic, same operation order)."""
+    if not col_indices or seq_len == 0 or not text:
+        return []
+    f = np.float32
+    EPS = f(1.1920929e-7)
+    eff = f(f(seq_len) * f(f(wh_ratio) / f(max_wh_ratio)))
+    if eff <= EPS:
+        return []
+    xs, ys = np.asarray(line_bbox, np.float32)[:, 0], np.asarray(line_bbox, np.float32)[:, 1]
+    x_min, y_min, x_max, y_max = f(xs.min()), f(ys.min()), f(xs.max()), f(ys.max())
+    width = f(x_max - x_min)
+    cell = f(width / max(eff, EPS))
+    chars = list(text)
+    avg_w = f(width / f(max(len(chars), 1)))
+    centers = [f(x_min + f(f(f(i) + f(0.5)) * cell)) for i in col_indices]
+    boxes = []
+    n = len(col_indices)
+    for i in range(n):
+        ch = chars[i] if i < len(chars) else "?"
+        c = centers[i]
+        if _is_cjk(ch):
+            half = f(avg_w / f(2.0))
+            l, r = max(f(c - half), x_min), min(f(c + half), x_max)
+        else:
+            l = max(x_min if i == 0 else f(f(centers[i - 1] + c) / f(2.0)), x_min)
+            r = min(x_max if i == n - 1 else f(f(c + centers[i + 1]) / f(2.0)), x_max)
+        boxes.append(np.array([[l, y_min], [r, y_min], [r, y_max], [l, y_max]], np.float32))
+    return boxes
+
+
+# ------------------------------------------------------------------------------------------------ device buffers / profiling
+class DeviceBuffer:
+    def __init__(self, data: np.ndarray, device_id: int = 0):
+        data = np.ascontiguousarray(data)
+        self.nbytes = data.nbytes
+        self.ptr = C.c_void_p()
+        _check(lib().oar_dev_alloc(device_id, self.nbytes, C.byref(self.ptr)))
+        _check(lib().oar_dev_upload(self.ptr, _p(data), self.nbytes))
+
+    def free(self):
+        if self.ptr:
+            lib().oar_dev_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def prof_enable(on: bool = True):
+    lib().oar_prof_enable(int(on))
+
+
+def prof_reset():
+    lib().oar_prof_reset()
+
+
+def prof_snapshot():
+    arr = (ProfEntry * 64)()
+    n = lib().oar_prof_snapshot(arr, 64)
+    return [{"name": arr[i].name.decode(), "launches": int(arr[i].launches), "total_ms": arr[i].total_ms,
+             "alg_bytes": arr[i].alg_bytes, "alg_flops": arr[i].alg_flops} for i in range(min(n, 64))]
+
+
+# stand-alone kernels (parity hooks)
+def k_normalize(rgb, alpha, beta, src=(0, 1, 2), layout="chw"):
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w, _ = rgb.shape
+    out = np.empty((3, h, w) if layout == "chw" else (h, w, 3), np.float32)
+    a, b = np.ascontiguousarray(alpha, np.float32), np.ascontiguousarray(beta, np.float32)
+    s = (C.c_int32 * 3)(*src)
+    _check(lib().oar_k_normalize(_p(rgb), w, h, s, a.ctypes.data_as(C.POINTER(C.c_float)), b.ctypes.data_as(C.POINTER(C.c_float)),
+                                 0 if layout == "chw" else 1, _p(out)))
+    return out
+
+
+def k_rec_preprocess(crops, img_h=48, img_w=320, max_img_w=3200):
+    imgs, ptrs, ws, hs = _img_arrays(crops)
+    tw = C.c_uint32(0)
+    _check(lib().oar_k_rec_preprocess(ptrs, ws, hs, len(imgs), img_h, img_w, max_img_w, None, C.byref(tw)))
+    out = np.empty((len(imgs), 3, img_h, tw.value), np.float32)
+    _check(lib().oar_k_rec_preprocess(ptrs, ws, hs, len(imgs), img_h, img_w, max_img_w, _p(out), C.byref(tw)))
+    return out
+
+
+def k_resize_triangle(rgb, nw, nh):
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w, _ = rgb.shape
+    out = np.empty((nh, nw, 3), np.uint8)
+    _check(lib().oar_k_resize_triangle(_p(rgb), w, h, nw, nh, _p(out)))
+    return out
+
+
+def k_threshold(pred, thresh):
+    pred = np.ascontiguousarray(pred, np.float32)
+    out = np.empty(pred.shape, np.uint8)
+    _check(lib().oar_k_threshold(_p(pred), pred.size, thresh, _p(out)))
+    return out
+
+
+def k_ctc_argmax(probs):
+    probs = np.ascontiguousarray(probs, np.float32)
+    v = probs.shape[-1]
+    rows = probs.size // v if v else 0
+    idx = np.zeros(rows, np.int64)
+    p = np.zeros(rows, np.float32)
+    _check(lib().oar_k_ctc_argmax(_p(probs), rows, v, _p(idx), _p(p)))
+    return idx, p
+
+
+def k_box_scores(pred, boxes):
+    pred = np.ascontiguousarray(pred, np.float32)
+    boxes = np.ascontiguousarray(boxes, np.float32).reshape(-1, 8)
+    h, w = pred.shape
+    out = np.zeros(boxes.shape[0], np.float32)
+    _check(lib().oar_k_box_scores(_p(pred), h, w, _p(boxes), boxes.shape[0], _p(out)))
+    return out
+
+
+def k_rotate_crop(img, box):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w, _ = img.shape
+    box = np.ascontiguousarray(box, np.float32).reshape(8)
+    cap = 3 * (w + h + 8) ** 2
+    out = np.empty(cap, np.uint8)
+    ow, oh = C.c_uint32(0), C.c_uint32(0)
+    _check(lib().oar_k_rotate_crop(_p(img), w, h, box.ctypes.data_as(C.POINTER(C.c_float)), _p(out), cap, C.byref(ow), C.byref(oh)))
+    if ow.value == 0:
+        return None
+    return out[:ow.value * oh.value * 3].reshape(oh.value, ow.value, 3).copy()

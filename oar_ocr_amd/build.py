@@ -1,0 +1,66 @@
+"""Builds libOarMi355x.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc.
+
+No torch / pybind dependency: the library is plain C ABI (include/oar_mi355x.h) and is loaded with ctypes.
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only build container."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+LIBDIR = HERE / "lib"
+LIB = LIBDIR / "libOarMi355x.so"
+SOURCES = ["common.cc", "onnx_parse.cc", "engine.cc", "db_host.cc", "pipeline.cc", "c_api.cc", "kernels.hip", "prepost.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-Wno-unused-result", "-Wno-pass-failed"]
+
+
+def _stale(out: Path, deps) -> bool:
+    if not out.exists():
+        return True
+    t = out.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> Path:
+    LIBDIR.mkdir(exist_ok=True)
+    objdir = LIBDIR / "obj"
+    objdir.mkdir(exist_ok=True)
+    headers = list(CSRC.glob("*.h")) + [HERE.parent / "include" / "oar_mi355x.h"]
+    jobs = []
+    for s in SOURCES:
+        src = CSRC / s
+        obj = objdir / (s.replace(".", "_") + ".o")
+        if force or _stale(obj, [src] + headers):
+            jobs.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        cmd = [HIPCC] + FLAGS + ["-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stderr[-4000:]}")
+        return obj
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(cc, jobs))
+    objs = [objdir / (s.replace(".", "_") + ".o") for s in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + [str(o) for o in objs] + ["-lpthread"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    return LIB
+
+
+if __name__ == "__main__":
+    p = build_lib(force="--force" in sys.argv, verbose=True)
+    print(p, p.stat().st_size)

@@ -1,0 +1,507 @@
+// c_api.cc -- extern "C" boundary (include/oar_mi355x.h). No exception crosses it.
+#include <cstdlib>
+#include <cstring>
+
+#include "engine.h"
+#include "pipeline.h"
+
+namespace oar {
+const std::string& last_error();
+}
+using namespace oar;
+
+struct oar_engine { std::unique_ptr<Engine> e; };
+struct oar_det { std::unique_ptr<Detector> d; };
+struct oar_rec { std::unique_ptr<Recognizer> r; };
+struct oar_ocr { std::unique_ptr<Ocr> o; };
+
+namespace {
+template <typename F>
+oar_status guard(F&& f) {
+    try {
+        f();
+        return OAR_OK;
+    } catch (const Error& e) {
+        set_last_error(e.what());
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        set_last_error("host allocation failed");
+        return OAR_OOM;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return OAR_INTERNAL;
+    } catch (...) {
+        set_last_error("unknown error");
+        return OAR_INTERNAL;
+    }
+}
+template <typename T>
+T* cmalloc(size_t n) {
+    T* p = (T*)std::malloc(std::max<size_t>(n, 1) * sizeof(T));
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+void require_device() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) fail(OAR_DEVICE, "no HIP device visible: libOarMi355x has no CPU fallback");
+}
+void fill_det_result(const std::vector<DetBoxes>& boxes, oar_det_result* out) {
+    std::memset(out, 0, sizeof *out);
+    out->n_images = (uint32_t)boxes.size();
+    size_t total = 0;
+    for (auto& b : boxes) total += b.scores.size();
+    out->n_boxes = (uint32_t)total;
+    out->box_offsets = cmalloc<uint32_t>(boxes.size() + 1);
+    out->points = cmalloc<float>(total * 8);
+    out->scores = cmalloc<float>(total);
+    size_t k = 0;
+    for (size_t i = 0; i < boxes.size(); ++i) {
+        out->box_offsets[i] = (uint32_t)k;
+        std::memcpy(out->points + k * 8, boxes[i].pts.data(), boxes[i].pts.size() * sizeof(float));
+        std::memcpy(out->scores + k, boxes[i].scores.data(), boxes[i].scores.size() * sizeof(float));
+        k += boxes[i].scores.size();
+    }
+    out->box_offsets[boxes.size()] = (uint32_t)k;
+}
+}  // namespace
+
+extern "C" {
+
+size_t oar_last_error(char* buf, size_t cap) {
+    const std::string& m = last_error();
+    if (buf && cap) {
+        size_t n = std::min(cap - 1, m.size());
+        std::memcpy(buf, m.data(), n);
+        buf[n] = 0;
+    }
+    return m.size();
+}
+
+size_t oar_version(char* buf, size_t cap) {
+    char tmp[256];
+    int n = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceCount(&n) == hipSuccess && n > 0 && hipGetDeviceProperties(&prop, 0) == hipSuccess)
+        snprintf(tmp, sizeof tmp, "libOarMi355x 0.1.0 %s %s CUs=%d", prop.gcnArchName, prop.name, prop.multiProcessorCount);
+    else
+        snprintf(tmp, sizeof tmp, "libOarMi355x 0.1.0 (no HIP device)");
+    size_t len = std::strlen(tmp);
+    if (buf && cap) {
+        size_t c = std::min(cap - 1, len);
+        std::memcpy(buf, tmp, c);
+        buf[c] = 0;
+    }
+    return len;
+}
+
+int oar_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------- Seam A
+oar_status oar_engine_create(const uint8_t* onnx, size_t onnx_len, const oar_engine_cfg* cfg, oar_engine** out) {
+    return guard([&] {
+        OAR_CHECK(out, OAR_INVALID_INPUT, "oar_engine_create: out is null");
+        *out = nullptr;
+        std::unique_ptr<oar_engine> h(new oar_engine());
+        h->e.reset(new Engine(onnx, onnx_len, cfg ? cfg->device_id : 0));
+        if (cfg && cfg->profile) Profiler::get().enabled = true;
+        *out = h.release();
+    });
+}
+void oar_engine_destroy(oar_engine* e) { delete e; }
+
+oar_status oar_engine_input_name(const oar_engine* e, char* buf, size_t cap) {
+    return guard([&] {
+        OAR_CHECK(e && buf && cap, OAR_INVALID_INPUT, "oar_engine_input_name: bad arguments");
+        snprintf(buf, cap, "%s", e->e->input_name().c_str());
+    });
+}
+
+oar_status oar_engine_run(oar_engine* e, const float* input, const int64_t* dims, int32_t rank, oar_tensor* outs, int32_t max_out,
+                          int32_t* n_out) {
+    return guard([&] {
+        OAR_CHECK(e && input && dims && rank > 0 && rank <= 8 && outs && n_out, OAR_INVALID_INPUT, "oar_engine_run: bad arguments");
+        Engine& E = *e->e;
+        std::lock_guard<std::mutex> lk(E.mutex());
+        OAR_HIP(hipSetDevice(E.device()));
+        std::vector<int64_t> d(dims, dims + rank);
+        int64_t cnt = 1;
+        for (auto v : d) { OAR_CHECK(v >= 0, OAR_INVALID_INPUT, "negative dimension"); cnt *= v; }
+        DevBuf din;
+        din.reserve((size_t)std::max<int64_t>(cnt, 1) * 4);
+        OAR_HIP(hipMemcpyAsync(din.p, input, (size_t)cnt * 4, hipMemcpyHostToDevice, E.stream()));
+        const Plan& p = E.run(din.as<float>(), d, false);
+        OAR_CHECK((int)p.outputs.size() <= max_out, OAR_INVALID_INPUT, "oar_engine_run: outs too small");
+        for (size_t i = 0; i < p.outputs.size(); ++i) {
+            const PlanOutput& po = p.outputs[i];
+            oar_tensor& t = outs[i];
+            std::memset(&t, 0, sizeof t);
+            t.rank = (int32_t)po.dims.size();
+            int64_t n = 1;
+            for (size_t k = 0; k < po.dims.size(); ++k) { t.dims[k] = po.dims[k]; n *= po.dims[k]; }
+            snprintf(t.name, sizeof t.name, "%s", po.name.c_str());
+            t.data = cmalloc<float>((size_t)n);
+            OAR_HIP(hipMemcpyAsync(t.data, E.out_ptr(po.loc), (size_t)n * 4, hipMemcpyDeviceToHost, E.stream()));
+        }
+        OAR_HIP(hipStreamSynchronize(E.stream()));
+        *n_out = (int32_t)p.outputs.size();
+        if (Profiler::get().enabled) Profiler::get().flush();
+    });
+}
+void oar_tensor_free(oar_tensor* t) {
+    if (t && t->data) { std::free(t->data); t->data = nullptr; }
+}
+
+oar_status oar_engine_cost(oar_engine* e, const int64_t* dims, int32_t rank, double* flops, double* bytes, int32_t* n_kernels) {
+    return guard([&] {
+        OAR_CHECK(e && dims && rank > 0, OAR_INVALID_INPUT, "oar_engine_cost: bad arguments");
+        std::lock_guard<std::mutex> lk(e->e->mutex());
+        const Plan& p = e->e->plan_for(std::vector<int64_t>(dims, dims + rank), rank >= 3);
+        if (flops) *flops = p.flops;
+        if (bytes) *bytes = p.bytes;
+        if (n_kernels) *n_kernels = p.n_kernels;
+    });
+}
+
+// ---------------------------------------------------------------------------------------------- detection
+oar_status oar_det_create(const uint8_t* onnx, size_t onnx_len, const oar_det_cfg* cfg, oar_det** out) {
+    return guard([&] {
+        OAR_CHECK(out, OAR_INVALID_INPUT, "oar_det_create: out is null");
+        *out = nullptr;
+        oar_det_cfg c;
+        std::memset(&c, 0, sizeof c);
+        if (cfg) c = *cfg;
+        std::unique_ptr<oar_det> h(new oar_det());
+        h->d.reset(new Detector(onnx, onnx_len, c));
+        if (c.profile) Profiler::get().enabled = true;
+        *out = h.release();
+    });
+}
+void oar_det_destroy(oar_det* d) { delete d; }
+
+oar_status oar_det_run(oar_det* d, const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights, uint32_t n_images,
+                       float thresh, float box_thresh, float unclip_ratio, oar_det_result* out) {
+    return guard([&] {
+        OAR_CHECK(d && out && (n_images == 0 || (rgb && widths && heights)), OAR_INVALID_INPUT, "oar_det_run: bad arguments");
+        std::vector<PageRef> pages(n_images);
+        for (uint32_t i = 0; i < n_images; ++i) { pages[i].host = rgb[i]; pages[i].w = widths[i]; pages[i].h = heights[i]; }
+        std::vector<DetBoxes> boxes;
+        d->d->run(pages, thresh, box_thresh, unclip_ratio, boxes);
+        fill_det_result(boxes, out);
+    });
+}
+void oar_det_result_free(oar_det_result* r) {
+    if (!r) return;
+    std::free(r->box_offsets); std::free(r->points); std::free(r->scores);
+    std::memset(r, 0, sizeof *r);
+}
+
+oar_status oar_db_postprocess(const float* pred, uint32_t height, uint32_t width, uint32_t src_w, uint32_t src_h, float thresh,
+                              float box_thresh, float unclip_ratio, uint32_t max_candidates, oar_det_result* out) {
+    return guard([&] {
+        OAR_CHECK(pred && out && height && width, OAR_INVALID_INPUT, "oar_db_postprocess: bad arguments");
+        std::vector<DetBoxes> boxes(1);
+        Detector::postprocess_host(pred, (int)height, (int)width, src_w, src_h, thresh, box_thresh, unclip_ratio, max_candidates, boxes[0]);
+        fill_det_result(boxes, out);
+    });
+}
+
+// ---------------------------------------------------------------------------------------------- recognition
+oar_status oar_rec_create(const uint8_t* onnx, size_t onnx_len, const oar_rec_cfg* cfg, oar_rec** out) {
+    return guard([&] {
+        OAR_CHECK(out, OAR_INVALID_INPUT, "oar_rec_create: out is null");
+        *out = nullptr;
+        oar_rec_cfg c;
+        std::memset(&c, 0, sizeof c);
+        if (cfg) c = *cfg;
+        std::unique_ptr<oar_rec> h(new oar_rec());
+        h->r.reset(new Recognizer(onnx, onnx_len, c));
+        if (c.profile) Profiler::get().enabled = true;
+        *out = h.release();
+    });
+}
+void oar_rec_destroy(oar_rec* r) { delete r; }
+
+oar_status oar_rec_run(oar_rec* r, const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights, uint32_t n_crops,
+                       oar_rec_result* out) {
+    return guard([&] {
+        OAR_CHECK(r && out && (n_crops == 0 || (rgb && widths && heights)), OAR_INVALID_INPUT, "oar_rec_run: bad arguments");
+        std::memset(out, 0, sizeof *out);
+        std::vector<Recognizer::Crop> crops(n_crops);
+        for (uint32_t i = 0; i < n_crops; ++i) { crops[i].host = rgb[i]; crops[i].w = widths[i]; crops[i].h = heights[i]; }
+        RecOut ro;
+        r->r->run(crops, ro);
+        out->batch = ro.idx.empty() ? 0 : n_crops;   // empty tensor => empty batch (decode.rs:465-472)
+        out->seq_len = ro.T; out->vocab = ro.V; out->tensor_width = ro.Wt;
+        out->indices = cmalloc<int64_t>(ro.idx.size());
+        out->probs = cmalloc<float>(ro.prob.size());
+        std::memcpy(out->indices, ro.idx.data(), ro.idx.size() * sizeof(int64_t));
+        std::memcpy(out->probs, ro.prob.data(), ro.prob.size() * sizeof(float));
+    });
+}
+void oar_rec_result_free(oar_rec_result* r) {
+    if (!r) return;
+    std::free(r->indices); std::free(r->probs);
+    std::memset(r, 0, sizeof *r);
+}
+
+// ---------------------------------------------------------------------------------------------- pipeline
+oar_status oar_ocr_create(const uint8_t* det_onnx, size_t det_len, const uint8_t* rec_onnx, size_t rec_len, const oar_ocr_cfg* cfg,
+                          oar_ocr** out) {
+    return guard([&] {
+        OAR_CHECK(out, OAR_INVALID_INPUT, "oar_ocr_create: out is null");
+        *out = nullptr;
+        oar_ocr_cfg c;
+        std::memset(&c, 0, sizeof c);
+        if (cfg) c = *cfg;
+        if (c.det_thresh == 0.f && c.det_box_thresh == 0.f && c.det_unclip_ratio == 0.f) {
+            c.det_thresh = 0.3f; c.det_box_thresh = 0.6f; c.det_unclip_ratio = 2.0f;  // builder defaults, ocr.rs:319-366
+        }
+        std::unique_ptr<oar_ocr> h(new oar_ocr());
+        h->o.reset(new Ocr(det_onnx, det_len, rec_onnx, rec_len, c));
+        if (c.det.profile || c.rec.profile) Profiler::get().enabled = true;
+        *out = h.release();
+    });
+}
+void oar_ocr_destroy(oar_ocr* o) { delete o; }
+
+static void fill_ocr_result(const std::vector<std::vector<OcrRegion>>& res, oar_ocr_result* out) {
+    std::memset(out, 0, sizeof *out);
+    size_t nreg = 0, nctc = 0;
+    for (auto& im : res) for (auto& r : im) { ++nreg; nctc += r.idx.size(); }
+    out->n_images = (uint32_t)res.size(); out->n_regions = (uint32_t)nreg;
+    out->region_offsets = cmalloc<uint32_t>(res.size() + 1);
+    out->points = cmalloc<float>(nreg * 8);
+    out->det_scores = cmalloc<float>(nreg);
+    out->crop_wh = cmalloc<uint32_t>(nreg * 2);
+    out->seq_len = cmalloc<uint32_t>(nreg);
+    out->max_wh_ratio = cmalloc<float>(nreg);
+    out->ctc_offsets = cmalloc<uint64_t>(nreg + 1);
+    out->ctc_indices = cmalloc<int64_t>(nctc);
+    out->ctc_probs = cmalloc<float>(nctc);
+    size_t k = 0, c = 0;
+    for (size_t i = 0; i < res.size(); ++i) {
+        out->region_offsets[i] = (uint32_t)k;
+        for (auto& r : res[i]) {
+            std::memcpy(out->points + k * 8, r.pts, sizeof r.pts);
+            out->det_scores[k] = r.det_score;
+            out->crop_wh[k * 2] = r.crop_w; out->crop_wh[k * 2 + 1] = r.crop_h;
+            out->seq_len[k] = r.T; out->max_wh_ratio[k] = r.max_wh_ratio;
+            out->ctc_offsets[k] = c;
+            std::memcpy(out->ctc_indices + c, r.idx.data(), r.idx.size() * sizeof(int64_t));
+            std::memcpy(out->ctc_probs + c, r.prob.data(), r.prob.size() * sizeof(float));
+            c += r.idx.size();
+            ++k;
+        }
+    }
+    out->region_offsets[res.size()] = (uint32_t)k;
+    out->ctc_offsets[k] = c;
+}
+
+static oar_status ocr_predict_impl(oar_ocr* o, const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights, uint32_t n,
+                                   bool device, oar_ocr_result* out) {
+    return guard([&] {
+        OAR_CHECK(o && out, OAR_INVALID_INPUT, "oar_ocr_predict: bad arguments");
+        OAR_CHECK(n > 0 && rgb && widths && heights, OAR_INVALID_INPUT, "OCR Pipeline: images must be a non-empty slice");
+        std::vector<PageRef> pages(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            if (device) pages[i].dev = rgb[i]; else pages[i].host = rgb[i];
+            pages[i].w = widths[i]; pages[i].h = heights[i];
+        }
+        std::vector<std::vector<OcrRegion>> res;
+        o->o->predict(pages, res);
+        fill_ocr_result(res, out);
+    });
+}
+oar_status oar_ocr_predict(oar_ocr* o, const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights, uint32_t n_images,
+                           oar_ocr_result* out) {
+    return ocr_predict_impl(o, rgb, widths, heights, n_images, false, out);
+}
+oar_status oar_ocr_predict_device(oar_ocr* o, const uint8_t* const* d_rgb, const uint32_t* widths, const uint32_t* heights,
+                                  uint32_t n_images, oar_ocr_result* out) {
+    return ocr_predict_impl(o, d_rgb, widths, heights, n_images, true, out);
+}
+void oar_ocr_result_free(oar_ocr_result* r) {
+    if (!r) return;
+    std::free(r->region_offsets); std::free(r->points); std::free(r->det_scores); std::free(r->crop_wh); std::free(r->seq_len);
+    std::free(r->max_wh_ratio); std::free(r->ctc_offsets); std::free(r->ctc_indices); std::free(r->ctc_probs);
+    std::memset(r, 0, sizeof *r);
+}
+
+// ---------------------------------------------------------------------------------------------- device helpers
+oar_status oar_dev_alloc(int32_t device_id, size_t bytes, void** out) {
+    return guard([&] {
+        OAR_CHECK(out, OAR_INVALID_INPUT, "oar_dev_alloc: out is null");
+        require_device();
+        OAR_HIP(hipSetDevice(device_id));
+        OAR_HIP(hipMalloc(out, std::max<size_t>(bytes, 16)));
+    });
+}
+oar_status oar_dev_upload(void* dst, const void* src, size_t bytes) {
+    return guard([&] { OAR_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); });
+}
+oar_status oar_dev_download(void* dst, const void* src, size_t bytes) {
+    return guard([&] { OAR_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); });
+}
+void oar_dev_free(void* p) {
+    if (p) (void)hipFree(p);
+}
+oar_status oar_dev_synchronize(int32_t device_id) {
+    return guard([&] {
+        require_device();
+        OAR_HIP(hipSetDevice(device_id));
+        OAR_HIP(hipDeviceSynchronize());
+    });
+}
+
+// ---------------------------------------------------------------------------------------------- stand-alone kernels
+oar_status oar_k_normalize(const uint8_t* rgb, uint32_t w, uint32_t h, const int32_t src_channels[3], const float alpha[3],
+                           const float beta[3], int32_t hwc_layout, float* out) {
+    return guard([&] {
+        OAR_CHECK(rgb && out && src_channels && alpha && beta, OAR_INVALID_INPUT, "oar_k_normalize: bad arguments");
+        require_device();
+        size_t plane = (size_t)w * h;
+        DevBuf din, dout;
+        din.reserve(plane * 3); dout.reserve(plane * 12);
+        OAR_HIP(hipMemcpy(din.p, rgb, plane * 3, hipMemcpyHostToDevice));
+        int src[3] = {src_channels[0], src_channels[1], src_channels[2]};
+        pp::normalize(nullptr, din.as<uint8_t>(), dout.as<float>(), 1, (int64_t)plane, src, alpha, beta, hwc_layout ? 1 : 0);
+        OAR_HIP(hipMemcpy(out, dout.p, plane * 12, hipMemcpyDeviceToHost));
+    });
+}
+
+oar_status oar_k_rec_preprocess(const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights, uint32_t n, uint32_t img_h,
+                                uint32_t img_w, uint32_t max_img_w, float* out_nchw, uint32_t* tensor_width) {
+    return guard([&] {
+        OAR_CHECK(tensor_width && (n == 0 || (rgb && widths && heights)), OAR_INVALID_INPUT, "oar_k_rec_preprocess: bad arguments");
+        require_device();
+        // size query when out_nchw is null
+        std::vector<uint32_t> ws(widths, widths + n), hs(heights, heights + n);
+        std::vector<int32_t> rws;
+        int Wt = host::rec_tensor_width(ws, hs, (int)img_h, (int)img_w, (int)max_img_w, rws);
+        *tensor_width = (uint32_t)Wt;
+        if (!out_nchw || n == 0) return;
+        size_t stage = 0;
+        for (uint32_t i = 0; i < n; ++i) stage += ((size_t)ws[i] * hs[i] * 3 + 63) & ~(size_t)63;
+        DevBuf dc, dd, dout;
+        dc.reserve(stage); dd.reserve(n * sizeof(pp::CropDesc)); dout.reserve((size_t)n * 3 * img_h * Wt * 4);
+        std::vector<pp::CropDesc> descs(n);
+        size_t off = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            size_t bytes = (size_t)ws[i] * hs[i] * 3;
+            OAR_HIP(hipMemcpy(dc.as<uint8_t>() + off, rgb[i], bytes, hipMemcpyHostToDevice));
+            descs[i].src = dc.as<uint8_t>() + off; descs[i].w = (int)ws[i]; descs[i].h = (int)hs[i]; descs[i].rw = rws[i]; descs[i].pad = 0;
+            off += (bytes + 63) & ~(size_t)63;
+        }
+        OAR_HIP(hipMemcpy(dd.p, descs.data(), n * sizeof(pp::CropDesc), hipMemcpyHostToDevice));
+        pp::rec_pack(nullptr, dd.as<pp::CropDesc>(), (int)n, (int)img_h, Wt, dout.as<float>(), 1);
+        OAR_HIP(hipMemcpy(out_nchw, dout.p, (size_t)n * 3 * img_h * Wt * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+oar_status oar_k_resize_triangle(const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, uint8_t* out) {
+    return guard([&] {
+        OAR_CHECK(rgb && out && w && h && nw && nh, OAR_INVALID_INPUT, "oar_k_resize_triangle: bad arguments");
+        require_device();
+        DevBuf din, dout;
+        din.reserve((size_t)w * h * 3); dout.reserve((size_t)nw * nh * 3);
+        OAR_HIP(hipMemcpy(din.p, rgb, (size_t)w * h * 3, hipMemcpyHostToDevice));
+        pp::resize_triangle(nullptr, din.as<uint8_t>(), (int)w, (int)h, dout.as<uint8_t>(), (int)nw, (int)nh);
+        OAR_HIP(hipMemcpy(out, dout.p, (size_t)nw * nh * 3, hipMemcpyDeviceToHost));
+    });
+}
+
+oar_status oar_k_threshold(const float* pred, size_t n, float thresh, uint8_t* mask) {
+    return guard([&] {
+        OAR_CHECK((pred && mask) || n == 0, OAR_INVALID_INPUT, "oar_k_threshold: bad arguments");
+        require_device();
+        if (n == 0) return;
+        DevBuf din, dout;
+        din.reserve(n * 4); dout.reserve(n + 4);
+        OAR_HIP(hipMemcpy(din.p, pred, n * 4, hipMemcpyHostToDevice));
+        pp::threshold(nullptr, din.as<float>(), dout.as<uint8_t>(), (int64_t)n, thresh);
+        OAR_HIP(hipMemcpy(mask, dout.p, n, hipMemcpyDeviceToHost));
+    });
+}
+
+oar_status oar_k_ctc_argmax(const float* probs, size_t rows, size_t vocab, int64_t* idx, float* prob) {
+    return guard([&] {
+        require_device();
+        if (rows == 0 || vocab == 0) return;  // empty tensor => no entries (decode.rs:465-472)
+        OAR_CHECK(probs && idx && prob, OAR_INVALID_INPUT, "oar_k_ctc_argmax: bad arguments");
+        DevBuf din, di, dp;
+        din.reserve(rows * vocab * 4); di.reserve(rows * 8); dp.reserve(rows * 4);
+        OAR_HIP(hipMemcpy(din.p, probs, rows * vocab * 4, hipMemcpyHostToDevice));
+        pp::ctc_argmax(nullptr, din.as<float>(), (int64_t)rows, (int)vocab, di.as<int64_t>(), dp.as<float>());
+        OAR_HIP(hipMemcpy(idx, di.p, rows * 8, hipMemcpyDeviceToHost));
+        OAR_HIP(hipMemcpy(prob, dp.p, rows * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+oar_status oar_k_box_scores(const float* pred, uint32_t height, uint32_t width, const float* boxes, uint32_t n_boxes, float* scores) {
+    return guard([&] {
+        require_device();
+        if (n_boxes == 0) return;
+        OAR_CHECK(pred && boxes && scores && height && width, OAR_INVALID_INPUT, "oar_k_box_scores: bad arguments");
+        size_t hw = (size_t)height * width;
+        DevBuf dpred, db, ds;
+        dpred.reserve(hw * 4); db.reserve(n_boxes * sizeof(pp::ScoreBox)); ds.reserve(n_boxes * 4);
+        std::vector<pp::ScoreBox> sb(n_boxes);
+        for (uint32_t i = 0; i < n_boxes; ++i) { std::memcpy(sb[i].pts, boxes + (size_t)i * 8, 32); sb[i].image = 0; sb[i].pad = 0; }
+        OAR_HIP(hipMemcpy(dpred.p, pred, hw * 4, hipMemcpyHostToDevice));
+        OAR_HIP(hipMemcpy(db.p, sb.data(), n_boxes * sizeof(pp::ScoreBox), hipMemcpyHostToDevice));
+        pp::box_scores(nullptr, dpred.as<float>(), (int)height, (int)width, db.as<pp::ScoreBox>(), (int)n_boxes, ds.as<float>());
+        OAR_HIP(hipMemcpy(scores, ds.p, n_boxes * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+oar_status oar_k_rotate_crop(const uint8_t* rgb, uint32_t w, uint32_t h, const float box[8], uint8_t* out, size_t cap, uint32_t* out_w,
+                             uint32_t* out_h) {
+    return guard([&] {
+        OAR_CHECK(rgb && box && out_w && out_h && w && h, OAR_INVALID_INPUT, "oar_k_rotate_crop: bad arguments");
+        require_device();
+        host::CropPlan pl = host::plan_crop((int)w, (int)h, box);
+        *out_w = *out_h = 0;
+        if (pl.mode == 0) return;
+        *out_w = (uint32_t)pl.out_w(); *out_h = (uint32_t)pl.out_h();
+        size_t bytes = (size_t)pl.out_w() * pl.out_h() * 3;
+        OAR_CHECK(out && cap >= bytes, OAR_INVALID_INPUT, "oar_k_rotate_crop: output buffer too small");
+        DevBuf dpage, dd, dout;
+        dpage.reserve((size_t)w * h * 3); dd.reserve(sizeof(pp::WarpDesc)); dout.reserve(bytes);
+        OAR_HIP(hipMemcpy(dpage.p, rgb, (size_t)w * h * 3, hipMemcpyHostToDevice));
+        pp::WarpDesc d;
+        std::memset(&d, 0, sizeof d);
+        d.page = dpage.as<uint8_t>(); d.page_w = (int)w; d.page_h = (int)h;
+        d.left = pl.left; d.top = pl.top; d.cw = pl.cw; d.ch = pl.ch; d.ow = pl.ow; d.oh = pl.oh; d.rot = pl.rot; d.mode = pl.mode;
+        std::memcpy(d.inv, pl.inv, sizeof d.inv);
+        d.out_off = 0;
+        OAR_HIP(hipMemcpy(dd.p, &d, sizeof d, hipMemcpyHostToDevice));
+        pp::rotate_crops(nullptr, dd.as<pp::WarpDesc>(), 1, dout.as<uint8_t>(), pl.out_w() * pl.out_h());
+        OAR_HIP(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
+    });
+}
+
+// ---------------------------------------------------------------------------------------------- profiling
+void oar_prof_reset(void) {
+    try { Profiler::get().reset(); } catch (...) {}
+}
+void oar_prof_enable(int32_t on) { Profiler::get().enabled = on != 0; }
+int32_t oar_prof_snapshot(oar_prof_entry* entries, int32_t cap) {
+    try {
+        Profiler& p = Profiler::get();
+        p.flush();
+        std::lock_guard<std::mutex> lk(p.mu);
+        std::vector<oar_prof_entry> v = p.totals;
+        std::sort(v.begin(), v.end(), [](const oar_prof_entry& a, const oar_prof_entry& b) { return a.total_ms > b.total_ms; });
+        int n = (int)std::min<size_t>(v.size(), (size_t)std::max(cap, 0));
+        for (int i = 0; i < n; ++i) entries[i] = v[i];
+        return (int32_t)v.size();
+    } catch (...) {
+        return 0;
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,124 @@
+// common.h -- error plumbing, HIP checks, device buffers, per-kernel profiler.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/oar_mi355x.h"
+
+namespace oar {
+
+struct Error : std::runtime_error {
+    oar_status code;
+    Error(oar_status c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+[[noreturn]] inline void fail(oar_status c, const std::string& m) { throw Error(c, m); }
+
+#define OAR_HIP(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess)                                                                               \
+            ::oar::fail(_e == hipErrorOutOfMemory ? OAR_OOM : OAR_DEVICE,                                   \
+                        std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + ":" +         \
+                            std::to_string(__LINE__) + ")");                                                \
+    } while (0)
+
+#define OAR_CHECK(cond, code, msg)                \
+    do {                                          \
+        if (!(cond)) ::oar::fail((code), (msg));  \
+    } while (0)
+
+void set_last_error(const std::string& m);
+
+// Growable device buffer (never shrinks).
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void reserve(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) OAR_HIP(hipFree(p));
+        p = nullptr;
+        size_t want = bytes + (bytes >> 3) + 256;
+        OAR_HIP(hipMalloc(&p, want));
+        cap = want;
+    }
+    template <typename T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+// Pinned host buffer.
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void reserve(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) OAR_HIP(hipHostFree(p));
+        p = nullptr;
+        size_t want = bytes + (bytes >> 3) + 256;
+        OAR_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+    }
+    template <typename T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+    ~PinBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+    PinBuf() = default;
+    PinBuf(const PinBuf&) = delete;
+    PinBuf& operator=(const PinBuf&) = delete;
+};
+
+// ---------------------------------------------------------------------------------- profiler
+// When enabled, launch sites bracket kernels with hipEvents on the launching stream; flush() (after a
+// stream sync) turns them into per-class totals.
+struct Profiler {
+    struct Pending {
+        hipEvent_t a, b;
+        int cls;
+        double bytes, flops;
+    };
+    std::mutex mu;
+    bool enabled = false;
+    std::vector<std::string> names;
+    std::map<std::string, int> index;
+    std::vector<oar_prof_entry> totals;
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+
+    static Profiler& get();
+    int cls(const char* name);
+    hipEvent_t ev();
+    void begin(hipStream_t s, int cls, double bytes, double flops);
+    void end(hipStream_t s);
+    void flush();  // requires the streams to be idle
+    void reset();
+};
+
+struct ProfScope {
+    hipStream_t s;
+    bool on;
+    ProfScope(hipStream_t s_, const char* name, double bytes, double flops) : s(s_) {
+        Profiler& p = Profiler::get();
+        on = p.enabled;
+        if (on) p.begin(s, p.cls(name), bytes, flops);
+    }
+    ~ProfScope() {
+        if (on) Profiler::get().end(s);
+    }
+};
+
+}  // namespace oar

@@ -1,0 +1,479 @@
+#include "db_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace oar {
+namespace host {
+
+namespace {
+constexpr float kEps = 1.1920929e-7f;          // f32::EPSILON
+constexpr double kEpsD = 2.220446049250313e-16; // f64::EPSILON
+constexpr float kPi = 3.14159265358979323846f;
+constexpr double kPiD = 3.14159265358979323846;
+
+inline uint32_t sat_u32(float v) {  // Rust `as u32`
+    if (!(v > 0.0f)) return 0u;
+    if (v >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)v;
+}
+inline int32_t total_order_key(float f) {  // f32::total_cmp
+    int32_t i;
+    std::memcpy(&i, &f, 4);
+    i ^= (int32_t)(((uint32_t)(i >> 31)) >> 1);
+    return i;
+}
+inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ contours
+std::vector<Contour> find_contours(const uint8_t* mask, int width, int height, size_t max_contours) {
+    static const int DX[8] = {-1, -1, 0, 1, 1, 1, 0, -1};  // w, nw, n, ne, e, se, s, sw (clockwise on screen)
+    static const int DY[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+    auto dir_of = [](int dx, int dy) {
+        for (int i = 0; i < 8; ++i)
+            if (DX[i] == dx && DY[i] == dy) return i;
+        return 0;
+    };
+    std::vector<int32_t> iv((size_t)width * height);
+    for (size_t i = 0; i < iv.size(); ++i) iv[i] = mask[i] > 0 ? 1 : 0;
+    auto at = [&](int x, int y) -> int32_t& { return iv[(size_t)y * width + x]; };
+    auto nonzero = [&](int x, int y) { return x > -1 && x < width && y > -1 && y < height && iv[(size_t)y * width + x] != 0; };
+
+    std::vector<Contour> out;
+    int border = 1;
+    for (int y = 0; y < height && out.size() < max_contours; ++y) {
+        int parent_border = 1;
+        for (int x = 0; x < width; ++x) {
+            int32_t v = at(x, y);
+            if (v == 0) continue;
+            bool start = false, hole = false;
+            int ax = 0, ay = y;
+            if (v == 1 && x > 0 && at(x - 1, y) == 0) { start = true; ax = x - 1; }
+            else if (v > 0 && x + 1 < width && at(x + 1, y) == 0) {
+                if (v > 1) parent_border = v;
+                start = true; hole = true; ax = x + 1;
+            }
+            if (start) {
+                ++border;
+                Contour c;
+                c.hole = hole;
+                if (parent_border > 1) {
+                    int pi = parent_border - 2;
+                    if (pi < (int)out.size()) {
+                        bool parent_outer = !out[pi].hole;
+                        c.parent = ((!hole) != parent_outer) ? pi : out[pi].parent;
+                    }
+                }
+                int first = dir_of(ax - x, ay - y);
+                bool found = false;
+                int p1x = 0, p1y = 0;
+                for (int k = 0; k < 8; ++k) {
+                    int d = (first + k) & 7;
+                    if (nonzero(x + DX[d], y + DY[d])) { found = true; p1x = x + DX[d]; p1y = y + DY[d]; break; }
+                }
+                if (!found) {
+                    c.pts.push_back({(float)x, (float)y});
+                    at(x, y) = -border;
+                } else {
+                    int p2x = p1x, p2y = p1y, p3x = x, p3y = y;
+                    while (true) {
+                        c.pts.push_back({(float)p3x, (float)p3y});
+                        int front = dir_of(p2x - p3x, p2y - p3y);
+                        int p4x = p3x, p4y = p3y, d4 = -1;
+                        for (int k = 7; k >= 0; --k) {  // counter-clockwise, starting next to p2
+                            int d = (front + k) & 7;
+                            if (nonzero(p3x + DX[d], p3y + DY[d])) { p4x = p3x + DX[d]; p4y = p3y + DY[d]; d4 = d; break; }
+                        }
+                        bool right_edge = false;
+                        for (int k = 7; k >= 0; --k) {
+                            int d = (front + k) & 7;
+                            if (d == d4) break;
+                            if (DX[d] == 1 && DY[d] == 0) { right_edge = true; break; }
+                        }
+                        if (p3x + 1 == width || right_edge) at(p3x, p3y) = -border;
+                        else if (at(p3x, p3y) == 1) at(p3x, p3y) = border;
+                        if (p4x == x && p4y == y && p3x == p1x && p3y == p1y) break;
+                        p2x = p3x; p2y = p3y; p3x = p4x; p3y = p4y;
+                    }
+                }
+                out.push_back(std::move(c));
+                if (out.size() >= max_contours) break;
+            }
+            int32_t nv = at(x, y);
+            if (nv != 1) parent_border = nv < 0 ? -nv : nv;
+        }
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------ hull / min-area rect
+std::vector<Pt> convex_hull(const std::vector<Pt>& src) {
+    if (src.size() < 3) return src;
+    std::vector<Pt> pts = src;
+    size_t si = 0;
+    for (size_t i = 1; i < pts.size(); ++i)
+        if (pts[i].y < pts[si].y || (pts[i].y == pts[si].y && pts[i].x < pts[si].x)) si = i;
+    std::swap(pts[0], pts[si]);
+    const Pt s = pts[0];
+    std::stable_sort(pts.begin() + 1, pts.end(), [s](const Pt& a, const Pt& b) {
+        int32_t ka = total_order_key(std::atan2(a.y - s.y, a.x - s.x)), kb = total_order_key(std::atan2(b.y - s.y, b.x - s.x));
+        if (ka != kb) return ka < kb;
+        float da = (a.x - s.x) * (a.x - s.x) + (a.y - s.y) * (a.y - s.y);
+        float db = (b.x - s.x) * (b.x - s.x) + (b.y - s.y) * (b.y - s.y);
+        return total_order_key(da) < total_order_key(db);
+    });
+    std::vector<Pt> hull;
+    hull.reserve(pts.size());
+    for (const Pt& p : pts) {
+        while (hull.size() > 1) {
+            const Pt &a = hull[hull.size() - 2], &b = hull[hull.size() - 1];
+            float cr = (b.x - a.x) * (p.y - a.y) - (b.y - a.y) * (p.x - a.x);
+            if (cr <= 0.0f) hull.pop_back();
+            else break;
+        }
+        hull.push_back(p);
+    }
+    return hull;
+}
+
+MinAreaRect min_area_rect(const std::vector<Pt>& src) {
+    MinAreaRect zero{0, 0, 0, 0, 0};
+    if (src.size() < 3) return zero;
+    std::vector<Pt> hp = convex_hull(src);
+    if (hp.size() < 3) {
+        float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+        for (const Pt& p : src) {
+            if (p.x < mnx) mnx = p.x;
+            if (p.x > mxx) mxx = p.x;
+            if (p.y < mny) mny = p.y;
+            if (p.y > mxy) mxy = p.y;
+        }
+        if (!std::isfinite(mnx)) return zero;
+        return {(mnx + mxx) * 0.5f, (mny + mxy) * 0.5f, mxx - mnx, mxy - mny, 0.0f};
+    }
+    float min_area = std::numeric_limits<float>::max();
+    MinAreaRect best = zero;
+    const size_t n = hp.size();
+    for (size_t i = 0; i < n; ++i) {
+        size_t j = (i + 1) % n;
+        float ex = hp[j].x - hp[i].x, ey = hp[j].y - hp[i].y;
+        float el2 = ex * ex + ey * ey;
+        if (el2 < kEps) continue;
+        float inv = 1.0f / std::sqrt(el2);
+        float nx = ex * inv, ny = ey * inv, px = -ny, py = nx;
+        float hix = hp[i].x, hiy = hp[i].y;
+        float mnn = std::numeric_limits<float>::max(), mxn = std::numeric_limits<float>::lowest();
+        float mnp = mnn, mxp = mxn;
+        for (const Pt& q : hp) {
+            float dx = q.x - hix, dy = q.y - hiy;
+            float pn = nx * dx + ny * dy, pp = px * dx + py * dy;
+            if (pn < mnn) mnn = pn;
+            if (pn > mxn) mxn = pn;
+            if (pp < mnp) mnp = pp;
+            if (pp > mxp) mxp = pp;
+        }
+        float w = mxn - mnn, h = mxp - mnp, area = w * h;
+        if (area < min_area) {
+            min_area = area;
+            float cn = (mnn + mxn) * 0.5f, cp = (mnp + mxp) * 0.5f;
+            best.cx = hix + cn * nx + cp * px;
+            best.cy = hiy + cn * ny + cp * py;
+            best.w = w; best.h = h;
+            best.angle = std::atan2(ny, nx) * 180.0f / kPi;
+        }
+    }
+    return best;
+}
+
+std::vector<Pt> simplify_chain(const std::vector<Pt>& p) {
+    const size_t n = p.size();
+    if (n <= 2) return p;
+    auto sgn = [](float v) { return v > 0.0f ? 1 : (v < 0.0f ? -1 : 0); };
+    std::vector<Pt> out;
+    out.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+        const Pt &prev = p[(i + n - 1) % n], &cur = p[i], &next = p[(i + 1) % n];
+        if (sgn(cur.x - prev.x) != sgn(next.x - cur.x) || sgn(cur.y - prev.y) != sgn(next.y - cur.y)) out.push_back(cur);
+    }
+    if (out.size() < 3) return p;
+    return out;
+}
+
+bool mini_box(const std::vector<Pt>& pts, Pt out[4], float& min_side) {
+    if (pts.size() < 3) return false;
+    MinAreaRect r = min_area_rect(pts);
+    float ms = r.w < r.h ? r.w : r.h;
+    if (!std::isfinite(ms) || ms <= 0.0f) return false;
+    float ca = std::cos(r.angle * kPi / 180.0f), sa = std::sin(r.angle * kPi / 180.0f);
+    float w2 = r.w / 2.0f, h2 = r.h / 2.0f;
+    const float cs[4][2] = {{-w2, -h2}, {w2, -h2}, {w2, h2}, {-w2, h2}};
+    Pt raw[4];
+    for (int i = 0; i < 4; ++i) {
+        raw[i].x = cs[i][0] * ca - cs[i][1] * sa + r.cx;
+        raw[i].y = cs[i][0] * sa + cs[i][1] * ca + r.cy;
+    }
+    std::stable_sort(raw, raw + 4, [](const Pt& a, const Pt& b) { return a.x < b.x; });
+    int i1, i4, i2, i3;
+    if (raw[1].y > raw[0].y) { i1 = 0; i4 = 1; } else { i1 = 1; i4 = 0; }
+    if (raw[3].y > raw[2].y) { i2 = 2; i3 = 3; } else { i2 = 3; i3 = 2; }
+    out[0] = raw[i1]; out[1] = raw[i2]; out[2] = raw[i3]; out[3] = raw[i4];
+    min_side = ms;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------ unclip (Clipper2 offset)
+std::vector<Pt> unclip(const Pt box[4], float ratio) {
+    struct P64 { int64_t x, y; };
+    struct PD { double x, y; };
+    const int nb = 4;
+    PD pd[4];
+    for (int i = 0; i < nb; ++i) pd[i] = {(double)box[i].x, (double)box[i].y};
+    double a = 0.0;
+    for (int i = 0, prev = nb - 1; i < nb; prev = i, ++i) a += (pd[prev].y + pd[i].y) * (pd[prev].x - pd[i].x);
+    a *= 0.5;
+    double area = std::fabs(a);
+    if (area <= kEpsD) return {};
+    double perim = 0.0;
+    for (int i = 1; i < nb; ++i) perim += std::hypot(pd[i].x - pd[i - 1].x, pd[i].y - pd[i - 1].y);
+    perim += std::hypot(pd[0].x - pd[nb - 1].x, pd[0].y - pd[nb - 1].y);
+    if (perim <= kEpsD) return {};
+    double delta = area * (double)ratio / perim;
+    if (std::fabs(delta) <= kEpsD) return {};
+
+    const double scale = 100.0;  // precision 2
+    std::vector<P64> path;
+    for (int i = 0; i < nb; ++i) {
+        P64 q{(int64_t)std::round(pd[i].x * scale), (int64_t)std::round(pd[i].y * scale)};
+        if (!path.empty() && path.back().x == q.x && path.back().y == q.y) continue;
+        path.push_back(q);
+    }
+    while (path.size() > 1 && path.back().x == path[0].x && path.back().y == path[0].y) path.pop_back();
+    const int n = (int)path.size();
+    if (n < 3) return {};
+    std::vector<Pt> out;
+    auto push = [&](double X, double Y) {
+        int64_t xi = (int64_t)std::round(X), yi = (int64_t)std::round(Y);
+        out.push_back({(float)((double)xi / scale), (float)((double)yi / scale)});
+    };
+    double d = delta * scale;
+    if (std::fabs(d) < 0.5) {
+        for (auto& q : path) out.push_back({(float)((double)q.x / scale), (float)((double)q.y / scale)});
+    } else {
+        double ai = 0.0;
+        for (int i = 0, prev = n - 1; i < n; prev = i, ++i) ai += (double)(path[prev].y + path[i].y) * (double)(path[prev].x - path[i].x);
+        ai *= 0.5;
+        double gd = ai < 0 ? -d : d, absd = std::fabs(gd);
+        double arc_tol = absd * 0.002;
+        double steps360 = std::min(kPiD / std::acos(1.0 - arc_tol / absd), absd * kPiD);
+        double step_sin = std::sin(2.0 * kPiD / steps360), step_cos = std::cos(2.0 * kPiD / steps360);
+        if (gd < 0.0) step_sin = -step_sin;
+        double steps_per_rad = steps360 / (2.0 * kPiD);
+        std::vector<PD> norms(n);
+        for (int i = 0; i < n; ++i) {
+            const P64 &p = path[i], &q = path[(i + 1) % n];
+            if (p.x == q.x && p.y == q.y) { norms[i] = {0.0, 0.0}; continue; }
+            double dx = (double)(q.x - p.x), dy = (double)(q.y - p.y);
+            double inv = 1.0 / std::sqrt(dx * dx + dy * dy);
+            dx *= inv; dy *= inv;
+            norms[i] = {dy, -dx};
+        }
+        for (int j = 0, k = n - 1; j < n; k = j, ++j) {
+            if (path[j].x == path[k].x && path[j].y == path[k].y) continue;
+            double sin_a = norms[j].y * norms[k].x - norms[k].y * norms[j].x;
+            double cos_a = norms[j].x * norms[k].x + norms[j].y * norms[k].y;
+            if (sin_a > 1.0) sin_a = 1.0; else if (sin_a < -1.0) sin_a = -1.0;
+            double px = (double)path[j].x, py = (double)path[j].y;
+            if (cos_a > -0.999 && (sin_a * gd < 0)) {
+                push(px + norms[k].x * gd, py + norms[k].y * gd);
+                push(px, py);
+                push(px + norms[j].x * gd, py + norms[j].y * gd);
+            } else {
+                double angle = std::atan2(sin_a, cos_a);
+                double ox = norms[k].x * gd, oy = norms[k].y * gd;
+                if (j == k) { ox = -ox; oy = -oy; }
+                push(px + ox, py + oy);
+                int steps = (int)std::ceil(steps_per_rad * std::fabs(angle));
+                for (int i = 1; i < steps; ++i) {
+                    double nx2 = ox * step_cos - step_sin * oy, ny2 = ox * step_sin + oy * step_cos;
+                    ox = nx2; oy = ny2;
+                    push(px + ox, py + oy);
+                }
+                push(px + norms[j].x * gd, py + norms[j].y * gd);
+            }
+        }
+    }
+    if (out.size() > 1 && std::fabs(out.front().x - out.back().x) < kEps && std::fabs(out.front().y - out.back().y) < kEps) out.pop_back();
+    if (out.size() < 3) return {};
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------ sorting
+std::vector<int> sort_quad_boxes(const std::vector<float>& b8) {
+    const int n = (int)(b8.size() / 8);
+    auto ymin = [&](int i) { float m = INFINITY; for (int k = 0; k < 4; ++k) m = b8[i * 8 + k * 2 + 1] < m ? b8[i * 8 + k * 2 + 1] : m; return m; };
+    auto xmin = [&](int i) { float m = INFINITY; for (int k = 0; k < 4; ++k) m = b8[i * 8 + k * 2] < m ? b8[i * 8 + k * 2] : m; return m; };
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        float ay = ymin(a), by = ymin(b);
+        if (ay < by) return true;
+        if (ay > by) return false;
+        if (ay == by) return xmin(a) < xmin(b);
+        return false;
+    });
+    for (int i = 0; i + 1 < n; ++i) {
+        for (int j = i; j >= 0; --j) {
+            if (j + 1 >= n) break;
+            int c = order[j], nx = order[j + 1];
+            if (std::fabs(ymin(nx) - ymin(c)) < 10.0f && xmin(nx) < xmin(c)) std::swap(order[j], order[j + 1]);
+            else break;
+        }
+    }
+    return order;
+}
+
+// ------------------------------------------------------------------------------------------ crop planning
+namespace {
+bool lu_solve8(float A[8][8], float b[8]) {  // nalgebra LU (partial pivoting) + solve
+    int pi[8], pp[8], np = 0;
+    for (int i = 0; i < 8; ++i) {
+        int piv = i;
+        float mx = std::fabs(A[i][i]);
+        for (int r = i + 1; r < 8; ++r) {
+            float v = std::fabs(A[r][i]);
+            if (v > mx) { mx = v; piv = r; }
+        }
+        float diag = A[piv][i];
+        if (diag == 0.0f) continue;
+        float inv = 1.0f / diag;
+        if (piv != i) {
+            pi[np] = i; pp[np] = piv; ++np;
+            for (int c = 0; c < i; ++c) std::swap(A[i][c], A[piv][c]);
+            std::swap(A[i][i], A[piv][i]);
+            for (int r = i + 1; r < 8; ++r) A[r][i] *= inv;
+            for (int k = i + 1; k < 8; ++k) {
+                std::swap(A[i][k], A[piv][k]);
+                float pk = -A[i][k];
+                for (int r = i + 1; r < 8; ++r) A[r][k] = pk * A[r][i] + A[r][k];
+            }
+        } else {
+            for (int r = i + 1; r < 8; ++r) A[r][i] *= inv;
+            for (int k = i + 1; k < 8; ++k) {
+                float pk = -A[i][k];
+                for (int r = i + 1; r < 8; ++r) A[r][k] = pk * A[r][i] + A[r][k];
+            }
+        }
+    }
+    for (int s = 0; s < np; ++s) std::swap(b[pi[s]], b[pp[s]]);
+    for (int i = 0; i < 7; ++i) {
+        float coeff = -(b[i] / 1.0f);
+        for (int r = i + 1; r < 8; ++r) b[r] = coeff * A[r][i] + b[r];
+    }
+    for (int i = 7; i >= 0; --i) {
+        float diag = A[i][i];
+        if (diag == 0.0f) return false;
+        float coeff = b[i] / diag;
+        b[i] = coeff;
+        float nc = -coeff;
+        for (int r = 0; r < i; ++r) b[r] = nc * A[r][i] + b[r];
+    }
+    return true;
+}
+bool inverse3(const float* m, float* o) {  // nalgebra Matrix3::try_inverse
+    float m11 = m[0], m12 = m[1], m13 = m[2], m21 = m[3], m22 = m[4], m23 = m[5], m31 = m[6], m32 = m[7], m33 = m[8];
+    float a = m22 * m33 - m32 * m23, b = m21 * m33 - m31 * m23, c = m21 * m32 - m31 * m22;
+    float det = m11 * a - m12 * b + m13 * c;
+    if (det == 0.0f) return false;
+    o[0] = a / det; o[1] = (m13 * m32 - m33 * m12) / det; o[2] = (m12 * m23 - m22 * m13) / det;
+    o[3] = -b / det; o[4] = (m11 * m33 - m31 * m13) / det; o[5] = (m13 * m21 - m23 * m11) / det;
+    o[6] = c / det; o[7] = (m12 * m31 - m32 * m11) / det; o[8] = (m11 * m22 - m21 * m12) / det;
+    return true;
+}
+}  // namespace
+
+CropPlan plan_crop(int img_w, int img_h, const float box8[8]) {
+    CropPlan pl;
+    float mnx = INFINITY, mxx = -INFINITY, mny = INFINITY, mxy = -INFINITY;
+    for (int i = 0; i < 4; ++i) {
+        mnx = std::fmin(mnx, box8[i * 2]); mxx = std::fmax(mxx, box8[i * 2]);
+        mny = std::fmin(mny, box8[i * 2 + 1]); mxy = std::fmax(mxy, box8[i * 2 + 1]);
+    }
+    uint32_t left = sat_u32(std::fmax(mnx, 0.0f)), top = sat_u32(std::fmax(mny, 0.0f));
+    uint32_t right = sat_u32(std::fmin(mxx, (float)img_w)), bottom = sat_u32(std::fmin(mxy, (float)img_h));
+    if (right <= left || bottom <= top) return pl;
+    uint32_t cw = right - left, ch = bottom - top;
+    Pt s[4];
+    for (int i = 0; i < 4; ++i) s[i] = {box8[i * 2] - (float)left, box8[i * 2 + 1] - (float)top};
+    std::stable_sort(s, s + 4, [](const Pt& a, const Pt& b) { return a.x < b.x; });
+    int ia = 0, id = 1, ib = 2, ic = 3;
+    if (s[1].y < s[0].y) { ia = 1; id = 0; }
+    if (s[3].y < s[2].y) { ib = 3; ic = 2; }
+    Pt o[4] = {s[ia], s[ib], s[ic], s[id]};
+    pl.left = (int)left; pl.top = (int)top; pl.cw = (int)cw; pl.ch = (int)ch;
+    float fw = (float)cw, fh = (float)ch;
+    if (o[0].x == 0.0f && o[0].y == 0.0f && o[1].x == fw && o[1].y == 0.0f && o[2].x == fw && o[2].y == fh && o[3].x == 0.0f && o[3].y == fh) {
+        pl.mode = 1; pl.ow = (int)cw; pl.oh = (int)ch;
+        pl.rot = (float)ch >= (float)cw * 1.5f ? 1 : 0;
+        return pl;
+    }
+    float w1 = std::hypot(o[0].x - o[1].x, o[0].y - o[1].y), w2 = std::hypot(o[2].x - o[3].x, o[2].y - o[3].y);
+    uint32_t ow = sat_u32(std::round(std::fmax(w1, w2)));
+    float h1 = std::hypot(o[0].x - o[3].x, o[0].y - o[3].y), h2 = std::hypot(o[1].x - o[2].x, o[1].y - o[2].y);
+    uint32_t oh = sat_u32(std::round(std::fmax(h1, h2)));
+    if (ow == 0 || oh == 0) return pl;
+    const Pt dst[4] = {{0.0f, 0.0f}, {(float)ow, 0.0f}, {(float)ow, (float)oh}, {0.0f, (float)oh}};
+    float A[8][8], b[8];
+    for (int i = 0; i < 4; ++i) {
+        float sx = o[i].x, sy = o[i].y, dx = dst[i].x, dy = dst[i].y;
+        float r0[8] = {sx, sy, 1.0f, 0.0f, 0.0f, 0.0f, -sx * dx, -sy * dx};
+        float r1[8] = {0.0f, 0.0f, 0.0f, sx, sy, 1.0f, -sx * dy, -sy * dy};
+        std::memcpy(A[i * 2], r0, sizeof r0);
+        std::memcpy(A[i * 2 + 1], r1, sizeof r1);
+        b[i * 2] = dx; b[i * 2 + 1] = dy;
+    }
+    if (!lu_solve8(A, b)) return pl;
+    float m[9] = {b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], 1.0f};
+    if (!inverse3(m, pl.inv)) return pl;
+    pl.mode = 2; pl.ow = (int)ow; pl.oh = (int)oh;
+    pl.rot = (float)oh >= (float)ow * 1.5f ? 1 : 0;
+    return pl;
+}
+
+bool det_resize_dims(uint32_t w, uint32_t h, uint32_t limit_side_len, int limit_type, uint32_t max_side_limit, uint32_t& rh, uint32_t& rw) {
+    uint32_t mx = std::max(h, w), mn = std::min(h, w);
+    float ratio;
+    if (limit_type == 0) ratio = mx > limit_side_len ? (float)limit_side_len / (float)mx : 1.0f;
+    else if (limit_type == 1) ratio = mn < limit_side_len ? (float)limit_side_len / (float)mn : 1.0f;
+    else ratio = (float)limit_side_len / (float)mx;
+    rh = sat_u32((float)h * ratio); rw = sat_u32((float)w * ratio);
+    uint32_t rmx = std::max(rh, rw);
+    if (rmx > max_side_limit) {
+        float lr = (float)max_side_limit / (float)rmx;
+        rh = sat_u32((float)rh * lr); rw = sat_u32((float)rw * lr);
+    }
+    rh = std::max((rh + 16) / 32 * 32, 32u);
+    rw = std::max((rw + 16) / 32 * 32, 32u);
+    return !(rh == h && rw == w);
+}
+
+int rec_tensor_width(const std::vector<uint32_t>& ws, const std::vector<uint32_t>& hs, int img_h, int img_w, int max_img_w, std::vector<int32_t>& resized_w) {
+    float max_wh = (float)img_w / (float)std::max(img_h, 1);
+    for (size_t i = 0; i < ws.size(); ++i) {
+        float r = (float)ws[i] / (float)std::max<uint32_t>(hs[i], 1);
+        if (r > max_wh) max_wh = r;
+    }
+    uint32_t tw = std::min<uint32_t>(sat_u32((float)img_h * max_wh), (uint32_t)max_img_w);
+    resized_w.resize(ws.size());
+    for (size_t i = 0; i < ws.size(); ++i) {
+        float ratio = (float)ws[i] / (float)hs[i];
+        uint32_t rw = std::min<uint32_t>(sat_u32(std::ceil((float)img_h * ratio)), tw);
+        resized_w[i] = (int32_t)rw;
+    }
+    return (int)tw;
+}
+
+}  // namespace host
+}  // namespace oar

@@ -1,0 +1,52 @@
+// db_host.h -- host-side (serial, per-contour) geometry of DB post-processing and crop planning.
+// These steps are pointer-chasing / tiny-N float work with libm calls (atan2f/cosf/sinf/hypotf) whose exact
+// results are part of the box contract, so they stay on the host (one worker per page) -- see DESIGN.md.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace oar {
+namespace host {
+
+struct Pt { float x, y; };
+
+struct Contour {
+    std::vector<Pt> pts;   // border pixels in tracing order
+    bool hole = false;
+    int parent = -1;
+};
+
+// imageproc 0.27 `find_contours::<u32>` call at processors/db_bitmap.rs:100 (Suzuki-Abe, raster discovery order,
+// hole borders included).  Stops after max_contours contours (the reference `take(max_candidates)` only ever
+// consumes that many).
+std::vector<Contour> find_contours(const uint8_t* mask, int width, int height, size_t max_contours);
+
+struct MinAreaRect { float cx, cy, w, h, angle; };
+std::vector<Pt> convex_hull(const std::vector<Pt>& src);                 // processors/geometry.rs:226-271
+MinAreaRect min_area_rect(const std::vector<Pt>& src);                   // processors/geometry.rs:310-441
+std::vector<Pt> simplify_chain(const std::vector<Pt>& p);                // processors/db_bitmap.rs:207-239
+// processors/db_bitmap.rs:164-205,253-277: ordered mini box + min side; false when rejected.
+bool mini_box(const std::vector<Pt>& pts, Pt out[4], float& min_side);
+// processors/db_bitmap.rs:279-368 (clipper2 inflate, Round join, precision 2)
+std::vector<Pt> unclip(const Pt box[4], float ratio);
+// processors/sorting.rs:35-84: returns the permutation
+std::vector<int> sort_quad_boxes(const std::vector<float>& boxes8);
+
+struct CropPlan {        // utils/transform.rs:76-191
+    int mode = 0;        // 0 failed, 1 axis aligned, 2 perspective
+    int left = 0, top = 0, cw = 0, ch = 0, ow = 0, oh = 0, rot = 0;
+    float inv[9] = {0};
+    int out_w() const { return rot ? oh : ow; }
+    int out_h() const { return rot ? ow : oh; }
+};
+CropPlan plan_crop(int img_w, int img_h, const float box8[8]);
+
+// processors/resize_detection.rs:243-319 (type0). Returns true when a resize is needed.
+bool det_resize_dims(uint32_t w, uint32_t h, uint32_t limit_side_len, int limit_type, uint32_t max_side_limit,
+                     uint32_t& rh, uint32_t& rw);
+// models/recognition/crnn.rs:80-103
+int rec_tensor_width(const std::vector<uint32_t>& ws, const std::vector<uint32_t>& hs, int img_h, int img_w, int max_img_w,
+                     std::vector<int32_t>& resized_w);
+
+}  // namespace host
+}  // namespace oar

@@ -1,0 +1,1266 @@
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <set>
+#include <sstream>
+
+namespace oar {
+
+using k::Act;
+
+// =================================================================================================
+// construction + load-time graph rewrites
+// =================================================================================================
+static int64_t numel(const std::vector<int64_t>& d) {
+    int64_t n = 1;
+    for (auto v : d) n *= v;
+    return n;
+}
+
+Engine::Engine(const uint8_t* onnx, size_t len, int device_id) : device_(device_id) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        fail(OAR_DEVICE, "no HIP device visible: libOarMi355x has no CPU fallback");
+    OAR_CHECK(device_id >= 0 && device_id < ndev, OAR_DEVICE, "device_id out of range");
+    OAR_HIP(hipSetDevice(device_));
+    OAR_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    OnnxModel m = parse_onnx(onnx, len);
+    input_name_ = m.inputs[0];
+    output_names_ = m.outputs;
+    opset_ = m.opset;
+    rewrite_graph(m);
+}
+
+Engine::~Engine() {
+    (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    for (void* p : dev_allocs_) (void)hipFree(p);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+const float* Engine::upload_const(const std::string& key, const std::vector<float>& v) {
+    auto it = dev_consts_.find(key);
+    if (it != dev_consts_.end()) return it->second;
+    void* p = nullptr;
+    size_t bytes = std::max<size_t>(v.size() * sizeof(float), 16);
+    OAR_HIP(hipMalloc(&p, bytes));
+    dev_allocs_.push_back(p);
+    if (!v.empty()) OAR_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    dev_consts_[key] = (const float*)p;
+    return (const float*)p;
+}
+
+static bool is_unary_act(const std::string& op) {
+    return op == "Relu" || op == "HardSwish" || op == "HardSigmoid" || op == "Sigmoid" || op == "LeakyRelu" || op == "Tanh";
+}
+static Act act_of(const GNode& n) {
+    Act a;
+    if (n.op == "Relu") a.kind = k::ACT_RELU;
+    else if (n.op == "HardSwish") a.kind = k::ACT_HSWISH;
+    else if (n.op == "HardSigmoid") { a.kind = k::ACT_HSIGMOID; a.alpha = n.af("alpha", 0.2f); a.beta = n.af("beta", 0.5f); }
+    else if (n.op == "Sigmoid") a.kind = k::ACT_SIGMOID;
+    else if (n.op == "LeakyRelu") { a.kind = k::ACT_LEAKY; a.alpha = n.af("alpha", 0.01f); }
+    else if (n.op == "Tanh") a.kind = k::ACT_TANH;
+    return a;
+}
+
+void Engine::rewrite_graph(OnnxModel& m) {
+    inits_ = std::move(m.initializers);
+    std::vector<GNode> nodes;
+    for (auto& on : m.nodes) {
+        if (on.op == "Constant") {
+            auto it = on.attrs.find("value");
+            OAR_CHECK(it != on.attrs.end() && it->second.kind == Attr::T, OAR_UNSUPPORTED_OP, "Constant without tensor value");
+            HostTensor t = it->second.t;
+            t.name = on.outputs[0];
+            inits_[t.name] = std::move(t);
+            continue;
+        }
+        if (on.op == "Dropout") { on.op = "Identity"; on.outputs.resize(1); }
+        GNode g;
+        g.op = on.op; g.in = on.inputs; g.out = on.outputs; g.attrs = on.attrs;
+        nodes.push_back(std::move(g));
+    }
+    std::set<std::string> graph_outs(output_names_.begin(), output_names_.end());
+    auto consumers = [&](const std::vector<GNode>& ns) {
+        std::map<std::string, std::vector<int>> c;
+        for (int i = 0; i < (int)ns.size(); ++i)
+            for (auto& s : ns[i].in)
+                if (!s.empty()) c[s].push_back(i);
+        return c;
+    };
+    auto is_init = [&](const std::string& s) { return inits_.count(s) != 0; };
+
+    // ---- pass 1: fold BatchNormalization into the producing Conv / ConvTranspose
+    {
+        auto cons = consumers(nodes);
+        std::map<std::string, int> producer;
+        for (int i = 0; i < (int)nodes.size(); ++i) for (auto& o : nodes[i].out) producer[o] = i;
+        std::vector<bool> dead(nodes.size(), false);
+        for (int i = 0; i < (int)nodes.size(); ++i) {
+            GNode& bn = nodes[i];
+            if (bn.op != "BatchNormalization" || bn.in.size() < 5) continue;
+            auto pit = producer.find(bn.in[0]);
+            if (pit == producer.end()) continue;
+            GNode& cv = nodes[pit->second];
+            if (cv.op != "Conv" && cv.op != "ConvTranspose") continue;
+            if (cons[bn.in[0]].size() != 1 || graph_outs.count(bn.in[0])) continue;
+            if (!is_init(cv.in[1]) || !is_init(bn.in[1]) || !is_init(bn.in[2]) || !is_init(bn.in[3]) || !is_init(bn.in[4])) continue;
+            if (cv.in.size() > 2 && !cv.in[2].empty() && !is_init(cv.in[2])) continue;
+            const HostTensor& W = inits_[cv.in[1]];
+            const auto &ga = inits_[bn.in[1]].f, &be = inits_[bn.in[2]].f, &mu = inits_[bn.in[3]].f, &va = inits_[bn.in[4]].f;
+            float eps = bn.af("epsilon", 1e-5f);
+            int64_t C = (int64_t)ga.size();
+            HostTensor W2 = W;
+            std::vector<float> b2(C, 0.f);
+            if (cv.in.size() > 2 && !cv.in[2].empty()) b2 = inits_[cv.in[2]].f;
+            std::vector<float> sc(C);
+            for (int64_t c = 0; c < C; ++c) sc[c] = ga[c] / std::sqrt(va[c] + eps);
+            if (cv.op == "Conv") {
+                OAR_CHECK(W.dims[0] == C, OAR_SHAPE_MISMATCH, "BN fold: channel mismatch");
+                int64_t per = numel(W.dims) / C;
+                for (int64_t c = 0; c < C; ++c)
+                    for (int64_t j = 0; j < per; ++j) W2.f[c * per + j] = W.f[c * per + j] * sc[c];
+            } else {
+                int64_t g = cv.ai("group", 1);
+                if (g != 1) continue;
+                OAR_CHECK(W.dims[1] == C, OAR_SHAPE_MISMATCH, "BN fold (convT): channel mismatch");
+                int64_t khw = W.dims[2] * W.dims[3];
+                for (int64_t ci = 0; ci < W.dims[0]; ++ci)
+                    for (int64_t c = 0; c < C; ++c)
+                        for (int64_t j = 0; j < khw; ++j) W2.f[(ci * C + c) * khw + j] = W.f[(ci * C + c) * khw + j] * sc[c];
+            }
+            for (int64_t c = 0; c < C; ++c) b2[c] = (b2[c] - mu[c]) * sc[c] + be[c];
+            std::string wn = cv.in[1] + "::bnfold" + std::to_string(i), bnm = wn + "::b";
+            W2.name = wn;
+            inits_[wn] = std::move(W2);
+            HostTensor B; B.name = bnm; B.dtype = DType::F32; B.dims = {C}; B.f = b2;
+            inits_[bnm] = std::move(B);
+            cv.in.resize(3);
+            cv.in[1] = wn; cv.in[2] = bnm;
+            cv.out[0] = bn.out[0];
+            producer[bn.out[0]] = pit->second;
+            dead[i] = true;
+        }
+        std::vector<GNode> keep;
+        for (int i = 0; i < (int)nodes.size(); ++i) if (!dead[i]) keep.push_back(std::move(nodes[i]));
+        nodes.swap(keep);
+    }
+
+    // ---- pass 2: MatMul(x, Wconst) + Add(const bias)  ->  Linear
+    {
+        auto cons = consumers(nodes);
+        std::vector<bool> dead(nodes.size(), false);
+        for (int i = 0; i < (int)nodes.size(); ++i) {
+            GNode& mm = nodes[i];
+            if (mm.op != "MatMul" || !is_init(mm.in[1]) || inits_[mm.in[1]].dims.size() != 2) continue;
+            mm.op = "Linear";
+            auto& cs = cons[mm.out[0]];
+            if (cs.size() != 1 || graph_outs.count(mm.out[0])) continue;
+            GNode& ad = nodes[cs[0]];
+            if (ad.op != "Add" || dead[cs[0]]) continue;
+            int other = ad.in[0] == mm.out[0] ? 1 : 0;
+            if (!is_init(ad.in[other])) continue;
+            const HostTensor& b = inits_[ad.in[other]];
+            if (numel(b.dims) != inits_[mm.in[1]].dims[1] || b.dims.empty() || b.dims.back() != numel(b.dims)) continue;
+            mm.bias = ad.in[other];
+            mm.out[0] = ad.out[0];
+            dead[cs[0]] = true;
+        }
+        std::vector<GNode> keep;
+        for (int i = 0; i < (int)nodes.size(); ++i) if (!dead[i]) keep.push_back(std::move(nodes[i]));
+        nodes.swap(keep);
+    }
+
+    // ---- pass 3: fuse activations into Conv / ConvTranspose / Linear / Gemm / Add
+    {
+        bool changed = true;
+        while (changed) {
+            changed = false;
+            auto cons = consumers(nodes);
+            std::vector<bool> dead(nodes.size(), false);
+            for (int i = 0; i < (int)nodes.size(); ++i) {
+                GNode& p = nodes[i];
+                if (!(p.op == "Conv" || p.op == "ConvTranspose" || p.op == "Linear" || p.op == "Gemm" || p.op == "Add")) continue;
+                if (p.act.kind != k::ACT_NONE) continue;
+                const std::string& y = p.out[0];
+                if (graph_outs.count(y)) continue;
+                auto& cs = cons[y];
+                if (cs.size() == 1 && is_unary_act(nodes[cs[0]].op) && !dead[cs[0]]) {
+                    GNode& a = nodes[cs[0]];
+                    p.act = act_of(a);
+                    p.out[0] = a.out[0];
+                    dead[cs[0]] = true;
+                    changed = true;
+                    continue;
+                }
+                if (cs.size() == 2) {
+                    // x * HardSigmoid(x) (alpha 1/6, beta .5) = HardSwish ; x * Sigmoid(x) = Swish
+                    for (int t = 0; t < 2; ++t) {
+                        GNode& g = nodes[cs[t]];
+                        GNode& mul = nodes[cs[1 - t]];
+                        if (dead[cs[0]] || dead[cs[1]]) break;
+                        if (!(g.op == "HardSigmoid" || g.op == "Sigmoid") || mul.op != "Mul") continue;
+                        if (graph_outs.count(g.out[0]) || cons[g.out[0]].size() != 1 || cons[g.out[0]][0] != cs[1 - t]) continue;
+                        bool ok = (mul.in[0] == y && mul.in[1] == g.out[0]) || (mul.in[1] == y && mul.in[0] == g.out[0]);
+                        if (!ok) continue;
+                        if (g.op == "HardSigmoid") {
+                            float al = g.af("alpha", 0.2f), be = g.af("beta", 0.5f);
+                            if (std::fabs(al - 1.0f / 6.0f) > 1e-6f || std::fabs(be - 0.5f) > 1e-6f) continue;
+                            p.act.kind = k::ACT_HSWISH;
+                        } else {
+                            p.act.kind = k::ACT_SWISH;
+                        }
+                        p.out[0] = mul.out[0];
+                        dead[cs[0]] = dead[cs[1]] = true;
+                        changed = true;
+                        break;
+                    }
+                }
+            }
+            std::vector<GNode> keep;
+            for (int i = 0; i < (int)nodes.size(); ++i) if (!dead[i]) keep.push_back(std::move(nodes[i]));
+            nodes.swap(keep);
+        }
+    }
+
+    // ---- pass 4: Linear -> Add(residual): fold the residual into the Linear epilogue (no act between)
+    {
+        auto cons = consumers(nodes);
+        std::vector<bool> dead(nodes.size(), false);
+        std::map<std::string, int> producer;
+        for (int i = 0; i < (int)nodes.size(); ++i) for (auto& o : nodes[i].out) producer[o] = i;
+        for (int i = 0; i < (int)nodes.size(); ++i) {
+            GNode& ad = nodes[i];
+            if (ad.op != "Add" || ad.act.kind != k::ACT_NONE) continue;
+            for (int t = 0; t < 2; ++t) {
+                auto pit = producer.find(ad.in[t]);
+                if (pit == producer.end() || dead[pit->second]) continue;
+                GNode& lin = nodes[pit->second];
+                if (lin.op != "Linear" || lin.act.kind != k::ACT_NONE || !lin.residual.empty()) continue;
+                if (cons[ad.in[t]].size() != 1 || graph_outs.count(ad.in[t])) continue;
+                const std::string& other = ad.in[1 - t];
+                if (is_init(other)) continue;
+                // move the fused Linear to the Add's position so `other` is already computed
+                GNode f = lin;
+                f.residual = other;
+                f.out[0] = ad.out[0];
+                dead[pit->second] = true;
+                nodes[i] = std::move(f);
+                break;
+            }
+        }
+        std::vector<GNode> keep;
+        for (int i = 0; i < (int)nodes.size(); ++i) if (!dead[i]) keep.push_back(std::move(nodes[i]));
+        nodes.swap(keep);
+    }
+    for (int i = 0; i < (int)nodes.size(); ++i) nodes[i].id = i;
+    nodes_ = std::move(nodes);
+}
+
+// =================================================================================================
+// planner
+// =================================================================================================
+struct TInfo {
+    std::vector<int64_t> dims;  // logical
+    Layout layout = Layout::NATIVE;
+    Loc loc;
+    bool host_int = false;
+    std::vector<int64_t> hv;
+    const HostTensor* ht = nullptr;  // f32 initializer
+    std::string root;                // storage root (for liveness)
+    size_t bytes() const { return (size_t)std::max<int64_t>(numel(dims), 1) * 4; }
+};
+
+struct Arena {
+    struct Blk { size_t off, sz; };
+    std::vector<Blk> free_;
+    size_t top = 0;
+    static size_t al(size_t n) { return (n + 255) & ~(size_t)255; }
+    size_t alloc(size_t n) {
+        n = al(std::max<size_t>(n, 4));
+        int best = -1;
+        for (int i = 0; i < (int)free_.size(); ++i)
+            if (free_[i].sz >= n && (best < 0 || free_[i].sz < free_[best].sz)) best = i;
+        if (best >= 0) {
+            size_t off = free_[best].off;
+            if (free_[best].sz == n) free_.erase(free_.begin() + best);
+            else { free_[best].off += n; free_[best].sz -= n; }
+            return off;
+        }
+        size_t off = top;
+        top += n;
+        return off;
+    }
+    void release(size_t off, size_t n) {
+        n = al(std::max<size_t>(n, 4));
+        free_.push_back({off, n});
+        std::sort(free_.begin(), free_.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
+        std::vector<Blk> m;
+        for (auto& b : free_) {
+            if (!m.empty() && m.back().off + m.back().sz == b.off) m.back().sz += b.sz;
+            else m.push_back(b);
+        }
+        if (!m.empty() && m.back().off + m.back().sz == top) { top = m.back().off; m.pop_back(); }
+        free_.swap(m);
+    }
+};
+
+static std::vector<int64_t> clast_phys_dims(const std::vector<int64_t>& d) {  // [n,C,s...] -> [n,s...,C]
+    std::vector<int64_t> p;
+    p.push_back(d[0]);
+    for (size_t i = 2; i < d.size(); ++i) p.push_back(d[i]);
+    p.push_back(d[1]);
+    return p;
+}
+static std::vector<int64_t> contig_strides(const std::vector<int64_t>& d) {
+    std::vector<int64_t> s(d.size(), 1);
+    for (int i = (int)d.size() - 2; i >= 0; --i) s[i] = s[i + 1] * d[i + 1];
+    return s;
+}
+
+struct Planner {
+    Engine& E;
+    Plan& P;
+    std::map<std::string, TInfo> vals;
+    std::map<std::string, int> last_use;      // by root name
+    std::map<std::string, size_t> root_bytes; // arena-resident roots
+    std::map<std::string, size_t> root_off;
+    Arena arena;
+    int cur = 0;
+    std::vector<std::pair<size_t, size_t>> temps;  // freed after the current node
+
+    Planner(Engine& e, Plan& p) : E(e), P(p) { opset = e.opset_; }
+
+    // ------------------------------------------------------------------ values
+    TInfo& get(const std::string& name) {
+        auto it = vals.find(name);
+        if (it != vals.end()) return it->second;
+        auto ii = E.inits_.find(name);
+        OAR_CHECK(ii != E.inits_.end(), OAR_MODEL_LOAD, "graph references unknown value '" + name + "'");
+        TInfo t;
+        t.dims = ii->second.dims;
+        if (ii->second.dtype == DType::F32) {
+            t.ht = &ii->second;
+            t.loc.kind = Loc::CONST;
+            t.loc.cptr = E.upload_const("init:" + name, ii->second.f);
+        } else {
+            t.host_int = true;
+            t.hv = ii->second.i;
+        }
+        return vals[name] = t;
+    }
+    bool has_input(const GNode& n, size_t i) const { return i < n.in.size() && !n.in[i].empty(); }
+
+    Loc alloc_arena(size_t bytes, const std::string& root) {
+        Loc l;
+        l.kind = Loc::ARENA;
+        l.off = (int64_t)arena.alloc(bytes);
+        P.arena_bytes = std::max(P.arena_bytes, arena.top);
+        if (!root.empty()) { root_bytes[root] = bytes; root_off[root] = (size_t)l.off; }
+        return l;
+    }
+    Loc alloc_temp(size_t bytes) {
+        Loc l = alloc_arena(bytes, "");
+        temps.push_back({(size_t)l.off, bytes});
+        return l;
+    }
+    TInfo& new_out(const std::string& name, const std::vector<int64_t>& dims, Layout lay) {
+        TInfo t;
+        t.dims = dims; t.layout = lay; t.root = name;
+        t.loc = alloc_arena(t.bytes(), name);
+        return vals[name] = t;
+    }
+    TInfo& alias_out(const std::string& name, const TInfo& src, const std::vector<int64_t>& dims, Layout lay, int64_t byte_off = 0) {
+        TInfo t;
+        t.dims = dims; t.layout = lay; t.root = src.root; t.loc = src.loc; t.ht = nullptr;
+        if (t.loc.kind == Loc::CONST) t.loc.cptr = (const float*)((const char*)t.loc.cptr + byte_off);
+        else t.loc.off += byte_off;
+        return vals[name] = t;
+    }
+    void step(std::function<void(const RunCtx&)> f, double flops = 0, double bytes = 0) {
+        P.steps.push_back(std::move(f));
+        P.flops += flops; P.bytes += bytes; P.n_kernels++;
+    }
+
+    // ------------------------------------------------------------------ layout conversions
+    Loc to_clast_loc(const TInfo& t) {  // native [n,C,s..] -> channels-last copy in a temp
+        if (t.layout == Layout::CLAST) return t.loc;
+        OAR_CHECK(t.dims.size() >= 3 && t.dims.size() <= 5, OAR_UNSUPPORTED_OP, "channels-last conversion needs rank 3..5");
+        int r = (int)t.dims.size();
+        bool trivial = t.dims[1] == 1;
+        int64_t sp = 1;
+        for (int i = 2; i < r; ++i) sp *= t.dims[i];
+        if (trivial || sp == 1) return t.loc;
+        Loc tmp = alloc_temp(t.bytes());
+        std::vector<int64_t> od = clast_phys_dims(t.dims);
+        std::vector<int64_t> ns = contig_strides(t.dims), is(r);
+        is[0] = ns[0];
+        for (int i = 2; i < r; ++i) is[i - 1] = ns[i];
+        is[r - 1] = ns[1];
+        Loc src = t.loc;
+        step([=](const RunCtx& c) { k::permute(c.s, c.at(src), c.mut(tmp), r, od.data(), is.data()); }, 0, 2.0 * t.bytes());
+        return tmp;
+    }
+    Loc to_native_loc(const TInfo& t, Loc dst = Loc()) {
+        bool need = t.layout == Layout::CLAST;
+        int r = (int)t.dims.size();
+        if (need) {
+            int64_t sp = 1;
+            for (int i = 2; i < r; ++i) sp *= t.dims[i];
+            if (t.dims[1] == 1 || sp == 1) need = false;
+        }
+        if (!need) {
+            if (dst.kind == Loc::NONE) return t.loc;
+            Loc src = t.loc;
+            int64_t n = numel(t.dims);
+            step([=](const RunCtx& c) { k::copy2d(c.s, c.at(src), c.mut(dst), 1, (int)n, (int)n, (int)n); }, 0, 2.0 * t.bytes());
+            return dst;
+        }
+        if (dst.kind == Loc::NONE) dst = alloc_temp(t.bytes());
+        std::vector<int64_t> pd = clast_phys_dims(t.dims), ps = contig_strides(pd), is(r);
+        is[0] = ps[0];
+        is[1] = ps[r - 1];
+        for (int i = 2; i < r; ++i) is[i] = ps[i - 1];
+        std::vector<int64_t> od = t.dims;
+        Loc src = t.loc;
+        step([=](const RunCtx& c) { k::permute(c.s, c.at(src), c.mut(dst), r, od.data(), is.data()); }, 0, 2.0 * t.bytes());
+        return dst;
+    }
+
+    // ------------------------------------------------------------------ weights
+    const float* conv_weight_igemm(const GNode& n, const HostTensor& W) {
+        std::string key = "igemm:" + n.in[1];
+        auto it = E.dev_consts_.find(key);
+        if (it != E.dev_consts_.end()) return it->second;
+        int64_t Co = W.dims[0], Ci = W.dims[1], kh = W.dims[2], kw = W.dims[3];
+        int64_t K = kh * kw * Ci, Cp = (Co + 63) / 64 * 64;
+        std::vector<float> w((size_t)Cp * K, 0.f);
+        for (int64_t co = 0; co < Co; ++co)
+            for (int64_t ci = 0; ci < Ci; ++ci)
+                for (int64_t a = 0; a < kh; ++a)
+                    for (int64_t b = 0; b < kw; ++b)
+                        w[(size_t)co * K + (a * kw + b) * Ci + ci] = W.f[((co * Ci + ci) * kh + a) * kw + b];
+        return E.upload_const(key, w);
+    }
+    const float* conv_weight_dw(const GNode& n, const HostTensor& W) {
+        std::string key = "dw:" + n.in[1];
+        auto it = E.dev_consts_.find(key);
+        if (it != E.dev_consts_.end()) return it->second;
+        int64_t C = W.dims[0], kh = W.dims[2], kw = W.dims[3];
+        std::vector<float> w((size_t)C * kh * kw);
+        for (int64_t c = 0; c < C; ++c)
+            for (int64_t a = 0; a < kh; ++a)
+                for (int64_t b = 0; b < kw; ++b) w[(size_t)(a * kw + b) * C + c] = W.f[(c * kh + a) * kw + b];
+        return E.upload_const(key, w);
+    }
+    const float* conv_weight_direct(const GNode& n, const HostTensor& W) {
+        std::string key = "direct:" + n.in[1];
+        auto it = E.dev_consts_.find(key);
+        if (it != E.dev_consts_.end()) return it->second;
+        int64_t Co = W.dims[0], cpg = W.dims[1], kh = W.dims[2], kw = W.dims[3];
+        std::vector<float> w((size_t)Co * cpg * kh * kw);
+        for (int64_t co = 0; co < Co; ++co)
+            for (int64_t ci = 0; ci < cpg; ++ci)
+                for (int64_t a = 0; a < kh; ++a)
+                    for (int64_t b = 0; b < kw; ++b)
+                        w[(size_t)(((a * kw + b) * cpg + ci) * Co + co)] = W.f[((co * cpg + ci) * kh + a) * kw + b];
+        return E.upload_const(key, w);
+    }
+    const float* convt_weight(const GNode& n, const HostTensor& W, bool igemm) {
+        std::string key = (igemm ? "convt_ig:" : "convt_dir:") + n.in[1];
+        auto it = E.dev_consts_.find(key);
+        if (it != E.dev_consts_.end()) return it->second;
+        int64_t Ci = W.dims[0], Co = W.dims[1], kh = W.dims[2], kw = W.dims[3];
+        std::vector<float> w;
+        if (igemm) {
+            int64_t rows = (kh * kw * Co + 63) / 64 * 64;
+            w.assign((size_t)rows * Ci, 0.f);
+            for (int64_t ci = 0; ci < Ci; ++ci)
+                for (int64_t co = 0; co < Co; ++co)
+                    for (int64_t a = 0; a < kh; ++a)
+                        for (int64_t b = 0; b < kw; ++b)
+                            w[(size_t)((a * kw + b) * Co + co) * Ci + ci] = W.f[((ci * Co + co) * kh + a) * kw + b];
+        } else {
+            w.assign((size_t)kh * kw * Ci * Co, 0.f);
+            for (int64_t ci = 0; ci < Ci; ++ci)
+                for (int64_t co = 0; co < Co; ++co)
+                    for (int64_t a = 0; a < kh; ++a)
+                        for (int64_t b = 0; b < kw; ++b)
+                            w[(size_t)(((a * kw + b) * Ci + ci) * Co + co)] = W.f[((ci * Co + co) * kh + a) * kw + b];
+        }
+        return E.upload_const(key, w);
+    }
+    const float* linear_weight(const std::string& name, const HostTensor& B, bool transB) {  // -> [N_pad64][K]
+        std::string key = std::string("lin:") + (transB ? "t:" : "") + name;
+        auto it = E.dev_consts_.find(key);
+        if (it != E.dev_consts_.end()) return it->second;
+        int64_t K = transB ? B.dims[1] : B.dims[0], N = transB ? B.dims[0] : B.dims[1];
+        int64_t Np = (N + 63) / 64 * 64;
+        std::vector<float> w((size_t)Np * K, 0.f);
+        for (int64_t kk = 0; kk < K; ++kk)
+            for (int64_t nn = 0; nn < N; ++nn) w[(size_t)nn * K + kk] = transB ? B.f[nn * K + kk] : B.f[kk * N + nn];
+        return E.upload_const(key, w);
+    }
+
+    // ------------------------------------------------------------------ ops
+    void get_pads(const GNode& n, int64_t H, int64_t W, int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t dh, int64_t dw,
+                  int64_t& pt, int64_t& pl, int64_t& pb, int64_t& pr) {
+        std::vector<int64_t> pads = n.ais("pads");
+        pt = pl = pb = pr = 0;
+        if (pads.size() == 4) { pt = pads[0]; pl = pads[1]; pb = pads[2]; pr = pads[3]; }
+        std::string ap = n.as("auto_pad", "NOTSET");
+        if (ap == "SAME_UPPER" || ap == "SAME_LOWER") {
+            int64_t oh = (H + sh - 1) / sh, ow = (W + sw - 1) / sw;
+            int64_t th = std::max<int64_t>((oh - 1) * sh + (kh - 1) * dh + 1 - H, 0), tw = std::max<int64_t>((ow - 1) * sw + (kw - 1) * dw + 1 - W, 0);
+            if (ap == "SAME_UPPER") { pt = th / 2; pb = th - pt; pl = tw / 2; pr = tw - pl; }
+            else { pb = th / 2; pt = th - pb; pr = tw / 2; pl = tw - pr; }
+        }
+    }
+
+    void op_conv(const GNode& n) {
+        TInfo x = get(n.in[0]);
+        OAR_CHECK(x.dims.size() == 4, OAR_UNSUPPORTED_OP, "Conv: only 2-D convolutions are supported");
+        const TInfo& wt = get(n.in[1]);
+        OAR_CHECK(wt.ht, OAR_UNSUPPORTED_OP, "Conv: weights must be an initializer");
+        const HostTensor& W = *wt.ht;
+        int64_t N = x.dims[0], Cin = x.dims[1], H = x.dims[2], Wd = x.dims[3];
+        int64_t Cout = W.dims[0], kh = W.dims[2], kw = W.dims[3], g = n.ai("group", 1);
+        OAR_CHECK(W.dims[1] * g == Cin, OAR_SHAPE_MISMATCH, "Conv: weight/input channel mismatch at " + n.out[0]);
+        auto st = n.ais("strides"), dl = n.ais("dilations");
+        int64_t sh = st.size() == 2 ? st[0] : 1, sw = st.size() == 2 ? st[1] : 1;
+        int64_t dh = dl.size() == 2 ? dl[0] : 1, dw = dl.size() == 2 ? dl[1] : 1;
+        int64_t pt, pl, pb, pr;
+        get_pads(n, H, Wd, kh, kw, sh, sw, dh, dw, pt, pl, pb, pr);
+        int64_t Ho = (H + pt + pb - dh * (kh - 1) - 1) / sh + 1, Wo = (Wd + pl + pr - dw * (kw - 1) - 1) / sw + 1;
+        Loc xin = to_clast_loc(x);
+        const float* bias = has_input(n, 2) ? get(n.in[2]).loc.cptr : nullptr;
+        Loc res;
+        if (!n.residual.empty()) { TInfo r = get(n.residual); res = to_clast_loc(r); }
+        TInfo& y = new_out(n.out[0], {N, Cout, Ho, Wo}, Layout::CLAST);
+        k::ConvP p{};
+        p.N = (int)N; p.H = (int)H; p.W = (int)Wd; p.Cin = (int)Cin; p.Ho = (int)Ho; p.Wo = (int)Wo; p.Cout = (int)Cout;
+        p.kh = (int)kh; p.kw = (int)kw; p.sh = (int)sh; p.sw = (int)sw; p.pt = (int)pt; p.pl = (int)pl; p.dh = (int)dh; p.dw = (int)dw;
+        p.groups = (int)g; p.act = n.act; p.bias = bias; p.y_ld = (int)Cout; p.convt2x2 = 0;
+        int kind;  // 0 igemm, 1 dw, 2 direct
+        if (g == 1 && Cin % 4 == 0) { kind = 0; p.w = conv_weight_igemm(n, W); }
+        else if (g == Cin && g == Cout && Cout % 4 == 0) { kind = 1; p.w = conv_weight_dw(n, W); }
+        else { kind = 2; p.w = conv_weight_direct(n, W); }
+        Loc yl = y.loc;
+        bool has_res = res.kind != Loc::NONE;
+        double flops = 2.0 * N * Ho * Wo * Cout * (Cin / g) * kh * kw;
+        double bytes = 4.0 * (N * H * Wd * Cin + N * Ho * Wo * Cout * (has_res ? 2 : 1) + numel(W.dims));
+        step([=](const RunCtx& c) {
+            k::ConvP q = p;
+            q.x = c.at(xin); q.y = c.mut(yl); q.residual = has_res ? c.at(res) : nullptr;
+            if (kind == 0) k::conv_igemm(c.s, q);
+            else if (kind == 1) k::conv_dw(c.s, q);
+            else k::conv_direct(c.s, q);
+        }, flops, bytes);
+    }
+
+    void op_convt(const GNode& n) {
+        TInfo x = get(n.in[0]);
+        OAR_CHECK(x.dims.size() == 4, OAR_UNSUPPORTED_OP, "ConvTranspose: only 2-D");
+        const TInfo& wt = get(n.in[1]);
+        OAR_CHECK(wt.ht, OAR_UNSUPPORTED_OP, "ConvTranspose: weights must be an initializer");
+        const HostTensor& W = *wt.ht;
+        OAR_CHECK(n.ai("group", 1) == 1, OAR_UNSUPPORTED_OP, "ConvTranspose: group != 1");
+        int64_t N = x.dims[0], Cin = x.dims[1], H = x.dims[2], Wd = x.dims[3];
+        int64_t Cout = W.dims[1], kh = W.dims[2], kw = W.dims[3];
+        auto st = n.ais("strides"), dl = n.ais("dilations"), pads = n.ais("pads"), op = n.ais("output_padding");
+        int64_t sh = st.size() == 2 ? st[0] : 1, sw = st.size() == 2 ? st[1] : 1;
+        int64_t dh = dl.size() == 2 ? dl[0] : 1, dw = dl.size() == 2 ? dl[1] : 1;
+        int64_t pt = pads.size() == 4 ? pads[0] : 0, pl = pads.size() == 4 ? pads[1] : 0, pb = pads.size() == 4 ? pads[2] : 0, pr = pads.size() == 4 ? pads[3] : 0;
+        int64_t oph = op.size() == 2 ? op[0] : 0, opw = op.size() == 2 ? op[1] : 0;
+        int64_t Ho = (H - 1) * sh - pt - pb + dh * (kh - 1) + oph + 1, Wo = (Wd - 1) * sw - pl - pr + dw * (kw - 1) + opw + 1;
+        Loc xin = to_clast_loc(x);
+        const float* bias = has_input(n, 2) ? get(n.in[2]).loc.cptr : nullptr;
+        TInfo& y = new_out(n.out[0], {N, Cout, Ho, Wo}, Layout::CLAST);
+        bool fast = kh == 2 && kw == 2 && sh == 2 && sw == 2 && pt == 0 && pl == 0 && pb == 0 && pr == 0 && oph == 0 && opw == 0 && Cin % 4 == 0 && dh == 1 && dw == 1;
+        k::ConvP p{};
+        p.N = (int)N; p.H = (int)H; p.W = (int)Wd; p.Cin = (int)Cin; p.Ho = (int)Ho; p.Wo = (int)Wo; p.Cout = (int)Cout;
+        p.kh = (int)kh; p.kw = (int)kw; p.sh = (int)sh; p.sw = (int)sw; p.pt = (int)pt; p.pl = (int)pl; p.dh = (int)dh; p.dw = (int)dw;
+        p.groups = 1; p.act = n.act; p.bias = bias; p.y_ld = (int)Cout; p.convt2x2 = fast ? 1 : 0;
+        p.w = convt_weight(n, W, fast);
+        Loc yl = y.loc;
+        double flops = 2.0 * N * H * Wd * Cin * Cout * kh * kw;
+        double bytes = 4.0 * (N * H * Wd * Cin + N * Ho * Wo * Cout + numel(W.dims));
+        step([=](const RunCtx& c) {
+            k::ConvP q = p;
+            q.x = c.at(xin); q.y = c.mut(yl);
+            if (fast) k::conv_igemm(c.s, q); else k::convt_direct(c.s, q);
+        }, flops, bytes);
+    }
+
+    void op_bn(const GNode& n) {  // leftover BN: per-channel affine as a 1x1 depthwise conv
+        TInfo x = get(n.in[0]);
+        OAR_CHECK(x.dims.size() == 4, OAR_UNSUPPORTED_OP, "BatchNormalization: rank-4 only");
+        const auto &ga = get(n.in[1]), &be = get(n.in[2]), &mu = get(n.in[3]), &va = get(n.in[4]);
+        OAR_CHECK(ga.ht && be.ht && mu.ht && va.ht, OAR_UNSUPPORTED_OP, "BatchNormalization: params must be initializers");
+        int64_t C = x.dims[1];
+        float eps = n.af("epsilon", 1e-5f);
+        std::vector<float> sc(C), sh(C);
+        for (int64_t c = 0; c < C; ++c) { sc[c] = ga.ht->f[c] / std::sqrt(va.ht->f[c] + eps); sh[c] = be.ht->f[c] - mu.ht->f[c] * sc[c]; }
+        const float* dsc = E.upload_const("bn_sc:" + n.out[0], sc);
+        const float* dsh = E.upload_const("bn_sh:" + n.out[0], sh);
+        Loc xin = to_clast_loc(x);
+        TInfo& y = new_out(n.out[0], x.dims, Layout::CLAST);
+        k::ConvP p{};
+        p.N = (int)x.dims[0]; p.H = p.Ho = (int)x.dims[2]; p.W = p.Wo = (int)x.dims[3]; p.Cin = p.Cout = (int)C;
+        p.kh = p.kw = p.sh = p.sw = p.dh = p.dw = 1; p.groups = (int)C; p.act = n.act; p.w = dsc; p.bias = dsh; p.y_ld = (int)C;
+        Loc yl = y.loc;
+        bool dwok = C % 4 == 0;
+        step([=](const RunCtx& c) {
+            k::ConvP q = p; q.x = c.at(xin); q.y = c.mut(yl);
+            if (dwok) k::conv_dw(c.s, q); else k::conv_direct(c.s, q);
+        }, 0, 8.0 * numel(x.dims));
+    }
+
+    void op_unary(const GNode& n, Act a) {
+        TInfo x = get(n.in[0]);
+        TInfo& y = new_out(n.out[0], x.dims, x.layout);
+        Loc xl = x.loc, yl = y.loc;
+        int64_t cnt = numel(x.dims);
+        step([=](const RunCtx& c) { k::unary(c.s, c.at(xl), c.mut(yl), cnt, a); }, 0, 8.0 * cnt);
+    }
+
+    // host permutation of a constant to channels-last physical order
+    const float* const_clast(const std::string& name, const HostTensor& t, const std::vector<int64_t>& dims_aligned) {
+        std::string key = "clast:" + name + ":" + std::to_string(dims_aligned.size());
+        auto it = E.dev_consts_.find(key);
+        if (it != E.dev_consts_.end()) return it->second;
+        int r = (int)dims_aligned.size();
+        std::vector<int64_t> pd = clast_phys_dims(dims_aligned), ns = contig_strides(dims_aligned), is(r);
+        is[0] = ns[0];
+        for (int i = 2; i < r; ++i) is[i - 1] = ns[i];
+        is[r - 1] = ns[1];
+        int64_t total = numel(pd);
+        std::vector<float> out((size_t)total);
+        std::vector<int64_t> idx(r, 0);
+        for (int64_t i = 0; i < total; ++i) {
+            int64_t rem = i, off = 0;
+            for (int d = r - 1; d >= 0; --d) { int64_t q = rem / pd[d]; off += (rem - q * pd[d]) * is[d]; rem = q; }
+            out[i] = t.f[off];
+        }
+        return E.upload_const(key, out);
+    }
+
+    void op_binary(const GNode& n, int op) {
+        TInfo a = get(n.in[0]), b = get(n.in[1]);
+        OAR_CHECK(!a.host_int && !b.host_int, OAR_UNSUPPORTED_OP, "binary op on integer tensors reached the device path");
+        int r = (int)std::max(a.dims.size(), b.dims.size());
+        auto align = [&](const std::vector<int64_t>& d) { std::vector<int64_t> o(r - d.size(), 1); o.insert(o.end(), d.begin(), d.end()); return o; };
+        std::vector<int64_t> ad = align(a.dims), bd = align(b.dims), od(r);
+        for (int i = 0; i < r; ++i) {
+            OAR_CHECK(ad[i] == bd[i] || ad[i] == 1 || bd[i] == 1, OAR_SHAPE_MISMATCH, "binary: shapes do not broadcast at " + n.out[0]);
+            od[i] = std::max(ad[i], bd[i]);
+        }
+        bool clast = (a.layout == Layout::CLAST && (int)a.dims.size() == r) || (b.layout == Layout::CLAST && (int)b.dims.size() == r);
+        Loc al = a.loc, bl = b.loc;
+        std::vector<int64_t> pad, pbd, pod;  // physical dims
+        if (clast) {
+            auto fix = [&](TInfo& t, const std::vector<int64_t>& d, const std::string& nm, Loc& l) {
+                if (t.layout == Layout::CLAST && (int)t.dims.size() == r) return;
+                // count non-1 dims: with <= 1 the memory order is unaffected by the permutation
+                int non1 = 0;
+                for (auto v : d) if (v != 1) ++non1;
+                if (non1 <= 1) return;
+                if (t.ht) { l.kind = Loc::CONST; l.cptr = const_clast(nm, *t.ht, d); return; }
+                TInfo tmp = t; tmp.dims = d; tmp.layout = Layout::NATIVE;
+                l = to_clast_loc(tmp);
+            };
+            fix(a, ad, n.in[0], al);
+            fix(b, bd, n.in[1], bl);
+            pad = clast_phys_dims(ad); pbd = clast_phys_dims(bd); pod = clast_phys_dims(od);
+        } else {
+            if (a.layout == Layout::CLAST) { al = to_native_loc(a); }
+            if (b.layout == Layout::CLAST) { bl = to_native_loc(b); }
+            pad = ad; pbd = bd; pod = od;
+        }
+        auto bstr = [&](const std::vector<int64_t>& d) {
+            std::vector<int64_t> s = contig_strides(d);
+            for (size_t i = 0; i < d.size(); ++i) if (d[i] == 1) s[i] = 0;
+            return s;
+        };
+        std::vector<int64_t> sa = bstr(pad), sb = bstr(pbd);
+        // commutative ops: put the full-size operand first (fast paths key on `a`)
+        bool commut = op == 0 || op == 2;
+        if (commut && numel(pad) < numel(pbd)) { std::swap(al, bl); std::swap(sa, sb); }
+        TInfo& y = new_out(n.out[0], od, clast ? Layout::CLAST : Layout::NATIVE);
+        Loc yl = y.loc;
+        Act post = n.act;
+        int64_t cnt = numel(od);
+        step([=](const RunCtx& c) { k::binary(c.s, c.at(al), c.at(bl), c.mut(yl), op, r, pod.data(), sa.data(), sb.data(), post); }, (double)cnt, 12.0 * cnt);
+    }
+
+    void op_gap(const GNode& n) {
+        TInfo x = get(n.in[0]);
+        OAR_CHECK(x.dims.size() == 4, OAR_UNSUPPORTED_OP, "GlobalAveragePool: rank-4 only");
+        Loc xin = to_clast_loc(x);
+        int64_t N = x.dims[0], C = x.dims[1], HW = x.dims[2] * x.dims[3];
+        TInfo& y = new_out(n.out[0], {N, C, 1, 1}, Layout::CLAST);
+        Loc yl = y.loc;
+        step([=](const RunCtx& c) { k::global_avgpool(c.s, c.at(xin), c.mut(yl), (int)N, (int)HW, (int)C); }, 0, 4.0 * numel(x.dims));
+    }
+
+    void op_pool(const GNode& n, bool is_max) {
+        TInfo x = get(n.in[0]);
+        OAR_CHECK(x.dims.size() == 4, OAR_UNSUPPORTED_OP, "Pool: rank-4 only");
+        auto ks = n.ais("kernel_shape"), st = n.ais("strides");
+        OAR_CHECK(ks.size() == 2, OAR_UNSUPPORTED_OP, "Pool: kernel_shape");
+        int64_t kh = ks[0], kw = ks[1], sh = st.size() == 2 ? st[0] : 1, sw = st.size() == 2 ? st[1] : 1;
+        int64_t pt, pl, pb, pr;
+        get_pads(n, x.dims[2], x.dims[3], kh, kw, sh, sw, 1, 1, pt, pl, pb, pr);
+        bool ceil_mode = n.ai("ceil_mode", 0) != 0;
+        auto od = [&](int64_t in, int64_t k_, int64_t s_, int64_t p0, int64_t p1) {
+            int64_t t = in + p0 + p1 - k_;
+            int64_t o = (ceil_mode ? (t + s_ - 1) / s_ : t / s_) + 1;
+            if (ceil_mode && (o - 1) * s_ >= in + p0) --o;
+            return o;
+        };
+        int64_t Ho = od(x.dims[2], kh, sh, pt, pb), Wo = od(x.dims[3], kw, sw, pl, pr);
+        Loc xin = to_clast_loc(x);
+        TInfo& y = new_out(n.out[0], {x.dims[0], x.dims[1], Ho, Wo}, Layout::CLAST);
+        k::PoolP p{};
+        p.N = (int)x.dims[0]; p.H = (int)x.dims[2]; p.W = (int)x.dims[3]; p.C = (int)x.dims[1]; p.Ho = (int)Ho; p.Wo = (int)Wo;
+        p.kh = (int)kh; p.kw = (int)kw; p.sh = (int)sh; p.sw = (int)sw; p.pt = (int)pt; p.pl = (int)pl;
+        p.is_max = is_max; p.count_include_pad = (int)n.ai("count_include_pad", 0);
+        Loc yl = y.loc;
+        step([=](const RunCtx& c) { k::PoolP q = p; q.x = c.at(xin); q.y = c.mut(yl); k::pool2d(c.s, q); }, 0, 4.0 * (numel(x.dims) + numel(y.dims)));
+    }
+
+    void op_resize(const GNode& n) {
+        TInfo x = get(n.in[0]);
+        OAR_CHECK(x.dims.size() == 4, OAR_UNSUPPORTED_OP, "Resize: rank-4 only");
+        int64_t H = x.dims[2], W = x.dims[3], Ho, Wo;
+        float sh, sw;
+        if (has_input(n, 3)) {
+            const TInfo& sz = get(n.in[3]);
+            OAR_CHECK(sz.host_int && sz.hv.size() == 4, OAR_UNSUPPORTED_OP, "Resize: sizes must be a host int tensor");
+            Ho = sz.hv[2]; Wo = sz.hv[3]; sh = (float)Ho / (float)H; sw = (float)Wo / (float)W;
+        } else {
+            OAR_CHECK(has_input(n, 2), OAR_UNSUPPORTED_OP, "Resize: neither scales nor sizes");
+            const TInfo& sc = get(n.in[2]);
+            OAR_CHECK(sc.ht && sc.ht->f.size() == 4, OAR_UNSUPPORTED_OP, "Resize: scales must be a constant of 4 floats");
+            sh = sc.ht->f[2]; sw = sc.ht->f[3];
+            Ho = (int64_t)std::floor((float)H * sh); Wo = (int64_t)std::floor((float)W * sw);
+        }
+        std::string mode = n.as("mode", "nearest"), ctm = n.as("coordinate_transformation_mode", "half_pixel"), nm = n.as("nearest_mode", "round_prefer_floor");
+        int imode = mode == "nearest" ? 0 : 1;
+        OAR_CHECK(mode == "nearest" || mode == "linear", OAR_UNSUPPORTED_OP, "Resize: mode " + mode);
+        int ictm = ctm == "asymmetric" ? 0 : ctm == "half_pixel" ? 1 : ctm == "align_corners" ? 2 : ctm == "pytorch_half_pixel" ? 3 : -1;
+        OAR_CHECK(ictm >= 0, OAR_UNSUPPORTED_OP, "Resize: coordinate_transformation_mode " + ctm);
+        int inm = nm == "floor" ? 0 : nm == "round_prefer_floor" ? 1 : nm == "round_prefer_ceil" ? 2 : 3;
+        Loc xin = to_clast_loc(x);
+        TInfo& y = new_out(n.out[0], {x.dims[0], x.dims[1], Ho, Wo}, Layout::CLAST);
+        Loc yl = y.loc;
+        int N = (int)x.dims[0], C = (int)x.dims[1];
+        step([=](const RunCtx& c) { k::resize(c.s, c.at(xin), c.mut(yl), N, (int)H, (int)W, C, (int)Ho, (int)Wo, sh, sw, imode, ictm, inm, C); }, 0,
+             4.0 * (numel(x.dims) + numel(y.dims)));
+    }
+
+    void op_concat(const GNode& n) {
+        std::vector<TInfo> xs;
+        for (auto& s : n.in) xs.push_back(get(s));
+        bool all_host = true;
+        for (auto& t : xs) all_host = all_host && t.host_int;
+        if (all_host) {
+            TInfo o; o.host_int = true;
+            for (auto& t : xs) o.hv.insert(o.hv.end(), t.hv.begin(), t.hv.end());
+            o.dims = {(int64_t)o.hv.size()};
+            vals[n.out[0]] = o;
+            return;
+        }
+        int r = (int)xs[0].dims.size();
+        int64_t axis = n.ai("axis", 0);
+        if (axis < 0) axis += r;
+        bool clast = false;
+        for (auto& t : xs) clast = clast || (t.layout == Layout::CLAST);
+        std::vector<int64_t> od = xs[0].dims;
+        od[axis] = 0;
+        for (auto& t : xs) od[axis] += t.dims[axis];
+        if (clast && r >= 3) {
+            // physical axis of the logical axis
+            int pax = axis == 0 ? 0 : (axis == 1 ? r - 1 : (int)axis - 1);
+            std::vector<int64_t> pod = clast_phys_dims(od);
+            int64_t outer = 1, inner = 1;
+            for (int i = 0; i < pax; ++i) outer *= pod[i];
+            for (int i = pax + 1; i < r; ++i) inner *= pod[i];
+            std::vector<Loc> ins;
+            for (auto& t : xs) ins.push_back(to_clast_loc(t));
+            TInfo& y = new_out(n.out[0], od, Layout::CLAST);
+            Loc yl = y.loc;
+            int64_t coff = 0, total = pod[pax] * inner;
+            for (size_t i = 0; i < xs.size(); ++i) {
+                int64_t w = xs[i].dims[axis] * inner;
+                Loc il = ins[i];
+                int64_t off = coff;
+                step([=](const RunCtx& c) { k::copy2d(c.s, c.at(il), c.mut(yl) + off, outer, (int)w, (int)w, (int)total); }, 0, 8.0 * outer * w);
+                coff += w;
+            }
+            return;
+        }
+        int64_t outer = 1, inner = 1;
+        for (int i = 0; i < axis; ++i) outer *= od[i];
+        for (int i = (int)axis + 1; i < r; ++i) inner *= od[i];
+        std::vector<Loc> ins;
+        for (auto& t : xs) ins.push_back(to_native_loc(t));
+        TInfo& y = new_out(n.out[0], od, Layout::NATIVE);
+        Loc yl = y.loc;
+        int64_t coff = 0, total = od[axis] * inner;
+        for (size_t i = 0; i < xs.size(); ++i) {
+            int64_t w = xs[i].dims[axis] * inner;
+            Loc il = ins[i];
+            int64_t off = coff;
+            step([=](const RunCtx& c) { k::copy2d(c.s, c.at(il), c.mut(yl) + off, outer, (int)w, (int)w, (int)total); }, 0, 8.0 * outer * w);
+            coff += w;
+        }
+    }
+
+    // Reshape-like ops produce views of the native buffer.
+    void view_native(const GNode& n, const TInfo& x, const std::vector<int64_t>& od) {
+        OAR_CHECK(numel(od) == numel(x.dims), OAR_SHAPE_MISMATCH, "reshape: element count mismatch at " + n.out[0]);
+        if (x.layout == Layout::CLAST) {
+            int r = (int)x.dims.size();
+            int64_t sp = 1;
+            for (int i = 2; i < r; ++i) sp *= x.dims[i];
+            if (x.dims[1] != 1 && sp != 1) {  // genuine transpose needed
+                TInfo& y = new_out(n.out[0], od, Layout::NATIVE);
+                to_native_loc(x, y.loc);
+                return;
+            }
+        }
+        alias_out(n.out[0], x, od, Layout::NATIVE);
+    }
+
+    void op_reshape(const GNode& n) {
+        TInfo x = get(n.in[0]);
+        const TInfo& sh = get(n.in[1]);
+        OAR_CHECK(sh.host_int, OAR_UNSUPPORTED_OP, "Reshape: shape must be known on the host");
+        if (x.host_int) { TInfo o = x; o.dims.assign(sh.hv.begin(), sh.hv.end()); vals[n.out[0]] = o; return; }
+        std::vector<int64_t> od(sh.hv.size());
+        int64_t known = 1; int infer = -1;
+        for (size_t i = 0; i < od.size(); ++i) {
+            int64_t v = sh.hv[i];
+            if (v == 0 && n.ai("allowzero", 0) == 0) v = x.dims[i];
+            if (v == -1) { infer = (int)i; v = 1; }
+            od[i] = v; known *= v;
+        }
+        if (infer >= 0) od[infer] = numel(x.dims) / std::max<int64_t>(known, 1);
+        view_native(n, x, od);
+    }
+
+    void op_flatten(const GNode& n) {
+        TInfo x = get(n.in[0]);
+        int64_t ax = n.ai("axis", 1);
+        if (ax < 0) ax += (int64_t)x.dims.size();
+        int64_t a = 1, b = 1;
+        for (int i = 0; i < (int)x.dims.size(); ++i) (i < ax ? a : b) *= x.dims[i];
+        view_native(n, x, {a, b});
+    }
+
+    std::vector<int64_t> axes_of(const GNode& n, size_t input_idx) {
+        if (has_input(n, input_idx)) { const TInfo& a = get(n.in[input_idx]); OAR_CHECK(a.host_int, OAR_UNSUPPORTED_OP, "axes must be host ints"); return a.hv; }
+        return n.ais("axes");
+    }
+
+    void op_squeeze(const GNode& n) {
+        TInfo x = get(n.in[0]);
+        std::vector<int64_t> axes = axes_of(n, 1);
+        int r = (int)x.dims.size();
+        std::set<int> ax;
+        if (axes.empty()) { for (int i = 0; i < r; ++i) if (x.dims[i] == 1) ax.insert(i); }
+        for (auto a : axes) ax.insert((int)(a < 0 ? a + r : a));
+        std::vector<int64_t> od;
+        for (int i = 0; i < r; ++i) if (!ax.count(i)) od.push_back(x.dims[i]);
+        if (x.host_int) { TInfo o = x; o.dims = od; vals[n.out[0]] = o; return; }
+        // channels-last stays channels-last when only spatial axes are removed and rank stays >= 3
+        if (x.layout == Layout::CLAST && !ax.count(0) && !ax.count(1) && od.size() >= 3) { alias_out(n.out[0], x, od, Layout::CLAST); return; }
+        view_native(n, x, od);
+    }
+
+    void op_unsqueeze(const GNode& n) {
+        TInfo x = get(n.in[0]);
+        std::vector<int64_t> axes = axes_of(n, 1);
+        int r = (int)x.dims.size() + (int)axes.size();
+        std::set<int> ax;
+        for (auto a : axes) ax.insert((int)(a < 0 ? a + r : a));
+        std::vector<int64_t> od;
+        size_t j = 0;
+        for (int i = 0; i < r; ++i) od.push_back(ax.count(i) ? 1 : x.dims[j++]);
+        if (x.host_int) { TInfo o = x; o.dims = od; vals[n.out[0]] = o; return; }
+        if (x.layout == Layout::CLAST && !ax.count(0) && !ax.count(1) && r <= 5) { alias_out(n.out[0], x, od, Layout::CLAST); return; }
+        view_native(n, x, od);
+    }
+
+    void op_transpose(const GNode& n) {
+        TInfo x = get(n.in[0]);
+        int r = (int)x.dims.size();
+        std::vector<int64_t> perm = n.ais("perm");
+        if (perm.empty()) for (int i = r - 1; i >= 0; --i) perm.push_back(i);
+        std::vector<int64_t> od(r);
+        for (int i = 0; i < r; ++i) od[i] = x.dims[perm[i]];
+        // lazy channels-last moves: [n,C,s..] <-> [n,s..,C]
+        bool to_last = r >= 3 && perm[0] == 0 && perm[r - 1] == 1;
+        if (to_last) for (int i = 1; i < r - 1; ++i) to_last = to_last && perm[i] == i + 1;
+        bool from_last = r >= 3 && perm[0] == 0 && perm[1] == r - 1;
+        if (from_last) for (int i = 2; i < r; ++i) from_last = from_last && perm[i] == i - 1;
+        if (x.layout == Layout::CLAST && to_last) { alias_out(n.out[0], x, od, Layout::NATIVE); return; }
+        if (x.layout == Layout::NATIVE && from_last && r <= 5 && !x.ht) { alias_out(n.out[0], x, od, Layout::CLAST); return; }
+        Loc xin = to_native_loc(x);
+        std::vector<int64_t> ns = contig_strides(x.dims), is(r);
+        for (int i = 0; i < r; ++i) is[i] = ns[perm[i]];
+        TInfo& y = new_out(n.out[0], od, Layout::NATIVE);
+        Loc yl = y.loc;
+        step([=](const RunCtx& c) { k::permute(c.s, c.at(xin), c.mut(yl), r, od.data(), is.data()); }, 0, 8.0 * numel(od));
+    }
+
+    // strided sub-tensor copy (or alias when the slice is a contiguous prefix-dim block)
+    void slice_out(const std::string& out, const TInfo& x, Loc xin, int axis, int64_t start, int64_t len) {
+        std::vector<int64_t> od = x.dims;
+        od[axis] = len;
+        std::vector<int64_t> ns = contig_strides(x.dims);
+        bool outer_all_one = true;
+        for (int i = 0; i < axis; ++i) outer_all_one = outer_all_one && x.dims[i] == 1;
+        if (outer_all_one) {
+            TInfo tmp = x; tmp.loc = xin; tmp.layout = Layout::NATIVE;
+            if (xin.kind != x.loc.kind || xin.off != x.loc.off) tmp.root = "";  // temp buffers cannot be aliased safely
+            if (!tmp.root.empty() || xin.kind == Loc::CONST) { alias_out(out, tmp, od, Layout::NATIVE, start * ns[axis] * 4); return; }
+        }
+        TInfo& y = new_out(out, od, Layout::NATIVE);
+        Loc yl = y.loc;
+        int r = (int)od.size();
+        int64_t off = start * ns[axis];
+        step([=](const RunCtx& c) { k::permute(c.s, c.at(xin) + off, c.mut(yl), r, od.data(), ns.data()); }, 0, 8.0 * numel(od));
+    }
+
+    void op_split(const GNode& n) {
+        TInfo x = get(n.in[0]);
+        int r = (int)x.dims.size();
+        int64_t axis = n.ai("axis", 0);
+        if (axis < 0) axis += r;
+        std::vector<int64_t> parts;
+        if (has_input(n, 1)) parts = get(n.in[1]).hv;
+        else if (n.has("split")) parts = n.ais("split");
+        else parts.assign(n.out.size(), x.dims[axis] / (int64_t)n.out.size());
+        Loc xin = to_native_loc(x);
+        int64_t start = 0;
+        for (size_t i = 0; i < n.out.size(); ++i) { slice_out(n.out[i], x, xin, (int)axis, start, parts[i]); start += parts[i]; }
+    }
+
+    void op_slice(const GNode& n) {
+        TInfo x = get(n.in[0]);
+        std::vector<int64_t> starts = get(n.in[1]).hv, ends = get(n.in[2]).hv, axes, steps;
+        if (has_input(n, 3)) axes = get(n.in[3]).hv; else for (size_t i = 0; i < starts.size(); ++i) axes.push_back((int64_t)i);
+        if (has_input(n, 4)) steps = get(n.in[4]).hv; else steps.assign(starts.size(), 1);
+        int r = (int)x.dims.size();
+        if (x.host_int) {
+            OAR_CHECK(r == 1 && axes.size() == 1 && steps[0] == 1, OAR_UNSUPPORTED_OP, "Slice: host tensors support 1-D unit-step only");
+            int64_t d = x.dims[0], s = starts[0] < 0 ? starts[0] + d : starts[0], e = ends[0] < 0 ? ends[0] + d : ends[0];
+            s = std::min(std::max<int64_t>(s, 0), d); e = std::min(std::max<int64_t>(e, 0), d);
+            TInfo o; o.host_int = true; o.hv.assign(x.hv.begin() + s, x.hv.begin() + std::max(s, e)); o.dims = {(int64_t)o.hv.size()};
+            vals[n.out[0]] = o; return;
+        }
+        OAR_CHECK(axes.size() == 1 && steps[0] == 1, OAR_UNSUPPORTED_OP, "Slice: single axis, unit step only");
+        int64_t ax = axes[0] < 0 ? axes[0] + r : axes[0], d = x.dims[ax];
+        int64_t s = starts[0] < 0 ? starts[0] + d : starts[0], e = ends[0] < 0 ? ends[0] + d : ends[0];
+        s = std::min(std::max<int64_t>(s, 0), d); e = std::min(std::max<int64_t>(e, 0), d);
+        Loc xin = to_native_loc(x);
+        slice_out(n.out[0], x, xin, (int)ax, s, std::max<int64_t>(e - s, 0));
+    }
+
+    void op_gather(const GNode& n) {
+        TInfo x = get(n.in[0]);
+        const TInfo& idx = get(n.in[1]);
+        OAR_CHECK(idx.host_int, OAR_UNSUPPORTED_OP, "Gather: indices must be host ints");
+        int64_t axis = n.ai("axis", 0);
+        if (x.host_int) {
+            OAR_CHECK(x.dims.size() <= 1, OAR_UNSUPPORTED_OP, "Gather: host data rank > 1");
+            TInfo o; o.host_int = true;
+            for (auto i : idx.hv) o.hv.push_back(x.hv[i < 0 ? i + (int64_t)x.hv.size() : i]);
+            o.dims = idx.dims;
+            vals[n.out[0]] = o; return;
+        }
+        int r = (int)x.dims.size();
+        if (axis < 0) axis += r;
+        OAR_CHECK(idx.hv.size() == 1, OAR_UNSUPPORTED_OP, "Gather: only a single index is supported on device tensors");
+        int64_t i = idx.hv[0] < 0 ? idx.hv[0] + x.dims[axis] : idx.hv[0];
+        Loc xin = to_native_loc(x);
+        std::string tmpn = n.out[0] + "::gather_slice";
+        slice_out(tmpn, x, xin, (int)axis, i, 1);
+        TInfo s = vals[tmpn];
+        std::vector<int64_t> od;
+        for (int d = 0; d < r; ++d) if (d != axis || !idx.dims.empty()) od.push_back(d == axis ? 1 : x.dims[d]);
+        alias_out(n.out[0], s, od, Layout::NATIVE);
+    }
+
+    void op_linear(const GNode& n, bool gemm) {
+        TInfo a = get(n.in[0]);
+        const TInfo& bt = get(n.in[1]);
+        OAR_CHECK(bt.ht, OAR_UNSUPPORTED_OP, "Linear: B must be an initializer");
+        bool transB = gemm && n.ai("transB", 0) != 0;
+        OAR_CHECK(!gemm || n.ai("transA", 0) == 0, OAR_UNSUPPORTED_OP, "Gemm: transA");
+        int64_t K = transB ? bt.ht->dims[1] : bt.ht->dims[0], N = transB ? bt.ht->dims[0] : bt.ht->dims[1];
+        OAR_CHECK(a.dims.back() == K, OAR_SHAPE_MISMATCH, "Linear: inner dimension mismatch at " + n.out[0]);
+        Loc ain = to_native_loc(a);
+        int64_t M = numel(a.dims) / K;
+        std::vector<int64_t> od = a.dims;
+        od.back() = N;
+        const float* bias = nullptr;
+        float alpha = gemm ? n.af("alpha", 1.0f) : 1.0f;
+        if (!n.bias.empty()) bias = get(n.bias).loc.cptr;
+        if (gemm && has_input(n, 2)) {
+            const TInfo& c = get(n.in[2]);
+            OAR_CHECK(c.ht && numel(c.dims) == N && n.af("beta", 1.0f) == 1.0f, OAR_UNSUPPORTED_OP, "Gemm: C must be a constant [N] with beta 1");
+            bias = c.loc.cptr;
+        }
+        Loc res;
+        if (!n.residual.empty()) { TInfo r = get(n.residual); OAR_CHECK(numel(r.dims) == M * N, OAR_SHAPE_MISMATCH, "Linear: residual shape"); res = to_native_loc(r); }
+        bool has_res = res.kind != Loc::NONE;
+        TInfo& y = new_out(n.out[0], od, Layout::NATIVE);
+        Loc yl = y.loc;
+        Act act = n.act;
+        double flops = 2.0 * M * N * K, bytes = 4.0 * (M * K + M * N * (has_res ? 2 : 1) + K * N);
+        if (K % 4 == 0 && alpha == 1.0f) {
+            const float* w = linear_weight(n.in[1], *bt.ht, transB);
+            k::ConvP p{};
+            p.N = 1; p.H = 1; p.W = (int)M; p.Cin = (int)K; p.Ho = 1; p.Wo = (int)M; p.Cout = (int)N;
+            p.kh = p.kw = p.sh = p.sw = p.dh = p.dw = 1; p.groups = 1; p.act = act; p.w = w; p.bias = bias; p.y_ld = (int)N;
+            step([=](const RunCtx& c) { k::ConvP q = p; q.x = c.at(ain); q.y = c.mut(yl); q.residual = has_res ? c.at(res) : nullptr; k::conv_igemm(c.s, q); }, flops, bytes);
+        } else {
+            const float* w = bt.loc.cptr;
+            k::GemmP g{};
+            g.batch = 1; g.M = (int)M; g.N = (int)N; g.K = (int)K; g.transB = transB; g.alpha = alpha; g.B = w; g.bias = bias; g.act = act;
+            step([=](const RunCtx& c) { k::GemmP q = g; q.A = c.at(ain); q.C = c.mut(yl); q.residual = has_res ? c.at(res) : nullptr; k::gemm_batched(c.s, q); }, flops, bytes);
+        }
+    }
+
+    void op_matmul(const GNode& n) {
+        TInfo a = get(n.in[0]), b = get(n.in[1]);
+        OAR_CHECK(a.dims.size() >= 2 && b.dims.size() >= 2, OAR_UNSUPPORTED_OP, "MatMul: rank < 2");
+        Loc al = to_native_loc(a), bl = to_native_loc(b);
+        int64_t M = a.dims[a.dims.size() - 2], K = a.dims.back(), N = b.dims.back();
+        OAR_CHECK(b.dims[b.dims.size() - 2] == K, OAR_SHAPE_MISMATCH, "MatMul: inner dimension mismatch at " + n.out[0]);
+        std::vector<int64_t> ba(a.dims.begin(), a.dims.end() - 2), bb(b.dims.begin(), b.dims.end() - 2);
+        int64_t na = numel(ba), nb = numel(bb);
+        OAR_CHECK(na == nb || nb == 1 || na == 1, OAR_UNSUPPORTED_OP, "MatMul: general batch broadcasting is not supported");
+        std::vector<int64_t> od = na >= nb ? ba : bb;
+        od.push_back(M); od.push_back(N);
+        int64_t batch = std::max(na, nb);
+        TInfo& y = new_out(n.out[0], od, Layout::NATIVE);
+        Loc yl = y.loc;
+        k::GemmP g{};
+        g.batch = (int)batch; g.M = (int)M; g.N = (int)N; g.K = (int)K; g.transB = 0; g.alpha = 1.0f;
+        g.sA = na == 1 ? 0 : M * K; g.sB = nb == 1 ? 0 : K * N; g.sC = M * N; g.act = n.act;
+        step([=](const RunCtx& c) { k::GemmP q = g; q.A = c.at(al); q.B = c.at(bl); q.C = c.mut(yl); k::gemm_batched(c.s, q); },
+             2.0 * batch * M * N * K, 4.0 * batch * (M * K + K * N + M * N));
+    }
+
+    void op_softmax(const GNode& n) {
+        TInfo x = get(n.in[0]);
+        int r = (int)x.dims.size();
+        int64_t axis = n.ai("axis", E_opset13() ? -1 : 1);
+        if (axis < 0) axis += r;
+        Loc xin = to_native_loc(x);
+        int64_t C, rows;
+        if (E_opset13()) {
+            OAR_CHECK(axis == r - 1, OAR_UNSUPPORTED_OP, "Softmax: only the last axis is supported");
+            C = x.dims.back(); rows = numel(x.dims) / std::max<int64_t>(C, 1);
+        } else {  // opset < 13: flatten to 2-D at `axis`
+            rows = 1; C = 1;
+            for (int i = 0; i < r; ++i) (i < axis ? rows : C) *= x.dims[i];
+        }
+        TInfo& y = new_out(n.out[0], x.dims, Layout::NATIVE);
+        Loc yl = y.loc;
+        step([=](const RunCtx& c) { k::softmax_lastdim(c.s, c.at(xin), c.mut(yl), rows, (int)C); }, 4.0 * rows * C, 8.0 * rows * C);
+    }
+    bool E_opset13() const { return opset >= 13 || opset == 0; }
+    int64_t opset = 17;
+
+    void op_layernorm(const GNode& n) {
+        TInfo x = get(n.in[0]);
+        int r = (int)x.dims.size();
+        int64_t axis = n.ai("axis", -1);
+        if (axis < 0) axis += r;
+        OAR_CHECK(axis == r - 1, OAR_UNSUPPORTED_OP, "LayerNormalization: only the last axis is supported");
+        Loc xin = to_native_loc(x);
+        const float* g = has_input(n, 1) ? get(n.in[1]).loc.cptr : nullptr;
+        const float* b = has_input(n, 2) ? get(n.in[2]).loc.cptr : nullptr;
+        int64_t C = x.dims.back(), rows = numel(x.dims) / std::max<int64_t>(C, 1);
+        float eps = n.af("epsilon", 1e-5f);
+        TInfo& y = new_out(n.out[0], x.dims, Layout::NATIVE);
+        Loc yl = y.loc;
+        step([=](const RunCtx& c) { k::layernorm(c.s, c.at(xin), g, b, c.mut(yl), rows, (int)C, eps); }, 8.0 * rows * C, 8.0 * rows * C);
+    }
+
+    void op_host_arith(const GNode& n, int op) {
+        const TInfo &a = get(n.in[0]), &b = get(n.in[1]);
+        TInfo o; o.host_int = true;
+        size_t cnt = std::max(a.hv.size(), b.hv.size());
+        for (size_t i = 0; i < cnt; ++i) {
+            int64_t x = a.hv[a.hv.size() == 1 ? 0 : i], y = b.hv[b.hv.size() == 1 ? 0 : i], v = 0;
+            switch (op) { case 0: v = x + y; break; case 1: v = x - y; break; case 2: v = x * y; break; default: v = y ? x / y : 0; }
+            o.hv.push_back(v);
+        }
+        o.dims = a.hv.size() >= b.hv.size() ? a.dims : b.dims;
+        vals[n.out[0]] = o;
+    }
+
+    // ------------------------------------------------------------------ driver
+    void compute_last_use() {
+        static const std::set<std::string> alias_ops = {"Reshape", "Flatten", "Squeeze", "Unsqueeze", "Transpose", "Identity", "Split", "Slice", "Gather"};
+        std::map<std::string, int> lu;
+        for (int i = 0; i < (int)E.nodes_.size(); ++i) {
+            const GNode& n = E.nodes_[i];
+            for (auto& s : n.in) if (!s.empty()) lu[s] = i;
+            if (!n.residual.empty()) lu[n.residual] = i;
+        }
+        for (auto& o : E.output_names_) lu[o] = 1 << 30;
+        for (int i = (int)E.nodes_.size() - 1; i >= 0; --i) {
+            const GNode& n = E.nodes_[i];
+            if (!alias_ops.count(n.op) || n.in.empty()) continue;
+            int m = lu.count(n.in[0]) ? lu[n.in[0]] : i;
+            for (auto& o : n.out) if (lu.count(o)) m = std::max(m, lu[o]);
+            lu[n.in[0]] = m;
+        }
+        last_use = lu;
+    }
+
+    void release_dead(int i) {
+        for (auto& t : temps) arena.release(t.first, t.second);
+        temps.clear();
+        std::vector<std::string> dead;
+        for (auto& rb : root_bytes) {
+            auto it = last_use.find(rb.first);
+            int lu = it == last_use.end() ? i : it->second;
+            if (lu <= i) dead.push_back(rb.first);
+        }
+        for (auto& d : dead) { arena.release(root_off[d], root_bytes[d]); root_bytes.erase(d); root_off.erase(d); }
+    }
+
+    void build(const std::vector<int64_t>& in_dims, bool in_clast) {
+        compute_last_use();
+        TInfo in;
+        in.dims = in_dims;
+        in.layout = (in_clast && in_dims.size() >= 3) ? Layout::CLAST : Layout::NATIVE;
+        in.loc.kind = Loc::INPUT;
+        in.root = "";
+        vals[E.input_name_] = in;
+        for (int i = 0; i < (int)E.nodes_.size(); ++i) {
+            const GNode& n = E.nodes_[i];
+            cur = i;
+            dispatch(n);
+            release_dead(i);
+        }
+        for (auto& on : E.output_names_) {
+            auto it = vals.find(on);
+            OAR_CHECK(it != vals.end(), OAR_MODEL_LOAD, "graph output '" + on + "' was never produced");
+            TInfo t = it->second;
+            OAR_CHECK(!t.host_int, OAR_UNSUPPORTED_OP, "integer graph outputs are not supported");
+            PlanOutput po;
+            po.name = on; po.dims = t.dims;
+            if (t.layout == Layout::CLAST) { po.has_clast = true; po.loc_clast = t.loc; }
+            Loc nat = to_native_loc(t);
+            if (nat.kind == Loc::ARENA && nat.off != t.loc.off) {
+                // keep the converted copy alive: move it out of the temp list
+                for (auto it2 = temps.begin(); it2 != temps.end(); ++it2)
+                    if ((int64_t)it2->first == nat.off) { temps.erase(it2); break; }
+            }
+            po.loc = nat;
+            P.outputs.push_back(po);
+        }
+        P.arena_bytes = std::max<size_t>(P.arena_bytes, 256);
+    }
+
+    void dispatch(const GNode& n) {
+        const std::string& op = n.op;
+        bool host_inputs = !n.in.empty();
+        for (auto& s : n.in) if (!s.empty()) host_inputs = host_inputs && get(s).host_int;
+        if (op == "Shape") {
+            const TInfo& x = get(n.in[0]);
+            TInfo o; o.host_int = true; o.hv = x.dims; o.dims = {(int64_t)x.dims.size()};
+            vals[n.out[0]] = o; return;
+        }
+        if (host_inputs) {
+            if (op == "Add") return op_host_arith(n, 0);
+            if (op == "Sub") return op_host_arith(n, 1);
+            if (op == "Mul") return op_host_arith(n, 2);
+            if (op == "Div") return op_host_arith(n, 3);
+            if (op == "Cast" || op == "Identity") { vals[n.out[0]] = get(n.in[0]); return; }
+        }
+        if (op == "Conv") return op_conv(n);
+        if (op == "ConvTranspose") return op_convt(n);
+        if (op == "BatchNormalization") return op_bn(n);
+        if (is_unary_act(op)) return op_unary(n, act_of(n));
+        if (op == "Clip") {
+            Act a; a.kind = k::ACT_CLIP; a.alpha = n.af("min", -3.402823466e38f); a.beta = n.af("max", 3.402823466e38f);
+            if (has_input(n, 1)) { const TInfo& t = get(n.in[1]); OAR_CHECK(t.ht, OAR_UNSUPPORTED_OP, "Clip: dynamic min"); a.alpha = t.ht->f[0]; }
+            if (has_input(n, 2)) { const TInfo& t = get(n.in[2]); OAR_CHECK(t.ht, OAR_UNSUPPORTED_OP, "Clip: dynamic max"); a.beta = t.ht->f[0]; }
+            return op_unary(n, a);
+        }
+        if (op == "Add") return op_binary(n, 0);
+        if (op == "Sub") return op_binary(n, 1);
+        if (op == "Mul") return op_binary(n, 2);
+        if (op == "Div") return op_binary(n, 3);
+        if (op == "Pow") return op_binary(n, 4);
+        if (op == "GlobalAveragePool") return op_gap(n);
+        if (op == "AveragePool") return op_pool(n, false);
+        if (op == "MaxPool") return op_pool(n, true);
+        if (op == "Resize") return op_resize(n);
+        if (op == "Concat") return op_concat(n);
+        if (op == "Reshape") return op_reshape(n);
+        if (op == "Flatten") return op_flatten(n);
+        if (op == "Squeeze") return op_squeeze(n);
+        if (op == "Unsqueeze") return op_unsqueeze(n);
+        if (op == "Transpose") return op_transpose(n);
+        if (op == "Split") return op_split(n);
+        if (op == "Slice") return op_slice(n);
+        if (op == "Gather") return op_gather(n);
+        if (op == "Linear") return op_linear(n, false);
+        if (op == "Gemm") return op_linear(n, true);
+        if (op == "MatMul") return op_matmul(n);
+        if (op == "Softmax") return op_softmax(n);
+        if (op == "LayerNormalization") return op_layernorm(n);
+        if (op == "Identity") { const TInfo& x = get(n.in[0]); if (x.host_int) { vals[n.out[0]] = x; } else { TInfo xx = x; alias_out(n.out[0], xx, xx.dims, xx.layout); } return; }
+        if (op == "Cast") { const TInfo& x = get(n.in[0]); OAR_CHECK(n.ai("to", 1) == 1, OAR_UNSUPPORTED_OP, "Cast of a device tensor to non-f32"); TInfo xx = x; alias_out(n.out[0], xx, xx.dims, xx.layout); return; }
+        fail(OAR_UNSUPPORTED_OP, "operator '" + op + "' is not implemented (node output " + (n.out.empty() ? "?" : n.out[0]) + ")");
+    }
+};
+
+const Plan& Engine::plan_for(const std::vector<int64_t>& dims, bool in_clast) {
+    std::ostringstream key;
+    key << (in_clast ? "L" : "N");
+    for (auto d : dims) key << "x" << d;
+    auto it = plans_.find(key.str());
+    if (it != plans_.end()) return *it->second;
+    OAR_HIP(hipSetDevice(device_));
+    std::unique_ptr<Plan> p(new Plan());
+    Planner pl(*this, *p);
+    pl.build(dims, in_clast);
+    const Plan& ref = *p;
+    plans_[key.str()] = std::move(p);
+    return ref;
+}
+
+const Plan& Engine::run(const float* d_in, const std::vector<int64_t>& dims, bool in_clast) {
+    const Plan& p = plan_for(dims, in_clast);
+    OAR_HIP(hipSetDevice(device_));
+    if (arena_.cap < p.arena_bytes) {
+        OAR_HIP(hipStreamSynchronize(stream_));
+        arena_.reserve(p.arena_bytes);
+    }
+    RunCtx c{stream_, d_in, arena_.as<char>()};
+    last_input_ = d_in;
+    for (auto& st : p.steps) st(c);
+    OAR_HIP(hipGetLastError());
+    return p;
+}
+
+const float* Engine::out_ptr(const Loc& l) const {
+    RunCtx c{stream_, last_input_, arena_.as<char>()};
+    return c.at(l);
+}
+
+}  // namespace oar

@@ -1,0 +1,109 @@
+// engine.h -- ONNX graph -> shape-specialised plan of HIP kernel launches.
+// Stands where `OrtInfer` stands in the reference (core/inference/ort_infer_execution.rs:121-306): one f32
+// input, all graph outputs.  Feature maps live in HBM as NHWC ("channels-last"); the ONNX (NCHW) view is
+// only materialised at the boundary.
+#pragma once
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+#include "onnx_parse.h"
+
+namespace oar {
+
+enum class Layout : int { NATIVE = 0, CLAST = 1 };  // CLAST: logical [n, C, s...] stored as [n, s..., C]
+
+struct GNode {  // graph node after load-time rewrites
+    std::string op;
+    std::vector<std::string> in, out;
+    std::map<std::string, Attr> attrs;
+    k::Act act;                 // fused activation
+    std::string bias;           // fused bias initializer (Linear)
+    std::string residual;       // fused residual input
+    int id = 0;
+    int64_t ai(const char* k, int64_t d) const { auto it = attrs.find(k); return it == attrs.end() ? d : it->second.i; }
+    float af(const char* k, float d) const { auto it = attrs.find(k); return it == attrs.end() ? d : it->second.f; }
+    std::string as(const char* k, const std::string& d) const { auto it = attrs.find(k); return it == attrs.end() ? d : it->second.s; }
+    std::vector<int64_t> ais(const char* k) const { auto it = attrs.find(k); return it == attrs.end() ? std::vector<int64_t>{} : it->second.is; }
+    bool has(const char* k) const { return attrs.count(k) != 0; }
+};
+
+struct Loc {  // where a value lives at run time
+    enum Kind { NONE, INPUT, ARENA, CONST } kind = NONE;
+    int64_t off = 0;             // byte offset (ARENA / INPUT)
+    const float* cptr = nullptr; // CONST
+};
+
+struct RunCtx {
+    hipStream_t s;
+    const float* input;
+    char* arena;
+    const float* at(const Loc& l) const {
+        switch (l.kind) {
+            case Loc::INPUT: return reinterpret_cast<const float*>(reinterpret_cast<const char*>(input) + l.off);
+            case Loc::ARENA: return reinterpret_cast<const float*>(arena + l.off);
+            case Loc::CONST: return l.cptr;
+            default: return nullptr;
+        }
+    }
+    float* mut(const Loc& l) const { return const_cast<float*>(at(l)); }
+};
+
+struct PlanOutput {
+    std::string name;
+    std::vector<int64_t> dims;  // logical (ONNX) dims
+    Loc loc;                    // native layout
+    Loc loc_clast;              // valid when has_clast: the channels-last copy (no conversion needed)
+    bool has_clast = false;
+};
+
+struct Plan {
+    std::vector<std::function<void(const RunCtx&)>> steps;
+    size_t arena_bytes = 0;
+    std::vector<PlanOutput> outputs;
+    double flops = 0, bytes = 0;
+    int n_kernels = 0;
+};
+
+class Engine {
+   public:
+    Engine(const uint8_t* onnx, size_t len, int device_id);
+    ~Engine();
+    const std::string& input_name() const { return input_name_; }
+    int device() const { return device_; }
+    hipStream_t stream() const { return stream_; }
+
+    // d_in: device pointer. dims: logical ONNX dims. in_clast: rank-4 input already stored NHWC.
+    // Outputs stay on the device (valid until the next run on this engine).
+    const Plan& run(const float* d_in, const std::vector<int64_t>& dims, bool in_clast);
+    const Plan& plan_for(const std::vector<int64_t>& dims, bool in_clast);
+    const float* out_ptr(const Loc& l) const;
+    char* arena() const { return arena_.as<char>(); }
+    std::mutex& mutex() { return mu_; }
+
+   private:
+    friend struct Planner;
+    void rewrite_graph(OnnxModel& m);
+    const float* upload_const(const std::string& key, const std::vector<float>& v);
+
+    int device_ = 0;
+    int64_t opset_ = 17;
+    hipStream_t stream_ = nullptr;
+    std::string input_name_;
+    std::vector<std::string> output_names_;
+    std::map<std::string, HostTensor> inits_;
+    std::vector<GNode> nodes_;
+    std::map<std::string, const float*> dev_consts_;
+    std::vector<void*> dev_allocs_;
+    std::map<std::string, std::unique_ptr<Plan>> plans_;
+    DevBuf arena_;
+    std::mutex mu_;
+    const float* last_input_ = nullptr;
+};
+
+}  // namespace oar

@@ -1,0 +1,80 @@
+// kernels.h -- launchers for the gfx950 NN kernels (all activations f32, NHWC for rank-4 feature maps).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace oar {
+namespace k {
+
+enum ActKind : int { ACT_NONE = 0, ACT_RELU, ACT_HSWISH, ACT_HSIGMOID, ACT_SIGMOID, ACT_SWISH, ACT_LEAKY, ACT_CLIP, ACT_TANH, ACT_GELU_ERF };
+struct Act {
+    int kind = ACT_NONE;
+    float alpha = 0.f, beta = 0.f;  // HardSigmoid(alpha,beta) / LeakyRelu(alpha) / Clip(alpha=min,beta=max)
+};
+
+struct ConvP {
+    int N, H, W, Cin;       // input NHWC
+    int Ho, Wo, Cout;       // output NHWC
+    int kh, kw, sh, sw, pt, pl, dh, dw, groups;
+    Act act;
+    const float* x;
+    const float* w;         // layout depends on the kernel (see each launcher)
+    const float* bias;      // may be null
+    const float* residual;  // may be null; same shape/ld as y
+    float* y;
+    int y_ld;               // channel stride of the output buffer (>= Cout); y points at channel offset already
+    int convt2x2;           // igemm only: output scatter of a 2x2/stride-2 ConvTranspose (Cout is the real Cout)
+};
+
+// Implicit-GEMM conv on f32 MFMA (v_mfma_f32_16x16x4_f32). groups == 1, Cin % 4 == 0.
+// w: [Cout_pad16][K], K = kh*kw*Cin ordered (kh, kw, ci); Cout_pad16 = round_up(gemm_cout, 16), zero rows.
+void conv_igemm(hipStream_t s, const ConvP& p);
+// Depthwise conv. w: [kh][kw][C]. C % 4 == 0.
+void conv_dw(hipStream_t s, const ConvP& p);
+// Direct conv for everything else (small Cin, odd channels, grouped). w: [kh][kw][Cin/g][Cout].
+void conv_direct(hipStream_t s, const ConvP& p);
+// General ConvTranspose (gather form). w: [kh][kw][Cin][Cout] (groups == 1), output_padding folded in Ho/Wo.
+void convt_direct(hipStream_t s, const ConvP& p);
+
+struct PoolP {
+    int N, H, W, C, Ho, Wo, kh, kw, sh, sw, pt, pl;
+    int is_max, count_include_pad;
+    const float* x;
+    float* y;
+};
+void pool2d(hipStream_t s, const PoolP& p);
+void global_avgpool(hipStream_t s, const float* x, float* y, int N, int HW, int C);
+
+// Resize NHWC. mode 0 = nearest, 1 = bilinear. ctm: 0 = asymmetric, 1 = half_pixel, 2 = align_corners,
+// 3 = pytorch_half_pixel. nearest_mode: 0 = floor, 1 = round_prefer_floor, 2 = round_prefer_ceil, 3 = ceil.
+void resize(hipStream_t s, const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, float scale_h,
+            float scale_w, int mode, int ctm, int nearest_mode, int y_ld);
+
+void unary(hipStream_t s, const float* x, float* y, int64_t n, Act act);
+// y = op(a, b) with numpy broadcasting over up to 6 dims. op: 0 add, 1 sub, 2 mul, 3 div, 4 pow. Strides in elements
+// (0 for broadcast dims); output is contiguous with dims `dims`.
+void binary(hipStream_t s, const float* a, const float* b, float* y, int op, int rank, const int64_t* dims,
+            const int64_t* sa, const int64_t* sb, Act post);
+// Copies `rows` rows of `c` floats from x (ld x_ld) to y (ld y_ld): channel concat / strided views.
+void copy2d(hipStream_t s, const float* x, float* y, int64_t rows, int c, int x_ld, int y_ld);
+// Generic permute: y (contiguous, dims out_dims) = x indexed with in_strides (already permuted), rank <= 6.
+void permute(hipStream_t s, const float* x, float* y, int rank, const int64_t* out_dims, const int64_t* in_strides);
+
+// Batched GEMM, row-major: C[b] (MxN) = alpha * A[b] (MxK) * B[b] (KxN or NxK if transB) (+ bias[N]) (+ residual) then act.
+// batch strides in elements (0 = shared). VALU-tiled kernel for the small attention products.
+struct GemmP {
+    int batch, M, N, K, transB;
+    int64_t sA, sB, sC;
+    float alpha;
+    const float *A, *B, *bias, *residual;
+    float* C;
+    Act act;
+};
+void gemm_batched(hipStream_t s, const GemmP& p);
+
+void layernorm(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C, float eps);
+void softmax_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C);
+
+}  // namespace k
+}  // namespace oar

@@ -1,0 +1,767 @@
+// kernels.hip -- hand-written gfx950 (CDNA4) kernels for the detector / recognizer networks.
+//
+// Data layout: feature maps are NHWC f32 in HBM (channel innermost => every conv reads/writes fully
+// coalesced 16-byte vectors).  Dense convs / Linear layers run as implicit GEMM on the f32-input matrix
+// cores (v_mfma_f32_16x16x4_f32: exact f32 FMA chain, bit-reproducible) with LDS-staged operand tiles;
+// depthwise / pooling / resize / elementwise are bandwidth kernels with float4 accesses.
+// Wave = 64 lanes everywhere.  Compiled with -ffp-contract=off; FMAs are written explicitly.
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace oar {
+namespace k {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------ activations
+__device__ __forceinline__ float apply_act(float v, int kind, float alpha, float beta) {
+    switch (kind) {
+        case ACT_NONE: return v;
+        case ACT_RELU: return v > 0.f ? v : 0.f;
+        case ACT_HSWISH: {
+            float t = fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.f), 1.f);
+            return v * t;
+        }
+        case ACT_HSIGMOID: return fminf(fmaxf(v * alpha + beta, 0.f), 1.f);
+        case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+        case ACT_SWISH: return v * (1.0f / (1.0f + expf(-v)));
+        case ACT_LEAKY: return v > 0.f ? v : v * alpha;
+        case ACT_CLIP: return fminf(fmaxf(v, alpha), beta);
+        case ACT_TANH: return tanhf(v);
+        case ACT_GELU_ERF: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        default: return v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ implicit-GEMM conv
+// GEMM view: D[cout][pixel] = sum_k Wt[cout][k] * X[pixel][k];  k = (kh, kw, ci), ci innermost.
+// MFMA 16x16x4 f32 operand map (cdna_hip_programming.md section 3): A[i = lane&15][k = lane>>4],
+// B[k = lane>>4][j = lane&15], D[row = (lane>>4)*4 + r][col = lane&15].  A = weights (rows = cout),
+// B = im2col pixels (cols = pixel), so each lane ends up with 4 CONSECUTIVE output channels of one pixel:
+// a single 16-byte NHWC store.
+// Workgroup = 4 waves = 256 pixels x NT*16 couts; each wave owns 64 pixels (4 pixel fragments).
+// LDS tiles are [row][16 k + 1 pad]: the fragment read `row = lane&15, k = lane>>4` walks stride-17 rows,
+// conflict-free across a 32-lane ds_read_b32 group (17 is odd).
+struct IgemmP {
+    const float* x;
+    const float* w;
+    const float* bias;
+    const float* res;
+    float* y;
+    long M;            // N*Ho*Wo pixels
+    int K;             // kh*kw*Cin
+    int gemm_cout;     // rows of the GEMM (Cout, or 4*Cout for convT 2x2)
+    int Cout;          // real channel count of y
+    int H, W, Cin, Ho, Wo, kh, kw, sh, sw, pt, pl, dh, dw;
+    int y_ld;
+    int act, convt;
+    float alpha, beta;
+};
+
+template <int NT, bool IS1X1>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmP p) {
+    __shared__ float Xs[256][17];
+    __shared__ float Ws[NT * 16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long m0 = (long)blockIdx.x * 256;
+    const int n0 = blockIdx.y * NT * 16;
+    const int lrow = tid >> 2, lq = tid & 3;  // loader: 64 rows per pass, 4 k-quads per row
+
+    // per-pass pixel decode (fixed over the K loop)
+    long pix_base[4];
+    int ih0[4], iw0[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        long m = m0 + ps * 64 + lrow;
+        if (m < p.M) {
+            if (IS1X1) {
+                pix_base[ps] = m * (long)p.Cin;
+                ih0[ps] = 0; iw0[ps] = 0;
+            } else {
+                long hw = (long)p.Ho * p.Wo;
+                long n = m / hw; long r = m - n * hw;
+                int oh = (int)(r / p.Wo), ow = (int)(r - (long)oh * p.Wo);
+                pix_base[ps] = n * (long)p.H * p.W * p.Cin;
+                ih0[ps] = oh * p.sh - p.pt; iw0[ps] = ow * p.sw - p.pl;
+            }
+        } else {
+            pix_base[ps] = -1; ih0[ps] = 0; iw0[ps] = 0;
+        }
+    }
+
+    f32x4 acc[NT][4];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < p.K; k0 += 16) {
+        const int k = k0 + 4 * lq;
+        int tap_h = 0, tap_w = 0, ci = k;
+        if (!IS1X1) {
+            int tap = k / p.Cin; ci = k - tap * p.Cin;
+            tap_h = tap / p.kw; tap_w = tap - tap_h * p.kw;
+        }
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pix_base[ps] >= 0 && k < p.K) {
+                if (IS1X1) {
+                    v = *reinterpret_cast<const float4*>(p.x + pix_base[ps] + k);
+                } else {
+                    int ih = ih0[ps] + tap_h * p.dh, iw = iw0[ps] + tap_w * p.dw;
+                    if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                        v = *reinterpret_cast<const float4*>(p.x + pix_base[ps] + ((long)ih * p.W + iw) * p.Cin + ci);
+                }
+            }
+            float* d = &Xs[ps * 64 + lrow][4 * lq];
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        if (tid < NT * 64) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < p.K) v = *reinterpret_cast<const float4*>(p.w + (long)(n0 + lrow) * p.K + k);
+            float* d = &Ws[lrow][4 * lq];
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float a[NT], b[4];
+#pragma unroll
+            for (int nf = 0; nf < NT; ++nf) a[nf] = Ws[nf * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+#pragma unroll
+            for (int pf = 0; pf < 4; ++pf) b[pf] = Xs[wave * 64 + pf * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+#pragma unroll
+            for (int nf = 0; nf < NT; ++nf)
+#pragma unroll
+                for (int pf = 0; pf < 4; ++pf)
+                    acc[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nf], b[pf], acc[nf][pf], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: bias + residual + activation, 16-byte NHWC stores
+    const bool vec_ok = ((p.Cout & 3) == 0) && ((p.y_ld & 3) == 0);
+#pragma unroll
+    for (int pf = 0; pf < 4; ++pf) {
+        long m = m0 + wave * 64 + pf * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        long obase;
+        if (p.convt) {
+            long hw = (long)p.Ho * p.Wo;  // here Ho/Wo are the INPUT spatial dims of the convT
+            long n = m / hw; long r = m - n * hw;
+            int h = (int)(r / p.Wo), w = (int)(r - (long)h * p.Wo);
+            obase = (n * (2L * p.Ho) + 2L * h) * (2L * p.Wo) + 2L * w;  // pixel index of (2h, 2w)
+        } else {
+            obase = m;
+        }
+#pragma unroll
+        for (int nf = 0; nf < NT; ++nf) {
+            int c = n0 + nf * 16 + (lane >> 4) * 4;
+            if (c >= p.gemm_cout) continue;
+            f32x4 v = acc[nf][pf];
+            float o[4] = {v[0], v[1], v[2], v[3]};
+            if (vec_ok) {
+                int co = c; long opix = obase;
+                if (p.convt) { int ab = c / p.Cout; co = c - ab * p.Cout; opix = obase + (long)(ab >> 1) * (2L * p.Wo) + (ab & 1); }
+                if (p.bias) { float4 bv = *reinterpret_cast<const float4*>(p.bias + co); o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w; }
+                float* dst = p.y + opix * p.y_ld + co;
+                if (p.res) { float4 rv = *reinterpret_cast<const float4*>(p.res + opix * p.y_ld + co); o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = apply_act(o[r], p.act, p.alpha, p.beta);
+                *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int cc = c + r;
+                    if (cc >= p.gemm_cout) continue;
+                    int co = cc; long opix = obase;
+                    if (p.convt) { int ab = cc / p.Cout; co = cc - ab * p.Cout; opix = obase + (long)(ab >> 1) * (2L * p.Wo) + (ab & 1); }
+                    float t = o[r];
+                    if (p.bias) t += p.bias[co];
+                    if (p.res) t += p.res[opix * p.y_ld + co];
+                    p.y[opix * p.y_ld + co] = apply_act(t, p.act, p.alpha, p.beta);
+                }
+            }
+        }
+    }
+}
+
+void conv_igemm(hipStream_t s, const ConvP& c) {
+    IgemmP p;
+    p.x = c.x; p.w = c.w; p.bias = c.bias; p.res = c.residual; p.y = c.y;
+    p.H = c.H; p.W = c.W; p.Cin = c.Cin; p.kh = c.kh; p.kw = c.kw; p.sh = c.sh; p.sw = c.sw;
+    p.pt = c.pt; p.pl = c.pl; p.dh = c.dh; p.dw = c.dw; p.y_ld = c.y_ld;
+    p.act = c.act.kind; p.alpha = c.act.alpha; p.beta = c.act.beta;
+    p.convt = c.convt2x2; p.Cout = c.Cout;
+    if (c.convt2x2) {
+        p.Ho = c.H; p.Wo = c.W;  // GEMM rows are INPUT pixels
+        p.M = (long)c.N * c.H * c.W; p.K = c.Cin; p.gemm_cout = 4 * c.Cout;
+    } else {
+        p.Ho = c.Ho; p.Wo = c.Wo;
+        p.M = (long)c.N * c.Ho * c.Wo; p.K = c.kh * c.kw * c.Cin; p.gemm_cout = c.Cout;
+    }
+    if (p.M == 0) return;
+    const bool is1x1 = c.convt2x2 || (c.kh == 1 && c.kw == 1 && c.sh == 1 && c.sw == 1 && c.pt == 0 && c.pl == 0);
+    int nfrag = (p.gemm_cout + 15) / 16;
+    int NT = nfrag >= 4 ? 4 : (nfrag >= 2 ? 2 : 1);
+    if (nfrag == 3) NT = 4;
+    dim3 grid((unsigned)((p.M + 255) / 256), (unsigned)((nfrag + NT - 1) / NT));
+    double flops = 2.0 * (double)p.M * p.K * p.gemm_cout;
+    double bytes = 4.0 * ((double)c.N * c.H * c.W * c.Cin + (double)p.M * p.gemm_cout + (double)p.K * p.gemm_cout);
+    ProfScope ps(s, "conv_igemm", bytes, flops);
+#define LAUNCH(NTV)                                                                                      \
+    do {                                                                                                 \
+        if (is1x1) hipLaunchKernelGGL((conv_igemm_kernel<NTV, true>), grid, dim3(256), 0, s, p);        \
+        else hipLaunchKernelGGL((conv_igemm_kernel<NTV, false>), grid, dim3(256), 0, s, p);             \
+    } while (0)
+    if (NT == 4) LAUNCH(4);
+    else if (NT == 2) LAUNCH(2);
+    else LAUNCH(1);
+#undef LAUNCH
+}
+
+// ------------------------------------------------------------------------------------------ depthwise conv
+// One thread = 4 channels x 1 output pixel. Weights [kh][kw][C]. Pure bandwidth kernel: the kxk window re-reads
+// hit L1/L2 (neighbouring threads share rows).
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void conv_dw_kernel(ConvP p) {
+    const int C4 = p.Cout >> 2;
+    long total = (long)p.N * p.Ho * p.Wo * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c4 = (int)(i % C4); long pix = i / C4;
+        int ow = (int)(pix % p.Wo); long t = pix / p.Wo;
+        int oh = (int)(t % p.Ho); long n = t / p.Ho;
+        const int c = c4 * 4;
+        float4 acc = p.bias ? *reinterpret_cast<const float4*>(p.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int kh = KH > 0 ? KH : p.kh, kw = KW > 0 ? KW : p.kw;
+        const float* xb = p.x + n * (long)p.H * p.W * p.Cin + c;
+#pragma unroll
+        for (int a = 0; a < kh; ++a) {
+            int ih = oh * p.sh - p.pt + a * p.dh;
+            if (ih < 0 || ih >= p.H) continue;
+#pragma unroll
+            for (int b = 0; b < kw; ++b) {
+                int iw = ow * p.sw - p.pl + b * p.dw;
+                if (iw < 0 || iw >= p.W) continue;
+                float4 xv = *reinterpret_cast<const float4*>(xb + ((long)ih * p.W + iw) * p.Cin);
+                float4 wv = *reinterpret_cast<const float4*>(p.w + (long)(a * kw + b) * p.Cout + c);
+                acc.x = fmaf(xv.x, wv.x, acc.x); acc.y = fmaf(xv.y, wv.y, acc.y);
+                acc.z = fmaf(xv.z, wv.z, acc.z); acc.w = fmaf(xv.w, wv.w, acc.w);
+            }
+        }
+        long o = pix * p.y_ld + c;
+        if (p.residual) { float4 r = *reinterpret_cast<const float4*>(p.residual + o); acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w; }
+        acc.x = apply_act(acc.x, p.act.kind, p.act.alpha, p.act.beta);
+        acc.y = apply_act(acc.y, p.act.kind, p.act.alpha, p.act.beta);
+        acc.z = apply_act(acc.z, p.act.kind, p.act.alpha, p.act.beta);
+        acc.w = apply_act(acc.w, p.act.kind, p.act.alpha, p.act.beta);
+        *reinterpret_cast<float4*>(p.y + o) = acc;
+    }
+}
+
+static inline unsigned grid_for(long work, int block = 256, long cap = 256L * 32) {
+    long g = (work + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+void conv_dw(hipStream_t s, const ConvP& p) {
+    long total = (long)p.N * p.Ho * p.Wo * (p.Cout / 4);
+    if (total == 0) return;
+    double bytes = 4.0 * ((double)p.N * p.H * p.W * p.Cin + (double)p.N * p.Ho * p.Wo * p.Cout + (double)p.kh * p.kw * p.Cout);
+    double flops = 2.0 * (double)p.N * p.Ho * p.Wo * p.Cout * p.kh * p.kw;
+    ProfScope ps(s, "conv_dw", bytes, flops);
+    dim3 g(grid_for(total)), b(256);
+    if (p.kh == 3 && p.kw == 3) hipLaunchKernelGGL((conv_dw_kernel<3, 3>), g, b, 0, s, p);
+    else if (p.kh == 5 && p.kw == 5) hipLaunchKernelGGL((conv_dw_kernel<5, 5>), g, b, 0, s, p);
+    else hipLaunchKernelGGL((conv_dw_kernel<0, 0>), g, b, 0, s, p);
+}
+
+// ------------------------------------------------------------------------------------------ direct conv (fallback)
+// One thread = one output element. w: [kh][kw][Cin/g][Cout].
+__global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p) {
+    long total = (long)p.N * p.Ho * p.Wo * p.Cout;
+    const int cpg = p.Cin / p.groups, opg = p.Cout / p.groups;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int co = (int)(i % p.Cout); long pix = i / p.Cout;
+        int ow = (int)(pix % p.Wo); long t = pix / p.Wo;
+        int oh = (int)(t % p.Ho); long n = t / p.Ho;
+        int g = co / opg;
+        float acc = p.bias ? p.bias[co] : 0.f;
+        const float* xb = p.x + n * (long)p.H * p.W * p.Cin + (long)g * cpg;
+        for (int a = 0; a < p.kh; ++a) {
+            int ih = oh * p.sh - p.pt + a * p.dh;
+            if (ih < 0 || ih >= p.H) continue;
+            for (int b = 0; b < p.kw; ++b) {
+                int iw = ow * p.sw - p.pl + b * p.dw;
+                if (iw < 0 || iw >= p.W) continue;
+                const float* xp = xb + ((long)ih * p.W + iw) * p.Cin;
+                const float* wp = p.w + ((long)(a * p.kw + b) * cpg) * p.Cout + co;
+                for (int ci = 0; ci < cpg; ++ci) acc = fmaf(xp[ci], wp[(long)ci * p.Cout], acc);
+            }
+        }
+        long o = pix * p.y_ld + co;
+        if (p.residual) acc += p.residual[o];
+        p.y[o] = apply_act(acc, p.act.kind, p.act.alpha, p.act.beta);
+    }
+}
+void conv_direct(hipStream_t s, const ConvP& p) {
+    long total = (long)p.N * p.Ho * p.Wo * p.Cout;
+    if (total == 0) return;
+    double bytes = 4.0 * ((double)p.N * p.H * p.W * p.Cin + (double)total + (double)p.kh * p.kw * (p.Cin / p.groups) * p.Cout);
+    double flops = 2.0 * (double)total * p.kh * p.kw * (p.Cin / p.groups);
+    ProfScope ps(s, "conv_direct", bytes, flops);
+    hipLaunchKernelGGL(conv_direct_kernel, dim3(grid_for(total)), dim3(256), 0, s, p);
+}
+
+// General ConvTranspose, gather form: y[n,oh,ow,co] = sum_{a,b,ci} x[n,(oh+pt-a*dh)/sh,(ow+pl-b*dw)/sw,ci] * w[a][b][ci][co]
+__global__ __launch_bounds__(256) void convt_direct_kernel(ConvP p) {
+    long total = (long)p.N * p.Ho * p.Wo * p.Cout;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int co = (int)(i % p.Cout); long pix = i / p.Cout;
+        int ow = (int)(pix % p.Wo); long t = pix / p.Wo;
+        int oh = (int)(t % p.Ho); long n = t / p.Ho;
+        float acc = p.bias ? p.bias[co] : 0.f;
+        for (int a = 0; a < p.kh; ++a) {
+            int th = oh + p.pt - a * p.dh;
+            if (th < 0 || th % p.sh) continue;
+            int ih = th / p.sh;
+            if (ih >= p.H) continue;
+            for (int b = 0; b < p.kw; ++b) {
+                int tw = ow + p.pl - b * p.dw;
+                if (tw < 0 || tw % p.sw) continue;
+                int iw = tw / p.sw;
+                if (iw >= p.W) continue;
+                const float* xp = p.x + ((n * p.H + ih) * (long)p.W + iw) * p.Cin;
+                const float* wp = p.w + ((long)(a * p.kw + b) * p.Cin) * p.Cout + co;
+                for (int ci = 0; ci < p.Cin; ++ci) acc = fmaf(xp[ci], wp[(long)ci * p.Cout], acc);
+            }
+        }
+        p.y[pix * p.y_ld + co] = apply_act(acc, p.act.kind, p.act.alpha, p.act.beta);
+    }
+}
+void convt_direct(hipStream_t s, const ConvP& p) {
+    long total = (long)p.N * p.Ho * p.Wo * p.Cout;
+    if (total == 0) return;
+    ProfScope ps(s, "convt_direct", 4.0 * ((double)p.N * p.H * p.W * p.Cin + (double)total), 2.0 * (double)p.N * p.H * p.W * p.Cin * p.Cout * p.kh * p.kw);
+    hipLaunchKernelGGL(convt_direct_kernel, dim3(grid_for(total)), dim3(256), 0, s, p);
+}
+
+// ------------------------------------------------------------------------------------------ pooling
+__global__ __launch_bounds__(256) void pool2d_kernel(PoolP p) {
+    long total = (long)p.N * p.Ho * p.Wo * p.C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % p.C); long pix = i / p.C;
+        int ow = (int)(pix % p.Wo); long t = pix / p.Wo;
+        int oh = (int)(t % p.Ho); long n = t / p.Ho;
+        float acc = p.is_max ? -3.402823466e38f : 0.f;
+        int cnt = 0;
+        for (int a = 0; a < p.kh; ++a) {
+            int ih = oh * p.sh - p.pt + a;
+            if (ih < 0 || ih >= p.H) continue;
+            for (int b = 0; b < p.kw; ++b) {
+                int iw = ow * p.sw - p.pl + b;
+                if (iw < 0 || iw >= p.W) continue;
+                float v = p.x[((n * p.H + ih) * (long)p.W + iw) * p.C + c];
+                if (p.is_max) acc = fmaxf(acc, v); else acc += v;
+                ++cnt;
+            }
+        }
+        if (!p.is_max) acc = acc / (float)(p.count_include_pad ? p.kh * p.kw : (cnt > 0 ? cnt : 1));
+        p.y[i] = acc;
+    }
+}
+void pool2d(hipStream_t s, const PoolP& p) {
+    long total = (long)p.N * p.Ho * p.Wo * p.C;
+    if (total == 0) return;
+    ProfScope ps(s, "pool2d", 4.0 * ((double)p.N * p.H * p.W * p.C + (double)total), 0.0);
+    hipLaunchKernelGGL(pool2d_kernel, dim3(grid_for(total)), dim3(256), 0, s, p);
+}
+
+// One workgroup per (n, 64-channel slab): threads stride over HW, LDS tree-reduce. Sum order is fixed.
+__global__ __launch_bounds__(256) void global_avgpool_kernel(const float* x, float* y, int HW, int C) {
+    __shared__ float red[4][64];
+    const int n = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < C) {
+        const float* xb = x + (long)n * HW * C + c;
+        for (int i = part; i < HW; i += 4) acc += xb[(long)i * C];
+    }
+    red[part][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        y[(long)n * C + c] = t / (float)HW;
+    }
+}
+void global_avgpool(hipStream_t s, const float* x, float* y, int N, int HW, int C) {
+    if (N == 0 || C == 0) return;
+    ProfScope ps(s, "global_avgpool", 4.0 * (double)N * HW * C, 0.0);
+    hipLaunchKernelGGL(global_avgpool_kernel, dim3((C + 63) / 64, N), dim3(256), 0, s, x, y, HW, C);
+}
+
+// ------------------------------------------------------------------------------------------ resize
+__device__ __forceinline__ float src_coord(int o, float scale, int in, int out, int ctm) {
+    switch (ctm) {
+        case 0: return (float)o / scale;
+        case 2: return out > 1 ? (float)o * (float)(in - 1) / (float)(out - 1) : 0.f;
+        case 3: return out > 1 ? ((float)o + 0.5f) / scale - 0.5f : 0.f;
+        default: return ((float)o + 0.5f) / scale - 0.5f;
+    }
+}
+__global__ __launch_bounds__(256) void resize_kernel(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo,
+                                                     float sh, float sw, int mode, int ctm, int nm, int y_ld) {
+    const int C4 = C >> 2;  // launcher guarantees C % 4 == 0 for the vector path, else C4 == 0 and scalar path
+    const bool vec = (C & 3) == 0 && (y_ld & 3) == 0;
+    const int cw = vec ? C4 : C;
+    long total = (long)N * Ho * Wo * cw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int cc = (int)(i % cw); long pix = i / cw;
+        int ow = (int)(pix % Wo); long t = pix / Wo;
+        int oh = (int)(t % Ho); long n = t / Ho;
+        float fy = src_coord(oh, sh, H, Ho, ctm), fx = src_coord(ow, sw, W, Wo, ctm);
+        const float* xb = x + n * (long)H * W * C;
+        if (mode == 0) {
+            float ry, rx;
+            switch (nm) {
+                case 0: ry = floorf(fy); rx = floorf(fx); break;
+                case 3: ry = ceilf(fy); rx = ceilf(fx); break;
+                case 2: ry = floorf(fy + 0.5f); rx = floorf(fx + 0.5f); break;
+                default: ry = ceilf(fy - 0.5f); rx = ceilf(fx - 0.5f); break;
+            }
+            int iy = min(max((int)ry, 0), H - 1), ix = min(max((int)rx, 0), W - 1);
+            if (vec) *reinterpret_cast<float4*>(y + pix * y_ld + cc * 4) = *reinterpret_cast<const float4*>(xb + ((long)iy * W + ix) * C + cc * 4);
+            else y[pix * y_ld + cc] = xb[((long)iy * W + ix) * C + cc];
+        } else {
+            fy = fminf(fmaxf(fy, 0.f), (float)(H - 1)); fx = fminf(fmaxf(fx, 0.f), (float)(W - 1));
+            int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+            int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+            float wy = fy - (float)y0, wx = fx - (float)x0;
+            int nc = vec ? 4 : 1;
+            for (int q = 0; q < nc; ++q) {
+                int c = vec ? cc * 4 + q : cc;
+                float v00 = xb[((long)y0 * W + x0) * C + c], v01 = xb[((long)y0 * W + x1) * C + c];
+                float v10 = xb[((long)y1 * W + x0) * C + c], v11 = xb[((long)y1 * W + x1) * C + c];
+                float top = v00 + (v01 - v00) * wx, bot = v10 + (v11 - v10) * wx;
+                y[pix * y_ld + c] = top + (bot - top) * wy;
+            }
+        }
+    }
+}
+void resize(hipStream_t s, const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, float scale_h,
+            float scale_w, int mode, int ctm, int nearest_mode, int y_ld) {
+    long total = (long)N * Ho * Wo * C;
+    if (total == 0) return;
+    ProfScope ps(s, "resize", 4.0 * ((double)N * H * W * C + (double)total), 0.0);
+    long work = ((C & 3) == 0 && (y_ld & 3) == 0) ? total / 4 : total;
+    hipLaunchKernelGGL(resize_kernel, dim3(grid_for(work)), dim3(256), 0, s, x, y, N, H, W, C, Ho, Wo, scale_h, scale_w, mode, ctm, nearest_mode, y_ld);
+}
+
+// ------------------------------------------------------------------------------------------ elementwise
+__global__ __launch_bounds__(256) void unary_kernel(const float* x, float* y, long n, int kind, float alpha, float beta) {
+    long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        v.x = apply_act(v.x, kind, alpha, beta); v.y = apply_act(v.y, kind, alpha, beta);
+        v.z = apply_act(v.z, kind, alpha, beta); v.w = apply_act(v.w, kind, alpha, beta);
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        y[i] = apply_act(x[i], kind, alpha, beta);
+}
+void unary(hipStream_t s, const float* x, float* y, int64_t n, Act act) {
+    if (n == 0) return;
+    ProfScope ps(s, "unary", 8.0 * (double)n, 0.0);
+    hipLaunchKernelGGL(unary_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, x, y, (long)n, act.kind, act.alpha, act.beta);
+}
+
+struct BinP {
+    int rank, op;
+    long dims[6], sa[6], sb[6];
+    int akind;
+    float alpha, beta;
+};
+__device__ __forceinline__ float bin_op(float a, float b, int op) {
+    switch (op) {
+        case 0: return a + b;
+        case 1: return a - b;
+        case 2: return a * b;
+        case 3: return a / b;
+        default: return powf(a, b);
+    }
+}
+__global__ __launch_bounds__(256) void binary_kernel(const float* a, const float* b, float* y, long n, BinP p) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        long r = i, oa = 0, ob = 0;
+#pragma unroll
+        for (int d = 5; d >= 0; --d) {
+            if (d < p.rank) {
+                long q = r / p.dims[d]; long idx = r - q * p.dims[d]; r = q;
+                oa += idx * p.sa[d]; ob += idx * p.sb[d];
+            }
+        }
+        y[i] = apply_act(bin_op(a[oa], b[ob], p.op), p.akind, p.alpha, p.beta);
+    }
+}
+// fast paths: same shape (flat float4), and "inner broadcast" y[r][c] = a[r][c] op b[r / rep][c]-style handled by generic.
+__global__ __launch_bounds__(256) void binary_flat_kernel(const float* a, const float* b, float* y, long n, int op, int akind, float alpha, float beta) {
+    long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i], o;
+        o.x = apply_act(bin_op(u.x, v.x, op), akind, alpha, beta); o.y = apply_act(bin_op(u.y, v.y, op), akind, alpha, beta);
+        o.z = apply_act(bin_op(u.z, v.z, op), akind, alpha, beta); o.w = apply_act(bin_op(u.w, v.w, op), akind, alpha, beta);
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        y[i] = apply_act(bin_op(a[i], b[i], op), akind, alpha, beta);
+}
+// y[n][hw][c] = a[n][hw][c] op b[n or 0][c]  (per-channel / SE broadcast on NHWC); C % 4 == 0
+__global__ __launch_bounds__(256) void binary_chan_kernel(const float* a, const float* b, float* y, long total4, int C4, long hw, long b_nstride4, int op, int akind, float alpha, float beta) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        int c4 = (int)(i % C4); long pix = i / C4; long n = pix / hw;
+        float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[n * b_nstride4 + c4], o;
+        o.x = apply_act(bin_op(u.x, v.x, op), akind, alpha, beta); o.y = apply_act(bin_op(u.y, v.y, op), akind, alpha, beta);
+        o.z = apply_act(bin_op(u.z, v.z, op), akind, alpha, beta); o.w = apply_act(bin_op(u.w, v.w, op), akind, alpha, beta);
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+void binary(hipStream_t s, const float* a, const float* b, float* y, int op, int rank, const int64_t* dims,
+            const int64_t* sa, const int64_t* sb, Act post) {
+    long n = 1;
+    for (int i = 0; i < rank; ++i) n *= dims[i];
+    if (n == 0) return;
+    ProfScope ps(s, "binary", 12.0 * (double)n, (double)n);
+    // contiguity analysis
+    bool a_full = true, b_full = true;
+    long exp = 1;
+    for (int d = rank - 1; d >= 0; --d) {
+        if (dims[d] != 1) {
+            if (sa[d] != exp) a_full = false;
+            if (sb[d] != exp) b_full = false;
+        }
+        exp *= dims[d];
+    }
+    if (a_full && b_full) {
+        hipLaunchKernelGGL(binary_flat_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, a, b, y, n, op, post.kind, post.alpha, post.beta);
+        return;
+    }
+    // channel broadcast: last dim C contiguous in both, b broadcast over all middle dims, optional leading batch
+    if (a_full && rank >= 2 && (dims[rank - 1] & 3) == 0 && sb[rank - 1] == 1) {
+        bool mid_bcast = true;
+        for (int d = 1; d < rank - 1; ++d) if (dims[d] != 1 && sb[d] != 0) mid_bcast = false;
+        if (mid_bcast && (sb[0] == 0 || sb[0] == dims[rank - 1] || dims[0] == 1)) {
+            long C = dims[rank - 1], hw = 1;
+            for (int d = 1; d < rank - 1; ++d) hw *= dims[d];
+            long bn = (dims[0] == 1) ? 0 : sb[0];
+            hipLaunchKernelGGL(binary_chan_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, a, b, y, n / 4, (int)(C / 4), hw, bn / 4, op, post.kind, post.alpha, post.beta);
+            return;
+        }
+    }
+    OAR_CHECK(rank <= 6, OAR_UNSUPPORTED_OP, "binary: rank > 6");
+    BinP p;
+    p.rank = rank; p.op = op; p.akind = post.kind; p.alpha = post.alpha; p.beta = post.beta;
+    for (int i = 0; i < 6; ++i) { p.dims[i] = i < rank ? dims[i] : 1; p.sa[i] = i < rank ? sa[i] : 0; p.sb[i] = i < rank ? sb[i] : 0; }
+    hipLaunchKernelGGL(binary_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, b, y, n, p);
+}
+
+__global__ __launch_bounds__(256) void copy2d_kernel(const float* x, float* y, long rows, int c, int x_ld, int y_ld, int vec) {
+    if (vec) {
+        int c4 = c >> 2; long total = rows * c4;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            long r = i / c4; int q = (int)(i - r * c4);
+            *reinterpret_cast<float4*>(y + r * y_ld + q * 4) = *reinterpret_cast<const float4*>(x + r * x_ld + q * 4);
+        }
+    } else {
+        long total = rows * c;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            long r = i / c; int q = (int)(i - r * c);
+            y[r * y_ld + q] = x[r * x_ld + q];
+        }
+    }
+}
+void copy2d(hipStream_t s, const float* x, float* y, int64_t rows, int c, int x_ld, int y_ld) {
+    if (rows == 0 || c == 0) return;
+    ProfScope ps(s, "copy2d", 8.0 * (double)rows * c, 0.0);
+    int vec = ((c & 3) == 0 && (x_ld & 3) == 0 && (y_ld & 3) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(vec ? rows * c / 4 : rows * c)), dim3(256), 0, s, x, y, (long)rows, c, x_ld, y_ld, vec);
+}
+
+struct PermP {
+    int rank;
+    long dims[6], st[6];
+};
+__global__ __launch_bounds__(256) void permute_kernel(const float* x, float* y, long n, PermP p) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        long r = i, o = 0;
+#pragma unroll
+        for (int d = 5; d >= 0; --d) {
+            if (d < p.rank) { long q = r / p.dims[d]; o += (r - q * p.dims[d]) * p.st[d]; r = q; }
+        }
+        y[i] = x[o];
+    }
+}
+void permute(hipStream_t s, const float* x, float* y, int rank, const int64_t* out_dims, const int64_t* in_strides) {
+    OAR_CHECK(rank <= 6, OAR_UNSUPPORTED_OP, "permute: rank > 6");
+    PermP p; p.rank = rank; long n = 1;
+    for (int i = 0; i < 6; ++i) { p.dims[i] = i < rank ? out_dims[i] : 1; p.st[i] = i < rank ? in_strides[i] : 0; if (i < rank) n *= out_dims[i]; }
+    if (n == 0) return;
+    ProfScope ps(s, "permute", 8.0 * (double)n, 0.0);
+    hipLaunchKernelGGL(permute_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n, p);
+}
+
+// ------------------------------------------------------------------------------------------ batched GEMM (small, VALU)
+// 64x64 C tile per workgroup, 16x16 threads, 4x4 micro-tile, K step 16 through LDS.
+__global__ __launch_bounds__(256) void gemm_batched_kernel(GemmP p) {
+    __shared__ float As[16][65];
+    __shared__ float Bs[16][65];
+    const int b = blockIdx.z;
+    const float* A = p.A + (long)b * p.sA;
+    const float* B = p.B + (long)b * p.sB;
+    float* C = p.C + (long)b * p.sC;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < p.K; k0 += 16) {
+        for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+            int r = i >> 4, kk = i & 15;  // A: rows along M, k fastest (coalesced along K)
+            int m = m0 + r, k = k0 + kk;
+            As[kk][r] = (m < p.M && k < p.K) ? A[(long)m * p.K + k] : 0.f;
+        }
+        if (p.transB) {
+            for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+                int r = i >> 4, kk = i & 15;
+                int n = n0 + r, k = k0 + kk;
+                Bs[kk][r] = (n < p.N && k < p.K) ? B[(long)n * p.K + k] : 0.f;
+            }
+        } else {
+            for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+                int kk = i >> 6, r = i & 63;
+                int n = n0 + r, k = k0 + kk;
+                Bs[kk][r] = (n < p.N && k < p.K) ? B[(long)k * p.N + n] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], bb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; bb[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], bb[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + ty * 4 + i;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int n = n0 + tx * 4 + j;
+            if (n >= p.N) continue;
+            float v = acc[i][j] * p.alpha;
+            if (p.bias) v += p.bias[n];
+            if (p.residual) v += p.residual[(long)b * p.sC + (long)m * p.N + n];
+            C[(long)m * p.N + n] = apply_act(v, p.act.kind, p.act.alpha, p.act.beta);
+        }
+    }
+}
+void gemm_batched(hipStream_t s, const GemmP& p) {
+    if (p.batch == 0 || p.M == 0 || p.N == 0) return;
+    ProfScope ps(s, "gemm_batched", 4.0 * (double)p.batch * ((double)p.M * p.K + (double)p.K * p.N + (double)p.M * p.N), 2.0 * (double)p.batch * p.M * p.N * p.K);
+    dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, p.batch);
+    hipLaunchKernelGGL(gemm_batched_kernel, grid, dim3(256), 0, s, p);
+}
+
+// ------------------------------------------------------------------------------------------ layernorm / softmax
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// one wave per row
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* g, const float* b, float* y, long rows, int C, float eps) {
+    long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + row * C;
+    float s = 0.f;
+    for (int i = lane; i < C; i += 64) s += xr[i];
+    float mean = wave_sum(s) / (float)C;
+    float v = 0.f;
+    for (int i = lane; i < C; i += 64) { float d = xr[i] - mean; v += d * d; }
+    float var = wave_sum(v) / (float)C;
+    float inv = 1.0f / sqrtf(var + eps);
+    for (int i = lane; i < C; i += 64) {
+        float t = (xr[i] - mean) * inv;
+        if (g) t *= g[i];
+        if (b) t += b[i];
+        y[row * C + i] = t;
+    }
+}
+void layernorm(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C, float eps) {
+    if (rows == 0) return;
+    ProfScope ps(s, "layernorm", 8.0 * (double)rows * C, 8.0 * (double)rows * C);
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, gamma, beta, y, (long)rows, C, eps);
+}
+
+// Softmax over the last dim. Small C: one wave per row; large C (CTC vocab): one workgroup per row.
+__global__ __launch_bounds__(256) void softmax_wave_kernel(const float* x, float* y, long rows, int C) {
+    long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + row * C;
+    float m = -3.402823466e38f;
+    for (int i = lane; i < C; i += 64) m = fmaxf(m, xr[i]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int i = lane; i < C; i += 64) s += expf(xr[i] - m);
+    s = wave_sum(s);
+    for (int i = lane; i < C; i += 64) y[row * C + i] = expf(xr[i] - m) / s;
+}
+__global__ __launch_bounds__(256) void softmax_block_kernel(const float* x, float* y, int C) {
+    __shared__ float red[4];
+    __shared__ float bcast;
+    const long row = blockIdx.x;
+    const float* xr = x + row * C;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float m = -3.402823466e38f;
+    for (int i = tid; i < C; i += 256) m = fmaxf(m, xr[i]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    if (tid == 0) bcast = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    m = bcast;
+    float s = 0.f;
+    for (int i = tid; i < C; i += 256) s += expf(xr[i] - m);
+    s = wave_sum(s);
+    __syncthreads();
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) bcast = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    s = bcast;
+    for (int i = tid; i < C; i += 256) y[row * C + i] = expf(xr[i] - m) / s;
+}
+void softmax_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C) {
+    if (rows == 0 || C == 0) return;
+    ProfScope ps(s, "softmax", 8.0 * (double)rows * C, 4.0 * (double)rows * C);
+    if (C <= 1024) hipLaunchKernelGGL(softmax_wave_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, y, (long)rows, C);
+    else hipLaunchKernelGGL(softmax_block_kernel, dim3((unsigned)rows), dim3(256), 0, s, x, y, C);
+}
+
+}  // namespace k
+}  // namespace oar

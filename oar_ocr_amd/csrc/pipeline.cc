@@ -1,0 +1,511 @@
+#include "pipeline.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace oar {
+
+// ================================================================================================= thread pool
+ThreadPool::ThreadPool(int n) {
+    if (n <= 0) n = (int)std::thread::hardware_concurrency();
+    if (n <= 0) n = 1;
+    if (n > 64) n = 64;
+    for (int i = 0; i < n - 1; ++i) workers_.emplace_back([this] { loop(); });
+}
+ThreadPool::~ThreadPool() {
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+}
+void ThreadPool::loop() {
+    int seen = 0;
+    while (true) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || (gen_ != seen && next_ < count_); });
+        if (stop_) return;
+        seen = gen_;
+        while (next_ < count_) {
+            int i = next_++;
+            ++active_;
+            lk.unlock();
+            try {
+                (*fn_)(i);
+            } catch (...) {
+                std::lock_guard<std::mutex> g(mu_);
+                if (!err_) err_ = std::current_exception();
+            }
+            lk.lock();
+            --active_;
+        }
+        if (active_ == 0) done_cv_.notify_all();
+    }
+}
+void ThreadPool::parallel_for(int count, const std::function<void(int)>& fn) {
+    if (count <= 0) return;
+    if (workers_.empty() || count == 1) {
+        for (int i = 0; i < count; ++i) fn(i);
+        return;
+    }
+    std::unique_lock<std::mutex> lk(mu_);
+    fn_ = &fn; next_ = 0; count_ = count; err_ = nullptr; ++gen_;
+    cv_.notify_all();
+    while (next_ < count_) {  // the caller works too
+        int i = next_++;
+        ++active_;
+        lk.unlock();
+        try {
+            fn(i);
+        } catch (...) {
+            std::lock_guard<std::mutex> g(mu_);
+            if (!err_) err_ = std::current_exception();
+        }
+        lk.lock();
+        --active_;
+    }
+    done_cv_.wait(lk, [&] { return active_ == 0; });
+    fn_ = nullptr; count_ = 0; next_ = 0;
+    if (err_) { auto e = err_; err_ = nullptr; std::rethrow_exception(e); }
+}
+
+// ================================================================================================= detector
+static const int kDbSrc[3] = {2, 1, 0};  // ColorOrder::BGR (models/detection/db.rs:409-415)
+
+Detector::Detector(const uint8_t* onnx, size_t len, const oar_det_cfg& cfg) : cfg_(cfg) {
+    if (cfg_.limit_side_len == 0) cfg_.limit_side_len = 960;
+    if (cfg_.max_side_limit == 0) cfg_.max_side_limit = 4000;
+    if (cfg_.max_candidates == 0) cfg_.max_candidates = 1000;
+    eng_.reset(new Engine(onnx, len, cfg_.device_id));
+    pool_.reset(new ThreadPool(cfg_.host_threads));
+}
+
+namespace {
+struct Candidate { float pts[8]; };
+
+void page_candidates(const uint8_t* mask, int H, int W, uint32_t max_candidates, std::vector<Candidate>& out) {
+    out.clear();
+    std::vector<host::Contour> cs = host::find_contours(mask, W, H, max_candidates);
+    for (auto& c : cs) {
+        std::vector<host::Pt> simp = host::simplify_chain(c.pts);
+        host::Pt mb[4];
+        float min_side = 0.f;
+        bool ok = simp.size() >= 3 ? host::mini_box(simp, mb, min_side) : host::mini_box(c.pts, mb, min_side);
+        if (!ok) continue;
+        if (min_side < 3.0f) continue;  // DBPostProcess::min_size (db_postprocess.rs:83)
+        Candidate cd;
+        for (int i = 0; i < 4; ++i) { cd.pts[i * 2] = mb[i].x; cd.pts[i * 2 + 1] = mb[i].y; }
+        out.push_back(cd);
+    }
+}
+
+void finish_boxes(const std::vector<Candidate>& cands, const float* scores, int H, int W, uint32_t src_w, uint32_t src_h, float box_thresh,
+                  float unclip_ratio, DetBoxes& out) {
+    out.pts.clear(); out.scores.clear();
+    const float wscale = (float)src_w / (float)W, hscale = (float)src_h / (float)H;
+    const float dwf = (float)src_w, dhf = (float)src_h;
+    for (size_t i = 0; i < cands.size(); ++i) {
+        float score = scores[i];
+        if (score < box_thresh) continue;
+        host::Pt mb[4];
+        for (int k = 0; k < 4; ++k) mb[k] = {cands[i].pts[k * 2], cands[i].pts[k * 2 + 1]};
+        std::vector<host::Pt> un = host::unclip(mb, unclip_ratio);
+        if (un.empty()) continue;
+        host::Pt bp[4];
+        float sside = 0.f;
+        if (!host::mini_box(un, bp, sside)) continue;
+        if (sside < 3.0f + 2.0f) continue;
+        for (int k = 0; k < 4; ++k) {
+            float x = std::round(bp[k].x * wscale), y = std::round(bp[k].y * hscale);
+            x = x < 0.0f ? 0.0f : (x > dwf ? dwf : x);
+            y = y < 0.0f ? 0.0f : (y > dhf ? dhf : y);
+            out.pts.push_back(x); out.pts.push_back(y);
+        }
+        out.scores.push_back(score);
+    }
+}
+}  // namespace
+
+void Detector::run(const std::vector<PageRef>& pages, float thresh, float box_thresh, float unclip, std::vector<DetBoxes>& out,
+                   std::vector<const uint8_t*>* dev_pages_out) {
+    std::lock_guard<std::mutex> lk(mu_);
+    const int n = (int)pages.size();
+    out.assign(n, DetBoxes());
+    if (n == 0) return;
+    OAR_HIP(hipSetDevice(eng_->device()));
+    hipStream_t s = eng_->stream();
+    // stage host pages into HBM
+    size_t total = 0;
+    for (auto& p : pages) {
+        OAR_CHECK(p.w > 0 && p.h > 0 && (p.host || p.dev), OAR_INVALID_INPUT, "detector: empty page");
+        if (!p.dev) total += ((size_t)p.w * p.h * 3 + 255) & ~(size_t)255;
+    }
+    if (total > pages_dev_.cap) { OAR_HIP(hipStreamSynchronize(s)); pages_dev_.reserve(total); }
+    page_ptrs_.assign(n, nullptr);
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        if (pages[i].dev) { page_ptrs_[i] = pages[i].dev; continue; }
+        uint8_t* d = pages_dev_.as<uint8_t>() + off;
+        size_t bytes = (size_t)pages[i].w * pages[i].h * 3;
+        OAR_HIP(hipMemcpyAsync(d, pages[i].host, bytes, hipMemcpyHostToDevice, s));
+        page_ptrs_[i] = d;
+        off += (bytes + 255) & ~(size_t)255;
+    }
+    if (dev_pages_out) *dev_pages_out = page_ptrs_;
+    // group by resized shape, first-appearance order (models/detection/db.rs:297-309)
+    struct Group { uint32_t rh, rw; std::vector<int> idx; };
+    std::vector<Group> groups;
+    for (int i = 0; i < n; ++i) {
+        uint32_t w = pages[i].w, h = pages[i].h;
+        OAR_CHECK(h + w >= 64, OAR_UNSUPPORTED_OP, "detector: images with h+w < 64 (image_padding path) are not supported");
+        uint32_t rh, rw;
+        host::det_resize_dims(w, h, cfg_.limit_side_len, cfg_.limit_type, cfg_.max_side_limit, rh, rw);
+        bool placed = false;
+        for (auto& g : groups) if (g.rh == rh && g.rw == rw) { g.idx.push_back(i); placed = true; break; }
+        if (!placed) groups.push_back({rh, rw, {i}});
+    }
+    for (auto& g : groups) run_group(g.idx, pages, g.rh, g.rw, thresh, box_thresh, unclip, out);
+}
+
+void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>& pages, uint32_t rh, uint32_t rw, float thresh,
+                         float box_thresh, float unclip, std::vector<DetBoxes>& out) {
+    hipStream_t s = eng_->stream();
+    const int B = (int)idx.size();
+    const size_t plane = (size_t)rh * rw;
+    // DB normalisation constants (processors/normalization.rs:142-143, f32): alpha = scale/std, beta = -mean/std
+    const float scale = 1.0f / 255.0f;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    float alpha[3], beta[3];
+    for (int c = 0; c < 3; ++c) { alpha[c] = scale / stdv[c]; beta[c] = -mean[c] / stdv[c]; }
+
+    size_t need_in = (size_t)B * plane * 3 * sizeof(float);
+    size_t need_rs = 0;
+    for (int b = 0; b < B; ++b) if (pages[idx[b]].w != rw || pages[idx[b]].h != rh) need_rs += (plane * 3 + 255) & ~(size_t)255;
+    if (need_in > input_f32_.cap || need_rs > resized_dev_.cap) {
+        OAR_HIP(hipStreamSynchronize(s));
+        input_f32_.reserve(need_in);
+        resized_dev_.reserve(need_rs);
+    }
+    size_t rs_off = 0;
+    for (int b = 0; b < B; ++b) {
+        const PageRef& pg = pages[idx[b]];
+        const uint8_t* src = page_ptrs_[idx[b]];
+        if (pg.w != rw || pg.h != rh) {
+            uint8_t* dst = resized_dev_.as<uint8_t>() + rs_off;
+            pp::resize_triangle(s, src, (int)pg.w, (int)pg.h, dst, (int)rw, (int)rh);
+            src = dst;
+            rs_off += (plane * 3 + 255) & ~(size_t)255;
+        }
+        pp::normalize(s, src, input_f32_.as<float>() + (size_t)b * plane * 3, 1, (int64_t)plane, kDbSrc, alpha, beta, 1);
+    }
+    const Plan& plan = eng_->run(input_f32_.as<float>(), {B, 3, (int64_t)rh, (int64_t)rw}, true);
+    OAR_CHECK(!plan.outputs.empty(), OAR_INTERNAL, "DB: no output returned from inference");
+    const PlanOutput& po = plan.outputs[0];
+    OAR_CHECK(po.dims.size() == 4 && po.dims[0] == B, OAR_SHAPE_MISMATCH, "DB: expected a 4-D [batch,1,H,W] output");
+    const int C = (int)po.dims[1], H = (int)po.dims[2], W = (int)po.dims[3];
+    const float* pred = eng_->out_ptr(po.loc);
+    const size_t hw = (size_t)H * W;
+    const size_t need_mask = (size_t)B * hw + (C != 1 ? (size_t)B * hw * 4 : 0);
+    if (need_mask > mask_dev_.cap) { OAR_HIP(hipStreamSynchronize(s)); mask_dev_.reserve(need_mask); }
+    mask_host_.reserve((size_t)B * hw);
+    if (C != 1) {  // only channel 0 is used (processors/db_postprocess.rs:122-123)
+        float* compact = reinterpret_cast<float*>(mask_dev_.as<uint8_t>() + (((size_t)B * hw + 255) & ~(size_t)255));
+        OAR_CHECK((((size_t)B * hw + 255) & ~(size_t)255) + (size_t)B * hw * 4 <= mask_dev_.cap, OAR_INTERNAL, "mask buffer sizing");
+        k::copy2d(s, pred, compact, B, (int)hw, (int)(hw * C), (int)hw);
+        pred = compact;
+    }
+    pp::threshold(s, pred, mask_dev_.as<uint8_t>(), (int64_t)B * hw, thresh);
+    OAR_HIP(hipMemcpyAsync(mask_host_.p, mask_dev_.p, (size_t)B * hw, hipMemcpyDeviceToHost, s));
+    OAR_HIP(hipStreamSynchronize(s));
+
+    std::vector<std::vector<Candidate>> cands(B);
+    const uint8_t* mh = mask_host_.as<uint8_t>();
+    const uint32_t maxc = cfg_.max_candidates;
+    pool_->parallel_for(B, [&](int b) { page_candidates(mh + (size_t)b * hw, H, W, maxc, cands[b]); });
+
+    size_t total = 0;
+    std::vector<size_t> base(B + 1, 0);
+    for (int b = 0; b < B; ++b) { base[b] = total; total += cands[b].size(); }
+    base[B] = total;
+    std::vector<float> scores(total, 0.f);
+    if (total) {
+        boxes_host_.reserve(total * sizeof(pp::ScoreBox));
+        scores_host_.reserve(total * sizeof(float));
+        if (total * sizeof(pp::ScoreBox) > boxes_dev_.cap || total * sizeof(float) > scores_dev_.cap) {
+            boxes_dev_.reserve(total * sizeof(pp::ScoreBox));
+            scores_dev_.reserve(total * sizeof(float));
+        }
+        pp::ScoreBox* sb = boxes_host_.as<pp::ScoreBox>();
+        for (int b = 0; b < B; ++b)
+            for (size_t i = 0; i < cands[b].size(); ++i) {
+                pp::ScoreBox& x = sb[base[b] + i];
+                std::memcpy(x.pts, cands[b][i].pts, sizeof x.pts);
+                x.image = b; x.pad = 0;
+            }
+        OAR_HIP(hipMemcpyAsync(boxes_dev_.p, sb, total * sizeof(pp::ScoreBox), hipMemcpyHostToDevice, s));
+        pp::box_scores(s, pred, H, W, boxes_dev_.as<pp::ScoreBox>(), (int)total, scores_dev_.as<float>());
+        OAR_HIP(hipMemcpyAsync(scores_host_.p, scores_dev_.p, total * sizeof(float), hipMemcpyDeviceToHost, s));
+        OAR_HIP(hipStreamSynchronize(s));
+        std::memcpy(scores.data(), scores_host_.p, total * sizeof(float));
+    }
+    pool_->parallel_for(B, [&](int b) {
+        const PageRef& pg = pages[idx[b]];
+        finish_boxes(cands[b], scores.data() + base[b], H, W, pg.w, pg.h, box_thresh, unclip, out[idx[b]]);
+    });
+    if (Profiler::get().enabled) Profiler::get().flush();
+}
+
+void Detector::postprocess_host(const float* pred, int H, int W, uint32_t src_w, uint32_t src_h, float thresh, float box_thresh,
+                                float unclip, uint32_t max_candidates, DetBoxes& out) {
+    // Stand-alone DB post-processing on a host probability map (parity hook for a7..a12): same kernels, tiny batch.
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) fail(OAR_DEVICE, "no HIP device visible: libOarMi355x has no CPU fallback");
+    const size_t hw = (size_t)H * W;
+    DevBuf dpred, dmask, dboxes, dscores;
+    dpred.reserve(hw * 4); dmask.reserve(hw);
+    OAR_HIP(hipMemcpy(dpred.p, pred, hw * 4, hipMemcpyHostToDevice));
+    pp::threshold(nullptr, dpred.as<float>(), dmask.as<uint8_t>(), (int64_t)hw, thresh);
+    std::vector<uint8_t> mask(hw);
+    OAR_HIP(hipMemcpy(mask.data(), dmask.p, hw, hipMemcpyDeviceToHost));
+    std::vector<Candidate> cands;
+    page_candidates(mask.data(), H, W, max_candidates ? max_candidates : 1000, cands);
+    std::vector<float> scores(cands.size(), 0.f);
+    if (!cands.empty()) {
+        std::vector<pp::ScoreBox> sb(cands.size());
+        for (size_t i = 0; i < cands.size(); ++i) { std::memcpy(sb[i].pts, cands[i].pts, sizeof sb[i].pts); sb[i].image = 0; sb[i].pad = 0; }
+        dboxes.reserve(sb.size() * sizeof(pp::ScoreBox)); dscores.reserve(sb.size() * 4);
+        OAR_HIP(hipMemcpy(dboxes.p, sb.data(), sb.size() * sizeof(pp::ScoreBox), hipMemcpyHostToDevice));
+        pp::box_scores(nullptr, dpred.as<float>(), H, W, dboxes.as<pp::ScoreBox>(), (int)sb.size(), dscores.as<float>());
+        OAR_HIP(hipMemcpy(scores.data(), dscores.p, sb.size() * 4, hipMemcpyDeviceToHost));
+    }
+    finish_boxes(cands, scores.data(), H, W, src_w, src_h, box_thresh, unclip, out);
+}
+
+// ================================================================================================= recognizer
+Recognizer::Recognizer(const uint8_t* onnx, size_t len, const oar_rec_cfg& cfg) : cfg_(cfg) {
+    if (cfg_.rec_image_shape[0] == 0) { cfg_.rec_image_shape[0] = 3; cfg_.rec_image_shape[1] = 48; cfg_.rec_image_shape[2] = 320; }
+    if (cfg_.max_img_w == 0) cfg_.max_img_w = 3200;
+    eng_.reset(new Engine(onnx, len, cfg_.device_id));
+}
+
+const float* Recognizer::pack(const std::vector<Crop>& crops, int& Wt, bool nchw) {
+    hipStream_t s = eng_->stream();
+    const int n = (int)crops.size();
+    const int img_h = (int)cfg_.rec_image_shape[1], img_w = (int)cfg_.rec_image_shape[2];
+    std::vector<uint32_t> ws(n), hs(n);
+    size_t stage = 0;
+    for (int i = 0; i < n; ++i) {
+        OAR_CHECK(crops[i].w > 0 && crops[i].h > 0 && (crops[i].host || crops[i].dev), OAR_INVALID_INPUT, "recognizer: empty crop");
+        ws[i] = crops[i].w; hs[i] = crops[i].h;
+        if (!crops[i].dev) stage += ((size_t)crops[i].w * crops[i].h * 3 + 63) & ~(size_t)63;
+    }
+    std::vector<int32_t> rws;
+    Wt = host::rec_tensor_width(ws, hs, img_h, img_w, (int)cfg_.max_img_w, rws);
+    size_t need_in = (size_t)n * 3 * img_h * Wt * sizeof(float);
+    if (stage > crops_dev_.cap || need_in > input_f32_.cap || (size_t)n * sizeof(pp::CropDesc) > descs_dev_.cap) {
+        OAR_HIP(hipStreamSynchronize(s));
+        crops_dev_.reserve(stage); input_f32_.reserve(need_in); descs_dev_.reserve((size_t)n * sizeof(pp::CropDesc));
+    }
+    descs_host_.reserve((size_t)n * sizeof(pp::CropDesc));
+    stage_host_.reserve(stage);
+    pp::CropDesc* dh = descs_host_.as<pp::CropDesc>();
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        const uint8_t* d = crops[i].dev;
+        if (!d) {
+            size_t bytes = (size_t)crops[i].w * crops[i].h * 3;
+            std::memcpy(stage_host_.as<uint8_t>() + off, crops[i].host, bytes);
+            d = crops_dev_.as<uint8_t>() + off;
+            off += (bytes + 63) & ~(size_t)63;
+        }
+        dh[i].src = d; dh[i].w = (int)crops[i].w; dh[i].h = (int)crops[i].h; dh[i].rw = rws[i]; dh[i].pad = 0;
+    }
+    if (stage) OAR_HIP(hipMemcpyAsync(crops_dev_.p, stage_host_.p, stage, hipMemcpyHostToDevice, s));
+    OAR_HIP(hipMemcpyAsync(descs_dev_.p, dh, (size_t)n * sizeof(pp::CropDesc), hipMemcpyHostToDevice, s));
+    pp::rec_pack(s, descs_dev_.as<pp::CropDesc>(), n, img_h, Wt, input_f32_.as<float>(), nchw ? 1 : 0);
+    return input_f32_.as<float>();
+}
+
+void Recognizer::pack_only(const std::vector<Crop>& crops, std::vector<float>& nchw, uint32_t& Wt_out) {
+    std::lock_guard<std::mutex> lk(mu_);
+    OAR_HIP(hipSetDevice(eng_->device()));
+    nchw.clear(); Wt_out = 0;
+    if (crops.empty()) return;
+    int Wt = 0;
+    const float* d = pack(crops, Wt, true);
+    size_t cnt = crops.size() * 3 * (size_t)cfg_.rec_image_shape[1] * Wt;
+    nchw.resize(cnt);
+    OAR_HIP(hipMemcpyAsync(nchw.data(), d, cnt * 4, hipMemcpyDeviceToHost, eng_->stream()));
+    OAR_HIP(hipStreamSynchronize(eng_->stream()));
+    Wt_out = (uint32_t)Wt;
+}
+
+void Recognizer::run(const std::vector<Crop>& crops, RecOut& out) {
+    std::lock_guard<std::mutex> lk(mu_);
+    out = RecOut();
+    const int n = (int)crops.size();
+    if (n == 0) return;
+    OAR_HIP(hipSetDevice(eng_->device()));
+    hipStream_t s = eng_->stream();
+    int Wt = 0;
+    const float* in = pack(crops, Wt, false);
+    const int img_h = (int)cfg_.rec_image_shape[1];
+    const Plan& plan = eng_->run(in, {n, 3, img_h, Wt}, true);
+    OAR_CHECK(!plan.outputs.empty(), OAR_INTERNAL, "CRNN: no output returned from inference");
+    const PlanOutput& po = plan.outputs[0];
+    OAR_CHECK(po.dims.size() == 3, OAR_SHAPE_MISMATCH, "CRNN: expected 3D output (batch, time, vocab)");  // crnn.rs:273-279
+    OAR_CHECK(po.dims[0] == n, OAR_SHAPE_MISMATCH, "CRNN: output batch differs from input batch");
+    const int64_t T = po.dims[1], V = po.dims[2];
+    const int64_t rows = (int64_t)n * T;
+    out.T = (uint32_t)T; out.V = (uint32_t)V; out.Wt = (uint32_t)Wt;
+    if (rows == 0 || V == 0) return;
+    if ((size_t)rows * 8 > idx_dev_.cap || (size_t)rows * 4 > prob_dev_.cap) {
+        OAR_HIP(hipStreamSynchronize(s));
+        idx_dev_.reserve((size_t)rows * 8); prob_dev_.reserve((size_t)rows * 4);
+    }
+    idx_host_.reserve((size_t)rows * 8); prob_host_.reserve((size_t)rows * 4);
+    pp::ctc_argmax(s, eng_->out_ptr(po.loc), rows, (int)V, idx_dev_.as<int64_t>(), prob_dev_.as<float>());
+    OAR_HIP(hipMemcpyAsync(idx_host_.p, idx_dev_.p, (size_t)rows * 8, hipMemcpyDeviceToHost, s));
+    OAR_HIP(hipMemcpyAsync(prob_host_.p, prob_dev_.p, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
+    OAR_HIP(hipStreamSynchronize(s));
+    out.idx.assign(idx_host_.as<int64_t>(), idx_host_.as<int64_t>() + rows);
+    out.prob.assign(prob_host_.as<float>(), prob_host_.as<float>() + rows);
+    if (Profiler::get().enabled) Profiler::get().flush();
+}
+
+// ================================================================================================= OCR pipeline
+Ocr::Ocr(const uint8_t* det, size_t det_len, const uint8_t* rec, size_t rec_len, const oar_ocr_cfg& cfg) : cfg_(cfg) {
+    if (cfg_.image_batch_size == 0) cfg_.image_batch_size = 8;     // text_detection_adapter.rs:85-87
+    if (cfg_.region_batch_size == 0) cfg_.region_batch_size = 64;  // text_recognition_adapter.rs:117-127
+    if (cfg_.max_pooled_crops == 0) cfg_.max_pooled_crops = 4096;  // src/oarocr/ocr.rs:603
+    OAR_CHECK(cfg_.image_batch_size <= 4096 && cfg_.region_batch_size <= 4096, OAR_INVALID_INPUT,
+              "batch sizes must be in 1..=4096");                  // src/oarocr/ocr.rs:250-255,419-430
+    det_.reset(new Detector(det, det_len, cfg_.det));
+    rec_.reset(new Recognizer(rec, rec_len, cfg_.rec));
+}
+
+void Ocr::predict(const std::vector<PageRef>& pages, std::vector<std::vector<OcrRegion>>& out) {
+    std::lock_guard<std::mutex> lk(mu_);
+    OAR_CHECK(!pages.empty(), OAR_INVALID_INPUT, "OCR Pipeline: images must be a non-empty slice");  // ocr.rs:525-532
+    const int n = (int)pages.size();
+    OAR_HIP(hipSetDevice(det_->engine().device()));
+    hipStream_t s = det_->engine().stream();
+    struct PoolItem { int img; int det_index; uint32_t w, h; float wh_ratio; size_t off; };
+    struct Slot { bool filled = false; OcrRegion r; };
+    std::vector<std::vector<Slot>> per_image(n);
+    std::vector<PoolItem> pool;
+    size_t pool_bytes = 0;
+    const float base_ratio = (float)cfg_.rec.rec_image_shape[2] > 0 ? (float)cfg_.rec.rec_image_shape[2] / (float)cfg_.rec.rec_image_shape[1] : 320.0f / 48.0f;
+
+    auto flush = [&]() {
+        if (pool.empty()) return;
+        OAR_HIP(hipStreamSynchronize(s));  // crops complete
+        std::vector<PoolItem> sorted = pool;
+        std::stable_sort(sorted.begin(), sorted.end(), [](const PoolItem& a, const PoolItem& b) { return a.wh_ratio < b.wh_ratio; });
+        const size_t bs = cfg_.region_batch_size;
+        for (size_t c0 = 0; c0 < sorted.size(); c0 += bs) {
+            size_t c1 = std::min(sorted.size(), c0 + bs);
+            std::vector<Recognizer::Crop> crops;
+            float chunk_max = base_ratio;
+            for (size_t i = c0; i < c1; ++i) {
+                Recognizer::Crop c;
+                c.dev = crop_pool_.as<uint8_t>() + sorted[i].off; c.w = sorted[i].w; c.h = sorted[i].h;
+                crops.push_back(c);
+                if (sorted[i].wh_ratio > chunk_max) chunk_max = sorted[i].wh_ratio;
+            }
+            RecOut ro;
+            rec_->run(crops, ro);
+            for (size_t i = c0; i < c1; ++i) {
+                Slot& sl = per_image[sorted[i].img][sorted[i].det_index];
+                sl.filled = true;
+                sl.r.T = ro.T; sl.r.max_wh_ratio = chunk_max;
+                size_t k = i - c0;
+                sl.r.idx.assign(ro.idx.begin() + k * ro.T, ro.idx.begin() + (k + 1) * ro.T);
+                sl.r.prob.assign(ro.prob.begin() + k * ro.T, ro.prob.begin() + (k + 1) * ro.T);
+            }
+        }
+        pool.clear();
+        pool_bytes = 0;
+    };
+
+    for (int start = 0; start < n; start += (int)cfg_.image_batch_size) {
+        const int end = std::min(n, start + (int)cfg_.image_batch_size);
+        std::vector<PageRef> chunk(pages.begin() + start, pages.begin() + end);
+        std::vector<DetBoxes> boxes;
+        std::vector<const uint8_t*> dev_pages;
+        det_->run(chunk, cfg_.det_thresh, cfg_.det_box_thresh, cfg_.det_unclip_ratio, boxes, &dev_pages);
+        // sort + plan crops (host), then one warp launch for the whole chunk
+        struct Planned { int img; int det_index; host::CropPlan plan; };
+        std::vector<Planned> planned;
+        for (int li = 0; li < end - start; ++li) {
+            const int img = start + li;
+            std::vector<int> order = host::sort_quad_boxes(boxes[li].pts);
+            per_image[img].resize(order.size());
+            for (size_t k = 0; k < order.size(); ++k) {
+                Slot& sl = per_image[img][k];
+                std::memcpy(sl.r.pts, boxes[li].pts.data() + (size_t)order[k] * 8, sizeof sl.r.pts);
+                sl.r.det_score = boxes[li].scores[order[k]];
+                host::CropPlan pl = host::plan_crop((int)pages[img].w, (int)pages[img].h, sl.r.pts);
+                if (pl.mode == 0) continue;  // crop failure => region dropped (ocr.rs:736-738)
+                sl.r.crop_w = (uint32_t)pl.out_w(); sl.r.crop_h = (uint32_t)pl.out_h();
+                planned.push_back({img, (int)k, pl});
+            }
+        }
+        size_t pi = 0;
+        while (pi < planned.size()) {
+            // respect the pool cap exactly like the reference's per-crop flush check
+            size_t room = cfg_.max_pooled_crops - pool.size();
+            size_t take = std::min(room, planned.size() - pi);
+            size_t add_bytes = 0;
+            int max_px = 0;
+            for (size_t q = pi; q < pi + take; ++q) {
+                const host::CropPlan& pl = planned[q].plan;
+                add_bytes += ((size_t)pl.out_w() * pl.out_h() * 3 + 63) & ~(size_t)63;
+                max_px = std::max(max_px, pl.out_w() * pl.out_h());
+            }
+            if (pool_bytes + add_bytes > crop_pool_.cap) {
+                // grow while preserving existing crops
+                OAR_HIP(hipStreamSynchronize(s));
+                DevBuf bigger;
+                bigger.reserve((pool_bytes + add_bytes) * 2);
+                if (pool_bytes) OAR_HIP(hipMemcpy(bigger.p, crop_pool_.p, pool_bytes, hipMemcpyDeviceToDevice));
+                std::swap(bigger.p, crop_pool_.p); std::swap(bigger.cap, crop_pool_.cap);
+            }
+            warp_descs_host_.reserve(take * sizeof(pp::WarpDesc));
+            if (take * sizeof(pp::WarpDesc) > warp_descs_dev_.cap) { OAR_HIP(hipStreamSynchronize(s)); warp_descs_dev_.reserve(take * sizeof(pp::WarpDesc)); }
+            else OAR_HIP(hipStreamSynchronize(s));  // previous launch may still read the pinned descriptors
+            pp::WarpDesc* wd = warp_descs_host_.as<pp::WarpDesc>();
+            for (size_t q = 0; q < take; ++q) {
+                const Planned& P = planned[pi + q];
+                const host::CropPlan& pl = P.plan;
+                pp::WarpDesc& d = wd[q];
+                d.page = dev_pages[P.img - start]; d.page_w = (int)pages[P.img].w; d.page_h = (int)pages[P.img].h;
+                d.left = pl.left; d.top = pl.top; d.cw = pl.cw; d.ch = pl.ch; d.ow = pl.ow; d.oh = pl.oh; d.rot = pl.rot; d.mode = pl.mode;
+                std::memcpy(d.inv, pl.inv, sizeof d.inv);
+                d.out_off = (int64_t)pool_bytes;
+                PoolItem it;
+                it.img = P.img; it.det_index = P.det_index; it.w = (uint32_t)pl.out_w(); it.h = (uint32_t)pl.out_h();
+                it.wh_ratio = (float)it.w / (float)std::max<uint32_t>(it.h, 1);  // ocr.rs:739
+                it.off = pool_bytes;
+                pool.push_back(it);
+                pool_bytes += ((size_t)it.w * it.h * 3 + 63) & ~(size_t)63;
+            }
+            OAR_HIP(hipMemcpyAsync(warp_descs_dev_.p, wd, take * sizeof(pp::WarpDesc), hipMemcpyHostToDevice, s));
+            pp::rotate_crops(s, warp_descs_dev_.as<pp::WarpDesc>(), (int)take, crop_pool_.as<uint8_t>(), max_px);
+            pi += take;
+            if (pool.size() >= cfg_.max_pooled_crops) flush();
+        }
+        // the detector's page staging buffer is reused by the next chunk: crops must be done first
+        OAR_HIP(hipStreamSynchronize(s));
+    }
+    flush();
+    out.assign(n, {});
+    for (int i = 0; i < n; ++i)
+        for (auto& sl : per_image[i])
+            if (sl.filled) out[i].push_back(std::move(sl.r));
+    if (Profiler::get().enabled) Profiler::get().flush();
+}
+
+}  // namespace oar

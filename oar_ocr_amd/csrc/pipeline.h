@@ -1,0 +1,122 @@
+// pipeline.h -- the MI355X stand-ins for the reference's text-detection / text-recognition adapters and
+// for OAROCR::predict (src/oarocr/ocr.rs:518-659).
+#pragma once
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "db_host.h"
+#include "engine.h"
+#include "prepost.h"
+
+namespace oar {
+
+class ThreadPool {
+   public:
+    explicit ThreadPool(int n);
+    ~ThreadPool();
+    void parallel_for(int count, const std::function<void(int)>& fn);
+    int size() const { return (int)workers_.size(); }
+
+   private:
+    void loop();
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int next_ = 0, count_ = 0, active_ = 0, gen_ = 0;
+    bool stop_ = false;
+    std::exception_ptr err_;
+};
+
+struct PageRef {              // one input page (RGB8 HWC)
+    const uint8_t* host = nullptr;
+    const uint8_t* dev = nullptr;
+    uint32_t w = 0, h = 0;
+};
+
+struct DetBoxes {             // per image, discovery order
+    std::vector<float> pts;   // n*8
+    std::vector<float> scores;
+};
+
+// TextDetectionAdapter + DBModel (domain/adapters/text_detection_adapter.rs:36-79, models/detection/db.rs:281-335)
+class Detector {
+   public:
+    Detector(const uint8_t* onnx, size_t len, const oar_det_cfg& cfg);
+    // Pages may be host or device resident. dev_pages_out (optional) receives the device pointer of each page
+    // (uploaded copies stay valid until the next call).
+    void run(const std::vector<PageRef>& pages, float thresh, float box_thresh, float unclip, std::vector<DetBoxes>& out,
+             std::vector<const uint8_t*>* dev_pages_out = nullptr);
+    Engine& engine() { return *eng_; }
+    static void postprocess_host(const float* pred, int H, int W, uint32_t src_w, uint32_t src_h, float thresh, float box_thresh,
+                                 float unclip, uint32_t max_candidates, DetBoxes& out);
+    ThreadPool& pool() { return *pool_; }
+
+   private:
+    void run_group(const std::vector<int>& idx, const std::vector<PageRef>& pages, uint32_t rh, uint32_t rw, float thresh,
+                   float box_thresh, float unclip, std::vector<DetBoxes>& out);
+    std::unique_ptr<Engine> eng_;
+    std::unique_ptr<ThreadPool> pool_;
+    oar_det_cfg cfg_;
+    DevBuf pages_dev_, resized_dev_, input_f32_, mask_dev_, boxes_dev_, scores_dev_;
+    PinBuf mask_host_, boxes_host_, scores_host_;
+    std::vector<const uint8_t*> page_ptrs_;
+    std::mutex mu_;
+};
+
+struct RecOut {
+    uint32_t T = 0, V = 0, Wt = 0;
+    std::vector<int64_t> idx;  // n*T
+    std::vector<float> prob;
+};
+
+// TextRecognitionAdapter + CRNNModel (domain/adapters/text_recognition_adapter.rs:35-111, models/recognition/crnn.rs:247-293)
+class Recognizer {
+   public:
+    Recognizer(const uint8_t* onnx, size_t len, const oar_rec_cfg& cfg);
+    struct Crop { const uint8_t* host = nullptr; const uint8_t* dev = nullptr; uint32_t w = 0, h = 0; };
+    void run(const std::vector<Crop>& crops, RecOut& out);
+    // test hook: packed input tensor only
+    void pack_only(const std::vector<Crop>& crops, std::vector<float>& nchw, uint32_t& Wt);
+    Engine& engine() { return *eng_; }
+
+   private:
+    const float* pack(const std::vector<Crop>& crops, int& Wt, bool nchw);
+    std::unique_ptr<Engine> eng_;
+    oar_rec_cfg cfg_;
+    DevBuf crops_dev_, descs_dev_, input_f32_, idx_dev_, prob_dev_;
+    PinBuf descs_host_, idx_host_, prob_host_, stage_host_;
+    std::mutex mu_;
+};
+
+struct OcrRegion {
+    float pts[8];
+    float det_score;
+    uint32_t crop_w, crop_h, T;
+    float max_wh_ratio;
+    std::vector<int64_t> idx;
+    std::vector<float> prob;
+};
+
+// OAROCR (src/oarocr/ocr.rs)
+class Ocr {
+   public:
+    Ocr(const uint8_t* det, size_t det_len, const uint8_t* rec, size_t rec_len, const oar_ocr_cfg& cfg);
+    void predict(const std::vector<PageRef>& pages, std::vector<std::vector<OcrRegion>>& out);
+    Detector& det() { return *det_; }
+    Recognizer& rec() { return *rec_; }
+
+   private:
+    std::unique_ptr<Detector> det_;
+    std::unique_ptr<Recognizer> rec_;
+    oar_ocr_cfg cfg_;
+    DevBuf crop_pool_, warp_descs_dev_;
+    PinBuf warp_descs_host_;
+    std::mutex mu_;
+};
+
+}  // namespace oar

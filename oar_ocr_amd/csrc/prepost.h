@@ -1,0 +1,54 @@
+// prepost.h -- launchers for the pre/post-processing HIP kernels (byte / index work: bit-exact vs the reference).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace oar {
+namespace pp {
+
+// a4 processors/simd.rs:87-123. rgb: [n_pix*3] u8 (any number of tightly packed images back to back).
+// layout 0: out[c*plane + p] per image (CHW); layout 1: out[p*3 + c] (HWC / NHWC).
+void normalize(hipStream_t s, const uint8_t* rgb, float* out, int64_t n_images, int64_t plane, const int src[3],
+               const float alpha[3], const float beta[3], int layout);
+
+struct CropDesc {          // one recognizer input crop (device-resident u8 HWC)
+    const uint8_t* src;
+    int32_t w, h;          // source crop size
+    int32_t rw;            // resized width (<= tensor width)
+    int32_t pad;
+};
+// a16 models/recognition/crnn.rs:98-121 + simd.rs:248-308: Triangle resize to (rw x img_h), BGR (v/255-0.5)/0.5,
+// zero padding to Wt.  out layout: NHWC [n][img_h][Wt][3] (channel c = source channel 2-c) or NCHW when nchw != 0.
+void rec_pack(hipStream_t s, const CropDesc* d_descs, int n, int img_h, int Wt, float* out, int nchw);
+
+// image 0.25.6 imageops::resize(Triangle) on u8 RGB (processors/resize_detection.rs:314).
+void resize_triangle(hipStream_t s, const uint8_t* src, int w, int h, uint8_t* dst, int nw, int nh);
+
+// a7 processors/db_postprocess.rs:185-221
+void threshold(hipStream_t s, const float* pred, uint8_t* mask, int64_t n, float thresh);
+
+// a18 processors/decode.rs:452-501: last index of the row maximum + the maximum
+void ctc_argmax(hipStream_t s, const float* probs, int64_t rows, int vocab, int64_t* idx, float* prob);
+
+struct ScoreBox {          // a10 processors/db_score.rs:34-134
+    float pts[8];
+    int32_t image;         // which prob map of the batch
+    int32_t pad;
+};
+void box_scores(hipStream_t s, const float* pred, int height, int width, const ScoreBox* d_boxes, int n_boxes, float* d_scores);
+
+struct WarpDesc {          // a14 utils/transform.rs:76-191 (plan computed on the host)
+    const uint8_t* page;   // device u8 HWC
+    int32_t page_w, page_h;
+    int32_t left, top, cw, ch;   // AABB crop inside the page
+    int32_t ow, oh;              // warp output size BEFORE the optional rotate270
+    int32_t rot;                 // 1: output is rotate270 of the warp (out dims oh x ow)
+    int32_t mode;                // 1 axis-aligned copy, 2 perspective bicubic
+    float inv[9];                // inverse homography (dst -> src), row-major
+    int64_t out_off;             // byte offset of this crop in the output pool
+};
+void rotate_crops(hipStream_t s, const WarpDesc* d_descs, int n, uint8_t* out_pool, int max_out_pixels);
+
+}  // namespace pp
+}  // namespace oar

@@ -1,0 +1,368 @@
+// prepost.hip -- gfx950 kernels for the byte/index stages around the two networks.
+//
+// These stages are HBM-bound integer/byte work; they are NOT reshaped into GEMMs.  Each kernel restates the
+// reference's CPU loop with the same f32 operation order (compiled with -ffp-contract=off: the reference
+// never fuses mul+add, processors/simd.rs:11-14), so results are bit-identical, not merely close.
+#include "prepost.h"
+
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace oar {
+namespace pp {
+
+static inline unsigned grid_for(long work, int block = 256, long cap = 256L * 32) {
+    long g = (work + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+// ------------------------------------------------------------------------------------------ a4 normalize
+// One thread = 4 pixels = 12 source bytes (three aligned 32-bit loads) -> 12 floats.
+struct NormP {
+    int src[3];
+    float alpha[3], beta[3];
+};
+__global__ __launch_bounds__(256) void normalize_kernel(const uint8_t* __restrict__ rgb, float* __restrict__ out, long n_images,
+                                                        long plane, NormP p, int layout) {
+    const long quads_per_img = (plane + 3) >> 2;
+    const long total = n_images * quads_per_img;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long img = i / quads_per_img, q = i - img * quads_per_img;
+        long p0 = q * 4;
+        const uint8_t* s = rgb + (img * plane + p0) * 3;
+        int np = (int)min(4L, plane - p0);
+        uint8_t b[12];
+        if (np == 4 && ((reinterpret_cast<uintptr_t>(s) & 3) == 0)) {
+            const uint32_t* s4 = reinterpret_cast<const uint32_t*>(s);
+            uint32_t w0 = s4[0], w1 = s4[1], w2 = s4[2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { b[k] = (w0 >> (8 * k)) & 0xFF; b[4 + k] = (w1 >> (8 * k)) & 0xFF; b[8 + k] = (w2 >> (8 * k)) & 0xFF; }
+        } else {
+            for (int k = 0; k < np * 3; ++k) b[k] = s[k];
+        }
+        if (layout == 1) {
+            float* o = out + (img * plane + p0) * 3;
+            float v[12];
+#pragma unroll
+            for (int px = 0; px < 4; ++px)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { float t = (float)b[px * 3 + p.src[c]] * p.alpha[c]; v[px * 3 + c] = t + p.beta[c]; }
+            if (np == 4 && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
+                float4* o4 = reinterpret_cast<float4*>(o);
+                o4[0] = make_float4(v[0], v[1], v[2], v[3]);
+                o4[1] = make_float4(v[4], v[5], v[6], v[7]);
+                o4[2] = make_float4(v[8], v[9], v[10], v[11]);
+            } else {
+                for (int k = 0; k < np * 3; ++k) o[k] = v[k];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float* o = out + (img * 3 + c) * plane + p0;
+                for (int px = 0; px < np; ++px) { float t = (float)b[px * 3 + p.src[c]] * p.alpha[c]; o[px] = t + p.beta[c]; }
+            }
+        }
+    }
+}
+void normalize(hipStream_t s, const uint8_t* rgb, float* out, int64_t n_images, int64_t plane, const int src[3],
+               const float alpha[3], const float beta[3], int layout) {
+    if (n_images * plane == 0) return;
+    NormP p;
+    for (int i = 0; i < 3; ++i) { p.src[i] = src[i]; p.alpha[i] = alpha[i]; p.beta[i] = beta[i]; }
+    ProfScope ps(s, "normalize", 15.0 * (double)n_images * plane, 6.0 * (double)n_images * plane);
+    hipLaunchKernelGGL(normalize_kernel, dim3(grid_for(n_images * ((plane + 3) / 4))), dim3(256), 0, s, rgb, out, (long)n_images, (long)plane, p, layout);
+}
+
+// ------------------------------------------------------------------------------------------ Triangle resize helpers
+// image 0.25.6 imageops::sample: per output coordinate o along an axis of input length `in`:
+//   ratio = in/out; sratio = max(ratio,1); support = sratio; c = (o+0.5)*ratio;
+//   left = clamp(floor(c-support), 0, in-1); right = clamp(ceil(c+support), left+1, in);
+//   w_i = tri((i - (c-0.5))/sratio) for i in [left,right), normalised by their (sequential) sum.
+struct Taps {
+    int left, right;
+    float center, sratio, sum;
+};
+__device__ __forceinline__ float tri(float x) { float a = fabsf(x); return a < 1.0f ? 1.0f - a : 0.0f; }
+__device__ __forceinline__ Taps make_taps(int o, int in, int out) {
+    Taps t;
+    float ratio = (float)in / (float)out;
+    t.sratio = ratio < 1.0f ? 1.0f : ratio;
+    float support = 1.0f * t.sratio;
+    float c = ((float)o + 0.5f) * ratio;
+    long l = (long)floorf(c - support);
+    l = l < 0 ? 0 : (l > (long)in - 1 ? (long)in - 1 : l);
+    long r = (long)ceilf(c + support);
+    r = r < l + 1 ? l + 1 : (r > (long)in ? (long)in : r);
+    t.left = (int)l; t.right = (int)r;
+    t.center = c - 0.5f;
+    float sum = 0.0f;
+    for (int i = t.left; i < t.right; ++i) sum += tri(((float)i - t.center) / t.sratio);
+    t.sum = sum;
+    return t;
+}
+__device__ __forceinline__ float tap_w(const Taps& t, int i) { return tri(((float)i - t.center) / t.sratio) / t.sum; }
+
+// Vertical pass value (f32, unrounded) of source column x for output row described by tv.
+__device__ __forceinline__ void vertical_sum(const uint8_t* src, int w, int x, const Taps& tv, float& r, float& g, float& b) {
+    float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+    for (int j = tv.left; j < tv.right; ++j) {
+        const uint8_t* p = src + ((long)j * w + x) * 3;
+        float wv = tap_w(tv, j);
+        t0 += (float)p[0] * wv; t1 += (float)p[1] * wv; t2 += (float)p[2] * wv;
+    }
+    r = t0; g = t1; b = t2;
+}
+__device__ __forceinline__ uint8_t to_u8_round(float v) { return (uint8_t)roundf(fminf(fmaxf(v, 0.0f), 255.0f)); }
+
+__device__ __forceinline__ void resize_pixel(const uint8_t* src, int w, int h, int nw, int nh, int ox, int oy, uint8_t out[3]) {
+    if (nw == w && nh == h) {
+        const uint8_t* p = src + ((long)oy * w + ox) * 3;
+        out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
+        return;
+    }
+    Taps tv = make_taps(oy, h, nh), th = make_taps(ox, w, nw);
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+    for (int i = th.left; i < th.right; ++i) {
+        float r, g, b;
+        vertical_sum(src, w, i, tv, r, g, b);
+        float wh = tap_w(th, i);
+        a0 += r * wh; a1 += g * wh; a2 += b * wh;
+    }
+    out[0] = to_u8_round(a0); out[1] = to_u8_round(a1); out[2] = to_u8_round(a2);
+}
+
+__global__ __launch_bounds__(256) void resize_triangle_kernel(const uint8_t* src, int w, int h, uint8_t* dst, int nw, int nh) {
+    long total = (long)nw * nh;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int ox = (int)(i % nw), oy = (int)(i / nw);
+        uint8_t o[3];
+        resize_pixel(src, w, h, nw, nh, ox, oy, o);
+        dst[i * 3] = o[0]; dst[i * 3 + 1] = o[1]; dst[i * 3 + 2] = o[2];
+    }
+}
+void resize_triangle(hipStream_t s, const uint8_t* src, int w, int h, uint8_t* dst, int nw, int nh) {
+    if ((long)nw * nh == 0) return;
+    ProfScope ps(s, "resize_triangle", 3.0 * ((double)w * h + (double)nw * nh), 0.0);
+    hipLaunchKernelGGL(resize_triangle_kernel, dim3(grid_for((long)nw * nh)), dim3(256), 0, s, src, w, h, dst, nw, nh);
+}
+
+// ------------------------------------------------------------------------------------------ a16 recognizer input pack
+__global__ __launch_bounds__(256) void rec_pack_kernel(const CropDesc* descs, int img_h, int Wt, float* out, int nchw) {
+    const int n = blockIdx.y;
+    const CropDesc d = descs[n];
+    const long plane = (long)img_h * Wt;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (long)gridDim.x * blockDim.x) {
+        int ox = (int)(i % Wt), oy = (int)(i / Wt);
+        float v[3] = {0.0f, 0.0f, 0.0f};
+        if (ox < d.rw) {
+            uint8_t px[3];
+            resize_pixel(d.src, d.w, d.h, d.rw, img_h, ox, oy, px);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = ((float)px[2 - c] / 255.0f - 0.5f) / 0.5f;
+        }
+        if (nchw) {
+            float* o = out + (long)n * 3 * plane + i;
+            o[0] = v[0]; o[plane] = v[1]; o[2 * plane] = v[2];
+        } else {
+            float* o = out + ((long)n * plane + i) * 3;
+            o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+        }
+    }
+}
+void rec_pack(hipStream_t s, const CropDesc* d_descs, int n, int img_h, int Wt, float* out, int nchw) {
+    if (n == 0 || Wt == 0) return;
+    ProfScope ps(s, "rec_pack", 12.0 * (double)n * img_h * Wt, 0.0);
+    long plane = (long)img_h * Wt;
+    hipLaunchKernelGGL(rec_pack_kernel, dim3(grid_for(plane, 256, 64), n), dim3(256), 0, s, d_descs, img_h, Wt, out, nchw);
+}
+
+// ------------------------------------------------------------------------------------------ a7 threshold
+__global__ __launch_bounds__(256) void threshold_kernel(const float* __restrict__ pred, uint8_t* __restrict__ mask, long n, float thresh) {
+    long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(pred)[i];
+        uint32_t o = (v.x > thresh ? 0xFFu : 0u) | (v.y > thresh ? 0xFF00u : 0u) | (v.z > thresh ? 0xFF0000u : 0u) | (v.w > thresh ? 0xFF000000u : 0u);
+        reinterpret_cast<uint32_t*>(mask)[i] = o;
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) mask[i] = pred[i] > thresh ? 255 : 0;
+}
+void threshold(hipStream_t s, const float* pred, uint8_t* mask, int64_t n, float thresh) {
+    if (n == 0) return;
+    ProfScope ps(s, "threshold", 5.0 * (double)n, 0.0);
+    hipLaunchKernelGGL(threshold_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, pred, mask, (long)n, thresh);
+}
+
+// ------------------------------------------------------------------------------------------ a18 CTC argmax
+// One workgroup per (batch,time) row. Each lane keeps (max, LAST index attaining it) over its strided slice;
+// the reduction prefers the larger value and, on equal values, the larger index => "last max index wins".
+__device__ __forceinline__ void amax_merge(float& v, int& i, float ov, int oi) {
+    if (ov > v || (ov == v && oi > i)) { v = ov; i = oi; }
+}
+__global__ __launch_bounds__(256) void ctc_argmax_kernel(const float* __restrict__ probs, int vocab, int64_t* idx, float* prob) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const long row = blockIdx.x;
+    const float* r = probs + row * (long)vocab;
+    float best = -INFINITY;
+    int bi = 0;
+    for (int i = threadIdx.x; i < vocab; i += 256) {
+        float v = r[i];
+        if (v >= best) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(best, o, 64);
+        int oi = __shfl_xor(bi, o, 64);
+        amax_merge(best, bi, ov, oi);
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) amax_merge(best, bi, sv[w], si[w]);
+        idx[row] = bi;
+        prob[row] = best;
+    }
+}
+void ctc_argmax(hipStream_t s, const float* probs, int64_t rows, int vocab, int64_t* idx, float* prob) {
+    if (rows == 0) return;
+    OAR_CHECK(vocab > 0, OAR_INVALID_INPUT, "ctc_argmax: vocab == 0");
+    ProfScope ps(s, "ctc_argmax", 4.0 * (double)rows * vocab, 0.0);
+    hipLaunchKernelGGL(ctc_argmax_kernel, dim3((unsigned)rows), dim3(256), 0, s, probs, vocab, idx, prob);
+}
+
+// ------------------------------------------------------------------------------------------ a10 box score
+// One workgroup per box. Rows are summed left-to-right by one lane each (the reference's sequential `+=`),
+// then lane 0 adds the row sums in row order -- exactly the reference's summation tree (db_score.rs:86-132).
+__device__ __forceinline__ unsigned f2u(float v) { return v > 0.0f ? (v >= 4294967296.0f ? 0xFFFFFFFFu : (unsigned)v) : 0u; }
+__global__ __launch_bounds__(256) void box_scores_kernel(const float* pred, int height, int width, const ScoreBox* boxes, float* scores) {
+    __shared__ float rsum[256];
+    __shared__ unsigned rcnt[256];
+    const ScoreBox b = boxes[blockIdx.x];
+    const float* map = pred + (long)b.image * height * width;
+    float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float x = b.pts[i * 2], y = b.pts[i * 2 + 1];
+        if (x < mnx) mnx = x; if (x > mxx) mxx = x;
+        if (y < mny) mny = y; if (y > mxy) mxy = y;
+    }
+    float fx0 = fminf(fmaxf(floorf(mnx), 0.0f), (float)width - 1.0f), fx1 = fminf(fmaxf(ceilf(mxx), 0.0f), (float)width - 1.0f);
+    float fy0 = fminf(fmaxf(floorf(mny), 0.0f), (float)height - 1.0f), fy1 = fminf(fmaxf(ceilf(mxy), 0.0f), (float)height - 1.0f);
+    const unsigned start_y = f2u(fy0), end_y = f2u(fy1) + 1, start_x = f2u(fx0), end_x = f2u(fx1) + 1;
+    float total = 0.0f;
+    unsigned long long pixels = 0;
+    for (unsigned y0 = start_y; y0 < end_y; y0 += 256) {
+        unsigned yy = y0 + threadIdx.x;
+        float line = 0.0f;
+        unsigned lp = 0;
+        if (yy < end_y) {
+            float y = (float)yy + 0.5f;
+            float xs[4];
+            int ni = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int j = (i + 1) & 3;
+                float p1x = b.pts[i * 2], p1y = b.pts[i * 2 + 1], p2x = b.pts[j * 2], p2y = b.pts[j * 2 + 1];
+                if (((p1y <= y && y < p2y) || (p2y <= y && y < p1y)) && fabsf(p2y - p1y) > 1.1920929e-7f) {
+                    float x = p1x + (y - p1y) * (p2x - p1x) / (p2y - p1y);
+                    xs[ni++] = x;
+                }
+            }
+            for (int i = 1; i < ni; ++i) { float k = xs[i]; int j = i - 1; while (j >= 0 && xs[j] > k) { xs[j + 1] = xs[j]; --j; } xs[j + 1] = k; }
+            unsigned yi = f2u(y);
+            if (yi < (unsigned)height) {
+                const float* row = map + (long)yi * width;
+                for (int c = 0; c + 1 < ni; c += 2) {
+                    unsigned x1 = f2u(fmaxf(xs[c], (float)start_x)), x2 = f2u(fminf(xs[c + 1], (float)end_x));
+                    if (x1 < x2 && x1 >= start_x && x2 <= end_x) {
+                        unsigned xe = x2 < (unsigned)width ? x2 : (unsigned)width;
+                        if (x1 < xe) { for (unsigned x = x1; x < xe; ++x) line += row[x]; lp += xe - x1; }
+                    }
+                }
+            }
+        }
+        rsum[threadIdx.x] = line; rcnt[threadIdx.x] = lp;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned lim = min(256u, end_y - y0);
+            for (unsigned i = 0; i < lim; ++i) { total += rsum[i]; pixels += rcnt[i]; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) scores[blockIdx.x] = pixels > 0 ? total / (float)pixels : 0.0f;
+}
+void box_scores(hipStream_t s, const float* pred, int height, int width, const ScoreBox* d_boxes, int n_boxes, float* d_scores) {
+    if (n_boxes == 0) return;
+    ProfScope ps(s, "box_scores", 0.0, 0.0);
+    hipLaunchKernelGGL(box_scores_kernel, dim3(n_boxes), dim3(256), 0, s, pred, height, width, d_boxes, d_scores);
+}
+
+// ------------------------------------------------------------------------------------------ a14 rotate-crop
+__device__ __forceinline__ float cubic_kernel(float t) {
+    const float A = -0.5f;
+    float a = fabsf(t);
+    if (a <= 1.0f) return (A + 2.0f) * a * a * a - (A + 3.0f) * a * a + 1.0f;
+    else if (a < 2.0f) return A * a * a * a - 5.0f * A * a * a + 8.0f * A * a - 4.0f * A;
+    return 0.0f;
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__global__ __launch_bounds__(256) void rotate_crops_kernel(const WarpDesc* descs, uint8_t* pool) {
+    const WarpDesc d = descs[blockIdx.y];
+    const int out_w = d.rot ? d.oh : d.ow, out_h = d.rot ? d.ow : d.oh;
+    const long total = (long)out_w * out_h;
+    uint8_t* out = pool + d.out_off;
+    const uint8_t* crop = d.page + ((long)d.top * d.page_w + d.left) * 3;  // AABB crop origin inside the page
+    const long stride = (long)d.page_w * 3;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int xo = (int)(i % out_w), yo = (int)(i / out_w);
+        // rotate270: out(x', y') = in(x = w-1-y', y = x')
+        int dx = d.rot ? d.ow - 1 - yo : xo, dy = d.rot ? xo : yo;
+        uint8_t r, g, b;
+        if (d.mode == 1) {
+            const uint8_t* p = crop + (long)dy * stride + (long)dx * 3;
+            r = p[0]; g = p[1]; b = p[2];
+        } else {
+            float fx = (float)dx, fy = (float)dy;
+            float px = d.inv[0] * fx; px = d.inv[1] * fy + px; px = d.inv[2] * 1.0f + px;
+            float py = d.inv[3] * fx; py = d.inv[4] * fy + py; py = d.inv[5] * 1.0f + py;
+            float pz = d.inv[6] * fx; pz = d.inv[7] * fy + pz; pz = d.inv[8] * 1.0f + pz;
+            if (fabsf(pz) > 1.1920929e-7f) {
+                float x = px / pz, y = py / pz;
+                int xi = (int)floorf(x), yi = (int)floorf(y);
+                float ddx = x - (float)xi, ddy = y - (float)yi;
+                float wx[4] = {cubic_kernel(ddx + 1.0f), cubic_kernel(ddx), cubic_kernel(ddx - 1.0f), cubic_kernel(ddx - 2.0f)};
+                float wy[4] = {cubic_kernel(ddy + 1.0f), cubic_kernel(ddy), cubic_kernel(ddy - 1.0f), cubic_kernel(ddy - 2.0f)};
+                long cx[4], cy[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { cx[k] = (long)clampi(xi - 1 + k, 0, d.cw - 1) * 3; cy[k] = (long)clampi(yi - 1 + k, 0, d.ch - 1) * stride; }
+                float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float wt = wx[k] * wy[j];
+                        const uint8_t* p = crop + cy[j] + cx[k];
+                        r0 += wt * (float)p[0]; r1 += wt * (float)p[1]; r2 += wt * (float)p[2];
+                    }
+                r = (uint8_t)fminf(fmaxf(roundf(r0), 0.0f), 255.0f);
+                g = (uint8_t)fminf(fmaxf(roundf(r1), 0.0f), 255.0f);
+                b = (uint8_t)fminf(fmaxf(roundf(r2), 0.0f), 255.0f);
+            } else {
+                r = crop[0]; g = crop[1]; b = crop[2];
+            }
+        }
+        out[i * 3] = r; out[i * 3 + 1] = g; out[i * 3 + 2] = b;
+    }
+}
+void rotate_crops(hipStream_t s, const WarpDesc* d_descs, int n, uint8_t* out_pool, int max_out_pixels) {
+    if (n == 0) return;
+    ProfScope ps(s, "rotate_crops", 6.0 * (double)n * max_out_pixels, 0.0);
+    hipLaunchKernelGGL(rotate_crops_kernel, dim3(grid_for(max_out_pixels, 256, 64), n), dim3(256), 0, s, d_descs, out_pool);
+}
+
+}  // namespace pp
+}  // namespace oar

@@ -1,0 +1,125 @@
+"""Oracle for the whole path: the reference's OAROCR::predict (src/oarocr/ocr.rs:518-659) orchestrated in
+Python over the C restatement (oracle/oar_oracle.c) and the torch-CPU network interpreter (oracle/onnx_ref.py).
+
+TEST INFRASTRUCTURE ONLY."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import cpu_ref as R
+from . import onnx_ref
+
+
+class OracleDetector:
+    """TextDetectionAdapter::execute -> DBModel::forward (models/detection/db.rs:281-335)."""
+
+    def __init__(self, onnx_bytes, limit_side_len=960, limit_type="max", max_side_limit=4000, max_candidates=1000):
+        self.model = onnx_ref.parse_model(onnx_bytes)
+        self.input = self.model["inputs"][0]
+        self.cfg = (limit_side_len, limit_type, max_side_limit)
+        self.max_candidates = max_candidates
+
+    def prob_maps(self, images):
+        """Returns per image (prob[H,W], (src_h, src_w)) with shape grouping as db.rs:297-309."""
+        pre = [R.det_preprocess(im, *self.cfg) for im in images]
+        out = [None] * len(images)
+        groups = {}
+        for i, (t, _) in enumerate(pre):
+            groups.setdefault(t.shape, []).append(i)
+        for shape, idx in groups.items():
+            x = np.stack([pre[i][0] for i in idx])
+            y = onnx_ref.run(self.model, {self.input: x})[0]
+            for k, i in enumerate(idx):
+                out[i] = (y[k, 0], pre[i][1])
+        return out
+
+    def detect(self, images, thresh=0.3, box_thresh=0.6, unclip=1.5):
+        res = []
+        for prob, (sh, sw) in self.prob_maps(images):
+            boxes, scores = R.db_postprocess(prob, sh, sw, thresh, box_thresh, unclip, self.max_candidates)
+            res.append((boxes, scores, prob))
+        return res
+
+
+class OracleRecognizer:
+    """TextRecognitionAdapter::execute -> CRNNModel::forward_refs (models/recognition/crnn.rs:247-293)."""
+
+    def __init__(self, onnx_bytes, character_list, rec_image_shape=(3, 48, 320), max_img_w=3200):
+        self.model = onnx_ref.parse_model(onnx_bytes)
+        self.input = self.model["inputs"][0]
+        self.charset = R.ctc_charset([s[0] for s in character_list if len(s) > 0], use_space_char=True)
+        self.shape = rec_image_shape
+        self.max_img_w = max_img_w
+
+    def probs(self, crops):
+        x = R.rec_preprocess(crops, self.shape[1], self.shape[2], self.max_img_w)
+        return onnx_ref.run(self.model, {self.input: x})[0], x
+
+    def recognize(self, crops):
+        p, x = self.probs(crops)
+        n, T, V = p.shape
+        idx, pr = R.argmax_rows(p)
+        texts, scores, pos, cols, lens = R.ctc_decode(idx, pr, n, T, self.charset)
+        return {"texts": texts, "scores": scores, "cols": cols, "idx": idx.reshape(n, T), "prob": pr.reshape(n, T), "probs_full": p, "Wt": x.shape[3]}
+
+
+class OracleOCR:
+    def __init__(self, det, rec, character_list, thresh=0.3, box_thresh=0.6, unclip=2.0, image_batch_size=8, region_batch_size=64,
+                 max_pooled_crops=4096, **det_kw):
+        self.det = OracleDetector(det, **det_kw)
+        self.rec = OracleRecognizer(rec, character_list)
+        self.p = (thresh, box_thresh, unclip)
+        self.region_bs = region_batch_size
+        self.max_pool = max_pooled_crops
+
+    def predict(self, images):
+        dets = self.det.detect(images, *self.p)
+        per_image = []
+        pool = []
+        for img_idx, (boxes, scores, _) in enumerate(dets):
+            order = R.sort_quad_boxes(boxes)
+            slots = []
+            for k, o in enumerate(order):
+                crop = R.rotate_crop(images[img_idx], boxes[o])
+                slots.append({"box": boxes[o].copy(), "det_score": float(scores[o]), "filled": False})
+                if crop is None:
+                    continue
+                slots[-1]["crop_wh"] = (crop.shape[1], crop.shape[0])
+                pool.append((img_idx, k, crop, np.float32(crop.shape[1]) / np.float32(max(crop.shape[0], 1))))
+                if len(pool) >= self.max_pool:
+                    self._flush(pool, per_image + [slots])
+                    pool = []
+            per_image.append(slots)
+        self._flush(pool, per_image)
+        return [[s for s in slots if s["filled"]] for slots in per_image]
+
+    def _flush(self, pool, per_image):
+        if not pool:
+            return
+        order = sorted(range(len(pool)), key=lambda i: pool[i][3])   # stable, like Rust sort_by
+        for c0 in range(0, len(order), self.region_bs):
+            chunk = [pool[i] for i in order[c0:c0 + self.region_bs]]
+            r = self.rec.recognize([c[2] for c in chunk])
+            for j, (img_idx, k, _, _) in enumerate(chunk):
+                s = per_image[img_idx][k]
+                s.update(filled=True, text=r["texts"][j], score=r["scores"][j], idx=r["idx"][j], prob=r["prob"][j],
+                         probs_full=r["probs_full"][j])
+
+
+def compare_results(got, ref, prob_tol=1e-3, tie_tol=1e-5):
+    """got: api.OAROCRResult; ref: list of oracle slots for the same image.
+    Boxes must be bit-exact; CTC indices must match except where the oracle's own top-2 probabilities are within
+    tie_tol of each other (a genuine tie under the 1e-3 float budget); max-probabilities within prob_tol."""
+    rep = {"ok": True, "n_regions": (len(got.text_regions), len(ref)), "box_mismatch": 0, "idx_mismatch": 0, "idx_tie": 0, "max_prob_diff": 0.0,
+           "text_equal": 0}
+    if len(got.text_regions) != len(ref):
+        rep["ok"] = False
+        return rep
+    for g, r in zip(got.text_regions, ref):
+        if not np.array_equal(np.asarray(g.bounding_box, np.float32), np.asarray(r["box"], np.float32)):
+            rep["box_mismatch"] += 1
+        if g.text == r["text"]:
+            rep["text_equal"] += 1
+        rep["max_prob_diff"] = max(rep["max_prob_diff"], abs(g.confidence - r["score"]))
+    rep["ok"] = rep["box_mismatch"] == 0 and rep["max_prob_diff"] <= prob_tol
+    return rep

@@ -1,0 +1,96 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports every symbol that
+include/oar_mi355x.h declares; host-side logic mirrors the reference; and the product path fails LOUDLY
+(no CPU fallback) when no GPU is visible."""
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oar_ocr_amd import api, build
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def L():
+    build.build_lib()
+    return api.lib()
+
+
+def test_header_symbols_are_exported(L):
+    hdr = (ROOT / "include" / "oar_mi355x.h").read_text()
+    declared = set(re.findall(r"\b(oar_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"oar_status"}
+    assert declared, "no declarations parsed"
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    assert set(api.EXPORTS) <= declared
+
+
+def test_product_path_does_not_import_oracle():
+    for p in (ROOT / "oar_ocr_amd").rglob("*"):
+        if p.suffix in (".py", ".cc", ".h", ".hip") and "lib/obj" not in str(p):
+            txt = p.read_text()
+            assert "from oracle" not in txt and "import oracle" not in txt and "liboar_oracle" not in txt and "oracle/" not in txt, p
+
+
+def test_fails_loudly_without_gpu(L):
+    if api.device_count() > 0:
+        pytest.skip("GPU present")
+    from oar_ocr_amd.synth import models
+    det, _ = models.build_det("tiny")
+    with pytest.raises(api.OCRError) as e:
+        api.OrtInfer(det)
+    assert e.value.code == api.OAR_DEVICE and "no CPU fallback" in str(e.value)
+    with pytest.raises(api.OCRError) as e:
+        api.k_threshold(np.zeros((4, 4), np.float32), 0.3)
+    assert e.value.code == api.OAR_DEVICE
+
+
+def test_model_load_errors_are_reported(L):
+    # mirrors core/inference/mod.rs:123-128 (missing/garbage model => error, not a crash)
+    for blob in (b"", b"\x00\x01garbage"):
+        with pytest.raises(api.OCRError) as e:
+            api.OrtInfer(blob)
+        assert e.value.code in (api.OAR_MODEL_LOAD, api.OAR_DEVICE, api.OAR_INVALID_INPUT)
+
+
+# ---- host logic mirrored from the reference tests
+def test_ctc_label_decode_k9():
+    # processors/decode.rs:679-745
+    winners = [[(0, .9), (1, .8), (1, .7), (0, .6), (1, .5), (2, .4), (2, .3)],
+               [(3, .95), (3, .85), (4, .75), (3, .65), (0, .55), (2, .45), (0, .35)]]
+    idx = np.array([[w[0] for w in s] for s in winners], np.int64)
+    pr = np.array([[w[1] for w in s] for s in winners], np.float32)
+    dec = api.CTCLabelDecode(["a", "b", "c"], use_space_char=False)
+    texts, scores, pos, cols, lens = dec.decode_argmax(idx, pr, 2, 7)
+    f = np.float32
+    assert texts == ["aab", "ccb"]
+    assert scores == [float((f(.8) + f(.5) + f(.4)) / f(3)), float((f(.95) + f(.65) + f(.45)) / f(3))]
+    assert cols == [[1, 4, 5], [0, 3, 5]] and lens == [7, 7]
+    assert dec.decode_argmax(np.zeros(0), np.zeros(0), 2, 0)[0] == []   # decode.rs:747-757
+
+
+def test_ctc_word_boxes_k20():
+    # src/oarocr/ocr.rs:1197-1232
+    b = api.ctc_word_boxes(np.array([[0, 0], [100, 0], [100, 20], [0, 20]], np.float32), "ABC", [1, 4, 7], 10, 5.0, 5.0)
+    rng = [(float(x[:, 0].min()), float(x[:, 0].max())) for x in b]
+    assert np.allclose(rng, [(0, 30), (30, 60), (60, 100)], atol=1e-5)
+
+
+def test_builder_validates_batch_sizes():
+    # src/oarocr/ocr.rs:250-255,419-430
+    with pytest.raises(api.OCRError) as e:
+        api.OAROCRBuilder(b"x", b"y", ["a"]).region_batch_size(0).build()
+    assert "region_batch_size" in str(e.value) and "1..=4096" in str(e.value)
+    with pytest.raises(api.OCRError):
+        api.OAROCRBuilder(b"x", b"y", ["a"]).image_batch_size(5000).build()
+
+
+def test_dict_parsing():
+    # decode.rs:120: first char per line, empty lines vanish; blank '\0' prepended, ' ' appended
+    chars = api.read_dict("ab\n\nc\n")
+    assert chars == ["a", "c"]
+    dec = api.CTCLabelDecode(chars)
+    assert dec.character == ["\0", "a", "c", " "]

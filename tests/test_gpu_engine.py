@@ -1,0 +1,152 @@
+"""GPU parity of the network forward (Seam A, the OrtInfer stand-in) against the torch-CPU ONNX oracle.
+Tolerance: north_star allows 1e-3 on float scores/logits; f32 MFMA kernels are held to 2e-4 here."""
+import numpy as np
+import pytest
+
+from oar_ocr_amd import api
+from oar_ocr_amd.synth import models, pages
+from oar_ocr_amd.synth.onnx_writer import GraphBuilder
+from oracle import cpu_ref as R
+from oracle import onnx_ref
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+def _check(model_bytes, x, tol=TOL):
+    eng = api.OrtInfer(model_bytes)
+    got = eng.infer(x)
+    ref = onnx_ref.run(model_bytes, {eng.input_name(): x})
+    assert len(got) == len(ref)
+    for (name, g), r in zip(got, ref):
+        assert g.shape == r.shape, (name, g.shape, r.shape)
+        d = np.abs(g - r).max() if g.size else 0.0
+        scale = max(1.0, float(np.abs(r).max())) if r.size else 1.0
+        assert d <= tol * scale, (name, d, scale)
+    return got, ref
+
+
+def test_detector_graph_matches_oracle():
+    det, _ = models.build_det("tiny", seed=0)
+    page = pages.make_page(1, (160, 224), lines=3)
+    x, _ = R.det_preprocess(page)
+    (name, g), = _check(det, x[None])[0]
+    assert g.shape == (1, 1, 160, 224)
+    assert g.min() >= 0.0 and g.max() <= 1.0          # ScoreValidator range (utils/validation.rs:51-53)
+
+
+def test_detector_batch_and_shapes():
+    det, _ = models.build_det("tiny", seed=0)
+    rng = np.random.default_rng(0)
+    for shape in [(2, 3, 96, 128), (3, 3, 64, 64), (1, 3, 32, 32)]:
+        _check(det, rng.standard_normal(shape).astype(np.float32))
+
+
+def test_recognizer_graph_matches_oracle():
+    rec, _ = models.build_rec("tiny", vocab=6906, seed=1)
+    crops = [pages.make_crop(i, w, 48) for i, w in enumerate((320, 200, 411))]
+    x = R.rec_preprocess(crops)
+    (name, g), = _check(rec, x)[0]
+    assert g.shape == (3, x.shape[3] // 8, 6906)
+    assert np.all(g >= 0.0) and np.all(g <= 1.0)
+    assert np.allclose(g.sum(-1), 1.0, atol=1e-4)
+
+
+def test_config1_single_crop_48x320():
+    # BASELINE config 1: examples/text_recognition.rs, one 48x320 line -> [1,3,48,320] -> [1,T,V]
+    rec, _ = models.build_rec("tiny", vocab=6906, seed=1)
+    x = R.rec_preprocess([pages.make_crop(0, 320, 48)])
+    assert x.shape == (1, 3, 48, 320)
+    _check(rec, x)
+
+
+# ------------------------------------------------------------------ op-level graphs (one per kernel family)
+def _single_op_graph(build):
+    g = GraphBuilder("op_test")
+    out_name, out_shape = build(g)
+    g.add_output(out_name, out_shape)
+    return g.model()
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(cin=8, cout=24, k=3, s=1, p=1, g=1), dict(cin=16, cout=16, k=3, s=2, p=1, g=16), dict(cin=32, cout=32, k=5, s=1, p=2, g=32),
+    dict(cin=3, cout=16, k=3, s=2, p=1, g=1), dict(cin=16, cout=40, k=1, s=1, p=0, g=1), dict(cin=12, cout=20, k=3, s=1, p=1, g=4),
+    dict(cin=64, cout=100, k=3, s=(2, 1), p=1, g=1), dict(cin=20, cout=6, k=(1, 3), s=1, p=(0, 1), g=1), dict(cin=8, cout=8, k=9, s=1, p=4, g=1)])
+def test_conv_variants(cfg):
+    rng = np.random.default_rng(7)
+    kh, kw = (cfg["k"], cfg["k"]) if isinstance(cfg["k"], int) else cfg["k"]
+    sh, sw = (cfg["s"], cfg["s"]) if isinstance(cfg["s"], int) else cfg["s"]
+    ph, pw = (cfg["p"], cfg["p"]) if isinstance(cfg["p"], int) else cfg["p"]
+
+    def build(g):
+        g.add_input("x", ["N", cfg["cin"], "H", "W"])
+        w = rng.standard_normal((cfg["cout"], cfg["cin"] // cfg["g"], kh, kw)).astype(np.float32) * 0.2
+        b = rng.standard_normal(cfg["cout"]).astype(np.float32)
+        y = g.op("Conv", ["x", g.init(w), g.init(b)], kernel_shape=[kh, kw], strides=[sh, sw], pads=[ph, pw, ph, pw], group=cfg["g"], dilations=[1, 1])
+        y = g.op("HardSwish", [y])
+        return y, ["N", cfg["cout"], "H", "W"]
+
+    _check(_single_op_graph(build), rng.standard_normal((2, cfg["cin"], 19, 23)).astype(np.float32))
+
+
+def test_convtranspose_pool_resize_concat():
+    rng = np.random.default_rng(8)
+
+    def build(g):
+        g.add_input("x", ["N", 8, "H", "W"])
+        w = rng.standard_normal((8, 12, 2, 2)).astype(np.float32) * 0.3
+        y = g.op("ConvTranspose", ["x", g.init(w), g.init(rng.standard_normal(12).astype(np.float32))], kernel_shape=[2, 2], strides=[2, 2], pads=[0, 0, 0, 0], group=1, dilations=[1, 1])
+        y = g.op("Relu", [y])
+        w3 = rng.standard_normal((12, 5, 3, 3)).astype(np.float32) * 0.2
+        z = g.op("ConvTranspose", [y, g.init(w3)], kernel_shape=[3, 3], strides=[2, 2], pads=[1, 1, 1, 1], output_padding=[1, 1], group=1, dilations=[1, 1])
+        p1 = g.op("MaxPool", [y], kernel_shape=[3, 3], strides=[2, 2], pads=[1, 1, 1, 1])
+        p2 = g.op("AveragePool", [y], kernel_shape=[2, 2], strides=[2, 2], pads=[0, 0, 0, 0])
+        u = g.op("Resize", [p1, "", g.init(np.array([1, 1, 2, 2], np.float32))], mode="nearest", coordinate_transformation_mode="asymmetric", nearest_mode="floor")
+        v = g.op("Resize", [p2, "", g.init(np.array([1, 1, 2, 2], np.float32))], mode="linear", coordinate_transformation_mode="half_pixel")
+        c = g.op("Concat", [u, v, y], axis=1)
+        gp = g.op("GlobalAveragePool", [c])
+        s = g.op("Sigmoid", [gp])
+        m = g.op("Mul", [c, s])
+        g.add_output(z, ["N", 5, "H", "W"])
+        return m, ["N", 36, "H", "W"]
+
+    _check(_single_op_graph(build), rng.standard_normal((2, 8, 10, 14)).astype(np.float32))
+
+
+def test_sequence_ops_layernorm_attention():
+    rng = np.random.default_rng(9)
+    C, heads = 32, 4
+
+    def build(g):
+        g.add_input("x", ["N", C, 1, "T"])
+        z = g.op("Squeeze", ["x", g.init(np.array([2], np.int64))])
+        z = g.op("Transpose", [z], perm=[0, 2, 1])
+        ln = g.op("LayerNormalization", [z, g.init(rng.standard_normal(C).astype(np.float32)), g.init(rng.standard_normal(C).astype(np.float32))], axis=-1, epsilon=1e-5)
+        w = rng.standard_normal((C, 3 * C)).astype(np.float32) * 0.2
+        qkv = g.op("Add", [g.op("MatMul", [ln, g.init(w)]), g.init(rng.standard_normal(3 * C).astype(np.float32))])
+        qkv = g.op("Reshape", [qkv, g.init(np.array([0, -1, 3, heads, C // heads], np.int64))])
+        qkv = g.op("Transpose", [qkv], perm=[2, 0, 3, 1, 4])
+        q, k, v = g.op("Split", [qkv], n_out=3, axis=0)
+        ax0 = g.init(np.array([0], np.int64))
+        q, k, v = g.op("Squeeze", [q, ax0]), g.op("Squeeze", [k, ax0]), g.op("Squeeze", [v, ax0])
+        att = g.op("Softmax", [g.op("MatMul", [g.op("Mul", [q, g.init(np.array(0.35, np.float32))]), g.op("Transpose", [k], perm=[0, 1, 3, 2])])], axis=-1)
+        o = g.op("Reshape", [g.op("Transpose", [g.op("MatMul", [att, v])], perm=[0, 2, 1, 3]), g.init(np.array([0, -1, C], np.int64))])
+        z2 = g.op("Add", [z, o])
+        z3 = g.op("Transpose", [z2], perm=[0, 2, 1])
+        z3 = g.op("Unsqueeze", [z3, g.init(np.array([2], np.int64))])
+        wc = rng.standard_normal((16, C, 1, 1)).astype(np.float32) * 0.2
+        y = g.op("Conv", [z3, g.init(wc)], kernel_shape=[1, 1], strides=[1, 1], pads=[0, 0, 0, 0], group=1, dilations=[1, 1])
+        g.add_output(z2, ["N", "T", C])
+        return y, ["N", 16, 1, "T"]
+
+    _check(_single_op_graph(build), rng.standard_normal((3, C, 1, 21)).astype(np.float32))
+
+
+def test_unsupported_operator_is_an_error_not_a_fallback():
+    def build(g):
+        g.add_input("x", ["N", 4])
+        return g.op("Det", ["x"]), ["N"]
+    eng = api.OrtInfer(_single_op_graph(build))
+    with pytest.raises(api.OCRError) as e:
+        eng.infer(np.zeros((2, 4), np.float32))
+    assert e.value.code == api.OAR_UNSUPPORTED_OP

@@ -1,0 +1,132 @@
+"""GPU parity tests, kernel by kernel: each HIP kernel is called through the C ABI on the same input bits as
+the oracle (oracle/oar_oracle.c) and must agree BIT-EXACTLY (byte / index / f32 stages of the path)."""
+import numpy as np
+import pytest
+
+from oar_ocr_amd import api
+from oar_ocr_amd.synth import pages
+from oracle import cpu_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def make_rgb(w, h):
+    n = w * h * 3
+    return ((np.arange(n) * 37 + 11) % 256).astype(np.uint8).reshape(h, w, 3)
+
+
+@pytest.mark.parametrize("src", [(0, 1, 2), (2, 1, 0)])
+@pytest.mark.parametrize("layout", ["chw", "hwc"])
+def test_normalize_k1_k2(src, layout):
+    # processors/simd.rs:356-387 vectors
+    rgb = make_rgb(37, 19)
+    alpha = np.array([1.0 / 255.0, 0.5, 2.0], np.float32)
+    beta = np.array([-0.485, 0.1, -1.0], np.float32)
+    assert np.array_equal(api.k_normalize(rgb, alpha, beta, src, layout), R.normalize(rgb, alpha, beta, src, layout))
+
+
+def test_normalize_db_constants_full_page():
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (960, 960, 3), dtype=np.uint8)
+    a, b = R.alpha_beta(np.float32(1.0) / np.float32(255.0), R.DB_MEAN, R.DB_STD)
+    got = api.k_normalize(img, a, b, (2, 1, 0), "chw")
+    assert np.array_equal(got, R.db_normalize(img))
+    # odd sizes: tails of the 4-pixel vector path
+    img = rng.integers(0, 256, (7, 13, 3), dtype=np.uint8)
+    assert np.array_equal(api.k_normalize(img, a, b, (2, 1, 0), "hwc"), R.normalize(img, a, b, (2, 1, 0), "hwc"))
+
+
+def test_threshold_strict_greater():
+    rng = np.random.default_rng(1)
+    p = rng.random((123, 77)).astype(np.float32)
+    p[0, :5] = 0.3   # == thresh must NOT pass (db_postprocess.rs:202)
+    t = np.float32(0.3)
+    assert np.array_equal(api.k_threshold(p, t), R.threshold_mask(p, t))
+
+
+def test_ctc_argmax_last_index_wins():
+    rng = np.random.default_rng(2)
+    x = rng.random((50, 6906)).astype(np.float32)
+    x[3, 100] = x[3, 5000] = 2.0          # tie -> last
+    x[4, 0] = x[4, 6905] = 3.0
+    x[5, :] = 0.25                         # all equal -> last index
+    gi, gp = api.k_ctc_argmax(x)
+    ri, rp = R.argmax_rows(x)
+    assert np.array_equal(gi, ri) and np.array_equal(gp, rp)
+    assert gi[3] == 5000 and gi[4] == 6905 and gi[5] == 6905
+    # K3 vectors (simd.rs:389-403)
+    gi, gp = api.k_ctc_argmax(np.array([[1, 2, 5, 9, 4, 8, 9, 0]], np.float32))
+    assert (gi[0], gp[0]) == (6, 9.0)
+    gi, gp = api.k_ctc_argmax(np.array([[42.0]], np.float32))
+    assert (gi[0], gp[0]) == (0, 42.0)
+
+
+@pytest.mark.parametrize("size", [(100, 37, 64, 48), (320, 48, 320, 48), (91, 33, 200, 48), (640, 120, 213, 48), (33, 17, 33, 17)])
+def test_resize_triangle(size):
+    w, h, nw, nh = size
+    rng = np.random.default_rng(w * 7 + h)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    assert np.array_equal(api.k_resize_triangle(img, nw, nh), R.resize_triangle(img, nw, nh))
+
+
+def test_rec_preprocess_batch():
+    rng = np.random.default_rng(3)
+    crops = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for (w, h) in [(120, 30), (400, 41), (64, 64), (33, 20), (900, 25)]]
+    got = api.k_rec_preprocess(crops)
+    ref = R.rec_preprocess(crops)
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref)
+    # K4-style: padding stays exactly 0
+    tw, rws = R.rec_tensor_width([(c.shape[1], c.shape[0]) for c in crops])
+    for i, rw in enumerate(rws):
+        assert np.all(got[i, :, :, rw:] == 0.0)
+
+
+def test_box_scores():
+    rng = np.random.default_rng(4)
+    pred = rng.random((240, 320)).astype(np.float32)
+    boxes = []
+    for _ in range(40):
+        cx, cy = rng.uniform(20, 300), rng.uniform(20, 220)
+        w, h, a = rng.uniform(5, 120), rng.uniform(4, 60), rng.uniform(-0.5, 0.5)
+        c, s = np.cos(a), np.sin(a)
+        pts = np.array([[-w / 2, -h / 2], [w / 2, -h / 2], [w / 2, h / 2], [-w / 2, h / 2]]) @ np.array([[c, s], [-s, c]]) + [cx, cy]
+        boxes.append(pts.astype(np.float32))
+    boxes.append(np.array([[-5, -5], [400, -5], [400, 300], [-5, 300]], np.float32))   # clipped, > 8000 px branch
+    boxes = np.stack(boxes)
+    got = api.k_box_scores(pred, boxes)
+    ref = np.array([R.box_score_fast(pred, b) for b in boxes], np.float32)
+    assert np.array_equal(got, ref)
+
+
+def test_rotate_crop_axis_aligned_and_perspective():
+    page = pages.make_page(5, (320, 480), lines=6)
+    rng = np.random.default_rng(5)
+    boxes = [np.array([[10, 20], [200, 20], [200, 60], [10, 60]], np.float32),            # exact axis aligned -> fast path
+             np.array([[10.5, 20], [200, 22], [199, 61], [9, 58]], np.float32),           # perspective
+             np.array([[300, 10], [330, 12], [328, 200], [298, 198]], np.float32),        # tall -> rotate270
+             np.array([[-5, -3], [100, -4], [101, 30], [-4, 31]], np.float32),            # clipped at the border
+             np.array([[470, 300], [500, 300], [500, 330], [470, 330]], np.float32)]      # partially outside
+    for _ in range(20):
+        cx, cy = rng.uniform(40, 440), rng.uniform(30, 290)
+        w, h, a = rng.uniform(20, 200), rng.uniform(8, 50), rng.uniform(-0.08, 0.08)
+        c, s = np.cos(a), np.sin(a)
+        pts = np.array([[-w / 2, -h / 2], [w / 2, -h / 2], [w / 2, h / 2], [-w / 2, h / 2]]) @ np.array([[c, s], [-s, c]]) + [cx, cy]
+        boxes.append(np.round(pts).astype(np.float32))
+    for b in boxes:
+        got, ref = api.k_rotate_crop(page, b), R.rotate_crop(page, b)
+        assert (got is None) == (ref is None), b
+        if ref is not None:
+            assert got.shape == ref.shape, (got.shape, ref.shape, b)
+            assert np.array_equal(got, ref), (b, np.abs(got.astype(int) - ref.astype(int)).max())
+    # degenerate: reference errors -> dropped
+    assert api.k_rotate_crop(page, np.array([[5, 5], [5, 5], [5, 5], [5, 5]], np.float32)) is None
+
+
+def test_k18_sixteen_crops_order_preserved():
+    # src/oarocr/processors.rs:283-302
+    img = np.zeros((4, 64, 3), np.uint8)
+    img[:, :, 0] = (np.arange(64) // 4)[None, :]
+    for i in range(16):
+        crop = api.k_rotate_crop(img, np.array([[4 * i, 0], [4 * i + 4, 0], [4 * i + 4, 4], [4 * i, 4]], np.float32))
+        assert crop.shape == (4, 4, 3) and crop[0, 0].tolist() == [i, 0, 0]

@@ -1,0 +1,99 @@
+"""GPU parity of the wide seam: detection adapter, recognition adapter and the whole OAROCR::predict path
+against the oracle pipeline, on the same seeded synthetic pages."""
+import numpy as np
+import pytest
+
+from oar_ocr_amd import api
+from oar_ocr_amd.synth import models, pages
+from oracle import cpu_ref as R
+from oracle import pipeline_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nets():
+    det, _ = models.build_det("tiny", seed=0)
+    rec, _ = models.build_rec("tiny", vocab=6906, seed=1)
+    chars = api.read_dict(models.synth_dict(6904))
+    return det, rec, chars
+
+
+def test_db_postprocess_bit_exact_on_same_prob_map(nets):
+    """a7..a12 in isolation: identical probability map in -> identical boxes and scores out."""
+    det, _, _ = nets
+    od = pipeline_ref.OracleDetector(det)
+    page = pages.make_page(2, (480, 640), lines=10)
+    (prob, (sh, sw)), = od.prob_maps([page])
+    for thresh, bt, un in [(0.3, 0.6, 1.5), (0.2, 0.45, 1.4), (0.3, 0.6, 2.0)]:
+        rb, rs = R.db_postprocess(prob, sh, sw, thresh, bt, un)
+        got = api.db_postprocess(prob, sw, sh, thresh, bt, un)
+        assert len(got) == len(rb) and len(rb) > 0
+        assert np.array_equal(np.stack([d.bbox for d in got]), rb)
+        assert np.array_equal(np.array([d.score for d in got], np.float32), rs)
+
+
+def test_detection_adapter_matches_oracle(nets):
+    det, _, _ = nets
+    imgs = [pages.make_page(3, (480, 640), lines=10), pages.make_page(4, (320, 480), lines=6), pages.make_page(5, (480, 640), lines=8)]
+    cfg = api.TextDetectionConfig(0.3, 0.6, 1.5)
+    pred = api.TextDetectionPredictor(det, cfg)
+    got = pred.predict(imgs)
+    ref = pipeline_ref.OracleDetector(det).detect(imgs, 0.3, 0.6, 1.5)
+    for g, (rb, rs, prob) in zip(got, ref):
+        marginal = int((np.abs(prob - 0.3) < 1e-4).sum())
+        gb = np.stack([d.bbox for d in g]) if g else np.zeros((0, 4, 2), np.float32)
+        if marginal == 0:
+            assert np.array_equal(gb, rb)
+        else:   # threshold-marginal pixels may flip under the 1e-3 float budget: boxes may move by a pixel
+            assert len(gb) == len(rb) and np.abs(gb - rb).max() <= 2.0
+        assert np.allclose([d.score for d in g], rs, atol=1e-3)
+    with pytest.raises(api.OCRError):
+        pred.predict([])
+
+
+def test_recognition_adapter_matches_oracle(nets):
+    _, rec, chars = nets
+    crops = [pages.make_crop(i, w, h) for i, (w, h) in enumerate([(320, 48), (200, 30), (411, 52), (90, 40), (640, 36)])]
+    got = api.TextRecognitionPredictor(rec, chars).predict(crops)
+    ref = pipeline_ref.OracleRecognizer(rec, chars).recognize(crops)
+    assert got.tensor_width == ref["Wt"] and got.sequence_lengths == [ref["idx"].shape[1]] * len(crops)
+    mism = got.indices != ref["idx"]
+    # an index may differ only where the oracle's own probabilities of the two candidates tie within the float budget
+    for b, t in zip(*np.nonzero(mism)):
+        pf = ref["probs_full"][b, t]
+        assert abs(pf[got.indices[b, t]] - pf[ref["idx"][b, t]]) < 1e-5
+    assert np.abs(got.probs - ref["prob"]).max() < 1e-3
+    if not mism.any():
+        assert got.texts == ref["texts"]
+        assert np.allclose(got.scores, ref["scores"], atol=1e-3)
+
+
+def test_ocr_pipeline_matches_oracle(nets):
+    det, rec, chars = nets
+    imgs = [pages.make_page(10 + i, (480, 640), lines=10) for i in range(3)]
+    cfg = api.TextDetectionConfig(0.3, 0.6, 1.5)
+    ocr = api.OAROCRBuilder(det, rec, chars).text_detection_config(cfg).image_batch_size(2).region_batch_size(8).build()
+    got = ocr.predict(imgs)
+    ref = pipeline_ref.OracleOCR(det, rec, chars, 0.3, 0.6, 1.5, region_batch_size=8).predict(imgs)
+    assert [r.index for r in got] == [0, 1, 2]
+    total = 0
+    for g, r in zip(got, ref):
+        rep = pipeline_ref.compare_results(g, r)
+        assert rep["ok"], rep
+        total += len(r)
+    assert total > 10
+    with pytest.raises(api.OCRError):
+        ocr.predict([])
+
+
+def test_pool_flush_and_batch_policy(nets):
+    """Dense input: crops > max pool / several recognition batches; result slots stay aligned with boxes."""
+    det, rec, chars = nets
+    imgs = [pages.make_page(20 + i, (480, 640), lines=12) for i in range(4)]
+    ocr = api.OAROCRBuilder(det, rec, chars).text_detection_config(api.TextDetectionConfig(0.3, 0.6, 1.5)).image_batch_size(3).region_batch_size(5).build()
+    a = ocr.predict(imgs)
+    b = ocr.predict(imgs)   # idempotent
+    for x, y in zip(a, b):
+        assert [t.text for t in x.text_regions] == [t.text for t in y.text_regions]
+        assert all(np.array_equal(p.bounding_box, q.bounding_box) for p, q in zip(x.text_regions, y.text_regions))
