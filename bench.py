@@ -1,0 +1,166 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of the det+rec hot path (OAROCR::predict behind the C ABI) on N MI355X of one node.
+
+A "step" = one pass of the hot path over one batch of synthetic pages per GPU.  Default workload is BASELINE.json
+configs[1]: PP-OCRv6-tiny-class det+rec, batch = 32 synthetic 960x960 pages, pages already resident in HBM when the
+timed region starts.  N > 1: one process per GPU (torchrun contract), pages are sharded image-parallel (weak scaling:
+every rank processes its own 32 pages per step), no data-path collective; value = pages of ALL ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, hipEvent-timed on the engine's own stream inside the
+timed region) and `cpu_baseline` (the oracle pipeline -- C restatement + torch-CPU network -- on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: f32-input MFMA dense peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pages", type=int, default=32, help="pages per GPU per step (BASELINE configs[1]: 32)")
+    ap.add_argument("--size", type=int, default=960)
+    ap.add_argument("--lines", type=int, default=40)
+    ap.add_argument("--region-batch", type=int, default=64, help="recognition batch (reference accelerator default 64)")
+    ap.add_argument("--cpu-pages", type=int, default=3, help="pages in the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-prof", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from oar_ocr_amd import api, dist as oard
+    from oar_ocr_amd.synth import models, pages as synth_pages
+
+    rank, local, world = oard.init_from_env("nccl" if args.gpus > 1 else None)
+    if world > 1:
+        import torch.distributed as dist
+    assert api.device_count() > 0, "bench.py needs a GPU: libOarMi355x has no CPU fallback"
+    dev = local % api.device_count()
+    torch.cuda.set_device(dev)
+
+    det, det_info = models.build_det("tiny", seed=0)
+    rec, rec_info = models.build_rec("tiny", vocab=6906, seed=1)
+    chars = api.read_dict(models.synth_dict(6904))
+    n_pages = args.pages
+    host_pages = [synth_pages.make_page(rank * n_pages + i, (args.size, args.size), args.lines) for i in range(n_pages)]
+    dev_pages = [api.DeviceBuffer(p, dev) for p in host_pages]           # inputs resident in HBM before timing
+    ptrs = [int(b.ptr.value) for b in dev_pages]
+    ws = [args.size] * n_pages
+    hs = [args.size] * n_pages
+
+    cfg = api.TextDetectionConfig(score_threshold=0.3, box_threshold=0.6, unclip_ratio=1.5)   # examples/ocr.rs:119-133 set
+    ocr = (api.OAROCRBuilder(det, rec, chars).text_detection_config(cfg).image_batch_size(n_pages)
+           .region_batch_size(args.region_batch).device(dev).build())
+
+    def step():
+        return ocr.predict_device(ptrs, ws, hs, raw=True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # -- untimed: discover the dominant kernel class with every class instrumented
+    dominant = None
+    if not args.no_prof:
+        step()
+        api.prof_enable(True)
+        api.prof_filter("")
+        api.prof_reset()
+        step()
+        snap = api.prof_snapshot()
+        api.prof_enable(False)
+        if snap and snap[0]["total_ms"] > 0:
+            dominant = snap[0]["name"]
+        breakdown = {e["name"]: round(e["total_ms"], 3) for e in snap[:12]}
+    else:
+        breakdown = {}
+
+    for _ in range(args.warmup):
+        regions, ctc = step()
+    if dominant:
+        api.prof_filter(dominant)
+        api.prof_enable(True)
+        api.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        regions, ctc = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    roof = None
+    if dominant:
+        snap = {e["name"]: e for e in api.prof_snapshot()}
+        api.prof_enable(False)
+        api.prof_filter("")
+        e = snap.get(dominant)
+        if e and e["launches"] > 0 and e["total_ms"] > 0:
+            sec = e["total_ms"] / 1e3
+            ai = e["alg_flops"] / max(e["alg_bytes"], 1.0)
+            balance = MFMA_F32_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)
+            if ai >= balance:
+                ach, peak, unit, bound = e["alg_flops"] / sec / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s", "mfma"
+            else:
+                ach, peak, unit, bound = e["alg_bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
+            roof = {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": None,
+                    "kernel": dominant, "launches_per_step": e["launches"] / args.steps, "avg_launch_us": round(e["total_ms"] * 1e3 / e["launches"], 2),
+                    "alg_bytes_per_launch": e["alg_bytes"] / e["launches"], "alg_flops_per_launch": e["alg_flops"] / e["launches"],
+                    "share_of_step": round(e["total_ms"] / (dt * 1e3), 4)}
+
+    tmax = dt
+    if world > 1:
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tmax = float(t.item())
+        cnt = torch.tensor([float(regions)], device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        regions_total = int(cnt.item())
+    else:
+        regions_total = regions
+
+    if rank == 0:
+        total_pages = n_pages * world * args.steps
+        value = total_pages / tmax
+        cpu = None
+        if args.cpu_pages > 0:
+            from oracle import pipeline_ref
+            torch.set_num_threads(min(os.cpu_count() or 1, 64))
+            sample = host_pages[:args.cpu_pages]
+            oc = pipeline_ref.OracleOCR(det, rec, chars, 0.3, 0.6, 1.5, image_batch_size=1, region_batch_size=16)  # reference CPU policy (builder_utils.rs:111-125)
+            oc.predict(sample[:1])  # warm
+            c0 = time.perf_counter()
+            oc.predict(sample)
+            cdt = time.perf_counter() - c0
+            cpu = {"value": round(len(sample) / cdt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+                   "sample": f"{len(sample)} of the same 960x960 synthetic pages, det batch 1 / rec batch 16 (reference CPU defaults); "
+                             "oracle = C restatement of pre/post (1 thread) + torch-CPU fp32 network (threads above)"}
+        line = {
+            "metric": "images/sec end-to-end PP-OCRv6 det+rec", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(tmax / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"PP-OCRv6-tiny-class det+rec (synthetic-weight graphs: det {det_info['params']} params, rec {rec_info['params']} params, V=6906), "
+                                   f"batch={n_pages} synthetic {args.size}x{args.size} pages per GPU, {args.lines} text lines/page, pages resident in HBM",
+                       "pages_per_gpu_per_step": n_pages, "region_batch_size": args.region_batch, "regions_per_step": regions_total,
+                       "parallelism": f"image-parallel x{world}"},
+            "roofline": roof, "cpu_baseline": cpu, "kernel_ms_per_step_untimed_pass": breakdown,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

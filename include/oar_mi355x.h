@@ -240,6 +240,8 @@ typedef struct {
 } oar_prof_entry;
 void oar_prof_reset(void);
 void oar_prof_enable(int32_t on);
+/* Restrict instrumentation to one kernel class (NULL or "" = all): keeps event overhead out of a timed region. */
+void oar_prof_filter(const char* class_name);
 /* Fills up to cap entries, sorted by total_ms descending; returns the number of classes. */
 int32_t oar_prof_snapshot(oar_prof_entry* entries, int32_t cap);
 

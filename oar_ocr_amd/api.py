@@ -84,7 +84,7 @@ EXPORTS = [
     "oar_db_postprocess", "oar_rec_create", "oar_rec_destroy", "oar_rec_run", "oar_rec_result_free", "oar_ocr_create", "oar_ocr_destroy",
     "oar_ocr_predict", "oar_ocr_predict_device", "oar_ocr_result_free", "oar_dev_alloc", "oar_dev_upload", "oar_dev_download",
     "oar_dev_free", "oar_dev_synchronize", "oar_k_normalize", "oar_k_rec_preprocess", "oar_k_resize_triangle", "oar_k_threshold",
-    "oar_k_ctc_argmax", "oar_k_box_scores", "oar_k_rotate_crop", "oar_prof_reset", "oar_prof_enable", "oar_prof_snapshot",
+    "oar_k_ctc_argmax", "oar_k_box_scores", "oar_k_rotate_crop", "oar_prof_reset", "oar_prof_enable", "oar_prof_filter", "oar_prof_snapshot",
 ]
 
 
@@ -147,6 +147,8 @@ def lib():
     L.oar_prof_reset.restype = None
     L.oar_prof_enable.argtypes = [C.c_int32]
     L.oar_prof_enable.restype = None
+    L.oar_prof_filter.argtypes = [C.c_char_p]
+    L.oar_prof_filter.restype = None
     L.oar_prof_snapshot.argtypes = [C.POINTER(ProfEntry), C.c_int32]
     L.oar_prof_snapshot.restype = C.c_int32
     _lib = L
@@ -631,6 +633,10 @@ class DeviceBuffer:
 
 def prof_enable(on: bool = True):
     lib().oar_prof_enable(int(on))
+
+
+def prof_filter(name: str = ""):
+    lib().oar_prof_filter(name.encode() if name else None)
 
 
 def prof_reset():

@@ -489,6 +489,7 @@ void oar_prof_reset(void) {
     try { Profiler::get().reset(); } catch (...) {}
 }
 void oar_prof_enable(int32_t on) { Profiler::get().enabled = on != 0; }
+void oar_prof_filter(const char* cls) { Profiler::get().filter = cls ? cls : ""; }
 int32_t oar_prof_snapshot(oar_prof_entry* entries, int32_t cap) {
     try {
         Profiler& p = Profiler::get();

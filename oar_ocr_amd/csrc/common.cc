@@ -1,6 +1,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace oar {
 
@@ -10,6 +11,8 @@ const std::string& last_error() { return g_last_error; }
 
 Profiler& Profiler::get() {
     static Profiler p;
+    static bool init = [] { const char* e = getenv("OAR_PROF_DETAIL"); p.detail = e && e[0] == '1'; return true; }();
+    (void)init;
     return p;
 }
 int Profiler::cls(const char* name) {

@@ -93,6 +93,8 @@ struct Profiler {
     };
     std::mutex mu;
     bool enabled = false;
+    bool detail = false;  // OAR_PROF_DETAIL=1: split conv classes by shape
+    std::string filter;  // when non-empty only this kernel class is instrumented
     std::vector<std::string> names;
     std::map<std::string, int> index;
     std::vector<oar_prof_entry> totals;
@@ -113,7 +115,7 @@ struct ProfScope {
     bool on;
     ProfScope(hipStream_t s_, const char* name, double bytes, double flops) : s(s_) {
         Profiler& p = Profiler::get();
-        on = p.enabled;
+        on = p.enabled && (p.filter.empty() || p.filter == name);
         if (on) p.begin(s, p.cls(name), bytes, flops);
     }
     ~ProfScope() {

@@ -212,7 +212,13 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     dim3 grid((unsigned)((p.M + 255) / 256), (unsigned)((nfrag + NT - 1) / NT));
     double flops = 2.0 * (double)p.M * p.K * p.gemm_cout;
     double bytes = 4.0 * ((double)c.N * c.H * c.W * c.Cin + (double)p.M * p.gemm_cout + (double)p.K * p.gemm_cout);
-    ProfScope ps(s, "conv_igemm", bytes, flops);
+    char pname[96];
+    const char* cls = "conv_igemm";
+    if (Profiler::get().detail) {
+        snprintf(pname, sizeof pname, "conv_igemm M=%ld K=%d N=%d k%dx%d s%d%s", p.M, p.K, p.gemm_cout, c.kh, c.kw, c.sh, c.convt2x2 ? " convT" : "");
+        cls = pname;
+    }
+    ProfScope ps(s, cls, bytes, flops);
 #define LAUNCH(NTV)                                                                                      \
     do {                                                                                                 \
         if (is1x1) hipLaunchKernelGGL((conv_igemm_kernel<NTV, true>), grid, dim3(256), 0, s, p);        \
@@ -275,7 +281,10 @@ void conv_dw(hipStream_t s, const ConvP& p) {
     if (total == 0) return;
     double bytes = 4.0 * ((double)p.N * p.H * p.W * p.Cin + (double)p.N * p.Ho * p.Wo * p.Cout + (double)p.kh * p.kw * p.Cout);
     double flops = 2.0 * (double)p.N * p.Ho * p.Wo * p.Cout * p.kh * p.kw;
-    ProfScope ps(s, "conv_dw", bytes, flops);
+    char pname[96];
+    const char* cls = "conv_dw";
+    if (Profiler::get().detail) { snprintf(pname, sizeof pname, "conv_dw px=%ld C=%d k%d s%d", (long)p.N * p.Ho * p.Wo, p.Cout, p.kh, p.sh); cls = pname; }
+    ProfScope ps(s, cls, bytes, flops);
     dim3 g(grid_for(total)), b(256);
     if (p.kh == 3 && p.kw == 3) hipLaunchKernelGGL((conv_dw_kernel<3, 3>), g, b, 0, s, p);
     else if (p.kh == 5 && p.kw == 5) hipLaunchKernelGGL((conv_dw_kernel<5, 5>), g, b, 0, s, p);

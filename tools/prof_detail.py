@@ -1,0 +1,22 @@
+import sys, json
+sys.path.insert(0,'.')
+import numpy as np
+from oar_ocr_amd import api
+from oar_ocr_amd.synth import models, pages
+det,_=models.build_det(); rec,_=models.build_rec()
+chars=api.read_dict(models.synth_dict())
+P=[pages.make_page(i,(960,960),40) for i in range(32)]
+bufs=[api.DeviceBuffer(p) for p in P]
+ocr=api.OAROCRBuilder(det,rec,chars).text_detection_config(api.TextDetectionConfig(0.3,0.6,1.5)).image_batch_size(32).region_batch_size(64).build()
+ptrs=[int(b.ptr.value) for b in bufs]
+ocr.predict_device(ptrs,[960]*32,[960]*32,raw=True)
+api.prof_enable(True); api.prof_reset()
+import time
+t=time.perf_counter(); r=ocr.predict_device(ptrs,[960]*32,[960]*32,raw=True); dt=time.perf_counter()-t
+snap=api.prof_snapshot()
+print('step ms',dt*1e3, r)
+tot=sum(e['total_ms'] for e in snap)
+print('total kernel ms',tot, 'classes',len(snap))
+for e in snap[:64]:
+    ms=e['total_ms']; 
+    print(f"{e['name']:60s} n={e['launches']:4d} ms={ms:8.3f} us/launch={ms*1e3/max(e['launches'],1):8.1f} GB/s={e['alg_bytes']/ms/1e6 if ms else 0:8.1f} TF={e['alg_flops']/ms/1e9 if ms else 0:6.2f}")
