@@ -160,6 +160,13 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    # release native handles explicitly: destroying them from interpreter teardown (after the HIP runtime / a
+    # profiler tool has finalised) was observed to hang the process under rocprofv3
+    ocr.close()
+    for b in dev_pages:
+        b.free()
+    sys.stdout.flush()
+    sys.stderr.flush()
 
 
 if __name__ == "__main__":

@@ -225,10 +225,17 @@ class OrtInfer:
         _check(lib().oar_engine_cost(self._h, dims, len(shape), C.byref(fl), C.byref(by), C.byref(nk)))
         return fl.value, by.value, nk.value
 
-    def __del__(self):
+    def close(self):
+        """Releases the native handle (streams, HBM). Safe to call twice."""
         if getattr(self, "_h", None) and _lib is not None:
             _lib.oar_engine_destroy(self._h)
             self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ------------------------------------------------------------------------------------------------ host-side types
@@ -356,10 +363,17 @@ class TextDetectionPredictor:
         lib().oar_det_result_free(C.byref(res))
         return out
 
-    def __del__(self):
+    def close(self):
+        """Releases the native handle (streams, HBM). Safe to call twice."""
         if getattr(self, "_h", None) and _lib is not None:
             _lib.oar_det_destroy(self._h)
             self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _unpack_det(res: DetResult) -> List[List[Detection]]:
@@ -429,10 +443,17 @@ class TextRecognitionPredictor:
                 texts[i], pos[i], cols[i] = "", [], []
         return TextRecognitionOutput(texts, scores, pos, cols, lens, idx.reshape(n, T), pr.reshape(n, T), tw)
 
-    def __del__(self):
+    def close(self):
+        """Releases the native handle (streams, HBM). Safe to call twice."""
         if getattr(self, "_h", None) and _lib is not None:
             _lib.oar_rec_destroy(self._h)
             self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ------------------------------------------------------------------------------------------------ pipeline
@@ -573,10 +594,17 @@ class OAROCR:
             results.append(OAROCRResult(f"image_{i}", i, regions))
         return results
 
-    def __del__(self):
+    def close(self):
+        """Releases the native handle (streams, HBM). Safe to call twice."""
         if getattr(self, "_h", None) and _lib is not None:
             _lib.oar_ocr_destroy(self._h)
             self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def ctc_word_boxes(line_bbox: np.ndarray, text: str, col_indices, seq_len: int, wh_ratio: float, max_wh_ratio: float):

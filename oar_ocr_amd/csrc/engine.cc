@@ -430,6 +430,18 @@ struct Planner {
     }
 
     // ------------------------------------------------------------------ weights
+    // [rows][K] row-major GEMM weights -> MFMA fragment order Wf[rows/16][KC][lane][4]
+    // (lane = (row & 15) + 16 * g holds k = 16*kc + 4*g + j, j = 0..3); rows padded to 64, K to 16.
+    static std::vector<float> to_fragment_order(const std::vector<float>& w, int64_t rows, int64_t K) {
+        int64_t Rp = (rows + 63) / 64 * 64, KC = (K + 15) / 16;
+        std::vector<float> f((size_t)Rp * KC * 16, 0.f);
+        for (int64_t r = 0; r < rows; ++r)
+            for (int64_t k = 0; k < K; ++k) {
+                int64_t nf = r / 16, c = r % 16, kc = k / 16, g = (k % 16) / 4, j = k % 4;
+                f[(size_t)(((nf * KC + kc) * 64 + (c + 16 * g)) * 4 + j)] = w[(size_t)r * K + k];
+            }
+        return f;
+    }
     const float* conv_weight_igemm(const GNode& n, const HostTensor& W) {
         std::string key = "igemm:" + n.in[1];
         auto it = E.dev_consts_.find(key);
@@ -442,7 +454,9 @@ struct Planner {
                 for (int64_t a = 0; a < kh; ++a)
                     for (int64_t b = 0; b < kw; ++b)
                         w[(size_t)co * K + (a * kw + b) * Ci + ci] = W.f[((co * Ci + ci) * kh + a) * kw + b];
-        return E.upload_const(key, w);
+        (void)Cp;
+        w.resize((size_t)Co * K);
+        return E.upload_const(key, to_fragment_order(w, Co, K));
     }
     const float* conv_weight_dw(const GNode& n, const HostTensor& W) {
         std::string key = "dw:" + n.in[1];
@@ -475,13 +489,14 @@ struct Planner {
         int64_t Ci = W.dims[0], Co = W.dims[1], kh = W.dims[2], kw = W.dims[3];
         std::vector<float> w;
         if (igemm) {
-            int64_t rows = (kh * kw * Co + 63) / 64 * 64;
+            int64_t rows = kh * kw * Co;
             w.assign((size_t)rows * Ci, 0.f);
             for (int64_t ci = 0; ci < Ci; ++ci)
                 for (int64_t co = 0; co < Co; ++co)
                     for (int64_t a = 0; a < kh; ++a)
                         for (int64_t b = 0; b < kw; ++b)
                             w[(size_t)((a * kw + b) * Co + co) * Ci + ci] = W.f[((ci * Co + co) * kh + a) * kw + b];
+            w = to_fragment_order(w, rows, Ci);
         } else {
             w.assign((size_t)kh * kw * Ci * Co, 0.f);
             for (int64_t ci = 0; ci < Ci; ++ci)
@@ -497,11 +512,10 @@ struct Planner {
         auto it = E.dev_consts_.find(key);
         if (it != E.dev_consts_.end()) return it->second;
         int64_t K = transB ? B.dims[1] : B.dims[0], N = transB ? B.dims[0] : B.dims[1];
-        int64_t Np = (N + 63) / 64 * 64;
-        std::vector<float> w((size_t)Np * K, 0.f);
+        std::vector<float> w((size_t)N * K, 0.f);
         for (int64_t kk = 0; kk < K; ++kk)
             for (int64_t nn = 0; nn < N; ++nn) w[(size_t)nn * K + kk] = transB ? B.f[nn * K + kk] : B.f[kk * N + nn];
-        return E.upload_const(key, w);
+        return E.upload_const(key, to_fragment_order(w, N, K));
     }
 
     // ------------------------------------------------------------------ ops

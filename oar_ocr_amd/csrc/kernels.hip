@@ -37,117 +37,131 @@ __device__ __forceinline__ float apply_act(float v, int kind, float alpha, float
 }
 
 // ------------------------------------------------------------------------------------------ implicit-GEMM conv
-// GEMM view: D[cout][pixel] = sum_k Wt[cout][k] * X[pixel][k];  k = (kh, kw, ci), ci innermost.
+// GEMM view: D[cout][pixel] = sum_k W[cout][k] * X[pixel][k];  k = (kh, kw, ci), ci innermost (NHWC).
 // MFMA 16x16x4 f32 operand map (cdna_hip_programming.md section 3): A[i = lane&15][k = lane>>4],
 // B[k = lane>>4][j = lane&15], D[row = (lane>>4)*4 + r][col = lane&15].  A = weights (rows = cout),
-// B = im2col pixels (cols = pixel), so each lane ends up with 4 CONSECUTIVE output channels of one pixel:
-// a single 16-byte NHWC store.
-// Workgroup = 4 waves = 256 pixels x NT*16 couts; each wave owns 64 pixels (4 pixel fragments).
-// LDS tiles are [row][16 k + 1 pad]: the fragment read `row = lane&15, k = lane>>4` walks stride-17 rows,
-// conflict-free across a 32-lane ds_read_b32 group (17 is odd).
+// B = pixels (cols = pixel), so a lane ends with 4 CONSECUTIVE output channels of one pixel = one 16-byte
+// NHWC store.
+//
+// No LDS and no barriers: within a 16-deep K chunk lane (p = lane&15, g = lane>>4) loads ONE float4
+// X[pixel p][16*kc + 4g .. +3] straight from HBM (16 pixels x 64 contiguous bytes per wave instruction) and
+// feeds component j to MFMA step j, i.e. step j contracts k = {j, 4+j, 8+j, 12+j}.  The weights are stored
+// host-side in the matching fragment order Wf[cout/16][kc][lane][4] so the A operand is one coalesced float4
+// per lane (1 KiB per wave instruction, identical for every wave => L1/L2 resident).  The K permutation is the
+// same on both operands, so the contraction is exact.
+// Workgroup = 4 independent waves; a wave owns PF*16 pixels x NT*16 couts (accumulators NT*PF*4 VGPRs).
 struct IgemmP {
     const float* x;
-    const float* w;
+    const float* w;      // fragment order, see above; KC = ceil(K/16) chunks, rows padded to 64 couts
     const float* bias;
     const float* res;
     float* y;
-    long M;            // N*Ho*Wo pixels
-    int K;             // kh*kw*Cin
-    int gemm_cout;     // rows of the GEMM (Cout, or 4*Cout for convT 2x2)
-    int Cout;          // real channel count of y
+    long M;              // GEMM columns: N*Ho*Wo pixels (convT: input pixels)
+    int K, KC;
+    int gemm_cout;       // GEMM rows (Cout, or 4*Cout for convT 2x2)
+    int Cout;            // channel count of y
     int H, W, Cin, Ho, Wo, kh, kw, sh, sw, pt, pl, dh, dw;
     int y_ld;
     int act, convt;
     float alpha, beta;
 };
 
-template <int NT, bool IS1X1>
+template <int NT, int PF, bool IS1X1>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmP p) {
-    __shared__ float Xs[256][17];
-    __shared__ float Ws[NT * 16][17];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long m0 = (long)blockIdx.x * 256;
-    const int n0 = blockIdx.y * NT * 16;
-    const int lrow = tid >> 2, lq = tid & 3;  // loader: 64 rows per pass, 4 k-quads per row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pl_ = lane & 15, g = lane >> 4;
+    const long m0 = ((long)blockIdx.x * 4 + wave) * (PF * 16);
+    const int nf0 = blockIdx.y * NT;
+    if (m0 >= p.M) return;
 
-    // per-pass pixel decode (fixed over the K loop)
-    long pix_base[4];
-    int ih0[4], iw0[4];
+    long pix_base[PF];
+    int ih0[PF], iw0[PF];
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        long m = m0 + ps * 64 + lrow;
+    for (int pf = 0; pf < PF; ++pf) {
+        long m = m0 + pf * 16 + pl_;
         if (m < p.M) {
             if (IS1X1) {
-                pix_base[ps] = m * (long)p.Cin;
-                ih0[ps] = 0; iw0[ps] = 0;
+                pix_base[pf] = m * (long)p.Cin; ih0[pf] = 0; iw0[pf] = 0;
             } else {
                 long hw = (long)p.Ho * p.Wo;
                 long n = m / hw; long r = m - n * hw;
                 int oh = (int)(r / p.Wo), ow = (int)(r - (long)oh * p.Wo);
-                pix_base[ps] = n * (long)p.H * p.W * p.Cin;
-                ih0[ps] = oh * p.sh - p.pt; iw0[ps] = ow * p.sw - p.pl;
+                pix_base[pf] = n * (long)p.H * p.W * p.Cin;
+                ih0[pf] = oh * p.sh - p.pt; iw0[pf] = ow * p.sw - p.pl;
             }
         } else {
-            pix_base[ps] = -1; ih0[ps] = 0; iw0[ps] = 0;
+            pix_base[pf] = -1; ih0[pf] = 0; iw0[pf] = 0;
         }
     }
-
-    f32x4 acc[NT][4];
+    f32x4 acc[NT][PF];
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < PF; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = 0; k0 < p.K; k0 += 16) {
-        const int k = k0 + 4 * lq;
-        int tap_h = 0, tap_w = 0, ci = k;
-        if (!IS1X1) {
-            int tap = k / p.Cin; ci = k - tap * p.Cin;
-            tap_h = tap / p.kw; tap_w = tap - tap_h * p.kw;
-        }
+    // this lane's k position: k = 16*kc + 4*g ; (tap_h, tap_w, ci) tracked incrementally for the general case
+    int ci = 4 * g, tap_h = 0, tap_w = 0;
+    if (!IS1X1) {
+        while (ci >= p.Cin) { ci -= p.Cin; if (++tap_w == p.kw) { tap_w = 0; ++tap_h; } }
+    }
+    const float4* wf = reinterpret_cast<const float4*>(p.w) + ((long)nf0 * p.KC) * 64 + lane;
+
+    auto load_x = [&](int kc, float4 (&xv)[PF]) {
+        const int k = kc * 16 + 4 * g;
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
+        for (int pf = 0; pf < PF; ++pf) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pix_base[ps] >= 0 && k < p.K) {
+            if (pix_base[pf] >= 0 && k < p.K) {
                 if (IS1X1) {
-                    v = *reinterpret_cast<const float4*>(p.x + pix_base[ps] + k);
+                    v = *reinterpret_cast<const float4*>(p.x + pix_base[pf] + k);
                 } else {
-                    int ih = ih0[ps] + tap_h * p.dh, iw = iw0[ps] + tap_w * p.dw;
+                    int ih = ih0[pf] + tap_h * p.dh, iw = iw0[pf] + tap_w * p.dw;
                     if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
-                        v = *reinterpret_cast<const float4*>(p.x + pix_base[ps] + ((long)ih * p.W + iw) * p.Cin + ci);
+                        v = *reinterpret_cast<const float4*>(p.x + pix_base[pf] + ((long)ih * p.W + iw) * p.Cin + ci);
                 }
             }
-            float* d = &Xs[ps * 64 + lrow][4 * lq];
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            xv[pf] = v;
         }
-        if (tid < NT * 64) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < p.K) v = *reinterpret_cast<const float4*>(p.w + (long)(n0 + lrow) * p.K + k);
-            float* d = &Ws[lrow][4 * lq];
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        if (!IS1X1) {  // advance this lane's k by 16 for the next chunk
+            ci += 16;
+            while (ci >= p.Cin) { ci -= p.Cin; if (++tap_w == p.kw) { tap_w = 0; ++tap_h; } }
         }
-        __syncthreads();
+    };
+    auto load_w = [&](int kc, float4 (&wv)[NT]) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            float a[NT], b[4];
+        for (int nf = 0; nf < NT; ++nf) wv[nf] = wf[((long)nf * p.KC + kc) * 64];
+    };
+    auto mma = [&](const float4 (&wv)[NT], const float4 (&xv)[PF]) {
 #pragma unroll
-            for (int nf = 0; nf < NT; ++nf) a[nf] = Ws[nf * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+        for (int nf = 0; nf < NT; ++nf)
 #pragma unroll
-            for (int pf = 0; pf < 4; ++pf) b[pf] = Xs[wave * 64 + pf * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
-#pragma unroll
-            for (int nf = 0; nf < NT; ++nf)
-#pragma unroll
-                for (int pf = 0; pf < 4; ++pf)
-                    acc[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nf], b[pf], acc[nf][pf], 0, 0, 0);
-        }
-        __syncthreads();
+            for (int pf = 0; pf < PF; ++pf) {
+                acc[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nf].x, xv[pf].x, acc[nf][pf], 0, 0, 0);
+                acc[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nf].y, xv[pf].y, acc[nf][pf], 0, 0, 0);
+                acc[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nf].z, xv[pf].z, acc[nf][pf], 0, 0, 0);
+                acc[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nf].w, xv[pf].w, acc[nf][pf], 0, 0, 0);
+            }
+    };
+
+    // software pipeline: chunk kc+1 is in flight while chunk kc is multiplied
+    float4 xa[PF], xb[PF], wa[NT], wb[NT];
+    load_x(0, xa);
+    load_w(0, wa);
+    int kc = 0;
+    for (; kc + 1 < p.KC; kc += 2) {
+        load_x(kc + 1, xb);
+        load_w(kc + 1, wb);
+        mma(wa, xa);
+        if (kc + 2 < p.KC) { load_x(kc + 2, xa); load_w(kc + 2, wa); }
+        mma(wb, xb);
     }
+    if (kc < p.KC) mma(wa, xa);
 
     // epilogue: bias + residual + activation, 16-byte NHWC stores
     const bool vec_ok = ((p.Cout & 3) == 0) && ((p.y_ld & 3) == 0);
 #pragma unroll
-    for (int pf = 0; pf < 4; ++pf) {
-        long m = m0 + wave * 64 + pf * 16 + (lane & 15);
+    for (int pf = 0; pf < PF; ++pf) {
+        long m = m0 + pf * 16 + pl_;
         if (m >= p.M) continue;
         long obase;
         if (p.convt) {
@@ -160,7 +174,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmP p) {
         }
 #pragma unroll
         for (int nf = 0; nf < NT; ++nf) {
-            int c = n0 + nf * 16 + (lane >> 4) * 4;
+            int c = (nf0 + nf) * 16 + g * 4;
             if (c >= p.gemm_cout) continue;
             f32x4 v = acc[nf][pf];
             float o[4] = {v[0], v[1], v[2], v[3]};
@@ -198,18 +212,19 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     p.act = c.act.kind; p.alpha = c.act.alpha; p.beta = c.act.beta;
     p.convt = c.convt2x2; p.Cout = c.Cout;
     if (c.convt2x2) {
-        p.Ho = c.H; p.Wo = c.W;  // GEMM rows are INPUT pixels
+        p.Ho = c.H; p.Wo = c.W;  // GEMM columns are INPUT pixels
         p.M = (long)c.N * c.H * c.W; p.K = c.Cin; p.gemm_cout = 4 * c.Cout;
     } else {
         p.Ho = c.Ho; p.Wo = c.Wo;
         p.M = (long)c.N * c.Ho * c.Wo; p.K = c.kh * c.kw * c.Cin; p.gemm_cout = c.Cout;
     }
+    p.KC = (p.K + 15) / 16;
     if (p.M == 0) return;
     const bool is1x1 = c.convt2x2 || (c.kh == 1 && c.kw == 1 && c.sh == 1 && c.sw == 1 && c.pt == 0 && c.pl == 0);
     int nfrag = (p.gemm_cout + 15) / 16;
-    int NT = nfrag >= 4 ? 4 : (nfrag >= 2 ? 2 : 1);
-    if (nfrag == 3) NT = 4;
-    dim3 grid((unsigned)((p.M + 255) / 256), (unsigned)((nfrag + NT - 1) / NT));
+    int NT = nfrag >= 3 ? 4 : (nfrag == 2 ? 2 : 1);
+    constexpr int PF = 4;
+    dim3 grid((unsigned)((p.M + 4 * PF * 16 - 1) / (4 * PF * 16)), (unsigned)((nfrag + NT - 1) / NT));
     double flops = 2.0 * (double)p.M * p.K * p.gemm_cout;
     double bytes = 4.0 * ((double)c.N * c.H * c.W * c.Cin + (double)p.M * p.gemm_cout + (double)p.K * p.gemm_cout);
     char pname[96];
@@ -219,10 +234,10 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
         cls = pname;
     }
     ProfScope ps(s, cls, bytes, flops);
-#define LAUNCH(NTV)                                                                                      \
-    do {                                                                                                 \
-        if (is1x1) hipLaunchKernelGGL((conv_igemm_kernel<NTV, true>), grid, dim3(256), 0, s, p);        \
-        else hipLaunchKernelGGL((conv_igemm_kernel<NTV, false>), grid, dim3(256), 0, s, p);             \
+#define LAUNCH(NTV)                                                                                          \
+    do {                                                                                                     \
+        if (is1x1) hipLaunchKernelGGL((conv_igemm_kernel<NTV, PF, true>), grid, dim3(256), 0, s, p);        \
+        else hipLaunchKernelGGL((conv_igemm_kernel<NTV, PF, false>), grid, dim3(256), 0, s, p);             \
     } while (0)
     if (NT == 4) LAUNCH(4);
     else if (NT == 2) LAUNCH(2);

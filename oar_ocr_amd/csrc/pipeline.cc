@@ -290,7 +290,9 @@ Recognizer::Recognizer(const uint8_t* onnx, size_t len, const oar_rec_cfg& cfg) 
     eng_.reset(new Engine(onnx, len, cfg_.device_id));
 }
 
-const float* Recognizer::pack(const std::vector<Crop>& crops, int& Wt, bool nchw) {
+const float* Recognizer::pack(const std::vector<Crop>& crops, int& Wt, bool nchw, size_t desc_slot, size_t stage_slot) {
+    // desc_slot / stage_slot: element / byte offsets into the pinned + device staging areas, so that several batches
+    // can be enqueued without the host overwriting a descriptor block an earlier async copy has not consumed yet.
     hipStream_t s = eng_->stream();
     const int n = (int)crops.size();
     const int img_h = (int)cfg_.rec_image_shape[1], img_w = (int)cfg_.rec_image_shape[2];
@@ -304,14 +306,19 @@ const float* Recognizer::pack(const std::vector<Crop>& crops, int& Wt, bool nchw
     std::vector<int32_t> rws;
     Wt = host::rec_tensor_width(ws, hs, img_h, img_w, (int)cfg_.max_img_w, rws);
     size_t need_in = (size_t)n * 3 * img_h * Wt * sizeof(float);
-    if (stage > crops_dev_.cap || need_in > input_f32_.cap || (size_t)n * sizeof(pp::CropDesc) > descs_dev_.cap) {
+    size_t need_desc = (desc_slot + n) * sizeof(pp::CropDesc), need_stage = stage_slot + stage;
+    if (need_stage > crops_dev_.cap || need_in > input_f32_.cap || need_desc > descs_dev_.cap) {
         OAR_HIP(hipStreamSynchronize(s));
-        crops_dev_.reserve(stage); input_f32_.reserve(need_in); descs_dev_.reserve((size_t)n * sizeof(pp::CropDesc));
+        OAR_CHECK(desc_slot == 0 && stage_slot == 0, OAR_INTERNAL, "recognizer staging buffers must be pre-sized for multi-batch runs");
+        crops_dev_.reserve(need_stage); input_f32_.reserve(need_in); descs_dev_.reserve(need_desc);
     }
-    descs_host_.reserve((size_t)n * sizeof(pp::CropDesc));
-    stage_host_.reserve(stage);
-    pp::CropDesc* dh = descs_host_.as<pp::CropDesc>();
-    size_t off = 0;
+    if (need_desc > descs_host_.cap || need_stage > stage_host_.cap) {
+        OAR_CHECK(desc_slot == 0 && stage_slot == 0, OAR_INTERNAL, "recognizer pinned buffers must be pre-sized for multi-batch runs");
+        descs_host_.reserve(need_desc); stage_host_.reserve(need_stage);
+    }
+    pp::CropDesc* dh = descs_host_.as<pp::CropDesc>() + desc_slot;
+    pp::CropDesc* dd = descs_dev_.as<pp::CropDesc>() + desc_slot;
+    size_t off = stage_slot;
     for (int i = 0; i < n; ++i) {
         const uint8_t* d = crops[i].dev;
         if (!d) {
@@ -322,9 +329,9 @@ const float* Recognizer::pack(const std::vector<Crop>& crops, int& Wt, bool nchw
         }
         dh[i].src = d; dh[i].w = (int)crops[i].w; dh[i].h = (int)crops[i].h; dh[i].rw = rws[i]; dh[i].pad = 0;
     }
-    if (stage) OAR_HIP(hipMemcpyAsync(crops_dev_.p, stage_host_.p, stage, hipMemcpyHostToDevice, s));
-    OAR_HIP(hipMemcpyAsync(descs_dev_.p, dh, (size_t)n * sizeof(pp::CropDesc), hipMemcpyHostToDevice, s));
-    pp::rec_pack(s, descs_dev_.as<pp::CropDesc>(), n, img_h, Wt, input_f32_.as<float>(), nchw ? 1 : 0);
+    if (stage) OAR_HIP(hipMemcpyAsync(crops_dev_.as<uint8_t>() + stage_slot, stage_host_.as<uint8_t>() + stage_slot, stage, hipMemcpyHostToDevice, s));
+    OAR_HIP(hipMemcpyAsync(dd, dh, (size_t)n * sizeof(pp::CropDesc), hipMemcpyHostToDevice, s));
+    pp::rec_pack(s, dd, n, img_h, Wt, input_f32_.as<float>(), nchw ? 1 : 0);
     return input_f32_.as<float>();
 }
 
@@ -343,35 +350,91 @@ void Recognizer::pack_only(const std::vector<Crop>& crops, std::vector<float>& n
 }
 
 void Recognizer::run(const std::vector<Crop>& crops, RecOut& out) {
+    std::vector<std::vector<Crop>> b(1, crops);
+    std::vector<RecOut> o;
+    run_batches(b, o);
+    out = std::move(o[0]);
+}
+
+void Recognizer::run_batches(const std::vector<std::vector<Crop>>& batches, std::vector<RecOut>& outs) {
     std::lock_guard<std::mutex> lk(mu_);
-    out = RecOut();
-    const int n = (int)crops.size();
-    if (n == 0) return;
+    outs.assign(batches.size(), RecOut());
     OAR_HIP(hipSetDevice(eng_->device()));
     hipStream_t s = eng_->stream();
-    int Wt = 0;
-    const float* in = pack(crops, Wt, false);
-    const int img_h = (int)cfg_.rec_image_shape[1];
-    const Plan& plan = eng_->run(in, {n, 3, img_h, Wt}, true);
-    OAR_CHECK(!plan.outputs.empty(), OAR_INTERNAL, "CRNN: no output returned from inference");
-    const PlanOutput& po = plan.outputs[0];
-    OAR_CHECK(po.dims.size() == 3, OAR_SHAPE_MISMATCH, "CRNN: expected 3D output (batch, time, vocab)");  // crnn.rs:273-279
-    OAR_CHECK(po.dims[0] == n, OAR_SHAPE_MISMATCH, "CRNN: output batch differs from input batch");
-    const int64_t T = po.dims[1], V = po.dims[2];
-    const int64_t rows = (int64_t)n * T;
-    out.T = (uint32_t)T; out.V = (uint32_t)V; out.Wt = (uint32_t)Wt;
-    if (rows == 0 || V == 0) return;
-    if ((size_t)rows * 8 > idx_dev_.cap || (size_t)rows * 4 > prob_dev_.cap) {
-        OAR_HIP(hipStreamSynchronize(s));
-        idx_dev_.reserve((size_t)rows * 8); prob_dev_.reserve((size_t)rows * 4);
+    const int img_h = (int)cfg_.rec_image_shape[1], img_w = (int)cfg_.rec_image_shape[2];
+    // pre-size every staging area for the whole run so nothing is reallocated (or overwritten) mid-flight
+    size_t total_crops = 0, total_stage = 0, max_in = 0;
+    for (auto& b : batches) {
+        std::vector<uint32_t> ws, hs;
+        for (auto& c : b) {
+            ws.push_back(c.w); hs.push_back(c.h);
+            OAR_CHECK(c.w > 0 && c.h > 0 && (c.host || c.dev), OAR_INVALID_INPUT, "recognizer: empty crop");
+            if (!c.dev) total_stage += ((size_t)c.w * c.h * 3 + 63) & ~(size_t)63;
+        }
+        if (b.empty()) continue;
+        std::vector<int32_t> rws;
+        int Wt = host::rec_tensor_width(ws, hs, img_h, img_w, (int)cfg_.max_img_w, rws);
+        max_in = std::max(max_in, (size_t)b.size() * 3 * img_h * Wt * sizeof(float));
+        total_crops += b.size();
     }
-    idx_host_.reserve((size_t)rows * 8); prob_host_.reserve((size_t)rows * 4);
-    pp::ctc_argmax(s, eng_->out_ptr(po.loc), rows, (int)V, idx_dev_.as<int64_t>(), prob_dev_.as<float>());
-    OAR_HIP(hipMemcpyAsync(idx_host_.p, idx_dev_.p, (size_t)rows * 8, hipMemcpyDeviceToHost, s));
-    OAR_HIP(hipMemcpyAsync(prob_host_.p, prob_dev_.p, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
+    if (total_crops == 0) return;
+    if (total_stage > crops_dev_.cap || max_in > input_f32_.cap || total_crops * sizeof(pp::CropDesc) > descs_dev_.cap) {
+        OAR_HIP(hipStreamSynchronize(s));
+        crops_dev_.reserve(total_stage); input_f32_.reserve(max_in); descs_dev_.reserve(total_crops * sizeof(pp::CropDesc));
+    }
+    descs_host_.reserve(total_crops * sizeof(pp::CropDesc));
+    stage_host_.reserve(total_stage);
+
+    struct Pending { size_t row0, rows; };
+    std::vector<Pending> pend(batches.size(), Pending{0, 0});
+    size_t desc_slot = 0, stage_slot = 0, row_total = 0;
+    // first pass: plans (shape inference only) to size the result buffers
+    std::vector<int> Wts(batches.size(), 0);
+    for (size_t bi = 0; bi < batches.size(); ++bi) {
+        const auto& b = batches[bi];
+        if (b.empty()) continue;
+        std::vector<uint32_t> ws, hs;
+        for (auto& c : b) { ws.push_back(c.w); hs.push_back(c.h); }
+        std::vector<int32_t> rws;
+        Wts[bi] = host::rec_tensor_width(ws, hs, img_h, img_w, (int)cfg_.max_img_w, rws);
+        const Plan& plan = eng_->plan_for({(int64_t)b.size(), 3, img_h, Wts[bi]}, true);
+        OAR_CHECK(!plan.outputs.empty(), OAR_INTERNAL, "CRNN: no output returned from inference");
+        const PlanOutput& po = plan.outputs[0];
+        OAR_CHECK(po.dims.size() == 3, OAR_SHAPE_MISMATCH, "CRNN: expected 3D output (batch, time, vocab)");  // crnn.rs:273-279
+        OAR_CHECK(po.dims[0] == (int64_t)b.size(), OAR_SHAPE_MISMATCH, "CRNN: output batch differs from input batch");
+        outs[bi].T = (uint32_t)po.dims[1]; outs[bi].V = (uint32_t)po.dims[2]; outs[bi].Wt = (uint32_t)Wts[bi];
+        pend[bi].row0 = row_total; pend[bi].rows = (size_t)b.size() * po.dims[1];
+        if (po.dims[2] == 0) pend[bi].rows = 0;
+        row_total += pend[bi].rows;
+    }
+    if (row_total * 8 > idx_dev_.cap || row_total * 4 > prob_dev_.cap) {
+        OAR_HIP(hipStreamSynchronize(s));
+        idx_dev_.reserve(row_total * 8); prob_dev_.reserve(row_total * 4);
+    }
+    idx_host_.reserve(row_total * 8); prob_host_.reserve(row_total * 4);
+    for (size_t bi = 0; bi < batches.size(); ++bi) {
+        const auto& b = batches[bi];
+        if (b.empty()) continue;
+        int Wt = 0;
+        const float* in = pack(b, Wt, false, desc_slot, stage_slot);
+        desc_slot += b.size();
+        for (auto& c : b) if (!c.dev) stage_slot += ((size_t)c.w * c.h * 3 + 63) & ~(size_t)63;
+        const Plan& plan = eng_->run(in, {(int64_t)b.size(), 3, img_h, Wt}, true);
+        if (pend[bi].rows == 0) continue;
+        const PlanOutput& po = plan.outputs[0];
+        pp::ctc_argmax(s, eng_->out_ptr(po.loc), (int64_t)pend[bi].rows, (int)po.dims[2], idx_dev_.as<int64_t>() + pend[bi].row0,
+                       prob_dev_.as<float>() + pend[bi].row0);
+    }
+    if (row_total) {
+        OAR_HIP(hipMemcpyAsync(idx_host_.p, idx_dev_.p, row_total * 8, hipMemcpyDeviceToHost, s));
+        OAR_HIP(hipMemcpyAsync(prob_host_.p, prob_dev_.p, row_total * 4, hipMemcpyDeviceToHost, s));
+    }
     OAR_HIP(hipStreamSynchronize(s));
-    out.idx.assign(idx_host_.as<int64_t>(), idx_host_.as<int64_t>() + rows);
-    out.prob.assign(prob_host_.as<float>(), prob_host_.as<float>() + rows);
+    for (size_t bi = 0; bi < batches.size(); ++bi) {
+        if (pend[bi].rows == 0) continue;
+        outs[bi].idx.assign(idx_host_.as<int64_t>() + pend[bi].row0, idx_host_.as<int64_t>() + pend[bi].row0 + pend[bi].rows);
+        outs[bi].prob.assign(prob_host_.as<float>() + pend[bi].row0, prob_host_.as<float>() + pend[bi].row0 + pend[bi].rows);
+    }
     if (Profiler::get().enabled) Profiler::get().flush();
 }
 
@@ -405,25 +468,34 @@ void Ocr::predict(const std::vector<PageRef>& pages, std::vector<std::vector<Ocr
         std::vector<PoolItem> sorted = pool;
         std::stable_sort(sorted.begin(), sorted.end(), [](const PoolItem& a, const PoolItem& b) { return a.wh_ratio < b.wh_ratio; });
         const size_t bs = cfg_.region_batch_size;
+        std::vector<std::vector<Recognizer::Crop>> batches;
+        std::vector<float> chunk_max;
         for (size_t c0 = 0; c0 < sorted.size(); c0 += bs) {
             size_t c1 = std::min(sorted.size(), c0 + bs);
             std::vector<Recognizer::Crop> crops;
-            float chunk_max = base_ratio;
+            float cm = base_ratio;
             for (size_t i = c0; i < c1; ++i) {
                 Recognizer::Crop c;
                 c.dev = crop_pool_.as<uint8_t>() + sorted[i].off; c.w = sorted[i].w; c.h = sorted[i].h;
                 crops.push_back(c);
-                if (sorted[i].wh_ratio > chunk_max) chunk_max = sorted[i].wh_ratio;
+                if (sorted[i].wh_ratio > cm) cm = sorted[i].wh_ratio;
             }
-            RecOut ro;
-            rec_->run(crops, ro);
-            for (size_t i = c0; i < c1; ++i) {
-                Slot& sl = per_image[sorted[i].img][sorted[i].det_index];
+            batches.push_back(std::move(crops));
+            chunk_max.push_back(cm);
+        }
+        std::vector<RecOut> ros;
+        rec_->run_batches(batches, ros);
+        for (size_t bi = 0; bi < batches.size(); ++bi) {
+            const RecOut& ro = ros[bi];
+            const size_t c0 = bi * bs;
+            for (size_t k = 0; k < batches[bi].size(); ++k) {
+                Slot& sl = per_image[sorted[c0 + k].img][sorted[c0 + k].det_index];
                 sl.filled = true;
-                sl.r.T = ro.T; sl.r.max_wh_ratio = chunk_max;
-                size_t k = i - c0;
-                sl.r.idx.assign(ro.idx.begin() + k * ro.T, ro.idx.begin() + (k + 1) * ro.T);
-                sl.r.prob.assign(ro.prob.begin() + k * ro.T, ro.prob.begin() + (k + 1) * ro.T);
+                sl.r.T = ro.T; sl.r.max_wh_ratio = chunk_max[bi];
+                if (!ro.idx.empty()) {
+                    sl.r.idx.assign(ro.idx.begin() + k * ro.T, ro.idx.begin() + (k + 1) * ro.T);
+                    sl.r.prob.assign(ro.prob.begin() + k * ro.T, ro.prob.begin() + (k + 1) * ro.T);
+                }
             }
         }
         pool.clear();

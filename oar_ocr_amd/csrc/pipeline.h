@@ -80,12 +80,15 @@ class Recognizer {
     Recognizer(const uint8_t* onnx, size_t len, const oar_rec_cfg& cfg);
     struct Crop { const uint8_t* host = nullptr; const uint8_t* dev = nullptr; uint32_t w = 0, h = 0; };
     void run(const std::vector<Crop>& crops, RecOut& out);
+    // Several recognition batches back to back on the engine stream with ONE synchronisation at the end
+    // (the reference runs them serially under the session lock, src/oarocr/ocr.rs:827-841).
+    void run_batches(const std::vector<std::vector<Crop>>& batches, std::vector<RecOut>& outs);
     // test hook: packed input tensor only
     void pack_only(const std::vector<Crop>& crops, std::vector<float>& nchw, uint32_t& Wt);
     Engine& engine() { return *eng_; }
 
    private:
-    const float* pack(const std::vector<Crop>& crops, int& Wt, bool nchw);
+    const float* pack(const std::vector<Crop>& crops, int& Wt, bool nchw, size_t desc_slot = 0, size_t stage_slot = 0);
     std::unique_ptr<Engine> eng_;
     oar_rec_cfg cfg_;
     DevBuf crops_dev_, descs_dev_, input_f32_, idx_dev_, prob_dev_;
