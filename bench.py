@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--pages", type=int, default=32, help="pages per GPU per step (BASELINE configs[1]: 32)")
     ap.add_argument("--size", type=int, default=960)
     ap.add_argument("--lines", type=int, default=40)
-    ap.add_argument("--region-batch", type=int, default=64, help="recognition batch (reference accelerator default 64)")
+    ap.add_argument("--region-batch", type=int, default=256, help="recognition batch (this backend's recommended_batch_size; reference adapter: 64)")
     ap.add_argument("--cpu-pages", type=int, default=3, help="pages in the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-prof", action="store_true")
     args = ap.parse_args()

@@ -167,7 +167,7 @@ typedef struct {
     float det_box_thresh;      /* builder default 0.6                                         */
     float det_unclip_ratio;    /* builder default 2.0; explicit TextDetectionConfig: 1.5      */
     uint32_t image_batch_size; /* 0 => adapter recommended 8  (text_detection_adapter.rs:85-87)   */
-    uint32_t region_batch_size;/* 0 => adapter recommended 64 (text_recognition_adapter.rs:117-127) */
+    uint32_t region_batch_size;/* 0 => this backend's recommended 256 (reference adapter: 64, text_recognition_adapter.rs:117-127) */
     uint32_t max_pooled_crops; /* 0 => 4096 (src/oarocr/ocr.rs:603)                            */
 } oar_ocr_cfg;
 

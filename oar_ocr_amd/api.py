@@ -422,7 +422,7 @@ class TextRecognitionPredictor:
 
     @staticmethod
     def recommended_batch_size() -> int:
-        return 64  # text_recognition_adapter.rs:117-127
+        return 256  # reference adapter reports 64 (text_recognition_adapter.rs:117-127); this backend recommends 256
 
     def predict(self, images: Sequence[np.ndarray]) -> TextRecognitionOutput:
         if len(images) == 0:

@@ -9,6 +9,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace oar {
@@ -63,15 +65,54 @@ struct IgemmP {
     int H, W, Cin, Ho, Wo, kh, kw, sh, sw, pt, pl, dh, dw;
     int y_ld;
     int act, convt;
+    int ny;              // number of cout tiles (for the XCD-aware tile order)
+    long mx_per_xcd;     // pixel tiles per XCD band
     float alpha, beta;
 };
 
+__device__ __forceinline__ void igemm_store(const IgemmP& p, f32x4 v, bool valid, long obase, int c, bool vec_ok) {
+    if (!valid || c >= p.gemm_cout) return;
+    float o[4] = {v[0], v[1], v[2], v[3]};
+    if (vec_ok) {
+        int co = c; long opix = obase;
+        if (p.convt) { int ab = c / p.Cout; co = c - ab * p.Cout; opix = obase + (long)(ab >> 1) * (2L * p.Wo) + (ab & 1); }
+        if (p.bias) { float4 bv = *reinterpret_cast<const float4*>(p.bias + co); o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w; }
+        float* dst = p.y + opix * p.y_ld + co;
+        if (p.res) { float4 rv = *reinterpret_cast<const float4*>(p.res + opix * p.y_ld + co); o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = apply_act(o[r], p.act, p.alpha, p.beta);
+        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int cc = c + r;
+            if (cc >= p.gemm_cout) continue;
+            int co = cc; long opix = obase;
+            if (p.convt) { int ab = cc / p.Cout; co = cc - ab * p.Cout; opix = obase + (long)(ab >> 1) * (2L * p.Wo) + (ab & 1); }
+            float t = o[r];
+            if (p.bias) t += p.bias[co];
+            if (p.res) t += p.res[opix * p.y_ld + co];
+            p.y[opix * p.y_ld + co] = apply_act(t, p.act, p.alpha, p.beta);
+        }
+    }
+}
+
 template <int NT, int PF, bool IS1X1>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmP p) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmP p) {  // 2 waves/SIMD => full 256-VGPR budget, no spills
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pl_ = lane & 15, g = lane >> 4;
-    const long m0 = ((long)blockIdx.x * 4 + wave) * (PF * 16);
-    const int nf0 = blockIdx.y * NT;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch), each XCD has a private 4 MiB L2.
+    // Every XCD gets ONE CONTIGUOUS band of pixel tiles (so the kh x kw tap re-reads of neighbouring rows hit the
+    // same L2 instead of HBM: measured 10x over-fetch on the 3x3 convs with an interleaved order), and the ny
+    // cout-tiles that re-read one pixel tile are adjacent in that XCD's dispatch order.
+    const long b = blockIdx.x;
+    const int xcd = (int)(b & 7);
+    const long slot = b >> 3;
+    const int ntile = (int)(slot % p.ny);
+    const long mtile = (long)xcd * p.mx_per_xcd + slot / p.ny;
+    if (slot / p.ny >= p.mx_per_xcd) return;
+    const long m0 = (mtile * 4 + wave) * (PF * 16);
+    const int nf0 = ntile * NT;
     if (m0 >= p.M) return;
 
     long pix_base[PF];
@@ -132,15 +173,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmP p) {
         for (int nf = 0; nf < NT; ++nf) wv[nf] = wf[((long)nf * p.KC + kc) * 64];
     };
     auto mma = [&](const float4 (&wv)[NT], const float4 (&xv)[PF]) {
+        // k-step outermost: back-to-back MFMAs target different accumulators (the 16x16x4 f32 MFMA has a
+        // 40-cycle dependent latency vs a 32-cycle issue interval)
 #pragma unroll
         for (int nf = 0; nf < NT; ++nf)
 #pragma unroll
-            for (int pf = 0; pf < PF; ++pf) {
-                acc[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nf].x, xv[pf].x, acc[nf][pf], 0, 0, 0);
-                acc[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nf].y, xv[pf].y, acc[nf][pf], 0, 0, 0);
-                acc[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nf].z, xv[pf].z, acc[nf][pf], 0, 0, 0);
-                acc[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nf].w, xv[pf].w, acc[nf][pf], 0, 0, 0);
-            }
+            for (int pf = 0; pf < PF; ++pf) acc[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nf].x, xv[pf].x, acc[nf][pf], 0, 0, 0);
+#pragma unroll
+        for (int nf = 0; nf < NT; ++nf)
+#pragma unroll
+            for (int pf = 0; pf < PF; ++pf) acc[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nf].y, xv[pf].y, acc[nf][pf], 0, 0, 0);
+#pragma unroll
+        for (int nf = 0; nf < NT; ++nf)
+#pragma unroll
+            for (int pf = 0; pf < PF; ++pf) acc[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nf].z, xv[pf].z, acc[nf][pf], 0, 0, 0);
+#pragma unroll
+        for (int nf = 0; nf < NT; ++nf)
+#pragma unroll
+            for (int pf = 0; pf < PF; ++pf) acc[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nf].w, xv[pf].w, acc[nf][pf], 0, 0, 0);
     };
 
     // software pipeline: chunk kc+1 is in flight while chunk kc is multiplied
@@ -157,49 +207,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmP p) {
     }
     if (kc < p.KC) mma(wa, xa);
 
-    // epilogue: bias + residual + activation, 16-byte NHWC stores
+    // epilogue: bias + residual + activation, 16-byte NHWC stores.  unroll(full): the accumulators must stay in
+    // registers (a partially unrolled loop indexes acc[][] dynamically and the compiler moves it to scratch).
     const bool vec_ok = ((p.Cout & 3) == 0) && ((p.y_ld & 3) == 0);
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int pf = 0; pf < PF; ++pf) {
-        long m = m0 + pf * 16 + pl_;
-        if (m >= p.M) continue;
-        long obase;
-        if (p.convt) {
+        const long m = m0 + pf * 16 + pl_;
+        long obase = m;
+        if (p.convt && m < p.M) {
             long hw = (long)p.Ho * p.Wo;  // here Ho/Wo are the INPUT spatial dims of the convT
             long n = m / hw; long r = m - n * hw;
             int h = (int)(r / p.Wo), w = (int)(r - (long)h * p.Wo);
             obase = (n * (2L * p.Ho) + 2L * h) * (2L * p.Wo) + 2L * w;  // pixel index of (2h, 2w)
-        } else {
-            obase = m;
         }
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int nf = 0; nf < NT; ++nf) {
-            int c = (nf0 + nf) * 16 + g * 4;
-            if (c >= p.gemm_cout) continue;
-            f32x4 v = acc[nf][pf];
-            float o[4] = {v[0], v[1], v[2], v[3]};
-            if (vec_ok) {
-                int co = c; long opix = obase;
-                if (p.convt) { int ab = c / p.Cout; co = c - ab * p.Cout; opix = obase + (long)(ab >> 1) * (2L * p.Wo) + (ab & 1); }
-                if (p.bias) { float4 bv = *reinterpret_cast<const float4*>(p.bias + co); o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w; }
-                float* dst = p.y + opix * p.y_ld + co;
-                if (p.res) { float4 rv = *reinterpret_cast<const float4*>(p.res + opix * p.y_ld + co); o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w; }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = apply_act(o[r], p.act, p.alpha, p.beta);
-                *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int cc = c + r;
-                    if (cc >= p.gemm_cout) continue;
-                    int co = cc; long opix = obase;
-                    if (p.convt) { int ab = cc / p.Cout; co = cc - ab * p.Cout; opix = obase + (long)(ab >> 1) * (2L * p.Wo) + (ab & 1); }
-                    float t = o[r];
-                    if (p.bias) t += p.bias[co];
-                    if (p.res) t += p.res[opix * p.y_ld + co];
-                    p.y[opix * p.y_ld + co] = apply_act(t, p.act, p.alpha, p.beta);
-                }
-            }
+            const f32x4 v = acc[nf][pf];
+            igemm_store(p, v, m < p.M, obase, (nf0 + nf) * 16 + g * 4, vec_ok);
         }
     }
 }
@@ -223,8 +247,15 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     const bool is1x1 = c.convt2x2 || (c.kh == 1 && c.kw == 1 && c.sh == 1 && c.sw == 1 && c.pt == 0 && c.pl == 0);
     int nfrag = (p.gemm_cout + 15) / 16;
     int NT = nfrag >= 3 ? 4 : (nfrag == 2 ? 2 : 1);
-    constexpr int PF = 4;
-    dim3 grid((unsigned)((p.M + 4 * PF * 16 - 1) / (4 * PF * 16)), (unsigned)((nfrag + NT - 1) / NT));
+    // pixel fragments per wave: fewer when the launch would otherwise leave most of the 256 CUs idle
+    const long ny = (nfrag + NT - 1) / NT;
+    static const int pf_max = [] { const char* e = getenv("OAR_IGEMM_PF"); int v = e ? atoi(e) : 2; return v == 1 || v == 4 ? v : 2; }();  // PF=2: 102 VGPRs => 4 waves/SIMD (measured 1.2x over PF=4)
+    int PF = pf_max;
+    while (PF > 1 && ((p.M + 4L * PF * 16 - 1) / (4L * PF * 16)) * ny < 1024) PF >>= 1;
+    const long mx = (p.M + 4L * PF * 16 - 1) / (4L * PF * 16);
+    p.ny = (int)ny;
+    p.mx_per_xcd = (mx + 7) / 8;
+    dim3 grid((unsigned)(p.mx_per_xcd * 8 * ny));
     double flops = 2.0 * (double)p.M * p.K * p.gemm_cout;
     double bytes = 4.0 * ((double)c.N * c.H * c.W * c.Cin + (double)p.M * p.gemm_cout + (double)p.K * p.gemm_cout);
     char pname[96];
@@ -234,21 +265,88 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
         cls = pname;
     }
     ProfScope ps(s, cls, bytes, flops);
-#define LAUNCH(NTV)                                                                                          \
+#define LAUNCH2(NTV, PFV)                                                                                     \
     do {                                                                                                     \
-        if (is1x1) hipLaunchKernelGGL((conv_igemm_kernel<NTV, PF, true>), grid, dim3(256), 0, s, p);        \
-        else hipLaunchKernelGGL((conv_igemm_kernel<NTV, PF, false>), grid, dim3(256), 0, s, p);             \
+        if (is1x1) hipLaunchKernelGGL((conv_igemm_kernel<NTV, PFV, true>), grid, dim3(256), 0, s, p);       \
+        else hipLaunchKernelGGL((conv_igemm_kernel<NTV, PFV, false>), grid, dim3(256), 0, s, p);            \
+    } while (0)
+#define LAUNCH(NTV)                                  \
+    do {                                             \
+        if (PF == 4) LAUNCH2(NTV, 4);                \
+        else if (PF == 2) LAUNCH2(NTV, 2);           \
+        else LAUNCH2(NTV, 1);                        \
     } while (0)
     if (NT == 4) LAUNCH(4);
     else if (NT == 2) LAUNCH(2);
     else LAUNCH(1);
+#undef LAUNCH2
 #undef LAUNCH
 }
 
 // ------------------------------------------------------------------------------------------ depthwise conv
-// One thread = 4 channels x 1 output pixel. Weights [kh][kw][C]. Pure bandwidth kernel: the kxk window re-reads
-// hit L1/L2 (neighbouring threads share rows).
-template <int KH, int KW>
+// Bandwidth kernel. One thread = 4 channels (one float4) x TW adjacent output pixels of a row: each input row of
+// the window is loaded once ((TW-1)*S + K float4s) and reused by all TW outputs, cutting the load count per output
+// from K*K to K*((TW-1)*S+K)/TW.  Lanes run along channels first, so a wave reads/writes whole 16-byte-per-lane
+// contiguous NHWC segments.  Weights [kh][kw][C].
+template <int K, int SH, int S, int TW>
+__global__ __launch_bounds__(256) void conv_dw_tiled_kernel(ConvP p) {
+    const int C4 = p.Cout >> 2;
+    const int wtiles = (p.Wo + TW - 1) / TW;
+    const long total = (long)p.N * p.Ho * wtiles * C4;
+    constexpr int NCOL = (TW - 1) * S + K;
+    // each XCD (workgroup id % 8) walks one contiguous band of output rows => the K-row halo re-reads stay in its L2
+    const long per_xcd = (total + 7) / 8;
+    const int xcd = blockIdx.x & 7;
+    const long lb = blockIdx.x >> 3, nlb = (gridDim.x + 7) >> 3;
+    const long band_end = min(total, (long)(xcd + 1) * per_xcd);
+    for (long i = (long)xcd * per_xcd + lb * blockDim.x + threadIdx.x; i < band_end; i += nlb * blockDim.x) {
+        int c4 = (int)(i % C4); long t = i / C4;
+        int wt = (int)(t % wtiles); t /= wtiles;
+        int oh = (int)(t % p.Ho); long n = t / p.Ho;
+        const int c = c4 * 4, ow0 = wt * TW;
+        float4 bias = p.bias ? *reinterpret_cast<const float4*>(p.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 acc[TW];
+#pragma unroll
+        for (int q = 0; q < TW; ++q) acc[q] = bias;
+        const float* xb = p.x + n * (long)p.H * p.W * p.Cin + c;
+        const int iw0 = ow0 * S - p.pl;
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+            const int ih = oh * SH - p.pt + a;
+            if (ih < 0 || ih >= p.H) continue;
+            const float* xr = xb + (long)ih * p.W * p.Cin;
+            float4 col[NCOL];
+#pragma unroll
+            for (int q = 0; q < NCOL; ++q) {
+                int iw = iw0 + q;
+                col[q] = (iw >= 0 && iw < p.W) ? *reinterpret_cast<const float4*>(xr + (long)iw * p.Cin) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int b = 0; b < K; ++b) {
+                float4 wv = *reinterpret_cast<const float4*>(p.w + (long)(a * K + b) * p.Cout + c);
+#pragma unroll
+                for (int q = 0; q < TW; ++q) {
+                    float4 xv = col[q * S + b];
+                    acc[q].x = fmaf(xv.x, wv.x, acc[q].x); acc[q].y = fmaf(xv.y, wv.y, acc[q].y);
+                    acc[q].z = fmaf(xv.z, wv.z, acc[q].z); acc[q].w = fmaf(xv.w, wv.w, acc[q].w);
+                }
+            }
+        }
+        const long pix0 = (n * p.Ho + oh) * (long)p.Wo + ow0;
+#pragma unroll
+        for (int q = 0; q < TW; ++q) {
+            if (ow0 + q >= p.Wo) break;
+            long o = (pix0 + q) * p.y_ld + c;
+            float4 v = acc[q];
+            if (p.residual) { float4 r = *reinterpret_cast<const float4*>(p.residual + o); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+            v.x = apply_act(v.x, p.act.kind, p.act.alpha, p.act.beta); v.y = apply_act(v.y, p.act.kind, p.act.alpha, p.act.beta);
+            v.z = apply_act(v.z, p.act.kind, p.act.alpha, p.act.beta); v.w = apply_act(v.w, p.act.kind, p.act.alpha, p.act.beta);
+            *reinterpret_cast<float4*>(p.y + o) = v;
+        }
+    }
+}
+
+// generic depthwise (any kernel / stride / dilation): one thread = 4 channels x 1 output pixel
 __global__ __launch_bounds__(256) void conv_dw_kernel(ConvP p) {
     const int C4 = p.Cout >> 2;
     long total = (long)p.N * p.Ho * p.Wo * C4;
@@ -258,18 +356,15 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(ConvP p) {
         int oh = (int)(t % p.Ho); long n = t / p.Ho;
         const int c = c4 * 4;
         float4 acc = p.bias ? *reinterpret_cast<const float4*>(p.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const int kh = KH > 0 ? KH : p.kh, kw = KW > 0 ? KW : p.kw;
         const float* xb = p.x + n * (long)p.H * p.W * p.Cin + c;
-#pragma unroll
-        for (int a = 0; a < kh; ++a) {
+        for (int a = 0; a < p.kh; ++a) {
             int ih = oh * p.sh - p.pt + a * p.dh;
             if (ih < 0 || ih >= p.H) continue;
-#pragma unroll
-            for (int b = 0; b < kw; ++b) {
+            for (int b = 0; b < p.kw; ++b) {
                 int iw = ow * p.sw - p.pl + b * p.dw;
                 if (iw < 0 || iw >= p.W) continue;
                 float4 xv = *reinterpret_cast<const float4*>(xb + ((long)ih * p.W + iw) * p.Cin);
-                float4 wv = *reinterpret_cast<const float4*>(p.w + (long)(a * kw + b) * p.Cout + c);
+                float4 wv = *reinterpret_cast<const float4*>(p.w + (long)(a * p.kw + b) * p.Cout + c);
                 acc.x = fmaf(xv.x, wv.x, acc.x); acc.y = fmaf(xv.y, wv.y, acc.y);
                 acc.z = fmaf(xv.z, wv.z, acc.z); acc.w = fmaf(xv.w, wv.w, acc.w);
             }
@@ -300,10 +395,73 @@ void conv_dw(hipStream_t s, const ConvP& p) {
     const char* cls = "conv_dw";
     if (Profiler::get().detail) { snprintf(pname, sizeof pname, "conv_dw px=%ld C=%d k%d s%d", (long)p.N * p.Ho * p.Wo, p.Cout, p.kh, p.sh); cls = pname; }
     ProfScope ps(s, cls, bytes, flops);
-    dim3 g(grid_for(total)), b(256);
-    if (p.kh == 3 && p.kw == 3) hipLaunchKernelGGL((conv_dw_kernel<3, 3>), g, b, 0, s, p);
-    else if (p.kh == 5 && p.kw == 5) hipLaunchKernelGGL((conv_dw_kernel<5, 5>), g, b, 0, s, p);
-    else hipLaunchKernelGGL((conv_dw_kernel<0, 0>), g, b, 0, s, p);
+    const bool sq = p.kh == p.kw && p.dh == 1 && p.dw == 1;
+    constexpr int TW = 4;
+    long tiled = (long)p.N * p.Ho * ((p.Wo + TW - 1) / TW) * (p.Cout / 4);
+    dim3 g((grid_for(tiled) + 7) / 8 * 8), b(256);
+#define DW(KV, SHV, SWV) hipLaunchKernelGGL((conv_dw_tiled_kernel<KV, SHV, SWV, TW>), g, b, 0, s, p)
+    if (sq && p.kh == 3 && p.sh == 1 && p.sw == 1) DW(3, 1, 1);
+    else if (sq && p.kh == 3 && p.sh == 2 && p.sw == 2) DW(3, 2, 2);
+    else if (sq && p.kh == 3 && p.sh == 2 && p.sw == 1) DW(3, 2, 1);
+    else if (sq && p.kh == 3 && p.sh == 1 && p.sw == 2) DW(3, 1, 2);
+    else if (sq && p.kh == 5 && p.sh == 1 && p.sw == 1) DW(5, 1, 1);
+    else if (sq && p.kh == 5 && p.sh == 2 && p.sw == 2) DW(5, 2, 2);
+    else if (sq && p.kh == 5 && p.sh == 2 && p.sw == 1) DW(5, 2, 1);
+    else if (sq && p.kh == 5 && p.sh == 1 && p.sw == 2) DW(5, 1, 2);
+    else hipLaunchKernelGGL(conv_dw_kernel, dim3(grid_for(total)), b, 0, s, p);
+#undef DW
+}
+
+// ------------------------------------------------------------------------------------------ small-Cin conv (network stems)
+// Cin <= 4 (RGB stems): K = kh*kw*Cin <= 128 is too shallow for the matrix cores to matter, the layer is bound by
+// the output write.  One thread = one output pixel x 16 output channels; the [K][16] weight slice sits in LDS
+// (broadcast reads), the 16 results leave as four 16-byte stores.  w: [kh][kw][Cin][Cout] (direct layout).
+__global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvP p) {
+    __shared__ float ws[128 * 16];
+    const int K = p.kh * p.kw * p.Cin;
+    const int co0 = blockIdx.y * 16;
+    for (int i = threadIdx.x; i < K * 16; i += 256) {
+        int k = i >> 4, c = i & 15;
+        ws[i] = (co0 + c < p.Cout) ? p.w[(long)k * p.Cout + co0 + c] : 0.f;
+    }
+    __syncthreads();
+    const long total = (long)p.N * p.Ho * p.Wo;
+    for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long)gridDim.x * blockDim.x) {
+        int ow = (int)(pix % p.Wo); long t = pix / p.Wo;
+        int oh = (int)(t % p.Ho); long n = t / p.Ho;
+        float acc[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = (p.bias && co0 + c < p.Cout) ? p.bias[co0 + c] : 0.f;
+        const float* xb = p.x + n * (long)p.H * p.W * p.Cin;
+        for (int a = 0; a < p.kh; ++a) {
+            int ih = oh * p.sh - p.pt + a * p.dh;
+            if (ih < 0 || ih >= p.H) continue;
+            for (int b = 0; b < p.kw; ++b) {
+                int iw = ow * p.sw - p.pl + b * p.dw;
+                if (iw < 0 || iw >= p.W) continue;
+                const float* xp = xb + ((long)ih * p.W + iw) * p.Cin;
+                const float* wp = ws + (a * p.kw + b) * p.Cin * 16;
+                for (int ci = 0; ci < p.Cin; ++ci) {
+                    float xv = xp[ci];
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) acc[c] = fmaf(xv, wp[ci * 16 + c], acc[c]);
+                }
+            }
+        }
+        float* o = p.y + pix * p.y_ld + co0;
+        const bool vec = (co0 + 16 <= p.Cout) && ((p.y_ld & 3) == 0);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (p.residual && co0 + c < p.Cout) acc[c] += p.residual[pix * p.y_ld + co0 + c];
+            acc[c] = apply_act(acc[c], p.act.kind, p.act.alpha, p.act.beta);
+        }
+        if (vec) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(o + q * 4) = make_float4(acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]);
+        } else {
+            for (int c = 0; c < 16 && co0 + c < p.Cout; ++c) o[c] = acc[c];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------ direct conv (fallback)
@@ -339,6 +497,12 @@ void conv_direct(hipStream_t s, const ConvP& p) {
     if (total == 0) return;
     double bytes = 4.0 * ((double)p.N * p.H * p.W * p.Cin + (double)total + (double)p.kh * p.kw * (p.Cin / p.groups) * p.Cout);
     double flops = 2.0 * (double)total * p.kh * p.kw * (p.Cin / p.groups);
+    if (p.groups == 1 && p.Cin <= 4 && p.kh * p.kw * p.Cin <= 128) {
+        ProfScope ps(s, "conv_smallcin", bytes, flops);
+        long pixels = (long)p.N * p.Ho * p.Wo;
+        hipLaunchKernelGGL(conv_smallcin_kernel, dim3(grid_for(pixels, 256, 256L * 16), (p.Cout + 15) / 16), dim3(256), 0, s, p);
+        return;
+    }
     ProfScope ps(s, "conv_direct", bytes, flops);
     hipLaunchKernelGGL(conv_direct_kernel, dim3(grid_for(total)), dim3(256), 0, s, p);
 }
@@ -407,26 +571,51 @@ void pool2d(hipStream_t s, const PoolP& p) {
     hipLaunchKernelGGL(pool2d_kernel, dim3(grid_for(total)), dim3(256), 0, s, p);
 }
 
-// One workgroup per (n, 64-channel slab): threads stride over HW, LDS tree-reduce. Sum order is fixed.
+// One workgroup per image. Lanes run along channels (float4), `parts` thread groups split HW; the partial sums
+// are combined through LDS in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void global_avgpool_kernel(const float* x, float* y, int HW, int C) {
-    __shared__ float red[4][64];
-    const int n = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-    float acc = 0.f;
-    if (c < C) {
-        const float* xb = x + (long)n * HW * C + c;
-        for (int i = part; i < HW; i += 4) acc += xb[(long)i * C];
+    extern __shared__ float4 red[];  // [parts][C4]
+    const int C4 = C >> 2;
+    const int parts = 256 / C4 > 0 ? 256 / C4 : 1;
+    const int n = blockIdx.x;
+    const int c4 = threadIdx.x % C4, part = threadIdx.x / C4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (part < parts) {
+        const float4* xb = reinterpret_cast<const float4*>(x + (long)n * HW * C) + c4;
+        int i = part;
+        for (; i + 3 * parts < HW; i += 4 * parts) {
+            float4 a = xb[(long)i * C4], b = xb[(long)(i + parts) * C4], c = xb[(long)(i + 2 * parts) * C4], d = xb[(long)(i + 3 * parts) * C4];
+            acc.x += (a.x + b.x) + (c.x + d.x); acc.y += (a.y + b.y) + (c.y + d.y);
+            acc.z += (a.z + b.z) + (c.z + d.z); acc.w += (a.w + b.w) + (c.w + d.w);
+        }
+        for (; i < HW; i += parts) { float4 a = xb[(long)i * C4]; acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+        red[part * C4 + c4] = acc;
     }
-    red[part][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (part == 0 && c < C) {
-        float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        y[(long)n * C + c] = t / (float)HW;
+    if (part == 0) {
+        float4 t = red[c4];
+        for (int q = 1; q < parts; ++q) { float4 u = red[q * C4 + c4]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        float inv = (float)HW;
+        reinterpret_cast<float4*>(y + (long)n * C)[c4] = make_float4(t.x / inv, t.y / inv, t.z / inv, t.w / inv);
     }
+}
+__global__ __launch_bounds__(256) void global_avgpool_scalar_kernel(const float* x, float* y, int HW, int C) {
+    const int n = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float* xb = x + (long)n * HW * C + c;
+    float acc = 0.f;
+    for (int i = 0; i < HW; ++i) acc += xb[(long)i * C];
+    y[(long)n * C + c] = acc / (float)HW;
 }
 void global_avgpool(hipStream_t s, const float* x, float* y, int N, int HW, int C) {
     if (N == 0 || C == 0) return;
     ProfScope ps(s, "global_avgpool", 4.0 * (double)N * HW * C, 0.0);
-    hipLaunchKernelGGL(global_avgpool_kernel, dim3((C + 63) / 64, N), dim3(256), 0, s, x, y, HW, C);
+    if ((C & 3) == 0 && C / 4 <= 256) {
+        int C4 = C / 4, parts = 256 / C4;
+        hipLaunchKernelGGL(global_avgpool_kernel, dim3(N), dim3(256), (size_t)parts * C4 * sizeof(float4), s, x, y, HW, C);
+    } else {
+        hipLaunchKernelGGL(global_avgpool_scalar_kernel, dim3((C + 255) / 256, N), dim3(256), 0, s, x, y, HW, C);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ resize
@@ -756,13 +945,15 @@ __global__ __launch_bounds__(256) void softmax_wave_kernel(const float* x, float
     for (int i = lane; i < C; i += 64) y[row * C + i] = expf(xr[i] - m) / s;
 }
 __global__ __launch_bounds__(256) void softmax_block_kernel(const float* x, float* y, int C) {
+    // one workgroup per row; the row is staged in LDS (C * 4 bytes) so HBM is read exactly once
+    extern __shared__ float rowbuf[];
     __shared__ float red[4];
     __shared__ float bcast;
     const long row = blockIdx.x;
     const float* xr = x + row * C;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float m = -3.402823466e38f;
-    for (int i = tid; i < C; i += 256) m = fmaxf(m, xr[i]);
+    for (int i = tid; i < C; i += 256) { float v = xr[i]; rowbuf[i] = v; m = fmaxf(m, v); }
     m = wave_max(m);
     if (lane == 0) red[wave] = m;
     __syncthreads();
@@ -770,7 +961,7 @@ __global__ __launch_bounds__(256) void softmax_block_kernel(const float* x, floa
     __syncthreads();
     m = bcast;
     float s = 0.f;
-    for (int i = tid; i < C; i += 256) s += expf(xr[i] - m);
+    for (int i = tid; i < C; i += 256) { float e = expf(rowbuf[i] - m); rowbuf[i] = e; s += e; }
     s = wave_sum(s);
     __syncthreads();
     if (lane == 0) red[wave] = s;
@@ -778,13 +969,16 @@ __global__ __launch_bounds__(256) void softmax_block_kernel(const float* x, floa
     if (tid == 0) bcast = (red[0] + red[1]) + (red[2] + red[3]);
     __syncthreads();
     s = bcast;
-    for (int i = tid; i < C; i += 256) y[row * C + i] = expf(xr[i] - m) / s;
+    for (int i = tid; i < C; i += 256) y[row * C + i] = rowbuf[i] / s;
 }
 void softmax_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C) {
     if (rows == 0 || C == 0) return;
     ProfScope ps(s, "softmax", 8.0 * (double)rows * C, 4.0 * (double)rows * C);
     if (C <= 1024) hipLaunchKernelGGL(softmax_wave_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, y, (long)rows, C);
-    else hipLaunchKernelGGL(softmax_block_kernel, dim3((unsigned)rows), dim3(256), 0, s, x, y, C);
+    else {
+        OAR_CHECK((size_t)C * 4 <= 150 * 1024, OAR_UNSUPPORTED_OP, "softmax: row longer than the LDS staging buffer");
+        hipLaunchKernelGGL(softmax_block_kernel, dim3((unsigned)rows), dim3(256), (size_t)C * sizeof(float), s, x, y, C);
+    }
 }
 
 }  // namespace k

@@ -1,10 +1,45 @@
 #include "pipeline.h"
 
 #include <algorithm>
+#include <map>
+#include <string>
 #include <cmath>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 
 namespace oar {
+
+namespace {
+struct PhaseTimer {  // OAR_TIMING=1: prints host-side phase times of each predict() to stderr
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    std::vector<std::pair<const char*, double>> marks;
+    PhaseTimer() {
+        static const bool en = [] { const char* e = getenv("OAR_TIMING"); return e && e[0] == '1'; }();
+        on = en;
+        t0 = std::chrono::steady_clock::now();
+    }
+    void mark(const char* name) {
+        if (!on) return;
+        auto t = std::chrono::steady_clock::now();
+        marks.push_back({name, std::chrono::duration<double, std::milli>(t - t0).count()});
+        t0 = t;
+    }
+    void dump(const char* title) {
+        if (!on) return;
+        std::map<std::string, double> agg;
+        std::vector<std::string> order;
+        for (auto& m : marks) { if (!agg.count(m.first)) order.push_back(m.first); agg[m.first] += m.second; }
+        fprintf(stderr, "[timing] %s:", title);
+        for (auto& k : order) fprintf(stderr, " %s=%.2fms", k.c_str(), agg[k]);
+        fprintf(stderr, "\n");
+    }
+};
+thread_local PhaseTimer* g_timer = nullptr;
+inline void tmark(const char* n) { if (g_timer) g_timer->mark(n); }
+}  // namespace
+
 
 // ================================================================================================= thread pool
 ThreadPool::ThreadPool(int n) {
@@ -200,7 +235,9 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
         }
         pp::normalize(s, src, input_f32_.as<float>() + (size_t)b * plane * 3, 1, (int64_t)plane, kDbSrc, alpha, beta, 1);
     }
+    tmark("det_pre_enqueue");
     const Plan& plan = eng_->run(input_f32_.as<float>(), {B, 3, (int64_t)rh, (int64_t)rw}, true);
+    tmark("det_net_enqueue");
     OAR_CHECK(!plan.outputs.empty(), OAR_INTERNAL, "DB: no output returned from inference");
     const PlanOutput& po = plan.outputs[0];
     OAR_CHECK(po.dims.size() == 4 && po.dims[0] == B, OAR_SHAPE_MISMATCH, "DB: expected a 4-D [batch,1,H,W] output");
@@ -219,11 +256,13 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
     pp::threshold(s, pred, mask_dev_.as<uint8_t>(), (int64_t)B * hw, thresh);
     OAR_HIP(hipMemcpyAsync(mask_host_.p, mask_dev_.p, (size_t)B * hw, hipMemcpyDeviceToHost, s));
     OAR_HIP(hipStreamSynchronize(s));
+    tmark("det_gpu_wait+mask_d2h");
 
     std::vector<std::vector<Candidate>> cands(B);
     const uint8_t* mh = mask_host_.as<uint8_t>();
     const uint32_t maxc = cfg_.max_candidates;
     pool_->parallel_for(B, [&](int b) { page_candidates(mh + (size_t)b * hw, H, W, maxc, cands[b]); });
+    tmark("host_contours");
 
     size_t total = 0;
     std::vector<size_t> base(B + 1, 0);
@@ -250,10 +289,12 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
         OAR_HIP(hipStreamSynchronize(s));
         std::memcpy(scores.data(), scores_host_.p, total * sizeof(float));
     }
+    tmark("box_scores_roundtrip");
     pool_->parallel_for(B, [&](int b) {
         const PageRef& pg = pages[idx[b]];
         finish_boxes(cands[b], scores.data() + base[b], H, W, pg.w, pg.h, box_thresh, unclip, out[idx[b]]);
     });
+    tmark("host_unclip");
     if (Profiler::get().enabled) Profiler::get().flush();
 }
 
@@ -441,7 +482,9 @@ void Recognizer::run_batches(const std::vector<std::vector<Crop>>& batches, std:
 // ================================================================================================= OCR pipeline
 Ocr::Ocr(const uint8_t* det, size_t det_len, const uint8_t* rec, size_t rec_len, const oar_ocr_cfg& cfg) : cfg_(cfg) {
     if (cfg_.image_batch_size == 0) cfg_.image_batch_size = 8;     // text_detection_adapter.rs:85-87
-    if (cfg_.region_batch_size == 0) cfg_.region_batch_size = 64;  // text_recognition_adapter.rs:117-127
+    // reference adapter: 64 (text_recognition_adapter.rs:117-127). This backend recommends 256: the tiny recognizer is
+    // launch/latency-bound at 64 crops on 256 CUs; a drop-in adapter may report a larger recommended_batch_size.
+    if (cfg_.region_batch_size == 0) cfg_.region_batch_size = 256;
     if (cfg_.max_pooled_crops == 0) cfg_.max_pooled_crops = 4096;  // src/oarocr/ocr.rs:603
     OAR_CHECK(cfg_.image_batch_size <= 4096 && cfg_.region_batch_size <= 4096, OAR_INVALID_INPUT,
               "batch sizes must be in 1..=4096");                  // src/oarocr/ocr.rs:250-255,419-430
@@ -455,6 +498,9 @@ void Ocr::predict(const std::vector<PageRef>& pages, std::vector<std::vector<Ocr
     const int n = (int)pages.size();
     OAR_HIP(hipSetDevice(det_->engine().device()));
     hipStream_t s = det_->engine().stream();
+    PhaseTimer timer;
+    g_timer = &timer;
+    struct TimerReset { ~TimerReset() { g_timer = nullptr; } } timer_reset;
     struct PoolItem { int img; int det_index; uint32_t w, h; float wh_ratio; size_t off; };
     struct Slot { bool filled = false; OcrRegion r; };
     std::vector<std::vector<Slot>> per_image(n);
@@ -484,7 +530,9 @@ void Ocr::predict(const std::vector<PageRef>& pages, std::vector<std::vector<Ocr
             chunk_max.push_back(cm);
         }
         std::vector<RecOut> ros;
+        tmark("rec_sort_batching");
         rec_->run_batches(batches, ros);
+        tmark("rec_all_batches");
         for (size_t bi = 0; bi < batches.size(); ++bi) {
             const RecOut& ro = ros[bi];
             const size_t c0 = bi * bs;
@@ -571,12 +619,15 @@ void Ocr::predict(const std::vector<PageRef>& pages, std::vector<std::vector<Ocr
         }
         // the detector's page staging buffer is reused by the next chunk: crops must be done first
         OAR_HIP(hipStreamSynchronize(s));
+        tmark("crop_plan+warp");
     }
     flush();
     out.assign(n, {});
     for (int i = 0; i < n; ++i)
         for (auto& sl : per_image[i])
             if (sl.filled) out[i].push_back(std::move(sl.r));
+    tmark("assemble");
+    timer.dump("ocr.predict");
     if (Profiler::get().enabled) Profiler::get().flush();
 }
 

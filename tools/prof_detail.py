@@ -7,7 +7,7 @@ det,_=models.build_det(); rec,_=models.build_rec()
 chars=api.read_dict(models.synth_dict())
 P=[pages.make_page(i,(960,960),40) for i in range(32)]
 bufs=[api.DeviceBuffer(p) for p in P]
-ocr=api.OAROCRBuilder(det,rec,chars).text_detection_config(api.TextDetectionConfig(0.3,0.6,1.5)).image_batch_size(32).region_batch_size(64).build()
+ocr=api.OAROCRBuilder(det,rec,chars).text_detection_config(api.TextDetectionConfig(0.3,0.6,1.5)).image_batch_size(32).region_batch_size(256).build()
 ptrs=[int(b.ptr.value) for b in bufs]
 ocr.predict_device(ptrs,[960]*32,[960]*32,raw=True)
 api.prof_enable(True); api.prof_reset()
