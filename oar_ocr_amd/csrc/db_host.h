@@ -2,6 +2,7 @@
 // These steps are pointer-chasing / tiny-N float work with libm calls (atan2f/cosf/sinf/hypotf) whose exact
 // results are part of the box contract, so they stay on the host (one worker per page) -- see DESIGN.md.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 

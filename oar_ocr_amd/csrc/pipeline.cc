@@ -43,40 +43,59 @@ inline void tmark(const char* n) { if (g_timer) g_timer->mark(n); }
 
 // ================================================================================================= thread pool
 ThreadPool::ThreadPool(int n) {
-    if (n <= 0) n = (int)std::thread::hardware_concurrency();
+    if (n <= 0) n = std::min<int>((int)std::thread::hardware_concurrency(), 16);
     if (n <= 0) n = 1;
     if (n > 64) n = 64;
     for (int i = 0; i < n - 1; ++i) workers_.emplace_back([this] { loop(); });
 }
 ThreadPool::~ThreadPool() {
+    stop_.store(true, std::memory_order_release);
     {
         std::lock_guard<std::mutex> lk(mu_);
-        stop_ = true;
+        cv_.notify_all();
     }
-    cv_.notify_all();
     for (auto& t : workers_) t.join();
 }
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+}
 void ThreadPool::loop() {
+    // OAR_POOL_SPIN_MS: how long an idle worker keeps polling before it parks (default 25 ms ~ one predict() of the
+    // bench workload, so workers stay hot across the recognition phase of continuous serving)
+    static const int spin_ms = [] { const char* e = getenv("OAR_POOL_SPIN_MS"); int v = e ? atoi(e) : 25; return v < 0 ? 0 : v; }();
     int seen = 0;
-    while (true) {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return stop_ || (gen_ != seen && next_ < count_); });
-        if (stop_) return;
-        seen = gen_;
-        while (next_ < count_) {
-            int i = next_++;
-            ++active_;
-            lk.unlock();
+    while (!stop_.load(std::memory_order_acquire)) {
+        // wait for a new generation: spin first (~1-2 ms), then park
+        int g = gen_.load(std::memory_order_acquire);
+        if (g == seen) {
+            auto t0 = std::chrono::steady_clock::now();
+            int spins = 0;
+            while ((g = gen_.load(std::memory_order_acquire)) == seen && !stop_.load(std::memory_order_acquire)) {
+                cpu_relax();
+                if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(spin_ms)) {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    cv_.wait_for(lk, std::chrono::milliseconds(50), [&] { return stop_.load() || gen_.load() != seen; });
+                    t0 = std::chrono::steady_clock::now();
+                }
+            }
+            if (stop_.load(std::memory_order_acquire)) return;
+        }
+        seen = g;
+        const std::function<void(int)>* fn = fn_;
+        const int count = count_.load(std::memory_order_acquire);
+        while (true) {
+            int i = next_.fetch_add(1, std::memory_order_acq_rel);
+            if (i >= count) break;
             try {
-                (*fn_)(i);
+                (*fn)(i);
             } catch (...) {
-                std::lock_guard<std::mutex> g(mu_);
+                std::lock_guard<std::mutex> g2(err_mu_);
                 if (!err_) err_ = std::current_exception();
             }
-            lk.lock();
-            --active_;
+            done_.fetch_add(1, std::memory_order_acq_rel);
         }
-        if (active_ == 0) done_cv_.notify_all();
     }
 }
 void ThreadPool::parallel_for(int count, const std::function<void(int)>& fn) {
@@ -85,25 +104,35 @@ void ThreadPool::parallel_for(int count, const std::function<void(int)>& fn) {
         for (int i = 0; i < count; ++i) fn(i);
         return;
     }
-    std::unique_lock<std::mutex> lk(mu_);
-    fn_ = &fn; next_ = 0; count_ = count; err_ = nullptr; ++gen_;
-    cv_.notify_all();
-    while (next_ < count_) {  // the caller works too
-        int i = next_++;
-        ++active_;
-        lk.unlock();
+    fn_ = &fn;
+    done_.store(0, std::memory_order_relaxed);
+    next_.store(0, std::memory_order_relaxed);
+    count_.store(count, std::memory_order_release);
+    gen_.fetch_add(1, std::memory_order_acq_rel);
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        cv_.notify_all();
+    }
+    while (true) {  // the caller works too
+        int i = next_.fetch_add(1, std::memory_order_acq_rel);
+        if (i >= count) break;
         try {
             fn(i);
         } catch (...) {
-            std::lock_guard<std::mutex> g(mu_);
+            std::lock_guard<std::mutex> g2(err_mu_);
             if (!err_) err_ = std::current_exception();
         }
-        lk.lock();
-        --active_;
+        done_.fetch_add(1, std::memory_order_acq_rel);
     }
-    done_cv_.wait(lk, [&] { return active_ == 0; });
-    fn_ = nullptr; count_ = 0; next_ = 0;
-    if (err_) { auto e = err_; err_ = nullptr; std::rethrow_exception(e); }
+    while (done_.load(std::memory_order_acquire) < count) cpu_relax();
+    // late workers may still bump next_ past count; they never touch fn again once next_ >= count
+    std::exception_ptr e;
+    {
+        std::lock_guard<std::mutex> g2(err_mu_);
+        e = err_;
+        err_ = nullptr;
+    }
+    if (e) std::rethrow_exception(e);
 }
 
 // ================================================================================================= detector
@@ -120,19 +149,62 @@ Detector::Detector(const uint8_t* onnx, size_t len, const oar_det_cfg& cfg) : cf
 namespace {
 struct Candidate { float pts[8]; };
 
+// a9: one contour -> mini box candidate (false when rejected)
+bool contour_candidate(const host::Contour& c, Candidate& cd) {
+    std::vector<host::Pt> simp = host::simplify_chain(c.pts);
+    host::Pt mb[4];
+    float min_side = 0.f;
+    bool ok = simp.size() >= 3 ? host::mini_box(simp, mb, min_side) : host::mini_box(c.pts, mb, min_side);
+    if (!ok) return false;
+    if (min_side < 3.0f) return false;  // DBPostProcess::min_size (db_postprocess.rs:83)
+    for (int i = 0; i < 4; ++i) { cd.pts[i * 2] = mb[i].x; cd.pts[i * 2 + 1] = mb[i].y; }
+    return true;
+}
+
 void page_candidates(const uint8_t* mask, int H, int W, uint32_t max_candidates, std::vector<Candidate>& out) {
     out.clear();
     std::vector<host::Contour> cs = host::find_contours(mask, W, H, max_candidates);
     for (auto& c : cs) {
-        std::vector<host::Pt> simp = host::simplify_chain(c.pts);
-        host::Pt mb[4];
-        float min_side = 0.f;
-        bool ok = simp.size() >= 3 ? host::mini_box(simp, mb, min_side) : host::mini_box(c.pts, mb, min_side);
-        if (!ok) continue;
-        if (min_side < 3.0f) continue;  // DBPostProcess::min_size (db_postprocess.rs:83)
         Candidate cd;
-        for (int i = 0; i < 4; ++i) { cd.pts[i * 2] = mb[i].x; cd.pts[i * 2 + 1] = mb[i].y; }
-        out.push_back(cd);
+        if (contour_candidate(c, cd)) out.push_back(cd);
+    }
+}
+
+// Two-stage variant for a sub-batch: contour tracing is inherently serial per page (one worker per page), the
+// per-contour geometry is then spread over the whole pool; discovery order is preserved.
+void subbatch_candidates(ThreadPool& pool, const uint8_t* masks, size_t hw, int H, int W, int nb, uint32_t max_candidates,
+                         std::vector<Candidate>* out /* [nb] */) {
+    std::vector<std::vector<host::Contour>> cs(nb);
+    std::vector<double> tpage(nb, 0.0);
+    auto ta = std::chrono::steady_clock::now();
+    pool.parallel_for(nb, [&](int k) {
+        auto t0 = std::chrono::steady_clock::now();
+        cs[k] = host::find_contours(masks + (size_t)k * hw, W, H, max_candidates);
+        tpage[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    });
+    auto tb = std::chrono::steady_clock::now();
+    struct Chunk { int page; size_t c0, c1; };
+    std::vector<Chunk> chunks;
+    const size_t step = 8;
+    for (int k = 0; k < nb; ++k)
+        for (size_t c0 = 0; c0 < cs[k].size(); c0 += step) chunks.push_back({k, c0, std::min(cs[k].size(), c0 + step)});
+    std::vector<std::vector<Candidate>> res(nb);
+    std::vector<std::vector<uint8_t>> ok(nb);
+    for (int k = 0; k < nb; ++k) { res[k].resize(cs[k].size()); ok[k].assign(cs[k].size(), 0); }
+    pool.parallel_for((int)chunks.size(), [&](int i) {
+        const Chunk& ch = chunks[i];
+        for (size_t c = ch.c0; c < ch.c1; ++c) ok[ch.page][c] = contour_candidate(cs[ch.page][c], res[ch.page][c]) ? 1 : 0;
+    });
+    for (int k = 0; k < nb; ++k) {
+        out[k].clear();
+        for (size_t c = 0; c < cs[k].size(); ++c) if (ok[k][c]) out[k].push_back(res[k][c]);
+    }
+    if (g_timer && g_timer->on) {
+        auto tc = std::chrono::steady_clock::now();
+        double mx = 0, sum = 0;
+        for (double t : tpage) { mx = std::max(mx, t); sum += t; }
+        fprintf(stderr, "[timing]   subbatch nb=%d stage1=%.2fms (per-page max %.2f avg %.2f) stage2=%.2fms chunks=%zu\n", nb,
+                std::chrono::duration<double, std::milli>(tb - ta).count(), mx, sum / nb, std::chrono::duration<double, std::milli>(tc - tb).count(), chunks.size());
     }
 }
 
@@ -206,6 +278,9 @@ void Detector::run(const std::vector<PageRef>& pages, float thresh, float box_th
 
 void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>& pages, uint32_t rh, uint32_t rw, float thresh,
                          float box_thresh, float unclip, std::vector<DetBoxes>& out) {
+    // The group is cut into sub-batches whose GPU work (normalize -> network -> threshold -> mask D2H) is enqueued
+    // back to back; the host traces the contours of sub-batch i while the GPU is already on sub-batch i+1.
+    // Pages are independent in detection, so the result is identical to one big batch.
     hipStream_t s = eng_->stream();
     const int B = (int)idx.size();
     const size_t plane = (size_t)rh * rw;
@@ -214,55 +289,65 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
     float alpha[3], beta[3];
     for (int c = 0; c < 3; ++c) { alpha[c] = scale / stdv[c]; beta[c] = -mean[c] / stdv[c]; }
+    static const int kSub = [] { const char* e = getenv("OAR_DET_SUB"); int v = e ? atoi(e) : 8; return v > 0 ? v : 8; }();
+    const int SB = std::min(B, kSub);
+    const int nsub = (B + SB - 1) / SB;
 
-    size_t need_in = (size_t)B * plane * 3 * sizeof(float);
+    // output geometry from the plan of the largest sub-batch (shape inference only)
+    const Plan& plan0 = eng_->plan_for({SB, 3, (int64_t)rh, (int64_t)rw}, true);
+    OAR_CHECK(!plan0.outputs.empty(), OAR_INTERNAL, "DB: no output returned from inference");
+    OAR_CHECK(plan0.outputs[0].dims.size() == 4, OAR_SHAPE_MISMATCH, "DB: expected a 4-D [batch,1,H,W] output");
+    const int C = (int)plan0.outputs[0].dims[1], H = (int)plan0.outputs[0].dims[2], W = (int)plan0.outputs[0].dims[3];
+    const size_t hw = (size_t)H * W;
+
+    size_t need_in = (size_t)SB * plane * 3 * sizeof(float);
     size_t need_rs = 0;
     for (int b = 0; b < B; ++b) if (pages[idx[b]].w != rw || pages[idx[b]].h != rh) need_rs += (plane * 3 + 255) & ~(size_t)255;
-    if (need_in > input_f32_.cap || need_rs > resized_dev_.cap) {
+    if (need_in > input_f32_.cap || need_rs > resized_dev_.cap || (size_t)B * hw > mask_dev_.cap || (size_t)B * hw * 4 > probs_keep_.cap) {
         OAR_HIP(hipStreamSynchronize(s));
-        input_f32_.reserve(need_in);
-        resized_dev_.reserve(need_rs);
+        input_f32_.reserve(need_in); resized_dev_.reserve(need_rs); mask_dev_.reserve((size_t)B * hw); probs_keep_.reserve((size_t)B * hw * 4);
     }
-    size_t rs_off = 0;
-    for (int b = 0; b < B; ++b) {
-        const PageRef& pg = pages[idx[b]];
-        const uint8_t* src = page_ptrs_[idx[b]];
-        if (pg.w != rw || pg.h != rh) {
-            uint8_t* dst = resized_dev_.as<uint8_t>() + rs_off;
-            pp::resize_triangle(s, src, (int)pg.w, (int)pg.h, dst, (int)rw, (int)rh);
-            src = dst;
-            rs_off += (plane * 3 + 255) & ~(size_t)255;
-        }
-        pp::normalize(s, src, input_f32_.as<float>() + (size_t)b * plane * 3, 1, (int64_t)plane, kDbSrc, alpha, beta, 1);
-    }
-    tmark("det_pre_enqueue");
-    const Plan& plan = eng_->run(input_f32_.as<float>(), {B, 3, (int64_t)rh, (int64_t)rw}, true);
-    tmark("det_net_enqueue");
-    OAR_CHECK(!plan.outputs.empty(), OAR_INTERNAL, "DB: no output returned from inference");
-    const PlanOutput& po = plan.outputs[0];
-    OAR_CHECK(po.dims.size() == 4 && po.dims[0] == B, OAR_SHAPE_MISMATCH, "DB: expected a 4-D [batch,1,H,W] output");
-    const int C = (int)po.dims[1], H = (int)po.dims[2], W = (int)po.dims[3];
-    const float* pred = eng_->out_ptr(po.loc);
-    const size_t hw = (size_t)H * W;
-    const size_t need_mask = (size_t)B * hw + (C != 1 ? (size_t)B * hw * 4 : 0);
-    if (need_mask > mask_dev_.cap) { OAR_HIP(hipStreamSynchronize(s)); mask_dev_.reserve(need_mask); }
     mask_host_.reserve((size_t)B * hw);
-    if (C != 1) {  // only channel 0 is used (processors/db_postprocess.rs:122-123)
-        float* compact = reinterpret_cast<float*>(mask_dev_.as<uint8_t>() + (((size_t)B * hw + 255) & ~(size_t)255));
-        OAR_CHECK((((size_t)B * hw + 255) & ~(size_t)255) + (size_t)B * hw * 4 <= mask_dev_.cap, OAR_INTERNAL, "mask buffer sizing");
-        k::copy2d(s, pred, compact, B, (int)hw, (int)(hw * C), (int)hw);
-        pred = compact;
+    while ((int)sub_events_.size() < nsub) { hipEvent_t e; OAR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); sub_events_.push_back(e); }
+
+    float* probs = probs_keep_.as<float>();   // [B][H][W] channel-0 planes, kept for the score kernel
+    size_t rs_off = 0;
+    for (int sb = 0; sb < nsub; ++sb) {
+        const int b0 = sb * SB, nb = std::min(SB, B - b0);
+        for (int k = 0; k < nb; ++k) {
+            const PageRef& pg = pages[idx[b0 + k]];
+            const uint8_t* src = page_ptrs_[idx[b0 + k]];
+            if (pg.w != rw || pg.h != rh) {
+                uint8_t* dst = resized_dev_.as<uint8_t>() + rs_off;
+                pp::resize_triangle(s, src, (int)pg.w, (int)pg.h, dst, (int)rw, (int)rh);
+                src = dst;
+                rs_off += (plane * 3 + 255) & ~(size_t)255;
+            }
+            pp::normalize(s, src, input_f32_.as<float>() + (size_t)k * plane * 3, 1, (int64_t)plane, kDbSrc, alpha, beta, 1);
+        }
+        const Plan& plan = eng_->run(input_f32_.as<float>(), {nb, 3, (int64_t)rh, (int64_t)rw}, true);
+        const PlanOutput& po = plan.outputs[0];
+        OAR_CHECK(po.dims.size() == 4 && po.dims[0] == nb && po.dims[1] == C && po.dims[2] == H && po.dims[3] == W, OAR_SHAPE_MISMATCH,
+                  "DB: inconsistent output shape across sub-batches");
+        // only channel 0 is used (processors/db_postprocess.rs:122-123); keep it past the next sub-batch's arena reuse
+        k::copy2d(s, eng_->out_ptr(po.loc), probs + (size_t)b0 * hw, nb, (int)hw, (int)(hw * C), (int)hw);
+        pp::threshold(s, probs + (size_t)b0 * hw, mask_dev_.as<uint8_t>() + (size_t)b0 * hw, (int64_t)nb * hw, thresh);
+        OAR_HIP(hipMemcpyAsync(mask_host_.as<uint8_t>() + (size_t)b0 * hw, mask_dev_.as<uint8_t>() + (size_t)b0 * hw, (size_t)nb * hw,
+                               hipMemcpyDeviceToHost, s));
+        OAR_HIP(hipEventRecord(sub_events_[sb], s));
     }
-    pp::threshold(s, pred, mask_dev_.as<uint8_t>(), (int64_t)B * hw, thresh);
-    OAR_HIP(hipMemcpyAsync(mask_host_.p, mask_dev_.p, (size_t)B * hw, hipMemcpyDeviceToHost, s));
-    OAR_HIP(hipStreamSynchronize(s));
-    tmark("det_gpu_wait+mask_d2h");
+    tmark("det_enqueue");
 
     std::vector<std::vector<Candidate>> cands(B);
     const uint8_t* mh = mask_host_.as<uint8_t>();
     const uint32_t maxc = cfg_.max_candidates;
-    pool_->parallel_for(B, [&](int b) { page_candidates(mh + (size_t)b * hw, H, W, maxc, cands[b]); });
-    tmark("host_contours");
+    for (int sb = 0; sb < nsub; ++sb) {
+        const int b0 = sb * SB, nb = std::min(SB, B - b0);
+        OAR_HIP(hipEventSynchronize(sub_events_[sb]));
+        tmark("det_gpu_wait");
+        subbatch_candidates(*pool_, mh + (size_t)b0 * hw, hw, H, W, nb, maxc, &cands[b0]);
+        tmark("host_contours");
+    }
 
     size_t total = 0;
     std::vector<size_t> base(B + 1, 0);
@@ -273,18 +358,19 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
         boxes_host_.reserve(total * sizeof(pp::ScoreBox));
         scores_host_.reserve(total * sizeof(float));
         if (total * sizeof(pp::ScoreBox) > boxes_dev_.cap || total * sizeof(float) > scores_dev_.cap) {
+            OAR_HIP(hipStreamSynchronize(s));
             boxes_dev_.reserve(total * sizeof(pp::ScoreBox));
             scores_dev_.reserve(total * sizeof(float));
         }
-        pp::ScoreBox* sb = boxes_host_.as<pp::ScoreBox>();
+        pp::ScoreBox* sbx = boxes_host_.as<pp::ScoreBox>();
         for (int b = 0; b < B; ++b)
             for (size_t i = 0; i < cands[b].size(); ++i) {
-                pp::ScoreBox& x = sb[base[b] + i];
+                pp::ScoreBox& x = sbx[base[b] + i];
                 std::memcpy(x.pts, cands[b][i].pts, sizeof x.pts);
                 x.image = b; x.pad = 0;
             }
-        OAR_HIP(hipMemcpyAsync(boxes_dev_.p, sb, total * sizeof(pp::ScoreBox), hipMemcpyHostToDevice, s));
-        pp::box_scores(s, pred, H, W, boxes_dev_.as<pp::ScoreBox>(), (int)total, scores_dev_.as<float>());
+        OAR_HIP(hipMemcpyAsync(boxes_dev_.p, sbx, total * sizeof(pp::ScoreBox), hipMemcpyHostToDevice, s));
+        pp::box_scores(s, probs, H, W, boxes_dev_.as<pp::ScoreBox>(), (int)total, scores_dev_.as<float>());
         OAR_HIP(hipMemcpyAsync(scores_host_.p, scores_dev_.p, total * sizeof(float), hipMemcpyDeviceToHost, s));
         OAR_HIP(hipStreamSynchronize(s));
         std::memcpy(scores.data(), scores_host_.p, total * sizeof(float));

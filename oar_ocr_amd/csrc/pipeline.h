@@ -1,6 +1,7 @@
 // pipeline.h -- the MI355X stand-ins for the reference's text-detection / text-recognition adapters and
 // for OAROCR::predict (src/oarocr/ocr.rs:518-659).
 #pragma once
+#include <atomic>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -14,6 +15,9 @@
 
 namespace oar {
 
+// Small fork-join pool for the host-side geometry. Workers SPIN for a short window after each job before they
+// go to sleep on a condition variable: the work arrives as ~1 ms bursts every few ms, and waking parked cores
+// (deep C-states, min clocks) was measured to cost more than the work itself.
 class ThreadPool {
    public:
     explicit ThreadPool(int n);
@@ -25,10 +29,11 @@ class ThreadPool {
     void loop();
     std::vector<std::thread> workers_;
     std::mutex mu_;
-    std::condition_variable cv_, done_cv_;
+    std::condition_variable cv_;
     const std::function<void(int)>* fn_ = nullptr;
-    int next_ = 0, count_ = 0, active_ = 0, gen_ = 0;
-    bool stop_ = false;
+    std::atomic<int> gen_{0}, next_{0}, done_{0}, count_{0};
+    std::atomic<bool> stop_{false};
+    std::mutex err_mu_;
     std::exception_ptr err_;
 };
 
@@ -62,7 +67,8 @@ class Detector {
     std::unique_ptr<Engine> eng_;
     std::unique_ptr<ThreadPool> pool_;
     oar_det_cfg cfg_;
-    DevBuf pages_dev_, resized_dev_, input_f32_, mask_dev_, boxes_dev_, scores_dev_;
+    DevBuf pages_dev_, resized_dev_, input_f32_, mask_dev_, boxes_dev_, scores_dev_, probs_keep_;
+    std::vector<hipEvent_t> sub_events_;
     PinBuf mask_host_, boxes_host_, scores_host_;
     std::vector<const uint8_t*> page_ptrs_;
     std::mutex mu_;
