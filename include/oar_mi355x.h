@@ -227,6 +227,22 @@ oar_status oar_k_box_scores(const float* pred, uint32_t height, uint32_t width, 
 oar_status oar_k_rotate_crop(const uint8_t* rgb, uint32_t w, uint32_t h, const float box[8], uint8_t* out,
                              size_t cap, uint32_t* out_w, uint32_t* out_h);
 
+/* ------------------------------------------------------------------------------------------------ host-side geometry hooks
+ * The serial per-contour stages of DB post-processing and crop planning run on the host.
+ * These hooks expose them WITHOUT touching a GPU so the CPU test-suite can check them against the oracle.
+ * a8+a9 db_bitmap.rs:100-113,153-277: mask -> mini-box candidates (8 floats each, discovery order). max_bands > 1
+ * traces row bands cut at blank rows in the same order (identical result). Returns the count (<= cap written). */
+int32_t oar_host_candidates(const uint8_t* mask, uint32_t width, uint32_t height, uint32_t max_candidates, int32_t max_bands,
+                            float* boxes8, int32_t cap);
+/* a11 db_bitmap.rs:279-368: unclip a 4-point box; returns the number of points (0 = dropped), x,y pairs in out. */
+int32_t oar_host_unclip(const float box8[8], float ratio, float* out_xy, int32_t cap_points);
+/* a9 mini box of an arbitrary point set (db_bitmap.rs:164-205): returns 1 and fills box8/min_side, or 0. */
+int32_t oar_host_mini_box(const float* xy, int32_t n_points, float box8[8], float* min_side);
+/* a13 processors/sorting.rs:35-84: permutation that sorts n quad boxes into reading order. */
+void oar_host_sort_quad_boxes(const float* boxes8, int32_t n, int32_t* order);
+/* a14 utils/transform.rs:76-191 planning half: plan[8] = {mode, left, top, cw, ch, out_w, out_h, rot}; inv[9]. */
+void oar_host_plan_crop(uint32_t img_w, uint32_t img_h, const float box8[8], int32_t plan[8], float inv[9]);
+
 /* ------------------------------------------------------------------------------------------------ profiling
  * Per-kernel-class accumulators filled from hipEvents recorded on the engine's own stream while cfg.profile
  * is set.  class_name e.g. "conv_igemm", "dwconv", "softmax".  alg_bytes / alg_flops are the algorithmic

@@ -85,6 +85,7 @@ EXPORTS = [
     "oar_ocr_predict", "oar_ocr_predict_device", "oar_ocr_result_free", "oar_dev_alloc", "oar_dev_upload", "oar_dev_download",
     "oar_dev_free", "oar_dev_synchronize", "oar_k_normalize", "oar_k_rec_preprocess", "oar_k_resize_triangle", "oar_k_threshold",
     "oar_k_ctc_argmax", "oar_k_box_scores", "oar_k_rotate_crop", "oar_prof_reset", "oar_prof_enable", "oar_prof_filter", "oar_prof_snapshot",
+    "oar_host_candidates", "oar_host_unclip", "oar_host_mini_box", "oar_host_sort_quad_boxes", "oar_host_plan_crop",
 ]
 
 
@@ -144,6 +145,16 @@ def lib():
     L.oar_k_ctc_argmax.argtypes = [vp, C.c_size_t, C.c_size_t, vp, vp]
     L.oar_k_box_scores.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp]
     L.oar_k_rotate_crop.argtypes = [vp, C.c_uint32, C.c_uint32, f32p, vp, C.c_size_t, u32p, u32p]
+    L.oar_host_candidates.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, vp, C.c_int32]
+    L.oar_host_candidates.restype = C.c_int32
+    L.oar_host_unclip.argtypes = [vp, C.c_float, vp, C.c_int32]
+    L.oar_host_unclip.restype = C.c_int32
+    L.oar_host_mini_box.argtypes = [vp, C.c_int32, vp, f32p]
+    L.oar_host_mini_box.restype = C.c_int32
+    L.oar_host_sort_quad_boxes.argtypes = [vp, C.c_int32, vp]
+    L.oar_host_sort_quad_boxes.restype = None
+    L.oar_host_plan_crop.argtypes = [C.c_uint32, C.c_uint32, vp, vp, vp]
+    L.oar_host_plan_crop.restype = None
     L.oar_prof_reset.restype = None
     L.oar_prof_enable.argtypes = [C.c_int32]
     L.oar_prof_enable.restype = None
@@ -744,3 +755,45 @@ def k_rotate_crop(img, box):
     if ow.value == 0:
         return None
     return out[:ow.value * oh.value * 3].reshape(oh.value, ow.value, 3).copy()
+
+
+# host-side geometry hooks (no GPU needed)
+def host_candidates(mask, max_candidates=1000, max_bands=1):
+    mask = np.ascontiguousarray(mask, np.uint8)
+    h, w = mask.shape
+    out = np.zeros((max_candidates, 4, 2), np.float32)
+    n = lib().oar_host_candidates(_p(mask), w, h, max_candidates, max_bands, _p(out), max_candidates)
+    if n < 0:
+        raise OCRError(OAR_INTERNAL, "oar_host_candidates failed")
+    return out[:n].copy()
+
+
+def host_unclip(box, ratio):
+    box = np.ascontiguousarray(box, np.float32).reshape(8)
+    out = np.zeros((1024, 2), np.float32)
+    n = lib().oar_host_unclip(_p(box), ratio, _p(out), 1024)
+    return out[:max(n, 0)].copy()
+
+
+def host_mini_box(points):
+    pts = np.ascontiguousarray(points, np.float32).reshape(-1, 2)
+    out = np.zeros((4, 2), np.float32)
+    ms = C.c_float(0)
+    ok = lib().oar_host_mini_box(_p(pts), pts.shape[0], _p(out), C.byref(ms))
+    return (out, float(ms.value)) if ok == 1 else None
+
+
+def host_sort_quad_boxes(boxes):
+    b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 8)
+    order = np.zeros(b.shape[0], np.int32)
+    if b.shape[0]:
+        lib().oar_host_sort_quad_boxes(_p(b), b.shape[0], _p(order))
+    return order
+
+
+def host_plan_crop(img_w, img_h, box):
+    b = np.ascontiguousarray(box, np.float32).reshape(8)
+    plan = np.zeros(8, np.int32)
+    inv = np.zeros(9, np.float32)
+    lib().oar_host_plan_crop(img_w, img_h, _p(b), _p(plan), _p(inv))
+    return plan, inv

@@ -484,6 +484,67 @@ oar_status oar_k_rotate_crop(const uint8_t* rgb, uint32_t w, uint32_t h, const f
     });
 }
 
+// ---------------------------------------------------------------------------------------------- host hooks (no GPU)
+int32_t oar_host_candidates(const uint8_t* mask, uint32_t width, uint32_t height, uint32_t max_candidates, int32_t max_bands,
+                            float* boxes8, int32_t cap) {
+    try {
+        std::vector<int32_t> scratch((size_t)width * height);
+        std::vector<int> cuts = host::blank_row_bands(mask, (int)width, (int)height, max_bands < 1 ? 1 : max_bands);
+        std::vector<host::Contour> cs;
+        for (size_t i = 0; i + 1 < cuts.size(); ++i) {
+            auto part = host::find_contours_band(mask, (int)width, (int)height, cuts[i], cuts[i + 1], max_candidates, scratch.data());
+            for (auto& c : part) { if (cs.size() >= max_candidates) break; cs.push_back(std::move(c)); }
+        }
+        int32_t n = 0;
+        for (auto& c : cs) {
+            std::vector<host::Pt> simp = host::simplify_chain(c.pts);
+            host::Pt mb[4];
+            float ms = 0.f;
+            bool ok = simp.size() >= 3 ? host::mini_box(simp, mb, ms) : host::mini_box(c.pts, mb, ms);
+            if (!ok || ms < 3.0f) continue;
+            if (n < cap) for (int k = 0; k < 4; ++k) { boxes8[n * 8 + k * 2] = mb[k].x; boxes8[n * 8 + k * 2 + 1] = mb[k].y; }
+            ++n;
+        }
+        return n;
+    } catch (...) { return -1; }
+}
+int32_t oar_host_unclip(const float box8[8], float ratio, float* out_xy, int32_t cap_points) {
+    try {
+        host::Pt b[4];
+        for (int k = 0; k < 4; ++k) b[k] = {box8[k * 2], box8[k * 2 + 1]};
+        std::vector<host::Pt> r = host::unclip(b, ratio);
+        for (size_t i = 0; i < r.size() && (int32_t)i < cap_points; ++i) { out_xy[i * 2] = r[i].x; out_xy[i * 2 + 1] = r[i].y; }
+        return (int32_t)r.size();
+    } catch (...) { return -1; }
+}
+int32_t oar_host_mini_box(const float* xy, int32_t n_points, float box8[8], float* min_side) {
+    try {
+        std::vector<host::Pt> p(n_points);
+        for (int i = 0; i < n_points; ++i) p[i] = {xy[i * 2], xy[i * 2 + 1]};
+        host::Pt mb[4];
+        float ms = 0.f;
+        if (!host::mini_box(p, mb, ms)) return 0;
+        for (int k = 0; k < 4; ++k) { box8[k * 2] = mb[k].x; box8[k * 2 + 1] = mb[k].y; }
+        if (min_side) *min_side = ms;
+        return 1;
+    } catch (...) { return -1; }
+}
+void oar_host_sort_quad_boxes(const float* boxes8, int32_t n, int32_t* order) {
+    try {
+        std::vector<float> b(boxes8, boxes8 + (size_t)n * 8);
+        std::vector<int> o = host::sort_quad_boxes(b);
+        for (int i = 0; i < n; ++i) order[i] = o[i];
+    } catch (...) {}
+}
+void oar_host_plan_crop(uint32_t img_w, uint32_t img_h, const float box8[8], int32_t plan[8], float inv[9]) {
+    try {
+        host::CropPlan pl = host::plan_crop((int)img_w, (int)img_h, box8);
+        plan[0] = pl.mode; plan[1] = pl.left; plan[2] = pl.top; plan[3] = pl.cw; plan[4] = pl.ch;
+        plan[5] = pl.mode ? pl.out_w() : 0; plan[6] = pl.mode ? pl.out_h() : 0; plan[7] = pl.rot;
+        std::memcpy(inv, pl.inv, sizeof pl.inv);
+    } catch (...) { plan[0] = 0; }
+}
+
 // ---------------------------------------------------------------------------------------------- profiling
 void oar_prof_reset(void) {
     try { Profiler::get().reset(); } catch (...) {}

@@ -30,15 +30,46 @@ inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi 
 
 // ------------------------------------------------------------------------------------------ contours
 std::vector<Contour> find_contours(const uint8_t* mask, int width, int height, size_t max_contours) {
+    static thread_local std::vector<int32_t> iv;   // reused per worker thread (3.7 MB per 960x960 page)
+    iv.resize((size_t)width * height);
+    return find_contours_band(mask, width, height, 0, height, max_contours, iv.data());
+}
+
+std::vector<int> blank_row_bands(const uint8_t* mask, int width, int height, int max_bands) {
+    std::vector<uint8_t> occupied(height, 0);
+    int fg_rows = 0;
+    for (int y = 0; y < height; ++y) {
+        const uint8_t* r = mask + (size_t)y * width;
+        int x = 0;
+        bool any = false;
+        for (; x + 8 <= width; x += 8) { uint64_t w8; std::memcpy(&w8, r + x, 8); if (w8) { any = true; break; } }
+        if (!any) for (; x < width; ++x) if (r[x]) { any = true; break; }
+        occupied[y] = any;
+        fg_rows += any;
+    }
+    std::vector<int> cuts{0};
+    if (max_bands > 1 && fg_rows > 0) {
+        const int target = (fg_rows + max_bands - 1) / max_bands;
+        int acc = 0;
+        for (int y = 0; y < height; ++y) {
+            if (occupied[y]) { ++acc; continue; }
+            if (acc >= target && y > cuts.back()) { cuts.push_back(y); acc = 0; }   // y is blank: safe cut
+        }
+    }
+    cuts.push_back(height);
+    return cuts;
+}
+
+std::vector<Contour> find_contours_band(const uint8_t* mask, int width, int height, int band_y0, int band_y1, size_t max_contours, int32_t* ivp) {
     static const int DX[8] = {-1, -1, 0, 1, 1, 1, 0, -1};  // w, nw, n, ne, e, se, s, sw (clockwise on screen)
     static const int DY[8] = {0, -1, -1, -1, 0, 1, 1, 1};
     static const int8_t DIR_LUT[9] = {1, 2, 3, 0, 0, 4, 7, 6, 5};  // index (dy+1)*3 + (dx+1)
     auto dir_of = [](int dx, int dy) { return (int)DIR_LUT[(dy + 1) * 3 + (dx + 1)]; };
-    static thread_local std::vector<int32_t> iv;   // reused per worker thread (3.7 MB per 960x960 page)
-    iv.resize((size_t)width * height);
-    for (size_t i = 0; i < iv.size(); ++i) iv[i] = mask[i] > 0 ? 1 : 0;
+    // the band may be cut only at blank rows, so neighbours outside [band_y0, band_y1) are background by construction
+    int32_t* iv = ivp;
+    for (size_t i = (size_t)band_y0 * width; i < (size_t)band_y1 * width; ++i) iv[i] = mask[i] > 0 ? 1 : 0;
     auto at = [&](int x, int y) -> int32_t& { return iv[(size_t)y * width + x]; };
-    auto nonzero = [&](int x, int y) { return (unsigned)x < (unsigned)width && (unsigned)y < (unsigned)height && iv[(size_t)y * width + x] != 0; };
+    auto nonzero = [&](int x, int y) { return (unsigned)x < (unsigned)width && y >= band_y0 && y < band_y1 && iv[(size_t)y * width + x] != 0; };
 
     std::vector<Contour> out;
     int border = 1;
@@ -104,7 +135,8 @@ std::vector<Contour> find_contours(const uint8_t* mask, int width, int height, s
         if (nv != 1) parent_border = nv < 0 ? -nv : nv;
     };
 
-    for (int y = 0; y < height && !full; ++y) {
+    (void)height;
+    for (int y = band_y0; y < band_y1 && !full; ++y) {
         int parent_border = 1;
         const uint8_t* mrow = mask + (size_t)y * width;
         int x = 0;

@@ -21,6 +21,13 @@ struct Contour {
 // hole borders included).  Stops after max_contours contours (the reference `take(max_candidates)` only ever
 // consumes that many).
 std::vector<Contour> find_contours(const uint8_t* mask, int width, int height, size_t max_contours);
+// Same result, restricted to rows [y0, y1) of the image (contour coordinates stay global).  Connected components
+// cannot cross a fully-blank row, so an image cut at blank rows can be traced band by band, in parallel, and the
+// per-band results concatenated in band order are exactly find_contours' raster discovery order.
+std::vector<Contour> find_contours_band(const uint8_t* mask, int width, int height, int y0, int y1, size_t max_contours, int32_t* scratch);
+// Row cuts for find_contours_band: returns band boundaries (first = 0, last = height); every interior boundary is a
+// row whose pixels are all zero; at most max_bands bands of roughly equal foreground-row count.
+std::vector<int> blank_row_bands(const uint8_t* mask, int width, int height, int max_bands);
 
 struct MinAreaRect { float cx, cy, w, h, angle; };
 std::vector<Pt> convex_hull(const std::vector<Pt>& src);                 // processors/geometry.rs:226-271

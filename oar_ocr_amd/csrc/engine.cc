@@ -1154,6 +1154,7 @@ struct Planner {
         for (auto& d : dead) { arena.release(root_off[d], root_bytes[d]); root_bytes.erase(d); root_off.erase(d); }
     }
 
+    bool skip_final_softmax = false;
     void build(const std::vector<int64_t>& in_dims, bool in_clast) {
         compute_last_use();
         TInfo in;
@@ -1165,6 +1166,18 @@ struct Planner {
         for (int i = 0; i < (int)E.nodes_.size(); ++i) {
             const GNode& n = E.nodes_[i];
             cur = i;
+            if (skip_final_softmax && n.op == "Softmax" && !n.out.empty() && n.out[0] == E.output_names_[0]) {
+                TInfo x = get(n.in[0]);
+                int r = (int)x.dims.size();
+                int64_t axis = n.ai("axis", -1);
+                if (axis < 0) axis += r;
+                if (E_opset13() && axis == r - 1 && x.layout == Layout::NATIVE) {
+                    alias_out(n.out[0], x, x.dims, Layout::NATIVE);
+                    P.skipped_softmax = true;
+                    release_dead(i);
+                    continue;
+                }
+            }
             dispatch(n);
             release_dead(i);
         }
@@ -1243,23 +1256,24 @@ struct Planner {
     }
 };
 
-const Plan& Engine::plan_for(const std::vector<int64_t>& dims, bool in_clast) {
+const Plan& Engine::plan_for(const std::vector<int64_t>& dims, bool in_clast, bool skip_final_softmax) {
     std::ostringstream key;
-    key << (in_clast ? "L" : "N");
+    key << (in_clast ? "L" : "N") << (skip_final_softmax ? "S" : "");
     for (auto d : dims) key << "x" << d;
     auto it = plans_.find(key.str());
     if (it != plans_.end()) return *it->second;
     OAR_HIP(hipSetDevice(device_));
     std::unique_ptr<Plan> p(new Plan());
     Planner pl(*this, *p);
+    pl.skip_final_softmax = skip_final_softmax;
     pl.build(dims, in_clast);
     const Plan& ref = *p;
     plans_[key.str()] = std::move(p);
     return ref;
 }
 
-const Plan& Engine::run(const float* d_in, const std::vector<int64_t>& dims, bool in_clast) {
-    const Plan& p = plan_for(dims, in_clast);
+const Plan& Engine::run(const float* d_in, const std::vector<int64_t>& dims, bool in_clast, bool skip_final_softmax) {
+    const Plan& p = plan_for(dims, in_clast, skip_final_softmax);
     OAR_HIP(hipSetDevice(device_));
     if (arena_.cap < p.arena_bytes) {
         OAR_HIP(hipStreamSynchronize(stream_));

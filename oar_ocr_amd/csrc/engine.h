@@ -68,6 +68,7 @@ struct Plan {
     std::vector<PlanOutput> outputs;
     double flops = 0, bytes = 0;
     int n_kernels = 0;
+    bool skipped_softmax = false;
 };
 
 class Engine {
@@ -80,8 +81,10 @@ class Engine {
 
     // d_in: device pointer. dims: logical ONNX dims. in_clast: rank-4 input already stored NHWC.
     // Outputs stay on the device (valid until the next run on this engine).
-    const Plan& run(const float* d_in, const std::vector<int64_t>& dims, bool in_clast);
-    const Plan& plan_for(const std::vector<int64_t>& dims, bool in_clast);
+    // skip_final_softmax: when output[0] is produced by a Softmax over its last axis, stop before it and return the
+    // logits instead (Plan::skipped_softmax is set) -- the recognizer fuses that softmax with the CTC argmax.
+    const Plan& run(const float* d_in, const std::vector<int64_t>& dims, bool in_clast, bool skip_final_softmax = false);
+    const Plan& plan_for(const std::vector<int64_t>& dims, bool in_clast, bool skip_final_softmax = false);
     const float* out_ptr(const Loc& l) const;
     char* arena() const { return arena_.as<char>(); }
     std::mutex& mutex() { return mu_; }

@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -246,7 +247,12 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     if (p.M == 0) return;
     const bool is1x1 = c.convt2x2 || (c.kh == 1 && c.kw == 1 && c.sh == 1 && c.sw == 1 && c.pt == 0 && c.pl == 0);
     int nfrag = (p.gemm_cout + 15) / 16;
-    int NT = nfrag >= 3 ? 4 : (nfrag == 2 ? 2 : 1);
+    // cout fragments per wave: minimise padded (wasted) MFMA work, prefer the larger tile on ties
+    int NT = 1;
+    {
+        int best = 1 << 30;
+        for (int t = 4; t >= 1; --t) { int padded = (nfrag + t - 1) / t * t; if (padded < best) { best = padded; NT = t; } }
+    }
     // pixel fragments per wave: fewer when the launch would otherwise leave most of the 256 CUs idle
     const long ny = (nfrag + NT - 1) / NT;
     static const int pf_max = [] { const char* e = getenv("OAR_IGEMM_PF"); int v = e ? atoi(e) : 2; return v == 1 || v == 4 ? v : 2; }();  // PF=2: 102 VGPRs => 4 waves/SIMD (measured 1.2x over PF=4)
@@ -256,6 +262,8 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     p.ny = (int)ny;
     p.mx_per_xcd = (mx + 7) / 8;
     dim3 grid((unsigned)(p.mx_per_xcd * 8 * ny));
+    // (A variant with the cout tile of W resident in LDS and chunk-pair X prefetch was measured at parity with this
+    // kernel -- 78-81 TFLOP/s on the K=192/256 shapes either way -- and dropped.)
     double flops = 2.0 * (double)p.M * p.K * p.gemm_cout;
     double bytes = 4.0 * ((double)c.N * c.H * c.W * c.Cin + (double)p.M * p.gemm_cout + (double)p.K * p.gemm_cout);
     char pname[96];
@@ -277,6 +285,7 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
         else LAUNCH2(NTV, 1);                        \
     } while (0)
     if (NT == 4) LAUNCH(4);
+    else if (NT == 3) LAUNCH(3);
     else if (NT == 2) LAUNCH(2);
     else LAUNCH(1);
 #undef LAUNCH2
@@ -971,6 +980,49 @@ __global__ __launch_bounds__(256) void softmax_block_kernel(const float* x, floa
     s = bcast;
     for (int i = tid; i < C; i += 256) y[row * C + i] = rowbuf[i] / s;
 }
+// Fused CTC tail for the recognizer seam: softmax over the vocabulary + "last index of the row maximum" + its
+// probability, without writing the [rows, C] probability tensor.  Bit-identical to softmax_block_kernel followed by
+// pp::ctc_argmax_kernel: same expf, same partial-sum tree; p_max = expf(0)/s = 1/s and the tie set
+// {i : p_i == p_max} is exactly {i : expf(x_i - m) == 1.0f} (division by the same s is monotone).
+__global__ __launch_bounds__(256) void softmax_argmax_kernel(const float* x, int C, int64_t* idx, float* prob) {
+    extern __shared__ float rowbuf[];
+    __shared__ float red[4];
+    __shared__ int redi[4];
+    __shared__ float bcast;
+    const long row = blockIdx.x;
+    const float* xr = x + row * C;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float m = -3.402823466e38f;
+    for (int i = tid; i < C; i += 256) { float v = xr[i]; rowbuf[i] = v; m = fmaxf(m, v); }
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    if (tid == 0) bcast = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    m = bcast;
+    float s = 0.f;
+    int last = -1;
+    for (int i = tid; i < C; i += 256) { float e = expf(rowbuf[i] - m); s += e; if (e == 1.0f) last = i; }
+    s = wave_sum(s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
+    __syncthreads();
+    if (lane == 0) { red[wave] = s; redi[wave] = last; }
+    __syncthreads();
+    if (tid == 0) {
+        float tot = (red[0] + red[1]) + (red[2] + red[3]);
+        int li = max(max(redi[0], redi[1]), max(redi[2], redi[3]));
+        idx[row] = li < 0 ? 0 : li;
+        prob[row] = 1.0f / tot;
+    }
+}
+void softmax_argmax(hipStream_t s, const float* logits, int64_t rows, int C, int64_t* idx, float* prob) {
+    if (rows == 0 || C == 0) return;
+    OAR_CHECK((size_t)C * 4 <= 150 * 1024, OAR_UNSUPPORTED_OP, "softmax_argmax: row longer than the LDS staging buffer");
+    ProfScope ps(s, "softmax_argmax", 4.0 * (double)rows * C, 4.0 * (double)rows * C);
+    hipLaunchKernelGGL(softmax_argmax_kernel, dim3((unsigned)rows), dim3(256), (size_t)C * sizeof(float), s, logits, C, idx, prob);
+}
+
 void softmax_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C) {
     if (rows == 0 || C == 0) return;
     ProfScope ps(s, "softmax", 8.0 * (double)rows * C, 4.0 * (double)rows * C);

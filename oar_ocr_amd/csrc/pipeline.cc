@@ -174,14 +174,36 @@ void page_candidates(const uint8_t* mask, int H, int W, uint32_t max_candidates,
 // per-contour geometry is then spread over the whole pool; discovery order is preserved.
 void subbatch_candidates(ThreadPool& pool, const uint8_t* masks, size_t hw, int H, int W, int nb, uint32_t max_candidates,
                          std::vector<Candidate>* out /* [nb] */) {
-    std::vector<std::vector<host::Contour>> cs(nb);
-    std::vector<double> tpage(nb, 0.0);
+    // stage 1: contour tracing, parallel over (page, row band) -- bands are cut at fully-blank rows
+    static thread_local std::vector<std::vector<int32_t>> scratch;   // one label plane per page of the sub-batch
+    if ((int)scratch.size() < nb) scratch.resize(nb);
+    struct Band { int page, y0, y1; };
+    std::vector<Band> bands;
+    const int bands_per_page = std::max(1, std::min(8, (pool.size() + 1) * 2 / std::max(nb, 1)));
+    auto t_setup = std::chrono::steady_clock::now();
+    std::vector<std::vector<int>> cuts(nb);
+    for (int k = 0; k < nb; ++k) scratch[k].resize(hw);
+    pool.parallel_for(nb, [&](int k) { cuts[k] = host::blank_row_bands(masks + (size_t)k * hw, W, H, bands_per_page); });
+    for (int k = 0; k < nb; ++k)
+        for (size_t i = 0; i + 1 < cuts[k].size(); ++i) bands.push_back({k, cuts[k][i], cuts[k][i + 1]});
+    std::vector<std::vector<host::Contour>> band_cs(bands.size());
+    std::vector<double> tpage(bands.size(), 0.0);
     auto ta = std::chrono::steady_clock::now();
-    pool.parallel_for(nb, [&](int k) {
+    // NB: a thread_local is never captured by a lambda -- workers would see their OWN (empty) instance; pass the
+    // caller's label planes explicitly
+    std::vector<int32_t*> planes(nb);
+    for (int k = 0; k < nb; ++k) planes[k] = scratch[k].data();
+    pool.parallel_for((int)bands.size(), [&](int i) {
         auto t0 = std::chrono::steady_clock::now();
-        cs[k] = host::find_contours(masks + (size_t)k * hw, W, H, max_candidates);
-        tpage[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        const Band& bd = bands[i];
+        band_cs[i] = host::find_contours_band(masks + (size_t)bd.page * hw, W, H, bd.y0, bd.y1, max_candidates, planes[bd.page]);
+        tpage[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     });
+    std::vector<std::vector<host::Contour>> cs(nb);
+    for (size_t i = 0; i < bands.size(); ++i) {   // band order == raster discovery order; `take(max_candidates)` afterwards
+        auto& dst = cs[bands[i].page];
+        for (auto& c : band_cs[i]) { if (dst.size() >= max_candidates) break; dst.push_back(std::move(c)); }
+    }
     auto tb = std::chrono::steady_clock::now();
     struct Chunk { int page; size_t c0, c1; };
     std::vector<Chunk> chunks;
@@ -203,8 +225,9 @@ void subbatch_candidates(ThreadPool& pool, const uint8_t* masks, size_t hw, int 
         auto tc = std::chrono::steady_clock::now();
         double mx = 0, sum = 0;
         for (double t : tpage) { mx = std::max(mx, t); sum += t; }
-        fprintf(stderr, "[timing]   subbatch nb=%d stage1=%.2fms (per-page max %.2f avg %.2f) stage2=%.2fms chunks=%zu\n", nb,
-                std::chrono::duration<double, std::milli>(tb - ta).count(), mx, sum / nb, std::chrono::duration<double, std::milli>(tc - tb).count(), chunks.size());
+        fprintf(stderr, "[timing]   subbatch nb=%d setup=%.2fms stage1=%.2fms (per-band max %.2f avg %.2f, %zu bands) stage2=%.2fms chunks=%zu\n", nb,
+                std::chrono::duration<double, std::milli>(ta - t_setup).count(), std::chrono::duration<double, std::milli>(tb - ta).count(), mx,
+                sum / std::max<size_t>(tpage.size(), 1), tpage.size(), std::chrono::duration<double, std::milli>(tc - tb).count(), chunks.size());
     }
 }
 
@@ -517,6 +540,7 @@ void Recognizer::run_batches(const std::vector<std::vector<Crop>>& batches, std:
     size_t desc_slot = 0, stage_slot = 0, row_total = 0;
     // first pass: plans (shape inference only) to size the result buffers
     std::vector<int> Wts(batches.size(), 0);
+    std::vector<char> fuse_tail(batches.size(), 0);
     for (size_t bi = 0; bi < batches.size(); ++bi) {
         const auto& b = batches[bi];
         if (b.empty()) continue;
@@ -524,8 +548,12 @@ void Recognizer::run_batches(const std::vector<std::vector<Crop>>& batches, std:
         for (auto& c : b) { ws.push_back(c.w); hs.push_back(c.h); }
         std::vector<int32_t> rws;
         Wts[bi] = host::rec_tensor_width(ws, hs, img_h, img_w, (int)cfg_.max_img_w, rws);
-        const Plan& plan = eng_->plan_for({(int64_t)b.size(), 3, img_h, Wts[bi]}, true);
-        OAR_CHECK(!plan.outputs.empty(), OAR_INTERNAL, "CRNN: no output returned from inference");
+        // the fused tail mirrors the workgroup-per-row softmax kernel (vocab > 1024); smaller vocabularies keep the
+        // unfused path so both seams stay bit-identical
+        const Plan& probe = eng_->plan_for({(int64_t)b.size(), 3, img_h, Wts[bi]}, true, false);
+        OAR_CHECK(!probe.outputs.empty(), OAR_INTERNAL, "CRNN: no output returned from inference");
+        fuse_tail[bi] = probe.outputs[0].dims.size() == 3 && probe.outputs[0].dims[2] > 1024;
+        const Plan& plan = fuse_tail[bi] ? eng_->plan_for({(int64_t)b.size(), 3, img_h, Wts[bi]}, true, true) : probe;
         const PlanOutput& po = plan.outputs[0];
         OAR_CHECK(po.dims.size() == 3, OAR_SHAPE_MISMATCH, "CRNN: expected 3D output (batch, time, vocab)");  // crnn.rs:273-279
         OAR_CHECK(po.dims[0] == (int64_t)b.size(), OAR_SHAPE_MISMATCH, "CRNN: output batch differs from input batch");
@@ -546,11 +574,15 @@ void Recognizer::run_batches(const std::vector<std::vector<Crop>>& batches, std:
         const float* in = pack(b, Wt, false, desc_slot, stage_slot);
         desc_slot += b.size();
         for (auto& c : b) if (!c.dev) stage_slot += ((size_t)c.w * c.h * 3 + 63) & ~(size_t)63;
-        const Plan& plan = eng_->run(in, {(int64_t)b.size(), 3, img_h, Wt}, true);
+        const Plan& plan = eng_->run(in, {(int64_t)b.size(), 3, img_h, Wt}, true, fuse_tail[bi] != 0);
         if (pend[bi].rows == 0) continue;
         const PlanOutput& po = plan.outputs[0];
-        pp::ctc_argmax(s, eng_->out_ptr(po.loc), (int64_t)pend[bi].rows, (int)po.dims[2], idx_dev_.as<int64_t>() + pend[bi].row0,
-                       prob_dev_.as<float>() + pend[bi].row0);
+        if (plan.skipped_softmax)   // output[0] holds logits: softmax + argmax in one pass, probabilities never hit HBM
+            k::softmax_argmax(s, eng_->out_ptr(po.loc), (int64_t)pend[bi].rows, (int)po.dims[2], idx_dev_.as<int64_t>() + pend[bi].row0,
+                              prob_dev_.as<float>() + pend[bi].row0);
+        else
+            pp::ctc_argmax(s, eng_->out_ptr(po.loc), (int64_t)pend[bi].rows, (int)po.dims[2], idx_dev_.as<int64_t>() + pend[bi].row0,
+                           prob_dev_.as<float>() + pend[bi].row0);
     }
     if (row_total) {
         OAR_HIP(hipMemcpyAsync(idx_host_.p, idx_dev_.p, row_total * 8, hipMemcpyDeviceToHost, s));

@@ -97,3 +97,16 @@ def test_pool_flush_and_batch_policy(nets):
     for x, y in zip(a, b):
         assert [t.text for t in x.text_regions] == [t.text for t in y.text_regions]
         assert all(np.array_equal(p.bounding_box, q.bounding_box) for p, q in zip(x.text_regions, y.text_regions))
+
+
+def test_fused_ctc_tail_is_bit_identical_to_unfused(nets):
+    """Seam B fuses softmax+argmax (probabilities never written to HBM); Seam A + the stand-alone argmax kernel on the
+    same input must give the same indices and the same probability bits."""
+    _, rec, chars = nets
+    crops = [pages.make_crop(40 + i, w, h) for i, (w, h) in enumerate([(320, 48), (260, 40), (500, 44), (150, 30)])]
+    got = api.TextRecognitionPredictor(rec, chars).predict(crops)
+    x = api.k_rec_preprocess(crops)
+    (name, probs), = api.OrtInfer(rec).infer(x)
+    idx, pr = api.k_ctc_argmax(probs)
+    assert np.array_equal(got.indices.reshape(-1), idx)
+    assert np.array_equal(got.probs.reshape(-1), pr)
