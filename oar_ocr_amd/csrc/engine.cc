@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <set>
 #include <sstream>
 
@@ -442,8 +443,50 @@ struct Planner {
             }
         return f;
     }
-    const float* conv_weight_igemm(const GNode& n, const HostTensor& W) {
-        std::string key = "igemm:" + n.in[1];
+    // [rows][K] f32 GEMM weights -> bf16x6 fragment order Wx[rows/16][K/32][3 planes][lane][8 bf16]
+    // (lane = (row & 15) + 16 * g holds k = 32*kc + 8*g + e, e = 0..7; plane 0/1/2 = the h/m/l truncation pieces)
+    static std::vector<float> to_fragment_x6(const std::vector<float>& w, int64_t rows, int64_t K) {
+        int64_t Rp = (rows + 63) / 64 * 64, KC = (K + 31) / 32;
+        std::vector<uint16_t> f((size_t)Rp * KC * 32 * 3, 0);
+        for (int64_t r = 0; r < rows; ++r)
+            for (int64_t k = 0; k < K; ++k) {
+                float x = w[(size_t)r * K + k];
+                uint32_t u, um, ul;
+                std::memcpy(&u, &x, 4);
+                uint32_t uh = u & 0xFFFF0000u;
+                float fh; std::memcpy(&fh, &uh, 4);
+                float r1 = x - fh;
+                std::memcpy(&um, &r1, 4); um &= 0xFFFF0000u;
+                float fm; std::memcpy(&fm, &um, 4);
+                float r2 = r1 - fm;
+                std::memcpy(&ul, &r2, 4); ul &= 0xFFFF0000u;
+                int64_t nf = r / 16, c = r % 16, kc = k / 32, g = (k % 32) / 8, e = k % 8;
+                size_t lane = (size_t)(c + 16 * g);
+                size_t base = (size_t)((nf * KC + kc) * 3) * 64 * 8;
+                f[base + (0 * 64 + lane) * 8 + e] = (uint16_t)(uh >> 16);
+                f[base + (1 * 64 + lane) * 8 + e] = (uint16_t)(um >> 16);
+                f[base + (2 * 64 + lane) * 8 + e] = (uint16_t)(ul >> 16);
+            }
+        std::vector<float> out(f.size() / 2);
+        std::memcpy(out.data(), f.data(), f.size() * 2);
+        return out;
+    }
+    // [rows][K] -> Wk[rows/16][K/32][half][lane][4]: lane = (row & 15) + 16 * g holds k = 32*kc + 8*g + 4*half + j
+    static std::vector<float> to_fragment_k32(const std::vector<float>& w, int64_t rows, int64_t K) {
+        int64_t Rp = (rows + 63) / 64 * 64, KC = (K + 31) / 32;
+        std::vector<float> f((size_t)Rp * KC * 32, 0.f);
+        for (int64_t r = 0; r < rows; ++r)
+            for (int64_t k = 0; k < K; ++k) {
+                int64_t nf = r / 16, c = r % 16, kc = k / 32, g = (k % 32) / 8, h = (k % 8) / 4, j = k % 4;
+                f[(size_t)((((nf * KC + kc) * 2 + h) * 64 + (c + 16 * g)) * 4 + j)] = w[(size_t)r * K + k];
+            }
+        return f;
+    }
+    static std::vector<float> to_fragments(int fmt, const std::vector<float>& w, int64_t rows, int64_t K) {
+        return fmt == k::IGEMM_W_X6 ? to_fragment_x6(w, rows, K) : fmt == k::IGEMM_W_K32 ? to_fragment_k32(w, rows, K) : to_fragment_order(w, rows, K);
+    }
+    const float* conv_weight_igemm(const GNode& n, const HostTensor& W, int fmt) {
+        std::string key = "igemm" + std::to_string(fmt) + ":" + n.in[1];
         auto it = E.dev_consts_.find(key);
         if (it != E.dev_consts_.end()) return it->second;
         int64_t Co = W.dims[0], Ci = W.dims[1], kh = W.dims[2], kw = W.dims[3];
@@ -456,7 +499,7 @@ struct Planner {
                         w[(size_t)co * K + (a * kw + b) * Ci + ci] = W.f[((co * Ci + ci) * kh + a) * kw + b];
         (void)Cp;
         w.resize((size_t)Co * K);
-        return E.upload_const(key, to_fragment_order(w, Co, K));
+        return E.upload_const(key, to_fragments(fmt, w, Co, K));
     }
     const float* conv_weight_dw(const GNode& n, const HostTensor& W) {
         std::string key = "dw:" + n.in[1];
@@ -482,8 +525,8 @@ struct Planner {
                         w[(size_t)(((a * kw + b) * cpg + ci) * Co + co)] = W.f[((co * cpg + ci) * kh + a) * kw + b];
         return E.upload_const(key, w);
     }
-    const float* convt_weight(const GNode& n, const HostTensor& W, bool igemm) {
-        std::string key = (igemm ? "convt_ig:" : "convt_dir:") + n.in[1];
+    const float* convt_weight(const GNode& n, const HostTensor& W, bool igemm, int fmt = 0) {
+        std::string key = (igemm ? "convt_ig" + std::to_string(fmt) + ":" : std::string("convt_dir:")) + n.in[1];
         auto it = E.dev_consts_.find(key);
         if (it != E.dev_consts_.end()) return it->second;
         int64_t Ci = W.dims[0], Co = W.dims[1], kh = W.dims[2], kw = W.dims[3];
@@ -496,7 +539,7 @@ struct Planner {
                     for (int64_t a = 0; a < kh; ++a)
                         for (int64_t b = 0; b < kw; ++b)
                             w[(size_t)((a * kw + b) * Co + co) * Ci + ci] = W.f[((ci * Co + co) * kh + a) * kw + b];
-            w = to_fragment_order(w, rows, Ci);
+            w = to_fragments(fmt, w, rows, Ci);
         } else {
             w.assign((size_t)kh * kw * Ci * Co, 0.f);
             for (int64_t ci = 0; ci < Ci; ++ci)
@@ -507,15 +550,15 @@ struct Planner {
         }
         return E.upload_const(key, w);
     }
-    const float* linear_weight(const std::string& name, const HostTensor& B, bool transB) {  // -> [N_pad64][K]
-        std::string key = std::string("lin:") + (transB ? "t:" : "") + name;
+    const float* linear_weight(const std::string& name, const HostTensor& B, bool transB, int fmt) {
+        std::string key = "lin" + std::to_string(fmt) + ":" + (transB ? "t:" : "") + name;
         auto it = E.dev_consts_.find(key);
         if (it != E.dev_consts_.end()) return it->second;
         int64_t K = transB ? B.dims[1] : B.dims[0], N = transB ? B.dims[0] : B.dims[1];
         std::vector<float> w((size_t)N * K, 0.f);
         for (int64_t kk = 0; kk < K; ++kk)
             for (int64_t nn = 0; nn < N; ++nn) w[(size_t)nn * K + kk] = transB ? B.f[nn * K + kk] : B.f[kk * N + nn];
-        return E.upload_const(key, to_fragment_order(w, N, K));
+        return E.upload_const(key, to_fragments(fmt, w, N, K));
     }
 
     // ------------------------------------------------------------------ ops
@@ -558,7 +601,12 @@ struct Planner {
         p.kh = (int)kh; p.kw = (int)kw; p.sh = (int)sh; p.sw = (int)sw; p.pt = (int)pt; p.pl = (int)pl; p.dh = (int)dh; p.dw = (int)dw;
         p.groups = (int)g; p.act = n.act; p.bias = bias; p.y_ld = (int)Cout; p.convt2x2 = 0;
         int kind;  // 0 igemm, 1 dw, 2 direct
-        if (g == 1 && Cin % 4 == 0) { kind = 0; p.w = conv_weight_igemm(n, W); }
+        if (g == 1 && Cin % 4 == 0) {
+            kind = 0;
+            const bool is1x1 = kh == 1 && kw == 1 && sh == 1 && sw == 1 && pt == 0 && pl == 0;
+            p.w_fmt = k::igemm_weight_format((int)(kh * kw * Cin), (int)Cin, is1x1);
+            p.w = conv_weight_igemm(n, W, p.w_fmt);
+        }
         else if (g == Cin && g == Cout && Cout % 4 == 0) { kind = 1; p.w = conv_weight_dw(n, W); }
         else { kind = 2; p.w = conv_weight_direct(n, W); }
         Loc yl = y.loc;
@@ -597,7 +645,8 @@ struct Planner {
         p.N = (int)N; p.H = (int)H; p.W = (int)Wd; p.Cin = (int)Cin; p.Ho = (int)Ho; p.Wo = (int)Wo; p.Cout = (int)Cout;
         p.kh = (int)kh; p.kw = (int)kw; p.sh = (int)sh; p.sw = (int)sw; p.pt = (int)pt; p.pl = (int)pl; p.dh = (int)dh; p.dw = (int)dw;
         p.groups = 1; p.act = n.act; p.bias = bias; p.y_ld = (int)Cout; p.convt2x2 = fast ? 1 : 0;
-        p.w = convt_weight(n, W, fast);
+        p.w_fmt = fast ? k::igemm_weight_format((int)Cin, (int)Cin, true) : 0;
+        p.w = convt_weight(n, W, fast, p.w_fmt);
         Loc yl = y.loc;
         double flops = 2.0 * N * H * Wd * Cin * Cout * kh * kw;
         double bytes = 4.0 * (N * H * Wd * Cin + N * Ho * Wo * Cout + numel(W.dims));
@@ -1038,8 +1087,10 @@ struct Planner {
         Act act = n.act;
         double flops = 2.0 * M * N * K, bytes = 4.0 * (M * K + M * N * (has_res ? 2 : 1) + K * N);
         if (K % 4 == 0 && alpha == 1.0f) {
-            const float* w = linear_weight(n.in[1], *bt.ht, transB);
+            const int fmt = k::igemm_weight_format((int)K, (int)K, true);
+            const float* w = linear_weight(n.in[1], *bt.ht, transB, fmt);
             k::ConvP p{};
+            p.w_fmt = fmt;
             p.N = 1; p.H = 1; p.W = (int)M; p.Cin = (int)K; p.Ho = 1; p.Wo = (int)M; p.Cout = (int)N;
             p.kh = p.kw = p.sh = p.sw = p.dh = p.dw = 1; p.groups = 1; p.act = act; p.w = w; p.bias = bias; p.y_ld = (int)N;
             step([=](const RunCtx& c) { k::ConvP q = p; q.x = c.at(ain); q.y = c.mut(yl); q.residual = has_res ? c.at(res) : nullptr; k::conv_igemm(c.s, q); }, flops, bytes);

@@ -25,11 +25,17 @@ struct ConvP {
     float* y;
     int y_ld;               // channel stride of the output buffer (>= Cout); y points at channel offset already
     int convt2x2;           // igemm only: output scatter of a 2x2/stride-2 ConvTranspose (Cout is the real Cout)
+    int w_fmt;              // igemm only: weight fragment layout, one of IGEMM_W_* (chosen by igemm_weight_format)
 };
+enum : int { IGEMM_W_K16 = 0, IGEMM_W_X6 = 1, IGEMM_W_K32 = 2 };
 
-// Implicit-GEMM conv on f32 MFMA (v_mfma_f32_16x16x4_f32). groups == 1, Cin % 4 == 0.
-// w: [Cout_pad16][K], K = kh*kw*Cin ordered (kh, kw, ci); Cout_pad16 = round_up(gemm_cout, 16), zero rows.
+// Implicit-GEMM conv on the matrix cores. groups == 1, Cin % 4 == 0. Weight layouts (ConvP::w_fmt):
+//   K16: f32 fragments  Wf[cout/16][K/16][lane][4 f32]              -> v_mfma_f32_16x16x4_f32 (exact f32 FMA chain)
+//   K32: f32 fragments  Wk[cout/16][K/32][half][lane][4 f32]        -> same MFMA, whole 128-byte X lines per chunk
+//   X6 : bf16x6 fragments Wx[cout/16][K/32][3 planes][lane][8 bf16] -> v_mfma_f32_16x16x32_bf16 x 6 (f32-equivalent)
+// Rows are padded to 64 couts, K to the chunk size, with zeros.
 void conv_igemm(hipStream_t s, const ConvP& p);
+int igemm_weight_format(int K, int Cin, bool is1x1);
 // Depthwise conv. w: [kh][kw][C]. C % 4 == 0.
 void conv_dw(hipStream_t s, const ConvP& p);
 // Direct conv for everything else (small Cin, odd channels, grouped). w: [kh][kw][Cin/g][Cout].
