@@ -14,7 +14,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIBDIR = HERE / "lib"
 LIB = LIBDIR / "libOarMi355x.so"
-SOURCES = ["common.cc", "onnx_parse.cc", "engine.cc", "db_host.cc", "pipeline.cc", "c_api.cc", "kernels.hip", "prepost.hip"]
+SOURCES = ["common.cc", "onnx_parse.cc", "engine.cc", "db_host.cc", "pipeline.cc", "c_api.cc", "kernels.hip", "igemm.hip", "igemm_ws_1x1.hip", "igemm_ws_gen.hip", "prepost.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wno-unused-result", "-Wno-pass-failed"]
@@ -31,7 +31,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> Path:
     LIBDIR.mkdir(exist_ok=True)
     objdir = LIBDIR / "obj"
     objdir.mkdir(exist_ok=True)
-    headers = list(CSRC.glob("*.h")) + [HERE.parent / "include" / "oar_mi355x.h"]
+    headers = list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + [HERE.parent / "include" / "oar_mi355x.h"]
     jobs = []
     for s in SOURCES:
         src = CSRC / s

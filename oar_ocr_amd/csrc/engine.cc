@@ -471,19 +471,8 @@ struct Planner {
         std::memcpy(out.data(), f.data(), f.size() * 2);
         return out;
     }
-    // [rows][K] -> Wk[rows/16][K/32][half][lane][4]: lane = (row & 15) + 16 * g holds k = 32*kc + 8*g + 4*half + j
-    static std::vector<float> to_fragment_k32(const std::vector<float>& w, int64_t rows, int64_t K) {
-        int64_t Rp = (rows + 63) / 64 * 64, KC = (K + 31) / 32;
-        std::vector<float> f((size_t)Rp * KC * 32, 0.f);
-        for (int64_t r = 0; r < rows; ++r)
-            for (int64_t k = 0; k < K; ++k) {
-                int64_t nf = r / 16, c = r % 16, kc = k / 32, g = (k % 32) / 8, h = (k % 8) / 4, j = k % 4;
-                f[(size_t)((((nf * KC + kc) * 2 + h) * 64 + (c + 16 * g)) * 4 + j)] = w[(size_t)r * K + k];
-            }
-        return f;
-    }
     static std::vector<float> to_fragments(int fmt, const std::vector<float>& w, int64_t rows, int64_t K) {
-        return fmt == k::IGEMM_W_X6 ? to_fragment_x6(w, rows, K) : fmt == k::IGEMM_W_K32 ? to_fragment_k32(w, rows, K) : to_fragment_order(w, rows, K);
+        return fmt == k::IGEMM_W_X6 ? to_fragment_x6(w, rows, K) : to_fragment_order(w, rows, K);
     }
     const float* conv_weight_igemm(const GNode& n, const HostTensor& W, int fmt) {
         std::string key = "igemm" + std::to_string(fmt) + ":" + n.in[1];

@@ -1,0 +1,186 @@
+// igemm_dev.h -- shared pieces of the implicit-GEMM conv kernels (igemm.hip, igemm_ws_*.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
+#include "common.h"
+#include "kernels_dev.h"
+
+namespace oar {
+namespace k {
+
+// ------------------------------------------------------------------------------------------ implicit-GEMM conv
+// GEMM view: D[cout][pixel] = sum_k W[cout][k] * X[pixel][k];  k = (kh, kw, ci), ci innermost (NHWC).
+// MFMA 16x16x4 f32 operand map (cdna_hip_programming.md section 3): A[i = lane&15][k = lane>>4],
+// B[k = lane>>4][j = lane&15], D[row = (lane>>4)*4 + r][col = lane&15].  A = weights (rows = cout),
+// B = pixels (cols = pixel), so a lane ends with 4 CONSECUTIVE output channels of one pixel = one 16-byte
+// NHWC store.
+//
+// No LDS and no barriers: within a 16-deep K chunk lane (p = lane&15, g = lane>>4) loads ONE float4
+// X[pixel p][16*kc + 4g .. +3] straight from HBM (16 pixels x 64 contiguous bytes per wave instruction) and
+// feeds component j to MFMA step j, i.e. step j contracts k = {j, 4+j, 8+j, 12+j}.  The weights are stored
+// host-side in the matching fragment order Wf[cout/16][kc][lane][4] so the A operand is one coalesced float4
+// per lane (1 KiB per wave instruction, identical for every wave => L1/L2 resident).  The K permutation is the
+// same on both operands, so the contraction is exact.
+// Workgroup = 4 independent waves; a wave owns PF*16 pixels x NT*16 couts (accumulators NT*PF*4 VGPRs).
+struct IgemmP {
+    const float* x;
+    const float* w;      // fragment order, see above; KC = ceil(K/16) chunks, rows padded to 64 couts
+    const float* bias;
+    const float* res;
+    float* y;
+    long M;              // GEMM columns: N*Ho*Wo pixels (convT: input pixels)
+    int K, KC;
+    int gemm_cout;       // GEMM rows (Cout, or 4*Cout for convT 2x2)
+    int Cout;            // channel count of y
+    int H, W, Cin, Ho, Wo, kh, kw, sh, sw, pt, pl, dh, dw;
+    int y_ld;
+    int act, convt;
+    int ny;              // number of cout tiles (for the XCD-aware tile order)
+    unsigned cin_magic, kw_magic;   // floor(2^32 / d) + 1: q = umulhi(n, magic) == n / d for n < 2^16
+    long mx_per_xcd;     // pixel tiles per XCD band
+    float alpha, beta;
+};
+
+__device__ __forceinline__ void igemm_store(const IgemmP& p, f32x4 v, bool valid, long obase, int c, bool vec_ok, bool add_bias = true) {
+    if (!valid || c >= p.gemm_cout) return;
+    float o[4] = {v[0], v[1], v[2], v[3]};
+    if (vec_ok) {
+        int co = c; long opix = obase;
+        if (p.convt) { int ab = c / p.Cout; co = c - ab * p.Cout; opix = obase + (long)(ab >> 1) * (2L * p.Wo) + (ab & 1); }
+        if (p.bias && add_bias) { float4 bv = *reinterpret_cast<const float4*>(p.bias + co); o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w; }
+        float* dst = p.y + opix * p.y_ld + co;
+        if (p.res) { float4 rv = *reinterpret_cast<const float4*>(p.res + opix * p.y_ld + co); o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = apply_act(o[r], p.act, p.alpha, p.beta);
+        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int cc = c + r;
+            if (cc >= p.gemm_cout) continue;
+            int co = cc; long opix = obase;
+            if (p.convt) { int ab = cc / p.Cout; co = cc - ab * p.Cout; opix = obase + (long)(ab >> 1) * (2L * p.Wo) + (ab & 1); }
+            float t = o[r];
+            if (p.bias && add_bias) t += p.bias[co];
+            if (p.res) t += p.res[opix * p.y_ld + co];
+            p.y[opix * p.y_ld + co] = apply_act(t, p.act, p.alpha, p.beta);
+        }
+    }
+}
+
+// Epilogue of one wave tile: bias + residual + activation + NHWC stores.  Every load (bias, residual) is issued
+// BEFORE the first store: with a load between two stores the compiler waits vmcnt(0) for it, which also waits for the
+// previous store to be acknowledged -- NT serialised store round trips per tile (measured: as long as the whole K
+// loop).  unroll(full) everywhere: the accumulators must stay in registers.
+template <int NT, int PF, bool VEC_ONLY = false>
+__device__ __forceinline__ void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[NT][PF], long m0, int pl_, int g, int nf0, bool add_bias) {
+    const bool vec_ok = ((p.Cout & 3) == 0) && ((p.y_ld & 3) == 0);
+    long obase[PF];
+    bool mvalid[PF];
+#pragma clang loop unroll(full)
+    for (int pf = 0; pf < PF; ++pf) {
+        const long m = m0 + pf * 16 + pl_;
+        mvalid[pf] = m < p.M;
+        const long mc = mvalid[pf] ? m : p.M - 1;
+        obase[pf] = mc;
+        if (p.convt) {
+            long hw = (long)p.Ho * p.Wo;  // here Ho/Wo are the INPUT spatial dims of the convT
+            long n = mc / hw; long r = mc - n * hw;
+            int h = (int)(r / p.Wo), w = (int)(r - (long)h * p.Wo);
+            obase[pf] = (n * (2L * p.Ho) + 2L * h) * (2L * p.Wo) + 2L * w;  // pixel index of (2h, 2w)
+        }
+    }
+    if (!VEC_ONLY && !vec_ok) {
+#pragma clang loop unroll(full)
+        for (int pf = 0; pf < PF; ++pf)
+#pragma clang loop unroll(full)
+            for (int nf = 0; nf < NT; ++nf) igemm_store(p, acc[nf][pf], mvalid[pf], obase[pf], (nf0 + nf) * 16 + g * 4, false, add_bias);
+        return;
+    }
+    // this lane's element offset for (nf, pf): recomputed where it is needed instead of kept in NT*PF 64-bit registers
+    auto coff = [&](int nf, int pf, bool& cvalid, int& co) -> long {
+        const int c = (nf0 + nf) * 16 + g * 4;
+        cvalid = c < p.gemm_cout;
+        const int cc = cvalid ? c : 0;
+        co = cc; long dpix = 0;
+        if (p.convt) { int ab = cc / p.Cout; co = cc - ab * p.Cout; dpix = (long)(ab >> 1) * (2L * p.Wo) + (ab & 1); }
+        return (obase[pf] + dpix) * p.y_ld + co;
+    };
+    if (p.bias && add_bias) {
+        float4 bv[NT];
+#pragma clang loop unroll(full)
+        for (int nf = 0; nf < NT; ++nf) { bool cv; int co; (void)coff(nf, 0, cv, co); bv[nf] = *reinterpret_cast<const float4*>(p.bias + co); }
+#pragma clang loop unroll(full)
+        for (int nf = 0; nf < NT; ++nf)
+#pragma clang loop unroll(full)
+            for (int pf = 0; pf < PF; ++pf) { acc[nf][pf][0] += bv[nf].x; acc[nf][pf][1] += bv[nf].y; acc[nf][pf][2] += bv[nf].z; acc[nf][pf][3] += bv[nf].w; }
+    }
+    if (p.res) {
+        float4 rv[NT][PF];
+#pragma clang loop unroll(full)
+        for (int nf = 0; nf < NT; ++nf)
+#pragma clang loop unroll(full)
+            for (int pf = 0; pf < PF; ++pf) { bool cv; int co; rv[nf][pf] = *reinterpret_cast<const float4*>(p.res + coff(nf, pf, cv, co)); }
+#pragma clang loop unroll(full)
+        for (int nf = 0; nf < NT; ++nf)
+#pragma clang loop unroll(full)
+            for (int pf = 0; pf < PF; ++pf) { acc[nf][pf][0] += rv[nf][pf].x; acc[nf][pf][1] += rv[nf][pf].y; acc[nf][pf][2] += rv[nf][pf].z; acc[nf][pf][3] += rv[nf][pf].w; }
+    }
+    // one (uniform) switch around the whole tile instead of one per element
+    auto act_all = [&](auto f) {
+#pragma clang loop unroll(full)
+        for (int nf = 0; nf < NT; ++nf)
+#pragma clang loop unroll(full)
+            for (int pf = 0; pf < PF; ++pf)
+#pragma clang loop unroll(full)
+                for (int r = 0; r < 4; ++r) acc[nf][pf][r] = f(acc[nf][pf][r]);
+    };
+    switch (p.act) {
+        case ACT_NONE: break;
+        case ACT_RELU: act_all([](float v) { return v > 0.f ? v : 0.f; }); break;
+        case ACT_HSWISH: act_all([](float v) { float t = fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.f), 1.f); return v * t; }); break;
+        default: { const int kind = p.act; const float al = p.alpha, be = p.beta; act_all([=](float v) { return apply_act(v, kind, al, be); }); } break;
+    }
+#pragma clang loop unroll(full)
+    for (int nf = 0; nf < NT; ++nf)
+#pragma clang loop unroll(full)
+        for (int pf = 0; pf < PF; ++pf) {
+            bool cv; int co;
+            const long o = coff(nf, pf, cv, co);
+            if (mvalid[pf] && cv) *reinterpret_cast<float4*>(p.y + o) = make_float4(acc[nf][pf][0], acc[nf][pf][1], acc[nf][pf][2], acc[nf][pf][3]);
+        }
+}
+
+// Accumulators start from the bias (row g*4+r of fragment nf = channel (nf0+nf)*16 + g*4 + r, i.e. exactly this lane's
+// float4 of the bias vector), so the epilogue has no load in front of its stores.  Returns false (and zeroes) when the
+// channel count does not allow the float4 path; the epilogue then adds the bias itself.
+template <int NT, int PF>
+__device__ __forceinline__ bool igemm_init_acc(const IgemmP& p, f32x4 (&acc)[NT][PF], int g, int nf0) {
+    const bool fast = p.bias != nullptr && ((p.Cout & 3) == 0) && ((p.y_ld & 3) == 0);
+#pragma clang loop unroll(full)
+    for (int nf = 0; nf < NT; ++nf) {
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (fast) {
+            const int c = (nf0 + nf) * 16 + g * 4;
+            const int cc = c < p.gemm_cout ? c : 0;
+            const int co = p.convt ? cc % p.Cout : cc;
+            b = *reinterpret_cast<const float4*>(p.bias + co);
+        }
+#pragma clang loop unroll(full)
+        for (int pf = 0; pf < PF; ++pf) acc[nf][pf] = (f32x4){b.x, b.y, b.z, b.w};
+    }
+    return fast;
+}
+
+// weight-stationary variant (igemm_ws.inc, instantiated in igemm_ws_1x1.hip / igemm_ws_gen.hip)
+void conv_igemm_ws_1x1(hipStream_t s, const IgemmP& p, int ws_nt, int ny, size_t lds);
+void conv_igemm_ws_gen(hipStream_t s, const IgemmP& p, int ws_nt, int ny, size_t lds);
+
+}  // namespace k
+}  // namespace oar

@@ -27,11 +27,10 @@ struct ConvP {
     int convt2x2;           // igemm only: output scatter of a 2x2/stride-2 ConvTranspose (Cout is the real Cout)
     int w_fmt;              // igemm only: weight fragment layout, one of IGEMM_W_* (chosen by igemm_weight_format)
 };
-enum : int { IGEMM_W_K16 = 0, IGEMM_W_X6 = 1, IGEMM_W_K32 = 2 };
+enum : int { IGEMM_W_K16 = 0, IGEMM_W_X6 = 1 };
 
 // Implicit-GEMM conv on the matrix cores. groups == 1, Cin % 4 == 0. Weight layouts (ConvP::w_fmt):
 //   K16: f32 fragments  Wf[cout/16][K/16][lane][4 f32]              -> v_mfma_f32_16x16x4_f32 (exact f32 FMA chain)
-//   K32: f32 fragments  Wk[cout/16][K/32][half][lane][4 f32]        -> same MFMA, whole 128-byte X lines per chunk
 //   X6 : bf16x6 fragments Wx[cout/16][K/32][3 planes][lane][8 bf16] -> v_mfma_f32_16x16x32_bf16 x 6 (f32-equivalent)
 // Rows are padded to 64 couts, K to the chunk size, with zeros.
 void conv_igemm(hipStream_t s, const ConvP& p);

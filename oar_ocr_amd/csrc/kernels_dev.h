@@ -1,0 +1,33 @@
+// kernels_dev.h -- device helpers shared by the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace oar {
+namespace k {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------ activations
+__device__ __forceinline__ float apply_act(float v, int kind, float alpha, float beta) {
+    switch (kind) {
+        case ACT_NONE: return v;
+        case ACT_RELU: return v > 0.f ? v : 0.f;
+        case ACT_HSWISH: {
+            float t = fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.f), 1.f);
+            return v * t;
+        }
+        case ACT_HSIGMOID: return fminf(fmaxf(v * alpha + beta, 0.f), 1.f);
+        case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+        case ACT_SWISH: return v * (1.0f / (1.0f + expf(-v)));
+        case ACT_LEAKY: return v > 0.f ? v : v * alpha;
+        case ACT_CLIP: return fminf(fmaxf(v, alpha), beta);
+        case ACT_TANH: return tanhf(v);
+        case ACT_GELU_ERF: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        default: return v;
+    }
+}
+
+}  // namespace k
+}  // namespace oar

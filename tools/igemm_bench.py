@@ -14,6 +14,10 @@ def conv_graph(cin, cout, k=1):
     return g.model()
 
 shapes = [(256, 192, 192, 12, 80, 1), (256, 256, 256, 6, 80, 1), (256, 48, 48, 24, 160, 1), (256, 96, 96, 12, 160, 1), (8, 64, 16, 240, 240, 3)]
+if os.environ.get("SWEEP_K"):
+    shapes = [(256, k, 192, 12, 80, 1) for k in (64, 128, 192, 256, 384, 512, 768)]
+if os.environ.get("SWEEP_N"):
+    shapes = [(256, 192, n, 12, 80, 1) for n in (64, 128, 192, 256, 384, 512)]
 api.prof_enable(True)
 for (n, cin, cout, h, w, k) in shapes:
     eng = api.OrtInfer(conv_graph(cin, cout, k))
