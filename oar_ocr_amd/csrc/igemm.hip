@@ -326,7 +326,11 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     static const int ws_min_n = [] { const char* e = getenv("OAR_IGEMM_WS_MIN_N"); return e ? atoi(e) : 96; }();
     int ws_nt = 0;
     const bool vec_ok = ((p.Cout & 3) == 0) && ((p.y_ld & 3) == 0);
-    if (!x6 && vec_ok && p.KC >= 2 && ws_mode != 0 && (ws_mode == 1 || p.gemm_cout >= ws_min_n)) {
+    // auto rule (per-shape A/B on the bench graphs, profiles/r1): the persistent kernel needs enough wave tiles to fill its
+    // 4096 resident waves and pays for staging W once per workgroup, so it wins on wide layers with many pixels and
+    // on the long-K 3x3 convs; small-M / tiny-K layers stay on the per-tile kernel
+    const bool ws_auto = (p.gemm_cout >= ws_min_n && p.M >= 65536) || (p.K >= 512 && p.M >= 262144);
+    if (!x6 && vec_ok && p.KC >= 2 && ws_mode != 0 && (ws_mode == 1 || ws_auto)) {
         static const int max_nt = [] { const char* e = getenv("OAR_IGEMM_WS_MAXNT"); return e ? atoi(e) : 8; }();
         const int cand[6] = {8, 6, 4, 3, 2, 1};
         int best = 1 << 30;
