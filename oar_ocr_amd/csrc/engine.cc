@@ -1048,6 +1048,15 @@ struct Planner {
         alias_out(n.out[0], s, od, Layout::NATIVE);
     }
 
+    // true when `name` is consumed by nothing but the Softmax that produces graph output 0
+    bool feeds_final_softmax(const std::string& name) {
+        int users = 0; bool ok = false;
+        for (const GNode& m : E.nodes_)
+            for (const std::string& in : m.in)
+                if (in == name) { ++users; ok = m.op == "Softmax" && !m.out.empty() && m.out[0] == E.output_names_[0]; }
+        for (const std::string& on : E.output_names_) if (on == name) return false;
+        return users == 1 && ok;
+    }
     void op_linear(const GNode& n, bool gemm) {
         TInfo a = get(n.in[0]);
         const TInfo& bt = get(n.in[1]);
@@ -1071,6 +1080,26 @@ struct Planner {
         Loc res;
         if (!n.residual.empty()) { TInfo r = get(n.residual); OAR_CHECK(numel(r.dims) == M * N, OAR_SHAPE_MISMATCH, "Linear: residual shape"); res = to_native_loc(r); }
         bool has_res = res.kind != Loc::NONE;
+        // Logits that only feed the fused softmax+argmax tail are produced with their row padded to a multiple of 16
+        // channels (zero weight rows, zero bias): every store is a full float4 and the wide layer qualifies for the
+        // weight-stationary kernel; the tail reads the first N columns of each row (Plan::logits_valid).
+        int64_t Np = N;
+        if (skip_final_softmax && !has_res && K % 4 == 0 && alpha == 1.0f && (N & 15) != 0 && feeds_final_softmax(n.out[0])) {
+            Np = (N + 15) / 16 * 16;
+            od.back() = Np;
+            P.logits_valid = (int)N;
+            if (bias) {
+                std::string key = "biaspad:" + n.out[0];
+                auto it = E.dev_consts_.find(key);
+                if (it == E.dev_consts_.end()) {
+                    const HostTensor* hb = !n.bias.empty() ? get(n.bias).ht : get(n.in[2]).ht;
+                    OAR_CHECK(hb, OAR_INTERNAL, "Linear: bias initializer missing");
+                    std::vector<float> bp((size_t)Np, 0.f);
+                    for (int64_t i = 0; i < N; ++i) bp[(size_t)i] = hb->f[(size_t)i];
+                    bias = E.upload_const(key, bp);
+                } else bias = it->second;
+            }
+        }
         TInfo& y = new_out(n.out[0], od, Layout::NATIVE);
         Loc yl = y.loc;
         Act act = n.act;
@@ -1080,6 +1109,7 @@ struct Planner {
             const float* w = linear_weight(n.in[1], *bt.ht, transB, fmt);
             k::ConvP p{};
             p.w_fmt = fmt;
+            N = Np;
             p.N = 1; p.H = 1; p.W = (int)M; p.Cin = (int)K; p.Ho = 1; p.Wo = (int)M; p.Cout = (int)N;
             p.kh = p.kw = p.sh = p.sw = p.dh = p.dw = 1; p.groups = 1; p.act = act; p.w = w; p.bias = bias; p.y_ld = (int)N;
             step([=](const RunCtx& c) { k::ConvP q = p; q.x = c.at(ain); q.y = c.mut(yl); q.residual = has_res ? c.at(res) : nullptr; k::conv_igemm(c.s, q); }, flops, bytes);

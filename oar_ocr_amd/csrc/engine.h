@@ -69,6 +69,7 @@ struct Plan {
     double flops = 0, bytes = 0;
     int n_kernels = 0;
     bool skipped_softmax = false;
+    int logits_valid = 0;   // > 0: output[0]'s rows are padded; only the first logits_valid columns are logits
 };
 
 class Engine {

@@ -329,7 +329,8 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     // auto rule (per-shape A/B on the bench graphs, profiles/r1): the persistent kernel needs enough wave tiles to fill its
     // 4096 resident waves and pays for staging W once per workgroup, so it wins on wide layers with many pixels and
     // on the long-K 3x3 convs; small-M / tiny-K layers stay on the per-tile kernel
-    const bool ws_auto = (p.gemm_cout >= ws_min_n && p.M >= 65536) || (p.K >= 512 && p.M >= 262144);
+    const long wave_tile_passes = ((p.M + 15) / 16) * ((nfrag + 7) / 8);   // (16-pixel tile, 128-cout tile) pairs
+    const bool ws_auto = (p.gemm_cout >= ws_min_n && wave_tile_passes >= 4096) || (p.K >= 512 && p.M >= 262144);
     if (!x6 && vec_ok && p.KC >= 2 && ws_mode != 0 && (ws_mode == 1 || ws_auto)) {
         static const int max_nt = [] { const char* e = getenv("OAR_IGEMM_WS_MAXNT"); return e ? atoi(e) : 8; }();
         const int cand[6] = {8, 6, 4, 3, 2, 1};

@@ -81,7 +81,7 @@ void gemm_batched(hipStream_t s, const GemmP& p);
 void layernorm(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C, float eps);
 void softmax_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C);
 // softmax over the last dim fused with CTC argmax (last max index wins) -- see kernels.hip
-void softmax_argmax(hipStream_t s, const float* logits, int64_t rows, int C, int64_t* idx, float* prob);
+void softmax_argmax(hipStream_t s, const float* logits, int64_t rows, int C, int ld, int64_t* idx, float* prob);   // ld = row stride
 
 }  // namespace k
 }  // namespace oar

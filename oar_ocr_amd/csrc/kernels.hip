@@ -711,13 +711,13 @@ __global__ __launch_bounds__(256) void softmax_block_kernel(const float* x, floa
 // probability, without writing the [rows, C] probability tensor.  Bit-identical to softmax_block_kernel followed by
 // pp::ctc_argmax_kernel: same expf, same partial-sum tree; p_max = expf(0)/s = 1/s and the tie set
 // {i : p_i == p_max} is exactly {i : expf(x_i - m) == 1.0f} (division by the same s is monotone).
-__global__ __launch_bounds__(256) void softmax_argmax_kernel(const float* x, int C, int64_t* idx, float* prob) {
+__global__ __launch_bounds__(256) void softmax_argmax_kernel(const float* x, int C, int ld, int64_t* idx, float* prob) {
     extern __shared__ float rowbuf[];
     __shared__ float red[4];
     __shared__ int redi[4];
     __shared__ float bcast;
     const long row = blockIdx.x;
-    const float* xr = x + row * C;
+    const float* xr = x + row * ld;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float m = -3.402823466e38f;
     for (int i = tid; i < C; i += 256) { float v = xr[i]; rowbuf[i] = v; m = fmaxf(m, v); }
@@ -743,11 +743,11 @@ __global__ __launch_bounds__(256) void softmax_argmax_kernel(const float* x, int
         prob[row] = 1.0f / tot;
     }
 }
-void softmax_argmax(hipStream_t s, const float* logits, int64_t rows, int C, int64_t* idx, float* prob) {
+void softmax_argmax(hipStream_t s, const float* logits, int64_t rows, int C, int ld, int64_t* idx, float* prob) {
     if (rows == 0 || C == 0) return;
     OAR_CHECK((size_t)C * 4 <= 150 * 1024, OAR_UNSUPPORTED_OP, "softmax_argmax: row longer than the LDS staging buffer");
     ProfScope ps(s, "softmax_argmax", 4.0 * (double)rows * C, 4.0 * (double)rows * C);
-    hipLaunchKernelGGL(softmax_argmax_kernel, dim3((unsigned)rows), dim3(256), (size_t)C * sizeof(float), s, logits, C, idx, prob);
+    hipLaunchKernelGGL(softmax_argmax_kernel, dim3((unsigned)rows), dim3(256), (size_t)C * sizeof(float), s, logits, C, ld, idx, prob);
 }
 
 void softmax_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C) {

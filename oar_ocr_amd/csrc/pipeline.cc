@@ -578,8 +578,8 @@ void Recognizer::run_batches(const std::vector<std::vector<Crop>>& batches, std:
         if (pend[bi].rows == 0) continue;
         const PlanOutput& po = plan.outputs[0];
         if (plan.skipped_softmax)   // output[0] holds logits: softmax + argmax in one pass, probabilities never hit HBM
-            k::softmax_argmax(s, eng_->out_ptr(po.loc), (int64_t)pend[bi].rows, (int)po.dims[2], idx_dev_.as<int64_t>() + pend[bi].row0,
-                              prob_dev_.as<float>() + pend[bi].row0);
+            k::softmax_argmax(s, eng_->out_ptr(po.loc), (int64_t)pend[bi].rows, plan.logits_valid > 0 ? plan.logits_valid : (int)po.dims[2], (int)po.dims[2],
+                              idx_dev_.as<int64_t>() + pend[bi].row0, prob_dev_.as<float>() + pend[bi].row0);
         else
             pp::ctc_argmax(s, eng_->out_ptr(po.loc), (int64_t)pend[bi].rows, (int)po.dims[2], idx_dev_.as<int64_t>() + pend[bi].row0,
                            prob_dev_.as<float>() + pend[bi].row0);

@@ -99,9 +99,10 @@ def test_pool_flush_and_batch_policy(nets):
         assert all(np.array_equal(p.bounding_box, q.bounding_box) for p, q in zip(x.text_regions, y.text_regions))
 
 
-def test_fused_ctc_tail_is_bit_identical_to_unfused(nets):
-    """Seam B fuses softmax+argmax (probabilities never written to HBM); Seam A + the stand-alone argmax kernel on the
-    same input must give the same indices and the same probability bits."""
+def test_fused_ctc_tail_matches_unfused(nets):
+    """Seam B fuses softmax+argmax (probabilities never written to HBM) and produces the logits with padded rows through
+    the float4 / weight-stationary path (bias enters the accumulation first); Seam A + the stand-alone argmax kernel on
+    the same input must give the same indices, and probabilities equal up to that re-association (a few ulp)."""
     _, rec, chars = nets
     crops = [pages.make_crop(40 + i, w, h) for i, (w, h) in enumerate([(320, 48), (260, 40), (500, 44), (150, 30)])]
     got = api.TextRecognitionPredictor(rec, chars).predict(crops)
@@ -109,4 +110,4 @@ def test_fused_ctc_tail_is_bit_identical_to_unfused(nets):
     (name, probs), = api.OrtInfer(rec).infer(x)
     idx, pr = api.k_ctc_argmax(probs)
     assert np.array_equal(got.indices.reshape(-1), idx)
-    assert np.array_equal(got.probs.reshape(-1), pr)
+    np.testing.assert_allclose(got.probs.reshape(-1), pr, rtol=2e-6, atol=0)
