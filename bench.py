@@ -114,7 +114,18 @@ def main():
                 ach, peak, unit, bound = e["alg_flops"] / sec / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s", "mfma"
             else:
                 ach, peak, unit, bound = e["alg_bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
-            roof = {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": None,
+            # HBM bytes per launch of this kernel class from the committed PMC passes (rocprofv3 cannot run inside the timed
+            # region; tools/make_profile_summaries.py writes the file from separate --pmc FETCH_SIZE / WRITE_SIZE passes)
+            traffic, traffic_src = None, None
+            for tf in sorted(ROOT.glob("profiles/r*/pmc_traffic.json"), reverse=True):
+                try:
+                    t = json.loads(tf.read_text()).get(dominant)
+                    if t:
+                        traffic, traffic_src = t["hbm_bytes_per_launch"], str(tf.relative_to(ROOT))
+                        break
+                except Exception:
+                    pass
+            roof = {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel": dominant, "launches_per_step": e["launches"] / args.steps, "avg_launch_us": round(e["total_ms"] * 1e3 / e["launches"], 2),
                     "alg_bytes_per_launch": e["alg_bytes"] / e["launches"], "alg_flops_per_launch": e["alg_flops"] / e["launches"],
                     "share_of_step": round(e["total_ms"] / (dt * 1e3), 4)}
