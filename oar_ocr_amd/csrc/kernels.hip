@@ -24,13 +24,21 @@ namespace k {
 // the window is loaded once ((TW-1)*S + K float4s) and reused by all TW outputs, cutting the load count per output
 // from K*K to K*((TW-1)*S+K)/TW.  Lanes run along channels first, so a wave reads/writes whole 16-byte-per-lane
 // contiguous NHWC segments.  Weights [kh][kw][C].
-template <int K, int SH, int S, int TW>
+template <int K, int SH, int S, int TW, int TH>
 __global__ __launch_bounds__(256) void conv_dw_tiled_kernel(ConvP p) {
+    // One thread = 4 channels x TH output rows x TW output columns.  Every input row of the (TH-1)*SH+K row window is
+    // loaded once ((TW-1)*S+K float4s) and feeds every output row it overlaps; the K*K*C weights sit in LDS (their own
+    // 128 B/clk pipe), so per output float4 the vector-memory path carries ((TH-1)*SH+K)*((TW-1)*S+K)/(TH*TW) loads
+    // (6 for 5x5 s1) instead of the 16.25 of a one-row tile with weights from L1 -- the one-row version ran at ~60 %
+    // of the L1 peak (the practical ceiling measured on the igemm kernels) and 2.5 TB/s of HBM traffic.
+    extern __shared__ float4 dw_w[];   // [K*K][C4]
     const int C4 = p.Cout >> 2;
-    const int wtiles = (p.Wo + TW - 1) / TW;
-    const long total = (long)p.N * p.Ho * wtiles * C4;
-    constexpr int NCOL = (TW - 1) * S + K;
-    // each XCD (workgroup id % 8) walks one contiguous band of output rows => the K-row halo re-reads stay in its L2
+    for (int i = threadIdx.x; i < K * K * C4; i += blockDim.x) dw_w[i] = reinterpret_cast<const float4*>(p.w)[i];
+    __syncthreads();
+    const int wtiles = (p.Wo + TW - 1) / TW, htiles = (p.Ho + TH - 1) / TH;
+    const long total = (long)p.N * htiles * wtiles * C4;
+    constexpr int NCOL = (TW - 1) * S + K, NROW = (TH - 1) * SH + K;
+    // each XCD (workgroup id % 8) walks one contiguous band of output rows => the row-halo re-reads stay in its L2
     const long per_xcd = (total + 7) / 8;
     const int xcd = blockIdx.x & 7;
     const long lb = blockIdx.x >> 3, nlb = (gridDim.x + 7) >> 3;
@@ -38,17 +46,19 @@ __global__ __launch_bounds__(256) void conv_dw_tiled_kernel(ConvP p) {
     for (long i = (long)xcd * per_xcd + lb * blockDim.x + threadIdx.x; i < band_end; i += nlb * blockDim.x) {
         int c4 = (int)(i % C4); long t = i / C4;
         int wt = (int)(t % wtiles); t /= wtiles;
-        int oh = (int)(t % p.Ho); long n = t / p.Ho;
-        const int c = c4 * 4, ow0 = wt * TW;
+        int ht = (int)(t % htiles); long n = t / htiles;
+        const int c = c4 * 4, ow0 = wt * TW, oh0 = ht * TH;
         float4 bias = p.bias ? *reinterpret_cast<const float4*>(p.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 acc[TW];
+        float4 acc[TH][TW];
 #pragma unroll
-        for (int q = 0; q < TW; ++q) acc[q] = bias;
+        for (int r = 0; r < TH; ++r)
+#pragma unroll
+            for (int q = 0; q < TW; ++q) acc[r][q] = bias;
         const float* xb = p.x + n * (long)p.H * p.W * p.Cin + c;
-        const int iw0 = ow0 * S - p.pl;
+        const int iw0 = ow0 * S - p.pl, ih0 = oh0 * SH - p.pt;
 #pragma unroll
-        for (int a = 0; a < K; ++a) {
-            const int ih = oh * SH - p.pt + a;
+        for (int r = 0; r < NROW; ++r) {
+            const int ih = ih0 + r;
             if (ih < 0 || ih >= p.H) continue;
             const float* xr = xb + (long)ih * p.W * p.Cin;
             float4 col[NCOL];
@@ -58,26 +68,35 @@ __global__ __launch_bounds__(256) void conv_dw_tiled_kernel(ConvP p) {
                 col[q] = (iw >= 0 && iw < p.W) ? *reinterpret_cast<const float4*>(xr + (long)iw * p.Cin) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (int b = 0; b < K; ++b) {
-                float4 wv = *reinterpret_cast<const float4*>(p.w + (long)(a * K + b) * p.Cout + c);
+            for (int tr = 0; tr < TH; ++tr) {
+                const int a = r - tr * SH;       // kernel row of this input row for output row tr (compile-time)
+                if (a < 0 || a >= K) continue;
 #pragma unroll
-                for (int q = 0; q < TW; ++q) {
-                    float4 xv = col[q * S + b];
-                    acc[q].x = fmaf(xv.x, wv.x, acc[q].x); acc[q].y = fmaf(xv.y, wv.y, acc[q].y);
-                    acc[q].z = fmaf(xv.z, wv.z, acc[q].z); acc[q].w = fmaf(xv.w, wv.w, acc[q].w);
+                for (int b = 0; b < K; ++b) {
+                    const float4 wv = dw_w[(a * K + b) * C4 + c4];
+#pragma unroll
+                    for (int q = 0; q < TW; ++q) {
+                        float4 xv = col[q * S + b];
+                        acc[tr][q].x = fmaf(xv.x, wv.x, acc[tr][q].x); acc[tr][q].y = fmaf(xv.y, wv.y, acc[tr][q].y);
+                        acc[tr][q].z = fmaf(xv.z, wv.z, acc[tr][q].z); acc[tr][q].w = fmaf(xv.w, wv.w, acc[tr][q].w);
+                    }
                 }
             }
         }
-        const long pix0 = (n * p.Ho + oh) * (long)p.Wo + ow0;
 #pragma unroll
-        for (int q = 0; q < TW; ++q) {
-            if (ow0 + q >= p.Wo) break;
-            long o = (pix0 + q) * p.y_ld + c;
-            float4 v = acc[q];
-            if (p.residual) { float4 r = *reinterpret_cast<const float4*>(p.residual + o); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-            v.x = apply_act(v.x, p.act.kind, p.act.alpha, p.act.beta); v.y = apply_act(v.y, p.act.kind, p.act.alpha, p.act.beta);
-            v.z = apply_act(v.z, p.act.kind, p.act.alpha, p.act.beta); v.w = apply_act(v.w, p.act.kind, p.act.alpha, p.act.beta);
-            *reinterpret_cast<float4*>(p.y + o) = v;
+        for (int tr = 0; tr < TH; ++tr) {
+            if (oh0 + tr >= p.Ho) break;
+            const long pix0 = (n * p.Ho + oh0 + tr) * (long)p.Wo + ow0;
+#pragma unroll
+            for (int q = 0; q < TW; ++q) {
+                if (ow0 + q >= p.Wo) break;
+                long o = (pix0 + q) * p.y_ld + c;
+                float4 v = acc[tr][q];
+                if (p.residual) { float4 rr = *reinterpret_cast<const float4*>(p.residual + o); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+                v.x = apply_act(v.x, p.act.kind, p.act.alpha, p.act.beta); v.y = apply_act(v.y, p.act.kind, p.act.alpha, p.act.beta);
+                v.z = apply_act(v.z, p.act.kind, p.act.alpha, p.act.beta); v.w = apply_act(v.w, p.act.kind, p.act.alpha, p.act.beta);
+                *reinterpret_cast<float4*>(p.y + o) = v;
+            }
         }
     }
 }
@@ -133,18 +152,31 @@ void conv_dw(hipStream_t s, const ConvP& p) {
     ProfScope ps(s, cls, bytes, flops);
     const bool sq = p.kh == p.kw && p.dh == 1 && p.dw == 1;
     constexpr int TW = 4;
-    long tiled = (long)p.N * p.Ho * ((p.Wo + TW - 1) / TW) * (p.Cout / 4);
+    // output rows per thread: the tallest tile that still leaves >= 4 resident workgroups' worth of threads per CU
+    auto threads_for = [&](int th) { return (long)p.N * ((p.Ho + th - 1) / th) * ((p.Wo + TW - 1) / TW) * (p.Cout / 4); };
+    const long want = 256L * 256 * 4;
+    int TH = 1;
+    if (threads_for(2) >= want) TH = 2;   // (4 rows per thread measured slower on the 5x5 layers: 134 vs 112 us)
+    long tiled = threads_for(TH);
     dim3 g((grid_for(tiled) + 7) / 8 * 8), b(256);
-#define DW(KV, SHV, SWV) hipLaunchKernelGGL((conv_dw_tiled_kernel<KV, SHV, SWV, TW>), g, b, 0, s, p)
-    if (sq && p.kh == 3 && p.sh == 1 && p.sw == 1) DW(3, 1, 1);
-    else if (sq && p.kh == 3 && p.sh == 2 && p.sw == 2) DW(3, 2, 2);
-    else if (sq && p.kh == 3 && p.sh == 2 && p.sw == 1) DW(3, 2, 1);
-    else if (sq && p.kh == 3 && p.sh == 1 && p.sw == 2) DW(3, 1, 2);
-    else if (sq && p.kh == 5 && p.sh == 1 && p.sw == 1) DW(5, 1, 1);
-    else if (sq && p.kh == 5 && p.sh == 2 && p.sw == 2) DW(5, 2, 2);
-    else if (sq && p.kh == 5 && p.sh == 2 && p.sw == 1) DW(5, 2, 1);
-    else if (sq && p.kh == 5 && p.sh == 1 && p.sw == 2) DW(5, 1, 2);
+    const size_t lds = (size_t)p.kh * p.kw * p.Cout * sizeof(float);
+    const bool fits = lds <= 64 * 1024;
+#define DW2(KV, SHV, SWV, THV) hipLaunchKernelGGL((conv_dw_tiled_kernel<KV, SHV, SWV, TW, THV>), g, b, lds, s, p)
+#define DW(KV, SHV, SWV)                                   \
+    do {                                                   \
+        if (TH == 2) DW2(KV, SHV, SWV, 2);                 \
+        else DW2(KV, SHV, SWV, 1);                         \
+    } while (0)
+    if (fits && sq && p.kh == 3 && p.sh == 1 && p.sw == 1) DW(3, 1, 1);
+    else if (fits && sq && p.kh == 3 && p.sh == 2 && p.sw == 2) DW(3, 2, 2);
+    else if (fits && sq && p.kh == 3 && p.sh == 2 && p.sw == 1) DW(3, 2, 1);
+    else if (fits && sq && p.kh == 3 && p.sh == 1 && p.sw == 2) DW(3, 1, 2);
+    else if (fits && sq && p.kh == 5 && p.sh == 1 && p.sw == 1) DW(5, 1, 1);
+    else if (fits && sq && p.kh == 5 && p.sh == 2 && p.sw == 2) DW(5, 2, 2);
+    else if (fits && sq && p.kh == 5 && p.sh == 2 && p.sw == 1) DW(5, 2, 1);
+    else if (fits && sq && p.kh == 5 && p.sh == 1 && p.sw == 2) DW(5, 1, 2);
     else hipLaunchKernelGGL(conv_dw_kernel, dim3(grid_for(total)), b, 0, s, p);
+#undef DW2
 #undef DW
 }
 
