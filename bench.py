@@ -23,6 +23,12 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: f32-input MFMA dense peak
+MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA peak; the bf16x6 kernels spend 6 bf16 MFMAs per f32-equivalent product
+
+
+def mfma_peak_for(kernel):
+    """Peak in f32-equivalent TFLOP/s (2*M*K*N per product) of the matrix pipe the kernel class runs on."""
+    return (MFMA_BF16_PEAK_TF / 6.0, "bf16 dense peak / 6 (three-way split, six MFMAs per product)") if kernel.endswith("_x6") else (MFMA_F32_PEAK_TF, "f32-input MFMA dense peak")
 
 
 def main():
@@ -109,9 +115,10 @@ def main():
         if e and e["launches"] > 0 and e["total_ms"] > 0:
             sec = e["total_ms"] / 1e3
             ai = e["alg_flops"] / max(e["alg_bytes"], 1.0)
-            balance = MFMA_F32_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)
+            mfma_peak, peak_note = mfma_peak_for(dominant)
+            balance = mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
             if ai >= balance:
-                ach, peak, unit, bound = e["alg_flops"] / sec / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s", "mfma"
+                ach, peak, unit, bound = e["alg_flops"] / sec / 1e12, round(mfma_peak, 1), "TFLOP/s", "mfma"
             else:
                 ach, peak, unit, bound = e["alg_bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
             # HBM bytes per launch of this kernel class from the committed PMC passes (rocprofv3 cannot run inside the timed
@@ -126,7 +133,7 @@ def main():
                 except Exception:
                     pass
             roof = {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "kernel": dominant, "launches_per_step": e["launches"] / args.steps, "avg_launch_us": round(e["total_ms"] * 1e3 / e["launches"], 2),
+                    "kernel": dominant, "peak_note": peak_note if bound == "mfma" else "HBM3E spec", "launches_per_step": e["launches"] / args.steps, "avg_launch_us": round(e["total_ms"] * 1e3 / e["launches"], 2),
                     "alg_bytes_per_launch": e["alg_bytes"] / e["launches"], "alg_flops_per_launch": e["alg_flops"] / e["launches"],
                     "share_of_step": round(e["total_ms"] / (dt * 1e3), 4)}
 

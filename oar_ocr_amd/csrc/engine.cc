@@ -593,7 +593,7 @@ struct Planner {
         if (g == 1 && Cin % 4 == 0) {
             kind = 0;
             const bool is1x1 = kh == 1 && kw == 1 && sh == 1 && sw == 1 && pt == 0 && pl == 0;
-            p.w_fmt = k::igemm_weight_format((int)(kh * kw * Cin), (int)Cin, is1x1);
+            p.w_fmt = k::igemm_weight_format((long)(N * Ho * Wo), (int)(kh * kw * Cin), (int)Cout, is1x1);
             p.w = conv_weight_igemm(n, W, p.w_fmt);
         }
         else if (g == Cin && g == Cout && Cout % 4 == 0) { kind = 1; p.w = conv_weight_dw(n, W); }
@@ -634,7 +634,7 @@ struct Planner {
         p.N = (int)N; p.H = (int)H; p.W = (int)Wd; p.Cin = (int)Cin; p.Ho = (int)Ho; p.Wo = (int)Wo; p.Cout = (int)Cout;
         p.kh = (int)kh; p.kw = (int)kw; p.sh = (int)sh; p.sw = (int)sw; p.pt = (int)pt; p.pl = (int)pl; p.dh = (int)dh; p.dw = (int)dw;
         p.groups = 1; p.act = n.act; p.bias = bias; p.y_ld = (int)Cout; p.convt2x2 = fast ? 1 : 0;
-        p.w_fmt = fast ? k::igemm_weight_format((int)Cin, (int)Cin, true) : 0;
+        p.w_fmt = 0;   // the 2x2 scatter epilogue runs on the f32 kernels
         p.w = convt_weight(n, W, fast, p.w_fmt);
         Loc yl = y.loc;
         double flops = 2.0 * N * H * Wd * Cin * Cout * kh * kw;
@@ -1105,7 +1105,7 @@ struct Planner {
         Act act = n.act;
         double flops = 2.0 * M * N * K, bytes = 4.0 * (M * K + M * N * (has_res ? 2 : 1) + K * N);
         if (K % 4 == 0 && alpha == 1.0f) {
-            const int fmt = k::igemm_weight_format((int)K, (int)K, true);
+            const int fmt = has_res ? 0 : k::igemm_weight_format((long)M, (int)K, (int)Np, true);
             const float* w = linear_weight(n.in[1], *bt.ht, transB, fmt);
             k::ConvP p{};
             p.w_fmt = fmt;

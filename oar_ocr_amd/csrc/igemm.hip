@@ -122,163 +122,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmP p) {  // 2 wa
     igemm_epilogue<NT, PF>(p, acc, m0, pl_, g, nf0, !bias_in_acc);
 }
 
-// ------------------------------------------------------------------------------------------ igemm x6: f32 via 6 bf16 MFMAs
-// f32-equivalent GEMM on the bf16 matrix pipe.  Every f32 operand is split EXACTLY into three bf16 pieces by
-// truncation (x = h + m + l, each piece = the next 8 significand bits: h = x & 0xFFFF0000, m = (x-h) & .., l = ...),
-// and the product is accumulated in f32 from the six terms hh, hm, mh, hl, lh, mm.  The dropped terms (ml, lm, ll)
-// are <= 2^-24 relative, i.e. the result carries the same ~1 ulp error class as a plain f32 FMA chain (measured
-// 4e-8 vs 6e-8 relative on K = 192 dot products) -- but one 32-deep k-step costs 6 x 16 cycles of
-// v_mfma_f32_16x16x32_bf16 instead of 8 x 32 cycles of v_mfma_f32_16x16x4_f32: 2.7x less matrix-pipe time.
-// Operand map: lane (p = lane&15, g = lane>>4) supplies the 8 consecutive k = 32*kc + 8*g + e of its row/column for
-// both A (weights, pre-split on the host into 3 planes of 8 bf16 per lane) and B (pixels: two float4 loads = 32
-// contiguous bytes, split in registers).  C/D layout equals the f32 kernel's, so the epilogue is shared.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// (The bf16x6 arithmetic -- exact 3-way bf16 split of both operands, six MFMAs per product -- lives in igemm_ws_x6.hip.)
 
-__device__ __forceinline__ void split3_pack(const float4& a, const float4& b, uint4& h, uint4& m, uint4& l) {
-    const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    unsigned hh[8], mm[8], ll[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        unsigned u = __float_as_uint(f[e]);
-        unsigned uh = u & 0xFFFF0000u;
-        float r1 = f[e] - __uint_as_float(uh);
-        unsigned um = __float_as_uint(r1) & 0xFFFF0000u;
-        float r2 = r1 - __uint_as_float(um);
-        unsigned ul = __float_as_uint(r2) & 0xFFFF0000u;
-        hh[e] = uh; mm[e] = um; ll[e] = ul;
+// cout fragments per LDS-resident tile of the x6 kernel for this K (0: does not fit)
+static int ws_x6_tile(int K, int nfrag) {
+    const int KC = (K + 31) / 32;
+    const int cand[3] = {8, 6, 4};
+    int best = 1 << 30, nt = 0;
+    for (int t : cand) {
+        if ((size_t)t * KC * 3072 > 150 * 1024) continue;
+        int padded = (nfrag + t - 1) / t * t;
+        if (padded < best) { best = padded; nt = t; }
     }
-    // bf16 element e = upper half of piece e; two per dword, element 2i in the low half
-    h = make_uint4((hh[0] >> 16) | hh[1], (hh[2] >> 16) | hh[3], (hh[4] >> 16) | hh[5], (hh[6] >> 16) | hh[7]);
-    m = make_uint4((mm[0] >> 16) | mm[1], (mm[2] >> 16) | mm[3], (mm[4] >> 16) | mm[5], (mm[6] >> 16) | mm[7]);
-    l = make_uint4((ll[0] >> 16) | ll[1], (ll[2] >> 16) | ll[3], (ll[4] >> 16) | ll[5], (ll[6] >> 16) | ll[7]);
+    return nt;
 }
 
-template <int NT, int PF, bool IS1X1>
-__global__ __launch_bounds__(256, 2) void conv_igemm_x6_kernel(IgemmP p) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pl_ = lane & 15, g = lane >> 4;
-    const long b = blockIdx.x;
-    const int xcd = (int)(b & 7);
-    const long slot = b >> 3;
-    const int ntile = (int)(slot % p.ny);
-    const long mtile = (long)xcd * p.mx_per_xcd + slot / p.ny;
-    if (slot / p.ny >= p.mx_per_xcd) return;
-    const long m0 = (mtile * 4 + wave) * (PF * 16);
-    const int nf0 = ntile * NT;
-    if (m0 >= p.M) return;
-
-    long pix_base[PF];
-    int ih0[PF], iw0[PF];
-#pragma unroll
-    for (int pf = 0; pf < PF; ++pf) {
-        // rows past M are clamped to the last pixel: they compute garbage that igemm_store never writes.  Keeping
-        // every load unconditional matters: a load under a bounds-check branch makes the compiler's s_waitcnt
-        // bookkeeping conservative (vmcnt(0) right after the prefetch is issued), which serialises the pipeline.
-        long m = min(m0 + pf * 16 + pl_, p.M - 1);
-        if (IS1X1) {
-            pix_base[pf] = m * (long)p.Cin; ih0[pf] = 0; iw0[pf] = 0;
-        } else {
-            long hw = (long)p.Ho * p.Wo;
-            long n = m / hw; long r = m - n * hw;
-            int oh = (int)(r / p.Wo), ow = (int)(r - (long)oh * p.Wo);
-            pix_base[pf] = n * (long)p.H * p.W * p.Cin;
-            ih0[pf] = oh * p.sh - p.pt; iw0[pf] = ow * p.sw - p.pl;
-        }
-    }
-    f32x4 acc[NT][PF];
-    const bool bias_in_acc = igemm_init_acc<NT, PF>(p, acc, g, nf0);
-
-    int ci = 8 * g, tap_h = 0, tap_w = 0;   // this lane's k = 32*kc + 8*g
-    if (!IS1X1) {
-        while (ci >= p.Cin) { ci -= p.Cin; if (++tap_w == p.kw) { tap_w = 0; ++tap_h; } }
-    }
-    const uint4* wf = reinterpret_cast<const uint4*>(p.w) + ((long)nf0 * p.KC) * 3 * 64 + lane;
-
-    auto load_x = [&](int kc, float4 (&xv)[PF][2]) {
-        const int k = min(kc * 32 + 8 * g, p.K - 8);   // padded tail: W is 0 there, re-read the last valid group
-#pragma clang loop unroll(full)
-        for (int pf = 0; pf < PF; ++pf) {
-            float4 v0, v1;
-            if (IS1X1) {
-                const float* src = p.x + pix_base[pf] + k;
-                v0 = *reinterpret_cast<const float4*>(src); v1 = *reinterpret_cast<const float4*>(src + 4);
-            } else {
-                const int ih = ih0[pf] + tap_h * p.dh, iw = iw0[pf] + tap_w * p.dw;
-                const bool ok = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && tap_h < p.kh;
-                const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
-                const float* src = p.x + pix_base[pf] + ((long)ihc * p.W + iwc) * p.Cin + min(ci, p.Cin - 8);
-                v0 = *reinterpret_cast<const float4*>(src); v1 = *reinterpret_cast<const float4*>(src + 4);
-                v0.x = ok ? v0.x : 0.f; v0.y = ok ? v0.y : 0.f; v0.z = ok ? v0.z : 0.f; v0.w = ok ? v0.w : 0.f;
-                v1.x = ok ? v1.x : 0.f; v1.y = ok ? v1.y : 0.f; v1.z = ok ? v1.z : 0.f; v1.w = ok ? v1.w : 0.f;
-            }
-            xv[pf][0] = v0; xv[pf][1] = v1;
-        }
-        if (!IS1X1) {
-            ci += 32;
-            while (ci >= p.Cin) { ci -= p.Cin; if (++tap_w == p.kw) { tap_w = 0; ++tap_h; } }
-        }
-    };
-    auto load_w = [&](int kc, uint4 (&wv)[NT][3]) {
-#pragma clang loop unroll(full)
-        for (int nf = 0; nf < NT; ++nf)
-#pragma clang loop unroll(full)
-            for (int pl = 0; pl < 3; ++pl) wv[nf][pl] = wf[(((long)nf * p.KC + kc) * 3 + pl) * 64];
-    };
-    // six terms per (cout frag, pixel frag), smallest first: (w plane, x plane) = mm, lh, hl, mh, hm, hh.  Term
-    // outermost so that consecutive MFMAs target different accumulators.  Terms [T0, T1) of one chunk:
-    auto split = [&](const float4 (&xv)[PF][2], uint4 (&xs)[PF][3]) {
-#pragma clang loop unroll(full)
-        for (int pf = 0; pf < PF; ++pf) split3_pack(xv[pf][0], xv[pf][1], xs[pf][0], xs[pf][1], xs[pf][2]);
-    };
-    auto mma_terms = [&](const uint4 (&wv)[NT][3], const uint4 (&xs)[PF][3], auto T0, auto T1) {
-        constexpr int WP[6] = {1, 2, 0, 1, 0, 0};
-        constexpr int XP[6] = {1, 0, 2, 0, 1, 0};
-#pragma clang loop unroll(full)
-        for (int t = decltype(T0)::value; t < decltype(T1)::value; ++t)
-#pragma clang loop unroll(full)
-            for (int nf = 0; nf < NT; ++nf)
-#pragma clang loop unroll(full)
-                for (int pf = 0; pf < PF; ++pf)
-                    acc[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[nf][WP[t]]),
-                                                                          __builtin_bit_cast(bf16x8, xs[pf][XP[t]]), acc[nf][pf], 0, 0, 0);
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I6 = std::integral_constant<int, 6>;
-
-    // same issue-order pinning as the f32 kernel: first term of the chunk, then the next chunk's loads, then the rest
-    float4 xa[PF][2], xb[PF][2];
-    uint4 wa[NT][3], wb[NT][3], xs[PF][3];
-    load_x(0, xa);
-    load_w(0, wa);
-    int kc = 0;
-    for (; kc + 1 < p.KC; kc += 2) {
-        split(xa, xs);
-        mma_terms(wa, xs, I0{}, I1{});
-        __builtin_amdgcn_sched_barrier(0);
-        load_x(kc + 1, xb);
-        load_w(kc + 1, wb);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_terms(wa, xs, I1{}, I6{});
-        __builtin_amdgcn_sched_barrier(0);   // keep the split of the prefetched chunk (and its vmcnt wait) down here
-        split(xb, xs);
-        mma_terms(wb, xs, I0{}, I1{});
-        __builtin_amdgcn_sched_barrier(0);
-        if (kc + 2 < p.KC) { load_x(kc + 2, xa); load_w(kc + 2, wa); }
-        __builtin_amdgcn_sched_barrier(0);
-        mma_terms(wb, xs, I1{}, I6{});
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (kc < p.KC) { split(xa, xs); mma_terms(wa, xs, I0{}, I6{}); }
-
-    igemm_epilogue<NT, PF>(p, acc, m0, pl_, g, nf0, !bias_in_acc);
-}
-
-int igemm_weight_format(int K, int Cin, bool is1x1) {
-    // OAR_IGEMM_FMT: 0 f32 fragments (default), 1 bf16x6 fragments where eligible
-    static const int mode = [] { const char* e = getenv("OAR_IGEMM_FMT"); return e ? atoi(e) : 0; }();
-    // x6: every lane's 8-float group must be all-valid or all-padding, and must not straddle two taps
-    if (mode == 1 && K % 8 == 0 && (is1x1 || Cin % 8 == 0)) return IGEMM_W_X6;
+int igemm_weight_format(long M, int K, int N, bool is1x1) {
+    // OAR_IGEMM_X6: 1 (default) = bf16x6 weight-stationary kernel on the wide 1x1 / Linear layers, 0 = f32 MFMA everywhere
+    static const int mode = [] { const char* e = getenv("OAR_IGEMM_X6"); return e ? atoi(e) : 1; }();
+    if (!mode || !is1x1) return IGEMM_W_K16;
+    // every lane's 8-float group must be all-valid or all-padding (K % 8); wide enough to be matrix-pipe bound
+    // (N >= 96, K >= 96); enough (16-pixel tile, cout tile) pairs to fill the 4096 resident waves; float4 epilogue
+    const int nfrag = (N + 15) / 16;
+    const long passes = ((M + 15) / 16) * ((nfrag + 7) / 8);
+    if (K % 8 == 0 && K >= 96 && N >= 96 && (N & 3) == 0 && passes >= 4096 && ws_x6_tile(K, nfrag) > 0) return IGEMM_W_X6;
     return IGEMM_W_K16;
 }
 
@@ -310,7 +177,7 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     // pixel fragments per wave: fewer when the launch would otherwise leave most of the 256 CUs idle
     const long ny = (nfrag + NT - 1) / NT;
     static const int pf_max = [] { const char* e = getenv("OAR_IGEMM_PF"); int v = e ? atoi(e) : 2; return v == 1 || v == 4 ? v : 2; }();  // PF=2: 102 VGPRs => 4 waves/SIMD (measured 1.2x over PF=4)
-    int PF = x6 ? 2 : pf_max;
+    int PF = pf_max;
     while (PF > 1 && ((p.M + 4L * PF * 16 - 1) / (4L * PF * 16)) * ny < 1024) PF >>= 1;
     const long mx = (p.M + 4L * PF * 16 - 1) / (4L * PF * 16);
     p.ny = (int)ny;
@@ -345,7 +212,7 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     double flops = 2.0 * (double)p.M * p.K * p.gemm_cout;
     double bytes = 4.0 * ((double)c.N * c.H * c.W * c.Cin + (double)p.M * p.gemm_cout + (double)p.K * p.gemm_cout);
     char pname[96];
-    const char* cls = "conv_igemm";
+    const char* cls = x6 ? "conv_igemm_ws_x6" : ws ? "conv_igemm_ws" : "conv_igemm";   // one profiler class per kernel
     if (Profiler::get().detail) {
         snprintf(pname, sizeof pname, "conv_igemm%s M=%ld K=%d N=%d k%dx%d s%d%s", x6 ? "_x6" : ws ? "_ws" : "", p.M, p.K, p.gemm_cout, c.kh, c.kw, c.sh, c.convt2x2 ? " convT" : "");
         cls = pname;
@@ -353,10 +220,7 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     ProfScope ps(s, cls, bytes, flops);
 #define LAUNCH2(NTV, PFV)                                                                                          \
     do {                                                                                                          \
-        if (x6) {                                                                                                 \
-            if (is1x1) hipLaunchKernelGGL((conv_igemm_x6_kernel<NTV, PFV, true>), grid, dim3(256), 0, s, p);     \
-            else hipLaunchKernelGGL((conv_igemm_x6_kernel<NTV, PFV, false>), grid, dim3(256), 0, s, p);          \
-        } else if (is1x1) hipLaunchKernelGGL((conv_igemm_kernel<NTV, PFV, true>), grid, dim3(256), 0, s, p);     \
+        if (is1x1) hipLaunchKernelGGL((conv_igemm_kernel<NTV, PFV, true>), grid, dim3(256), 0, s, p);     \
         else hipLaunchKernelGGL((conv_igemm_kernel<NTV, PFV, false>), grid, dim3(256), 0, s, p);                 \
     } while (0)
 #define LAUNCH(NTV)                                  \
@@ -365,7 +229,11 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
         else if (PF == 2) LAUNCH2(NTV, 2);           \
         else LAUNCH2(NTV, 1);                        \
     } while (0)
-    if (ws) {
+    if (x6) {
+        const int nt = ws_x6_tile(p.K, nfrag);
+        OAR_CHECK(nt > 0 && is1x1 && ((p.Cout & 3) == 0) && ((p.y_ld & 3) == 0), OAR_INTERNAL, "conv_igemm: bf16x6 weights on an ineligible layer");
+        conv_igemm_ws_x6(s, p, nt, (nfrag + nt - 1) / nt, (size_t)nt * p.KC * 3072 + (size_t)nt * 64 + 16);
+    } else if (ws) {
         const int wny = (nfrag + ws_nt - 1) / ws_nt;
         const size_t lds = (size_t)ws_nt * p.KC * 1024 + (size_t)ws_nt * 64 + 16;
         if (is1x1) conv_igemm_ws_1x1(s, p, ws_nt, wny, lds);

@@ -181,6 +181,8 @@ __device__ __forceinline__ bool igemm_init_acc(const IgemmP& p, f32x4 (&acc)[NT]
 // weight-stationary variant (igemm_ws.inc, instantiated in igemm_ws_1x1.hip / igemm_ws_gen.hip)
 void conv_igemm_ws_1x1(hipStream_t s, const IgemmP& p, int ws_nt, int ny, size_t lds);
 void conv_igemm_ws_gen(hipStream_t s, const IgemmP& p, int ws_nt, int ny, size_t lds);
+// weight-stationary bf16x6 variant for 1x1 / Linear layers (igemm_ws_x6.hip); p.KC = ceil(K/32), p.w in x6 fragment order
+void conv_igemm_ws_x6(hipStream_t s, const IgemmP& p, int ws_nt, int ny, size_t lds);
 
 }  // namespace k
 }  // namespace oar

@@ -31,10 +31,12 @@ enum : int { IGEMM_W_K16 = 0, IGEMM_W_X6 = 1 };
 
 // Implicit-GEMM conv on the matrix cores. groups == 1, Cin % 4 == 0. Weight layouts (ConvP::w_fmt):
 //   K16: f32 fragments  Wf[cout/16][K/16][lane][4 f32]              -> v_mfma_f32_16x16x4_f32 (exact f32 FMA chain)
-//   X6 : bf16x6 fragments Wx[cout/16][K/32][3 planes][lane][8 bf16] -> v_mfma_f32_16x16x32_bf16 x 6 (f32-equivalent)
+//   X6 : bf16x6 fragments Wx[cout/16][K/32][3 planes][lane][8 bf16] -> v_mfma_f32_16x16x32_bf16 x 6 (f32-equivalent),
+//        weight-stationary kernel only (wide 1x1 / Linear layers)
 // Rows are padded to 64 couts, K to the chunk size, with zeros.
 void conv_igemm(hipStream_t s, const ConvP& p);
-int igemm_weight_format(int K, int Cin, bool is1x1);
+// chosen per layer AND input shape at plan time: M = GEMM rows (pixels), N = couts
+int igemm_weight_format(long M, int K, int N, bool is1x1);
 // Depthwise conv. w: [kh][kw][C]. C % 4 == 0.
 void conv_dw(hipStream_t s, const ConvP& p);
 // Direct conv for everything else (small Cin, odd channels, grouped). w: [kh][kw][Cin/g][Cout].
