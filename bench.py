@@ -94,11 +94,14 @@ def main():
     else:
         breakdown = {}
 
-    for _ in range(args.warmup):
-        regions, ctc = step()
+    # the timed region's instrumentation (events around the dominant class only) is switched on BEFORE the warm-up: the
+    # engines replay their plans as hipGraphs, and a graph embeds the event nodes of the profiler state it was captured in
     if dominant:
         api.prof_filter(dominant)
         api.prof_enable(True)
+    for _ in range(args.warmup):
+        regions, ctc = step()
+    if dominant:
         api.prof_reset()
     barrier()
     t0 = time.perf_counter()

@@ -549,8 +549,19 @@ void oar_host_plan_crop(uint32_t img_w, uint32_t img_h, const float box8[8], int
 void oar_prof_reset(void) {
     try { Profiler::get().reset(); } catch (...) {}
 }
-void oar_prof_enable(int32_t on) { Profiler::get().enabled = on != 0; }
-void oar_prof_filter(const char* cls) { Profiler::get().filter = cls ? cls : ""; }
+void oar_prof_enable(int32_t on) {
+    Profiler& p = Profiler::get();
+    p.flush();   // captured graphs carry the instrumentation of the epoch they were captured in
+    std::lock_guard<std::mutex> lk(p.mu);
+    if (p.enabled != (on != 0)) { p.enabled = on != 0; ++p.epoch; }
+}
+void oar_prof_filter(const char* cls) {
+    Profiler& p = Profiler::get();
+    p.flush();
+    std::lock_guard<std::mutex> lk(p.mu);
+    std::string f = cls ? cls : "";
+    if (p.filter != f) { p.filter = f; ++p.epoch; }
+}
 int32_t oar_prof_snapshot(oar_prof_entry* entries, int32_t cap) {
     try {
         Profiler& p = Profiler::get();

@@ -38,6 +38,8 @@ hipEvent_t Profiler::ev() {
     OAR_HIP(hipEventCreate(&e));
     return e;
 }
+thread_local Profiler::GraphEvents* Profiler::capturing = nullptr;
+
 void Profiler::begin(hipStream_t s, int c, double bytes, double flops) {
     std::lock_guard<std::mutex> lk(mu);
     Pending p;
@@ -46,17 +48,54 @@ void Profiler::begin(hipStream_t s, int c, double bytes, double flops) {
     p.cls = c;
     p.bytes = bytes;
     p.flops = flops;
-    OAR_HIP(hipEventRecord(p.a, s));
-    pending.push_back(p);
+    if (capturing) {   // external event-record node: re-recorded by every replay, readable from the host afterwards
+        OAR_HIP(hipEventRecordWithFlags(p.a, s, hipEventRecordExternal));
+        capturing->ev.push_back(p);
+    } else {
+        OAR_HIP(hipEventRecord(p.a, s));
+        pending.push_back(p);
+    }
 }
 void Profiler::end(hipStream_t s) {
     std::lock_guard<std::mutex> lk(mu);
+    if (capturing) {
+        if (!capturing->ev.empty()) (void)hipEventRecordWithFlags(capturing->ev.back().b, s, hipEventRecordExternal);
+        return;
+    }
     if (pending.empty()) return;
     // the most recent pending entry on this thread's stream
     (void)hipEventRecord(pending.back().b, s);
 }
+static void harvest_locked(Profiler& P, Profiler::GraphEvents& g) {
+    if (!g.launched) return;
+    for (auto& p : g.ev) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            auto& t = P.totals[p.cls];
+            t.launches += 1;
+            t.total_ms += ms;
+            t.alg_bytes += p.bytes;
+            t.alg_flops += p.flops;
+        }
+    }
+    g.launched = false;
+}
+void Profiler::harvest(GraphEvents& g) {
+    std::lock_guard<std::mutex> lk(mu);
+    harvest_locked(*this, g);
+}
+void Profiler::release(GraphEvents& g) {
+    std::lock_guard<std::mutex> lk(mu);
+    harvest_locked(*this, g);
+    for (auto& p : g.ev) { pool.push_back(p.a); pool.push_back(p.b); }
+    g.ev.clear();
+}
 void Profiler::flush() {
     std::lock_guard<std::mutex> lk(mu);
+    for (auto it = graphs.begin(); it != graphs.end();) {
+        if (auto g = it->lock()) { harvest_locked(*this, *g); ++it; }
+        else it = graphs.erase(it);
+    }
     for (auto& p : pending) {
         float ms = 0.f;
         if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -91,7 +92,18 @@ struct Profiler {
         int cls;
         double bytes, flops;
     };
+    // Events recorded by the event-record nodes of ONE captured hipGraph (Engine keeps one per graph).  Every replay
+    // re-records the same events, so they are harvested into the totals before the graph is launched again and at flush().
+    struct GraphEvents {
+        std::vector<Pending> ev;
+        bool launched = false;   // replayed since the last harvest
+    };
     std::mutex mu;
+    int epoch = 0;        // bumped when enabled / filter change: captured graphs embed the instrumentation of their epoch
+    static thread_local GraphEvents* capturing;   // set by Engine while it captures a plan on this thread
+    std::vector<std::weak_ptr<GraphEvents>> graphs;
+    void harvest(GraphEvents& g);    // the graph's last launch must have been submitted; synchronises on its events
+    void release(GraphEvents& g);    // harvest + give the events back to the pool
     bool enabled = false;
     bool detail = false;  // OAR_PROF_DETAIL=1: split conv classes by shape
     std::string filter;  // when non-empty only this kernel class is instrumented

@@ -8,6 +8,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "common.h"
@@ -69,6 +70,7 @@ struct Plan {
     double flops = 0, bytes = 0;
     int n_kernels = 0;
     bool skipped_softmax = false;
+    mutable int runs = 0;   // completed uncaptured runs (a plan is captured into a hipGraph from its second run on)
     int logits_valid = 0;   // > 0: output[0]'s rows are padded; only the first logits_valid columns are logits
 };
 
@@ -106,6 +108,17 @@ class Engine {
     std::vector<void*> dev_allocs_;
     std::map<std::string, std::unique_ptr<Plan>> plans_;
     DevBuf arena_;
+    // hipGraph replay (opt-in, OAR_HIP_GRAPH=1; measured at parity with plain launches, see Engine::replay): from its
+    // second run a plan is captured once per (input pointer, arena base, profiler epoch) and replayed.
+    struct GraphEntry {
+        hipGraphExec_t exec = nullptr;
+        std::shared_ptr<Profiler::GraphEvents> events;
+        int epoch = 0;
+    };
+    std::map<std::tuple<const Plan*, const void*, const void*>, GraphEntry> graphs_;
+    bool graphs_ok_ = true;
+    void clear_graphs();
+    bool replay(const Plan& p, const RunCtx& c);
     std::mutex mu_;
     const float* last_input_ = nullptr;
 };
