@@ -1111,9 +1111,21 @@ struct Planner {
             k::ConvP p{};
             p.w_fmt = fmt;
             N = Np;
+            // CTC head: when the logits only feed the fused tail, do not even write them -- per-tile softmax partials
+            Loc part;
+            if (P.logits_valid > 0 && od.back() == Np && fmt == k::IGEMM_W_K16 && act.kind == k::ACT_NONE && k::ctc_partials_supported((int)K)) {
+                static const bool on = [] { const char* e = getenv("OAR_CTC_PARTIALS"); return !e || atoi(e) != 0; }();
+                if (on) {
+                    P.ctc_tiles = k::ctc_tiles((int)Np);
+                    part = alloc_arena((size_t)M * P.ctc_tiles * 16, "");   // no root: stays allocated until the end of the plan
+                    P.ctc_part = part;
+                }
+            }
+            const bool has_part = part.kind != Loc::NONE;
+            p.ctc_valid = P.logits_valid;
             p.N = 1; p.H = 1; p.W = (int)M; p.Cin = (int)K; p.Ho = 1; p.Wo = (int)M; p.Cout = (int)N;
             p.kh = p.kw = p.sh = p.sw = p.dh = p.dw = 1; p.groups = 1; p.act = act; p.w = w; p.bias = bias; p.y_ld = (int)N;
-            step([=](const RunCtx& c) { k::ConvP q = p; q.x = c.at(ain); q.y = c.mut(yl); q.residual = has_res ? c.at(res) : nullptr; k::conv_igemm(c.s, q); }, flops, bytes);
+            step([=](const RunCtx& c) { k::ConvP q = p; q.x = c.at(ain); q.y = c.mut(yl); q.residual = has_res ? c.at(res) : nullptr; q.ctc_part = has_part ? c.mut(part) : nullptr; k::conv_igemm(c.s, q); }, flops, bytes);
         } else {
             const float* w = bt.loc.cptr;
             k::GemmP g{};

@@ -72,6 +72,8 @@ struct Plan {
     bool skipped_softmax = false;
     mutable int runs = 0;   // completed uncaptured runs (a plan is captured into a hipGraph from its second run on)
     int logits_valid = 0;   // > 0: output[0]'s rows are padded; only the first logits_valid columns are logits
+    Loc ctc_part;           // kind != NONE: output[0] was never materialised; softmax partials [rows][ctc_tiles] float4 live here
+    int ctc_tiles = 0;
 };
 
 class Engine {

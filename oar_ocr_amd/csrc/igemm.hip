@@ -137,6 +137,9 @@ static int ws_x6_tile(int K, int nfrag) {
     return nt;
 }
 
+int ctc_tiles(int n_padded) { return ((n_padded + 15) / 16 + 7) / 8; }
+bool ctc_partials_supported(int K) { return K % 4 == 0 && K >= 32 && (size_t)8 * ((K + 15) / 16) * 1024 <= 150 * 1024; }
+
 int igemm_weight_format(long M, int K, int N, bool is1x1) {
     // OAR_IGEMM_X6: 1 (default) = bf16x6 weight-stationary kernel on the wide 1x1 / Linear layers, 0 = f32 MFMA everywhere
     static const int mode = [] { const char* e = getenv("OAR_IGEMM_X6"); return e ? atoi(e) : 1; }();
@@ -156,6 +159,7 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     p.pt = c.pt; p.pl = c.pl; p.dh = c.dh; p.dw = c.dw; p.y_ld = c.y_ld;
     p.act = c.act.kind; p.alpha = c.act.alpha; p.beta = c.act.beta;
     p.convt = c.convt2x2; p.Cout = c.Cout;
+    p.ctc_part = c.ctc_part; p.ctc_valid = c.ctc_valid;
     if (c.convt2x2) {
         p.Ho = c.H; p.Wo = c.W;  // GEMM columns are INPUT pixels
         p.M = (long)c.N * c.H * c.W; p.K = c.Cin; p.gemm_cout = 4 * c.Cout;
@@ -207,6 +211,10 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
             int padded = (nfrag + t - 1) / t * t;
             if (padded < best) { best = padded; ws_nt = t; }
         }
+    }
+    if (c.ctc_part) {   // the partial-softmax epilogue lives in the f32 weight-stationary kernel, 8 fragments per tile
+        OAR_CHECK(!x6 && vec_ok && ctc_partials_supported(p.K) && is1x1, OAR_INTERNAL, "conv_igemm: CTC partials on an ineligible layer");
+        ws_nt = 8;
     }
     const bool ws = ws_nt > 0;
     double flops = 2.0 * (double)p.M * p.K * p.gemm_cout;

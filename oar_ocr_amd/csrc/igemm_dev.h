@@ -45,6 +45,8 @@ struct IgemmP {
     unsigned cin_magic, kw_magic;   // floor(2^32 / d) + 1: q = umulhi(n, magic) == n / d for n < 2^16
     long mx_per_xcd;     // pixel tiles per XCD band
     float alpha, beta;
+    float* ctc_part;     // != null (weight-stationary f32 kernel only): no logits are stored; per (row, cout tile) the
+    int ctc_valid;       // softmax partials {max, sum exp(x - max), last arg max} over the tile's valid columns go here
 };
 
 __device__ __forceinline__ void igemm_store(const IgemmP& p, f32x4 v, bool valid, long obase, int c, bool vec_ok, bool add_bias = true) {
@@ -155,6 +157,47 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[NT]
             const long o = coff(nf, pf, cv, co);
             if (mvalid[pf] && cv) *reinterpret_cast<float4*>(p.y + o) = make_float4(acc[nf][pf][0], acc[nf][pf][1], acc[nf][pf][2], acc[nf][pf][3]);
         }
+}
+
+// CTC-head epilogue of the weight-stationary kernel: the logits of this wave tile (16 rows x NT*16 columns) never reach
+// HBM.  Per row, over the tile's columns c < ctc_valid: m = max, s = sum expf(x - m), i = the LAST column with
+// expf(x - m) == 1.0f (the tie rule of the unfused tail: equal probabilities -> last index wins).  ctc_combine merges the
+// ny tiles of a row.  Lane (p, g) holds columns (nf0+nf)*16 + g*4 + r of row p; the four g-lanes of a row are merged
+// with two xor-shuffles.
+template <int NT>
+__device__ __forceinline__ void igemm_ctc_epilogue(const IgemmP& p, f32x4 (&acc)[NT][1], long m0, int pl_, int g, int nf0, int ntile, int ny) {
+    float m = -3.402823466e38f;
+#pragma clang loop unroll(full)
+    for (int nf = 0; nf < NT; ++nf)
+#pragma clang loop unroll(full)
+        for (int r = 0; r < 4; ++r) {
+            const int c = (nf0 + nf) * 16 + g * 4 + r;
+            if (c < p.ctc_valid) m = fmaxf(m, acc[nf][0][r]);
+        }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+    int last = -1;
+#pragma clang loop unroll(full)
+    for (int nf = 0; nf < NT; ++nf)
+#pragma clang loop unroll(full)
+        for (int r = 0; r < 4; ++r) {
+            const int c = (nf0 + nf) * 16 + g * 4 + r;
+            if (c < p.ctc_valid) {
+                const float e = __expf(acc[nf][0][r] - m);   // v_exp_f32 path (~2 ulp): 32 of these per lane and tile
+                sum += e;
+                if (e == 1.0f) last = c;   // columns ascend with (nf, r): the last hit is the largest
+            }
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    last = max(last, __shfl_xor(last, 16, 64));
+    last = max(last, __shfl_xor(last, 32, 64));
+    const long row = m0 + pl_;
+    if (g == 0 && row < p.M) {
+        float4* dst = reinterpret_cast<float4*>(p.ctc_part) + row * ny + ntile;
+        *dst = make_float4(m, sum, __int_as_float(last), 0.f);
+    }
 }
 
 // Accumulators start from the bias (row g*4+r of fragment nf = channel (nf0+nf)*16 + g*4 + r, i.e. exactly this lane's

@@ -26,6 +26,8 @@ struct ConvP {
     int y_ld;               // channel stride of the output buffer (>= Cout); y points at channel offset already
     int convt2x2;           // igemm only: output scatter of a 2x2/stride-2 ConvTranspose (Cout is the real Cout)
     int w_fmt;              // igemm only: weight fragment layout, one of IGEMM_W_* (chosen by igemm_weight_format)
+    float* ctc_part;        // igemm only, Linear feeding the fused CTC tail: softmax partials [rows][ctc_tiles()] float4
+    int ctc_valid;          //   instead of logits (y is not written); ctc_valid = number of real classes
 };
 enum : int { IGEMM_W_K16 = 0, IGEMM_W_X6 = 1 };
 
@@ -83,6 +85,11 @@ void gemm_batched(hipStream_t s, const GemmP& p);
 void layernorm(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C, float eps);
 void softmax_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C);
 // softmax over the last dim fused with CTC argmax (last max index wins) -- see kernels.hip
+// CTC head without logits: conv_igemm with ConvP::ctc_part set writes {max, sum exp, last arg max} per (row, cout tile
+// of 128 columns); ctc_combine merges the tiles of each row into the arg max index and its softmax probability.
+int ctc_tiles(int n_padded);   // cout tiles per row for a (16-padded) class count
+bool ctc_partials_supported(int K);
+void ctc_combine(hipStream_t s, const float* part, int64_t rows, int tiles, int64_t* idx, float* prob);
 void softmax_argmax(hipStream_t s, const float* logits, int64_t rows, int C, int ld, int64_t* idx, float* prob);   // ld = row stride
 
 }  // namespace k

@@ -782,6 +782,30 @@ void softmax_argmax(hipStream_t s, const float* logits, int64_t rows, int C, int
     hipLaunchKernelGGL(softmax_argmax_kernel, dim3((unsigned)rows), dim3(256), (size_t)C * sizeof(float), s, logits, C, ld, idx, prob);
 }
 
+// merges the per-tile softmax partials of conv_igemm's CTC epilogue: one thread per row
+__global__ __launch_bounds__(256) void ctc_combine_kernel(const float4* part, long rows, int tiles, int64_t* idx, float* prob) {
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const float4* pr = part + row * tiles;
+    float M = -3.402823466e38f;
+    for (int t = 0; t < tiles; ++t) M = fmaxf(M, pr[t].x);
+    float S = 0.f;
+    int last = 0;
+    for (int t = 0; t < tiles; ++t) {
+        const float4 v = pr[t];
+        const float e = expf(v.x - M);
+        S += v.y * e;
+        if (e == 1.0f && __float_as_int(v.z) >= 0) last = __float_as_int(v.z);   // tiles ascend in column order
+    }
+    idx[row] = last;
+    prob[row] = 1.0f / S;
+}
+void ctc_combine(hipStream_t s, const float* part, int64_t rows, int tiles, int64_t* idx, float* prob) {
+    if (rows == 0) return;
+    ProfScope ps(s, "ctc_combine", 16.0 * (double)rows * tiles, 0.0);
+    hipLaunchKernelGGL(ctc_combine_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(part), (long)rows, tiles, idx, prob);
+}
+
 void softmax_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C) {
     if (rows == 0 || C == 0) return;
     ProfScope ps(s, "softmax", 8.0 * (double)rows * C, 4.0 * (double)rows * C);

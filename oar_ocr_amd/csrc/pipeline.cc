@@ -577,7 +577,10 @@ void Recognizer::run_batches(const std::vector<std::vector<Crop>>& batches, std:
         const Plan& plan = eng_->run(in, {(int64_t)b.size(), 3, img_h, Wt}, true, fuse_tail[bi] != 0);
         if (pend[bi].rows == 0) continue;
         const PlanOutput& po = plan.outputs[0];
-        if (plan.skipped_softmax)   // output[0] holds logits: softmax + argmax in one pass, probabilities never hit HBM
+        if (plan.skipped_softmax && plan.ctc_part.kind != Loc::NONE)   // not even the logits hit HBM: merge the per-tile partials
+            k::ctc_combine(s, eng_->out_ptr(plan.ctc_part), (int64_t)pend[bi].rows, plan.ctc_tiles, idx_dev_.as<int64_t>() + pend[bi].row0,
+                           prob_dev_.as<float>() + pend[bi].row0);
+        else if (plan.skipped_softmax)   // output[0] holds logits: softmax + argmax in one pass, probabilities never hit HBM
             k::softmax_argmax(s, eng_->out_ptr(po.loc), (int64_t)pend[bi].rows, plan.logits_valid > 0 ? plan.logits_valid : (int)po.dims[2], (int)po.dims[2],
                               idx_dev_.as<int64_t>() + pend[bi].row0, prob_dev_.as<float>() + pend[bi].row0);
         else
