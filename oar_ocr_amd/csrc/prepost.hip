@@ -125,11 +125,31 @@ __device__ __forceinline__ void resize_pixel(const uint8_t* src, int w, int h, i
     }
     Taps tv = make_taps(oy, h, nh), th = make_taps(ox, w, nw);
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-    for (int i = th.left; i < th.right; ++i) {
-        float r, g, b;
-        vertical_sum(src, w, i, tv, r, g, b);
-        float wh = tap_w(th, i);
-        a0 += r * wh; a1 += g * wh; a2 += b * wh;
+    constexpr int MAXT = 8;
+    const int nv = tv.right - tv.left;
+    if (nv <= MAXT) {
+        // the vertical weights do not depend on the column: evaluate them once (same values, same summation order as
+        // vertical_sum -- only the redundant divisions go away)
+        float wv[MAXT];
+#pragma unroll
+        for (int j = 0; j < MAXT; ++j) wv[j] = j < nv ? tap_w(tv, tv.left + j) : 0.0f;
+        for (int i = th.left; i < th.right; ++i) {
+            float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+            const uint8_t* p = src + ((long)tv.left * w + i) * 3;
+#pragma unroll
+            for (int j = 0; j < MAXT; ++j) {
+                if (j < nv) { t0 += (float)p[0] * wv[j]; t1 += (float)p[1] * wv[j]; t2 += (float)p[2] * wv[j]; p += (long)w * 3; }
+            }
+            float wh = tap_w(th, i);
+            a0 += t0 * wh; a1 += t1 * wh; a2 += t2 * wh;
+        }
+    } else {
+        for (int i = th.left; i < th.right; ++i) {
+            float r, g, b;
+            vertical_sum(src, w, i, tv, r, g, b);
+            float wh = tap_w(th, i);
+            a0 += r * wh; a1 += g * wh; a2 += b * wh;
+        }
     }
     out[0] = to_u8_round(a0); out[1] = to_u8_round(a1); out[2] = to_u8_round(a2);
 }
