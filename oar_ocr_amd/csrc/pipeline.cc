@@ -337,6 +337,7 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
     size_t rs_off = 0;
     for (int sb = 0; sb < nsub; ++sb) {
         const int b0 = sb * SB, nb = std::min(SB, B - b0);
+        const uint8_t* srcs[32];
         for (int k = 0; k < nb; ++k) {
             const PageRef& pg = pages[idx[b0 + k]];
             const uint8_t* src = page_ptrs_[idx[b0 + k]];
@@ -346,8 +347,10 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
                 src = dst;
                 rs_off += (plane * 3 + 255) & ~(size_t)255;
             }
-            pp::normalize(s, src, input_f32_.as<float>() + (size_t)k * plane * 3, 1, (int64_t)plane, kDbSrc, alpha, beta, 1);
+            if (nb <= 32) srcs[k] = src;
+            else pp::normalize(s, src, input_f32_.as<float>() + (size_t)k * plane * 3, 1, (int64_t)plane, kDbSrc, alpha, beta, 1);
         }
+        if (nb <= 32) pp::normalize_pages(s, srcs, nb, input_f32_.as<float>(), (int64_t)plane, kDbSrc, alpha, beta, 1);   // one launch per sub-batch
         const Plan& plan = eng_->run(input_f32_.as<float>(), {nb, 3, (int64_t)rh, (int64_t)rw}, true);
         const PlanOutput& po = plan.outputs[0];
         OAR_CHECK(po.dims.size() == 4 && po.dims[0] == nb && po.dims[1] == C && po.dims[2] == H && po.dims[3] == W, OAR_SHAPE_MISMATCH,

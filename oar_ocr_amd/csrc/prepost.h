@@ -11,6 +11,9 @@ namespace pp {
 // layout 0: out[c*plane + p] per image (CHW); layout 1: out[p*3 + c] (HWC / NHWC).
 void normalize(hipStream_t s, const uint8_t* rgb, float* out, int64_t n_images, int64_t plane, const int src[3],
                const float alpha[3], const float beta[3], int layout);
+// same arithmetic, n_pages (<= 32) separately allocated device pages of `plane` pixels each in ONE launch (host array of device pointers)
+void normalize_pages(hipStream_t s, const uint8_t* const* d_pages, int n_pages, float* out, int64_t plane, const int src[3], const float alpha[3],
+                     const float beta[3], int layout);
 
 struct CropDesc {          // one recognizer input crop (device-resident u8 HWC)
     const uint8_t* src;

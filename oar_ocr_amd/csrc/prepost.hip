@@ -25,14 +25,15 @@ struct NormP {
     int src[3];
     float alpha[3], beta[3];
 };
-__global__ __launch_bounds__(256) void normalize_kernel(const uint8_t* __restrict__ rgb, float* __restrict__ out, long n_images,
+struct NormSrcs { const uint8_t* p[32]; };   // separate page buffers of one launch (null table: images are contiguous in rgb)
+__global__ __launch_bounds__(256) void normalize_kernel(const uint8_t* __restrict__ rgb, NormSrcs srcs, int use_srcs, float* __restrict__ out, long n_images,
                                                         long plane, NormP p, int layout) {
     const long quads_per_img = (plane + 3) >> 2;
     const long total = n_images * quads_per_img;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long img = i / quads_per_img, q = i - img * quads_per_img;
         long p0 = q * 4;
-        const uint8_t* s = rgb + (img * plane + p0) * 3;
+        const uint8_t* s = (use_srcs ? srcs.p[img] + p0 * 3 : rgb + (img * plane + p0) * 3);
         int np = (int)min(4L, plane - p0);
         uint8_t b[12];
         if (np == 4 && ((reinterpret_cast<uintptr_t>(s) & 3) == 0)) {
@@ -73,7 +74,19 @@ void normalize(hipStream_t s, const uint8_t* rgb, float* out, int64_t n_images, 
     NormP p;
     for (int i = 0; i < 3; ++i) { p.src[i] = src[i]; p.alpha[i] = alpha[i]; p.beta[i] = beta[i]; }
     ProfScope ps(s, "normalize", 15.0 * (double)n_images * plane, 6.0 * (double)n_images * plane);
-    hipLaunchKernelGGL(normalize_kernel, dim3(grid_for(n_images * ((plane + 3) / 4))), dim3(256), 0, s, rgb, out, (long)n_images, (long)plane, p, layout);
+    NormSrcs none{};
+    hipLaunchKernelGGL(normalize_kernel, dim3(grid_for(n_images * ((plane + 3) / 4))), dim3(256), 0, s, rgb, none, 0, out, (long)n_images, (long)plane, p, layout);
+}
+void normalize_pages(hipStream_t s, const uint8_t* const* d_pages, int n_pages, float* out, int64_t plane, const int src[3], const float alpha[3],
+                     const float beta[3], int layout) {
+    if (n_pages * plane == 0) return;
+    OAR_CHECK(n_pages <= 32, OAR_INTERNAL, "normalize_pages: at most 32 pages per launch");
+    NormP p;
+    for (int i = 0; i < 3; ++i) { p.src[i] = src[i]; p.alpha[i] = alpha[i]; p.beta[i] = beta[i]; }
+    NormSrcs t{};
+    for (int i = 0; i < n_pages; ++i) t.p[i] = d_pages[i];
+    ProfScope ps(s, "normalize", 15.0 * (double)n_pages * plane, 6.0 * (double)n_pages * plane);
+    hipLaunchKernelGGL(normalize_kernel, dim3(grid_for(n_pages * ((plane + 3) / 4))), dim3(256), 0, s, nullptr, t, 1, out, (long)n_pages, (long)plane, p, layout);
 }
 
 // ------------------------------------------------------------------------------------------ Triangle resize helpers
