@@ -216,7 +216,8 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
         OAR_CHECK(!x6 && vec_ok && ctc_partials_supported(p.K) && is1x1, OAR_INTERNAL, "conv_igemm: CTC partials on an ineligible layer");
         ws_nt = 8;
     }
-    const bool ws = ws_nt > 0;
+    const bool ws3 = !x6 && !c.ctc_part && conv_igemm_ws3_eligible(p, nfrag);
+    const bool ws = ws_nt > 0 || ws3;
     double flops = 2.0 * (double)p.M * p.K * p.gemm_cout;
     double bytes = 4.0 * ((double)c.N * c.H * c.W * c.Cin + (double)p.M * p.gemm_cout + (double)p.K * p.gemm_cout);
     char pname[96];
@@ -237,7 +238,9 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
         else if (PF == 2) LAUNCH2(NTV, 2);           \
         else LAUNCH2(NTV, 1);                        \
     } while (0)
-    if (x6) {
+    if (ws3) {
+        conv_igemm_ws3(s, p, nfrag);
+    } else if (x6) {
         const int nt = ws_x6_tile(p.K, nfrag);
         OAR_CHECK(nt > 0 && is1x1 && ((p.Cout & 3) == 0) && ((p.y_ld & 3) == 0), OAR_INTERNAL, "conv_igemm: bf16x6 weights on an ineligible layer");
         conv_igemm_ws_x6(s, p, nt, (nfrag + nt - 1) / nt, (size_t)nt * p.KC * 3072 + (size_t)nt * 64 + 16);
