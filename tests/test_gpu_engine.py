@@ -150,3 +150,47 @@ def test_unsupported_operator_is_an_error_not_a_fallback():
     with pytest.raises(api.OCRError) as e:
         eng.infer(np.zeros((2, 4), np.float32))
     assert e.value.code == api.OAR_UNSUPPORTED_OP
+
+
+def test_config3_server_size_graphs_match_oracle():
+    """BASELINE config 3 (v5-server-class det + SVTRv2-class rec, vocab 18710): the wide layers take the weight-stationary
+    f32 / bf16x6 kernels at larger K and N than the tiny graphs exercise.  Small inputs keep the torch-CPU oracle fast."""
+    det, dinfo = models.build_det("server", seed=2)
+    page = pages.make_page(3, (256, 320), lines=4)
+    x, _ = R.det_preprocess(page)
+    (name, g), = _check(det, np.stack([x, x[:, ::-1].copy()]), tol=5e-4)[0]
+    assert g.shape == (2, 1, 256, 320)
+    rec, rinfo = models.build_rec("server", vocab=18710, seed=3)
+    crops = [pages.make_crop(10 + i, w, 48) for i, w in enumerate((320, 280, 512, 96))]
+    xr = R.rec_preprocess(crops)
+    (name, p), = _check(rec, xr, tol=5e-4)[0]
+    assert p.shape == (4, xr.shape[3] // 8, 18710)
+    assert np.allclose(p.sum(-1), 1.0, atol=1e-4)
+
+
+def _conv_graph(cin, cout, k, seed, relu=True):
+    g = GraphBuilder("conv")
+    rng = np.random.default_rng(seed)
+    g.add_input("x", ["N", cin, "H", "W"])
+    w = (rng.standard_normal((cout, cin, k, k)) * (1.0 / np.sqrt(cin * k * k))).astype(np.float32)
+    y = g.op("Conv", ["x", g.init(w), g.init(rng.standard_normal(cout).astype(np.float32))], kernel_shape=[k, k], strides=[1, 1],
+             pads=[k // 2] * 4, group=1, dilations=[1, 1])
+    if relu:
+        y = g.op("Relu", [y])
+    g.add_output(y, ["N", cout, "H", "W"])
+    return g.model()
+
+
+@pytest.mark.parametrize("case", [
+    ("ws_x6 1x1 192->192", 37, 192, 192, 12, 80, 1),       # bf16x6 weight-stationary kernel (K, N >= 96, many pixels)
+    ("ws_x6 1x1 104->96 K tail", 80, 104, 96, 12, 80, 1),   # K = 104: zero-padded tail of the last 32-deep chunk
+    ("ws f32 1x1 48->96", 128, 48, 96, 12, 80, 1),         # f32 weight-stationary kernel (N >= 96, K < 96)
+    ("ws3 3x3 64->16", 2, 64, 16, 240, 240, 3),            # 3x3 same conv with DPP tap reuse (M >= 100000)
+    ("ws3 3x3 32->32 ragged", 3, 32, 32, 150, 231, 3),     # two cout fragments, row length not a multiple of the tile
+    ("per-tile 1x1 24->32", 2, 24, 32, 240, 240, 1),       # per-wave-tile kernel, K not a multiple of 16
+])
+def test_igemm_kernels_at_bench_shapes(case):
+    """Each implicit-GEMM kernel at a shape large enough to select it (see conv_igemm's rules), against torch-CPU conv2d."""
+    name, n, cin, cout, h, w, k = case
+    x = np.random.default_rng(len(name)).standard_normal((n, cin, h, w)).astype(np.float32)
+    _check(_conv_graph(cin, cout, k, seed=n + cin), x)
