@@ -441,12 +441,21 @@ Recognizer::Recognizer(const uint8_t* onnx, size_t len, const oar_rec_cfg& cfg) 
     if (cfg_.rec_image_shape[0] == 0) { cfg_.rec_image_shape[0] = 3; cfg_.rec_image_shape[1] = 48; cfg_.rec_image_shape[2] = 320; }
     if (cfg_.max_img_w == 0) cfg_.max_img_w = 3200;
     eng_.reset(new Engine(onnx, len, cfg_.device_id));
+    static const int n_lanes = [] { const char* e = getenv("OAR_REC_LANES"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : v > 4 ? 4 : v; }();
+    for (int i = 1; i < n_lanes; ++i) {
+        lanes_.emplace_back(new Engine(onnx, len, cfg_.device_id));
+        lane_in_.emplace_back(new DevBuf());
+        hipEvent_t ev;
+        OAR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        lane_done_.push_back(ev);
+    }
 }
 
-const float* Recognizer::pack(const std::vector<Crop>& crops, int& Wt, bool nchw, size_t desc_slot, size_t stage_slot) {
+const float* Recognizer::pack(const std::vector<Crop>& crops, int& Wt, bool nchw, size_t desc_slot, size_t stage_slot, int lane) {
     // desc_slot / stage_slot: element / byte offsets into the pinned + device staging areas, so that several batches
     // can be enqueued without the host overwriting a descriptor block an earlier async copy has not consumed yet.
-    hipStream_t s = eng_->stream();
+    hipStream_t s = lane_engine(lane).stream();
+    DevBuf& in_buf = lane == 0 ? input_f32_ : *lane_in_[lane - 1];
     const int n = (int)crops.size();
     const int img_h = (int)cfg_.rec_image_shape[1], img_w = (int)cfg_.rec_image_shape[2];
     std::vector<uint32_t> ws(n), hs(n);
@@ -460,10 +469,10 @@ const float* Recognizer::pack(const std::vector<Crop>& crops, int& Wt, bool nchw
     Wt = host::rec_tensor_width(ws, hs, img_h, img_w, (int)cfg_.max_img_w, rws);
     size_t need_in = (size_t)n * 3 * img_h * Wt * sizeof(float);
     size_t need_desc = (desc_slot + n) * sizeof(pp::CropDesc), need_stage = stage_slot + stage;
-    if (need_stage > crops_dev_.cap || need_in > input_f32_.cap || need_desc > descs_dev_.cap) {
+    if (need_stage > crops_dev_.cap || need_in > in_buf.cap || need_desc > descs_dev_.cap) {
         OAR_HIP(hipStreamSynchronize(s));
         OAR_CHECK(desc_slot == 0 && stage_slot == 0, OAR_INTERNAL, "recognizer staging buffers must be pre-sized for multi-batch runs");
-        crops_dev_.reserve(need_stage); input_f32_.reserve(need_in); descs_dev_.reserve(need_desc);
+        crops_dev_.reserve(need_stage); in_buf.reserve(need_in); descs_dev_.reserve(need_desc);
     }
     if (need_desc > descs_host_.cap || need_stage > stage_host_.cap) {
         OAR_CHECK(desc_slot == 0 && stage_slot == 0, OAR_INTERNAL, "recognizer pinned buffers must be pre-sized for multi-batch runs");
@@ -484,8 +493,8 @@ const float* Recognizer::pack(const std::vector<Crop>& crops, int& Wt, bool nchw
     }
     if (stage) OAR_HIP(hipMemcpyAsync(crops_dev_.as<uint8_t>() + stage_slot, stage_host_.as<uint8_t>() + stage_slot, stage, hipMemcpyHostToDevice, s));
     OAR_HIP(hipMemcpyAsync(dd, dh, (size_t)n * sizeof(pp::CropDesc), hipMemcpyHostToDevice, s));
-    pp::rec_pack(s, dd, n, img_h, Wt, input_f32_.as<float>(), nchw ? 1 : 0);
-    return input_f32_.as<float>();
+    pp::rec_pack(s, dd, n, img_h, Wt, in_buf.as<float>(), nchw ? 1 : 0);
+    return in_buf.as<float>();
 }
 
 void Recognizer::pack_only(const std::vector<Crop>& crops, std::vector<float>& nchw, uint32_t& Wt_out) {
@@ -535,6 +544,8 @@ void Recognizer::run_batches(const std::vector<std::vector<Crop>>& batches, std:
         OAR_HIP(hipStreamSynchronize(s));
         crops_dev_.reserve(total_stage); input_f32_.reserve(max_in); descs_dev_.reserve(total_crops * sizeof(pp::CropDesc));
     }
+    for (auto& lb : lane_in_)
+        if (max_in > lb->cap) { for (auto& le : lanes_) OAR_HIP(hipStreamSynchronize(le->stream())); lb->reserve(max_in); }
     descs_host_.reserve(total_crops * sizeof(pp::CropDesc));
     stage_host_.reserve(total_stage);
 
@@ -570,25 +581,38 @@ void Recognizer::run_batches(const std::vector<std::vector<Crop>>& batches, std:
         idx_dev_.reserve(row_total * 8); prob_dev_.reserve(row_total * 4);
     }
     idx_host_.reserve(row_total * 8); prob_host_.reserve(row_total * 4);
+    const int n_lanes = 1 + (int)lanes_.size();
+    std::vector<char> lane_used(n_lanes, 0);
+    int next_lane = 0;
     for (size_t bi = 0; bi < batches.size(); ++bi) {
         const auto& b = batches[bi];
         if (b.empty()) continue;
+        const int lane = next_lane;
+        next_lane = (next_lane + 1) % n_lanes;
+        lane_used[lane] = 1;
+        Engine& eng = lane_engine(lane);
+        hipStream_t sl = eng.stream();
         int Wt = 0;
-        const float* in = pack(b, Wt, false, desc_slot, stage_slot);
+        const float* in = pack(b, Wt, false, desc_slot, stage_slot, lane);
         desc_slot += b.size();
         for (auto& c : b) if (!c.dev) stage_slot += ((size_t)c.w * c.h * 3 + 63) & ~(size_t)63;
-        const Plan& plan = eng_->run(in, {(int64_t)b.size(), 3, img_h, Wt}, true, fuse_tail[bi] != 0);
+        const Plan& plan = eng.run(in, {(int64_t)b.size(), 3, img_h, Wt}, true, fuse_tail[bi] != 0);
         if (pend[bi].rows == 0) continue;
         const PlanOutput& po = plan.outputs[0];
         if (plan.skipped_softmax && plan.ctc_part.kind != Loc::NONE)   // not even the logits hit HBM: merge the per-tile partials
-            k::ctc_combine(s, eng_->out_ptr(plan.ctc_part), (int64_t)pend[bi].rows, plan.ctc_tiles, idx_dev_.as<int64_t>() + pend[bi].row0,
+            k::ctc_combine(sl, eng.out_ptr(plan.ctc_part), (int64_t)pend[bi].rows, plan.ctc_tiles, idx_dev_.as<int64_t>() + pend[bi].row0,
                            prob_dev_.as<float>() + pend[bi].row0);
         else if (plan.skipped_softmax)   // output[0] holds logits: softmax + argmax in one pass, probabilities never hit HBM
-            k::softmax_argmax(s, eng_->out_ptr(po.loc), (int64_t)pend[bi].rows, plan.logits_valid > 0 ? plan.logits_valid : (int)po.dims[2], (int)po.dims[2],
+            k::softmax_argmax(sl, eng.out_ptr(po.loc), (int64_t)pend[bi].rows, plan.logits_valid > 0 ? plan.logits_valid : (int)po.dims[2], (int)po.dims[2],
                               idx_dev_.as<int64_t>() + pend[bi].row0, prob_dev_.as<float>() + pend[bi].row0);
         else
-            pp::ctc_argmax(s, eng_->out_ptr(po.loc), (int64_t)pend[bi].rows, (int)po.dims[2], idx_dev_.as<int64_t>() + pend[bi].row0,
+            pp::ctc_argmax(sl, eng.out_ptr(po.loc), (int64_t)pend[bi].rows, (int)po.dims[2], idx_dev_.as<int64_t>() + pend[bi].row0,
                            prob_dev_.as<float>() + pend[bi].row0);
+    }
+    for (int lane = 1; lane < n_lanes; ++lane) {   // the result copies below run on lane 0's stream after every lane is done
+        if (!lane_used[lane]) continue;
+        OAR_HIP(hipEventRecord(lane_done_[lane - 1], lanes_[lane - 1]->stream()));
+        OAR_HIP(hipStreamWaitEvent(s, lane_done_[lane - 1], 0));
     }
     if (row_total) {
         OAR_HIP(hipMemcpyAsync(idx_host_.p, idx_dev_.p, row_total * 8, hipMemcpyDeviceToHost, s));

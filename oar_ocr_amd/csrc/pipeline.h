@@ -94,8 +94,14 @@ class Recognizer {
     Engine& engine() { return *eng_; }
 
    private:
-    const float* pack(const std::vector<Crop>& crops, int& Wt, bool nchw, size_t desc_slot = 0, size_t stage_slot = 0);
+    const float* pack(const std::vector<Crop>& crops, int& Wt, bool nchw, size_t desc_slot = 0, size_t stage_slot = 0, int lane = 0);
+    Engine& lane_engine(int lane) { return lane == 0 ? *eng_ : *lanes_[lane - 1]; }
     std::unique_ptr<Engine> eng_;
+    // Recognition batches are independent: they are dealt round-robin to `1 + lanes_.size()` engines (own stream, own
+    // arena, own input tensor), so one batch's short kernels and dispatch gaps overlap with another batch's work.
+    std::vector<std::unique_ptr<Engine>> lanes_;
+    std::vector<std::unique_ptr<DevBuf>> lane_in_;
+    std::vector<hipEvent_t> lane_done_;
     oar_rec_cfg cfg_;
     DevBuf crops_dev_, descs_dev_, input_f32_, idx_dev_, prob_dev_;
     PinBuf descs_host_, idx_host_, prob_host_, stage_host_;
