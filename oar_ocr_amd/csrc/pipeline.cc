@@ -313,8 +313,19 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
     float alpha[3], beta[3];
     for (int c = 0; c < 3; ++c) { alpha[c] = scale / stdv[c]; beta[c] = -mean[c] / stdv[c]; }
     static const int kSub = [] { const char* e = getenv("OAR_DET_SUB"); int v = e ? atoi(e) : 8; return v > 0 ? v : 8; }();
-    const int SB = std::min(B, kSub);
-    const int nsub = (B + SB - 1) / SB;
+    const int nsub = (B + std::min(B, kSub) - 1) / std::min(B, kSub);
+    // sub-batch sizes: the LAST one is half-size (its contour tracing is the only host work the GPU cannot overlap), the
+    // others share the rest evenly
+    std::vector<int> sb_off(nsub + 1, 0);
+    {
+        const int base = std::min(B, kSub);
+        const int last = nsub >= 2 ? std::max(1, base / 2) : B;
+        int rest = B - last, left = nsub - 1;
+        for (int i = 0; i < nsub - 1; ++i) { int take = (rest + left - 1) / left; sb_off[i + 1] = sb_off[i] + take; rest -= take; --left; }
+        sb_off[nsub] = B;
+    }
+    int SB = 0;
+    for (int i = 0; i < nsub; ++i) SB = std::max(SB, sb_off[i + 1] - sb_off[i]);
 
     // output geometry from the plan of the largest sub-batch (shape inference only)
     const Plan& plan0 = eng_->plan_for({SB, 3, (int64_t)rh, (int64_t)rw}, true);
@@ -336,7 +347,7 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
     float* probs = probs_keep_.as<float>();   // [B][H][W] channel-0 planes, kept for the score kernel
     size_t rs_off = 0;
     for (int sb = 0; sb < nsub; ++sb) {
-        const int b0 = sb * SB, nb = std::min(SB, B - b0);
+        const int b0 = sb_off[sb], nb = sb_off[sb + 1] - b0;
         const uint8_t* srcs[32];
         for (int k = 0; k < nb; ++k) {
             const PageRef& pg = pages[idx[b0 + k]];
@@ -368,7 +379,7 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
     const uint8_t* mh = mask_host_.as<uint8_t>();
     const uint32_t maxc = cfg_.max_candidates;
     for (int sb = 0; sb < nsub; ++sb) {
-        const int b0 = sb * SB, nb = std::min(SB, B - b0);
+        const int b0 = sb_off[sb], nb = sb_off[sb + 1] - b0;
         OAR_HIP(hipEventSynchronize(sub_events_[sb]));
         tmark("det_gpu_wait");
         subbatch_candidates(*pool_, mh + (size_t)b0 * hw, hw, H, W, nb, maxc, &cands[b0]);
