@@ -190,8 +190,6 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     p.kw_magic = (unsigned)((1ull << 32) / (unsigned)c.kw + 1);
     p.mx_per_xcd = (mx + 7) / 8;
     dim3 grid((unsigned)(p.mx_per_xcd * 8 * ny));
-    // (A variant with the cout tile of W resident in LDS and chunk-pair X prefetch was measured at parity with this
-    // kernel -- 78-81 TFLOP/s on the K=192/256 shapes either way -- and dropped.)
     // weight-stationary variant (see conv_igemm_ws_kernel): OAR_IGEMM_WS = 0 off, 1 wherever it fits, default: N >= ws_min_n
     static const int ws_mode = [] { const char* e = getenv("OAR_IGEMM_WS"); return e ? atoi(e) : -1; }();
     static const int ws_min_n = [] { const char* e = getenv("OAR_IGEMM_WS_MIN_N"); return e ? atoi(e) : 96; }();

@@ -1,9 +1,9 @@
 // kernels.hip -- hand-written gfx950 (CDNA4) kernels for the detector / recognizer networks.
 //
 // Data layout: feature maps are NHWC f32 in HBM (channel innermost => every conv reads/writes fully
-// coalesced 16-byte vectors).  Dense convs / Linear layers run as implicit GEMM on the f32-input matrix
-// cores (v_mfma_f32_16x16x4_f32: exact f32 FMA chain, bit-reproducible) with LDS-staged operand tiles;
-// depthwise / pooling / resize / elementwise are bandwidth kernels with float4 accesses.
+// coalesced 16-byte vectors).  Dense convs / Linear layers live in igemm*.hip (implicit GEMM on the matrix
+// cores); this file holds the bandwidth kernels -- depthwise, stem conv, pooling, resize, elementwise, the
+// small batched GEMM / layernorm / softmax of the SVTR neck and the CTC tail -- all with float4 accesses.
 // Wave = 64 lanes everywhere.  Compiled with -ffp-contract=off; FMAs are written explicitly.
 #include "kernels.h"
 
