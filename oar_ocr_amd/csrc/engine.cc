@@ -227,7 +227,8 @@ void Engine::rewrite_graph(OnnxModel& m) {
         }
     }
 
-    // ---- pass 4: Linear -> Add(residual): fold the residual into the Linear epilogue (no act between)
+    // ---- pass 4: Linear / Conv -> Add(residual): fold the residual into the producer's epilogue (no act between);
+    // shapes are only known at plan time: op_conv / op_linear fall back to a separate add when they do not match
     {
         auto cons = consumers(nodes);
         std::vector<bool> dead(nodes.size(), false);
@@ -240,7 +241,7 @@ void Engine::rewrite_graph(OnnxModel& m) {
                 auto pit = producer.find(ad.in[t]);
                 if (pit == producer.end() || dead[pit->second]) continue;
                 GNode& lin = nodes[pit->second];
-                if (lin.op != "Linear" || lin.act.kind != k::ACT_NONE || !lin.residual.empty()) continue;
+                if ((lin.op != "Linear" && lin.op != "Conv") || lin.act.kind != k::ACT_NONE || !lin.residual.empty()) continue;
                 if (cons[ad.in[t]].size() != 1 || graph_outs.count(ad.in[t])) continue;
                 const std::string& other = ad.in[1 - t];
                 if (is_init(other)) continue;
@@ -584,7 +585,21 @@ struct Planner {
         Loc xin = to_clast_loc(x);
         const float* bias = has_input(n, 2) ? get(n.in[2]).loc.cptr : nullptr;
         Loc res;
-        if (!n.residual.empty()) { TInfo r = get(n.residual); res = to_clast_loc(r); }
+        if (!n.residual.empty()) {
+            TInfo r = get(n.residual);
+            if (r.host_int || r.dims != std::vector<int64_t>{N, Cout, Ho, Wo}) {
+                // the folded Add broadcasts: plan the conv and the add separately after all
+                GNode pre = n;
+                pre.residual.clear();
+                pre.out[0] = n.out[0] + "::pre";
+                op_conv(pre);
+                GNode add;
+                add.op = "Add"; add.in = {pre.out[0], n.residual}; add.out = {n.out[0]};
+                op_binary(add, 0);
+                return;
+            }
+            res = to_clast_loc(r);
+        }
         TInfo& y = new_out(n.out[0], {N, Cout, Ho, Wo}, Layout::CLAST);
         k::ConvP p{};
         p.N = (int)N; p.H = (int)H; p.W = (int)Wd; p.Cin = (int)Cin; p.Ho = (int)Ho; p.Wo = (int)Wo; p.Cout = (int)Cout;
