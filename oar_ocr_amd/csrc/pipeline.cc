@@ -287,9 +287,27 @@ void Detector::run(const std::vector<PageRef>& pages, float thresh, float box_th
     // group by resized shape, first-appearance order (models/detection/db.rs:297-309)
     struct Group { uint32_t rh, rw; std::vector<int> idx; };
     std::vector<Group> groups;
+    // small pages (h + w < 64) are padded with black to at least 32 x 32, origin at (0, 0); box coordinates are still
+    // scaled with the ORIGINAL size (ImageScaleInfo keeps the pre-padding src_h / src_w, resize_detection.rs:170,191)
+    det_src_.assign(n, nullptr); det_w_.assign(n, 0); det_h_.assign(n, 0);
+    size_t pad_total = 0;
+    for (int i = 0; i < n; ++i)
+        if (pages[i].h + pages[i].w < 64) pad_total += ((size_t)std::max(pages[i].w, 32u) * std::max(pages[i].h, 32u) * 3 + 255) & ~(size_t)255;
+    if (pad_total > padded_dev_.cap) { OAR_HIP(hipStreamSynchronize(s)); padded_dev_.reserve(pad_total); }
+    size_t pad_off = 0;
     for (int i = 0; i < n; ++i) {
-        uint32_t w = pages[i].w, h = pages[i].h;
-        OAR_CHECK(h + w >= 64, OAR_UNSUPPORTED_OP, "detector: images with h+w < 64 (image_padding path) are not supported");
+        det_src_[i] = page_ptrs_[i]; det_w_[i] = pages[i].w; det_h_[i] = pages[i].h;
+        if (pages[i].h + pages[i].w >= 64) continue;
+        const uint32_t pw = std::max(pages[i].w, 32u), ph = std::max(pages[i].h, 32u);
+        if (pw == pages[i].w && ph == pages[i].h) continue;
+        uint8_t* d = padded_dev_.as<uint8_t>() + pad_off;
+        OAR_HIP(hipMemsetAsync(d, 0, (size_t)pw * ph * 3, s));
+        OAR_HIP(hipMemcpy2DAsync(d, (size_t)pw * 3, page_ptrs_[i], (size_t)pages[i].w * 3, (size_t)pages[i].w * 3, pages[i].h, hipMemcpyDeviceToDevice, s));
+        det_src_[i] = d; det_w_[i] = pw; det_h_[i] = ph;
+        pad_off += ((size_t)pw * ph * 3 + 255) & ~(size_t)255;
+    }
+    for (int i = 0; i < n; ++i) {
+        uint32_t w = det_w_[i], h = det_h_[i];
         uint32_t rh, rw;
         host::det_resize_dims(w, h, cfg_.limit_side_len, cfg_.limit_type, cfg_.max_side_limit, rh, rw);
         bool placed = false;
@@ -336,7 +354,7 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
 
     size_t need_in = (size_t)SB * plane * 3 * sizeof(float);
     size_t need_rs = 0;
-    for (int b = 0; b < B; ++b) if (pages[idx[b]].w != rw || pages[idx[b]].h != rh) need_rs += (plane * 3 + 255) & ~(size_t)255;
+    for (int b = 0; b < B; ++b) if (det_w_[idx[b]] != rw || det_h_[idx[b]] != rh) need_rs += (plane * 3 + 255) & ~(size_t)255;
     if (need_in > input_f32_.cap || need_rs > resized_dev_.cap || (size_t)B * hw > mask_dev_.cap || (size_t)B * hw * 4 > probs_keep_.cap) {
         OAR_HIP(hipStreamSynchronize(s));
         input_f32_.reserve(need_in); resized_dev_.reserve(need_rs); mask_dev_.reserve((size_t)B * hw); probs_keep_.reserve((size_t)B * hw * 4);
@@ -350,11 +368,11 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
         const int b0 = sb_off[sb], nb = sb_off[sb + 1] - b0;
         const uint8_t* srcs[32];
         for (int k = 0; k < nb; ++k) {
-            const PageRef& pg = pages[idx[b0 + k]];
-            const uint8_t* src = page_ptrs_[idx[b0 + k]];
-            if (pg.w != rw || pg.h != rh) {
+            const int pi = idx[b0 + k];
+            const uint8_t* src = det_src_[pi];
+            if (det_w_[pi] != rw || det_h_[pi] != rh) {
                 uint8_t* dst = resized_dev_.as<uint8_t>() + rs_off;
-                pp::resize_triangle(s, src, (int)pg.w, (int)pg.h, dst, (int)rw, (int)rh);
+                pp::resize_triangle(s, src, (int)det_w_[pi], (int)det_h_[pi], dst, (int)rw, (int)rh);
                 src = dst;
                 rs_off += (plane * 3 + 255) & ~(size_t)255;
             }

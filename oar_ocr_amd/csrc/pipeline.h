@@ -68,6 +68,11 @@ class Detector {
     std::unique_ptr<ThreadPool> pool_;
     oar_det_cfg cfg_;
     DevBuf pages_dev_, resized_dev_, input_f32_, mask_dev_, boxes_dev_, scores_dev_, probs_keep_;
+    // image as the resize stage sees it: the page itself, or its black-padded copy when h + w < 64
+    // (DetResizeForTest::image_padding, processors/resize_detection.rs:174-176,204-220)
+    DevBuf padded_dev_;
+    std::vector<const uint8_t*> det_src_;
+    std::vector<uint32_t> det_w_, det_h_;
     std::vector<hipEvent_t> sub_events_;
     PinBuf mask_host_, boxes_host_, scores_host_;
     std::vector<const uint8_t*> page_ptrs_;

@@ -111,3 +111,24 @@ def test_fused_ctc_tail_matches_unfused(nets):
     idx, pr = api.k_ctc_argmax(probs)
     assert np.array_equal(got.indices.reshape(-1), idx)
     np.testing.assert_allclose(got.probs.reshape(-1), pr, rtol=1e-5, atol=0)
+
+
+def test_small_page_is_padded_like_the_reference(nets):
+    """h + w < 64: DetResizeForTest pads with black to at least 32 x 32 before resizing (resize_detection.rs:174-176,
+    204-220) while box coordinates keep scaling with the original size.  Mixed with a normal page in one call."""
+    det, _, _ = nets
+    rng = np.random.default_rng(7)
+    tiny = np.full((20, 30, 3), 255, np.uint8)
+    tiny[6:14, 4:26] = rng.integers(0, 60, (8, 22, 3), dtype=np.uint8)      # one dark "word"
+    narrow = np.full((40, 12, 3), 255, np.uint8)                            # only the width is below 32
+    narrow[10:30, 3:9] = 20
+    imgs = [tiny, pages.make_page(8, (320, 480), lines=5), narrow]
+    got = api.TextDetectionPredictor(det, api.TextDetectionConfig(0.3, 0.6, 1.5)).predict(imgs)
+    ref = pipeline_ref.OracleDetector(det).detect(imgs, 0.3, 0.6, 1.5)
+    for g, (rb, rs, prob) in zip(got, ref):
+        gb = np.stack([d.bbox for d in g]) if g else np.zeros((0, 4, 2), np.float32)
+        assert len(gb) == len(rb)
+        if len(gb):
+            marginal = int((np.abs(prob - 0.3) < 1e-4).sum())
+            assert np.array_equal(gb, rb) if marginal == 0 else np.abs(gb - rb).max() <= 2.0
+            assert np.allclose([d.score for d in g], rs, atol=1e-3)
