@@ -185,6 +185,10 @@ typedef struct {
     uint64_t* ctc_offsets;     /* n_regions + 1 into ctc_indices / ctc_probs                */
     int64_t* ctc_indices;
     float* ctc_probs;
+    /* optional stages (oar_ocr_attach); filled with -1 / 0 when a stage is not attached */
+    float* page_angle;         /* n_images: OAROCRResult::orientation_angle (0/90/180/270), -1 = none (ocr.rs:653)      */
+    uint8_t* page_rectified;   /* n_images: 1 when rectified_img would be Some (ocr.rs:654); boxes then stay in rectified space */
+    float* line_angle;         /* n_regions: TextRegion::orientation_angle (0/180), -1 = none (ocr.rs:782-783,888)      */
 } oar_ocr_result;
 
 oar_status oar_ocr_create(const uint8_t* det_onnx, size_t det_len, const uint8_t* rec_onnx, size_t rec_len,
@@ -196,6 +200,60 @@ oar_status oar_ocr_predict(oar_ocr* o, const uint8_t* const* rgb, const uint32_t
 oar_status oar_ocr_predict_device(oar_ocr* o, const uint8_t* const* d_rgb, const uint32_t* widths,
                                   const uint32_t* heights, uint32_t n_images, oar_ocr_result* out);
 void oar_ocr_result_free(oar_ocr_result* r);
+
+/* ------------------------------------------------------------------------------------------------ Seam B: config-5 stages
+ * PP-LCNet classifier adapters: DocumentOrientationAdapter / TextLineOrientationAdapter ->
+ * PPLCNetModel::forward_refs (oar-ocr-core/src/models/classification/pp_lcnet.rs:139-330): Triangle resize
+ * (short edge -> resize_short + centre crop, or direct resize when resize_short == 0), ImageNet RGB normalisation,
+ * graph, Topk (utils/topk.rs:181-199: stable descending sort, first index wins ties).
+ * Defaults: doc orientation 224x224 / resize_short 256 / 4 classes (domain/tasks/document_orientation.rs:46-53);
+ * text-line orientation 80x160 (h x w) / direct resize / 2 classes (text_line_orientation.rs:25-32).            */
+typedef struct oar_cls oar_cls;
+typedef struct {
+    int32_t device_id;
+    uint32_t input_h, input_w;   /* 0,0 => 224,224                                      */
+    uint32_t resize_short;       /* 0 => direct resize to (input_w, input_h)            */
+    uint32_t topk;               /* 0 => 1                                              */
+    uint32_t batch;              /* 0 => 64 images per inference                        */
+} oar_cls_cfg;
+typedef struct {
+    uint32_t n_images, topk, n_classes;
+    int32_t* class_ids;          /* n_images * topk (PPLCNetModelOutput::class_ids)     */
+    float* scores;               /* n_images * topk                                     */
+} oar_cls_result;
+oar_status oar_cls_create(const uint8_t* onnx, size_t onnx_len, const oar_cls_cfg* cfg, oar_cls** out);
+void oar_cls_destroy(oar_cls* c);
+oar_status oar_cls_run(oar_cls* c, const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights, uint32_t n_images,
+                       oar_cls_result* out);
+void oar_cls_result_free(oar_cls_result* r);
+/* test hook: the preprocessed batch tensor [n,3,input_h,input_w] (NCHW) of PPLCNetModel::preprocess_refs */
+oar_status oar_cls_preprocess(oar_cls* c, const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights, uint32_t n_images,
+                              float* out_nchw);
+
+/* UVDoc rectifier adapter (row a23): UVDocModel::{preprocess_refs, postprocess}
+ * (oar-ocr-core/src/models/rectification/uvdoc.rs:82-109,166-207): Triangle resize to target, BGR v/255, graph
+ * ("image" -> [n,3,h,w] BGR in [0,1]), (v*255).clamp(0,255) as u8 -> RGB (processors/simd.rs:327-348), Triangle resize
+ * back to the input size.  out_rgb: caller-allocated w*h*3 bytes.                                               */
+typedef struct oar_rect oar_rect;
+typedef struct { int32_t device_id; uint32_t target_h, target_w; /* 0,0 => 512,512 */ } oar_rect_cfg;
+oar_status oar_rect_create(const uint8_t* onnx, size_t onnx_len, const oar_rect_cfg* cfg, oar_rect** out);
+void oar_rect_destroy(oar_rect* r);
+oar_status oar_rect_run(oar_rect* r, const uint8_t* rgb, uint32_t width, uint32_t height, uint8_t* out_rgb);
+
+/* OAROCRBuilder::with_document_image_orientation_classification / with_document_image_rectification /
+ * with_text_line_orientation_classification (src/oarocr/ocr.rs): attaches the optional stages of OAROCR::predict --
+ * DocumentPreprocessor::preprocess per page (src/oarocr/preprocess.rs:59-141), classify_line_orientations per crop
+ * (ocr.rs:757-790), rotate_text_regions_back (ocr.rs:898-925).  Any handle may be NULL; handles are borrowed and must
+ * outlive the pipeline's use of them.                                                                           */
+oar_status oar_ocr_attach(oar_ocr* o, oar_cls* doc_orientation, oar_rect* rectifier, oar_cls* line_orientation);
+
+/* config-5 stand-alone kernels / host hooks (parity tests) */
+/* image::imageops::rotate90/180/270: clockwise by quarter*90 degrees; out is (h x w) for quarter 1, 3 */
+oar_status oar_k_rotate_rgb(const uint8_t* rgb, uint32_t w, uint32_t h, int32_t quarter, uint8_t* out);
+/* processors/simd.rs:327-348; planes = 3*plane f32 (B, G, R), out = plane*3 u8 RGB */
+oar_status oar_k_bgr_planes_to_rgb(const float* planes, uint64_t plane, float scale, uint8_t* out);
+/* BoundingBox::rotate_back_to_original (processors/geometry.rs:848-889), in place on n (x, y) pairs */
+oar_status oar_host_rotate_back_points(float* pts, uint32_t n_points, float angle, uint32_t rotated_w, uint32_t rotated_h);
 
 /* ------------------------------------------------------------------------------------------------ device helpers */
 oar_status oar_dev_alloc(int32_t device_id, size_t bytes, void** out);

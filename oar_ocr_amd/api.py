@@ -71,7 +71,22 @@ class OcrResult(C.Structure):
     _fields_ = [("n_images", C.c_uint32), ("n_regions", C.c_uint32), ("region_offsets", C.POINTER(C.c_uint32)),
                 ("points", C.POINTER(C.c_float)), ("det_scores", C.POINTER(C.c_float)), ("crop_wh", C.POINTER(C.c_uint32)),
                 ("seq_len", C.POINTER(C.c_uint32)), ("max_wh_ratio", C.POINTER(C.c_float)), ("ctc_offsets", C.POINTER(C.c_uint64)),
-                ("ctc_indices", C.POINTER(C.c_int64)), ("ctc_probs", C.POINTER(C.c_float))]
+                ("ctc_indices", C.POINTER(C.c_int64)), ("ctc_probs", C.POINTER(C.c_float)),
+                ("page_angle", C.POINTER(C.c_float)), ("page_rectified", C.POINTER(C.c_uint8)), ("line_angle", C.POINTER(C.c_float))]
+
+
+class ClsCfg(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("input_h", C.c_uint32), ("input_w", C.c_uint32), ("resize_short", C.c_uint32),
+                ("topk", C.c_uint32), ("batch", C.c_uint32)]
+
+
+class ClsResult(C.Structure):
+    _fields_ = [("n_images", C.c_uint32), ("topk", C.c_uint32), ("n_classes", C.c_uint32), ("class_ids", C.POINTER(C.c_int32)),
+                ("scores", C.POINTER(C.c_float))]
+
+
+class RectCfg(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("target_h", C.c_uint32), ("target_w", C.c_uint32)]
 
 
 class ProfEntry(C.Structure):
@@ -86,6 +101,8 @@ EXPORTS = [
     "oar_dev_free", "oar_dev_synchronize", "oar_k_normalize", "oar_k_rec_preprocess", "oar_k_resize_triangle", "oar_k_threshold",
     "oar_k_ctc_argmax", "oar_k_box_scores", "oar_k_rotate_crop", "oar_prof_reset", "oar_prof_enable", "oar_prof_filter", "oar_prof_snapshot",
     "oar_host_candidates", "oar_host_unclip", "oar_host_mini_box", "oar_host_sort_quad_boxes", "oar_host_plan_crop",
+    "oar_cls_create", "oar_cls_destroy", "oar_cls_run", "oar_cls_result_free", "oar_cls_preprocess", "oar_rect_create", "oar_rect_destroy",
+    "oar_rect_run", "oar_ocr_attach", "oar_k_rotate_rgb", "oar_k_bgr_planes_to_rgb", "oar_host_rotate_back_points",
 ]
 
 
@@ -155,6 +172,21 @@ def lib():
     L.oar_host_sort_quad_boxes.restype = None
     L.oar_host_plan_crop.argtypes = [C.c_uint32, C.c_uint32, vp, vp, vp]
     L.oar_host_plan_crop.restype = None
+    L.oar_cls_create.argtypes = [vp, C.c_size_t, C.POINTER(ClsCfg), C.POINTER(vp)]
+    L.oar_cls_destroy.argtypes = [vp]
+    L.oar_cls_destroy.restype = None
+    L.oar_cls_run.argtypes = [vp, u8pp, u32p, u32p, C.c_uint32, C.POINTER(ClsResult)]
+    L.oar_cls_result_free.argtypes = [C.POINTER(ClsResult)]
+    L.oar_cls_result_free.restype = None
+    L.oar_cls_preprocess.argtypes = [vp, u8pp, u32p, u32p, C.c_uint32, vp]
+    L.oar_rect_create.argtypes = [vp, C.c_size_t, C.POINTER(RectCfg), C.POINTER(vp)]
+    L.oar_rect_destroy.argtypes = [vp]
+    L.oar_rect_destroy.restype = None
+    L.oar_rect_run.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp]
+    L.oar_ocr_attach.argtypes = [vp, vp, vp, vp]
+    L.oar_k_rotate_rgb.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int32, vp]
+    L.oar_k_bgr_planes_to_rgb.argtypes = [vp, C.c_uint64, C.c_float, vp]
+    L.oar_host_rotate_back_points.argtypes = [vp, C.c_uint32, C.c_float, C.c_uint32, C.c_uint32]
     L.oar_prof_reset.restype = None
     L.oar_prof_enable.argtypes = [C.c_int32]
     L.oar_prof_enable.restype = None
@@ -288,6 +320,7 @@ class TextRegion:
     word_boxes: Optional[List[np.ndarray]] = None
     det_score: float = 0.0
     crop_wh: tuple = (0, 0)
+    orientation_angle: Optional[float] = None   # text-line orientation (0 / 180), ocr.rs:888
 
 
 @dataclass
@@ -297,6 +330,7 @@ class OAROCRResult:
     index: int
     text_regions: List[TextRegion] = field(default_factory=list)
     orientation_angle: Optional[float] = None
+    rectified: bool = False   # rectified_img is Some: boxes are in rectified space (preprocess.rs:84-89)
 
 
 def read_dict(text: str) -> List[str]:
@@ -486,6 +520,22 @@ class OAROCRBuilder:
         self._device = 0
         self._profile = False
         self._host_threads = 0
+        self._doc_ori = self._rectifier = self._line_ori = None
+
+    def with_document_image_orientation_classification(self, model: bytes):
+        """PP-LCNet_x1_0_doc_ori: 224x224, resize_short 256, 4 classes (domain/tasks/document_orientation.rs:46-53)"""
+        self._doc_ori = model
+        return self
+
+    def with_document_image_rectification(self, model: bytes):
+        """UVDoc (models/rectification/uvdoc.rs)"""
+        self._rectifier = model
+        return self
+
+    def with_text_line_orientation_classification(self, model: bytes):
+        """PP-LCNet_x1_0_textline_ori: direct resize to 160x80 (w x h), 2 classes (text_line_orientation.rs:25-32)"""
+        self._line_ori = model
+        return self
 
     def image_batch_size(self, n: int):
         self._image_bs = n
@@ -533,7 +583,12 @@ class OAROCRBuilder:
         cfg.image_batch_size = self._image_bs or 0      # accelerator: adapter defaults 8 / 64 (builder_utils.rs:86-102)
         cfg.region_batch_size = self._region_bs or 0
         cfg.max_pooled_crops = 0
-        return OAROCR(self._det, self._rec, self._dict, cfg, self._score_thr)
+        ocr = OAROCR(self._det, self._rec, self._dict, cfg, self._score_thr)
+        if self._doc_ori or self._rectifier or self._line_ori:
+            ocr.attach(ImageClassifier(self._doc_ori, device_id=self._device) if self._doc_ori else None,
+                       DocumentRectifier(self._rectifier, device_id=self._device) if self._rectifier else None,
+                       ImageClassifier(self._line_ori, input_hw=(80, 160), resize_short=0, device_id=self._device) if self._line_ori else None)
+        return ocr
 
 
 class OAROCR:
@@ -545,6 +600,13 @@ class OAROCR:
         b1 = (C.c_char * len(det)).from_buffer_copy(det)
         b2 = (C.c_char * len(rec)).from_buffer_copy(rec)
         _check(lib().oar_ocr_create(C.cast(b1, C.c_void_p), len(det), C.cast(b2, C.c_void_p), len(rec), C.byref(cfg), C.byref(self._h)))
+        self._stages = (None, None, None)
+
+    def attach(self, doc_orientation=None, rectifier=None, line_orientation=None):
+        """Optional stages of OAROCR::predict (preprocess.rs:59-141, ocr.rs:757-790). The adapters stay referenced here."""
+        self._stages = (doc_orientation, rectifier, line_orientation)
+        h = [x._h if x is not None else None for x in self._stages]
+        _check(lib().oar_ocr_attach(self._h, h[0], h[1], h[2]))
 
     def predict(self, images: Sequence[np.ndarray]) -> List[OAROCRResult]:
         if len(images) == 0:
@@ -576,13 +638,17 @@ class OAROCR:
     def _assemble(self, res: OcrResult) -> List[OAROCRResult]:
         n, nr = res.n_images, res.n_regions
         offs = np.ctypeslib.as_array(res.region_offsets, shape=(n + 1,)).copy()
+        pang = np.ctypeslib.as_array(res.page_angle, shape=(n,)).copy()
+        prect = np.ctypeslib.as_array(res.page_rectified, shape=(n,)).copy()
+        page_kw = [dict(orientation_angle=(float(pang[i]) if pang[i] >= 0 else None), rectified=bool(prect[i])) for i in range(n)]
         if nr == 0:
-            return [OAROCRResult(f"image_{i}", i) for i in range(n)]
+            return [OAROCRResult(f"image_{i}", i, **page_kw[i]) for i in range(n)]
         pts = np.ctypeslib.as_array(res.points, shape=(nr * 8,)).copy().reshape(nr, 4, 2)
         dsc = np.ctypeslib.as_array(res.det_scores, shape=(nr,)).copy()
         cwh = np.ctypeslib.as_array(res.crop_wh, shape=(nr * 2,)).copy().reshape(nr, 2)
         sl = np.ctypeslib.as_array(res.seq_len, shape=(nr,)).copy()
         mwh = np.ctypeslib.as_array(res.max_wh_ratio, shape=(nr,)).copy()
+        lang = np.ctypeslib.as_array(res.line_angle, shape=(nr,)).copy()
         co = np.ctypeslib.as_array(res.ctc_offsets, shape=(nr + 1,)).copy()
         nctc = int(co[nr])
         ci = np.ctypeslib.as_array(res.ctc_indices, shape=(max(nctc, 1),)).copy()
@@ -601,8 +667,9 @@ class OAROCR:
                 if self.return_word_box and col and T > 0:
                     wh = np.float32(cwh[k, 0]) / np.float32(max(int(cwh[k, 1]), 1))
                     wb = ctc_word_boxes(pts[k], text, col, T, float(wh), float(mwh[k]))
-                regions.append(TextRegion(pts[k].copy(), text, score, pts[k].copy(), pts[k].copy(), wb, float(dsc[k]), (int(cwh[k, 0]), int(cwh[k, 1]))))
-            results.append(OAROCRResult(f"image_{i}", i, regions))
+                regions.append(TextRegion(pts[k].copy(), text, score, pts[k].copy(), pts[k].copy(), wb, float(dsc[k]), (int(cwh[k, 0]), int(cwh[k, 1])),
+                                          float(lang[k]) if lang[k] >= 0 else None))
+            results.append(OAROCRResult(f"image_{i}", i, regions, **page_kw[i]))
         return results
 
     def close(self):
@@ -797,3 +864,102 @@ def host_plan_crop(img_w, img_h, box):
     inv = np.zeros(9, np.float32)
     lib().oar_host_plan_crop(img_w, img_h, _p(b), _p(plan), _p(inv))
     return plan, inv
+
+
+# ---------------------------------------------------------------------------------------------- config-5 adapters
+@dataclass
+class Classification:
+    class_id: int
+    score: float
+
+
+class ImageClassifier:
+    """DocumentOrientationAdapter / TextLineOrientationAdapter over PPLCNetModel (pp_lcnet.rs:139-330)."""
+
+    def __init__(self, model: bytes, input_hw=(224, 224), resize_short: int = 256, topk: int = 1, device_id: int = 0, batch: int = 0):
+        self._h = C.c_void_p()
+        self.input_hw = tuple(input_hw)
+        cfg = ClsCfg(device_id, input_hw[0], input_hw[1], resize_short or 0, topk, batch)
+        buf = (C.c_char * len(model)).from_buffer_copy(model)
+        _check(lib().oar_cls_create(C.cast(buf, C.c_void_p), len(model), C.byref(cfg), C.byref(self._h)))
+
+    def predict(self, images: Sequence[np.ndarray]) -> List[List[Classification]]:
+        if len(images) == 0:
+            return []
+        imgs, ptrs, ws, hs = _img_arrays(images)
+        res = ClsResult()
+        _check(lib().oar_cls_run(self._h, ptrs, ws, hs, len(imgs), C.byref(res)))
+        n, k = res.n_images, res.topk
+        ids = np.ctypeslib.as_array(res.class_ids, shape=(n * k,)).copy().reshape(n, k)
+        sc = np.ctypeslib.as_array(res.scores, shape=(n * k,)).copy().reshape(n, k)
+        lib().oar_cls_result_free(C.byref(res))
+        return [[Classification(int(ids[i, j]), float(sc[i, j])) for j in range(k) if ids[i, j] >= 0] for i in range(n)]
+
+    def preprocess(self, images: Sequence[np.ndarray]) -> np.ndarray:
+        imgs, ptrs, ws, hs = _img_arrays(images)
+        out = np.zeros((len(imgs), 3, self.input_hw[0], self.input_hw[1]), np.float32)
+        _check(lib().oar_cls_preprocess(self._h, ptrs, ws, hs, len(imgs), _p(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.oar_cls_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DocumentRectifier:
+    """UVDocRectifierAdapter (models/rectification/uvdoc.rs:82-109,166-207)."""
+
+    def __init__(self, model: bytes, target_hw=(512, 512), device_id: int = 0):
+        self._h = C.c_void_p()
+        cfg = RectCfg(device_id, target_hw[0], target_hw[1])
+        buf = (C.c_char * len(model)).from_buffer_copy(model)
+        _check(lib().oar_rect_create(C.cast(buf, C.c_void_p), len(model), C.byref(cfg), C.byref(self._h)))
+
+    def predict(self, images: Sequence[np.ndarray]) -> List[np.ndarray]:
+        outs = []
+        for im in images:
+            im = np.ascontiguousarray(im, np.uint8)
+            out = np.zeros_like(im)
+            _check(lib().oar_rect_run(self._h, _p(im), im.shape[1], im.shape[0], _p(out)))
+            outs.append(out)
+        return outs
+
+    def close(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.oar_rect_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def k_rotate_rgb(rgb: np.ndarray, quarter: int) -> np.ndarray:
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w, _ = rgb.shape
+    out = np.zeros((w, h, 3) if quarter in (1, 3) else (h, w, 3), np.uint8)
+    _check(lib().oar_k_rotate_rgb(_p(rgb), w, h, quarter, _p(out)))
+    return out
+
+
+def k_bgr_planes_to_rgb(planes: np.ndarray, scale: float = 255.0) -> np.ndarray:
+    planes = np.ascontiguousarray(planes, np.float32)
+    _, h, w = planes.shape
+    out = np.zeros((h, w, 3), np.uint8)
+    _check(lib().oar_k_bgr_planes_to_rgb(_p(planes), h * w, C.c_float(scale), _p(out)))
+    return out
+
+
+def host_rotate_back_points(pts: np.ndarray, angle: float, rotated_w: int, rotated_h: int) -> np.ndarray:
+    p = np.ascontiguousarray(pts, np.float32).copy()
+    _check(lib().oar_host_rotate_back_points(_p(p), p.size // 2, C.c_float(angle), rotated_w, rotated_h))
+    return p

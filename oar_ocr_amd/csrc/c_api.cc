@@ -14,6 +14,8 @@ struct oar_engine { std::unique_ptr<Engine> e; };
 struct oar_det { std::unique_ptr<Detector> d; };
 struct oar_rec { std::unique_ptr<Recognizer> r; };
 struct oar_ocr { std::unique_ptr<Ocr> o; };
+struct oar_cls { std::unique_ptr<Classifier> c; };
+struct oar_rect { std::unique_ptr<Rectifier> r; };
 
 namespace {
 template <typename F>
@@ -268,7 +270,7 @@ oar_status oar_ocr_create(const uint8_t* det_onnx, size_t det_len, const uint8_t
 }
 void oar_ocr_destroy(oar_ocr* o) { delete o; }
 
-static void fill_ocr_result(const std::vector<std::vector<OcrRegion>>& res, oar_ocr_result* out) {
+static void fill_ocr_result(const std::vector<std::vector<OcrRegion>>& res, const std::vector<Ocr::PageMeta>& meta, oar_ocr_result* out) {
     std::memset(out, 0, sizeof *out);
     size_t nreg = 0, nctc = 0;
     for (auto& im : res) for (auto& r : im) { ++nreg; nctc += r.idx.size(); }
@@ -282,6 +284,13 @@ static void fill_ocr_result(const std::vector<std::vector<OcrRegion>>& res, oar_
     out->ctc_offsets = cmalloc<uint64_t>(nreg + 1);
     out->ctc_indices = cmalloc<int64_t>(nctc);
     out->ctc_probs = cmalloc<float>(nctc);
+    out->page_angle = cmalloc<float>(res.size());
+    out->page_rectified = cmalloc<uint8_t>(res.size());
+    out->line_angle = cmalloc<float>(nreg);
+    for (size_t i = 0; i < res.size(); ++i) {
+        out->page_angle[i] = i < meta.size() ? meta[i].angle : -1.0f;
+        out->page_rectified[i] = i < meta.size() && meta[i].rectified ? 1 : 0;
+    }
     size_t k = 0, c = 0;
     for (size_t i = 0; i < res.size(); ++i) {
         out->region_offsets[i] = (uint32_t)k;
@@ -289,7 +298,7 @@ static void fill_ocr_result(const std::vector<std::vector<OcrRegion>>& res, oar_
             std::memcpy(out->points + k * 8, r.pts, sizeof r.pts);
             out->det_scores[k] = r.det_score;
             out->crop_wh[k * 2] = r.crop_w; out->crop_wh[k * 2 + 1] = r.crop_h;
-            out->seq_len[k] = r.T; out->max_wh_ratio[k] = r.max_wh_ratio;
+            out->seq_len[k] = r.T; out->max_wh_ratio[k] = r.max_wh_ratio; out->line_angle[k] = r.line_angle;
             out->ctc_offsets[k] = c;
             std::memcpy(out->ctc_indices + c, r.idx.data(), r.idx.size() * sizeof(int64_t));
             std::memcpy(out->ctc_probs + c, r.prob.data(), r.prob.size() * sizeof(float));
@@ -313,7 +322,7 @@ static oar_status ocr_predict_impl(oar_ocr* o, const uint8_t* const* rgb, const 
         }
         std::vector<std::vector<OcrRegion>> res;
         o->o->predict(pages, res);
-        fill_ocr_result(res, out);
+        fill_ocr_result(res, o->o->page_meta(), out);
     });
 }
 oar_status oar_ocr_predict(oar_ocr* o, const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights, uint32_t n_images,
@@ -328,7 +337,128 @@ void oar_ocr_result_free(oar_ocr_result* r) {
     if (!r) return;
     std::free(r->region_offsets); std::free(r->points); std::free(r->det_scores); std::free(r->crop_wh); std::free(r->seq_len);
     std::free(r->max_wh_ratio); std::free(r->ctc_offsets); std::free(r->ctc_indices); std::free(r->ctc_probs);
+    std::free(r->page_angle); std::free(r->page_rectified); std::free(r->line_angle);
     std::memset(r, 0, sizeof *r);
+}
+
+// ---------------------------------------------------------------------------------------------- config-5 stages
+oar_status oar_cls_create(const uint8_t* onnx, size_t onnx_len, const oar_cls_cfg* cfg, oar_cls** out) {
+    return guard([&] {
+        OAR_CHECK(out, OAR_INVALID_INPUT, "oar_cls_create: out is null");
+        *out = nullptr;
+        ClsCfg c;
+        if (cfg) {
+            c.device_id = cfg->device_id;
+            if (cfg->input_h && cfg->input_w) { c.input_h = cfg->input_h; c.input_w = cfg->input_w; }
+            c.resize_short = cfg->resize_short;
+            c.topk = cfg->topk ? cfg->topk : 1;
+            c.batch = cfg->batch ? cfg->batch : 64;
+        }
+        std::unique_ptr<oar_cls> h(new oar_cls());
+        h->c.reset(new Classifier(onnx, onnx_len, c));
+        *out = h.release();
+    });
+}
+void oar_cls_destroy(oar_cls* c) { delete c; }
+static std::vector<Classifier::Image> cls_images(const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights, uint32_t n) {
+    std::vector<Classifier::Image> v(n);
+    for (uint32_t i = 0; i < n; ++i) { v[i].host = rgb[i]; v[i].w = widths[i]; v[i].h = heights[i]; }
+    return v;
+}
+oar_status oar_cls_run(oar_cls* c, const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights, uint32_t n_images,
+                       oar_cls_result* out) {
+    return guard([&] {
+        OAR_CHECK(c && out && (n_images == 0 || (rgb && widths && heights)), OAR_INVALID_INPUT, "oar_cls_run: bad arguments");
+        std::memset(out, 0, sizeof *out);
+        ClsOut co;
+        c->c->run(cls_images(rgb, widths, heights, n_images), co);
+        out->n_images = n_images; out->topk = co.topk; out->n_classes = co.n_classes;
+        out->class_ids = cmalloc<int32_t>(co.ids.size());
+        out->scores = cmalloc<float>(co.scores.size());
+        std::memcpy(out->class_ids, co.ids.data(), co.ids.size() * sizeof(int32_t));
+        std::memcpy(out->scores, co.scores.data(), co.scores.size() * sizeof(float));
+    });
+}
+void oar_cls_result_free(oar_cls_result* r) {
+    if (!r) return;
+    std::free(r->class_ids); std::free(r->scores);
+    std::memset(r, 0, sizeof *r);
+}
+oar_status oar_cls_preprocess(oar_cls* c, const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights, uint32_t n_images,
+                              float* out_nchw) {
+    return guard([&] {
+        OAR_CHECK(c && out_nchw && rgb && widths && heights, OAR_INVALID_INPUT, "oar_cls_preprocess: bad arguments");
+        std::vector<float> v;
+        c->c->pack_only(cls_images(rgb, widths, heights, n_images), v);
+        std::memcpy(out_nchw, v.data(), v.size() * sizeof(float));
+    });
+}
+
+oar_status oar_rect_create(const uint8_t* onnx, size_t onnx_len, const oar_rect_cfg* cfg, oar_rect** out) {
+    return guard([&] {
+        OAR_CHECK(out, OAR_INVALID_INPUT, "oar_rect_create: out is null");
+        *out = nullptr;
+        RectCfg c;
+        if (cfg) { c.device_id = cfg->device_id; if (cfg->target_h && cfg->target_w) { c.target_h = cfg->target_h; c.target_w = cfg->target_w; } }
+        std::unique_ptr<oar_rect> h(new oar_rect());
+        h->r.reset(new Rectifier(onnx, onnx_len, c));
+        *out = h.release();
+    });
+}
+void oar_rect_destroy(oar_rect* r) { delete r; }
+oar_status oar_rect_run(oar_rect* r, const uint8_t* rgb, uint32_t width, uint32_t height, uint8_t* out_rgb) {
+    return guard([&] {
+        OAR_CHECK(r && rgb && out_rgb && width > 0 && height > 0, OAR_INVALID_INPUT, "oar_rect_run: bad arguments");
+        r->r->run_host(rgb, width, height, out_rgb);
+    });
+}
+
+oar_status oar_ocr_attach(oar_ocr* o, oar_cls* doc_orientation, oar_rect* rectifier, oar_cls* line_orientation) {
+    return guard([&] {
+        OAR_CHECK(o, OAR_INVALID_INPUT, "oar_ocr_attach: pipeline handle is null");
+        o->o->attach(doc_orientation ? doc_orientation->c.get() : nullptr, rectifier ? rectifier->r.get() : nullptr,
+                     line_orientation ? line_orientation->c.get() : nullptr);
+    });
+}
+
+oar_status oar_k_rotate_rgb(const uint8_t* rgb, uint32_t w, uint32_t h, int32_t quarter, uint8_t* out) {
+    return guard([&] {
+        OAR_CHECK(rgb && out && quarter >= 0 && quarter <= 3, OAR_INVALID_INPUT, "oar_k_rotate_rgb: bad arguments");
+        require_device();
+        const size_t bytes = (size_t)w * h * 3;
+        if (bytes == 0) return;
+        DevBuf a, b;
+        a.reserve(bytes); b.reserve(bytes);
+        OAR_HIP(hipMemcpy(a.p, rgb, bytes, hipMemcpyHostToDevice));
+        pp::rotate_rgb(nullptr, a.as<uint8_t>(), (int)w, (int)h, quarter, b.as<uint8_t>());
+        OAR_HIP(hipDeviceSynchronize());
+        OAR_HIP(hipMemcpy(out, b.p, bytes, hipMemcpyDeviceToHost));
+    });
+}
+oar_status oar_k_bgr_planes_to_rgb(const float* planes, uint64_t plane, float scale, uint8_t* out) {
+    return guard([&] {
+        OAR_CHECK(planes && out, OAR_INVALID_INPUT, "oar_k_bgr_planes_to_rgb: bad arguments");
+        require_device();
+        if (plane == 0) return;
+        DevBuf a, b;
+        a.reserve(plane * 12); b.reserve(plane * 3);
+        OAR_HIP(hipMemcpy(a.p, planes, plane * 12, hipMemcpyHostToDevice));
+        pp::bgr_planes_to_rgb(nullptr, a.as<float>(), (int64_t)plane, scale, b.as<uint8_t>());
+        OAR_HIP(hipDeviceSynchronize());
+        OAR_HIP(hipMemcpy(out, b.p, plane * 3, hipMemcpyDeviceToHost));
+    });
+}
+oar_status oar_host_rotate_back_points(float* pts, uint32_t n_points, float angle, uint32_t rotated_w, uint32_t rotated_h) {
+    return guard([&] {
+        OAR_CHECK(pts || n_points == 0, OAR_INVALID_INPUT, "oar_host_rotate_back_points: pts is null");
+        const int a = (int)angle;
+        for (uint32_t i = 0; i < n_points; ++i) {
+            const float x = pts[2 * i], y = pts[2 * i + 1];
+            if (a == 90) { pts[2 * i] = (float)rotated_h - y; pts[2 * i + 1] = x; }
+            else if (a == 180) { pts[2 * i] = (float)rotated_w - x; pts[2 * i + 1] = (float)rotated_h - y; }
+            else if (a == 270) { pts[2 * i] = y; pts[2 * i + 1] = (float)rotated_w - x; }
+        }
+    });
 }
 
 // ---------------------------------------------------------------------------------------------- device helpers

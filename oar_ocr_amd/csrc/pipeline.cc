@@ -659,6 +659,164 @@ void Recognizer::run_batches(const std::vector<std::vector<Crop>>& batches, std:
     if (Profiler::get().enabled) Profiler::get().flush();
 }
 
+// ================================================================================================= classifier (a22)
+Classifier::Classifier(const uint8_t* onnx, size_t len, const ClsCfg& cfg) : cfg_(cfg) {
+    if (cfg_.input_h == 0 || cfg_.input_w == 0) { cfg_.input_h = 224; cfg_.input_w = 224; }
+    if (cfg_.topk == 0) cfg_.topk = 1;
+    if (cfg_.batch == 0) cfg_.batch = 64;
+    eng_.reset(new Engine(onnx, len, cfg_.device_id));
+}
+
+const float* Classifier::pack(const std::vector<Image>& images, size_t i0, size_t n, bool nchw) {
+    hipStream_t s = eng_->stream();
+    const int ch = (int)cfg_.input_h, cw = (int)cfg_.input_w;
+    size_t stage = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const Image& im = images[i0 + i];
+        OAR_CHECK(im.w > 0 && im.h > 0 && (im.host || im.dev), OAR_INVALID_INPUT, "classifier: empty image");
+        if (!im.dev) stage += ((size_t)im.w * im.h * 3 + 255) & ~(size_t)255;
+    }
+    const size_t need_in = n * 3 * (size_t)ch * cw * sizeof(float), need_desc = n * sizeof(pp::ClsDesc);
+    if (stage > stage_dev_.cap || need_in > input_f32_.cap || need_desc > descs_dev_.cap) {
+        OAR_HIP(hipStreamSynchronize(s));
+        stage_dev_.reserve(stage); input_f32_.reserve(need_in); descs_dev_.reserve(need_desc);
+    } else {
+        OAR_HIP(hipStreamSynchronize(s));   // the pinned staging / descriptor blocks are reused by every batch
+    }
+    stage_host_.reserve(stage); descs_host_.reserve(need_desc);
+    pp::ClsDesc* dh = descs_host_.as<pp::ClsDesc>();
+    size_t off = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const Image& im = images[i0 + i];
+        const uint8_t* d = im.dev;
+        if (!d) {
+            const size_t bytes = (size_t)im.w * im.h * 3;
+            std::memcpy(stage_host_.as<uint8_t>() + off, im.host, bytes);
+            d = stage_dev_.as<uint8_t>() + off;
+            off += (bytes + 255) & ~(size_t)255;
+        }
+        pp::ClsDesc& c = dh[i];
+        c.src = d; c.w = (int)im.w; c.h = (int)im.h; c.pad = 0;
+        if (cfg_.resize_short == 0) {      // direct resize (pp_lcnet.rs:172-189)
+            c.nw = cw; c.nh = ch; c.x1 = 0; c.y1 = 0;
+        } else {                           // short edge -> resize_short, centre crop (pp_lcnet.rs:147-170)
+            const float shortf = (float)std::min(im.w, im.h);
+            const float scale = (float)cfg_.resize_short / shortf;
+            const uint32_t nw = (uint32_t)std::max(std::round((float)im.w * scale), (float)cw);
+            const uint32_t nh = (uint32_t)std::max(std::round((float)im.h * scale), (float)ch);
+            c.nw = (int)nw; c.nh = (int)nh;
+            c.x1 = (int)((nw > (uint32_t)cw ? nw - (uint32_t)cw : 0u) / 2);
+            c.y1 = (int)((nh > (uint32_t)ch ? nh - (uint32_t)ch : 0u) / 2);
+        }
+    }
+    if (stage) OAR_HIP(hipMemcpyAsync(stage_dev_.p, stage_host_.p, stage, hipMemcpyHostToDevice, s));
+    OAR_HIP(hipMemcpyAsync(descs_dev_.p, descs_host_.p, need_desc, hipMemcpyHostToDevice, s));
+    // ImageNet constants, RGB order (pp_lcnet.rs:48-50, 400-412): alpha = scale/std, beta = -mean/std in f32
+    const float scale = 1.0f / 255.0f;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    float alpha[3], beta[3];
+    for (int c = 0; c < 3; ++c) { alpha[c] = scale / stdv[c]; beta[c] = -mean[c] / stdv[c]; }
+    pp::cls_pack(s, descs_dev_.as<pp::ClsDesc>(), (int)n, ch, cw, alpha, beta, input_f32_.as<float>(), nchw ? 1 : 0);
+    return input_f32_.as<float>();
+}
+
+void Classifier::pack_only(const std::vector<Image>& images, std::vector<float>& nchw) {
+    std::lock_guard<std::mutex> lk(mu_);
+    OAR_HIP(hipSetDevice(eng_->device()));
+    nchw.clear();
+    if (images.empty()) return;
+    const float* d = pack(images, 0, images.size(), true);
+    nchw.resize(images.size() * 3 * (size_t)cfg_.input_h * cfg_.input_w);
+    OAR_HIP(hipMemcpyAsync(nchw.data(), d, nchw.size() * 4, hipMemcpyDeviceToHost, eng_->stream()));
+    OAR_HIP(hipStreamSynchronize(eng_->stream()));
+}
+
+void Classifier::run(const std::vector<Image>& images, ClsOut& out) {
+    std::lock_guard<std::mutex> lk(mu_);
+    OAR_HIP(hipSetDevice(eng_->device()));
+    hipStream_t s = eng_->stream();
+    out = ClsOut();
+    out.topk = cfg_.topk;
+    for (size_t i0 = 0; i0 < images.size(); i0 += cfg_.batch) {
+        const size_t n = std::min<size_t>(cfg_.batch, images.size() - i0);
+        const float* in = pack(images, i0, n, false);
+        const Plan& plan = eng_->run(in, {(int64_t)n, 3, (int64_t)cfg_.input_h, (int64_t)cfg_.input_w}, true);
+        OAR_CHECK(!plan.outputs.empty(), OAR_INTERNAL, "PP-LCNet: no output returned from inference");        // pp_lcnet.rs:226-231
+        const PlanOutput& po = plan.outputs[0];
+        OAR_CHECK(po.dims.size() == 2 && po.dims[0] == (int64_t)n, OAR_SHAPE_MISMATCH, "PP-LCNet: failed to convert output to 2D array");
+        const int nc = (int)po.dims[1];
+        out.n_classes = (uint32_t)nc;
+        probs_host_.reserve(n * nc * sizeof(float));
+        OAR_HIP(hipMemcpyAsync(probs_host_.p, eng_->out_ptr(po.loc), n * nc * sizeof(float), hipMemcpyDeviceToHost, s));
+        OAR_HIP(hipStreamSynchronize(s));
+        const float* pr = probs_host_.as<float>();
+        const int k = std::min<int>((int)cfg_.topk, nc);
+        for (size_t i = 0; i < n; ++i) {
+            // Topk (utils/topk.rs:181-199): stable sort by score descending => the first index wins ties
+            std::vector<int> order(nc);
+            for (int c = 0; c < nc; ++c) order[c] = c;
+            const float* row = pr + i * nc;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return row[a] > row[b]; });
+            for (int t = 0; t < (int)cfg_.topk; ++t) {
+                out.ids.push_back(t < k ? order[t] : -1);
+                out.scores.push_back(t < k ? row[order[t]] : 0.0f);
+            }
+        }
+    }
+    if (Profiler::get().enabled) Profiler::get().flush();
+}
+
+// ================================================================================================= rectifier (a23)
+Rectifier::Rectifier(const uint8_t* onnx, size_t len, const RectCfg& cfg) : cfg_(cfg) {
+    eng_.reset(new Engine(onnx, len, cfg_.device_id));
+}
+
+void Rectifier::run_device(const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst) {
+    std::lock_guard<std::mutex> lk(mu_);
+    OAR_CHECK(w > 0 && h > 0 && src && dst, OAR_INVALID_INPUT, "rectifier: empty image");
+    OAR_HIP(hipSetDevice(eng_->device()));
+    hipStream_t s = eng_->stream();
+    const uint32_t th = cfg_.target_h, tw = cfg_.target_w;
+    const bool resize = th > 0 && tw > 0 && (w != tw || h != th);          // uvdoc.rs:88-101
+    const uint32_t iw = resize ? tw : w, ih = resize ? th : h;
+    const size_t plane = (size_t)iw * ih;
+    if (plane * 3 > resized_dev_.cap || plane * 12 > input_f32_.cap) {
+        OAR_HIP(hipStreamSynchronize(s));
+        resized_dev_.reserve(plane * 3); input_f32_.reserve(plane * 12);
+    }
+    const uint8_t* in_u8 = src;
+    if (resize) { pp::resize_triangle(s, src, (int)w, (int)h, resized_dev_.as<uint8_t>(), (int)iw, (int)ih); in_u8 = resized_dev_.as<uint8_t>(); }
+    // v / 255 in BGR plane order, no mean shift (uvdoc.rs:296-303)
+    const int srcc[3] = {2, 1, 0};
+    const float alpha[3] = {1.0f / 255.0f, 1.0f / 255.0f, 1.0f / 255.0f}, beta[3] = {-0.0f, -0.0f, -0.0f};
+    pp::normalize(s, in_u8, input_f32_.as<float>(), 1, (int64_t)plane, srcc, alpha, beta, 1);
+    const Plan& plan = eng_->run(input_f32_.as<float>(), {1, 3, (int64_t)ih, (int64_t)iw}, true);
+    OAR_CHECK(!plan.outputs.empty(), OAR_INTERNAL, "UVDoc: no output returned from inference");
+    const PlanOutput& po = plan.outputs[0];
+    OAR_CHECK(po.dims.size() == 4 && po.dims[0] == 1 && po.dims[1] == 3, OAR_SHAPE_MISMATCH, "UVDoc: expected a [n,3,h,w] output");
+    const uint32_t oh = (uint32_t)po.dims[2], ow = (uint32_t)po.dims[3];
+    const size_t oplane = (size_t)oh * ow;
+    const bool back = ow != w || oh != h;                                   // uvdoc.rs:188-203
+    if (back && oplane * 3 > out_u8_.cap) { OAR_HIP(hipStreamSynchronize(s)); out_u8_.reserve(oplane * 3); }
+    uint8_t* o8 = back ? out_u8_.as<uint8_t>() : dst;
+    pp::bgr_planes_to_rgb(s, eng_->out_ptr(po.loc), (int64_t)oplane, 255.0f, o8);
+    if (back) pp::resize_triangle(s, o8, (int)ow, (int)oh, dst, (int)w, (int)h);
+}
+
+void Rectifier::run_host(const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst) {
+    const size_t bytes = (size_t)w * h * 3;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        OAR_HIP(hipSetDevice(eng_->device()));
+        if (bytes * 2 > io_dev_.cap) { OAR_HIP(hipStreamSynchronize(eng_->stream())); io_dev_.reserve(bytes * 2); }
+        OAR_HIP(hipMemcpyAsync(io_dev_.p, src, bytes, hipMemcpyHostToDevice, eng_->stream()));
+    }
+    run_device(io_dev_.as<uint8_t>(), w, h, io_dev_.as<uint8_t>() + bytes);
+    std::lock_guard<std::mutex> lk(mu_);
+    OAR_HIP(hipMemcpyAsync(dst, io_dev_.as<uint8_t>() + bytes, bytes, hipMemcpyDeviceToHost, eng_->stream()));
+    OAR_HIP(hipStreamSynchronize(eng_->stream()));
+}
+
 // ================================================================================================= OCR pipeline
 Ocr::Ocr(const uint8_t* det, size_t det_len, const uint8_t* rec, size_t rec_len, const oar_ocr_cfg& cfg) : cfg_(cfg) {
     if (cfg_.image_batch_size == 0) cfg_.image_batch_size = 8;     // text_detection_adapter.rs:85-87
@@ -672,16 +830,104 @@ Ocr::Ocr(const uint8_t* det, size_t det_len, const uint8_t* rec, size_t rec_len,
     rec_.reset(new Recognizer(rec, rec_len, cfg_.rec));
 }
 
+// DocumentPreprocessor::preprocess (src/oarocr/preprocess.rs:59-97) for every page: optional orientation class ->
+// rotate (class 1 -> rotate270, 2 -> rotate180, 3 -> rotate90, :128-133), optional UVDoc rectification.  The corrected
+// pages live in pre_pages_ (device); meta_ records what was done so that boxes can be mapped back.
+void Ocr::preprocess_pages(const std::vector<PageRef>& pages, std::vector<PageRef>& cur) {
+    const int n = (int)pages.size();
+    hipStream_t s = det_->engine().stream();
+    cur = pages;
+    meta_.assign(n, PageMeta());
+    // device copies of host pages (the rotate / rectify kernels read device memory)
+    size_t up = 0;
+    for (auto& p : pages) {
+        OAR_CHECK(p.w > 0 && p.h > 0 && (p.host || p.dev), OAR_INVALID_INPUT, "OCR Pipeline: empty page");
+        if (!p.dev) up += ((size_t)p.w * p.h * 3 + 255) & ~(size_t)255;
+    }
+    if (up > upload_pages_.cap) { OAR_HIP(hipStreamSynchronize(s)); upload_pages_.reserve(up); }
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        if (cur[i].dev) continue;
+        uint8_t* d = upload_pages_.as<uint8_t>() + off;
+        const size_t bytes = (size_t)pages[i].w * pages[i].h * 3;
+        OAR_HIP(hipMemcpyAsync(d, pages[i].host, bytes, hipMemcpyHostToDevice, s));
+        cur[i].dev = d; cur[i].host = nullptr;
+        off += (bytes + 255) & ~(size_t)255;
+    }
+    OAR_HIP(hipStreamSynchronize(s));
+    // room for one rotated and one rectified copy of every page
+    size_t need = 0;
+    for (auto& p : pages) need += 2 * (((size_t)p.w * p.h * 3 + 255) & ~(size_t)255);
+    if (need > pre_pages_.cap) pre_pages_.reserve(need);
+    size_t poff = 0;
+    std::vector<int32_t> cls(n, -1);
+    if (doc_cls_) {
+        std::vector<Classifier::Image> imgs(n);
+        for (int i = 0; i < n; ++i) { imgs[i].dev = cur[i].dev; imgs[i].w = cur[i].w; imgs[i].h = cur[i].h; }
+        ClsOut co;
+        doc_cls_->run(imgs, co);   // the pipeline only reads classifications[0] (preprocess.rs:155-159)
+        for (int i = 0; i < n; ++i) cls[i] = co.ids[(size_t)i * co.topk];
+    }
+    for (int i = 0; i < n; ++i) {
+        if (doc_cls_ && cls[i] >= 0) {
+            const int quarter = cls[i] == 1 ? 3 : cls[i] == 2 ? 2 : cls[i] == 3 ? 1 : 0;
+            if (quarter) {
+                uint8_t* d = pre_pages_.as<uint8_t>() + poff;
+                pp::rotate_rgb(s, cur[i].dev, (int)cur[i].w, (int)cur[i].h, quarter, d);
+                poff += ((size_t)cur[i].w * cur[i].h * 3 + 255) & ~(size_t)255;
+                cur[i].dev = d;
+                if (quarter != 2) std::swap(cur[i].w, cur[i].h);
+            }
+            meta_[i].angle = (float)cls[i] * 90.0f;
+            meta_[i].rotated_w = cur[i].w; meta_[i].rotated_h = cur[i].h;
+        }
+    }
+    OAR_HIP(hipStreamSynchronize(s));
+    if (rect_) {
+        for (int i = 0; i < n; ++i) {
+            uint8_t* d = pre_pages_.as<uint8_t>() + poff;
+            rect_->run_device(cur[i].dev, cur[i].w, cur[i].h, d);
+            poff += ((size_t)cur[i].w * cur[i].h * 3 + 255) & ~(size_t)255;
+            cur[i].dev = d;
+            meta_[i].rectified = true;
+        }
+        OAR_HIP(hipStreamSynchronize(rect_->engine().stream()));
+    }
+}
+
 void Ocr::predict(const std::vector<PageRef>& pages, std::vector<std::vector<OcrRegion>>& out) {
     std::lock_guard<std::mutex> lk(mu_);
     OAR_CHECK(!pages.empty(), OAR_INVALID_INPUT, "OCR Pipeline: images must be a non-empty slice");  // ocr.rs:525-532
+    OAR_HIP(hipSetDevice(det_->engine().device()));
+    meta_.assign(pages.size(), PageMeta());
+    if (!doc_cls_ && !rect_) { predict_core(pages, out); return; }
+    std::vector<PageRef> cur;
+    preprocess_pages(pages, cur);
+    predict_core(cur, out);
+    // boxes are mapped back only when the page was rotated and NOT rectified (preprocess.rs:84-89, ocr.rs:644-646,
+    // BoundingBox::rotate_back_to_original geometry.rs:848-889)
+    for (size_t i = 0; i < out.size(); ++i) {
+        const PageMeta& m = meta_[i];
+        if (m.rectified || m.angle < 0.0f) continue;
+        const int a = (int)m.angle;
+        for (auto& r : out[i])
+            for (int k = 0; k < 4; ++k) {
+                const float x = r.pts[2 * k], y = r.pts[2 * k + 1];
+                if (a == 90) { r.pts[2 * k] = (float)m.rotated_h - y; r.pts[2 * k + 1] = x; }
+                else if (a == 180) { r.pts[2 * k] = (float)m.rotated_w - x; r.pts[2 * k + 1] = (float)m.rotated_h - y; }
+                else if (a == 270) { r.pts[2 * k] = y; r.pts[2 * k + 1] = (float)m.rotated_w - x; }
+            }
+    }
+}
+
+void Ocr::predict_core(const std::vector<PageRef>& pages, std::vector<std::vector<OcrRegion>>& out) {
     const int n = (int)pages.size();
     OAR_HIP(hipSetDevice(det_->engine().device()));
     hipStream_t s = det_->engine().stream();
     PhaseTimer timer;
     g_timer = &timer;
     struct TimerReset { ~TimerReset() { g_timer = nullptr; } } timer_reset;
-    struct PoolItem { int img; int det_index; uint32_t w, h; float wh_ratio; size_t off; };
+    struct PoolItem { int img; int det_index; uint32_t w, h; float wh_ratio; size_t off; const uint8_t* rot = nullptr; };
     struct Slot { bool filled = false; OcrRegion r; };
     std::vector<std::vector<Slot>> per_image(n);
     std::vector<PoolItem> pool;
@@ -691,6 +937,31 @@ void Ocr::predict(const std::vector<PageRef>& pages, std::vector<std::vector<Ocr
     auto flush = [&]() {
         if (pool.empty()) return;
         OAR_HIP(hipStreamSynchronize(s));  // crops complete
+        std::vector<float> line_angle(pool.size(), -1.0f);
+        if (line_cls_) {
+            // classify_line_orientations (src/oarocr/ocr.rs:757-790): class 1 => the crop is rotated by 180 degrees
+            std::vector<Classifier::Image> imgs(pool.size());
+            for (size_t i = 0; i < pool.size(); ++i) { imgs[i].dev = crop_pool_.as<uint8_t>() + pool[i].off; imgs[i].w = pool[i].w; imgs[i].h = pool[i].h; }
+            ClsOut co;
+            line_cls_->run(imgs, co);
+            size_t need = 0;
+            for (size_t i = 0; i < pool.size(); ++i)
+                if (co.ids[i * co.topk] == 1) need += ((size_t)pool[i].w * pool[i].h * 3 + 63) & ~(size_t)63;
+            if (need > rot_crops_.cap) rot_crops_.reserve(need);
+            size_t roff = 0;
+            for (size_t i = 0; i < pool.size(); ++i) {
+                const int c = co.ids[i * co.topk];
+                if (c < 0) continue;
+                line_angle[i] = (float)c * 180.0f;
+                per_image[pool[i].img][pool[i].det_index].r.line_angle = line_angle[i];
+                if (c != 1) continue;
+                uint8_t* d = rot_crops_.as<uint8_t>() + roff;
+                pp::rotate_rgb(s, crop_pool_.as<uint8_t>() + pool[i].off, (int)pool[i].w, (int)pool[i].h, 2, d);
+                roff += ((size_t)pool[i].w * pool[i].h * 3 + 63) & ~(size_t)63;
+                pool[i].rot = d;
+            }
+            OAR_HIP(hipStreamSynchronize(s));
+        }
         std::vector<PoolItem> sorted = pool;
         std::stable_sort(sorted.begin(), sorted.end(), [](const PoolItem& a, const PoolItem& b) { return a.wh_ratio < b.wh_ratio; });
         const size_t bs = cfg_.region_batch_size;
@@ -702,7 +973,7 @@ void Ocr::predict(const std::vector<PageRef>& pages, std::vector<std::vector<Ocr
             float cm = base_ratio;
             for (size_t i = c0; i < c1; ++i) {
                 Recognizer::Crop c;
-                c.dev = crop_pool_.as<uint8_t>() + sorted[i].off; c.w = sorted[i].w; c.h = sorted[i].h;
+                c.dev = sorted[i].rot ? sorted[i].rot : crop_pool_.as<uint8_t>() + sorted[i].off; c.w = sorted[i].w; c.h = sorted[i].h;
                 crops.push_back(c);
                 if (sorted[i].wh_ratio > cm) cm = sorted[i].wh_ratio;
             }

@@ -113,6 +113,52 @@ class Recognizer {
     std::mutex mu_;
 };
 
+// PP-LCNet image classifier adapter: DocumentOrientationAdapter / TextLineOrientationAdapter
+// (models/classification/pp_lcnet.rs:139-330, utils/topk.rs:181-199).  SURVEY 8a row a22.
+struct ClsCfg {
+    int32_t device_id = 0;
+    uint32_t input_h = 224, input_w = 224;
+    uint32_t resize_short = 256;   // 0: direct resize to (input_w, input_h) (text-line orientation: 160 x 80)
+    uint32_t topk = 1;
+    uint32_t batch = 64;
+};
+struct ClsOut { std::vector<int32_t> ids; std::vector<float> scores; uint32_t topk = 0, n_classes = 0; };   // n * topk each
+class Classifier {
+   public:
+    Classifier(const uint8_t* onnx, size_t len, const ClsCfg& cfg);
+    struct Image { const uint8_t* host = nullptr; const uint8_t* dev = nullptr; uint32_t w = 0, h = 0; };
+    void run(const std::vector<Image>& images, ClsOut& out);
+    // test hook: the packed input tensor (NCHW) of the images
+    void pack_only(const std::vector<Image>& images, std::vector<float>& nchw);
+    Engine& engine() { return *eng_; }
+    const ClsCfg& cfg() const { return cfg_; }
+
+   private:
+    const float* pack(const std::vector<Image>& images, size_t i0, size_t n, bool nchw);
+    std::unique_ptr<Engine> eng_;
+    ClsCfg cfg_;
+    DevBuf stage_dev_, descs_dev_, input_f32_;
+    PinBuf stage_host_, descs_host_, probs_host_;
+    std::mutex mu_;
+};
+
+// UVDoc rectifier adapter (models/rectification/uvdoc.rs:82-109,166-207).  SURVEY 8a row a23.
+struct RectCfg { int32_t device_id = 0; uint32_t target_h = 512, target_w = 512; };
+class Rectifier {
+   public:
+    Rectifier(const uint8_t* onnx, size_t len, const RectCfg& cfg);
+    // src: device u8 HWC (w x h); dst: device u8 HWC of the SAME size (caller-allocated).  Enqueued on stream(), not synchronised.
+    void run_device(const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst);
+    void run_host(const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst);
+    Engine& engine() { return *eng_; }
+
+   private:
+    std::unique_ptr<Engine> eng_;
+    RectCfg cfg_;
+    DevBuf resized_dev_, input_f32_, out_u8_, io_dev_;
+    std::mutex mu_;
+};
+
 struct OcrRegion {
     float pts[8];
     float det_score;
@@ -120,6 +166,7 @@ struct OcrRegion {
     float max_wh_ratio;
     std::vector<int64_t> idx;
     std::vector<float> prob;
+    float line_angle = -1.0f;   // text-line orientation (0 / 180), -1 when that stage is not attached (ocr.rs:782-783)
 };
 
 // OAROCR (src/oarocr/ocr.rs)
@@ -127,14 +174,26 @@ class Ocr {
    public:
     Ocr(const uint8_t* det, size_t det_len, const uint8_t* rec, size_t rec_len, const oar_ocr_cfg& cfg);
     void predict(const std::vector<PageRef>& pages, std::vector<std::vector<OcrRegion>>& out);
+    // Optional stages of OAROCR (src/oarocr/preprocess.rs:59-97, src/oarocr/ocr.rs:760-790); not owned.
+    void attach(Classifier* doc_orientation, Rectifier* rectifier, Classifier* line_orientation) { doc_cls_ = doc_orientation; rect_ = rectifier; line_cls_ = line_orientation; }
+    struct PageMeta { float angle = -1.0f; bool rectified = false; uint32_t rotated_w = 0, rotated_h = 0; };
+    const std::vector<PageMeta>& page_meta() const { return meta_; }
     Detector& det() { return *det_; }
     Recognizer& rec() { return *rec_; }
 
    private:
+    void predict_core(const std::vector<PageRef>& pages, std::vector<std::vector<OcrRegion>>& out);
+    void preprocess_pages(const std::vector<PageRef>& pages, std::vector<PageRef>& cur);
     std::unique_ptr<Detector> det_;
     std::unique_ptr<Recognizer> rec_;
     oar_ocr_cfg cfg_;
     DevBuf crop_pool_, warp_descs_dev_;
+    Classifier* doc_cls_ = nullptr;
+    Rectifier* rect_ = nullptr;
+    Classifier* line_cls_ = nullptr;
+    std::vector<PageMeta> meta_;
+    DevBuf pre_pages_, rot_crops_;   // corrected pages / rotated crops (device)
+    DevBuf upload_pages_;
     PinBuf warp_descs_host_;
     std::mutex mu_;
 };

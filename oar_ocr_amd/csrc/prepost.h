@@ -53,5 +53,21 @@ struct WarpDesc {          // a14 utils/transform.rs:76-191 (plan computed on th
 };
 void rotate_crops(hipStream_t s, const WarpDesc* d_descs, int n, uint8_t* out_pool, int max_out_pixels);
 
+// ---- config 5
+struct ClsDesc {           // one classifier input image (device-resident u8 HWC)
+    const uint8_t* src;
+    int32_t w, h;          // source size
+    int32_t nw, nh;        // Triangle-resize target (pp_lcnet.rs:158-163 short-edge rule, or the input size itself)
+    int32_t x1, y1;        // centre-crop origin inside the resized image (pp_lcnet.rs:166-169)
+    int32_t pad;
+};
+// a22 models/classification/pp_lcnet.rs:139-196: resize (Triangle) + centre crop + `v*alpha[c] + beta[c]` in RGB order.
+// out: NHWC [n][crop_h][crop_w][3] (nchw == 0) or NCHW.
+void cls_pack(hipStream_t s, const ClsDesc* d_descs, int n, int crop_h, int crop_w, const float alpha[3], const float beta[3], float* out, int nchw);
+// image 0.25 imageops::rotate90 / 180 / 270 (clockwise quarter turns) on u8 RGB; dst is (h x w) for quarter 1, 3.
+void rotate_rgb(hipStream_t s, const uint8_t* src, int w, int h, int quarter, uint8_t* dst);
+// a23 processors/simd.rs:327-348: planes (B, G, R) f32 -> interleaved RGB8 with `(v*scale).clamp(0,255) as u8`.
+void bgr_planes_to_rgb(hipStream_t s, const float* planes, int64_t plane, float scale, uint8_t* out);
+
 }  // namespace pp
 }  // namespace oar

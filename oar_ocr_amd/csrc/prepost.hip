@@ -397,5 +397,70 @@ void rotate_crops(hipStream_t s, const WarpDesc* d_descs, int n, uint8_t* out_po
     hipLaunchKernelGGL(rotate_crops_kernel, dim3(grid_for(max_out_pixels, 256, 64), n), dim3(256), 0, s, d_descs, out_pool);
 }
 
+// ------------------------------------------------------------------------------------------ config 5: a22 / a23
+__global__ __launch_bounds__(256) void cls_pack_kernel(const ClsDesc* descs, int crop_h, int crop_w, NormP np_, float* out, int nchw) {
+    const int n = blockIdx.y;
+    const ClsDesc d = descs[n];
+    const long plane = (long)crop_h * crop_w;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % crop_w), oy = (int)(i / crop_w);
+        uint8_t px[3];
+        // the value of a resized pixel does not depend on the crop: sample the resize at (x1 + ox, y1 + oy) directly
+        resize_pixel(d.src, d.w, d.h, d.nw, d.nh, d.x1 + ox, d.y1 + oy, px);
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { float t = (float)px[np_.src[c]] * np_.alpha[c]; v[c] = t + np_.beta[c]; }
+        if (nchw) {
+            float* o = out + (long)n * 3 * plane + i;
+            o[0] = v[0]; o[plane] = v[1]; o[2 * plane] = v[2];
+        } else {
+            float* o = out + ((long)n * plane + i) * 3;
+            o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+        }
+    }
+}
+void cls_pack(hipStream_t s, const ClsDesc* d_descs, int n, int crop_h, int crop_w, const float alpha[3], const float beta[3], float* out, int nchw) {
+    if (n == 0 || crop_h * crop_w == 0) return;
+    NormP p;
+    for (int i = 0; i < 3; ++i) { p.src[i] = i; p.alpha[i] = alpha[i]; p.beta[i] = beta[i]; }
+    ProfScope ps(s, "cls_pack", 12.0 * (double)n * crop_h * crop_w, 0.0);
+    hipLaunchKernelGGL(cls_pack_kernel, dim3(grid_for((long)crop_h * crop_w, 256, 64), n), dim3(256), 0, s, d_descs, crop_h, crop_w, p, out, nchw);
+}
+
+__global__ __launch_bounds__(256) void rotate_rgb_kernel(const uint8_t* __restrict__ src, int w, int h, int quarter, uint8_t* __restrict__ dst) {
+    const long total = (long)w * h;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w), y = (int)(i / w);
+        long o;
+        if (quarter == 1) o = (long)x * h + (h - 1 - y);
+        else if (quarter == 2) o = (long)(h - 1 - y) * w + (w - 1 - x);
+        else if (quarter == 3) o = (long)(w - 1 - x) * h + y;
+        else o = i;
+        const uint8_t* p = src + i * 3;
+        dst[o * 3] = p[0]; dst[o * 3 + 1] = p[1]; dst[o * 3 + 2] = p[2];
+    }
+}
+void rotate_rgb(hipStream_t s, const uint8_t* src, int w, int h, int quarter, uint8_t* dst) {
+    if ((long)w * h == 0) return;
+    ProfScope ps(s, "rotate_rgb", 6.0 * (double)w * h, 0.0);
+    hipLaunchKernelGGL(rotate_rgb_kernel, dim3(grid_for((long)w * h)), dim3(256), 0, s, src, w, h, quarter, dst);
+}
+
+__global__ __launch_bounds__(256) void bgr_planes_to_rgb_kernel(const float* __restrict__ planes, long plane, float scale, uint8_t* __restrict__ out) {
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < plane; p += (long)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = planes[(long)(2 - c) * plane + p] * scale;
+            v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);       // f32::clamp; `NaN as u8` == 0
+            out[p * 3 + c] = (v != v) ? (uint8_t)0 : (uint8_t)v;   // truncation
+        }
+    }
+}
+void bgr_planes_to_rgb(hipStream_t s, const float* planes, int64_t plane, float scale, uint8_t* out) {
+    if (plane == 0) return;
+    ProfScope ps(s, "bgr_planes_to_rgb", 15.0 * (double)plane, 0.0);
+    hipLaunchKernelGGL(bgr_planes_to_rgb_kernel, dim3(grid_for(plane)), dim3(256), 0, s, planes, (long)plane, scale, out);
+}
+
 }  // namespace pp
 }  // namespace oar

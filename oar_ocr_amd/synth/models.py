@@ -292,3 +292,54 @@ def synth_dict(n_chars=6904):
         chars.append(chr(c))
         c += 1
     return "\n".join(chars[:n_chars]) + "\n"
+
+
+# ---------------------------------------------------------------------------------------------- config 5 graphs
+def build_cls(n_classes=4, seed=5, width=(16, 32, 64, 128)):
+    """PP-LCNet-style image classifier (doc orientation: 4 classes on 224x224; text-line orientation: 2 classes on
+    80x160): stem s2, depthwise-separable stages with SE on the last two, GAP -> 1x1 conv (hswish) -> Flatten ->
+    Gemm -> Softmax.  Input "x" [n,3,H,W] f32, output [n, n_classes] probabilities
+    (oar-ocr-core/src/models/classification/pp_lcnet.rs:207-240 reads output[0] as a 2-D array)."""
+    net = _Net("synth_cls", seed)
+    g = net.g
+    g.add_input("x", ["N", 3, "H", "W"])
+    c0, c1, c2, c3 = width
+    x = net.conv("x", 3, c0, 3, 2, act="hswish")
+    x = net.ds_block(x, c0, c1, 3, 2)
+    x = net.ds_block(x, c1, c2, 3, 2)
+    x = net.ds_block(x, c2, c2, 5, 1, use_se=True)
+    x = net.ds_block(x, c2, c3, 5, 2, use_se=True)
+    x = g.op("GlobalAveragePool", [x])
+    x = net.conv(x, c3, 256, 1, 1, act="hswish")
+    x = g.op("Flatten", [x], axis=1)
+    w = net._w((256, n_classes), 256, gain=8.0)
+    x = g.op("Gemm", [x, g.init(w), g.init(net._b(n_classes, 0.5), "b")])
+    y = g.op("Softmax", [x], axis=-1)
+    g.add_output(y, ["N", n_classes])
+    return g.model(), {"params": g.param_count() if hasattr(g, "param_count") else None, "classes": n_classes}
+
+
+def build_uvdoc(seed=6, width=(16, 32, 64)):
+    """UVDoc-style rectifier stand-in: input "image" [n,3,512,512] BGR in [0,1], output [n,3,512,512] BGR in [0,1]
+    (oar-ocr-core/src/models/rectification/uvdoc.rs:291-293 input name; :166-207 consumes output[0] as 4-D).  Encoder
+    (s2, s2, s2) -> bottleneck -> nearest x2 decoders with skip adds -> 3-channel Sigmoid head."""
+    net = _Net("synth_uvdoc", seed)
+    g = net.g
+    g.add_input("image", ["N", 3, "H", "W"])
+    c0, c1, c2 = width
+    e0 = net.conv("image", 3, c0, 3, 2, act="relu")
+    e1 = net.ds_block(e0, c0, c1, 3, 2, act="relu")
+    e2 = net.ds_block(e1, c1, c2, 3, 2, act="relu")
+    b = net.ds_block(e2, c2, c2, 5, 1, use_se=True, act="relu")
+    scales = g.init(np.array([1.0, 1.0, 2.0, 2.0], np.float32), "scales")
+
+    def up(x):
+        return g.op("Resize", [x, "", scales], mode="nearest", coordinate_transformation_mode="asymmetric", nearest_mode="floor")
+
+    d1 = net.conv(up(b), c2, c1, 3, 1, act="relu")
+    d1 = g.op("Add", [d1, e1])
+    d0 = net.conv(up(d1), c1, c0, 3, 1, act="relu")
+    d0 = g.op("Add", [d0, e0])
+    y = net.conv(up(d0), c0, 3, 3, 1, act="sigmoid")
+    g.add_output(y, ["N", 3, "H", "W"])
+    return g.model(), {"classes": 3}

@@ -352,3 +352,76 @@ def resolve_device_batch_sizes(user_image, user_region, accelerated: bool, model
 def is_cjk(ch: str) -> bool:
     c = ord(ch)
     return (0x4E00 <= c <= 0x9FFF) or (0x3400 <= c <= 0x4DBF) or (0x3040 <= c <= 0x30FF) or (0xAC00 <= c <= 0xD7AF)
+
+
+# ---------------------------------------------------------------------------------------------- config 5 (a22 / a23)
+def cls_resize_dims(w, h, resize_short, crop_w, crop_h):
+    out = np.zeros(4, np.uint32)
+    lib().orc_cls_resize_dims(int(w), int(h), int(resize_short), int(crop_w), int(crop_h), _p(out))
+    return tuple(int(v) for v in out)
+
+
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def cls_preprocess(rgb: np.ndarray, input_hw=(224, 224), resize_short=256) -> np.ndarray:
+    """pp_lcnet.rs:139-196: (short-edge resize + centre crop) or direct resize, Triangle; ImageNet normalisation, RGB, CHW."""
+    h, w, _ = rgb.shape
+    ch, cw = input_hw
+    nw, nh, x1, y1 = cls_resize_dims(w, h, resize_short or 0, cw, ch)
+    img = resize_triangle(rgb, nw, nh) if (nw, nh) != (w, h) else rgb
+    img = np.ascontiguousarray(img[y1:y1 + ch, x1:x1 + cw])
+    a, b = alpha_beta(1.0 / 255.0, IMAGENET_MEAN, IMAGENET_STD)
+    return normalize(img, a, b, src=(0, 1, 2), layout="chw")
+
+
+def topk(scores: np.ndarray, k: int):
+    scores = _f32(scores)
+    idx = np.zeros(k, np.int32); sc = np.zeros(k, np.float32)
+    lib().orc_topk(_p(scores), scores.size, k, _p(idx), _p(sc))
+    return idx, sc
+
+
+def rotate_rgb(rgb: np.ndarray, quarter: int) -> np.ndarray:
+    """image::imageops::rotate90/180/270: clockwise by quarter * 90 degrees."""
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w, _ = rgb.shape
+    out = np.zeros((w, h, 3) if quarter in (1, 3) else (h, w, 3), np.uint8)
+    lib().orc_rotate_rgb(_p(rgb), w, h, int(quarter), _p(out))
+    return out
+
+
+def correct_orientation(rgb: np.ndarray, class_id):
+    """src/oarocr/preprocess.rs:109-141: class 1 -> rotate270, 2 -> rotate180, 3 -> rotate90; returns (image, (angle, rw, rh))."""
+    if class_id is None:
+        return rgb, None
+    q = {1: 3, 2: 2, 3: 1}.get(int(class_id), 0)
+    out = rotate_rgb(rgb, q) if q else rgb
+    return out, (float(class_id) * 90.0, out.shape[1], out.shape[0])
+
+
+def rotate_back_points(pts: np.ndarray, angle: float, rotated_w: int, rotated_h: int) -> np.ndarray:
+    p = np.ascontiguousarray(pts, np.float32).copy()
+    lib().orc_rotate_back_points(_p(p), p.size // 2, C.c_float(angle), int(rotated_w), int(rotated_h))
+    return p
+
+
+def uvdoc_preprocess(rgb: np.ndarray, target_hw=(512, 512)) -> np.ndarray:
+    """uvdoc.rs:82-109 + :296-303: Triangle resize to the target, then v/255 in BGR plane order (no mean shift), CHW."""
+    h, w, _ = rgb.shape
+    th, tw = target_hw
+    img = resize_triangle(rgb, tw, th) if (th > 0 and tw > 0 and (w, h) != (tw, th)) else rgb
+    a, b = alpha_beta(1.0 / 255.0, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+    return normalize(img, a, b, src=(2, 1, 0), layout="chw")
+
+
+def uvdoc_postprocess(pred_chw: np.ndarray, orig_wh) -> np.ndarray:
+    """uvdoc.rs:166-207: BGR planes * 255, clamp, truncate -> RGB8; Triangle resize back to the original size."""
+    c, h, w = pred_chw.shape
+    pl = [np.ascontiguousarray(pred_chw[i], np.float32) for i in range(3)]
+    out = np.zeros((h, w, 3), np.uint8)
+    lib().orc_bgr_planes_to_rgb(_p(pl[0]), _p(pl[1]), _p(pl[2]), h * w, C.c_float(255.0), _p(out))
+    ow, oh = orig_wh
+    if ow and oh and (ow, oh) != (w, h):
+        out = resize_triangle(out, ow, oh)
+    return out

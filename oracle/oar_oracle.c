@@ -849,3 +849,77 @@ int orc_rec_tensor_width(const int32_t* ws, const int32_t* hs, int n, int img_h,
     }
     return (int)tw;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Config-5 stages: PP-LCNet classifier pre/post, orientation correction, UVDoc pre/post.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* models/classification/pp_lcnet.rs:147-190.  resize_short > 0: short edge -> resize_short keeping the ratio
+ * (`(w as f32 * scale).round().max(crop) as u32`), then centre crop; resize_short == 0: direct resize to (crop_w, crop_h).
+ * out4 = {new_w, new_h, x1, y1}. */
+void orc_cls_resize_dims(uint32_t w, uint32_t h, uint32_t resize_short, uint32_t crop_w, uint32_t crop_h, uint32_t* out4) {
+    if (resize_short == 0) { out4[0] = crop_w; out4[1] = crop_h; out4[2] = 0; out4[3] = 0; return; }
+    float shortf = (float)(w < h ? w : h);
+    float scale = (float)resize_short / shortf;
+    float fw = roundf((float)w * scale), fh = roundf((float)h * scale);
+    if (fw < (float)crop_w) fw = (float)crop_w;
+    if (fh < (float)crop_h) fh = (float)crop_h;
+    uint32_t nw = (uint32_t)fw, nh = (uint32_t)fh;
+    out4[0] = nw; out4[1] = nh;
+    out4[2] = (nw > crop_w ? nw - crop_w : 0) / 2;      /* saturating_sub / 2 (pp_lcnet.rs:166-167) */
+    out4[3] = (nh > crop_h ? nh - crop_h : 0) / 2;
+}
+
+/* utils/topk.rs:181-199: (index, score) pairs, STABLE sort by score descending (equal scores keep index order =>
+ * the first index wins), take k. */
+void orc_topk(const float* scores, int n, int k, int32_t* idx_out, float* score_out) {
+    int32_t order[4096];
+    if (n > 4096) n = 4096;
+    for (int i = 0; i < n; ++i) order[i] = i;
+    for (int i = 1; i < n; ++i) {            /* insertion sort = stable */
+        int32_t v = order[i];
+        int j = i - 1;
+        while (j >= 0 && scores[order[j]] < scores[v]) { order[j + 1] = order[j]; --j; }
+        order[j + 1] = v;
+    }
+    for (int i = 0; i < k && i < n; ++i) { idx_out[i] = order[i]; score_out[i] = scores[order[i]]; }
+}
+
+/* image 0.25 imageops::rotate90 / rotate180 / rotate270 (clockwise by quarter * 90 degrees) on RGB8; called at
+ * src/oarocr/preprocess.rs:128-133 and src/oarocr/ocr.rs:785-788.  dst: quarter 1, 3 -> (h x w) image; 2 -> (w x h). */
+void orc_rotate_rgb(const uint8_t* src, int w, int h, int quarter, uint8_t* dst) {
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const uint8_t* p = src + ((long)y * w + x) * 3;
+            long o;
+            if (quarter == 1) o = ((long)x * h + (h - 1 - y));            /* put_pixel(h-1-y, x), dest width h */
+            else if (quarter == 2) o = ((long)(h - 1 - y) * w + (w - 1 - x));
+            else if (quarter == 3) o = ((long)(w - 1 - x) * h + y);       /* put_pixel(y, w-1-x), dest width h */
+            else o = (long)y * w + x;
+            dst[o * 3] = p[0]; dst[o * 3 + 1] = p[1]; dst[o * 3 + 2] = p[2];
+        }
+}
+
+/* processors/geometry.rs:848-889 BoundingBox::rotate_back_to_original: angle as i32 in {90, 180, 270}, else identity */
+void orc_rotate_back_points(float* pts, int n, float angle, uint32_t rotated_w, uint32_t rotated_h) {
+    int a = (int)angle;
+    for (int i = 0; i < n; ++i) {
+        float x = pts[2 * i], y = pts[2 * i + 1];
+        if (a == 90) { pts[2 * i] = (float)rotated_h - y; pts[2 * i + 1] = x; }
+        else if (a == 180) { pts[2 * i] = (float)rotated_w - x; pts[2 * i + 1] = (float)rotated_h - y; }
+        else if (a == 270) { pts[2 * i] = y; pts[2 * i + 1] = (float)rotated_w - x; }
+    }
+}
+
+/* processors/simd.rs:327-348 scale_clamp_bgr_planes_to_rgb: px = ((v * scale).clamp(0, 255)) as u8 (truncation),
+ * planes c0, c1, c2 = B, G, R  ->  interleaved RGB */
+void orc_bgr_planes_to_rgb(const float* c0, const float* c1, const float* c2, long n, float scale, uint8_t* out) {
+    for (long p = 0; p < n; ++p) {
+        const float* src[3] = {c2, c1, c0};
+        for (int c = 0; c < 3; ++c) {
+            float v = src[c][p] * scale;
+            v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);   /* f32::clamp; NaN stays NaN -> `as u8` = 0 */
+            out[p * 3 + c] = (v != v) ? 0 : (uint8_t)v;
+        }
+    }
+}

@@ -63,16 +63,83 @@ class OracleRecognizer:
         return {"texts": texts, "scores": scores, "cols": cols, "idx": idx.reshape(n, T), "prob": pr.reshape(n, T), "probs_full": p, "Wt": x.shape[3]}
 
 
+class OracleClassifier:
+    """DocumentOrientationAdapter / TextLineOrientationAdapter -> PPLCNetModel::forward_refs (pp_lcnet.rs:139-330)."""
+
+    def __init__(self, onnx_bytes, input_hw=(224, 224), resize_short=256, topk=1):
+        self.model = onnx_ref.parse_model(onnx_bytes)
+        self.input = self.model["inputs"][0]
+        self.input_hw, self.resize_short, self.topk = input_hw, resize_short, topk
+
+    def preprocess(self, images):
+        return np.stack([R.cls_preprocess(im, self.input_hw, self.resize_short) for im in images])
+
+    def probs(self, images):
+        return onnx_ref.run(self.model, {self.input: self.preprocess(images)})[0]
+
+    def classify(self, images):
+        """[(class_ids[topk], scores[topk])] per image (utils/topk.rs:181-199)."""
+        return [R.topk(row, min(self.topk, row.size)) for row in self.probs(images)]
+
+
+class OracleRectifier:
+    """UVDocRectifierAdapter -> UVDocModel::forward (uvdoc.rs:82-109,166-207)."""
+
+    def __init__(self, onnx_bytes, target_hw=(512, 512)):
+        self.model = onnx_ref.parse_model(onnx_bytes)
+        self.input = self.model["inputs"][0]
+        self.target_hw = target_hw
+
+    def rectify(self, images):
+        out = []
+        for im in images:
+            x = R.uvdoc_preprocess(im, self.target_hw)[None]
+            y = onnx_ref.run(self.model, {self.input: x})[0]
+            out.append(R.uvdoc_postprocess(y[0], (im.shape[1], im.shape[0])))
+        return out
+
+
 class OracleOCR:
     def __init__(self, det, rec, character_list, thresh=0.3, box_thresh=0.6, unclip=2.0, image_batch_size=8, region_batch_size=64,
-                 max_pooled_crops=4096, **det_kw):
+                 max_pooled_crops=4096, doc_orientation=None, rectifier=None, line_orientation=None, **det_kw):
         self.det = OracleDetector(det, **det_kw)
         self.rec = OracleRecognizer(rec, character_list)
         self.p = (thresh, box_thresh, unclip)
         self.region_bs = region_batch_size
         self.max_pool = max_pooled_crops
+        self.doc_ori = OracleClassifier(doc_orientation) if doc_orientation else None
+        self.rect = OracleRectifier(rectifier) if rectifier else None
+        self.line_ori = OracleClassifier(line_orientation, (80, 160), None) if line_orientation else None
+        self.page_meta = []
+
+    def preprocess(self, image):
+        """DocumentPreprocessor::preprocess (src/oarocr/preprocess.rs:59-97): (image, angle | None, rotation | None, rectified)."""
+        cur, angle, rotation = image, None, None
+        if self.doc_ori is not None:
+            ids, _ = self.doc_ori.classify([image])[0]
+            cur, rotation = R.correct_orientation(image, int(ids[0]))
+            angle = rotation[0]
+        rectified = False
+        if self.rect is not None:
+            cur = self.rect.rectify([cur])[0]
+            rectified = True
+            rotation = None
+        return cur, angle, rotation, rectified
 
     def predict(self, images):
+        """With optional stages attached: slots carry boxes mapped back to the input page unless it was rectified
+        (ocr.rs:644-646, 898-925); page_meta[i] = (orientation_angle | None, rectified)."""
+        pre = [self.preprocess(im) for im in images]
+        self.page_meta = [(p[1], p[3]) for p in pre]
+        res = self._predict_core([p[0] for p in pre])
+        for slots, (_, _, rotation, _) in zip(res, pre):
+            if rotation is None:
+                continue
+            for s in slots:
+                s["box"] = R.rotate_back_points(s["box"], rotation[0], rotation[1], rotation[2]).reshape(4, 2)
+        return res
+
+    def _predict_core(self, images):
         dets = self.det.detect(images, *self.p)
         per_image = []
         pool = []
@@ -96,6 +163,15 @@ class OracleOCR:
     def _flush(self, pool, per_image):
         if not pool:
             return
+        line_angle = [None] * len(pool)
+        if self.line_ori is not None:   # classify_line_orientations (ocr.rs:757-790): class 1 => rotate180 of the crop
+            cls = self.line_ori.classify([c[2] for c in pool])
+            for i, (ids, _) in enumerate(cls):
+                line_angle[i] = float(ids[0]) * 180.0
+                if int(ids[0]) == 1:
+                    pool[i] = (pool[i][0], pool[i][1], R.rotate_rgb(pool[i][2], 2), pool[i][3])
+            for i, (img_idx, k, _, _) in enumerate(pool):
+                per_image[img_idx][k]["line_angle"] = line_angle[i]
         order = sorted(range(len(pool)), key=lambda i: pool[i][3])   # stable, like Rust sort_by
         for c0 in range(0, len(order), self.region_bs):
             chunk = [pool[i] for i in order[c0:c0 + self.region_bs]]
