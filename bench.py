@@ -42,6 +42,10 @@ def main():
     ap.add_argument("--region-batch", type=int, default=256, help="recognition batch (this backend's recommended_batch_size; reference adapter: 64)")
     ap.add_argument("--cpu-pages", type=int, default=3, help="pages in the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--config", type=int, default=1, choices=(1, 2, 4),
+                    help="BASELINE.json configs index: 1 = v6-tiny det+rec on 32 x 960^2 pages (the metric's configuration, default); "
+                         "2 = server-size det + SVTR rec (V=18710) on 64 x 1280^2 pages; 4 = full pipeline (doc orientation + UVDoc + det + rec + "
+                         "text-line orientation) on 16 x 960^2 pages")
     args = ap.parse_args()
 
     import numpy as np
@@ -56,9 +60,14 @@ def main():
     dev = local % api.device_count()
     torch.cuda.set_device(dev)
 
-    det, det_info = models.build_det("tiny", seed=0)
-    rec, rec_info = models.build_rec("tiny", vocab=6906, seed=1)
-    chars = api.read_dict(models.synth_dict(6904))
+    size_name, vocab = ("server", 18710) if args.config == 2 else ("tiny", 6906)
+    if args.config == 2 and args.pages == 32 and args.size == 960:
+        args.pages, args.size = 64, 1280
+    if args.config == 4 and args.pages == 32:
+        args.pages = 16
+    det, det_info = models.build_det(size_name, seed=0)
+    rec, rec_info = models.build_rec(size_name, vocab=vocab, seed=1)
+    chars = api.read_dict(models.synth_dict(vocab - 2))
     n_pages = args.pages
     host_pages = [synth_pages.make_page(rank * n_pages + i, (args.size, args.size), args.lines) for i in range(n_pages)]
     dev_pages = [api.DeviceBuffer(p, dev) for p in host_pages]           # inputs resident in HBM before timing
@@ -67,8 +76,13 @@ def main():
     hs = [args.size] * n_pages
 
     cfg = api.TextDetectionConfig(score_threshold=0.3, box_threshold=0.6, unclip_ratio=1.5)   # examples/ocr.rs:119-133 set
-    ocr = (api.OAROCRBuilder(det, rec, chars).text_detection_config(cfg).image_batch_size(n_pages)
-           .region_batch_size(args.region_batch).device(dev).build())
+    builder = (api.OAROCRBuilder(det, rec, chars).text_detection_config(cfg).image_batch_size(n_pages)
+               .region_batch_size(args.region_batch).device(dev))
+    if args.config == 4:
+        builder = (builder.with_document_image_orientation_classification(models.build_cls(4, seed=5)[0])
+                   .with_document_image_rectification(models.build_uvdoc(seed=6)[0])
+                   .with_text_line_orientation_classification(models.build_cls(2, seed=9)[0]))
+    ocr = builder.build()
 
     def step():
         return ocr.predict_device(ptrs, ws, hs, raw=True)
@@ -159,19 +173,24 @@ def main():
             from oracle import pipeline_ref
             torch.set_num_threads(min(os.cpu_count() or 1, 64))
             sample = host_pages[:args.cpu_pages]
-            oc = pipeline_ref.OracleOCR(det, rec, chars, 0.3, 0.6, 1.5, image_batch_size=1, region_batch_size=16)  # reference CPU policy (builder_utils.rs:111-125)
+            stages = dict(doc_orientation=models.build_cls(4, seed=5)[0], rectifier=models.build_uvdoc(seed=6)[0],
+                          line_orientation=models.build_cls(2, seed=9)[0]) if args.config == 4 else {}
+            oc = pipeline_ref.OracleOCR(det, rec, chars, 0.3, 0.6, 1.5, image_batch_size=1, region_batch_size=16, **stages)  # reference CPU policy (builder_utils.rs:111-125)
             oc.predict(sample[:1])  # warm
             c0 = time.perf_counter()
             oc.predict(sample)
             cdt = time.perf_counter() - c0
             cpu = {"value": round(len(sample) / cdt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-                   "sample": f"{len(sample)} of the same 960x960 synthetic pages, det batch 1 / rec batch 16 (reference CPU defaults); "
+                   "sample": f"{len(sample)} of the same {args.size}x{args.size} synthetic pages, det batch 1 / rec batch 16 (reference CPU defaults); "
                              "oracle = C restatement of pre/post (1 thread) + torch-CPU fp32 network (threads above)"}
         line = {
             "metric": "images/sec end-to-end PP-OCRv6 det+rec", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(tmax / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"PP-OCRv6-tiny-class det+rec (synthetic-weight graphs: det {det_info['params']} params, rec {rec_info['params']} params, V=6906), "
+            "config": {"baseline_config": args.config,
+                       "workload": f"{'PP-OCRv5-server-class det + SVTR rec' if args.config == 2 else 'PP-OCRv6-tiny-class det+rec'}"
+                                   f"{' + doc orientation + UVDoc + text-line orientation' if args.config == 4 else ''} "
+                                   f"(synthetic-weight graphs: det {det_info['params']} params, rec {rec_info['params']} params, V={vocab}), "
                                    f"batch={n_pages} synthetic {args.size}x{args.size} pages per GPU, {args.lines} text lines/page, pages resident in HBM",
                        "pages_per_gpu_per_step": n_pages, "region_batch_size": args.region_batch, "regions_per_step": regions_total,
                        "parallelism": f"image-parallel x{world}"},
