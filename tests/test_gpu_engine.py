@@ -168,13 +168,13 @@ def test_config3_server_size_graphs_match_oracle():
     assert np.allclose(p.sum(-1), 1.0, atol=1e-4)
 
 
-def _conv_graph(cin, cout, k, seed, relu=True):
+def _conv_graph(cin, cout, k, seed, relu=True, group=1, strides=(1, 1)):
     g = GraphBuilder("conv")
     rng = np.random.default_rng(seed)
     g.add_input("x", ["N", cin, "H", "W"])
-    w = (rng.standard_normal((cout, cin, k, k)) * (1.0 / np.sqrt(cin * k * k))).astype(np.float32)
-    y = g.op("Conv", ["x", g.init(w), g.init(rng.standard_normal(cout).astype(np.float32))], kernel_shape=[k, k], strides=[1, 1],
-             pads=[k // 2] * 4, group=1, dilations=[1, 1])
+    w = (rng.standard_normal((cout, cin // group, k, k)) * (1.0 / np.sqrt(cin // group * k * k))).astype(np.float32)
+    y = g.op("Conv", ["x", g.init(w), g.init(rng.standard_normal(cout).astype(np.float32))], kernel_shape=[k, k], strides=list(strides),
+             pads=[k // 2] * 4, group=group, dilations=[1, 1])
     if relu:
         y = g.op("Relu", [y])
     g.add_output(y, ["N", cout, "H", "W"])
@@ -194,3 +194,18 @@ def test_igemm_kernels_at_bench_shapes(case):
     name, n, cin, cout, h, w, k = case
     x = np.random.default_rng(len(name)).standard_normal((n, cin, h, w)).astype(np.float32)
     _check(_conv_graph(cin, cout, k, seed=n + cin), x)
+
+
+@pytest.mark.parametrize("case", [
+    ("5x5 s1 H=6", 16, 192, 6, 160, 5, (1, 1)),            # recognizer shapes: the whole height in three 2-row tiles
+    ("5x5 s(2,1) H=6", 16, 192, 6, 160, 5, (2, 1)),
+    ("5x5 s1 ragged", 3, 128, 61, 75, 5, (1, 1)),          # partial tiles in both directions
+    ("5x5 s2", 2, 64, 90, 90, 5, (2, 2)),
+    ("3x3 s1 C=48", 2, 48, 120, 120, 3, (1, 1)),
+    ("5x5 one row per thread", 1, 128, 20, 20, 5, (1, 1)), # too few threads for 2-row tiles
+])
+def test_depthwise_kernels_at_bench_shapes(case):
+    """The register-tiled depthwise kernel (kernels.hip) at the bench's layer shapes, against torch-CPU conv2d."""
+    name, n, c, h, w, k, strides = case
+    x = np.random.default_rng(len(name)).standard_normal((n, c, h, w)).astype(np.float32)
+    _check(_conv_graph(c, c, k, seed=n + c, group=c, strides=strides), x)
