@@ -78,6 +78,12 @@ def main():
     cfg = api.TextDetectionConfig(score_threshold=0.3, box_threshold=0.6, unclip_ratio=1.5)   # examples/ocr.rs:119-133 set
     builder = (api.OAROCRBuilder(det, rec, chars).text_detection_config(cfg).image_batch_size(n_pages)
                .region_batch_size(args.region_batch).device(dev))
+    if world > 1:
+        # one process per GPU shares the host: give each rank's geometry pool its slice of the cores (the pool spins
+        # between bursts, so oversubscribed ranks would fight each other for cycles)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        builder = builder.host_threads(max(2, min(16, cpus // max(local_world, 1) - 1)))
     if args.config == 4:
         builder = (builder.with_document_image_orientation_classification(models.build_cls(4, seed=5)[0])
                    .with_document_image_rectification(models.build_uvdoc(seed=6)[0])

@@ -56,6 +56,18 @@ void Profiler::begin(hipStream_t s, int c, double bytes, double flops) {
         pending.push_back(p);
     }
 }
+bool Profiler::begin_ext(int c, double bytes, double flops, hipEvent_t& a, hipEvent_t& b) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (capturing) return false;
+    Pending p;
+    p.a = a = ev();
+    p.b = b = ev();
+    p.cls = c;
+    p.bytes = bytes;
+    p.flops = flops;
+    pending.push_back(p);
+    return true;
+}
 void Profiler::end(hipStream_t s) {
     std::lock_guard<std::mutex> lk(mu);
     if (capturing) {

@@ -117,6 +117,11 @@ struct Profiler {
     int cls(const char* name);
     hipEvent_t ev();
     void begin(hipStream_t s, int cls, double bytes, double flops);
+    // Events for ONE kernel launched with hipExtLaunchKernelGGL(..., a, b, 0, ...): they are bound to the dispatch's own
+    // completion signal (its begin / end timestamps), so the stream carries no extra barrier packets -- two
+    // hipEventRecord calls around a kernel cost ~6 us of idle queue on either side of it (rocprofv3 kernel trace).
+    // Returns false while a graph is being captured (use begin / end there).
+    bool begin_ext(int cls, double bytes, double flops, hipEvent_t& a, hipEvent_t& b);
     void end(hipStream_t s);
     void flush();  // requires the streams to be idle
     void reset();
@@ -125,14 +130,23 @@ struct Profiler {
 struct ProfScope {
     hipStream_t s;
     bool on;
-    ProfScope(hipStream_t s_, const char* name, double bytes, double flops) : s(s_) {
+    bool ext = false;
+    hipEvent_t a = nullptr, b = nullptr;
+    // single_launch: the scope covers exactly one kernel and the launch site passes start() / stop() to
+    // hipExtLaunchKernelGGL (null events = a plain launch).
+    ProfScope(hipStream_t s_, const char* name, double bytes, double flops, bool single_launch = false) : s(s_) {
         Profiler& p = Profiler::get();
         on = p.enabled && (p.filter.empty() || p.filter == name);
-        if (on) p.begin(s, p.cls(name), bytes, flops);
+        if (!on) return;
+        const int c = p.cls(name);
+        if (single_launch && p.begin_ext(c, bytes, flops, a, b)) ext = true;
+        else p.begin(s, c, bytes, flops);
     }
     ~ProfScope() {
-        if (on) Profiler::get().end(s);
+        if (on && !ext) Profiler::get().end(s);
     }
+    hipEvent_t start() const { return ext ? a : nullptr; }
+    hipEvent_t stop() const { return ext ? b : nullptr; }
 };
 
 }  // namespace oar

@@ -7,6 +7,7 @@
 // Wave = 64 lanes everywhere.  Compiled with -ffp-contract=off; FMAs are written explicitly.
 #include "kernels.h"
 
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -149,7 +150,7 @@ void conv_dw(hipStream_t s, const ConvP& p) {
     char pname[96];
     const char* cls = "conv_dw";
     if (Profiler::get().detail) { snprintf(pname, sizeof pname, "conv_dw px=%ld C=%d k%d s%d", (long)p.N * p.Ho * p.Wo, p.Cout, p.kh, p.sh); cls = pname; }
-    ProfScope ps(s, cls, bytes, flops);
+    ProfScope ps(s, cls, bytes, flops, /*single_launch=*/true);
     const bool sq = p.kh == p.kw && p.dh == 1 && p.dw == 1;
     constexpr int TW = 4;
     // output rows per thread: the tallest tile that still leaves >= 4 resident workgroups' worth of threads per CU
@@ -161,7 +162,7 @@ void conv_dw(hipStream_t s, const ConvP& p) {
     dim3 g((grid_for(tiled) + 7) / 8 * 8), b(256);
     const size_t lds = (size_t)p.kh * p.kw * p.Cout * sizeof(float);
     const bool fits = lds <= 64 * 1024;
-#define DW2(KV, SHV, SWV, THV) hipLaunchKernelGGL((conv_dw_tiled_kernel<KV, SHV, SWV, TW, THV>), g, b, lds, s, p)
+#define DW2(KV, SHV, SWV, THV) hipExtLaunchKernelGGL((conv_dw_tiled_kernel<KV, SHV, SWV, TW, THV>), g, b, lds, s, ps.start(), ps.stop(), 0, p)
 #define DW(KV, SHV, SWV)                                   \
     do {                                                   \
         if (TH == 2) DW2(KV, SHV, SWV, 2);                 \
@@ -175,7 +176,7 @@ void conv_dw(hipStream_t s, const ConvP& p) {
     else if (fits && sq && p.kh == 5 && p.sh == 2 && p.sw == 2) DW(5, 2, 2);
     else if (fits && sq && p.kh == 5 && p.sh == 2 && p.sw == 1) DW(5, 2, 1);
     else if (fits && sq && p.kh == 5 && p.sh == 1 && p.sw == 2) DW(5, 1, 2);
-    else hipLaunchKernelGGL(conv_dw_kernel, dim3(grid_for(total)), b, 0, s, p);
+    else hipExtLaunchKernelGGL(conv_dw_kernel, dim3(grid_for(total)), b, 0, s, ps.start(), ps.stop(), 0, p);
 #undef DW2
 #undef DW
 }
