@@ -749,11 +749,11 @@ def prof_reset():
     lib().oar_prof_reset()
 
 
-def prof_snapshot():
-    arr = (ProfEntry * 64)()
-    n = lib().oar_prof_snapshot(arr, 64)
+def prof_snapshot(max_entries: int = 512):
+    arr = (ProfEntry * max_entries)()
+    n = lib().oar_prof_snapshot(arr, max_entries)
     return [{"name": arr[i].name.decode(), "launches": int(arr[i].launches), "total_ms": arr[i].total_ms,
-             "alg_bytes": arr[i].alg_bytes, "alg_flops": arr[i].alg_flops} for i in range(min(n, 64))]
+             "alg_bytes": arr[i].alg_bytes, "alg_flops": arr[i].alg_flops} for i in range(min(n, max_entries))]
 
 
 # stand-alone kernels (parity hooks)

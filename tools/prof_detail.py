@@ -17,6 +17,6 @@ snap=api.prof_snapshot()
 print('step ms',dt*1e3, r)
 tot=sum(e['total_ms'] for e in snap)
 print('total kernel ms',tot, 'classes',len(snap))
-for e in snap[:64]:
+for e in snap:
     ms=e['total_ms']; 
     print(f"{e['name']:60s} n={e['launches']:4d} ms={ms:8.3f} us/launch={ms*1e3/max(e['launches'],1):8.1f} GB/s={e['alg_bytes']/ms/1e6 if ms else 0:8.1f} TF={e['alg_flops']/ms/1e9 if ms else 0:6.2f}")
