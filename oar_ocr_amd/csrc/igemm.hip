@@ -122,6 +122,84 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmP p) {  // 2 wa
     igemm_epilogue<NT, PF>(p, acc, m0, pl_, g, nf0, !bias_in_acc);
 }
 
+// Latency variant for launches too small to hide memory latency behind other waves (SE / SVTR projections, the
+// coarse FPN levels: a few hundred wave tiles).  The per-tile kernel above keeps one chunk in flight, so such a launch
+// costs ~(KC + 1) load round trips (8 us at K = 64, 15 us at K = 256, whatever M is); here D = 4 chunks are in flight
+// per wave (a register ring; D * (NT + 1) float4s), the arithmetic and the epilogue are the same.
+template <int NT, bool IS1X1>
+__global__ __launch_bounds__(256, 2) void conv_igemm_small_kernel(IgemmP p) {
+    constexpr int D = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pl_ = lane & 15, g = lane >> 4;
+    const long b = blockIdx.x;
+    const int ntile = (int)(b % p.ny);
+    const long m0 = ((b / p.ny) * 4 + wave) * 16;
+    const int nf0 = ntile * NT;
+    if (m0 >= p.M) return;
+    long pix_base;
+    int ih0 = 0, iw0 = 0;
+    {
+        const long m = min(m0 + pl_, p.M - 1);   // rows past M: clamped loads, never stored
+        if (IS1X1) {
+            pix_base = m * (long)p.Cin;
+        } else {
+            const long hw = (long)p.Ho * p.Wo;
+            const long n = m / hw, r = m - n * hw;
+            const int oh = (int)(r / p.Wo), ow = (int)(r - (long)oh * p.Wo);
+            pix_base = n * (long)p.H * p.W * p.Cin;
+            ih0 = oh * p.sh - p.pt; iw0 = ow * p.sw - p.pl;
+        }
+    }
+    f32x4 acc[NT][1];
+    const bool bias_in_acc = igemm_init_acc<NT, 1>(p, acc, g, nf0);
+    const float4* wf = reinterpret_cast<const float4*>(p.w) + ((long)nf0 * p.KC) * 64 + lane;
+
+    float4 xs[D], ws[D][NT];
+    bool ok[D];
+    auto request = [&](int kc_, int d) {
+        const int kc = min(kc_, p.KC - 1);   // past the end: a harmless re-read keeps every load unconditional
+        const int k = min(kc * 16 + 4 * g, p.K - 4);
+        if (IS1X1) {
+            xs[d] = *reinterpret_cast<const float4*>(p.x + pix_base + k);
+            ok[d] = true;
+        } else {
+            const int tap = (int)__umulhi((unsigned)k, p.cin_magic), ci = k - tap * p.Cin;
+            const int tap_h = (int)__umulhi((unsigned)tap, p.kw_magic), tap_w = tap - tap_h * p.kw;
+            const int ih = ih0 + tap_h * p.dh, iw = iw0 + tap_w * p.dw;
+            ok[d] = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
+            xs[d] = *reinterpret_cast<const float4*>(p.x + pix_base + ((long)ihc * p.W + iwc) * p.Cin + ci);
+        }
+#pragma clang loop unroll(full)
+        for (int nf = 0; nf < NT; ++nf) ws[d][nf] = wf[((long)nf * p.KC + kc) * 64];
+    };
+    auto comp = [](const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; };
+    auto consume = [&](int d) {
+        float4 v = xs[d];
+        if (!IS1X1) { v.x = ok[d] ? v.x : 0.f; v.y = ok[d] ? v.y : 0.f; v.z = ok[d] ? v.z : 0.f; v.w = ok[d] ? v.w : 0.f; }
+#pragma clang loop unroll(full)
+        for (int j = 0; j < 4; ++j)
+#pragma clang loop unroll(full)
+            for (int nf = 0; nf < NT; ++nf)
+                acc[nf][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(ws[d][nf], j), comp(v, j), acc[nf][0], 0, 0, 0);
+    };
+#pragma clang loop unroll(full)
+    for (int d = 0; d < D; ++d) request(d, d);
+    int kc = 0;
+    for (; kc + D <= p.KC; kc += D) {
+#pragma clang loop unroll(full)
+        for (int d = 0; d < D; ++d) {
+            consume(d);
+            request(kc + d + D, d);
+        }
+    }
+    const int rem = p.KC - kc;   // stages 0 .. rem-1 hold the last chunks
+#pragma clang loop unroll(full)
+    for (int d = 0; d < D - 1; ++d)
+        if (d < rem) consume(d);
+    igemm_epilogue<NT, 1>(p, acc, m0, pl_, g, nf0, !bias_in_acc);
+}
+
 // (The bf16x6 arithmetic -- exact 3-way bf16 split of both operands, six MFMAs per product -- lives in igemm_ws_x6.hip.)
 
 // cout fragments per LDS-resident tile of the x6 kernel for this K (0: does not fit)
@@ -216,6 +294,9 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     }
     const bool ws3 = !x6 && !c.ctc_part && conv_igemm_ws3_eligible(p, nfrag);
     const bool ws = ws_nt > 0 || ws3;
+    // launches of at most `small_max` wave tiles are latency-bound: the deep-prefetch variant (OAR_IGEMM_SMALL=0 disables)
+    static const long small_max = [] { const char* e = getenv("OAR_IGEMM_SMALL"); return e ? atol(e) : 4096L; }();
+    const bool small = !x6 && !ws && ((p.M + 15) / 16) * ny <= small_max;
     double flops = 2.0 * (double)p.M * p.K * p.gemm_cout;
     double bytes = 4.0 * ((double)c.N * c.H * c.W * c.Cin + (double)p.M * p.gemm_cout + (double)p.K * p.gemm_cout);
     char pname[96];
@@ -247,6 +328,18 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
         const size_t lds = (size_t)ws_nt * p.KC * 1024 + (size_t)ws_nt * 64 + 16;
         if (is1x1) conv_igemm_ws_1x1(s, p, ws_nt, wny, lds);
         else conv_igemm_ws_gen(s, p, ws_nt, wny, lds);
+    } else if (small) {
+        const dim3 sgrid((unsigned)(((p.M + 63) / 64) * ny));
+#define LAUNCH_SMALL(NTV)                                                                                          \
+    do {                                                                                                          \
+        if (is1x1) hipLaunchKernelGGL((conv_igemm_small_kernel<NTV, true>), sgrid, dim3(256), 0, s, p);        \
+        else hipLaunchKernelGGL((conv_igemm_small_kernel<NTV, false>), sgrid, dim3(256), 0, s, p);             \
+    } while (0)
+        if (NT == 4) LAUNCH_SMALL(4);
+        else if (NT == 3) LAUNCH_SMALL(3);
+        else if (NT == 2) LAUNCH_SMALL(2);
+        else LAUNCH_SMALL(1);
+#undef LAUNCH_SMALL
     } else if (NT == 4) LAUNCH(4);
     else if (NT == 3) LAUNCH(3);
     else if (NT == 2) LAUNCH(2);
