@@ -258,6 +258,95 @@ void Engine::rewrite_graph(OnnxModel& m) {
         for (int i = 0; i < (int)nodes.size(); ++i) if (!dead[i]) keep.push_back(std::move(nodes[i]));
         nodes.swap(keep);
     }
+    // ---- pass 5: the SVTR global-attention block (EncoderWithSVTR), as the recognizer exports emit it:
+    //   Reshape[0,-1,3,h,d] -> Transpose[2,0,3,1,4] -> Split(axis 0) -> 3 x Squeeze[0] -> (Mul by a scalar on q) ->
+    //   MatMul(q, Transpose[0,1,3,2](k)) -> Softmax(-1) -> MatMul(., v) -> Transpose[0,2,1,3] -> Reshape[0,-1,h*d]
+    // becomes ONE Attention node that reads the [n, T, 3*h*d] projection in place (12 glue kernels + 2 batched GEMMs +
+    // softmax -> 1 kernel).  OAR_FUSE_ATTENTION=0 keeps the op-by-op path.
+    {
+        const char* fe = getenv("OAR_FUSE_ATTENTION");
+        const bool fuse = !fe || atoi(fe) != 0;
+        auto cons = consumers(nodes);
+        std::map<std::string, int> producer;
+        for (int i = 0; i < (int)nodes.size(); ++i) for (auto& o : nodes[i].out) producer[o] = i;
+        std::vector<bool> dead(nodes.size(), false);
+        auto prod = [&](const std::string& v, const char* op) -> int {
+            auto it = producer.find(v);
+            if (it == producer.end() || dead[it->second] || nodes[it->second].op != op) return -1;
+            return it->second;
+        };
+        auto single_use = [&](const std::string& v) { return cons[v].size() == 1 && !graph_outs.count(v); };
+        auto ints_of = [&](const std::string& v) -> std::vector<int64_t> {
+            auto it = inits_.find(v);
+            return it == inits_.end() ? std::vector<int64_t>{} : it->second.i;
+        };
+        auto perm_is = [&](const GNode& t, std::initializer_list<int64_t> want) { return t.ais("perm") == std::vector<int64_t>(want); };
+        auto squeeze0 = [&](const GNode& q) {
+            std::vector<int64_t> ax = q.in.size() > 1 ? ints_of(q.in[1]) : q.ais("axes");
+            return ax.size() == 1 && ax[0] == 0;
+        };
+        for (int i = 0; fuse && i < (int)nodes.size(); ++i) {
+            if (nodes[i].op != "Softmax" || dead[i]) continue;
+            const GNode& sm = nodes[i];
+            const int64_t sax = sm.ai("axis", -1);
+            if (sax != -1 && sax != 3) continue;
+            const int mm1 = prod(sm.in[0], "MatMul");
+            if (mm1 < 0 || !single_use(sm.in[0]) || !single_use(sm.out[0])) continue;
+            const int mm2 = cons[sm.out[0]][0];
+            if (nodes[mm2].op != "MatMul" || nodes[mm2].in[0] != sm.out[0]) continue;
+            // q side: Squeeze [-> Mul scalar]
+            float scale = 1.0f;
+            std::string qv = nodes[mm1].in[0];
+            int mul = prod(qv, "Mul");
+            if (mul >= 0) {
+                if (!single_use(qv)) continue;
+                int ci = is_init(nodes[mul].in[1]) ? 1 : is_init(nodes[mul].in[0]) ? 0 : -1;
+                if (ci < 0) continue;
+                const HostTensor& sc = inits_[nodes[mul].in[ci]];
+                if (sc.dtype != DType::F32 || sc.f.size() != 1) continue;
+                scale = sc.f[0];
+                qv = nodes[mul].in[1 - ci];
+            }
+            const int sq_q = prod(qv, "Squeeze");
+            const int tk = prod(nodes[mm1].in[1], "Transpose");
+            if (sq_q < 0 || tk < 0 || !single_use(qv) || !single_use(nodes[mm1].in[1]) || !perm_is(nodes[tk], {0, 1, 3, 2})) continue;
+            const int sq_k = prod(nodes[tk].in[0], "Squeeze");
+            const int sq_v = prod(nodes[mm2].in[1], "Squeeze");
+            if (sq_k < 0 || sq_v < 0 || !single_use(nodes[tk].in[0]) || !single_use(nodes[mm2].in[1])) continue;
+            if (!squeeze0(nodes[sq_q]) || !squeeze0(nodes[sq_k]) || !squeeze0(nodes[sq_v])) continue;
+            const int sp = prod(nodes[sq_q].in[0], "Split");
+            if (sp < 0 || nodes[sp].out.size() != 3 || nodes[sp].ai("axis", 0) != 0) continue;
+            if (nodes[sq_q].in[0] != nodes[sp].out[0] || nodes[sq_k].in[0] != nodes[sp].out[1] || nodes[sq_v].in[0] != nodes[sp].out[2]) continue;
+            if (!single_use(nodes[sp].out[0]) || !single_use(nodes[sp].out[1]) || !single_use(nodes[sp].out[2])) continue;
+            const int t1 = prod(nodes[sp].in[0], "Transpose");
+            if (t1 < 0 || !single_use(nodes[sp].in[0]) || !perm_is(nodes[t1], {2, 0, 3, 1, 4})) continue;
+            const int r1 = prod(nodes[t1].in[0], "Reshape");
+            if (r1 < 0 || !single_use(nodes[t1].in[0]) || nodes[r1].in.size() < 2) continue;
+            const std::vector<int64_t> shp = ints_of(nodes[r1].in[1]);
+            if (shp.size() != 5 || shp[0] != 0 || shp[1] != -1 || shp[2] != 3 || shp[3] <= 0 || shp[4] <= 0 || shp[4] > 64) continue;
+            // output side: Transpose[0,2,1,3] -> Reshape[0,-1,h*d]
+            if (!single_use(nodes[mm2].out[0])) continue;
+            const int t2 = cons[nodes[mm2].out[0]][0];
+            if (nodes[t2].op != "Transpose" || !perm_is(nodes[t2], {0, 2, 1, 3}) || !single_use(nodes[t2].out[0])) continue;
+            const int r2 = cons[nodes[t2].out[0]][0];
+            if (nodes[r2].op != "Reshape" || nodes[r2].in.size() < 2) continue;
+            const std::vector<int64_t> shp2 = ints_of(nodes[r2].in[1]);
+            if (shp2.size() != 3 || shp2[0] != 0 || shp2[1] != -1 || shp2[2] != shp[3] * shp[4]) continue;
+            GNode at;
+            at.op = "Attention";
+            at.in = {nodes[r1].in[0]};
+            at.out = {nodes[r2].out[0]};
+            Attr ah; ah.kind = Attr::I; ah.i = shp[3]; at.attrs["heads"] = ah;
+            Attr ad; ad.kind = Attr::I; ad.i = shp[4]; at.attrs["head_dim"] = ad;
+            Attr as; as.kind = Attr::F; as.f = scale; at.attrs["scale"] = as;
+            for (int d : {r1, t1, sp, sq_q, sq_k, sq_v, tk, mm1, i, mm2, t2}) dead[d] = true;
+            if (mul >= 0) dead[mul] = true;
+            nodes[r2] = std::move(at);   // the last node of the block: its input is long computed
+        }
+        std::vector<GNode> keep;
+        for (int i = 0; i < (int)nodes.size(); ++i) if (!dead[i]) keep.push_back(std::move(nodes[i]));
+        nodes.swap(keep);
+    }
     for (int i = 0; i < (int)nodes.size(); ++i) nodes[i].id = i;
     nodes_ = std::move(nodes);
 }
@@ -1188,6 +1277,20 @@ struct Planner {
         Loc yl = y.loc;
         step([=](const RunCtx& c) { k::softmax_lastdim(c.s, c.at(xin), c.mut(yl), rows, (int)C); }, 4.0 * rows * C, 8.0 * rows * C);
     }
+    // fused SVTR attention (rewrite pass 5): x [n, T, 3*h*d] (q | k | v, each [h][d]) -> [n, T, h*d]
+    void op_attention(const GNode& n) {
+        TInfo x = get(n.in[0]);
+        const int64_t h = n.ai("heads", 1), d = n.ai("head_dim", 1);
+        OAR_CHECK(x.dims.size() == 3 && x.dims[2] == 3 * h * d, OAR_SHAPE_MISMATCH, "Attention: input must be [n, T, 3*heads*head_dim]");
+        const int64_t N = x.dims[0], T = x.dims[1];
+        OAR_CHECK(2 * T * d * 4 <= 150 * 1024, OAR_UNSUPPORTED_OP, "Attention: K and V of one head must fit LDS");
+        Loc xin = to_native_loc(x);
+        TInfo& y = new_out(n.out[0], {N, T, h * d}, Layout::NATIVE);
+        Loc yl = y.loc;
+        const float scale = n.af("scale", 1.0f);
+        step([=](const RunCtx& c) { k::attention(c.s, c.at(xin), c.mut(yl), (int)N, (int)T, (int)h, (int)d, scale); },
+             4.0 * N * h * T * T * d, 4.0 * N * T * 4 * h * d);
+    }
     bool E_opset13() const { return opset >= 13 || opset == 0; }
     int64_t opset = 17;
 
@@ -1347,6 +1450,7 @@ struct Planner {
         if (op == "Gemm") return op_linear(n, true);
         if (op == "MatMul") return op_matmul(n);
         if (op == "Softmax") return op_softmax(n);
+        if (op == "Attention") return op_attention(n);
         if (op == "LayerNormalization") return op_layernorm(n);
         if (op == "Identity") { const TInfo& x = get(n.in[0]); if (x.host_int) { vals[n.out[0]] = x; } else { TInfo xx = x; alias_out(n.out[0], xx, xx.dims, xx.layout); } return; }
         if (op == "Cast") { const TInfo& x = get(n.in[0]); OAR_CHECK(n.ai("to", 1) == 1, OAR_UNSUPPORTED_OP, "Cast of a device tensor to non-f32"); TInfo xx = x; alias_out(n.out[0], xx, xx.dims, xx.layout); return; }

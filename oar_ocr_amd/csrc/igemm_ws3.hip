@@ -44,12 +44,17 @@ __global__ __launch_bounds__(1024) void conv_igemm_ws3_kernel(IgemmWs3P q) {
     const int team = j % q.groups, member = j / q.groups, team_size = (per_xcd - team + q.groups - 1) / q.groups;
     float* lds_bias = reinterpret_cast<float*>(ws_lds + (long)NT * p.KC * 64);
     unsigned* ws_ctr = reinterpret_cast<unsigned*>(lds_bias + NT * 16);
-    long wt_begin, wt_count;
+    // The XCD's band of tiles is dealt CYCLICALLY to its workgroups (tile = band start + u * team_size + member): at any
+    // moment the ~512 tiles in flight on the XCD are one compact run of ~30 image rows, so the kh = 0 / 2 re-reads of
+    // the rows above and below hit this XCD's L2.  (With one contiguous sub-band per workgroup each of the 32 workgroups
+    // kept its own three rows alive -- 12 MB against a 4 MB L2 -- and the input was fetched 3x.)
+    long wt_begin, wt_count, wt_stride;
     {
         const long x0 = (long)xcd * q.wt_per_xcd, x1 = min(q.wt_total, x0 + q.wt_per_xcd);
-        const long n_x = max(0L, x1 - x0), share = (n_x + team_size - 1) / team_size;
-        wt_begin = x0 + (long)member * share;
-        wt_count = max(0L, min(share, x1 - wt_begin));
+        const long n_x = max(0L, x1 - x0);
+        wt_stride = team_size;
+        wt_begin = x0 + member;
+        wt_count = n_x > member ? (n_x - member + team_size - 1) / team_size : 0;
     }
     constexpr int NL = PF + 2;                 // loads per step: PF centre fragments + left / right halo pixel
     const int CC = p.Cin >> 4;                 // 16-channel chunks per tap
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(1024) void conv_igemm_ws3_kernel(IgemmWs3P q) {
         long u = grab();
         if (u >= wt_count) continue;
         Tile cur, nxt;
-        tile_of(wt_begin + u, cur);
+        tile_of(wt_begin + u * wt_stride, cur);
         Stage s0, s1, s2;
         auto stage = [&](auto Ic) -> Stage& {
             constexpr int I = decltype(Ic)::value % 3;
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(1024) void conv_igemm_ws3_kernel(IgemmWs3P q) {
         for (;;) {
             const long un = grab();
             const bool has_next = un < wt_count;
-            tile_of(wt_begin + (has_next ? un : u), nxt);
+            tile_of(wt_begin + (has_next ? un : u) * wt_stride, nxt);
             run_tile();
             if (!has_next) break;
             const int rot = NSTEP % 3;   // = 0 (NSTEP = 3 * CC), kept for clarity: steps 0 / 1 of the next tile sit in stages 0 / 1

@@ -84,6 +84,8 @@ void gemm_batched(hipStream_t s, const GemmP& p);
 
 void layernorm(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C, float eps);
 void softmax_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C);
+// softmax(scale * q k^T) v per (image, head); qkv [n][T][3][heads][hd] row-major, out [n][T][heads][hd]; hd <= 64
+void attention(hipStream_t s, const float* qkv, float* out, int n, int T, int heads, int hd, float scale);
 // softmax over the last dim fused with CTC argmax (last max index wins) -- see kernels.hip
 // CTC head without logits: conv_igemm with ConvP::ctc_part set writes {max, sum exp, last arg max} per (row, cout tile
 // of 128 columns); ctc_combine merges the tiles of each row into the arg max index and its softmax probability.

@@ -817,5 +817,88 @@ void softmax_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int 
     }
 }
 
+// ------------------------------------------------------------------------------------------ SVTR attention
+// softmax(scale * q k^T) v for one (image, head) per workgroup: K and V of the head sit in LDS (rows padded to HD with
+// zeros), one thread per query row.  Two passes over the keys (row maximum, then exp / sum / weighted V), all in f32
+// with explicit FMAs in ascending key / channel order -- the arithmetic of the Mul -> MatMul -> Softmax -> MatMul chain
+// it replaces, without the [n, heads, T, T] score tensor or the q / k / v transposes ever reaching HBM.
+template <int HD>
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T, int heads, int hd, float scale) {
+    extern __shared__ float4 att_lds[];   // K [T][HD] | V [T][HD]
+    constexpr int H4 = HD / 4;
+    float4* Ks = att_lds;
+    float4* Vs = att_lds + (long)T * H4;
+    const int n = blockIdx.x / heads, h = blockIdx.x - n * heads, dim = heads * hd;
+    const float* base = qkv + (long)n * T * 3 * dim + h * hd;
+    float* Kf = reinterpret_cast<float*>(Ks);
+    float* Vf = reinterpret_cast<float*>(Vs);
+    for (int i = threadIdx.x; i < T * HD; i += blockDim.x) {
+        const int t = i / HD, d = i - t * HD;
+        float kv = 0.f, vv = 0.f;
+        if (d < hd) { kv = base[(long)t * 3 * dim + dim + d]; vv = base[(long)t * 3 * dim + 2 * dim + d]; }
+        Kf[i] = kv; Vf[i] = vv;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        float q[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) q[d] = d < hd ? base[(long)t * 3 * dim + d] * scale : 0.f;
+        auto score = [&](int j) {
+            float a = 0.f;
+#pragma unroll
+            for (int d4 = 0; d4 < H4; ++d4) {
+                const float4 kk = Ks[j * H4 + d4];
+                a = fmaf(q[4 * d4], kk.x, a); a = fmaf(q[4 * d4 + 1], kk.y, a); a = fmaf(q[4 * d4 + 2], kk.z, a); a = fmaf(q[4 * d4 + 3], kk.w, a);
+            }
+            return a;
+        };
+        float m = -3.402823466e38f;
+#pragma unroll 4
+        for (int j = 0; j < T; ++j) m = fmaxf(m, score(j));
+        float l = 0.f;
+        float o[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) o[d] = 0.f;
+#pragma unroll 4
+        for (int j = 0; j < T; ++j) {
+            const float p = expf(score(j) - m);
+            l += p;
+#pragma unroll
+            for (int d4 = 0; d4 < H4; ++d4) {
+                const float4 vv = Vs[j * H4 + d4];
+                o[4 * d4] = fmaf(p, vv.x, o[4 * d4]); o[4 * d4 + 1] = fmaf(p, vv.y, o[4 * d4 + 1]);
+                o[4 * d4 + 2] = fmaf(p, vv.z, o[4 * d4 + 2]); o[4 * d4 + 3] = fmaf(p, vv.w, o[4 * d4 + 3]);
+            }
+        }
+        float* y = out + ((long)n * T + t) * dim + h * hd;
+#pragma unroll
+        for (int d = 0; d < HD; ++d)
+            if (d < hd) y[d] = o[d] / l;
+    }
+}
+
+template <int HD>
+static void launch_attention(hipStream_t s, const float* qkv, float* out, int n, int T, int heads, int hd, float scale) {
+    static const bool once = [] {
+        OAR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        return true;
+    }();
+    (void)once;
+    const size_t lds = (size_t)2 * T * HD * sizeof(float);
+    OAR_CHECK(lds <= 150 * 1024, OAR_UNSUPPORTED_OP, "attention: K and V of one head exceed the LDS staging buffer");
+    const int threads = std::min(256, (T + 63) / 64 * 64);
+    hipLaunchKernelGGL((attention_kernel<HD>), dim3((unsigned)(n * heads)), dim3(threads), lds, s, qkv, out, T, heads, hd, scale);
+}
+
+void attention(hipStream_t s, const float* qkv, float* out, int n, int T, int heads, int hd, float scale) {
+    if (n == 0 || T == 0) return;
+    OAR_CHECK(hd >= 1 && hd <= 64, OAR_UNSUPPORTED_OP, "attention: head_dim must be in 1..=64");
+    const double nh = (double)n * heads;
+    ProfScope ps(s, "attention", 4.0 * nh * T * 4.0 * hd, 4.0 * nh * T * T * hd);
+    if (hd <= 16) launch_attention<16>(s, qkv, out, n, T, heads, hd, scale);
+    else if (hd <= 32) launch_attention<32>(s, qkv, out, n, T, heads, hd, scale);
+    else launch_attention<64>(s, qkv, out, n, T, heads, hd, scale);
+}
+
 }  // namespace k
 }  // namespace oar

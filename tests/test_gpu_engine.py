@@ -209,3 +209,41 @@ def test_depthwise_kernels_at_bench_shapes(case):
     name, n, c, h, w, k, strides = case
     x = np.random.default_rng(len(name)).standard_normal((n, c, h, w)).astype(np.float32)
     _check(_conv_graph(c, c, k, seed=n + c, group=c, strides=strides), x)
+
+
+def _attention_graph(dim, heads, seed, scaled=True):
+    """LayerNorm-free SVTR attention block exactly as the recognizer graphs emit it (synth/models.py)."""
+    g = GraphBuilder("attn")
+    rng = np.random.default_rng(seed)
+    hd = dim // heads
+    g.add_input("x", ["N", "T", dim])
+    w = (rng.standard_normal((dim, 3 * dim)) / np.sqrt(dim)).astype(np.float32)
+    qkv = g.op("MatMul", ["x", g.init(w)])
+    qkv = g.op("Add", [qkv, g.init((0.1 * rng.standard_normal(3 * dim)).astype(np.float32))])
+    qkv = g.op("Reshape", [qkv, g.init(np.array([0, -1, 3, heads, hd], np.int64), "shape")])
+    qkv = g.op("Transpose", [qkv], perm=[2, 0, 3, 1, 4])
+    q, k, v = g.op("Split", [qkv], n_out=3, axis=0)
+    ax0 = g.init(np.array([0], np.int64), "axes")
+    q, k, v = g.op("Squeeze", [q, ax0]), g.op("Squeeze", [k, ax0]), g.op("Squeeze", [v, ax0])
+    if scaled:
+        q = g.op("Mul", [q, g.init(np.array(hd ** -0.5, np.float32), "scale")])
+    att = g.op("Softmax", [g.op("MatMul", [q, g.op("Transpose", [k], perm=[0, 1, 3, 2])])], axis=-1)
+    o = g.op("Transpose", [g.op("MatMul", [att, v])], perm=[0, 2, 1, 3])
+    o = g.op("Reshape", [o, g.init(np.array([0, -1, dim], np.int64), "shape")])
+    g.add_output(o, ["N", "T", dim])
+    return g.model()
+
+
+@pytest.mark.parametrize("case", [
+    ("tiny rec head", 64, 4, 7, 40, True),
+    ("server rec head", 192, 6, 3, 100, True),
+    ("odd head_dim, no scale", 45, 3, 2, 37, False),       # head_dim 15: zero-padded to 16 in LDS
+    ("long line", 64, 1, 2, 300, True),                    # head_dim 64, query loop (T > 256), 150 KB of K / V
+])
+def test_fused_attention_matches_oracle(case):
+    """Rewrite pass 5: the whole q / k / v split -> softmax(q k^T) v -> merge block runs as one kernel after the projection."""
+    name, dim, heads, n, T, scaled = case
+    model = _attention_graph(dim, heads, seed=len(name), scaled=scaled)
+    x = np.random.default_rng(n + T).standard_normal((n, T, dim)).astype(np.float32)
+    _check(model, x)
+    assert api.OrtInfer(model).cost((n, T, dim))[2] <= 3       # Linear + Attention (+ output copy); 14 op by op
