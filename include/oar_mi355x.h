@@ -316,6 +316,11 @@ void oar_prof_reset(void);
 void oar_prof_enable(int32_t on);
 /* Restrict instrumentation to one kernel class (NULL or "" = all): keeps event overhead out of a timed region. */
 void oar_prof_filter(const char* class_name);
+/* Time only every stride-th launch of the instrumented class(es): launches are counted from this call, launch i is
+   timed iff i % stride == phase (stride <= 1: every launch; phase < 0: none).  A caller that rotates phase over the
+   steps of a region times every launch position equally often at 1/stride of the event overhead (an event-bracketed
+   kernel costs ~11 us of idle queue around it). */
+void oar_prof_sampling(int32_t stride, int32_t phase);
 /* Fills up to cap entries, sorted by total_ms descending; returns the number of classes. */
 int32_t oar_prof_snapshot(oar_prof_entry* entries, int32_t cap);
 

@@ -99,7 +99,7 @@ EXPORTS = [
     "oar_db_postprocess", "oar_rec_create", "oar_rec_destroy", "oar_rec_run", "oar_rec_result_free", "oar_ocr_create", "oar_ocr_destroy",
     "oar_ocr_predict", "oar_ocr_predict_device", "oar_ocr_result_free", "oar_dev_alloc", "oar_dev_upload", "oar_dev_download",
     "oar_dev_free", "oar_dev_synchronize", "oar_k_normalize", "oar_k_rec_preprocess", "oar_k_resize_triangle", "oar_k_threshold",
-    "oar_k_ctc_argmax", "oar_k_box_scores", "oar_k_rotate_crop", "oar_prof_reset", "oar_prof_enable", "oar_prof_filter", "oar_prof_snapshot",
+    "oar_k_ctc_argmax", "oar_k_box_scores", "oar_k_rotate_crop", "oar_prof_reset", "oar_prof_enable", "oar_prof_filter", "oar_prof_sampling", "oar_prof_snapshot",
     "oar_host_candidates", "oar_host_unclip", "oar_host_mini_box", "oar_host_sort_quad_boxes", "oar_host_plan_crop",
     "oar_cls_create", "oar_cls_destroy", "oar_cls_run", "oar_cls_result_free", "oar_cls_preprocess", "oar_rect_create", "oar_rect_destroy",
     "oar_rect_run", "oar_ocr_attach", "oar_k_rotate_rgb", "oar_k_bgr_planes_to_rgb", "oar_host_rotate_back_points",
@@ -192,6 +192,8 @@ def lib():
     L.oar_prof_enable.restype = None
     L.oar_prof_filter.argtypes = [C.c_char_p]
     L.oar_prof_filter.restype = None
+    L.oar_prof_sampling.argtypes = [C.c_int32, C.c_int32]
+    L.oar_prof_sampling.restype = None
     L.oar_prof_snapshot.argtypes = [C.POINTER(ProfEntry), C.c_int32]
     L.oar_prof_snapshot.restype = C.c_int32
     _lib = L
@@ -743,6 +745,11 @@ def prof_enable(on: bool = True):
 
 def prof_filter(name: str = ""):
     lib().oar_prof_filter(name.encode() if name else None)
+
+
+def prof_sampling(stride: int = 1, phase: int = 0):
+    """Time launch i (counted from this call) iff i % stride == phase; phase < 0: none."""
+    lib().oar_prof_sampling(stride, phase)
 
 
 def prof_reset():

@@ -685,6 +685,12 @@ void oar_prof_enable(int32_t on) {
     std::lock_guard<std::mutex> lk(p.mu);
     if (p.enabled != (on != 0)) { p.enabled = on != 0; ++p.epoch; }
 }
+void oar_prof_sampling(int32_t stride, int32_t phase) {
+    Profiler& p = Profiler::get();
+    p.sample_stride.store(stride < 1 ? 1 : stride, std::memory_order_relaxed);
+    p.sample_phase.store(phase, std::memory_order_relaxed);
+    p.sample_counter.store(0, std::memory_order_relaxed);
+}
 void oar_prof_filter(const char* cls) {
     Profiler& p = Profiler::get();
     p.flush();

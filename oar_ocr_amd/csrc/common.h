@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -105,6 +106,9 @@ struct Profiler {
     void harvest(GraphEvents& g);    // the graph's last launch must have been submitted; synchronises on its events
     void release(GraphEvents& g);    // harvest + give the events back to the pool
     bool enabled = false;
+    // launch sampling (oar_prof_sampling): launch i since the last call is timed iff i % stride == phase
+    std::atomic<int> sample_stride{1}, sample_phase{0};
+    std::atomic<long> sample_counter{0};
     bool detail = false;  // OAR_PROF_DETAIL=1: split conv classes by shape
     std::string filter;  // when non-empty only this kernel class is instrumented
     std::vector<std::string> names;
@@ -137,6 +141,11 @@ struct ProfScope {
     ProfScope(hipStream_t s_, const char* name, double bytes, double flops, bool single_launch = false) : s(s_) {
         Profiler& p = Profiler::get();
         on = p.enabled && (p.filter.empty() || p.filter == name);
+        if (on && !Profiler::capturing) {   // (a captured graph keeps every event node: sampling cannot vary per replay)
+            const int stride = p.sample_stride.load(std::memory_order_relaxed), phase = p.sample_phase.load(std::memory_order_relaxed);
+            if (phase < 0) on = false;
+            else if (stride > 1) on = (p.sample_counter.fetch_add(1, std::memory_order_relaxed) % stride) == phase;
+        }
         if (!on) return;
         const int c = p.cls(name);
         if (single_launch && p.begin_ext(c, bytes, flops, a, b)) ext = true;
