@@ -144,6 +144,13 @@ Detector::Detector(const uint8_t* onnx, size_t len, const oar_det_cfg& cfg) : cf
     if (cfg_.max_candidates == 0) cfg_.max_candidates = 1000;
     eng_.reset(new Engine(onnx, len, cfg_.device_id));
     pool_.reset(new ThreadPool(cfg_.host_threads));
+    OAR_HIP(hipSetDevice(eng_->device()));
+    OAR_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+}
+Detector::~Detector() {
+    if (copy_stream_) { (void)hipStreamSynchronize(copy_stream_); (void)hipStreamDestroy(copy_stream_); }
+    for (hipEvent_t e : sub_events_) (void)hipEventDestroy(e);
+    for (hipEvent_t e : mask_ready_) (void)hipEventDestroy(e);
 }
 
 namespace {
@@ -361,6 +368,7 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
     }
     mask_host_.reserve((size_t)B * hw);
     while ((int)sub_events_.size() < nsub) { hipEvent_t e; OAR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); sub_events_.push_back(e); }
+    while ((int)mask_ready_.size() < nsub) { hipEvent_t e; OAR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); mask_ready_.push_back(e); }
 
     float* probs = probs_keep_.as<float>();   // [B][H][W] channel-0 planes, kept for the score kernel
     size_t rs_off = 0;
@@ -387,9 +395,11 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
         // only channel 0 is used (processors/db_postprocess.rs:122-123); keep it past the next sub-batch's arena reuse
         k::copy2d(s, eng_->out_ptr(po.loc), probs + (size_t)b0 * hw, nb, (int)hw, (int)(hw * C), (int)hw);
         pp::threshold(s, probs + (size_t)b0 * hw, mask_dev_.as<uint8_t>() + (size_t)b0 * hw, (int64_t)nb * hw, thresh);
+        OAR_HIP(hipEventRecord(mask_ready_[sb], s));
+        OAR_HIP(hipStreamWaitEvent(copy_stream_, mask_ready_[sb], 0));
         OAR_HIP(hipMemcpyAsync(mask_host_.as<uint8_t>() + (size_t)b0 * hw, mask_dev_.as<uint8_t>() + (size_t)b0 * hw, (size_t)nb * hw,
-                               hipMemcpyDeviceToHost, s));
-        OAR_HIP(hipEventRecord(sub_events_[sb], s));
+                               hipMemcpyDeviceToHost, copy_stream_));
+        OAR_HIP(hipEventRecord(sub_events_[sb], copy_stream_));
     }
     tmark("det_enqueue");
 

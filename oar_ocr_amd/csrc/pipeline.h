@@ -52,6 +52,7 @@ struct DetBoxes {             // per image, discovery order
 class Detector {
    public:
     Detector(const uint8_t* onnx, size_t len, const oar_det_cfg& cfg);
+    ~Detector();
     // Pages may be host or device resident. dev_pages_out (optional) receives the device pointer of each page
     // (uploaded copies stay valid until the next call).
     void run(const std::vector<PageRef>& pages, float thresh, float box_thresh, float unclip, std::vector<DetBoxes>& out,
@@ -73,7 +74,10 @@ class Detector {
     DevBuf padded_dev_;
     std::vector<const uint8_t*> det_src_;
     std::vector<uint32_t> det_w_, det_h_;
-    std::vector<hipEvent_t> sub_events_;
+    std::vector<hipEvent_t> sub_events_, mask_ready_;
+    // mask read-back runs on its own stream: a D2H copy is a blit KERNEL on the queue it is issued to (150 us per 9-page
+    // sub-batch over PCIe), which on the engine stream held up the next sub-batch's network
+    hipStream_t copy_stream_ = nullptr;
     PinBuf mask_host_, boxes_host_, scores_host_;
     std::vector<const uint8_t*> page_ptrs_;
     std::mutex mu_;
