@@ -43,6 +43,7 @@ inline void tmark(const char* n) { if (g_timer) g_timer->mark(n); }
 
 // ================================================================================================= thread pool
 ThreadPool::ThreadPool(int n) {
+    if (n <= 0) { const char* e = getenv("OAR_HOST_THREADS"); n = e ? atoi(e) : 0; }
     if (n <= 0) n = std::min<int>((int)std::thread::hardware_concurrency(), 16);
     if (n <= 0) n = 1;
     if (n > 64) n = 64;
@@ -146,11 +147,14 @@ Detector::Detector(const uint8_t* onnx, size_t len, const oar_det_cfg& cfg) : cf
     pool_.reset(new ThreadPool(cfg_.host_threads));
     OAR_HIP(hipSetDevice(eng_->device()));
     OAR_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+    OAR_HIP(hipStreamCreateWithFlags(&score_stream_, hipStreamNonBlocking));
 }
 Detector::~Detector() {
     if (copy_stream_) { (void)hipStreamSynchronize(copy_stream_); (void)hipStreamDestroy(copy_stream_); }
+    if (score_stream_) { (void)hipStreamSynchronize(score_stream_); (void)hipStreamDestroy(score_stream_); }
     for (hipEvent_t e : sub_events_) (void)hipEventDestroy(e);
     for (hipEvent_t e : mask_ready_) (void)hipEventDestroy(e);
+    for (hipEvent_t e : score_done_) (void)hipEventDestroy(e);
 }
 
 namespace {
@@ -266,7 +270,7 @@ void finish_boxes(const std::vector<Candidate>& cands, const float* scores, int 
 }  // namespace
 
 void Detector::run(const std::vector<PageRef>& pages, float thresh, float box_thresh, float unclip, std::vector<DetBoxes>& out,
-                   std::vector<const uint8_t*>* dev_pages_out) {
+                   std::vector<const uint8_t*>* dev_pages_out, const ReadyFn& on_ready) {
     std::lock_guard<std::mutex> lk(mu_);
     const int n = (int)pages.size();
     out.assign(n, DetBoxes());
@@ -321,11 +325,15 @@ void Detector::run(const std::vector<PageRef>& pages, float thresh, float box_th
         for (auto& g : groups) if (g.rh == rh && g.rw == rw) { g.idx.push_back(i); placed = true; break; }
         if (!placed) groups.push_back({rh, rw, {i}});
     }
-    for (auto& g : groups) run_group(g.idx, pages, g.rh, g.rw, thresh, box_thresh, unclip, out);
+    // one shape group (the common case): pages become final sub-batch by sub-batch, in page order.  Several groups: the
+    // groups interleave page indices, so the callback fires once at the end to keep the caller's page order.
+    const bool stream_out = on_ready && groups.size() == 1;
+    for (auto& g : groups) run_group(g.idx, pages, g.rh, g.rw, thresh, box_thresh, unclip, out, stream_out ? on_ready : ReadyFn());
+    if (on_ready && !stream_out) on_ready(0, n);
 }
 
 void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>& pages, uint32_t rh, uint32_t rw, float thresh,
-                         float box_thresh, float unclip, std::vector<DetBoxes>& out) {
+                         float box_thresh, float unclip, std::vector<DetBoxes>& out, const ReadyFn& on_ready) {
     // The group is cut into sub-batches whose GPU work (normalize -> network -> threshold -> mask D2H) is enqueued
     // back to back; the host traces the contours of sub-batch i while the GPU is already on sub-batch i+1.
     // Pages are independent in detection, so the result is identical to one big batch.
@@ -403,49 +411,59 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
     }
     tmark("det_enqueue");
 
+    // Software pipeline over the sub-batches, while the GPU runs the later ones:
+    //   wait mask(sb) -> contours(sb) (host) -> enqueue the box-score kernel of sb on the score stream (it shares the GPU
+    //   with the next sub-batch's network and is slow there, ~0.7 ms, but nobody waits for it: its result is read one
+    //   contour pass later) -> finish(sb-1): box scores back -> unclip / scale (host) -> on_ready.
+    // Only the last, half-size sub-batch's contours + scores + unclip are exposed.
     std::vector<std::vector<Candidate>> cands(B);
     const uint8_t* mh = mask_host_.as<uint8_t>();
     const uint32_t maxc = cfg_.max_candidates;
+    while ((int)score_slots_.size() < nsub) score_slots_.emplace_back(new ScoreSlot());
+    while ((int)score_done_.size() < nsub) { hipEvent_t e; OAR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); score_done_.push_back(e); }
+    auto finish = [&](int sb) {
+        const int b0 = sb_off[sb], nb = sb_off[sb + 1] - b0;
+        ScoreSlot& sl = *score_slots_[sb];
+        if (sl.total) OAR_HIP(hipEventSynchronize(score_done_[sb]));
+        tmark("box_scores_wait");
+        const float* sc = sl.scores_host.as<float>();
+        pool_->parallel_for(nb, [&](int k) {
+            const PageRef& pg = pages[idx[b0 + k]];
+            finish_boxes(cands[b0 + k], sc + sl.base[k], H, W, pg.w, pg.h, box_thresh, unclip, out[idx[b0 + k]]);
+        });
+        tmark("host_unclip");
+        if (on_ready) { on_ready(idx[b0], nb); tmark("crop_plan+warp"); }
+    };
     for (int sb = 0; sb < nsub; ++sb) {
         const int b0 = sb_off[sb], nb = sb_off[sb + 1] - b0;
         OAR_HIP(hipEventSynchronize(sub_events_[sb]));
         tmark("det_gpu_wait");
         subbatch_candidates(*pool_, mh + (size_t)b0 * hw, hw, H, W, nb, maxc, &cands[b0]);
         tmark("host_contours");
-    }
-
-    size_t total = 0;
-    std::vector<size_t> base(B + 1, 0);
-    for (int b = 0; b < B; ++b) { base[b] = total; total += cands[b].size(); }
-    base[B] = total;
-    std::vector<float> scores(total, 0.f);
-    if (total) {
-        boxes_host_.reserve(total * sizeof(pp::ScoreBox));
-        scores_host_.reserve(total * sizeof(float));
-        if (total * sizeof(pp::ScoreBox) > boxes_dev_.cap || total * sizeof(float) > scores_dev_.cap) {
-            OAR_HIP(hipStreamSynchronize(s));
-            boxes_dev_.reserve(total * sizeof(pp::ScoreBox));
-            scores_dev_.reserve(total * sizeof(float));
+        ScoreSlot& sl = *score_slots_[sb];
+        sl.base.assign(nb + 1, 0);
+        size_t total = 0;
+        for (int k = 0; k < nb; ++k) { sl.base[k] = total; total += cands[b0 + k].size(); }
+        sl.base[nb] = total; sl.total = total;
+        if (total) {
+            sl.boxes_host.reserve(total * sizeof(pp::ScoreBox)); sl.scores_host.reserve(total * sizeof(float));
+            sl.boxes_dev.reserve(total * sizeof(pp::ScoreBox)); sl.scores_dev.reserve(total * sizeof(float));
+            pp::ScoreBox* sbx = sl.boxes_host.as<pp::ScoreBox>();
+            for (int k = 0; k < nb; ++k)
+                for (size_t i = 0; i < cands[b0 + k].size(); ++i) {
+                    pp::ScoreBox& x = sbx[sl.base[k] + i];
+                    std::memcpy(x.pts, cands[b0 + k][i].pts, sizeof x.pts);
+                    x.image = b0 + k; x.pad = 0;
+                }
+            OAR_HIP(hipMemcpyAsync(sl.boxes_dev.p, sbx, total * sizeof(pp::ScoreBox), hipMemcpyHostToDevice, score_stream_));
+            pp::box_scores(score_stream_, probs, H, W, sl.boxes_dev.as<pp::ScoreBox>(), (int)total, sl.scores_dev.as<float>());
+            OAR_HIP(hipMemcpyAsync(sl.scores_host.p, sl.scores_dev.p, total * sizeof(float), hipMemcpyDeviceToHost, score_stream_));
+            OAR_HIP(hipEventRecord(score_done_[sb], score_stream_));
         }
-        pp::ScoreBox* sbx = boxes_host_.as<pp::ScoreBox>();
-        for (int b = 0; b < B; ++b)
-            for (size_t i = 0; i < cands[b].size(); ++i) {
-                pp::ScoreBox& x = sbx[base[b] + i];
-                std::memcpy(x.pts, cands[b][i].pts, sizeof x.pts);
-                x.image = b; x.pad = 0;
-            }
-        OAR_HIP(hipMemcpyAsync(boxes_dev_.p, sbx, total * sizeof(pp::ScoreBox), hipMemcpyHostToDevice, s));
-        pp::box_scores(s, probs, H, W, boxes_dev_.as<pp::ScoreBox>(), (int)total, scores_dev_.as<float>());
-        OAR_HIP(hipMemcpyAsync(scores_host_.p, scores_dev_.p, total * sizeof(float), hipMemcpyDeviceToHost, s));
-        OAR_HIP(hipStreamSynchronize(s));
-        std::memcpy(scores.data(), scores_host_.p, total * sizeof(float));
+        tmark("box_scores_enqueue");
+        if (sb > 0) finish(sb - 1);   // its scores were enqueued one contour pass ago
     }
-    tmark("box_scores_roundtrip");
-    pool_->parallel_for(B, [&](int b) {
-        const PageRef& pg = pages[idx[b]];
-        finish_boxes(cands[b], scores.data() + base[b], H, W, pg.w, pg.h, box_thresh, unclip, out[idx[b]]);
-    });
-    tmark("host_unclip");
+    finish(nsub - 1);
     if (Profiler::get().enabled) Profiler::get().flush();
 }
 
@@ -1016,71 +1034,81 @@ void Ocr::predict_core(const std::vector<PageRef>& pages, std::vector<std::vecto
         std::vector<PageRef> chunk(pages.begin() + start, pages.begin() + end);
         std::vector<DetBoxes> boxes;
         std::vector<const uint8_t*> dev_pages;
-        det_->run(chunk, cfg_.det_thresh, cfg_.det_box_thresh, cfg_.det_unclip_ratio, boxes, &dev_pages);
-        // sort + plan crops (host), then one warp launch for the whole chunk
-        struct Planned { int img; int det_index; host::CropPlan plan; };
-        std::vector<Planned> planned;
-        for (int li = 0; li < end - start; ++li) {
-            const int img = start + li;
-            std::vector<int> order = host::sort_quad_boxes(boxes[li].pts);
-            per_image[img].resize(order.size());
-            for (size_t k = 0; k < order.size(); ++k) {
-                Slot& sl = per_image[img][k];
-                std::memcpy(sl.r.pts, boxes[li].pts.data() + (size_t)order[k] * 8, sizeof sl.r.pts);
-                sl.r.det_score = boxes[li].scores[order[k]];
-                host::CropPlan pl = host::plan_crop((int)pages[img].w, (int)pages[img].h, sl.r.pts);
-                if (pl.mode == 0) continue;  // crop failure => region dropped (ocr.rs:736-738)
-                sl.r.crop_w = (uint32_t)pl.out_w(); sl.r.crop_h = (uint32_t)pl.out_h();
-                planned.push_back({img, (int)k, pl});
+        size_t desc_used = 0;   // warp descriptors of this chunk already handed to the GPU (each launch gets its own slots)
+        // Called by the detector as soon as the boxes of pages [first, first + count) of the chunk are final (the GPU is
+        // still on later pages): sort + plan the crops on the host, one warp launch for those pages.
+        auto plan_pages = [&](int first, int count) {
+            struct Planned { int img; int det_index; host::CropPlan plan; };
+            std::vector<Planned> planned;
+            for (int li = first; li < first + count; ++li) {
+                const int img = start + li;
+                std::vector<int> order = host::sort_quad_boxes(boxes[li].pts);
+                per_image[img].resize(order.size());
+                for (size_t k = 0; k < order.size(); ++k) {
+                    Slot& sl = per_image[img][k];
+                    std::memcpy(sl.r.pts, boxes[li].pts.data() + (size_t)order[k] * 8, sizeof sl.r.pts);
+                    sl.r.det_score = boxes[li].scores[order[k]];
+                    host::CropPlan pl = host::plan_crop((int)pages[img].w, (int)pages[img].h, sl.r.pts);
+                    if (pl.mode == 0) continue;  // crop failure => region dropped (ocr.rs:736-738)
+                    sl.r.crop_w = (uint32_t)pl.out_w(); sl.r.crop_h = (uint32_t)pl.out_h();
+                    planned.push_back({img, (int)k, pl});
+                }
             }
-        }
-        size_t pi = 0;
-        while (pi < planned.size()) {
-            // respect the pool cap exactly like the reference's per-crop flush check
-            size_t room = cfg_.max_pooled_crops - pool.size();
-            size_t take = std::min(room, planned.size() - pi);
-            size_t add_bytes = 0;
-            int max_px = 0;
-            for (size_t q = pi; q < pi + take; ++q) {
-                const host::CropPlan& pl = planned[q].plan;
-                add_bytes += ((size_t)pl.out_w() * pl.out_h() * 3 + 63) & ~(size_t)63;
-                max_px = std::max(max_px, pl.out_w() * pl.out_h());
+            size_t pi = 0;
+            while (pi < planned.size()) {
+                // respect the pool cap exactly like the reference's per-crop flush check
+                size_t room = cfg_.max_pooled_crops - pool.size();
+                size_t take = std::min(room, planned.size() - pi);
+                size_t add_bytes = 0;
+                int max_px = 0;
+                for (size_t q = pi; q < pi + take; ++q) {
+                    const host::CropPlan& pl = planned[q].plan;
+                    add_bytes += ((size_t)pl.out_w() * pl.out_h() * 3 + 63) & ~(size_t)63;
+                    max_px = std::max(max_px, pl.out_w() * pl.out_h());
+                }
+                if (pool_bytes + add_bytes > crop_pool_.cap) {
+                    // grow while preserving existing crops
+                    OAR_HIP(hipStreamSynchronize(s));
+                    DevBuf bigger;
+                    bigger.reserve((pool_bytes + add_bytes) * 2);
+                    if (pool_bytes) OAR_HIP(hipMemcpy(bigger.p, crop_pool_.p, pool_bytes, hipMemcpyDeviceToDevice));
+                    std::swap(bigger.p, crop_pool_.p); std::swap(bigger.cap, crop_pool_.cap);
+                }
+                const size_t need_desc = (desc_used + take) * sizeof(pp::WarpDesc);
+                if (need_desc > warp_descs_dev_.cap || need_desc > warp_descs_host_.cap) {
+                    OAR_HIP(hipStreamSynchronize(s));   // earlier launches may still read the buffers that are about to move
+                    const size_t want = std::max<size_t>(2 * take * sizeof(pp::WarpDesc), 8192 * sizeof(pp::WarpDesc));
+                    warp_descs_host_.reserve(want); warp_descs_dev_.reserve(want);
+                    desc_used = 0;
+                }
+                pp::WarpDesc* wd = warp_descs_host_.as<pp::WarpDesc>() + desc_used;
+                pp::WarpDesc* wd_dev = warp_descs_dev_.as<pp::WarpDesc>() + desc_used;
+                for (size_t q = 0; q < take; ++q) {
+                    const Planned& P = planned[pi + q];
+                    const host::CropPlan& pl = P.plan;
+                    pp::WarpDesc& d = wd[q];
+                    d.page = dev_pages[P.img - start]; d.page_w = (int)pages[P.img].w; d.page_h = (int)pages[P.img].h;
+                    d.left = pl.left; d.top = pl.top; d.cw = pl.cw; d.ch = pl.ch; d.ow = pl.ow; d.oh = pl.oh; d.rot = pl.rot; d.mode = pl.mode;
+                    std::memcpy(d.inv, pl.inv, sizeof d.inv);
+                    d.out_off = (int64_t)pool_bytes;
+                    PoolItem it;
+                    it.img = P.img; it.det_index = P.det_index; it.w = (uint32_t)pl.out_w(); it.h = (uint32_t)pl.out_h();
+                    it.wh_ratio = (float)it.w / (float)std::max<uint32_t>(it.h, 1);  // ocr.rs:739
+                    it.off = pool_bytes;
+                    pool.push_back(it);
+                    pool_bytes += ((size_t)it.w * it.h * 3 + 63) & ~(size_t)63;
+                }
+                OAR_HIP(hipMemcpyAsync(wd_dev, wd, take * sizeof(pp::WarpDesc), hipMemcpyHostToDevice, s));
+                pp::rotate_crops(s, wd_dev, (int)take, crop_pool_.as<uint8_t>(), max_px);
+                desc_used += take;
+                pi += take;
+                if (pool.size() >= cfg_.max_pooled_crops) { flush(); desc_used = 0; }
             }
-            if (pool_bytes + add_bytes > crop_pool_.cap) {
-                // grow while preserving existing crops
-                OAR_HIP(hipStreamSynchronize(s));
-                DevBuf bigger;
-                bigger.reserve((pool_bytes + add_bytes) * 2);
-                if (pool_bytes) OAR_HIP(hipMemcpy(bigger.p, crop_pool_.p, pool_bytes, hipMemcpyDeviceToDevice));
-                std::swap(bigger.p, crop_pool_.p); std::swap(bigger.cap, crop_pool_.cap);
-            }
-            warp_descs_host_.reserve(take * sizeof(pp::WarpDesc));
-            if (take * sizeof(pp::WarpDesc) > warp_descs_dev_.cap) { OAR_HIP(hipStreamSynchronize(s)); warp_descs_dev_.reserve(take * sizeof(pp::WarpDesc)); }
-            else OAR_HIP(hipStreamSynchronize(s));  // previous launch may still read the pinned descriptors
-            pp::WarpDesc* wd = warp_descs_host_.as<pp::WarpDesc>();
-            for (size_t q = 0; q < take; ++q) {
-                const Planned& P = planned[pi + q];
-                const host::CropPlan& pl = P.plan;
-                pp::WarpDesc& d = wd[q];
-                d.page = dev_pages[P.img - start]; d.page_w = (int)pages[P.img].w; d.page_h = (int)pages[P.img].h;
-                d.left = pl.left; d.top = pl.top; d.cw = pl.cw; d.ch = pl.ch; d.ow = pl.ow; d.oh = pl.oh; d.rot = pl.rot; d.mode = pl.mode;
-                std::memcpy(d.inv, pl.inv, sizeof d.inv);
-                d.out_off = (int64_t)pool_bytes;
-                PoolItem it;
-                it.img = P.img; it.det_index = P.det_index; it.w = (uint32_t)pl.out_w(); it.h = (uint32_t)pl.out_h();
-                it.wh_ratio = (float)it.w / (float)std::max<uint32_t>(it.h, 1);  // ocr.rs:739
-                it.off = pool_bytes;
-                pool.push_back(it);
-                pool_bytes += ((size_t)it.w * it.h * 3 + 63) & ~(size_t)63;
-            }
-            OAR_HIP(hipMemcpyAsync(warp_descs_dev_.p, wd, take * sizeof(pp::WarpDesc), hipMemcpyHostToDevice, s));
-            pp::rotate_crops(s, warp_descs_dev_.as<pp::WarpDesc>(), (int)take, crop_pool_.as<uint8_t>(), max_px);
-            pi += take;
-            if (pool.size() >= cfg_.max_pooled_crops) flush();
-        }
+        };
+        det_->run(chunk, cfg_.det_thresh, cfg_.det_box_thresh, cfg_.det_unclip_ratio, boxes, &dev_pages, plan_pages);
         // the detector's page staging buffer is reused by the next chunk: crops must be done first
         OAR_HIP(hipStreamSynchronize(s));
-        tmark("crop_plan+warp");
+        tmark("crop_sync");
     }
     flush();
     out.assign(n, {});

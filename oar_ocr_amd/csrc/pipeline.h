@@ -55,8 +55,11 @@ class Detector {
     ~Detector();
     // Pages may be host or device resident. dev_pages_out (optional) receives the device pointer of each page
     // (uploaded copies stay valid until the next call).
+    // on_ready(first, count) (optional) is called as soon as the boxes of pages [first, first + count) are final, in
+    // page order and while the GPU is still busy with later pages; dev_pages_out is filled before the first call.
+    using ReadyFn = std::function<void(int first, int count)>;
     void run(const std::vector<PageRef>& pages, float thresh, float box_thresh, float unclip, std::vector<DetBoxes>& out,
-             std::vector<const uint8_t*>* dev_pages_out = nullptr);
+             std::vector<const uint8_t*>* dev_pages_out = nullptr, const ReadyFn& on_ready = nullptr);
     Engine& engine() { return *eng_; }
     static void postprocess_host(const float* pred, int H, int W, uint32_t src_w, uint32_t src_h, float thresh, float box_thresh,
                                  float unclip, uint32_t max_candidates, DetBoxes& out);
@@ -64,21 +67,25 @@ class Detector {
 
    private:
     void run_group(const std::vector<int>& idx, const std::vector<PageRef>& pages, uint32_t rh, uint32_t rw, float thresh,
-                   float box_thresh, float unclip, std::vector<DetBoxes>& out);
+                   float box_thresh, float unclip, std::vector<DetBoxes>& out, const ReadyFn& on_ready);
     std::unique_ptr<Engine> eng_;
     std::unique_ptr<ThreadPool> pool_;
     oar_det_cfg cfg_;
-    DevBuf pages_dev_, resized_dev_, input_f32_, mask_dev_, boxes_dev_, scores_dev_, probs_keep_;
+    DevBuf pages_dev_, resized_dev_, input_f32_, mask_dev_, probs_keep_;
     // image as the resize stage sees it: the page itself, or its black-padded copy when h + w < 64
     // (DetResizeForTest::image_padding, processors/resize_detection.rs:174-176,204-220)
     DevBuf padded_dev_;
     std::vector<const uint8_t*> det_src_;
     std::vector<uint32_t> det_w_, det_h_;
-    std::vector<hipEvent_t> sub_events_, mask_ready_;
+    std::vector<hipEvent_t> sub_events_, mask_ready_, score_done_;
+    // box-score round trip of each sub-batch (its own slots: the next sub-batch's is enqueued before this one is read)
+    struct ScoreSlot { PinBuf boxes_host, scores_host; DevBuf boxes_dev, scores_dev; std::vector<size_t> base; size_t total = 0; };
+    std::vector<std::unique_ptr<ScoreSlot>> score_slots_;
     // mask read-back runs on its own stream: a D2H copy is a blit KERNEL on the queue it is issued to (150 us per 9-page
     // sub-batch over PCIe), which on the engine stream held up the next sub-batch's network
     hipStream_t copy_stream_ = nullptr;
-    PinBuf mask_host_, boxes_host_, scores_host_;
+    hipStream_t score_stream_ = nullptr;   // box-score round trips (not behind the queued mask copies of later sub-batches)
+    PinBuf mask_host_;
     std::vector<const uint8_t*> page_ptrs_;
     std::mutex mu_;
 };
