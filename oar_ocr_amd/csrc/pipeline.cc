@@ -190,7 +190,8 @@ void subbatch_candidates(ThreadPool& pool, const uint8_t* masks, size_t hw, int 
     if ((int)scratch.size() < nb) scratch.resize(nb);
     struct Band { int page, y0, y1; };
     std::vector<Band> bands;
-    const int bands_per_page = std::max(1, std::min(8, (pool.size() + 1) * 2 / std::max(nb, 1)));
+    static const int bands_mult = [] { const char* e = getenv("OAR_BANDS_MULT"); int v = e ? atoi(e) : 2; return v > 0 ? v : 2; }();
+    const int bands_per_page = std::max(1, std::min(12, (pool.size() + 1) * bands_mult / std::max(nb, 1)));
     auto t_setup = std::chrono::steady_clock::now();
     std::vector<std::vector<int>> cuts(nb);
     for (int k = 0; k < nb; ++k) scratch[k].resize(hw);
