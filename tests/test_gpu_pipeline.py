@@ -87,6 +87,27 @@ def test_ocr_pipeline_matches_oracle(nets):
         ocr.predict([])
 
 
+@pytest.mark.parametrize("mode", ["one shape group, several sub-batches", "mixed shapes and a blank page"])
+def test_ocr_pipeline_streaming_paths_match_oracle(nets, mode):
+    """The detector hands finished pages to the crop planner sub-batch by sub-batch (one shape group) or once at the
+    end (several groups: their page indices interleave); both must give the oracle's regions in the oracle's order."""
+    det, rec, chars = nets
+    if mode.startswith("one"):
+        imgs = [pages.make_page(50 + i, (320, 480), lines=6) for i in range(11)]       # 11 pages: sub-batches of 6 + 5 (last = half of 8 -> 4)
+    else:
+        blank = np.full((200, 300, 3), 255, np.uint8)
+        imgs = [pages.make_page(70, (320, 480), lines=6), blank, pages.make_page(71, (480, 320), lines=7), pages.make_page(72, (320, 480), lines=5)]
+    ocr = api.OAROCRBuilder(det, rec, chars).text_detection_config(api.TextDetectionConfig(0.3, 0.6, 1.5)).image_batch_size(16).region_batch_size(16).build()
+    got = ocr.predict(imgs)
+    ref = pipeline_ref.OracleOCR(det, rec, chars, 0.3, 0.6, 1.5, image_batch_size=16, region_batch_size=16).predict(imgs)
+    assert len(got) == len(imgs)
+    for g, r in zip(got, ref):
+        rep = pipeline_ref.compare_results(g, r)
+        assert rep["ok"], rep
+    if not mode.startswith("one"):
+        assert len(got[1].text_regions) == 0 and sum(len(g.text_regions) for g in got) > 8
+
+
 def test_pool_flush_and_batch_policy(nets):
     """Dense input: crops > max pool / several recognition batches; result slots stay aligned with boxes."""
     det, rec, chars = nets
