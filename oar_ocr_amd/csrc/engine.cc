@@ -54,7 +54,8 @@ const float* Engine::upload_const(const std::string& key, const std::vector<floa
 }
 
 static bool is_unary_act(const std::string& op) {
-    return op == "Relu" || op == "HardSwish" || op == "HardSigmoid" || op == "Sigmoid" || op == "LeakyRelu" || op == "Tanh";
+    return op == "Relu" || op == "HardSwish" || op == "HardSigmoid" || op == "Sigmoid" || op == "LeakyRelu" || op == "Tanh" || op == "Erf" ||
+           op == "Sqrt" || op == "Exp" || op == "Abs" || op == "Neg" || op == "Reciprocal" || op == "Log" || op == "Gelu" || op == "Softplus";
 }
 static Act act_of(const GNode& n) {
     Act a;
@@ -64,6 +65,15 @@ static Act act_of(const GNode& n) {
     else if (n.op == "Sigmoid") a.kind = k::ACT_SIGMOID;
     else if (n.op == "LeakyRelu") { a.kind = k::ACT_LEAKY; a.alpha = n.af("alpha", 0.01f); }
     else if (n.op == "Tanh") a.kind = k::ACT_TANH;
+    else if (n.op == "Erf") a.kind = k::ACT_ERF;
+    else if (n.op == "Sqrt") a.kind = k::ACT_SQRT;
+    else if (n.op == "Exp") a.kind = k::ACT_EXP;
+    else if (n.op == "Abs") a.kind = k::ACT_ABS;
+    else if (n.op == "Neg") a.kind = k::ACT_NEG;
+    else if (n.op == "Reciprocal") a.kind = k::ACT_RECIP;
+    else if (n.op == "Log") a.kind = k::ACT_LOG;
+    else if (n.op == "Gelu") a.kind = n.as("approximate", "none") == "tanh" ? k::ACT_GELU_TANH : k::ACT_GELU_ERF;
+    else if (n.op == "Softplus") a.kind = k::ACT_SOFTPLUS;
     return a;
 }
 
@@ -852,6 +862,46 @@ struct Planner {
         step([=](const RunCtx& c) { k::binary(c.s, c.at(al), c.at(bl), c.mut(yl), op, r, pod.data(), sa.data(), sb.data(), post); }, (double)cnt, 12.0 * cnt);
     }
 
+    // ReduceMean: the last axis (decomposed LayerNorm exports) or all spatial axes of an NCHW tensor (= GlobalAveragePool)
+    void op_reduce_mean(const GNode& n) {
+        TInfo x = get(n.in[0]);
+        const int r = (int)x.dims.size();
+        std::vector<int64_t> axes = has_input(n, 1) ? get(n.in[1]).hv : n.ais("axes");
+        for (auto& a : axes) if (a < 0) a += r;
+        std::sort(axes.begin(), axes.end());
+        const bool keep = n.ai("keepdims", 1) != 0;
+        bool spatial = r == 4 && axes.size() == 2 && axes[0] == 2 && axes[1] == 3;
+        if (spatial) {
+            OAR_CHECK(keep, OAR_UNSUPPORTED_OP, "ReduceMean over H, W with keepdims = 0");
+            return op_gap(n);
+        }
+        OAR_CHECK(axes.size() == 1 && axes[0] == r - 1, OAR_UNSUPPORTED_OP, "ReduceMean: only the last axis or the spatial axes of an NCHW tensor");
+        Loc xin = to_native_loc(x);
+        const int64_t C = x.dims.back(), rows = numel(x.dims) / std::max<int64_t>(C, 1);
+        std::vector<int64_t> od(x.dims.begin(), x.dims.end() - 1);
+        if (keep) od.push_back(1);
+        TInfo& y = new_out(n.out[0], od, Layout::NATIVE);
+        Loc yl = y.loc;
+        step([=](const RunCtx& c) { k::reduce_mean_lastdim(c.s, c.at(xin), c.mut(yl), rows, (int)C); }, (double)rows * C, 4.0 * rows * (C + 1));
+    }
+
+    // GridSample (UVDoc's final un-warp): X [N,C,H,W], grid [N,Ho,Wo,2] -> [N,C,Ho,Wo]
+    void op_grid_sample(const GNode& n) {
+        TInfo x = get(n.in[0]), g = get(n.in[1]);
+        OAR_CHECK(x.dims.size() == 4 && g.dims.size() == 4 && g.dims[3] == 2 && g.dims[0] == x.dims[0], OAR_UNSUPPORTED_OP, "GridSample: 4-D input and [N,Ho,Wo,2] grid only");
+        const std::string mode = n.as("mode", "linear"), pad = n.as("padding_mode", "zeros");
+        const int imode = (mode == "linear" || mode == "bilinear") ? 0 : mode == "nearest" ? 1 : -1;
+        const int ipad = pad == "zeros" ? 0 : pad == "border" ? 1 : pad == "reflection" ? 2 : -1;
+        OAR_CHECK(imode >= 0 && ipad >= 0, OAR_UNSUPPORTED_OP, "GridSample: mode " + mode + " / padding_mode " + pad);
+        const int align = (int)n.ai("align_corners", 0);
+        Loc xin = to_clast_loc(x), gin = to_native_loc(g);
+        const int64_t N = x.dims[0], C = x.dims[1], H = x.dims[2], W = x.dims[3], Ho = g.dims[1], Wo = g.dims[2];
+        TInfo& y = new_out(n.out[0], {N, C, Ho, Wo}, Layout::CLAST);
+        Loc yl = y.loc;
+        step([=](const RunCtx& c) { k::grid_sample(c.s, c.at(xin), c.at(gin), c.mut(yl), (int)N, (int)H, (int)W, (int)C, (int)Ho, (int)Wo, imode, ipad, align); },
+             8.0 * N * Ho * Wo * C, 4.0 * N * Ho * Wo * (2 + 5 * C));
+    }
+
     void op_gap(const GNode& n) {
         TInfo x = get(n.in[0]);
         OAR_CHECK(x.dims.size() == 4, OAR_UNSUPPORTED_OP, "GlobalAveragePool: rank-4 only");
@@ -1433,6 +1483,9 @@ struct Planner {
         if (op == "Mul") return op_binary(n, 2);
         if (op == "Div") return op_binary(n, 3);
         if (op == "Pow") return op_binary(n, 4);
+        if (op == "PRelu") return op_binary(n, 5);
+        if (op == "ReduceMean") return op_reduce_mean(n);
+        if (op == "GridSample") return op_grid_sample(n);
         if (op == "GlobalAveragePool") return op_gap(n);
         if (op == "AveragePool") return op_pool(n, false);
         if (op == "MaxPool") return op_pool(n, true);

@@ -7,7 +7,9 @@
 namespace oar {
 namespace k {
 
-enum ActKind : int { ACT_NONE = 0, ACT_RELU, ACT_HSWISH, ACT_HSIGMOID, ACT_SIGMOID, ACT_SWISH, ACT_LEAKY, ACT_CLIP, ACT_TANH, ACT_GELU_ERF };
+enum ActKind : int { ACT_NONE = 0, ACT_RELU, ACT_HSWISH, ACT_HSIGMOID, ACT_SIGMOID, ACT_SWISH, ACT_LEAKY, ACT_CLIP, ACT_TANH, ACT_GELU_ERF,
+                     // element-wise math (decomposed GELU / LayerNorm exports, UVDoc)
+                     ACT_ERF, ACT_SQRT, ACT_EXP, ACT_ABS, ACT_NEG, ACT_RECIP, ACT_LOG, ACT_GELU_TANH, ACT_SOFTPLUS };
 struct Act {
     int kind = ACT_NONE;
     float alpha = 0.f, beta = 0.f;  // HardSigmoid(alpha,beta) / LeakyRelu(alpha) / Clip(alpha=min,beta=max)
@@ -84,6 +86,11 @@ void gemm_batched(hipStream_t s, const GemmP& p);
 
 void layernorm(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C, float eps);
 void softmax_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C);
+// mean over the last axis: x [rows][C] -> y [rows]
+void reduce_mean_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C);
+// ONNX GridSample (4-D): x [N][H][W][C] channels-last, grid [N][Ho][Wo][2] (x, y in [-1, 1]) -> y [N][Ho][Wo][C].
+// mode 0 bilinear / 1 nearest; padding 0 zeros / 1 border / 2 reflection
+void grid_sample(hipStream_t s, const float* x, const float* grid, float* y, int N, int H, int W, int C, int Ho, int Wo, int mode, int padding, int align_corners);
 // softmax(scale * q k^T) v per (image, head); qkv [n][T][3][heads][hd] row-major, out [n][T][heads][hd]; hd <= 64
 void attention(hipStream_t s, const float* qkv, float* out, int n, int T, int heads, int hd, float scale);
 // softmax over the last dim fused with CTC argmax (last max index wins) -- see kernels.hip

@@ -474,6 +474,7 @@ __device__ __forceinline__ float bin_op(float a, float b, int op) {
         case 1: return a - b;
         case 2: return a * b;
         case 3: return a / b;
+        case 5: return a > 0.f ? a : a * b;   // PRelu(x, slope)
         default: return powf(a, b);
     }
 }
@@ -815,6 +816,77 @@ void softmax_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int 
         OAR_CHECK((size_t)C * 4 <= 150 * 1024, OAR_UNSUPPORTED_OP, "softmax: row longer than the LDS staging buffer");
         hipLaunchKernelGGL(softmax_block_kernel, dim3((unsigned)rows), dim3(256), (size_t)C * sizeof(float), s, x, y, C);
     }
+}
+
+// ------------------------------------------------------------------------------------------ ReduceMean (last axis)
+__global__ __launch_bounds__(256) void reduce_mean_kernel(const float* __restrict__ x, float* __restrict__ y, long rows, int C) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int i = lane; i < C; i += 64) s += x[row * C + i];
+    s = wave_sum(s);
+    if (lane == 0) y[row] = s / (float)C;
+}
+void reduce_mean_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C) {
+    if (rows == 0 || C == 0) return;
+    ProfScope ps(s, "reduce_mean", 4.0 * (double)rows * (C + 1), (double)rows * C);
+    hipLaunchKernelGGL(reduce_mean_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, y, (long)rows, C);
+}
+
+// ------------------------------------------------------------------------------------------ GridSample (UVDoc's un-warp)
+// One thread per output pixel; channels are innermost (channels-last), so the four taps are contiguous C-float reads.
+__device__ __forceinline__ float gs_reflect(float v, float lo, float hi) {   // reflect v into [lo, hi] (ONNX gs_reflect)
+    const float range = hi - lo;
+    if (range <= 0.f) return lo;
+    if (v < lo) {
+        const float dv = lo - v;
+        const int n = (int)(dv / range);
+        const float r = dv - n * range;
+        return (n & 1) ? hi - r : lo + r;
+    }
+    if (v > hi) {
+        const float dv = v - hi;
+        const int n = (int)(dv / range);
+        const float r = dv - n * range;
+        return (n & 1) ? lo + r : hi - r;
+    }
+    return v;
+}
+__global__ __launch_bounds__(256) void grid_sample_kernel(const float* __restrict__ x, const float* __restrict__ grid, float* __restrict__ y, long total, int H, int W,
+                                                          int C, int Ho, int Wo, int mode, int padding, int align) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / ((long)Ho * Wo);
+        const float gx = grid[i * 2], gy = grid[i * 2 + 1];
+        // [-1, 1] -> pixel coordinates
+        float fx = align ? (gx + 1.f) * 0.5f * (float)(W - 1) : ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+        float fy = align ? (gy + 1.f) * 0.5f * (float)(H - 1) : ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+        if (padding == 1) { fx = fminf(fmaxf(fx, 0.f), (float)(W - 1)); fy = fminf(fmaxf(fy, 0.f), (float)(H - 1)); }
+        else if (padding == 2) {
+            if (align) { fx = gs_reflect(fx, 0.f, (float)(W - 1)); fy = gs_reflect(fy, 0.f, (float)(H - 1)); }
+            else { fx = gs_reflect(fx, -0.5f, (float)W - 0.5f); fy = gs_reflect(fy, -0.5f, (float)H - 0.5f); }
+            fx = fminf(fmaxf(fx, 0.f), (float)(W - 1)); fy = fminf(fmaxf(fy, 0.f), (float)(H - 1));
+        }
+        const float* xb = x + n * (long)H * W * C;
+        float* o = y + i * C;
+        auto tap = [&](int yy, int xx, int c) { return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xb[((long)yy * W + xx) * C + c] : 0.f; };
+        if (mode == 1) {
+            const int xi = (int)nearbyintf(fx), yi = (int)nearbyintf(fy);
+            for (int c = 0; c < C; ++c) o[c] = tap(yi, xi, c);
+        } else {
+            const float x0f = floorf(fx), y0f = floorf(fy);
+            const int x0 = (int)x0f, y0 = (int)y0f;
+            const float wx1 = fx - x0f, wy1 = fy - y0f, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+            for (int c = 0; c < C; ++c)
+                o[c] = tap(y0, x0, c) * (wy0 * wx0) + tap(y0, x0 + 1, c) * (wy0 * wx1) + tap(y0 + 1, x0, c) * (wy1 * wx0) + tap(y0 + 1, x0 + 1, c) * (wy1 * wx1);
+        }
+    }
+}
+void grid_sample(hipStream_t s, const float* x, const float* grid, float* y, int N, int H, int W, int C, int Ho, int Wo, int mode, int padding, int align_corners) {
+    const long total = (long)N * Ho * Wo;
+    if (total == 0 || C == 0) return;
+    ProfScope ps(s, "grid_sample", 4.0 * (double)total * (2 + 5 * C), 8.0 * (double)total * C);
+    hipLaunchKernelGGL(grid_sample_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, grid, y, total, H, W, C, Ho, Wo, mode, padding, align_corners);
 }
 
 // ------------------------------------------------------------------------------------------ SVTR attention

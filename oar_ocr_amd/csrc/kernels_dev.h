@@ -25,6 +25,15 @@ __device__ __forceinline__ float apply_act(float v, int kind, float alpha, float
         case ACT_CLIP: return fminf(fmaxf(v, alpha), beta);
         case ACT_TANH: return tanhf(v);
         case ACT_GELU_ERF: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        case ACT_ERF: return erff(v);
+        case ACT_SQRT: return sqrtf(v);
+        case ACT_EXP: return expf(v);
+        case ACT_ABS: return fabsf(v);
+        case ACT_NEG: return -v;
+        case ACT_RECIP: return 1.0f / v;
+        case ACT_LOG: return logf(v);
+        case ACT_GELU_TANH: return 0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v)));
+        case ACT_SOFTPLUS: return v > 20.0f ? v : log1pf(expf(v));
         default: return v;
     }
 }

@@ -319,10 +319,12 @@ def build_cls(n_classes=4, seed=5, width=(16, 32, 64, 128)):
     return g.model(), {"params": g.param_count() if hasattr(g, "param_count") else None, "classes": n_classes}
 
 
-def build_uvdoc(seed=6, width=(16, 32, 64)):
+def build_uvdoc(seed=6, width=(16, 32, 64), head="grid", size=512):
     """UVDoc-style rectifier stand-in: input "image" [n,3,512,512] BGR in [0,1], output [n,3,512,512] BGR in [0,1]
-    (oar-ocr-core/src/models/rectification/uvdoc.rs:291-293 input name; :166-207 consumes output[0] as 4-D).  Encoder
-    (s2, s2, s2) -> bottleneck -> nearest x2 decoders with skip adds -> 3-channel Sigmoid head."""
+    (oar-ocr-core/src/models/rectification/uvdoc.rs:291-293 input name; :166-207 consumes output[0] as 4-D).
+    head="grid" (default, the UVDoc topology): encoder (s2, s2, s2, PRelu blocks) -> bottleneck -> 2-channel sampling grid
+    at 1/8 resolution (identity + a small predicted displacement) -> bilinear Resize to full size (align_corners) ->
+    GridSample of the input image.  head="image": nearest x2 decoders with skip adds -> 3-channel Sigmoid head."""
     net = _Net("synth_uvdoc", seed)
     g = net.g
     g.add_input("image", ["N", 3, "H", "W"])
@@ -331,6 +333,20 @@ def build_uvdoc(seed=6, width=(16, 32, 64)):
     e1 = net.ds_block(e0, c0, c1, 3, 2, act="relu")
     e2 = net.ds_block(e1, c1, c2, 3, 2, act="relu")
     b = net.ds_block(e2, c2, c2, 5, 1, use_se=True, act="relu")
+    if head == "grid":
+        gs = size // 8
+        t = net.conv(b, c2, c1, 3, 1, act=None)
+        t = g.op("PRelu", [t, g.init((0.05 + 0.2 * net.rng.random((c1, 1, 1))).astype(np.float32), "slope")])
+        disp = g.op("Tanh", [net.conv(t, c1, 2, 3, 1, act=None)])
+        disp = g.op("Mul", [disp, g.init(np.array(0.02, np.float32), "gain")])          # +-2 % of the page: a mild warp
+        lin = np.linspace(-1.0, 1.0, gs, dtype=np.float32)
+        ident = np.stack([np.broadcast_to(lin[None, :], (gs, gs)), np.broadcast_to(lin[:, None], (gs, gs))])[None]   # [1,2,gs,gs]: x, y
+        grid = g.op("Add", [disp, g.init(np.ascontiguousarray(ident, np.float32), "identity_grid")])
+        grid = g.op("Resize", [grid, "", g.init(np.array([1.0, 1.0, 8.0, 8.0], np.float32), "scales")], mode="linear", coordinate_transformation_mode="align_corners")
+        grid = g.op("Transpose", [grid], perm=[0, 2, 3, 1])
+        y = g.op("GridSample", ["image", grid], mode="linear", padding_mode="border", align_corners=1)
+        g.add_output(y, ["N", 3, "H", "W"])
+        return g.model(), {"classes": 3}
     scales = g.init(np.array([1.0, 1.0, 2.0, 2.0], np.float32), "scales")
 
     def up(x):

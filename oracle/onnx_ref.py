@@ -262,6 +262,23 @@ def run(model, feeds: dict, want=None):
                 y = torch.sqrt(x[0])
             elif op == "Exp":
                 y = torch.exp(x[0])
+            elif op == "Abs":
+                y = torch.abs(x[0])
+            elif op == "Neg":
+                y = -x[0]
+            elif op == "Reciprocal":
+                y = 1.0 / x[0]
+            elif op == "Log":
+                y = torch.log(x[0])
+            elif op == "Softplus":
+                y = F.softplus(x[0])
+            elif op == "Gelu":
+                y = F.gelu(x[0], approximate=a.get("approximate", "none"))
+            elif op == "PRelu":
+                y = torch.where(x[0] > 0, x[0], x[0] * x[1])
+            elif op == "GridSample":
+                mode = {"linear": "bilinear", "bilinear": "bilinear", "nearest": "nearest"}[a.get("mode", "linear")]
+                y = F.grid_sample(x[0], x[1], mode=mode, padding_mode=a.get("padding_mode", "zeros"), align_corners=bool(a.get("align_corners", 0)))
             elif op == "Clip":
                 lo = float(x[1]) if len(x) > 1 and x[1] is not None else a.get("min", -3.4e38)
                 hi = float(x[2]) if len(x) > 2 and x[2] is not None else a.get("max", 3.4e38)

@@ -142,6 +142,58 @@ def test_sequence_ops_layernorm_attention():
     _check(_single_op_graph(build), rng.standard_normal((3, C, 1, 21)).astype(np.float32))
 
 
+def test_elementwise_math_prelu_reducemean():
+    """Ops of decomposed GELU / LayerNorm exports and of UVDoc's blocks."""
+    rng = np.random.default_rng(11)
+    C = 12
+
+    def build(g):
+        g.add_input("x", ["N", C, "H", "W"])
+        w = rng.standard_normal((C, C, 3, 3)).astype(np.float32) * 0.2
+        y = g.op("Conv", ["x", g.init(w)], kernel_shape=[3, 3], strides=[1, 1], pads=[1, 1, 1, 1], group=1, dilations=[1, 1])
+        y = g.op("PRelu", [y, g.init((0.1 + 0.3 * rng.random((C, 1, 1))).astype(np.float32))])
+        gelu = g.op("Mul", [g.op("Mul", [y, g.init(np.array(0.5, np.float32))]),
+                            g.op("Add", [g.op("Erf", [g.op("Div", [y, g.init(np.array(np.sqrt(2.0), np.float32))])]), g.init(np.array(1.0, np.float32))])])
+        z = g.op("Add", [g.op("Sqrt", [g.op("Abs", [gelu])]), g.op("Exp", [g.op("Neg", [g.op("Abs", [y])])])])
+        z = g.op("Add", [z, g.op("Reciprocal", [g.op("Add", [g.op("Softplus", [y]), g.init(np.array(1.0, np.float32))])])])
+        z = g.op("Add", [z, g.op("Log", [g.op("Add", [g.op("Abs", [y]), g.init(np.array(1.0, np.float32))])])])
+        z = g.op("Add", [z, g.op("Gelu", [y], approximate="tanh")])
+        m = g.op("ReduceMean", [z], axes=[2, 3], keepdims=1)                    # == GlobalAveragePool
+        z = g.op("Mul", [z, g.op("Sigmoid", [m])])
+        t = g.op("Transpose", [g.op("Reshape", [z, g.init(np.array([0, C, -1], np.int64))])], perm=[0, 2, 1])   # [N, HW, C]
+        mu = g.op("ReduceMean", [t], axes=[-1], keepdims=1)                      # decomposed LayerNorm
+        d = g.op("Sub", [t, mu])
+        var = g.op("ReduceMean", [g.op("Mul", [d, d])], axes=[-1], keepdims=1)
+        ln = g.op("Div", [d, g.op("Sqrt", [g.op("Add", [var, g.init(np.array(1e-5, np.float32))])])])
+        g.add_output(g.op("ReduceMean", [t], axes=[2], keepdims=0), ["N", "HW"])
+        return ln, ["N", "HW", C]
+
+    _check(_single_op_graph(build), rng.standard_normal((2, C, 9, 11)).astype(np.float32))
+
+
+@pytest.mark.parametrize("cfg", [("linear", "zeros", 0), ("linear", "border", 1), ("linear", "reflection", 0), ("nearest", "zeros", 0),
+                                 ("linear", "reflection", 1)])
+def test_grid_sample(cfg):
+    """UVDoc's final un-warp: a conv predicts the sampling grid, GridSample reads the image through it."""
+    mode, pad, align = cfg
+    rng = np.random.default_rng(12)
+
+    def build(g):
+        g.add_input("x", ["N", 3, "H", "W"])
+        w = rng.standard_normal((2, 3, 3, 3)).astype(np.float32) * 0.4
+        grid = g.op("Tanh", [g.op("Conv", ["x", g.init(w)], kernel_shape=[3, 3], strides=[2, 2], pads=[1, 1, 1, 1], group=1, dilations=[1, 1])])
+        grid = g.op("Mul", [grid, g.init(np.array(1.3, np.float32))])                  # leaves [-1, 1]: exercises the padding modes
+        grid = g.op("Transpose", [grid], perm=[0, 2, 3, 1])                             # [N, Ho, Wo, 2]
+        y = g.op("GridSample", ["x", grid], mode=mode, padding_mode=pad, align_corners=align)
+        return y, ["N", 3, "Ho", "Wo"]
+
+    tol = TOL if mode == "linear" else 1.0     # nearest: a coordinate within float noise of .5 may legitimately pick the other pixel
+    x = rng.standard_normal((2, 3, 20, 26)).astype(np.float32)
+    got, ref = _check(_single_op_graph(build), x, tol=tol)
+    if mode == "nearest":
+        assert (np.abs(got[0][1] - ref[0]) > 1e-4).mean() < 0.02
+
+
 def test_unsupported_operator_is_an_error_not_a_fallback():
     def build(g):
         g.add_input("x", ["N", 4])
