@@ -1539,8 +1539,9 @@ void Engine::clear_graphs() {
 // kernel (first run, graphs disabled, capture failed).
 bool Engine::replay(const Plan& p, const RunCtx& c) {
     // Opt-in (OAR_HIP_GRAPH=1).  Measured on ROCm 7.2 / MI355X with bench.py: 22.8-22.9 ms per step with replay vs
-    // 21.9-23.0 ms without -- the ~5 us between dependent kernels is the queue's own dispatch latency, not host launch
-    // cost, and a graph of kernel nodes pays it too; with external event-record nodes (profiler on) replay is 6 % slower.
+    // 21.9-23.0 ms without.  The rocprofv3 kernel trace explains it: dependent kernels enqueued one by one already start
+    // back to back (median gap 0.00 us), so a graph of kernel nodes has no dispatch gap left to remove; with external
+    // event-record nodes (profiler on) replay is 6 % slower.
     static const bool env_on = [] { const char* e = getenv("OAR_HIP_GRAPH"); return e && atoi(e) != 0; }();
     if (!env_on || !graphs_ok_ || p.runs == 0) return false;
     Profiler& prof = Profiler::get();
