@@ -185,7 +185,7 @@ def main():
         total_pages = n_pages * world * args.steps
         value = total_pages / tmax
         cpu = None
-        if args.cpu_pages > 0:
+        if args.cpu_pages > 0 and world == 1:   # the CPU baseline is timed on rank 0 of the single-GPU run only
             from oracle import pipeline_ref
             torch.set_num_threads(min(os.cpu_count() or 1, 64))
             sample = host_pages[:args.cpu_pages]
