@@ -53,7 +53,11 @@ def main():
     from oar_ocr_amd import api, dist as oard
     from oar_ocr_amd.synth import models, pages as synth_pages
 
-    rank, local, world = oard.init_from_env("nccl" if args.gpus > 1 else None)
+    # one rank per GPU over RCCL; OAR_DIST_BACKEND=gloo exists so that the N > 1 path can be exercised with two ranks on a
+    # single-GPU box (RCCL refuses two ranks on one device)
+    backend = os.environ.get("OAR_DIST_BACKEND", "nccl")
+    red_dev = "cuda" if backend == "nccl" else "cpu"
+    rank, local, world = oard.init_from_env(backend if args.gpus > 1 else None)
     if world > 1:
         import torch.distributed as dist
     assert api.device_count() > 0, "bench.py needs a GPU: libOarMi355x has no CPU fallback"
@@ -172,10 +176,10 @@ def main():
 
     tmax = dt
     if world > 1:
-        t = torch.tensor([dt], device="cuda")
+        t = torch.tensor([dt], device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         tmax = float(t.item())
-        cnt = torch.tensor([float(regions)], device="cuda")
+        cnt = torch.tensor([float(regions)], device=red_dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         regions_total = int(cnt.item())
     else:
