@@ -47,15 +47,20 @@ def make_page(seed: int, size=(960, 960), lines: int = 40, rotated_fraction: flo
     margin = 24
     slot = 44 if lines >= 18 else 60
     rows = (H - 2 * margin) // slot
+    if rows <= 0 or W - 2 * margin < 120 or lines <= 0:   # too small for a text line: a blank page
+        return page
     cols = max(1, int(np.ceil(lines / rows)))
     col_w = (W - 2 * margin) // cols
+    if col_w < 96:
+        cols = max(1, (W - 2 * margin) // 96)
+        col_w = (W - 2 * margin) // cols
     k = 0
     for r in range(rows):
         for c in range(cols):
             if k >= lines:
                 break
             h = int(rng.integers(18, min(31, slot - 12)))
-            max_w = min(800, col_w - 24)
+            max_w = max(min(800, col_w - 24), 40)
             w = int(rng.integers(min(200, max_w - 1), max_w))
             x0 = margin + c * col_w + int(rng.integers(0, max(col_w - 24 - w, 1)))
             y0 = margin + r * slot + int(rng.integers(0, slot - 4 - h))

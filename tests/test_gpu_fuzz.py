@@ -1,0 +1,16 @@
+"""A short, seeded slice of tools/parity_fuzz.py: random page sizes (above and below the 960 resize limit, down to
+blank slivers), line counts, thresholds, unclip ratios and batch sizes -- boxes bit-exact, scores within 1e-3."""
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_random_pages_match_oracle():
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / "tools" / "parity_fuzz.py"), "8", "7"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "8/8 cases identical" in r.stdout

@@ -1,0 +1,41 @@
+"""Randomised end-to-end parity sweep: OAROCR (HIP, through the C ABI) against the oracle pipeline on random page sizes,
+line counts, thresholds and batch sizes.  usage: python tools/parity_fuzz.py [n_cases] [seed]"""
+import sys, time
+sys.path.insert(0, ".")
+import numpy as np
+from oar_ocr_amd import api
+from oar_ocr_amd.synth import models, pages
+from oracle import pipeline_ref
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+det, _ = models.build_det("tiny", seed=0)
+rec, _ = models.build_rec("tiny", vocab=6906, seed=1)
+chars = api.read_dict(models.synth_dict(6904))
+bad = 0
+t0 = time.time()
+for case in range(n_cases):
+    n_img = int(rng.integers(1, 5))
+    same = rng.random() < 0.5
+    h0, w0 = int(rng.integers(48, 1100)), int(rng.integers(48, 1100))
+    imgs = []
+    for i in range(n_img):
+        h, w = (h0, w0) if same else (int(rng.integers(48, 1100)), int(rng.integers(48, 1100)))
+        imgs.append(pages.make_page(int(rng.integers(0, 1 << 30)), (h, w), int(rng.integers(0, 24))))
+    thr, bthr, unclip = float(rng.choice([0.2, 0.3, 0.4])), float(rng.choice([0.5, 0.6, 0.7])), float(rng.choice([1.5, 1.8, 2.0]))
+    ibs, rbs = int(rng.choice([1, 2, 8])), int(rng.choice([3, 16, 64]))
+    ocr = (api.OAROCRBuilder(det, rec, chars).text_detection_config(api.TextDetectionConfig(thr, bthr, unclip)).image_batch_size(ibs).region_batch_size(rbs).build())
+    got = ocr.predict(imgs)
+    ref = pipeline_ref.OracleOCR(det, rec, chars, thr, bthr, unclip, image_batch_size=ibs, region_batch_size=rbs).predict(imgs)
+    ok = True
+    for g, r in zip(got, ref):
+        rep = pipeline_ref.compare_results(g, r)
+        ok = ok and rep["ok"]
+        if not rep["ok"]:
+            print("  MISMATCH", rep)
+    nreg = sum(len(r) for r in ref)
+    print(f"case {case}: {n_img} pages {[im.shape[:2] for im in imgs]} thr={thr} box={bthr} unclip={unclip} ibs={ibs} rbs={rbs} regions={nreg} {'ok' if ok else 'FAIL'}", flush=True)
+    bad += 0 if ok else 1
+    ocr.close()
+print(f"{n_cases - bad}/{n_cases} cases identical (boxes bit-exact, scores <= 1e-3) in {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)
