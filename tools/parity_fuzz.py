@@ -9,6 +9,8 @@ from oracle import pipeline_ref
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+with_stages = len(sys.argv) > 3 and sys.argv[3] == "stages"   # randomly attach doc orientation / UVDoc / text-line orientation
+cls4, cls2, uvdoc = models.build_cls(4, seed=5)[0], models.build_cls(2, seed=9)[0], models.build_uvdoc(seed=6)[0]
 det, _ = models.build_det("tiny", seed=0)
 rec, _ = models.build_rec("tiny", vocab=6906, seed=1)
 chars = api.read_dict(models.synth_dict(6904))
@@ -24,9 +26,19 @@ for case in range(n_cases):
         imgs.append(pages.make_page(int(rng.integers(0, 1 << 30)), (h, w), int(rng.integers(0, 24))))
     thr, bthr, unclip = float(rng.choice([0.2, 0.3, 0.4])), float(rng.choice([0.5, 0.6, 0.7])), float(rng.choice([1.5, 1.8, 2.0]))
     ibs, rbs = int(rng.choice([1, 2, 8])), int(rng.choice([3, 16, 64]))
-    ocr = (api.OAROCRBuilder(det, rec, chars).text_detection_config(api.TextDetectionConfig(thr, bthr, unclip)).image_batch_size(ibs).region_batch_size(rbs).build())
+    b = api.OAROCRBuilder(det, rec, chars).text_detection_config(api.TextDetectionConfig(thr, bthr, unclip)).image_batch_size(ibs).region_batch_size(rbs)
+    stages = {}
+    if with_stages:
+        if rng.random() < 0.6:
+            b = b.with_document_image_orientation_classification(cls4); stages["doc_orientation"] = cls4
+            imgs = [np.ascontiguousarray(np.rot90(im, int(rng.integers(0, 4)))) for im in imgs]
+        if rng.random() < 0.5:
+            b = b.with_document_image_rectification(uvdoc); stages["rectifier"] = uvdoc
+        if rng.random() < 0.6:
+            b = b.with_text_line_orientation_classification(cls2); stages["line_orientation"] = cls2
+    ocr = b.build()
     got = ocr.predict(imgs)
-    ref = pipeline_ref.OracleOCR(det, rec, chars, thr, bthr, unclip, image_batch_size=ibs, region_batch_size=rbs).predict(imgs)
+    ref = pipeline_ref.OracleOCR(det, rec, chars, thr, bthr, unclip, image_batch_size=ibs, region_batch_size=rbs, **stages).predict(imgs)
     ok = True
     for g, r in zip(got, ref):
         rep = pipeline_ref.compare_results(g, r)
@@ -34,7 +46,7 @@ for case in range(n_cases):
         if not rep["ok"]:
             print("  MISMATCH", rep)
     nreg = sum(len(r) for r in ref)
-    print(f"case {case}: {n_img} pages {[im.shape[:2] for im in imgs]} thr={thr} box={bthr} unclip={unclip} ibs={ibs} rbs={rbs} regions={nreg} {'ok' if ok else 'FAIL'}", flush=True)
+    print(f"case {case}: stages={sorted(stages)} {n_img} pages {[im.shape[:2] for im in imgs]} thr={thr} box={bthr} unclip={unclip} ibs={ibs} rbs={rbs} regions={nreg} {'ok' if ok else 'FAIL'}", flush=True)
     bad += 0 if ok else 1
     ocr.close()
 print(f"{n_cases - bad}/{n_cases} cases identical (boxes bit-exact, scores <= 1e-3) in {time.time() - t0:.0f} s")
