@@ -357,6 +357,49 @@ void Engine::rewrite_graph(OnnxModel& m) {
         for (int i = 0; i < (int)nodes.size(); ++i) if (!dead[i]) keep.push_back(std::move(nodes[i]));
         nodes.swap(keep);
     }
+    // ---- pass 6: squeeze-excite gate: GlobalAveragePool -> Conv 1x1 (+act) -> Conv 1x1 (+act) on the pooled vector
+    // becomes one SEGate node (two GEMVs per image in one kernel instead of two implicit-GEMM launches).
+    {
+        const char* fe = getenv("OAR_FUSE_SE");
+        const bool fuse = !fe || atoi(fe) != 0;
+        auto cons = consumers(nodes);
+        std::map<std::string, int> producer;
+        for (int i = 0; i < (int)nodes.size(); ++i) for (auto& o : nodes[i].out) producer[o] = i;
+        std::vector<bool> dead(nodes.size(), false);
+        auto plain_1x1 = [&](const GNode& c) {
+            if (c.op != "Conv" || c.in.size() < 2 || !is_init(c.in[1]) || !c.residual.empty() || c.ai("group", 1) != 1) return false;
+            const HostTensor& w = inits_[c.in[1]];
+            if (w.dims.size() != 4 || w.dims[2] != 1 || w.dims[3] != 1) return false;
+            for (auto v : c.ais("strides")) if (v != 1) return false;
+            for (auto v : c.ais("pads")) if (v != 0) return false;
+            return c.as("auto_pad", "NOTSET") == "NOTSET" && (c.in.size() < 3 || c.in[2].empty() || is_init(c.in[2]));
+        };
+        for (int i = 0; fuse && i < (int)nodes.size(); ++i) {
+            if (dead[i] || nodes[i].op != "GlobalAveragePool") continue;
+            const std::string& pooled = nodes[i].out[0];
+            if (cons[pooled].size() != 1 || graph_outs.count(pooled)) continue;
+            const int a = cons[pooled][0];
+            if (!plain_1x1(nodes[a]) || nodes[a].in[0] != pooled) continue;
+            const std::string& mid = nodes[a].out[0];
+            if (cons[mid].size() != 1 || graph_outs.count(mid)) continue;
+            const int b = cons[mid][0];
+            if (!plain_1x1(nodes[b]) || nodes[b].in[0] != mid) continue;
+            if (inits_[nodes[b].in[1]].dims[1] != inits_[nodes[a].in[1]].dims[0]) continue;
+            GNode g;
+            g.op = "SEGate";
+            g.in = {pooled, nodes[a].in[1], nodes[a].in.size() > 2 ? nodes[a].in[2] : std::string(), nodes[b].in[1], nodes[b].in.size() > 2 ? nodes[b].in[2] : std::string()};
+            g.out = {nodes[b].out[0]};
+            g.act = nodes[b].act;
+            Attr k1; k1.kind = Attr::I; k1.i = nodes[a].act.kind; g.attrs["act1"] = k1;
+            Attr al; al.kind = Attr::F; al.f = nodes[a].act.alpha; g.attrs["act1_alpha"] = al;
+            Attr be; be.kind = Attr::F; be.f = nodes[a].act.beta; g.attrs["act1_beta"] = be;
+            dead[a] = true;
+            nodes[b] = std::move(g);
+        }
+        std::vector<GNode> keep;
+        for (int i = 0; i < (int)nodes.size(); ++i) if (!dead[i]) keep.push_back(std::move(nodes[i]));
+        nodes.swap(keep);
+    }
     for (int i = 0; i < (int)nodes.size(); ++i) nodes[i].id = i;
     nodes_ = std::move(nodes);
 }
@@ -900,6 +943,30 @@ struct Planner {
         Loc yl = y.loc;
         step([=](const RunCtx& c) { k::grid_sample(c.s, c.at(xin), c.at(gin), c.mut(yl), (int)N, (int)H, (int)W, (int)C, (int)Ho, (int)Wo, imode, ipad, align); },
              8.0 * N * Ho * Wo * C, 4.0 * N * Ho * Wo * (2 + 5 * C));
+    }
+
+    // fused squeeze-excite gate (rewrite pass 6): pooled [n,C,1,1] -> [n,Cout,1,1]
+    void op_se_gate(const GNode& n) {
+        TInfo x = get(n.in[0]);
+        OAR_CHECK(x.dims.size() == 4 && x.dims[2] == 1 && x.dims[3] == 1, OAR_SHAPE_MISMATCH, "SEGate: input must be [n, C, 1, 1]");
+        const TInfo &w1 = get(n.in[1]), &w2 = get(n.in[3]);
+        OAR_CHECK(w1.ht && w2.ht, OAR_UNSUPPORTED_OP, "SEGate: weights must be initializers");
+        const int64_t N = x.dims[0], C = x.dims[1], Cmid = w1.ht->dims[0], Cout = w2.ht->dims[0];
+        OAR_CHECK(w1.ht->dims[1] == C && w2.ht->dims[1] == Cmid, OAR_SHAPE_MISMATCH, "SEGate: weight shapes");
+        const float* b1 = has_input(n, 2) ? get(n.in[2]).loc.cptr : nullptr;
+        const float* b2 = has_input(n, 4) ? get(n.in[4]).loc.cptr : nullptr;
+        const float* w1p = w1.loc.cptr;
+        std::vector<float> w2t((size_t)(Cmid * Cout));   // [Cout][Cmid] -> [Cmid][Cout]: the kernel's threads run along Cout
+        for (int64_t c = 0; c < Cout; ++c)
+            for (int64_t j = 0; j < Cmid; ++j) w2t[(size_t)(j * Cout + c)] = w2.ht->f[(size_t)(c * Cmid + j)];
+        const float* w2p = E.upload_const("segate_w2t:" + n.in[3], w2t);
+        Act a1; a1.kind = (int)n.ai("act1", 0); a1.alpha = n.af("act1_alpha", 0.f); a1.beta = n.af("act1_beta", 0.f);
+        Act a2 = n.act;
+        Loc xin = x.loc;   // [n, C, 1, 1]: the same bytes in either layout
+        TInfo& y = new_out(n.out[0], {N, Cout, 1, 1}, Layout::CLAST);
+        Loc yl = y.loc;
+        step([=](const RunCtx& c) { k::se_fc(c.s, c.at(xin), w1p, b1, a1, w2p, b2, a2, c.mut(yl), (int)N, (int)C, (int)Cmid, (int)Cout); },
+             2.0 * N * Cmid * (C + Cout), 4.0 * (N * (C + Cout) + Cmid * (C + Cout)));
     }
 
     void op_gap(const GNode& n) {
@@ -1504,6 +1571,7 @@ struct Planner {
         if (op == "MatMul") return op_matmul(n);
         if (op == "Softmax") return op_softmax(n);
         if (op == "Attention") return op_attention(n);
+        if (op == "SEGate") return op_se_gate(n);
         if (op == "LayerNormalization") return op_layernorm(n);
         if (op == "Identity") { const TInfo& x = get(n.in[0]); if (x.host_int) { vals[n.out[0]] = x; } else { TInfo xx = x; alias_out(n.out[0], xx, xx.dims, xx.layout); } return; }
         if (op == "Cast") { const TInfo& x = get(n.in[0]); OAR_CHECK(n.ai("to", 1) == 1, OAR_UNSUPPORTED_OP, "Cast of a device tensor to non-f32"); TInfo xx = x; alias_out(n.out[0], xx, xx.dims, xx.layout); return; }

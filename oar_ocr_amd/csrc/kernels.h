@@ -86,6 +86,9 @@ void gemm_batched(hipStream_t s, const GemmP& p);
 
 void layernorm(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C, float eps);
 void softmax_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C);
+// squeeze-excite gate on a pooled vector: y[n] = act2(W2 act1(W1 x[n] + b1) + b2); w1 = W1 [Cmid][C], w2 = W2 TRANSPOSED [Cmid][Cout]
+void se_fc(hipStream_t s, const float* x, const float* w1, const float* b1, Act act1, const float* w2, const float* b2, Act act2, float* y, int N, int C,
+           int Cmid, int Cout);
 // mean over the last axis: x [rows][C] -> y [rows]
 void reduce_mean_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C);
 // ONNX GridSample (4-D): x [N][H][W][C] channels-last, grid [N][Ho][Wo][2] (x, y in [-1, 1]) -> y [N][Ho][Wo][C].

@@ -818,6 +818,55 @@ void softmax_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int 
     }
 }
 
+// ------------------------------------------------------------------------------------------ squeeze-excite gate
+// GlobalAveragePool -> 1x1 conv -> act -> 1x1 conv -> act on [n, C, 1, 1] is two GEMVs per image: as implicit-GEMM launches
+// they are two ~10 us kernels of a few workgroups each; here one workgroup per image does both, the pooled vector and
+// the hidden vector staying in LDS.
+__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1, Act a1,
+                                                    const float* __restrict__ w2, const float* __restrict__ b2, Act a2, float* __restrict__ y, int C, int Cmid, int Cout) {
+    extern __shared__ float se_lds[];   // pooled [C] | hidden [Cmid]
+    float* pooled = se_lds;
+    float* hidden = se_lds + C;
+    const long n = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) pooled[c] = x[n * C + c];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int jb = wave * 4; jb < Cmid; jb += 16) {   // four hidden units per wave per pass: their weight rows load together
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = lane; c < C; c += 64) {
+            const float pv = pooled[c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = fmaf(w1[(long)min(jb + u, Cmid - 1) * C + c], pv, acc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float v = wave_sum(acc[u]);
+            if (lane == 0 && jb + u < Cmid) hidden[jb + u] = apply_act(v + (b1 ? b1[jb + u] : 0.f), a1.kind, a1.alpha, a1.beta);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Cout; c += blockDim.x) {
+        float acc = b2 ? b2[c] : 0.f;
+        int j = 0;
+        for (; j + 8 <= Cmid; j += 8) {   // eight independent loads in flight (a rolled loop pays one L2 round trip per term)
+            float w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = w2[(long)(j + u) * Cout + c];   // W2 transposed: coalesced over c
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(w[u], hidden[j + u], acc);
+        }
+        for (; j < Cmid; ++j) acc = fmaf(w2[(long)j * Cout + c], hidden[j], acc);
+        y[n * Cout + c] = apply_act(acc, a2.kind, a2.alpha, a2.beta);
+    }
+}
+void se_fc(hipStream_t s, const float* x, const float* w1, const float* b1, Act act1, const float* w2, const float* b2, Act act2, float* y, int N, int C,
+           int Cmid, int Cout) {
+    if (N == 0) return;
+    OAR_CHECK((size_t)(C + Cmid) * 4 <= 64 * 1024, OAR_UNSUPPORTED_OP, "se_fc: vectors exceed LDS");
+    ProfScope ps(s, "se_fc", 4.0 * ((double)N * (C + Cout) + (double)Cmid * (C + Cout)), 2.0 * N * (double)Cmid * (C + Cout));
+    hipLaunchKernelGGL(se_fc_kernel, dim3((unsigned)N), dim3(256), (size_t)(C + Cmid) * sizeof(float), s, x, w1, b1, act1, w2, b2, act2, y, C, Cmid, Cout);
+}
+
 // ------------------------------------------------------------------------------------------ ReduceMean (last axis)
 __global__ __launch_bounds__(256) void reduce_mean_kernel(const float* __restrict__ x, float* __restrict__ y, long rows, int C) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);

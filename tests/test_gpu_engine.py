@@ -194,6 +194,25 @@ def test_grid_sample(cfg):
         assert (np.abs(got[0][1] - ref[0]) > 1e-4).mean() < 0.02
 
 
+def test_squeeze_excite_gate_is_one_kernel():
+    """Rewrite pass 6: GlobalAveragePool -> Conv 1x1 + ReLU -> Conv 1x1 + HardSigmoid -> Mul (PP-LCNet's SE block)."""
+    rng = np.random.default_rng(13)
+    C, R = 48, 12
+
+    def build(g):
+        g.add_input("x", ["N", C, "H", "W"])
+        p = g.op("GlobalAveragePool", ["x"])
+        w1, b1 = rng.standard_normal((R, C, 1, 1)).astype(np.float32) * 0.3, rng.standard_normal(R).astype(np.float32) * 0.1
+        w2, b2 = rng.standard_normal((C, R, 1, 1)).astype(np.float32) * 0.3, rng.standard_normal(C).astype(np.float32) * 0.1
+        h = g.op("Relu", [g.op("Conv", [p, g.init(w1), g.init(b1)], kernel_shape=[1, 1], strides=[1, 1], pads=[0, 0, 0, 0], group=1, dilations=[1, 1])])
+        s = g.op("HardSigmoid", [g.op("Conv", [h, g.init(w2), g.init(b2)], kernel_shape=[1, 1], strides=[1, 1], pads=[0, 0, 0, 0], group=1, dilations=[1, 1])], alpha=0.2, beta=0.5)
+        return g.op("Mul", ["x", s]), ["N", C, "H", "W"]
+
+    model = _single_op_graph(build)
+    _check(model, rng.standard_normal((5, C, 7, 9)).astype(np.float32))
+    assert api.OrtInfer(model).cost((5, C, 7, 9))[2] <= 5      # layout copy in, pool, gate, scale, layout copy out
+
+
 def test_unsupported_operator_is_an_error_not_a_fallback():
     def build(g):
         g.add_input("x", ["N", 4])
