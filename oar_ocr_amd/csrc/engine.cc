@@ -969,6 +969,42 @@ struct Planner {
              2.0 * N * Cmid * (C + Cout), 4.0 * (N * (C + Cout) + Cmid * (C + Cout)));
     }
 
+    // Pad (UVDoc's reflect-padded convolutions export as Pad(reflect) + Conv).  Works on the physical layout: a
+    // channels-last tensor is padded in place of a conversion (the pads are permuted with the dims).
+    void op_pad(const GNode& n) {
+        TInfo x = get(n.in[0]);
+        const int r = (int)x.dims.size();
+        std::vector<int64_t> pads = has_input(n, 1) ? get(n.in[1]).hv : n.ais("pads");
+        std::vector<int64_t> axes;
+        if (has_input(n, 3)) axes = get(n.in[3]).hv;
+        std::vector<int64_t> before(r, 0), after(r, 0);
+        if (axes.empty()) {
+            OAR_CHECK((int)pads.size() == 2 * r, OAR_SHAPE_MISMATCH, "Pad: pads must have 2 * rank entries");
+            for (int d = 0; d < r; ++d) { before[d] = pads[d]; after[d] = pads[r + d]; }
+        } else {
+            OAR_CHECK(pads.size() == 2 * axes.size(), OAR_SHAPE_MISMATCH, "Pad: pads must have 2 * len(axes) entries");
+            for (size_t k = 0; k < axes.size(); ++k) { int64_t a = axes[k] < 0 ? axes[k] + r : axes[k]; before[a] = pads[k]; after[a] = pads[axes.size() + k]; }
+        }
+        const std::string mode = n.as("mode", "constant");
+        const int imode = mode == "constant" ? 0 : mode == "reflect" ? 1 : mode == "edge" ? 2 : -1;
+        OAR_CHECK(imode >= 0, OAR_UNSUPPORTED_OP, "Pad: mode " + mode);
+        float value = n.af("value", 0.0f);
+        if (has_input(n, 2)) { const TInfo& v = get(n.in[2]); if (v.ht && !v.ht->f.empty()) value = v.ht->f[0]; }
+        std::vector<int64_t> od(r);
+        for (int d = 0; d < r; ++d) {
+            od[d] = x.dims[d] + before[d] + after[d];
+            OAR_CHECK(od[d] >= 0, OAR_SHAPE_MISMATCH, "Pad: negative output dimension");
+            OAR_CHECK(imode != 1 || (before[d] < std::max<int64_t>(x.dims[d], 1) && after[d] < std::max<int64_t>(x.dims[d], 1)) || x.dims[d] == 1, OAR_UNSUPPORTED_OP,
+                      "Pad: reflect padding wider than the axis");
+        }
+        const bool clast = x.layout == Layout::CLAST && r >= 3;
+        std::vector<int64_t> pin = clast ? clast_phys_dims(x.dims) : x.dims, pout = clast ? clast_phys_dims(od) : od, pbef = clast ? clast_phys_dims(before) : before;
+        Loc xin = x.loc;
+        TInfo& y = new_out(n.out[0], od, clast ? Layout::CLAST : Layout::NATIVE);
+        Loc yl = y.loc;
+        step([=](const RunCtx& c) { k::pad_nd(c.s, c.at(xin), c.mut(yl), r, pin.data(), pout.data(), pbef.data(), imode, value); }, 0, 8.0 * numel(od));
+    }
+
     void op_gap(const GNode& n) {
         TInfo x = get(n.in[0]);
         OAR_CHECK(x.dims.size() == 4, OAR_UNSUPPORTED_OP, "GlobalAveragePool: rank-4 only");
@@ -1553,6 +1589,7 @@ struct Planner {
         if (op == "PRelu") return op_binary(n, 5);
         if (op == "ReduceMean") return op_reduce_mean(n);
         if (op == "GridSample") return op_grid_sample(n);
+        if (op == "Pad") return op_pad(n);
         if (op == "GlobalAveragePool") return op_gap(n);
         if (op == "AveragePool") return op_pool(n, false);
         if (op == "MaxPool") return op_pool(n, true);

@@ -89,6 +89,9 @@ void softmax_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int 
 // squeeze-excite gate on a pooled vector: y[n] = act2(W2 act1(W1 x[n] + b1) + b2); w1 = W1 [Cmid][C], w2 = W2 TRANSPOSED [Cmid][Cout]
 void se_fc(hipStream_t s, const float* x, const float* w1, const float* b1, Act act1, const float* w2, const float* b2, Act act2, float* y, int N, int C,
            int Cmid, int Cout);
+// ONNX Pad on a contiguous tensor of rank <= 6: out_dims[d] = in_dims[d] + before[d] + after[d] (negative = crop);
+// mode 0 constant (value), 1 reflect, 2 edge
+void pad_nd(hipStream_t s, const float* x, float* y, int rank, const int64_t* in_dims, const int64_t* out_dims, const int64_t* before, int mode, float value);
 // mean over the last axis: x [rows][C] -> y [rows]
 void reduce_mean_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C);
 // ONNX GridSample (4-D): x [N][H][W][C] channels-last, grid [N][Ho][Wo][2] (x, y in [-1, 1]) -> y [N][Ho][Wo][C].

@@ -597,6 +597,51 @@ void permute(hipStream_t s, const float* x, float* y, int rank, const int64_t* o
     hipLaunchKernelGGL(permute_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n, p);
 }
 
+// ------------------------------------------------------------------------------------------ Pad (constant / reflect / edge)
+struct PadP { int rank; long in_dims[6], out_dims[6], before[6], in_st[6]; int mode; float value; };
+__global__ __launch_bounds__(256) void pad_kernel(const float* x, float* y, long n, PadP p) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        long r = i, o = 0;
+        bool inside = true;
+#pragma unroll
+        for (int d = 5; d >= 0; --d) {
+            if (d < p.rank) {
+                const long q = r / p.out_dims[d];
+                long c = (r - q * p.out_dims[d]) - p.before[d];
+                r = q;
+                const long D = p.in_dims[d];
+                if (c < 0 || c >= D) {
+                    if (p.mode == 0) inside = false;
+                    else if (p.mode == 2) c = c < 0 ? 0 : D - 1;
+                    else {   // reflect (no edge repeat); D == 1 degenerates to the only element
+                        if (D == 1) c = 0;
+                        else {
+                            const long period = 2 * (D - 1);
+                            c %= period; if (c < 0) c += period;
+                            if (c >= D) c = period - c;
+                        }
+                    }
+                }
+                o += c * p.in_st[d];
+            }
+        }
+        y[i] = inside ? x[o] : p.value;
+    }
+}
+void pad_nd(hipStream_t s, const float* x, float* y, int rank, const int64_t* in_dims, const int64_t* out_dims, const int64_t* before, int mode, float value) {
+    OAR_CHECK(rank >= 1 && rank <= 6, OAR_UNSUPPORTED_OP, "Pad: rank must be 1..6");
+    PadP p; p.rank = rank; p.mode = mode; p.value = value;
+    long n = 1, st = 1;
+    for (int d = 5; d >= 0; --d) {
+        p.in_dims[d] = d < rank ? in_dims[d] : 1; p.out_dims[d] = d < rank ? out_dims[d] : 1; p.before[d] = d < rank ? before[d] : 0;
+    }
+    for (int d = rank - 1; d >= 0; --d) { p.in_st[d] = st; st *= in_dims[d]; n *= out_dims[d]; }
+    for (int d = rank; d < 6; ++d) p.in_st[d] = 0;
+    if (n == 0) return;
+    ProfScope ps(s, "pad", 8.0 * (double)n, 0.0);
+    hipLaunchKernelGGL(pad_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n, p);
+}
+
 // ------------------------------------------------------------------------------------------ batched GEMM (small, VALU)
 // 64x64 C tile per workgroup, 16x16 threads, 4x4 micro-tile, K step 16 through LDS.
 __global__ __launch_bounds__(256) void gemm_batched_kernel(GemmP p) {

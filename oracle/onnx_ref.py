@@ -274,6 +274,21 @@ def run(model, feeds: dict, want=None):
                 y = F.softplus(x[0])
             elif op == "Gelu":
                 y = F.gelu(x[0], approximate=a.get("approximate", "none"))
+            elif op == "Pad":
+                pads = [int(v) for v in x[1]] if len(x) > 1 and x[1] is not None else list(a.get("pads"))
+                r = x[0].dim()
+                axes = [int(v) % r for v in x[3]] if len(x) > 3 and x[3] is not None else list(range(r))
+                before, after = [0] * r, [0] * r
+                for k_, ax in enumerate(axes):
+                    before[ax], after[ax] = pads[k_], pads[len(axes) + k_]
+                mode = {"constant": "constant", "reflect": "reflect", "edge": "replicate"}[a.get("mode", "constant")]
+                value = float(x[2]) if len(x) > 2 and x[2] is not None else float(a.get("value", 0.0))
+                flat = []
+                for d in range(r - 1, -1, -1):      # torch order: last axis first
+                    flat += [before[d], after[d]]
+                while len(flat) > 2 and flat[-1] == 0 and flat[-2] == 0:
+                    flat = flat[:-2]
+                y = F.pad(x[0], flat, mode=mode, value=value) if mode == "constant" else F.pad(x[0], flat, mode=mode)
             elif op == "PRelu":
                 y = torch.where(x[0] > 0, x[0], x[0] * x[1])
             elif op == "GridSample":

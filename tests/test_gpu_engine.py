@@ -194,6 +194,26 @@ def test_grid_sample(cfg):
         assert (np.abs(got[0][1] - ref[0]) > 1e-4).mean() < 0.02
 
 
+@pytest.mark.parametrize("mode", ["reflect", "edge", "constant"])
+def test_pad_modes(mode):
+    """UVDoc's reflect-padded convolutions export as Pad + Conv; Pad runs on whichever layout its input has."""
+    rng = np.random.default_rng(14)
+
+    def build(g):
+        g.add_input("x", ["N", 4, "H", "W"])
+        w = rng.standard_normal((8, 4, 3, 3)).astype(np.float32) * 0.3
+        a = g.op("Relu", [g.op("Conv", ["x", g.init(w)], kernel_shape=[3, 3], strides=[1, 1], pads=[1, 1, 1, 1], group=1, dilations=[1, 1])])   # channels-last value
+        extra = {"value": 0.75} if mode == "constant" else {}
+        padded = g.op("Pad", [a, g.init(np.array([0, 0, 2, 3, 0, 0, 1, 2], np.int64), "pads")], mode=mode, **extra)
+        w2 = rng.standard_normal((6, 8, 3, 3)).astype(np.float32) * 0.2
+        y = g.op("Conv", [padded, g.init(w2)], kernel_shape=[3, 3], strides=[1, 1], pads=[0, 0, 0, 0], group=1, dilations=[1, 1])
+        flat = g.op("Pad", [g.op("Reshape", ["x", g.init(np.array([0, -1], np.int64), "shape")]), g.init(np.array([0, 2, 0, 1], np.int64), "pads2")], mode=mode)   # rank-2, native layout
+        g.add_output(flat, ["N", "L"])
+        return y, ["N", 6, "Ho", "Wo"]
+
+    _check(_single_op_graph(build), rng.standard_normal((2, 4, 9, 11)).astype(np.float32))
+
+
 def test_squeeze_excite_gate_is_one_kernel():
     """Rewrite pass 6: GlobalAveragePool -> Conv 1x1 + ReLU -> Conv 1x1 + HardSigmoid -> Mul (PP-LCNet's SE block)."""
     rng = np.random.default_rng(13)
