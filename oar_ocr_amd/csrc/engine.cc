@@ -53,6 +53,12 @@ const float* Engine::upload_const(const std::string& key, const std::vector<floa
     return (const float*)p;
 }
 
+// activations that may be folded into a conv / linear / add epilogue (apply_act).  The rest of is_unary_act only ever runs
+// as a stand-alone element-wise kernel (apply_unary): every extra case in apply_act costs registers in each conv epilogue --
+// with all of them in, the depthwise kernel lost a wave per SIMD and a quarter of its bandwidth.
+static bool is_fusable_act(const std::string& op) {
+    return op == "Relu" || op == "HardSwish" || op == "HardSigmoid" || op == "Sigmoid" || op == "LeakyRelu" || op == "Tanh";
+}
 static bool is_unary_act(const std::string& op) {
     return op == "Relu" || op == "HardSwish" || op == "HardSigmoid" || op == "Sigmoid" || op == "LeakyRelu" || op == "Tanh" || op == "Erf" ||
            op == "Sqrt" || op == "Exp" || op == "Abs" || op == "Neg" || op == "Reciprocal" || op == "Log" || op == "Gelu" || op == "Softplus";
@@ -199,7 +205,7 @@ void Engine::rewrite_graph(OnnxModel& m) {
                 const std::string& y = p.out[0];
                 if (graph_outs.count(y)) continue;
                 auto& cs = cons[y];
-                if (cs.size() == 1 && is_unary_act(nodes[cs[0]].op) && !dead[cs[0]]) {
+                if (cs.size() == 1 && is_fusable_act(nodes[cs[0]].op) && !dead[cs[0]]) {
                     GNode& a = nodes[cs[0]];
                     p.act = act_of(a);
                     p.out[0] = a.out[0];

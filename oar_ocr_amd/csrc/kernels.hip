@@ -449,12 +449,12 @@ __global__ __launch_bounds__(256) void unary_kernel(const float* x, float* y, lo
     long n4 = n >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         float4 v = reinterpret_cast<const float4*>(x)[i];
-        v.x = apply_act(v.x, kind, alpha, beta); v.y = apply_act(v.y, kind, alpha, beta);
-        v.z = apply_act(v.z, kind, alpha, beta); v.w = apply_act(v.w, kind, alpha, beta);
+        v.x = apply_unary(v.x, kind, alpha, beta); v.y = apply_unary(v.y, kind, alpha, beta);
+        v.z = apply_unary(v.z, kind, alpha, beta); v.w = apply_unary(v.w, kind, alpha, beta);
         reinterpret_cast<float4*>(y)[i] = v;
     }
     for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        y[i] = apply_act(x[i], kind, alpha, beta);
+        y[i] = apply_unary(x[i], kind, alpha, beta);
 }
 void unary(hipStream_t s, const float* x, float* y, int64_t n, Act act) {
     if (n == 0) return;

@@ -25,6 +25,13 @@ __device__ __forceinline__ float apply_act(float v, int kind, float alpha, float
         case ACT_CLIP: return fminf(fmaxf(v, alpha), beta);
         case ACT_TANH: return tanhf(v);
         case ACT_GELU_ERF: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        default: return v;
+    }
+}
+
+// stand-alone element-wise kernel only: the fused-epilogue set plus the math ops of decomposed GELU / LayerNorm exports
+__device__ __forceinline__ float apply_unary(float v, int kind, float alpha, float beta) {
+    switch (kind) {
         case ACT_ERF: return erff(v);
         case ACT_SQRT: return sqrtf(v);
         case ACT_EXP: return expf(v);
@@ -34,7 +41,7 @@ __device__ __forceinline__ float apply_act(float v, int kind, float alpha, float
         case ACT_LOG: return logf(v);
         case ACT_GELU_TANH: return 0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v)));
         case ACT_SOFTPLUS: return v > 20.0f ? v : log1pf(expf(v));
-        default: return v;
+        default: return apply_act(v, kind, alpha, beta);
     }
 }
 
