@@ -1,5 +1,5 @@
 """Randomised end-to-end parity sweep: OAROCR (HIP, through the C ABI) against the oracle pipeline on random page sizes,
-line counts, thresholds and batch sizes.  usage: python tools/parity_fuzz.py [n_cases] [seed]"""
+line counts, thresholds and batch sizes.  usage: python tools/parity_fuzz.py [n_cases] [seed] [stages|server]"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -11,18 +11,21 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 with_stages = len(sys.argv) > 3 and sys.argv[3] == "stages"   # randomly attach doc orientation / UVDoc / text-line orientation
 cls4, cls2, uvdoc = models.build_cls(4, seed=5)[0], models.build_cls(2, seed=9)[0], models.build_uvdoc(seed=6)[0]
-det, _ = models.build_det("tiny", seed=0)
-rec, _ = models.build_rec("tiny", vocab=6906, seed=1)
-chars = api.read_dict(models.synth_dict(6904))
+server = len(sys.argv) > 3 and sys.argv[3] == "server"       # BASELINE config 3 graphs (wide layers: large-K weight-stationary kernels);
+#                                                               the torch-CPU oracle needs ~15 min per case on them: run a handful at most
+det, _ = models.build_det("server" if server else "tiny", seed=2 if server else 0)
+rec, _ = models.build_rec("server" if server else "tiny", vocab=18710 if server else 6906, seed=3 if server else 1)
+chars = api.read_dict(models.synth_dict(18708 if server else 6904))
+max_side = 640 if server else 1100
 bad = 0
 t0 = time.time()
 for case in range(n_cases):
     n_img = int(rng.integers(1, 5))
     same = rng.random() < 0.5
-    h0, w0 = int(rng.integers(48, 1100)), int(rng.integers(48, 1100))
+    h0, w0 = int(rng.integers(48, max_side)), int(rng.integers(48, max_side))
     imgs = []
     for i in range(n_img):
-        h, w = (h0, w0) if same else (int(rng.integers(48, 1100)), int(rng.integers(48, 1100)))
+        h, w = (h0, w0) if same else (int(rng.integers(48, max_side)), int(rng.integers(48, max_side)))
         imgs.append(pages.make_page(int(rng.integers(0, 1 << 30)), (h, w), int(rng.integers(0, 24))))
     thr, bthr, unclip = float(rng.choice([0.2, 0.3, 0.4])), float(rng.choice([0.5, 0.6, 0.7])), float(rng.choice([1.5, 1.8, 2.0]))
     ibs, rbs = int(rng.choice([1, 2, 8])), int(rng.choice([3, 16, 64]))
