@@ -1018,7 +1018,10 @@ struct Planner {
         int64_t N = x.dims[0], C = x.dims[1], HW = x.dims[2] * x.dims[3];
         TInfo& y = new_out(n.out[0], {N, C, 1, 1}, Layout::CLAST);
         Loc yl = y.loc;
-        step([=](const RunCtx& c) { k::global_avgpool(c.s, c.at(xin), c.mut(yl), (int)N, (int)HW, (int)C); }, 0, 4.0 * numel(x.dims));
+        const int splits = k::global_avgpool_splits((int)N, (int)HW, (int)C);
+        Loc part;
+        if (splits > 1) part = alloc_temp((size_t)N * splits * C * sizeof(float));
+        step([=](const RunCtx& c) { k::global_avgpool(c.s, c.at(xin), c.mut(yl), (int)N, (int)HW, (int)C, splits > 1 ? c.mut(part) : nullptr); }, 0, 4.0 * numel(x.dims));
     }
 
     void op_pool(const GNode& n, bool is_max) {

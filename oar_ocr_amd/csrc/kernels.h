@@ -55,7 +55,9 @@ struct PoolP {
     float* y;
 };
 void pool2d(hipStream_t s, const PoolP& p);
-void global_avgpool(hipStream_t s, const float* x, float* y, int N, int HW, int C);
+// partial: scratch of N * global_avgpool_splits(N, HW, C) * C floats (may be null when the split count is 1)
+int global_avgpool_splits(int N, int HW, int C);
+void global_avgpool(hipStream_t s, const float* x, float* y, int N, int HW, int C, float* partial = nullptr);
 
 // Resize NHWC. mode 0 = nearest, 1 = bilinear. ctm: 0 = asymmetric, 1 = half_pixel, 2 = align_corners,
 // 3 = pytorch_half_pixel. nearest_mode: 0 = floor, 1 = round_prefer_floor, 2 = round_prefer_ceil, 3 = ceil.

@@ -340,32 +340,34 @@ void pool2d(hipStream_t s, const PoolP& p) {
     hipLaunchKernelGGL(pool2d_kernel, dim3(grid_for(total)), dim3(256), 0, s, p);
 }
 
-// One workgroup per image. Lanes run along channels (float4), `parts` thread groups split HW; the partial sums
-// are combined through LDS in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void global_avgpool_kernel(const float* x, float* y, int HW, int C) {
+// One workgroup per (image, pixel split). Lanes run along channels (float4), `parts` thread groups stride over the split's
+// pixels; the partial sums are combined through LDS in a fixed order, and -- when an image is cut into several splits so
+// that a 9-image detector sub-batch still fills the GPU -- by a second launch of the same kernel over the [splits][C]
+// partial sums (fixed order again: deterministic).  scale = 1 / HW on the final pass, 1 on the partial pass.
+__global__ __launch_bounds__(256) void global_avgpool_kernel(const float* x, float* y, int HW, int C, int splits, float div) {
     extern __shared__ float4 red[];  // [parts][C4]
     const int C4 = C >> 2;
     const int parts = 256 / C4 > 0 ? 256 / C4 : 1;
-    const int n = blockIdx.x;
+    const int n = blockIdx.x / splits, sp = blockIdx.x - n * splits;
+    const int per = (HW + splits - 1) / splits, p0 = sp * per, p1 = min(HW, p0 + per);
     const int c4 = threadIdx.x % C4, part = threadIdx.x / C4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (part < parts) {
         const float4* xb = reinterpret_cast<const float4*>(x + (long)n * HW * C) + c4;
-        int i = part;
-        for (; i + 3 * parts < HW; i += 4 * parts) {
+        int i = p0 + part;
+        for (; i + 3 * parts < p1; i += 4 * parts) {
             float4 a = xb[(long)i * C4], b = xb[(long)(i + parts) * C4], c = xb[(long)(i + 2 * parts) * C4], d = xb[(long)(i + 3 * parts) * C4];
             acc.x += (a.x + b.x) + (c.x + d.x); acc.y += (a.y + b.y) + (c.y + d.y);
             acc.z += (a.z + b.z) + (c.z + d.z); acc.w += (a.w + b.w) + (c.w + d.w);
         }
-        for (; i < HW; i += parts) { float4 a = xb[(long)i * C4]; acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+        for (; i < p1; i += parts) { float4 a = xb[(long)i * C4]; acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
         red[part * C4 + c4] = acc;
     }
     __syncthreads();
     if (part == 0) {
         float4 t = red[c4];
         for (int q = 1; q < parts; ++q) { float4 u = red[q * C4 + c4]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-        float inv = (float)HW;
-        reinterpret_cast<float4*>(y + (long)n * C)[c4] = make_float4(t.x / inv, t.y / inv, t.z / inv, t.w / inv);
+        reinterpret_cast<float4*>(y + (long)blockIdx.x * C)[c4] = make_float4(t.x / div, t.y / div, t.z / div, t.w / div);
     }
 }
 __global__ __launch_bounds__(256) void global_avgpool_scalar_kernel(const float* x, float* y, int HW, int C) {
@@ -376,12 +378,26 @@ __global__ __launch_bounds__(256) void global_avgpool_scalar_kernel(const float*
     for (int i = 0; i < HW; ++i) acc += xb[(long)i * C];
     y[(long)n * C + c] = acc / (float)HW;
 }
-void global_avgpool(hipStream_t s, const float* x, float* y, int N, int HW, int C) {
+int global_avgpool_splits(int N, int HW, int C) {
+    if ((C & 3) != 0 || C / 4 > 256 || N <= 0) return 1;
+    // enough workgroups for the 256 CUs, at least 256 pixels per split
+    int s = (1024 + N - 1) / N;
+    s = std::min(s, std::max(HW / 256, 1));
+    return std::max(1, std::min(s, 256));
+}
+void global_avgpool(hipStream_t s, const float* x, float* y, int N, int HW, int C, float* partial) {
     if (N == 0 || C == 0) return;
     ProfScope ps(s, "global_avgpool", 4.0 * (double)N * HW * C, 0.0);
     if ((C & 3) == 0 && C / 4 <= 256) {
-        int C4 = C / 4, parts = 256 / C4;
-        hipLaunchKernelGGL(global_avgpool_kernel, dim3(N), dim3(256), (size_t)parts * C4 * sizeof(float4), s, x, y, HW, C);
+        const int C4 = C / 4, parts = 256 / C4;
+        const size_t lds = (size_t)parts * C4 * sizeof(float4);
+        const int splits = partial ? global_avgpool_splits(N, HW, C) : 1;
+        if (splits == 1) {
+            hipLaunchKernelGGL(global_avgpool_kernel, dim3(N), dim3(256), lds, s, x, y, HW, C, 1, (float)HW);
+        } else {
+            hipLaunchKernelGGL(global_avgpool_kernel, dim3(N * splits), dim3(256), lds, s, x, partial, HW, C, splits, 1.0f);
+            hipLaunchKernelGGL(global_avgpool_kernel, dim3(N), dim3(256), lds, s, (const float*)partial, y, splits, C, 1, (float)HW);
+        }
     } else {
         hipLaunchKernelGGL(global_avgpool_scalar_kernel, dim3((C + 255) / 256, N), dim3(256), 0, s, x, y, HW, C);
     }
