@@ -86,9 +86,8 @@ void ThreadPool::loop() {
         seen = g;
         const std::function<void(int)>* fn = fn_;
         const int count = count_.load(std::memory_order_acquire);
-        while (true) {
-            int i = next_.fetch_add(1, std::memory_order_acq_rel);
-            if (i >= count) break;
+        int i;
+        while (claim(g, count, i)) {
             try {
                 (*fn)(i);
             } catch (...) {
@@ -99,24 +98,34 @@ void ThreadPool::loop() {
         }
     }
 }
+bool ThreadPool::claim(int gen, int count, int& index) {
+    uint64_t v = state_.load(std::memory_order_acquire);
+    for (;;) {
+        if ((int)(v >> 32) != gen) return false;            // the job this descriptor belongs to is over
+        const int i = (int)(v & 0xffffffffu);
+        if (i >= count) return false;
+        if (state_.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel, std::memory_order_acquire)) { index = i; return true; }
+    }
+}
 void ThreadPool::parallel_for(int count, const std::function<void(int)>& fn) {
     if (count <= 0) return;
     if (workers_.empty() || count == 1) {
         for (int i = 0; i < count; ++i) fn(i);
         return;
     }
+    // publish the job: descriptor first, then the (generation, 0) claim word, then the generation the workers poll
+    const int g = gen_.load(std::memory_order_relaxed) + 1;
     fn_ = &fn;
     done_.store(0, std::memory_order_relaxed);
-    next_.store(0, std::memory_order_relaxed);
-    count_.store(count, std::memory_order_release);
-    gen_.fetch_add(1, std::memory_order_acq_rel);
+    count_.store(count, std::memory_order_relaxed);
+    state_.store((uint64_t)(uint32_t)g << 32, std::memory_order_release);
+    gen_.store(g, std::memory_order_release);
     {
         std::lock_guard<std::mutex> lk(mu_);
         cv_.notify_all();
     }
-    while (true) {  // the caller works too
-        int i = next_.fetch_add(1, std::memory_order_acq_rel);
-        if (i >= count) break;
+    int i;
+    while (claim(g, count, i)) {  // the caller works too
         try {
             fn(i);
         } catch (...) {
@@ -126,7 +135,7 @@ void ThreadPool::parallel_for(int count, const std::function<void(int)>& fn) {
         done_.fetch_add(1, std::memory_order_acq_rel);
     }
     while (done_.load(std::memory_order_acquire) < count) cpu_relax();
-    // late workers may still bump next_ past count; they never touch fn again once next_ >= count
+    // every claimed index has finished; a late worker still holding this job's descriptor fails its next claim (generation)
     std::exception_ptr e;
     {
         std::lock_guard<std::mutex> g2(err_mu_);

@@ -31,7 +31,12 @@ class ThreadPool {
     std::mutex mu_;
     std::condition_variable cv_;
     const std::function<void(int)>* fn_ = nullptr;
-    std::atomic<int> gen_{0}, next_{0}, done_{0}, count_{0};
+    std::atomic<int> gen_{0}, done_{0}, count_{0};
+    // (generation << 32) | next index.  An index is claimed by CAS, so a worker that is still holding an OLD job's
+    // descriptor can never take an index of the next job (with a bare counter it could, and then ran the old, already
+    // destroyed closure on it).
+    std::atomic<uint64_t> state_{0};
+    bool claim(int gen, int count, int& index);
     std::atomic<bool> stop_{false};
     std::mutex err_mu_;
     std::exception_ptr err_;
