@@ -298,6 +298,9 @@ int32_t oar_host_unclip(const float box8[8], float ratio, float* out_xy, int32_t
 int32_t oar_host_mini_box(const float* xy, int32_t n_points, float box8[8], float* min_side);
 /* a13 processors/sorting.rs:35-84: permutation that sorts n quad boxes into reading order. */
 void oar_host_sort_quad_boxes(const float* boxes8, int32_t n, int32_t* order);
+/* Self-test of the geometry thread pool: `jobs` back-to-back parallel loops of varying length on `threads` workers;
+   returns 0 when every index of every loop ran exactly once in its own loop, else 1 + the index of the first bad loop. */
+int32_t oar_host_pool_selftest(int32_t threads, int32_t jobs);
 /* a14 utils/transform.rs:76-191 planning half: plan[8] = {mode, left, top, cw, ch, out_w, out_h, rot}; inv[9]. */
 void oar_host_plan_crop(uint32_t img_w, uint32_t img_h, const float box8[8], int32_t plan[8], float inv[9]);
 

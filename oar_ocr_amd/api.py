@@ -100,7 +100,7 @@ EXPORTS = [
     "oar_ocr_predict", "oar_ocr_predict_device", "oar_ocr_result_free", "oar_dev_alloc", "oar_dev_upload", "oar_dev_download",
     "oar_dev_free", "oar_dev_synchronize", "oar_k_normalize", "oar_k_rec_preprocess", "oar_k_resize_triangle", "oar_k_threshold",
     "oar_k_ctc_argmax", "oar_k_box_scores", "oar_k_rotate_crop", "oar_prof_reset", "oar_prof_enable", "oar_prof_filter", "oar_prof_sampling", "oar_prof_snapshot",
-    "oar_host_candidates", "oar_host_unclip", "oar_host_mini_box", "oar_host_sort_quad_boxes", "oar_host_plan_crop",
+    "oar_host_candidates", "oar_host_unclip", "oar_host_mini_box", "oar_host_sort_quad_boxes", "oar_host_pool_selftest", "oar_host_plan_crop",
     "oar_cls_create", "oar_cls_destroy", "oar_cls_run", "oar_cls_result_free", "oar_cls_preprocess", "oar_rect_create", "oar_rect_destroy",
     "oar_rect_run", "oar_ocr_attach", "oar_k_rotate_rgb", "oar_k_bgr_planes_to_rgb", "oar_host_rotate_back_points",
 ]

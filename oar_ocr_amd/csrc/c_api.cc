@@ -659,6 +659,27 @@ int32_t oar_host_mini_box(const float* xy, int32_t n_points, float box8[8], floa
         return 1;
     } catch (...) { return -1; }
 }
+int32_t oar_host_pool_selftest(int32_t threads, int32_t jobs) {
+    try {
+        ThreadPool pool(threads);
+        for (int j = 0; j < jobs; ++j) {
+            const int count = 2 + (j * 7) % 37;
+            std::vector<std::atomic<int>> seen(count);
+            for (auto& a : seen) a.store(0);
+            std::atomic<int> bad{0};
+            const int tag = j;
+            pool.parallel_for(count, [&seen, &bad, count, tag](int i) {
+                if (i < 0 || i >= count || tag < 0) bad.fetch_add(1);
+                else seen[i].fetch_add(1);
+            });
+            if (bad.load()) return j + 1;
+            for (auto& a : seen) if (a.load() != 1) return j + 1;
+        }
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}
 void oar_host_sort_quad_boxes(const float* boxes8, int32_t n, int32_t* order) {
     try {
         std::vector<float> b(boxes8, boxes8 + (size_t)n * 8);

@@ -94,3 +94,14 @@ def test_unclip_minibox_sort_crop_plan_match_oracle():
     # degenerate boxes are dropped, not crashed on
     assert len(api.host_unclip(np.zeros((4, 2), np.float32), 1.5)) == 0
     assert api.host_plan_crop(100, 100, np.array([[5, 5]] * 4, np.float32))[0][0] == 0
+
+
+def test_thread_pool_back_to_back_jobs():
+    """Every index of every loop runs exactly once, in its own loop -- also with more workers than cores, where a worker
+    is regularly descheduled between reading a job's descriptor and claiming its first index."""
+    import ctypes as C
+    L = api.lib()
+    L.oar_host_pool_selftest.argtypes = [C.c_int32, C.c_int32]
+    L.oar_host_pool_selftest.restype = C.c_int32
+    for threads in (2, 7, 16, 48):
+        assert L.oar_host_pool_selftest(threads, 20000) == 0
