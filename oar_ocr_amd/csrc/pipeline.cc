@@ -84,7 +84,7 @@ void ThreadPool::loop() {
             if (stop_.load(std::memory_order_acquire)) return;
         }
         seen = g;
-        const std::function<void(int)>* fn = fn_;
+        const std::function<void(int)>* fn = fn_.load(std::memory_order_relaxed);
         const int count = count_.load(std::memory_order_acquire);
         int i;
         while (claim(g, count, i)) {
@@ -115,7 +115,7 @@ void ThreadPool::parallel_for(int count, const std::function<void(int)>& fn) {
     }
     // publish the job: descriptor first, then the (generation, 0) claim word, then the generation the workers poll
     const int g = gen_.load(std::memory_order_relaxed) + 1;
-    fn_ = &fn;
+    fn_.store(&fn, std::memory_order_relaxed);
     done_.store(0, std::memory_order_relaxed);
     count_.store(count, std::memory_order_relaxed);
     state_.store((uint64_t)(uint32_t)g << 32, std::memory_order_release);

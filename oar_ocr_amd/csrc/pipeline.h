@@ -30,7 +30,7 @@ class ThreadPool {
     std::vector<std::thread> workers_;
     std::mutex mu_;
     std::condition_variable cv_;
-    const std::function<void(int)>* fn_ = nullptr;
+    std::atomic<const std::function<void(int)>*> fn_{nullptr};   // published before gen_ (release), read after it (acquire)
     std::atomic<int> gen_{0}, done_{0}, count_{0};
     // (generation << 32) | next index.  An index is claimed by CAS, so a worker that is still holding an OLD job's
     // descriptor can never take an index of the next job (with a bare counter it could, and then ran the old, already
