@@ -79,6 +79,16 @@ void oar_tensor_free(oar_tensor* t);
 oar_status oar_engine_cost(oar_engine* e, const int64_t* dims, int32_t rank, double* flops, double* bytes,
                            int32_t* n_kernels);
 
+/* Plan-cache statistics: plans are specialised per input shape and kept in an LRU of OAR_PLAN_CACHE (default 256)
+ * entries per engine, so a long-running server on heterogeneous pages has bounded host memory. */
+oar_status oar_engine_cache_stats(oar_engine* e, uint64_t* cached_plans, uint64_t* evicted_plans);
+/* Host-only model check (no GPU needed): parses the file exactly as oar_engine_create does and writes a one-line
+ * summary "opset=.. input=.. nodes=.. | Op:count ..." (operators the engine does not implement are prefixed '!').
+ * OAR_MODEL_LOAD for a malformed / truncated file (dims, payload sizes and ranks are validated before anything is
+ * indexed), OAR_UNSUPPORTED_OP when an operator is missing.  Stands where `Session::builder().commit_from_file`
+ * fails in the reference (core/inference/session.rs:30-44). */
+oar_status oar_onnx_inspect(const uint8_t* onnx, size_t onnx_len, char* summary, size_t cap);
+
 /* ------------------------------------------------------------------------------------------------ Seam B: detection
  * TextDetectionAdapter::execute (domain/adapters/text_detection_adapter.rs:36-79) -> DBModel::forward
  * (models/detection/db.rs:281-335): resize (processors/resize_detection.rs:243-319) -> normalize

@@ -103,6 +103,7 @@ EXPORTS = [
     "oar_host_candidates", "oar_host_unclip", "oar_host_mini_box", "oar_host_sort_quad_boxes", "oar_host_pool_selftest", "oar_host_plan_crop",
     "oar_cls_create", "oar_cls_destroy", "oar_cls_run", "oar_cls_result_free", "oar_cls_preprocess", "oar_rect_create", "oar_rect_destroy",
     "oar_rect_run", "oar_ocr_attach", "oar_k_rotate_rgb", "oar_k_bgr_planes_to_rgb", "oar_host_rotate_back_points",
+    "oar_engine_cache_stats", "oar_onnx_inspect",
 ]
 
 
@@ -129,6 +130,8 @@ def lib():
     L.oar_tensor_free.argtypes = [C.POINTER(Tensor)]
     L.oar_tensor_free.restype = None
     L.oar_engine_cost.argtypes = [vp, C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    L.oar_engine_cache_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.oar_onnx_inspect.argtypes = [vp, C.c_size_t, C.c_char_p, C.c_size_t]
     L.oar_det_create.argtypes = [vp, C.c_size_t, C.POINTER(DetCfg), C.POINTER(vp)]
     L.oar_det_destroy.argtypes = [vp]
     L.oar_det_destroy.restype = None
@@ -213,6 +216,15 @@ def version() -> str:
     return buf.value.decode()
 
 
+def onnx_inspect(model: bytes) -> str:
+    """Host-only: parse + validate a model like oar_engine_create does; returns the op-histogram summary."""
+    buf = C.create_string_buffer(8192)
+    b = (C.c_char * max(len(model), 1)).from_buffer_copy(model or b"\0")
+    st = lib().oar_onnx_inspect(C.cast(b, C.c_void_p), len(model), buf, 8192)
+    _check(st)
+    return buf.value.decode()
+
+
 def device_count() -> int:
     return int(lib().oar_device_count())
 
@@ -263,6 +275,12 @@ class OrtInfer:
             res.append((t.name.decode(), arr))
             lib().oar_tensor_free(C.byref(outs[i]))
         return res
+
+    def cache_stats(self):
+        """(cached plans, evicted plans): plans are per input shape, LRU-bounded (OAR_PLAN_CACHE, default 256)."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _check(lib().oar_engine_cache_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def cost(self, shape):
         dims = (C.c_int64 * len(shape))(*shape)

@@ -157,6 +157,35 @@ void oar_tensor_free(oar_tensor* t) {
     if (t && t->data) { std::free(t->data); t->data = nullptr; }
 }
 
+oar_status oar_engine_cache_stats(oar_engine* e, uint64_t* cached_plans, uint64_t* evicted_plans) {
+    return guard([&] {
+        OAR_CHECK(e, OAR_INVALID_INPUT, "oar_engine_cache_stats: engine is null");
+        std::lock_guard<std::mutex> lk(e->e->mutex());
+        if (cached_plans) *cached_plans = e->e->cached_plans();
+        if (evicted_plans) *evicted_plans = e->e->evicted_plans();
+    });
+}
+
+oar_status oar_onnx_inspect(const uint8_t* onnx, size_t onnx_len, char* summary, size_t cap) {
+    if (summary && cap) summary[0] = 0;
+    return guard([&] {
+        OnnxModel m = parse_onnx(onnx, onnx_len);   // throws OAR_MODEL_LOAD on malformed / truncated files
+        Engine::validate_model(m);
+        std::map<std::string, int> hist;
+        for (auto& n : m.nodes) hist[n.op]++;
+        std::string text, missing;
+        for (auto& kv : hist) {
+            const bool ok = Engine::supported_ops().count(kv.first) != 0;
+            text += (text.empty() ? "" : " ") + std::string(ok ? "" : "!") + kv.first + ":" + std::to_string(kv.second);
+            if (!ok) missing += (missing.empty() ? "" : ", ") + kv.first;
+        }
+        text = "opset=" + std::to_string(m.opset) + " input=" + m.inputs[0] + " outputs=" + std::to_string(m.outputs.size()) + " initializers=" +
+               std::to_string(m.initializers.size()) + " nodes=" + std::to_string(m.nodes.size()) + " | " + text;
+        if (summary && cap) snprintf(summary, cap, "%s", text.c_str());
+        OAR_CHECK(missing.empty(), OAR_UNSUPPORTED_OP, "operators not implemented: " + missing);
+    });
+}
+
 oar_status oar_engine_cost(oar_engine* e, const int64_t* dims, int32_t rank, double* flops, double* bytes, int32_t* n_kernels) {
     return guard([&] {
         OAR_CHECK(e && dims && rank > 0, OAR_INVALID_INPUT, "oar_engine_cost: bad arguments");
@@ -321,8 +350,9 @@ static oar_status ocr_predict_impl(oar_ocr* o, const uint8_t* const* rgb, const 
             pages[i].w = widths[i]; pages[i].h = heights[i];
         }
         std::vector<std::vector<OcrRegion>> res;
-        o->o->predict(pages, res);
-        fill_ocr_result(res, o->o->page_meta(), out);
+        std::vector<Ocr::PageMeta> meta;
+        o->o->predict(pages, res, &meta);
+        fill_ocr_result(res, meta, out);
     });
 }
 oar_status oar_ocr_predict(oar_ocr* o, const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights, uint32_t n_images,
@@ -661,19 +691,58 @@ int32_t oar_host_mini_box(const float* xy, int32_t n_points, float box8[8], floa
 }
 int32_t oar_host_pool_selftest(int32_t threads, int32_t jobs) {
     try {
-        ThreadPool pool(threads);
-        for (int j = 0; j < jobs; ++j) {
-            const int count = 2 + (j * 7) % 37;
-            std::vector<std::atomic<int>> seen(count);
-            for (auto& a : seen) a.store(0);
+        // phase 1: back-to-back loops of varying length
+        {
+            ThreadPool pool(threads);
+            for (int j = 0; j < jobs; ++j) {
+                const int count = 2 + (j * 7) % 37;
+                std::vector<std::atomic<int>> seen(count);
+                for (auto& a : seen) a.store(0);
+                std::atomic<int> bad{0};
+                const int tag = j;
+                pool.parallel_for(count, [&seen, &bad, count, tag](int i) {
+                    if (i < 0 || i >= count || tag < 0) bad.fetch_add(1);
+                    else seen[i].fetch_add(1);
+                });
+                if (bad.load()) return j + 1;
+                for (auto& a : seen) if (a.load() != 1) return j + 1;
+            }
+        }
+        // phase 2: the stale-descriptor window.  Counts GROW from job to job, some workers are late between seeing a
+        // generation and reading its descriptor, and the publisher dawdles between writing the descriptor and opening the
+        // claim word: a late worker of job j must not obtain index count_j of job j (it would run it twice / on the dead
+        // closure) although it may already read job j+1's larger count.  Every job's counters live in one long-lived
+        // table so that a stray index shows up as a count != 1 instead of a crash.
+        {
+            ThreadPool pool(threads);
+            std::atomic<uint32_t> rng{12345};
+            auto jitter = [&rng](int max_spins) {
+                uint32_t x = rng.fetch_add(0x9e3779b9u, std::memory_order_relaxed);
+                x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
+                if ((x & 3) != 0) return;                       // 1 in 4 calls dawdles
+                const int spins = (int)((x >> 8) % (uint32_t)max_spins);
+                for (volatile int k = 0; k < spins; ++k) {}
+            };
+            pool.selftest_worker_delay_ = [&] { jitter(20000); };
+            pool.selftest_publish_delay_ = [&] { jitter(4000); };
+            const int rounds = std::max(1, jobs / 8), kMax = 96;
+            std::vector<std::atomic<int>> table((size_t)rounds * kMax);
+            for (auto& a : table) a.store(0);
             std::atomic<int> bad{0};
-            const int tag = j;
-            pool.parallel_for(count, [&seen, &bad, count, tag](int i) {
-                if (i < 0 || i >= count || tag < 0) bad.fetch_add(1);
-                else seen[i].fetch_add(1);
-            });
-            if (bad.load()) return j + 1;
-            for (auto& a : seen) if (a.load() != 1) return j + 1;
+            for (int j = 0; j < rounds; ++j) {
+                const int count = 2 + (j % 24) * 4;             // 2, 6, 10, ... 94, then back to 2
+                std::atomic<int>* row = table.data() + (size_t)j * kMax;
+                pool.parallel_for(count, [row, &bad, count](int i) {
+                    if (i < 0 || i >= count) bad.fetch_add(1);
+                    else row[i].fetch_add(1);
+                });
+                if (bad.load()) return 100000 + j + 1;
+            }
+            for (int j = 0; j < rounds; ++j) {
+                const int count = 2 + (j % 24) * 4;
+                for (int i = 0; i < kMax; ++i)
+                    if (table[(size_t)j * kMax + i].load() != (i < count ? 1 : 0)) return 100000 + j + 1;
+            }
         }
         return 0;
     } catch (...) {

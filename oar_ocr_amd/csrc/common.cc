@@ -40,7 +40,7 @@ hipEvent_t Profiler::ev() {
 }
 thread_local Profiler::GraphEvents* Profiler::capturing = nullptr;
 
-void Profiler::begin(hipStream_t s, int c, double bytes, double flops) {
+size_t Profiler::begin(hipStream_t s, int c, double bytes, double flops) {
     std::lock_guard<std::mutex> lk(mu);
     Pending p;
     p.a = ev();
@@ -48,13 +48,15 @@ void Profiler::begin(hipStream_t s, int c, double bytes, double flops) {
     p.cls = c;
     p.bytes = bytes;
     p.flops = flops;
+    p.b_recorded = false;
     if (capturing) {   // external event-record node: re-recorded by every replay, readable from the host afterwards
         OAR_HIP(hipEventRecordWithFlags(p.a, s, hipEventRecordExternal));
         capturing->ev.push_back(p);
-    } else {
-        OAR_HIP(hipEventRecord(p.a, s));
-        pending.push_back(p);
+        return capturing->ev.size() - 1;
     }
+    OAR_HIP(hipEventRecord(p.a, s));
+    pending.push_back(p);
+    return pending_base + pending.size() - 1;
 }
 bool Profiler::begin_ext(int c, double bytes, double flops, hipEvent_t& a, hipEvent_t& b) {
     std::lock_guard<std::mutex> lk(mu);
@@ -65,24 +67,27 @@ bool Profiler::begin_ext(int c, double bytes, double flops, hipEvent_t& a, hipEv
     p.cls = c;
     p.bytes = bytes;
     p.flops = flops;
+    p.b_recorded = true;   // bound to the dispatch itself by hipExtLaunchKernelGGL
     pending.push_back(p);
     return true;
 }
-void Profiler::end(hipStream_t s) {
+void Profiler::end(hipStream_t s, size_t handle) {
     std::lock_guard<std::mutex> lk(mu);
     if (capturing) {
-        if (!capturing->ev.empty()) (void)hipEventRecordWithFlags(capturing->ev.back().b, s, hipEventRecordExternal);
+        if (handle < capturing->ev.size()) { (void)hipEventRecordWithFlags(capturing->ev[handle].b, s, hipEventRecordExternal); capturing->ev[handle].b_recorded = true; }
         return;
     }
-    if (pending.empty()) return;
-    // the most recent pending entry on this thread's stream
-    (void)hipEventRecord(pending.back().b, s);
+    // handles count entries since the profiler was created; a flush() in between (only legal with idle streams, i.e. no
+    // open scope) retires everything below pending_base
+    if (handle < pending_base || handle - pending_base >= pending.size()) return;
+    Pending& p = pending[handle - pending_base];
+    if (hipEventRecord(p.b, s) == hipSuccess) p.b_recorded = true;
 }
 static void harvest_locked(Profiler& P, Profiler::GraphEvents& g) {
     if (!g.launched) return;
     for (auto& p : g.ev) {
         float ms = 0.f;
-        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+        if (p.b_recorded && hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             auto& t = P.totals[p.cls];
             t.launches += 1;
             t.total_ms += ms;
@@ -110,7 +115,7 @@ void Profiler::flush() {
     }
     for (auto& p : pending) {
         float ms = 0.f;
-        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+        if (p.b_recorded && hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             auto& t = totals[p.cls];
             t.launches += 1;
             t.total_ms += ms;
@@ -120,6 +125,7 @@ void Profiler::flush() {
         pool.push_back(p.a);
         pool.push_back(p.b);
     }
+    pending_base += pending.size();
     pending.clear();
 }
 void Profiler::reset() {

@@ -92,6 +92,7 @@ struct Profiler {
         hipEvent_t a, b;
         int cls;
         double bytes, flops;
+        bool b_recorded = false;   // an entry whose stop event was never recorded is skipped (hipEventElapsedTime would fail)
     };
     // Events recorded by the event-record nodes of ONE captured hipGraph (Engine keeps one per graph).  Every replay
     // re-records the same events, so they are harvested into the totals before the graph is launched again and at flush().
@@ -115,18 +116,22 @@ struct Profiler {
     std::map<std::string, int> index;
     std::vector<oar_prof_entry> totals;
     std::vector<Pending> pending;
+    size_t pending_base = 0;   // handle of pending[0]
     std::vector<hipEvent_t> pool;
 
     static Profiler& get();
     int cls(const char* name);
     hipEvent_t ev();
-    void begin(hipStream_t s, int cls, double bytes, double flops);
+    // Returns the handle end() needs: the index of the entry begin() created (in `pending`, or in the capturing graph's
+    // list).  Scopes from several host threads / handles interleave in the process-global list, so "the last entry" is not
+    // necessarily this scope's.
+    size_t begin(hipStream_t s, int cls, double bytes, double flops);
     // Events for ONE kernel launched with hipExtLaunchKernelGGL(..., a, b, 0, ...): they are bound to the dispatch's own
     // completion signal (its begin / end timestamps), so the stream carries no extra barrier packets -- two
     // hipEventRecord calls around a kernel cost ~6 us of idle queue on either side of it (rocprofv3 kernel trace).
     // Returns false while a graph is being captured (use begin / end there).
     bool begin_ext(int cls, double bytes, double flops, hipEvent_t& a, hipEvent_t& b);
-    void end(hipStream_t s);
+    void end(hipStream_t s, size_t handle);
     void flush();  // requires the streams to be idle
     void reset();
 };
@@ -136,6 +141,7 @@ struct ProfScope {
     bool on;
     bool ext = false;
     hipEvent_t a = nullptr, b = nullptr;
+    size_t handle = 0;
     // single_launch: the scope covers exactly one kernel and the launch site passes start() / stop() to
     // hipExtLaunchKernelGGL (null events = a plain launch).
     ProfScope(hipStream_t s_, const char* name, double bytes, double flops, bool single_launch = false) : s(s_) {
@@ -149,10 +155,10 @@ struct ProfScope {
         if (!on) return;
         const int c = p.cls(name);
         if (single_launch && p.begin_ext(c, bytes, flops, a, b)) ext = true;
-        else p.begin(s, c, bytes, flops);
+        else handle = p.begin(s, c, bytes, flops);
     }
     ~ProfScope() {
-        if (on && !ext) Profiler::get().end(s);
+        if (on && !ext) Profiler::get().end(s, handle);
     }
     hipEvent_t start() const { return ext ? a : nullptr; }
     hipEvent_t stop() const { return ext ? b : nullptr; }

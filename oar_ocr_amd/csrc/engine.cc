@@ -27,8 +27,10 @@ Engine::Engine(const uint8_t* onnx, size_t len, int device_id) : device_(device_
     OAR_HIP(hipSetDevice(device_));
     OAR_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     OnnxModel m = parse_onnx(onnx, len);
+    validate_model(m);
     input_name_ = m.inputs[0];
     output_names_ = m.outputs;
+    if (const char* e = getenv("OAR_PLAN_CACHE")) { long v = atol(e); if (v >= 2) plan_cap_ = (size_t)v; }
     opset_ = m.opset;
     rewrite_graph(m);
 }
@@ -130,6 +132,11 @@ void Engine::rewrite_graph(OnnxModel& m) {
             const auto &ga = inits_[bn.in[1]].f, &be = inits_[bn.in[2]].f, &mu = inits_[bn.in[3]].f, &va = inits_[bn.in[4]].f;
             float eps = bn.af("epsilon", 1e-5f);
             int64_t C = (int64_t)ga.size();
+            OAR_CHECK(W.dtype == DType::F32 && W.dims.size() == 4, OAR_MODEL_LOAD, "BN fold: conv weight must be a rank-4 f32 initializer (" + cv.in[1] + ")");
+            OAR_CHECK(C > 0 && (int64_t)be.size() == C && (int64_t)mu.size() == C && (int64_t)va.size() == C, OAR_MODEL_LOAD,
+                      "BatchNormalization: scale / bias / mean / var must all have C elements (" + bn.out[0] + ")");
+            if (cv.in.size() > 2 && !cv.in[2].empty())
+                OAR_CHECK((int64_t)inits_[cv.in[2]].f.size() == C, OAR_MODEL_LOAD, "BN fold: conv bias must have C elements (" + cv.in[2] + ")");
             HostTensor W2 = W;
             std::vector<float> b2(C, 0.f);
             if (cv.in.size() > 2 && !cv.in[2].empty()) b2 = inits_[cv.in[2]].f;
@@ -721,9 +728,11 @@ struct Planner {
         const TInfo& wt = get(n.in[1]);
         OAR_CHECK(wt.ht, OAR_UNSUPPORTED_OP, "Conv: weights must be an initializer");
         const HostTensor& W = *wt.ht;
+        OAR_CHECK(W.dims.size() == 4 && W.dims[0] > 0 && W.dims[1] > 0 && W.dims[2] > 0 && W.dims[3] > 0, OAR_MODEL_LOAD, "Conv: weight must be rank 4 with positive dims at " + n.out[0]);
         int64_t N = x.dims[0], Cin = x.dims[1], H = x.dims[2], Wd = x.dims[3];
         int64_t Cout = W.dims[0], kh = W.dims[2], kw = W.dims[3], g = n.ai("group", 1);
-        OAR_CHECK(W.dims[1] * g == Cin, OAR_SHAPE_MISMATCH, "Conv: weight/input channel mismatch at " + n.out[0]);
+        OAR_CHECK(g >= 1 && W.dims[1] * g == Cin && Cout % g == 0, OAR_SHAPE_MISMATCH, "Conv: weight/input channel mismatch at " + n.out[0]);
+        if (has_input(n, 2)) { const TInfo& bt = get(n.in[2]); OAR_CHECK(bt.ht && (int64_t)bt.ht->f.size() == Cout, OAR_MODEL_LOAD, "Conv: bias must be an f32 initializer of Cout elements at " + n.out[0]); }
         auto st = n.ais("strides"), dl = n.ais("dilations");
         int64_t sh = st.size() == 2 ? st[0] : 1, sw = st.size() == 2 ? st[1] : 1;
         int64_t dh = dl.size() == 2 ? dl[0] : 1, dw = dl.size() == 2 ? dl[1] : 1;
@@ -781,6 +790,8 @@ struct Planner {
         const TInfo& wt = get(n.in[1]);
         OAR_CHECK(wt.ht, OAR_UNSUPPORTED_OP, "ConvTranspose: weights must be an initializer");
         const HostTensor& W = *wt.ht;
+        OAR_CHECK(W.dims.size() == 4 && W.dims[0] == x.dims[1] && W.dims[1] > 0 && W.dims[2] > 0 && W.dims[3] > 0, OAR_MODEL_LOAD, "ConvTranspose: weight must be [Cin, Cout, kh, kw] at " + n.out[0]);
+        if (has_input(n, 2)) { const TInfo& bt = get(n.in[2]); OAR_CHECK(bt.ht && (int64_t)bt.ht->f.size() == W.dims[1], OAR_MODEL_LOAD, "ConvTranspose: bias must be an f32 initializer of Cout elements at " + n.out[0]); }
         OAR_CHECK(n.ai("group", 1) == 1, OAR_UNSUPPORTED_OP, "ConvTranspose: group != 1");
         int64_t N = x.dims[0], Cin = x.dims[1], H = x.dims[2], Wd = x.dims[3];
         int64_t Cout = W.dims[1], kh = W.dims[2], kw = W.dims[3];
@@ -816,6 +827,8 @@ struct Planner {
         const auto &ga = get(n.in[1]), &be = get(n.in[2]), &mu = get(n.in[3]), &va = get(n.in[4]);
         OAR_CHECK(ga.ht && be.ht && mu.ht && va.ht, OAR_UNSUPPORTED_OP, "BatchNormalization: params must be initializers");
         int64_t C = x.dims[1];
+        OAR_CHECK((int64_t)ga.ht->f.size() == C && (int64_t)be.ht->f.size() == C && (int64_t)mu.ht->f.size() == C && (int64_t)va.ht->f.size() == C, OAR_MODEL_LOAD,
+                  "BatchNormalization: scale / bias / mean / var must all have C elements (" + n.out[0] + ")");
         float eps = n.af("epsilon", 1e-5f);
         std::vector<float> sc(C), sh(C);
         for (int64_t c = 0; c < C; ++c) { sc[c] = ga.ht->f[c] / std::sqrt(va.ht->f[c] + eps); sh[c] = be.ht->f[c] - mu.ht->f[c] * sc[c]; }
@@ -1328,6 +1341,7 @@ struct Planner {
         TInfo a = get(n.in[0]);
         const TInfo& bt = get(n.in[1]);
         OAR_CHECK(bt.ht, OAR_UNSUPPORTED_OP, "Linear: B must be an initializer");
+        OAR_CHECK(bt.ht->dims.size() == 2 && !a.dims.empty(), OAR_MODEL_LOAD, "Linear: B must be a rank-2 initializer at " + n.out[0]);
         bool transB = gemm && n.ai("transB", 0) != 0;
         OAR_CHECK(!gemm || n.ai("transA", 0) == 0, OAR_UNSUPPORTED_OP, "Gemm: transA");
         int64_t K = transB ? bt.ht->dims[1] : bt.ht->dims[0], N = transB ? bt.ht->dims[0] : bt.ht->dims[1];
@@ -1338,7 +1352,7 @@ struct Planner {
         od.back() = N;
         const float* bias = nullptr;
         float alpha = gemm ? n.af("alpha", 1.0f) : 1.0f;
-        if (!n.bias.empty()) bias = get(n.bias).loc.cptr;
+        if (!n.bias.empty()) { const TInfo& bb = get(n.bias); OAR_CHECK(bb.ht && (int64_t)bb.ht->f.size() == N, OAR_MODEL_LOAD, "Linear: bias must have N elements at " + n.out[0]); bias = bb.loc.cptr; }
         if (gemm && has_input(n, 2)) {
             const TInfo& c = get(n.in[2]);
             OAR_CHECK(c.ht && numel(c.dims) == N && n.af("beta", 1.0f) == 1.0f, OAR_UNSUPPORTED_OP, "Gemm: C must be a constant [N] with beta 1");
@@ -1625,20 +1639,101 @@ struct Planner {
     }
 };
 
+// Host-only structural checks of the initializers the load-time rewrites and the planner index by their DECLARED dims
+// (a malformed file must end in OAR_MODEL_LOAD, not in an out-of-bounds read).
+void Engine::validate_model(const OnnxModel& m) {
+    auto init = [&](const std::string& name) -> const HostTensor* {
+        auto it = m.initializers.find(name);
+        return it == m.initializers.end() ? nullptr : &it->second;
+    };
+    auto in = [&](const OnnxNode& n, size_t i) -> const HostTensor* { return i < n.inputs.size() && !n.inputs[i].empty() ? init(n.inputs[i]) : nullptr; };
+    for (const OnnxNode& n : m.nodes) {
+        const std::string at = " (node output " + (n.outputs.empty() ? std::string("?") : n.outputs[0]) + ")";
+        OAR_CHECK(!n.outputs.empty(), OAR_MODEL_LOAD, "onnx: node '" + n.op + "' without outputs");
+        if (n.op == "Conv" || n.op == "ConvTranspose") {
+            OAR_CHECK(n.inputs.size() >= 2, OAR_MODEL_LOAD, n.op + ": needs at least 2 inputs" + at);
+            if (const HostTensor* w = in(n, 1)) {
+                OAR_CHECK(w->dtype == DType::F32 && w->dims.size() == 4, OAR_MODEL_LOAD, n.op + ": weight must be a rank-4 f32 tensor" + at);
+                for (int64_t d : w->dims) OAR_CHECK(d > 0, OAR_MODEL_LOAD, n.op + ": weight has an empty dimension" + at);
+                if (const HostTensor* b = in(n, 2)) {
+                    const int64_t cout = n.op == "Conv" ? w->dims[0] : w->dims[1] * n.ai("group", 1);
+                    OAR_CHECK(b->dtype == DType::F32 && (int64_t)b->f.size() == cout, OAR_MODEL_LOAD, n.op + ": bias must hold Cout f32 values" + at);
+                }
+            }
+        } else if (n.op == "BatchNormalization") {
+            OAR_CHECK(n.inputs.size() >= 5, OAR_MODEL_LOAD, "BatchNormalization: needs 5 inputs" + at);
+            int64_t c = -1;
+            for (size_t i = 1; i < 5; ++i)
+                if (const HostTensor* t = in(n, i)) {
+                    OAR_CHECK(t->dtype == DType::F32 && !t->f.empty(), OAR_MODEL_LOAD, "BatchNormalization: parameters must be non-empty f32 tensors" + at);
+                    if (c < 0) c = (int64_t)t->f.size();
+                    OAR_CHECK((int64_t)t->f.size() == c, OAR_MODEL_LOAD, "BatchNormalization: scale / bias / mean / var differ in length" + at);
+                }
+        } else if (n.op == "Gemm" || n.op == "MatMul") {
+            OAR_CHECK(n.inputs.size() >= 2, OAR_MODEL_LOAD, n.op + ": needs 2 inputs" + at);
+            if (const HostTensor* b = in(n, 1)) {
+                OAR_CHECK(b->dtype == DType::F32 && b->dims.size() >= 1, OAR_MODEL_LOAD, n.op + ": constant B must be an f32 tensor" + at);
+                if (n.op == "Gemm") OAR_CHECK(b->dims.size() == 2, OAR_MODEL_LOAD, "Gemm: B must be rank 2" + at);
+            }
+        } else if (n.op == "PRelu" || n.op == "LayerNormalization") {
+            OAR_CHECK(n.inputs.size() >= 2, OAR_MODEL_LOAD, n.op + ": needs 2 inputs" + at);
+        }
+    }
+}
+
+// every operator name dispatch() (or a load-time rewrite) accepts -- oar_onnx_inspect reports the rest
+const std::set<std::string>& Engine::supported_ops() {
+    static const std::set<std::string> ops = {
+        "Constant", "Dropout", "Identity", "Cast", "Shape", "Conv", "ConvTranspose", "BatchNormalization", "Relu", "HardSwish", "HardSigmoid", "Sigmoid",
+        "LeakyRelu", "Tanh", "Erf", "Sqrt", "Exp", "Abs", "Neg", "Reciprocal", "Log", "Gelu", "Softplus", "Clip", "Add", "Sub", "Mul", "Div", "Pow", "PRelu",
+        "ReduceMean", "GridSample", "Pad", "GlobalAveragePool", "AveragePool", "MaxPool", "Resize", "Concat", "Reshape", "Flatten", "Squeeze", "Unsqueeze",
+        "Transpose", "Split", "Slice", "Gather", "Gemm", "MatMul", "Softmax", "LayerNormalization"};
+    return ops;
+}
+
 const Plan& Engine::plan_for(const std::vector<int64_t>& dims, bool in_clast, bool skip_final_softmax) {
     std::ostringstream key;
     key << (in_clast ? "L" : "N") << (skip_final_softmax ? "S" : "");
     for (auto d : dims) key << "x" << d;
     auto it = plans_.find(key.str());
-    if (it != plans_.end()) return *it->second;
+    if (it != plans_.end()) { it->second->last_used = ++tick_; last_returned_ = it->second.get(); return *it->second; }
     OAR_HIP(hipSetDevice(device_));
     std::unique_ptr<Plan> p(new Plan());
     Planner pl(*this, *p);
     pl.skip_final_softmax = skip_final_softmax;
     pl.build(dims, in_clast);
+    evict_plans();
+    p->last_used = ++tick_;
     const Plan& ref = *p;
     plans_[key.str()] = std::move(p);
+    last_returned_ = &ref;
     return ref;
+}
+
+// The plan cache is keyed on exact input dims (every (batch, Wt) pair of the recognizer, every (sub-batch, rh, rw) of the
+// detector), so a long-running server on heterogeneous pages would grow it without bound: keep at most plan_cap_ plans,
+// least-recently-used out first.  The plan returned by the PREVIOUS plan_for / run call is never the victim, so a `const
+// Plan&` stays valid across one further call on the same engine (callers copy what they need before that).
+void Engine::evict_plans() {
+    while (plans_.size() >= plan_cap_) {
+        auto victim = plans_.end();
+        for (auto it = plans_.begin(); it != plans_.end(); ++it) {
+            if (it->second.get() == last_returned_) continue;
+            if (victim == plans_.end() || it->second->last_used < victim->second->last_used) victim = it;
+        }
+        if (victim == plans_.end()) return;
+        const Plan* dead = victim->second.get();
+        bool synced = false;
+        for (auto g = graphs_.begin(); g != graphs_.end();) {   // captured graphs of the evicted plan go with it
+            if (std::get<0>(g->first) != dead) { ++g; continue; }
+            if (!synced) { OAR_HIP(hipStreamSynchronize(stream_)); synced = true; }
+            if (g->second.events) Profiler::get().release(*g->second.events);
+            if (g->second.exec) (void)hipGraphExecDestroy(g->second.exec);
+            g = graphs_.erase(g);
+        }
+        plans_.erase(victim);
+        ++plans_evicted_;
+    }
 }
 
 void Engine::clear_graphs() {

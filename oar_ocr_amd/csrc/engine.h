@@ -7,6 +7,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -70,6 +71,7 @@ struct Plan {
     double flops = 0, bytes = 0;
     int n_kernels = 0;
     bool skipped_softmax = false;
+    mutable uint64_t last_used = 0;   // Engine's LRU tick
     mutable int runs = 0;   // completed uncaptured runs (a plan is captured into a hipGraph from its second run on)
     int logits_valid = 0;   // > 0: output[0]'s rows are padded; only the first logits_valid columns are logits
     Loc ctc_part;           // kind != NONE: output[0] was never materialised; softmax partials [rows][ctc_tiles] float4 live here
@@ -93,6 +95,10 @@ class Engine {
     const float* out_ptr(const Loc& l) const;
     char* arena() const { return arena_.as<char>(); }
     std::mutex& mutex() { return mu_; }
+    static const std::set<std::string>& supported_ops();
+    static void validate_model(const OnnxModel& m);   // throws OAR_MODEL_LOAD; host-only
+    size_t cached_plans() const { return plans_.size(); }
+    uint64_t evicted_plans() const { return plans_evicted_; }
 
    private:
     friend struct Planner;
@@ -109,6 +115,10 @@ class Engine {
     std::map<std::string, const float*> dev_consts_;
     std::vector<void*> dev_allocs_;
     std::map<std::string, std::unique_ptr<Plan>> plans_;
+    size_t plan_cap_ = 256;              // OAR_PLAN_CACHE: max cached plans (LRU)
+    uint64_t tick_ = 0, plans_evicted_ = 0;
+    const Plan* last_returned_ = nullptr;
+    void evict_plans();
     DevBuf arena_;
     // hipGraph replay (opt-in, OAR_HIP_GRAPH=1; measured at parity with plain launches, see Engine::replay): from its
     // second run a plan is captured once per (input pointer, arena base, profiler epoch) and replayed.

@@ -108,33 +108,44 @@ HostTensor parse_tensor(Rd r) {
             default: r.skip(wt);
         }
     }
-    int64_t n = t.numel();
+    // dims come from the file: every later index computation trusts numel(), so it is validated here, once
+    int64_t n = 1;
+    OAR_CHECK(t.dims.size() <= 8, OAR_MODEL_LOAD, "onnx: tensor rank > 8 in " + t.name);
+    for (int64_t d : t.dims) {
+        OAR_CHECK(d >= 0, OAR_MODEL_LOAD, "onnx: negative dimension in initializer " + t.name);
+        OAR_CHECK(d == 0 || n <= (int64_t)1 << 33, OAR_MODEL_LOAD, "onnx: initializer element count overflows in " + t.name);
+        n *= d;
+    }
+    OAR_CHECK(n <= (int64_t)1 << 33, OAR_MODEL_LOAD, "onnx: initializer too large: " + t.name);
+    auto need_raw = [&](size_t elem) { OAR_CHECK(raw_n == (size_t)n * elem, OAR_MODEL_LOAD, "onnx: raw_data size does not match dims in " + t.name); };
+    auto need_len = [&](size_t have) { OAR_CHECK((int64_t)have == n, OAR_MODEL_LOAD, "onnx: typed data length does not match dims in " + t.name); };
     switch (dt) {
         case 1:
             t.dtype = DType::F32;
             if (raw) {
-                OAR_CHECK(raw_n == (size_t)n * 4, OAR_MODEL_LOAD, "onnx: raw_data size mismatch (f32) in " + t.name);
+                need_raw(4);
                 t.f.resize(n);
-                memcpy(t.f.data(), raw, raw_n);
+                if (n) memcpy(t.f.data(), raw, raw_n);
             } else {
+                need_len(fdata.size());
                 t.f = fdata;
-                OAR_CHECK((int64_t)t.f.size() == n, OAR_MODEL_LOAD, "onnx: float_data size mismatch in " + t.name);
             }
             break;
         case 7:
             t.dtype = DType::I64;
             if (raw) {
-                OAR_CHECK(raw_n == (size_t)n * 8, OAR_MODEL_LOAD, "onnx: raw_data size mismatch (i64)");
+                need_raw(8);
                 t.i.resize(n);
-                memcpy(t.i.data(), raw, raw_n);
+                if (n) memcpy(t.i.data(), raw, raw_n);
             } else {
+                need_len(i64data.size());
                 t.i = i64data;
             }
             break;
         case 6:
             t.dtype = DType::I32;
             if (raw) {
-                OAR_CHECK(raw_n == (size_t)n * 4, OAR_MODEL_LOAD, "onnx: raw_data size mismatch (i32)");
+                need_raw(4);
                 t.i.resize(n);
                 for (int64_t k = 0; k < n; ++k) {
                     int32_t v;
@@ -142,6 +153,7 @@ HostTensor parse_tensor(Rd r) {
                     t.i[k] = v;
                 }
             } else {
+                need_len(i32data.size());
                 t.i.resize(i32data.size());
                 for (size_t k = 0; k < i32data.size(); ++k) t.i[k] = (int32_t)i32data[k];
             }
@@ -149,16 +161,19 @@ HostTensor parse_tensor(Rd r) {
         case 9:
             t.dtype = DType::BOOL;
             if (raw) {
+                need_raw(1);
                 t.i.resize(n);
                 for (int64_t k = 0; k < n; ++k) t.i[k] = raw[k];
             } else {
+                need_len(i32data.size());
                 t.i = i32data;
             }
             break;
         case 11: {  // double -> f32
             t.dtype = DType::F32;
+            OAR_CHECK(raw != nullptr || n == 0, OAR_MODEL_LOAD, "onnx: f64 tensor without raw_data in " + t.name);
+            if (raw) need_raw(8);
             t.f.resize(n);
-            OAR_CHECK(raw && raw_n == (size_t)n * 8, OAR_MODEL_LOAD, "onnx: f64 tensor without raw_data");
             for (int64_t k = 0; k < n; ++k) {
                 double v;
                 memcpy(&v, raw + k * 8, 8);

@@ -84,7 +84,8 @@ void ThreadPool::loop() {
             if (stop_.load(std::memory_order_acquire)) return;
         }
         seen = g;
-        const std::function<void(int)>* fn = fn_.load(std::memory_order_relaxed);
+        if (selftest_worker_delay_) selftest_worker_delay_();   // oar_host_pool_selftest: a worker that is late with its descriptor read
+        const std::function<void(int)>* fn = fn_.load(std::memory_order_acquire);
         const int count = count_.load(std::memory_order_acquire);
         int i;
         while (claim(g, count, i)) {
@@ -102,9 +103,9 @@ bool ThreadPool::claim(int gen, int count, int& index) {
     uint64_t v = state_.load(std::memory_order_acquire);
     for (;;) {
         if ((int)(v >> 32) != gen) return false;            // the job this descriptor belongs to is over
-        const int i = (int)(v & 0xffffffffu);
-        if (i >= count) return false;
-        if (state_.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel, std::memory_order_acquire)) { index = i; return true; }
+        const uint32_t i = (uint32_t)(v & 0xffffffffu);     // kClosed (0xffffffff) while the next job is being published
+        if (i >= (uint32_t)count) return false;
+        if (state_.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel, std::memory_order_acquire)) { index = (int)i; return true; }
     }
 }
 void ThreadPool::parallel_for(int count, const std::function<void(int)>& fn) {
@@ -113,12 +114,20 @@ void ThreadPool::parallel_for(int count, const std::function<void(int)>& fn) {
         for (int i = 0; i < count; ++i) fn(i);
         return;
     }
-    // publish the job: descriptor first, then the (generation, 0) claim word, then the generation the workers poll
+    // Publish the job.  Order matters: a worker that saw the PREVIOUS generation late (after that job was finished by
+    // the others) reads fn_ / count_ with no re-validation, so it may pick up THIS job's larger count while the claim word
+    // still says (previous generation, previous count) -- and would then claim index `previous count` of a finished
+    // job.  The claim word is therefore closed first (new generation, index = kClosed): from here on every claim made
+    // with an older generation fails, whatever count it was made with.  count_ is a release store, so a worker that
+    // read the new count also sees the closed word.  Only then the descriptor, the open word, and the generation.
+    constexpr uint64_t kClosed = 0xffffffffull;
     const int g = gen_.load(std::memory_order_relaxed) + 1;
-    fn_.store(&fn, std::memory_order_relaxed);
-    done_.store(0, std::memory_order_relaxed);
-    count_.store(count, std::memory_order_relaxed);
-    state_.store((uint64_t)(uint32_t)g << 32, std::memory_order_release);
+    state_.store(((uint64_t)(uint32_t)g << 32) | kClosed, std::memory_order_seq_cst);
+    fn_.store(&fn, std::memory_order_release);
+    done_.store(0, std::memory_order_release);
+    count_.store(count, std::memory_order_release);
+    if (selftest_publish_delay_) selftest_publish_delay_();   // oar_host_pool_selftest: widen the window between descriptor and claim word
+    state_.store((uint64_t)(uint32_t)g << 32, std::memory_order_seq_cst);
     gen_.store(g, std::memory_order_release);
     {
         std::lock_guard<std::mutex> lk(mu_);
@@ -811,6 +820,10 @@ Rectifier::Rectifier(const uint8_t* onnx, size_t len, const RectCfg& cfg) : cfg_
 
 void Rectifier::run_device(const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst) {
     std::lock_guard<std::mutex> lk(mu_);
+    run_device_locked(src, w, h, dst);
+}
+
+void Rectifier::run_device_locked(const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst) {
     OAR_CHECK(w > 0 && h > 0 && src && dst, OAR_INVALID_INPUT, "rectifier: empty image");
     OAR_HIP(hipSetDevice(eng_->device()));
     hipStream_t s = eng_->stream();
@@ -842,15 +855,14 @@ void Rectifier::run_device(const uint8_t* src, uint32_t w, uint32_t h, uint8_t* 
 }
 
 void Rectifier::run_host(const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst) {
+    // ONE lock across upload, run and read-back: io_dev_ is shared staging, a second caller (or its reserve()) must not
+    // get in between
     const size_t bytes = (size_t)w * h * 3;
-    {
-        std::lock_guard<std::mutex> lk(mu_);
-        OAR_HIP(hipSetDevice(eng_->device()));
-        if (bytes * 2 > io_dev_.cap) { OAR_HIP(hipStreamSynchronize(eng_->stream())); io_dev_.reserve(bytes * 2); }
-        OAR_HIP(hipMemcpyAsync(io_dev_.p, src, bytes, hipMemcpyHostToDevice, eng_->stream()));
-    }
-    run_device(io_dev_.as<uint8_t>(), w, h, io_dev_.as<uint8_t>() + bytes);
     std::lock_guard<std::mutex> lk(mu_);
+    OAR_HIP(hipSetDevice(eng_->device()));
+    if (bytes * 2 > io_dev_.cap) { OAR_HIP(hipStreamSynchronize(eng_->stream())); io_dev_.reserve(bytes * 2); }
+    OAR_HIP(hipMemcpyAsync(io_dev_.p, src, bytes, hipMemcpyHostToDevice, eng_->stream()));
+    run_device_locked(io_dev_.as<uint8_t>(), w, h, io_dev_.as<uint8_t>() + bytes);
     OAR_HIP(hipMemcpyAsync(dst, io_dev_.as<uint8_t>() + bytes, bytes, hipMemcpyDeviceToHost, eng_->stream()));
     OAR_HIP(hipStreamSynchronize(eng_->stream()));
 }
@@ -933,8 +945,12 @@ void Ocr::preprocess_pages(const std::vector<PageRef>& pages, std::vector<PageRe
     }
 }
 
-void Ocr::predict(const std::vector<PageRef>& pages, std::vector<std::vector<OcrRegion>>& out) {
+void Ocr::predict(const std::vector<PageRef>& pages, std::vector<std::vector<OcrRegion>>& out, std::vector<PageMeta>* meta_out) {
     std::lock_guard<std::mutex> lk(mu_);
+    struct MetaCopy {   // the caller's copy is taken under the lock (another thread's predict() overwrites meta_)
+        Ocr& o; std::vector<PageMeta>* dst;
+        ~MetaCopy() { if (dst) *dst = o.meta_; }
+    } meta_copy{*this, meta_out};
     OAR_CHECK(!pages.empty(), OAR_INVALID_INPUT, "OCR Pipeline: images must be a non-empty slice");  // ocr.rs:525-532
     OAR_HIP(hipSetDevice(det_->engine().device()));
     meta_.assign(pages.size(), PageMeta());

@@ -24,6 +24,10 @@ class ThreadPool {
     ~ThreadPool();
     void parallel_for(int count, const std::function<void(int)>& fn);
     int size() const { return (int)workers_.size(); }
+    // test hooks (oar_host_pool_selftest only; set before the first parallel_for, never in production): called by a worker
+    // between observing a new generation and reading the job descriptor / by the publisher between writing the descriptor
+    // and opening the claim word -- the two windows of the stale-descriptor race.
+    std::function<void()> selftest_worker_delay_, selftest_publish_delay_;
 
    private:
     void loop();
@@ -169,6 +173,7 @@ class Rectifier {
     Engine& engine() { return *eng_; }
 
    private:
+    void run_device_locked(const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst);   // mu_ held by the caller
     std::unique_ptr<Engine> eng_;
     RectCfg cfg_;
     DevBuf resized_dev_, input_f32_, out_u8_, io_dev_;
@@ -189,11 +194,11 @@ struct OcrRegion {
 class Ocr {
    public:
     Ocr(const uint8_t* det, size_t det_len, const uint8_t* rec, size_t rec_len, const oar_ocr_cfg& cfg);
-    void predict(const std::vector<PageRef>& pages, std::vector<std::vector<OcrRegion>>& out);
+    struct PageMeta { float angle = -1.0f; bool rectified = false; uint32_t rotated_w = 0, rotated_h = 0; };
+    // meta_out (optional) receives what the optional stages did to each page, copied while the call still holds the lock
+    void predict(const std::vector<PageRef>& pages, std::vector<std::vector<OcrRegion>>& out, std::vector<PageMeta>* meta_out = nullptr);
     // Optional stages of OAROCR (src/oarocr/preprocess.rs:59-97, src/oarocr/ocr.rs:760-790); not owned.
     void attach(Classifier* doc_orientation, Rectifier* rectifier, Classifier* line_orientation) { doc_cls_ = doc_orientation; rect_ = rectifier; line_cls_ = line_orientation; }
-    struct PageMeta { float angle = -1.0f; bool rectified = false; uint32_t rotated_w = 0, rotated_h = 0; };
-    const std::vector<PageMeta>& page_meta() const { return meta_; }
     Detector& det() { return *det_; }
     Recognizer& rec() { return *rec_; }
 
