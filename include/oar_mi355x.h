@@ -302,6 +302,11 @@ oar_status oar_k_rotate_crop(const uint8_t* rgb, uint32_t w, uint32_t h, const f
  * traces row bands cut at blank rows in the same order (identical result). Returns the count (<= cap written). */
 int32_t oar_host_candidates(const uint8_t* mask, uint32_t width, uint32_t height, uint32_t max_candidates, int32_t max_bands,
                             float* boxes8, int32_t cap);
+/* a8 alone: the contours find_contours yields (imageproc semantics at db_bitmap.rs:100: outer AND hole borders, raster
+ * discovery order, border pixels in tracing order).  offsets: max_contours + 1 entries; pts_xy: (x, y) pairs, at most
+ * cap_points of them are written (offsets still count every point); types: 0 outer / 1 hole.  Returns the count. */
+int32_t oar_host_contours(const uint8_t* mask, uint32_t width, uint32_t height, uint32_t max_contours, int32_t max_bands,
+                          int64_t* offsets, int32_t* pts_xy, int32_t* types, int64_t cap_points);
 /* a11 db_bitmap.rs:279-368: unclip a 4-point box; returns the number of points (0 = dropped), x,y pairs in out. */
 int32_t oar_host_unclip(const float box8[8], float ratio, float* out_xy, int32_t cap_points);
 /* a9 mini box of an arbitrary point set (db_bitmap.rs:164-205): returns 1 and fills box8/min_side, or 0. */

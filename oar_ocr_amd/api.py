@@ -103,7 +103,7 @@ EXPORTS = [
     "oar_host_candidates", "oar_host_unclip", "oar_host_mini_box", "oar_host_sort_quad_boxes", "oar_host_pool_selftest", "oar_host_plan_crop",
     "oar_cls_create", "oar_cls_destroy", "oar_cls_run", "oar_cls_result_free", "oar_cls_preprocess", "oar_rect_create", "oar_rect_destroy",
     "oar_rect_run", "oar_ocr_attach", "oar_k_rotate_rgb", "oar_k_bgr_planes_to_rgb", "oar_host_rotate_back_points",
-    "oar_engine_cache_stats", "oar_onnx_inspect",
+    "oar_engine_cache_stats", "oar_onnx_inspect", "oar_host_contours",
 ]
 
 
@@ -167,6 +167,8 @@ def lib():
     L.oar_k_rotate_crop.argtypes = [vp, C.c_uint32, C.c_uint32, f32p, vp, C.c_size_t, u32p, u32p]
     L.oar_host_candidates.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, vp, C.c_int32]
     L.oar_host_candidates.restype = C.c_int32
+    L.oar_host_contours.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, vp, vp, vp, C.c_int64]
+    L.oar_host_contours.restype = C.c_int32
     L.oar_host_unclip.argtypes = [vp, C.c_float, vp, C.c_int32]
     L.oar_host_unclip.restype = C.c_int32
     L.oar_host_mini_box.argtypes = [vp, C.c_int32, vp, f32p]
@@ -858,6 +860,20 @@ def host_candidates(mask, max_candidates=1000, max_bands=1):
     if n < 0:
         raise OCRError(OAR_INTERNAL, "oar_host_candidates failed")
     return out[:n].copy()
+
+
+def host_contours(mask, max_contours=100000, max_bands=1):
+    """[(points [n,2] int32 (x, y) in tracing order, type 0 outer / 1 hole)] in discovery order (a8)."""
+    mask = np.ascontiguousarray(mask, np.uint8)
+    h, w = mask.shape
+    cap = 4 * h * w + 16
+    offs = np.zeros(max_contours + 1, np.int64)
+    pts = np.zeros((cap, 2), np.int32)
+    types = np.zeros(max_contours, np.int32)
+    n = lib().oar_host_contours(_p(mask), w, h, max_contours, max_bands, _p(offs), _p(pts), _p(types), cap)
+    if n < 0:
+        raise OCRError(OAR_INTERNAL, "oar_host_contours failed")
+    return [(pts[offs[i]:offs[i + 1]].copy(), int(types[i])) for i in range(n)]
 
 
 def host_unclip(box, ratio):

@@ -668,6 +668,30 @@ int32_t oar_host_candidates(const uint8_t* mask, uint32_t width, uint32_t height
         return n;
     } catch (...) { return -1; }
 }
+int32_t oar_host_contours(const uint8_t* mask, uint32_t width, uint32_t height, uint32_t max_contours, int32_t max_bands, int64_t* offsets,
+                          int32_t* pts_xy, int32_t* types, int64_t cap_points) {
+    try {
+        std::vector<int32_t> scratch((size_t)width * height);
+        std::vector<int> cuts = host::blank_row_bands(mask, (int)width, (int)height, max_bands < 1 ? 1 : max_bands);
+        int32_t n = 0;
+        int64_t np = 0;
+        if (offsets) offsets[0] = 0;
+        for (size_t i = 0; i + 1 < cuts.size(); ++i) {
+            auto part = host::find_contours_band(mask, (int)width, (int)height, cuts[i], cuts[i + 1], max_contours, scratch.data());
+            for (auto& c : part) {
+                if ((uint32_t)n >= max_contours) break;
+                for (auto& q : c.pts) {
+                    if (pts_xy && np < cap_points) { pts_xy[np * 2] = (int32_t)q.x; pts_xy[np * 2 + 1] = (int32_t)q.y; }
+                    ++np;
+                }
+                if (types) types[n] = c.hole ? 1 : 0;
+                ++n;
+                if (offsets) offsets[n] = np;
+            }
+        }
+        return n;
+    } catch (...) { return -1; }
+}
 int32_t oar_host_unclip(const float box8[8], float ratio, float* out_xy, int32_t cap_points) {
     try {
         host::Pt b[4];

@@ -296,88 +296,107 @@ bool mini_box(const std::vector<Pt>& pts, Pt out[4], float& min_side) {
 }
 
 // ------------------------------------------------------------------------------------------ unclip (Clipper2 offset)
+// DBPostProcess::unclip (processors/db_bitmap.rs:279-368) for the one shape the hot path feeds it: the 4 corners of a
+// mini box.  Clipper2's InflatePaths(Round, Polygon, precision 2) on a ring of at most 4 vertices, organised around
+// the ring's EDGES: each edge contributes its offset vector (unit normal x signed delta, on the 1/100 px integer
+// grid); walking the ring, corner i is the pivot of an arc that swings the previous edge's offset vector onto the next
+// edge's.  The arithmetic inside an arc (the incremental rotation, the rounding of every emitted vertex to the grid)
+// is Clipper2's own, because the vertices -- and through them the hull / min-area rectangle / integer box corners --
+// must match the reference to the bit.  What is checked independently of any restatement: tests/test_third_party_pins_cpu.py
+// (analytic offsets of axis-aligned and rotated rectangles, arc radius / sagitta / vertex-count bounds).
+namespace {
+struct Ring4 {
+    int n = 0;
+    int64_t x[4], y[4];
+    double twice_area() const {   // Clipper2 Area(): sum (y_prev + y_cur) * (x_prev - x_cur)
+        double s = 0.0;
+        for (int i = 0, p = n - 1; i < n; p = i++) s += (double)(y[p] + y[i]) * (double)(x[p] - x[i]);
+        return s;
+    }
+};
+struct ArcStepper {   // constant-angle rotation, sized from the offset radius (ClipperOffset::DoGroupOffset)
+    double cs, sn, per_rad;
+    ArcStepper(double signed_radius) {
+        const double r = std::fabs(signed_radius), tol = r * 0.002;   // arc_tolerance 0.0 => radius / 500
+        const double per_turn = std::min(kPiD / std::acos(1.0 - tol / r), r * kPiD);
+        sn = std::sin(2.0 * kPiD / per_turn);
+        cs = std::cos(2.0 * kPiD / per_turn);
+        if (signed_radius < 0.0) sn = -sn;
+        per_rad = per_turn / (2.0 * kPiD);
+    }
+};
+}  // namespace
+
 std::vector<Pt> unclip(const Pt box[4], float ratio) {
-    struct P64 { int64_t x, y; };
-    struct PD { double x, y; };
-    const int nb = 4;
-    PD pd[4];
-    for (int i = 0; i < nb; ++i) pd[i] = {(double)box[i].x, (double)box[i].y};
-    double a = 0.0;
-    for (int i = 0, prev = nb - 1; i < nb; prev = i, ++i) a += (pd[prev].y + pd[i].y) * (pd[prev].x - pd[i].x);
-    a *= 0.5;
-    double area = std::fabs(a);
-    if (area <= kEpsD) return {};
-    double perim = 0.0;
-    for (int i = 1; i < nb; ++i) perim += std::hypot(pd[i].x - pd[i - 1].x, pd[i].y - pd[i - 1].y);
-    perim += std::hypot(pd[0].x - pd[nb - 1].x, pd[0].y - pd[nb - 1].y);
-    if (perim <= kEpsD) return {};
-    double delta = area * (double)ratio / perim;
+    constexpr double kGrid = 100.0;   // precision 2
+    // offset distance from the f64 polygon: area * ratio / perimeter (db_bitmap.rs:297-323)
+    double qx[4], qy[4];
+    for (int i = 0; i < 4; ++i) { qx[i] = (double)box[i].x; qy[i] = (double)box[i].y; }
+    double shoelace = 0.0, perimeter = 0.0;
+    for (int i = 0, p = 3; i < 4; p = i++) shoelace += (qy[p] + qy[i]) * (qx[p] - qx[i]);
+    const double area = std::fabs(shoelace * 0.5);
+    for (int i = 1; i < 4; ++i) perimeter += std::hypot(qx[i] - qx[i - 1], qy[i] - qy[i - 1]);
+    perimeter += std::hypot(qx[0] - qx[3], qy[0] - qy[3]);
+    if (area <= kEpsD || perimeter <= kEpsD) return {};
+    const double delta = area * (double)ratio / perimeter;
     if (std::fabs(delta) <= kEpsD) return {};
 
-    const double scale = 100.0;  // precision 2
-    std::vector<P64> path;
-    for (int i = 0; i < nb; ++i) {
-        P64 q{(int64_t)std::round(pd[i].x * scale), (int64_t)std::round(pd[i].y * scale)};
-        if (!path.empty() && path.back().x == q.x && path.back().y == q.y) continue;
-        path.push_back(q);
+    // onto the integer grid, consecutive duplicates (and a duplicated closing vertex) removed
+    Ring4 ring;
+    for (int i = 0; i < 4; ++i) {
+        const int64_t gx = (int64_t)std::round(qx[i] * kGrid), gy = (int64_t)std::round(qy[i] * kGrid);
+        if (ring.n && ring.x[ring.n - 1] == gx && ring.y[ring.n - 1] == gy) continue;
+        ring.x[ring.n] = gx; ring.y[ring.n] = gy; ++ring.n;
     }
-    while (path.size() > 1 && path.back().x == path[0].x && path.back().y == path[0].y) path.pop_back();
-    const int n = (int)path.size();
-    if (n < 3) return {};
+    while (ring.n > 1 && ring.x[ring.n - 1] == ring.x[0] && ring.y[ring.n - 1] == ring.y[0]) --ring.n;
+    if (ring.n < 3) return {};
+
     std::vector<Pt> out;
-    auto push = [&](double X, double Y) {
-        int64_t xi = (int64_t)std::round(X), yi = (int64_t)std::round(Y);
-        out.push_back({(float)((double)xi / scale), (float)((double)yi / scale)});
+    out.reserve(96);
+    auto emit = [&](double gx, double gy) {   // Point64(double, double) rounds; back to pixels in f64, then f32
+        out.push_back({(float)((double)(int64_t)std::round(gx) / kGrid), (float)((double)(int64_t)std::round(gy) / kGrid)});
     };
-    double d = delta * scale;
-    if (std::fabs(d) < 0.5) {
-        for (auto& q : path) out.push_back({(float)((double)q.x / scale), (float)((double)q.y / scale)});
+    const double grid_delta = delta * kGrid;
+    if (std::fabs(grid_delta) < 0.5) {   // an offset below half a grid step leaves the ring as it is
+        for (int i = 0; i < ring.n; ++i) emit((double)ring.x[i], (double)ring.y[i]);
     } else {
-        double ai = 0.0;
-        for (int i = 0, prev = n - 1; i < n; prev = i, ++i) ai += (double)(path[prev].y + path[i].y) * (double)(path[prev].x - path[i].x);
-        ai *= 0.5;
-        double gd = ai < 0 ? -d : d, absd = std::fabs(gd);
-        double arc_tol = absd * 0.002;
-        double steps360 = std::min(kPiD / std::acos(1.0 - arc_tol / absd), absd * kPiD);
-        double step_sin = std::sin(2.0 * kPiD / steps360), step_cos = std::cos(2.0 * kPiD / steps360);
-        if (gd < 0.0) step_sin = -step_sin;
-        double steps_per_rad = steps360 / (2.0 * kPiD);
-        std::vector<PD> norms(n);
-        for (int i = 0; i < n; ++i) {
-            const P64 &p = path[i], &q = path[(i + 1) % n];
-            if (p.x == q.x && p.y == q.y) { norms[i] = {0.0, 0.0}; continue; }
-            double dx = (double)(q.x - p.x), dy = (double)(q.y - p.y);
-            double inv = 1.0 / std::sqrt(dx * dx + dy * dy);
-            dx *= inv; dy *= inv;
-            norms[i] = {dy, -dx};
+        // a clockwise ring is grown by a negative radius
+        const double radius = ring.twice_area() * 0.5 < 0 ? -grid_delta : grid_delta;
+        const ArcStepper arc(radius);
+        // offset vector of edge e (vertex e -> e + 1): unit normal (dy, -dx) / |edge|, times the radius
+        double ux[4], uy[4];
+        for (int e = 0; e < ring.n; ++e) {
+            const int f = e + 1 == ring.n ? 0 : e + 1;
+            double dx = (double)(ring.x[f] - ring.x[e]), dy = (double)(ring.y[f] - ring.y[e]);
+            if (dx == 0.0 && dy == 0.0) { ux[e] = uy[e] = 0.0; continue; }
+            const double inv_len = 1.0 / std::sqrt(dx * dx + dy * dy);
+            dx *= inv_len; dy *= inv_len;
+            ux[e] = dy; uy[e] = -dx;
         }
-        for (int j = 0, k = n - 1; j < n; k = j, ++j) {
-            if (path[j].x == path[k].x && path[j].y == path[k].y) continue;
-            double sin_a = norms[j].y * norms[k].x - norms[k].y * norms[j].x;
-            double cos_a = norms[j].x * norms[k].x + norms[j].y * norms[k].y;
-            if (sin_a > 1.0) sin_a = 1.0; else if (sin_a < -1.0) sin_a = -1.0;
-            double px = (double)path[j].x, py = (double)path[j].y;
-            if (cos_a > -0.999 && (sin_a * gd < 0)) {
-                push(px + norms[k].x * gd, py + norms[k].y * gd);
-                push(px, py);
-                push(px + norms[j].x * gd, py + norms[j].y * gd);
-            } else {
-                double angle = std::atan2(sin_a, cos_a);
-                double ox = norms[k].x * gd, oy = norms[k].y * gd;
-                if (j == k) { ox = -ox; oy = -oy; }
-                push(px + ox, py + oy);
-                int steps = (int)std::ceil(steps_per_rad * std::fabs(angle));
-                for (int i = 1; i < steps; ++i) {
-                    double nx2 = ox * step_cos - step_sin * oy, ny2 = ox * step_sin + oy * step_cos;
-                    ox = nx2; oy = ny2;
-                    push(px + ox, py + oy);
-                }
-                push(px + norms[j].x * gd, py + norms[j].y * gd);
+        for (int v = 0, in_e = ring.n - 1; v < ring.n; in_e = v++) {   // corner v sits between edge in_e and edge v
+            const double cx = (double)ring.x[v], cy = (double)ring.y[v];
+            double turn_sin = uy[v] * ux[in_e] - uy[in_e] * ux[v];
+            const double turn_cos = ux[v] * ux[in_e] + uy[v] * uy[in_e];
+            turn_sin = turn_sin > 1.0 ? 1.0 : turn_sin < -1.0 ? -1.0 : turn_sin;
+            double sx = ux[in_e] * radius, sy = uy[in_e] * radius;   // where the arc starts (relative to the corner)
+            const double ex = cx + ux[v] * radius, ey = cy + uy[v] * radius;   // where it ends
+            if (turn_cos > -0.999 && turn_sin * radius < 0) {   // reflex corner (never for a mini box): spike through the corner
+                emit(cx + sx, cy + sy); emit(cx, cy); emit(ex, ey);
+                continue;
             }
+            emit(cx + sx, cy + sy);
+            const int hops = (int)std::ceil(arc.per_rad * std::fabs(std::atan2(turn_sin, turn_cos)));
+            for (int h = 1; h < hops; ++h) {
+                const double rx = sx * arc.cs - arc.sn * sy, ry = sx * arc.sn + sy * arc.cs;
+                sx = rx; sy = ry;
+                emit(cx + sx, cy + sy);
+            }
+            emit(ex, ey);
         }
     }
+    // db_bitmap.rs:355-361: the closing vertex is dropped when it repeats the first
     if (out.size() > 1 && std::fabs(out.front().x - out.back().x) < kEps && std::fabs(out.front().y - out.back().y) < kEps) out.pop_back();
-    if (out.size() < 3) return {};
+    if (out.size() < 3) out.clear();
     return out;
 }
 
@@ -408,59 +427,65 @@ std::vector<int> sort_quad_boxes(const std::vector<float>& b8) {
 
 // ------------------------------------------------------------------------------------------ crop planning
 namespace {
-bool lu_solve8(float A[8][8], float b[8]) {  // nalgebra LU (partial pivoting) + solve
-    int pi[8], pp[8], np = 0;
-    for (int i = 0; i < 8; ++i) {
-        int piv = i;
-        float mx = std::fabs(A[i][i]);
-        for (int r = i + 1; r < 8; ++r) {
-            float v = std::fabs(A[r][i]);
-            if (v > mx) { mx = v; piv = r; }
+// The homography of a crop: 8 unknowns from 4 point pairs, solved the way `nalgebra` 0.35 does it for the reference
+// (utils/transform.rs:266-267: `a.lu().solve(&b)`, then Matrix3::try_inverse :312-316).  The pixel each bicubic tap lands on
+// depends on the last bit of these nine numbers, so the elimination ORDER is nalgebra's (column-major axpy updates,
+// partial pivoting by |value|, unit-diagonal forward substitution, then back substitution); the storage and the driver
+// are this file's own: one flat column-major array with the right-hand side as a ninth column, so a row exchange swaps
+// one row of the whole tableau, and the pivots are remembered as a permutation instead of a swap log.
+// Independent check: tests/test_third_party_pins_cpu.py compares against numpy float64 solve / inv.
+struct Tableau8 {
+    float v[9][8];   // v[col][row]; column 8 = right-hand side
+    float& at(int r, int c) { return v[c][r]; }
+};
+bool solve_homography8(Tableau8& t, float sol[8]) {
+    int row_of[8];   // row_of[i]: which ORIGINAL rhs entry sits in row i after the exchanges
+    for (int i = 0; i < 8; ++i) row_of[i] = i;
+    float rhs0[8];
+    for (int i = 0; i < 8; ++i) rhs0[i] = t.at(i, 8);
+    for (int c = 0; c < 8; ++c) {
+        int best = c;
+        float best_abs = std::fabs(t.at(c, c));
+        for (int r = c + 1; r < 8; ++r) { const float a = std::fabs(t.at(r, c)); if (a > best_abs) { best_abs = a; best = r; } }
+        const float pivot = t.at(best, c);
+        if (pivot == 0.0f) continue;            // an all-zero column below the diagonal: nothing to eliminate
+        if (best != c) {
+            std::swap(row_of[c], row_of[best]);
+            for (int k = 0; k < 8; ++k) std::swap(t.at(c, k), t.at(best, k));
         }
-        float diag = A[piv][i];
-        if (diag == 0.0f) continue;
-        float inv = 1.0f / diag;
-        if (piv != i) {
-            pi[np] = i; pp[np] = piv; ++np;
-            for (int c = 0; c < i; ++c) std::swap(A[i][c], A[piv][c]);
-            std::swap(A[i][i], A[piv][i]);
-            for (int r = i + 1; r < 8; ++r) A[r][i] *= inv;
-            for (int k = i + 1; k < 8; ++k) {
-                std::swap(A[i][k], A[piv][k]);
-                float pk = -A[i][k];
-                for (int r = i + 1; r < 8; ++r) A[r][k] = pk * A[r][i] + A[r][k];
-            }
-        } else {
-            for (int r = i + 1; r < 8; ++r) A[r][i] *= inv;
-            for (int k = i + 1; k < 8; ++k) {
-                float pk = -A[i][k];
-                for (int r = i + 1; r < 8; ++r) A[r][k] = pk * A[r][i] + A[r][k];
-            }
+        const float inv_pivot = 1.0f / pivot;
+        float* col = t.v[c];
+        for (int r = c + 1; r < 8; ++r) col[r] *= inv_pivot;          // multipliers stay in place (the L factor)
+        for (int k = c + 1; k < 8; ++k) {                             // column k -= U[c][k] * multipliers
+            float* dst = t.v[k];
+            const float f = -dst[c];
+            for (int r = c + 1; r < 8; ++r) dst[r] = f * col[r] + dst[r];
         }
     }
-    for (int s = 0; s < np; ++s) std::swap(b[pi[s]], b[pp[s]]);
-    for (int i = 0; i < 7; ++i) {
-        float coeff = -(b[i] / 1.0f);
-        for (int r = i + 1; r < 8; ++r) b[r] = coeff * A[r][i] + b[r];
+    for (int i = 0; i < 8; ++i) sol[i] = rhs0[row_of[i]];              // P b
+    for (int c = 0; c < 7; ++c) {                                      // L y = P b, unit diagonal
+        const float f = -(sol[c] / 1.0f);
+        for (int r = c + 1; r < 8; ++r) sol[r] = f * t.at(r, c) + sol[r];
     }
-    for (int i = 7; i >= 0; --i) {
-        float diag = A[i][i];
-        if (diag == 0.0f) return false;
-        float coeff = b[i] / diag;
-        b[i] = coeff;
-        float nc = -coeff;
-        for (int r = 0; r < i; ++r) b[r] = nc * A[r][i] + b[r];
+    for (int c = 7; c >= 0; --c) {                                     // U x = y
+        const float d = t.at(c, c);
+        if (d == 0.0f) return false;
+        const float x = sol[c] / d;
+        sol[c] = x;
+        const float f = -x;
+        for (int r = 0; r < c; ++r) sol[r] = f * t.at(r, c) + sol[r];
     }
     return true;
 }
-bool inverse3(const float* m, float* o) {  // nalgebra Matrix3::try_inverse
-    float m11 = m[0], m12 = m[1], m13 = m[2], m21 = m[3], m22 = m[4], m23 = m[5], m31 = m[6], m32 = m[7], m33 = m[8];
-    float a = m22 * m33 - m32 * m23, b = m21 * m33 - m31 * m23, c = m21 * m32 - m31 * m22;
-    float det = m11 * a - m12 * b + m13 * c;
+// adjugate / determinant inverse of a row-major 3x3, nalgebra's cofactor grouping (Matrix3::try_inverse)
+bool invert3(const float m[9], float out[9]) {
+    const float c00 = m[4] * m[8] - m[7] * m[5], c01 = m[3] * m[8] - m[6] * m[5], c02 = m[3] * m[7] - m[6] * m[4];
+    const float det = m[0] * c00 - m[1] * c01 + m[2] * c02;
     if (det == 0.0f) return false;
-    o[0] = a / det; o[1] = (m13 * m32 - m33 * m12) / det; o[2] = (m12 * m23 - m22 * m13) / det;
-    o[3] = -b / det; o[4] = (m11 * m33 - m31 * m13) / det; o[5] = (m13 * m21 - m23 * m11) / det;
-    o[6] = c / det; o[7] = (m12 * m31 - m32 * m11) / det; o[8] = (m11 * m22 - m21 * m12) / det;
+    const float adj[9] = {c00, m[2] * m[7] - m[8] * m[1], m[1] * m[5] - m[4] * m[2],
+                          -c01, m[0] * m[8] - m[6] * m[2], m[2] * m[3] - m[5] * m[0],
+                          c02, m[1] * m[6] - m[7] * m[0], m[0] * m[4] - m[3] * m[1]};
+    for (int i = 0; i < 9; ++i) out[i] = adj[i] / det;
     return true;
 }
 }  // namespace
@@ -496,18 +521,18 @@ CropPlan plan_crop(int img_w, int img_h, const float box8[8]) {
     uint32_t oh = sat_u32(std::round(std::fmax(h1, h2)));
     if (ow == 0 || oh == 0) return pl;
     const Pt dst[4] = {{0.0f, 0.0f}, {(float)ow, 0.0f}, {(float)ow, (float)oh}, {0.0f, (float)oh}};
-    float A[8][8], b[8];
+    // two equations per correspondence (utils/transform.rs:230-262): rows 2i / 2i+1 of the 8 x 8 system
+    Tableau8 t;
     for (int i = 0; i < 4; ++i) {
-        float sx = o[i].x, sy = o[i].y, dx = dst[i].x, dy = dst[i].y;
-        float r0[8] = {sx, sy, 1.0f, 0.0f, 0.0f, 0.0f, -sx * dx, -sy * dx};
-        float r1[8] = {0.0f, 0.0f, 0.0f, sx, sy, 1.0f, -sx * dy, -sy * dy};
-        std::memcpy(A[i * 2], r0, sizeof r0);
-        std::memcpy(A[i * 2 + 1], r1, sizeof r1);
-        b[i * 2] = dx; b[i * 2 + 1] = dy;
+        const float sx = o[i].x, sy = o[i].y, dx = dst[i].x, dy = dst[i].y;
+        const float eq_x[9] = {sx, sy, 1.0f, 0.0f, 0.0f, 0.0f, -sx * dx, -sy * dx, dx};
+        const float eq_y[9] = {0.0f, 0.0f, 0.0f, sx, sy, 1.0f, -sx * dy, -sy * dy, dy};
+        for (int c = 0; c < 9; ++c) { t.at(2 * i, c) = eq_x[c]; t.at(2 * i + 1, c) = eq_y[c]; }
     }
-    if (!lu_solve8(A, b)) return pl;
-    float m[9] = {b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], 1.0f};
-    if (!inverse3(m, pl.inv)) return pl;
+    float hcoef[8];
+    if (!solve_homography8(t, hcoef)) return pl;
+    const float m[9] = {hcoef[0], hcoef[1], hcoef[2], hcoef[3], hcoef[4], hcoef[5], hcoef[6], hcoef[7], 1.0f};
+    if (!invert3(m, pl.inv)) return pl;
     pl.mode = 2; pl.ow = (int)ow; pl.oh = (int)oh;
     pl.rot = (float)oh >= (float)ow * 1.5f ? 1 : 0;
     return pl;
