@@ -1,19 +1,27 @@
 #!/usr/bin/env python
 """bench.py -- images/sec of the det+rec hot path (OAROCR::predict behind the C ABI) on N MI355X of one node.
 
-A "step" = one pass of the hot path over one batch of synthetic pages per GPU.  Default workload is BASELINE.json
-configs[1]: PP-OCRv6-tiny-class det+rec, batch = 32 synthetic 960x960 pages, pages already resident in HBM when the
-timed region starts.  N > 1: one process per GPU (torchrun contract), pages are sharded image-parallel (weak scaling:
-every rank processes its own 32 pages per step), no data-path collective; value = pages of ALL ranks / max-over-ranks time.
+The metric is SURVEY.md section 8d's: u8 pages in HOST memory -> final sorted boxes + texts + scores on the host.
+A "step" = one pass of the hot path over one batch of synthetic pages per GPU: ONE `oar_ocr_predict` (H2D upload of the
+pages overlapped sub-batch by sub-batch with the detector network, detection, crops, recognition, CTC argmax) + ONE
+`oar_ocr_decode` (CTC collapse, strings, score filter inside the library); with N > 1 the per-rank results are gathered on
+rank 0 inside the timed region.  Default workload = BASELINE.json configs[1]: PP-OCRv6-tiny-class det+rec, 32 synthetic
+960x960 pages per GPU per step ("weak" scaling: every rank processes its own 32 pages; value = pages of ALL ranks /
+max-over-ranks time).  `--config 3` is BASELINE configs[3]: 1024 pages block-partitioned over the ranks (128 per GPU at
+N = 8, "strong" scaling).  The device-resident figure (pages already in HBM, no decode -- round 1's headline) is reported
+as the extra field `device_resident`.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, hipEvent-timed on the engine's own stream inside the
-timed region) and `cpu_baseline` (the oracle pipeline -- C restatement + torch-CPU network -- on a bounded sample).
+`--gpus N` without a torchrun environment starts its own N ranks (one process per GPU, RCCL over xGMI).
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel class, hipEvent-timed on the engine's own stream inside
+the timed region) and `cpu_baseline` (the oracle pipeline -- C restatement + torch-CPU network -- on a bounded sample).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -28,83 +36,177 @@ MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA peak; the bf16x6 kernels spend 6 
 
 def mfma_peak_for(kernel):
     """Peak in f32-equivalent TFLOP/s (2*M*K*N per product) of the matrix pipe the kernel class runs on."""
-    return (MFMA_BF16_PEAK_TF / 6.0, "bf16 dense peak / 6 (three-way split, six MFMAs per product)") if kernel.endswith("_x6") else (MFMA_F32_PEAK_TF, "f32-input MFMA dense peak")
+    return (MFMA_BF16_PEAK_TF / 6.0, "bf16 dense peak / 6 (three-way split, six MFMAs per product)") if "_x6" in kernel else (MFMA_F32_PEAK_TF, "f32-input MFMA dense peak")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pages", type=int, default=32, help="pages per GPU per step (BASELINE configs[1]: 32)")
-    ap.add_argument("--size", type=int, default=960)
+    ap.add_argument("--pages", type=int, default=0, help="pages per GPU per step (0 = the config's: 32 / 64 / 1024 total / 16)")
+    ap.add_argument("--size", type=int, default=0)
     ap.add_argument("--lines", type=int, default=40)
     ap.add_argument("--region-batch", type=int, default=256, help="recognition batch (this backend's recommended_batch_size; reference adapter: 64)")
     ap.add_argument("--cpu-pages", type=int, default=3, help="pages in the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-prof", action="store_true")
-    ap.add_argument("--config", type=int, default=1, choices=(1, 2, 4),
-                    help="BASELINE.json configs index: 1 = v6-tiny det+rec on 32 x 960^2 pages (the metric's configuration, default); "
-                         "2 = server-size det + SVTR rec (V=18710) on 64 x 1280^2 pages; 4 = full pipeline (doc orientation + UVDoc + det + rec + "
-                         "text-line orientation) on 16 x 960^2 pages")
-    args = ap.parse_args()
+    ap.add_argument("--no-device-resident", action="store_true", help="skip the second, device-resident timing")
+    ap.add_argument("--config", type=int, default=1, choices=(1, 2, 3, 4),
+                    help="BASELINE.json configs index: 1 = v6-tiny det+rec on 32 x 960^2 pages per GPU (the metric's configuration, default); "
+                         "2 = server-size det + SVTR rec (V=18710) on 64 x 1280^2 pages; 3 = v6-tiny, 1024 pages block-partitioned over the ranks; "
+                         "4 = full pipeline (doc orientation + UVDoc + det + rec + text-line orientation) on 16 x 960^2 pages")
+    ap.add_argument("--stub-engine", action="store_true", help=argparse.SUPPRESS)   # tests/test_bench_cpu.py: control flow without a GPU
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py starts its own ranks (0 = pick a free one)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` outside torchrun: start N ranks (one per GPU) of this same script, rendezvous on 127.0.0.1."""
+    port = args.master_port
+    if not port:
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (the host driver's only mode): RCCL needs it
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def pin_rank_to_its_cores(local_rank: int, local_world: int) -> int:
+    """One process per GPU shares the host: give each rank a contiguous slice of the cores BEFORE its geometry pool is
+    created (threads inherit the affinity), so that N spinning pools never compete for a core.  Returns the slice size."""
+    if not hasattr(os, "sched_getaffinity"):
+        return max(1, (os.cpu_count() or 1) // max(local_world, 1))
+    cpus = sorted(os.sched_getaffinity(0))
+    per = max(1, len(cpus) // max(local_world, 1))
+    if local_world > 1:
+        mine = cpus[local_rank * per:(local_rank + 1) * per] or cpus
+        try:
+            os.sched_setaffinity(0, mine)
+        except OSError:
+            pass
+    return per
+
+
+class StubEngine:
+    """Stands in for the HIP pipeline in the CPU-only control-flow test: same interface, fabricated results."""
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def predict_packed(self, pages):
+        import numpy as np
+        from oar_ocr_amd import api
+        n = len(pages)
+        per = 3
+        ro = np.arange(0, (n + 1) * per, per, dtype=np.uint32)
+        pts = np.tile(np.array([[0, 0], [10, 0], [10, 5], [0, 5]], np.float32), (n * per, 1, 1)) + self.rank
+        texts = [f"r{self.rank}p{i // per}k{i % per}".encode() for i in range(n * per)]
+        to = np.concatenate([[0], np.cumsum([len(t) for t in texts])]).astype(np.uint64)
+        time.sleep(0.002)
+        return api.PackedPages(ro, pts, np.full(n * per, 0.5, np.float32), b"".join(texts), to)
+
+    def predict_device(self):
+        return (0, 0)
+
+    def close(self):
+        pass
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     import numpy as np
     import torch
     from oar_ocr_amd import api, dist as oard
     from oar_ocr_amd.synth import models, pages as synth_pages
 
-    # one rank per GPU over RCCL; OAR_DIST_BACKEND=gloo exists so that the N > 1 path can be exercised with two ranks on a
-    # single-GPU box (RCCL refuses two ranks on one device)
-    backend = os.environ.get("OAR_DIST_BACKEND", "nccl")
-    red_dev = "cuda" if backend == "nccl" else "cpu"
+    stub = args.stub_engine
+    # one rank per GPU over RCCL; OAR_DIST_BACKEND=gloo exists so that the N > 1 path can be exercised on a box with fewer
+    # GPUs than ranks (RCCL refuses two ranks on one device) and by the CPU control-flow test
+    backend = os.environ.get("OAR_DIST_BACKEND", "gloo" if stub else "nccl")
     rank, local, world = oard.init_from_env(backend if args.gpus > 1 else None)
     if world > 1:
         import torch.distributed as dist
-    assert api.device_count() > 0, "bench.py needs a GPU: libOarMi355x has no CPU fallback"
-    dev = local % api.device_count()
-    torch.cuda.set_device(dev)
+    if not stub:
+        assert api.device_count() > 0, "bench.py needs a GPU: libOarMi355x has no CPU fallback"
+    dev = local % max(api.device_count(), 1) if not stub else 0
+    comm_dev = torch.device("cuda", dev) if (backend == "nccl" and not stub) else torch.device("cpu")
+    if not stub:
+        torch.cuda.set_device(dev)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    cores = pin_rank_to_its_cores(local, local_world)
 
+    # ---- workload
     size_name, vocab = ("server", 18710) if args.config == 2 else ("tiny", 6906)
-    if args.config == 2 and args.pages == 32 and args.size == 960:
-        args.pages, args.size = 64, 1280
-    if args.config == 4 and args.pages == 32:
-        args.pages = 16
-    det, det_info = models.build_det(size_name, seed=0)
-    rec, rec_info = models.build_rec(size_name, vocab=vocab, seed=1)
-    chars = api.read_dict(models.synth_dict(vocab - 2))
-    n_pages = args.pages
-    host_pages = [synth_pages.make_page(rank * n_pages + i, (args.size, args.size), args.lines) for i in range(n_pages)]
-    dev_pages = [api.DeviceBuffer(p, dev) for p in host_pages]           # inputs resident in HBM before timing
-    ptrs = [int(b.ptr.value) for b in dev_pages]
-    ws = [args.size] * n_pages
-    hs = [args.size] * n_pages
+    size = args.size or (1280 if args.config == 2 else 960)
+    if args.config == 3:      # BASELINE configs[3]: 1024 pages over the ranks (block partition, 128 per GPU at N = 8)
+        total_pages = args.pages or 1024
+        a, b = oard.shard_range(total_pages, world, rank)
+        n_pages, seed0, scaling = b - a, a, "strong"
+    else:
+        n_pages = args.pages or {1: 32, 2: 64, 4: 16}[args.config]
+        seed0, scaling, total_pages = rank * n_pages, "weak", n_pages * world
+    host_pages = [synth_pages.make_page(seed0 + i, (size, size), args.lines) for i in range(n_pages)]
+    image_batch = min(n_pages, 64 if args.config == 2 else 32)
 
-    cfg = api.TextDetectionConfig(score_threshold=0.3, box_threshold=0.6, unclip_ratio=1.5)   # examples/ocr.rs:119-133 set
-    builder = (api.OAROCRBuilder(det, rec, chars).text_detection_config(cfg).image_batch_size(n_pages)
-               .region_batch_size(args.region_batch).device(dev))
-    if world > 1:
-        # one process per GPU shares the host: give each rank's geometry pool its slice of the cores (the pool spins
-        # between bursts, so oversubscribed ranks would fight each other for cycles)
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-        cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        builder = builder.host_threads(max(2, min(16, cpus // max(local_world, 1) - 1)))
-    if args.config == 4:
-        builder = (builder.with_document_image_orientation_classification(models.build_cls(4, seed=5)[0])
-                   .with_document_image_rectification(models.build_uvdoc(seed=6)[0])
-                   .with_text_line_orientation_classification(models.build_cls(2, seed=9)[0]))
-    ocr = builder.build()
+    if stub:
+        eng, det_info, rec_info = StubEngine(rank), {"params": 0}, {"params": 0}
+    else:
+        det, det_info = models.build_det(size_name, seed=0)
+        rec, rec_info = models.build_rec(size_name, vocab=vocab, seed=1)
+        chars = api.read_dict(models.synth_dict(vocab - 2))
+        cfg = api.TextDetectionConfig(score_threshold=0.3, box_threshold=0.6, unclip_ratio=1.5)   # examples/ocr.rs:119-133 set
+        builder = (api.OAROCRBuilder(det, rec, chars).text_detection_config(cfg).image_batch_size(image_batch)
+                   .region_batch_size(args.region_batch).device(dev))
+        if world > 1:
+            builder = builder.host_threads(max(2, min(16, cores)))   # this rank's geometry pool stays inside its core slice
+        if args.config == 4:
+            builder = (builder.with_document_image_orientation_classification(models.build_cls(4, seed=5)[0])
+                       .with_document_image_rectification(models.build_uvdoc(seed=6)[0])
+                       .with_text_line_orientation_classification(models.build_cls(2, seed=9)[0]))
+        ocr = builder.build()
+        _, h_ptrs, h_ws, h_hs = api._img_arrays(host_pages)   # pageable host buffers, exactly what a caller's Vec<RgbImage> is
 
-    def step():
-        return ocr.predict_device(ptrs, ws, hs, raw=True)
+        class HipEngine:
+            def predict_packed(self, pages):
+                return ocr.predict_packed(h_ptrs, h_ws, h_hs, n_pages)
+
+            def close(self):
+                ocr.close()
+        eng = HipEngine()
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
+
+    gathered = {"pages": 0, "regions": 0, "bytes": 0}
+
+    def step():
+        """host pages -> boxes + texts + scores on the host of rank 0"""
+        packed = eng.predict_packed(host_pages)
+        if world == 1:
+            gathered.update(pages=len(packed.region_offsets) - 1, regions=len(packed.scores), bytes=len(packed.utf8))
+            return packed
+        blobs = oard.gather_bytes(packed.to_bytes(), 0, comm_dev)
+        if rank == 0:
+            parts = [api.PackedPages.from_bytes(b) for b in blobs]   # block partition => concatenation restores page order
+            gathered.update(pages=sum(len(p.region_offsets) - 1 for p in parts), regions=sum(len(p.scores) for p in parts),
+                            bytes=sum(len(p.utf8) for p in parts))
+        return packed
 
     # -- untimed: discover the dominant kernel class with every class instrumented
-    dominant = None
-    if not args.no_prof:
+    dominant, dominant_launches, breakdown = None, 0, {}
+    if not args.no_prof and not stub:
         step()
         api.prof_enable(True)
         api.prof_filter("")
@@ -115,22 +217,17 @@ def main():
         if snap and snap[0]["total_ms"] > 0:
             dominant, dominant_launches = snap[0]["name"], snap[0]["launches"]
         breakdown = {e["name"]: round(e["total_ms"], 3) for e in snap[:12]}
-    else:
-        breakdown = {}
 
-    # the timed region's instrumentation (events around the dominant class only) is switched on BEFORE the warm-up: the
-    # engines replay their plans as hipGraphs, and a graph embeds the event nodes of the profiler state it was captured in
     if dominant:
         api.prof_filter(dominant)
         api.prof_enable(True)
     for _ in range(args.warmup):
-        regions, ctc = step()
+        step()
     if dominant:
         api.prof_reset()
-    # An event-bracketed kernel costs ~11 us of idle queue around it (rocprofv3 kernel trace), ~1 ms per
-    # step for this class.  So each step times 1 launch in S, with the phase rotating over the steps: every launch POSITION
-    # of the class is timed in exactly `balanced / S` of the timed steps (the steps past the last full rotation time none),
-    # which gives the same average as timing all of them at 1/S of the overhead.
+    # An event-bracketed kernel costs ~11 us of idle queue around it (rocprofv3 kernel trace).  So each
+    # step times 1 launch in S, with the phase rotating over the steps: every launch POSITION of the class is timed in exactly
+    # `balanced / S` of the timed steps, which gives the same average as timing all of them at 1/S of the overhead.
     S = min(5, max(args.steps, 1))
     balanced = S * (args.steps // S)
     barrier()
@@ -138,10 +235,11 @@ def main():
     for i in range(args.steps):
         if dominant:
             api.prof_sampling(S, i % S if i < balanced else -1)
-        regions, ctc = step()
+        step()
     barrier()
     dt = time.perf_counter() - t0
-    api.prof_sampling(1, 0)
+    if not stub:
+        api.prof_sampling(1, 0)
     roof = None
     if dominant:
         snap = {e["name"]: e for e in api.prof_snapshot()}
@@ -176,20 +274,33 @@ def main():
 
     tmax = dt
     if world > 1:
-        t = torch.tensor([dt], device=red_dev)
+        t = torch.tensor([dt], device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         tmax = float(t.item())
-        cnt = torch.tensor([float(regions)], device=red_dev)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        regions_total = int(cnt.item())
-    else:
-        regions_total = regions
+
+    # -- second figure: pages already resident in HBM, no decode (round 1's headline), same step count
+    dev_res = None
+    if not stub and not args.no_device_resident and world == 1:
+        dev_pages = [api.DeviceBuffer(p, dev) for p in host_pages]
+        ptrs = [int(b.ptr.value) for b in dev_pages]
+        ws = hs = [size] * n_pages
+        for _ in range(max(1, args.warmup)):
+            ocr.predict_device(ptrs, ws, hs, raw=True)
+        torch.cuda.synchronize()
+        d0 = time.perf_counter()
+        for _ in range(args.steps):
+            ocr.predict_device(ptrs, ws, hs, raw=True)
+        torch.cuda.synchronize()
+        ddt = time.perf_counter() - d0
+        dev_res = {"value": round(n_pages * args.steps / ddt, 2), "unit": "images/sec", "ms_per_step": round(ddt / args.steps * 1e3, 3),
+                   "what": "oar_ocr_predict_device only: pages resident in HBM, CTC indices returned, no string decode (round-1 definition)"}
+        for b in dev_pages:
+            b.free()
 
     if rank == 0:
-        total_pages = n_pages * world * args.steps
-        value = total_pages / tmax
+        value = total_pages * args.steps / tmax
         cpu = None
-        if args.cpu_pages > 0 and world == 1:   # the CPU baseline is timed on rank 0 of the single-GPU run only
+        if args.cpu_pages > 0 and world == 1 and not stub:   # the CPU baseline is timed on rank 0 of the single-GPU run only
             from oracle import pipeline_ref
             torch.set_num_threads(min(os.cpu_count() or 1, 64))
             sample = host_pages[:args.cpu_pages]
@@ -201,20 +312,25 @@ def main():
             oc.predict(sample)
             cdt = time.perf_counter() - c0
             cpu = {"value": round(len(sample) / cdt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-                   "sample": f"{len(sample)} of the same {args.size}x{args.size} synthetic pages, det batch 1 / rec batch 16 (reference CPU defaults); "
-                             "oracle = C restatement of pre/post (1 thread) + torch-CPU fp32 network (threads above)"}
+                   "sample": f"{len(sample)} of the same {size}x{size} synthetic pages, det batch 1 / rec batch 16 (reference CPU defaults); "
+                             "oracle = C restatement of pre/post (1 thread) + torch-CPU fp32 network (threads above); the reference's own "
+                             "published CPU figure is 34 ms/image (docs/FAQ.md:22, i9-13900KF, real weights)"}
         line = {
             "metric": "images/sec end-to-end PP-OCRv6 det+rec", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(tmax / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"baseline_config": args.config,
                        "workload": f"{'PP-OCRv5-server-class det + SVTR rec' if args.config == 2 else 'PP-OCRv6-tiny-class det+rec'}"
                                    f"{' + doc orientation + UVDoc + text-line orientation' if args.config == 4 else ''} "
                                    f"(synthetic-weight graphs: det {det_info['params']} params, rec {rec_info['params']} params, V={vocab}), "
-                                   f"batch={n_pages} synthetic {args.size}x{args.size} pages per GPU, {args.lines} text lines/page, pages resident in HBM",
-                       "pages_per_gpu_per_step": n_pages, "region_batch_size": args.region_batch, "regions_per_step": regions_total,
-                       "parallelism": f"image-parallel x{world}"},
-            "roofline": roof, "cpu_baseline": cpu, "kernel_ms_per_step_untimed_pass": breakdown,
+                                   + (f"{total_pages} synthetic {size}x{size} pages block-partitioned over {world} GPU(s)" if args.config == 3 else
+                                      f"batch={n_pages} synthetic {size}x{size} pages per GPU") +
+                                   f", {args.lines} text lines/page; timed region = u8 pages in pageable HOST memory -> oar_ocr_predict -> oar_ocr_decode -> "
+                                   f"sorted boxes + texts + scores on the host{' of rank 0 (RCCL gather inside the region)' if world > 1 else ''}",
+                       "pages_per_gpu_per_step": n_pages, "image_batch_size": image_batch, "region_batch_size": args.region_batch,
+                       "regions_per_step": gathered["regions"], "text_bytes_per_step": gathered["bytes"], "pages_gathered_per_step": gathered["pages"],
+                       "parallelism": f"image-parallel x{world}", "host_cores_per_rank": cores},
+            "roofline": roof, "cpu_baseline": cpu, "device_resident": dev_res, "kernel_ms_per_step_untimed_pass": breakdown,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
@@ -222,9 +338,7 @@ def main():
         dist.destroy_process_group()
     # release native handles explicitly: destroying them from interpreter teardown (after the HIP runtime / a
     # profiler tool has finalised) was observed to hang the process under rocprofv3
-    ocr.close()
-    for b in dev_pages:
-        b.free()
+    eng.close()
     sys.stdout.flush()
     sys.stderr.flush()
 

@@ -105,6 +105,11 @@ typedef struct {
     int32_t use_hip_graph;
     int32_t profile;
     int32_t host_threads;      /* worker threads for the serial contour/geometry stage (0 = hw conc.)   */
+    /* DBPostProcess options the adapter exposes (processors/db_postprocess.rs:60-98, processors/types.rs):          */
+    int32_t box_type;          /* 0 = BoxType::Quad (default), 1 = BoxType::Poly (seal text; not implemented yet: create fails with OAR_UNSUPPORTED_OP) */
+    int32_t score_mode;        /* 0 = ScoreMode::Fast (mini-box scanline mean), 1 = ScoreMode::Slow (contour scanline mean, db_score.rs:139-181) */
+    int32_t use_dilation;      /* 1: dilate the mask (3 x 3, db_mask.rs:11) before contour tracing (db_postprocess.rs:163-168) */
+    int32_t reserved;
 } oar_det_cfg;
 
 /* CSR result: image i owns boxes [box_offsets[i], box_offsets[i+1]); each box is 4 points (x,y) f32 in
@@ -128,6 +133,10 @@ void oar_det_result_free(oar_det_result* r);
 oar_status oar_db_postprocess(const float* pred, uint32_t height, uint32_t width, uint32_t src_w, uint32_t src_h,
                               float thresh, float box_thresh, float unclip_ratio, uint32_t max_candidates,
                               oar_det_result* out);
+/* Same, with the DBPostProcess options that oar_det_cfg carries: score_mode, use_dilation; box_type must be 0. */
+oar_status oar_db_postprocess_ex(const float* pred, uint32_t height, uint32_t width, uint32_t src_w, uint32_t src_h,
+                                 float thresh, float box_thresh, float unclip_ratio, uint32_t max_candidates,
+                                 int32_t box_type, int32_t score_mode, int32_t use_dilation, oar_det_result* out);
 
 /* ------------------------------------------------------------------------------------------------ Seam B: recognition
  * TextRecognitionAdapter::execute (domain/adapters/text_recognition_adapter.rs:35-111) -> CRNNModel::forward_refs
@@ -160,6 +169,33 @@ void oar_rec_destroy(oar_rec* r);
 oar_status oar_rec_run(oar_rec* r, const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights,
                        uint32_t n_crops, oar_rec_result* out);
 void oar_rec_result_free(oar_rec_result* r);
+
+/* CTC collapse + text assembly + score filter on the host, inside the library (rows a19 / a20):
+ * CTCLabelDecode::from_string_list(dict lines, use_space_char, has_explicit_blank = false) (processors/decode.rs:391-421;
+ * lines from `char_dict.lines()`, src/oarocr/ocr.rs:386; only the first char of a line counts, empty lines vanish,
+ * decode.rs:120) -> oar_ctc_dict_create;  decode_argmax_with_positions (decode.rs:549-614) + the adapter's
+ * `score >= threshold` filter that blanks text / positions but keeps slot and score
+ * (domain/adapters/text_recognition_adapter.rs:60-102) -> oar_ctc_decode / oar_ocr_decode.  No GPU involved. */
+typedef struct oar_ctc_dict oar_ctc_dict;
+typedef struct {
+    uint32_t n;               /* sequences (regions)                                                   */
+    uint64_t* text_offsets;   /* n + 1 byte offsets into utf8                                         */
+    char* utf8;               /* concatenated texts, text_offsets[n] bytes (+ one NUL)                */
+    float* scores;            /* n: mean probability of the kept characters, 0.0 when none            */
+    uint64_t* char_offsets;   /* n + 1 offsets into char_cols / char_positions                        */
+    uint32_t* char_cols;      /* char_col_indices: time step of each character                        */
+    float* char_positions;    /* time step / T                                                        */
+    uint32_t* seq_len;        /* n: T                                                                 */
+    uint8_t* kept;            /* n: 0 when score < threshold (text and positions were blanked)        */
+} oar_text_result;
+/* dict_utf8: the dictionary file's text (UTF-8, one entry per line). */
+oar_status oar_ctc_dict_create(const char* dict_utf8, size_t len, int32_t use_space_char, oar_ctc_dict** out);
+void oar_ctc_dict_destroy(oar_ctc_dict* d);
+uint32_t oar_ctc_dict_classes(const oar_ctc_dict* d);   /* blank + entries (+ space) */
+/* indices / probs: batch * seq_len (an oar_rec_result). */
+oar_status oar_ctc_decode(const oar_ctc_dict* dict, const int64_t* indices, const float* probs, uint32_t batch, uint32_t seq_len,
+                          float score_threshold, oar_text_result* out);
+void oar_text_result_free(oar_text_result* r);
 
 /* ------------------------------------------------------------------------------------------------ Seam B: whole pipeline
  * OAROCRBuilder::new(det, rec, dict)...build() (src/oarocr/ocr.rs:105,249-417) -> oar_ocr_create
@@ -210,6 +246,9 @@ oar_status oar_ocr_predict(oar_ocr* o, const uint8_t* const* rgb, const uint32_t
 oar_status oar_ocr_predict_device(oar_ocr* o, const uint8_t* const* d_rgb, const uint32_t* widths,
                                   const uint32_t* heights, uint32_t n_images, oar_ocr_result* out);
 void oar_ocr_result_free(oar_ocr_result* r);
+/* Texts / scores / character columns of every region of a pipeline result, region order = res's
+ * (OAROCR::recognize_global's scatter, src/oarocr/ocr.rs:840-891). */
+oar_status oar_ocr_decode(const oar_ctc_dict* dict, const oar_ocr_result* res, float score_threshold, oar_text_result* out);
 
 /* ------------------------------------------------------------------------------------------------ Seam B: config-5 stages
  * PP-LCNet classifier adapters: DocumentOrientationAdapter / TextLineOrientationAdapter ->
@@ -285,6 +324,12 @@ oar_status oar_k_rec_preprocess(const uint8_t* const* rgb, const uint32_t* width
 oar_status oar_k_resize_triangle(const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, uint8_t* out);
 /* a7  processors/db_postprocess.rs:185-221 */
 oar_status oar_k_threshold(const float* pred, size_t n, float thresh, uint8_t* mask);
+/* processors/db_mask.rs:11 (imageproc dilate, LInf, k = 1) on one height x width mask */
+oar_status oar_k_dilate(const uint8_t* mask, uint32_t height, uint32_t width, uint8_t* out);
+/* processors/db_score.rs:139-181 (and db_bitmap.rs:49): scanline mean over polygons of any size; polygon i has
+ * counts[i] (x, y) points, stored back to back in pts_xy */
+oar_status oar_k_poly_scores(const float* pred, uint32_t height, uint32_t width, const float* pts_xy, const uint32_t* counts,
+                             uint32_t n_polys, float* scores);
 /* a18 processors/decode.rs:452-501 + simd.rs:72-81 */
 oar_status oar_k_ctc_argmax(const float* probs, size_t rows, size_t vocab, int64_t* idx, float* prob);
 /* a10 processors/db_score.rs:34-134: boxes = n_boxes * 8 floats */
@@ -318,6 +363,11 @@ void oar_host_sort_quad_boxes(const float* boxes8, int32_t n, int32_t* order);
 int32_t oar_host_pool_selftest(int32_t threads, int32_t jobs);
 /* a14 utils/transform.rs:76-191 planning half: plan[8] = {mode, left, top, cw, ch, out_w, out_h, rot}; inv[9]. */
 void oar_host_plan_crop(uint32_t img_w, uint32_t img_h, const float box8[8], int32_t plan[8], float inv[9]);
+
+/* Test hook: makes the next `count` occurrences of a failure site throw OAR_DEVICE.  Sites: "batched_detection" (a
+ * detector run over more than one page) -- exercises OAROCR::predict's "batched text detection failed; falling back to
+ * per-image detection" path (src/oarocr/ocr.rs:576-588), which oar_ocr_predict reproduces inside the call. */
+oar_status oar_debug_inject_failure(const char* site, int32_t count);
 
 /* ------------------------------------------------------------------------------------------------ profiling
  * Per-kernel-class accumulators filled from hipEvents recorded on the engine's own stream while cfg.profile

@@ -44,7 +44,8 @@ class Tensor(C.Structure):
 
 class DetCfg(C.Structure):
     _fields_ = [("device_id", C.c_int32), ("limit_side_len", C.c_uint32), ("limit_type", C.c_int32), ("max_side_limit", C.c_uint32),
-                ("max_candidates", C.c_uint32), ("use_hip_graph", C.c_int32), ("profile", C.c_int32), ("host_threads", C.c_int32)]
+                ("max_candidates", C.c_uint32), ("use_hip_graph", C.c_int32), ("profile", C.c_int32), ("host_threads", C.c_int32),
+                ("box_type", C.c_int32), ("score_mode", C.c_int32), ("use_dilation", C.c_int32), ("reserved", C.c_int32)]
 
 
 class DetResult(C.Structure):
@@ -89,6 +90,12 @@ class RectCfg(C.Structure):
     _fields_ = [("device_id", C.c_int32), ("target_h", C.c_uint32), ("target_w", C.c_uint32)]
 
 
+class TextResult(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("text_offsets", C.POINTER(C.c_uint64)), ("utf8", C.POINTER(C.c_char)), ("scores", C.POINTER(C.c_float)),
+                ("char_offsets", C.POINTER(C.c_uint64)), ("char_cols", C.POINTER(C.c_uint32)), ("char_positions", C.POINTER(C.c_float)),
+                ("seq_len", C.POINTER(C.c_uint32)), ("kept", C.POINTER(C.c_uint8))]
+
+
 class ProfEntry(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double), ("alg_bytes", C.c_double), ("alg_flops", C.c_double)]
 
@@ -103,7 +110,8 @@ EXPORTS = [
     "oar_host_candidates", "oar_host_unclip", "oar_host_mini_box", "oar_host_sort_quad_boxes", "oar_host_pool_selftest", "oar_host_plan_crop",
     "oar_cls_create", "oar_cls_destroy", "oar_cls_run", "oar_cls_result_free", "oar_cls_preprocess", "oar_rect_create", "oar_rect_destroy",
     "oar_rect_run", "oar_ocr_attach", "oar_k_rotate_rgb", "oar_k_bgr_planes_to_rgb", "oar_host_rotate_back_points",
-    "oar_engine_cache_stats", "oar_onnx_inspect", "oar_host_contours",
+    "oar_engine_cache_stats", "oar_onnx_inspect", "oar_host_contours", "oar_ctc_dict_create", "oar_ctc_dict_destroy", "oar_ctc_dict_classes",
+    "oar_ctc_decode", "oar_ocr_decode", "oar_text_result_free", "oar_db_postprocess_ex", "oar_k_dilate", "oar_k_poly_scores", "oar_debug_inject_failure",
 ]
 
 
@@ -139,6 +147,11 @@ def lib():
     L.oar_det_result_free.argtypes = [C.POINTER(DetResult)]
     L.oar_det_result_free.restype = None
     L.oar_db_postprocess.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_uint32, C.POINTER(DetResult)]
+    L.oar_db_postprocess_ex.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_int32, C.c_int32,
+                                        C.c_int32, C.POINTER(DetResult)]
+    L.oar_debug_inject_failure.argtypes = [C.c_char_p, C.c_int32]
+    L.oar_k_dilate.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    L.oar_k_poly_scores.argtypes = [vp, C.c_uint32, C.c_uint32, vp, u32p, C.c_uint32, vp]
     L.oar_rec_create.argtypes = [vp, C.c_size_t, C.POINTER(RecCfg), C.POINTER(vp)]
     L.oar_rec_destroy.argtypes = [vp]
     L.oar_rec_destroy.restype = None
@@ -192,6 +205,15 @@ def lib():
     L.oar_k_rotate_rgb.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int32, vp]
     L.oar_k_bgr_planes_to_rgb.argtypes = [vp, C.c_uint64, C.c_float, vp]
     L.oar_host_rotate_back_points.argtypes = [vp, C.c_uint32, C.c_float, C.c_uint32, C.c_uint32]
+    L.oar_ctc_dict_create.argtypes = [C.c_char_p, C.c_size_t, C.c_int32, C.POINTER(vp)]
+    L.oar_ctc_dict_destroy.argtypes = [vp]
+    L.oar_ctc_dict_destroy.restype = None
+    L.oar_ctc_dict_classes.argtypes = [vp]
+    L.oar_ctc_dict_classes.restype = C.c_uint32
+    L.oar_ctc_decode.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_float, C.POINTER(TextResult)]
+    L.oar_ocr_decode.argtypes = [vp, C.POINTER(OcrResult), C.c_float, C.POINTER(TextResult)]
+    L.oar_text_result_free.argtypes = [C.POINTER(TextResult)]
+    L.oar_text_result_free.restype = None
     L.oar_prof_reset.restype = None
     L.oar_prof_enable.argtypes = [C.c_int32]
     L.oar_prof_enable.restype = None
@@ -225,6 +247,11 @@ def onnx_inspect(model: bytes) -> str:
     st = lib().oar_onnx_inspect(C.cast(b, C.c_void_p), len(model), buf, 8192)
     _check(st)
     return buf.value.decode()
+
+
+def debug_inject_failure(site: str, count: int):
+    """Test hook (oar_debug_inject_failure): the next `count` occurrences of `site` fail with OAR_DEVICE."""
+    _check(lib().oar_debug_inject_failure(site.encode(), count))
 
 
 def device_count() -> int:
@@ -314,8 +341,14 @@ class TextDetectionConfig:
     limit_side_len: Optional[int] = None
     limit_type: Optional[str] = None   # "max" | "min" | "resize_long"
     max_side_len: Optional[int] = None
+    # DBPostProcess options (processors/db_postprocess.rs:60-98; the adapters set them at build time)
+    box_type: str = "quad"             # "quad" | "poly" (seal text; not implemented yet)
+    score_mode: str = "fast"           # "fast" | "slow"
+    use_dilation: bool = False
 
     def validate(self):
+        if self.box_type not in ("quad", "poly") or self.score_mode not in ("fast", "slow"):
+            raise OCRError(OAR_INVALID_INPUT, "box_type must be quad|poly and score_mode fast|slow")
         for name, v, lo, hi in (("score_threshold", self.score_threshold, 0.0, 1.0), ("box_threshold", self.box_threshold, 0.0, 1.0)):
             if not (lo <= v <= hi):
                 raise OCRError(OAR_INVALID_INPUT, f"{name} must be in [{lo}, {hi}]")
@@ -343,6 +376,8 @@ class TextRegion:
     det_score: float = 0.0
     crop_wh: tuple = (0, 0)
     orientation_angle: Optional[float] = None   # text-line orientation (0 / 180), ocr.rs:888
+    rec_max_wh_ratio: float = 0.0               # chunk_max_wh_ratio of the recognition batch the crop was in (ocr.rs:828-831)
+    rec_seq_len: int = 0
 
 
 @dataclass
@@ -355,9 +390,96 @@ class OAROCRResult:
     rectified: bool = False   # rectified_img is Some: boxes are in rectified space (preprocess.rs:84-89)
 
 
+def dict_lines(text: str) -> List[str]:
+    """Rust `str::lines()` (src/oarocr/ocr.rs:386): split at '\n', a '\r' right before it belongs to the terminator; no
+    trailing empty line.  (Python's splitlines() also splits at \x0b, \x0c, \x1c-\x1e, \x85, \u2028, \u2029 and a bare \r.)"""
+    parts = text.split("\n")
+    lines = [p[:-1] if p.endswith("\r") else p for p in parts[:-1]]
+    if parts[-1] != "":
+        lines.append(parts[-1])
+    return lines
+
+
 def read_dict(text: str) -> List[str]:
-    """Dictionary file -> entries (src/oarocr/ocr.rs:277-291, decode.rs:120): first char of each non-empty line."""
-    return [ln[0] for ln in text.splitlines() if len(ln) > 0]
+    """Dictionary file -> entries (src/oarocr/ocr.rs:277-291,386, decode.rs:120): first char of each non-empty line."""
+    return [ln[0] for ln in dict_lines(text) if len(ln) > 0]
+
+
+@dataclass
+class DecodedTexts:
+    """What oar_ctc_decode / oar_ocr_decode return (TextRecognitionOutput after the adapter's score filter)."""
+    texts: List[str]
+    scores: np.ndarray              # [n] f32
+    char_cols: List[np.ndarray]     # per sequence: time step of each character
+    char_positions: List[np.ndarray]
+    seq_len: np.ndarray             # [n]
+    kept: np.ndarray                # [n] bool: score >= threshold
+    utf8: bytes = b""               # the concatenated texts as the library produced them
+    text_offsets: Optional[np.ndarray] = None
+
+
+class CtcDict:
+    """The library-side CTCLabelDecode (processors/decode.rs:391-421,549-614): collapse, text, mean score, positions and
+    the adapter's score filter in C (microseconds per region; the Python CTCLabelDecode below is the readable mirror)."""
+
+    def __init__(self, dict_text: str, use_space_char: bool = True):
+        raw = dict_text.encode("utf-8")
+        self._h = C.c_void_p()
+        _check(lib().oar_ctc_dict_create(raw, len(raw), int(use_space_char), C.byref(self._h)))
+
+    @classmethod
+    def from_entries(cls, entries: Sequence[str], use_space_char: bool = True) -> "CtcDict":
+        return cls("".join(e + "\n" for e in entries), use_space_char)
+
+    @property
+    def classes(self) -> int:
+        return int(lib().oar_ctc_dict_classes(self._h))
+
+    @staticmethod
+    def _unpack(res: TextResult, want_positions: bool = True) -> DecodedTexts:
+        n = int(res.n)
+        to = np.ctypeslib.as_array(res.text_offsets, shape=(n + 1,)).copy()
+        raw = C.string_at(res.utf8, int(to[n]))
+        sc = np.ctypeslib.as_array(res.scores, shape=(max(n, 1),)).copy()[:n]
+        sl = np.ctypeslib.as_array(res.seq_len, shape=(max(n, 1),)).copy()[:n]
+        kept = np.ctypeslib.as_array(res.kept, shape=(max(n, 1),)).copy()[:n].astype(bool)
+        texts = [raw[to[i]:to[i + 1]].decode("utf-8", errors="replace") for i in range(n)]
+        cols, pos = [], []
+        if want_positions:
+            co = np.ctypeslib.as_array(res.char_offsets, shape=(n + 1,)).copy()
+            nc = int(co[n])
+            cc = np.ctypeslib.as_array(res.char_cols, shape=(max(nc, 1),)).copy()[:nc]
+            cp = np.ctypeslib.as_array(res.char_positions, shape=(max(nc, 1),)).copy()[:nc]
+            cols = [cc[co[i]:co[i + 1]] for i in range(n)]
+            pos = [cp[co[i]:co[i + 1]] for i in range(n)]
+        return DecodedTexts(texts, sc, cols, pos, sl, kept, raw, to)
+
+    def decode(self, indices: np.ndarray, probs: np.ndarray, batch: int, T: int, score_threshold: float = 0.0) -> DecodedTexts:
+        idx = np.ascontiguousarray(indices, np.int64)
+        pr = np.ascontiguousarray(probs, np.float32)
+        res = TextResult()
+        _check(lib().oar_ctc_decode(self._h, _p(idx) if idx.size else None, _p(pr) if pr.size else None, batch, T, C.c_float(score_threshold), C.byref(res)))
+        out = self._unpack(res)
+        lib().oar_text_result_free(C.byref(res))
+        return out
+
+    def decode_ocr(self, res: "OcrResult", score_threshold: float = 0.0, want_positions: bool = True) -> DecodedTexts:
+        tr = TextResult()
+        _check(lib().oar_ocr_decode(self._h, C.byref(res), C.c_float(score_threshold), C.byref(tr)))
+        out = self._unpack(tr, want_positions)
+        lib().oar_text_result_free(C.byref(tr))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.oar_ctc_dict_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class CTCLabelDecode:
@@ -410,7 +532,8 @@ class TextDetectionPredictor:
         self.config = config or TextDetectionConfig()
         self.config.validate()
         cfg = DetCfg(device_id, self.config.limit_side_len or limit_side_len, _LIMIT[self.config.limit_type or limit_type],
-                     self.config.max_side_len or max_side_limit, self.config.max_candidates, 0, int(profile), host_threads)
+                     self.config.max_side_len or max_side_limit, self.config.max_candidates, 0, int(profile), host_threads,
+                     int(self.config.box_type == "poly"), int(self.config.score_mode == "slow"), int(self.config.use_dilation), 0)
         self._h = C.c_void_p()
         buf = (C.c_char * len(model)).from_buffer_copy(model)
         _check(lib().oar_det_create(C.cast(buf, C.c_void_p), len(model), C.byref(cfg), C.byref(self._h)))
@@ -451,12 +574,14 @@ def _unpack_det(res: DetResult) -> List[List[Detection]]:
     return [[Detection(pts[k].copy(), float(sc[k])) for k in range(offs[i], offs[i + 1])] for i in range(n)]
 
 
-def db_postprocess(pred: np.ndarray, src_w: int, src_h: int, thresh=0.3, box_thresh=0.6, unclip_ratio=1.5, max_candidates=1000):
+def db_postprocess(pred: np.ndarray, src_w: int, src_h: int, thresh=0.3, box_thresh=0.6, unclip_ratio=1.5, max_candidates=1000,
+                   score_mode="fast", use_dilation=False):
     """Test hook: DB post-processing (a7..a12) on a host probability map through the HIP kernels."""
     pred = np.ascontiguousarray(pred, np.float32)
     h, w = pred.shape
     res = DetResult()
-    _check(lib().oar_db_postprocess(_p(pred), h, w, src_w, src_h, thresh, box_thresh, unclip_ratio, max_candidates, C.byref(res)))
+    _check(lib().oar_db_postprocess_ex(_p(pred), h, w, src_w, src_h, thresh, box_thresh, unclip_ratio, max_candidates, 0, int(score_mode == "slow"),
+                                       int(use_dilation), C.byref(res)))
     out = _unpack_det(res)[0]
     lib().oar_det_result_free(C.byref(res))
     return out
@@ -596,10 +721,12 @@ class OAROCRBuilder:
             d.validate()
             thresh, box_thresh, unclip, maxc = d.score_threshold, d.box_threshold, d.unclip_ratio, d.max_candidates
             lsl, lt, msl = d.limit_side_len or 960, d.limit_type or "max", d.max_side_len or 4000
+            opts = (int(d.box_type == "poly"), int(d.score_mode == "slow"), int(d.use_dilation))
         else:   # builder defaults (ocr.rs:319-366)
             thresh, box_thresh, unclip, maxc, lsl, lt, msl = 0.3, 0.6, 2.0, 1000, 960, "max", 4000
+            opts = (0, 0, 0)
         cfg = OcrCfg()
-        cfg.det = DetCfg(self._device, lsl, _LIMIT[lt], msl, maxc, 0, int(self._profile), self._host_threads)
+        cfg.det = DetCfg(self._device, lsl, _LIMIT[lt], msl, maxc, 0, int(self._profile), self._host_threads, *opts, 0)
         cfg.rec = RecCfg(self._device, (C.c_uint32 * 3)(3, 48, 320), 3200, 0, int(self._profile), 0)
         cfg.det_thresh, cfg.det_box_thresh, cfg.det_unclip_ratio = thresh, box_thresh, unclip
         cfg.image_batch_size = self._image_bs or 0      # accelerator: adapter defaults 8 / 64 (builder_utils.rs:86-102)
@@ -616,6 +743,7 @@ class OAROCRBuilder:
 class OAROCR:
     def __init__(self, det: bytes, rec: bytes, character_dict, cfg: OcrCfg, score_threshold: float):
         self.decoder = CTCLabelDecode(character_dict, use_space_char=True)
+        self.ctc = CtcDict.from_entries([s[0] for s in character_dict if len(s) > 0], use_space_char=True)
         self.score_threshold = score_threshold
         self.return_word_box = False
         self._h = C.c_void_p()
@@ -642,7 +770,7 @@ class OAROCR:
 
     def predict_device(self, dev_ptrs: Sequence[int], widths: Sequence[int], heights: Sequence[int], raw: bool = False):
         """Pages already resident in HBM (pointers from DeviceBuffer). raw=True skips string assembly and returns
-        (n_regions, n_ctc) -- used by bench.py so the timed region is exactly the C-ABI call."""
+        (n_regions, n_ctc)."""
         n = len(dev_ptrs)
         ptrs = (C.c_void_p * n)(*dev_ptrs)
         ws = (C.c_uint32 * n)(*widths)
@@ -656,6 +784,22 @@ class OAROCR:
         out = self._assemble(res)
         lib().oar_ocr_result_free(C.byref(res))
         return out
+
+    def predict_packed(self, ptrs, ws, hs, n: int, device: bool = False) -> "PackedPages":
+        """The metric path of bench.py (u8 pages in host memory -> sorted boxes + texts + scores on the host):
+        ONE oar_ocr_predict + ONE oar_ocr_decode, results as flat arrays (no per-region Python objects).  ptrs / ws / hs are
+        prepared ctypes arrays (the caller owns the page buffers, as the Rust caller owns its `RgbImage`s)."""
+        res = OcrResult()
+        fn = lib().oar_ocr_predict_device if device else lib().oar_ocr_predict
+        _check(fn(self._h, ptrs, ws, hs, n, C.byref(res)))
+        try:
+            d = self.ctc.decode_ocr(res, self.score_threshold, want_positions=False)
+            nr = int(res.n_regions)
+            offs = np.ctypeslib.as_array(res.region_offsets, shape=(n + 1,)).copy()
+            pts = np.ctypeslib.as_array(res.points, shape=(max(nr, 1) * 8,)).copy()[:nr * 8].reshape(nr, 4, 2)
+        finally:
+            lib().oar_ocr_result_free(C.byref(res))
+        return PackedPages(offs, pts, d.scores, d.utf8, d.text_offsets)
 
     def _assemble(self, res: OcrResult) -> List[OAROCRResult]:
         n, nr = res.n_images, res.n_regions
@@ -671,26 +815,19 @@ class OAROCR:
         sl = np.ctypeslib.as_array(res.seq_len, shape=(nr,)).copy()
         mwh = np.ctypeslib.as_array(res.max_wh_ratio, shape=(nr,)).copy()
         lang = np.ctypeslib.as_array(res.line_angle, shape=(nr,)).copy()
-        co = np.ctypeslib.as_array(res.ctc_offsets, shape=(nr + 1,)).copy()
-        nctc = int(co[nr])
-        ci = np.ctypeslib.as_array(res.ctc_indices, shape=(max(nctc, 1),)).copy()
-        cp = np.ctypeslib.as_array(res.ctc_probs, shape=(max(nctc, 1),)).copy()
+        dec = self.ctc.decode_ocr(res, self.score_threshold)   # collapse + text + score filter inside the library
         results = []
         for i in range(n):
             regions = []
             for k in range(offs[i], offs[i + 1]):
                 T = int(sl[k])
-                texts, scores, pos, cols, _ = self.decoder.decode_argmax(ci[co[k]:co[k + 1]], cp[co[k]:co[k + 1]], 1 if T else 0, T)
-                text, score = (texts[0], scores[0]) if texts else ("", 0.0)
-                col = cols[0] if cols else []
-                if not (score >= self.score_threshold):
-                    text, col = "", []
+                text, score, col = dec.texts[k], float(dec.scores[k]), dec.char_cols[k]
                 wb = None
-                if self.return_word_box and col and T > 0:
+                if self.return_word_box and len(col) and T > 0:
                     wh = np.float32(cwh[k, 0]) / np.float32(max(int(cwh[k, 1]), 1))
-                    wb = ctc_word_boxes(pts[k], text, col, T, float(wh), float(mwh[k]))
+                    wb = ctc_word_boxes(pts[k], text, [int(c) for c in col], T, float(wh), float(mwh[k]))
                 regions.append(TextRegion(pts[k].copy(), text, score, pts[k].copy(), pts[k].copy(), wb, float(dsc[k]), (int(cwh[k, 0]), int(cwh[k, 1])),
-                                          float(lang[k]) if lang[k] >= 0 else None))
+                                          float(lang[k]) if lang[k] >= 0 else None, float(mwh[k]), T))
             results.append(OAROCRResult(f"image_{i}", i, regions, **page_kw[i]))
         return results
 
@@ -705,6 +842,37 @@ class OAROCR:
             self.close()
         except Exception:
             pass
+
+
+@dataclass
+class PackedPages:
+    """Flat result of OAROCR.predict_packed: page i owns regions [region_offsets[i], region_offsets[i+1]) in reading order;
+    region k has box points[k] (4 x 2 f32, original-image coordinates), score[k] and text utf8[text_offsets[k]:text_offsets[k+1]]."""
+    region_offsets: np.ndarray
+    points: np.ndarray
+    scores: np.ndarray
+    utf8: bytes
+    text_offsets: np.ndarray
+
+    def text(self, k: int) -> str:
+        return self.utf8[self.text_offsets[k]:self.text_offsets[k + 1]].decode("utf-8", errors="replace")
+
+    def to_bytes(self) -> bytes:
+        """one contiguous blob (what a rank ships to rank 0): header of 3 counts, then the arrays"""
+        n, nr = len(self.region_offsets) - 1, len(self.scores)
+        head = np.array([n, nr, len(self.utf8)], np.int64)
+        return b"".join([head.tobytes(), self.region_offsets.astype(np.uint32).tobytes(), self.points.astype(np.float32).tobytes(),
+                         self.scores.astype(np.float32).tobytes(), self.text_offsets.astype(np.uint64).tobytes(), self.utf8])
+
+    @classmethod
+    def from_bytes(cls, blob: bytes) -> "PackedPages":
+        n, nr, nb = (int(v) for v in np.frombuffer(blob, np.int64, 3))
+        o = 24
+        ro = np.frombuffer(blob, np.uint32, n + 1, o); o += 4 * (n + 1)
+        pts = np.frombuffer(blob, np.float32, nr * 8, o).reshape(nr, 4, 2); o += 32 * nr
+        sc = np.frombuffer(blob, np.float32, nr, o); o += 4 * nr
+        to = np.frombuffer(blob, np.uint64, nr + 1, o); o += 8 * (nr + 1)
+        return cls(ro, pts, sc, bytes(blob[o:o + nb]), to)
 
 
 def ctc_word_boxes(line_bbox: np.ndarray, text: str, col_indices, seq_len: int, wh_ratio: float, max_wh_ratio: float):
@@ -816,6 +984,24 @@ def k_threshold(pred, thresh):
     pred = np.ascontiguousarray(pred, np.float32)
     out = np.empty(pred.shape, np.uint8)
     _check(lib().oar_k_threshold(_p(pred), pred.size, thresh, _p(out)))
+    return out
+
+
+def k_dilate(mask):
+    mask = np.ascontiguousarray(mask, np.uint8)
+    out = np.empty_like(mask)
+    _check(lib().oar_k_dilate(_p(mask), mask.shape[0], mask.shape[1], _p(out)))
+    return out
+
+
+def k_poly_scores(pred, polys):
+    """polys: list of [n_i, 2] point arrays"""
+    pred = np.ascontiguousarray(pred, np.float32)
+    h, w = pred.shape
+    pts = np.ascontiguousarray(np.concatenate([np.asarray(p, np.float32).reshape(-1, 2) for p in polys]) if polys else np.zeros((0, 2), np.float32))
+    counts = (C.c_uint32 * max(len(polys), 1))(*[len(p) for p in polys])
+    out = np.zeros(len(polys), np.float32)
+    _check(lib().oar_k_poly_scores(_p(pred), h, w, _p(pts), counts, len(polys), _p(out)))
     return out
 
 

@@ -7,6 +7,7 @@
 
 namespace oar {
 const std::string& last_error();
+extern std::atomic<int> g_inject_batched_det_failures;   // pipeline.cc
 }
 using namespace oar;
 
@@ -236,6 +237,19 @@ oar_status oar_db_postprocess(const float* pred, uint32_t height, uint32_t width
         OAR_CHECK(pred && out && height && width, OAR_INVALID_INPUT, "oar_db_postprocess: bad arguments");
         std::vector<DetBoxes> boxes(1);
         Detector::postprocess_host(pred, (int)height, (int)width, src_w, src_h, thresh, box_thresh, unclip_ratio, max_candidates, boxes[0]);
+        fill_det_result(boxes, out);
+    });
+}
+
+oar_status oar_db_postprocess_ex(const float* pred, uint32_t height, uint32_t width, uint32_t src_w, uint32_t src_h, float thresh,
+                                 float box_thresh, float unclip_ratio, uint32_t max_candidates, int32_t box_type, int32_t score_mode,
+                                 int32_t use_dilation, oar_det_result* out) {
+    return guard([&] {
+        OAR_CHECK(pred && out && height && width, OAR_INVALID_INPUT, "oar_db_postprocess_ex: bad arguments");
+        OAR_CHECK(box_type == 0, OAR_UNSUPPORTED_OP, "BoxType::Poly (seal text detection) is not implemented yet");
+        OAR_CHECK(score_mode == 0 || score_mode == 1, OAR_INVALID_INPUT, "score_mode must be 0 (fast) or 1 (slow)");
+        std::vector<DetBoxes> boxes(1);
+        Detector::postprocess_host(pred, (int)height, (int)width, src_w, src_h, thresh, box_thresh, unclip_ratio, max_candidates, boxes[0], score_mode, use_dilation);
         fill_det_result(boxes, out);
     });
 }
@@ -587,6 +601,39 @@ oar_status oar_k_threshold(const float* pred, size_t n, float thresh, uint8_t* m
     });
 }
 
+oar_status oar_k_dilate(const uint8_t* mask, uint32_t height, uint32_t width, uint8_t* out) {
+    return guard([&] {
+        OAR_CHECK(mask && out && height && width, OAR_INVALID_INPUT, "oar_k_dilate: bad arguments");
+        require_device();
+        const size_t n = (size_t)height * width;
+        DevBuf din, dout;
+        din.reserve(n); dout.reserve(n);
+        OAR_HIP(hipMemcpy(din.p, mask, n, hipMemcpyHostToDevice));
+        pp::dilate3x3(nullptr, din.as<uint8_t>(), dout.as<uint8_t>(), 1, (int)height, (int)width);
+        OAR_HIP(hipMemcpy(out, dout.p, n, hipMemcpyDeviceToHost));
+    });
+}
+
+oar_status oar_k_poly_scores(const float* pred, uint32_t height, uint32_t width, const float* pts_xy, const uint32_t* counts, uint32_t n_polys,
+                             float* scores) {
+    return guard([&] {
+        OAR_CHECK(pred && height && width && (n_polys == 0 || (pts_xy && counts && scores)), OAR_INVALID_INPUT, "oar_k_poly_scores: bad arguments");
+        require_device();
+        if (n_polys == 0) return;
+        std::vector<pp::PolyDesc> pd(n_polys);
+        size_t at = 0;
+        for (uint32_t i = 0; i < n_polys; ++i) { pd[i] = pp::PolyDesc{(int32_t)at, (int32_t)counts[i], 0, 0}; at += counts[i]; }
+        const size_t hw = (size_t)height * width;
+        DevBuf dpred, dpts, dpd, dsc;
+        dpred.reserve(hw * 4); dpts.reserve(at * 8 + 8); dpd.reserve(pd.size() * sizeof(pp::PolyDesc)); dsc.reserve((size_t)n_polys * 4);
+        OAR_HIP(hipMemcpy(dpred.p, pred, hw * 4, hipMemcpyHostToDevice));
+        if (at) OAR_HIP(hipMemcpy(dpts.p, pts_xy, at * 8, hipMemcpyHostToDevice));
+        OAR_HIP(hipMemcpy(dpd.p, pd.data(), pd.size() * sizeof(pp::PolyDesc), hipMemcpyHostToDevice));
+        pp::poly_scores(nullptr, dpred.as<float>(), (int)height, (int)width, dpts.as<float>(), dpd.as<pp::PolyDesc>(), (int)n_polys, dsc.as<float>());
+        OAR_HIP(hipMemcpy(scores, dsc.p, (size_t)n_polys * 4, hipMemcpyDeviceToHost));
+    });
+}
+
 oar_status oar_k_ctc_argmax(const float* probs, size_t rows, size_t vocab, int64_t* idx, float* prob) {
     return guard([&] {
         require_device();
@@ -787,6 +834,15 @@ void oar_host_plan_crop(uint32_t img_w, uint32_t img_h, const float box8[8], int
         plan[5] = pl.mode ? pl.out_w() : 0; plan[6] = pl.mode ? pl.out_h() : 0; plan[7] = pl.rot;
         std::memcpy(inv, pl.inv, sizeof pl.inv);
     } catch (...) { plan[0] = 0; }
+}
+
+// ---------------------------------------------------------------------------------------------- test hooks
+oar_status oar_debug_inject_failure(const char* site, int32_t count) {
+    return guard([&] {
+        OAR_CHECK(site, OAR_INVALID_INPUT, "oar_debug_inject_failure: site is null");
+        if (std::string(site) == "batched_detection") g_inject_batched_det_failures.store(count);
+        else fail(OAR_INVALID_INPUT, std::string("oar_debug_inject_failure: unknown site '") + site + "'");
+    });
 }
 
 // ---------------------------------------------------------------------------------------------- profiling

@@ -63,7 +63,8 @@ static bool is_fusable_act(const std::string& op) {
 }
 static bool is_unary_act(const std::string& op) {
     return op == "Relu" || op == "HardSwish" || op == "HardSigmoid" || op == "Sigmoid" || op == "LeakyRelu" || op == "Tanh" || op == "Erf" ||
-           op == "Sqrt" || op == "Exp" || op == "Abs" || op == "Neg" || op == "Reciprocal" || op == "Log" || op == "Gelu" || op == "Softplus";
+           op == "Sqrt" || op == "Exp" || op == "Abs" || op == "Neg" || op == "Reciprocal" || op == "Log" || op == "Gelu" || op == "Softplus" ||
+           op == "Floor" || op == "Ceil" || op == "Round" || op == "Not";
 }
 static Act act_of(const GNode& n) {
     Act a;
@@ -82,6 +83,10 @@ static Act act_of(const GNode& n) {
     else if (n.op == "Log") a.kind = k::ACT_LOG;
     else if (n.op == "Gelu") a.kind = n.as("approximate", "none") == "tanh" ? k::ACT_GELU_TANH : k::ACT_GELU_ERF;
     else if (n.op == "Softplus") a.kind = k::ACT_SOFTPLUS;
+    else if (n.op == "Floor") a.kind = k::ACT_FLOOR;
+    else if (n.op == "Ceil") a.kind = k::ACT_CEIL;
+    else if (n.op == "Round") a.kind = k::ACT_ROUND;
+    else if (n.op == "Not") a.kind = k::ACT_NOT;
     return a;
 }
 
@@ -424,8 +429,10 @@ struct TInfo {
     std::vector<int64_t> dims;  // logical
     Layout layout = Layout::NATIVE;
     Loc loc;
-    bool host_int = false;
-    std::vector<int64_t> hv;
+    bool host_int = false;           // value known at plan time (shape arithmetic): lives on the host, never in HBM
+    std::vector<int64_t> hv;         //   as integers (floats truncated toward zero)
+    bool host_f = false;             //   the host value is floating point: hd is authoritative
+    std::vector<double> hd;
     const HostTensor* ht = nullptr;  // f32 initializer
     std::string root;                // storage root (for liveness)
     size_t bytes() const { return (size_t)std::max<int64_t>(numel(dims), 1) * 4; }
@@ -878,7 +885,9 @@ struct Planner {
 
     void op_binary(const GNode& n, int op) {
         TInfo a = get(n.in[0]), b = get(n.in[1]);
-        OAR_CHECK(!a.host_int && !b.host_int, OAR_UNSUPPORTED_OP, "binary op on integer tensors reached the device path");
+        // a plan-time value meeting a device tensor (e.g. a scale computed from Shape): materialise it as an f32 constant
+        if (a.host_int) { a.loc = host_to_device(n.in[0], a); a.host_int = false; a.layout = Layout::NATIVE; }
+        if (b.host_int) { b.loc = host_to_device(n.in[1], b); b.host_int = false; b.layout = Layout::NATIVE; }
         int r = (int)std::max(a.dims.size(), b.dims.size());
         auto align = [&](const std::vector<int64_t>& d) { std::vector<int64_t> o(r - d.size(), 1); o.insert(o.end(), d.begin(), d.end()); return o; };
         std::vector<int64_t> ad = align(a.dims), bd = align(b.dims), od(r);
@@ -915,7 +924,7 @@ struct Planner {
         };
         std::vector<int64_t> sa = bstr(pad), sb = bstr(pbd);
         // commutative ops: put the full-size operand first (fast paths key on `a`)
-        bool commut = op == 0 || op == 2;
+        bool commut = op == 0 || op == 2 || op == 6 || op == 7 || op == 8 || op == 11 || op == 12;
         if (commut && numel(pad) < numel(pbd)) { std::swap(al, bl); std::swap(sa, sb); }
         TInfo& y = new_out(n.out[0], od, clast ? Layout::CLAST : Layout::NATIVE);
         Loc yl = y.loc;
@@ -924,27 +933,284 @@ struct Planner {
         step([=](const RunCtx& c) { k::binary(c.s, c.at(al), c.at(bl), c.mut(yl), op, r, pod.data(), sa.data(), sb.data(), post); }, (double)cnt, 12.0 * cnt);
     }
 
-    // ReduceMean: the last axis (decomposed LayerNorm exports) or all spatial axes of an NCHW tensor (= GlobalAveragePool)
-    void op_reduce_mean(const GNode& n) {
+    // ReduceMean / ReduceSum / ReduceMax / ReduceMin / ReduceProd over the trailing axes (decomposed LayerNorm / softmax
+    // exports), or ReduceMean over the spatial axes of an NCHW tensor (= GlobalAveragePool).  mode: k::reduce_lastdim's.
+    void op_reduce(const GNode& n, int mode) {
         TInfo x = get(n.in[0]);
         const int r = (int)x.dims.size();
         std::vector<int64_t> axes = has_input(n, 1) ? get(n.in[1]).hv : n.ais("axes");
+        if (axes.empty() && n.ai("noop_with_empty_axes", 0) == 0) for (int i = 0; i < r; ++i) axes.push_back(i);
         for (auto& a : axes) if (a < 0) a += r;
         std::sort(axes.begin(), axes.end());
         const bool keep = n.ai("keepdims", 1) != 0;
-        bool spatial = r == 4 && axes.size() == 2 && axes[0] == 2 && axes[1] == 3;
+        bool spatial = mode == 0 && r == 4 && axes.size() == 2 && axes[0] == 2 && axes[1] == 3;
         if (spatial) {
             OAR_CHECK(keep, OAR_UNSUPPORTED_OP, "ReduceMean over H, W with keepdims = 0");
             return op_gap(n);
         }
-        OAR_CHECK(axes.size() == 1 && axes[0] == r - 1, OAR_UNSUPPORTED_OP, "ReduceMean: only the last axis or the spatial axes of an NCHW tensor");
+        bool trailing = !axes.empty();
+        for (size_t i = 0; i < axes.size(); ++i) trailing = trailing && axes[i] == r - (int64_t)axes.size() + (int64_t)i;
+        OAR_CHECK(trailing, OAR_UNSUPPORTED_OP, n.op + ": only the trailing axes (or H, W of an NCHW tensor for ReduceMean) are supported");
         Loc xin = to_native_loc(x);
-        const int64_t C = x.dims.back(), rows = numel(x.dims) / std::max<int64_t>(C, 1);
-        std::vector<int64_t> od(x.dims.begin(), x.dims.end() - 1);
-        if (keep) od.push_back(1);
+        int64_t C = 1;
+        for (auto a : axes) C *= x.dims[a];
+        const int64_t rows = numel(x.dims) / std::max<int64_t>(C, 1);
+        std::vector<int64_t> od(x.dims.begin(), x.dims.end() - (int64_t)axes.size());
+        if (keep) for (size_t i = 0; i < axes.size(); ++i) od.push_back(1);
         TInfo& y = new_out(n.out[0], od, Layout::NATIVE);
         Loc yl = y.loc;
-        step([=](const RunCtx& c) { k::reduce_mean_lastdim(c.s, c.at(xin), c.mut(yl), rows, (int)C); }, (double)rows * C, 4.0 * rows * (C + 1));
+        step([=](const RunCtx& c) { k::reduce_lastdim(c.s, c.at(xin), c.mut(yl), rows, (int)C, mode); }, (double)rows * C, 4.0 * rows * (C + 1));
+    }
+
+    // ------------------------------------------------------------------ broadcast copies (Expand / Tile)
+    // y (contiguous, dims od) = x read through `in_strides` (0 = broadcast); dims of size 1 are dropped and neighbours that
+    // are contiguous in x are merged so that real-world ranks fit the 6-d permute kernel
+    void strided_copy(const std::string& out, Loc xin, std::vector<int64_t> od_full, std::vector<int64_t> vd, std::vector<int64_t> vs) {
+        std::vector<int64_t> d, st;
+        for (size_t i = 0; i < vd.size(); ++i) {
+            if (vd[i] == 1) continue;
+            if (!d.empty() && st.back() == vs[i] * vd[i] && vs[i] != 0) { d.back() *= vd[i]; st.back() = vs[i]; }
+            else if (!d.empty() && st.back() == 0 && vs[i] == 0) d.back() *= vd[i];
+            else { d.push_back(vd[i]); st.push_back(vs[i]); }
+        }
+        if (d.empty()) { d.push_back(1); st.push_back(0); }
+        OAR_CHECK(d.size() <= 6, OAR_UNSUPPORTED_OP, "Expand / Tile: more than 6 effective dimensions at " + out);
+        TInfo& y = new_out(out, od_full, Layout::NATIVE);
+        Loc yl = y.loc;
+        const int r = (int)d.size();
+        step([=](const RunCtx& c) { k::permute(c.s, c.at(xin), c.mut(yl), r, d.data(), st.data()); }, 0, 8.0 * numel(od_full));
+    }
+    void op_expand(const GNode& n) {
+        TInfo x = get(n.in[0]);
+        const TInfo& sh = get(n.in[1]);
+        OAR_CHECK(sh.host_int, OAR_UNSUPPORTED_OP, "Expand: shape must be known on the host");
+        const int r = (int)std::max(x.dims.size(), sh.hv.size());
+        std::vector<int64_t> xd(r - x.dims.size(), 1), td(r - sh.hv.size(), 1), od(r);
+        xd.insert(xd.end(), x.dims.begin(), x.dims.end());
+        td.insert(td.end(), sh.hv.begin(), sh.hv.end());
+        for (int i = 0; i < r; ++i) {
+            OAR_CHECK(xd[i] == td[i] || xd[i] == 1 || td[i] == 1, OAR_SHAPE_MISMATCH, "Expand: shapes do not broadcast at " + n.out[0]);
+            od[i] = std::max(xd[i], td[i]);
+        }
+        Loc xin = to_native_loc(x);
+        std::vector<int64_t> st = contig_strides(xd);
+        for (int i = 0; i < r; ++i) if (xd[i] == 1) st[i] = 0;
+        strided_copy(n.out[0], xin, od, od, st);
+    }
+    void op_tile(const GNode& n) {
+        TInfo x = get(n.in[0]);
+        const TInfo& rp = get(n.in[1]);
+        OAR_CHECK(rp.host_int && rp.hv.size() == x.dims.size(), OAR_UNSUPPORTED_OP, "Tile: repeats must be host ints, one per axis");
+        Loc xin = to_native_loc(x);
+        std::vector<int64_t> xs = contig_strides(x.dims), od, vd, vs;
+        for (size_t i = 0; i < x.dims.size(); ++i) {
+            OAR_CHECK(rp.hv[i] >= 1, OAR_INVALID_INPUT, "Tile: repeats must be >= 1");
+            od.push_back(x.dims[i] * rp.hv[i]);
+            vd.push_back(rp.hv[i]); vs.push_back(0);          // [repeat][extent] with stride [0][s]
+            vd.push_back(x.dims[i]); vs.push_back(xs[i]);
+        }
+        strided_copy(n.out[0], xin, od, vd, vs);
+    }
+    void op_constant_of_shape(const GNode& n) {
+        const TInfo& sh = get(n.in[0]);
+        OAR_CHECK(sh.host_int, OAR_UNSUPPORTED_OP, "ConstantOfShape: shape must be known on the host");
+        double v = 0.0; bool is_f = true;
+        auto it = n.attrs.find("value");
+        if (it != n.attrs.end() && it->second.kind == Attr::T) {
+            const HostTensor& t = it->second.t;
+            if (t.dtype == DType::F32) v = t.f.empty() ? 0.0 : t.f[0];
+            else { v = t.i.empty() ? 0.0 : (double)t.i[0]; is_f = false; }
+        }
+        const int64_t cnt = numel(sh.hv);
+        OAR_CHECK(cnt >= 0 && cnt <= (int64_t)1 << 28, OAR_SHAPE_MISMATCH, "ConstantOfShape: unreasonable element count");
+        if (!is_f || cnt <= 64) {   // shape plumbing stays on the host
+            TInfo o; o.host_int = true; o.dims = sh.hv; o.host_f = is_f;
+            o.hv.assign((size_t)cnt, (int64_t)v); o.hd.assign((size_t)cnt, v);
+            vals[n.out[0]] = o; return;
+        }
+        TInfo t;
+        t.dims = sh.hv; t.layout = Layout::NATIVE; t.loc.kind = Loc::CONST;
+        t.loc.cptr = E.upload_const("cos:" + std::to_string(v) + ":" + std::to_string(cnt), std::vector<float>((size_t)cnt, (float)v));
+        vals[n.out[0]] = t;
+    }
+    // device value of a host-known tensor (a bool / int mask or scalar that a device op consumes)
+    Loc host_to_device(const std::string& name, const TInfo& t) {
+        std::vector<float> f(t.hv.size());
+        for (size_t i = 0; i < f.size(); ++i) f[i] = t.host_f && i < t.hd.size() ? (float)t.hd[i] : (float)t.hv[i];
+        std::string key = "hostval:" + name + ":";
+        for (float v : f) key += std::to_string(v) + ",";
+        Loc l; l.kind = Loc::CONST; l.cptr = E.upload_const(key, f);
+        return l;
+    }
+    void op_where(const GNode& n) {
+        TInfo c = get(n.in[0]), a = get(n.in[1]), b = get(n.in[2]);
+        auto dev = [&](const std::string& nm, TInfo& t) -> Loc { return t.host_int ? host_to_device(nm, t) : to_native_loc(t); };
+        Loc cl, al = dev(n.in[1], a), bl = dev(n.in[2], b);
+        if (c.host_int) cl = host_to_device(n.in[0], c);
+        else if (c.ht == nullptr && c.loc.kind != Loc::NONE) cl = to_native_loc(c);
+        else cl = c.loc;   // a bool initializer arrives as host ints (handled above); f32 0/1 masks as constants
+        const int r = (int)std::max({c.dims.size(), a.dims.size(), b.dims.size()});
+        OAR_CHECK(r <= 6, OAR_UNSUPPORTED_OP, "Where: rank > 6");
+        auto align = [&](const std::vector<int64_t>& d) { std::vector<int64_t> o(r - d.size(), 1); o.insert(o.end(), d.begin(), d.end()); return o; };
+        std::vector<int64_t> cd = align(c.dims), ad = align(a.dims), bd = align(b.dims), od(r);
+        for (int i = 0; i < r; ++i) {
+            od[i] = std::max({cd[i], ad[i], bd[i]});
+            OAR_CHECK((cd[i] == od[i] || cd[i] == 1) && (ad[i] == od[i] || ad[i] == 1) && (bd[i] == od[i] || bd[i] == 1), OAR_SHAPE_MISMATCH, "Where: shapes do not broadcast at " + n.out[0]);
+        }
+        auto bstr = [&](const std::vector<int64_t>& d) { std::vector<int64_t> st = contig_strides(d); for (size_t i = 0; i < d.size(); ++i) if (d[i] == 1) st[i] = 0; return st; };
+        std::vector<int64_t> sc = bstr(cd), sa = bstr(ad), sb = bstr(bd);
+        TInfo& y = new_out(n.out[0], od, Layout::NATIVE);
+        Loc yl = y.loc;
+        step([=](const RunCtx& cx) { k::where(cx.s, cx.at(cl), cx.at(al), cx.at(bl), cx.mut(yl), r, od.data(), sc.data(), sa.data(), sb.data()); }, 0, 16.0 * numel(od));
+    }
+
+    // ------------------------------------------------------------------ host evaluation (shape arithmetic)
+    // Paddle2ONNX / torch exports compute Reshape / Resize / Slice arguments with little integer (and sometimes float)
+    // graphs hanging off Shape nodes.  Every value reachable from Shape + constants only is evaluated here, at plan time,
+    // with numpy broadcasting; nothing of it is ever launched.
+    static std::vector<double> host_values(const TInfo& t) {
+        std::vector<double> v;
+        if (t.host_int) {
+            if (t.host_f && t.hd.size() == t.hv.size()) return t.hd;
+            v.assign(t.hv.begin(), t.hv.end());
+        } else if (t.ht) {
+            v.assign(t.ht->f.begin(), t.ht->f.end());
+        }
+        return v;
+    }
+    bool host_evaluable(const TInfo& t) const { return t.host_int || (t.ht && t.ht->f.size() <= 64); }
+    void set_host(const std::string& name, const std::vector<int64_t>& dims, const std::vector<double>& v, bool is_float) {
+        TInfo o;
+        o.host_int = true; o.host_f = is_float; o.dims = dims; o.hd = v;
+        o.hv.resize(v.size());
+        for (size_t i = 0; i < v.size(); ++i) o.hv[i] = (int64_t)v[i];   // truncation toward zero, like Cast
+        vals[name] = o;
+    }
+    static bool float_like(const TInfo& t) { return t.host_int ? t.host_f : t.ht != nullptr; }
+    // returns true when the node was evaluated on the host
+    bool op_host(const GNode& n) {
+        const std::string& op = n.op;
+        std::vector<TInfo> in;
+        for (auto& sname : n.in) in.push_back(sname.empty() ? TInfo() : get(sname));
+        auto bin = [&](int code) {
+            const TInfo &a = in[0], &b = in[1];
+            std::vector<double> av = host_values(a), bv = host_values(b);
+            const int r = (int)std::max(a.dims.size(), b.dims.size());
+            std::vector<int64_t> ad(r - a.dims.size(), 1), bd(r - b.dims.size(), 1), od(r);
+            ad.insert(ad.end(), a.dims.begin(), a.dims.end());
+            bd.insert(bd.end(), b.dims.begin(), b.dims.end());
+            for (int i = 0; i < r; ++i) {
+                OAR_CHECK(ad[i] == bd[i] || ad[i] == 1 || bd[i] == 1, OAR_SHAPE_MISMATCH, "host " + op + ": shapes do not broadcast at " + n.out[0]);
+                od[i] = std::max(ad[i], bd[i]);
+            }
+            std::vector<int64_t> sa = contig_strides(ad), sb = contig_strides(bd);
+            const bool fl = (float_like(a) || float_like(b)) && code <= 6;
+            std::vector<double> out((size_t)numel(od));
+            for (int64_t i = 0; i < (int64_t)out.size(); ++i) {
+                int64_t rem = i, oa = 0, ob = 0;
+                for (int d = r - 1; d >= 0; --d) { const int64_t q = rem / od[d], ix = rem - q * od[d]; rem = q; oa += (ad[d] == 1 ? 0 : ix) * sa[d]; ob += (bd[d] == 1 ? 0 : ix) * sb[d]; }
+                const double x = av[(size_t)oa], y = bv[(size_t)ob];
+                double v = 0;
+                switch (code) {
+                    case 0: v = x + y; break;
+                    case 1: v = x - y; break;
+                    case 2: v = x * y; break;
+                    case 3: v = fl ? x / y : (y != 0 ? (double)((int64_t)x / (int64_t)y) : 0.0); break;   // integer Div truncates
+                    case 4: v = std::pow(x, y); break;
+                    case 5: v = std::max(x, y); break;
+                    case 6: v = std::min(x, y); break;
+                    case 7: v = x == y; break;
+                    case 8: v = x < y; break;
+                    case 9: v = x > y; break;
+                    case 10: v = (x != 0) && (y != 0); break;
+                    default: v = (x != 0) || (y != 0); break;
+                }
+                out[(size_t)i] = fl ? (double)(float)v : v;   // f32 tensors stay f32
+            }
+            set_host(n.out[0], od, out, fl);
+            return true;
+        };
+        auto un = [&](double (*f)(double)) {
+            std::vector<double> v = host_values(in[0]);
+            for (auto& e : v) e = f(e);
+            set_host(n.out[0], in[0].dims, v, float_like(in[0]));
+            return true;
+        };
+        if (op == "Add") return bin(0);
+        if (op == "Sub") return bin(1);
+        if (op == "Mul") return bin(2);
+        if (op == "Div") return bin(3);
+        if (op == "Pow") return bin(4);
+        if (op == "Max") return bin(5);
+        if (op == "Min") return bin(6);
+        if (op == "Equal") return bin(7);
+        if (op == "Less") return bin(8);
+        if (op == "Greater") return bin(9);
+        if (op == "And") return bin(10);
+        if (op == "Or") return bin(11);
+        if (op == "Neg") return un([](double v) { return -v; });
+        if (op == "Abs") return un([](double v) { return std::fabs(v); });
+        if (op == "Floor") return un([](double v) { return std::floor(v); });
+        if (op == "Ceil") return un([](double v) { return std::ceil(v); });
+        if (op == "Round") return un([](double v) { return std::nearbyint(v); });
+        if (op == "Sqrt") return un([](double v) { return (double)std::sqrt((float)v); });
+        if (op == "Not") return un([](double v) { return v != 0 ? 0.0 : 1.0; });
+        if (op == "Identity") { set_host(n.out[0], in[0].dims, host_values(in[0]), float_like(in[0])); return true; }
+        if (op == "Cast") {
+            const int64_t to = n.ai("to", 1);
+            std::vector<double> v = host_values(in[0]);
+            const bool to_f = to == 1 || to == 10 || to == 11 || to == 16;
+            if (!to_f) for (auto& e : v) e = to == 9 ? (double)(e != 0) : (double)(int64_t)e;
+            else if (to == 1) for (auto& e : v) e = (double)(float)e;
+            set_host(n.out[0], in[0].dims, v, to_f);
+            return true;
+        }
+        if (op == "Where") {
+            std::vector<double> c = host_values(in[0]), a = host_values(in[1]), b = host_values(in[2]);
+            const size_t cnt = std::max({c.size(), a.size(), b.size()});
+            if (!((c.size() == cnt || c.size() == 1) && (a.size() == cnt || a.size() == 1) && (b.size() == cnt || b.size() == 1))) return false;   // device path broadcasts
+            std::vector<double> out(cnt);
+            for (size_t i = 0; i < cnt; ++i) out[i] = c[c.size() == 1 ? 0 : i] != 0 ? a[a.size() == 1 ? 0 : i] : b[b.size() == 1 ? 0 : i];
+            const TInfo& big = c.size() == cnt ? in[0] : a.size() == cnt ? in[1] : in[2];
+            set_host(n.out[0], big.dims, out, float_like(in[1]) || float_like(in[2]));
+            return true;
+        }
+        if (op == "Expand") {
+            if (!in[1].host_int) return false;
+            std::vector<double> v = host_values(in[0]);
+            const int64_t cnt = numel(in[1].hv);
+            if (!(v.size() == 1 || ((int64_t)v.size() == cnt && in[0].dims.size() <= 1)) || cnt > 4096) return false;   // real data: device path
+            std::vector<double> out((size_t)cnt);
+            for (int64_t i = 0; i < cnt; ++i) out[(size_t)i] = v[v.size() == 1 ? 0 : (size_t)i];
+            set_host(n.out[0], in[1].hv, out, float_like(in[0]));
+            return true;
+        }
+        if (op == "Tile") {
+            if (!(in[0].dims.size() <= 1 && in[1].hv.size() == 1 && in[1].host_int)) return false;   // real data: device path
+            std::vector<double> v = host_values(in[0]), out;
+            for (int64_t k = 0; k < in[1].hv[0]; ++k) out.insert(out.end(), v.begin(), v.end());
+            set_host(n.out[0], {(int64_t)out.size()}, out, float_like(in[0]));
+            return true;
+        }
+        if (op == "Range") {
+            const double a = host_values(in[0])[0], lim = host_values(in[1])[0], d = host_values(in[2])[0];
+            OAR_CHECK(d != 0, OAR_INVALID_INPUT, "Range: delta 0");
+            std::vector<double> out;
+            const int64_t cnt = std::max<int64_t>((int64_t)std::ceil((lim - a) / d), 0);
+            OAR_CHECK(cnt <= 1 << 20, OAR_SHAPE_MISMATCH, "Range: too long");
+            for (int64_t i = 0; i < cnt; ++i) out.push_back(a + (double)i * d);
+            set_host(n.out[0], {cnt}, out, float_like(in[0]));
+            return true;
+        }
+        if (op == "ReduceProd" || op == "ReduceSum" || op == "ReduceMax" || op == "ReduceMin") {
+            std::vector<double> v = host_values(in[0]);
+            if (in[0].dims.size() > 1) return false;
+            double acc = op == "ReduceProd" ? 1.0 : op == "ReduceSum" ? 0.0 : op == "ReduceMax" ? -INFINITY : INFINITY;
+            for (double e : v) acc = op == "ReduceProd" ? acc * e : op == "ReduceSum" ? acc + e : op == "ReduceMax" ? std::max(acc, e) : std::min(acc, e);
+            set_host(n.out[0], n.ai("keepdims", 1) ? std::vector<int64_t>{1} : std::vector<int64_t>{}, {acc}, float_like(in[0]));
+            return true;
+        }
+        return false;
     }
 
     // GridSample (UVDoc's final un-warp): X [N,C,H,W], grid [N,Ho,Wo,2] -> [N,C,Ho,Wo]
@@ -1075,8 +1341,9 @@ struct Planner {
         } else {
             OAR_CHECK(has_input(n, 2), OAR_UNSUPPORTED_OP, "Resize: neither scales nor sizes");
             const TInfo& sc = get(n.in[2]);
-            OAR_CHECK(sc.ht && sc.ht->f.size() == 4, OAR_UNSUPPORTED_OP, "Resize: scales must be a constant of 4 floats");
-            sh = sc.ht->f[2]; sw = sc.ht->f[3];
+            std::vector<double> scv = host_values(sc);   // an initializer, or computed from Shape on the host
+            OAR_CHECK(host_evaluable(sc) && scv.size() == 4, OAR_UNSUPPORTED_OP, "Resize: scales must be 4 floats known at plan time");
+            sh = (float)scv[2]; sw = (float)scv[3];
             Ho = (int64_t)std::floor((float)H * sh); Wo = (int64_t)std::floor((float)W * sw);
         }
         std::string mode = n.as("mode", "nearest"), ctm = n.as("coordinate_transformation_mode", "half_pixel"), nm = n.as("nearest_mode", "round_prefer_floor");
@@ -1096,13 +1363,12 @@ struct Planner {
     void op_concat(const GNode& n) {
         std::vector<TInfo> xs;
         for (auto& s : n.in) xs.push_back(get(s));
-        bool all_host = true;
-        for (auto& t : xs) all_host = all_host && t.host_int;
-        if (all_host) {
-            TInfo o; o.host_int = true;
-            for (auto& t : xs) o.hv.insert(o.hv.end(), t.hv.begin(), t.hv.end());
-            o.dims = {(int64_t)o.hv.size()};
-            vals[n.out[0]] = o;
+        bool all_host = true, any_host = false, any_f = false;
+        for (auto& t : xs) { all_host = all_host && host_evaluable(t) && t.dims.size() <= 1; any_host = any_host || t.host_int; any_f = any_f || float_like(t); }
+        if (all_host && any_host) {   // 1-D shape / scale vectors
+            std::vector<double> v;
+            for (auto& t : xs) { std::vector<double> e = host_values(t); v.insert(v.end(), e.begin(), e.end()); }
+            set_host(n.out[0], {(int64_t)v.size()}, v, any_f);
             return;
         }
         int r = (int)xs[0].dims.size();
@@ -1292,8 +1558,9 @@ struct Planner {
             OAR_CHECK(r == 1 && axes.size() == 1 && steps[0] == 1, OAR_UNSUPPORTED_OP, "Slice: host tensors support 1-D unit-step only");
             int64_t d = x.dims[0], s = starts[0] < 0 ? starts[0] + d : starts[0], e = ends[0] < 0 ? ends[0] + d : ends[0];
             s = std::min(std::max<int64_t>(s, 0), d); e = std::min(std::max<int64_t>(e, 0), d);
-            TInfo o; o.host_int = true; o.hv.assign(x.hv.begin() + s, x.hv.begin() + std::max(s, e)); o.dims = {(int64_t)o.hv.size()};
-            vals[n.out[0]] = o; return;
+            std::vector<double> xv = host_values(x);
+            set_host(n.out[0], {std::max<int64_t>(e - s, 0)}, std::vector<double>(xv.begin() + s, xv.begin() + std::max(s, e)), x.host_f);
+            return;
         }
         OAR_CHECK(axes.size() == 1 && steps[0] == 1, OAR_UNSUPPORTED_OP, "Slice: single axis, unit step only");
         int64_t ax = axes[0] < 0 ? axes[0] + r : axes[0], d = x.dims[ax];
@@ -1310,10 +1577,14 @@ struct Planner {
         int64_t axis = n.ai("axis", 0);
         if (x.host_int) {
             OAR_CHECK(x.dims.size() <= 1, OAR_UNSUPPORTED_OP, "Gather: host data rank > 1");
-            TInfo o; o.host_int = true;
-            for (auto i : idx.hv) o.hv.push_back(x.hv[i < 0 ? i + (int64_t)x.hv.size() : i]);
-            o.dims = idx.dims;
-            vals[n.out[0]] = o; return;
+            std::vector<double> xv = host_values(x), ov;
+            for (auto i : idx.hv) {
+                const int64_t j = i < 0 ? i + (int64_t)xv.size() : i;
+                OAR_CHECK(j >= 0 && j < (int64_t)xv.size(), OAR_SHAPE_MISMATCH, "Gather: index out of range at " + n.out[0]);
+                ov.push_back(xv[(size_t)j]);
+            }
+            set_host(n.out[0], idx.dims, ov, x.host_f);
+            return;
         }
         int r = (int)x.dims.size();
         if (axis < 0) axis += r;
@@ -1501,7 +1772,7 @@ struct Planner {
 
     // ------------------------------------------------------------------ driver
     void compute_last_use() {
-        static const std::set<std::string> alias_ops = {"Reshape", "Flatten", "Squeeze", "Unsqueeze", "Transpose", "Identity", "Split", "Slice", "Gather"};
+        static const std::set<std::string> alias_ops = {"Reshape", "Flatten", "Squeeze", "Unsqueeze", "Transpose", "Identity", "Split", "Slice", "Gather", "Cast"};
         std::map<std::string, int> lu;
         for (int i = 0; i < (int)E.nodes_.size(); ++i) {
             const GNode& n = E.nodes_[i];
@@ -1587,13 +1858,12 @@ struct Planner {
             TInfo o; o.host_int = true; o.hv = x.dims; o.dims = {(int64_t)x.dims.size()};
             vals[n.out[0]] = o; return;
         }
-        if (host_inputs) {
-            if (op == "Add") return op_host_arith(n, 0);
-            if (op == "Sub") return op_host_arith(n, 1);
-            if (op == "Mul") return op_host_arith(n, 2);
-            if (op == "Div") return op_host_arith(n, 3);
-            if (op == "Cast" || op == "Identity") { vals[n.out[0]] = get(n.in[0]); return; }
-        }
+        // shape arithmetic: every input is a host value or a small constant, and at least one really is a host value
+        bool evaluable = !n.in.empty(), any_host = false;
+        for (auto& s : n.in) if (!s.empty()) { const TInfo& t = get(s); evaluable = evaluable && host_evaluable(t); any_host = any_host || t.host_int; }
+        if (evaluable && (any_host || op == "Range") && op_host(n)) return;
+        (void)host_inputs;
+        if (op == "ConstantOfShape") return op_constant_of_shape(n);
         if (op == "Conv") return op_conv(n);
         if (op == "ConvTranspose") return op_convt(n);
         if (op == "BatchNormalization") return op_bn(n);
@@ -1610,7 +1880,21 @@ struct Planner {
         if (op == "Div") return op_binary(n, 3);
         if (op == "Pow") return op_binary(n, 4);
         if (op == "PRelu") return op_binary(n, 5);
-        if (op == "ReduceMean") return op_reduce_mean(n);
+        if (op == "Max") return op_binary(n, 6);
+        if (op == "Min") return op_binary(n, 7);
+        if (op == "Equal") return op_binary(n, 8);
+        if (op == "Less") return op_binary(n, 9);
+        if (op == "Greater") return op_binary(n, 10);
+        if (op == "And") return op_binary(n, 11);
+        if (op == "Or") return op_binary(n, 12);
+        if (op == "ReduceMean") return op_reduce(n, 0);
+        if (op == "ReduceSum") return op_reduce(n, 1);
+        if (op == "ReduceMax") return op_reduce(n, 2);
+        if (op == "ReduceMin") return op_reduce(n, 3);
+        if (op == "ReduceProd") return op_reduce(n, 4);
+        if (op == "Expand") return op_expand(n);
+        if (op == "Tile") return op_tile(n);
+        if (op == "Where") return op_where(n);
         if (op == "GridSample") return op_grid_sample(n);
         if (op == "Pad") return op_pad(n);
         if (op == "GlobalAveragePool") return op_gap(n);
@@ -1634,7 +1918,12 @@ struct Planner {
         if (op == "SEGate") return op_se_gate(n);
         if (op == "LayerNormalization") return op_layernorm(n);
         if (op == "Identity") { const TInfo& x = get(n.in[0]); if (x.host_int) { vals[n.out[0]] = x; } else { TInfo xx = x; alias_out(n.out[0], xx, xx.dims, xx.layout); } return; }
-        if (op == "Cast") { const TInfo& x = get(n.in[0]); OAR_CHECK(n.ai("to", 1) == 1, OAR_UNSUPPORTED_OP, "Cast of a device tensor to non-f32"); TInfo xx = x; alias_out(n.out[0], xx, xx.dims, xx.layout); return; }
+        if (op == "Cast") {   // device tensors are f32 whatever they are called: float <-> bool casts of 0/1 masks are aliases
+            const TInfo& x = get(n.in[0]);
+            const int64_t to = n.ai("to", 1);
+            OAR_CHECK(to == 1 || to == 9 || to == 10 || to == 11, OAR_UNSUPPORTED_OP, "Cast of a device tensor to an integer type");
+            TInfo xx = x; alias_out(n.out[0], xx, xx.dims, xx.layout); return;
+        }
         fail(OAR_UNSUPPORTED_OP, "operator '" + op + "' is not implemented (node output " + (n.out.empty() ? "?" : n.out[0]) + ")");
     }
 };
@@ -1687,7 +1976,8 @@ const std::set<std::string>& Engine::supported_ops() {
         "Constant", "Dropout", "Identity", "Cast", "Shape", "Conv", "ConvTranspose", "BatchNormalization", "Relu", "HardSwish", "HardSigmoid", "Sigmoid",
         "LeakyRelu", "Tanh", "Erf", "Sqrt", "Exp", "Abs", "Neg", "Reciprocal", "Log", "Gelu", "Softplus", "Clip", "Add", "Sub", "Mul", "Div", "Pow", "PRelu",
         "ReduceMean", "GridSample", "Pad", "GlobalAveragePool", "AveragePool", "MaxPool", "Resize", "Concat", "Reshape", "Flatten", "Squeeze", "Unsqueeze",
-        "Transpose", "Split", "Slice", "Gather", "Gemm", "MatMul", "Softmax", "LayerNormalization"};
+        "Transpose", "Split", "Slice", "Gather", "Gemm", "MatMul", "Softmax", "LayerNormalization", "Max", "Min", "Equal", "Less", "Greater", "And", "Or", "Not",
+        "Floor", "Ceil", "Round", "ReduceSum", "ReduceMax", "ReduceMin", "ReduceProd", "Expand", "Tile", "Where", "ConstantOfShape", "Range"};
     return ops;
 }
 

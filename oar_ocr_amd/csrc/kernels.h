@@ -9,7 +9,7 @@ namespace k {
 
 enum ActKind : int { ACT_NONE = 0, ACT_RELU, ACT_HSWISH, ACT_HSIGMOID, ACT_SIGMOID, ACT_SWISH, ACT_LEAKY, ACT_CLIP, ACT_TANH, ACT_GELU_ERF,
                      // element-wise math (decomposed GELU / LayerNorm exports, UVDoc)
-                     ACT_ERF, ACT_SQRT, ACT_EXP, ACT_ABS, ACT_NEG, ACT_RECIP, ACT_LOG, ACT_GELU_TANH, ACT_SOFTPLUS };
+                     ACT_ERF, ACT_SQRT, ACT_EXP, ACT_ABS, ACT_NEG, ACT_RECIP, ACT_LOG, ACT_GELU_TANH, ACT_SOFTPLUS, ACT_FLOOR, ACT_CEIL, ACT_ROUND, ACT_NOT };
 struct Act {
     int kind = ACT_NONE;
     float alpha = 0.f, beta = 0.f;  // HardSigmoid(alpha,beta) / LeakyRelu(alpha) / Clip(alpha=min,beta=max)
@@ -65,7 +65,8 @@ void resize(hipStream_t s, const float* x, float* y, int N, int H, int W, int C,
             float scale_w, int mode, int ctm, int nearest_mode, int y_ld);
 
 void unary(hipStream_t s, const float* x, float* y, int64_t n, Act act);
-// y = op(a, b) with numpy broadcasting over up to 6 dims. op: 0 add, 1 sub, 2 mul, 3 div, 4 pow. Strides in elements
+// y = op(a, b) with numpy broadcasting over up to 6 dims. op: 0 add, 1 sub, 2 mul, 3 div, 4 pow, 5 prelu, 6 max, 7 min,
+// 8 equal, 9 less, 10 greater, 11 and, 12 or (comparisons / logic give 1.0f or 0.0f: bool tensors live as f32 on the device). Strides in elements
 // (0 for broadcast dims); output is contiguous with dims `dims`.
 void binary(hipStream_t s, const float* a, const float* b, float* y, int op, int rank, const int64_t* dims,
             const int64_t* sa, const int64_t* sb, Act post);
@@ -94,8 +95,11 @@ void se_fc(hipStream_t s, const float* x, const float* w1, const float* b1, Act 
 // ONNX Pad on a contiguous tensor of rank <= 6: out_dims[d] = in_dims[d] + before[d] + after[d] (negative = crop);
 // mode 0 constant (value), 1 reflect, 2 edge
 void pad_nd(hipStream_t s, const float* x, float* y, int rank, const int64_t* in_dims, const int64_t* out_dims, const int64_t* before, int mode, float value);
-// mean over the last axis: x [rows][C] -> y [rows]
-void reduce_mean_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C);
+// reduction over the last axis: x [rows][C] -> y [rows]; mode 0 mean, 1 sum, 2 max, 3 min, 4 prod
+void reduce_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C, int mode);
+inline void reduce_mean_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C) { reduce_lastdim(s, x, y, rows, C, 0); }
+// y = cond != 0 ? a : b with numpy broadcasting over up to 6 dims (strides in elements, 0 = broadcast)
+void where(hipStream_t s, const float* cond, const float* a, const float* b, float* y, int rank, const int64_t* dims, const int64_t* sc, const int64_t* sa, const int64_t* sb);
 // ONNX GridSample (4-D): x [N][H][W][C] channels-last, grid [N][Ho][Wo][2] (x, y in [-1, 1]) -> y [N][Ho][Wo][C].
 // mode 0 bilinear / 1 nearest; padding 0 zeros / 1 border / 2 reflection
 void grid_sample(hipStream_t s, const float* x, const float* grid, float* y, int N, int H, int W, int C, int Ho, int Wo, int mode, int padding, int align_corners);

@@ -491,6 +491,13 @@ __device__ __forceinline__ float bin_op(float a, float b, int op) {
         case 2: return a * b;
         case 3: return a / b;
         case 5: return a > 0.f ? a : a * b;   // PRelu(x, slope)
+        case 6: return fmaxf(a, b);
+        case 7: return fminf(a, b);
+        case 8: return a == b ? 1.0f : 0.0f;
+        case 9: return a < b ? 1.0f : 0.0f;
+        case 10: return a > b ? 1.0f : 0.0f;
+        case 11: return (a != 0.0f && b != 0.0f) ? 1.0f : 0.0f;
+        case 12: return (a != 0.0f || b != 0.0f) ? 1.0f : 0.0f;
         default: return powf(a, b);
     }
 }
@@ -929,19 +936,58 @@ void se_fc(hipStream_t s, const float* x, const float* w1, const float* b1, Act 
 }
 
 // ------------------------------------------------------------------------------------------ ReduceMean (last axis)
-__global__ __launch_bounds__(256) void reduce_mean_kernel(const float* __restrict__ x, float* __restrict__ y, long rows, int C) {
+__device__ __forceinline__ float wave_reduce_mode(float v, int mode) {
+    if (mode <= 1) return wave_sum(v);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(v, off, 64);
+        v = mode == 2 ? fmaxf(v, o) : mode == 3 ? fminf(v, o) : v * o;
+    }
+    return v;
+}
+__global__ __launch_bounds__(256) void reduce_lastdim_kernel(const float* __restrict__ x, float* __restrict__ y, long rows, int C, int mode) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
-    float s = 0.f;
-    for (int i = lane; i < C; i += 64) s += x[row * C + i];
-    s = wave_sum(s);
-    if (lane == 0) y[row] = s / (float)C;
+    float s = mode <= 1 ? 0.f : mode == 2 ? -INFINITY : mode == 3 ? INFINITY : 1.f;
+    for (int i = lane; i < C; i += 64) {
+        const float v = x[row * C + i];
+        s = mode <= 1 ? s + v : mode == 2 ? fmaxf(s, v) : mode == 3 ? fminf(s, v) : s * v;
+    }
+    s = wave_reduce_mode(s, mode);
+    if (lane == 0) y[row] = mode == 0 ? s / (float)C : s;
 }
-void reduce_mean_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C) {
+void reduce_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C, int mode) {
     if (rows == 0 || C == 0) return;
     ProfScope ps(s, "reduce_mean", 4.0 * (double)rows * (C + 1), (double)rows * C);
-    hipLaunchKernelGGL(reduce_mean_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, y, (long)rows, C);
+    hipLaunchKernelGGL(reduce_lastdim_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, y, (long)rows, C, mode);
+}
+
+// ------------------------------------------------------------------------------------------ Where
+struct WhereP { int rank; long dims[6], sc[6], sa[6], sb[6]; };
+__global__ __launch_bounds__(256) void where_kernel(const float* c, const float* a, const float* b, float* y, long n, WhereP p) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        long r = i, oc = 0, oa = 0, ob = 0;
+#pragma unroll
+        for (int d = 5; d >= 0; --d) {
+            if (d < p.rank) {
+                long q = r / p.dims[d]; long idx = r - q * p.dims[d]; r = q;
+                oc += idx * p.sc[d]; oa += idx * p.sa[d]; ob += idx * p.sb[d];
+            }
+        }
+        y[i] = c[oc] != 0.0f ? a[oa] : b[ob];
+    }
+}
+void where(hipStream_t s, const float* cond, const float* a, const float* b, float* y, int rank, const int64_t* dims, const int64_t* sc, const int64_t* sa, const int64_t* sb) {
+    OAR_CHECK(rank <= 6, OAR_UNSUPPORTED_OP, "Where: rank > 6");
+    long n = 1;
+    for (int i = 0; i < rank; ++i) n *= dims[i];
+    if (n == 0) return;
+    ProfScope ps(s, "where", 16.0 * (double)n, 0.0);
+    WhereP p;
+    p.rank = rank;
+    for (int i = 0; i < 6; ++i) { p.dims[i] = i < rank ? dims[i] : 1; p.sc[i] = i < rank ? sc[i] : 0; p.sa[i] = i < rank ? sa[i] : 0; p.sb[i] = i < rank ? sb[i] : 0; }
+    hipLaunchKernelGGL(where_kernel, dim3(grid_for(n)), dim3(256), 0, s, cond, a, b, y, n, p);
 }
 
 // ------------------------------------------------------------------------------------------ GridSample (UVDoc's un-warp)

@@ -41,6 +41,10 @@ __device__ __forceinline__ float apply_unary(float v, int kind, float alpha, flo
         case ACT_LOG: return logf(v);
         case ACT_GELU_TANH: return 0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v)));
         case ACT_SOFTPLUS: return v > 20.0f ? v : log1pf(expf(v));
+        case ACT_FLOOR: return floorf(v);
+        case ACT_CEIL: return ceilf(v);
+        case ACT_ROUND: return rintf(v);   // ONNX Round: half to even
+        case ACT_NOT: return v != 0.0f ? 0.0f : 1.0f;
         default: return apply_act(v, kind, alpha, beta);
     }
 }

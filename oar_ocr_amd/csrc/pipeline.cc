@@ -161,25 +161,32 @@ Detector::Detector(const uint8_t* onnx, size_t len, const oar_det_cfg& cfg) : cf
     if (cfg_.limit_side_len == 0) cfg_.limit_side_len = 960;
     if (cfg_.max_side_limit == 0) cfg_.max_side_limit = 4000;
     if (cfg_.max_candidates == 0) cfg_.max_candidates = 1000;
+    OAR_CHECK(cfg_.box_type == 0, OAR_UNSUPPORTED_OP, "BoxType::Poly (seal text detection) is not implemented yet: use box_type = 0 (Quad)");
+    OAR_CHECK(cfg_.score_mode == 0 || cfg_.score_mode == 1, OAR_INVALID_INPUT, "score_mode must be 0 (fast) or 1 (slow)");
     eng_.reset(new Engine(onnx, len, cfg_.device_id));
     pool_.reset(new ThreadPool(cfg_.host_threads));
     OAR_HIP(hipSetDevice(eng_->device()));
     OAR_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
     OAR_HIP(hipStreamCreateWithFlags(&score_stream_, hipStreamNonBlocking));
+    OAR_HIP(hipStreamCreateWithFlags(&upload_stream_, hipStreamNonBlocking));
+    OAR_HIP(hipEventCreateWithFlags(&stage_free_, hipEventDisableTiming));
 }
 Detector::~Detector() {
     if (copy_stream_) { (void)hipStreamSynchronize(copy_stream_); (void)hipStreamDestroy(copy_stream_); }
     if (score_stream_) { (void)hipStreamSynchronize(score_stream_); (void)hipStreamDestroy(score_stream_); }
+    if (upload_stream_) { (void)hipStreamSynchronize(upload_stream_); (void)hipStreamDestroy(upload_stream_); }
+    if (stage_free_) (void)hipEventDestroy(stage_free_);
+    for (hipEvent_t e : upload_done_) (void)hipEventDestroy(e);
     for (hipEvent_t e : sub_events_) (void)hipEventDestroy(e);
     for (hipEvent_t e : mask_ready_) (void)hipEventDestroy(e);
     for (hipEvent_t e : score_done_) (void)hipEventDestroy(e);
 }
 
 namespace {
-struct Candidate { float pts[8]; };
+struct Candidate { float pts[8]; std::vector<host::Pt> contour; /* ScoreMode::Slow only */ };
 
 // a9: one contour -> mini box candidate (false when rejected)
-bool contour_candidate(const host::Contour& c, Candidate& cd) {
+bool contour_candidate(const host::Contour& c, Candidate& cd, bool keep_contour = false) {
     std::vector<host::Pt> simp = host::simplify_chain(c.pts);
     host::Pt mb[4];
     float min_side = 0.f;
@@ -187,22 +194,23 @@ bool contour_candidate(const host::Contour& c, Candidate& cd) {
     if (!ok) return false;
     if (min_side < 3.0f) return false;  // DBPostProcess::min_size (db_postprocess.rs:83)
     for (int i = 0; i < 4; ++i) { cd.pts[i * 2] = mb[i].x; cd.pts[i * 2 + 1] = mb[i].y; }
+    if (keep_contour) cd.contour = c.pts;
     return true;
 }
 
-void page_candidates(const uint8_t* mask, int H, int W, uint32_t max_candidates, std::vector<Candidate>& out) {
+void page_candidates(const uint8_t* mask, int H, int W, uint32_t max_candidates, std::vector<Candidate>& out, bool keep_contour = false) {
     out.clear();
     std::vector<host::Contour> cs = host::find_contours(mask, W, H, max_candidates);
     for (auto& c : cs) {
         Candidate cd;
-        if (contour_candidate(c, cd)) out.push_back(cd);
+        if (contour_candidate(c, cd, keep_contour)) out.push_back(std::move(cd));
     }
 }
 
 // Two-stage variant for a sub-batch: contour tracing is inherently serial per page (one worker per page), the
 // per-contour geometry is then spread over the whole pool; discovery order is preserved.
 void subbatch_candidates(ThreadPool& pool, const uint8_t* masks, size_t hw, int H, int W, int nb, uint32_t max_candidates,
-                         std::vector<Candidate>* out /* [nb] */) {
+                         std::vector<Candidate>* out /* [nb] */, bool keep_contour = false) {
     // stage 1: contour tracing, parallel over (page, row band) -- bands are cut at fully-blank rows
     static thread_local std::vector<std::vector<int32_t>> scratch;   // one label plane per page of the sub-batch
     if ((int)scratch.size() < nb) scratch.resize(nb);
@@ -245,11 +253,11 @@ void subbatch_candidates(ThreadPool& pool, const uint8_t* masks, size_t hw, int 
     for (int k = 0; k < nb; ++k) { res[k].resize(cs[k].size()); ok[k].assign(cs[k].size(), 0); }
     pool.parallel_for((int)chunks.size(), [&](int i) {
         const Chunk& ch = chunks[i];
-        for (size_t c = ch.c0; c < ch.c1; ++c) ok[ch.page][c] = contour_candidate(cs[ch.page][c], res[ch.page][c]) ? 1 : 0;
+        for (size_t c = ch.c0; c < ch.c1; ++c) ok[ch.page][c] = contour_candidate(cs[ch.page][c], res[ch.page][c], keep_contour) ? 1 : 0;
     });
     for (int k = 0; k < nb; ++k) {
         out[k].clear();
-        for (size_t c = 0; c < cs[k].size(); ++c) if (ok[k][c]) out[k].push_back(res[k][c]);
+        for (size_t c = 0; c < cs[k].size(); ++c) if (ok[k][c]) out[k].push_back(std::move(res[k][c]));
     }
     if (g_timer && g_timer->on) {
         auto tc = std::chrono::steady_clock::now();
@@ -288,30 +296,41 @@ void finish_boxes(const std::vector<Candidate>& cands, const float* scores, int 
 }
 }  // namespace
 
+std::atomic<int> g_inject_batched_det_failures{0};   // oar_debug_inject_failure("batched_detection", n): the next n multi-page runs throw
+
 void Detector::run(const std::vector<PageRef>& pages, float thresh, float box_thresh, float unclip, std::vector<DetBoxes>& out,
                    std::vector<const uint8_t*>* dev_pages_out, const ReadyFn& on_ready) {
     std::lock_guard<std::mutex> lk(mu_);
     const int n = (int)pages.size();
+    if (n > 1 && g_inject_batched_det_failures.load(std::memory_order_relaxed) > 0 && g_inject_batched_det_failures.fetch_sub(1) > 0)
+        fail(OAR_DEVICE, "injected failure of a batched detection (oar_debug_inject_failure)");
     out.assign(n, DetBoxes());
     if (n == 0) return;
     OAR_HIP(hipSetDevice(eng_->device()));
     hipStream_t s = eng_->stream();
-    // stage host pages into HBM
+    // Host pages get their slot in the HBM staging area now; the copies themselves are issued sub-batch by sub-batch on
+    // upload_stream_ (run_group), so the H2D of sub-batch k+1 runs while the network of sub-batch k does: from pageable
+    // memory a hipMemcpyAsync occupies the CALLING thread for the duration (~0.7 ms per 8 pages of 960^2 at ~35 GB/s), which
+    // is exactly the time the GPU needs no new work from it.  Only the first sub-batch's upload is exposed.
     size_t total = 0;
     for (auto& p : pages) {
         OAR_CHECK(p.w > 0 && p.h > 0 && (p.host || p.dev), OAR_INVALID_INPUT, "detector: empty page");
         if (!p.dev) total += ((size_t)p.w * p.h * 3 + 255) & ~(size_t)255;
     }
-    if (total > pages_dev_.cap) { OAR_HIP(hipStreamSynchronize(s)); pages_dev_.reserve(total); }
+    if (total > pages_dev_.cap) { OAR_HIP(hipStreamSynchronize(s)); OAR_HIP(hipStreamSynchronize(upload_stream_)); pages_dev_.reserve(total); }
+    // whatever still reads the staging area on the engine stream (the previous call's crop kernels) must be done before
+    // this call's uploads overwrite it
+    OAR_HIP(hipEventRecord(stage_free_, s));
+    OAR_HIP(hipStreamWaitEvent(upload_stream_, stage_free_, 0));
     page_ptrs_.assign(n, nullptr);
+    upload_src_.assign(n, nullptr);
     size_t off = 0;
     for (int i = 0; i < n; ++i) {
         if (pages[i].dev) { page_ptrs_[i] = pages[i].dev; continue; }
         uint8_t* d = pages_dev_.as<uint8_t>() + off;
-        size_t bytes = (size_t)pages[i].w * pages[i].h * 3;
-        OAR_HIP(hipMemcpyAsync(d, pages[i].host, bytes, hipMemcpyHostToDevice, s));
         page_ptrs_[i] = d;
-        off += (bytes + 255) & ~(size_t)255;
+        upload_src_[i] = pages[i].host;   // pending until run_group reaches the page's sub-batch
+        off += ((size_t)pages[i].w * pages[i].h * 3 + 255) & ~(size_t)255;
     }
     if (dev_pages_out) *dev_pages_out = page_ptrs_;
     // group by resized shape, first-appearance order (models/detection/db.rs:297-309)
@@ -330,6 +349,10 @@ void Detector::run(const std::vector<PageRef>& pages, float thresh, float box_th
         if (pages[i].h + pages[i].w >= 64) continue;
         const uint32_t pw = std::max(pages[i].w, 32u), ph = std::max(pages[i].h, 32u);
         if (pw == pages[i].w && ph == pages[i].h) continue;
+        if (upload_src_[i]) {   // the padding copy below reads the page on the engine stream: upload it there, now
+            OAR_HIP(hipMemcpyAsync(const_cast<uint8_t*>(page_ptrs_[i]), upload_src_[i], (size_t)pages[i].w * pages[i].h * 3, hipMemcpyHostToDevice, s));
+            upload_src_[i] = nullptr;
+        }
         uint8_t* d = padded_dev_.as<uint8_t>() + pad_off;
         OAR_HIP(hipMemsetAsync(d, 0, (size_t)pw * ph * 3, s));
         OAR_HIP(hipMemcpy2DAsync(d, (size_t)pw * 3, page_ptrs_[i], (size_t)pages[i].w * 3, (size_t)pages[i].w * 3, pages[i].h, hipMemcpyDeviceToDevice, s));
@@ -389,19 +412,64 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
     size_t need_in = (size_t)SB * plane * 3 * sizeof(float);
     size_t need_rs = 0;
     for (int b = 0; b < B; ++b) if (det_w_[idx[b]] != rw || det_h_[idx[b]] != rh) need_rs += (plane * 3 + 255) & ~(size_t)255;
-    if (need_in > input_f32_.cap || need_rs > resized_dev_.cap || (size_t)B * hw > mask_dev_.cap || (size_t)B * hw * 4 > probs_keep_.cap) {
+    if (need_in > input_f32_.cap || need_rs > resized_dev_.cap || (size_t)B * hw > mask_dev_.cap || (size_t)B * hw * 4 > probs_keep_.cap ||
+        (cfg_.use_dilation && (size_t)B * hw > mask_dil_.cap)) {
         OAR_HIP(hipStreamSynchronize(s));
         input_f32_.reserve(need_in); resized_dev_.reserve(need_rs); mask_dev_.reserve((size_t)B * hw); probs_keep_.reserve((size_t)B * hw * 4);
+        if (cfg_.use_dilation) mask_dil_.reserve((size_t)B * hw);
     }
     mask_host_.reserve((size_t)B * hw);
     while ((int)sub_events_.size() < nsub) { hipEvent_t e; OAR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); sub_events_.push_back(e); }
     while ((int)mask_ready_.size() < nsub) { hipEvent_t e; OAR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); mask_ready_.push_back(e); }
 
     float* probs = probs_keep_.as<float>();   // [B][H][W] channel-0 planes, kept for the score kernel
+    while ((int)upload_done_.size() < nsub) { hipEvent_t e; OAR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); upload_done_.push_back(e); }
+
+    // ---- uploader: the sub-batches' host pages -> HBM, in order, on upload_stream_.  From pageable memory a
+    // hipMemcpyAsync occupies its CALLING thread for the whole copy (~0.7 ms per 8 pages of 960^2), so the copies are issued
+    // from a helper thread while this one keeps the kernel queue full; `issued` counts the sub-batches whose upload (and
+    // the event that follows it) has been submitted -- an event must be recorded before a stream can wait on it.
+    struct Uploader {
+        std::thread th;
+        std::atomic<int> issued{0};
+        std::atomic<bool> failed{false};
+        std::string error;
+        ~Uploader() { if (th.joinable()) th.join(); }
+    } up;
+    bool any_upload = false;
+    for (int b = 0; b < B; ++b) any_upload = any_upload || upload_src_[idx[b]] != nullptr;
+    if (any_upload) {
+        const int device = eng_->device();
+        up.th = std::thread([&, device] {
+            try {
+                OAR_HIP(hipSetDevice(device));
+                for (int sb = 0; sb < nsub; ++sb) {
+                    for (int k = sb_off[sb]; k < sb_off[sb + 1]; ++k) {
+                        const int pi = idx[k];
+                        if (!upload_src_[pi]) continue;
+                        OAR_HIP(hipMemcpyAsync(const_cast<uint8_t*>(page_ptrs_[pi]), upload_src_[pi], (size_t)pages[pi].w * pages[pi].h * 3, hipMemcpyHostToDevice, upload_stream_));
+                        upload_src_[pi] = nullptr;
+                    }
+                    OAR_HIP(hipEventRecord(upload_done_[sb], upload_stream_));
+                    up.issued.store(sb + 1, std::memory_order_release);
+                }
+            } catch (const std::exception& e) {
+                up.error = e.what();
+                up.failed.store(true, std::memory_order_release);
+            }
+        });
+    }
+
     size_t rs_off = 0;
-    for (int sb = 0; sb < nsub; ++sb) {
+    // GPU work of one sub-batch: (wait for its pages) -> normalize -> network -> threshold -> mask D2H on the copy stream
+    auto enqueue = [&](int sb) {
         const int b0 = sb_off[sb], nb = sb_off[sb + 1] - b0;
         const uint8_t* srcs[32];
+        if (any_upload) {
+            while (up.issued.load(std::memory_order_acquire) <= sb && !up.failed.load(std::memory_order_acquire)) cpu_relax();
+            if (up.failed.load(std::memory_order_acquire)) fail(OAR_DEVICE, "page upload failed: " + up.error);
+            OAR_HIP(hipStreamWaitEvent(s, upload_done_[sb], 0));
+        }
         for (int k = 0; k < nb; ++k) {
             const int pi = idx[b0 + k];
             const uint8_t* src = det_src_[pi];
@@ -422,17 +490,22 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
         // only channel 0 is used (processors/db_postprocess.rs:122-123); keep it past the next sub-batch's arena reuse
         k::copy2d(s, eng_->out_ptr(po.loc), probs + (size_t)b0 * hw, nb, (int)hw, (int)(hw * C), (int)hw);
         pp::threshold(s, probs + (size_t)b0 * hw, mask_dev_.as<uint8_t>() + (size_t)b0 * hw, (int64_t)nb * hw, thresh);
+        const uint8_t* traced = mask_dev_.as<uint8_t>() + (size_t)b0 * hw;
+        if (cfg_.use_dilation) {   // db_postprocess.rs:163-168: the contours are traced on the dilated mask, the scores still read pred
+            pp::dilate3x3(s, traced, mask_dil_.as<uint8_t>() + (size_t)b0 * hw, nb, H, W);
+            traced = mask_dil_.as<uint8_t>() + (size_t)b0 * hw;
+        }
         OAR_HIP(hipEventRecord(mask_ready_[sb], s));
         OAR_HIP(hipStreamWaitEvent(copy_stream_, mask_ready_[sb], 0));
-        OAR_HIP(hipMemcpyAsync(mask_host_.as<uint8_t>() + (size_t)b0 * hw, mask_dev_.as<uint8_t>() + (size_t)b0 * hw, (size_t)nb * hw,
-                               hipMemcpyDeviceToHost, copy_stream_));
+        OAR_HIP(hipMemcpyAsync(mask_host_.as<uint8_t>() + (size_t)b0 * hw, traced, (size_t)nb * hw, hipMemcpyDeviceToHost, copy_stream_));
         OAR_HIP(hipEventRecord(sub_events_[sb], copy_stream_));
-    }
-    tmark("det_enqueue");
+        tmark("det_enqueue");
+    };
 
-    // Software pipeline over the sub-batches, while the GPU runs the later ones:
-    //   wait mask(sb) -> contours(sb) (host) -> enqueue the box-score kernel of sb on the score stream (it shares the GPU
-    //   with the next sub-batch's network and is slow there, ~0.7 ms, but nobody waits for it: its result is read one
+    // Software pipeline over the sub-batches: the GPU always has the NEXT sub-batch queued while the host works on this one
+    //   enqueue(0), enqueue(1), host(0), enqueue(2), host(1), ... , host(last)
+    //   host(sb): wait mask(sb) -> contours(sb) -> enqueue the box-score kernel of sb on the score stream (it shares the GPU
+    //   with a later sub-batch's network and is slow there, ~0.7 ms, but nobody waits for it: its result is read one
     //   contour pass later) -> finish(sb-1): box scores back -> unclip / scale (host) -> on_ready.
     // Only the last, half-size sub-batch's contours + scores + unclip are exposed.
     std::vector<std::vector<Candidate>> cands(B);
@@ -453,18 +526,38 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
         tmark("host_unclip");
         if (on_ready) { on_ready(idx[b0], nb); tmark("crop_plan+warp"); }
     };
-    for (int sb = 0; sb < nsub; ++sb) {
+    auto host_stage = [&](int sb) {
         const int b0 = sb_off[sb], nb = sb_off[sb + 1] - b0;
         OAR_HIP(hipEventSynchronize(sub_events_[sb]));
         tmark("det_gpu_wait");
-        subbatch_candidates(*pool_, mh + (size_t)b0 * hw, hw, H, W, nb, maxc, &cands[b0]);
+        const bool slow = cfg_.score_mode == 1;
+        subbatch_candidates(*pool_, mh + (size_t)b0 * hw, hw, H, W, nb, maxc, &cands[b0], slow);
         tmark("host_contours");
         ScoreSlot& sl = *score_slots_[sb];
         sl.base.assign(nb + 1, 0);
         size_t total = 0;
         for (int k = 0; k < nb; ++k) { sl.base[k] = total; total += cands[b0 + k].size(); }
         sl.base[nb] = total; sl.total = total;
-        if (total) {
+        if (total && slow) {   // ScoreMode::Slow: the contour is the polygon (db_score.rs:139-181)
+            size_t npts = 0;
+            for (int k = 0; k < nb; ++k) for (auto& cd : cands[b0 + k]) npts += cd.contour.size();
+            sl.poly_pts_host.reserve(npts * 8 + 8); sl.poly_desc_host.reserve(total * sizeof(pp::PolyDesc)); sl.scores_host.reserve(total * sizeof(float));
+            sl.poly_pts_dev.reserve(npts * 8 + 8); sl.poly_desc_dev.reserve(total * sizeof(pp::PolyDesc)); sl.scores_dev.reserve(total * sizeof(float));
+            float* pp_ = sl.poly_pts_host.as<float>();
+            pp::PolyDesc* pdesc = sl.poly_desc_host.as<pp::PolyDesc>();
+            size_t at = 0, q = 0;
+            for (int k = 0; k < nb; ++k)
+                for (auto& cd : cands[b0 + k]) {
+                    pdesc[q++] = pp::PolyDesc{(int32_t)at, (int32_t)cd.contour.size(), b0 + k, 0};
+                    for (auto& p : cd.contour) { pp_[at * 2] = p.x; pp_[at * 2 + 1] = p.y; ++at; }
+                    std::vector<host::Pt>().swap(cd.contour);
+                }
+            OAR_HIP(hipMemcpyAsync(sl.poly_pts_dev.p, pp_, npts * 8, hipMemcpyHostToDevice, score_stream_));
+            OAR_HIP(hipMemcpyAsync(sl.poly_desc_dev.p, pdesc, total * sizeof(pp::PolyDesc), hipMemcpyHostToDevice, score_stream_));
+            pp::poly_scores(score_stream_, probs, H, W, sl.poly_pts_dev.as<float>(), sl.poly_desc_dev.as<pp::PolyDesc>(), (int)total, sl.scores_dev.as<float>());
+            OAR_HIP(hipMemcpyAsync(sl.scores_host.p, sl.scores_dev.p, total * sizeof(float), hipMemcpyDeviceToHost, score_stream_));
+            OAR_HIP(hipEventRecord(score_done_[sb], score_stream_));
+        } else if (total) {
             sl.boxes_host.reserve(total * sizeof(pp::ScoreBox)); sl.scores_host.reserve(total * sizeof(float));
             sl.boxes_dev.reserve(total * sizeof(pp::ScoreBox)); sl.scores_dev.reserve(total * sizeof(float));
             pp::ScoreBox* sbx = sl.boxes_host.as<pp::ScoreBox>();
@@ -481,27 +574,46 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
         }
         tmark("box_scores_enqueue");
         if (sb > 0) finish(sb - 1);   // its scores were enqueued one contour pass ago
+    };
+    enqueue(0);
+    for (int sb = 0; sb < nsub; ++sb) {
+        if (sb + 1 < nsub) enqueue(sb + 1);
+        host_stage(sb);
     }
     finish(nsub - 1);
     if (Profiler::get().enabled) Profiler::get().flush();
 }
 
 void Detector::postprocess_host(const float* pred, int H, int W, uint32_t src_w, uint32_t src_h, float thresh, float box_thresh,
-                                float unclip, uint32_t max_candidates, DetBoxes& out) {
+                                float unclip, uint32_t max_candidates, DetBoxes& out, int score_mode, int use_dilation) {
     // Stand-alone DB post-processing on a host probability map (parity hook for a7..a12): same kernels, tiny batch.
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) fail(OAR_DEVICE, "no HIP device visible: libOarMi355x has no CPU fallback");
     const size_t hw = (size_t)H * W;
-    DevBuf dpred, dmask, dboxes, dscores;
+    DevBuf dpred, dmask, dmask2, dboxes, dscores, dpts;
     dpred.reserve(hw * 4); dmask.reserve(hw);
     OAR_HIP(hipMemcpy(dpred.p, pred, hw * 4, hipMemcpyHostToDevice));
     pp::threshold(nullptr, dpred.as<float>(), dmask.as<uint8_t>(), (int64_t)hw, thresh);
+    const uint8_t* traced = dmask.as<uint8_t>();
+    if (use_dilation) { dmask2.reserve(hw); pp::dilate3x3(nullptr, traced, dmask2.as<uint8_t>(), 1, H, W); traced = dmask2.as<uint8_t>(); }
     std::vector<uint8_t> mask(hw);
-    OAR_HIP(hipMemcpy(mask.data(), dmask.p, hw, hipMemcpyDeviceToHost));
+    OAR_HIP(hipMemcpy(mask.data(), traced, hw, hipMemcpyDeviceToHost));
     std::vector<Candidate> cands;
-    page_candidates(mask.data(), H, W, max_candidates ? max_candidates : 1000, cands);
+    page_candidates(mask.data(), H, W, max_candidates ? max_candidates : 1000, cands, score_mode == 1);
     std::vector<float> scores(cands.size(), 0.f);
-    if (!cands.empty()) {
+    if (!cands.empty() && score_mode == 1) {
+        std::vector<float> pts;
+        std::vector<pp::PolyDesc> pd;
+        for (auto& c : cands) {
+            pd.push_back(pp::PolyDesc{(int32_t)(pts.size() / 2), (int32_t)c.contour.size(), 0, 0});
+            for (auto& p : c.contour) { pts.push_back(p.x); pts.push_back(p.y); }
+        }
+        dpts.reserve(pts.size() * 4 + 8); dboxes.reserve(pd.size() * sizeof(pp::PolyDesc)); dscores.reserve(pd.size() * 4);
+        OAR_HIP(hipMemcpy(dpts.p, pts.data(), pts.size() * 4, hipMemcpyHostToDevice));
+        OAR_HIP(hipMemcpy(dboxes.p, pd.data(), pd.size() * sizeof(pp::PolyDesc), hipMemcpyHostToDevice));
+        pp::poly_scores(nullptr, dpred.as<float>(), H, W, dpts.as<float>(), dboxes.as<pp::PolyDesc>(), (int)pd.size(), dscores.as<float>());
+        OAR_HIP(hipMemcpy(scores.data(), dscores.p, pd.size() * 4, hipMemcpyDeviceToHost));
+    } else if (!cands.empty()) {
         std::vector<pp::ScoreBox> sb(cands.size());
         for (size_t i = 0; i < cands.size(); ++i) { std::memcpy(sb[i].pts, cands[i].pts, sizeof sb[i].pts); sb[i].image = 0; sb[i].pad = 0; }
         dboxes.reserve(sb.size() * sizeof(pp::ScoreBox)); dscores.reserve(sb.size() * 4);
@@ -1055,8 +1167,8 @@ void Ocr::predict_core(const std::vector<PageRef>& pages, std::vector<std::vecto
         pool_bytes = 0;
     };
 
-    for (int start = 0; start < n; start += (int)cfg_.image_batch_size) {
-        const int end = std::min(n, start + (int)cfg_.image_batch_size);
+    int flush_count = 0;
+    auto run_chunk = [&](int start, int end) {
         std::vector<PageRef> chunk(pages.begin() + start, pages.begin() + end);
         std::vector<DetBoxes> boxes;
         std::vector<const uint8_t*> dev_pages;
@@ -1128,13 +1240,36 @@ void Ocr::predict_core(const std::vector<PageRef>& pages, std::vector<std::vecto
                 pp::rotate_crops(s, wd_dev, (int)take, crop_pool_.as<uint8_t>(), max_px);
                 desc_used += take;
                 pi += take;
-                if (pool.size() >= cfg_.max_pooled_crops) { flush(); desc_used = 0; }
+                if (pool.size() >= cfg_.max_pooled_crops) { flush(); ++flush_count; desc_used = 0; }
             }
         };
         det_->run(chunk, cfg_.det_thresh, cfg_.det_box_thresh, cfg_.det_unclip_ratio, boxes, &dev_pages, plan_pages);
         // the detector's page staging buffer is reused by the next chunk: crops must be done first
         OAR_HIP(hipStreamSynchronize(s));
         tmark("crop_sync");
+    };
+    for (int start = 0; start < n; start += (int)cfg_.image_batch_size) {
+        const int end = std::min(n, start + (int)cfg_.image_batch_size);
+        const size_t pool_mark = pool.size(), bytes_mark = pool_bytes;
+        const int flush_mark = flush_count;
+        try {
+            run_chunk(start, end);
+        } catch (const Error& err) {
+            // "Batched text detection failed; falling back to per-image detection" (src/oarocr/ocr.rs:576-588): the chunk is
+            // redone page by page; a page that fails on its own fails the call, as the reference's `?` does.
+            if (end - start <= 1) throw;
+            fprintf(stderr, "[oar] batched text detection failed (%s); falling back to per-image detection for pages %d..%d\n", err.what(), start, end);
+            (void)hipStreamSynchronize(s);
+            (void)hipGetLastError();
+            // forget what the failed attempt planned for this chunk's pages (a flush in between consumed everything older)
+            if (flush_count == flush_mark) { pool.resize(pool_mark); pool_bytes = bytes_mark; }
+            else {
+                pool.erase(std::remove_if(pool.begin(), pool.end(), [&](const PoolItem& it) { return it.img >= start; }), pool.end());
+                pool_bytes = pool.empty() ? 0 : pool.back().off + ((((size_t)pool.back().w * pool.back().h * 3) + 63) & ~(size_t)63);
+            }
+            for (int i = start; i < end; ++i) per_image[i].clear();
+            for (int i = start; i < end; ++i) run_chunk(i, i + 1);
+        }
     }
     flush();
     out.assign(n, {});

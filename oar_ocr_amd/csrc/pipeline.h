@@ -71,7 +71,7 @@ class Detector {
              std::vector<const uint8_t*>* dev_pages_out = nullptr, const ReadyFn& on_ready = nullptr);
     Engine& engine() { return *eng_; }
     static void postprocess_host(const float* pred, int H, int W, uint32_t src_w, uint32_t src_h, float thresh, float box_thresh,
-                                 float unclip, uint32_t max_candidates, DetBoxes& out);
+                                 float unclip, uint32_t max_candidates, DetBoxes& out, int score_mode = 0, int use_dilation = 0);
     ThreadPool& pool() { return *pool_; }
 
    private:
@@ -81,6 +81,7 @@ class Detector {
     std::unique_ptr<ThreadPool> pool_;
     oar_det_cfg cfg_;
     DevBuf pages_dev_, resized_dev_, input_f32_, mask_dev_, probs_keep_;
+    DevBuf mask_dil_;   // use_dilation: the dilated masks (what the host traces)
     // image as the resize stage sees it: the page itself, or its black-padded copy when h + w < 64
     // (DetResizeForTest::image_padding, processors/resize_detection.rs:174-176,204-220)
     DevBuf padded_dev_;
@@ -88,11 +89,18 @@ class Detector {
     std::vector<uint32_t> det_w_, det_h_;
     std::vector<hipEvent_t> sub_events_, mask_ready_, score_done_;
     // box-score round trip of each sub-batch (its own slots: the next sub-batch's is enqueued before this one is read)
-    struct ScoreSlot { PinBuf boxes_host, scores_host; DevBuf boxes_dev, scores_dev; std::vector<size_t> base; size_t total = 0; };
+    struct ScoreSlot {
+        PinBuf boxes_host, scores_host; DevBuf boxes_dev, scores_dev; std::vector<size_t> base; size_t total = 0;
+        PinBuf poly_pts_host, poly_desc_host; DevBuf poly_pts_dev, poly_desc_dev;   // ScoreMode::Slow: the contours themselves
+    };
     std::vector<std::unique_ptr<ScoreSlot>> score_slots_;
     // mask read-back runs on its own stream: a D2H copy is a blit KERNEL on the queue it is issued to (150 us per 9-page
     // sub-batch over PCIe), which on the engine stream held up the next sub-batch's network
     hipStream_t copy_stream_ = nullptr;
+    hipStream_t upload_stream_ = nullptr;  // host pages -> HBM, one sub-batch ahead of the network
+    hipEvent_t stage_free_ = nullptr;
+    std::vector<hipEvent_t> upload_done_;
+    std::vector<const uint8_t*> upload_src_;   // per page: host source still to be uploaded (nullptr = resident)
     hipStream_t score_stream_ = nullptr;   // box-score round trips (not behind the queued mask copies of later sub-batches)
     PinBuf mask_host_;
     std::vector<const uint8_t*> page_ptrs_;

@@ -31,6 +31,10 @@ void resize_triangle(hipStream_t s, const uint8_t* src, int w, int h, uint8_t* d
 // a7 processors/db_postprocess.rs:185-221
 void threshold(hipStream_t s, const float* pred, uint8_t* mask, int64_t n, float thresh);
 
+// DBPostProcess::dilate_mask_img (processors/db_mask.rs:11: imageproc morphology::dilate, Norm::LInf, k = 1) on n_images
+// masks of height x width each: a pixel becomes 255 when any pixel of its 3 x 3 neighbourhood inside the image is non-zero.
+void dilate3x3(hipStream_t s, const uint8_t* mask, uint8_t* out, int n_images, int height, int width);
+
 // a18 processors/decode.rs:452-501: last index of the row maximum + the maximum
 void ctc_argmax(hipStream_t s, const float* probs, int64_t rows, int vocab, int64_t* idx, float* prob);
 
@@ -40,6 +44,12 @@ struct ScoreBox {          // a10 processors/db_score.rs:34-134
     int32_t pad;
 };
 void box_scores(hipStream_t s, const float* pred, int height, int width, const ScoreBox* d_boxes, int n_boxes, float* d_scores);
+
+// Scanline mean over an arbitrary polygon: box_score_slow (processors/db_score.rs:139-181, the contour itself is the
+// polygon) and the polygon (seal) path's box_score_fast on the approximated contour (db_bitmap.rs:49).  Same arithmetic and
+// summation order as box_scores; polygon i = pts[poly[i].first .. first + count) (x, y pairs).
+struct PolyDesc { int32_t first, count, image, pad; };
+void poly_scores(hipStream_t s, const float* pred, int height, int width, const float* d_pts_xy, const PolyDesc* d_polys, int n_polys, float* d_scores);
 
 struct WarpDesc {          // a14 utils/transform.rs:76-191 (plan computed on the host)
     const uint8_t* page;   // device u8 HWC

@@ -228,6 +228,31 @@ void threshold(hipStream_t s, const float* pred, uint8_t* mask, int64_t n, float
     hipLaunchKernelGGL(threshold_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, pred, mask, (long)n, thresh);
 }
 
+// ------------------------------------------------------------------------------------------ mask dilation (use_dilation)
+__global__ __launch_bounds__(256) void dilate3x3_kernel(const uint8_t* __restrict__ mask, uint8_t* __restrict__ out, int height, int width) {
+    const long plane = (long)height * width;
+    const uint8_t* m = mask + (long)blockIdx.y * plane;
+    uint8_t* o = out + (long)blockIdx.y * plane;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % width), y = (int)(i / width);
+        unsigned any = 0;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= height) continue;
+            const uint8_t* r = m + (long)yy * width;
+            any |= r[x];
+            if (x > 0) any |= r[x - 1];
+            if (x + 1 < width) any |= r[x + 1];
+        }
+        o[i] = any ? 255 : 0;
+    }
+}
+void dilate3x3(hipStream_t s, const uint8_t* mask, uint8_t* out, int n_images, int height, int width) {
+    if (n_images == 0 || height == 0 || width == 0) return;
+    ProfScope ps(s, "dilate", 2.0 * (double)n_images * height * width, 0.0);
+    hipLaunchKernelGGL(dilate3x3_kernel, dim3(grid_for((long)height * width, 256, 64), n_images), dim3(256), 0, s, mask, out, height, width);
+}
+
 // ------------------------------------------------------------------------------------------ a18 CTC argmax
 // One workgroup per (batch,time) row. Each lane keeps (max, LAST index attaining it) over its strided slice;
 // the reduction prefers the larger value and, on equal values, the larger index => "last max index wins".
@@ -331,6 +356,90 @@ void box_scores(hipStream_t s, const float* pred, int height, int width, const S
     if (n_boxes == 0) return;
     ProfScope ps(s, "box_scores", 0.0, 0.0);
     hipLaunchKernelGGL(box_scores_kernel, dim3(n_boxes), dim3(256), 0, s, pred, height, width, d_boxes, d_scores);
+}
+
+// Polygon of any size.  One workgroup per polygon, one lane per scanline row.  The reference collects the row's edge
+// crossings, sorts them and sums the spans pair by pair; here the crossings are produced in sorted order by repeated
+// selection of the next smallest (x, edge) over the edge list -- the same multiset in the same order, with no per-row
+// buffer whose size would cap the polygon.  Row sums and their reduction are those of box_scores_kernel.
+__global__ __launch_bounds__(256) void poly_scores_kernel(const float* pred, int height, int width, const float* pts, const PolyDesc* polys, float* scores) {
+    __shared__ float rsum[256];
+    __shared__ unsigned rcnt[256];
+    extern __shared__ float lp_pts[];     // the polygon's points when they fit (cap floats), else read from global
+    const PolyDesc pd = polys[blockIdx.x];
+    const float* map = pred + (long)pd.image * height * width;
+    const float* gp = pts + (long)pd.first * 2;
+    const int n = pd.count;
+    const int cap = 8192;                 // floats = 4096 points
+    const bool staged = n * 2 <= cap;
+    if (staged) for (int i = threadIdx.x; i < n * 2; i += 256) lp_pts[i] = gp[i];
+    __syncthreads();
+    const float* P = staged ? lp_pts : gp;
+    // aabb: the same single pass over the points, by lane 0-style min/max (order independent)
+    float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+    if (n == 0) { mnx = mny = mxx = mxy = 0.0f; }
+    for (int i = 0; i < n; ++i) {
+        const float x = P[i * 2], y = P[i * 2 + 1];
+        if (x < mnx) mnx = x; if (x > mxx) mxx = x;
+        if (y < mny) mny = y; if (y > mxy) mxy = y;
+    }
+    float fx0 = fminf(fmaxf(floorf(mnx), 0.0f), (float)width - 1.0f), fx1 = fminf(fmaxf(ceilf(mxx), 0.0f), (float)width - 1.0f);
+    float fy0 = fminf(fmaxf(floorf(mny), 0.0f), (float)height - 1.0f), fy1 = fminf(fmaxf(ceilf(mxy), 0.0f), (float)height - 1.0f);
+    const unsigned start_y = f2u(fy0), end_y = f2u(fy1) + 1, start_x = f2u(fx0), end_x = f2u(fx1) + 1;
+    float total = 0.0f;
+    unsigned long long pixels = 0;
+    for (unsigned y0 = start_y; y0 < end_y; y0 += 256) {
+        const unsigned yy = y0 + threadIdx.x;
+        float line = 0.0f;
+        unsigned lp = 0;
+        if (yy < end_y && n > 0) {
+            const float y = (float)yy + 0.5f;
+            const unsigned yi = f2u(y);
+            const float* row = map + (long)yi * width;
+            float last_x = -INFINITY;
+            int last_e = -1;
+            bool have_open = false;
+            float open_x = 0.0f;
+            for (;;) {
+                // next crossing in (x, edge index) order after (last_x, last_e)
+                float bx = INFINITY;
+                int be = -1;
+                for (int i = 0; i < n; ++i) {
+                    const int j = i + 1 == n ? 0 : i + 1;
+                    const float p1y = P[i * 2 + 1], p2y = P[j * 2 + 1];
+                    if (!(((p1y <= y && y < p2y) || (p2y <= y && y < p1y)) && fabsf(p2y - p1y) > 1.1920929e-7f)) continue;
+                    const float p1x = P[i * 2], p2x = P[j * 2];
+                    const float x = p1x + (y - p1y) * (p2x - p1x) / (p2y - p1y);
+                    const bool after = x > last_x || (x == last_x && i > last_e);
+                    if (after && (x < bx || (x == bx && i < be) || be < 0)) { bx = x; be = i; }
+                }
+                if (be < 0) break;
+                last_x = bx; last_e = be;
+                if (!have_open) { open_x = bx; have_open = true; continue; }
+                have_open = false;
+                if (yi < (unsigned)height) {
+                    const unsigned x1 = f2u(fmaxf(open_x, (float)start_x)), x2 = f2u(fminf(bx, (float)end_x));
+                    if (x1 < x2 && x1 >= start_x && x2 <= end_x) {
+                        const unsigned xe = x2 < (unsigned)width ? x2 : (unsigned)width;
+                        if (x1 < xe) { for (unsigned x = x1; x < xe; ++x) line += row[x]; lp += xe - x1; }
+                    }
+                }
+            }
+        }
+        rsum[threadIdx.x] = line; rcnt[threadIdx.x] = lp;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned lim = min(256u, end_y - y0);
+            for (unsigned i = 0; i < lim; ++i) { total += rsum[i]; pixels += rcnt[i]; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) scores[blockIdx.x] = pixels > 0 ? total / (float)pixels : 0.0f;
+}
+void poly_scores(hipStream_t s, const float* pred, int height, int width, const float* d_pts_xy, const PolyDesc* d_polys, int n_polys, float* d_scores) {
+    if (n_polys == 0) return;
+    ProfScope ps(s, "poly_scores", 0.0, 0.0);
+    hipLaunchKernelGGL(poly_scores_kernel, dim3(n_polys), dim3(256), 8192 * sizeof(float), s, pred, height, width, d_pts_xy, d_polys, d_scores);
 }
 
 // ------------------------------------------------------------------------------------------ a14 rotate-crop

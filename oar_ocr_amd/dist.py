@@ -55,6 +55,32 @@ def gather_results(local_results: list, dst: int = 0) -> List | None:
     return merged
 
 
+def gather_bytes(blob: bytes, dst: int, device) -> List[bytes] | None:
+    """Variable-length gather of one byte string per rank on `dst` (the final, tiny exchange of SURVEY 8e): an all_gather of
+    the lengths, then ONE gather of the blobs padded to the longest -- two collectives on `device` ("cuda" for RCCL over xGMI,
+    "cpu" for gloo), no pickling.  Returns the blobs in rank order on `dst`, None elsewhere."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [blob]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = torch.tensor([len(blob)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    cap = max(max(sizes), 1)
+    buf = torch.zeros(cap, dtype=torch.uint8)
+    if blob:
+        buf[:len(blob)] = torch.from_numpy(np.frombuffer(blob, np.uint8).copy())
+    buf = buf.to(device)
+    out = [torch.zeros(cap, dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, out, dst=dst)
+    if rank != dst:
+        return None
+    return [bytes(o[:sizes[i]].cpu().numpy().tobytes()) for i, o in enumerate(out)]
+
+
 def sharded_predict(predict_fn, pages: Sequence, dst: int = 0):
     """Runs predict_fn on this rank's shard of `pages` and gathers the results on `dst` in page order."""
     import torch.distributed as dist

@@ -359,3 +359,92 @@ def build_uvdoc(seed=6, width=(16, 32, 64), head="grid", size=512):
     y = net.conv(up(d0), c0, 3, 3, 1, act="sigmoid")
     g.add_output(y, ["N", 3, "H", "W"])
     return g.model(), {"classes": 3}
+
+
+# ---------------------------------------------------------------------------------------------- exporter-shaped fixture
+def build_p2o_fixture(seed=11, c=32, vocab=37):
+    """A small recognizer-like graph written the way Paddle2ONNX / torch.onnx write real exports, i.e. WITHOUT the
+    conveniences the other synthetic graphs use (first contact with a real file was likely
+    OAR_UNSUPPORTED_OP):
+      * Conv -> BatchNormalization kept as separate nodes; HardSwish decomposed to Add(3) / Clip(0, 6) / Mul / Div(6);
+        SE gate from ReduceMean(axes 2, 3) + HardSigmoid decomposed to Mul / Add / Clip;
+      * dynamic Resize: sizes = Concat(Slice(Shape(x), 0:2), Cast(Mul(Cast(Slice(Shape(x), 2:4), float), 2.0), int64));
+      * Reshape targets built from Shape -> Gather -> Unsqueeze -> Concat, a `0`-entry resolved by Where(Equal(shape, 0), Shape, shape);
+      * LayerNorm decomposed to ReduceMean / Sub / Pow / ReduceMean / Add / Sqrt / Div / Mul / Add;
+      * a positional term from Range -> Cast -> Div -> Unsqueeze, a bias from ConstantOfShape -> Expand, a learned row Tile'd to
+        [N, T, C] with repeats from Shape; leaky activation as Where(Greater(x, 0), x, 0.1 x); clamp as Min(Max(x, lo), hi);
+      * softmax spelled Exp / ReduceSum / Div after a ReduceMax shift.
+    Input "x" [N, 3, 32, W] (W % 8 == 0), output [N, T, vocab] with T = W / 4."""
+    net = _Net("synth_p2o_fixture", seed, opset=17)
+    g, rng = net.g, net.rng
+    f32, i64 = np.float32, np.int64
+    g.add_input("x", ["N", 3, 32, "W"])
+
+    def conv_bn_hswish(x, cin, cout, k, stride, groups=1):
+        w = net._w((cout, cin // groups, k, k), (cin // groups) * k * k)
+        y = g.op("Conv", [x, g.init(w)], kernel_shape=[k, k], strides=list(stride), pads=[k // 2] * 4, group=groups, dilations=[1, 1])
+        y = net.bn(y, cout)
+        t = g.op("Add", [y, g.init(np.array([3.0], f32))])
+        t = g.op("Clip", [t, g.init(np.array(0.0, f32)), g.init(np.array(6.0, f32))])
+        t = g.op("Mul", [y, t])
+        return g.op("Div", [t, g.init(np.array([6.0], f32))])
+
+    x = conv_bn_hswish("x", 3, c // 2, 3, (2, 2))                 # 16 x W/2
+    x = conv_bn_hswish(x, c // 2, c // 2, 3, (1, 1), groups=c // 2)
+    x = conv_bn_hswish(x, c // 2, c, 1, (1, 1))
+    # SE: ReduceMean over (2, 3), decomposed hard-sigmoid
+    p = g.op("ReduceMean", [x], axes=[2, 3], keepdims=1)
+    h = g.op("Relu", [g.op("Conv", [p, g.init(net._w((c // 4, c, 1, 1), c)), g.init(net._b(c // 4), "b")], kernel_shape=[1, 1], strides=[1, 1], pads=[0] * 4, group=1, dilations=[1, 1])])
+    h = g.op("Conv", [h, g.init(net._w((c, c // 4, 1, 1), c // 4)), g.init(net._b(c), "b")], kernel_shape=[1, 1], strides=[1, 1], pads=[0] * 4, group=1, dilations=[1, 1])
+    h = g.op("Clip", [g.op("Add", [g.op("Mul", [h, g.init(np.array([0.2], f32))]), g.init(np.array([0.5], f32))]),
+                      g.init(np.array(0.0, f32)), g.init(np.array(1.0, f32))])
+    x = g.op("Mul", [x, h])
+    # down to 8 x W/4, then a dynamic nearest x2 back up to 16 x W/2 and a skip add (FPN-style)
+    d = conv_bn_hswish(x, c, c, 3, (2, 2))
+    shp = g.op("Shape", [d])
+    nc = g.op("Slice", [shp, g.init(np.array([0], i64)), g.init(np.array([2], i64)), g.init(np.array([0], i64))])
+    hw = g.op("Slice", [shp, g.init(np.array([2], i64)), g.init(np.array([4], i64)), g.init(np.array([0], i64))])
+    hw2 = g.op("Cast", [g.op("Mul", [g.op("Cast", [hw], to=1), g.init(np.array([2.0, 2.0], f32))])], to=7)
+    sizes = g.op("Concat", [nc, hw2], axis=0)
+    up = g.op("Resize", [d, "", "", sizes], mode="nearest", coordinate_transformation_mode="asymmetric", nearest_mode="floor")
+    x = g.op("Add", [x, up])
+    x = g.op("AveragePool", [x, ], kernel_shape=[16, 2], strides=[16, 2], pads=[0, 0, 0, 0])      # [N, c, 1, W/4]
+    # [N, c, 1, T] -> [N, c, T] with a Paddle-style reshape: target [0, c, -1] whose 0 is resolved by Where(Equal(.., 0), Shape, ..)
+    tgt = g.init(np.array([0, c, -1], i64))
+    s3 = g.op("Slice", [g.op("Shape", [x]), g.init(np.array([0], i64)), g.init(np.array([3], i64)), g.init(np.array([0], i64))])
+    tgt = g.op("Where", [g.op("Equal", [tgt, g.init(np.array([0, 0, 0], i64))]), s3, tgt])
+    x = g.op("Reshape", [x, tgt])
+    x = g.op("Transpose", [x], perm=[0, 2, 1])                                                      # [N, T, c]
+    # shape scalars
+    xs = g.op("Shape", [x])
+    n_ = g.op("Unsqueeze", [g.op("Gather", [xs, g.init(np.array(0, i64))], axis=0), g.init(np.array([0], i64))])
+    t_ = g.op("Gather", [xs, g.init(np.array(1, i64))], axis=0)
+    t1 = g.op("Unsqueeze", [t_, g.init(np.array([0], i64))])
+    # positional ramp: Range(0, T, 1) / T -> [1, T, 1]
+    ramp = g.op("Div", [g.op("Cast", [g.op("Range", [g.init(np.array(0, i64)), t_, g.init(np.array(1, i64))])], to=1), g.op("Cast", [t_], to=1)])
+    ramp = g.op("Unsqueeze", [ramp, g.init(np.array([0, 2], i64))])
+    x = g.op("Add", [x, ramp])
+    # bias: ConstantOfShape([T, c]) = 0.25 -> Expand to [N, T, c]
+    cos = g.op("ConstantOfShape", [g.op("Concat", [t1, g.init(np.array([c], i64))], axis=0)], value=np.array([0.25], f32))
+    x = g.op("Sub", [x, g.op("Expand", [cos, g.op("Concat", [n_, t1, g.init(np.array([c], i64))], axis=0)])])
+    # learned row, Tile'd to [N, T, c]
+    row = g.init((0.1 * rng.standard_normal((1, 1, c))).astype(f32))
+    x = g.op("Add", [x, g.op("Tile", [row, g.op("Concat", [n_, t1, g.init(np.array([1], i64))], axis=0)])])
+    # decomposed LayerNorm over the last axis
+    mu = g.op("ReduceMean", [x], axes=[-1], keepdims=1)
+    xc = g.op("Sub", [x, mu])
+    var = g.op("ReduceMean", [g.op("Pow", [xc, g.init(np.array(2.0, f32))])], axes=[-1], keepdims=1)
+    x = g.op("Div", [xc, g.op("Sqrt", [g.op("Add", [var, g.init(np.array(1e-5, f32))])])])
+    x = g.op("Add", [g.op("Mul", [x, g.init((1.0 + 0.1 * rng.standard_normal(c)).astype(f32))]), g.init((0.05 * rng.standard_normal(c)).astype(f32))])
+    # MatMul + Add, leaky via Greater / Where, clamp via Max / Min
+    x = g.op("Add", [g.op("MatMul", [x, g.init(net._w((c, c), c))]), g.init(net._b(c))])
+    x = g.op("Where", [g.op("Greater", [x, g.init(np.array(0.0, f32))]), x, g.op("Mul", [x, g.init(np.array(0.1, f32))])])
+    x = g.op("Min", [g.op("Max", [x, g.init(np.array(-4.0, f32))]), g.init(np.array(4.0, f32))])
+    # head + softmax spelled out (ReduceMax shift, Exp, ReduceSum (opset-13 axes input), Div)
+    z = g.op("Add", [g.op("MatMul", [x, g.init(net._w((c, vocab), c))]), g.init(net._b(vocab))])
+    z = g.op("Sub", [z, g.op("ReduceMax", [z], axes=[-1], keepdims=1)])
+    e = g.op("Exp", [z])
+    y = g.op("Div", [e, g.op("ReduceSum", [e, g.init(np.array([-1], i64))], keepdims=1)])
+    g.nodes.append(node("Identity", [y], ["probs"]))
+    g.add_output("probs", ["N", "T", vocab])
+    return g.model(), {"params": g.n_params}

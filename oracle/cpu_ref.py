@@ -169,11 +169,16 @@ def rec_tensor_width(sizes, img_h=48, img_w=320, max_img_w=3200):
     return tw, rw
 
 
-def rec_preprocess(crops, img_h=48, img_w=320, max_img_w=3200) -> np.ndarray:
-    """models/recognition/crnn.rs:71-125. crops: list of [h,w,3] u8. Returns [n,3,img_h,Wt] f32."""
+def rec_preprocess(crops, img_h=48, img_w=320, max_img_w=3200, batch_max_wh_ratio=None) -> np.ndarray:
+    """models/recognition/crnn.rs:71-125. crops: list of [h,w,3] u8. Returns [n,3,img_h,Wt] f32.
+    batch_max_wh_ratio: the crops are PART of a larger batch whose widest member has this w/h ratio (the tensor width of a
+    batch is set by its widest crop, crnn.rs:80-87) -- used to check a few pages of a big pooled run."""
     if not crops:
         return np.zeros((0, 0, 0, 0), np.float32)
     tw, rws = rec_tensor_width([(c.shape[1], c.shape[0]) for c in crops], img_h, img_w, max_img_w)
+    if batch_max_wh_ratio is not None:
+        tw = min(int(np.float32(img_h) * np.float32(batch_max_wh_ratio)), max_img_w)   # `(img_h as f32 * max_wh) as usize` (crnn.rs:87)
+        rws = np.array([min(int(np.ceil(np.float32(img_h) * (np.float32(c.shape[1]) / np.float32(c.shape[0])))), tw) for c in crops], np.int32)
     out = np.zeros((len(crops), 3, img_h, tw), np.float32)
     for i, c in enumerate(crops):
         r = resize_triangle(c, int(rws[i]), img_h)
@@ -240,22 +245,32 @@ def convex_hull(points: np.ndarray) -> np.ndarray:
     return out[:n].copy()
 
 
-def boxes_from_bitmap(pred, mask, dest_w, dest_h, box_thresh=0.6, unclip_ratio=1.5, max_candidates=1000, min_size=3.0):
+def dilate3x3(mask: np.ndarray) -> np.ndarray:
+    """processors/db_mask.rs:11"""
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    out = np.empty_like(mask)
+    lib().orc_dilate3x3(_p(mask), mask.shape[0], mask.shape[1], _p(out))
+    return out
+
+
+def boxes_from_bitmap(pred, mask, dest_w, dest_h, box_thresh=0.6, unclip_ratio=1.5, max_candidates=1000, min_size=3.0, score_mode="fast"):
     pred = _f32(pred)
     mask = np.ascontiguousarray(mask, dtype=np.uint8)
     h, w = pred.shape
     cap = max_candidates
     boxes = np.zeros((cap, 4, 2), np.float32)
     scores = np.zeros(cap, np.float32)
-    n = lib().orc_boxes_from_bitmap(_p(pred), _p(mask), h, w, dest_w, dest_h, C.c_float(box_thresh),
-                                    C.c_float(unclip_ratio), max_candidates, C.c_float(min_size), _p(boxes), _p(scores), cap)
+    n = lib().orc_boxes_from_bitmap_ex(_p(pred), _p(mask), h, w, dest_w, dest_h, C.c_float(box_thresh),
+                                       C.c_float(unclip_ratio), max_candidates, C.c_float(min_size), 1 if score_mode == "slow" else 0, _p(boxes), _p(scores), cap)
     return boxes[:n].copy(), scores[:n].copy()
 
 
-def db_postprocess(pred, src_h, src_w, thresh=0.3, box_thresh=0.6, unclip_ratio=1.5, max_candidates=1000):
-    """processors/db_postprocess.rs:134-183 (Quad / Fast / no dilation). pred: [H,W] f32."""
+def db_postprocess(pred, src_h, src_w, thresh=0.3, box_thresh=0.6, unclip_ratio=1.5, max_candidates=1000, score_mode="fast", use_dilation=False):
+    """processors/db_postprocess.rs:134-183 (BoxType::Quad). pred: [H,W] f32."""
     mask = threshold_mask(pred, thresh)
-    return boxes_from_bitmap(pred, mask, int(src_w), int(src_h), box_thresh, unclip_ratio, max_candidates)
+    if use_dilation:
+        mask = dilate3x3(mask)
+    return boxes_from_bitmap(pred, mask, int(src_w), int(src_h), box_thresh, unclip_ratio, max_candidates, score_mode=score_mode)
 
 
 def sort_quad_boxes(boxes: np.ndarray) -> np.ndarray:
@@ -304,7 +319,9 @@ def argmax_rows(probs: np.ndarray):
 
 def read_dict_lines(text: str):
     """decode.rs:120 + ocr.rs:277-291: one entry per line, first char only, empty lines vanish."""
-    return [ln[0] for ln in text.splitlines() if len(ln) > 0]
+    parts = text.split("\n")   # Rust str::lines(): "\n" / "\r\n" terminate a line, nothing else does (ocr.rs:386)
+    lines = [p[:-1] if p.endswith("\r") else p for p in parts[:-1]] + ([parts[-1]] if parts[-1] != "" else [])
+    return [ln[0] for ln in lines if len(ln) > 0]
 
 
 def ctc_charset(dict_chars, use_space_char=True):

@@ -601,9 +601,9 @@ int orc_unclip(const pt_t* box, int nb, float unclip_ratio, pt_t* out, int out_c
  * processors/db_bitmap.rs:84-150 (Quad, ScoreMode::Fast). dest = (src_w as u32, src_h as u32).
  * Output boxes: 8 floats per box (x0,y0..x3,y3) + score; returns count.
  */
-int orc_boxes_from_bitmap(const float* pred, const uint8_t* mask, int height, int width, uint32_t dest_w,
-                          uint32_t dest_h, float box_thresh, float unclip_ratio, int max_candidates,
-                          float min_size, float* out_boxes, float* out_scores, int out_cap) {
+int orc_boxes_from_bitmap_ex(const float* pred, const uint8_t* mask, int height, int width, uint32_t dest_w,
+                             uint32_t dest_h, float box_thresh, float unclip_ratio, int max_candidates,
+                             float min_size, int score_mode_slow, float* out_boxes, float* out_scores, int out_cap) {
     float wscale = (float)dest_w / (float)width, hscale = (float)dest_h / (float)height;
     float dwf = (float)dest_w, dhf = (float)dest_h;
     contour_set_t* cs = orc_find_contours(mask, width, height);
@@ -618,10 +618,13 @@ int orc_boxes_from_bitmap(const float* pred, const uint8_t* mask, int height, in
         int ns = orc_simplify_chain(pts, np, simp);
         pt_t mb[4]; float min_side = 0.0f; int ok;
         if (ns >= 3) ok = mini_box_from_points(simp, ns, mb, &min_side); else ok = mini_box_from_points(pts, np, mb, &min_side);
+        /* ScoreMode::Slow (db_bitmap.rs:115-118 -> db_score.rs:139-181): the scanline mean over the contour itself, region = its
+         * aabb with the same floor / ceil / clamp rule -- i.e. box_score_fast's arithmetic on the contour's points */
+        float slow = (ok && min_side >= min_size && score_mode_slow) ? (np > 0 ? orc_box_score_fast(pred, height, width, pts, np) : 0.0f) : 0.0f;
         free(pts); free(simp);
         if (!ok) continue;
         if (min_side < min_size) continue;
-        float score = orc_box_score_fast(pred, height, width, mb, 4);
+        float score = score_mode_slow ? slow : orc_box_score_fast(pred, height, width, mb, 4);
         if (score < box_thresh) continue;
         pt_t un[512];
         int nu = orc_unclip(mb, 4, unclip_ratio, un, 512);
@@ -640,6 +643,32 @@ int orc_boxes_from_bitmap(const float* pred, const uint8_t* mask, int height, in
     }
     orc_contours_free(cs);
     return nout;
+}
+
+int orc_boxes_from_bitmap(const float* pred, const uint8_t* mask, int height, int width, uint32_t dest_w,
+                          uint32_t dest_h, float box_thresh, float unclip_ratio, int max_candidates,
+                          float min_size, float* out_boxes, float* out_scores, int out_cap) {
+    return orc_boxes_from_bitmap_ex(pred, mask, height, width, dest_w, dest_h, box_thresh, unclip_ratio, max_candidates, min_size, 0,
+                                    out_boxes, out_scores, out_cap);
+}
+
+/* ============================================================ use_dilation
+ * DBPostProcess::dilate_mask_img (processors/db_mask.rs:11): imageproc morphology::dilate(mask, Norm::LInf, 1)
+ * [third-party imageproc 0.27: distance transform, then `distance <= k`]: a pixel is set when a foreground pixel lies within
+ * Chebyshev distance 1, i.e. in its 3 x 3 neighbourhood clipped to the image.
+ */
+void orc_dilate3x3(const uint8_t* mask, int height, int width, uint8_t* out) {
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+            int any = 0;
+            for (int dy = -1; dy <= 1 && !any; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    int yy = y + dy, xx = x + dx;
+                    if (yy < 0 || yy >= height || xx < 0 || xx >= width) continue;
+                    if (mask[(size_t)yy * width + xx]) { any = 1; break; }
+                }
+            out[(size_t)y * width + x] = any ? 255 : 0;
+        }
 }
 
 /* ============================================================ a13 sort_quad_boxes

@@ -366,7 +366,7 @@ def run(model, feeds: dict, want=None):
             elif op == "Shape":
                 y = torch.tensor(list(x[0].shape), dtype=torch.int64)
             elif op == "Cast":
-                to = {1: torch.float32, 6: torch.int32, 7: torch.int64}[a["to"]]
+                to = {1: torch.float32, 6: torch.int32, 7: torch.int64, 9: torch.bool, 11: torch.float64}[a["to"]]
                 y = x[0].to(to)
             elif op == "Constant":
                 y = torch.from_numpy(np.asarray(a["value"]))
@@ -384,9 +384,48 @@ def run(model, feeds: dict, want=None):
                 ax = a.get("axis", -1)
                 shape = x[0].shape[ax:] if ax < 0 else x[0].shape[ax:]
                 y = F.layer_norm(x[0], tuple(shape), x[1], x[2] if len(x) > 2 else None, a.get("epsilon", 1e-5))
-            elif op == "ReduceMean":
-                axes = a.get("axes") or [int(v) for v in x[1]]
-                y = x[0].mean(dim=axes, keepdim=bool(a.get("keepdims", 1)))
+            elif op in ("ReduceMean", "ReduceSum", "ReduceMax", "ReduceMin", "ReduceProd"):
+                axes = a.get("axes") or ([int(v) for v in x[1]] if len(x) > 1 and x[1] is not None else list(range(x[0].dim())))
+                kd = bool(a.get("keepdims", 1))
+                if op == "ReduceMean":
+                    y = x[0].mean(dim=axes, keepdim=kd)
+                elif op == "ReduceSum":
+                    y = x[0].sum(dim=axes, keepdim=kd)
+                elif op == "ReduceMax":
+                    y = torch.amax(x[0], dim=axes, keepdim=kd)
+                elif op == "ReduceMin":
+                    y = torch.amin(x[0], dim=axes, keepdim=kd)
+                else:
+                    y = x[0]
+                    for ax in sorted([(v + y.dim()) % y.dim() for v in axes], reverse=True):
+                        y = y.prod(dim=ax, keepdim=kd)
+            elif op in ("Max", "Min"):
+                y = (torch.maximum if op == "Max" else torch.minimum)(*torch.broadcast_tensors(x[0], x[1]))
+            elif op in ("Equal", "Less", "Greater"):
+                y = {"Equal": torch.eq, "Less": torch.lt, "Greater": torch.gt}[op](x[0], x[1])
+            elif op in ("And", "Or"):
+                y = torch.logical_and(x[0], x[1]) if op == "And" else torch.logical_or(x[0], x[1])
+            elif op == "Not":
+                y = torch.logical_not(x[0])
+            elif op == "Where":
+                y = torch.where(x[0].bool(), x[1], x[2])
+            elif op == "Expand":
+                shp = [int(v) for v in x[1]]
+                y = x[0] * torch.ones(shp, dtype=x[0].dtype) if x[0].dtype != torch.bool else x[0].expand(torch.broadcast_shapes(x[0].shape, tuple(shp)))
+            elif op == "Tile":
+                y = x[0].repeat([int(v) for v in x[1]])
+            elif op == "ConstantOfShape":
+                v = a.get("value")
+                v = np.asarray(v).reshape(-1) if v is not None else np.zeros(1, np.float32)
+                y = torch.full([int(s_) for s_ in x[0]], v[0].item(), dtype=torch.from_numpy(v).dtype)
+            elif op == "Range":
+                y = torch.arange(x[0].item(), x[1].item(), x[2].item(), dtype=x[0].dtype)
+            elif op == "Floor":
+                y = torch.floor(x[0])
+            elif op == "Ceil":
+                y = torch.ceil(x[0])
+            elif op == "Round":
+                y = torch.round(x[0])
             else:
                 raise NotImplementedError(op)
             env[nd["outputs"][0]] = y

@@ -51,12 +51,12 @@ class OracleRecognizer:
         self.shape = rec_image_shape
         self.max_img_w = max_img_w
 
-    def probs(self, crops):
-        x = R.rec_preprocess(crops, self.shape[1], self.shape[2], self.max_img_w)
+    def probs(self, crops, batch_max_wh_ratio=None):
+        x = R.rec_preprocess(crops, self.shape[1], self.shape[2], self.max_img_w, batch_max_wh_ratio)
         return onnx_ref.run(self.model, {self.input: x})[0], x
 
-    def recognize(self, crops):
-        p, x = self.probs(crops)
+    def recognize(self, crops, batch_max_wh_ratio=None):
+        p, x = self.probs(crops, batch_max_wh_ratio)
         n, T, V = p.shape
         idx, pr = R.argmax_rows(p)
         texts, scores, pos, cols, lens = R.ctc_decode(idx, pr, n, T, self.charset)

@@ -94,3 +94,59 @@ def test_dict_parsing():
     assert chars == ["a", "c"]
     dec = api.CTCLabelDecode(chars)
     assert dec.character == ["\0", "a", "c", " "]
+
+
+# ---- the library-side CTC decoder (oar_ctc_decode): same vectors as the Python mirror, plus a randomised cross-check
+def test_c_ctc_decode_k9_k10_and_score_filter(L):
+    winners = [[(0, .9), (1, .8), (1, .7), (0, .6), (1, .5), (2, .4), (2, .3)],
+               [(3, .95), (3, .85), (4, .75), (3, .65), (0, .55), (2, .45), (0, .35)]]
+    idx = np.array([[w[0] for w in s] for s in winners], np.int64)
+    pr = np.array([[w[1] for w in s] for s in winners], np.float32)
+    d = api.CtcDict("a\nb\nc\n", use_space_char=False)
+    assert d.classes == 4
+    r = d.decode(idx, pr, 2, 7)
+    f = np.float32
+    assert r.texts == ["aab", "ccb"]                                         # decode.rs:679-745 (index 4 is outside the table)
+    assert r.scores.tolist() == [float((f(.8) + f(.5) + f(.4)) / f(3)), float((f(.95) + f(.65) + f(.45)) / f(3))]
+    assert [c.tolist() for c in r.char_cols] == [[1, 4, 5], [0, 3, 5]] and r.seq_len.tolist() == [7, 7]
+    assert np.array_equal(r.char_positions[0], (np.array([1, 4, 5], f) / f(7)))
+    assert d.decode(np.zeros(0), np.zeros(0), 2, 0).texts == []              # decode.rs:747-757: [2, 0, V] collapses to nothing
+    # the adapter keeps slot and score but blanks text / positions below the threshold (text_recognition_adapter.rs:88-101)
+    r = d.decode(idx, pr, 2, 7, score_threshold=0.6)
+    assert r.texts == ["", "ccb"] and r.kept.tolist() == [False, True] and len(r.char_cols[0]) == 0
+    assert r.scores[0] == np.float32((f(.8) + f(.5) + f(.4)) / f(3))
+
+
+def test_c_ctc_dict_follows_rust_lines_semantics(L):
+    text = "ab\r\n\n中文\nc\rd\n\re"            # CRLF, an empty line, a multi-byte first char, a bare \r inside / leading a line
+    assert api.dict_lines(text) == ["ab", "", "中文", "c\rd", "\re"]
+    assert api.read_dict(text) == ["a", "中", "c", "\r"]
+    d = api.CtcDict(text, use_space_char=True)
+    assert d.classes == 1 + 4 + 1
+    r = d.decode(np.array([[1, 2, 0, 2, 5, 3, 4]], np.int64), np.full((1, 7), 0.5, np.float32), 1, 7)
+    assert r.texts == ["a中中 c\r"]
+    assert api.dict_lines("x\n") == ["x"] and api.dict_lines("") == [] and api.dict_lines("\n") == [""]
+
+
+def test_c_ctc_decode_matches_the_python_mirror_and_the_oracle(L):
+    from oracle import cpu_ref
+    rng = np.random.default_rng(0)
+    entries = [chr(0x4E00 + i) for i in range(300)] + list("abcdefghij")
+    d = api.CtcDict.from_entries(entries)
+    py = api.CTCLabelDecode(entries)
+    charset = cpu_ref.ctc_charset(entries)
+    assert d.classes == len(py.character) == len(charset)
+    for T in (1, 5, 40, 133):
+        n = 17
+        idx = rng.integers(0, d.classes + 3, (n, T))      # includes out-of-table classes
+        idx[rng.random((n, T)) < 0.5] = 0
+        rep = rng.random((n, T)) < 0.3                       # repeats, so the collapse rule is exercised
+        for t in range(1, T):
+            idx[rep[:, t], t] = idx[rep[:, t], t - 1]
+        pr = rng.random((n, T)).astype(np.float32)
+        r = d.decode(idx, pr, n, T)
+        texts, scores, pos, cols, lens = py.decode_argmax(idx, pr, n, T)
+        assert r.texts == texts and r.scores.tolist() == [np.float32(s) for s in scores]
+        assert [c.tolist() for c in r.char_cols] == cols
+        ot, osc, ocols = cpu_ref.ctc_decode(idx.astype(np.int64), pr, n, T, charset)[:3]
+        assert r.texts == list(ot) and np.array_equal(r.scores, np.asarray(osc, np.float32))

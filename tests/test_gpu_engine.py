@@ -338,3 +338,40 @@ def test_fused_attention_matches_oracle(case):
     x = np.random.default_rng(n + T).standard_normal((n, T, dim)).astype(np.float32)
     _check(model, x)
     assert api.OrtInfer(model).cost((n, T, dim))[2] <= 3       # Linear + Attention (+ output copy); 14 op by op
+
+
+# ------------------------------------------------------------------------------------------------ exporter-shaped graph
+@pytest.mark.parametrize("shape", [(1, 3, 32, 64), (3, 3, 32, 200), (2, 3, 32, 320)])
+def test_exporter_shaped_fixture_matches_oracle(shape):
+    """Seam A on a graph written the way Paddle2ONNX / torch.onnx write real exports (unfolded BN, decomposed
+    HardSwish / HardSigmoid / LayerNorm / softmax, Shape-Gather-Concat reshape plumbing, dynamic Resize sizes, Where / Equal,
+    ConstantOfShape / Expand / Tile / Range, ReduceSum / ReduceMax, Max / Min, Greater) -- oar_ocr_amd/synth/models.py
+    build_p2o_fixture -- against the torch-CPU interpreter, for several input shapes (every shape re-evaluates the host-side
+    shape arithmetic)."""
+    m, _ = models.build_p2o_fixture()
+    assert "!" not in api.onnx_inspect(m)
+    x = np.random.default_rng(shape[3]).standard_normal(shape).astype(np.float32)
+    eng = api.OrtInfer(m)
+    (name, got), = eng.infer(x)
+    want = onnx_ref.run(m, {"x": x})[0]
+    assert name == "probs" and got.shape == want.shape == (shape[0], shape[3] // 4, 37)
+    assert np.abs(got - want).max() < 2e-4 and np.abs(got.sum(-1) - 1).max() < 1e-5
+    assert np.array_equal(got.argmax(-1), want.argmax(-1)) or np.abs(np.sort(want, -1)[..., -1] - np.sort(want, -1)[..., -2]).min() < 1e-5
+    eng.close()
+
+
+def test_plan_cache_is_lru_bounded(monkeypatch):
+    """plans_ grew without bound (one plan per input shape).  With OAR_PLAN_CACHE=4 ten different widths leave 4
+    cached plans and 6+ evictions, and a re-run of an evicted shape still gives the first run's result."""
+    monkeypatch.setenv("OAR_PLAN_CACHE", "4")
+    m, _ = models.build_p2o_fixture()
+    eng = api.OrtInfer(m)
+    rng = np.random.default_rng(0)
+    xs = [rng.standard_normal((1, 3, 32, 32 + 8 * i)).astype(np.float32) for i in range(10)]
+    first = [eng.infer(x)[0][1] for x in xs]
+    cached, evicted = eng.cache_stats()
+    assert cached <= 4 and evicted >= 6
+    again = [eng.infer(x)[0][1] for x in xs]
+    for a, b in zip(first, again):
+        assert np.array_equal(a, b)
+    eng.close()

@@ -1,0 +1,100 @@
+"""End-to-end parity at the sizes BASELINE.json quotes ("no -m gpu test runs BASELINE C2 at its real size";
+C3 had only Seam-A graph checks at 256x320).
+
+C2  PP-OCRv6-tiny-class det+rec, ONE predict of 32 pages of 960x960 (image batch 32, region batch 256: the bench's
+    workload, with its 8/9-page detector sub-batches, the M >= 100 k kernel selections and ~1100 pooled crops);
+    4 pages -- one from each detector sub-batch -- are checked against the oracle.
+C3  PP-OCRv5-server-class det + SVTR rec (V = 18710) through OAROCR.predict on 1280x1280 pages with limit_side_len = 1280
+    (the reference needs that setting to really run 1280^2, src/oarocr/ocr.rs:351-363), every page checked.
+
+Bar: boxes bit-exact, region order identical, recognition scores within 1e-3, texts equal unless the oracle's own top-2
+probabilities tie within 1e-5 at some time step."""
+import numpy as np
+import pytest
+
+from oar_ocr_amd import api
+from oar_ocr_amd.synth import models, pages
+from oracle import cpu_ref as R
+from oracle import pipeline_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_pages_against_oracle(got, imgs, check, det, rec, chars, det_kw, thresholds):
+    """got: OAROCRResult list of ALL pages (crops pooled over all of them); check: page indices verified with the oracle.
+    Detection / sorting / cropping of a page do not depend on the other pages.  Recognition does, through the padding
+    width of its batch only (crnn.rs:80-87): every sample of the network is independent, so the oracle recognises the
+    checked crops padded to the width of the batch the pipeline put them in (TextRegion.rec_max_wh_ratio)."""
+    od = pipeline_ref.OracleDetector(det, **det_kw)
+    orec = pipeline_ref.OracleRecognizer(rec, chars)
+    n_regions = n_ties = 0
+    for pi in check:
+        (boxes, scores, prob), = od.detect([imgs[pi]], *thresholds)
+        order = R.sort_quad_boxes(boxes)
+        regs = got[pi].text_regions
+        slots = []
+        for o in order:
+            crop = R.rotate_crop(imgs[pi], boxes[o])
+            if crop is not None:
+                slots.append((boxes[o], float(scores[o]), crop))
+        marginal = int((np.abs(prob - thresholds[0]) < 1e-4).sum())
+        assert len(regs) == len(slots), (pi, len(regs), len(slots), marginal)
+        by_width = {}
+        for k, (box, sc, crop) in enumerate(slots):
+            g = regs[k]
+            assert np.array_equal(np.asarray(g.bounding_box, np.float32), box), (pi, k, g.bounding_box, box, marginal)
+            assert abs(g.det_score - sc) <= 1e-3
+            assert g.crop_wh == (crop.shape[1], crop.shape[0])
+            by_width.setdefault(np.float32(g.rec_max_wh_ratio).item(), []).append(k)
+        for mwh, ks in by_width.items():
+            r = orec.recognize([slots[k][2] for k in ks], batch_max_wh_ratio=mwh)
+            for j, k in enumerate(ks):
+                g = regs[k]
+                assert g.rec_seq_len == r["idx"].shape[1]
+                assert abs(g.confidence - r["scores"][j]) <= 1e-3, (pi, k, g.confidence, r["scores"][j])
+                if g.text != r["texts"][j]:   # only where the oracle's own top-2 tie at some time step
+                    top2 = np.sort(r["probs_full"][j], axis=1)[:, -2:]
+                    assert (top2[:, 1] - top2[:, 0]).min() < 1e-5, (pi, k, g.text, r["texts"][j])
+                    n_ties += 1
+                n_regions += 1
+    return n_regions, n_ties
+
+
+def test_c2_32_pages_of_960x960_in_one_predict():
+    det, _ = models.build_det("tiny", seed=0)
+    rec, _ = models.build_rec("tiny", vocab=6906, seed=1)
+    chars = api.read_dict(models.synth_dict(6904))
+    imgs = [pages.make_page(i, (960, 960), 40) for i in range(32)]
+    cfg = api.TextDetectionConfig(score_threshold=0.3, box_threshold=0.6, unclip_ratio=1.5)
+    ocr = api.OAROCRBuilder(det, rec, chars).text_detection_config(cfg).image_batch_size(32).region_batch_size(256).build()
+    got = ocr.predict(imgs)
+    assert len(got) == 32
+    total = sum(len(g.text_regions) for g in got)
+    assert total > 900                                            # ~1090 regions: several 256-crop recognition batches
+    assert len({round(t.rec_max_wh_ratio, 4) for g in got for t in g.text_regions}) >= 3
+    n, ties = _check_pages_against_oracle(got, imgs, [0, 9, 20, 31], det, rec, chars, {}, (0.3, 0.6, 1.5))
+    assert n > 100 and ties <= 2
+    # the packed metric path of bench.py returns the same boxes / texts / scores
+    _, ptrs, ws, hs = api._img_arrays(imgs)
+    packed = ocr.predict_packed(ptrs, ws, hs, 32)
+    assert packed.region_offsets.tolist() == np.concatenate([[0], np.cumsum([len(g.text_regions) for g in got])]).tolist()
+    k = 0
+    for g in got:
+        for t in g.text_regions:
+            assert np.array_equal(packed.points[k], t.bounding_box) and packed.text(k) == t.text and packed.scores[k] == np.float32(t.confidence)
+            k += 1
+    ocr.close()
+
+
+def test_c3_server_graphs_on_1280x1280_pages():
+    det, _ = models.build_det("server", seed=0)
+    rec, _ = models.build_rec("server", vocab=18710, seed=1)
+    chars = api.read_dict(models.synth_dict(18708))
+    imgs = [pages.make_page(100 + i, (1280, 1280), 40) for i in range(3)]
+    cfg = api.TextDetectionConfig(score_threshold=0.3, box_threshold=0.6, unclip_ratio=1.5, limit_side_len=1280)
+    ocr = api.OAROCRBuilder(det, rec, chars).text_detection_config(cfg).image_batch_size(64).region_batch_size(64).build()
+    got = ocr.predict(imgs)
+    assert sum(len(g.text_regions) for g in got) > 60
+    n, ties = _check_pages_against_oracle(got, imgs, [0, 1, 2], det, rec, chars, dict(limit_side_len=1280), (0.3, 0.6, 1.5))
+    assert n > 60 and ties <= 2
+    ocr.close()

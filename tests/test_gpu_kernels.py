@@ -130,3 +130,34 @@ def test_k18_sixteen_crops_order_preserved():
     for i in range(16):
         crop = api.k_rotate_crop(img, np.array([[4 * i, 0], [4 * i + 4, 0], [4 * i + 4, 4], [4 * i, 4]], np.float32))
         assert crop.shape == (4, 4, 3) and crop[0, 0].tolist() == [i, 0, 0]
+
+
+# ------------------------------------------------------------------------------------------------ DBPostProcess options
+def test_dilate_matches_oracle():
+    rng = np.random.default_rng(3)
+    for h, w in [(1, 1), (5, 7), (64, 33), (257, 129)]:
+        m = (rng.random((h, w)) > 0.93).astype(np.uint8) * 255
+        m[0, 0] = 255; m[-1, -1] = 255          # corners: the neighbourhood is clipped to the image
+        assert np.array_equal(api.k_dilate(m), R.dilate3x3(m))
+    import scipy.ndimage as ndi
+    m = (rng.random((40, 50)) > 0.9).astype(np.uint8) * 255
+    assert np.array_equal(api.k_dilate(m) > 0, ndi.binary_dilation(m > 0, structure=np.ones((3, 3), bool)))   # independent pin: LInf ball of radius 1
+
+
+def test_poly_scores_match_oracle_on_contours_and_boxes():
+    """ScoreMode::Slow's polygon is the traced contour (hundreds of points); the same kernel on 4-point boxes must equal
+    box_score_fast bit for bit, including the >= 8000-pixel branch."""
+    rng = np.random.default_rng(5)
+    import scipy.ndimage as ndi
+    pred = ndi.gaussian_filter(rng.random((200, 320)), 3).astype(np.float32)
+    pred = (pred - pred.min()) / (pred.max() - pred.min())
+    mask = (pred > 0.55).astype(np.uint8) * 255
+    polys = [p.astype(np.float32) for p, _, _ in R.find_contours(mask)][:80]
+    assert len(polys) > 5 and max(len(p) for p in polys) > 100
+    boxes = [np.array([[10, 10], [300, 12], [298, 150], [8, 148]], np.float32), np.array([[50.5, 20.25], [90.75, 30.5], [80.25, 70.75], [40.5, 60.5]], np.float32),
+             np.array([[0, 0], [319, 0], [319, 199], [0, 199]], np.float32), np.array([[5, 5], [5, 5], [5, 5], [5, 5]], np.float32)]
+    allp = polys + boxes
+    got = api.k_poly_scores(pred, allp)
+    want = np.array([R.box_score_fast(pred, p) for p in allp], np.float32)
+    assert np.array_equal(got, want)
+    assert np.array_equal(api.k_box_scores(pred, np.stack(boxes)), want[len(polys):])

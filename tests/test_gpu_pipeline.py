@@ -153,3 +153,57 @@ def test_small_page_is_padded_like_the_reference(nets):
             marginal = int((np.abs(prob - 0.3) < 1e-4).sum())
             assert np.array_equal(gb, rb) if marginal == 0 else np.abs(gb - rb).max() <= 2.0
             assert np.allclose([d.score for d in g], rs, atol=1e-3)
+
+
+@pytest.mark.parametrize("score_mode,use_dilation", [("slow", False), ("fast", True), ("slow", True)])
+def test_db_postprocess_options_match_oracle(nets, score_mode, use_dilation):
+    """DBPostProcess::{score_mode, use_dilation} (processors/db_postprocess.rs:60-98): ScoreMode::Slow scores the traced
+    contour (db_score.rs:139-181), use_dilation traces the 3 x 3-dilated mask (db_mask.rs:11); same probability map in ->
+    identical boxes and scores out, stand-alone and through the detection adapter."""
+    det, _, _ = nets
+    od = pipeline_ref.OracleDetector(det)
+    page = pages.make_page(2, (480, 640), lines=10)
+    (prob, (sh, sw)), = od.prob_maps([page])
+    rb, rs = R.db_postprocess(prob, sh, sw, 0.3, 0.6, 1.5, score_mode=score_mode, use_dilation=use_dilation)
+    got = api.db_postprocess(prob, sw, sh, 0.3, 0.6, 1.5, score_mode=score_mode, use_dilation=use_dilation)
+    assert len(got) == len(rb) and len(rb) > 5
+    assert np.array_equal(np.stack([d.bbox for d in got]), rb)
+    assert np.array_equal(np.array([d.score for d in got], np.float32), rs)
+    base_b, base_s = R.db_postprocess(prob, sh, sw, 0.3, 0.6, 1.5)
+    assert not (np.array_equal(rb, base_b) and np.array_equal(rs, base_s))     # the option really changes the result
+    cfg = api.TextDetectionConfig(0.3, 0.6, 1.5, score_mode=score_mode, use_dilation=use_dilation)
+    imgs = [page, pages.make_page(9, (480, 640), lines=8)]
+    dets = api.TextDetectionPredictor(det, cfg).predict(imgs)
+    for g, (prob_i, (sh_i, sw_i)) in zip(dets, od.prob_maps(imgs)):
+        rb, rs = R.db_postprocess(prob_i, sh_i, sw_i, 0.3, 0.6, 1.5, score_mode=score_mode, use_dilation=use_dilation)
+        if int((np.abs(prob_i - 0.3) < 1e-4).sum()) == 0:
+            assert np.array_equal(np.stack([d.bbox for d in g]), rb)
+        assert np.allclose([d.score for d in g], rs, atol=1e-3)
+
+
+def test_poly_box_type_is_reported_as_unsupported(nets):
+    det, _, _ = nets
+    with pytest.raises(api.OCRError) as e:
+        api.TextDetectionPredictor(det, api.TextDetectionConfig(box_type="poly"))
+    assert e.value.code == api.OAR_UNSUPPORTED_OP
+
+
+def test_failed_batched_detection_falls_back_to_per_image(nets):
+    """src/oarocr/ocr.rs:576-588: when the batched detection of a chunk fails, the reference redoes the chunk image by
+    image and carries on; oar_ocr_predict does the same inside the call.  The result equals an undisturbed run; a page that
+    also fails alone fails the call."""
+    det, rec, chars = nets
+    imgs = [pages.make_page(80 + i, (320, 480), lines=6) for i in range(5)]
+    ocr = api.OAROCRBuilder(det, rec, chars).text_detection_config(api.TextDetectionConfig(0.3, 0.6, 1.5)).image_batch_size(3).region_batch_size(16).build()
+    clean = ocr.predict(imgs)
+    api.debug_inject_failure("batched_detection", 1)        # the first chunk (3 pages) fails once
+    again = ocr.predict(imgs)
+    api.debug_inject_failure("batched_detection", 0)
+    assert sum(len(g.text_regions) for g in clean) > 15
+    for a, b in zip(clean, again):
+        assert len(a.text_regions) == len(b.text_regions)
+        for p, q in zip(a.text_regions, b.text_regions):
+            assert np.array_equal(p.bounding_box, q.bounding_box) and p.text == q.text and abs(p.confidence - q.confidence) <= 1e-3
+    with pytest.raises(api.OCRError):
+        api.debug_inject_failure("no_such_site", 1)
+    ocr.close()
