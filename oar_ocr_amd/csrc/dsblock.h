@@ -1,0 +1,32 @@
+// dsblock.h -- fused depthwise-separable block (dsblock.inc); launcher + eligibility.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "kernels.h"
+
+namespace oar {
+namespace k {
+
+struct DsBlockP {
+    int N, H, W, C;            // input NHWC
+    int Ho, Wo, Cout;          // output NHWC
+    int ks, sh, sw, pt, pl;    // depthwise: square kernel 3 / 5, strides 1 / 2
+    Act act1, act2;
+    const float* x;
+    const float* wd;           // depthwise weights [ks*ks][C]
+    const float* bd;           // may be null
+    const float* wp;           // pointwise weights in bf16x6 fragment order (IGEMM_W_X6)
+    const float* bp;           // may be null
+    const float* residual;     // may be null, shape of y
+    const float* se;           // may be null: [N][C] gate applied to the depthwise output after act1
+    float* y;
+    int y_ld;
+};
+// true when dsblock() can run the block (shape / stride / channel limits); the planner keeps the two convolutions otherwise
+bool dsblock_eligible(const DsBlockP& p);
+void dsblock(hipStream_t s, const DsBlockP& p);
+
+}  // namespace k
+}  // namespace oar

@@ -1,0 +1,82 @@
+// dsblock.hip -- host side of the fused depthwise-separable block: tile shape, wave layout, launch (kernel: dsblock.inc).
+#include "dsblock_dev.h"
+
+namespace oar {
+namespace k {
+
+namespace {
+struct DsPlanShape { int TR, TC, IR, IC, nfw, pfw; long tiles; int tiles_x, tiles_y; size_t lds; bool ok; };
+
+DsPlanShape ds_shape(const DsBlockP& p) {
+    DsPlanShape r{};
+    r.ok = false;
+    if (!(p.ks == 3 || p.ks == 5) || !(p.sh == 1 || p.sh == 2) || !(p.sw == 1 || p.sw == 2)) return r;
+    if (p.C <= 0 || (p.C & 3) || p.Cout <= 0 || (p.Cout & 3) || p.Cout > 256 || (p.y_ld & 3)) return r;
+    if (p.N <= 0 || p.Ho <= 0 || p.Wo <= 0) return r;
+    // Measured per layer on the bench graphs (tools/dsblock_bench.py vs the conv_dw + conv_igemm pair, profiles/r2): the fused
+    // kernel wins 10-45 % on every 3x3 block and loses on the wide 5x5 ones (192 -> 192: 271 us vs 117 + 130 us; 128 -> 128:
+    // 41 vs 37 us), where one workgroup per CU (185+ VGPRs) is left and nothing hides its barrier / LDS latencies.
+    static const bool force = [] { const char* e = getenv("OAR_FUSE_DSBLOCK"); return e && atoi(e) == 2; }();
+    if (!force && p.ks == 5 && p.C >= 128) return r;
+    // wave layout: WN cout groups x WP pixel groups (WN * WP = 4 waves), NFW fragments of 16 couts per wave
+    const int nf = (p.Cout + 15) / 16;
+    if (nf <= 4) { r.nfw = nf; r.pfw = 1; }                        // 8 waves = 1 cout group x 8 pixel groups
+    else if (nf <= 8) { r.nfw = (nf + 1) / 2; r.pfw = 2; }         //           2 x 4
+    else { r.nfw = (nf + 3) / 4; r.pfw = 4; }                      //           4 x 2
+    if (r.pfw != 1 && r.nfw < 3) r.nfw = 3;
+    // tile of 128 output pixels: the fewest tiles (least padded MFMA work), then the smallest input tile
+    const int np_cap = (p.sw == 1 ? 6 : 11) * 64;   // pixels the prefetch registers can carry
+    long best_tiles = -1; int best_in = 0;
+    for (int tc : {16, 32, 64}) {
+        const int tr = 128 / tc;
+        const int ir = (tr - 1) * p.sh + p.ks, ic = (tc - 1) * p.sw + p.ks;
+        if (ir * ic > np_cap) continue;
+        const size_t lds = (size_t)ir * ic * 128 + (size_t)(p.ks * p.ks + 1) * 128 + 8 * 3 * 64 * 16 + (size_t)ir * ic * 4 + 16;
+        if (lds > 150 * 1024) continue;
+        const int tx = (p.Wo + tc - 1) / tc, ty = (p.Ho + tr - 1) / tr;
+        const long tiles = (long)p.N * tx * ty;
+        if (best_tiles < 0 || tiles < best_tiles || (tiles == best_tiles && ir * ic < best_in)) {
+            best_tiles = tiles; best_in = ir * ic;
+            r.TR = tr; r.TC = tc; r.IR = ir; r.IC = ic; r.tiles = tiles; r.tiles_x = tx; r.tiles_y = ty; r.lds = lds;
+        }
+    }
+    r.ok = best_tiles > 0;
+    return r;
+}
+}  // namespace
+
+bool dsblock_eligible(const DsBlockP& p) {
+    static const bool on = [] { const char* e = getenv("OAR_FUSE_DSBLOCK"); return !e || atoi(e) != 0; }();
+    return on && ds_shape(p).ok;
+}
+
+void dsblock(hipStream_t s, const DsBlockP& b) {
+    const DsPlanShape sh = ds_shape(b);
+    OAR_CHECK(sh.ok, OAR_INTERNAL, "dsblock: called on an ineligible block");
+    DsP p{};
+    p.x = b.x; p.y = b.y; p.wd = b.wd; p.bd = b.bd; p.wp = reinterpret_cast<const uint4*>(b.wp); p.bp = b.bp; p.res = b.residual; p.se = b.se;
+    p.N = b.N; p.H = b.H; p.W = b.W; p.C = b.C; p.Ho = b.Ho; p.Wo = b.Wo; p.Cout = b.Cout;
+    p.sh = b.sh; p.sw = b.sw; p.pt = b.pt; p.pl = b.pl;
+    p.act1 = b.act1.kind; p.a1 = b.act1.alpha; p.b1 = b.act1.beta;
+    p.act2 = b.act2.kind; p.a2 = b.act2.alpha; p.b2 = b.act2.beta;
+    p.TR = sh.TR; p.TC = sh.TC; p.IR = sh.IR; p.IC = sh.IC; p.tiles_x = sh.tiles_x; p.tiles_y = sh.tiles_y; p.tiles = sh.tiles;
+    p.KC = (b.C + 31) / 32; p.NF = (b.Cout + 15) / 16; p.y_ld = b.y_ld;
+    // two workgroups per CU when LDS allows (and the variant's registers: the narrow layouts fit 128 VGPRs)
+    const int per_cu = sh.lds * 2 <= 160 * 1024 ? 2 : 1;
+    long grid = std::min<long>(sh.tiles, 256L * per_cu);
+    grid = std::max<long>(8, (grid + 7) / 8 * 8);   // a multiple of the 8 XCDs: workgroup i runs on XCD i % 8 and walks that XCD's band of tiles
+    const double px_in = (double)b.N * b.H * b.W, px_out = (double)b.N * b.Ho * b.Wo;
+    const double bytes = 4.0 * (px_in * b.C + px_out * b.Cout * (b.residual ? 2 : 1)) + 4.0 * b.ks * b.ks * b.C + 6.0 * b.C * b.Cout;
+    const double flops = 2.0 * px_out * b.C * (b.ks * b.ks + (double)b.Cout);
+    char pname[96];
+    const char* cls = "dsblock";
+    if (Profiler::get().detail) { snprintf(pname, sizeof pname, "dsblock px=%ld C=%d N=%d k%d s%dx%d t%dx%d", (long)px_out, b.C, b.Cout, b.ks, b.sh, b.sw, sh.TR, sh.TC); cls = pname; }
+    ProfScope ps(s, cls, bytes, flops, true);
+    if (b.ks == 3 && b.sw == 1) dsblock_launch_k3s1(s, p, sh.nfw, sh.pfw, (int)grid, sh.lds, ps.start(), ps.stop());
+    else if (b.ks == 3) dsblock_launch_k3s2(s, p, sh.nfw, sh.pfw, (int)grid, sh.lds, ps.start(), ps.stop());
+    else if (b.sw == 1) dsblock_launch_k5s1(s, p, sh.nfw, sh.pfw, (int)grid, sh.lds, ps.start(), ps.stop());
+    else dsblock_launch_k5s2(s, p, sh.nfw, sh.pfw, (int)grid, sh.lds, ps.start(), ps.stop());
+}
+
+}  // namespace k
+}  // namespace oar

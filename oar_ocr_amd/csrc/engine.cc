@@ -1,5 +1,7 @@
 #include "engine.h"
 
+#include "dsblock.h"
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -418,6 +420,55 @@ void Engine::rewrite_graph(OnnxModel& m) {
         for (int i = 0; i < (int)nodes.size(); ++i) if (!dead[i]) keep.push_back(std::move(nodes[i]));
         nodes.swap(keep);
     }
+    // ---- pass 7: depthwise-separable block: Conv (depthwise k x k, folded activation) -> Conv (1 x 1, folded activation /
+    // residual) with nothing else reading the expanded tensor becomes ONE DSBlock node (csrc/dsblock.inc: the depthwise
+    // output stays in LDS and feeds the matrix pipe).  Shapes are only known at plan time: op_dsblock falls back to the two
+    // convolutions when dsblock_eligible() says no.  OAR_FUSE_DSBLOCK=0 keeps them apart.
+    {
+        const char* fe = getenv("OAR_FUSE_DSBLOCK");
+        const bool fuse = !fe || atoi(fe) != 0;
+        auto cons = consumers(nodes);
+        std::vector<bool> dead(nodes.size(), false);
+        auto ints = [](const GNode& c, const char* k, int64_t dflt) { auto v = c.ais(k); return v.empty() ? std::vector<int64_t>{dflt, dflt} : v; };
+        for (int i = 0; fuse && i < (int)nodes.size(); ++i) {
+            const GNode& d = nodes[i];
+            if (dead[i] || d.op != "Conv" || d.in.size() < 2 || !is_init(d.in[1]) || !d.residual.empty()) continue;
+            const HostTensor& wd = inits_[d.in[1]];
+            if (wd.dims.size() != 4 || wd.dims[1] != 1 || wd.dims[2] != wd.dims[3] || (wd.dims[2] != 3 && wd.dims[2] != 5)) continue;
+            if (d.ai("group", 1) != wd.dims[0] || wd.dims[0] < 8) continue;
+            for (auto v : d.ais("dilations")) if (v != 1) goto next_node;
+            if (d.as("auto_pad", "NOTSET") != "NOTSET" || (d.in.size() > 2 && !d.in[2].empty() && !is_init(d.in[2]))) continue;
+            {
+                const std::string& mid = d.out[0];
+                if (graph_outs.count(mid) || cons[mid].size() != 1) continue;
+                const int j = cons[mid][0];
+                GNode& pw = nodes[j];
+                if (dead[j] || pw.op != "Conv" || pw.in[0] != mid || pw.in.size() < 2 || !is_init(pw.in[1]) || pw.ai("group", 1) != 1) continue;
+                const HostTensor& wp = inits_[pw.in[1]];
+                if (wp.dims.size() != 4 || wp.dims[2] != 1 || wp.dims[3] != 1 || wp.dims[1] != wd.dims[0]) continue;
+                bool plain = pw.as("auto_pad", "NOTSET") == "NOTSET" && (pw.in.size() < 3 || pw.in[2].empty() || is_init(pw.in[2]));
+                for (auto v : ints(pw, "strides", 1)) plain = plain && v == 1;
+                for (auto v : pw.ais("pads")) plain = plain && v == 0;
+                if (!plain) continue;
+                GNode f;
+                f.op = "DSBlock";
+                f.in = {d.in[0], d.in[1], d.in.size() > 2 ? d.in[2] : std::string(), pw.in[1], pw.in.size() > 2 ? pw.in[2] : std::string()};
+                f.out = {pw.out[0]};
+                f.attrs = d.attrs;                      // strides / pads / kernel_shape of the depthwise conv
+                f.act = pw.act; f.residual = pw.residual;
+                Attr k1; k1.kind = Attr::I; k1.i = d.act.kind; f.attrs["act1"] = k1;
+                Attr al; al.kind = Attr::F; al.f = d.act.alpha; f.attrs["act1_alpha"] = al;
+                Attr be; be.kind = Attr::F; be.f = d.act.beta; f.attrs["act1_beta"] = be;
+                Attr mn; mn.kind = Attr::S; mn.s = mid; f.attrs["mid_name"] = mn;
+                dead[i] = true;
+                nodes[j] = std::move(f);   // at the pointwise conv's position: a folded residual is computed by then
+            }
+        next_node:;
+        }
+        std::vector<GNode> keep;
+        for (int i = 0; i < (int)nodes.size(); ++i) if (!dead[i]) keep.push_back(std::move(nodes[i]));
+        nodes.swap(keep);
+    }
     for (int i = 0; i < (int)nodes.size(); ++i) nodes[i].id = i;
     nodes_ = std::move(nodes);
 }
@@ -788,6 +839,59 @@ struct Planner {
             if (kind == 0) k::conv_igemm(c.s, q);
             else if (kind == 1) k::conv_dw(c.s, q);
             else k::conv_direct(c.s, q);
+        }, flops, bytes);
+    }
+
+    // fused depthwise-separable block (rewrite pass 7)
+    void op_dsblock(const GNode& n) {
+        TInfo x = get(n.in[0]);
+        const TInfo &wdt = get(n.in[1]), &wpt = get(n.in[3]);
+        OAR_CHECK(wdt.ht && wpt.ht, OAR_UNSUPPORTED_OP, "DSBlock: weights must be initializers");
+        const HostTensor &WD = *wdt.ht, &WP = *wpt.ht;
+        // the two convolutions this node stands for (used when the fused kernel does not take the shape)
+        GNode dwn, pwn;
+        dwn.op = "Conv"; dwn.in = {n.in[0], n.in[1]}; if (!n.in[2].empty()) dwn.in.push_back(n.in[2]);
+        dwn.out = {n.as("mid_name", n.out[0] + "::dw")}; dwn.attrs = n.attrs;
+        dwn.act.kind = (int)n.ai("act1", 0); dwn.act.alpha = n.af("act1_alpha", 0.f); dwn.act.beta = n.af("act1_beta", 0.f);
+        pwn.op = "Conv"; pwn.in = {dwn.out[0], n.in[3]}; if (!n.in[4].empty()) pwn.in.push_back(n.in[4]);
+        pwn.out = n.out; pwn.act = n.act; pwn.residual = n.residual;
+        Attr g1; g1.kind = Attr::I; g1.i = 1; pwn.attrs["group"] = g1;
+        auto unfused = [&]() { op_conv(dwn); op_conv(pwn); };
+        if (x.dims.size() != 4 || x.host_int) return unfused();
+        const int64_t N = x.dims[0], C = x.dims[1], H = x.dims[2], W = x.dims[3], ks = WD.dims[2], Cout = WP.dims[0];
+        OAR_CHECK(WD.dims[0] == C && WP.dims[1] == C, OAR_SHAPE_MISMATCH, "DSBlock: channel mismatch at " + n.out[0]);
+        auto st = n.ais("strides");
+        const int64_t sh = st.size() == 2 ? st[0] : 1, sw = st.size() == 2 ? st[1] : 1;
+        int64_t pt, pl, pb, pr;
+        get_pads(n, H, W, ks, ks, sh, sw, 1, 1, pt, pl, pb, pr);
+        const int64_t Ho = (H + pt + pb - (ks - 1) - 1) / sh + 1, Wo = (W + pl + pr - (ks - 1) - 1) / sw + 1;
+        k::DsBlockP p{};
+        p.N = (int)N; p.H = (int)H; p.W = (int)W; p.C = (int)C; p.Ho = (int)Ho; p.Wo = (int)Wo; p.Cout = (int)Cout;
+        p.ks = (int)ks; p.sh = (int)sh; p.sw = (int)sw; p.pt = (int)pt; p.pl = (int)pl;
+        p.act1 = dwn.act; p.act2 = n.act; p.y_ld = (int)Cout;
+        Loc res;
+        if (!n.residual.empty()) {
+            TInfo r = get(n.residual);
+            if (r.host_int || r.dims != std::vector<int64_t>{N, Cout, Ho, Wo}) return unfused();   // broadcasting add: op_conv splits it off
+        }
+        if (Ho <= 0 || Wo <= 0 || !k::dsblock_eligible(p)) return unfused();
+        if (!n.residual.empty()) res = to_clast_loc(get(n.residual));
+        Loc xin = to_clast_loc(x);
+        p.wd = conv_weight_dw(dwn, WD);
+        p.bd = n.in[2].empty() ? nullptr : get(n.in[2]).loc.cptr;
+        p.wp = conv_weight_igemm(pwn, WP, k::IGEMM_W_X6);
+        p.bp = n.in[4].empty() ? nullptr : get(n.in[4]).loc.cptr;
+        if (!n.in[2].empty()) OAR_CHECK((int64_t)get(n.in[2]).ht->f.size() == C, OAR_MODEL_LOAD, "DSBlock: depthwise bias size");
+        if (!n.in[4].empty()) OAR_CHECK((int64_t)get(n.in[4]).ht->f.size() == Cout, OAR_MODEL_LOAD, "DSBlock: pointwise bias size");
+        TInfo& y = new_out(n.out[0], {N, Cout, Ho, Wo}, Layout::CLAST);
+        Loc yl = y.loc;
+        const bool has_res = res.kind != Loc::NONE;
+        const double flops = 2.0 * N * Ho * Wo * C * (ks * ks + (double)Cout);
+        const double bytes = 4.0 * (N * H * W * C + N * Ho * Wo * Cout * (has_res ? 2 : 1) + numel(WD.dims) + numel(WP.dims));
+        step([=](const RunCtx& c) {
+            k::DsBlockP q = p;
+            q.x = c.at(xin); q.y = c.mut(yl); q.residual = has_res ? c.at(res) : nullptr;
+            k::dsblock(c.s, q);
         }, flops, bytes);
     }
 
@@ -1916,6 +2020,7 @@ struct Planner {
         if (op == "Softmax") return op_softmax(n);
         if (op == "Attention") return op_attention(n);
         if (op == "SEGate") return op_se_gate(n);
+        if (op == "DSBlock") return op_dsblock(n);
         if (op == "LayerNormalization") return op_layernorm(n);
         if (op == "Identity") { const TInfo& x = get(n.in[0]); if (x.host_int) { vals[n.out[0]] = x; } else { TInfo xx = x; alias_out(n.out[0], xx, xx.dims, xx.layout); } return; }
         if (op == "Cast") {   // device tensors are f32 whatever they are called: float <-> bool casts of 0/1 masks are aliases

@@ -375,3 +375,37 @@ def test_plan_cache_is_lru_bounded(monkeypatch):
     for a, b in zip(first, again):
         assert np.array_equal(a, b)
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ fused depthwise-separable block
+DS_CASES = [  # (C, Cout, k, stride, N, H, W, act, residual)
+    (16, 24, 3, (1, 1), 2, 24, 40, "hswish", False), (24, 48, 3, (1, 1), 1, 24, 33, "hswish", False), (48, 48, 3, (1, 1), 3, 12, 80, "relu", True),
+    (48, 96, 3, (2, 1), 2, 24, 50, "hswish", False), (96, 192, 3, (1, 2), 2, 12, 64, "hswish", False), (192, 192, 5, (1, 1), 3, 12, 40, "hswish", False),
+    (64, 128, 5, (2, 2), 2, 30, 46, "hswish", False), (128, 128, 5, (1, 1), 2, 15, 23, "hswish", True), (32, 64, 3, (2, 2), 1, 37, 61, "relu", False),
+    (192, 256, 5, (2, 1), 2, 12, 40, "swish", False), (8, 16, 3, (1, 1), 1, 9, 17, "hswish", False), (72, 40, 5, (1, 1), 1, 20, 36, None, False),
+]
+
+
+@pytest.mark.parametrize("case", DS_CASES, ids=[f"C{c[0]}-N{c[1]}-k{c[2]}-s{c[3][0]}{c[3][1]}" for c in DS_CASES])
+def test_fused_dsblock_matches_oracle(case, monkeypatch):
+    """Conv(depthwise k x k) + act -> Conv(1 x 1) + act (+ residual) runs as one kernel (csrc/dsblock.inc: depthwise on the
+    VALU pipe into LDS operand fragments, pointwise as bf16x6 MFMAs).  Every wave layout, both kernel sizes, all four
+    stride combinations, partial edge tiles and channel counts that are not multiples of 32 / 16 -- against the torch-CPU
+    interpreter, and against the same graph with the fusion switched off (OAR_FUSE_DSBLOCK=0)."""
+    C, Cout, k, stride, N, H, W, act, residual = case
+    net = models._Net("ds", seed=C * 7 + Cout, decomposed_hswish=False)
+    g = net.g
+    g.add_input("x", ["N", C, "H", "W"])
+    y = net.conv("x", C, C, k, stride, groups=C, act=act)
+    z = net.conv(y, C, Cout, 1, 1, act=None if residual else act)
+    if residual:
+        r = net.conv("x", C, Cout, 1, stride)              # a second branch with the output's shape
+        z = g.op("Relu", [g.op("Add", [z, r])])
+    g.nodes.append(models.node("Identity", [z], ["out"]))
+    g.add_output("out", ["N", Cout, "H", "W"])
+    m = g.model()
+    x = np.random.default_rng(1).standard_normal((N, C, H, W)).astype(np.float32)
+    got, ref = _check(m, x, tol=2e-4)
+    monkeypatch.setenv("OAR_FUSE_DSBLOCK", "0")
+    plain = api.OrtInfer(m).infer(x)[0][1]
+    assert np.abs(plain - got[0][1]).max() <= 2e-4 * max(1.0, float(np.abs(plain).max()))
