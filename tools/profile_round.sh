@@ -1,8 +1,22 @@
+#!/bin/bash
+# One profiling session of the bench workload on the GPU box (run from the repo root through gpurun):
+#   1. rocprofv3 --kernel-trace --stats            -> gpurun_out/prof_<tag>/<tag>_kernel_stats.csv
+#   2. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE     -> gpurun_out/pmc_FETCH_SIZE, pmc_WRITE_SIZE   (separate passes: TCC has 4 slots)
+#   3. rocprofv3 --pmc <matrix-pipe counters>      -> gpurun_out/pmc_MFMA   (SQ_VALU_MFMA_BUSY_CYCLES, MOPS, GRBM_GUI_ACTIVE, ...)
+#   4. the same matrix-pipe counters over tools/mfma_peak (a kernel that IS at the bf16 / f32 MFMA peak): calibrates the
+#      utilisation formula used by tools/pmc_summary.py
+# PMC passes never carry --kernel-trace / --stats (gpurun refuses the combination).  Then: python tools/make_profile_summaries.py <tag> 5 profiles/r2
+TAG=${1:-r2a}
 R=$PWD; cd /tmp; export TMPDIR=/tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r1j -o r1j -- python $R/bench.py --steps 5 --warmup 2 --cpu-pages 0 > $R/gpurun_out/prof_r1j.log 2>&1 < /dev/null
-for c in FETCH_SIZE WRITE_SIZE SQ_WAVES; do
+BENCH="python $R/bench.py --cpu-pages 0 --no-device-resident"
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o $TAG -- $BENCH --steps 5 --warmup 2 > $R/gpurun_out/prof_$TAG.log 2>&1 < /dev/null
+for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_$c
-  timeout -k 10 500 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o p -- python $R/bench.py --steps 2 --warmup 1 --cpu-pages 0 --no-prof > $R/gpurun_out/pmc_$c.log 2>&1 < /dev/null
+  timeout -k 10 500 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o p -- $BENCH --steps 2 --warmup 1 --no-prof > $R/gpurun_out/pmc_$c.log 2>&1 < /dev/null
 done
-ls $R/gpurun_out/prof_r1j $R/gpurun_out/pmc_FETCH_SIZE | head; tail -2 $R/gpurun_out/prof_r1j.log | cut -c1-400
-cd $R; timeout 300 python bench.py --steps 10 --warmup 3 > gpurun_out/bench_final2.json 2> gpurun_out/bench_final2.err; tail -c 600 gpurun_out/bench_final2.json
+MFMA="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
+rm -rf $R/gpurun_out/pmc_MFMA $R/gpurun_out/pmc_MFMA_peak
+timeout -k 10 500 rocprofv3 --pmc $MFMA --output-format csv -d $R/gpurun_out/pmc_MFMA -o p -- $BENCH --steps 2 --warmup 1 --no-prof > $R/gpurun_out/pmc_MFMA.log 2>&1 < /dev/null
+if [ ! -x $R/tools/mfma_peak ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $R/tools/mfma_peak $R/tools/mfma_peak.hip > /dev/null 2>&1; fi
+timeout -k 10 200 rocprofv3 --pmc $MFMA --output-format csv -d $R/gpurun_out/pmc_MFMA_peak -o p -- $R/tools/mfma_peak > $R/gpurun_out/pmc_MFMA_peak.log 2>&1 < /dev/null
+ls $R/gpurun_out/prof_$TAG $R/gpurun_out/pmc_MFMA $R/gpurun_out/pmc_MFMA_peak | head -20; tail -2 $R/gpurun_out/prof_$TAG.log | cut -c1-300
