@@ -58,12 +58,41 @@ typedef struct {
     int32_t reserved;
 } oar_engine_cfg;
 
+/* TensorOutput::{F32, I64} (core/inference/tensor_output.rs:16-21) */
+typedef enum { OAR_DTYPE_F32 = 1, OAR_DTYPE_I64 = 7 } oar_dtype;
 typedef struct {
     int32_t rank;
     int64_t dims[8];
-    float* data;            /* host memory owned by the library; free with oar_tensor_free           */
+    float* data;            /* dtype F32: host memory owned by the library; free with oar_tensor_free */
     char name[64];
+    int32_t dtype;          /* oar_dtype                                                             */
+    int32_t reserved;
+    int64_t* data_i64;      /* dtype I64 (token ids, ArgMax, shapes): data is NULL, this holds the values */
 } oar_tensor;
+
+/* One named f32 input of OrtInfer::infer (`&[(&str, TensorInput)]`, ort_infer_execution.rs:12-19, 121-135): Array2 / Array3 /
+ * Array4 are rank 2 / 3 / 4 here.  name NULL or "" = the graph's primary input. */
+typedef struct {
+    const char* name;
+    const float* data;      /* row-major, host memory                                               */
+    const int64_t* dims;
+    int32_t rank;
+    int32_t reserved;
+} oar_input;
+
+/* Declared name / element type / shape of one graph input or output (dynamic dimensions are -1), as
+ * OrtInfer::input_names_from_model / primary_input_shape / output_shapes report them (core/inference/mod.rs:66-112). */
+typedef struct {
+    char name[64];
+    int32_t dtype;          /* onnx TensorProto.DataType as declared by the model file (1 = f32, 7 = i64, 0 = undeclared) */
+    int32_t rank;           /* -1: the model file declares no shape                                  */
+    int64_t dims[8];
+} oar_io_info;
+
+/* Borrowed view of the first output (OrtInfer::infer_first_output_f32's `FnOnce(&[i64], &[f32])`, ort_infer_execution.rs:234-306):
+ * `data` points into a pinned staging buffer owned by the engine and is valid only until the callback returns.
+ * A non-zero return value aborts with OAR_INVALID_INPUT and is reported through oar_last_error. */
+typedef int32_t (*oar_output_view_fn)(void* user, const int64_t* dims, int32_t rank, const float* data);
 
 oar_status oar_engine_create(const uint8_t* onnx, size_t onnx_len, const oar_engine_cfg* cfg, oar_engine** out);
 void oar_engine_destroy(oar_engine* e);
@@ -74,6 +103,17 @@ oar_status oar_engine_input_name(const oar_engine* e, char* buf, size_t cap);
 oar_status oar_engine_run(oar_engine* e, const float* input, const int64_t* dims, int32_t rank,
                           oar_tensor* outs, int32_t max_out, int32_t* n_out);
 void oar_tensor_free(oar_tensor* t);
+/* OrtInfer::infer (ort_infer_execution.rs:121-219): n_in named f32 inputs -- every declared graph input must be given exactly
+ * once (OAR_INVALID_INPUT otherwise, naming the missing / unknown one) -- all graph outputs back, F32 or I64. */
+oar_status oar_engine_run_named(oar_engine* e, const oar_input* inputs, int32_t n_in, oar_tensor* outs, int32_t max_out,
+                                int32_t* n_out);
+/* OrtInfer::infer_first_output_f32 (ort_infer_execution.rs:234-306): runs the graph and hands the FIRST output to `fn`
+ * without an owned copy.  OAR_SHAPE_MISMATCH when that output is not f32. */
+oar_status oar_engine_run_first_f32(oar_engine* e, const oar_input* inputs, int32_t n_in, oar_output_view_fn fn, void* user);
+/* Declared inputs (initializers excluded; entry 0 is the primary input) and outputs of the model file.  Either array may
+ * be NULL to query the counts only. */
+oar_status oar_engine_io(const oar_engine* e, oar_io_info* inputs, int32_t max_in, int32_t* n_in, oar_io_info* outputs,
+                         int32_t max_out, int32_t* n_out);
 /* Analytic cost of the plan for a given input shape (what roofline.achieved is computed from):
  * flops = sum 2*MACs over conv/matmul steps; bytes = sum (activations in + out + weights once). */
 oar_status oar_engine_cost(oar_engine* e, const int64_t* dims, int32_t rank, double* flops, double* bytes,

@@ -39,7 +39,20 @@ class EngineCfg(C.Structure):
 
 
 class Tensor(C.Structure):
-    _fields_ = [("rank", C.c_int32), ("dims", C.c_int64 * 8), ("data", C.POINTER(C.c_float)), ("name", C.c_char * 64)]
+    _fields_ = [("rank", C.c_int32), ("dims", C.c_int64 * 8), ("data", C.POINTER(C.c_float)), ("name", C.c_char * 64),
+                ("dtype", C.c_int32), ("reserved", C.c_int32), ("data_i64", C.POINTER(C.c_int64))]
+
+
+class Input(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("dims", C.POINTER(C.c_int64)), ("rank", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class IoInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("dtype", C.c_int32), ("rank", C.c_int32), ("dims", C.c_int64 * 8)]
+
+
+OUTPUT_VIEW_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_float))
 
 
 class DetCfg(C.Structure):
@@ -102,7 +115,7 @@ class ProfEntry(C.Structure):
 
 EXPORTS = [
     "oar_last_error", "oar_version", "oar_device_count", "oar_engine_create", "oar_engine_destroy", "oar_engine_input_name",
-    "oar_engine_run", "oar_tensor_free", "oar_engine_cost", "oar_det_create", "oar_det_destroy", "oar_det_run", "oar_det_result_free",
+    "oar_engine_run", "oar_engine_run_named", "oar_engine_run_first_f32", "oar_engine_io", "oar_tensor_free", "oar_engine_cost", "oar_det_create", "oar_det_destroy", "oar_det_run", "oar_det_result_free",
     "oar_db_postprocess", "oar_rec_create", "oar_rec_destroy", "oar_rec_run", "oar_rec_result_free", "oar_ocr_create", "oar_ocr_destroy",
     "oar_ocr_predict", "oar_ocr_predict_device", "oar_ocr_result_free", "oar_dev_alloc", "oar_dev_upload", "oar_dev_download",
     "oar_dev_free", "oar_dev_synchronize", "oar_k_normalize", "oar_k_rec_preprocess", "oar_k_resize_triangle", "oar_k_threshold",
@@ -135,6 +148,9 @@ def lib():
     L.oar_engine_destroy.restype = None
     L.oar_engine_input_name.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.oar_engine_run.argtypes = [vp, vp, C.POINTER(C.c_int64), C.c_int32, C.POINTER(Tensor), C.c_int32, C.POINTER(C.c_int32)]
+    L.oar_engine_run_named.argtypes = [vp, C.POINTER(Input), C.c_int32, C.POINTER(Tensor), C.c_int32, C.POINTER(C.c_int32)]
+    L.oar_engine_run_first_f32.argtypes = [vp, C.POINTER(Input), C.c_int32, OUTPUT_VIEW_FN, vp]
+    L.oar_engine_io.argtypes = [vp, C.POINTER(IoInfo), C.c_int32, C.POINTER(C.c_int32), C.POINTER(IoInfo), C.c_int32, C.POINTER(C.c_int32)]
     L.oar_tensor_free.argtypes = [C.POINTER(Tensor)]
     L.oar_tensor_free.restype = None
     L.oar_engine_cost.argtypes = [vp, C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
@@ -288,22 +304,89 @@ class OrtInfer:
         _check(lib().oar_engine_input_name(self._h, buf, 256))
         return buf.value.decode()
 
-    def infer(self, x: np.ndarray):
-        """Returns [(name, ndarray)] for every graph output (ort_infer_execution.rs:121-219)."""
-        x = np.ascontiguousarray(x, dtype=np.float32)
-        dims = (C.c_int64 * x.ndim)(*x.shape)
-        outs = (Tensor * 16)()
-        n = C.c_int32(0)
-        _check(lib().oar_engine_run(self._h, _p(x), dims, x.ndim, outs, 16, C.byref(n)))
+    @staticmethod
+    def _collect(outs, n):
         res = []
-        for i in range(n.value):
+        for i in range(n):
             t = outs[i]
             shape = tuple(t.dims[k] for k in range(t.rank))
             cnt = int(np.prod(shape)) if shape else 1
-            arr = np.ctypeslib.as_array(t.data, shape=(cnt,)).copy().reshape(shape)
+            src = t.data_i64 if t.dtype == 7 else t.data     # TensorOutput::I64 / ::F32 (tensor_output.rs:16-21)
+            arr = (np.ctypeslib.as_array(src, shape=(cnt,)).copy() if cnt else np.zeros(0, np.int64 if t.dtype == 7 else np.float32)).reshape(shape)
             res.append((t.name.decode(), arr))
             lib().oar_tensor_free(C.byref(outs[i]))
         return res
+
+    @staticmethod
+    def _inputs(inputs):
+        keep, arr = [], (Input * len(inputs))()
+        for i, (name, x) in enumerate(inputs):
+            x = np.ascontiguousarray(x, dtype=np.float32)
+            dims = (C.c_int64 * x.ndim)(*x.shape)
+            keep += [x, dims]
+            arr[i] = Input(name.encode() if name else None, x.ctypes.data_as(C.POINTER(C.c_float)), dims, x.ndim, 0)
+        return arr, keep
+
+    def infer(self, x, *more):
+        """Returns [(name, ndarray)] for every graph output (ort_infer_execution.rs:121-219).  `x` is either one f32 array
+        (bound to the primary input) or a list of (name, array) pairs -- the reference's `&[(&str, TensorInput)]`."""
+        outs = (Tensor * 16)()
+        n = C.c_int32(0)
+        if isinstance(x, (list, tuple)) and x and isinstance(x[0], (list, tuple)):
+            arr, keep = self._inputs(list(x))
+            _check(lib().oar_engine_run_named(self._h, arr, len(arr), outs, 16, C.byref(n)))
+            return self._collect(outs, n.value)
+        if isinstance(x, (list, tuple)) and not x:
+            _check(lib().oar_engine_run_named(self._h, None, 0, outs, 16, C.byref(n)))
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        dims = (C.c_int64 * x.ndim)(*x.shape)
+        _check(lib().oar_engine_run(self._h, _p(x), dims, x.ndim, outs, 16, C.byref(n)))
+        return self._collect(outs, n.value)
+
+    def infer_first_output_f32(self, inputs, fn):
+        """`fn(shape, data)` sees the first output as a borrowed f32 view, valid only inside the call
+        (OrtInfer::infer_first_output_f32, ort_infer_execution.rs:234-306); returns fn's result."""
+        if isinstance(inputs, np.ndarray):
+            inputs = [("", inputs)]
+        arr, keep = self._inputs(list(inputs))
+        box = {}
+
+        def tramp(_user, dims, rank, data):
+            try:
+                shape = tuple(dims[k] for k in range(rank))
+                cnt = int(np.prod(shape)) if shape else 1
+                view = np.ctypeslib.as_array(data, shape=(cnt,)).reshape(shape) if cnt else np.zeros(shape, np.float32)
+                box["r"] = fn(shape, view)
+                return 0
+            except Exception as ex:      # noqa: BLE001 -- must not unwind through the C frame
+                box["e"] = ex
+                return 1
+
+        cb = OUTPUT_VIEW_FN(tramp)
+        st = lib().oar_engine_run_first_f32(self._h, arr, len(arr), cb, None)
+        if "e" in box:
+            raise box["e"]
+        _check(st)
+        return box.get("r")
+
+    def _io(self):
+        ins, outs = (IoInfo * 32)(), (IoInfo * 32)()
+        ni, no = C.c_int32(0), C.c_int32(0)
+        _check(lib().oar_engine_io(self._h, ins, 32, C.byref(ni), outs, 32, C.byref(no)))
+        conv = lambda a, n: [(a[i].name.decode(), a[i].dtype, None if a[i].rank < 0 else [a[i].dims[k] for k in range(a[i].rank)]) for i in range(n)]
+        return conv(ins, ni.value), conv(outs, no.value)
+
+    def input_names_from_model(self):
+        """core/inference/mod.rs:66-79"""
+        return [n for n, _, _ in self._io()[0]]
+
+    def primary_input_shape(self):
+        """Declared shape of the first input, dynamic dimensions as -1; None when undeclared (mod.rs:81-92)."""
+        return self._io()[0][0][2]
+
+    def output_shapes(self):
+        """[(name, declared shape)] of the outputs that declare one (mod.rs:94-112)."""
+        return [(n, sh) for n, _, sh in self._io()[1] if sh is not None]
 
     def cache_stats(self):
         """(cached plans, evicted plans): plans are per input shape, LRU-bounded (OAR_PLAN_CACHE, default 256)."""

@@ -11,7 +11,7 @@ extern std::atomic<int> g_inject_batched_det_failures;   // pipeline.cc
 }
 using namespace oar;
 
-struct oar_engine { std::unique_ptr<Engine> e; };
+struct oar_engine { std::unique_ptr<Engine> e; PinBuf view; };   // view: staging for oar_engine_run_first_f32
 struct oar_det { std::unique_ptr<Detector> d; };
 struct oar_rec { std::unique_ptr<Recognizer> r; };
 struct oar_ocr { std::unique_ptr<Ocr> o; };
@@ -123,6 +123,81 @@ oar_status oar_engine_input_name(const oar_engine* e, char* buf, size_t cap) {
     });
 }
 
+namespace {
+// copies every plan output back to the host (F32 as floats; I64 either from the plan-time host value or by converting the
+// integer-valued f32 device tensor).  The caller holds the engine mutex and synchronises the stream afterwards.
+struct PendingI64 { oar_tensor* t; std::vector<float> tmp; int64_t n; };
+void fetch_outputs(Engine& E, const Plan& p, oar_tensor* outs, int32_t max_out, int32_t* n_out) {
+    OAR_CHECK((int)p.outputs.size() <= max_out, OAR_INVALID_INPUT, "oar_engine_run: outs too small");
+    for (int i = 0; i < max_out; ++i) std::memset(&outs[i], 0, sizeof outs[i]);
+    std::vector<PendingI64> pend;
+    pend.reserve(p.outputs.size());
+    try {
+        for (size_t i = 0; i < p.outputs.size(); ++i) {
+            const PlanOutput& po = p.outputs[i];
+            oar_tensor& t = outs[i];
+            OAR_CHECK(po.dims.size() <= 8, OAR_UNSUPPORTED_OP, "graph output of rank > 8");
+            t.rank = (int32_t)po.dims.size();
+            int64_t n = 1;
+            for (size_t k = 0; k < po.dims.size(); ++k) { t.dims[k] = po.dims[k]; n *= po.dims[k]; }
+            snprintf(t.name, sizeof t.name, "%s", po.name.c_str());
+            t.dtype = po.dtype == 7 ? OAR_DTYPE_I64 : OAR_DTYPE_F32;
+            if (po.dtype == 7) {
+                t.data_i64 = cmalloc<int64_t>((size_t)std::max<int64_t>(n, 1));
+                if (po.on_host) {
+                    for (int64_t k = 0; k < n; ++k) t.data_i64[k] = (int64_t)po.host_vals[k];
+                } else {
+                    pend.push_back(PendingI64{&t, std::vector<float>((size_t)n), n});
+                    if (n) OAR_HIP(hipMemcpyAsync(pend.back().tmp.data(), E.out_ptr(po.loc), (size_t)n * 4, hipMemcpyDeviceToHost, E.stream()));
+                }
+            } else {
+                t.data = cmalloc<float>((size_t)std::max<int64_t>(n, 1));
+                if (po.on_host) {
+                    for (int64_t k = 0; k < n; ++k) t.data[k] = (float)po.host_vals[k];
+                } else if (n) {
+                    OAR_HIP(hipMemcpyAsync(t.data, E.out_ptr(po.loc), (size_t)n * 4, hipMemcpyDeviceToHost, E.stream()));
+                }
+            }
+        }
+        OAR_HIP(hipStreamSynchronize(E.stream()));
+    } catch (...) {
+        (void)hipStreamSynchronize(E.stream());
+        for (int i = 0; i < max_out; ++i) oar_tensor_free(&outs[i]);
+        throw;
+    }
+    for (auto& q : pend)
+        for (int64_t k = 0; k < q.n; ++k) q.t->data_i64[k] = (int64_t)std::llround((double)q.tmp[(size_t)k]);
+    *n_out = (int32_t)p.outputs.size();
+}
+
+// uploads the named inputs in the order the model declares them and runs the plan; `bufs` keeps the device copies alive
+const Plan& run_named(Engine& E, const oar_input* inputs, int32_t n_in, std::vector<std::unique_ptr<DevBuf>>& bufs) {
+    const auto& infos = E.input_infos();
+    OAR_CHECK(inputs && n_in > 0, OAR_INVALID_INPUT, "No inputs provided for inference");   // ort_infer_execution.rs:125-129
+    OAR_CHECK((size_t)n_in == infos.size(), OAR_INVALID_INPUT,
+              "the model declares " + std::to_string(infos.size()) + " input(s), " + std::to_string(n_in) + " given");
+    std::vector<const float*> ptrs(infos.size(), nullptr);
+    std::vector<std::vector<int64_t>> dims(infos.size());
+    for (size_t k = 0; k < infos.size(); ++k) bufs.emplace_back(new DevBuf());
+    for (int32_t i = 0; i < n_in; ++i) {
+        const oar_input& in = inputs[i];
+        OAR_CHECK(in.data && in.dims && in.rank >= 1 && in.rank <= 8, OAR_INVALID_INPUT, "input " + std::to_string(i) + ": bad tensor");
+        size_t slot = infos.size();
+        if (!in.name || !in.name[0]) slot = 0;
+        else for (size_t k = 0; k < infos.size(); ++k) if (infos[k].name == in.name) slot = k;
+        OAR_CHECK(slot < infos.size(), OAR_INVALID_INPUT, std::string("the model has no input named '") + (in.name ? in.name : "") + "'");
+        OAR_CHECK(ptrs[slot] == nullptr, OAR_INVALID_INPUT, "input '" + infos[slot].name + "' given twice");
+        int64_t cnt = 1;
+        for (int32_t k = 0; k < in.rank; ++k) { OAR_CHECK(in.dims[k] >= 0, OAR_INVALID_INPUT, "negative dimension"); cnt *= in.dims[k]; }
+        dims[slot].assign(in.dims, in.dims + in.rank);
+        bufs[slot]->reserve((size_t)std::max<int64_t>(cnt, 1) * 4);
+        if (cnt) OAR_HIP(hipMemcpyAsync(bufs[slot]->p, in.data, (size_t)cnt * 4, hipMemcpyHostToDevice, E.stream()));
+        ptrs[slot] = bufs[slot]->as<float>();
+    }
+    return E.run_multi(ptrs, dims);
+}
+}  // namespace
+
 oar_status oar_engine_run(oar_engine* e, const float* input, const int64_t* dims, int32_t rank, oar_tensor* outs, int32_t max_out,
                           int32_t* n_out) {
     return guard([&] {
@@ -130,6 +205,7 @@ oar_status oar_engine_run(oar_engine* e, const float* input, const int64_t* dims
         Engine& E = *e->e;
         std::lock_guard<std::mutex> lk(E.mutex());
         OAR_HIP(hipSetDevice(E.device()));
+        OAR_CHECK(E.input_infos().size() == 1, OAR_INVALID_INPUT, "oar_engine_run: the model declares several inputs, use oar_engine_run_named");
         std::vector<int64_t> d(dims, dims + rank);
         int64_t cnt = 1;
         for (auto v : d) { OAR_CHECK(v >= 0, OAR_INVALID_INPUT, "negative dimension"); cnt *= v; }
@@ -137,25 +213,77 @@ oar_status oar_engine_run(oar_engine* e, const float* input, const int64_t* dims
         din.reserve((size_t)std::max<int64_t>(cnt, 1) * 4);
         OAR_HIP(hipMemcpyAsync(din.p, input, (size_t)cnt * 4, hipMemcpyHostToDevice, E.stream()));
         const Plan& p = E.run(din.as<float>(), d, false);
-        OAR_CHECK((int)p.outputs.size() <= max_out, OAR_INVALID_INPUT, "oar_engine_run: outs too small");
-        for (size_t i = 0; i < p.outputs.size(); ++i) {
-            const PlanOutput& po = p.outputs[i];
-            oar_tensor& t = outs[i];
-            std::memset(&t, 0, sizeof t);
-            t.rank = (int32_t)po.dims.size();
-            int64_t n = 1;
-            for (size_t k = 0; k < po.dims.size(); ++k) { t.dims[k] = po.dims[k]; n *= po.dims[k]; }
-            snprintf(t.name, sizeof t.name, "%s", po.name.c_str());
-            t.data = cmalloc<float>((size_t)n);
-            OAR_HIP(hipMemcpyAsync(t.data, E.out_ptr(po.loc), (size_t)n * 4, hipMemcpyDeviceToHost, E.stream()));
-        }
-        OAR_HIP(hipStreamSynchronize(E.stream()));
-        *n_out = (int32_t)p.outputs.size();
+        fetch_outputs(E, p, outs, max_out, n_out);
         if (Profiler::get().enabled) Profiler::get().flush();
     });
 }
+
+oar_status oar_engine_run_named(oar_engine* e, const oar_input* inputs, int32_t n_in, oar_tensor* outs, int32_t max_out, int32_t* n_out) {
+    return guard([&] {
+        OAR_CHECK(e && outs && n_out, OAR_INVALID_INPUT, "oar_engine_run_named: bad arguments");
+        Engine& E = *e->e;
+        std::lock_guard<std::mutex> lk(E.mutex());
+        OAR_HIP(hipSetDevice(E.device()));
+        std::vector<std::unique_ptr<DevBuf>> bufs;
+        const Plan& p = run_named(E, inputs, n_in, bufs);
+        fetch_outputs(E, p, outs, max_out, n_out);
+        if (Profiler::get().enabled) Profiler::get().flush();
+    });
+}
+
+oar_status oar_engine_run_first_f32(oar_engine* e, const oar_input* inputs, int32_t n_in, oar_output_view_fn fn, void* user) {
+    return guard([&] {
+        OAR_CHECK(e && fn, OAR_INVALID_INPUT, "oar_engine_run_first_f32: bad arguments");
+        Engine& E = *e->e;
+        std::lock_guard<std::mutex> lk(E.mutex());
+        OAR_HIP(hipSetDevice(E.device()));
+        std::vector<std::unique_ptr<DevBuf>> bufs;
+        const Plan& p = run_named(E, inputs, n_in, bufs);
+        OAR_CHECK(!p.outputs.empty(), OAR_INTERNAL, "no output returned from inference");
+        const PlanOutput& po = p.outputs[0];
+        OAR_CHECK(po.dtype == 1, OAR_SHAPE_MISMATCH, "output '" + po.name + "' is not an f32 tensor");   // ort_infer_execution.rs:283-290
+        OAR_CHECK(po.dims.size() <= 8, OAR_UNSUPPORTED_OP, "graph output of rank > 8");
+        int64_t n = 1;
+        for (auto d : po.dims) n *= d;
+        e->view.reserve((size_t)std::max<int64_t>(n, 1) * 4);
+        if (po.on_host) {
+            for (int64_t k = 0; k < n; ++k) e->view.as<float>()[k] = (float)po.host_vals[k];
+        } else if (n) {
+            OAR_HIP(hipMemcpyAsync(e->view.p, E.out_ptr(po.loc), (size_t)n * 4, hipMemcpyDeviceToHost, E.stream()));
+        }
+        OAR_HIP(hipStreamSynchronize(E.stream()));
+        if (Profiler::get().enabled) Profiler::get().flush();
+        const int32_t rc = fn(user, po.dims.data(), (int32_t)po.dims.size(), e->view.as<float>());
+        OAR_CHECK(rc == 0, OAR_INVALID_INPUT, "output view callback failed with code " + std::to_string(rc));
+    });
+}
+
+oar_status oar_engine_io(const oar_engine* e, oar_io_info* inputs, int32_t max_in, int32_t* n_in, oar_io_info* outputs, int32_t max_out,
+                         int32_t* n_out) {
+    return guard([&] {
+        OAR_CHECK(e, OAR_INVALID_INPUT, "oar_engine_io: engine is null");
+        auto fill = [](const std::vector<ValueInfo>& src, oar_io_info* dst, int32_t cap, int32_t* cnt) {
+            if (cnt) *cnt = (int32_t)src.size();
+            if (!dst) return;
+            OAR_CHECK((int32_t)src.size() <= cap, OAR_INVALID_INPUT, "oar_engine_io: array too small");
+            for (size_t i = 0; i < src.size(); ++i) {
+                oar_io_info& o = dst[i];
+                std::memset(&o, 0, sizeof o);
+                snprintf(o.name, sizeof o.name, "%s", src[i].name.c_str());
+                o.dtype = src[i].elem_type;
+                o.rank = src[i].has_shape && src[i].dims.size() <= 8 ? (int32_t)src[i].dims.size() : -1;
+                for (int32_t k = 0; k < o.rank; ++k) o.dims[k] = src[i].dims[(size_t)k];
+            }
+        };
+        fill(e->e->input_infos(), inputs, max_in, n_in);
+        fill(e->e->output_infos(), outputs, max_out, n_out);
+    });
+}
+
 void oar_tensor_free(oar_tensor* t) {
-    if (t && t->data) { std::free(t->data); t->data = nullptr; }
+    if (!t) return;
+    if (t->data) { std::free(t->data); t->data = nullptr; }
+    if (t->data_i64) { std::free(t->data_i64); t->data_i64 = nullptr; }
 }
 
 oar_status oar_engine_cache_stats(oar_engine* e, uint64_t* cached_plans, uint64_t* evicted_plans) {

@@ -32,6 +32,8 @@ Engine::Engine(const uint8_t* onnx, size_t len, int device_id) : device_(device_
     validate_model(m);
     input_name_ = m.inputs[0];
     output_names_ = m.outputs;
+    input_infos_ = m.input_infos;
+    output_infos_ = m.output_infos;
     if (const char* e = getenv("OAR_PLAN_CACHE")) { long v = atol(e); if (v >= 2) plan_cap_ = (size_t)v; }
     opset_ = m.opset;
     rewrite_graph(m);
@@ -485,6 +487,7 @@ struct TInfo {
     bool host_f = false;             //   the host value is floating point: hd is authoritative
     std::vector<double> hd;
     const HostTensor* ht = nullptr;  // f32 initializer
+    bool is_int = false;             // device tensor whose f32 values are integers by construction (ArgMax, integer Cast of one)
     std::string root;                // storage root (for liveness)
     size_t bytes() const { return (size_t)std::max<int64_t>(numel(dims), 1) * 4; }
 };
@@ -1064,6 +1067,25 @@ struct Planner {
         TInfo& y = new_out(n.out[0], od, Layout::NATIVE);
         Loc yl = y.loc;
         step([=](const RunCtx& c) { k::reduce_lastdim(c.s, c.at(xin), c.mut(yl), rows, (int)C, mode); }, (double)rows * C, 4.0 * rows * (C + 1));
+    }
+
+    // ArgMax / ArgMin over the last axis
+    void op_argreduce(const GNode& n, bool is_min) {
+        TInfo x = get(n.in[0]);
+        const int r = (int)x.dims.size();
+        int64_t axis = n.ai("axis", 0);
+        if (axis < 0) axis += r;
+        OAR_CHECK(r >= 1 && axis == r - 1, OAR_UNSUPPORTED_OP, n.op + ": only the last axis is supported");
+        Loc xin = to_native_loc(x);
+        const int64_t C = x.dims[axis], rows = numel(x.dims) / std::max<int64_t>(C, 1);
+        OAR_CHECK(C >= 1 && C < (1 << 24), OAR_UNSUPPORTED_OP, n.op + ": axis length must be in [1, 2^24)");
+        std::vector<int64_t> od(x.dims.begin(), x.dims.end() - 1);
+        if (n.ai("keepdims", 1) != 0) od.push_back(1);
+        const bool last = n.ai("select_last_index", 0) != 0;
+        TInfo& y = new_out(n.out[0], od, Layout::NATIVE);
+        y.is_int = true;
+        Loc yl = y.loc;
+        step([=](const RunCtx& c) { k::argreduce_lastdim(c.s, c.at(xin), c.mut(yl), rows, (int)C, is_min, last); }, (double)rows * C, 4.0 * rows * (C + 1));
     }
 
     // ------------------------------------------------------------------ broadcast copies (Expand / Tile)
@@ -1907,7 +1929,7 @@ struct Planner {
     }
 
     bool skip_final_softmax = false;
-    void build(const std::vector<int64_t>& in_dims, bool in_clast) {
+    void build(const std::vector<int64_t>& in_dims, bool in_clast, const std::vector<std::vector<int64_t>>* extra_dims) {
         compute_last_use();
         TInfo in;
         in.dims = in_dims;
@@ -1915,6 +1937,15 @@ struct Planner {
         in.loc.kind = Loc::INPUT;
         in.root = "";
         vals[E.input_name_] = in;
+        for (size_t i = 1; extra_dims && i < extra_dims->size() && i < E.input_infos_.size(); ++i) {
+            TInfo ex;
+            ex.dims = (*extra_dims)[i];
+            ex.layout = Layout::NATIVE;
+            ex.loc.kind = Loc::EXTRA;
+            ex.loc.idx = (int)i;
+            ex.root = "";
+            vals[E.input_infos_[i].name] = ex;
+        }
         for (int i = 0; i < (int)E.nodes_.size(); ++i) {
             const GNode& n = E.nodes_[i];
             cur = i;
@@ -1933,13 +1964,24 @@ struct Planner {
             dispatch(n);
             release_dead(i);
         }
-        for (auto& on : E.output_names_) {
+        for (size_t oi = 0; oi < E.output_names_.size(); ++oi) {
+            const std::string& on = E.output_names_[oi];
             auto it = vals.find(on);
             OAR_CHECK(it != vals.end(), OAR_MODEL_LOAD, "graph output '" + on + "' was never produced");
             TInfo t = it->second;
-            OAR_CHECK(!t.host_int, OAR_UNSUPPORTED_OP, "integer graph outputs are not supported");
             PlanOutput po;
             po.name = on; po.dims = t.dims;
+            const int declared = oi < E.output_infos_.size() ? E.output_infos_[oi].elem_type : 0;
+            if (t.host_int) {   // known at plan time (Shape and friends): TensorOutput::I64 unless the value is a float
+                po.on_host = true;
+                po.dtype = t.host_f ? 1 : 7;
+                if (t.host_f) po.host_vals = t.hd;
+                else po.host_vals.assign(t.hv.begin(), t.hv.end());
+                OAR_CHECK((int64_t)po.host_vals.size() == numel(t.dims), OAR_INTERNAL, "host output '" + on + "': value / shape mismatch");
+                P.outputs.push_back(po);
+                continue;
+            }
+            po.dtype = (t.is_int || declared == 7 || declared == 6) ? 7 : 1;
             if (t.layout == Layout::CLAST) { po.has_clast = true; po.loc_clast = t.loc; }
             Loc nat = to_native_loc(t);
             if (nat.kind == Loc::ARENA && nat.off != t.loc.off) {
@@ -1994,6 +2036,8 @@ struct Planner {
         if (op == "ReduceMean") return op_reduce(n, 0);
         if (op == "ReduceSum") return op_reduce(n, 1);
         if (op == "ReduceMax") return op_reduce(n, 2);
+        if (op == "ArgMax") return op_argreduce(n, false);
+        if (op == "ArgMin") return op_argreduce(n, true);
         if (op == "ReduceMin") return op_reduce(n, 3);
         if (op == "ReduceProd") return op_reduce(n, 4);
         if (op == "Expand") return op_expand(n);
@@ -2026,8 +2070,8 @@ struct Planner {
         if (op == "Cast") {   // device tensors are f32 whatever they are called: float <-> bool casts of 0/1 masks are aliases
             const TInfo& x = get(n.in[0]);
             const int64_t to = n.ai("to", 1);
-            OAR_CHECK(to == 1 || to == 9 || to == 10 || to == 11, OAR_UNSUPPORTED_OP, "Cast of a device tensor to an integer type");
-            TInfo xx = x; alias_out(n.out[0], xx, xx.dims, xx.layout); return;
+            OAR_CHECK(to == 1 || to == 9 || to == 10 || to == 11 || x.is_int, OAR_UNSUPPORTED_OP, "Cast of a device tensor to an integer type");
+            TInfo xx = x; alias_out(n.out[0], xx, xx.dims, xx.layout).is_int = x.is_int; return;
         }
         fail(OAR_UNSUPPORTED_OP, "operator '" + op + "' is not implemented (node output " + (n.out.empty() ? "?" : n.out[0]) + ")");
     }
@@ -2082,21 +2126,26 @@ const std::set<std::string>& Engine::supported_ops() {
         "LeakyRelu", "Tanh", "Erf", "Sqrt", "Exp", "Abs", "Neg", "Reciprocal", "Log", "Gelu", "Softplus", "Clip", "Add", "Sub", "Mul", "Div", "Pow", "PRelu",
         "ReduceMean", "GridSample", "Pad", "GlobalAveragePool", "AveragePool", "MaxPool", "Resize", "Concat", "Reshape", "Flatten", "Squeeze", "Unsqueeze",
         "Transpose", "Split", "Slice", "Gather", "Gemm", "MatMul", "Softmax", "LayerNormalization", "Max", "Min", "Equal", "Less", "Greater", "And", "Or", "Not",
-        "Floor", "Ceil", "Round", "ReduceSum", "ReduceMax", "ReduceMin", "ReduceProd", "Expand", "Tile", "Where", "ConstantOfShape", "Range"};
+        "Floor", "Ceil", "Round", "ReduceSum", "ReduceMax", "ReduceMin", "ReduceProd", "Expand", "Tile", "Where", "ConstantOfShape", "Range", "ArgMax", "ArgMin"};
     return ops;
 }
 
-const Plan& Engine::plan_for(const std::vector<int64_t>& dims, bool in_clast, bool skip_final_softmax) {
+const Plan& Engine::plan_for(const std::vector<int64_t>& dims, bool in_clast, bool skip_final_softmax,
+                             const std::vector<std::vector<int64_t>>* extra_dims) {
     std::ostringstream key;
     key << (in_clast ? "L" : "N") << (skip_final_softmax ? "S" : "");
     for (auto d : dims) key << "x" << d;
+    for (size_t i = 1; extra_dims && i < extra_dims->size(); ++i) {
+        key << "|";
+        for (auto d : (*extra_dims)[i]) key << "x" << d;
+    }
     auto it = plans_.find(key.str());
     if (it != plans_.end()) { it->second->last_used = ++tick_; last_returned_ = it->second.get(); return *it->second; }
     OAR_HIP(hipSetDevice(device_));
     std::unique_ptr<Plan> p(new Plan());
     Planner pl(*this, *p);
     pl.skip_final_softmax = skip_final_softmax;
-    pl.build(dims, in_clast);
+    pl.build(dims, in_clast, extra_dims);
     evict_plans();
     p->last_used = ++tick_;
     const Plan& ref = *p;
@@ -2212,8 +2261,28 @@ const Plan& Engine::run(const float* d_in, const std::vector<int64_t>& dims, boo
     return p;
 }
 
+const Plan& Engine::run_multi(const std::vector<const float*>& d_ins, const std::vector<std::vector<int64_t>>& dims) {
+    OAR_CHECK(!d_ins.empty() && d_ins.size() == dims.size() && d_ins.size() == input_infos_.size(), OAR_INVALID_INPUT,
+              "run_multi: one tensor per declared graph input is required");
+    if (d_ins.size() == 1) return run(d_ins[0], dims[0], false);
+    const Plan& p = plan_for(dims[0], false, false, &dims);
+    OAR_HIP(hipSetDevice(device_));
+    if (arena_.cap < p.arena_bytes) {
+        OAR_HIP(hipStreamSynchronize(stream_));
+        clear_graphs();
+        arena_.reserve(p.arena_bytes);
+    }
+    last_extra_ = d_ins;
+    RunCtx c{stream_, d_ins[0], arena_.as<char>(), last_extra_.data()};
+    last_input_ = d_ins[0];
+    for (auto& st : p.steps) st(c);   // no hipGraph replay here: a captured graph bakes in one input pointer only
+    ++p.runs;
+    OAR_HIP(hipGetLastError());
+    return p;
+}
+
 const float* Engine::out_ptr(const Loc& l) const {
-    RunCtx c{stream_, last_input_, arena_.as<char>()};
+    RunCtx c{stream_, last_input_, arena_.as<char>(), last_extra_.empty() ? nullptr : last_extra_.data()};
     return c.at(l);
 }
 

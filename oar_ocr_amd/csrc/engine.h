@@ -36,8 +36,9 @@ struct GNode {  // graph node after load-time rewrites
 };
 
 struct Loc {  // where a value lives at run time
-    enum Kind { NONE, INPUT, ARENA, CONST } kind = NONE;
-    int64_t off = 0;             // byte offset (ARENA / INPUT)
+    enum Kind { NONE, INPUT, ARENA, CONST, EXTRA } kind = NONE;
+    int64_t off = 0;             // byte offset (ARENA / INPUT / EXTRA)
+    int idx = 0;                 // EXTRA: which secondary graph input
     const float* cptr = nullptr; // CONST
 };
 
@@ -45,8 +46,10 @@ struct RunCtx {
     hipStream_t s;
     const float* input;
     char* arena;
+    const float* const* extra = nullptr;   // secondary graph inputs (Engine::run_multi), device pointers
     const float* at(const Loc& l) const {
         switch (l.kind) {
+            case Loc::EXTRA: return reinterpret_cast<const float*>(reinterpret_cast<const char*>(extra[l.idx]) + l.off);
             case Loc::INPUT: return reinterpret_cast<const float*>(reinterpret_cast<const char*>(input) + l.off);
             case Loc::ARENA: return reinterpret_cast<const float*>(arena + l.off);
             case Loc::CONST: return l.cptr;
@@ -62,6 +65,9 @@ struct PlanOutput {
     Loc loc;                    // native layout
     Loc loc_clast;              // valid when has_clast: the channels-last copy (no conversion needed)
     bool has_clast = false;
+    int dtype = 1;              // onnx elem type the caller sees: 1 = f32, 7 = i64 (device storage is f32 either way)
+    bool on_host = false;       // the value was computed at plan time (shape arithmetic): host_vals holds it, loc is unused
+    std::vector<double> host_vals;
 };
 
 struct Plan {
@@ -83,6 +89,10 @@ class Engine {
     Engine(const uint8_t* onnx, size_t len, int device_id);
     ~Engine();
     const std::string& input_name() const { return input_name_; }
+    // declared graph inputs (initializers excluded) / outputs, with the shapes the model file declares (-1 = dynamic):
+    // OrtInfer::input_names_from_model / primary_input_shape / output_shapes (core/inference/mod.rs:66-112)
+    const std::vector<ValueInfo>& input_infos() const { return input_infos_; }
+    const std::vector<ValueInfo>& output_infos() const { return output_infos_; }
     int device() const { return device_; }
     hipStream_t stream() const { return stream_; }
 
@@ -91,7 +101,11 @@ class Engine {
     // skip_final_softmax: when output[0] is produced by a Softmax over its last axis, stop before it and return the
     // logits instead (Plan::skipped_softmax is set) -- the recognizer fuses that softmax with the CTC argmax.
     const Plan& run(const float* d_in, const std::vector<int64_t>& dims, bool in_clast, bool skip_final_softmax = false);
-    const Plan& plan_for(const std::vector<int64_t>& dims, bool in_clast, bool skip_final_softmax = false);
+    const Plan& plan_for(const std::vector<int64_t>& dims, bool in_clast, bool skip_final_softmax = false,
+                         const std::vector<std::vector<int64_t>>* extra_dims = nullptr);
+    // Several named inputs (OrtInfer::infer, ort_infer_execution.rs:121-219): d_ins[i] / dims[i] belong to input_infos()[i]
+    // (the caller has matched the names); input 0 is the primary one, the others are bound as plain f32 device tensors.
+    const Plan& run_multi(const std::vector<const float*>& d_ins, const std::vector<std::vector<int64_t>>& dims);
     const float* out_ptr(const Loc& l) const;
     char* arena() const { return arena_.as<char>(); }
     std::mutex& mutex() { return mu_; }
@@ -110,6 +124,8 @@ class Engine {
     hipStream_t stream_ = nullptr;
     std::string input_name_;
     std::vector<std::string> output_names_;
+    std::vector<ValueInfo> input_infos_, output_infos_;
+    std::vector<const float*> last_extra_;
     std::map<std::string, HostTensor> inits_;
     std::vector<GNode> nodes_;
     std::map<std::string, const float*> dev_consts_;

@@ -97,6 +97,7 @@ void se_fc(hipStream_t s, const float* x, const float* w1, const float* b1, Act 
 void pad_nd(hipStream_t s, const float* x, float* y, int rank, const int64_t* in_dims, const int64_t* out_dims, const int64_t* before, int mode, float value);
 // reduction over the last axis: x [rows][C] -> y [rows]; mode 0 mean, 1 sum, 2 max, 3 min, 4 prod
 void reduce_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C, int mode);
+void argreduce_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C, bool is_min, bool select_last);
 inline void reduce_mean_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C) { reduce_lastdim(s, x, y, rows, C, 0); }
 // y = cond != 0 ? a : b with numpy broadcasting over up to 6 dims (strides in elements, 0 = broadcast)
 void where(hipStream_t s, const float* cond, const float* a, const float* b, float* y, int rank, const int64_t* dims, const int64_t* sc, const int64_t* sa, const int64_t* sb);

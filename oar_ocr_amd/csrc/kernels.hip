@@ -963,6 +963,35 @@ void reduce_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C
     hipLaunchKernelGGL(reduce_lastdim_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, y, (long)rows, C, mode);
 }
 
+// ------------------------------------------------------------------------------------------ ArgMax / ArgMin (last axis)
+// One wave per row; (value, index) pairs, ties to the smaller index (select_last_index = 0) or the larger one (= 1).  The
+// index is written as f32 (exact below 2^24; the boundary converts to i64).
+__global__ __launch_bounds__(256) void argreduce_lastdim_kernel(const float* __restrict__ x, float* __restrict__ y, long rows, int C, int is_min, int last) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float best = 0.f;
+    int bi = -1;
+    for (int i = lane; i < C; i += 64) {
+        const float v = x[row * C + i];
+        const bool better = bi < 0 || (is_min ? v < best : v > best) || (last && v == best);
+        if (better) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        const bool take = oi >= 0 && (bi < 0 || (is_min ? ov < best : ov > best) || (ov == best && (last ? oi > bi : oi < bi)));
+        if (take) { best = ov; bi = oi; }
+    }
+    if (lane == 0) y[row] = (float)bi;
+}
+void argreduce_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C, bool is_min, bool select_last) {
+    if (rows == 0 || C == 0) return;
+    ProfScope ps(s, "reduce_mean", 4.0 * (double)rows * (C + 1), (double)rows * C);
+    hipLaunchKernelGGL(argreduce_lastdim_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, y, (long)rows, C, is_min ? 1 : 0, select_last ? 1 : 0);
+}
+
 // ------------------------------------------------------------------------------------------ Where
 struct WhereP { int rank; long dims[6], sc[6], sa[6], sb[6]; };
 __global__ __launch_bounds__(256) void where_kernel(const float* c, const float* a, const float* b, float* y, long n, WhereP p) {

@@ -239,19 +239,53 @@ OnnxNode parse_node(Rd r) {
     return n;
 }
 
-std::string parse_value_info_name(Rd r) {
-    std::string name;
+// ValueInfoProto { name = 1, type = 2: TypeProto { tensor_type = 1: Tensor { elem_type = 1, shape = 2: TensorShapeProto {
+// dim = 1: Dimension { dim_value = 1 | dim_param = 2 } } } } }
+ValueInfo parse_value_info(Rd r) {
+    ValueInfo vi;
     while (!r.done()) {
         uint32_t f, wt;
         r.key(f, wt);
-        if (f == 1) name = r.str();
-        else r.skip(wt);
+        if (f == 1 && wt == 2) vi.name = r.str();
+        else if (f == 2 && wt == 2) {
+            Rd ty = r.sub();
+            while (!ty.done()) {
+                uint32_t f2, wt2;
+                ty.key(f2, wt2);
+                if (!(f2 == 1 && wt2 == 2)) { ty.skip(wt2); continue; }
+                Rd tt = ty.sub();
+                while (!tt.done()) {
+                    uint32_t f3, wt3;
+                    tt.key(f3, wt3);
+                    if (f3 == 1 && wt3 == 0) vi.elem_type = (int)tt.varint();
+                    else if (f3 == 2 && wt3 == 2) {
+                        vi.has_shape = true;
+                        Rd sh = tt.sub();
+                        while (!sh.done()) {
+                            uint32_t f4, wt4;
+                            sh.key(f4, wt4);
+                            if (!(f4 == 1 && wt4 == 2)) { sh.skip(wt4); continue; }
+                            Rd dm = sh.sub();
+                            int64_t v = -1;
+                            while (!dm.done()) {
+                                uint32_t f5, wt5;
+                                dm.key(f5, wt5);
+                                if (f5 == 1 && wt5 == 0) v = (int64_t)dm.varint();
+                                else dm.skip(wt5);
+                            }
+                            OAR_CHECK(vi.dims.size() < 16, OAR_MODEL_LOAD, "onnx: value_info rank > 16 in " + vi.name);
+                            vi.dims.push_back(v);
+                        }
+                    } else tt.skip(wt3);
+                }
+            }
+        } else r.skip(wt);
     }
-    return name;
+    return vi;
 }
 
 void parse_graph(Rd r, OnnxModel& m) {
-    std::vector<std::string> inputs;
+    std::vector<ValueInfo> inputs;
     while (!r.done()) {
         uint32_t f, wt;
         r.key(f, wt);
@@ -263,13 +297,13 @@ void parse_graph(Rd r, OnnxModel& m) {
                 m.initializers[nm] = std::move(t);
                 break;
             }
-            case 11: inputs.push_back(parse_value_info_name(r.sub())); break;
-            case 12: m.outputs.push_back(parse_value_info_name(r.sub())); break;
+            case 11: inputs.push_back(parse_value_info(r.sub())); break;
+            case 12: m.output_infos.push_back(parse_value_info(r.sub())); m.outputs.push_back(m.output_infos.back().name); break;
             default: r.skip(wt);
         }
     }
     for (auto& i : inputs)
-        if (!m.initializers.count(i)) m.inputs.push_back(i);
+        if (!m.initializers.count(i.name)) { m.inputs.push_back(i.name); m.input_infos.push_back(i); }
 }
 
 }  // namespace

@@ -57,11 +57,19 @@ struct OnnxNode {
     bool has(const char* k) const { return attrs.count(k) != 0; }
 };
 
+struct ValueInfo {  // a graph input / output as declared (ValueInfoProto): dynamic dimensions are -1
+    std::string name;
+    int elem_type = 0;          // onnx TensorProto.DataType (1 = f32, 7 = i64); 0 = not declared
+    bool has_shape = false;
+    std::vector<int64_t> dims;
+};
+
 struct OnnxModel {
     std::vector<OnnxNode> nodes;
     std::map<std::string, HostTensor> initializers;
     std::vector<std::string> inputs;   // non-initializer graph inputs
     std::vector<std::string> outputs;
+    std::vector<ValueInfo> input_infos, output_infos;   // same order as inputs / outputs
     int64_t opset = 0;
 };
 

@@ -448,3 +448,33 @@ def build_p2o_fixture(seed=11, c=32, vocab=37):
     g.nodes.append(node("Identity", [y], ["probs"]))
     g.add_output("probs", ["N", "T", vocab])
     return g.model(), {"params": g.n_params}
+
+
+# ---------------------------------------------------------------------------------------------- several inputs / integer outputs
+def build_multi_io_fixture(seed=5, c=16, vocab=29):
+    """Seam-A surface the single-input OCR graphs never touch (OrtInfer::infer with several named inputs and
+    TensorOutput::I64, core/inference/ort_infer_execution.rs:121-219, tensor_output.rs:16-21), shaped like the
+    reference's detection-style exports: inputs "image" [N, 3, H, W], "scale_factor" [N, 2], "im_shape" [N, 2];
+    outputs "boxes" f32 [N, 2] (a head scaled by scale_factor and offset by im_shape), "ids" i64 [N, T = H/4] (ArgMax over
+    the class axis of a per-row head), "dims" i64 [4] (Shape(image): a plan-time host value)."""
+    net = _Net("synth_multi_io", seed, opset=17)
+    g = net.g
+    f32, i64 = np.float32, np.int64
+    g.add_input("image", ["N", 3, "H", "W"])
+    g.add_input("scale_factor", ["N", 2])
+    g.add_input("im_shape", ["N", 2])
+    x = net.conv("image", 3, c, 3, stride=2, act="relu")
+    x = net.conv(x, c, c, 3, stride=2, act="hswish")
+    p = g.op("Flatten", [g.op("GlobalAveragePool", [x])], axis=1)                       # [N, c]
+    b = g.op("Gemm", [p, g.init(net._w((c, 2), c)), g.init(net._b(2))])                 # [N, 2]
+    b = g.op("Add", [g.op("Mul", [b, "scale_factor"]), "im_shape"])
+    g.nodes.append(node("Identity", [b], ["boxes"]))
+    col = g.op("ReduceMean", [x], axes=[3], keepdims=0)                                 # [N, c, H/4]
+    col = g.op("Transpose", [col], perm=[0, 2, 1])                                      # [N, T, c]
+    z = g.op("Add", [g.op("MatMul", [col, g.init(net._w((c, vocab), c))]), g.init(net._b(vocab))])
+    g.nodes.append(node("ArgMax", [z], ["ids"], axis=-1, keepdims=0))
+    g.nodes.append(node("Shape", ["image"], ["dims"]))
+    g.add_output("boxes", ["N", 2])
+    g.add_output("ids", ["N", "T"], elem_type=7)
+    g.add_output("dims", [4], elem_type=7)
+    return g.model(), {"params": g.n_params}

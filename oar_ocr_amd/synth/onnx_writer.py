@@ -129,8 +129,8 @@ class GraphBuilder:
     def add_input(self, name, shape):
         self.inputs.append(value_info(name, shape))
 
-    def add_output(self, name, shape):
-        self.outputs.append(value_info(name, shape))
+    def add_output(self, name, shape, elem_type: int = FLOAT):
+        self.outputs.append(value_info(name, shape, elem_type))
 
     def init(self, arr: np.ndarray, prefix: str = "w") -> str:
         name = self.uid(prefix)

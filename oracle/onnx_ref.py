@@ -399,6 +399,12 @@ def run(model, feeds: dict, want=None):
                     y = x[0]
                     for ax in sorted([(v + y.dim()) % y.dim() for v in axes], reverse=True):
                         y = y.prod(dim=ax, keepdim=kd)
+            elif op in ("ArgMax", "ArgMin"):
+                ax = a.get("axis", 0)
+                xx = x[0].flip(ax) if a.get("select_last_index", 0) else x[0]
+                y = (torch.argmax if op == "ArgMax" else torch.argmin)(xx, dim=ax, keepdim=bool(a.get("keepdims", 1)))
+                if a.get("select_last_index", 0):
+                    y = x[0].shape[ax] - 1 - y
             elif op in ("Max", "Min"):
                 y = (torch.maximum if op == "Max" else torch.minimum)(*torch.broadcast_tensors(x[0], x[1]))
             elif op in ("Equal", "Less", "Greater"):

@@ -360,6 +360,87 @@ def test_exporter_shaped_fixture_matches_oracle(shape):
     eng.close()
 
 
+# ------------------------------------------------------------------------------------------------ Seam A: the rest of OrtInfer
+def _multi_io_feeds(n, h, w, seed=0):
+    rng = np.random.default_rng(seed)
+    return {"image": rng.standard_normal((n, 3, h, w)).astype(np.float32),
+            "scale_factor": rng.uniform(0.5, 2.0, (n, 2)).astype(np.float32),
+            "im_shape": np.tile(np.array([[h, w]], np.float32), (n, 1))}
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 48), (3, 64, 40)])
+def test_named_inputs_and_i64_outputs_match_oracle(shape):
+    """OrtInfer::infer with several named inputs (ort_infer_execution.rs:121-219) and TensorOutput::I64 (tensor_output.rs:16-21):
+    three inputs given in a DIFFERENT order than the model declares them; outputs f32 (device), i64 from the device (ArgMax)
+    and i64 from a plan-time host value (Shape)."""
+    m, _ = models.build_multi_io_fixture()
+    feeds = _multi_io_feeds(*shape)
+    eng = api.OrtInfer(m)
+    outs = eng.infer([("im_shape", feeds["im_shape"]), ("image", feeds["image"]), ("scale_factor", feeds["scale_factor"])])
+    want = onnx_ref.run(m, feeds)
+    assert [n for n, _ in outs] == ["boxes", "ids", "dims"]
+    boxes, ids, dims = (a for _, a in outs)
+    assert boxes.dtype == np.float32 and ids.dtype == np.int64 and dims.dtype == np.int64
+    assert np.abs(boxes - want[0]).max() < 1e-4
+    assert ids.shape == want[1].shape == (shape[0], shape[1] // 4) and np.array_equal(ids, want[1])
+    assert np.array_equal(dims, np.array([shape[0], 3, shape[1], shape[2]]))
+    eng.close()
+
+
+def test_named_input_errors_read_like_the_reference():
+    m, _ = models.build_multi_io_fixture()
+    feeds = _multi_io_feeds(1, 32, 32)
+    eng = api.OrtInfer(m)
+    with pytest.raises(api.OCRError, match="No inputs provided"):                 # ort_infer_execution.rs:125-129
+        eng.infer([])
+    with pytest.raises(api.OCRError, match="3 input"):
+        eng.infer([("image", feeds["image"])])
+    with pytest.raises(api.OCRError, match="no input named 'bogus'"):
+        eng.infer([("image", feeds["image"]), ("bogus", feeds["im_shape"]), ("scale_factor", feeds["scale_factor"])])
+    with pytest.raises(api.OCRError, match="given twice"):
+        eng.infer([("image", feeds["image"]), ("im_shape", feeds["im_shape"]), ("im_shape", feeds["im_shape"])])
+    with pytest.raises(api.OCRError, match="several inputs"):
+        eng.infer(feeds["image"])
+    eng.close()
+
+
+def test_declared_io_metadata():
+    """input_names_from_model / primary_input_shape / output_shapes (core/inference/mod.rs:66-112): dynamic dims are -1."""
+    m, _ = models.build_multi_io_fixture()
+    eng = api.OrtInfer(m)
+    assert eng.input_names_from_model() == ["image", "scale_factor", "im_shape"]
+    assert eng.primary_input_shape() == [-1, 3, -1, -1]
+    assert eng.output_shapes() == [("boxes", [-1, 2]), ("ids", [-1, -1]), ("dims", [4])]
+    eng.close()
+    det, _ = models.build_det()
+    eng = api.OrtInfer(det)
+    assert eng.input_names_from_model() == [eng.input_name()] and eng.primary_input_shape()[1] == 3
+    eng.close()
+
+
+def test_borrowed_first_output_view():
+    """infer_first_output_f32 (ort_infer_execution.rs:234-306): the closure sees (shape, data) of output 0 without an owned
+    copy; its result is returned; an f32 view of a non-f32 first output is an error; a failing closure propagates."""
+    m, _ = models.build_p2o_fixture()
+    x = np.random.default_rng(1).standard_normal((2, 3, 32, 96)).astype(np.float32)
+    eng = api.OrtInfer(m)
+    owned = eng.infer(x)[0][1]
+    seen = eng.infer_first_output_f32(x, lambda shape, data: (shape, data.copy(), float(data.sum())))
+    assert seen[0] == owned.shape and np.array_equal(seen[1], owned) and abs(seen[2] - owned.sum()) < 1e-3
+    seen2 = eng.infer_first_output_f32([(eng.input_name(), x)], lambda shape, data: data.argmax(-1))
+    assert np.array_equal(seen2, owned.argmax(-1))
+
+    class Boom(RuntimeError):
+        pass
+
+    def bad(shape, data):
+        raise Boom("closure failed")
+    with pytest.raises(Boom):
+        eng.infer_first_output_f32(x, bad)
+    assert np.array_equal(eng.infer(x)[0][1], owned)           # the engine is still usable afterwards
+    eng.close()
+
+
 def test_plan_cache_is_lru_bounded(monkeypatch):
     """plans_ grew without bound (one plan per input shape).  With OAR_PLAN_CACHE=4 ten different widths leave 4
     cached plans and 6+ evictions, and a re-run of an evicted shape still gives the first run's result."""
