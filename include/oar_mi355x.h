@@ -107,9 +107,9 @@ void oar_tensor_free(oar_tensor* t);
  * once (OAR_INVALID_INPUT otherwise, naming the missing / unknown one) -- all graph outputs back, F32 or I64. */
 oar_status oar_engine_run_named(oar_engine* e, const oar_input* inputs, int32_t n_in, oar_tensor* outs, int32_t max_out,
                                 int32_t* n_out);
-/* OrtInfer::infer_first_output_f32 (ort_infer_execution.rs:234-306): runs the graph and hands the FIRST output to `fn`
+/* OrtInfer::infer_first_output_f32 (ort_infer_execution.rs:234-306): runs the graph and hands the FIRST output to `view`
  * without an owned copy.  OAR_SHAPE_MISMATCH when that output is not f32. */
-oar_status oar_engine_run_first_f32(oar_engine* e, const oar_input* inputs, int32_t n_in, oar_output_view_fn fn, void* user);
+oar_status oar_engine_run_first_f32(oar_engine* e, const oar_input* inputs, int32_t n_in, oar_output_view_fn view, void* user);
 /* Declared inputs (initializers excluded; entry 0 is the primary input) and outputs of the model file.  Either array may
  * be NULL to query the counts only. */
 oar_status oar_engine_io(const oar_engine* e, oar_io_info* inputs, int32_t max_in, int32_t* n_in, oar_io_info* outputs,
@@ -324,7 +324,11 @@ oar_status oar_cls_preprocess(oar_cls* c, const uint8_t* const* rgb, const uint3
  * ("image" -> [n,3,h,w] BGR in [0,1]), (v*255).clamp(0,255) as u8 -> RGB (processors/simd.rs:327-348), Triangle resize
  * back to the input size.  out_rgb: caller-allocated w*h*3 bytes.                                               */
 typedef struct oar_rect oar_rect;
-typedef struct { int32_t device_id; uint32_t target_h, target_w; /* 0,0 => 512,512 */ } oar_rect_cfg;
+/* target_h / target_w: 0,0 => 512,512 (UVDocPreprocessConfig::default, uvdoc.rs:21-27); OAR_RECT_NATIVE_SIZE => pages go through the
+ * graph at their own size, no resize either way -- what DocumentRectificationConfig::default()'s [3, 0, 0] means once it reaches
+ * the model through with_config (document_rectification_adapter.rs, uvdoc.rs:84-88). */
+#define OAR_RECT_NATIVE_SIZE 0xFFFFFFFFu
+typedef struct { int32_t device_id; uint32_t target_h, target_w; } oar_rect_cfg;
 oar_status oar_rect_create(const uint8_t* onnx, size_t onnx_len, const oar_rect_cfg* cfg, oar_rect** out);
 void oar_rect_destroy(oar_rect* r);
 oar_status oar_rect_run(oar_rect* r, const uint8_t* rgb, uint32_t width, uint32_t height, uint8_t* out_rgb);

@@ -571,7 +571,8 @@ oar_status oar_rect_create(const uint8_t* onnx, size_t onnx_len, const oar_rect_
         OAR_CHECK(out, OAR_INVALID_INPUT, "oar_rect_create: out is null");
         *out = nullptr;
         RectCfg c;
-        if (cfg) { c.device_id = cfg->device_id; if (cfg->target_h && cfg->target_w) { c.target_h = cfg->target_h; c.target_w = cfg->target_w; } }
+        if (cfg) { c.device_id = cfg->device_id; if (cfg->target_h == OAR_RECT_NATIVE_SIZE || cfg->target_w == OAR_RECT_NATIVE_SIZE) { c.target_h = 0; c.target_w = 0; }   // Rectifier: 0 = feed pages at their own size (uvdoc.rs:86)
+                   else if (cfg->target_h && cfg->target_w) { c.target_h = cfg->target_h; c.target_w = cfg->target_w; } }
         std::unique_ptr<oar_rect> h(new oar_rect());
         h->r.reset(new Rectifier(onnx, onnx_len, c));
         *out = h.release();

@@ -1,0 +1,198 @@
+"""The reference-side binding (rust/) against the C header and the built library.
+
+No Rust toolchain exists in this image, so the crates cannot be compiled here.  What CAN be checked mechanically:
+  * rust/oar-mi355x-sys/src/lib.rs is exactly what tools/gen_rust_sys.py derives from include/oar_mi355x.h (regenerate + diff);
+  * its extern block names exactly the symbols libOarMi355x.so exports (nm -D), no more, no fewer;
+  * its #[repr(C)] structs have the field order and sizes of the ctypes mirror the GPU tests drive (oar_ocr_amd/api.py);
+  * the adapters crate only names sys:: items that exist, calls every FFI function with the declared number of arguments,
+    has balanced delimiters, and implements the full ModelAdapter / AdapterBuilder surface for every adapter.
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gen_rust_sys  # noqa: E402
+
+from oar_ocr_amd import api  # noqa: E402
+
+SYS_RS = os.path.join(ROOT, "rust", "oar-mi355x-sys", "src", "lib.rs")
+ADAPTERS = os.path.join(ROOT, "rust", "oar-mi355x-adapters", "src")
+
+
+@pytest.fixture(scope="module")
+def header():
+    return gen_rust_sys.parse_header()
+
+
+def test_sys_crate_is_what_the_header_yields(header):
+    assert open(SYS_RS).read() == gen_rust_sys.generate(header), "run python tools/gen_rust_sys.py"
+
+
+def test_sys_crate_matches_exported_symbols(header):
+    lib = str(api.LIB_PATH)
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("oar_")}
+    declared = {name for name, _, _ in header["funcs"]}
+    in_rust = set(re.findall(r"^\s*pub fn (oar_\w+)\(", open(SYS_RS).read(), flags=re.M))
+    assert declared == in_rust
+    assert declared == exported, f"header-only: {sorted(declared - exported)}; library-only: {sorted(exported - declared)}"
+
+
+PRIM_SIZE = {"u8": 1, "i8": 1, "i32": 4, "u32": 4, "i64": 8, "u64": 8, "f32": 4, "f64": 8, "usize": 8, "c_int": 4, "c_char": 1}
+
+
+def _rust_structs():
+    text = open(SYS_RS).read()
+    structs = {}
+    for m in re.finditer(r"#\[repr\(C\)\]\n#\[derive\([^)]*\)\]\npub struct (\w+) \{\n(.*?)\n\}", text, flags=re.S):
+        fields = re.findall(r"pub (\w+): ([^,\n]+),", m.group(2))
+        structs[m.group(1)] = fields
+    return structs
+
+
+def _size_align(ty, structs):
+    ty = ty.strip()
+    if ty.startswith("*") or ty.startswith("Option<"):
+        return 8, 8
+    m = re.match(r"\[(.+); (\d+)\]$", ty)
+    if m:
+        s, a = _size_align(m.group(1), structs)
+        return s * int(m.group(2)), a
+    if ty in PRIM_SIZE:
+        return PRIM_SIZE[ty], PRIM_SIZE[ty]
+    return _struct_size(ty, structs)
+
+
+def _struct_size(name, structs):
+    off, align = 0, 1
+    for _, ty in structs[name]:
+        s, a = _size_align(ty, structs)
+        off = (off + a - 1) // a * a + s
+        align = max(align, a)
+    return (off + align - 1) // align * align, align
+
+
+CTYPES_MIRROR = {
+    "oar_engine_cfg": "EngineCfg", "oar_tensor": "Tensor", "oar_input": "Input", "oar_io_info": "IoInfo", "oar_det_cfg": "DetCfg",
+    "oar_det_result": "DetResult", "oar_rec_cfg": "RecCfg", "oar_rec_result": "RecResult", "oar_ocr_cfg": "OcrCfg",
+    "oar_ocr_result": "OcrResult", "oar_cls_cfg": "ClsCfg", "oar_cls_result": "ClsResult", "oar_rect_cfg": "RectCfg",
+    "oar_text_result": "TextResult", "oar_prof_entry": "ProfEntry",
+}
+
+
+def test_repr_c_structs_match_the_ctypes_mirror(header):
+    structs = _rust_structs()
+    assert set(structs) == {name for name, _ in header["structs"]}
+    checked = 0
+    for rust_name, py_name in CTYPES_MIRROR.items():
+        cls = getattr(api, py_name, None)
+        if cls is None:
+            continue
+        rust_fields = [f for f, _ in structs[rust_name]]
+        py_fields = [f[0] for f in cls._fields_]
+        assert rust_fields == py_fields, (rust_name, rust_fields, py_fields)
+        assert _struct_size(rust_name, structs)[0] == C.sizeof(cls), rust_name
+        checked += 1
+    assert checked >= 12
+
+
+def _strip_rust(text):
+    text = re.sub(r"//[^\n]*", "", text)
+    text = re.sub(r'"(?:\\.|[^"\\])*"', '""', text)
+    text = re.sub(r"'(?:\\.|[^'\\])'", "' '", text)     # char literals ('\n', 'a'); lifetimes have no closing quote
+    return text
+
+
+def _call_args(text, start):
+    """number of top-level arguments of the call whose '(' is at text[start]"""
+    depth, args, seen = 0, 0, False
+    for i in range(start, len(text)):
+        ch = text[i]
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+            if depth == 0:
+                return args + (1 if seen else 0)
+        elif ch == "," and depth == 1:
+            args += 1
+            seen = False
+        elif not ch.isspace() and depth >= 1:
+            seen = True
+    raise AssertionError("unbalanced call")
+
+
+def _literal_fields(body):
+    """field names of a struct literal body: `a: expr, b, c: [0; 8]` -> [a, b, c] (top-level commas only)"""
+    pieces, depth, cur = [], 0, []
+    for ch in body:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            pieces.append("".join(cur))
+            cur = []
+        else:
+            cur.append(ch)
+    pieces.append("".join(cur))
+    return [re.match(r"\s*(\w+)", p).group(1) for p in pieces if p.strip()]
+
+
+def test_adapters_crate_only_uses_what_the_sys_crate_declares(header):
+    funcs = {name: len(params) for name, _, params in header["funcs"]}
+    known = set(funcs) | {n for n, _ in header["structs"]} | set(header["opaque"]) | {n for n, _ in header["enums"]} \
+        | {k for _, items in header["enums"] for k, _ in items} | {n for n, _, _ in header["fnptrs"]} | {n for n, _ in header["defines"]}
+    struct_fields = {n: [f for f, _, _ in fields] for n, fields in header["structs"]}
+    files = sorted(f for f in os.listdir(ADAPTERS) if f.endswith(".rs"))
+    assert {"lib.rs", "error.rs", "infer.rs", "text_detection.rs", "text_recognition.rs", "orientation.rs", "rectification.rs",
+            "pipeline.rs"} <= set(files)
+    used_funcs = set()
+    for fn in files:
+        raw = open(os.path.join(ADAPTERS, fn)).read()
+        text = _strip_rust(raw)
+        for o, c in ("()", "[]", "{}"):
+            assert text.count(o) == text.count(c), f"{fn}: unbalanced {o}{c}"
+        for m in re.finditer(r"\b(?:sys|oar_mi355x_sys)::(\w+)", text):
+            name = m.group(1)
+            assert name in known, f"{fn}: sys::{name} is not declared by the header"
+            rest = text[m.end():]
+            if name in funcs and rest.lstrip().startswith("("):
+                used_funcs.add(name)
+                n = _call_args(text, m.end() + rest.index("("))
+                assert n == funcs[name], f"{fn}: {name} called with {n} arguments, declared with {funcs[name]}"
+            if name in struct_fields and rest.lstrip().startswith("{"):
+                body_start = m.end() + rest.index("{")
+                depth, i = 0, body_start
+                while True:
+                    depth += text[i] == "{"
+                    depth -= text[i] == "}"
+                    if depth == 0:
+                        break
+                    i += 1
+                given = _literal_fields(text[body_start + 1:i])
+                assert given == struct_fields[name], f"{fn}: literal of {name} has fields {given}, header has {struct_fields[name]}"
+    # the Seam-B entry points of every adapter plus Seam A are all bound
+    assert {"oar_det_create", "oar_det_run", "oar_rec_create", "oar_rec_run", "oar_ctc_dict_create", "oar_ctc_decode", "oar_cls_create",
+            "oar_cls_run", "oar_rect_create", "oar_rect_run", "oar_ocr_create", "oar_ocr_predict", "oar_ocr_decode", "oar_ocr_attach",
+            "oar_engine_create", "oar_engine_run_named", "oar_engine_run_first_f32", "oar_engine_io"} <= used_funcs
+
+
+@pytest.mark.parametrize("fn,adapters", [("text_detection.rs", 1), ("text_recognition.rs", 1), ("orientation.rs", 2), ("rectification.rs", 1)])
+def test_every_adapter_implements_the_reference_traits(fn, adapters):
+    """ModelAdapter { type Task; info; execute; supports_batching; recommended_batch_size } and
+    AdapterBuilder { type Config; type Adapter; build; with_config; adapter_type } (core/traits/adapter.rs:42-110)."""
+    text = _strip_rust(open(os.path.join(ADAPTERS, fn)).read())
+    assert len(re.findall(r"impl ModelAdapter for \w+", text)) == adapters
+    assert len(re.findall(r"impl AdapterBuilder for \w+", text)) == adapters
+    for member in (r"type Task = \w+;", r"fn info\(&self\) -> AdapterInfo", r"fn execute\(", r"fn supports_batching\(&self\) -> bool",
+                   r"fn recommended_batch_size\(&self\) -> usize", r"type Config = \w+;", r"type Adapter = \w+;",
+                   r"fn build\(self, model_source: impl Into<ModelSource>\) -> Result<Self::Adapter, OCRError>",
+                   r"fn with_config\(mut self, config: Self::Config\) -> Self", r"fn adapter_type\(&self\) -> &str"):
+        assert len(re.findall(member, text)) == adapters, (fn, member)
