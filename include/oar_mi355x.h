@@ -149,7 +149,11 @@ typedef struct {
     int32_t box_type;          /* 0 = BoxType::Quad (default), 1 = BoxType::Poly (seal text; not implemented yet: create fails with OAR_UNSUPPORTED_OP) */
     int32_t score_mode;        /* 0 = ScoreMode::Fast (mini-box scanline mean), 1 = ScoreMode::Slow (contour scanline mean, db_score.rs:139-181) */
     int32_t use_dilation;      /* 1: dilate the mask (3 x 3, db_mask.rs:11) before contour tracing (db_postprocess.rs:163-168) */
-    int32_t reserved;
+    /* Where find_contours (db_bitmap.rs:100) runs.  0: on the host thread pool from the read-back mask (default: fastest on one GPU,
+     * the host cores are otherwise idle).  1: on the GPU (contours.hip, one wavefront per mask segment), only the border chains
+     * cross PCIe and the host keeps the per-contour geometry -- for hosts whose cores are shared by many GPU ranks.  Identical
+     * results either way.  The environment variable OAR_GPU_CONTOURS=0|1 overrides this field. */
+    int32_t gpu_contours;
 } oar_det_cfg;
 
 /* CSR result: image i owns boxes [box_offsets[i], box_offsets[i+1]); each box is 4 points (x,y) f32 in
@@ -374,6 +378,10 @@ oar_status oar_k_dilate(const uint8_t* mask, uint32_t height, uint32_t width, ui
  * counts[i] (x, y) points, stored back to back in pts_xy */
 oar_status oar_k_poly_scores(const float* pred, uint32_t height, uint32_t width, const float* pts_xy, const uint32_t* counts,
                              uint32_t n_polys, float* scores);
+/* a8 processors/db_bitmap.rs:100 (imageproc find_contours) through the GPU border follower the detector uses (contours.hip): same
+ * outputs as oar_host_contours (offsets: max_contours + 1 entries; types 0 outer / 1 hole), the count through n_contours */
+oar_status oar_k_contours(const uint8_t* mask, uint32_t width, uint32_t height, uint32_t max_contours, int32_t* n_contours,
+                          int64_t* offsets, int32_t* pts_xy, int32_t* types, int64_t cap_points);
 /* a18 processors/decode.rs:452-501 + simd.rs:72-81 */
 oar_status oar_k_ctc_argmax(const float* probs, size_t rows, size_t vocab, int64_t* idx, float* prob);
 /* a10 processors/db_score.rs:34-134: boxes = n_boxes * 8 floats */

@@ -58,7 +58,7 @@ OUTPUT_VIEW_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_int64), C.c_in
 class DetCfg(C.Structure):
     _fields_ = [("device_id", C.c_int32), ("limit_side_len", C.c_uint32), ("limit_type", C.c_int32), ("max_side_limit", C.c_uint32),
                 ("max_candidates", C.c_uint32), ("use_hip_graph", C.c_int32), ("profile", C.c_int32), ("host_threads", C.c_int32),
-                ("box_type", C.c_int32), ("score_mode", C.c_int32), ("use_dilation", C.c_int32), ("reserved", C.c_int32)]
+                ("box_type", C.c_int32), ("score_mode", C.c_int32), ("use_dilation", C.c_int32), ("gpu_contours", C.c_int32)]
 
 
 class DetResult(C.Structure):
@@ -124,7 +124,7 @@ EXPORTS = [
     "oar_cls_create", "oar_cls_destroy", "oar_cls_run", "oar_cls_result_free", "oar_cls_preprocess", "oar_rect_create", "oar_rect_destroy",
     "oar_rect_run", "oar_ocr_attach", "oar_k_rotate_rgb", "oar_k_bgr_planes_to_rgb", "oar_host_rotate_back_points",
     "oar_engine_cache_stats", "oar_onnx_inspect", "oar_host_contours", "oar_ctc_dict_create", "oar_ctc_dict_destroy", "oar_ctc_dict_classes",
-    "oar_ctc_decode", "oar_ocr_decode", "oar_text_result_free", "oar_db_postprocess_ex", "oar_k_dilate", "oar_k_poly_scores", "oar_debug_inject_failure",
+    "oar_ctc_decode", "oar_ocr_decode", "oar_text_result_free", "oar_db_postprocess_ex", "oar_k_dilate", "oar_k_poly_scores", "oar_debug_inject_failure", "oar_k_contours",
 ]
 
 
@@ -428,6 +428,7 @@ class TextDetectionConfig:
     box_type: str = "quad"             # "quad" | "poly" (seal text; not implemented yet)
     score_mode: str = "fast"           # "fast" | "slow"
     use_dilation: bool = False
+    gpu_contours: bool = False         # backend option (not in the reference): follow the mask borders on the GPU (oar_det_cfg.gpu_contours)
 
     def validate(self):
         if self.box_type not in ("quad", "poly") or self.score_mode not in ("fast", "slow"):
@@ -616,7 +617,7 @@ class TextDetectionPredictor:
         self.config.validate()
         cfg = DetCfg(device_id, self.config.limit_side_len or limit_side_len, _LIMIT[self.config.limit_type or limit_type],
                      self.config.max_side_len or max_side_limit, self.config.max_candidates, 0, int(profile), host_threads,
-                     int(self.config.box_type == "poly"), int(self.config.score_mode == "slow"), int(self.config.use_dilation), 0)
+                     int(self.config.box_type == "poly"), int(self.config.score_mode == "slow"), int(self.config.use_dilation), int(self.config.gpu_contours))
         self._h = C.c_void_p()
         buf = (C.c_char * len(model)).from_buffer_copy(model)
         _check(lib().oar_det_create(C.cast(buf, C.c_void_p), len(model), C.byref(cfg), C.byref(self._h)))
@@ -804,12 +805,12 @@ class OAROCRBuilder:
             d.validate()
             thresh, box_thresh, unclip, maxc = d.score_threshold, d.box_threshold, d.unclip_ratio, d.max_candidates
             lsl, lt, msl = d.limit_side_len or 960, d.limit_type or "max", d.max_side_len or 4000
-            opts = (int(d.box_type == "poly"), int(d.score_mode == "slow"), int(d.use_dilation))
+            opts = (int(d.box_type == "poly"), int(d.score_mode == "slow"), int(d.use_dilation), int(d.gpu_contours))
         else:   # builder defaults (ocr.rs:319-366)
             thresh, box_thresh, unclip, maxc, lsl, lt, msl = 0.3, 0.6, 2.0, 1000, 960, "max", 4000
-            opts = (0, 0, 0)
+            opts = (0, 0, 0, 0)
         cfg = OcrCfg()
-        cfg.det = DetCfg(self._device, lsl, _LIMIT[lt], msl, maxc, 0, int(self._profile), self._host_threads, *opts, 0)
+        cfg.det = DetCfg(self._device, lsl, _LIMIT[lt], msl, maxc, 0, int(self._profile), self._host_threads, *opts)
         cfg.rec = RecCfg(self._device, (C.c_uint32 * 3)(3, 48, 320), 3200, 0, int(self._profile), 0)
         cfg.det_thresh, cfg.det_box_thresh, cfg.det_unclip_ratio = thresh, box_thresh, unclip
         cfg.image_batch_size = self._image_bs or 0      # accelerator: adapter defaults 8 / 64 (builder_utils.rs:86-102)
@@ -1143,6 +1144,19 @@ def host_contours(mask, max_contours=100000, max_bands=1):
     if n < 0:
         raise OCRError(OAR_INTERNAL, "oar_host_contours failed")
     return [(pts[offs[i]:offs[i + 1]].copy(), int(types[i])) for i in range(n)]
+
+
+def k_contours(mask, max_contours=100000):
+    """a8 through the GPU border follower (contours.hip): same result format as host_contours."""
+    mask = np.ascontiguousarray(mask, np.uint8)
+    h, w = mask.shape
+    cap = 4 * h * w + 16
+    offs = np.zeros(max_contours + 1, np.int64)
+    pts = np.zeros((cap, 2), np.int32)
+    types = np.zeros(max_contours, np.int32)
+    n = C.c_int32(0)
+    _check(lib().oar_k_contours(_p(mask), w, h, max_contours, C.byref(n), _p(offs), _p(pts), _p(types), cap))
+    return [(pts[offs[i]:offs[i + 1]].copy(), int(types[i])) for i in range(n.value)]
 
 
 def host_unclip(box, ratio):

@@ -868,6 +868,33 @@ int32_t oar_host_contours(const uint8_t* mask, uint32_t width, uint32_t height, 
         return n;
     } catch (...) { return -1; }
 }
+
+oar_status oar_k_contours(const uint8_t* mask, uint32_t width, uint32_t height, uint32_t max_contours, int32_t* n_contours, int64_t* offsets,
+                          int32_t* pts_xy, int32_t* types, int64_t cap_points) {
+    return guard([&] {
+        OAR_CHECK(mask && width > 0 && height > 0 && n_contours, OAR_INVALID_INPUT, "oar_k_contours: bad arguments");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) fail(OAR_DEVICE, "no HIP device visible: libOarMi355x has no CPU fallback");
+        DevBuf dm;
+        const size_t hw = (size_t)width * height;
+        dm.reserve(hw);
+        OAR_HIP(hipMemcpy(dm.p, mask, hw, hipMemcpyHostToDevice));
+        std::vector<host::Contour> cs = Detector::trace_device_mask(dm.as<uint8_t>(), (int)height, (int)width, max_contours);
+        int64_t np = 0;
+        if (offsets) offsets[0] = 0;
+        int32_t n = 0;
+        for (auto& c : cs) {
+            for (auto& q : c.pts) {
+                if (pts_xy && np < cap_points) { pts_xy[np * 2] = (int32_t)q.x; pts_xy[np * 2 + 1] = (int32_t)q.y; }
+                ++np;
+            }
+            if (types) types[n] = c.hole ? 1 : 0;
+            ++n;
+            if (offsets) offsets[n] = np;
+        }
+        *n_contours = n;
+    });
+}
 int32_t oar_host_unclip(const float box8[8], float ratio, float* out_xy, int32_t cap_points) {
     try {
         host::Pt b[4];

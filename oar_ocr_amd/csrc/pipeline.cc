@@ -183,6 +183,39 @@ Detector::~Detector() {
 }
 
 namespace {
+struct ContourSizes { size_t rows, band_y, n_bands, lists, scratch, ctrl, table_dev, ctrl_host, table, packed, packed_words_per_page; };
+ContourSizes contour_sizes(int pages, int sub_pages, int H, int W, int n_sub) {
+    ContourSizes z;
+    const size_t maxb = (size_t)pp::trace_max_bands(H);
+    z.packed_words_per_page = std::max<size_t>((size_t)H * W / 4, 4096);   // a page's border chains: 1 word per 4 pixels, else host fallback
+    z.rows = (size_t)sub_pages * H;
+    z.band_y = (size_t)sub_pages * maxb * 2 * sizeof(int32_t);
+    z.n_bands = (size_t)sub_pages * sizeof(int32_t);
+    z.lists = (size_t)sub_pages * ContourBufs::kSegsPerPage * 2 * sizeof(uint32_t);
+    z.scratch = (size_t)sub_pages * H * W * 2 * sizeof(uint32_t);
+    z.ctrl = (size_t)std::max(n_sub, 1) * pp::kTraceCtlWords * sizeof(uint32_t);
+    z.table_dev = (size_t)sub_pages * ContourBufs::kSegsPerPage * sizeof(pp::SegRec);
+    z.ctrl_host = z.ctrl;
+    z.table = (size_t)pages * ContourBufs::kSegsPerPage * sizeof(pp::SegRec);
+    z.packed = (size_t)pages * z.packed_words_per_page * sizeof(uint32_t);
+    return z;
+}
+}  // namespace
+
+bool ContourBufs::fits(int pages, int sub_pages, int H, int W, int n_sub) const {
+    const ContourSizes z = contour_sizes(pages, sub_pages, H, W, n_sub);
+    return z.rows <= rows.cap && z.band_y <= band_y.cap && z.n_bands <= n_bands.cap && z.lists <= lists.cap && z.scratch <= scratch.cap && z.ctrl <= ctrl.cap &&
+           z.table_dev <= table_dev.cap && z.ctrl_host <= ctrl_host.cap && z.table <= table.cap && z.packed <= packed.cap;
+}
+
+void ContourBufs::reserve(int pages, int sub_pages, int H, int W, int n_sub) {
+    const ContourSizes z = contour_sizes(pages, sub_pages, H, W, n_sub);
+    packed_words_per_page = z.packed_words_per_page;
+    rows.reserve(z.rows); band_y.reserve(z.band_y); n_bands.reserve(z.n_bands); lists.reserve(z.lists); scratch.reserve(z.scratch); ctrl.reserve(z.ctrl);
+    table_dev.reserve(z.table_dev); ctrl_host.reserve(z.ctrl_host); table.reserve(z.table); packed.reserve(z.packed);
+}
+
+namespace {
 struct Candidate { float pts[8]; std::vector<host::Pt> contour; /* ScoreMode::Slow only */ };
 
 // a9: one contour -> mini box candidate (false when rejected)
@@ -204,6 +237,27 @@ void page_candidates(const uint8_t* mask, int H, int W, uint32_t max_candidates,
     for (auto& c : cs) {
         Candidate cd;
         if (contour_candidate(c, cd, keep_contour)) out.push_back(std::move(cd));
+    }
+}
+
+// stage 2 of a sub-batch: per-contour geometry (simplify -> hull -> min-area rect -> mini box) spread over the pool in chunks of
+// 8 contours; discovery order is preserved
+void contours_to_candidates(ThreadPool& pool, std::vector<std::vector<host::Contour>>& cs, int nb, std::vector<Candidate>* out, bool keep_contour) {
+    struct Chunk { int page; size_t c0, c1; };
+    std::vector<Chunk> chunks;
+    const size_t step = 8;
+    for (int k = 0; k < nb; ++k)
+        for (size_t c0 = 0; c0 < cs[k].size(); c0 += step) chunks.push_back({k, c0, std::min(cs[k].size(), c0 + step)});
+    std::vector<std::vector<Candidate>> res(nb);
+    std::vector<std::vector<uint8_t>> ok(nb);
+    for (int k = 0; k < nb; ++k) { res[k].resize(cs[k].size()); ok[k].assign(cs[k].size(), 0); }
+    pool.parallel_for((int)chunks.size(), [&](int i) {
+        const Chunk& ch = chunks[i];
+        for (size_t c = ch.c0; c < ch.c1; ++c) ok[ch.page][c] = contour_candidate(cs[ch.page][c], res[ch.page][c], keep_contour) ? 1 : 0;
+    });
+    for (int k = 0; k < nb; ++k) {
+        out[k].clear();
+        for (size_t c = 0; c < cs[k].size(); ++c) if (ok[k][c]) out[k].push_back(std::move(res[k][c]));
     }
 }
 
@@ -243,30 +297,95 @@ void subbatch_candidates(ThreadPool& pool, const uint8_t* masks, size_t hw, int 
         for (auto& c : band_cs[i]) { if (dst.size() >= max_candidates) break; dst.push_back(std::move(c)); }
     }
     auto tb = std::chrono::steady_clock::now();
-    struct Chunk { int page; size_t c0, c1; };
-    std::vector<Chunk> chunks;
-    const size_t step = 8;
-    for (int k = 0; k < nb; ++k)
-        for (size_t c0 = 0; c0 < cs[k].size(); c0 += step) chunks.push_back({k, c0, std::min(cs[k].size(), c0 + step)});
-    std::vector<std::vector<Candidate>> res(nb);
-    std::vector<std::vector<uint8_t>> ok(nb);
-    for (int k = 0; k < nb; ++k) { res[k].resize(cs[k].size()); ok[k].assign(cs[k].size(), 0); }
-    pool.parallel_for((int)chunks.size(), [&](int i) {
-        const Chunk& ch = chunks[i];
-        for (size_t c = ch.c0; c < ch.c1; ++c) ok[ch.page][c] = contour_candidate(cs[ch.page][c], res[ch.page][c], keep_contour) ? 1 : 0;
-    });
-    for (int k = 0; k < nb; ++k) {
-        out[k].clear();
-        for (size_t c = 0; c < cs[k].size(); ++c) if (ok[k][c]) out[k].push_back(std::move(res[k][c]));
-    }
+    contours_to_candidates(pool, cs, nb, out, keep_contour);
     if (g_timer && g_timer->on) {
         auto tc = std::chrono::steady_clock::now();
         double mx = 0, sum = 0;
         for (double t : tpage) { mx = std::max(mx, t); sum += t; }
-        fprintf(stderr, "[timing]   subbatch nb=%d setup=%.2fms stage1=%.2fms (per-band max %.2f avg %.2f, %zu bands) stage2=%.2fms chunks=%zu\n", nb,
+        fprintf(stderr, "[timing]   subbatch nb=%d setup=%.2fms stage1=%.2fms (per-band max %.2f avg %.2f, %zu bands) stage2=%.2fms\n", nb,
                 std::chrono::duration<double, std::milli>(ta - t_setup).count(), std::chrono::duration<double, std::milli>(tb - ta).count(), mx,
-                sum / std::max<size_t>(tpage.size(), 1), tpage.size(), std::chrono::duration<double, std::milli>(tc - tb).count(), chunks.size());
+                sum / std::max<size_t>(tpage.size(), 1), tpage.size(), std::chrono::duration<double, std::milli>(tc - tb).count());
     }
+}
+
+// Border chains of one traced record (a word stream of pp::trace_contours) -> (start key, contour) items
+void parse_traced_record(const pp::SegRec& r, const uint32_t* packed, std::vector<std::pair<uint32_t, host::Contour>>& items) {
+    const uint32_t* w = packed + r.off;
+    uint32_t at = 0;
+    for (uint32_t c = 0; c < r.n_contours; ++c) {
+        OAR_CHECK(at < r.used, OAR_INTERNAL, "contour tracer: corrupt stream");
+        const uint32_t hdr = w[at++];
+        const uint32_t cnt = hdr & 0x7fffffffu;
+        OAR_CHECK(cnt >= 1 && at + cnt <= r.used, OAR_INTERNAL, "contour tracer: corrupt stream");
+        host::Contour ct;
+        ct.hole = (hdr >> 31) != 0;
+        ct.pts.resize(cnt);
+        for (uint32_t i = 0; i < cnt; ++i) { const uint32_t v = w[at + i]; ct.pts[i] = host::Pt{(float)(v & 0xffffu), (float)(v >> 16)}; }
+        const uint32_t first = w[at];
+        at += cnt;
+        items.emplace_back((first >> 16) << 16 | (first & 0xffffu), std::move(ct));   // key = y << 16 | x of the start pixel: raster order
+    }
+}
+
+// A record the kernel flagged: follow rows [y0, y1) x columns [x0, x1) of the page on the host (db_host.cc), from a copy of the
+// mask with everything outside the rectangle blanked -- the rectangle is bounded by background, so this changes nothing inside it.
+void trace_record_on_host(const pp::SegRec& r, const uint8_t* mask, int H, int W, size_t max_contours, std::vector<std::pair<uint32_t, host::Contour>>& items) {
+    std::vector<uint8_t> tmp((size_t)r.y1 * W, 0);
+    for (int y = r.y0; y < r.y1; ++y) std::memcpy(tmp.data() + (size_t)y * W + r.x0, mask + (size_t)y * W + r.x0, (size_t)(r.x1 - r.x0));
+    std::vector<int32_t> plane((size_t)r.y1 * W);
+    (void)H;
+    for (auto& c : host::find_contours_band(tmp.data(), W, r.y1, r.y0, r.y1, max_contours, plane.data())) {
+        const uint32_t key = ((uint32_t)c.pts[0].y << 16) | (uint32_t)c.pts[0].x;
+        items.emplace_back(key, std::move(c));
+    }
+}
+
+// One page's contours in find_contours order from its records: all borders sorted by start pixel, then take(max_candidates)
+void merge_traced_page(std::vector<std::pair<uint32_t, host::Contour>>& items, size_t max_candidates, std::vector<host::Contour>& dst) {
+    std::sort(items.begin(), items.end(), [](const std::pair<uint32_t, host::Contour>& a, const std::pair<uint32_t, host::Contour>& b) { return a.first < b.first; });
+    dst.clear();
+    for (auto& it : items) { if (dst.size() >= max_candidates) break; dst.push_back(std::move(it.second)); }
+}
+
+// The sub-batch variant fed by pp::trace_contours (contours.hip): the border chains of every segment arrive as word streams in
+// pinned host memory; what the kernel flagged (too large for LDS, table / stream overflow) is followed here from the mask,
+// which `fetch_mask` brings over on demand.
+void subbatch_candidates_traced(ThreadPool& pool, const uint32_t* ctrl, const pp::SegRec* table, uint32_t table_cap, const uint32_t* packed, int H, int W, int nb,
+                                uint32_t max_candidates, const std::function<const uint8_t*(int)>& fetch_mask, std::vector<Candidate>* out /* [nb] */,
+                                bool keep_contour = false) {
+    std::vector<std::vector<host::Contour>> cs(nb);
+    const uint32_t n_rec = ctrl[pp::kTraceCtlSegments];
+    int fallbacks = 0;
+    if (ctrl[pp::kTraceCtlOverflow] || n_rec > table_cap) {   // table too small for this sub-batch: every page on the host
+        std::vector<const uint8_t*> masks(nb);
+        for (int k = 0; k < nb; ++k) masks[k] = fetch_mask(k);
+        pool.parallel_for(nb, [&](int k) { cs[k] = host::find_contours(masks[k], W, H, max_candidates); });
+        fallbacks = nb;
+    } else {
+        std::vector<std::vector<uint32_t>> by_page(nb);
+        std::vector<const uint8_t*> masks(nb, nullptr);
+        for (uint32_t i = 0; i < n_rec; ++i) {
+            const pp::SegRec& r = table[i];
+            OAR_CHECK(r.page >= 0 && r.page < nb && r.y0 >= 0 && r.y0 < r.y1 && r.y1 <= H && r.x0 >= 0 && r.x0 < r.x1 && r.x1 <= W, OAR_INTERNAL,
+                      "contour tracer: corrupt segment record");
+            by_page[r.page].push_back(i);
+            if (r.flags) { if (!masks[r.page]) masks[r.page] = fetch_mask(r.page); ++fallbacks; }   // fetched before the workers start
+        }
+        pool.parallel_for(nb, [&](int k) {
+            std::vector<std::pair<uint32_t, host::Contour>> items;
+            for (uint32_t i : by_page[k]) {
+                const pp::SegRec& r = table[i];
+                if (r.flags) trace_record_on_host(r, masks[k], H, W, max_candidates, items);
+                else parse_traced_record(r, packed, items);
+            }
+            merge_traced_page(items, max_candidates, cs[k]);
+        });
+    }
+    auto tb = std::chrono::steady_clock::now();
+    contours_to_candidates(pool, cs, nb, out, keep_contour);
+    if (g_timer && g_timer->on)
+        fprintf(stderr, "[timing]   subbatch (gpu-traced) nb=%d records=%u host-fallback=%d stage2=%.2fms\n", nb, n_rec, fallbacks,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count());
 }
 
 void finish_boxes(const std::vector<Candidate>& cands, const float* scores, int H, int W, uint32_t src_w, uint32_t src_h, float box_thresh,
@@ -419,6 +538,13 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
         if (cfg_.use_dilation) mask_dil_.reserve((size_t)B * hw);
     }
     mask_host_.reserve((size_t)B * hw);
+    // a8 on the host pool (default) or on the GPU: oar_det_cfg.gpu_contours, overridden by OAR_GPU_CONTOURS=0|1
+    static const int gpu_contours_env = [] { const char* e = getenv("OAR_GPU_CONTOURS"); return e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : -1; }();
+    const bool gpu_contours = gpu_contours_env >= 0 ? gpu_contours_env == 1 : cfg_.gpu_contours != 0;
+    if (gpu_contours) {
+        if (!trace_.fits(B, SB, H, W, nsub)) { OAR_HIP(hipStreamSynchronize(s)); OAR_HIP(hipStreamSynchronize(copy_stream_)); }
+        trace_.reserve(B, SB, H, W, nsub);
+    }
     while ((int)sub_events_.size() < nsub) { hipEvent_t e; OAR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); sub_events_.push_back(e); }
     while ((int)mask_ready_.size() < nsub) { hipEvent_t e; OAR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); mask_ready_.push_back(e); }
 
@@ -497,7 +623,17 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
         }
         OAR_HIP(hipEventRecord(mask_ready_[sb], s));
         OAR_HIP(hipStreamWaitEvent(copy_stream_, mask_ready_[sb], 0));
-        OAR_HIP(hipMemcpyAsync(mask_host_.as<uint8_t>() + (size_t)b0 * hw, traced, (size_t)nb * hw, hipMemcpyDeviceToHost, copy_stream_));
+        if (gpu_contours) {
+            // a8 on the GPU, on the copy stream (concurrent with the next sub-batch's network): only the border chains cross PCIe
+            const uint32_t tcap = (uint32_t)nb * ContourBufs::kSegsPerPage;
+            pp::trace_contours(copy_stream_, traced, nb, H, W, trace_.rows.as<uint8_t>(), trace_.band_y.as<int32_t>(), trace_.n_bands.as<int32_t>(),
+                               trace_.lists.as<uint32_t>(), tcap, trace_.scratch.as<uint32_t>(), trace_.packed.as<uint32_t>() + (size_t)b0 * trace_.packed_words_per_page,
+                               (uint32_t)std::min<size_t>((size_t)nb * trace_.packed_words_per_page, 0xffffffffu),
+                               trace_.ctrl.as<uint32_t>() + (size_t)sb * pp::kTraceCtlWords, trace_.ctrl_host.as<uint32_t>() + (size_t)sb * pp::kTraceCtlWords,
+                               trace_.table_dev.as<pp::SegRec>(), trace_.table.as<pp::SegRec>() + (size_t)b0 * ContourBufs::kSegsPerPage, tcap);
+        } else {
+            OAR_HIP(hipMemcpyAsync(mask_host_.as<uint8_t>() + (size_t)b0 * hw, traced, (size_t)nb * hw, hipMemcpyDeviceToHost, copy_stream_));
+        }
         OAR_HIP(hipEventRecord(sub_events_[sb], copy_stream_));
         tmark("det_enqueue");
     };
@@ -531,7 +667,20 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
         OAR_HIP(hipEventSynchronize(sub_events_[sb]));
         tmark("det_gpu_wait");
         const bool slow = cfg_.score_mode == 1;
-        subbatch_candidates(*pool_, mh + (size_t)b0 * hw, hw, H, W, nb, maxc, &cands[b0], slow);
+        if (gpu_contours) {
+            const uint8_t* traced_dev = (cfg_.use_dilation ? mask_dil_.as<uint8_t>() : mask_dev_.as<uint8_t>()) + (size_t)b0 * hw;
+            auto fetch_mask = [&](int k) -> const uint8_t* {   // rare: a band the kernel could not hold in LDS
+                uint8_t* dst = mask_host_.as<uint8_t>() + (size_t)(b0 + k) * hw;
+                OAR_HIP(hipMemcpyAsync(dst, traced_dev + (size_t)k * hw, hw, hipMemcpyDeviceToHost, score_stream_));
+                OAR_HIP(hipStreamSynchronize(score_stream_));
+                return dst;
+            };
+            subbatch_candidates_traced(*pool_, trace_.ctrl_host.as<uint32_t>() + (size_t)sb * pp::kTraceCtlWords,
+                                       trace_.table.as<pp::SegRec>() + (size_t)b0 * ContourBufs::kSegsPerPage, (uint32_t)nb * ContourBufs::kSegsPerPage,
+                                       trace_.packed.as<uint32_t>() + (size_t)b0 * trace_.packed_words_per_page, H, W, nb, maxc, fetch_mask, &cands[b0], slow);
+        } else {
+            subbatch_candidates(*pool_, mh + (size_t)b0 * hw, hw, H, W, nb, maxc, &cands[b0], slow);
+        }
         tmark("host_contours");
         ScoreSlot& sl = *score_slots_[sb];
         sl.base.assign(nb + 1, 0);
@@ -575,13 +724,47 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
         tmark("box_scores_enqueue");
         if (sb > 0) finish(sb - 1);   // its scores were enqueued one contour pass ago
     };
-    enqueue(0);
+    // `depth` sub-batches are queued ahead of the one the host works on (OAR_DET_DEPTH, default 1; every buffer a sub-batch's GPU
+    // work touches is either per page or used in stream order, so any depth is safe)
+    static const int depth = [] { const char* e = getenv("OAR_DET_DEPTH"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : v > 8 ? 8 : v; }();
+    int queued = 0;
+    for (; queued < std::min(depth, nsub); ++queued) enqueue(queued);
     for (int sb = 0; sb < nsub; ++sb) {
-        if (sb + 1 < nsub) enqueue(sb + 1);
+        if (queued < nsub) enqueue(queued++);
         host_stage(sb);
     }
     finish(nsub - 1);
     if (Profiler::get().enabled) Profiler::get().flush();
+}
+
+// One device mask through pp::trace_contours (the same kernels the detector uses), flagged bands followed on the host.
+std::vector<host::Contour> Detector::trace_device_mask(const uint8_t* d_mask, int H, int W, uint32_t max_contours, bool gpu_contours) {
+    const size_t hw = (size_t)H * W;
+    std::vector<uint8_t> mask;
+    auto fetch = [&]() -> const uint8_t* {
+        if (mask.empty()) { mask.resize(hw); OAR_HIP(hipMemcpy(mask.data(), d_mask, hw, hipMemcpyDeviceToHost)); }
+        return mask.data();
+    };
+    if (!gpu_contours) return host::find_contours(fetch(), W, H, max_contours);
+    ContourBufs tb;
+    tb.reserve(1, 1, H, W, 1);
+    pp::trace_contours(nullptr, d_mask, 1, H, W, tb.rows.as<uint8_t>(), tb.band_y.as<int32_t>(), tb.n_bands.as<int32_t>(), tb.lists.as<uint32_t>(),
+                       ContourBufs::kSegsPerPage, tb.scratch.as<uint32_t>(), tb.packed.as<uint32_t>(), (uint32_t)std::min<size_t>(tb.packed_words_per_page, 0xffffffffu),
+                       tb.ctrl.as<uint32_t>(), tb.ctrl_host.as<uint32_t>(), tb.table_dev.as<pp::SegRec>(), tb.table.as<pp::SegRec>(), ContourBufs::kSegsPerPage);
+    OAR_HIP(hipStreamSynchronize(nullptr));
+    const uint32_t* ctrl = tb.ctrl_host.as<uint32_t>();
+    const uint32_t n_rec = ctrl[pp::kTraceCtlSegments];
+    if (ctrl[pp::kTraceCtlOverflow] || n_rec > ContourBufs::kSegsPerPage) return host::find_contours(fetch(), W, H, max_contours);
+    std::vector<std::pair<uint32_t, host::Contour>> items;
+    for (uint32_t i = 0; i < n_rec; ++i) {
+        const pp::SegRec& r = tb.table.as<pp::SegRec>()[i];
+        OAR_CHECK(r.page == 0 && r.y0 >= 0 && r.y0 < r.y1 && r.y1 <= H && r.x0 >= 0 && r.x0 < r.x1 && r.x1 <= W, OAR_INTERNAL, "contour tracer: corrupt segment record");
+        if (r.flags) trace_record_on_host(r, fetch(), H, W, max_contours, items);
+        else parse_traced_record(r, tb.packed.as<uint32_t>(), items);
+    }
+    std::vector<host::Contour> out;
+    merge_traced_page(items, max_contours, out);
+    return out;
 }
 
 void Detector::postprocess_host(const float* pred, int H, int W, uint32_t src_w, uint32_t src_h, float thresh, float box_thresh,
@@ -596,10 +779,14 @@ void Detector::postprocess_host(const float* pred, int H, int W, uint32_t src_w,
     pp::threshold(nullptr, dpred.as<float>(), dmask.as<uint8_t>(), (int64_t)hw, thresh);
     const uint8_t* traced = dmask.as<uint8_t>();
     if (use_dilation) { dmask2.reserve(hw); pp::dilate3x3(nullptr, traced, dmask2.as<uint8_t>(), 1, H, W); traced = dmask2.as<uint8_t>(); }
-    std::vector<uint8_t> mask(hw);
-    OAR_HIP(hipMemcpy(mask.data(), traced, hw, hipMemcpyDeviceToHost));
     std::vector<Candidate> cands;
-    page_candidates(mask.data(), H, W, max_candidates ? max_candidates : 1000, cands, score_mode == 1);
+    {
+        std::vector<host::Contour> cs = Detector::trace_device_mask(traced, H, W, max_candidates ? max_candidates : 1000);
+        for (auto& c : cs) {
+            Candidate cd;
+            if (contour_candidate(c, cd, score_mode == 1)) cands.push_back(std::move(cd));
+        }
+    }
     std::vector<float> scores(cands.size(), 0.f);
     if (!cands.empty() && score_mode == 1) {
         std::vector<float> pts;

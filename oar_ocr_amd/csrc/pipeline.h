@@ -58,6 +58,17 @@ struct DetBoxes {             // per image, discovery order
 };
 
 // TextDetectionAdapter + DBModel (domain/adapters/text_detection_adapter.rs:36-79, models/detection/db.rs:281-335)
+// Buffers of pp::trace_contours for up to `pages` masks of H x W (contours.hip): device work space shared by the sub-batches of a
+// detector call (they are traced one after the other on one stream), host-visible results per page / per sub-batch.
+struct ContourBufs {
+    DevBuf rows, band_y, n_bands, lists, scratch, ctrl, table_dev;
+    PinBuf ctrl_host, table, packed;
+    static constexpr uint32_t kSegsPerPage = 4096;   // segment-table entries per page (more segments: that page is followed on the host)
+    size_t packed_words_per_page = 0;
+    void reserve(int pages, int sub_pages, int H, int W, int n_sub);
+    bool fits(int pages, int sub_pages, int H, int W, int n_sub) const;
+};
+
 class Detector {
    public:
     Detector(const uint8_t* onnx, size_t len, const oar_det_cfg& cfg);
@@ -73,6 +84,8 @@ class Detector {
     static void postprocess_host(const float* pred, int H, int W, uint32_t src_w, uint32_t src_h, float thresh, float box_thresh,
                                  float unclip, uint32_t max_candidates, DetBoxes& out, int score_mode = 0, int use_dilation = 0);
     ThreadPool& pool() { return *pool_; }
+    // a8 through the GPU tracer for one device-resident mask (test hook + postprocess_host)
+    static std::vector<host::Contour> trace_device_mask(const uint8_t* d_mask, int H, int W, uint32_t max_contours, bool gpu_contours = true);
 
    private:
     void run_group(const std::vector<int>& idx, const std::vector<PageRef>& pages, uint32_t rh, uint32_t rw, float thresh,
@@ -103,6 +116,7 @@ class Detector {
     std::vector<const uint8_t*> upload_src_;   // per page: host source still to be uploaded (nullptr = resident)
     hipStream_t score_stream_ = nullptr;   // box-score round trips (not behind the queued mask copies of later sub-batches)
     PinBuf mask_host_;
+    ContourBufs trace_;     // a8 on the GPU (OAR_GPU_CONTOURS=0: trace on the host from the read-back mask instead)
     std::vector<const uint8_t*> page_ptrs_;
     std::mutex mu_;
 };

@@ -35,6 +35,24 @@ void threshold(hipStream_t s, const float* pred, uint8_t* mask, int64_t n, float
 // masks of height x width each: a pixel becomes 255 when any pixel of its 3 x 3 neighbourhood inside the image is non-zero.
 void dilate3x3(hipStream_t s, const uint8_t* mask, uint8_t* out, int n_images, int height, int width);
 
+// a8 on the GPU (contours.hip): imageproc find_contours (processors/db_bitmap.rs:100), one wavefront per segment (a rectangle of the
+// mask bounded by blank rows / columns; see contours.hip for why segments are independent and how discovery order is recovered).
+// masks: n_pages device masks of H x W.  Device work buffers: rows [n_pages * H] bytes, band_y [n_pages * trace_max_bands(H) * 2],
+// n_bands [n_pages], lists [2 * list_cap] words, scratch [n_pages * H * W * 2] words, ctrl [kTraceCtlWords] words, table_dev
+// [table_cap].  Host-visible (pinned) outputs: ctrl_host [kTraceCtlWords], table [table_cap], packed [packed_cap_words].
+// After the stream has drained: ctrl_host[kTraceCtlSegments] records are valid in `table` (when kTraceCtlOverflow is set, or the
+// count exceeds table_cap, the table was too small: follow those pages on the host).  Record r: flags == 0 -> its word stream
+// ([hole << 31 | n_points][x | y << 16]...) is packed[off .. off + used); flags != 0 -> follow rows [y0, y1) x columns [x0, x1)
+// of page `page` on the host.  The borders of a page in find_contours order = all its records' borders sorted by their first
+// point (y, then x).
+struct SegRec { int32_t page, y0, y1, x0, x1; uint32_t off, used, n_contours, flags; };
+enum { kTraceCtlTotal = 0, kTraceCtlNSmall = 1, kTraceCtlNLarge = 2, kTraceCtlCurSmall = 3, kTraceCtlCurLarge = 4, kTraceCtlSegments = 5, kTraceCtlOverflow = 6,
+       kTraceCtlWords = 8 };
+inline int trace_max_bands(int H) { return H / 2 + 1; }
+void trace_contours(hipStream_t s, const uint8_t* masks, int n_pages, int H, int W, uint8_t* rows, int32_t* band_y, int32_t* n_bands, uint32_t* lists,
+                    uint32_t list_cap, uint32_t* scratch, uint32_t* packed, uint32_t packed_cap_words, uint32_t* ctrl, uint32_t* ctrl_host, SegRec* table_dev,
+                    SegRec* table, uint32_t table_cap);
+
 // a18 processors/decode.rs:452-501: last index of the row maximum + the maximum
 void ctc_argmax(hipStream_t s, const float* probs, int64_t rows, int vocab, int64_t* idx, float* prob);
 

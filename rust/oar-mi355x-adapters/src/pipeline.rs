@@ -178,7 +178,7 @@ impl Mi355xOcrBuilder {
             box_type: 0,
             score_mode: 0,
             use_dilation: 0,
-            reserved: 0,
+            gpu_contours: 0,
         };
         let rec_cfg = sys::oar_rec_cfg {
             device_id: self.device_id,

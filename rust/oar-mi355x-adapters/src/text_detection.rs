@@ -150,6 +150,7 @@ pub struct Mi355xTextDetectionAdapterBuilder {
     model_name_override: Option<String>,
     device_id: i32,
     host_threads: i32,
+    gpu_contours: bool,
 }
 
 impl Default for Mi355xTextDetectionAdapterBuilder {
@@ -166,6 +167,7 @@ impl Mi355xTextDetectionAdapterBuilder {
             model_name_override: None,
             device_id: 0,
             host_threads: 0,
+            gpu_contours: false,
         }
     }
 
@@ -189,6 +191,13 @@ impl Mi355xTextDetectionAdapterBuilder {
     /// Worker threads of the host-side contour / geometry stage (0 = all hardware threads).
     pub fn host_threads(mut self, host_threads: i32) -> Self {
         self.host_threads = host_threads;
+        self
+    }
+
+    /// Follow the mask borders on the GPU instead of the host thread pool (`oar_det_cfg.gpu_contours`): identical boxes;
+    /// worthwhile when many GPU ranks share the host's cores.
+    pub fn gpu_contours(mut self, enable: bool) -> Self {
+        self.gpu_contours = enable;
         self
     }
 
@@ -242,7 +251,7 @@ impl AdapterBuilder for Mi355xTextDetectionAdapterBuilder {
             box_type: if is_seal_text { 1 } else { 0 },
             score_mode: 0,   // ScoreMode::Fast  (text_detection_adapter.rs:155)
             use_dilation: 0, // use_dilation: false (text_detection_adapter.rs:154)
-            reserved: 0,
+            gpu_contours: i32::from(self.gpu_contours),
         };
 
         let source: ModelSource = model_source.into();

@@ -123,7 +123,7 @@ pub struct oar_det_cfg {
     pub box_type: i32,
     pub score_mode: i32,
     pub use_dilation: i32,
-    pub reserved: i32,
+    pub gpu_contours: i32,
 }
 
 #[repr(C)]
@@ -304,6 +304,7 @@ unsafe extern "C" {
     pub fn oar_k_threshold(pred: *const f32, n: usize, thresh: f32, mask: *mut u8) -> oar_status;
     pub fn oar_k_dilate(mask: *const u8, height: u32, width: u32, out: *mut u8) -> oar_status;
     pub fn oar_k_poly_scores(pred: *const f32, height: u32, width: u32, pts_xy: *const f32, counts: *const u32, n_polys: u32, scores: *mut f32) -> oar_status;
+    pub fn oar_k_contours(mask: *const u8, width: u32, height: u32, max_contours: u32, n_contours: *mut i32, offsets: *mut i64, pts_xy: *mut i32, types: *mut i32, cap_points: i64) -> oar_status;
     pub fn oar_k_ctc_argmax(probs: *const f32, rows: usize, vocab: usize, idx: *mut i64, prob: *mut f32) -> oar_status;
     pub fn oar_k_box_scores(pred: *const f32, height: u32, width: u32, boxes: *const f32, n_boxes: u32, scores: *mut f32) -> oar_status;
     /// fixed-length arrays: box_: [f32; 8]

@@ -60,6 +60,25 @@ def _check_pages_against_oracle(got, imgs, check, det, rec, chars, det_kw, thres
     return n_regions, n_ties
 
 
+def test_c2_gpu_border_follower_gives_the_same_pages():
+    """BASELINE C2 size with oar_det_cfg.gpu_contours = 1: every box, text and score equal to the default (host-traced) run."""
+    det, _ = models.build_det("tiny", seed=0)
+    rec, _ = models.build_rec("tiny", vocab=6906, seed=1)
+    chars = api.read_dict(models.synth_dict(6904))
+    imgs = [pages.make_page(100 + i, (960, 960), 40) for i in range(12)]
+    runs = []
+    for gpu in (False, True):
+        cfg = api.TextDetectionConfig(score_threshold=0.3, box_threshold=0.6, unclip_ratio=1.5, gpu_contours=gpu)
+        ocr = api.OAROCRBuilder(det, rec, chars).text_detection_config(cfg).image_batch_size(32).region_batch_size(256).build()
+        runs.append(ocr.predict(imgs))
+        ocr.close()
+    assert sum(len(g.text_regions) for g in runs[0]) > 300
+    for a, b in zip(*runs):
+        assert len(a.text_regions) == len(b.text_regions)
+        for ta, tb in zip(a.text_regions, b.text_regions):
+            assert np.array_equal(ta.bounding_box, tb.bounding_box) and ta.text == tb.text and ta.confidence == tb.confidence
+
+
 def test_c2_32_pages_of_960x960_in_one_predict():
     det, _ = models.build_det("tiny", seed=0)
     rec, _ = models.build_rec("tiny", vocab=6906, seed=1)

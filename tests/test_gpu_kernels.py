@@ -161,3 +161,93 @@ def test_poly_scores_match_oracle_on_contours_and_boxes():
     want = np.array([R.box_score_fast(pred, p) for p in allp], np.float32)
     assert np.array_equal(got, want)
     assert np.array_equal(api.k_box_scores(pred, np.stack(boxes)), want[len(polys):])
+
+
+# ------------------------------------------------------------------------------------------------ a8 on the GPU (contours.hip)
+def _same_contours(mask, max_contours=100000):
+    want = R.find_contours(mask)[:max_contours]
+    got = api.k_contours(mask, max_contours)
+    assert len(got) == len(want), (mask.shape, len(got), len(want))
+    for (pw, tw, _), (pg, tg) in zip(want, got):
+        assert tw == tg and np.array_equal(pw, pg)
+    return len(want)
+
+
+def _noise_masks(n, seed, lo=4, hi=200):
+    from scipy import ndimage as ndi
+    rng = np.random.default_rng(seed)
+    for i in range(n):
+        h, w = int(rng.integers(lo, hi)), int(rng.integers(lo, hi))
+        sigma = float(rng.uniform(0.4, 2.5))
+        m = (ndi.gaussian_filter(rng.random((h, w)), sigma) > rng.uniform(0.42, 0.58)).astype(np.uint8) * 255
+        if i % 5 == 0:
+            m[:, 0] = 255 * (rng.random(h) > 0.4)        # components on the x == 0 column (imageproc's `x > 0` quirk)
+        if i % 7 == 0:
+            m[rng.integers(0, h)] = 255                   # a full-width line
+        if i % 3 == 0:
+            m[rng.random((h, w)) > 0.97] = 255            # isolated pixels and thin diagonal bridges
+        if i % 4 == 0:
+            m[rng.integers(0, h, 3)] = 0                  # blank rows -> several bands
+        yield m
+
+
+@pytest.mark.gpu
+def test_gpu_contours_equal_the_oracle_chain_for_chain():
+    """The wavefront border follower against the oracle's find_contours (imageproc semantics at db_bitmap.rs:100): same
+    contours, same order, same points in the same tracing order, same Outer / Hole typing -- on blob noise of every density
+    with thin bridges, single pixels, x == 0 components, full-width lines, odd widths (not a multiple of 16) and blank rows."""
+    total = 0
+    for mask in _noise_masks(120, 5):
+        total += _same_contours(mask)
+    assert total > 3000
+
+
+@pytest.mark.gpu
+def test_gpu_contours_special_shapes():
+    m = np.zeros((12, 9), np.uint8)
+    assert api.k_contours(m) == []                                   # blank mask: no band at all
+    m[3:6] = 255
+    assert api.k_contours(m) == []                                   # full-width band: no start pixel (the quirk)
+    m[4, 4] = 0
+    _same_contours(m)                                                # ... but the hole inside is found
+    m = np.full((40, 70), 255, np.uint8)
+    _same_contours(m)                                                # everything foreground
+    m = np.zeros((64, 64), np.uint8); m[::2, ::2] = 255
+    assert _same_contours(m) == 32 * 32                              # isolated pixels (those on x == 0 come out typed Hole)
+    m = np.zeros((33, 47), np.uint8); m[np.arange(33), np.arange(33)] = 255; m[np.arange(33), 46 - np.arange(33)] = 255
+    _same_contours(m)                                                # two crossing 1-pixel diagonals: pixels visited twice
+    m = np.zeros((50, 50), np.uint8)
+    for r in range(2, 24, 4):
+        m[r:50 - r, r:50 - r] = 255 if (r // 4) % 2 == 0 else 0     # nested rings: holes inside holes
+        m[r + 2:48 - r, r + 2:48 - r] = 0 if (r // 4) % 2 == 0 else 255
+    _same_contours(m)
+    m = np.zeros((30, 1000), np.uint8); m[5:25, 3:997] = 255; m[10:20, 100:900:7] = 0
+    _same_contours(m)                                                # one wide component, many holes, > 64 px groups
+    assert len(api.k_contours(np.pad(np.full((3, 3), 255, np.uint8), 1), max_contours=0)) == 0
+
+
+@pytest.mark.gpu
+def test_gpu_contours_text_page_and_host_fallback():
+    """A 960 x 960 detector-like mask (text-line blobs in ~40 bands) and a mask whose single band is taller than the LDS
+    capacity (a vertical rule joins every line): that band is flagged by the kernel and followed on the host -- same result."""
+    rng = np.random.default_rng(0)
+    m = np.zeros((960, 960), np.uint8)
+    for y in range(12, 940, 24):
+        x = 20
+        while x < 900:
+            w = int(rng.integers(30, 200))
+            m[y:y + int(rng.integers(9, 15)), x:min(x + w, 940)] = 255
+            x += w + int(rng.integers(6, 40))
+    n = _same_contours(m)
+    assert n > 150
+    assert len(api.k_contours(m, max_contours=25)) == 25 and _same_contours(m, 25) == 25      # take(max_candidates)
+    m2 = m.copy(); m2[5:955, 5:8] = 255                                                        # one band of 950 rows
+    _same_contours(m2)
+    holes = m.copy(); holes[::24, :] = 0; holes[14::24, 30:900:11] = 0                          # punch holes into the lines
+    _same_contours(holes)
+    m3 = m.copy(); m3[300:620, 10:950] = 255; m3[340:600:9, 40:900:13] = 0                     # a 320-row block: its segment exceeds the LDS classes
+    _same_contours(m3)                                                                          # -> followed on the host, merged with the GPU's segments
+    m4 = np.zeros((64, 3000), np.uint8); m4[8:40, 4:2990:3] = 255; m4[20, 4:2990] = 255          # ~1000 column segments joined by one row -> one wide segment
+    _same_contours(m4)
+    m5 = np.zeros((40, 9000), np.uint8); m5[5:30, ::2] = 255                                     # 4500 segments in one band: more than the table holds
+    _same_contours(m5)

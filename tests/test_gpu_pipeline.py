@@ -33,10 +33,12 @@ def test_db_postprocess_bit_exact_on_same_prob_map(nets):
         assert np.array_equal(np.array([d.score for d in got], np.float32), rs)
 
 
-def test_detection_adapter_matches_oracle(nets):
+@pytest.mark.parametrize("gpu_contours", [False, True])
+def test_detection_adapter_matches_oracle(nets, gpu_contours):
+    """gpu_contours: find_contours on the host pool (default) or by the GPU border follower (contours.hip) -- same boxes"""
     det, _, _ = nets
     imgs = [pages.make_page(3, (480, 640), lines=10), pages.make_page(4, (320, 480), lines=6), pages.make_page(5, (480, 640), lines=8)]
-    cfg = api.TextDetectionConfig(0.3, 0.6, 1.5)
+    cfg = api.TextDetectionConfig(0.3, 0.6, 1.5, gpu_contours=gpu_contours)
     pred = api.TextDetectionPredictor(det, cfg)
     got = pred.predict(imgs)
     ref = pipeline_ref.OracleDetector(det).detect(imgs, 0.3, 0.6, 1.5)
@@ -87,8 +89,9 @@ def test_ocr_pipeline_matches_oracle(nets):
         ocr.predict([])
 
 
+@pytest.mark.parametrize("gpu_contours", [False, True])
 @pytest.mark.parametrize("mode", ["one shape group, several sub-batches", "mixed shapes and a blank page"])
-def test_ocr_pipeline_streaming_paths_match_oracle(nets, mode):
+def test_ocr_pipeline_streaming_paths_match_oracle(nets, mode, gpu_contours):
     """The detector hands finished pages to the crop planner sub-batch by sub-batch (one shape group) or once at the
     end (several groups: their page indices interleave); both must give the oracle's regions in the oracle's order."""
     det, rec, chars = nets
@@ -97,7 +100,7 @@ def test_ocr_pipeline_streaming_paths_match_oracle(nets, mode):
     else:
         blank = np.full((200, 300, 3), 255, np.uint8)
         imgs = [pages.make_page(70, (320, 480), lines=6), blank, pages.make_page(71, (480, 320), lines=7), pages.make_page(72, (320, 480), lines=5)]
-    ocr = api.OAROCRBuilder(det, rec, chars).text_detection_config(api.TextDetectionConfig(0.3, 0.6, 1.5)).image_batch_size(16).region_batch_size(16).build()
+    ocr = api.OAROCRBuilder(det, rec, chars).text_detection_config(api.TextDetectionConfig(0.3, 0.6, 1.5, gpu_contours=gpu_contours)).image_batch_size(16).region_batch_size(16).build()
     got = ocr.predict(imgs)
     ref = pipeline_ref.OracleOCR(det, rec, chars, 0.3, 0.6, 1.5, image_batch_size=16, region_batch_size=16).predict(imgs)
     assert len(got) == len(imgs)
