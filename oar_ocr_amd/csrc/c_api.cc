@@ -922,6 +922,7 @@ int32_t oar_host_pool_selftest(int32_t threads, int32_t jobs) {
         {
             ThreadPool pool(threads);
             for (int j = 0; j < jobs; ++j) {
+                if (j == jobs / 2) pool.set_active(true);   // first half with parked workers (every loop wakes them), second half polling
                 const int count = 2 + (j * 7) % 37;
                 std::vector<std::atomic<int>> seen(count);
                 for (auto& a : seen) a.store(0);
@@ -942,6 +943,7 @@ int32_t oar_host_pool_selftest(int32_t threads, int32_t jobs) {
         // table so that a stray index shows up as a count != 1 instead of a crash.
         {
             ThreadPool pool(threads);
+            ThreadPool::ActiveScope hot(pool);
             std::atomic<uint32_t> rng{12345};
             auto jitter = [&rng](int max_spins) {
                 uint32_t x = rng.fetch_add(0x9e3779b9u, std::memory_order_relaxed);

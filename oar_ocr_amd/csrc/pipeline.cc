@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <sched.h>
 
 namespace oar {
 
@@ -42,9 +43,28 @@ inline void tmark(const char* n) { if (g_timer) g_timer->mark(n); }
 
 
 // ================================================================================================= thread pool
+int ThreadPool::available_cpus() {
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = n > 0 ? std::min(n, c) : c; }
+    // cgroup v2: "<quota> <period>" or "max <period>"; cgroup v1: cpu.cfs_quota_us / cpu.cfs_period_us (-1 = unlimited)
+    double quota = -1, period = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        if (fscanf(f, "%31s %lf", q, &period) == 2 && strcmp(q, "max") != 0) quota = atof(q);
+        fclose(f);
+    } else {
+        if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%lf", &quota) != 1) quota = -1; fclose(fq); }
+        if (FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lf", &period) != 1) period = 0; fclose(fp); }
+    }
+    if (quota > 0 && period > 0) { const int c = (int)(quota / period); if (c >= 1) n = n > 0 ? std::min(n, c) : c; }
+    return n > 0 ? n : 1;
+}
+
 ThreadPool::ThreadPool(int n) {
     if (n <= 0) { const char* e = getenv("OAR_HOST_THREADS"); n = e ? atoi(e) : 0; }
-    if (n <= 0) n = std::min<int>((int)std::thread::hardware_concurrency(), 16);
+    if (n <= 0) n = std::min<int>(available_cpus(), 16);
     if (n <= 0) n = 1;
     if (n > 64) n = 64;
     for (int i = 0; i < n - 1; ++i) workers_.emplace_back([this] { loop(); });
@@ -68,16 +88,17 @@ void ThreadPool::loop() {
     static const int spin_ms = [] { const char* e = getenv("OAR_POOL_SPIN_MS"); int v = e ? atoi(e) : 25; return v < 0 ? 0 : v; }();
     int seen = 0;
     while (!stop_.load(std::memory_order_acquire)) {
-        // wait for a new generation: spin first (~1-2 ms), then park
+        // wait for a new generation: poll while the pool is active (and for at most spin_ms), else park
         int g = gen_.load(std::memory_order_acquire);
         if (g == seen) {
             auto t0 = std::chrono::steady_clock::now();
             int spins = 0;
             while ((g = gen_.load(std::memory_order_acquire)) == seen && !stop_.load(std::memory_order_acquire)) {
                 cpu_relax();
-                if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(spin_ms)) {
+                const bool idle = active_.load(std::memory_order_acquire) == 0;
+                if (idle || ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(spin_ms))) {
                     std::unique_lock<std::mutex> lk(mu_);
-                    cv_.wait_for(lk, std::chrono::milliseconds(50), [&] { return stop_.load() || gen_.load() != seen; });
+                    cv_.wait_for(lk, std::chrono::milliseconds(50), [&] { return stop_.load() || gen_.load() != seen || (idle && active_.load() != 0); });
                     t0 = std::chrono::steady_clock::now();
                 }
             }
@@ -97,6 +118,16 @@ void ThreadPool::loop() {
             }
             done_.fetch_add(1, std::memory_order_acq_rel);
         }
+    }
+}
+void ThreadPool::set_active(bool on) {
+    if (on) {
+        if (active_.fetch_add(1, std::memory_order_acq_rel) == 0) {
+            std::lock_guard<std::mutex> lk(mu_);
+            cv_.notify_all();   // parked workers start polling: the first parallel_for of the phase finds them awake
+        }
+    } else {
+        active_.fetch_sub(1, std::memory_order_acq_rel);
     }
 }
 bool ThreadPool::claim(int gen, int count, int& index) {
@@ -420,6 +451,7 @@ std::atomic<int> g_inject_batched_det_failures{0};   // oar_debug_inject_failure
 void Detector::run(const std::vector<PageRef>& pages, float thresh, float box_thresh, float unclip, std::vector<DetBoxes>& out,
                    std::vector<const uint8_t*>* dev_pages_out, const ReadyFn& on_ready) {
     std::lock_guard<std::mutex> lk(mu_);
+    ThreadPool::ActiveScope hot(*pool_);   // the geometry workers poll for work during a detector call only
     const int n = (int)pages.size();
     if (n > 1 && g_inject_batched_det_failures.load(std::memory_order_relaxed) > 0 && g_inject_batched_det_failures.fetch_sub(1) > 0)
         fail(OAR_DEVICE, "injected failure of a batched detection (oar_debug_inject_failure)");

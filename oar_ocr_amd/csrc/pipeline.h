@@ -24,6 +24,13 @@ class ThreadPool {
     ~ThreadPool();
     void parallel_for(int count, const std::function<void(int)>& fn);
     int size() const { return (int)workers_.size(); }
+    // Workers poll for work only while the pool is ACTIVE (a detector call is in flight); otherwise they park on the condition
+    // variable at once.  A polling worker burns a whole CPU: under a container CPU quota (cgroup cpu.max) sixteen of them
+    // polling through the recognition phase as well were enough to get the process throttled for tens of milliseconds.
+    void set_active(bool on);
+    struct ActiveScope { ThreadPool& p; explicit ActiveScope(ThreadPool& pool) : p(pool) { p.set_active(true); } ~ActiveScope() { p.set_active(false); } };
+    // CPUs this process may really use: min(affinity mask, cgroup CPU quota), at least 1
+    static int available_cpus();
     // test hooks (oar_host_pool_selftest only; set before the first parallel_for, never in production): called by a worker
     // between observing a new generation and reading the job descriptor / by the publisher between writing the descriptor
     // and opening the claim word -- the two windows of the stale-descriptor race.
@@ -42,6 +49,7 @@ class ThreadPool {
     std::atomic<uint64_t> state_{0};
     bool claim(int gen, int count, int& index);
     std::atomic<bool> stop_{false};
+    std::atomic<int> active_{0};
     std::mutex err_mu_;
     std::exception_ptr err_;
 };
