@@ -30,9 +30,7 @@ inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi 
 
 // ------------------------------------------------------------------------------------------ contours
 std::vector<Contour> find_contours(const uint8_t* mask, int width, int height, size_t max_contours) {
-    static thread_local std::vector<int32_t> iv;   // reused per worker thread (3.7 MB per 960x960 page)
-    iv.resize((size_t)width * height);
-    return find_contours_band(mask, width, height, 0, height, max_contours, iv.data());
+    return find_contours_band(mask, width, height, 0, height, max_contours, nullptr);
 }
 
 std::vector<int> blank_row_bands(const uint8_t* mask, int width, int height, int max_bands) {
@@ -60,85 +58,83 @@ std::vector<int> blank_row_bands(const uint8_t* mask, int width, int height, int
     return cuts;
 }
 
-std::vector<Contour> find_contours_band(const uint8_t* mask, int width, int height, int band_y0, int band_y1, size_t max_contours, int32_t* ivp) {
-    static const int DX[8] = {-1, -1, 0, 1, 1, 1, 0, -1};  // w, nw, n, ne, e, se, s, sw (clockwise on screen)
-    static const int DY[8] = {0, -1, -1, -1, 0, 1, 1, 1};
-    static const int8_t DIR_LUT[9] = {1, 2, 3, 0, 0, 4, 7, 6, 5};  // index (dy+1)*3 + (dx+1)
-    auto dir_of = [](int dx, int dy) { return (int)DIR_LUT[(dy + 1) * 3 + (dx + 1)]; };
-    // the band may be cut only at blank rows, so neighbours outside [band_y0, band_y1) are background by construction
-    int32_t* iv = ivp;
-    for (size_t i = (size_t)band_y0 * width; i < (size_t)band_y1 * width; ++i) iv[i] = mask[i] > 0 ? 1 : 0;
-    auto at = [&](int x, int y) -> int32_t& { return iv[(size_t)y * width + x]; };
-    auto nonzero = [&](int x, int y) { return (unsigned)x < (unsigned)width && y >= band_y0 && y < band_y1 && iv[(size_t)y * width + x] != 0; };
-
+std::vector<Contour> find_contours_band(const uint8_t* mask, int width, int height, int band_y0, int band_y1, size_t max_contours, int32_t* /*unused*/) {
+    // imageproc's border labels only ever matter through three predicates -- `== 1` (foreground not yet on a followed border),
+    // `> 0` (that, or marked with a positive label) and `!= 0` -- plus the hierarchy (parent links), which DB post-processing
+    // never reads.  The state is therefore one byte per pixel: 0 background, 1 unmarked, 2 marked positive, 3 marked negative,
+    // in a plane framed by one background pixel on every side (the band may be cut only at blank rows, so its neighbours above
+    // and below ARE background), which removes every bounds check from the walk.
+    (void)height;
+    const int rows = band_y1 - band_y0;
     std::vector<Contour> out;
-    int border = 1;
+    if (rows <= 0 || width <= 0) return out;
+    const int stride = width + 2;
+    static thread_local std::vector<uint8_t> plane;
+    plane.resize((size_t)(rows + 2) * stride);
+    uint8_t* st = plane.data();
+    std::memset(st, 0, (size_t)stride);
+    std::memset(st + (size_t)(rows + 1) * stride, 0, (size_t)stride);
+    for (int r = 0; r < rows; ++r) {
+        uint8_t* d = st + (size_t)(r + 1) * stride;
+        const uint8_t* m = mask + (size_t)(band_y0 + r) * width;
+        d[0] = 0;
+        for (int x = 0; x < width; ++x) d[x + 1] = m[x] != 0;
+        d[width + 1] = 0;
+    }
+    // neighbour offsets in the framed plane: w, nw, n, ne, e, se, s, sw (clockwise on screen), twice so that (front + k) needs no mask
+    const int off8[16] = {-1, -stride - 1, -stride, -stride + 1, 1, stride + 1, stride, stride - 1,
+                          -1, -stride - 1, -stride, -stride + 1, 1, stride + 1, stride, stride - 1};
     bool full = false;
 
-    // Per-pixel step of the raster scan (imageproc's loop body).  Only called for pixels that can start a border
-    // (first / last pixel of a foreground run); interior pixels of a run can only update `parent_border`.
-    auto visit = [&](int x, int y, int& parent_border) {
-        int32_t v = at(x, y);
-        bool start = false, hole = false;
-        int ax = 0, ay = y;
-        if (v == 1 && x > 0 && at(x - 1, y) == 0) { start = true; ax = x - 1; }
-        else if (v > 0 && x + 1 < width && at(x + 1, y) == 0) {
-            if (v > 1) parent_border = v;
-            start = true; hole = true; ax = x + 1;
-        }
-        if (start) {
-            ++border;
-            Contour c;
-            c.hole = hole;
-            c.pts.reserve(256);
-            if (parent_border > 1) {
-                int pi = parent_border - 2;
-                if (pi < (int)out.size()) {
-                    bool parent_outer = !out[pi].hole;
-                    c.parent = ((!hole) != parent_outer) ? pi : out[pi].parent;
+    // One border from start pixel (x, y) [band-local row y]; `first` = direction index of the background neighbour that triggered it
+    auto follow = [&](int x, int y, int first, bool hole) {
+        Contour c;
+        c.hole = hole;
+        c.pts.reserve(256);
+        uint8_t* const p0 = st + (size_t)(y + 1) * stride + (x + 1);
+        int d1 = -1;
+        for (int k = 0; k < 8; ++k) if (p0[off8[first + k]]) { d1 = (first + k) & 7; break; }   // clockwise from the trigger
+        if (d1 < 0) {
+            c.pts.push_back({(float)x, (float)(y + band_y0)});
+            *p0 = 3;
+        } else {
+            uint8_t* const p1 = p0 + off8[d1];
+            uint8_t* p3 = p0;
+            int px = x, py = y, front = d1;   // front: direction from the current pixel to the previous one
+            static const int DX[8] = {-1, -1, 0, 1, 1, 1, 0, -1};
+            static const int DY[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+            for (;;) {
+                c.pts.push_back({(float)px, (float)(py + band_y0)});
+                // counter-clockwise search starting next to the previous pixel; the reference's second loop ("was the east
+                // neighbour examined before the next pixel was found") is folded into the same pass
+                int k4 = 0;
+                bool right_edge = false;
+                for (int k = 7; k >= 0; --k) {
+                    if (p3[off8[front + k]]) { k4 = k; break; }
+                    if (((front + k) & 7) == 4) right_edge = true;
                 }
+                const int d4 = (front + k4) & 7;
+                if (px + 1 == width || right_edge) *p3 = 3;
+                else if (*p3 == 1) *p3 = 2;
+                uint8_t* const p4 = p3 + off8[d4];
+                if (p4 == p0 && p3 == p1) break;
+                p3 = p4; px += DX[d4]; py += DY[d4];
+                front = (d4 + 4) & 7;
             }
-            int first = dir_of(ax - x, ay - y);
-            bool found = false;
-            int p1x = 0, p1y = 0;
-            for (int k = 0; k < 8; ++k) {
-                int d = (first + k) & 7;
-                if (nonzero(x + DX[d], y + DY[d])) { found = true; p1x = x + DX[d]; p1y = y + DY[d]; break; }
-            }
-            if (!found) {
-                c.pts.push_back({(float)x, (float)y});
-                at(x, y) = -border;
-            } else {
-                int p2x = p1x, p2y = p1y, p3x = x, p3y = y;
-                while (true) {
-                    c.pts.push_back({(float)p3x, (float)p3y});
-                    int front = dir_of(p2x - p3x, p2y - p3y);
-                    int p4x = p3x, p4y = p3y;
-                    // counter-clockwise scan starting next to p2; the reference's second loop ("was the east neighbour
-                    // examined before p4 was found") is folded into the same pass
-                    bool right_edge = false;
-                    for (int k = 7; k >= 0; --k) {
-                        int d = (front + k) & 7;
-                        if (nonzero(p3x + DX[d], p3y + DY[d])) { p4x = p3x + DX[d]; p4y = p3y + DY[d]; break; }
-                        if (d == 4) right_edge = true;
-                    }
-                    if (p3x + 1 == width || right_edge) at(p3x, p3y) = -border;
-                    else if (at(p3x, p3y) == 1) at(p3x, p3y) = border;
-                    if (p4x == x && p4y == y && p3x == p1x && p3y == p1y) break;
-                    p2x = p3x; p2y = p3y; p3x = p4x; p3y = p4y;
-                }
-            }
-            out.push_back(std::move(c));
-            if (out.size() >= max_contours) full = true;
         }
-        int32_t nv = at(x, y);
-        if (nv != 1) parent_border = nv < 0 ? -nv : nv;
+        out.push_back(std::move(c));
+        if (out.size() >= max_contours) full = true;
+    };
+    // imageproc's loop body for a pixel that can start a border (first / last pixel of a foreground run)
+    auto visit = [&](int x, int y) {
+        const uint8_t* p = st + (size_t)(y + 1) * stride + (x + 1);
+        const uint8_t v = *p;
+        if (v == 1 && x > 0 && p[-1] == 0) follow(x, y, 0, false);
+        else if ((v == 1 || v == 2) && x + 1 < width && p[1] == 0) follow(x, y, 4, true);
     };
 
-    (void)height;
-    for (int y = band_y0; y < band_y1 && !full; ++y) {
-        int parent_border = 1;
-        const uint8_t* mrow = mask + (size_t)y * width;
+    for (int y = 0; y < rows && !full; ++y) {
+        const uint8_t* mrow = mask + (size_t)(band_y0 + y) * width;
         int x = 0;
         while (x < width && !full) {
             // background never changes state (zero-ness is invariant under border labelling): skip 8 bytes at a time
@@ -152,21 +148,12 @@ std::vector<Contour> find_contours_band(const uint8_t* mask, int width, int heig
                 while (x < width && mrow[x] == 0) ++x;
                 if (x >= width) break;
             }
-            // foreground run [x, xe)
+            // foreground run [x, xe): interior pixels cannot start a border (both horizontal neighbours are foreground)
             const void* z = std::memchr(mrow + x, 0, (size_t)(width - x));
             const int xe = z ? (int)((const uint8_t*)z - mrow) : width;
-            visit(x, y, parent_border);                       // may start an outer (or, for a 1-px run, hole) border
+            visit(x, y);                                  // may start an outer (or, for a 1-px run, hole) border
             if (full) break;
-            if (xe - x > 1) {
-                // interior pixels cannot start a border (both horizontal neighbours are foreground); they only
-                // carry the id of the last labelled border they belong to
-                const int32_t* r = &iv[(size_t)y * width];
-                for (int i = x + 1; i < xe - 1; ++i) {
-                    int32_t v = r[i];
-                    if (v != 1) parent_border = v < 0 ? -v : v;
-                }
-                visit(xe - 1, y, parent_border);              // may start a hole border
-            }
+            if (xe - x > 1) visit(xe - 1, y);             // may start a hole border
             x = xe;
         }
     }
@@ -265,9 +252,12 @@ std::vector<Pt> simplify_chain(const std::vector<Pt>& p) {
     auto sgn = [](float v) { return v > 0.0f ? 1 : (v < 0.0f ? -1 : 0); };
     std::vector<Pt> out;
     out.reserve(n);
+    const Pt* prev = &p[n - 1];
     for (size_t i = 0; i < n; ++i) {
-        const Pt &prev = p[(i + n - 1) % n], &cur = p[i], &next = p[(i + 1) % n];
-        if (sgn(cur.x - prev.x) != sgn(next.x - cur.x) || sgn(cur.y - prev.y) != sgn(next.y - cur.y)) out.push_back(cur);
+        const Pt& cur = p[i];
+        const Pt& next = p[i + 1 == n ? 0 : i + 1];
+        if (sgn(cur.x - prev->x) != sgn(next.x - cur.x) || sgn(cur.y - prev->y) != sgn(next.y - cur.y)) out.push_back(cur);
+        prev = &cur;
     }
     if (out.size() < 3) return p;
     return out;
