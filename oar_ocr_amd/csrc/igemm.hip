@@ -218,15 +218,26 @@ static int ws_x6_tile(int K, int nfrag) {
 int ctc_tiles(int n_padded) { return ((n_padded + 15) / 16 + 7) / 8; }
 bool ctc_partials_supported(int K) { return K % 4 == 0 && K >= 32 && (size_t)8 * ((K + 15) / 16) * 1024 <= 150 * 1024; }
 
-int igemm_weight_format(long M, int K, int N, bool is1x1) {
-    // OAR_IGEMM_X6: 1 (default) = bf16x6 weight-stationary kernel on the wide 1x1 / Linear layers, 0 = f32 MFMA everywhere
+// OAR_IGEMM_OS: 1 (default) = output-stationary bf16x6 kernel where the weights do not fit LDS (long-K 1x1, k x k), 0 = off,
+// 2 = also wherever the weight-stationary x6 kernel would run (A/B)
+static int os_mode() { static const int m = [] { const char* e = getenv("OAR_IGEMM_OS"); return e ? atoi(e) : 1; }(); return m; }
+// layers the output-stationary x6 kernel takes: every lane's 8-float group inside one tap and all-valid or all-padding
+// (Cin % 8), wide and long enough to be matrix-pipe work, enough 256-pixel tiles to fill the chip, float4 epilogue
+static bool os_x6_eligible(long M, int K, int N, int Cin) {
+    return Cin % 8 == 0 && K >= 256 && N >= 64 && (N & 3) == 0 && M >= 65536 && K < 65536;
+}
+
+int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin) {
+    // OAR_IGEMM_X6: 1 (default) = bf16x6 kernels on the wide layers, 0 = f32 MFMA everywhere
     static const int mode = [] { const char* e = getenv("OAR_IGEMM_X6"); return e ? atoi(e) : 1; }();
-    if (!mode || !is1x1) return IGEMM_W_K16;
+    if (!mode) return IGEMM_W_K16;
+    if (!is1x1) return (os_mode() && Cin > 0 && os_x6_eligible(M, K, N, Cin)) ? IGEMM_W_X6 : IGEMM_W_K16;
     // every lane's 8-float group must be all-valid or all-padding (K % 8); wide enough to be matrix-pipe bound
     // (N >= 96, K >= 96); enough (16-pixel tile, cout tile) pairs to fill the 4096 resident waves; float4 epilogue
     const int nfrag = (N + 15) / 16;
     const long passes = ((M + 15) / 16) * ((nfrag + 7) / 8);
     if (K % 8 == 0 && K >= 96 && N >= 96 && (N & 3) == 0 && passes >= 4096 && ws_x6_tile(K, nfrag) > 0) return IGEMM_W_X6;
+    if (os_mode() && os_x6_eligible(M, K, N, K)) return IGEMM_W_X6;   // long K: the weights do not fit LDS
     return IGEMM_W_K16;
 }
 
@@ -300,9 +311,10 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     double flops = 2.0 * (double)p.M * p.K * p.gemm_cout;
     double bytes = 4.0 * ((double)c.N * c.H * c.W * c.Cin + (double)p.M * p.gemm_cout + (double)p.K * p.gemm_cout);
     char pname[96];
-    const char* cls = x6 ? "conv_igemm_ws_x6" : ws ? "conv_igemm_ws" : "conv_igemm";   // one profiler class per kernel
+    const bool x6_os = x6 && (!is1x1 || ws_x6_tile(p.K, nfrag) == 0 || (os_mode() == 2 && os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin)));
+    const char* cls = x6_os ? "conv_igemm_os_x6" : x6 ? "conv_igemm_ws_x6" : ws ? "conv_igemm_ws" : "conv_igemm";   // one profiler class per kernel
     if (Profiler::get().detail) {
-        snprintf(pname, sizeof pname, "conv_igemm%s M=%ld K=%d N=%d k%dx%d s%d%s", x6 ? "_x6" : ws ? "_ws" : "", p.M, p.K, p.gemm_cout, c.kh, c.kw, c.sh, c.convt2x2 ? " convT" : "");
+        snprintf(pname, sizeof pname, "conv_igemm%s M=%ld K=%d N=%d k%dx%d s%d%s", x6_os ? "_os_x6" : x6 ? "_x6" : ws ? "_ws" : "", p.M, p.K, p.gemm_cout, c.kh, c.kw, c.sh, c.convt2x2 ? " convT" : "");
         cls = pname;
     }
     ProfScope ps(s, cls, bytes, flops);
@@ -320,9 +332,15 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     if (ws3) {
         conv_igemm_ws3(s, p, nfrag);
     } else if (x6) {
-        const int nt = ws_x6_tile(p.K, nfrag);
-        OAR_CHECK(nt > 0 && is1x1 && ((p.Cout & 3) == 0) && ((p.y_ld & 3) == 0), OAR_INTERNAL, "conv_igemm: bf16x6 weights on an ineligible layer");
-        conv_igemm_ws_x6(s, p, nt, (nfrag + nt - 1) / nt, (size_t)nt * p.KC * 3072 + (size_t)nt * 64 + 16);
+        const int nt = is1x1 ? ws_x6_tile(p.K, nfrag) : 0;
+        OAR_CHECK(((p.Cout & 3) == 0) && ((p.y_ld & 3) == 0) && !c.convt2x2, OAR_INTERNAL, "conv_igemm: bf16x6 weights on an ineligible layer");
+        const bool os = nt == 0 || (os_mode() == 2 && os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin));
+        if (os) {
+            OAR_CHECK(os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin), OAR_INTERNAL, "conv_igemm: bf16x6 weights on a layer neither x6 kernel takes");
+            conv_igemm_os_x6(s, p, nfrag, is1x1);
+        } else {
+            conv_igemm_ws_x6(s, p, nt, (nfrag + nt - 1) / nt, (size_t)nt * p.KC * 3072 + (size_t)nt * 64 + 16);
+        }
     } else if (ws) {
         const int wny = (nfrag + ws_nt - 1) / ws_nt;
         const size_t lds = (size_t)ws_nt * p.KC * 1024 + (size_t)ws_nt * 64 + 16;

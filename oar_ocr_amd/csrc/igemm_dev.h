@@ -226,6 +226,9 @@ void conv_igemm_ws_1x1(hipStream_t s, const IgemmP& p, int ws_nt, int ny, size_t
 void conv_igemm_ws_gen(hipStream_t s, const IgemmP& p, int ws_nt, int ny, size_t lds);
 // weight-stationary bf16x6 variant for 1x1 / Linear layers (igemm_ws_x6.hip); p.KC = ceil(K/32), p.w in x6 fragment order
 void conv_igemm_ws_x6(hipStream_t s, const IgemmP& p, int ws_nt, int ny, size_t lds);
+// output-stationary bf16x6 variant for long-K 1x1 layers and k x k convolutions (igemm_os_x6.hip); same weight format
+int igemm_os_x6_tile(int nfrag);
+void conv_igemm_os_x6(hipStream_t s, const IgemmP& p, int nfrag, bool is1x1);
 // 3x3 / stride 1 / pad 1 variant with in-register horizontal tap reuse (igemm_ws3.hip); nfrag = ceil(cout / 16) <= 2
 bool conv_igemm_ws3_eligible(const IgemmP& p, int nfrag);
 void conv_igemm_ws3(hipStream_t s, const IgemmP& p, int nfrag);

@@ -40,7 +40,7 @@ enum : int { IGEMM_W_K16 = 0, IGEMM_W_X6 = 1 };
 // Rows are padded to 64 couts, K to the chunk size, with zeros.
 void conv_igemm(hipStream_t s, const ConvP& p);
 // chosen per layer AND input shape at plan time: M = GEMM rows (pixels), N = couts
-int igemm_weight_format(long M, int K, int N, bool is1x1);
+int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin = 0);   // Cin: input channels of a k x k conv (0: treat as not eligible for the x6 path)
 // Depthwise conv. w: [kh][kw][C]. C % 4 == 0.
 void conv_dw(hipStream_t s, const ConvP& p);
 // Direct conv for everything else (small Cin, odd channels, grouped). w: [kh][kw][Cin/g][Cout].

@@ -288,6 +288,38 @@ def test_igemm_kernels_at_bench_shapes(case):
 
 
 @pytest.mark.parametrize("case", [
+    ("os_x6 3x3 64->64", 2, 64, 64, 192, 192, 3, (1, 1), 1),            # K = 576: k x k conv on the output-stationary bf16x6 kernel
+    ("os_x6 1x1 512->128", 1, 512, 128, 256, 256, 1, (1, 1), 1),        # long-K 1x1: the weights do not fit the weight-stationary LDS tile
+    ("os_x6 3x3 s2 32->96 ragged", 1, 32, 96, 514, 514, 3, (2, 2), 1),  # stride 2, 66049 output pixels (not a multiple of the 256-pixel tile), 6 cout fragments
+    ("os_x6 3x3 40->64 K tail", 1, 40, 64, 260, 260, 3, (1, 1), 1),     # K = 360: zero-padded tail of the last 32-deep chunk, Cin not a multiple of 32
+    ("os_x6 3x3 dilated 64->80", 1, 64, 80, 264, 264, 3, (1, 1), 2),    # dilation 2 (padding 2), 5 cout fragments -> tile of 8 with 3 idle
+    ("os_x6 5x5 16->64", 1, 16, 64, 272, 272, 5, (1, 1), 1),            # K = 400, taps straddle the 32-deep chunks
+])
+def test_output_stationary_x6_kernel(case):
+    """igemm_os_x6.hip (the layers whose weights do not fit LDS) against torch-CPU conv2d: image borders (zero taps), strides,
+    dilation, ragged pixel / cout / K tails."""
+    name, n, cin, cout, h, w, k, strides, dil = case
+    g = GraphBuilder("conv")
+    rng = np.random.default_rng(len(name))
+    g.add_input("x", ["N", cin, "H", "W"])
+    wt = (rng.standard_normal((cout, cin, k, k)) * (1.0 / np.sqrt(cin * k * k))).astype(np.float32)
+    pad = dil * (k // 2)
+    y = g.op("Conv", ["x", g.init(wt), g.init(rng.standard_normal(cout).astype(np.float32))], kernel_shape=[k, k], strides=list(strides),
+             pads=[pad] * 4, group=1, dilations=[dil, dil])
+    y = g.op("HardSwish", [y])
+    g.add_output(y, ["N", cout, "H", "W"])
+    x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    m = g.model()
+    _check(m, x)
+    eng = api.OrtInfer(m, profile=True)
+    api.prof_reset()
+    eng.infer(x)
+    assert any(e["name"] == "conv_igemm_os_x6" for e in api.prof_snapshot()), "the layer did not select the output-stationary kernel"
+    api.prof_enable(False)
+    eng.close()
+
+
+@pytest.mark.parametrize("case", [
     ("5x5 s1 H=6", 16, 192, 6, 160, 5, (1, 1)),            # recognizer shapes: the whole height in three 2-row tiles
     ("5x5 s(2,1) H=6", 16, 192, 6, 160, 5, (2, 1)),
     ("5x5 s1 ragged", 3, 128, 61, 75, 5, (1, 1)),          # partial tiles in both directions

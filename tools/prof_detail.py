@@ -3,16 +3,21 @@ sys.path.insert(0,'.')
 import numpy as np
 from oar_ocr_amd import api
 from oar_ocr_amd.synth import models, pages
-det,_=models.build_det(); rec,_=models.build_rec()
-chars=api.read_dict(models.synth_dict())
-P=[pages.make_page(i,(960,960),40) for i in range(32)]
+SERVER = len(sys.argv) > 1 and sys.argv[1] == 'server'     # BASELINE C3: server-size det + SVTR rec (V = 18710), 1280^2 pages
+if SERVER:
+    det,_=models.build_det('server', seed=0); rec,_=models.build_rec('server', vocab=18710, seed=1)
+    chars=api.read_dict(models.synth_dict(18708)); S=1280; NP=16
+else:
+    det,_=models.build_det(); rec,_=models.build_rec()
+    chars=api.read_dict(models.synth_dict()); S=960; NP=32
+P=[pages.make_page(i,(S,S),40) for i in range(NP)]
 bufs=[api.DeviceBuffer(p) for p in P]
-ocr=api.OAROCRBuilder(det,rec,chars).text_detection_config(api.TextDetectionConfig(0.3,0.6,1.5)).image_batch_size(32).region_batch_size(256).build()
+ocr=api.OAROCRBuilder(det,rec,chars).text_detection_config(api.TextDetectionConfig(0.3,0.6,1.5,limit_side_len=S)).image_batch_size(32).region_batch_size(256).build()
 ptrs=[int(b.ptr.value) for b in bufs]
-ocr.predict_device(ptrs,[960]*32,[960]*32,raw=True)
+ocr.predict_device(ptrs,[S]*NP,[S]*NP,raw=True)
 api.prof_enable(True); api.prof_reset()
 import time
-t=time.perf_counter(); r=ocr.predict_device(ptrs,[960]*32,[960]*32,raw=True); dt=time.perf_counter()-t
+t=time.perf_counter(); r=ocr.predict_device(ptrs,[S]*NP,[S]*NP,raw=True); dt=time.perf_counter()-t
 snap=api.prof_snapshot()
 print('step ms',dt*1e3, r)
 tot=sum(e['total_ms'] for e in snap)
