@@ -1790,7 +1790,8 @@ struct Planner {
             N = Np;
             // CTC head: when the logits only feed the fused tail, do not even write them -- per-tile softmax partials
             Loc part;
-            if (P.logits_valid > 0 && od.back() == Np && fmt == k::IGEMM_W_K16 && act.kind == k::ACT_NONE && k::ctc_partials_supported((int)K)) {
+            if (P.logits_valid > 0 && od.back() == Np && act.kind == k::ACT_NONE &&
+                (fmt == k::IGEMM_W_K16 ? k::ctc_partials_supported((int)K) : k::ctc_partials_supported_x6((int)K))) {
                 static const bool on = [] { const char* e = getenv("OAR_CTC_PARTIALS"); return !e || atoi(e) != 0; }();
                 if (on) {
                     P.ctc_tiles = k::ctc_tiles((int)Np);

@@ -217,6 +217,8 @@ static int ws_x6_tile(int K, int nfrag) {
 
 int ctc_tiles(int n_padded) { return ((n_padded + 15) / 16 + 7) / 8; }
 bool ctc_partials_supported(int K) { return K % 4 == 0 && K >= 32 && (size_t)8 * ((K + 15) / 16) * 1024 <= 150 * 1024; }
+// the same epilogue on the bf16x6 weight-stationary kernel: its 8-fragment tile must fit LDS
+bool ctc_partials_supported_x6(int K) { return K % 8 == 0 && K >= 32 && (size_t)8 * ((K + 31) / 32) * 3072 <= 150 * 1024; }
 
 // OAR_IGEMM_OS: 1 (default) = output-stationary bf16x6 kernel where the weights do not fit LDS (long-K 1x1, k x k), 0 = off,
 // 2 = also wherever the weight-stationary x6 kernel would run (A/B)
@@ -237,6 +239,8 @@ int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin) {
     const int nfrag = (N + 15) / 16;
     const long passes = ((M + 15) / 16) * ((nfrag + 7) / 8);
     if (K % 8 == 0 && K >= 96 && N >= 96 && (N & 3) == 0 && passes >= 4096 && ws_x6_tile(K, nfrag) > 0) return IGEMM_W_X6;
+    // (a K = 64 CTC head was measured on this kernel too: 157 us against 141 us on the f32 kernel -- two chunks of K do not
+    // amortise the per-tile weight staging, it stays on f32)
     if (os_mode() && os_x6_eligible(M, K, N, K)) return IGEMM_W_X6;   // long K: the weights do not fit LDS
     return IGEMM_W_K16;
 }
@@ -299,8 +303,8 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
             if (padded < best) { best = padded; ws_nt = t; }
         }
     }
-    if (c.ctc_part) {   // the partial-softmax epilogue lives in the f32 weight-stationary kernel, 8 fragments per tile
-        OAR_CHECK(!x6 && vec_ok && ctc_partials_supported(p.K) && is1x1, OAR_INTERNAL, "conv_igemm: CTC partials on an ineligible layer");
+    if (c.ctc_part) {   // the partial-softmax epilogue lives in the weight-stationary kernels (f32 and bf16x6), 8 fragments per tile
+        OAR_CHECK(vec_ok && is1x1 && (x6 ? ctc_partials_supported_x6(p.K) : ctc_partials_supported(p.K)), OAR_INTERNAL, "conv_igemm: CTC partials on an ineligible layer");
         ws_nt = 8;
     }
     const bool ws3 = !x6 && !c.ctc_part && conv_igemm_ws3_eligible(p, nfrag);
@@ -311,7 +315,7 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     double flops = 2.0 * (double)p.M * p.K * p.gemm_cout;
     double bytes = 4.0 * ((double)c.N * c.H * c.W * c.Cin + (double)p.M * p.gemm_cout + (double)p.K * p.gemm_cout);
     char pname[96];
-    const bool x6_os = x6 && (!is1x1 || ws_x6_tile(p.K, nfrag) == 0 || (os_mode() == 2 && os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin)));
+    const bool x6_os = x6 && !c.ctc_part && (!is1x1 || ws_x6_tile(p.K, nfrag) == 0 || (os_mode() == 2 && os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin)));
     const char* cls = x6_os ? "conv_igemm_os_x6" : x6 ? "conv_igemm_ws_x6" : ws ? "conv_igemm_ws" : "conv_igemm";   // one profiler class per kernel
     if (Profiler::get().detail) {
         snprintf(pname, sizeof pname, "conv_igemm%s M=%ld K=%d N=%d k%dx%d s%d%s", x6_os ? "_os_x6" : x6 ? "_x6" : ws ? "_ws" : "", p.M, p.K, p.gemm_cout, c.kh, c.kw, c.sh, c.convt2x2 ? " convT" : "");
@@ -332,9 +336,9 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     if (ws3) {
         conv_igemm_ws3(s, p, nfrag);
     } else if (x6) {
-        const int nt = is1x1 ? ws_x6_tile(p.K, nfrag) : 0;
+        const int nt = c.ctc_part ? 8 : is1x1 ? ws_x6_tile(p.K, nfrag) : 0;
         OAR_CHECK(((p.Cout & 3) == 0) && ((p.y_ld & 3) == 0) && !c.convt2x2, OAR_INTERNAL, "conv_igemm: bf16x6 weights on an ineligible layer");
-        const bool os = nt == 0 || (os_mode() == 2 && os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin));
+        const bool os = !c.ctc_part && (nt == 0 || (os_mode() == 2 && os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin)));
         if (os) {
             OAR_CHECK(os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin), OAR_INTERNAL, "conv_igemm: bf16x6 weights on a layer neither x6 kernel takes");
             conv_igemm_os_x6(s, p, nfrag, is1x1);

@@ -183,6 +183,9 @@ __global__ __launch_bounds__(1024) void conv_igemm_ws_x6_kernel(IgemmWsX6P q) {
             if (kc + 4 < p.KC) chunk(kc + 4, I0{}, Wy{}, I0{});
             // land the two chunks requested for the next tile BEFORE any store is issued
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(s0.a), "+v"(s0.b), "+v"(s1.a), "+v"(s1.b), "+v"(s2.a), "+v"(s2.b));
+            if constexpr (NT == 8) {   // CTC head: softmax partials instead of logits (igemm_ctc_epilogue, tiles of 8 fragments)
+                if (p.ctc_part) { igemm_ctc_epilogue<NT>(p, acc, m0, pl_, g, nf0, ntile, q.ny); return; }
+            }
             igemm_epilogue<NT, 1, true>(p, acc, m0, pl_, g, nf0, false);
         };
 

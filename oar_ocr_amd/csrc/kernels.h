@@ -111,6 +111,7 @@ void attention(hipStream_t s, const float* qkv, float* out, int n, int T, int he
 // of 128 columns); ctc_combine merges the tiles of each row into the arg max index and its softmax probability.
 int ctc_tiles(int n_padded);   // cout tiles per row for a (16-padded) class count
 bool ctc_partials_supported(int K);
+bool ctc_partials_supported_x6(int K);
 void ctc_combine(hipStream_t s, const float* part, int64_t rows, int tiles, int64_t* idx, float* prob);
 void softmax_argmax(hipStream_t s, const float* logits, int64_t rows, int C, int ld, int64_t* idx, float* prob);   // ld = row stride
 
