@@ -226,7 +226,8 @@ static int os_mode() { static const int m = [] { const char* e = getenv("OAR_IGE
 // layers the output-stationary x6 kernel takes: every lane's 8-float group inside one tap and all-valid or all-padding
 // (Cin % 8), wide and long enough to be matrix-pipe work, enough 256-pixel tiles to fill the chip, float4 epilogue
 static bool os_x6_eligible(long M, int K, int N, int Cin) {
-    return Cin % 8 == 0 && K >= 256 && N >= 64 && (N & 3) == 0 && M >= 65536 && K < 65536;
+    static const int min_k = [] { const char* e = getenv("OAR_IGEMM_OS_MINK"); return e ? atoi(e) : 256; }();
+    return Cin % 8 == 0 && K >= min_k && N >= 64 && (N & 3) == 0 && M >= 65536 && K < 65536;
 }
 
 int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin) {
