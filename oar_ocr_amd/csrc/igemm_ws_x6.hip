@@ -41,8 +41,8 @@ __device__ __forceinline__ void split3(const f32x4& a, const f32x4& b, uint4& h,
     l = make_uint4((ll[0] >> 16) | ll[1], (ll[2] >> 16) | ll[3], (ll[4] >> 16) | ll[5], (ll[6] >> 16) | ll[7]);
 }
 
-template <int NT>
-__global__ __launch_bounds__(1024) void conv_igemm_ws_x6_kernel(IgemmWsX6P q) {
+template <int NT, bool CTC = false>   // CTC: the CTC-head variant (softmax partials instead of logits), its own instantiation so that
+__global__ __launch_bounds__(1024) void conv_igemm_ws_x6_kernel(IgemmWsX6P q) {   // the plain kernels keep their register budget
     extern __shared__ uint4 wx_lds[];   // [kc][nf][plane][lane] weights | [nf][16] bias | counter
     const IgemmP& p = q.g;
     const int lane = threadIdx.x & 63;
@@ -183,10 +183,8 @@ __global__ __launch_bounds__(1024) void conv_igemm_ws_x6_kernel(IgemmWsX6P q) {
             if (kc + 4 < p.KC) chunk(kc + 4, I0{}, Wy{}, I0{});
             // land the two chunks requested for the next tile BEFORE any store is issued
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(s0.a), "+v"(s0.b), "+v"(s1.a), "+v"(s1.b), "+v"(s2.a), "+v"(s2.b));
-            if constexpr (NT == 8) {   // CTC head: softmax partials instead of logits (igemm_ctc_epilogue, tiles of 8 fragments)
-                if (p.ctc_part) { igemm_ctc_epilogue<NT>(p, acc, m0, pl_, g, nf0, ntile, q.ny); return; }
-            }
-            igemm_epilogue<NT, 1, true>(p, acc, m0, pl_, g, nf0, false);
+            if constexpr (CTC) igemm_ctc_epilogue<NT>(p, acc, m0, pl_, g, nf0, ntile, q.ny);   // tiles of 8 fragments (ctc_tiles)
+            else igemm_epilogue<NT, 1, true>(p, acc, m0, pl_, g, nf0, false);
         };
 
         for (;;) {
@@ -205,10 +203,10 @@ __global__ __launch_bounds__(1024) void conv_igemm_ws_x6_kernel(IgemmWsX6P q) {
     }
 }
 
-template <int NT>
+template <int NT, bool CTC = false>
 static void launch_ws_x6(hipStream_t s, const IgemmP& p, int ny, size_t lds) {
     static const bool once = [] {
-        OAR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws_x6_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        OAR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws_x6_kernel<NT, CTC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         return true;
     }();
     (void)once;
@@ -218,10 +216,11 @@ static void launch_ws_x6(hipStream_t s, const IgemmP& p, int ny, size_t lds) {
     q.wt_total = (p.M + 15) / 16;
     q.wt_per_xcd = (q.wt_total + 7) / 8;
     q.groups = ny < per_xcd ? ny : per_xcd;
-    hipLaunchKernelGGL((conv_igemm_ws_x6_kernel<NT>), dim3(per_xcd * 8), dim3(1024), lds, s, q);
+    hipLaunchKernelGGL((conv_igemm_ws_x6_kernel<NT, CTC>), dim3(per_xcd * 8), dim3(1024), lds, s, q);
 }
 
 void conv_igemm_ws_x6(hipStream_t s, const IgemmP& p, int ws_nt, int ny, size_t lds) {
+    if (p.ctc_part) { launch_ws_x6<8, true>(s, p, ny, lds); return; }   // conv_igemm passes ws_nt = 8 for CTC heads
     switch (ws_nt) {
         case 8: launch_ws_x6<8>(s, p, ny, lds); break;
         case 6: launch_ws_x6<6>(s, p, ny, lds); break;
