@@ -52,3 +52,13 @@ def test_weight_stationary_kernels_fit_their_budget():
             assert r["vgprs"] <= 128, (name, r)     # 1024-thread workgroups: 4 waves per SIMD only inside 128 registers
             ctc_variant = "ILi8ELb1E" in name      # the CTC-head instantiation of the x6 kernel (softmax-partial epilogue): 164 B today
             assert r["scratch"] <= (200 if ctc_variant else 160), (name, r)   # today: 148 B (x6, 8 fragments) / 84 / 28 / 12 (3x3) of cold-path spill; a regression shows up as KBs
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
+def test_output_stationary_kernel_fits_two_workgroups_per_cu():
+    """igemm_os_x6.hip: 256-thread workgroups, two per CU (they overlap each other's barrier / split phases) -- needs <= 256
+    registers per lane; today 186-256 with at most 4 spilled dwords in the 8-fragment k x k variant."""
+    ks = {k: v for k, v in _resources("igemm_os_x6.hip").items() if "conv_igemm_os_x6_kernel" in k}
+    assert len(ks) == 4
+    for name, r in ks.items():
+        assert r["vgprs"] <= 256 and r["spill"] <= 8 and r["scratch"] <= 64, (name, r)
