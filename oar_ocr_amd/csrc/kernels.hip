@@ -161,8 +161,20 @@ void conv_dw(hipStream_t s, const ConvP& p) {
     long tiled = threads_for(TH);
     dim3 g((grid_for(tiled) + 7) / 8 * 8), b(256);
     const size_t lds = (size_t)p.kh * p.kw * p.Cout * sizeof(float);
-    const bool fits = lds <= 64 * 1024;
-#define DW2(KV, SHV, SWV, THV) hipExtLaunchKernelGGL((conv_dw_tiled_kernel<KV, SHV, SWV, TW, THV>), g, b, lds, s, ps.start(), ps.stop(), 0, p)
+    // weights of all channels in LDS: up to 96 KB (C = 768 at 5 x 5 needs 77 KB -- beyond the default 64 KB limit the kernel is
+    // opted in per instantiation; two workgroups per CU still beat the generic kernel's 1 TB/s by 3x)
+    const bool fits = lds <= 96 * 1024;
+#define DW2(KV, SHV, SWV, THV)                                                                                                                              \
+    do {                                                                                                                                                    \
+        if (lds > 64 * 1024) {                                                                                                                              \
+            static const bool once = [] {                                                                                                                   \
+                OAR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dw_tiled_kernel<KV, SHV, SWV, TW, THV>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); \
+                return true;                                                                                                                                \
+            }();                                                                                                                                            \
+            (void)once;                                                                                                                                     \
+        }                                                                                                                                                   \
+        hipExtLaunchKernelGGL((conv_dw_tiled_kernel<KV, SHV, SWV, TW, THV>), g, b, lds, s, ps.start(), ps.stop(), 0, p);                                    \
+    } while (0)
 #define DW(KV, SHV, SWV)                                   \
     do {                                                   \
         if (TH == 2) DW2(KV, SHV, SWV, 2);                 \
