@@ -77,11 +77,31 @@ def self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def cgroup_cpu_quota():
+    """CPUs the container may use per scheduling period (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited.  Polling
+    worker threads beyond this budget get the whole process throttled for tens of milliseconds (seen on the 1-GPU bench box:
+    cpu.max = 16 CPUs on a 256-thread host)."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def pin_rank_to_its_cores(local_rank: int, local_world: int) -> int:
     """One process per GPU shares the host: give each rank a contiguous slice of the cores BEFORE its geometry pool is
-    created (threads inherit the affinity), so that N spinning pools never compete for a core.  Returns the slice size."""
+    created (threads inherit the affinity), so that N spinning pools never compete for a core.  Returns the rank's CPU
+    budget = min(slice size, its share of the container's CPU quota)."""
+    quota = cgroup_cpu_quota()
     if not hasattr(os, "sched_getaffinity"):
-        return max(1, (os.cpu_count() or 1) // max(local_world, 1))
+        per = max(1, (os.cpu_count() or 1) // max(local_world, 1))
+        return per if quota is None else max(1, min(per, int(quota // max(local_world, 1))))
     cpus = sorted(os.sched_getaffinity(0))
     per = max(1, len(cpus) // max(local_world, 1))
     if local_world > 1:
@@ -90,7 +110,7 @@ def pin_rank_to_its_cores(local_rank: int, local_world: int) -> int:
             os.sched_setaffinity(0, mine)
         except OSError:
             pass
-    return per
+    return per if quota is None else max(1, min(per, int(quota // max(local_world, 1))))
 
 
 class StubEngine:
@@ -167,7 +187,12 @@ def main():
         builder = (api.OAROCRBuilder(det, rec, chars).text_detection_config(cfg).image_batch_size(image_batch)
                    .region_batch_size(args.region_batch).device(dev))
         if world > 1:
-            builder = builder.host_threads(max(2, min(16, cores)))   # this rank's geometry pool stays inside its core slice
+            builder = builder.host_threads(max(2, min(16, cores)))   # this rank's geometry pool stays inside its CPU budget
+            if cores < 6:
+                # too few CPUs per rank for the host border follower to keep up with the detector: follow the mask borders on
+                # the GPU instead (oar_det_cfg.gpu_contours; identical boxes)
+                cfg.gpu_contours = True
+                builder = builder.text_detection_config(cfg)
         if args.config == 4:
             builder = (builder.with_document_image_orientation_classification(models.build_cls(4, seed=5)[0])
                        .with_document_image_rectification(models.build_uvdoc(seed=6)[0])
