@@ -404,6 +404,10 @@ int32_t oar_host_candidates(const uint8_t* mask, uint32_t width, uint32_t height
  * cap_points of them are written (offsets still count every point); types: 0 outer / 1 hole.  Returns the count. */
 int32_t oar_host_contours(const uint8_t* mask, uint32_t width, uint32_t height, uint32_t max_contours, int32_t max_bands,
                           int64_t* offsets, int32_t* pts_xy, int32_t* types, int64_t cap_points);
+/* The same through the detector's read-back format: the mask is packed to a bit plane (pixel x = bit x & 7 of byte x >> 3) and the
+ * host border follower reads bits (what crosses PCIe after a detector pass; 8x smaller than the byte mask). */
+int32_t oar_host_contours_bits(const uint8_t* mask, uint32_t width, uint32_t height, uint32_t max_contours, int32_t max_bands,
+                               int64_t* offsets, int32_t* pts_xy, int32_t* types, int64_t cap_points);
 /* a11 db_bitmap.rs:279-368: unclip a 4-point box; returns the number of points (0 = dropped), x,y pairs in out. */
 int32_t oar_host_unclip(const float box8[8], float ratio, float* out_xy, int32_t cap_points);
 /* a9 mini box of an arbitrary point set (db_bitmap.rs:164-205): returns 1 and fills box8/min_side, or 0. */

@@ -124,7 +124,7 @@ EXPORTS = [
     "oar_cls_create", "oar_cls_destroy", "oar_cls_run", "oar_cls_result_free", "oar_cls_preprocess", "oar_rect_create", "oar_rect_destroy",
     "oar_rect_run", "oar_ocr_attach", "oar_k_rotate_rgb", "oar_k_bgr_planes_to_rgb", "oar_host_rotate_back_points",
     "oar_engine_cache_stats", "oar_onnx_inspect", "oar_host_contours", "oar_ctc_dict_create", "oar_ctc_dict_destroy", "oar_ctc_dict_classes",
-    "oar_ctc_decode", "oar_ocr_decode", "oar_text_result_free", "oar_db_postprocess_ex", "oar_k_dilate", "oar_k_poly_scores", "oar_debug_inject_failure", "oar_k_contours",
+    "oar_ctc_decode", "oar_ocr_decode", "oar_text_result_free", "oar_db_postprocess_ex", "oar_k_dilate", "oar_k_poly_scores", "oar_debug_inject_failure", "oar_k_contours", "oar_host_contours_bits",
 ]
 
 
@@ -1132,15 +1132,17 @@ def host_candidates(mask, max_candidates=1000, max_bands=1):
     return out[:n].copy()
 
 
-def host_contours(mask, max_contours=100000, max_bands=1):
-    """[(points [n,2] int32 (x, y) in tracing order, type 0 outer / 1 hole)] in discovery order (a8)."""
+def host_contours(mask, max_contours=100000, max_bands=1, bits=False):
+    """[(points [n,2] int32 (x, y) in tracing order, type 0 outer / 1 hole)] in discovery order (a8).  bits: through the
+    bit-plane read-back format of the detector."""
     mask = np.ascontiguousarray(mask, np.uint8)
     h, w = mask.shape
     cap = 4 * h * w + 16
     offs = np.zeros(max_contours + 1, np.int64)
     pts = np.zeros((cap, 2), np.int32)
     types = np.zeros(max_contours, np.int32)
-    n = lib().oar_host_contours(_p(mask), w, h, max_contours, max_bands, _p(offs), _p(pts), _p(types), cap)
+    fn = lib().oar_host_contours_bits if bits else lib().oar_host_contours
+    n = fn(_p(mask), w, h, max_contours, max_bands, _p(offs), _p(pts), _p(types), cap)
     if n < 0:
         raise OCRError(OAR_INTERNAL, "oar_host_contours failed")
     return [(pts[offs[i]:offs[i + 1]].copy(), int(types[i])) for i in range(n)]

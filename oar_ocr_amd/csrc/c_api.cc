@@ -844,6 +844,35 @@ int32_t oar_host_candidates(const uint8_t* mask, uint32_t width, uint32_t height
         return n;
     } catch (...) { return -1; }
 }
+int32_t oar_host_contours_bits(const uint8_t* mask, uint32_t width, uint32_t height, uint32_t max_contours, int32_t max_bands, int64_t* offsets,
+                               int32_t* pts_xy, int32_t* types, int64_t cap_points) {
+    try {
+        // the detector's read-back format: the byte mask packed to a bit plane (here on the host), followed band by band
+        const int row_bytes = ((int)width + 7) / 8;
+        std::vector<uint8_t> bits((size_t)row_bytes * height, 0);
+        for (uint32_t y = 0; y < height; ++y)
+            for (uint32_t x = 0; x < width; ++x)
+                if (mask[(size_t)y * width + x]) bits[(size_t)y * row_bytes + (x >> 3)] |= (uint8_t)(1u << (x & 7));
+        std::vector<int> cuts = host::blank_row_bands_bits(bits.data(), row_bytes, (int)height, max_bands < 1 ? 1 : max_bands);
+        int32_t n = 0;
+        int64_t np = 0;
+        if (offsets) offsets[0] = 0;
+        for (size_t i = 0; i + 1 < cuts.size(); ++i) {
+            auto part = host::find_contours_band_bits(bits.data(), row_bytes, (int)width, cuts[i], cuts[i + 1], max_contours);
+            for (auto& c : part) {
+                if ((uint32_t)n >= max_contours) break;
+                for (auto& q : c.pts) {
+                    if (pts_xy && np < cap_points) { pts_xy[np * 2] = (int32_t)q.x; pts_xy[np * 2 + 1] = (int32_t)q.y; }
+                    ++np;
+                }
+                if (types) types[n] = c.hole ? 1 : 0;
+                ++n;
+                if (offsets) offsets[n] = np;
+            }
+        }
+        return n;
+    } catch (...) { return -1; }
+}
 int32_t oar_host_contours(const uint8_t* mask, uint32_t width, uint32_t height, uint32_t max_contours, int32_t max_bands, int64_t* offsets,
                           int32_t* pts_xy, int32_t* types, int64_t cap_points) {
     try {

@@ -58,13 +58,15 @@ std::vector<int> blank_row_bands(const uint8_t* mask, int width, int height, int
     return cuts;
 }
 
-std::vector<Contour> find_contours_band(const uint8_t* mask, int width, int height, int band_y0, int band_y1, size_t max_contours, int32_t* /*unused*/) {
+namespace {
+// Border following over rows [band_y0, band_y1): `fill_row(r, dst)` writes the 0 / 1 foreground flags of band row r into dst[0 .. width)
+template <typename FillRow>
+std::vector<Contour> follow_band(int width, int band_y0, int band_y1, size_t max_contours, FillRow fill_row) {
     // imageproc's border labels only ever matter through three predicates -- `== 1` (foreground not yet on a followed border),
     // `> 0` (that, or marked with a positive label) and `!= 0` -- plus the hierarchy (parent links), which DB post-processing
     // never reads.  The state is therefore one byte per pixel: 0 background, 1 unmarked, 2 marked positive, 3 marked negative,
     // in a plane framed by one background pixel on every side (the band may be cut only at blank rows, so its neighbours above
     // and below ARE background), which removes every bounds check from the walk.
-    (void)height;
     const int rows = band_y1 - band_y0;
     std::vector<Contour> out;
     if (rows <= 0 || width <= 0) return out;
@@ -76,9 +78,8 @@ std::vector<Contour> find_contours_band(const uint8_t* mask, int width, int heig
     std::memset(st + (size_t)(rows + 1) * stride, 0, (size_t)stride);
     for (int r = 0; r < rows; ++r) {
         uint8_t* d = st + (size_t)(r + 1) * stride;
-        const uint8_t* m = mask + (size_t)(band_y0 + r) * width;
         d[0] = 0;
-        for (int x = 0; x < width; ++x) d[x + 1] = m[x] != 0;
+        fill_row(r, d + 1);
         d[width + 1] = 0;
     }
     // neighbour offsets in the framed plane: w, nw, n, ne, e, se, s, sw (clockwise on screen), twice so that (front + k) needs no mask
@@ -134,7 +135,7 @@ std::vector<Contour> find_contours_band(const uint8_t* mask, int width, int heig
     };
 
     for (int y = 0; y < rows && !full; ++y) {
-        const uint8_t* mrow = mask + (size_t)(band_y0 + y) * width;
+        const uint8_t* mrow = st + (size_t)(y + 1) * stride + 1;   // zero-ness of the state plane == zero-ness of the mask, whatever marks it carries
         int x = 0;
         while (x < width && !full) {
             // background never changes state (zero-ness is invariant under border labelling): skip 8 bytes at a time
@@ -158,6 +159,58 @@ std::vector<Contour> find_contours_band(const uint8_t* mask, int width, int heig
         }
     }
     return out;
+}
+}  // namespace
+
+std::vector<Contour> find_contours_band(const uint8_t* mask, int width, int height, int band_y0, int band_y1, size_t max_contours, int32_t* /*unused*/) {
+    (void)height;
+    return follow_band(width, band_y0, band_y1, max_contours, [&](int r, uint8_t* dst) {
+        const uint8_t* m = mask + (size_t)(band_y0 + r) * width;
+        for (int x = 0; x < width; ++x) dst[x] = m[x] != 0;
+    });
+}
+
+// The same from a bit-packed mask (pp::pack_mask_bits: pixel x of row y is bit x & 7 of byte bits[y * row_bytes + (x >> 3)])
+std::vector<Contour> find_contours_band_bits(const uint8_t* bits, int row_bytes, int width, int band_y0, int band_y1, size_t max_contours) {
+    return follow_band(width, band_y0, band_y1, max_contours, [&](int r, uint8_t* dst) {
+        const uint8_t* b = bits + (size_t)(band_y0 + r) * row_bytes;
+        int x = 0;
+        for (; x + 8 <= width; x += 8) {
+            // one mask byte -> eight 0 / 1 flag bytes: spread the bits to the byte lanes' low bits
+            const uint64_t v = b[x >> 3];
+            // bits 0..6: the seven shifted copies v7 << 7i put bit i of v7 on bit 8i and never overlap (j + 7i is a bijection
+            // for j in 0..6), so there are no carries; bit 7 separately
+            uint64_t flags = ((v & 0x7full) * 0x0002040810204081ull) & 0x0001010101010101ull;
+            flags |= (uint64_t)((v >> 7) & 1u) << 56;
+            std::memcpy(dst + x, &flags, 8);
+        }
+        for (; x < width; ++x) dst[x] = (b[x >> 3] >> (x & 7)) & 1u;
+    });
+}
+
+std::vector<int> blank_row_bands_bits(const uint8_t* bits, int row_bytes, int height, int max_bands) {
+    std::vector<uint8_t> occupied(height, 0);
+    int fg_rows = 0;
+    for (int y = 0; y < height; ++y) {
+        const uint8_t* r = bits + (size_t)y * row_bytes;
+        int x = 0;
+        bool any = false;
+        for (; x + 8 <= row_bytes; x += 8) { uint64_t w8; std::memcpy(&w8, r + x, 8); if (w8) { any = true; break; } }
+        if (!any) for (; x < row_bytes; ++x) if (r[x]) { any = true; break; }
+        occupied[y] = any;
+        fg_rows += any;
+    }
+    std::vector<int> cuts{0};
+    if (max_bands > 1 && fg_rows > 0) {
+        const int target = (fg_rows + max_bands - 1) / max_bands;
+        int acc = 0;
+        for (int y = 0; y < height; ++y) {
+            if (occupied[y]) { ++acc; continue; }
+            if (acc >= target && y > cuts.back()) { cuts.push_back(y); acc = 0; }   // y is blank: safe cut
+        }
+    }
+    cuts.push_back(height);
+    return cuts;
 }
 
 // ------------------------------------------------------------------------------------------ hull / min-area rect

@@ -294,32 +294,27 @@ void contours_to_candidates(ThreadPool& pool, std::vector<std::vector<host::Cont
 
 // Two-stage variant for a sub-batch: contour tracing is inherently serial per page (one worker per page), the
 // per-contour geometry is then spread over the whole pool; discovery order is preserved.
+// `masks`: nb bit planes of H rows x ceil(W / 8) bytes (pp::pack_mask_bits), hw = bytes per plane
 void subbatch_candidates(ThreadPool& pool, const uint8_t* masks, size_t hw, int H, int W, int nb, uint32_t max_candidates,
                          std::vector<Candidate>* out /* [nb] */, bool keep_contour = false) {
+    const int row_bytes = (W + 7) / 8;
     // stage 1: contour tracing, parallel over (page, row band) -- bands are cut at fully-blank rows
-    static thread_local std::vector<std::vector<int32_t>> scratch;   // one label plane per page of the sub-batch
-    if ((int)scratch.size() < nb) scratch.resize(nb);
     struct Band { int page, y0, y1; };
     std::vector<Band> bands;
     static const int bands_mult = [] { const char* e = getenv("OAR_BANDS_MULT"); int v = e ? atoi(e) : 2; return v > 0 ? v : 2; }();
     const int bands_per_page = std::max(1, std::min(12, (pool.size() + 1) * bands_mult / std::max(nb, 1)));
     auto t_setup = std::chrono::steady_clock::now();
     std::vector<std::vector<int>> cuts(nb);
-    for (int k = 0; k < nb; ++k) scratch[k].resize(hw);
-    pool.parallel_for(nb, [&](int k) { cuts[k] = host::blank_row_bands(masks + (size_t)k * hw, W, H, bands_per_page); });
+    pool.parallel_for(nb, [&](int k) { cuts[k] = host::blank_row_bands_bits(masks + (size_t)k * hw, row_bytes, H, bands_per_page); });
     for (int k = 0; k < nb; ++k)
         for (size_t i = 0; i + 1 < cuts[k].size(); ++i) bands.push_back({k, cuts[k][i], cuts[k][i + 1]});
     std::vector<std::vector<host::Contour>> band_cs(bands.size());
     std::vector<double> tpage(bands.size(), 0.0);
     auto ta = std::chrono::steady_clock::now();
-    // NB: a thread_local is never captured by a lambda -- workers would see their OWN (empty) instance; pass the
-    // caller's label planes explicitly
-    std::vector<int32_t*> planes(nb);
-    for (int k = 0; k < nb; ++k) planes[k] = scratch[k].data();
     pool.parallel_for((int)bands.size(), [&](int i) {
         auto t0 = std::chrono::steady_clock::now();
         const Band& bd = bands[i];
-        band_cs[i] = host::find_contours_band(masks + (size_t)bd.page * hw, W, H, bd.y0, bd.y1, max_candidates, planes[bd.page]);
+        band_cs[i] = host::find_contours_band_bits(masks + (size_t)bd.page * hw, row_bytes, W, bd.y0, bd.y1, max_candidates);
         tpage[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     });
     std::vector<std::vector<host::Contour>> cs(nb);
@@ -570,6 +565,8 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
         if (cfg_.use_dilation) mask_dil_.reserve((size_t)B * hw);
     }
     mask_host_.reserve((size_t)B * hw);
+    const size_t hbits = (size_t)H * ((W + 7) / 8);   // bytes of one mask as a bit plane (what the host border follower reads back)
+    if ((size_t)B * hbits > mask_bits_.cap) { OAR_HIP(hipStreamSynchronize(s)); OAR_HIP(hipStreamSynchronize(copy_stream_)); mask_bits_.reserve((size_t)B * hbits); }
     // a8 on the host pool (default) or on the GPU: oar_det_cfg.gpu_contours, overridden by OAR_GPU_CONTOURS=0|1
     static const int gpu_contours_env = [] { const char* e = getenv("OAR_GPU_CONTOURS"); return e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : -1; }();
     const bool gpu_contours = gpu_contours_env >= 0 ? gpu_contours_env == 1 : cfg_.gpu_contours != 0;
@@ -664,7 +661,10 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
                                trace_.ctrl.as<uint32_t>() + (size_t)sb * pp::kTraceCtlWords, trace_.ctrl_host.as<uint32_t>() + (size_t)sb * pp::kTraceCtlWords,
                                trace_.table_dev.as<pp::SegRec>(), trace_.table.as<pp::SegRec>() + (size_t)b0 * ContourBufs::kSegsPerPage, tcap);
         } else {
-            OAR_HIP(hipMemcpyAsync(mask_host_.as<uint8_t>() + (size_t)b0 * hw, traced, (size_t)nb * hw, hipMemcpyDeviceToHost, copy_stream_));
+            // the mask crosses PCIe as a bit plane: 8x less traffic for the blit kernel that shares the GPU with the next network
+            pp::pack_mask_bits(copy_stream_, traced, mask_bits_.as<uint8_t>() + (size_t)b0 * hbits, nb, H, W);
+            OAR_HIP(hipMemcpyAsync(mask_host_.as<uint8_t>() + (size_t)b0 * hbits, mask_bits_.as<uint8_t>() + (size_t)b0 * hbits, (size_t)nb * hbits,
+                                   hipMemcpyDeviceToHost, copy_stream_));
         }
         OAR_HIP(hipEventRecord(sub_events_[sb], copy_stream_));
         tmark("det_enqueue");
@@ -711,7 +711,7 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
                                        trace_.table.as<pp::SegRec>() + (size_t)b0 * ContourBufs::kSegsPerPage, (uint32_t)nb * ContourBufs::kSegsPerPage,
                                        trace_.packed.as<uint32_t>() + (size_t)b0 * trace_.packed_words_per_page, H, W, nb, maxc, fetch_mask, &cands[b0], slow);
         } else {
-            subbatch_candidates(*pool_, mh + (size_t)b0 * hw, hw, H, W, nb, maxc, &cands[b0], slow);
+            subbatch_candidates(*pool_, mh + (size_t)b0 * hbits, hbits, H, W, nb, maxc, &cands[b0], slow);
         }
         tmark("host_contours");
         ScoreSlot& sl = *score_slots_[sb];

@@ -103,6 +103,7 @@ class Detector {
     oar_det_cfg cfg_;
     DevBuf pages_dev_, resized_dev_, input_f32_, mask_dev_, probs_keep_;
     DevBuf mask_dil_;   // use_dilation: the dilated masks (what the host traces)
+    DevBuf mask_bits_;  // the traced masks as bit planes: what is read back (mask_host_ holds bits, row_bytes = ceil(W / 8))
     // image as the resize stage sees it: the page itself, or its black-padded copy when h + w < 64
     // (DetResizeForTest::image_padding, processors/resize_detection.rs:174-176,204-220)
     DevBuf padded_dev_;

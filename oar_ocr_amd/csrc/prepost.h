@@ -31,6 +31,10 @@ void resize_triangle(hipStream_t s, const uint8_t* src, int w, int h, uint8_t* d
 // a7 processors/db_postprocess.rs:185-221
 void threshold(hipStream_t s, const float* pred, uint8_t* mask, int64_t n, float thresh);
 
+// n_images masks of height x width bytes -> bit planes of ceil(width / 8) bytes per row (pixel x = bit x & 7 of byte x >> 3): the
+// form in which a mask is read back by the host border follower (8x less PCIe traffic; db_host.h find_contours_band_bits)
+void pack_mask_bits(hipStream_t s, const uint8_t* mask, uint8_t* bits, int n_images, int height, int width);
+
 // DBPostProcess::dilate_mask_img (processors/db_mask.rs:11: imageproc morphology::dilate, Norm::LInf, k = 1) on n_images
 // masks of height x width each: a pixel becomes 255 when any pixel of its 3 x 3 neighbourhood inside the image is non-zero.
 void dilate3x3(hipStream_t s, const uint8_t* mask, uint8_t* out, int n_images, int height, int width);

@@ -228,6 +228,33 @@ void threshold(hipStream_t s, const float* pred, uint8_t* mask, int64_t n, float
     hipLaunchKernelGGL(threshold_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, pred, mask, (long)n, thresh);
 }
 
+// ------------------------------------------------------------------------------------------ mask -> bits (what crosses PCIe)
+// One thread packs 8 mask bytes of one row into one byte (pixel x -> bit x & 7); rows are padded to row_bytes = ceil(W / 8).
+__global__ __launch_bounds__(256) void pack_mask_bits_kernel(const uint8_t* __restrict__ mask, uint8_t* __restrict__ bits, long rows, int W, int row_bytes) {
+    const long total = rows * row_bytes;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / row_bytes;
+        const int bx = (int)(i - r * row_bytes), x0 = bx * 8;
+        const uint8_t* m = mask + r * W + x0;
+        unsigned v = 0;
+        if (x0 + 8 <= W && (((size_t)m) & 7) == 0) {
+            const uint2 q = *reinterpret_cast<const uint2*>(m);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v |= ((q.x >> (8 * k)) & 0xffu) ? (1u << k) : 0u; v |= ((q.y >> (8 * k)) & 0xffu) ? (1u << (k + 4)) : 0u; }
+        } else {
+            for (int k = 0; k < 8 && x0 + k < W; ++k) v |= m[k] ? (1u << k) : 0u;
+        }
+        bits[i] = (uint8_t)v;
+    }
+}
+void pack_mask_bits(hipStream_t s, const uint8_t* mask, uint8_t* bits, int n_images, int height, int width) {
+    const long rows = (long)n_images * height;
+    if (rows == 0 || width == 0) return;
+    const int row_bytes = (width + 7) / 8;
+    ProfScope ps(s, "pack_mask", (double)rows * width + (double)rows * row_bytes, 0.0);
+    hipLaunchKernelGGL(pack_mask_bits_kernel, dim3(grid_for(rows * row_bytes)), dim3(256), 0, s, mask, bits, rows, width, row_bytes);
+}
+
 // ------------------------------------------------------------------------------------------ mask dilation (use_dilation)
 __global__ __launch_bounds__(256) void dilate3x3_kernel(const uint8_t* __restrict__ mask, uint8_t* __restrict__ out, int height, int width) {
     const long plane = (long)height * width;

@@ -172,8 +172,8 @@ def test_contours_are_the_component_borders(impl):
 def test_product_contours_equal_the_oracle_chain_for_chain():
     for mask in _random_masks(60, 23):
         a = cpu_ref.find_contours(mask)
-        for bands in (1, 5):
-            b = api.host_contours(mask, max_bands=bands)
+        for bands, bits in ((1, False), (5, False), (1, True), (4, True)):      # bits: the detector's bit-plane read-back format
+            b = api.host_contours(mask, max_bands=bands, bits=bits)
             assert len(a) == len(b)
             for (pa, ta, _), (pb, tb) in zip(a, b):
                 assert ta == tb and np.array_equal(pa, pb)
