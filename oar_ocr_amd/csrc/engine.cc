@@ -37,6 +37,21 @@ Engine::Engine(const uint8_t* onnx, size_t len, int device_id) : device_(device_
     if (const char* e = getenv("OAR_PLAN_CACHE")) { long v = atol(e); if (v >= 2) plan_cap_ = (size_t)v; }
     opset_ = m.opset;
     rewrite_graph(m);
+    // fused-stem eligibility: the input is consumed once, by a group-1 convolution with 3 input channels and a small kernel
+    {
+        int uses = 0;
+        const GNode* consumer = nullptr;
+        for (const GNode& n : nodes_) {
+            for (size_t i = 0; i < n.in.size(); ++i) if (n.in[i] == input_name_) { ++uses; consumer = &n; if (i != 0) uses += 100; }
+            if (n.residual == input_name_) uses += 100;
+        }
+        for (auto& on : output_names_) if (on == input_name_) uses += 100;
+        if (uses == 1 && consumer && consumer->op == "Conv" && consumer->ai("group", 1) == 1 && input_infos_.size() == 1) {
+            auto it = inits_.find(consumer->in.size() > 1 ? consumer->in[1] : std::string());
+            if (it != inits_.end() && it->second.dims.size() == 4 && it->second.dims[1] == 3 && it->second.dims[2] * it->second.dims[3] * 3 <= 128)
+                stem_fusable_ = true;
+        }
+    }
 }
 
 Engine::~Engine() {
@@ -488,6 +503,7 @@ struct TInfo {
     std::vector<double> hd;
     const HostTensor* ht = nullptr;  // f32 initializer
     bool is_int = false;             // device tensor whose f32 values are integers by construction (ArgMax, integer Cast of one)
+    bool u8_stem = false;            // the graph input of a run_stem plan: u8 pages read by the fused stem, no f32 tensor behind it
     std::string root;                // storage root (for liveness)
     size_t bytes() const { return (size_t)std::max<int64_t>(numel(dims), 1) * 4; }
 };
@@ -800,6 +816,24 @@ struct Planner {
         int64_t pt, pl, pb, pr;
         get_pads(n, H, Wd, kh, kw, sh, sw, dh, dw, pt, pl, pb, pr);
         int64_t Ho = (H + pt + pb - dh * (kh - 1) - 1) / sh + 1, Wo = (Wd + pl + pr - dw * (kw - 1) - 1) / sw + 1;
+        if (x.u8_stem) {   // Engine::run_stem: the stem reads the u8 pages and normalises on the fly (kernels.h StemU8)
+            OAR_CHECK(g == 1 && Cin == 3 && kh * kw * 3 <= 128 && N <= 32 && n.residual.empty(), OAR_INTERNAL, "run_stem on a graph whose first node is not an RGB stem");
+            const float* sb = has_input(n, 2) ? get(n.in[2]).loc.cptr : nullptr;
+            TInfo& ys = new_out(n.out[0], {N, Cout, Ho, Wo}, Layout::CLAST);
+            k::ConvP sp{};
+            sp.N = (int)N; sp.H = (int)H; sp.W = (int)Wd; sp.Cin = 3; sp.Ho = (int)Ho; sp.Wo = (int)Wo; sp.Cout = (int)Cout;
+            sp.kh = (int)kh; sp.kw = (int)kw; sp.sh = (int)sh; sp.sw = (int)sw; sp.pt = (int)pt; sp.pl = (int)pl; sp.dh = (int)dh; sp.dw = (int)dw;
+            sp.groups = 1; sp.act = n.act; sp.bias = sb; sp.y_ld = (int)Cout; sp.convt2x2 = 0;
+            sp.w = conv_weight_direct(n, W);
+            const Loc ysl = ys.loc;
+            step([=](const RunCtx& c) {
+                OAR_CHECK(c.stem != nullptr, OAR_INTERNAL, "stem plan run without pages");
+                k::ConvP q = sp;
+                q.y = c.mut(ysl);
+                k::conv_smallcin_u8(c.s, q, *c.stem);
+            }, 2.0 * N * Ho * Wo * Cout * 3 * kh * kw, 3.0 * N * H * Wd + 4.0 * N * Ho * Wo * Cout);
+            return;
+        }
         Loc xin = to_clast_loc(x);
         const float* bias = has_input(n, 2) ? get(n.in[2]).loc.cptr : nullptr;
         Loc res;
@@ -1930,9 +1964,11 @@ struct Planner {
     }
 
     bool skip_final_softmax = false;
+    bool stem_u8 = false;
     void build(const std::vector<int64_t>& in_dims, bool in_clast, const std::vector<std::vector<int64_t>>* extra_dims) {
         compute_last_use();
         TInfo in;
+        in.u8_stem = stem_u8;
         in.dims = in_dims;
         in.layout = (in_clast && in_dims.size() >= 3) ? Layout::CLAST : Layout::NATIVE;
         in.loc.kind = Loc::INPUT;
@@ -2132,9 +2168,9 @@ const std::set<std::string>& Engine::supported_ops() {
 }
 
 const Plan& Engine::plan_for(const std::vector<int64_t>& dims, bool in_clast, bool skip_final_softmax,
-                             const std::vector<std::vector<int64_t>>* extra_dims) {
+                             const std::vector<std::vector<int64_t>>* extra_dims, bool stem_u8) {
     std::ostringstream key;
-    key << (in_clast ? "L" : "N") << (skip_final_softmax ? "S" : "");
+    key << (in_clast ? "L" : "N") << (skip_final_softmax ? "S" : "") << (stem_u8 ? "U" : "");
     for (auto d : dims) key << "x" << d;
     for (size_t i = 1; extra_dims && i < extra_dims->size(); ++i) {
         key << "|";
@@ -2146,6 +2182,7 @@ const Plan& Engine::plan_for(const std::vector<int64_t>& dims, bool in_clast, bo
     std::unique_ptr<Plan> p(new Plan());
     Planner pl(*this, *p);
     pl.skip_final_softmax = skip_final_softmax;
+    pl.stem_u8 = stem_u8;
     pl.build(dims, in_clast, extra_dims);
     evict_plans();
     p->last_used = ++tick_;
@@ -2277,6 +2314,24 @@ const Plan& Engine::run_multi(const std::vector<const float*>& d_ins, const std:
     RunCtx c{stream_, d_ins[0], arena_.as<char>(), last_extra_.data()};
     last_input_ = d_ins[0];
     for (auto& st : p.steps) st(c);   // no hipGraph replay here: a captured graph bakes in one input pointer only
+    ++p.runs;
+    OAR_HIP(hipGetLastError());
+    return p;
+}
+
+const Plan& Engine::run_stem(const k::StemU8& st, const std::vector<int64_t>& dims) {
+    OAR_CHECK(stem_fusable_, OAR_INTERNAL, "run_stem on a graph without a fusable RGB stem");
+    OAR_CHECK(dims.size() == 4 && dims[1] == 3 && dims[0] >= 1 && dims[0] <= 32, OAR_INVALID_INPUT, "run_stem: dims must be {n <= 32, 3, H, W}");
+    const Plan& p = plan_for(dims, true, false, nullptr, true);
+    OAR_HIP(hipSetDevice(device_));
+    if (arena_.cap < p.arena_bytes) {
+        OAR_HIP(hipStreamSynchronize(stream_));
+        clear_graphs();
+        arena_.reserve(p.arena_bytes);
+    }
+    RunCtx c{stream_, nullptr, arena_.as<char>(), nullptr, &st};
+    last_input_ = nullptr;
+    for (auto& stp : p.steps) stp(c);   // no hipGraph replay: the page pointers change from call to call
     ++p.runs;
     OAR_HIP(hipGetLastError());
     return p;

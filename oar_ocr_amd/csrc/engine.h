@@ -47,6 +47,7 @@ struct RunCtx {
     const float* input;
     char* arena;
     const float* const* extra = nullptr;   // secondary graph inputs (Engine::run_multi), device pointers
+    const k::StemU8* stem = nullptr;       // Engine::run_stem: the u8 pages the fused stem reads (no f32 input tensor exists)
     const float* at(const Loc& l) const {
         switch (l.kind) {
             case Loc::EXTRA: return reinterpret_cast<const float*>(reinterpret_cast<const char*>(extra[l.idx]) + l.off);
@@ -102,7 +103,12 @@ class Engine {
     // logits instead (Plan::skipped_softmax is set) -- the recognizer fuses that softmax with the CTC argmax.
     const Plan& run(const float* d_in, const std::vector<int64_t>& dims, bool in_clast, bool skip_final_softmax = false);
     const Plan& plan_for(const std::vector<int64_t>& dims, bool in_clast, bool skip_final_softmax = false,
-                         const std::vector<std::vector<int64_t>>* extra_dims = nullptr);
+                         const std::vector<std::vector<int64_t>>* extra_dims = nullptr, bool stem_u8 = false);
+    // The graph input feeds exactly one node, an RGB stem convolution: the detector may hand the engine its u8 pages
+    // (run_stem) and skip the normalised f32 input tensor altogether.
+    bool stem_fusable() const { return stem_fusable_; }
+    // dims = {n, 3, H, W}; st.pages[0..n) are device pointers to H x W x 3 u8 pages; st.src / alpha / beta as pp::normalize
+    const Plan& run_stem(const k::StemU8& st, const std::vector<int64_t>& dims);
     // Several named inputs (OrtInfer::infer, ort_infer_execution.rs:121-219): d_ins[i] / dims[i] belong to input_infos()[i]
     // (the caller has matched the names); input 0 is the primary one, the others are bound as plain f32 device tensors.
     const Plan& run_multi(const std::vector<const float*>& d_ins, const std::vector<std::vector<int64_t>>& dims);
@@ -126,6 +132,7 @@ class Engine {
     std::vector<std::string> output_names_;
     std::vector<ValueInfo> input_infos_, output_infos_;
     std::vector<const float*> last_extra_;
+    bool stem_fusable_ = false;
     std::map<std::string, HostTensor> inits_;
     std::vector<GNode> nodes_;
     std::map<std::string, const float*> dev_consts_;

@@ -45,6 +45,12 @@ int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin = 0);   // Cin
 void conv_dw(hipStream_t s, const ConvP& p);
 // Direct conv for everything else (small Cin, odd channels, grouped). w: [kh][kw][Cin/g][Cout].
 void conv_direct(hipStream_t s, const ConvP& p);
+// RGB stem with the page normalisation folded in: the stem reads the u8 HWC pages themselves and computes
+// (float)v * alpha[c] + beta[c] for tensor channel c = page channel src[c] on the fly -- the same two f32 operations
+// pp::normalize performs, so the result is bit-identical to normalize + conv -- instead of a 12-bytes-per-pixel f32 tensor
+// being written and read back.  Up to 32 separately allocated pages per launch.
+struct StemU8 { const uint8_t* pages[32]; int src[3]; float alpha[3], beta[3]; };
+void conv_smallcin_u8(hipStream_t s, const ConvP& p, const StemU8& st);
 // General ConvTranspose (gather form). w: [kh][kw][Cin][Cout] (groups == 1), output_padding folded in Ho/Wo.
 void convt_direct(hipStream_t s, const ConvP& p);
 

@@ -245,6 +245,71 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvP p) {
     }
 }
 
+// The same kernel fed by u8 pages (StemU8, kernels.h): tap value = (float)byte * alpha + beta, two separate f32 operations
+// exactly as pp::normalize computes them; out-of-image taps contribute nothing (the conv zero-pads the NORMALISED tensor).
+__global__ __launch_bounds__(256) void conv_smallcin_u8_kernel(ConvP p, StemU8 st) {
+    __shared__ float ws[128 * 16];
+    const int K = p.kh * p.kw * 3;
+    const int co0 = blockIdx.y * 16;
+    for (int i = threadIdx.x; i < K * 16; i += 256) {
+        int k = i >> 4, c = i & 15;
+        ws[i] = (co0 + c < p.Cout) ? p.w[(long)k * p.Cout + co0 + c] : 0.f;
+    }
+    __syncthreads();
+    const long per_image = (long)p.Ho * p.Wo;
+    const float a0 = st.alpha[0], a1 = st.alpha[1], a2 = st.alpha[2], b0 = st.beta[0], b1 = st.beta[1], b2 = st.beta[2];
+    const int s0 = st.src[0], s1 = st.src[1], s2 = st.src[2];
+    // grid.z = image: the page pointer is wave-uniform (a per-thread index into the kernel-argument table would go through scratch)
+    const int n = blockIdx.z;
+    const uint8_t* __restrict__ pg = st.pages[n];
+    for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < per_image; pix += (long)gridDim.x * blockDim.x) {
+        const int ow = (int)(pix % p.Wo), oh = (int)(pix / p.Wo);
+        float acc[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = (p.bias && co0 + c < p.Cout) ? p.bias[co0 + c] : 0.f;
+        for (int a = 0; a < p.kh; ++a) {
+            const int ih = oh * p.sh - p.pt + a * p.dh;
+            if (ih < 0 || ih >= p.H) continue;
+            for (int b = 0; b < p.kw; ++b) {
+                const int iw = ow * p.sw - p.pl + b * p.dw;
+                if (iw < 0 || iw >= p.W) continue;
+                const uint8_t* xp = pg + ((long)ih * p.W + iw) * 3;
+                const float* wp = ws + (a * p.kw + b) * 3 * 16;
+                float t0 = (float)xp[s0] * a0, t1 = (float)xp[s1] * a1, t2 = (float)xp[s2] * a2;
+                const float x0 = t0 + b0, x1 = t1 + b1, x2 = t2 + b2;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) acc[c] = fmaf(x0, wp[c], acc[c]);
+#pragma unroll
+                for (int c = 0; c < 16; ++c) acc[c] = fmaf(x1, wp[16 + c], acc[c]);
+#pragma unroll
+                for (int c = 0; c < 16; ++c) acc[c] = fmaf(x2, wp[32 + c], acc[c]);
+            }
+        }
+        const long opix = (long)n * per_image + pix;
+        float* o = p.y + opix * p.y_ld + co0;
+        const bool vec = (co0 + 16 <= p.Cout) && ((p.y_ld & 3) == 0);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (p.residual && co0 + c < p.Cout) acc[c] += p.residual[opix * p.y_ld + co0 + c];
+            acc[c] = apply_act(acc[c], p.act.kind, p.act.alpha, p.act.beta);
+        }
+        if (vec) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(o + q * 4) = make_float4(acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]);
+        } else {
+            for (int c = 0; c < 16 && co0 + c < p.Cout; ++c) o[c] = acc[c];
+        }
+    }
+}
+void conv_smallcin_u8(hipStream_t s, const ConvP& p, const StemU8& st) {
+    const long per_image = (long)p.Ho * p.Wo;
+    if (per_image == 0 || p.N == 0) return;
+    OAR_CHECK(p.groups == 1 && p.Cin == 3 && p.kh * p.kw * 3 <= 128 && p.N <= 32, OAR_INTERNAL, "conv_smallcin_u8: not an RGB stem");
+    const double total = (double)p.N * per_image * p.Cout;
+    ProfScope ps(s, "conv_smallcin", 3.0 * (double)p.N * p.H * p.W + 4.0 * total, 2.0 * total * p.kh * p.kw * 3);
+    hipLaunchKernelGGL(conv_smallcin_u8_kernel, dim3(grid_for(per_image, 256, 256L * 4), (p.Cout + 15) / 16, p.N), dim3(256), 0, s, p, st);
+}
+
 // ------------------------------------------------------------------------------------------ direct conv (fallback)
 // One thread = one output element. w: [kh][kw][Cin/g][Cout].
 __global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p) {

@@ -556,7 +556,10 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
     for (int i = 0; i < nsub; ++i) SB = std::max(SB, sb_off[i + 1] - sb_off[i]);
 
     // output geometry from the plan of the largest sub-batch (shape inference only)
-    const Plan& plan0 = eng_->plan_for({SB, 3, (int64_t)rh, (int64_t)rw}, true);
+    // normalisation folded into the stem convolution when the graph allows it (OAR_FUSE_STEM=0: separate normalize kernel)
+    static const bool fuse_stem = [] { const char* e = getenv("OAR_FUSE_STEM"); return !(e && e[0] == '0'); }();
+    const bool stem = fuse_stem && SB <= 32 && eng_->stem_fusable();
+    const Plan& plan0 = eng_->plan_for({SB, 3, (int64_t)rh, (int64_t)rw}, true, false, nullptr, stem);
     OAR_CHECK(!plan0.outputs.empty(), OAR_INTERNAL, "DB: no output returned from inference");
     OAR_CHECK(plan0.outputs[0].dims.size() == 4, OAR_SHAPE_MISMATCH, "DB: expected a 4-D [batch,1,H,W] output");
     const int C = (int)plan0.outputs[0].dims[1], H = (int)plan0.outputs[0].dims[2], W = (int)plan0.outputs[0].dims[3];
@@ -644,8 +647,14 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
             if (nb <= 32) srcs[k] = src;
             else pp::normalize(s, src, input_f32_.as<float>() + (size_t)k * plane * 3, 1, (int64_t)plane, kDbSrc, alpha, beta, 1);
         }
-        if (nb <= 32) pp::normalize_pages(s, srcs, nb, input_f32_.as<float>(), (int64_t)plane, kDbSrc, alpha, beta, 1);   // one launch per sub-batch
-        const Plan& plan = eng_->run(input_f32_.as<float>(), {nb, 3, (int64_t)rh, (int64_t)rw}, true);
+        k::StemU8 st{};
+        if (stem) {
+            for (int k = 0; k < nb; ++k) st.pages[k] = srcs[k];
+            for (int c = 0; c < 3; ++c) { st.src[c] = kDbSrc[c]; st.alpha[c] = alpha[c]; st.beta[c] = beta[c]; }
+        } else if (nb <= 32) {
+            pp::normalize_pages(s, srcs, nb, input_f32_.as<float>(), (int64_t)plane, kDbSrc, alpha, beta, 1);   // one launch per sub-batch
+        }
+        const Plan& plan = stem ? eng_->run_stem(st, {nb, 3, (int64_t)rh, (int64_t)rw}) : eng_->run(input_f32_.as<float>(), {nb, 3, (int64_t)rh, (int64_t)rw}, true);
         const PlanOutput& po = plan.outputs[0];
         OAR_CHECK(po.dims.size() == 4 && po.dims[0] == nb && po.dims[1] == C && po.dims[2] == H && po.dims[3] == W, OAR_SHAPE_MISMATCH,
                   "DB: inconsistent output shape across sub-batches");
