@@ -91,7 +91,8 @@ typedef struct {
 
 /* Borrowed view of the first output (OrtInfer::infer_first_output_f32's `FnOnce(&[i64], &[f32])`, ort_infer_execution.rs:234-306):
  * `data` points into a pinned staging buffer owned by the engine and is valid only until the callback returns.
- * A non-zero return value aborts with OAR_INVALID_INPUT and is reported through oar_last_error. */
+ * A non-zero return value aborts with OAR_INVALID_INPUT and is reported through oar_last_error.  The callback runs under the
+ * engine's lock (like the reference's closure under the session lock): it must not call back into the same engine. */
 typedef int32_t (*oar_output_view_fn)(void* user, const int64_t* dims, int32_t rank, const float* data);
 
 oar_status oar_engine_create(const uint8_t* onnx, size_t onnx_len, const oar_engine_cfg* cfg, oar_engine** out);
