@@ -147,7 +147,8 @@ typedef struct {
     int32_t profile;
     int32_t host_threads;      /* worker threads for the serial contour/geometry stage (0 = hw conc.)   */
     /* DBPostProcess options the adapter exposes (processors/db_postprocess.rs:60-98, processors/types.rs):          */
-    int32_t box_type;          /* 0 = BoxType::Quad (default), 1 = BoxType::Poly (seal text; not implemented yet: create fails with OAR_UNSUPPORTED_OP) */
+    int32_t box_type;          /* 0 = BoxType::Quad (default), 1 = BoxType::Poly (seal / curved text: polygons_from_bitmap, db_bitmap.rs:16-82;
+                                  results carry point_offsets) */
     int32_t score_mode;        /* 0 = ScoreMode::Fast (mini-box scanline mean), 1 = ScoreMode::Slow (contour scanline mean, db_score.rs:139-181) */
     int32_t use_dilation;      /* 1: dilate the mask (3 x 3, db_mask.rs:11) before contour tracing (db_postprocess.rs:163-168) */
     /* Where find_contours (db_bitmap.rs:100) runs.  0: on the host thread pool from the read-back mask (default: fastest on one GPU,
@@ -158,13 +159,17 @@ typedef struct {
 } oar_det_cfg;
 
 /* CSR result: image i owns boxes [box_offsets[i], box_offsets[i+1]); each box is 4 points (x,y) f32 in
- * original-image coordinates, contour discovery order (unsorted, as the adapter returns them). */
+ * original-image coordinates, contour discovery order (unsorted, as the adapter returns them).
+ * BoxType::Poly: a box is a polygon of any size -- box b owns points [point_offsets[b], point_offsets[b+1]) of `points`
+ * (BoundingBox::points of polygons_from_bitmap, db_bitmap.rs:66-78); point_offsets is NULL for quads. */
 typedef struct {
     uint32_t n_images;
     uint32_t n_boxes;
     uint32_t* box_offsets;   /* n_images + 1 */
-    float* points;           /* n_boxes * 8  */
+    float* points;           /* quads: n_boxes * 8; polygons: n_points * 2 */
     float* scores;           /* n_boxes      */
+    uint32_t n_points;       /* quads: n_boxes * 4 */
+    uint32_t* point_offsets; /* polygons: n_boxes + 1; quads: NULL */
 } oar_det_result;
 
 oar_status oar_det_create(const uint8_t* onnx, size_t onnx_len, const oar_det_cfg* cfg, oar_det** out);
@@ -178,7 +183,7 @@ void oar_det_result_free(oar_det_result* r);
 oar_status oar_db_postprocess(const float* pred, uint32_t height, uint32_t width, uint32_t src_w, uint32_t src_h,
                               float thresh, float box_thresh, float unclip_ratio, uint32_t max_candidates,
                               oar_det_result* out);
-/* Same, with the DBPostProcess options that oar_det_cfg carries: score_mode, use_dilation; box_type must be 0. */
+/* Same, with the DBPostProcess options that oar_det_cfg carries: box_type, score_mode, use_dilation. */
 oar_status oar_db_postprocess_ex(const float* pred, uint32_t height, uint32_t width, uint32_t src_w, uint32_t src_h,
                                  float thresh, float box_thresh, float unclip_ratio, uint32_t max_candidates,
                                  int32_t box_type, int32_t score_mode, int32_t use_dilation, oar_det_result* out);
@@ -268,7 +273,7 @@ typedef struct {
     uint32_t n_images;
     uint32_t n_regions;
     uint32_t* region_offsets;  /* n_images + 1                                              */
-    float* points;             /* n_regions * 8, original-image coordinates                 */
+    float* points;             /* n_regions * 8, original-image coordinates (polygons: see point_offsets) */
     float* det_scores;         /* n_regions (not part of OAROCRResult; kept for parity checks) */
     uint32_t* crop_wh;         /* n_regions * 2 (w,h) of the rectified crop                 */
     uint32_t* seq_len;         /* n_regions: T of the batch the region was recognised in    */
@@ -280,6 +285,11 @@ typedef struct {
     float* page_angle;         /* n_images: OAROCRResult::orientation_angle (0/90/180/270), -1 = none (ocr.rs:653)      */
     uint8_t* page_rectified;   /* n_images: 1 when rectified_img would be Some (ocr.rs:654); boxes then stay in rectified space */
     float* line_angle;         /* n_regions: TextRegion::orientation_angle (0/180), -1 = none (ocr.rs:782-783,888)      */
+    /* det.box_type = 1 (seal text): a region's box is a polygon -- region r owns points [point_offsets[r], point_offsets[r+1]) of
+     * `points` (then n_points * 2 floats); regions are in sort_poly_boxes order and cropped by their bounding rectangle
+     * (bbox_crop.rs:26-72) unless they have exactly 4 points.  point_offsets is NULL for quads. */
+    uint32_t n_points;         /* quads: n_regions * 4 */
+    uint32_t* point_offsets;
 } oar_ocr_result;
 
 oar_status oar_ocr_create(const uint8_t* det_onnx, size_t det_len, const uint8_t* rec_onnx, size_t rec_len,
@@ -411,6 +421,22 @@ int32_t oar_host_contours_bits(const uint8_t* mask, uint32_t width, uint32_t hei
                                int64_t* offsets, int32_t* pts_xy, int32_t* types, int64_t cap_points);
 /* a11 db_bitmap.rs:279-368: unclip a 4-point box; returns the number of points (0 = dropped), x,y pairs in out. */
 int32_t oar_host_unclip(const float box8[8], float ratio, float* out_xy, int32_t cap_points);
+/* f2 (polygon / seal branch) processors/geometry.rs:453-561: Douglas-Peucker over the open chain xy[0 .. n_points); returns the
+ * number of kept points (<= cap_points written). */
+int32_t oar_host_approx_poly_dp(const float* xy, int32_t n_points, float epsilon, float* out_xy, int32_t cap_points);
+/* f2 processors/geometry.rs:161-171: closed-ring perimeter, f32 accumulation. */
+float oar_host_perimeter(const float* xy, int32_t n_points);
+/* f2 db_bitmap.rs:279-368 for ANY polygon (Clipper2 round-join offset + the outline its closing union keeps); returns the number
+ * of points, 0 = the reference drops the box (degenerate input or an offset that is not exactly one path), -1 = error. */
+int32_t oar_host_unclip_poly(const float* xy, int32_t n_points, float ratio, float* out_xy, int32_t cap_points);
+/* f2 the two halves of the above on 1/100 px grid coordinates, for the tests: the raw Clipper2 offset ring of a closed ring
+ * (radius < 0 for a clockwise ring), and the outline of a raw ring (negative != 0: the ring runs clockwise).  Return the number of
+ * vertices, 0 (outline: not exactly one loop), -1 when cap_points is too small. */
+int32_t oar_host_offset_ring(const int64_t* xy, int32_t n_points, double radius, int64_t* out_xy, int32_t cap_points);
+int32_t oar_host_ring_outline(const int64_t* xy, int32_t n_points, int32_t negative, int64_t* out_xy, int32_t cap_points);
+/* f2 processors/sorting.rs:100-118: permutation that sorts n polygons (CSR: polygon i = points [offsets[i], offsets[i + 1]))
+ * by their smallest y, stably. */
+void oar_host_sort_poly_boxes(const float* pts_xy, const uint32_t* offsets, int32_t n, int32_t* order);
 /* a9 mini box of an arbitrary point set (db_bitmap.rs:164-205): returns 1 and fills box8/min_side, or 0. */
 int32_t oar_host_mini_box(const float* xy, int32_t n_points, float box8[8], float* min_side);
 /* a13 processors/sorting.rs:35-84: permutation that sorts n quad boxes into reading order. */

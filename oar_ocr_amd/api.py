@@ -63,7 +63,7 @@ class DetCfg(C.Structure):
 
 class DetResult(C.Structure):
     _fields_ = [("n_images", C.c_uint32), ("n_boxes", C.c_uint32), ("box_offsets", C.POINTER(C.c_uint32)),
-                ("points", C.POINTER(C.c_float)), ("scores", C.POINTER(C.c_float))]
+                ("points", C.POINTER(C.c_float)), ("scores", C.POINTER(C.c_float)), ("n_points", C.c_uint32), ("point_offsets", C.POINTER(C.c_uint32))]
 
 
 class RecCfg(C.Structure):
@@ -86,7 +86,8 @@ class OcrResult(C.Structure):
                 ("points", C.POINTER(C.c_float)), ("det_scores", C.POINTER(C.c_float)), ("crop_wh", C.POINTER(C.c_uint32)),
                 ("seq_len", C.POINTER(C.c_uint32)), ("max_wh_ratio", C.POINTER(C.c_float)), ("ctc_offsets", C.POINTER(C.c_uint64)),
                 ("ctc_indices", C.POINTER(C.c_int64)), ("ctc_probs", C.POINTER(C.c_float)),
-                ("page_angle", C.POINTER(C.c_float)), ("page_rectified", C.POINTER(C.c_uint8)), ("line_angle", C.POINTER(C.c_float))]
+                ("page_angle", C.POINTER(C.c_float)), ("page_rectified", C.POINTER(C.c_uint8)), ("line_angle", C.POINTER(C.c_float)),
+                ("n_points", C.c_uint32), ("point_offsets", C.POINTER(C.c_uint32))]
 
 
 class ClsCfg(C.Structure):
@@ -125,6 +126,7 @@ EXPORTS = [
     "oar_rect_run", "oar_ocr_attach", "oar_k_rotate_rgb", "oar_k_bgr_planes_to_rgb", "oar_host_rotate_back_points",
     "oar_engine_cache_stats", "oar_onnx_inspect", "oar_host_contours", "oar_ctc_dict_create", "oar_ctc_dict_destroy", "oar_ctc_dict_classes",
     "oar_ctc_decode", "oar_ocr_decode", "oar_text_result_free", "oar_db_postprocess_ex", "oar_k_dilate", "oar_k_poly_scores", "oar_debug_inject_failure", "oar_k_contours", "oar_host_contours_bits",
+    "oar_host_approx_poly_dp", "oar_host_perimeter", "oar_host_unclip_poly", "oar_host_offset_ring", "oar_host_ring_outline", "oar_host_sort_poly_boxes",
 ]
 
 
@@ -200,6 +202,18 @@ def lib():
     L.oar_host_contours.restype = C.c_int32
     L.oar_host_unclip.argtypes = [vp, C.c_float, vp, C.c_int32]
     L.oar_host_unclip.restype = C.c_int32
+    L.oar_host_approx_poly_dp.argtypes = [vp, C.c_int32, C.c_float, vp, C.c_int32]
+    L.oar_host_approx_poly_dp.restype = C.c_int32
+    L.oar_host_perimeter.argtypes = [vp, C.c_int32]
+    L.oar_host_perimeter.restype = C.c_float
+    L.oar_host_unclip_poly.argtypes = [vp, C.c_int32, C.c_float, vp, C.c_int32]
+    L.oar_host_unclip_poly.restype = C.c_int32
+    L.oar_host_offset_ring.argtypes = [vp, C.c_int32, C.c_double, vp, C.c_int32]
+    L.oar_host_offset_ring.restype = C.c_int32
+    L.oar_host_ring_outline.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_int32]
+    L.oar_host_ring_outline.restype = C.c_int32
+    L.oar_host_sort_poly_boxes.argtypes = [vp, vp, C.c_int32, vp]
+    L.oar_host_sort_poly_boxes.restype = None
     L.oar_host_mini_box.argtypes = [vp, C.c_int32, vp, f32p]
     L.oar_host_mini_box.restype = C.c_int32
     L.oar_host_sort_quad_boxes.argtypes = [vp, C.c_int32, vp]
@@ -425,7 +439,7 @@ class TextDetectionConfig:
     limit_type: Optional[str] = None   # "max" | "min" | "resize_long"
     max_side_len: Optional[int] = None
     # DBPostProcess options (processors/db_postprocess.rs:60-98; the adapters set them at build time)
-    box_type: str = "quad"             # "quad" | "poly" (seal text; not implemented yet)
+    box_type: str = "quad"             # "quad" | "poly" (seal / curved text: Detection.bbox is [n, 2] with n >= 3)
     score_mode: str = "fast"           # "fast" | "slow"
     use_dilation: bool = False
     gpu_contours: bool = False         # backend option (not in the reference): follow the mask borders on the GPU (oar_det_cfg.gpu_contours)
@@ -444,7 +458,7 @@ class TextDetectionConfig:
 
 @dataclass
 class Detection:
-    bbox: np.ndarray   # [4,2] f32
+    bbox: np.ndarray   # [4,2] f32 (BoxType::Poly: [n,2])
     score: float
 
 
@@ -611,13 +625,18 @@ _LIMIT = {"max": 0, "min": 1, "resize_long": 2}
 class TextDetectionPredictor:
     """predictors/text_detection.rs + domain/adapters/text_detection_adapter.rs:36-79"""
 
-    def __init__(self, model: bytes, config: Optional[TextDetectionConfig] = None, device_id: int = 0, limit_side_len: int = 960,
-                 limit_type: str = "max", max_side_limit: int = 4000, host_threads: int = 0, profile: bool = False):
+    def __init__(self, model: bytes, config: Optional[TextDetectionConfig] = None, device_id: int = 0, limit_side_len: Optional[int] = None,
+                 limit_type: Optional[str] = None, max_side_limit: int = 4000, host_threads: int = 0, profile: bool = False,
+                 text_type: Optional[str] = None):
         self.config = config or TextDetectionConfig()
         self.config.validate()
+        # text_type "seal": 736 / min preprocessing and polygon boxes (text_detection_adapter.rs:131-150, preprocessing.rs:44-62)
+        seal = (text_type or "").lower() == "seal"
+        limit_side_len = limit_side_len or (736 if seal else 960)
+        limit_type = limit_type or ("min" if seal else "max")
         cfg = DetCfg(device_id, self.config.limit_side_len or limit_side_len, _LIMIT[self.config.limit_type or limit_type],
                      self.config.max_side_len or max_side_limit, self.config.max_candidates, 0, int(profile), host_threads,
-                     int(self.config.box_type == "poly"), int(self.config.score_mode == "slow"), int(self.config.use_dilation), int(self.config.gpu_contours))
+                     int(self.config.box_type == "poly" or seal), int(self.config.score_mode == "slow"), int(self.config.use_dilation), int(self.config.gpu_contours))
         self._h = C.c_void_p()
         buf = (C.c_char * len(model)).from_buffer_copy(model)
         _check(lib().oar_det_create(C.cast(buf, C.c_void_p), len(model), C.byref(cfg), C.byref(self._h)))
@@ -650,21 +669,45 @@ class TextDetectionPredictor:
             pass
 
 
+@dataclass
+class SealTextDetectionConfig:
+    """domain/tasks/seal_text_detection.rs:15-43"""
+    score_threshold: float = 0.2
+    box_threshold: float = 0.6
+    unclip_ratio: float = 0.5
+    max_candidates: int = 1000
+
+
+class SealTextDetectionPredictor(TextDetectionPredictor):
+    """domain/adapters/seal_text_detection_adapter.rs:20-160: the DB model with seal preprocessing (736 / min), BoxType::Poly,
+    ScoreMode::Fast, no dilation.  Detection.bbox is an [n, 2] polygon."""
+
+    def __init__(self, model: bytes, config: Optional[SealTextDetectionConfig] = None, device_id: int = 0, host_threads: int = 0):
+        c = config or SealTextDetectionConfig()
+        super().__init__(model, TextDetectionConfig(c.score_threshold, c.box_threshold, c.unclip_ratio, c.max_candidates, box_type="poly"),
+                         device_id=device_id, host_threads=host_threads, text_type="seal")
+
+
 def _unpack_det(res: DetResult) -> List[List[Detection]]:
     n, nb = res.n_images, res.n_boxes
     offs = np.ctypeslib.as_array(res.box_offsets, shape=(n + 1,)).copy()
-    pts = np.ctypeslib.as_array(res.points, shape=(max(nb, 1) * 8,)).copy()[:nb * 8].reshape(nb, 4, 2)
     sc = np.ctypeslib.as_array(res.scores, shape=(max(nb, 1),)).copy()[:nb]
+    if res.point_offsets:   # BoxType::Poly: polygons of any size
+        po = np.ctypeslib.as_array(res.point_offsets, shape=(nb + 1,)).copy()
+        npt = int(res.n_points)
+        flat = np.ctypeslib.as_array(res.points, shape=(max(npt, 1) * 2,)).copy()[:npt * 2].reshape(npt, 2)
+        return [[Detection(flat[po[k]:po[k + 1]].copy(), float(sc[k])) for k in range(offs[i], offs[i + 1])] for i in range(n)]
+    pts = np.ctypeslib.as_array(res.points, shape=(max(nb, 1) * 8,)).copy()[:nb * 8].reshape(nb, 4, 2)
     return [[Detection(pts[k].copy(), float(sc[k])) for k in range(offs[i], offs[i + 1])] for i in range(n)]
 
 
 def db_postprocess(pred: np.ndarray, src_w: int, src_h: int, thresh=0.3, box_thresh=0.6, unclip_ratio=1.5, max_candidates=1000,
-                   score_mode="fast", use_dilation=False):
+                   score_mode="fast", use_dilation=False, box_type="quad"):
     """Test hook: DB post-processing (a7..a12) on a host probability map through the HIP kernels."""
     pred = np.ascontiguousarray(pred, np.float32)
     h, w = pred.shape
     res = DetResult()
-    _check(lib().oar_db_postprocess_ex(_p(pred), h, w, src_w, src_h, thresh, box_thresh, unclip_ratio, max_candidates, 0, int(score_mode == "slow"),
+    _check(lib().oar_db_postprocess_ex(_p(pred), h, w, src_w, src_h, thresh, box_thresh, unclip_ratio, max_candidates, int(box_type == "poly"), int(score_mode == "slow"),
                                        int(use_dilation), C.byref(res)))
     out = _unpack_det(res)[0]
     lib().oar_det_result_free(C.byref(res))
@@ -752,6 +795,12 @@ class OAROCRBuilder:
         self._profile = False
         self._host_threads = 0
         self._doc_ori = self._rectifier = self._line_ori = None
+        self._text_type: Optional[str] = None
+
+    def text_type(self, text_type: str):
+        """ocr.rs:218-229: "seal" selects polygon boxes, sort_poly_boxes and bounding-rectangle crops (curved text)."""
+        self._text_type = text_type
+        return self
 
     def with_document_image_orientation_classification(self, model: bytes):
         """PP-LCNet_x1_0_doc_ori: 224x224, resize_short 256, 4 classes (domain/tasks/document_orientation.rs:46-53)"""
@@ -800,15 +849,22 @@ class OAROCRBuilder:
         for name, v in (("image_batch_size", self._image_bs), ("region_batch_size", self._region_bs)):
             if v is not None and not (1 <= v <= 4096):   # ocr.rs:250-255,419-430
                 raise OCRError(OAR_INVALID_INPUT, f"{name} must be in 1..=4096")
+        # the adapter decides by the lower-cased text type (text_detection_adapter.rs:131-136), the builder's default table by the
+        # exact string (ocr.rs:322)
+        seal = (self._text_type or "").lower() == "seal"
+        pre_lsl, pre_lt = (736, "min") if seal else (960, "max")   # db_preprocess_for_text_type (preprocessing.rs:44-62)
         if self._det_cfg is not None:
             d = self._det_cfg
             d.validate()
             thresh, box_thresh, unclip, maxc = d.score_threshold, d.box_threshold, d.unclip_ratio, d.max_candidates
-            lsl, lt, msl = d.limit_side_len or 960, d.limit_type or "max", d.max_side_len or 4000
-            opts = (int(d.box_type == "poly"), int(d.score_mode == "slow"), int(d.use_dilation), int(d.gpu_contours))
+            lsl, lt, msl = d.limit_side_len or pre_lsl, d.limit_type or pre_lt, d.max_side_len or 4000
+            opts = (int(d.box_type == "poly" or seal), int(d.score_mode == "slow"), int(d.use_dilation), int(d.gpu_contours))
         else:   # builder defaults (ocr.rs:319-366)
-            thresh, box_thresh, unclip, maxc, lsl, lt, msl = 0.3, 0.6, 2.0, 1000, 960, "max", 4000
-            opts = (0, 0, 0, 0)
+            tt = self._text_type or "general"
+            thresh, box_thresh, unclip = (0.3, 0.4, 2.0) if tt == "table" else (0.2, 0.6, 0.5) if tt == "seal" else (0.3, 0.6, 2.0)
+            maxc, msl = 1000, 4000
+            lsl, lt = (736, "min") if tt == "seal" else (960, "max")
+            opts = (int(seal), 0, 0, 0)
         cfg = OcrCfg()
         cfg.det = DetCfg(self._device, lsl, _LIMIT[lt], msl, maxc, 0, int(self._profile), self._host_threads, *opts)
         cfg.rec = RecCfg(self._device, (C.c_uint32 * 3)(3, 48, 320), 3200, 0, int(self._profile), 0)
@@ -879,6 +935,8 @@ class OAROCR:
         try:
             d = self.ctc.decode_ocr(res, self.score_threshold, want_positions=False)
             nr = int(res.n_regions)
+            if res.point_offsets:
+                raise OCRError(OAR_INVALID_INPUT, "predict_packed carries quad boxes only: use predict() for seal text")
             offs = np.ctypeslib.as_array(res.region_offsets, shape=(n + 1,)).copy()
             pts = np.ctypeslib.as_array(res.points, shape=(max(nr, 1) * 8,)).copy()[:nr * 8].reshape(nr, 4, 2)
         finally:
@@ -893,7 +951,12 @@ class OAROCR:
         page_kw = [dict(orientation_angle=(float(pang[i]) if pang[i] >= 0 else None), rectified=bool(prect[i])) for i in range(n)]
         if nr == 0:
             return [OAROCRResult(f"image_{i}", i, **page_kw[i]) for i in range(n)]
-        pts = np.ctypeslib.as_array(res.points, shape=(nr * 8,)).copy().reshape(nr, 4, 2)
+        if res.point_offsets:   # seal text: polygons of any size
+            po = np.ctypeslib.as_array(res.point_offsets, shape=(nr + 1,)).copy()
+            flat = np.ctypeslib.as_array(res.points, shape=(max(int(res.n_points), 1) * 2,)).copy()[:int(res.n_points) * 2].reshape(-1, 2)
+            pts = [flat[po[k]:po[k + 1]] for k in range(nr)]
+        else:
+            pts = np.ctypeslib.as_array(res.points, shape=(nr * 8,)).copy().reshape(nr, 4, 2)
         dsc = np.ctypeslib.as_array(res.det_scores, shape=(nr,)).copy()
         cwh = np.ctypeslib.as_array(res.crop_wh, shape=(nr * 2,)).copy().reshape(nr, 2)
         sl = np.ctypeslib.as_array(res.seq_len, shape=(nr,)).copy()
@@ -1166,6 +1229,60 @@ def host_unclip(box, ratio):
     out = np.zeros((1024, 2), np.float32)
     n = lib().oar_host_unclip(_p(box), ratio, _p(out), 1024)
     return out[:max(n, 0)].copy()
+
+
+def host_approx_poly_dp(points, epsilon):
+    """geometry.rs:453-561 on the open chain `points`."""
+    pts = np.ascontiguousarray(points, np.float32).reshape(-1, 2)
+    out = np.zeros((max(len(pts), 1), 2), np.float32)
+    n = lib().oar_host_approx_poly_dp(_p(pts), pts.shape[0], C.c_float(epsilon), _p(out), out.shape[0])
+    return out[:max(n, 0)].copy()
+
+
+def host_perimeter(points) -> float:
+    pts = np.ascontiguousarray(points, np.float32).reshape(-1, 2)
+    return float(lib().oar_host_perimeter(_p(pts), pts.shape[0]))
+
+
+def host_unclip_poly(points, ratio):
+    """db_bitmap.rs:279-368 for any polygon; an empty array where the reference drops the box."""
+    pts = np.ascontiguousarray(points, np.float32).reshape(-1, 2)
+    cap = 64 * len(pts) + 1024
+    out = np.zeros((cap, 2), np.float32)
+    n = lib().oar_host_unclip_poly(_p(pts), pts.shape[0], C.c_float(ratio), _p(out), cap)
+    if n < 0:
+        raise RuntimeError("oar_host_unclip_poly failed")
+    return out[:n].copy()
+
+
+def host_offset_ring(ring, radius):
+    r = np.ascontiguousarray(ring, np.int64).reshape(-1, 2)
+    cap = 64 * len(r) + 1024
+    out = np.zeros((cap, 2), np.int64)
+    n = lib().oar_host_offset_ring(_p(r), r.shape[0], C.c_double(radius), _p(out), cap)
+    return out[:max(n, 0)].copy()
+
+
+def host_ring_outline(raw, negative=False):
+    """None when the outline is not exactly one loop."""
+    r = np.ascontiguousarray(raw, np.int64).reshape(-1, 2)
+    cap = 4 * len(r) + 64
+    out = np.zeros((cap, 2), np.int64)
+    n = lib().oar_host_ring_outline(_p(r), r.shape[0], 1 if negative else 0, _p(out), cap)
+    return out[:n].copy() if n > 0 else None
+
+
+def host_sort_poly_boxes(polys):
+    if not polys:
+        return np.zeros(0, np.int32)
+    offs = np.zeros(len(polys) + 1, np.uint32)
+    offs[1:] = np.cumsum([len(p) for p in polys])
+    pts = np.ascontiguousarray(np.concatenate([np.asarray(p, np.float32).reshape(-1, 2) for p in polys] + [np.zeros((0, 2), np.float32)]), np.float32)
+    if len(pts) == 0:
+        pts = np.zeros((1, 2), np.float32)
+    order = np.zeros(len(polys), np.int32)
+    lib().oar_host_sort_poly_boxes(_p(pts), _p(offs), len(polys), _p(order))
+    return order
 
 
 def host_mini_box(points):

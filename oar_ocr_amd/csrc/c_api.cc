@@ -54,17 +54,28 @@ void fill_det_result(const std::vector<DetBoxes>& boxes, oar_det_result* out) {
     size_t total = 0;
     for (auto& b : boxes) total += b.scores.size();
     out->n_boxes = (uint32_t)total;
+    bool poly = false;
+    size_t floats = 0;
+    for (auto& b : boxes) { poly = poly || !b.counts.empty(); floats += b.pts.size(); }
+    out->n_points = (uint32_t)(floats / 2);
     out->box_offsets = cmalloc<uint32_t>(boxes.size() + 1);
-    out->points = cmalloc<float>(total * 8);
+    out->points = cmalloc<float>(floats);
     out->scores = cmalloc<float>(total);
-    size_t k = 0;
+    if (poly) out->point_offsets = cmalloc<uint32_t>(total + 1);
+    size_t k = 0, f = 0;
     for (size_t i = 0; i < boxes.size(); ++i) {
         out->box_offsets[i] = (uint32_t)k;
-        std::memcpy(out->points + k * 8, boxes[i].pts.data(), boxes[i].pts.size() * sizeof(float));
+        if (poly) {
+            size_t at = f / 2;
+            for (size_t b = 0; b < boxes[i].counts.size(); ++b) { out->point_offsets[k + b] = (uint32_t)at; at += boxes[i].counts[b]; }
+        }
+        std::memcpy(out->points + f, boxes[i].pts.data(), boxes[i].pts.size() * sizeof(float));
         std::memcpy(out->scores + k, boxes[i].scores.data(), boxes[i].scores.size() * sizeof(float));
         k += boxes[i].scores.size();
+        f += boxes[i].pts.size();
     }
     out->box_offsets[boxes.size()] = (uint32_t)k;
+    if (poly) out->point_offsets[total] = (uint32_t)(f / 2);
 }
 }  // namespace
 
@@ -355,7 +366,7 @@ oar_status oar_det_run(oar_det* d, const uint8_t* const* rgb, const uint32_t* wi
 }
 void oar_det_result_free(oar_det_result* r) {
     if (!r) return;
-    std::free(r->box_offsets); std::free(r->points); std::free(r->scores);
+    std::free(r->box_offsets); std::free(r->points); std::free(r->scores); std::free(r->point_offsets);
     std::memset(r, 0, sizeof *r);
 }
 
@@ -374,10 +385,10 @@ oar_status oar_db_postprocess_ex(const float* pred, uint32_t height, uint32_t wi
                                  int32_t use_dilation, oar_det_result* out) {
     return guard([&] {
         OAR_CHECK(pred && out && height && width, OAR_INVALID_INPUT, "oar_db_postprocess_ex: bad arguments");
-        OAR_CHECK(box_type == 0, OAR_UNSUPPORTED_OP, "BoxType::Poly (seal text detection) is not implemented yet");
+        OAR_CHECK(box_type == 0 || box_type == 1, OAR_INVALID_INPUT, "box_type must be 0 (Quad) or 1 (Poly)");
         OAR_CHECK(score_mode == 0 || score_mode == 1, OAR_INVALID_INPUT, "score_mode must be 0 (fast) or 1 (slow)");
         std::vector<DetBoxes> boxes(1);
-        Detector::postprocess_host(pred, (int)height, (int)width, src_w, src_h, thresh, box_thresh, unclip_ratio, max_candidates, boxes[0], score_mode, use_dilation);
+        Detector::postprocess_host(pred, (int)height, (int)width, src_w, src_h, thresh, box_thresh, unclip_ratio, max_candidates, boxes[0], score_mode, use_dilation, box_type);
         fill_det_result(boxes, out);
     });
 }
@@ -447,7 +458,13 @@ static void fill_ocr_result(const std::vector<std::vector<OcrRegion>>& res, cons
     for (auto& im : res) for (auto& r : im) { ++nreg; nctc += r.idx.size(); }
     out->n_images = (uint32_t)res.size(); out->n_regions = (uint32_t)nreg;
     out->region_offsets = cmalloc<uint32_t>(res.size() + 1);
-    out->points = cmalloc<float>(nreg * 8);
+    bool poly = false;
+    size_t npoly_floats = 0;
+    for (auto& im : res) for (auto& r : im) { poly = poly || !r.poly.empty(); npoly_floats += r.poly.size(); }
+    out->points = cmalloc<float>(poly ? npoly_floats : nreg * 8);
+    out->n_points = (uint32_t)(poly ? npoly_floats / 2 : nreg * 4);
+    if (poly) out->point_offsets = cmalloc<uint32_t>(nreg + 1);
+    size_t pf = 0;
     out->det_scores = cmalloc<float>(nreg);
     out->crop_wh = cmalloc<uint32_t>(nreg * 2);
     out->seq_len = cmalloc<uint32_t>(nreg);
@@ -466,7 +483,13 @@ static void fill_ocr_result(const std::vector<std::vector<OcrRegion>>& res, cons
     for (size_t i = 0; i < res.size(); ++i) {
         out->region_offsets[i] = (uint32_t)k;
         for (auto& r : res[i]) {
-            std::memcpy(out->points + k * 8, r.pts, sizeof r.pts);
+            if (poly) {
+                out->point_offsets[k] = (uint32_t)(pf / 2);
+                std::memcpy(out->points + pf, r.poly.data(), r.poly.size() * sizeof(float));
+                pf += r.poly.size();
+            } else {
+                std::memcpy(out->points + k * 8, r.pts, sizeof r.pts);
+            }
             out->det_scores[k] = r.det_score;
             out->crop_wh[k * 2] = r.crop_w; out->crop_wh[k * 2 + 1] = r.crop_h;
             out->seq_len[k] = r.T; out->max_wh_ratio[k] = r.max_wh_ratio; out->line_angle[k] = r.line_angle;
@@ -478,6 +501,7 @@ static void fill_ocr_result(const std::vector<std::vector<OcrRegion>>& res, cons
         }
     }
     out->region_offsets[res.size()] = (uint32_t)k;
+    if (poly) out->point_offsets[k] = (uint32_t)(pf / 2);
     out->ctc_offsets[k] = c;
 }
 
@@ -509,7 +533,7 @@ void oar_ocr_result_free(oar_ocr_result* r) {
     if (!r) return;
     std::free(r->region_offsets); std::free(r->points); std::free(r->det_scores); std::free(r->crop_wh); std::free(r->seq_len);
     std::free(r->max_wh_ratio); std::free(r->ctc_offsets); std::free(r->ctc_indices); std::free(r->ctc_probs);
-    std::free(r->page_angle); std::free(r->page_rectified); std::free(r->line_angle);
+    std::free(r->page_angle); std::free(r->page_rectified); std::free(r->line_angle); std::free(r->point_offsets);
     std::memset(r, 0, sizeof *r);
 }
 
@@ -932,6 +956,46 @@ int32_t oar_host_unclip(const float box8[8], float ratio, float* out_xy, int32_t
         for (size_t i = 0; i < r.size() && (int32_t)i < cap_points; ++i) { out_xy[i * 2] = r[i].x; out_xy[i * 2 + 1] = r[i].y; }
         return (int32_t)r.size();
     } catch (...) { return -1; }
+}
+int32_t oar_host_approx_poly_dp(const float* xy, int32_t n_points, float epsilon, float* out_xy, int32_t cap_points) {
+    try {
+        std::vector<host::Pt> p(n_points > 0 ? n_points : 0);
+        for (int i = 0; i < n_points; ++i) p[i] = {xy[i * 2], xy[i * 2 + 1]};
+        std::vector<host::Pt> r = host::approx_poly_dp(p, epsilon);
+        for (size_t i = 0; i < r.size() && (int32_t)i < cap_points; ++i) { out_xy[i * 2] = r[i].x; out_xy[i * 2 + 1] = r[i].y; }
+        return (int32_t)r.size();
+    } catch (...) { return -1; }
+}
+float oar_host_perimeter(const float* xy, int32_t n_points) {
+    try {
+        std::vector<host::Pt> p(n_points > 0 ? n_points : 0);
+        for (int i = 0; i < n_points; ++i) p[i] = {xy[i * 2], xy[i * 2 + 1]};
+        return host::perimeter(p);
+    } catch (...) { return -1.0f; }
+}
+int32_t oar_host_unclip_poly(const float* xy, int32_t n_points, float ratio, float* out_xy, int32_t cap_points) {
+    try {
+        std::vector<host::Pt> p(n_points > 0 ? n_points : 0);
+        for (int i = 0; i < n_points; ++i) p[i] = {xy[i * 2], xy[i * 2 + 1]};
+        std::vector<host::Pt> r = host::unclip_poly(p, ratio);
+        for (size_t i = 0; i < r.size() && (int32_t)i < cap_points; ++i) { out_xy[i * 2] = r[i].x; out_xy[i * 2 + 1] = r[i].y; }
+        return (int32_t)r.size();
+    } catch (...) { return -1; }
+}
+int32_t oar_host_offset_ring(const int64_t* xy, int32_t n_points, double radius, int64_t* out_xy, int32_t cap_points) {
+    try { return host::offset_ring_for_tests(xy, n_points, radius, out_xy, cap_points); } catch (...) { return -1; }
+}
+int32_t oar_host_ring_outline(const int64_t* xy, int32_t n_points, int32_t negative, int64_t* out_xy, int32_t cap_points) {
+    try { return host::ring_outline_for_tests(xy, n_points, negative, out_xy, cap_points); } catch (...) { return -1; }
+}
+void oar_host_sort_poly_boxes(const float* pts_xy, const uint32_t* offsets, int32_t n, int32_t* order) {
+    try {
+        if (n <= 0) return;
+        std::vector<uint32_t> off(offsets, offsets + n + 1);
+        std::vector<float> pts(pts_xy, pts_xy + (size_t)off[n] * 2);
+        std::vector<int> o = host::sort_poly_boxes(pts, off);
+        for (int i = 0; i < n; ++i) order[i] = o[i];
+    } catch (...) {}
 }
 int32_t oar_host_mini_box(const float* xy, int32_t n_points, float box8[8], float* min_side) {
     try {

@@ -44,6 +44,17 @@ std::vector<Pt> unclip(const Pt box[4], float ratio);
 // processors/sorting.rs:35-84: returns the permutation
 std::vector<int> sort_quad_boxes(const std::vector<float>& boxes8);
 
+// ---- polygon (seal text) branch, poly_host.cc
+float perimeter(const std::vector<Pt>& pts);                                   // processors/geometry.rs:161-171
+std::vector<Pt> approx_poly_dp(const std::vector<Pt>& pts, float epsilon);     // processors/geometry.rs:453-561
+// processors/db_bitmap.rs:279-368 for any polygon: Clipper2 round-join offset + the outline its closing union keeps; empty when
+// the reference would drop the box (degenerate input, or an offset that is not exactly one path)
+std::vector<Pt> unclip_poly(const std::vector<Pt>& poly, float ratio);
+// processors/sorting.rs:100-118: stable by min y; box i = points [offsets[i], offsets[i + 1]) of pts_xy
+std::vector<int> sort_poly_boxes(const std::vector<float>& pts_xy, const std::vector<uint32_t>& offsets);
+int ring_outline_for_tests(const int64_t* xy, int n, int negative, int64_t* out_xy, int out_cap);
+int offset_ring_for_tests(const int64_t* xy, int n, double radius, int64_t* out_xy, int out_cap);
+
 struct CropPlan {        // utils/transform.rs:76-191
     int mode = 0;        // 0 failed, 1 axis aligned, 2 perspective
     int left = 0, top = 0, cw = 0, ch = 0, ow = 0, oh = 0, rot = 0;
@@ -52,6 +63,8 @@ struct CropPlan {        // utils/transform.rs:76-191
     int out_h() const { return rot ? ow : oh; }
 };
 CropPlan plan_crop(int img_w, int img_h, const float box8[8]);
+// utils/bbox_crop.rs:26-72: the polygon's bounding rectangle as an axis-aligned crop (mode 1), mode 0 where the reference errs
+CropPlan plan_bbox_crop(int img_w, int img_h, const float* pts_xy, int n_points);
 
 // processors/resize_detection.rs:243-319 (type0). Returns true when a resize is needed.
 bool det_resize_dims(uint32_t w, uint32_t h, uint32_t limit_side_len, int limit_type, uint32_t max_side_limit,

@@ -192,7 +192,7 @@ Detector::Detector(const uint8_t* onnx, size_t len, const oar_det_cfg& cfg) : cf
     if (cfg_.limit_side_len == 0) cfg_.limit_side_len = 960;
     if (cfg_.max_side_limit == 0) cfg_.max_side_limit = 4000;
     if (cfg_.max_candidates == 0) cfg_.max_candidates = 1000;
-    OAR_CHECK(cfg_.box_type == 0, OAR_UNSUPPORTED_OP, "BoxType::Poly (seal text detection) is not implemented yet: use box_type = 0 (Quad)");
+    OAR_CHECK(cfg_.box_type == 0 || cfg_.box_type == 1, OAR_INVALID_INPUT, "box_type must be 0 (Quad) or 1 (Poly)");
     OAR_CHECK(cfg_.score_mode == 0 || cfg_.score_mode == 1, OAR_INVALID_INPUT, "score_mode must be 0 (fast) or 1 (slow)");
     eng_.reset(new Engine(onnx, len, cfg_.device_id));
     pool_.reset(new ThreadPool(cfg_.host_threads));
@@ -247,10 +247,19 @@ void ContourBufs::reserve(int pages, int sub_pages, int H, int W, int n_sub) {
 }
 
 namespace {
-struct Candidate { float pts[8]; std::vector<host::Pt> contour; /* ScoreMode::Slow only */ };
+struct Candidate { float pts[8]; std::vector<host::Pt> contour; /* kCandSlow: the border chain; kCandPoly: the approximated polygon */ };
+// what a contour becomes: the mini box alone (Quad + ScoreMode::Fast), the mini box + the chain it is scored on (Quad +
+// ScoreMode::Slow), or the Douglas-Peucker polygon (BoxType::Poly, db_bitmap.rs:37-47)
+enum CandKind { kCandFast = 0, kCandSlow = 1, kCandPoly = 2 };
 
-// a9: one contour -> mini box candidate (false when rejected)
-bool contour_candidate(const host::Contour& c, Candidate& cd, bool keep_contour = false) {
+// a9: one contour -> candidate (false when rejected)
+bool contour_candidate(const host::Contour& c, Candidate& cd, int keep_contour = kCandFast) {
+    if (keep_contour == kCandPoly) {   // polygons_from_bitmap: >= 4 border points, approx_poly_dp(0.002 * perimeter), >= 4 vertices
+        if (c.pts.size() < 4) return false;
+        const float epsilon = 0.002f * host::perimeter(c.pts);
+        cd.contour = host::approx_poly_dp(c.pts, epsilon);
+        return cd.contour.size() >= 4;
+    }
     std::vector<host::Pt> simp = host::simplify_chain(c.pts);
     host::Pt mb[4];
     float min_side = 0.f;
@@ -262,7 +271,7 @@ bool contour_candidate(const host::Contour& c, Candidate& cd, bool keep_contour 
     return true;
 }
 
-void page_candidates(const uint8_t* mask, int H, int W, uint32_t max_candidates, std::vector<Candidate>& out, bool keep_contour = false) {
+void page_candidates(const uint8_t* mask, int H, int W, uint32_t max_candidates, std::vector<Candidate>& out, int keep_contour = kCandFast) {
     out.clear();
     std::vector<host::Contour> cs = host::find_contours(mask, W, H, max_candidates);
     for (auto& c : cs) {
@@ -273,7 +282,7 @@ void page_candidates(const uint8_t* mask, int H, int W, uint32_t max_candidates,
 
 // stage 2 of a sub-batch: per-contour geometry (simplify -> hull -> min-area rect -> mini box) spread over the pool in chunks of
 // 8 contours; discovery order is preserved
-void contours_to_candidates(ThreadPool& pool, std::vector<std::vector<host::Contour>>& cs, int nb, std::vector<Candidate>* out, bool keep_contour) {
+void contours_to_candidates(ThreadPool& pool, std::vector<std::vector<host::Contour>>& cs, int nb, std::vector<Candidate>* out, int keep_contour) {
     struct Chunk { int page; size_t c0, c1; };
     std::vector<Chunk> chunks;
     const size_t step = 8;
@@ -296,7 +305,7 @@ void contours_to_candidates(ThreadPool& pool, std::vector<std::vector<host::Cont
 // per-contour geometry is then spread over the whole pool; discovery order is preserved.
 // `masks`: nb bit planes of H rows x ceil(W / 8) bytes (pp::pack_mask_bits), hw = bytes per plane
 void subbatch_candidates(ThreadPool& pool, const uint8_t* masks, size_t hw, int H, int W, int nb, uint32_t max_candidates,
-                         std::vector<Candidate>* out /* [nb] */, bool keep_contour = false) {
+                         std::vector<Candidate>* out /* [nb] */, int keep_contour = kCandFast) {
     const int row_bytes = (W + 7) / 8;
     // stage 1: contour tracing, parallel over (page, row band) -- bands are cut at fully-blank rows
     struct Band { int page, y0, y1; };
@@ -378,7 +387,7 @@ void merge_traced_page(std::vector<std::pair<uint32_t, host::Contour>>& items, s
 // which `fetch_mask` brings over on demand.
 void subbatch_candidates_traced(ThreadPool& pool, const uint32_t* ctrl, const pp::SegRec* table, uint32_t table_cap, const uint32_t* packed, int H, int W, int nb,
                                 uint32_t max_candidates, const std::function<const uint8_t*(int)>& fetch_mask, std::vector<Candidate>* out /* [nb] */,
-                                bool keep_contour = false) {
+                                int keep_contour = kCandFast) {
     std::vector<std::vector<host::Contour>> cs(nb);
     const uint32_t n_rec = ctrl[pp::kTraceCtlSegments];
     int fallbacks = 0;
@@ -436,6 +445,33 @@ void finish_boxes(const std::vector<Candidate>& cands, const float* scores, int 
             y = y < 0.0f ? 0.0f : (y > dhf ? dhf : y);
             out.pts.push_back(x); out.pts.push_back(y);
         }
+        out.scores.push_back(score);
+    }
+}
+
+// BoxType::Poly tail of polygons_from_bitmap (db_bitmap.rs:49-78): score gate -> unclip -> min side of the unclipped polygon's
+// mini box -> every vertex scaled, rounded and clamped
+void finish_polys(const std::vector<Candidate>& cands, const float* scores, int H, int W, uint32_t src_w, uint32_t src_h, float box_thresh,
+                  float unclip_ratio, DetBoxes& out) {
+    out.pts.clear(); out.scores.clear(); out.counts.clear();
+    const float wscale = (float)src_w / (float)W, hscale = (float)src_h / (float)H;
+    const float dwf = (float)src_w, dhf = (float)src_h;
+    for (size_t i = 0; i < cands.size(); ++i) {
+        const float score = scores[i];
+        if (score < box_thresh) continue;
+        std::vector<host::Pt> un = host::unclip_poly(cands[i].contour, unclip_ratio);
+        if (un.empty()) continue;
+        host::Pt bp[4];
+        float sside = 0.f;
+        if (!host::mini_box(un, bp, sside)) continue;
+        if (sside < 3.0f + 2.0f) continue;
+        for (const host::Pt& p : un) {
+            float x = std::round(p.x * wscale), y = std::round(p.y * hscale);
+            x = x < 0.0f ? 0.0f : (x > dwf ? dwf : x);
+            y = y < 0.0f ? 0.0f : (y > dhf ? dhf : y);
+            out.pts.push_back(x); out.pts.push_back(y);
+        }
+        out.counts.push_back((uint32_t)un.size());
         out.scores.push_back(score);
     }
 }
@@ -705,7 +741,8 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
         const float* sc = sl.scores_host.as<float>();
         pool_->parallel_for(nb, [&](int k) {
             const PageRef& pg = pages[idx[b0 + k]];
-            finish_boxes(cands[b0 + k], sc + sl.base[k], H, W, pg.w, pg.h, box_thresh, unclip, out[idx[b0 + k]]);
+            if (cfg_.box_type == 1) finish_polys(cands[b0 + k], sc + sl.base[k], H, W, pg.w, pg.h, box_thresh, unclip, out[idx[b0 + k]]);
+            else finish_boxes(cands[b0 + k], sc + sl.base[k], H, W, pg.w, pg.h, box_thresh, unclip, out[idx[b0 + k]]);
         });
         tmark("host_unclip");
         if (on_ready) { on_ready(idx[b0], nb); tmark("crop_plan+warp"); }
@@ -714,7 +751,9 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
         const int b0 = sb_off[sb], nb = sb_off[sb + 1] - b0;
         OAR_HIP(hipEventSynchronize(sub_events_[sb]));
         tmark("det_gpu_wait");
-        const bool slow = cfg_.score_mode == 1;
+        // BoxType::Poly scores the approximated polygon with box_score_fast whatever score_mode says (db_bitmap.rs:49)
+        const bool poly = cfg_.box_type == 1;
+        const int slow = poly ? kCandPoly : cfg_.score_mode == 1 ? kCandSlow : kCandFast;
         if (gpu_contours) {
             const uint8_t* traced_dev = (cfg_.use_dilation ? mask_dil_.as<uint8_t>() : mask_dev_.as<uint8_t>()) + (size_t)b0 * hw;
             auto fetch_mask = [&](int k) -> const uint8_t* {   // rare: a band the kernel could not hold in LDS
@@ -735,7 +774,7 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
         size_t total = 0;
         for (int k = 0; k < nb; ++k) { sl.base[k] = total; total += cands[b0 + k].size(); }
         sl.base[nb] = total; sl.total = total;
-        if (total && slow) {   // ScoreMode::Slow: the contour is the polygon (db_score.rs:139-181)
+        if (total && slow) {   // ScoreMode::Slow: the contour is the polygon (db_score.rs:139-181); BoxType::Poly: its approximation
             size_t npts = 0;
             for (int k = 0; k < nb; ++k) for (auto& cd : cands[b0 + k]) npts += cd.contour.size();
             sl.poly_pts_host.reserve(npts * 8 + 8); sl.poly_desc_host.reserve(total * sizeof(pp::PolyDesc)); sl.scores_host.reserve(total * sizeof(float));
@@ -747,7 +786,7 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
                 for (auto& cd : cands[b0 + k]) {
                     pdesc[q++] = pp::PolyDesc{(int32_t)at, (int32_t)cd.contour.size(), b0 + k, 0};
                     for (auto& p : cd.contour) { pp_[at * 2] = p.x; pp_[at * 2 + 1] = p.y; ++at; }
-                    std::vector<host::Pt>().swap(cd.contour);
+                    if (!poly) std::vector<host::Pt>().swap(cd.contour);   // the polygon itself is unclipped later
                 }
             OAR_HIP(hipMemcpyAsync(sl.poly_pts_dev.p, pp_, npts * 8, hipMemcpyHostToDevice, score_stream_));
             OAR_HIP(hipMemcpyAsync(sl.poly_desc_dev.p, pdesc, total * sizeof(pp::PolyDesc), hipMemcpyHostToDevice, score_stream_));
@@ -816,7 +855,7 @@ std::vector<host::Contour> Detector::trace_device_mask(const uint8_t* d_mask, in
 }
 
 void Detector::postprocess_host(const float* pred, int H, int W, uint32_t src_w, uint32_t src_h, float thresh, float box_thresh,
-                                float unclip, uint32_t max_candidates, DetBoxes& out, int score_mode, int use_dilation) {
+                                float unclip, uint32_t max_candidates, DetBoxes& out, int score_mode, int use_dilation, int box_type) {
     // Stand-alone DB post-processing on a host probability map (parity hook for a7..a12): same kernels, tiny batch.
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) fail(OAR_DEVICE, "no HIP device visible: libOarMi355x has no CPU fallback");
@@ -828,15 +867,16 @@ void Detector::postprocess_host(const float* pred, int H, int W, uint32_t src_w,
     const uint8_t* traced = dmask.as<uint8_t>();
     if (use_dilation) { dmask2.reserve(hw); pp::dilate3x3(nullptr, traced, dmask2.as<uint8_t>(), 1, H, W); traced = dmask2.as<uint8_t>(); }
     std::vector<Candidate> cands;
+    const int kind = box_type == 1 ? kCandPoly : score_mode == 1 ? kCandSlow : kCandFast;
     {
         std::vector<host::Contour> cs = Detector::trace_device_mask(traced, H, W, max_candidates ? max_candidates : 1000);
         for (auto& c : cs) {
             Candidate cd;
-            if (contour_candidate(c, cd, score_mode == 1)) cands.push_back(std::move(cd));
+            if (contour_candidate(c, cd, kind)) cands.push_back(std::move(cd));
         }
     }
     std::vector<float> scores(cands.size(), 0.f);
-    if (!cands.empty() && score_mode == 1) {
+    if (!cands.empty() && kind != kCandFast) {
         std::vector<float> pts;
         std::vector<pp::PolyDesc> pd;
         for (auto& c : cands) {
@@ -856,7 +896,8 @@ void Detector::postprocess_host(const float* pred, int H, int W, uint32_t src_w,
         pp::box_scores(nullptr, dpred.as<float>(), H, W, dboxes.as<pp::ScoreBox>(), (int)sb.size(), dscores.as<float>());
         OAR_HIP(hipMemcpy(scores.data(), dscores.p, sb.size() * 4, hipMemcpyDeviceToHost));
     }
-    finish_boxes(cands, scores.data(), H, W, src_w, src_h, box_thresh, unclip, out);
+    if (box_type == 1) finish_polys(cands, scores.data(), H, W, src_w, src_h, box_thresh, unclip, out);
+    else finish_boxes(cands, scores.data(), H, W, src_w, src_h, box_thresh, unclip, out);
 }
 
 // ================================================================================================= recognizer
@@ -1311,13 +1352,18 @@ void Ocr::predict(const std::vector<PageRef>& pages, std::vector<std::vector<Ocr
         const PageMeta& m = meta_[i];
         if (m.rectified || m.angle < 0.0f) continue;
         const int a = (int)m.angle;
-        for (auto& r : out[i])
-            for (int k = 0; k < 4; ++k) {
-                const float x = r.pts[2 * k], y = r.pts[2 * k + 1];
-                if (a == 90) { r.pts[2 * k] = (float)m.rotated_h - y; r.pts[2 * k + 1] = x; }
-                else if (a == 180) { r.pts[2 * k] = (float)m.rotated_w - x; r.pts[2 * k + 1] = (float)m.rotated_h - y; }
-                else if (a == 270) { r.pts[2 * k] = y; r.pts[2 * k + 1] = (float)m.rotated_w - x; }
+        auto back = [&](float* q, size_t npts) {
+            for (size_t k = 0; k < npts; ++k) {
+                const float x = q[2 * k], y = q[2 * k + 1];
+                if (a == 90) { q[2 * k] = (float)m.rotated_h - y; q[2 * k + 1] = x; }
+                else if (a == 180) { q[2 * k] = (float)m.rotated_w - x; q[2 * k + 1] = (float)m.rotated_h - y; }
+                else if (a == 270) { q[2 * k] = y; q[2 * k + 1] = (float)m.rotated_w - x; }
             }
+        };
+        for (auto& r : out[i]) {
+            back(r.pts, 4);
+            if (!r.poly.empty()) back(r.poly.data(), r.poly.size() / 2);   // every point of a polygon (geometry.rs:848-889 maps self.points)
+        }
     }
 }
 
@@ -1415,13 +1461,36 @@ void Ocr::predict_core(const std::vector<PageRef>& pages, std::vector<std::vecto
             std::vector<Planned> planned;
             for (int li = first; li < first + count; ++li) {
                 const int img = start + li;
-                std::vector<int> order = host::sort_quad_boxes(boxes[li].pts);
+                const bool poly = cfg_.det.box_type == 1;   // seal text: polygons, sort_poly_boxes (ocr.rs:699-716)
+                std::vector<uint32_t> poly_off;
+                std::vector<int> order;
+                if (poly) {
+                    poly_off.assign(boxes[li].counts.size() + 1, 0);
+                    for (size_t b = 0; b < boxes[li].counts.size(); ++b) poly_off[b + 1] = poly_off[b] + boxes[li].counts[b];
+                    order = host::sort_poly_boxes(boxes[li].pts, poly_off);
+                } else {
+                    order = host::sort_quad_boxes(boxes[li].pts);
+                }
                 per_image[img].resize(order.size());
                 for (size_t k = 0; k < order.size(); ++k) {
                     Slot& sl = per_image[img][k];
-                    std::memcpy(sl.r.pts, boxes[li].pts.data() + (size_t)order[k] * 8, sizeof sl.r.pts);
                     sl.r.det_score = boxes[li].scores[order[k]];
-                    host::CropPlan pl = host::plan_crop((int)pages[img].w, (int)pages[img].h, sl.r.pts);
+                    host::CropPlan pl;
+                    if (poly) {
+                        const float* pp_ = boxes[li].pts.data() + (size_t)poly_off[order[k]] * 2;
+                        const uint32_t np_ = boxes[li].counts[order[k]];
+                        sl.r.poly.assign(pp_, pp_ + (size_t)np_ * 2);
+                        std::memset(sl.r.pts, 0, sizeof sl.r.pts);
+                        if (np_ == 4) {   // TextCroppingProcessor::crop_single: exactly four points take the rotated crop (processors.rs:96-102)
+                            std::memcpy(sl.r.pts, pp_, sizeof sl.r.pts);
+                            pl = host::plan_crop((int)pages[img].w, (int)pages[img].h, sl.r.pts);
+                        } else {
+                            pl = host::plan_bbox_crop((int)pages[img].w, (int)pages[img].h, pp_, (int)np_);
+                        }
+                    } else {
+                        std::memcpy(sl.r.pts, boxes[li].pts.data() + (size_t)order[k] * 8, sizeof sl.r.pts);
+                        pl = host::plan_crop((int)pages[img].w, (int)pages[img].h, sl.r.pts);
+                    }
                     if (pl.mode == 0) continue;  // crop failure => region dropped (ocr.rs:736-738)
                     sl.r.crop_w = (uint32_t)pl.out_w(); sl.r.crop_h = (uint32_t)pl.out_h();
                     planned.push_back({img, (int)k, pl});

@@ -61,8 +61,9 @@ struct PageRef {              // one input page (RGB8 HWC)
 };
 
 struct DetBoxes {             // per image, discovery order
-    std::vector<float> pts;   // n*8
+    std::vector<float> pts;   // BoxType::Quad: n * 8; BoxType::Poly: 2 * sum(counts)
     std::vector<float> scores;
+    std::vector<uint32_t> counts;   // BoxType::Poly: vertices per box (empty for quads)
 };
 
 // TextDetectionAdapter + DBModel (domain/adapters/text_detection_adapter.rs:36-79, models/detection/db.rs:281-335)
@@ -90,7 +91,7 @@ class Detector {
              std::vector<const uint8_t*>* dev_pages_out = nullptr, const ReadyFn& on_ready = nullptr);
     Engine& engine() { return *eng_; }
     static void postprocess_host(const float* pred, int H, int W, uint32_t src_w, uint32_t src_h, float thresh, float box_thresh,
-                                 float unclip, uint32_t max_candidates, DetBoxes& out, int score_mode = 0, int use_dilation = 0);
+                                 float unclip, uint32_t max_candidates, DetBoxes& out, int score_mode = 0, int use_dilation = 0, int box_type = 0);
     ThreadPool& pool() { return *pool_; }
     // a8 through the GPU tracer for one device-resident mask (test hook + postprocess_host)
     static std::vector<host::Contour> trace_device_mask(const uint8_t* d_mask, int H, int W, uint32_t max_contours, bool gpu_contours = true);
@@ -213,6 +214,7 @@ class Rectifier {
 
 struct OcrRegion {
     float pts[8];
+    std::vector<float> poly;   // BoxType::Poly (seal text): the polygon's (x, y) pairs; pts then holds the box only when it has 4 points
     float det_score;
     uint32_t crop_w, crop_h, T;
     float max_wh_ratio;

@@ -13,10 +13,12 @@ from . import onnx_ref
 class OracleDetector:
     """TextDetectionAdapter::execute -> DBModel::forward (models/detection/db.rs:281-335)."""
 
-    def __init__(self, onnx_bytes, limit_side_len=960, limit_type="max", max_side_limit=4000, max_candidates=1000):
+    def __init__(self, onnx_bytes, limit_side_len=None, limit_type=None, max_side_limit=4000, max_candidates=1000, text_type=None):
         self.model = onnx_ref.parse_model(onnx_bytes)
         self.input = self.model["inputs"][0]
-        self.cfg = (limit_side_len, limit_type, max_side_limit)
+        # text type "seal": 736 / min and BoxType::Poly (text_detection_adapter.rs:131-150, preprocessing.rs:44-62)
+        self.seal = (text_type or "").lower() == "seal"
+        self.cfg = (limit_side_len or (736 if self.seal else 960), limit_type or ("min" if self.seal else "max"), max_side_limit)
         self.max_candidates = max_candidates
 
     def prob_maps(self, images):
@@ -36,7 +38,11 @@ class OracleDetector:
     def detect(self, images, thresh=0.3, box_thresh=0.6, unclip=1.5):
         res = []
         for prob, (sh, sw) in self.prob_maps(images):
-            boxes, scores = R.db_postprocess(prob, sh, sw, thresh, box_thresh, unclip, self.max_candidates)
+            if self.seal:
+                from . import poly_ref
+                boxes, scores = poly_ref.db_postprocess_poly(prob, sh, sw, thresh, box_thresh, unclip, self.max_candidates)
+            else:
+                boxes, scores = R.db_postprocess(prob, sh, sw, thresh, box_thresh, unclip, self.max_candidates)
             res.append((boxes, scores, prob))
         return res
 
@@ -136,7 +142,7 @@ class OracleOCR:
             if rotation is None:
                 continue
             for s in slots:
-                s["box"] = R.rotate_back_points(s["box"], rotation[0], rotation[1], rotation[2]).reshape(4, 2)
+                s["box"] = R.rotate_back_points(s["box"], rotation[0], rotation[1], rotation[2]).reshape(-1, 2)
         return res
 
     def _predict_core(self, images):
@@ -144,10 +150,17 @@ class OracleOCR:
         per_image = []
         pool = []
         for img_idx, (boxes, scores, _) in enumerate(dets):
-            order = R.sort_quad_boxes(boxes)
+            if self.det.seal:   # sort_detection_boxes / crop_single for polygons (ocr.rs:699-716, processors.rs:96-102)
+                from . import poly_ref
+                order = poly_ref.sort_poly_boxes(boxes)
+            else:
+                order = R.sort_quad_boxes(boxes)
             slots = []
             for k, o in enumerate(order):
-                crop = R.rotate_crop(images[img_idx], boxes[o])
+                if self.det.seal and len(boxes[o]) != 4:
+                    crop = poly_ref.crop_bounding_box(images[img_idx], boxes[o])
+                else:
+                    crop = R.rotate_crop(images[img_idx], boxes[o])
                 slots.append({"box": boxes[o].copy(), "det_score": float(scores[o]), "filled": False})
                 if crop is None:
                     continue

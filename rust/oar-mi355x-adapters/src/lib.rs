@@ -9,6 +9,7 @@
 //! | reference adapter (domain/adapters/...)                     | this crate                          | C entry points            |
 //! |--------------------------------------------------------------|-------------------------------------|---------------------------|
 //! | `text_detection_adapter.rs`  `TextDetectionAdapter`          | [`Mi355xTextDetectionAdapter`]      | `oar_det_*`               |
+//! | `seal_text_detection_adapter.rs` `SealTextDetectionAdapter`  | [`Mi355xSealTextDetectionAdapter`]  | `oar_det_*` (box_type 1)  |
 //! | `text_recognition_adapter.rs` `TextRecognitionAdapter`       | [`Mi355xTextRecognitionAdapter`]    | `oar_rec_*`, `oar_ctc_*`  |
 //! | `document_orientation_adapter.rs`                            | [`Mi355xDocumentOrientationAdapter`]| `oar_cls_*`               |
 //! | `text_line_orientation_adapter.rs`                           | [`Mi355xTextLineOrientationAdapter`]| `oar_cls_*`               |
@@ -25,6 +26,7 @@ pub mod infer;
 pub mod orientation;
 pub mod pipeline;
 pub mod rectification;
+pub mod seal_text_detection;
 pub mod text_detection;
 pub mod text_recognition;
 
@@ -36,6 +38,7 @@ pub use orientation::{
 };
 pub use pipeline::{Mi355xOcr, Mi355xOcrBuilder, Mi355xOcrPage, Mi355xOcrRegion};
 pub use rectification::{Mi355xRectifierAdapter, Mi355xRectifierAdapterBuilder};
+pub use seal_text_detection::{Mi355xSealTextDetectionAdapter, Mi355xSealTextDetectionAdapterBuilder};
 pub use text_detection::{Mi355xTextDetectionAdapter, Mi355xTextDetectionAdapterBuilder};
 pub use text_recognition::{Mi355xTextRecognitionAdapter, Mi355xTextRecognitionAdapterBuilder};
 

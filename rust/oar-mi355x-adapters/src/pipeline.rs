@@ -3,7 +3,7 @@
 //!
 //! Going through the four adapters reproduces the reference pipeline stage by stage, with every stage's result
 //! crossing PCIe.  `Mi355xOcr` instead keeps everything between the u8 pages and the per-region (box, CTC indices)
-//! in HBM: detect -> `sort_quad_boxes` -> rotate-crop -> width-ratio pooled recognition batches -> CTC argmax
+//! in HBM: detect -> `sort_quad_boxes` (`sort_poly_boxes` for seal text) -> rotate-crop -> width-ratio pooled recognition batches -> CTC argmax
 //! (`oar_ocr_predict`), then the collapse / text assembly on the host (`oar_ocr_decode`).  Optional stages attach
 //! exactly like the builder methods of the reference (`with_document_image_orientation_classification`,
 //! `with_document_image_rectification`, `with_text_line_orientation_classification`).
@@ -85,6 +85,8 @@ pub struct Mi355xOcrBuilder {
     region_batch_size: u32,
     limit_side_len: u32,
     device_id: i32,
+    text_type: Option<String>,
+    explicit_det_thresholds: bool,
 }
 
 impl Mi355xOcrBuilder {
@@ -106,7 +108,16 @@ impl Mi355xOcrBuilder {
             region_batch_size: 0,
             limit_side_len: 0,
             device_id: 0,
+            text_type: None,
+            explicit_det_thresholds: false,
         }
+    }
+
+    /// `OAROCRBuilder::text_type` (ocr.rs:218-229): `"seal"` = curved text -- 736 / min preprocessing, polygon boxes
+    /// (`BoxType::Poly`), `sort_poly_boxes`, bounding-rectangle crops, and 0.2 / 0.6 / 0.5 as detection defaults.
+    pub fn text_type(mut self, text_type: impl Into<String>) -> Self {
+        self.text_type = Some(text_type.into());
+        self
     }
 
     pub fn with_document_image_orientation_classification(mut self, model: impl Into<ModelSource>) -> Self {
@@ -125,16 +136,19 @@ impl Mi355xOcrBuilder {
     }
 
     pub fn text_det_threshold(mut self, v: f32) -> Self {
+        self.explicit_det_thresholds = true;
         self.det_thresh = v;
         self
     }
 
     pub fn text_det_box_threshold(mut self, v: f32) -> Self {
+        self.explicit_det_thresholds = true;
         self.det_box_thresh = v;
         self
     }
 
     pub fn text_det_unclip_ratio(mut self, v: f32) -> Self {
+        self.explicit_det_thresholds = true;
         self.det_unclip_ratio = v;
         self
     }
@@ -166,16 +180,28 @@ impl Mi355xOcrBuilder {
 
     pub fn build(self) -> Result<Mi355xOcr, OCRError> {
         let dict = DictHandle::new(Some(&self.character_dict))?;
+        // the adapter decides by the lower-cased text type (text_detection_adapter.rs:131-136); the default thresholds by the exact
+        // string (ocr.rs:322-352)
+        let is_seal_text = self.text_type.as_ref().map(|t| t.to_lowercase() == "seal").unwrap_or(false);
+        let (det_thresh, det_box_thresh, det_unclip_ratio) = if self.explicit_det_thresholds {
+            (self.det_thresh, self.det_box_thresh, self.det_unclip_ratio)
+        } else {
+            match self.text_type.as_deref().unwrap_or("general") {
+                "table" => (0.3, 0.4, 2.0),
+                "seal" => (0.2, 0.6, 0.5),
+                _ => (0.3, 0.6, 2.0),
+            }
+        };
         let det_cfg = sys::oar_det_cfg {
             device_id: self.device_id,
-            limit_side_len: self.limit_side_len, // 0 => 960
-            limit_type: 0,
+            limit_side_len: if self.limit_side_len == 0 && is_seal_text { 736 } else { self.limit_side_len }, // 0 => 960
+            limit_type: if is_seal_text { 1 } else { 0 },
             max_side_limit: 0,
             max_candidates: 0,
             use_hip_graph: 0,
             profile: 0,
             host_threads: 0,
-            box_type: 0,
+            box_type: if is_seal_text { 1 } else { 0 },
             score_mode: 0,
             use_dilation: 0,
             gpu_contours: 0,
@@ -191,9 +217,9 @@ impl Mi355xOcrBuilder {
         let cfg = sys::oar_ocr_cfg {
             det: det_cfg,
             rec: rec_cfg,
-            det_thresh: self.det_thresh,
-            det_box_thresh: self.det_box_thresh,
-            det_unclip_ratio: self.det_unclip_ratio,
+            det_thresh,
+            det_box_thresh,
+            det_unclip_ratio,
             image_batch_size: self.image_batch_size,
             region_batch_size: self.region_batch_size,
             max_pooled_crops: 0,
@@ -311,16 +337,19 @@ impl Mi355xOcr {
         let r = &res.0;
         let (n, nr) = (r.n_images as usize, r.n_regions as usize);
         // SAFETY: lengths as documented for oar_ocr_result.
-        let (offsets, points, det_scores, crop_wh, max_wh, page_angle, page_rect, line_angle) = unsafe {
+        let n_points = r.n_points as usize;
+        let (offsets, points, det_scores, crop_wh, max_wh, page_angle, page_rect, line_angle, point_offsets) = unsafe {
             (
                 slice_or_empty(r.region_offsets, n + 1),
-                slice_or_empty(r.points, nr * 8),
+                slice_or_empty(r.points, n_points * 2),
                 slice_or_empty(r.det_scores, nr),
                 slice_or_empty(r.crop_wh, nr * 2),
                 slice_or_empty(r.max_wh_ratio, nr),
                 slice_or_empty(r.page_angle, n),
                 slice_or_empty(r.page_rectified, n),
                 slice_or_empty(r.line_angle, nr),
+                // seal text: region k owns points [point_offsets[k], point_offsets[k + 1]); quads: the 4 points at k * 4
+                if r.point_offsets.is_null() { None } else { Some(slice_or_empty(r.point_offsets, nr + 1)) },
             )
         };
         let mut pages = Vec::with_capacity(n);
@@ -328,13 +357,11 @@ impl Mi355xOcr {
             let (lo, hi) = (offsets[i] as usize, offsets[i + 1] as usize);
             let mut regions = Vec::with_capacity(hi - lo);
             for k in lo..hi {
-                let p = &points[k * 8..k * 8 + 8];
-                let bbox = BoundingBox::new(vec![
-                    Point::new(p[0], p[1]),
-                    Point::new(p[2], p[3]),
-                    Point::new(p[4], p[5]),
-                    Point::new(p[6], p[7]),
-                ]);
+                let (p0, p1) = match point_offsets {
+                    Some(po) => (po[k] as usize, po[k + 1] as usize),
+                    None => (k * 4, k * 4 + 4),
+                };
+                let bbox = BoundingBox::new((p0..p1).map(|q| Point::new(points[q * 2], points[q * 2 + 1])).collect());
                 let region = TextRegion {
                     bounding_box: bbox.clone(),
                     dt_poly: Some(bbox.clone()),

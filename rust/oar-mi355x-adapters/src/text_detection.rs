@@ -20,7 +20,7 @@ use std::ptr::NonNull;
 
 /// Owning handle of an `oar_det`.
 #[derive(Debug)]
-struct DetHandle(NonNull<sys::oar_det>);
+pub(crate) struct DetHandle(pub(crate) NonNull<sys::oar_det>);
 
 // SAFETY: the library documents that a handle may be used from any thread and that calls on one handle serialise on an
 // internal mutex (include/oar_mi355x.h, "Conventions"), which is what `ModelAdapter: Send + Sync` needs.
@@ -52,6 +52,87 @@ pub struct Mi355xTextDetectionAdapter {
     config: TextDetectionConfig,
 }
 
+/// One `oar_det_run` call -> `Vec<Vec<Detection>>`, shared by the text and the seal text adapters.
+///
+/// Quad boxes come back as 4 points; with `box_type = 1` (BoxType::Poly) `point_offsets` delimits polygons of any size, exactly
+/// the `BoundingBox::points` `polygons_from_bitmap` builds (processors/db_bitmap.rs:66-78).
+pub(crate) fn run_detection(
+    handle: *mut sys::oar_det,
+    images: &[&image::RgbImage],
+    score_threshold: f32,
+    box_threshold: f32,
+    unclip_ratio: f32,
+    adapter_name: &'static str,
+) -> Result<Vec<Vec<Detection>>, OCRError> {
+    let batch = ImageBatch::new(images.iter().copied());
+    if batch.is_empty() {
+        return Ok(Vec::new());
+    }
+    let mut result = DetResultGuard(sys::oar_det_result {
+        n_images: 0,
+        n_boxes: 0,
+        box_offsets: std::ptr::null_mut(),
+        points: std::ptr::null_mut(),
+        scores: std::ptr::null_mut(),
+        n_points: 0,
+        point_offsets: std::ptr::null_mut(),
+    });
+    // SAFETY: the three arrays hold batch.len() entries; every image pointer is valid for width * height * 3 bytes while
+    // `images` is alive; `result` is a valid out-parameter.
+    let status = unsafe {
+        sys::oar_det_run(
+            handle,
+            batch.ptrs.as_ptr(),
+            batch.widths.as_ptr(),
+            batch.heights.as_ptr(),
+            batch.len() as u32,
+            score_threshold,
+            box_threshold,
+            unclip_ratio,
+            &mut result.0,
+        )
+    };
+    check(status).map_err(|e| {
+        e.into_adapter_error(
+            adapter_name,
+            format!(
+                "failed to detect text (score_threshold={score_threshold}, box_threshold={box_threshold}, unclip_ratio={unclip_ratio})"
+            ),
+        )
+    })?;
+
+    // CSR -> Vec<Vec<Detection>>: image i owns boxes [box_offsets[i], box_offsets[i + 1]); box b owns points
+    // [point_offsets[b], point_offsets[b + 1]) when point_offsets is there, else the 4 points at b * 4
+    let r = &result.0;
+    let n_images = r.n_images as usize;
+    let n_boxes = r.n_boxes as usize;
+    let n_points = r.n_points as usize;
+    // SAFETY: array lengths are the ones the header documents for oar_det_result.
+    let (offsets, points, scores, point_offsets) = unsafe {
+        (
+            slice_or_empty(r.box_offsets, n_images + 1),
+            slice_or_empty(r.points, n_points * 2),
+            slice_or_empty(r.scores, n_boxes),
+            if r.point_offsets.is_null() { None } else { Some(slice_or_empty(r.point_offsets, n_boxes + 1)) },
+        )
+    };
+    let mut detections = Vec::with_capacity(n_images);
+    for i in 0..n_images {
+        let (lo, hi) = (offsets[i] as usize, offsets[i + 1] as usize);
+        let mut per_image = Vec::with_capacity(hi - lo);
+        for b in lo..hi {
+            let (p0, p1) = match point_offsets {
+                Some(po) => (po[b] as usize, po[b + 1] as usize),
+                None => (b * 4, b * 4 + 4),
+            };
+            let pts = (p0..p1).map(|k| Point::new(points[k * 2], points[k * 2 + 1])).collect();
+            per_image.push(Detection::new(BoundingBox::new(pts), scores[b]));
+        }
+        detections.push(per_image);
+    }
+    Ok(detections)
+}
+
 impl ModelAdapter for Mi355xTextDetectionAdapter {
     type Task = TextDetectionTask;
 
@@ -65,71 +146,15 @@ impl ModelAdapter for Mi355xTextDetectionAdapter {
         config: Option<&<Self::Task as Task>::Config>,
     ) -> Result<<Self::Task as Task>::Output, OCRError> {
         let effective_config = config.unwrap_or(&self.config);
-        let batch = ImageBatch::new(input.images.iter().map(AsRef::as_ref));
-        if batch.is_empty() {
-            return Ok(TextDetectionOutput { detections: Vec::new() });
-        }
-
-        let mut result = DetResultGuard(sys::oar_det_result {
-            n_images: 0,
-            n_boxes: 0,
-            box_offsets: std::ptr::null_mut(),
-            points: std::ptr::null_mut(),
-            scores: std::ptr::null_mut(),
-        });
-        // SAFETY: the three arrays hold batch.len() entries; every image pointer is valid for width * height * 3 bytes
-        // while `input` is alive; `result` is a valid out-parameter.
-        let status = unsafe {
-            sys::oar_det_run(
-                self.handle.0.as_ptr(),
-                batch.ptrs.as_ptr(),
-                batch.widths.as_ptr(),
-                batch.heights.as_ptr(),
-                batch.len() as u32,
-                effective_config.score_threshold,
-                effective_config.box_threshold,
-                effective_config.unclip_ratio,
-                &mut result.0,
-            )
-        };
-        check(status).map_err(|e| {
-            e.into_adapter_error(
-                "TextDetectionAdapter",
-                format!(
-                    "failed to detect text (score_threshold={}, box_threshold={}, unclip_ratio={})",
-                    effective_config.score_threshold, effective_config.box_threshold, effective_config.unclip_ratio
-                ),
-            )
-        })?;
-
-        // CSR -> Vec<Vec<Detection>>: image i owns boxes [box_offsets[i], box_offsets[i + 1])
-        let r = &result.0;
-        let n_images = r.n_images as usize;
-        let n_boxes = r.n_boxes as usize;
-        // SAFETY: array lengths are the ones the header documents for oar_det_result.
-        let (offsets, points, scores) = unsafe {
-            (
-                slice_or_empty(r.box_offsets, n_images + 1),
-                slice_or_empty(r.points, n_boxes * 8),
-                slice_or_empty(r.scores, n_boxes),
-            )
-        };
-        let mut detections = Vec::with_capacity(n_images);
-        for i in 0..n_images {
-            let (lo, hi) = (offsets[i] as usize, offsets[i + 1] as usize);
-            let mut per_image = Vec::with_capacity(hi - lo);
-            for b in lo..hi {
-                let p = &points[b * 8..b * 8 + 8];
-                let bbox = BoundingBox::new(vec![
-                    Point::new(p[0], p[1]),
-                    Point::new(p[2], p[3]),
-                    Point::new(p[4], p[5]),
-                    Point::new(p[6], p[7]),
-                ]);
-                per_image.push(Detection::new(bbox, scores[b]));
-            }
-            detections.push(per_image);
-        }
+        let images: Vec<&image::RgbImage> = input.images.iter().map(AsRef::as_ref).collect();
+        let detections = run_detection(
+            self.handle.0.as_ptr(),
+            &images,
+            effective_config.score_threshold,
+            effective_config.box_threshold,
+            effective_config.unclip_ratio,
+            "TextDetectionAdapter",
+        )?;
         Ok(TextDetectionOutput { detections })
     }
 
@@ -246,8 +271,7 @@ impl AdapterBuilder for Mi355xTextDetectionAdapterBuilder {
             use_hip_graph: 0,
             profile: 0,
             host_threads: self.host_threads,
-            // BoxType::Poly for seal text (text_detection_adapter.rs:144-148): the library reports OAR_UNSUPPORTED_OP for it
-            // today, which surfaces as a model-load error below instead of silently returning quads.
+            // BoxType::Poly for seal text (text_detection_adapter.rs:144-148): polygons come back through point_offsets
             box_type: if is_seal_text { 1 } else { 0 },
             score_mode: 0,   // ScoreMode::Fast  (text_detection_adapter.rs:155)
             use_dilation: 0, // use_dilation: false (text_detection_adapter.rs:154)

@@ -134,6 +134,8 @@ pub struct oar_det_result {
     pub box_offsets: *mut u32,
     pub points: *mut f32,
     pub scores: *mut f32,
+    pub n_points: u32,
+    pub point_offsets: *mut u32,
 }
 
 #[repr(C)]
@@ -202,6 +204,8 @@ pub struct oar_ocr_result {
     pub page_angle: *mut f32,
     pub page_rectified: *mut u8,
     pub line_angle: *mut f32,
+    pub n_points: u32,
+    pub point_offsets: *mut u32,
 }
 
 #[repr(C)]
@@ -314,6 +318,12 @@ unsafe extern "C" {
     pub fn oar_host_contours_bits(mask: *const u8, width: u32, height: u32, max_contours: u32, max_bands: i32, offsets: *mut i64, pts_xy: *mut i32, types: *mut i32, cap_points: i64) -> i32;
     /// fixed-length arrays: box8: [f32; 8]
     pub fn oar_host_unclip(box8: *const f32, ratio: f32, out_xy: *mut f32, cap_points: i32) -> i32;
+    pub fn oar_host_approx_poly_dp(xy: *const f32, n_points: i32, epsilon: f32, out_xy: *mut f32, cap_points: i32) -> i32;
+    pub fn oar_host_perimeter(xy: *const f32, n_points: i32) -> f32;
+    pub fn oar_host_unclip_poly(xy: *const f32, n_points: i32, ratio: f32, out_xy: *mut f32, cap_points: i32) -> i32;
+    pub fn oar_host_offset_ring(xy: *const i64, n_points: i32, radius: f64, out_xy: *mut i64, cap_points: i32) -> i32;
+    pub fn oar_host_ring_outline(xy: *const i64, n_points: i32, negative: i32, out_xy: *mut i64, cap_points: i32) -> i32;
+    pub fn oar_host_sort_poly_boxes(pts_xy: *const f32, offsets: *const u32, n: i32, order: *mut i32);
     /// fixed-length arrays: box8: [f32; 8]
     pub fn oar_host_mini_box(xy: *const f32, n_points: i32, box8: *mut f32, min_side: *mut f32) -> i32;
     pub fn oar_host_sort_quad_boxes(boxes8: *const f32, n: i32, order: *mut i32);
