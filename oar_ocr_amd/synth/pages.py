@@ -73,6 +73,44 @@ def make_page(seed: int, size=(960, 960), lines: int = 40, rotated_fraction: flo
     return page
 
 
+def make_seal_page(seed: int, size=(640, 640), arcs: int = 3, straight: int = 1) -> np.ndarray:
+    """A stamp-like page for the seal / polygon branch: `arcs` curved text bands on concentric circles (glyph cells
+    laid out along the arc, so the detector's blob is a bent band whose contour approximates to a concave polygon) and `straight`
+    ordinary lines through the middle.  Returns [H,W,3] u8; deterministic per (seed, size, arcs, straight)."""
+    H, W = size
+    rng = np.random.default_rng(seed)
+    page = np.full((H, W, 3), 255, np.uint8)
+    cx, cy = W / 2.0 + float(rng.uniform(-8, 8)), H / 2.0 + float(rng.uniform(-8, 8))
+    ys, xs = np.mgrid[0:H, 0:W]
+    rr = np.hypot(xs - cx, ys - cy)
+    th = np.arctan2(ys - cy, xs - cx)
+    r_out = min(H, W) / 2.0 - 28.0
+    for a in range(arcs):
+        band = float(rng.integers(20, 30))
+        r1 = r_out - a * (band + 26.0)
+        r0 = r1 - band
+        if r0 < 40:
+            break
+        t0 = float(rng.uniform(-np.pi, np.pi))
+        span = float(rng.uniform(1.6, 3.6))                      # radians of arc covered by the band
+        rel = np.mod(th - t0, 2 * np.pi)
+        inside = (rr >= r0) & (rr < r1) & (rel < span)
+        rm = 0.5 * (r0 + r1)
+        s_along = rel * rm                                       # arc length along the band's mid circle
+        cell = float(rng.integers(14, 24))
+        gap = 3.0
+        in_cell = np.mod(s_along, cell + gap) < cell
+        ink = (20 + 40 * ((np.floor(s_along / (cell + gap)).astype(np.int64) * 2654435761 + seed) % 7) / 7.0).astype(np.uint8)
+        m = inside & in_cell
+        page[m] = ink[m][:, None]
+    for k in range(straight):
+        h = int(rng.integers(18, 28))
+        w = int(min(W * 0.45, 2 * (r_out - arcs * 52.0) - 20)) if arcs else int(W * 0.5)
+        if w >= 60:
+            _draw_line(page, rng, int(cx - w / 2), int(cy - h / 2 + k * (h + 14)), w, h, 0.0)
+    return page
+
+
 def make_pages(n: int, size=(960, 960), lines: int = 40, seed0: int = 0):
     return [make_page(seed0 + i, size, lines) for i in range(n)]
 

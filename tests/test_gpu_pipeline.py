@@ -184,13 +184,6 @@ def test_db_postprocess_options_match_oracle(nets, score_mode, use_dilation):
         assert np.allclose([d.score for d in g], rs, atol=1e-3)
 
 
-def test_poly_box_type_is_reported_as_unsupported(nets):
-    det, _, _ = nets
-    with pytest.raises(api.OCRError) as e:
-        api.TextDetectionPredictor(det, api.TextDetectionConfig(box_type="poly"))
-    assert e.value.code == api.OAR_UNSUPPORTED_OP
-
-
 def test_failed_batched_detection_falls_back_to_per_image(nets):
     """src/oarocr/ocr.rs:576-588: when the batched detection of a chunk fails, the reference redoes the chunk image by
     image and carries on; oar_ocr_predict does the same inside the call.  The result equals an undisturbed run; a page that

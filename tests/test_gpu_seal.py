@@ -1,0 +1,106 @@
+"""SURVEY 8f-2 on the GPU: seal / curved text detection (BoxType::Poly) against the oracle.
+
+  polygons_from_bitmap (db_bitmap.rs:16-82) on the same probability map: polygons and scores bit-exact
+  SealTextDetectionAdapter (seal_text_detection_adapter.rs) end to end: 736 / min resize, network, polygons
+  OAROCR::predict with text_type "seal" (ocr.rs:699-716, processors.rs:96-102): sort_poly_boxes, bounding-rectangle crops,
+  recognition -- boxes bit-exact, CTC probabilities <= 1e-3
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oar_ocr_amd import api
+from oar_ocr_amd.synth import models, pages
+from oracle import pipeline_ref, poly_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nets():
+    det, _ = models.build_det("tiny", seed=0)
+    rec, _ = models.build_rec("tiny", vocab=6906, seed=1)
+    chars = api.read_dict(models.synth_dict(6904))
+    return det, rec, chars
+
+
+def _same_polys(got, ref_polys, ref_scores, exact=True):
+    assert len(got) == len(ref_polys)
+    for d, rp, rs in zip(got, ref_polys, ref_scores):
+        if exact:
+            assert d.bbox.shape == rp.shape and np.array_equal(d.bbox, rp)
+        assert abs(d.score - rs) <= (0.0 if exact else 1e-3)
+
+
+def test_polygons_from_bitmap_bit_exact_on_same_prob_map(nets):
+    det, _, _ = nets
+    od = pipeline_ref.OracleDetector(det, text_type="seal")
+    n_concave = 0
+    for seed, size in [(1, (480, 480)), (2, (400, 520)), (3, (520, 440))]:
+        (prob, (sh, sw)), = od.prob_maps([pages.make_seal_page(seed, size)])
+        for thresh, bt, un in [(0.2, 0.6, 0.5), (0.3, 0.5, 1.5)]:
+            rp, rs = poly_ref.db_postprocess_poly(prob, sh, sw, thresh, bt, un)
+            got = api.db_postprocess(prob, sw, sh, thresh, bt, un, box_type="poly")
+            assert len(rp) >= 2
+            _same_polys(got, rp, rs)
+            n_concave += sum(len(p) > 60 for p in rp)
+    assert n_concave >= 6      # the curved bands really came out as many-vertex polygons
+
+
+def test_polygon_branch_ignores_score_mode_and_honours_dilation(nets):
+    """polygons_from_bitmap always scores the approximated polygon with box_score_fast (db_bitmap.rs:49); use_dilation changes the
+    traced mask (db_postprocess.rs:163-168)."""
+    det, _, _ = nets
+    od = pipeline_ref.OracleDetector(det, text_type="seal")
+    (prob, (sh, sw)), = od.prob_maps([pages.make_seal_page(4, (480, 480))])
+    base = api.db_postprocess(prob, sw, sh, 0.2, 0.6, 0.5, box_type="poly")
+    slow = api.db_postprocess(prob, sw, sh, 0.2, 0.6, 0.5, box_type="poly", score_mode="slow")
+    assert len(base) == len(slow) and all(np.array_equal(a.bbox, b.bbox) and a.score == b.score for a, b in zip(base, slow))
+    rp, rs = poly_ref.db_postprocess_poly(prob, sh, sw, 0.2, 0.6, 0.5, use_dilation=True)
+    _same_polys(api.db_postprocess(prob, sw, sh, 0.2, 0.6, 0.5, box_type="poly", use_dilation=True), rp, rs)
+
+
+def test_seal_detection_adapter_matches_oracle(nets):
+    det, _, _ = nets
+    imgs = [pages.make_seal_page(11, (480, 480)), pages.make_seal_page(12, (400, 520), arcs=2), pages.make_seal_page(13, (480, 480), arcs=3, straight=2)]
+    pred = api.SealTextDetectionPredictor(det)
+    got = pred.predict(imgs)
+    ref = pipeline_ref.OracleDetector(det, text_type="seal").detect(imgs, 0.2, 0.6, 0.5)
+    total = 0
+    for g, (rp, rs, prob) in zip(got, ref):
+        marginal = int((np.abs(prob - 0.2) < 1e-4).sum())
+        _same_polys(g, rp, rs, exact=False)
+        if marginal == 0:
+            for d, p in zip(g, rp):
+                assert d.bbox.shape == p.shape and np.array_equal(d.bbox, p)
+        total += len(rp)
+    assert total >= 8
+    # the general-text predictor with text_type "seal" is the same thing (text_detection_adapter.rs:131-150)
+    alt = api.TextDetectionPredictor(det, api.TextDetectionConfig(0.2, 0.6, 0.5), text_type="seal").predict(imgs[:1])
+    assert len(alt[0]) == len(got[0]) and all(np.array_equal(a.bbox, b.bbox) for a, b in zip(alt[0], got[0]))
+
+
+def test_seal_ocr_pipeline_matches_oracle(nets):
+    det, rec, chars = nets
+    imgs = [pages.make_seal_page(21, (480, 480)), pages.make_seal_page(22, (440, 520), arcs=2, straight=2)]
+    ocr = api.OAROCRBuilder(det, rec, chars).text_type("seal").image_batch_size(2).region_batch_size(8).build()
+    got = ocr.predict(imgs)
+    ref = pipeline_ref.OracleOCR(det, rec, chars, 0.2, 0.6, 0.5, region_batch_size=8, text_type="seal").predict(imgs)
+    total = 0
+    for g, r in zip(got, ref):
+        rep = pipeline_ref.compare_results(g, r)
+        assert rep["ok"], rep
+        # sort_poly_boxes: regions come by ascending min y
+        ymins = [float(np.min(t.bounding_box[:, 1])) for t in g.text_regions]
+        assert ymins == sorted(ymins)
+        total += len(r)
+    assert total >= 6
+    assert any(len(t.bounding_box) > 4 for g in got for t in g.text_regions)
+
+
+def test_invalid_box_type_is_rejected(nets):
+    pred = np.zeros((32, 32), np.float32)
+    res = api.DetResult()
+    st = api.lib().oar_db_postprocess_ex(pred.ctypes.data_as(C.c_void_p), 32, 32, 32, 32, C.c_float(0.3), C.c_float(0.6), C.c_float(1.5), 1000, 2, 0, 0, C.byref(res))
+    assert st == api.OAR_INVALID_INPUT
