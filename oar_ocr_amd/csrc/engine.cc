@@ -568,8 +568,40 @@ struct Planner {
 
     Planner(Engine& e, Plan& p) : E(e), P(p) { opset = e.opset_; }
 
+    // ------------------------------------------------------------------ deferred nearest Resize
+    // A Resize with exactly one consumer is not run where it stands: its consumer either absorbs it (Concat on the channel axis:
+    // the resize writes straight into its slot of the concatenated tensor; Add: the sum reads the low-resolution operand through
+    // the index map) or, failing that, runs it first.  compute_last_use keeps the resize's input alive until that consumer.
+    struct PendingResize {
+        Loc xin;
+        std::vector<int64_t> dims;   // logical output dims [N, C, Ho, Wo]
+        int N, H, W, C, Ho, Wo, imode, ictm, inm;
+        float sh, sw;
+        int fh = 0, fw = 0;          // > 0: the index map is exactly o / f (integer-factor nearest upsampling)
+    };
+    std::map<std::string, PendingResize> pending_resize;
+    std::map<std::string, int> sole_consumer;   // Resize output -> index of its only consumer node
+    void run_resize(const PendingResize& r, Loc yl, int64_t y_off, int y_ld) {
+        const PendingResize q = r;
+        step([=](const RunCtx& c) { k::resize(c.s, c.at(q.xin), c.mut(yl) + y_off, q.N, q.H, q.W, q.C, q.Ho, q.Wo, q.sh, q.sw, q.imode, q.ictm, q.inm, y_ld); }, 0,
+             4.0 * ((double)q.N * q.H * q.W * q.C + (double)q.N * q.Ho * q.Wo * q.C));
+    }
+    const PendingResize* peek_pending(const std::string& name) const {
+        auto it = pending_resize.find(name);
+        return it == pending_resize.end() ? nullptr : &it->second;
+    }
+    void materialise_pending(const std::string& name) {
+        auto it = pending_resize.find(name);
+        if (it == pending_resize.end()) return;
+        const PendingResize r = it->second;
+        pending_resize.erase(it);
+        TInfo& y = new_out(name, r.dims, Layout::CLAST);
+        run_resize(r, y.loc, 0, r.C);
+    }
+
     // ------------------------------------------------------------------ values
     TInfo& get(const std::string& name) {
+        if (!pending_resize.empty()) materialise_pending(name);
         auto it = vals.find(name);
         if (it != vals.end()) return it->second;
         auto ii = E.inits_.find(name);
@@ -1025,6 +1057,24 @@ struct Planner {
     }
 
     void op_binary(const GNode& n, int op) {
+        // a + upsample(b) (FPN top-down path): the sum reads b at (oh / f, ow / f) -- no upsampled tensor
+        if (op == 0 && !pending_resize.empty() && n.act.kind == k::ACT_NONE) {
+            for (int side = 0; side < 2; ++side) {
+                const PendingResize* pr = peek_pending(n.in[side]);
+                if (!pr || peek_pending(n.in[1 - side]) || !pr->fh || (pr->C & 3)) continue;
+                const TInfo& o = get(n.in[1 - side]);
+                if (o.host_int || o.ht || o.layout != Layout::CLAST || o.dims != pr->dims) continue;
+                const PendingResize r = *pr;
+                pending_resize.erase(n.in[side]);
+                Loc al = o.loc;
+                TInfo& y = new_out(n.out[0], r.dims, Layout::CLAST);
+                Loc yl = y.loc;
+                const double cnt = (double)numel(r.dims);
+                step([=](const RunCtx& c) { k::binary_upsampled(c.s, c.at(al), c.at(r.xin), c.mut(yl), r.N, r.Ho, r.Wo, r.C, r.fh, r.fw, 0); }, cnt,
+                     4.0 * (2.0 * cnt + cnt / (r.fh * r.fw)));
+                return;
+            }
+        }
         TInfo a = get(n.in[0]), b = get(n.in[1]);
         // a plan-time value meeting a device tensor (e.g. a scale computed from Shape): materialise it as an f32 constant
         if (a.host_int) { a.loc = host_to_device(n.in[0], a); a.host_int = false; a.layout = Layout::NATIVE; }
@@ -1512,6 +1562,27 @@ struct Planner {
         int ictm = ctm == "asymmetric" ? 0 : ctm == "half_pixel" ? 1 : ctm == "align_corners" ? 2 : ctm == "pytorch_half_pixel" ? 3 : -1;
         OAR_CHECK(ictm >= 0, OAR_UNSUPPORTED_OP, "Resize: coordinate_transformation_mode " + ctm);
         int inm = nm == "floor" ? 0 : nm == "round_prefer_floor" ? 1 : nm == "round_prefer_ceil" ? 2 : 3;
+        static const bool defer_on = [] { const char* e = getenv("OAR_DEFER_RESIZE"); return !e || atoi(e) != 0; }();
+        if (defer_on && imode == 0 && x.layout == Layout::CLAST && sole_consumer.count(n.out[0])) {
+            PendingResize r;
+            r.xin = x.loc; r.dims = {x.dims[0], x.dims[1], Ho, Wo};
+            r.N = (int)x.dims[0]; r.H = (int)H; r.W = (int)W; r.C = (int)x.dims[1]; r.Ho = (int)Ho; r.Wo = (int)Wo;
+            r.imode = imode; r.ictm = ictm; r.inm = inm; r.sh = sh; r.sw = sw;
+            // integer-factor upsampling whose index map is o / f: checked on the map itself, whatever the attributes say
+            auto factor = [&](int in, int out, float scale) {
+                if (in <= 0 || out % in != 0) return 0;
+                const int f = out / in;
+                for (int o = 0; o < out; ++o) if (k::resize_nearest_index(o, scale, in, out, ictm, inm) != o / f) return 0;
+                return f;
+            };
+            r.fh = factor(r.H, r.Ho, sh); r.fw = factor(r.W, r.Wo, sw);
+            if (!r.fh || !r.fw) r.fh = r.fw = 0;
+            pending_resize[n.out[0]] = r;
+            TInfo t;   // known shape, no storage yet
+            t.dims = r.dims; t.layout = Layout::CLAST; t.root = "";
+            vals[n.out[0]] = t;
+            return;
+        }
         Loc xin = to_clast_loc(x);
         TInfo& y = new_out(n.out[0], {x.dims[0], x.dims[1], Ho, Wo}, Layout::CLAST);
         Loc yl = y.loc;
@@ -1521,8 +1592,26 @@ struct Planner {
     }
 
     void op_concat(const GNode& n) {
+        // deferred resizes among the inputs: absorbed when this is a channel concat of channels-last tensors with float4-aligned
+        // slots, run on the spot otherwise
+        bool absorb = false;
+        if (!pending_resize.empty()) {
+            int64_t axis0 = n.ai("axis", 0);
+            bool ok = true, any = false;
+            int64_t total_c = 0;
+            for (auto& s : n.in) {
+                const PendingResize* pr = peek_pending(s);
+                any = any || pr;
+                auto it = vals.find(s);
+                if (it == vals.end() || it->second.dims.size() != 4 || it->second.layout != Layout::CLAST || it->second.host_int) { ok = false; break; }
+                if ((it->second.dims[1] & 3) != 0) ok = false;
+                total_c += it->second.dims[1];
+            }
+            absorb = any && ok && (axis0 == 1 || axis0 == -3) && (total_c & 3) == 0;
+            if (!absorb) for (auto& s : n.in) materialise_pending(s);
+        }
         std::vector<TInfo> xs;
-        for (auto& s : n.in) xs.push_back(get(s));
+        for (auto& s : n.in) { auto it = vals.find(s); xs.push_back(absorb && peek_pending(s) ? it->second : get(s)); }
         bool all_host = true, any_host = false, any_f = false;
         for (auto& t : xs) { all_host = all_host && host_evaluable(t) && t.dims.size() <= 1; any_host = any_host || t.host_int; any_f = any_f || float_like(t); }
         if (all_host && any_host) {   // 1-D shape / scale vectors
@@ -1547,7 +1636,7 @@ struct Planner {
             for (int i = 0; i < pax; ++i) outer *= pod[i];
             for (int i = pax + 1; i < r; ++i) inner *= pod[i];
             std::vector<Loc> ins;
-            for (auto& t : xs) ins.push_back(to_clast_loc(t));
+            for (size_t i = 0; i < xs.size(); ++i) ins.push_back(absorb && peek_pending(n.in[i]) ? Loc() : to_clast_loc(xs[i]));
             TInfo& y = new_out(n.out[0], od, Layout::CLAST);
             Loc yl = y.loc;
             int64_t coff = 0, total = pod[pax] * inner;
@@ -1555,7 +1644,12 @@ struct Planner {
                 int64_t w = xs[i].dims[axis] * inner;
                 Loc il = ins[i];
                 int64_t off = coff;
-                step([=](const RunCtx& c) { k::copy2d(c.s, c.at(il), c.mut(yl) + off, outer, (int)w, (int)w, (int)total); }, 0, 8.0 * outer * w);
+                if (absorb && peek_pending(n.in[i])) {   // the resize writes its pixels' channel group in place
+                    run_resize(*peek_pending(n.in[i]), yl, off, (int)total);
+                    pending_resize.erase(n.in[i]);
+                } else {
+                    step([=](const RunCtx& c) { k::copy2d(c.s, c.at(il), c.mut(yl) + off, outer, (int)w, (int)w, (int)total); }, 0, 8.0 * outer * w);
+                }
                 coff += w;
             }
             return;
@@ -1941,6 +2035,26 @@ struct Planner {
             if (!n.residual.empty()) lu[n.residual] = i;
         }
         for (auto& o : E.output_names_) lu[o] = 1 << 30;
+        // a Resize with a single consumer may run at that consumer (PendingResize): its input has to live until then
+        sole_consumer.clear();
+        {
+            std::map<std::string, std::pair<int, int>> uses;   // value -> (count, last consumer)
+            for (int i = 0; i < (int)E.nodes_.size(); ++i) {
+                const GNode& n = E.nodes_[i];
+                for (auto& s : n.in) if (!s.empty()) { auto& u = uses[s]; ++u.first; u.second = i; }
+                if (!n.residual.empty()) { auto& u = uses[n.residual]; ++u.first; u.second = i; }
+            }
+            for (int i = 0; i < (int)E.nodes_.size(); ++i) {
+                const GNode& n = E.nodes_[i];
+                if (n.op != "Resize" || n.out.empty() || n.in.empty()) continue;
+                auto u = uses.find(n.out[0]);
+                if (u == uses.end() || u->second.first != 1) continue;
+                if (std::find(E.output_names_.begin(), E.output_names_.end(), n.out[0]) != E.output_names_.end()) continue;
+                sole_consumer[n.out[0]] = u->second.second;
+                int& l = lu[n.in[0]];
+                l = std::max(l, u->second.second);
+            }
+        }
         for (int i = (int)E.nodes_.size() - 1; i >= 0; --i) {
             const GNode& n = E.nodes_[i];
             if (!alias_ops.count(n.op) || n.in.empty()) continue;
@@ -2034,8 +2148,10 @@ struct Planner {
 
     void dispatch(const GNode& n) {
         const std::string& op = n.op;
+        // shape / kind of an input without forcing a deferred Resize to run (its consumer decides that)
+        auto info = [&](const std::string& s) -> const TInfo& { return peek_pending(s) ? vals.find(s)->second : get(s); };
         bool host_inputs = !n.in.empty();
-        for (auto& s : n.in) if (!s.empty()) host_inputs = host_inputs && get(s).host_int;
+        for (auto& s : n.in) if (!s.empty()) host_inputs = host_inputs && info(s).host_int;
         if (op == "Shape") {
             const TInfo& x = get(n.in[0]);
             TInfo o; o.host_int = true; o.hv = x.dims; o.dims = {(int64_t)x.dims.size()};
@@ -2043,7 +2159,7 @@ struct Planner {
         }
         // shape arithmetic: every input is a host value or a small constant, and at least one really is a host value
         bool evaluable = !n.in.empty(), any_host = false;
-        for (auto& s : n.in) if (!s.empty()) { const TInfo& t = get(s); evaluable = evaluable && host_evaluable(t); any_host = any_host || t.host_int; }
+        for (auto& s : n.in) if (!s.empty()) { const TInfo& t = info(s); evaluable = evaluable && host_evaluable(t); any_host = any_host || t.host_int; }
         if (evaluable && (any_host || op == "Range") && op_host(n)) return;
         (void)host_inputs;
         if (op == "ConstantOfShape") return op_constant_of_shape(n);

@@ -67,6 +67,10 @@ void global_avgpool(hipStream_t s, const float* x, float* y, int N, int HW, int 
 
 // Resize NHWC. mode 0 = nearest, 1 = bilinear. ctm: 0 = asymmetric, 1 = half_pixel, 2 = align_corners,
 // 3 = pytorch_half_pixel. nearest_mode: 0 = floor, 1 = round_prefer_floor, 2 = round_prefer_ceil, 3 = ceil.
+// source index of output index o for mode = nearest (host evaluation of the kernel's own index map)
+int resize_nearest_index(int o, float scale, int in, int out, int ctm, int nearest_mode);
+// y = a op nearest_upsample(b), integer factors (fh, fw), NHWC, C % 4 == 0: b is [N, Ho / fh, Wo / fw, C]
+void binary_upsampled(hipStream_t s, const float* a, const float* b, float* y, int N, int Ho, int Wo, int C, int fh, int fw, int op);
 void resize(hipStream_t s, const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, float scale_h,
             float scale_w, int mode, int ctm, int nearest_mode, int y_ld);
 

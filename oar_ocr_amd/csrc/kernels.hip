@@ -481,7 +481,7 @@ void global_avgpool(hipStream_t s, const float* x, float* y, int N, int HW, int 
 }
 
 // ------------------------------------------------------------------------------------------ resize
-__device__ __forceinline__ float src_coord(int o, float scale, int in, int out, int ctm) {
+__host__ __device__ __forceinline__ float src_coord(int o, float scale, int in, int out, int ctm) {
     switch (ctm) {
         case 0: return (float)o / scale;
         case 2: return out > 1 ? (float)o * (float)(in - 1) / (float)(out - 1) : 0.f;
@@ -489,6 +489,20 @@ __device__ __forceinline__ float src_coord(int o, float scale, int in, int out, 
         default: return ((float)o + 0.5f) / scale - 0.5f;
     }
 }
+// source index of output index o under mode = nearest (the planner evaluates the same function to recognise integer-factor maps)
+__host__ __device__ __forceinline__ int nearest_src(int o, float scale, int in, int out, int ctm, int nm) {
+    const float f = src_coord(o, scale, in, out, ctm);
+    float r;
+    switch (nm) {
+        case 0: r = floorf(f); break;
+        case 3: r = ceilf(f); break;
+        case 2: r = floorf(f + 0.5f); break;
+        default: r = ceilf(f - 0.5f); break;
+    }
+    const int i = (int)r;
+    return i < 0 ? 0 : i > in - 1 ? in - 1 : i;
+}
+int resize_nearest_index(int o, float scale, int in, int out, int ctm, int nearest_mode) { return nearest_src(o, scale, in, out, ctm, nearest_mode); }
 __global__ __launch_bounds__(256) void resize_kernel(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo,
                                                      float sh, float sw, int mode, int ctm, int nm, int y_ld) {
     const int C4 = C >> 2;  // launcher guarantees C % 4 == 0 for the vector path, else C4 == 0 and scalar path
@@ -502,14 +516,7 @@ __global__ __launch_bounds__(256) void resize_kernel(const float* x, float* y, i
         float fy = src_coord(oh, sh, H, Ho, ctm), fx = src_coord(ow, sw, W, Wo, ctm);
         const float* xb = x + n * (long)H * W * C;
         if (mode == 0) {
-            float ry, rx;
-            switch (nm) {
-                case 0: ry = floorf(fy); rx = floorf(fx); break;
-                case 3: ry = ceilf(fy); rx = ceilf(fx); break;
-                case 2: ry = floorf(fy + 0.5f); rx = floorf(fx + 0.5f); break;
-                default: ry = ceilf(fy - 0.5f); rx = ceilf(fx - 0.5f); break;
-            }
-            int iy = min(max((int)ry, 0), H - 1), ix = min(max((int)rx, 0), W - 1);
+            const int iy = nearest_src(oh, sh, H, Ho, ctm, nm), ix = nearest_src(ow, sw, W, Wo, ctm, nm);
             if (vec) *reinterpret_cast<float4*>(y + pix * y_ld + cc * 4) = *reinterpret_cast<const float4*>(xb + ((long)iy * W + ix) * C + cc * 4);
             else y[pix * y_ld + cc] = xb[((long)iy * W + ix) * C + cc];
         } else {
@@ -650,6 +657,33 @@ void binary(hipStream_t s, const float* a, const float* b, float* y, int op, int
     p.rank = rank; p.op = op; p.akind = post.kind; p.alpha = post.alpha; p.beta = post.beta;
     for (int i = 0; i < 6; ++i) { p.dims[i] = i < rank ? dims[i] : 1; p.sa[i] = i < rank ? sa[i] : 0; p.sb[i] = i < rank ? sb[i] : 0; }
     hipLaunchKernelGGL(binary_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, b, y, n, p);
+}
+
+// y = a op nearest_upsample(b) on NHWC with integer factors: b is [N, Ho / fh, Wo / fw, C], read through the index map (FPN
+// top-down sums: the upsampled tensor never exists); C % 4 == 0
+__global__ __launch_bounds__(256) void binary_upsampled_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long total4, int C4,
+                                                                int Ho, int Wo, int fh, int fw, int op) {
+    const int Wi = Wo / fw, Hi = Ho / fh;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const long pix = i / C4;
+        const int ow = (int)(pix % Wo);
+        const long t = pix / Wo;
+        const int oh = (int)(t % Ho);
+        const long n = t / Ho;
+        const float4 u = reinterpret_cast<const float4*>(a)[i];
+        const float4 v = reinterpret_cast<const float4*>(b)[((n * Hi + oh / fh) * Wi + ow / fw) * C4 + c4];
+        float4 o;
+        o.x = bin_op(u.x, v.x, op); o.y = bin_op(u.y, v.y, op); o.z = bin_op(u.z, v.z, op); o.w = bin_op(u.w, v.w, op);
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+void binary_upsampled(hipStream_t s, const float* a, const float* b, float* y, int N, int Ho, int Wo, int C, int fh, int fw, int op) {
+    const long total4 = (long)N * Ho * Wo * (C / 4);
+    if (total4 == 0) return;
+    OAR_CHECK((C & 3) == 0 && fh > 0 && fw > 0 && Ho % fh == 0 && Wo % fw == 0, OAR_INTERNAL, "binary_upsampled: bad shape");
+    ProfScope ps(s, "binary", 4.0 * (8.0 * (double)total4 + 4.0 * (double)total4 / (fh * fw)), 4.0 * (double)total4);
+    hipLaunchKernelGGL(binary_upsampled_kernel, dim3(grid_for(total4)), dim3(256), 0, s, a, b, y, total4, C / 4, Ho, Wo, fh, fw, op);
 }
 
 __global__ __launch_bounds__(256) void copy2d_kernel(const float* x, float* y, long rows, int c, int x_ld, int y_ld, int vec) {

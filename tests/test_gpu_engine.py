@@ -522,3 +522,51 @@ def test_fused_dsblock_matches_oracle(case, monkeypatch):
     monkeypatch.setenv("OAR_FUSE_DSBLOCK", "0")
     plain = api.OrtInfer(m).infer(x)[0][1]
     assert np.abs(plain - got[0][1]).max() <= 2e-4 * max(1.0, float(np.abs(plain).max()))
+
+
+@pytest.mark.parametrize("case", ["fpn", "fallbacks"])
+def test_deferred_resize_is_absorbed_or_run_in_place(case):
+    """A nearest Resize with one consumer runs AT that consumer (engine.cc PendingResize): a channel Concat lets it write into its
+    slot, an Add reads the low-resolution operand through the index map (integer factors only), anything else runs it first.
+    Same numbers as the oracle either way; the absorbed forms launch no `resize` / `copy2d` for those tensors."""
+    rng = np.random.default_rng(31)
+    sc = lambda f: np.array([1, 1, f, f], np.float32)
+
+    def build(g):
+        g.add_input("x", ["N", 8, "H", "W"])
+        conv = lambda t, cin, cout, k=1, s=1: g.op("Conv", [t, g.init(rng.standard_normal((cout, cin, k, k)).astype(np.float32) * 0.2), g.init(rng.standard_normal(cout).astype(np.float32) * 0.1)],
+                                                     kernel_shape=[k, k], strides=[s, s], pads=[k // 2] * 4, group=1, dilations=[1, 1])
+        f2 = conv("x", 8, 16, 3, 1)
+        f3 = conv(f2, 16, 16, 3, 2)
+        f4 = conv(f3, 16, 16, 3, 2)
+        up = lambda t, f, **kw: g.op("Resize", [t, "", g.init(sc(f))], mode="nearest", **(kw or dict(coordinate_transformation_mode="asymmetric", nearest_mode="floor")))
+        if case == "fpn":
+            o3 = g.op("Add", [f3, up(f4, 2)])                                   # absorbed by the sum (operand order: resize second)
+            o2 = g.op("Add", [up(o3, 2, coordinate_transformation_mode="half_pixel", nearest_mode="round_prefer_floor"), f2])   # resize first; another map = o / 2
+            p4 = conv(f4, 16, 8)
+            p3 = conv(o3, 16, 8)
+            p2 = conv(o2, 16, 8)
+            cat = g.op("Concat", [up(p4, 4), up(p3, 2), p2], axis=1)           # two resizes write into the concat, one copy
+            y = conv(cat, 24, 4, 3, 1)
+            return y, ["N", 4, "H", "W"]
+        a = g.op("Relu", [up(f4, 2)])                                           # consumer that absorbs nothing: runs in place
+        b = g.op("Mul", [f3, up(f4, 2)])                                        # Mul is not absorbed
+        u15 = g.op("Resize", [f4, "", g.init(np.array([1, 1, 1.5, 1.5], np.float32))], mode="nearest", coordinate_transformation_mode="asymmetric", nearest_mode="floor")
+        c = g.op("Add", [u15, g.op("Resize", [f3, "", g.init(np.array([1, 1, 0.75, 0.75], np.float32))], mode="nearest", coordinate_transformation_mode="asymmetric", nearest_mode="floor")])
+        d = g.op("Concat", [up(f4, 2), f3], axis=2)                             # not the channel axis: materialised, then copied
+        g.add_output(c, ["N", 16, "H", "W"])
+        g.add_output(d, ["N", 16, "H", "W"])
+        return g.op("Add", [a, b]), ["N", 16, "H", "W"]
+
+    model = _single_op_graph(build)
+    x = rng.standard_normal((2, 8, 32, 48)).astype(np.float32)
+    _check(model, x)
+    if case == "fpn":
+        eng = api.OrtInfer(model)
+        eng.infer(x)
+        api.prof_enable(True); api.prof_reset()
+        eng.infer(x)
+        names = {e["name"]: e["launches"] for e in api.prof_snapshot()}
+        api.prof_enable(False)
+        assert names.get("resize", 0) == 2, names        # only the two that feed the concat; the sums absorbed theirs
+        assert names.get("copy2d", 0) == 1, names        # p2's slot
