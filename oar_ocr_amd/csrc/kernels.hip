@@ -999,23 +999,44 @@ void softmax_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int 
 
 // ------------------------------------------------------------------------------------------ squeeze-excite gate
 // GlobalAveragePool -> 1x1 conv -> act -> 1x1 conv -> act on [n, C, 1, 1] is two GEMVs per image: as implicit-GEMM launches
-// they are two ~10 us kernels of a few workgroups each; here one workgroup per image does both, the pooled vector and
-// the hidden vector staying in LDS.
-__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1, Act a1,
-                                                    const float* __restrict__ w2, const float* __restrict__ b2, Act a2, float* __restrict__ y, int C, int Cmid, int Cout) {
-    extern __shared__ float se_lds[];   // pooled [C] | hidden [Cmid]
+// they are two ~10 us kernels of a few workgroups each; here ONE launch does both, the pooled vector and the hidden vector
+// staying in LDS.  The work is a few hundred kFLOP per image: what it costs is load round trips, so the kernel is shaped to make
+// them few -- 16 waves per workgroup; FC1: every wave owns 4 hidden units per pass and keeps 16 weight loads in flight;
+// FC2: the hidden axis is cut into P parts summed through LDS in a fixed order; with few images (a detector sub-batch) G
+// workgroups share an image, each recomputing the cheap hidden vector and producing its slice of the outputs.
+__global__ __launch_bounds__(1024) void se_fc_kernel(const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1, Act a1,
+                                                     const float* __restrict__ w2, const float* __restrict__ b2, Act a2, float* __restrict__ y, int C, int Cmid, int Cout,
+                                                     int slice, int parts) {
+    extern __shared__ float se_lds[];   // pooled [C] | hidden [Cmid] | partial [parts][slice]
     float* pooled = se_lds;
     float* hidden = se_lds + C;
+    float* partial = hidden + Cmid;
     const long n = blockIdx.x;
+    const int c_lo = blockIdx.y * slice, c_hi = min(c_lo + slice, Cout);
     for (int c = threadIdx.x; c < C; c += blockDim.x) pooled[c] = x[n * C + c];
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int jb = wave * 4; jb < Cmid; jb += 16) {   // four hidden units per wave per pass: their weight rows load together
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int jb = wave * 4; jb < Cmid; jb += nwaves * 4) {   // four hidden units per wave per pass: their weight rows load together
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int c = lane; c < C; c += 64) {
-            const float pv = pooled[c];
+        const float* r0 = w1 + (long)min(jb + 0, Cmid - 1) * C;
+        const float* r1 = w1 + (long)min(jb + 1, Cmid - 1) * C;
+        const float* r2 = w1 + (long)min(jb + 2, Cmid - 1) * C;
+        const float* r3 = w1 + (long)min(jb + 3, Cmid - 1) * C;
+        int c = lane;
+        for (; c + 192 < C; c += 256) {   // 16 independent loads per round trip
+            float w[16];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] = fmaf(w1[(long)min(jb + u, Cmid - 1) * C + c], pv, acc[u]);
+            for (int q = 0; q < 4; ++q) { w[q * 4 + 0] = r0[c + q * 64]; w[q * 4 + 1] = r1[c + q * 64]; w[q * 4 + 2] = r2[c + q * 64]; w[q * 4 + 3] = r3[c + q * 64]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float pv = pooled[c + q * 64];
+                acc[0] = fmaf(w[q * 4 + 0], pv, acc[0]); acc[1] = fmaf(w[q * 4 + 1], pv, acc[1]);
+                acc[2] = fmaf(w[q * 4 + 2], pv, acc[2]); acc[3] = fmaf(w[q * 4 + 3], pv, acc[3]);
+            }
+        }
+        for (; c < C; c += 64) {
+            const float pv = pooled[c];
+            acc[0] = fmaf(r0[c], pv, acc[0]); acc[1] = fmaf(r1[c], pv, acc[1]); acc[2] = fmaf(r2[c], pv, acc[2]); acc[3] = fmaf(r3[c], pv, acc[3]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1024,26 +1045,45 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ x,
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < Cout; c += blockDim.x) {
-        float acc = b2 ? b2[c] : 0.f;
-        int j = 0;
-        for (; j + 8 <= Cmid; j += 8) {   // eight independent loads in flight (a rolled loop pays one L2 round trip per term)
+    // FC2: thread (part, k) sums hidden units [j0, j1) of output c_lo + k (W2 transposed: coalesced over the output channel)
+    const int k = threadIdx.x % slice, part = threadIdx.x / slice;
+    if (part < parts && c_lo + k < c_hi) {
+        const int per = (Cmid + parts - 1) / parts, j0 = part * per, j1 = min(j0 + per, Cmid);
+        const float* col = w2 + c_lo + k;
+        float acc = 0.f;
+        int j = j0;
+        for (; j + 8 <= j1; j += 8) {   // eight independent loads in flight (a rolled loop pays one L2 round trip per term)
             float w[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) w[u] = w2[(long)(j + u) * Cout + c];   // W2 transposed: coalesced over c
+            for (int u = 0; u < 8; ++u) w[u] = col[(long)(j + u) * Cout];
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc = fmaf(w[u], hidden[j + u], acc);
         }
-        for (; j < Cmid; ++j) acc = fmaf(w2[(long)j * Cout + c], hidden[j], acc);
+        for (; j < j1; ++j) acc = fmaf(col[(long)j * Cout], hidden[j], acc);
+        partial[part * slice + k] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < slice && c_lo + (int)threadIdx.x < c_hi) {
+        const int c = c_lo + threadIdx.x;
+        float acc = b2 ? b2[c] : 0.f;
+        for (int q = 0; q < parts; ++q) acc += partial[q * slice + threadIdx.x];
         y[n * Cout + c] = apply_act(acc, a2.kind, a2.alpha, a2.beta);
     }
 }
 void se_fc(hipStream_t s, const float* x, const float* w1, const float* b1, Act act1, const float* w2, const float* b2, Act act2, float* y, int N, int C,
            int Cmid, int Cout) {
     if (N == 0) return;
-    OAR_CHECK((size_t)(C + Cmid) * 4 <= 64 * 1024, OAR_UNSUPPORTED_OP, "se_fc: vectors exceed LDS");
+    // G workgroups per image when the images alone leave most of the chip idle; a slice is a multiple of 64 outputs, <= 1024
+    int G = 1;
+    if (N < 128) G = std::max(1, std::min(std::min(8, 256 / N), (Cout + 63) / 64));
+    int slice = ((Cout + G - 1) / G + 63) / 64 * 64;
+    while (slice > 1024) { ++G; slice = ((Cout + G - 1) / G + 63) / 64 * 64; }
+    G = (Cout + slice - 1) / slice;
+    const int parts = std::max(1, std::min(std::min(8, 1024 / slice), (Cmid + 7) / 8));
+    const size_t lds = (size_t)(C + Cmid + parts * slice) * sizeof(float);
+    OAR_CHECK(lds <= 64 * 1024, OAR_UNSUPPORTED_OP, "se_fc: vectors exceed LDS");
     ProfScope ps(s, "se_fc", 4.0 * ((double)N * (C + Cout) + (double)Cmid * (C + Cout)), 2.0 * N * (double)Cmid * (C + Cout));
-    hipLaunchKernelGGL(se_fc_kernel, dim3((unsigned)N), dim3(256), (size_t)(C + Cmid) * sizeof(float), s, x, w1, b1, act1, w2, b2, act2, y, C, Cmid, Cout);
+    hipLaunchKernelGGL(se_fc_kernel, dim3((unsigned)N, (unsigned)G), dim3(1024), lds, s, x, w1, b1, act1, w2, b2, act2, y, C, Cmid, Cout, slice, parts);
 }
 
 // ------------------------------------------------------------------------------------------ ReduceMean (last axis)

@@ -214,10 +214,12 @@ def test_pad_modes(mode):
     _check(_single_op_graph(build), rng.standard_normal((2, 4, 9, 11)).astype(np.float32))
 
 
-def test_squeeze_excite_gate_is_one_kernel():
-    """Rewrite pass 6: GlobalAveragePool -> Conv 1x1 + ReLU -> Conv 1x1 + HardSigmoid -> Mul (PP-LCNet's SE block)."""
+@pytest.mark.parametrize("C,R,N", [(48, 12, 5), (192, 48, 130), (768, 192, 3), (1100, 70, 2), (20, 6, 40)])
+def test_squeeze_excite_gate_is_one_kernel(C, R, N):
+    """Rewrite pass 6: GlobalAveragePool -> Conv 1x1 + ReLU -> Conv 1x1 + HardSigmoid -> Mul (PP-LCNet's SE block).  The shapes walk
+    se_fc's launch geometry: one workgroup per image (many images), several per image with output slices (few images, wide
+    layers), slices of > 1 x 64 outputs, a hidden axis cut into parts, channel counts that are no multiple of anything."""
     rng = np.random.default_rng(13)
-    C, R = 48, 12
 
     def build(g):
         g.add_input("x", ["N", C, "H", "W"])
@@ -229,8 +231,8 @@ def test_squeeze_excite_gate_is_one_kernel():
         return g.op("Mul", ["x", s]), ["N", C, "H", "W"]
 
     model = _single_op_graph(build)
-    _check(model, rng.standard_normal((5, C, 7, 9)).astype(np.float32))
-    assert api.OrtInfer(model).cost((5, C, 7, 9))[2] <= 5      # layout copy in, pool, gate, scale, layout copy out
+    _check(model, rng.standard_normal((N, C, 3, 5)).astype(np.float32))
+    assert api.OrtInfer(model).cost((N, C, 3, 5))[2] <= 5      # layout copy in, pool, gate, scale, layout copy out
 
 
 def test_unsupported_operator_is_an_error_not_a_fallback():
