@@ -153,8 +153,9 @@ typedef struct {
     int32_t use_dilation;      /* 1: dilate the mask (3 x 3, db_mask.rs:11) before contour tracing (db_postprocess.rs:163-168) */
     /* Where find_contours (db_bitmap.rs:100) runs.  0: on the host thread pool from the read-back mask (default: fastest on one GPU,
      * the host cores are otherwise idle).  1: on the GPU (contours.hip, one wavefront per mask segment), only the border chains
-     * cross PCIe and the host keeps the per-contour geometry -- for hosts whose cores are shared by many GPU ranks.  Identical
-     * results either way.  The environment variable OAR_GPU_CONTOURS=0|1 overrides this field. */
+     * cross PCIe and the host keeps the per-contour geometry -- for hosts whose cores are shared by many GPU ranks.  With it the
+     * mini boxes are also unclipped on the GPU (pp::unclip_quads, in the box-score round trip).  Identical results either way.
+     * The environment variables OAR_GPU_CONTOURS=0|1 and OAR_GPU_UNCLIP=0|1 override this field. */
     int32_t gpu_contours;
 } oar_det_cfg;
 
@@ -395,6 +396,9 @@ oar_status oar_k_contours(const uint8_t* mask, uint32_t width, uint32_t height, 
                           int64_t* offsets, int32_t* pts_xy, int32_t* types, int64_t cap_points);
 /* a18 processors/decode.rs:452-501 + simd.rs:72-81 */
 oar_status oar_k_ctc_argmax(const float* probs, size_t rows, size_t vocab, int64_t* idx, float* prob);
+/* a11 db_bitmap.rs:279-368 on the GPU (the kernel the detector runs next to the box scores): boxes = n_boxes * 8 floats;
+ * counts[i] = vertices of box i (0 = dropped, -1 = left to the host routine); pts_xy: cap_points (x, y) pairs per box. */
+oar_status oar_k_unclip(const float* boxes, uint32_t n_boxes, float ratio, int32_t* counts, float* pts_xy, uint32_t cap_points);
 /* a10 processors/db_score.rs:34-134: boxes = n_boxes * 8 floats */
 oar_status oar_k_box_scores(const float* pred, uint32_t height, uint32_t width, const float* boxes,
                             uint32_t n_boxes, float* scores);

@@ -126,7 +126,7 @@ EXPORTS = [
     "oar_rect_run", "oar_ocr_attach", "oar_k_rotate_rgb", "oar_k_bgr_planes_to_rgb", "oar_host_rotate_back_points",
     "oar_engine_cache_stats", "oar_onnx_inspect", "oar_host_contours", "oar_ctc_dict_create", "oar_ctc_dict_destroy", "oar_ctc_dict_classes",
     "oar_ctc_decode", "oar_ocr_decode", "oar_text_result_free", "oar_db_postprocess_ex", "oar_k_dilate", "oar_k_poly_scores", "oar_debug_inject_failure", "oar_k_contours", "oar_host_contours_bits",
-    "oar_host_approx_poly_dp", "oar_host_perimeter", "oar_host_unclip_poly", "oar_host_offset_ring", "oar_host_ring_outline", "oar_host_sort_poly_boxes",
+    "oar_k_unclip", "oar_host_approx_poly_dp", "oar_host_perimeter", "oar_host_unclip_poly", "oar_host_offset_ring", "oar_host_ring_outline", "oar_host_sort_poly_boxes",
 ]
 
 
@@ -195,6 +195,7 @@ def lib():
     L.oar_k_threshold.argtypes = [vp, C.c_size_t, C.c_float, vp]
     L.oar_k_ctc_argmax.argtypes = [vp, C.c_size_t, C.c_size_t, vp, vp]
     L.oar_k_box_scores.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp]
+    L.oar_k_unclip.argtypes = [vp, C.c_uint32, C.c_float, vp, vp, C.c_uint32]
     L.oar_k_rotate_crop.argtypes = [vp, C.c_uint32, C.c_uint32, f32p, vp, C.c_size_t, u32p, u32p]
     L.oar_host_candidates.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, vp, C.c_int32]
     L.oar_host_candidates.restype = C.c_int32
@@ -1222,6 +1223,16 @@ def k_contours(mask, max_contours=100000):
     n = C.c_int32(0)
     _check(lib().oar_k_contours(_p(mask), w, h, max_contours, C.byref(n), _p(offs), _p(pts), _p(types), cap))
     return [(pts[offs[i]:offs[i + 1]].copy(), int(types[i])) for i in range(n.value)]
+
+
+def k_unclip(boxes, ratio, cap_points=96):
+    """pp::unclip_quads on n boxes [n, 4, 2]: list of [m, 2] polygons; None where the kernel leaves the box to the host."""
+    b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 8)
+    n = len(b)
+    counts = np.zeros(max(n, 1), np.int32)
+    pts = np.zeros((max(n, 1), cap_points, 2), np.float32)
+    _check(lib().oar_k_unclip(_p(b), n, C.c_float(ratio), _p(counts), _p(pts), cap_points))
+    return [None if counts[i] < 0 else pts[i, :counts[i]].copy() for i in range(n)]
 
 
 def host_unclip(box, ratio):

@@ -801,6 +801,26 @@ oar_status oar_k_ctc_argmax(const float* probs, size_t rows, size_t vocab, int64
     });
 }
 
+oar_status oar_k_unclip(const float* boxes, uint32_t n_boxes, float ratio, int32_t* counts, float* pts_xy, uint32_t cap_points) {
+    return guard([&] {
+        require_device();
+        OAR_CHECK(n_boxes == 0 || (boxes && counts && pts_xy), OAR_INVALID_INPUT, "oar_k_unclip: bad arguments");
+        if (n_boxes == 0) return;
+        std::vector<pp::ScoreBox> sb(n_boxes);
+        for (uint32_t i = 0; i < n_boxes; ++i) { std::memcpy(sb[i].pts, boxes + (size_t)i * 8, 32); sb[i].image = 0; sb[i].pad = 0; }
+        DevBuf db, dout;
+        db.reserve(n_boxes * sizeof(pp::ScoreBox)); dout.reserve(n_boxes * sizeof(pp::UnclipOut));
+        OAR_HIP(hipMemcpy(db.p, sb.data(), n_boxes * sizeof(pp::ScoreBox), hipMemcpyHostToDevice));
+        pp::unclip_quads(nullptr, db.as<pp::ScoreBox>(), (int)n_boxes, ratio, dout.as<pp::UnclipOut>());
+        std::vector<pp::UnclipOut> ho(n_boxes);
+        OAR_HIP(hipMemcpy(ho.data(), dout.p, n_boxes * sizeof(pp::UnclipOut), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n_boxes; ++i) {
+            counts[i] = ho[i].n_pts;
+            const int m = std::min<int>(std::max(ho[i].n_pts, 0), (int)cap_points);
+            std::memcpy(pts_xy + (size_t)i * cap_points * 2, ho[i].pts, (size_t)m * 2 * sizeof(float));
+        }
+    });
+}
 oar_status oar_k_box_scores(const float* pred, uint32_t height, uint32_t width, const float* boxes, uint32_t n_boxes, float* scores) {
     return guard([&] {
         require_device();

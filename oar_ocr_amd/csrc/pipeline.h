@@ -115,6 +115,7 @@ class Detector {
     struct ScoreSlot {
         PinBuf boxes_host, scores_host; DevBuf boxes_dev, scores_dev; std::vector<size_t> base; size_t total = 0;
         PinBuf poly_pts_host, poly_desc_host; DevBuf poly_pts_dev, poly_desc_dev;   // ScoreMode::Slow: the contours themselves
+        PinBuf unclip_host; DevBuf unclip_dev; bool unclipped = false;              // a11 on the GPU: pp::UnclipOut per candidate
     };
     std::vector<std::unique_ptr<ScoreSlot>> score_slots_;
     // mask read-back runs on its own stream: a D2H copy is a blit KERNEL on the queue it is issued to (150 us per 9-page

@@ -67,6 +67,15 @@ struct ScoreBox {          // a10 processors/db_score.rs:34-134
 };
 void box_scores(hipStream_t s, const float* pred, int height, int width, const ScoreBox* d_boxes, int n_boxes, float* d_scores);
 
+// a11 on the GPU: DBPostProcess::unclip (processors/db_bitmap.rs:279-368) of every mini box of a sub-batch, in the same round trip
+// as its score.  Same f64 operation sequence as host::unclip (db_host.cc), one lane per box; the vertices land on the 1/100 px
+// integer grid, which absorbs the last-ulp differences between the device's and glibc's acos / sin / cos / atan2 / hypot
+// (tests/test_gpu_kernels.py: identical to the host routine on 20 000 random boxes).  n_pts: >= 3 polygon, 0 = dropped by the
+// reference's degeneracy tests, -1 = not handled here (a reflex corner or more than kUnclipMaxPts vertices): the host routine runs.
+constexpr int kUnclipMaxPts = 80;
+struct UnclipOut { int32_t n_pts; int32_t pad; float pts[kUnclipMaxPts * 2]; };
+void unclip_quads(hipStream_t s, const ScoreBox* d_boxes, int n_boxes, float ratio, UnclipOut* d_out);
+
 // Scanline mean over an arbitrary polygon: box_score_slow (processors/db_score.rs:139-181, the contour itself is the
 // polygon) and the polygon (seal) path's box_score_fast on the approximated contour (db_bitmap.rs:49).  Same arithmetic and
 // summation order as box_scores; polygon i = pts[poly[i].first .. first + count) (x, y pairs).

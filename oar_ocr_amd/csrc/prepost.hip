@@ -385,6 +385,93 @@ void box_scores(hipStream_t s, const float* pred, int height, int width, const S
     hipLaunchKernelGGL(box_scores_kernel, dim3(n_boxes), dim3(256), 0, s, pred, height, width, d_boxes, d_scores);
 }
 
+// ------------------------------------------------------------------------------------------ a11 unclip
+// host::unclip (db_host.cc) statement for statement: f64 area / perimeter / delta, the ring on the 1/100 px grid, per corner the arc
+// that swings the previous edge's offset vector onto the next edge's (Clipper2 ClipperOffset::{BuildNormals, OffsetPoint, DoRound},
+// arc tolerance radius / 500).  -ffp-contract=off: no multiply-add is fused, as on the host.
+__global__ __launch_bounds__(64) void unclip_quads_kernel(const ScoreBox* __restrict__ boxes, int n, float ratio, UnclipOut* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    constexpr double kGrid = 100.0, kPi = 3.14159265358979323846, kEpsD = 2.220446049250313e-16;
+    UnclipOut& o = out[b];
+    double qx[4], qy[4];
+    for (int i = 0; i < 4; ++i) { qx[i] = (double)boxes[b].pts[i * 2]; qy[i] = (double)boxes[b].pts[i * 2 + 1]; }
+    double shoelace = 0.0, perimeter = 0.0;
+    for (int i = 0, p = 3; i < 4; p = i++) shoelace += (qy[p] + qy[i]) * (qx[p] - qx[i]);
+    const double area = fabs(shoelace * 0.5);
+    for (int i = 1; i < 4; ++i) perimeter += hypot(qx[i] - qx[i - 1], qy[i] - qy[i - 1]);
+    perimeter += hypot(qx[0] - qx[3], qy[0] - qy[3]);
+    if (area <= kEpsD || perimeter <= kEpsD) { o.n_pts = 0; return; }
+    const double delta = area * (double)ratio / perimeter;
+    if (fabs(delta) <= kEpsD) { o.n_pts = 0; return; }
+    long long rx[4], ry[4];
+    int rn = 0;
+    for (int i = 0; i < 4; ++i) {
+        const long long gx = (long long)round(qx[i] * kGrid), gy = (long long)round(qy[i] * kGrid);
+        if (rn && rx[rn - 1] == gx && ry[rn - 1] == gy) continue;
+        rx[rn] = gx; ry[rn] = gy; ++rn;
+    }
+    while (rn > 1 && rx[rn - 1] == rx[0] && ry[rn - 1] == ry[0]) --rn;
+    if (rn < 3) { o.n_pts = 0; return; }
+    int cnt = 0;
+    bool overflow = false;
+    auto emit = [&](double gx, double gy) {
+        if (cnt < kUnclipMaxPts) {
+            o.pts[cnt * 2] = (float)((double)(long long)round(gx) / kGrid);
+            o.pts[cnt * 2 + 1] = (float)((double)(long long)round(gy) / kGrid);
+        } else overflow = true;
+        ++cnt;
+    };
+    const double grid_delta = delta * kGrid;
+    if (fabs(grid_delta) < 0.5) {
+        for (int i = 0; i < rn; ++i) emit((double)rx[i], (double)ry[i]);
+    } else {
+        double twice = 0.0;
+        for (int i = 0, p = rn - 1; i < rn; p = i++) twice += (double)(ry[p] + ry[i]) * (double)(rx[p] - rx[i]);
+        const double radius = twice * 0.5 < 0 ? -grid_delta : grid_delta;
+        const double r = fabs(radius), tol = r * 0.002;
+        const double per_turn = fmin(kPi / acos(1.0 - tol / r), r * kPi);
+        double sn = sin(2.0 * kPi / per_turn);
+        const double cs = cos(2.0 * kPi / per_turn);
+        if (radius < 0.0) sn = -sn;
+        const double per_rad = per_turn / (2.0 * kPi);
+        double ux[4], uy[4];
+        for (int e = 0; e < rn; ++e) {
+            const int f = e + 1 == rn ? 0 : e + 1;
+            double dx = (double)(rx[f] - rx[e]), dy = (double)(ry[f] - ry[e]);
+            if (dx == 0.0 && dy == 0.0) { ux[e] = uy[e] = 0.0; continue; }
+            const double inv_len = 1.0 / sqrt(dx * dx + dy * dy);
+            dx *= inv_len; dy *= inv_len;
+            ux[e] = dy; uy[e] = -dx;
+        }
+        for (int v = 0, in_e = rn - 1; v < rn; in_e = v++) {
+            const double cx = (double)rx[v], cy = (double)ry[v];
+            double turn_sin = uy[v] * ux[in_e] - uy[in_e] * ux[v];
+            const double turn_cos = ux[v] * ux[in_e] + uy[v] * uy[in_e];
+            turn_sin = turn_sin > 1.0 ? 1.0 : turn_sin < -1.0 ? -1.0 : turn_sin;
+            double sx = ux[in_e] * radius, sy = uy[in_e] * radius;
+            const double ex = cx + ux[v] * radius, ey = cy + uy[v] * radius;
+            if (turn_cos > -0.999 && turn_sin * radius < 0) { o.n_pts = -1; return; }   // reflex corner: never for a mini box; the host handles it
+            emit(cx + sx, cy + sy);
+            const int hops = (int)ceil(per_rad * fabs(atan2(turn_sin, turn_cos)));
+            for (int h = 1; h < hops; ++h) {
+                const double nx = sx * cs - sn * sy, ny = sx * sn + sy * cs;
+                sx = nx; sy = ny;
+                emit(cx + sx, cy + sy);
+            }
+            emit(ex, ey);
+        }
+    }
+    if (overflow) { o.n_pts = -1; return; }
+    if (cnt > 1 && fabsf(o.pts[0] - o.pts[(cnt - 1) * 2]) < 1.1920929e-7f && fabsf(o.pts[1] - o.pts[(cnt - 1) * 2 + 1]) < 1.1920929e-7f) --cnt;
+    o.n_pts = cnt < 3 ? 0 : cnt;
+}
+void unclip_quads(hipStream_t s, const ScoreBox* d_boxes, int n_boxes, float ratio, UnclipOut* d_out) {
+    if (n_boxes == 0) return;
+    ProfScope ps(s, "unclip", 0.0, 0.0);
+    hipLaunchKernelGGL(unclip_quads_kernel, dim3((n_boxes + 63) / 64), dim3(64), 0, s, d_boxes, n_boxes, ratio, d_out);
+}
+
 // Polygon of any size.  One workgroup per polygon, one lane per scanline row.  The reference collects the row's edge
 // crossings, sorts them and sums the spans pair by pair; here the crossings are produced in sorted order by repeated
 // selection of the next smallest (x, edge) over the edge list -- the same multiset in the same order, with no per-row

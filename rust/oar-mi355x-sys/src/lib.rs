@@ -310,6 +310,7 @@ unsafe extern "C" {
     pub fn oar_k_poly_scores(pred: *const f32, height: u32, width: u32, pts_xy: *const f32, counts: *const u32, n_polys: u32, scores: *mut f32) -> oar_status;
     pub fn oar_k_contours(mask: *const u8, width: u32, height: u32, max_contours: u32, n_contours: *mut i32, offsets: *mut i64, pts_xy: *mut i32, types: *mut i32, cap_points: i64) -> oar_status;
     pub fn oar_k_ctc_argmax(probs: *const f32, rows: usize, vocab: usize, idx: *mut i64, prob: *mut f32) -> oar_status;
+    pub fn oar_k_unclip(boxes: *const f32, n_boxes: u32, ratio: f32, counts: *mut i32, pts_xy: *mut f32, cap_points: u32) -> oar_status;
     pub fn oar_k_box_scores(pred: *const f32, height: u32, width: u32, boxes: *const f32, n_boxes: u32, scores: *mut f32) -> oar_status;
     /// fixed-length arrays: box_: [f32; 8]
     pub fn oar_k_rotate_crop(rgb: *const u8, w: u32, h: u32, box_: *const f32, out: *mut u8, cap: usize, out_w: *mut u32, out_h: *mut u32) -> oar_status;

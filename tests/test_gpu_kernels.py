@@ -251,3 +251,35 @@ def test_gpu_contours_text_page_and_host_fallback():
     _same_contours(m4)
     m5 = np.zeros((40, 9000), np.uint8); m5[5:30, ::2] = 255                                     # 4500 segments in one band: more than the table holds
     _same_contours(m5)
+
+
+def test_gpu_unclip_equals_the_host_routine_on_random_boxes():
+    """a11 as a HIP kernel (pp::unclip_quads, run next to the box scores): vertex for vertex what host::unclip -- and therefore the
+    oracle -- produces, on 20 000 random rectangles of every orientation, size and winding, at several ratios; degenerate boxes are
+    dropped by both."""
+    rng = np.random.default_rng(77)
+    n = 20000
+    cx, cy = rng.uniform(20, 940, n), rng.uniform(20, 940, n)
+    w, h = rng.uniform(3, 600, n), rng.uniform(3, 90, n)
+    ang = np.where(rng.random(n) < 0.4, 0.0, rng.uniform(-np.pi, np.pi, n))
+    ca, sa = np.cos(ang), np.sin(ang)
+    corners = np.array([[-0.5, -0.5], [0.5, -0.5], [0.5, 0.5], [-0.5, 0.5]])
+    boxes = np.zeros((n, 4, 2), np.float32)
+    for k, (ux, uy) in enumerate(corners):
+        boxes[:, k, 0] = cx + ux * w * ca - uy * h * sa
+        boxes[:, k, 1] = cy + ux * w * sa + uy * h * ca
+    boxes[::3] = np.round(boxes[::3])                   # integer corners, as mini boxes of pixel contours often are
+    boxes[1::7] = boxes[1::7, ::-1]                     # the other winding
+    boxes[5] = boxes[5, [0, 0, 1, 1]]                   # zero area
+    boxes[6, :] = boxes[6, 0]                           # a point
+    for ratio in (1.5, 2.0, 0.5):
+        got = api.k_unclip(boxes, ratio)
+        bad = 0
+        for i in range(n):
+            ref = api.host_unclip(boxes[i], ratio)
+            g = got[i]
+            assert g is not None
+            if g.shape != ref.shape or not np.array_equal(g, ref):
+                bad += 1
+        assert bad == 0, (ratio, bad)
+    assert len(got[5]) == 0 and len(got[6]) == 0
