@@ -849,7 +849,7 @@ struct Planner {
         get_pads(n, H, Wd, kh, kw, sh, sw, dh, dw, pt, pl, pb, pr);
         int64_t Ho = (H + pt + pb - dh * (kh - 1) - 1) / sh + 1, Wo = (Wd + pl + pr - dw * (kw - 1) - 1) / sw + 1;
         if (x.u8_stem) {   // Engine::run_stem: the stem reads the u8 pages and normalises on the fly (kernels.h StemU8)
-            OAR_CHECK(g == 1 && Cin == 3 && kh * kw * 3 <= 128 && N <= 32 && n.residual.empty(), OAR_INTERNAL, "run_stem on a graph whose first node is not an RGB stem");
+            OAR_CHECK(g == 1 && Cin == 3 && kh * kw * 3 <= 128 && n.residual.empty(), OAR_INTERNAL, "run_stem on a graph whose first node is not an RGB stem");
             const float* sb = has_input(n, 2) ? get(n.in[2]).loc.cptr : nullptr;
             TInfo& ys = new_out(n.out[0], {N, Cout, Ho, Wo}, Layout::CLAST);
             k::ConvP sp{};
@@ -2435,10 +2435,10 @@ const Plan& Engine::run_multi(const std::vector<const float*>& d_ins, const std:
     return p;
 }
 
-const Plan& Engine::run_stem(const k::StemU8& st, const std::vector<int64_t>& dims) {
+const Plan& Engine::run_stem(const k::StemU8& st, const std::vector<int64_t>& dims, bool skip_final_softmax) {
     OAR_CHECK(stem_fusable_, OAR_INTERNAL, "run_stem on a graph without a fusable RGB stem");
-    OAR_CHECK(dims.size() == 4 && dims[1] == 3 && dims[0] >= 1 && dims[0] <= 32, OAR_INVALID_INPUT, "run_stem: dims must be {n <= 32, 3, H, W}");
-    const Plan& p = plan_for(dims, true, false, nullptr, true);
+    OAR_CHECK(dims.size() == 4 && dims[1] == 3 && dims[0] >= 1 && (st.dev || dims[0] <= 32), OAR_INVALID_INPUT, "run_stem: dims must be {n, 3, H, W} (n <= 32 pages by value)");
+    const Plan& p = plan_for(dims, true, skip_final_softmax, nullptr, true);
     OAR_HIP(hipSetDevice(device_));
     if (arena_.cap < p.arena_bytes) {
         OAR_HIP(hipStreamSynchronize(stream_));

@@ -108,7 +108,8 @@ class Engine {
     // (run_stem) and skip the normalised f32 input tensor altogether.
     bool stem_fusable() const { return stem_fusable_; }
     // dims = {n, 3, H, W}; st.pages[0..n) are device pointers to H x W x 3 u8 pages; st.src / alpha / beta as pp::normalize
-    const Plan& run_stem(const k::StemU8& st, const std::vector<int64_t>& dims);
+    // st.dev (device table of per-image pointers / widths, kernels.h): the recognizer's form, any n
+    const Plan& run_stem(const k::StemU8& st, const std::vector<int64_t>& dims, bool skip_final_softmax = false);
     // Several named inputs (OrtInfer::infer, ort_infer_execution.rs:121-219): d_ins[i] / dims[i] belong to input_infos()[i]
     // (the caller has matched the names); input 0 is the primary one, the others are bound as plain f32 device tensors.
     const Plan& run_multi(const std::vector<const float*>& d_ins, const std::vector<std::vector<int64_t>>& dims);

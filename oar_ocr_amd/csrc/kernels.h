@@ -49,7 +49,12 @@ void conv_direct(hipStream_t s, const ConvP& p);
 // (float)v * alpha[c] + beta[c] for tensor channel c = page channel src[c] on the fly -- the same two f32 operations
 // pp::normalize performs, so the result is bit-identical to normalize + conv -- instead of a 12-bytes-per-pixel f32 tensor
 // being written and read back.  Up to 32 separately allocated pages per launch.
-struct StemU8 { const uint8_t* pages[32]; int src[3]; float alpha[3], beta[3]; };
+// `dev` == nullptr: st.pages[0..n) are H x W x 3 pages of one size, normalised as x * alpha + beta (the detector).  `dev` != nullptr
+// (the recognizer): image i is dev[i].ptr, H rows of dev[i].w <= W pixels -- columns past its own width read as zero AFTER
+// normalisation, which is how the CRNN input is padded (crnn.rs:98-121) -- and a byte v becomes ((v / 255 - 0.5) / 0.5), the
+// recognizer's expression, through a 256-entry table.
+struct StemImg { const uint8_t* ptr; int32_t w; int32_t pad; };
+struct StemU8 { const uint8_t* pages[32]; int src[3]; float alpha[3], beta[3]; const StemImg* dev = nullptr; };
 void conv_smallcin_u8(hipStream_t s, const ConvP& p, const StemU8& st);
 // General ConvTranspose (gather form). w: [kh][kw][Cin][Cout] (groups == 1), output_padding folded in Ho/Wo.
 void convt_direct(hipStream_t s, const ConvP& p);

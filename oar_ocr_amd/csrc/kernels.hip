@@ -247,21 +247,25 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvP p) {
 
 // The same kernel fed by u8 pages (StemU8, kernels.h): tap value = (float)byte * alpha + beta, two separate f32 operations
 // exactly as pp::normalize computes them; out-of-image taps contribute nothing (the conv zero-pads the NORMALISED tensor).
+template <bool CRNN>
 __global__ __launch_bounds__(256) void conv_smallcin_u8_kernel(ConvP p, StemU8 st) {
     __shared__ float ws[128 * 16];
+    __shared__ float lut[CRNN ? 256 : 1];
     const int K = p.kh * p.kw * 3;
     const int co0 = blockIdx.y * 16;
     for (int i = threadIdx.x; i < K * 16; i += 256) {
         int k = i >> 4, c = i & 15;
         ws[i] = (co0 + c < p.Cout) ? p.w[(long)k * p.Cout + co0 + c] : 0.f;
     }
+    if (CRNN) lut[threadIdx.x] = ((float)threadIdx.x / 255.0f - 0.5f) / 0.5f;   // pp::rec_pack's expression, once per byte value
     __syncthreads();
     const long per_image = (long)p.Ho * p.Wo;
     const float a0 = st.alpha[0], a1 = st.alpha[1], a2 = st.alpha[2], b0 = st.beta[0], b1 = st.beta[1], b2 = st.beta[2];
     const int s0 = st.src[0], s1 = st.src[1], s2 = st.src[2];
     // grid.z = image: the page pointer is wave-uniform (a per-thread index into the kernel-argument table would go through scratch)
     const int n = blockIdx.z;
-    const uint8_t* __restrict__ pg = st.pages[n];
+    const uint8_t* __restrict__ pg = CRNN ? st.dev[n].ptr : st.pages[n];
+    const int img_w = CRNN ? st.dev[n].w : p.W;   // the image's own row length: taps past it are padding
     for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < per_image; pix += (long)gridDim.x * blockDim.x) {
         const int ow = (int)(pix % p.Wo), oh = (int)(pix / p.Wo);
         float acc[16];
@@ -272,11 +276,16 @@ __global__ __launch_bounds__(256) void conv_smallcin_u8_kernel(ConvP p, StemU8 s
             if (ih < 0 || ih >= p.H) continue;
             for (int b = 0; b < p.kw; ++b) {
                 const int iw = ow * p.sw - p.pl + b * p.dw;
-                if (iw < 0 || iw >= p.W) continue;
-                const uint8_t* xp = pg + ((long)ih * p.W + iw) * 3;
+                if (iw < 0 || iw >= img_w) continue;
+                const uint8_t* xp = pg + ((long)ih * img_w + iw) * 3;
                 const float* wp = ws + (a * p.kw + b) * 3 * 16;
-                float t0 = (float)xp[s0] * a0, t1 = (float)xp[s1] * a1, t2 = (float)xp[s2] * a2;
-                const float x0 = t0 + b0, x1 = t1 + b1, x2 = t2 + b2;
+                float x0, x1, x2;
+                if (CRNN) {
+                    x0 = lut[xp[s0]]; x1 = lut[xp[s1]]; x2 = lut[xp[s2]];
+                } else {
+                    const float t0 = (float)xp[s0] * a0, t1 = (float)xp[s1] * a1, t2 = (float)xp[s2] * a2;
+                    x0 = t0 + b0; x1 = t1 + b1; x2 = t2 + b2;
+                }
 #pragma unroll
                 for (int c = 0; c < 16; ++c) acc[c] = fmaf(x0, wp[c], acc[c]);
 #pragma unroll
@@ -304,10 +313,12 @@ __global__ __launch_bounds__(256) void conv_smallcin_u8_kernel(ConvP p, StemU8 s
 void conv_smallcin_u8(hipStream_t s, const ConvP& p, const StemU8& st) {
     const long per_image = (long)p.Ho * p.Wo;
     if (per_image == 0 || p.N == 0) return;
-    OAR_CHECK(p.groups == 1 && p.Cin == 3 && p.kh * p.kw * 3 <= 128 && p.N <= 32, OAR_INTERNAL, "conv_smallcin_u8: not an RGB stem");
+    OAR_CHECK(p.groups == 1 && p.Cin == 3 && p.kh * p.kw * 3 <= 128 && (st.dev ? p.N <= 65535 : p.N <= 32), OAR_INTERNAL, "conv_smallcin_u8: not an RGB stem");
     const double total = (double)p.N * per_image * p.Cout;
     ProfScope ps(s, "conv_smallcin", 3.0 * (double)p.N * p.H * p.W + 4.0 * total, 2.0 * total * p.kh * p.kw * 3);
-    hipLaunchKernelGGL(conv_smallcin_u8_kernel, dim3(grid_for(per_image, 256, 256L * 4), (p.Cout + 15) / 16, p.N), dim3(256), 0, s, p, st);
+    const dim3 grid(grid_for(per_image, 256, 256L * 4), (p.Cout + 15) / 16, p.N);
+    if (st.dev) hipLaunchKernelGGL(conv_smallcin_u8_kernel<true>, grid, dim3(256), 0, s, p, st);
+    else hipLaunchKernelGGL(conv_smallcin_u8_kernel<false>, grid, dim3(256), 0, s, p, st);
 }
 
 // ------------------------------------------------------------------------------------------ direct conv (fallback)
@@ -464,7 +475,10 @@ int global_avgpool_splits(int N, int HW, int C) {
 }
 void global_avgpool(hipStream_t s, const float* x, float* y, int N, int HW, int C, float* partial) {
     if (N == 0 || C == 0) return;
-    ProfScope ps(s, "global_avgpool", 4.0 * (double)N * HW * C, 0.0);
+    char pname[64];
+    const char* cls = "global_avgpool";
+    if (Profiler::get().detail) { snprintf(pname, sizeof pname, "global_avgpool N=%d HW=%d C=%d", N, HW, C); cls = pname; }
+    ProfScope ps(s, cls, 4.0 * (double)N * HW * C, 0.0);
     if ((C & 3) == 0 && C / 4 <= 256) {
         const int C4 = C / 4, parts = 256 / C4;
         const size_t lds = (size_t)parts * C4 * sizeof(float4);
@@ -625,7 +639,10 @@ void binary(hipStream_t s, const float* a, const float* b, float* y, int op, int
     long n = 1;
     for (int i = 0; i < rank; ++i) n *= dims[i];
     if (n == 0) return;
-    ProfScope ps(s, "binary", 12.0 * (double)n, (double)n);
+    char pname[64];
+    const char* cls = "binary";
+    if (Profiler::get().detail) { snprintf(pname, sizeof pname, "binary op%d n=%ld last=%ld", op, n, (long)dims[rank - 1]); cls = pname; }
+    ProfScope ps(s, cls, 12.0 * (double)n, (double)n);
     // contiguity analysis
     bool a_full = true, b_full = true;
     long exp = 1;

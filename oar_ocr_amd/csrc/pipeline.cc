@@ -985,6 +985,54 @@ const float* Recognizer::pack(const std::vector<Crop>& crops, int& Wt, bool nchw
     return in_buf.as<float>();
 }
 
+static_assert(sizeof(pp::ResizedImg) == sizeof(k::StemImg) && sizeof(pp::ResizedImg) == 16, "one table for pp::rec_resize_u8 and k::conv_smallcin_u8");
+
+// Fused-stem packing: the crops are resized to their own width in u8 (into the lane's input buffer, a quarter of what the f32
+// tensor would take); normalisation and zero padding to Wt happen inside the stem convolution (k::StemU8::dev).
+const pp::ResizedImg* Recognizer::pack_u8(const std::vector<Crop>& crops, int& Wt, size_t desc_slot, size_t stage_slot, int lane) {
+    hipStream_t s = lane_engine(lane).stream();
+    DevBuf& in_buf = lane == 0 ? input_f32_ : *lane_in_[lane - 1];
+    const int n = (int)crops.size();
+    const int img_h = (int)cfg_.rec_image_shape[1], img_w = (int)cfg_.rec_image_shape[2];
+    std::vector<uint32_t> ws(n), hs(n);
+    size_t stage = 0;
+    for (int i = 0; i < n; ++i) {
+        OAR_CHECK(crops[i].w > 0 && crops[i].h > 0 && (crops[i].host || crops[i].dev), OAR_INVALID_INPUT, "recognizer: empty crop");
+        ws[i] = crops[i].w; hs[i] = crops[i].h;
+        if (!crops[i].dev) stage += ((size_t)crops[i].w * crops[i].h * 3 + 63) & ~(size_t)63;
+    }
+    std::vector<int32_t> rws;
+    Wt = host::rec_tensor_width(ws, hs, img_h, img_w, (int)cfg_.max_img_w, rws);
+    size_t need_in = 0;
+    int max_rw = 0;
+    for (int i = 0; i < n; ++i) { need_in += ((size_t)img_h * rws[i] * 3 + 63) & ~(size_t)63; max_rw = std::max(max_rw, (int)rws[i]); }
+    const size_t need_desc = (desc_slot + n) * sizeof(pp::CropDesc), need_stage = stage_slot + stage, need_imgs = (desc_slot + n) * sizeof(pp::ResizedImg);
+    OAR_CHECK(need_stage <= crops_dev_.cap && need_in <= in_buf.cap && need_desc <= descs_dev_.cap && need_imgs <= imgs_dev_.cap && need_desc <= descs_host_.cap &&
+                  need_stage <= stage_host_.cap && need_imgs <= imgs_host_.cap, OAR_INTERNAL, "recognizer staging buffers must be pre-sized (run_batches)");
+    pp::CropDesc* dh = descs_host_.as<pp::CropDesc>() + desc_slot;
+    pp::CropDesc* dd = descs_dev_.as<pp::CropDesc>() + desc_slot;
+    pp::ResizedImg* ih = imgs_host_.as<pp::ResizedImg>() + desc_slot;
+    pp::ResizedImg* id = imgs_dev_.as<pp::ResizedImg>() + desc_slot;
+    size_t off = stage_slot, roff = 0;
+    for (int i = 0; i < n; ++i) {
+        const uint8_t* d = crops[i].dev;
+        if (!d) {
+            const size_t bytes = (size_t)crops[i].w * crops[i].h * 3;
+            std::memcpy(stage_host_.as<uint8_t>() + off, crops[i].host, bytes);
+            d = crops_dev_.as<uint8_t>() + off;
+            off += (bytes + 63) & ~(size_t)63;
+        }
+        dh[i].src = d; dh[i].w = (int)crops[i].w; dh[i].h = (int)crops[i].h; dh[i].rw = rws[i]; dh[i].pad = 0;
+        ih[i].ptr = in_buf.as<uint8_t>() + roff; ih[i].w = rws[i]; ih[i].pad = 0;
+        roff += ((size_t)img_h * rws[i] * 3 + 63) & ~(size_t)63;
+    }
+    if (stage) OAR_HIP(hipMemcpyAsync(crops_dev_.as<uint8_t>() + stage_slot, stage_host_.as<uint8_t>() + stage_slot, stage, hipMemcpyHostToDevice, s));
+    OAR_HIP(hipMemcpyAsync(dd, dh, (size_t)n * sizeof(pp::CropDesc), hipMemcpyHostToDevice, s));
+    OAR_HIP(hipMemcpyAsync(id, ih, (size_t)n * sizeof(pp::ResizedImg), hipMemcpyHostToDevice, s));
+    pp::rec_resize_u8(s, dd, id, n, img_h, max_rw);
+    return id;
+}
+
 void Recognizer::pack_only(const std::vector<Crop>& crops, std::vector<float>& nchw, uint32_t& Wt_out) {
     std::lock_guard<std::mutex> lk(mu_);
     OAR_HIP(hipSetDevice(eng_->device()));
@@ -1036,6 +1084,14 @@ void Recognizer::run_batches(const std::vector<std::vector<Crop>>& batches, std:
         if (max_in > lb->cap) { for (auto& le : lanes_) OAR_HIP(hipStreamSynchronize(le->stream())); lb->reserve(max_in); }
     descs_host_.reserve(total_crops * sizeof(pp::CropDesc));
     stage_host_.reserve(total_stage);
+    // the recognizer's stem fused with normalisation + padding (k::StemU8::dev) when the graph starts with an RGB convolution;
+    // OAR_REC_FUSE_STEM=0: the f32 input tensor is materialised by pp::rec_pack as before
+    const char* fuse_env = getenv("OAR_REC_FUSE_STEM");
+    const bool fuse_stem = !(fuse_env && fuse_env[0] == '0') && eng_->stem_fusable();
+    if (fuse_stem) {
+        if (total_crops * sizeof(pp::ResizedImg) > imgs_dev_.cap) { OAR_HIP(hipStreamSynchronize(s)); for (auto& le : lanes_) OAR_HIP(hipStreamSynchronize(le->stream())); imgs_dev_.reserve(total_crops * sizeof(pp::ResizedImg)); }
+        imgs_host_.reserve(total_crops * sizeof(pp::ResizedImg));
+    }
 
     struct Pending { size_t row0, rows; };
     std::vector<Pending> pend(batches.size(), Pending{0, 0});
@@ -1052,10 +1108,10 @@ void Recognizer::run_batches(const std::vector<std::vector<Crop>>& batches, std:
         Wts[bi] = host::rec_tensor_width(ws, hs, img_h, img_w, (int)cfg_.max_img_w, rws);
         // the fused tail mirrors the workgroup-per-row softmax kernel (vocab > 1024); smaller vocabularies keep the
         // unfused path so both seams stay bit-identical
-        const Plan& probe = eng_->plan_for({(int64_t)b.size(), 3, img_h, Wts[bi]}, true, false);
+        const Plan& probe = eng_->plan_for({(int64_t)b.size(), 3, img_h, Wts[bi]}, true, false, nullptr, fuse_stem);
         OAR_CHECK(!probe.outputs.empty(), OAR_INTERNAL, "CRNN: no output returned from inference");
         fuse_tail[bi] = probe.outputs[0].dims.size() == 3 && probe.outputs[0].dims[2] > 1024;
-        const Plan& plan = fuse_tail[bi] ? eng_->plan_for({(int64_t)b.size(), 3, img_h, Wts[bi]}, true, true) : probe;
+        const Plan& plan = fuse_tail[bi] ? eng_->plan_for({(int64_t)b.size(), 3, img_h, Wts[bi]}, true, true, nullptr, fuse_stem) : probe;
         const PlanOutput& po = plan.outputs[0];
         OAR_CHECK(po.dims.size() == 3, OAR_SHAPE_MISMATCH, "CRNN: expected 3D output (batch, time, vocab)");  // crnn.rs:273-279
         OAR_CHECK(po.dims[0] == (int64_t)b.size(), OAR_SHAPE_MISMATCH, "CRNN: output batch differs from input batch");
@@ -1081,10 +1137,19 @@ void Recognizer::run_batches(const std::vector<std::vector<Crop>>& batches, std:
         Engine& eng = lane_engine(lane);
         hipStream_t sl = eng.stream();
         int Wt = 0;
-        const float* in = pack(b, Wt, false, desc_slot, stage_slot, lane);
+        const float* in = nullptr;
+        const pp::ResizedImg* imgs = nullptr;
+        if (fuse_stem) imgs = pack_u8(b, Wt, desc_slot, stage_slot, lane);
+        else in = pack(b, Wt, false, desc_slot, stage_slot, lane);
         desc_slot += b.size();
         for (auto& c : b) if (!c.dev) stage_slot += ((size_t)c.w * c.h * 3 + 63) & ~(size_t)63;
-        const Plan& plan = eng.run(in, {(int64_t)b.size(), 3, img_h, Wt}, true, fuse_tail[bi] != 0);
+        k::StemU8 st{};
+        if (fuse_stem) {   // tensor channel c = source channel 2 - c (BGR), v -> (v / 255 - 0.5) / 0.5 (crnn.rs:98-121)
+            st.src[0] = 2; st.src[1] = 1; st.src[2] = 0;
+            st.dev = reinterpret_cast<const k::StemImg*>(imgs);
+        }
+        const Plan& plan = fuse_stem ? eng.run_stem(st, {(int64_t)b.size(), 3, img_h, Wt}, fuse_tail[bi] != 0)
+                                     : eng.run(in, {(int64_t)b.size(), 3, img_h, Wt}, true, fuse_tail[bi] != 0);
         if (pend[bi].rows == 0) continue;
         const PlanOutput& po = plan.outputs[0];
         if (plan.skipped_softmax && plan.ctc_part.kind != Loc::NONE)   // not even the logits hit HBM: merge the per-tile partials

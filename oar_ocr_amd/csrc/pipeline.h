@@ -153,6 +153,9 @@ class Recognizer {
 
    private:
     const float* pack(const std::vector<Crop>& crops, int& Wt, bool nchw, size_t desc_slot = 0, size_t stage_slot = 0, int lane = 0);
+    // the fused-stem form of pack: crops resized to u8 only (pp::rec_resize_u8); returns the device table the stem reads
+    const pp::ResizedImg* pack_u8(const std::vector<Crop>& crops, int& Wt, size_t desc_slot, size_t stage_slot, int lane);
+    DevBuf imgs_dev_; PinBuf imgs_host_;   // pp::ResizedImg per crop of a run (parallel to the CropDesc table)
     Engine& lane_engine(int lane) { return lane == 0 ? *eng_ : *lanes_[lane - 1]; }
     std::unique_ptr<Engine> eng_;
     // Recognition batches are independent: they are dealt round-robin to `1 + lanes_.size()` engines (own stream, own

@@ -24,6 +24,11 @@ struct CropDesc {          // one recognizer input crop (device-resident u8 HWC)
 // a16 models/recognition/crnn.rs:98-121 + simd.rs:248-308: Triangle resize to (rw x img_h), BGR (v/255-0.5)/0.5,
 // zero padding to Wt.  out layout: NHWC [n][img_h][Wt][3] (channel c = source channel 2-c) or NCHW when nchw != 0.
 void rec_pack(hipStream_t s, const CropDesc* d_descs, int n, int img_h, int Wt, float* out, int nchw);
+// The resize half of rec_pack alone: crop i -> img_h rows of d_descs[i].rw RGB pixels at d_dst[i] (u8, tightly packed).  The fused
+// recognizer stem (k::conv_smallcin_u8 with StemU8::dev) normalises and pads while it reads them: the f32 input tensor -- four
+// times the bytes, written once and read once -- never exists.
+struct ResizedImg { uint8_t* ptr; int32_t w; int32_t pad; };   // same layout as k::StemImg (kernels.h): one table serves both kernels
+void rec_resize_u8(hipStream_t s, const CropDesc* d_descs, const ResizedImg* d_dst, int n, int img_h, int max_rw);
 
 // image 0.25.6 imageops::resize(Triangle) on u8 RGB (processors/resize_detection.rs:314).
 void resize_triangle(hipStream_t s, const uint8_t* src, int w, int h, uint8_t* dst, int nw, int nh);

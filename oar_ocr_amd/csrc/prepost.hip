@@ -212,6 +212,24 @@ void rec_pack(hipStream_t s, const CropDesc* d_descs, int n, int img_h, int Wt, 
     hipLaunchKernelGGL(rec_pack_kernel, dim3(grid_for(plane, 256, 64), n), dim3(256), 0, s, d_descs, img_h, Wt, out, nchw);
 }
 
+__global__ __launch_bounds__(256) void rec_resize_u8_kernel(const CropDesc* descs, const ResizedImg* dst, int img_h) {
+    const int n = blockIdx.y;
+    const CropDesc d = descs[n];
+    uint8_t* out = dst[n].ptr;
+    const long plane = (long)img_h * d.rw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % d.rw), oy = (int)(i / d.rw);
+        uint8_t px[3];
+        resize_pixel(d.src, d.w, d.h, d.rw, img_h, ox, oy, px);
+        out[i * 3] = px[0]; out[i * 3 + 1] = px[1]; out[i * 3 + 2] = px[2];
+    }
+}
+void rec_resize_u8(hipStream_t s, const CropDesc* d_descs, const ResizedImg* d_dst, int n, int img_h, int max_rw) {
+    if (n == 0 || max_rw == 0) return;
+    ProfScope ps(s, "rec_pack", 3.0 * (double)n * img_h * max_rw, 0.0);
+    hipLaunchKernelGGL(rec_resize_u8_kernel, dim3(grid_for((long)img_h * max_rw, 256, 64), n), dim3(256), 0, s, d_descs, d_dst, img_h);
+}
+
 // ------------------------------------------------------------------------------------------ a7 threshold
 __global__ __launch_bounds__(256) void threshold_kernel(const float* __restrict__ pred, uint8_t* __restrict__ mask, long n, float thresh) {
     long n4 = n >> 2;

@@ -137,6 +137,26 @@ def test_fused_ctc_tail_matches_unfused(nets):
     np.testing.assert_allclose(got.probs.reshape(-1), pr, rtol=1e-5, atol=0)
 
 
+def test_fused_recognizer_stem_matches_the_packed_tensor_path(nets, monkeypatch):
+    """The recognizer reads u8 crops resized to their own width and normalises + pads inside its first convolution
+    (k::StemU8::dev) instead of going through the f32 tensor pp::rec_pack writes (OAR_REC_FUSE_STEM=0): the same input values
+    (the byte -> float table is rec_pack's expression, padding columns are zero after normalisation) in the same accumulation
+    order, so indices AND probabilities are identical, for mixed widths, very narrow crops, a taller-than-48 crop
+    (down-scaling) and a batch of one."""
+    _, rec, chars = nets
+    shapes = [(320, 48), (260, 40), (500, 44), (150, 30), (24, 20), (900, 61), (48, 48), (40, 16)]
+    crops = [pages.make_crop(60 + i, w, h) for i, (w, h) in enumerate(shapes)]
+    pred = api.TextRecognitionPredictor(rec, chars)
+    for batch in (crops, crops[:1], crops[4:6]):
+        fused = pred.predict(batch)
+        monkeypatch.setenv("OAR_REC_FUSE_STEM", "0")
+        plain = pred.predict(batch)
+        monkeypatch.delenv("OAR_REC_FUSE_STEM")
+        assert fused.texts == plain.texts
+        assert np.array_equal(fused.indices, plain.indices)
+        assert np.array_equal(fused.probs, plain.probs)
+
+
 def test_small_page_is_padded_like_the_reference(nets):
     """h + w < 64: DetResizeForTest pads with black to at least 32 x 32 before resizing (resize_detection.rs:174-176,
     204-220) while box coordinates keep scaling with the original size.  Mixed with a normal page in one call."""
