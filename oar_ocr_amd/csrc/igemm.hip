@@ -227,7 +227,9 @@ static int os_mode() { static const int m = [] { const char* e = getenv("OAR_IGE
 // (Cin % 8), wide and long enough to be matrix-pipe work, enough 256-pixel tiles to fill the chip, float4 epilogue
 static bool os_x6_eligible(long M, int K, int N, int Cin) {
     static const int min_k = [] { const char* e = getenv("OAR_IGEMM_OS_MINK"); return e ? atoi(e) : 256; }();
-    return Cin % 8 == 0 && K >= min_k && N >= 64 && (N & 3) == 0 && M >= 65536 && K < 65536;
+    // enough (256-pixel, 128-cout) tiles for the 512 workgroup slots of the chip: many pixels, or fewer pixels under a wide layer
+    const bool fills = M >= 65536 || (M >= 8192 && ((M + 255) / 256) * ((N + 127) / 128) >= 256);
+    return Cin % 8 == 0 && K >= min_k && N >= 64 && (N & 3) == 0 && fills && K < 65536;
 }
 
 int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin) {

@@ -296,6 +296,8 @@ def test_igemm_kernels_at_bench_shapes(case):
     ("os_x6 3x3 40->64 K tail", 1, 40, 64, 260, 260, 3, (1, 1), 1),     # K = 360: zero-padded tail of the last 32-deep chunk, Cin not a multiple of 32
     ("os_x6 3x3 dilated 64->80", 1, 64, 80, 264, 264, 3, (1, 1), 2),    # dilation 2 (padding 2), 5 cout fragments -> tile of 8 with 3 idle
     ("os_x6 5x5 16->64", 1, 16, 64, 272, 272, 5, (1, 1), 1),            # K = 400, taps straddle the 32-deep chunks
+    ("os_x6 1x1 512->512 few pixels", 1, 512, 512, 200, 192, 1, (1, 1), 1),   # M = 38400: eligible through the width of the layer
+    ("os_x6 1x1 1024->1024 fewer pixels", 1, 1024, 1024, 96, 100, 1, (1, 1), 1),   # M = 9600, 38 pixel tiles x 8 cout tiles
 ])
 def test_output_stationary_x6_kernel(case):
     """igemm_os_x6.hip (the layers whose weights do not fit LDS) against torch-CPU conv2d: image borders (zero taps), strides,
