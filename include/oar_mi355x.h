@@ -407,6 +407,17 @@ oar_status oar_k_box_scores(const float* pred, uint32_t height, uint32_t width, 
 oar_status oar_k_rotate_crop(const uint8_t* rgb, uint32_t w, uint32_t h, const float box[8], uint8_t* out,
                              size_t cap, uint32_t* out_w, uint32_t* out_h);
 
+/* ------------------------------------------------------------------------------------------------ image decode
+ * load_image_from_memory (oar-ocr-core/src/utils/image.rs:65-68: image::load_from_memory + DynamicImage::to_rgb8) for the
+ * formats this library decodes itself: PNG, every colour type / bit depth / interlace mode, to the bytes the image crate
+ * yields (palette and low-bit grey expanded, alpha dropped, 16-bit -> 8-bit as (v + 128) / 257).  *rgb receives width * height * 3
+ * bytes owned by the library (release with oar_image_free).  Errors: OAR_INVALID_INPUT = OCRError::ImageLoad (corrupt /
+ * truncated data, CRC mismatch); OAR_UNSUPPORTED_OP = a format of the image crate that is not decoded here (JPEG, BMP, ...; the
+ * message names it) -- keep the reference's loader for those.  Thread-safe, no lock: decode a batch from as many threads as the
+ * reference's rayon pool would use (utils/image.rs:299-345). */
+oar_status oar_image_decode(const uint8_t* bytes, size_t len, uint8_t** rgb, uint32_t* width, uint32_t* height);
+void oar_image_free(uint8_t* rgb);
+
 /* ------------------------------------------------------------------------------------------------ host-side geometry hooks
  * The serial per-contour stages of DB post-processing and crop planning run on the host.
  * These hooks expose them WITHOUT touching a GPU so the CPU test-suite can check them against the oracle.

@@ -12,6 +12,7 @@ when the HIP library is missing, and every call fails with OCRError(code=OAR_DEV
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from pathlib import Path
 from typing import List, Optional, Sequence
@@ -126,7 +127,7 @@ EXPORTS = [
     "oar_rect_run", "oar_ocr_attach", "oar_k_rotate_rgb", "oar_k_bgr_planes_to_rgb", "oar_host_rotate_back_points",
     "oar_engine_cache_stats", "oar_onnx_inspect", "oar_host_contours", "oar_ctc_dict_create", "oar_ctc_dict_destroy", "oar_ctc_dict_classes",
     "oar_ctc_decode", "oar_ocr_decode", "oar_text_result_free", "oar_db_postprocess_ex", "oar_k_dilate", "oar_k_poly_scores", "oar_debug_inject_failure", "oar_k_contours", "oar_host_contours_bits",
-    "oar_k_unclip", "oar_host_approx_poly_dp", "oar_host_perimeter", "oar_host_unclip_poly", "oar_host_offset_ring", "oar_host_ring_outline", "oar_host_sort_poly_boxes",
+    "oar_k_unclip", "oar_image_decode", "oar_image_free", "oar_host_approx_poly_dp", "oar_host_perimeter", "oar_host_unclip_poly", "oar_host_offset_ring", "oar_host_ring_outline", "oar_host_sort_poly_boxes",
 ]
 
 
@@ -196,6 +197,9 @@ def lib():
     L.oar_k_ctc_argmax.argtypes = [vp, C.c_size_t, C.c_size_t, vp, vp]
     L.oar_k_box_scores.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp]
     L.oar_k_unclip.argtypes = [vp, C.c_uint32, C.c_float, vp, vp, C.c_uint32]
+    L.oar_image_decode.argtypes = [vp, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.oar_image_free.argtypes = [C.POINTER(C.c_uint8)]
+    L.oar_image_free.restype = None
     L.oar_k_rotate_crop.argtypes = [vp, C.c_uint32, C.c_uint32, f32p, vp, C.c_size_t, u32p, u32p]
     L.oar_host_candidates.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, vp, C.c_int32]
     L.oar_host_candidates.restype = C.c_int32
@@ -263,6 +267,41 @@ def _check(st: int):
         buf = C.create_string_buffer(4096)
         lib().oar_last_error(buf, 4096)
         raise OCRError(st, buf.value.decode(errors="replace"))
+
+
+# ------------------------------------------------------------------------------------------------ image loading
+DEFAULT_PARALLEL_THRESHOLD = 4   # core/constants.rs:18
+
+
+def load_image_from_memory(data: bytes) -> np.ndarray:
+    """utils/image.rs:65-68: encoded bytes -> [H, W, 3] u8 (RgbImage).  PNG is decoded by the library to the bytes image 0.25.6
+    yields; other formats raise OCRError with OAR_UNSUPPORTED_OP (the message names the format)."""
+    buf = (C.c_char * len(data)).from_buffer_copy(data) if len(data) else (C.c_char * 1)()
+    out = C.POINTER(C.c_uint8)()
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    _check(lib().oar_image_decode(C.cast(buf, C.c_void_p), len(data), C.byref(out), C.byref(w), C.byref(h)))
+    try:
+        return np.ctypeslib.as_array(out, shape=(h.value, w.value, 3)).copy()
+    finally:
+        lib().oar_image_free(out)
+
+
+def load_image(path) -> np.ndarray:
+    """utils/image.rs:87-92"""
+    with open(path, "rb") as f:
+        return load_image_from_memory(f.read())
+
+
+def load_images(paths, parallel_threshold: Optional[int] = None) -> List[np.ndarray]:
+    """utils/image.rs:299-345: sequential up to the threshold, in parallel above it (the decoder holds no lock and ctypes
+    releases the GIL, so the threads really overlap, like the reference's rayon pool); any failure fails the call."""
+    paths = list(paths)
+    thr = DEFAULT_PARALLEL_THRESHOLD if parallel_threshold is None else parallel_threshold
+    if len(paths) > thr:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(paths), os.cpu_count() or 4)) as ex:
+            return list(ex.map(load_image, paths))
+    return [load_image(p) for p in paths]
 
 
 def version() -> str:

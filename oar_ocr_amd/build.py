@@ -14,7 +14,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIBDIR = HERE / "lib"
 LIB = LIBDIR / "libOarMi355x.so"
-SOURCES = ["common.cc", "onnx_parse.cc", "engine.cc", "db_host.cc", "poly_host.cc", "pipeline.cc", "c_api.cc", "ctc_host.cc", "kernels.hip", "igemm.hip", "igemm_ws_1x1.hip", "igemm_ws_gen.hip", "igemm_ws_x6.hip", "igemm_os_x6.hip", "igemm_ws3.hip", "prepost.hip", "contours.hip", "dsblock.hip", "dsblock_k3s1.hip", "dsblock_k3s2.hip", "dsblock_k5s1.hip", "dsblock_k5s2.hip"]
+SOURCES = ["common.cc", "onnx_parse.cc", "engine.cc", "db_host.cc", "poly_host.cc", "pipeline.cc", "c_api.cc", "ctc_host.cc", "image_decode.cc", "kernels.hip", "igemm.hip", "igemm_ws_1x1.hip", "igemm_ws_gen.hip", "igemm_ws_x6.hip", "igemm_os_x6.hip", "igemm_ws3.hip", "prepost.hip", "contours.hip", "dsblock.hip", "dsblock_k3s1.hip", "dsblock_k3s2.hip", "dsblock_k5s1.hip", "dsblock_k5s2.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wno-unused-result", "-Wno-pass-failed"]
@@ -54,7 +54,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> Path:
             list(ex.map(cc, jobs))
     objs = [objdir / (s.replace(".", "_") + ".o") for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + [str(o) for o in objs] + ["-lpthread"]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + [str(o) for o in objs] + ["-lpthread", "-lz"]   # zlib: the PNG decoder's inflate / crc32 (image_decode.cc)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")

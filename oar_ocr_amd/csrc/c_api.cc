@@ -18,6 +18,12 @@ struct oar_ocr { std::unique_ptr<Ocr> o; };
 struct oar_cls { std::unique_ptr<Classifier> c; };
 struct oar_rect { std::unique_ptr<Rectifier> r; };
 
+namespace oar { namespace img {
+bool is_png(const uint8_t* b, size_t n);
+const char* sniff(const uint8_t* b, size_t n);
+void decode_png(const uint8_t* b, size_t n, std::vector<uint8_t>& rgb, uint32_t& width, uint32_t& height);
+} }
+
 namespace {
 template <typename F>
 oar_status guard(F&& f) {
@@ -977,6 +983,25 @@ int32_t oar_host_unclip(const float box8[8], float ratio, float* out_xy, int32_t
         return (int32_t)r.size();
     } catch (...) { return -1; }
 }
+oar_status oar_image_decode(const uint8_t* bytes, size_t len, uint8_t** rgb, uint32_t* width, uint32_t* height) {
+    return guard([&] {
+        OAR_CHECK(bytes && rgb && width && height, OAR_INVALID_INPUT, "oar_image_decode: bad arguments");
+        *rgb = nullptr; *width = *height = 0;
+        if (!img::is_png(bytes, len)) {
+            const char* what = img::sniff(bytes, len);
+            if (what) fail(OAR_UNSUPPORTED_OP, std::string("image load: ") + what + " is not decoded by this library (PNG is); use the reference's loader for it");
+            fail(OAR_INVALID_INPUT, "image load: unrecognised image format");
+        }
+        std::vector<uint8_t> px;
+        uint32_t w = 0, h = 0;
+        img::decode_png(bytes, len, px, w, h);
+        uint8_t* out = cmalloc<uint8_t>(px.size());
+        std::memcpy(out, px.data(), px.size());
+        *rgb = out; *width = w; *height = h;
+    });
+}
+void oar_image_free(uint8_t* rgb) { std::free(rgb); }
+
 int32_t oar_host_approx_poly_dp(const float* xy, int32_t n_points, float epsilon, float* out_xy, int32_t cap_points) {
     try {
         std::vector<host::Pt> p(n_points > 0 ? n_points : 0);

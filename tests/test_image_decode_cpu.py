@@ -1,0 +1,178 @@
+"""SURVEY 8f-3 -- load_image_from_memory / load_image(s) (oar-ocr-core/src/utils/image.rs:65-92, 299-345) for PNG input.
+
+The files are written HERE by a small encoder (every colour type, bit depth, filter type, Adam7, split IDAT, ancillary chunks), so
+the expected RGB8 pixels are known from the source arrays and the three conversion rules of the image crate; the product decoder
+(csrc/image_decode.cc), the oracle (oracle/png_ref.py: zlib + numpy) and PIL (an independent implementation, where it implements
+the same conversion) must all agree with them.  No GPU involved."""
+import io
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from oar_ocr_amd import api
+from oracle import png_ref
+
+ADAM7 = ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2))
+CHANNELS = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}
+
+
+def chunk(kind: bytes, body: bytes) -> bytes:
+    return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body))
+
+
+def pack_row(samples: np.ndarray, depth: int) -> bytes:
+    """samples: [n] ints of one scanline (all channels interleaved) -> the scanline's bytes"""
+    if depth == 8:
+        return samples.astype(np.uint8).tobytes()
+    if depth == 16:
+        return samples.astype(">u2").tobytes()
+    bits = ((samples[:, None].astype(np.uint32) >> np.arange(depth - 1, -1, -1)) & 1).astype(np.uint8).reshape(-1)
+    return np.packbits(bits).tobytes()
+
+
+def paeth(a, b, c):
+    p = a + b - c
+    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+    return a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+
+
+def filter_row(ft, cur: bytes, prev: bytes, bpp: int) -> bytes:
+    out = bytearray(len(cur))
+    for i in range(len(cur)):
+        a = cur[i - bpp] if i >= bpp else 0
+        b = prev[i] if prev else 0
+        c = prev[i - bpp] if (prev and i >= bpp) else 0
+        pred = (0, a, b, (a + b) // 2, paeth(a, b, c))[ft]
+        out[i] = (cur[i] - pred) & 255
+    return bytes(out)
+
+
+def encode_png(samples: np.ndarray, color: int, depth: int, interlace=False, rng=None, plte=None, extra=(), idat_split=1):
+    """samples: [H, W, channels] integer samples at `depth` bits (palette: indices).  Filters are chosen at random per scanline."""
+    rng = rng or np.random.default_rng(0)
+    h, w, ch = samples.shape
+    assert ch == CHANNELS[color]
+    bpp = max(1, ch * depth // 8)
+    raw = bytearray()
+    for x0, y0, dx, dy in (ADAM7 if interlace else ((0, 0, 1, 1),)):
+        sub = samples[y0::dy, x0::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        prev = None
+        for r in range(sub.shape[0]):
+            cur = pack_row(sub[r].reshape(-1), depth)
+            ft = int(rng.integers(0, 5))
+            raw.append(ft)
+            raw += filter_row(ft, cur, prev, bpp)
+            prev = cur
+    z = zlib.compress(bytes(raw), 6)
+    cuts = [len(z) * k // idat_split for k in range(idat_split + 1)]
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color, 0, 0, 1 if interlace else 0))
+    for kind, body in extra:
+        out += chunk(kind, body)
+    if plte is not None:
+        out += chunk(b"PLTE", plte.astype(np.uint8).tobytes())
+    for k in range(idat_split):
+        out += chunk(b"IDAT", z[cuts[k]:cuts[k + 1]])
+    return out + chunk(b"IEND", b"")
+
+
+def expected_rgb8(samples, color, depth, plte=None):
+    """the conversion rules of png (EXPAND) + image (to_rgb8), applied to the source samples"""
+    s = samples.astype(np.uint32)
+    if color == 3:
+        return plte[s[:, :, 0]].astype(np.uint8)
+    v = ((s + 128) // 257) if depth == 16 else s if depth == 8 else s * (255 // ((1 << depth) - 1))
+    v = v.astype(np.uint8)
+    return np.repeat(v[:, :, :1], 3, 2) if color in (0, 4) else v[:, :, :3]
+
+
+CASES = [(0, d) for d in (1, 2, 4, 8, 16)] + [(2, 8), (2, 16), (3, 1), (3, 2), (3, 4), (3, 8), (4, 8), (4, 16), (6, 8), (6, 16)]
+
+
+@pytest.mark.parametrize("color,depth", CASES)
+@pytest.mark.parametrize("interlace", [False, True])
+def test_png_decodes_to_the_image_crates_rgb8(color, depth, interlace):
+    rng = np.random.default_rng(color * 100 + depth + (7 if interlace else 0))
+    for (h, w) in ((1, 1), (5, 3), (9, 17), (33, 40)):
+        ch = CHANNELS[color]
+        plte = rng.integers(0, 256, (min(256, 1 << depth), 3)).astype(np.uint8) if color == 3 else None
+        samples = rng.integers(0, 1 << depth, (h, w, ch))
+        extra = ((b"gAMA", struct.pack(">I", 45455)), (b"tRNS", bytes(rng.integers(0, 256, len(plte) if color == 3 else 2 * (1 if color == 0 else 3)).astype(np.uint8))))
+        if color in (4, 6):
+            extra = extra[:1]                       # tRNS is not allowed next to a real alpha channel
+        data = encode_png(samples, color, depth, interlace, rng, plte, extra, idat_split=int(rng.integers(1, 4)))
+        want = expected_rgb8(samples, color, depth, plte)
+        got = api.load_image_from_memory(data)
+        assert got.shape == (h, w, 3) and got.dtype == np.uint8
+        assert np.array_equal(got, want), (color, depth, interlace, h, w)
+        assert np.array_equal(png_ref.decode_png_rgb8(data), want)
+
+
+@pytest.mark.parametrize("mode", ["RGB", "RGBA", "L", "LA", "P", "1"])
+def test_png_files_written_by_pil_and_pil_as_an_independent_decoder(mode):
+    from PIL import Image
+    rng = np.random.default_rng(len(mode))
+    rgb = rng.integers(0, 256, (47, 61, 3)).astype(np.uint8)
+    im = Image.fromarray(rgb).convert(mode)
+    for opts in (dict(), dict(optimize=True), dict(compress_level=1)):
+        buf = io.BytesIO()
+        im.save(buf, format="PNG", **opts)
+        data = buf.getvalue()
+        got = api.load_image_from_memory(data)
+        assert np.array_equal(got, png_ref.decode_png_rgb8(data))
+        # PIL's own conversion to RGB agrees wherever alpha is not involved in it (PIL drops alpha like to_rgb8 does)
+        assert np.array_equal(got, np.asarray(Image.open(io.BytesIO(data)).convert("RGB")))
+
+
+def test_damaged_files_are_image_load_errors_not_pixels():
+    rng = np.random.default_rng(3)
+    good = encode_png(rng.integers(0, 256, (12, 12, 3)), 2, 8)
+    assert api.load_image_from_memory(good).shape == (12, 12, 3)
+    bad_crc = bytearray(good); bad_crc[40] ^= 1
+    truncated = good[:len(good) - 20]
+    no_idat = good[:33] + chunk(b"IEND", b"")
+    short_stream = encode_png(rng.integers(0, 256, (12, 12, 3)), 2, 8)
+    short_stream = short_stream[:16] + struct.pack(">II", 12, 13) + short_stream[24:29]     # IHDR says 13 rows, the data holds 12
+    short_stream = short_stream[:12] + short_stream[12:29] + struct.pack(">I", zlib.crc32(short_stream[12:29])) + good[33:]
+    for blob in (bytes(bad_crc), truncated, no_idat, short_stream, good[:8], b"", b"not an image at all"):
+        with pytest.raises(api.OCRError) as e:
+            api.load_image_from_memory(blob)
+        assert e.value.code == api.OAR_INVALID_INPUT, blob[:16]
+
+
+def test_formats_of_the_image_crate_that_are_not_decoded_here_say_so():
+    for name, head in (("JPEG", b"\xff\xd8\xff\xe0\x00\x10JFIF"), ("BMP", b"BM" + b"\0" * 30), ("GIF", b"GIF89a" + b"\0" * 20), ("WebP", b"RIFF\0\0\0\0WEBPVP8 "),
+                       ("TIFF", b"II*\0" + b"\0" * 20), ("PNM", b"P6\n1 1\n255\n\0\0\0")):
+        with pytest.raises(api.OCRError) as e:
+            api.load_image_from_memory(head)
+        assert e.value.code == api.OAR_UNSUPPORTED_OP and name in e.value.message
+
+
+def test_load_images_sequential_and_parallel(tmp_path):
+    rng = np.random.default_rng(9)
+    arrays, paths = [], []
+    for i in range(9):
+        a = rng.integers(0, 256, (20 + i, 30 + 2 * i, 3))
+        arrays.append(a.astype(np.uint8))
+        p = tmp_path / f"page_{i}.png"
+        p.write_bytes(encode_png(a, 2, 8, interlace=bool(i % 2), rng=rng))
+        paths.append(p)
+    assert np.array_equal(api.load_image(paths[0]), arrays[0])
+    for thr in (None, 100, 0):          # above the default threshold of 4 -> parallel; forced sequential; forced parallel
+        got = api.load_images(paths, parallel_threshold=thr)
+        assert len(got) == 9 and all(np.array_equal(g, a) for g, a in zip(got, arrays))     # order preserved
+    with pytest.raises(FileNotFoundError):
+        api.load_images(paths + [tmp_path / "missing.png"])
+    (tmp_path / "broken.png").write_bytes(paths[0].read_bytes()[:50])
+    with pytest.raises(api.OCRError):
+        api.load_images(paths + [tmp_path / "broken.png"])
+
+
+def test_decoded_page_goes_straight_into_the_pipeline_types():
+    """what load_image returns is what the predictors take: HxWx3 uint8, C-contiguous"""
+    a = np.random.default_rng(1).integers(0, 256, (8, 8, 3))
+    img = api.load_image_from_memory(encode_png(a, 2, 8))
+    assert img.flags["C_CONTIGUOUS"] and img.dtype == np.uint8 and img.shape == (8, 8, 3)
