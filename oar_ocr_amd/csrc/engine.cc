@@ -586,11 +586,22 @@ struct Planner {
         step([=](const RunCtx& c) { k::resize(c.s, c.at(q.xin), c.mut(yl) + y_off, q.N, q.H, q.W, q.C, q.Ho, q.Wo, q.sh, q.sw, q.imode, q.ictm, q.inm, y_ld); }, 0,
              4.0 * ((double)q.N * q.H * q.W * q.C + (double)q.N * q.Ho * q.Wo * q.C));
     }
+    // A 2x2 / stride-2 ConvTranspose whose only consumer is another one (the DB head's tail) is held back the same way: the
+    // consumer runs both as k::convt2x2_pair, anything else runs it first.
+    std::map<std::string, const GNode*> pending_convt;
     const PendingResize* peek_pending(const std::string& name) const {
         auto it = pending_resize.find(name);
         return it == pending_resize.end() ? nullptr : &it->second;
     }
     void materialise_pending(const std::string& name) {
+        auto ct = pending_convt.find(name);
+        if (ct != pending_convt.end()) {
+            const GNode* node = ct->second;
+            pending_convt.erase(ct);
+            vals.erase(name);
+            op_convt(*node, /*may_defer=*/false);
+            return;
+        }
         auto it = pending_resize.find(name);
         if (it == pending_resize.end()) return;
         const PendingResize r = it->second;
@@ -601,7 +612,7 @@ struct Planner {
 
     // ------------------------------------------------------------------ values
     TInfo& get(const std::string& name) {
-        if (!pending_resize.empty()) materialise_pending(name);
+        if (!pending_resize.empty() || !pending_convt.empty()) materialise_pending(name);
         auto it = vals.find(name);
         if (it != vals.end()) return it->second;
         auto ii = E.inits_.find(name);
@@ -964,7 +975,76 @@ struct Planner {
         }, flops, bytes);
     }
 
-    void op_convt(const GNode& n) {
+    // shape facts of a ConvTranspose node that decide whether it is the plain 2x2 / stride-2 kind
+    bool convt_is_2x2s2(const GNode& n, int64_t& cin, int64_t& cout) {
+        auto wi = E.inits_.find(n.in.size() > 1 ? n.in[1] : std::string());
+        if (wi == E.inits_.end() || wi->second.dtype != DType::F32 || wi->second.dims.size() != 4) return false;
+        const auto& d = wi->second.dims;
+        auto st = n.ais("strides"), dl = n.ais("dilations"), pads = n.ais("pads"), op = n.ais("output_padding");
+        const bool s2 = st.size() == 2 && st[0] == 2 && st[1] == 2;
+        bool zero = true;
+        for (auto v : pads) zero = zero && v == 0;
+        for (auto v : op) zero = zero && v == 0;
+        for (auto v : dl) zero = zero && v == 1;
+        cin = d[0]; cout = d[1];
+        return d[2] == 2 && d[3] == 2 && s2 && zero && n.ai("group", 1) == 1 && n.residual.empty();
+    }
+    void op_convt(const GNode& n, bool may_defer = true) {
+        static const bool pair_on = [] { const char* e = getenv("OAR_FUSE_CONVT_PAIR"); return !e || atoi(e) != 0; }();
+        // (a) this node's input is a held-back ConvTranspose: run the pair as one kernel
+        if (pair_on && !n.in.empty() && pending_convt.count(n.in[0])) {
+            const GNode& a = *pending_convt[n.in[0]];
+            int64_t c0 = 0, c1 = 0, c1b = 0, c2 = 0;
+            if (convt_is_2x2s2(a, c0, c1) && convt_is_2x2s2(n, c1b, c2) && c1 == c1b && k::convt2x2_pair_supported((int)c0, (int)c1, (int)c2)) {
+                TInfo x = get(a.in[0]);
+                if (x.dims.size() == 4 && x.dims[1] == c0 && x.layout == Layout::CLAST && !x.host_int) {
+                    pending_convt.erase(n.in[0]);
+                    vals.erase(n.in[0]);
+                    const HostTensor& W1 = E.inits_.at(a.in[1]);
+                    const HostTensor& W2 = E.inits_.at(n.in[1]);
+                    auto pack = [&](const std::string& key, const HostTensor& W) {   // [Cin][Cout][2][2] -> [Cin][a * 2 + b][Cout]
+                        auto it = E.dev_consts_.find(key);
+                        if (it != E.dev_consts_.end()) return it->second;
+                        const int64_t Ci = W.dims[0], Co = W.dims[1];
+                        std::vector<float> w((size_t)Ci * 4 * Co);
+                        for (int64_t ci = 0; ci < Ci; ++ci)
+                            for (int64_t co = 0; co < Co; ++co)
+                                for (int64_t q = 0; q < 4; ++q) w[(size_t)((ci * 4 + q) * Co + co)] = W.f[(size_t)((ci * Co + co) * 4 + q)];
+                        return E.upload_const(key, w);
+                    };
+                    k::ConvT2Pair cp{};
+                    cp.w1 = pack("convt_pair1:" + a.in[1], W1);
+                    cp.w2 = pack("convt_pair2:" + n.in[1], W2);
+                    cp.b1 = has_input(a, 2) ? get(a.in[2]).loc.cptr : nullptr;
+                    cp.b2 = has_input(n, 2) ? get(n.in[2]).loc.cptr : nullptr;
+                    cp.N = (int)x.dims[0]; cp.H = (int)x.dims[2]; cp.W = (int)x.dims[3]; cp.C0 = (int)c0; cp.C1 = (int)c1; cp.C2 = (int)c2;
+                    cp.act1 = a.act; cp.act2 = n.act;
+                    const Loc xin = x.loc;
+                    TInfo& y = new_out(n.out[0], {x.dims[0], c2, x.dims[2] * 4, x.dims[3] * 4}, Layout::CLAST);
+                    const Loc yl = y.loc;
+                    const double px = (double)x.dims[0] * x.dims[2] * x.dims[3];
+                    step([=](const RunCtx& c) { k::ConvT2Pair q = cp; q.x = c.at(xin); q.y = c.mut(yl); k::convt2x2_pair(c.s, q); },
+                         2.0 * px * 4.0 * ((double)c0 * c1 + 4.0 * c1 * c2), 4.0 * px * (c0 + 16.0 * c2));
+                    return;
+                }
+            }
+        }
+        // (b) this node may itself be held back for its consumer
+        if (pair_on && may_defer && sole_consumer.count(n.out[0]) && E.nodes_[sole_consumer[n.out[0]]].op == "ConvTranspose") {
+            int64_t c0 = 0, c1 = 0, c1b = 0, c2 = 0;
+            const GNode& b = E.nodes_[sole_consumer[n.out[0]]];
+            const bool feeds_first = !b.in.empty() && b.in[0] == n.out[0];
+            auto xi = vals.find(n.in[0]);
+            if (feeds_first && convt_is_2x2s2(n, c0, c1) && convt_is_2x2s2(b, c1b, c2) && c1 == c1b && k::convt2x2_pair_supported((int)c0, (int)c1, (int)c2) &&
+                xi != vals.end() && !peek_pending(n.in[0]) && !pending_convt.count(n.in[0]) && xi->second.dims.size() == 4 && xi->second.layout == Layout::CLAST) {
+                pending_convt[n.out[0]] = &n;
+                TInfo t;   // known shape, no storage
+                t.dims = {xi->second.dims[0], c1, xi->second.dims[2] * 2, xi->second.dims[3] * 2};
+                t.layout = Layout::CLAST; t.root = "";
+                vals[n.out[0]] = t;
+                return;
+            }
+        }
         TInfo x = get(n.in[0]);
         OAR_CHECK(x.dims.size() == 4, OAR_UNSUPPORTED_OP, "ConvTranspose: only 2-D");
         const TInfo& wt = get(n.in[1]);
@@ -2046,7 +2126,7 @@ struct Planner {
             }
             for (int i = 0; i < (int)E.nodes_.size(); ++i) {
                 const GNode& n = E.nodes_[i];
-                if (n.op != "Resize" || n.out.empty() || n.in.empty()) continue;
+                if ((n.op != "Resize" && n.op != "ConvTranspose") || n.out.empty() || n.in.empty()) continue;
                 auto u = uses.find(n.out[0]);
                 if (u == uses.end() || u->second.first != 1) continue;
                 if (std::find(E.output_names_.begin(), E.output_names_.end(), n.out[0]) != E.output_names_.end()) continue;
@@ -2149,7 +2229,7 @@ struct Planner {
     void dispatch(const GNode& n) {
         const std::string& op = n.op;
         // shape / kind of an input without forcing a deferred Resize to run (its consumer decides that)
-        auto info = [&](const std::string& s) -> const TInfo& { return peek_pending(s) ? vals.find(s)->second : get(s); };
+        auto info = [&](const std::string& s) -> const TInfo& { return (peek_pending(s) || pending_convt.count(s)) ? vals.find(s)->second : get(s); };
         bool host_inputs = !n.in.empty();
         for (auto& s : n.in) if (!s.empty()) host_inputs = host_inputs && info(s).host_int;
         if (op == "Shape") {

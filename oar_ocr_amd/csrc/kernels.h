@@ -56,6 +56,17 @@ void conv_direct(hipStream_t s, const ConvP& p);
 struct StemImg { const uint8_t* ptr; int32_t w; int32_t pad; };
 struct StemU8 { const uint8_t* pages[32]; int src[3]; float alpha[3], beta[3]; const StemImg* dev = nullptr; };
 void conv_smallcin_u8(hipStream_t s, const ConvP& p, const StemU8& st);
+// Two stacked ConvTranspose 2x2 / stride 2 layers as one kernel -- the tail of the DB head (C/4 -> C/4 -> 1 channels): the
+// intermediate map, 4x the input's pixels, never leaves the registers.  x: [N, H, W, C0] NHWC; w1: [C0][4][C1] (4 = a * 2 + b of
+// the first layer), w2: [C1][4][C2]; y: [N, 4H, 4W, C2] NHWC.  C0, C1 % 4 == 0, C1 <= 32, C2 <= 4.
+struct ConvT2Pair {
+    const float* x; float* y;
+    const float *w1, *b1, *w2, *b2;   // biases may be null
+    int N, H, W, C0, C1, C2;
+    Act act1, act2;
+};
+bool convt2x2_pair_supported(int C0, int C1, int C2);
+void convt2x2_pair(hipStream_t s, const ConvT2Pair& p);
 // General ConvTranspose (gather form). w: [kh][kw][Cin][Cout] (groups == 1), output_padding folded in Ho/Wo.
 void convt_direct(hipStream_t s, const ConvP& p);
 

@@ -364,6 +364,82 @@ void conv_direct(hipStream_t s, const ConvP& p) {
     hipLaunchKernelGGL(conv_direct_kernel, dim3(grid_for(total)), dim3(256), 0, s, p);
 }
 
+// ------------------------------------------------------------------------------------------ ConvTranspose 2x2 s2, twice (DB head tail)
+// One thread = one input pixel x one position (a, b) of the first layer: C1 mid values in registers (bias, then ci ascending),
+// activation, then the 2 x 2 block of the second layer for each of its C2 channels (bias, then cm ascending).  Both weight sets sit
+// in LDS.  Consecutive lanes walk (b, then w): a wave writes whole contiguous runs of two output rows.
+template <int C1>
+__global__ __launch_bounds__(256) void convt2x2_pair_kernel(ConvT2Pair p) {
+    extern __shared__ float4 cp_lds[];
+    float4* w1 = cp_lds;                                                  // [C0][4][C1 / 4]
+    float* w2 = reinterpret_cast<float*>(cp_lds + (long)p.C0 * C1);       // [C1][4][C2]
+    for (int i = threadIdx.x; i < p.C0 * C1; i += blockDim.x) w1[i] = reinterpret_cast<const float4*>(p.w1)[i];
+    for (int i = threadIdx.x; i < C1 * 4 * p.C2; i += blockDim.x) w2[i] = p.w2[i];
+    __syncthreads();
+    const long total = (long)p.N * p.H * p.W * 4;
+    const int Wo = p.W * 4, Ho = p.H * 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        // i = ((n * H + h) * 2 + a) * (2 W) + w * 2 + b : lanes sweep one row of first-layer outputs
+        const int wb = (int)(i % (2 * p.W));
+        const long t = i / (2 * p.W);
+        const int a = (int)(t & 1);
+        const long nh = t >> 1;
+        const int h = (int)(nh % p.H);
+        const long n = nh / p.H;
+        const int w = wb >> 1, b = wb & 1, pos = a * 2 + b;
+        const float* xp = p.x + ((n * p.H + h) * (long)p.W + w) * p.C0;
+        float mid[C1];
+#pragma unroll
+        for (int c = 0; c < C1; ++c) mid[c] = p.b1 ? p.b1[c] : 0.f;
+        for (int c4 = 0; c4 < p.C0; c4 += 4) {
+            const float4 xv = *reinterpret_cast<const float4*>(xp + c4);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float4* wr = w1 + ((long)(c4 + e) * 4 + pos) * (C1 / 4);
+#pragma unroll
+                for (int q = 0; q < C1 / 4; ++q) {
+                    const float4 wv = wr[q];
+                    mid[q * 4 + 0] = fmaf(xs[e], wv.x, mid[q * 4 + 0]); mid[q * 4 + 1] = fmaf(xs[e], wv.y, mid[q * 4 + 1]);
+                    mid[q * 4 + 2] = fmaf(xs[e], wv.z, mid[q * 4 + 2]); mid[q * 4 + 3] = fmaf(xs[e], wv.w, mid[q * 4 + 3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C1; ++c) mid[c] = apply_act(mid[c], p.act1.kind, p.act1.alpha, p.act1.beta);
+        // second layer: this thread's first-layer pixel is (2h + a, 2w + b); its 2 x 2 block starts at (4h + 2a, 4w + 2b)
+        const long orow = (n * Ho + 4 * h + 2 * a) * (long)Wo + 4 * w + 2 * b;
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2)
+                for (int co = 0; co < p.C2; ++co) {
+                    float acc = p.b2 ? p.b2[co] : 0.f;
+#pragma unroll
+                    for (int c = 0; c < C1; ++c) acc = fmaf(mid[c], w2[(c * 4 + a2 * 2 + b2) * p.C2 + co], acc);
+                    p.y[(orow + (long)a2 * Wo + b2) * p.C2 + co] = apply_act(acc, p.act2.kind, p.act2.alpha, p.act2.beta);
+                }
+    }
+}
+bool convt2x2_pair_supported(int C0, int C1, int C2) {
+    return C0 > 0 && (C0 & 3) == 0 && (C1 == 8 || C1 == 16 || C1 == 24 || C1 == 32) && C2 >= 1 && C2 <= 4 && (size_t)C0 * C1 * 16 + (size_t)C1 * 4 * C2 * 4 <= 60 * 1024;
+}
+void convt2x2_pair(hipStream_t s, const ConvT2Pair& p) {
+    const long total = (long)p.N * p.H * p.W * 4;
+    if (total == 0) return;
+    OAR_CHECK(convt2x2_pair_supported(p.C0, p.C1, p.C2), OAR_INTERNAL, "convt2x2_pair: unsupported channel counts");
+    const size_t lds = (size_t)p.C0 * p.C1 * 16 + (size_t)p.C1 * 4 * p.C2 * 4;
+    const double px = (double)p.N * p.H * p.W;
+    ProfScope ps(s, "convt_pair", 4.0 * px * (p.C0 + 16.0 * p.C2), 2.0 * px * 4.0 * ((double)p.C0 * p.C1 + 4.0 * p.C1 * p.C2));
+    const dim3 grid(grid_for(total, 256, 256L * 8));
+    switch (p.C1) {
+        case 8: hipLaunchKernelGGL(convt2x2_pair_kernel<8>, grid, dim3(256), lds, s, p); break;
+        case 16: hipLaunchKernelGGL(convt2x2_pair_kernel<16>, grid, dim3(256), lds, s, p); break;
+        case 24: hipLaunchKernelGGL(convt2x2_pair_kernel<24>, grid, dim3(256), lds, s, p); break;
+        default: hipLaunchKernelGGL(convt2x2_pair_kernel<32>, grid, dim3(256), lds, s, p); break;
+    }
+}
+
 // General ConvTranspose, gather form: y[n,oh,ow,co] = sum_{a,b,ci} x[n,(oh+pt-a*dh)/sh,(ow+pl-b*dw)/sw,ci] * w[a][b][ci][co]
 __global__ __launch_bounds__(256) void convt_direct_kernel(ConvP p) {
     long total = (long)p.N * p.Ho * p.Wo * p.Cout;

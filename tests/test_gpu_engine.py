@@ -574,3 +574,37 @@ def test_deferred_resize_is_absorbed_or_run_in_place(case):
         api.prof_enable(False)
         assert names.get("resize", 0) == 2, names        # only the two that feed the concat; the sums absorbed theirs
         assert names.get("copy2d", 0) == 1, names        # p2's slot
+
+
+@pytest.mark.parametrize("case", [("tiny head 64->16->16->1", 64, 16, 1, "Relu"), ("24 mid channels, 2 outputs", 32, 24, 2, "HardSwish"), ("not a pair shape (12 mid channels)", 16, 12, 1, "Relu")])
+def test_stacked_convtranspose_pair_is_one_kernel(case):
+    """The DB head ends in ConvTranspose 2x2 s2 -> act -> ConvTranspose 2x2 s2 -> Sigmoid: run as ONE kernel (k::convt2x2_pair; the
+    4x-pixels intermediate map stays in registers) when the channel counts fit, as two launches otherwise; same numbers as the
+    oracle either way, and a first layer with a second consumer is never held back."""
+    name, c0, c1, c2, act = case
+    rng = np.random.default_rng(len(name))
+
+    def build(g):
+        g.add_input("x", ["N", 8, "H", "W"])
+        f = g.op("Relu", [g.op("Conv", ["x", g.init(rng.standard_normal((c0, 8, 3, 3)).astype(np.float32) * 0.2), g.init(rng.standard_normal(c0).astype(np.float32) * 0.1)],
+                               kernel_shape=[3, 3], strides=[1, 1], pads=[1, 1, 1, 1], group=1, dilations=[1, 1])])
+        ct = lambda t, ci, co: g.op("ConvTranspose", [t, g.init((rng.standard_normal((ci, co, 2, 2)) * (1.0 / np.sqrt(ci))).astype(np.float32)), g.init(rng.standard_normal(co).astype(np.float32) * 0.1)],
+                                    kernel_shape=[2, 2], strides=[2, 2], pads=[0, 0, 0, 0], group=1, dilations=[1, 1])
+        a = g.op(act, [ct(f, c0, c1)])
+        y = g.op("Sigmoid", [ct(a, c1, c2)])
+        # a second branch whose first layer feeds two consumers: must run unfused
+        a2 = g.op("Relu", [ct(f, c0, 16)])
+        z = g.op("Add", [g.op("Sigmoid", [ct(a2, 16, 1)]), g.op("Sigmoid", [ct(a2, 16, 1)])])
+        g.add_output(z, ["N", 1, "H", "W"])
+        return y, ["N", c2, "H", "W"]
+
+    model = _single_op_graph(build)
+    x = rng.standard_normal((2, 8, 24, 40)).astype(np.float32)
+    _check(model, x)
+    eng = api.OrtInfer(model)
+    eng.infer(x)
+    api.prof_enable(True); api.prof_reset()
+    eng.infer(x)
+    names = {e["name"]: e["launches"] for e in api.prof_snapshot()}
+    api.prof_enable(False)
+    assert names.get("convt_pair", 0) == (1 if c1 != 12 else 0), names
