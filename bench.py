@@ -297,6 +297,21 @@ def main():
                     "alg_bytes_per_launch": e["alg_bytes"] / e["launches"], "alg_flops_per_launch": e["alg_flops"] / e["launches"],
                     "share_of_step": round(e["total_ms"] / e["launches"] * dominant_launches * args.steps / (dt * 1e3), 4)}
 
+    # The second half of BASELINE.json's metric ("conv MFMA util %"): counter-measured matrix-pipe use per conv-GEMM class, from the
+    # committed rocprofv3 --pmc pass over this same command (tools/profile_round.sh pass 3 -> profiles/r*/mfma_util.json; the
+    # counters cannot be collected inside the timed region).  Only reported for the workload the pass was made on (config 1).
+    mfma_util = None
+    if rank == 0 and args.config == 1:
+        for mf in sorted(ROOT.glob("profiles/r*/mfma_util.json"), reverse=True):
+            try:
+                m = json.loads(mf.read_text())
+                mfma_util = {"unit": "% of the dense MFMA peak of the class's dtype (bf16 2500 / f32 157.3 TFLOP/s), time-weighted per class",
+                             "source": str(mf.relative_to(ROOT)),
+                             "classes": {k: v["pct_of_dense_peak"] for k, v in m.items() if isinstance(v, dict) and "pct_of_dense_peak" in v}}
+                break
+            except Exception:
+                pass
+
     tmax = dt
     if world > 1:
         t = torch.tensor([dt], device=comm_dev)
@@ -355,7 +370,7 @@ def main():
                        "pages_per_gpu_per_step": n_pages, "image_batch_size": image_batch, "region_batch_size": args.region_batch,
                        "regions_per_step": gathered["regions"], "text_bytes_per_step": gathered["bytes"], "pages_gathered_per_step": gathered["pages"],
                        "parallelism": f"image-parallel x{world}", "host_cores_per_rank": cores},
-            "roofline": roof, "cpu_baseline": cpu, "device_resident": dev_res, "kernel_ms_per_step_untimed_pass": breakdown,
+            "roofline": roof, "cpu_baseline": cpu, "device_resident": dev_res, "conv_mfma_util": mfma_util, "kernel_ms_per_step_untimed_pass": breakdown,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
