@@ -1,5 +1,5 @@
 """Randomised end-to-end parity sweep: OAROCR (HIP, through the C ABI) against the oracle pipeline on random page sizes,
-line counts, thresholds and batch sizes.  usage: python tools/parity_fuzz.py [n_cases] [seed] [stages|server]"""
+line counts, thresholds and batch sizes.  usage: python tools/parity_fuzz.py [n_cases] [seed] [stages|server|seal]"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -13,6 +13,7 @@ with_stages = len(sys.argv) > 3 and sys.argv[3] == "stages"   # randomly attach 
 cls4, cls2, uvdoc = models.build_cls(4, seed=5)[0], models.build_cls(2, seed=9)[0], models.build_uvdoc(seed=6)[0]
 server = len(sys.argv) > 3 and sys.argv[3] == "server"       # BASELINE config 3 graphs (wide layers: large-K weight-stationary kernels);
 #                                                               the torch-CPU oracle needs ~15 min per case on them: run a handful at most
+seal = len(sys.argv) > 3 and sys.argv[3] == "seal"           # text_type "seal": stamp-like pages, polygon boxes, sort_poly_boxes, bounding-rectangle crops
 det, _ = models.build_det("server" if server else "tiny", seed=2 if server else 0)
 rec, _ = models.build_rec("server" if server else "tiny", vocab=18710 if server else 6906, seed=3 if server else 1)
 chars = api.read_dict(models.synth_dict(18708 if server else 6904))
@@ -26,10 +27,18 @@ for case in range(n_cases):
     imgs = []
     for i in range(n_img):
         h, w = (h0, w0) if same else (int(rng.integers(48, max_side)), int(rng.integers(48, max_side)))
-        imgs.append(pages.make_page(int(rng.integers(0, 1 << 30)), (h, w), int(rng.integers(0, 24))))
+        if seal:
+            h, w = max(h, 260) // 2 + 130, max(w, 260) // 2 + 130      # 260 .. 680: room for at least one arc band, oracle polygons stay affordable
+            imgs.append(pages.make_seal_page(int(rng.integers(0, 1 << 30)), (h, w), arcs=int(rng.integers(1, 4)), straight=int(rng.integers(0, 3))))
+        else:
+            imgs.append(pages.make_page(int(rng.integers(0, 1 << 30)), (h, w), int(rng.integers(0, 24))))
     thr, bthr, unclip = float(rng.choice([0.2, 0.3, 0.4])), float(rng.choice([0.5, 0.6, 0.7])), float(rng.choice([1.5, 1.8, 2.0]))
+    if seal:
+        unclip = float(rng.choice([0.5, 1.0, 1.5]))
     ibs, rbs = int(rng.choice([1, 2, 8])), int(rng.choice([3, 16, 64]))
     b = api.OAROCRBuilder(det, rec, chars).text_detection_config(api.TextDetectionConfig(thr, bthr, unclip)).image_batch_size(ibs).region_batch_size(rbs)
+    if seal:
+        b = b.text_type("seal")
     stages = {}
     if with_stages:
         if rng.random() < 0.6:
@@ -41,7 +50,7 @@ for case in range(n_cases):
             b = b.with_text_line_orientation_classification(cls2); stages["line_orientation"] = cls2
     ocr = b.build()
     got = ocr.predict(imgs)
-    ref = pipeline_ref.OracleOCR(det, rec, chars, thr, bthr, unclip, image_batch_size=ibs, region_batch_size=rbs, **stages).predict(imgs)
+    ref = pipeline_ref.OracleOCR(det, rec, chars, thr, bthr, unclip, image_batch_size=ibs, region_batch_size=rbs, **stages, **({"text_type": "seal"} if seal else {})).predict(imgs)
     ok = True
     for g, r in zip(got, ref):
         rep = pipeline_ref.compare_results(g, r)
