@@ -380,6 +380,11 @@ oar_status oar_k_normalize(const uint8_t* rgb, uint32_t w, uint32_t h, const int
 oar_status oar_k_rec_preprocess(const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights,
                                 uint32_t n, uint32_t img_h, uint32_t img_w, uint32_t max_img_w,
                                 float* out_nchw, uint32_t* tensor_width);
+/* the same with flips[i] != 0 => crop i is read as its imageops::rotate180 (classify_line_orientations' class 1,
+ * src/oarocr/ocr.rs:785-788) without a rotated copy being made; flips == NULL: none */
+oar_status oar_k_rec_preprocess_flip(const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights, const uint8_t* flips,
+                                     uint32_t n, uint32_t img_h, uint32_t img_w, uint32_t max_img_w,
+                                     float* out_nchw, uint32_t* tensor_width);
 /* a3  image Triangle resize (processors/resize_detection.rs:314) */
 oar_status oar_k_resize_triangle(const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, uint8_t* out);
 /* a7  processors/db_postprocess.rs:185-221 */

@@ -127,7 +127,7 @@ EXPORTS = [
     "oar_rect_run", "oar_ocr_attach", "oar_k_rotate_rgb", "oar_k_bgr_planes_to_rgb", "oar_host_rotate_back_points",
     "oar_engine_cache_stats", "oar_onnx_inspect", "oar_host_contours", "oar_ctc_dict_create", "oar_ctc_dict_destroy", "oar_ctc_dict_classes",
     "oar_ctc_decode", "oar_ocr_decode", "oar_text_result_free", "oar_db_postprocess_ex", "oar_k_dilate", "oar_k_poly_scores", "oar_debug_inject_failure", "oar_k_contours", "oar_host_contours_bits",
-    "oar_k_unclip", "oar_image_decode", "oar_image_free", "oar_host_approx_poly_dp", "oar_host_perimeter", "oar_host_unclip_poly", "oar_host_offset_ring", "oar_host_ring_outline", "oar_host_sort_poly_boxes",
+    "oar_k_unclip", "oar_k_rec_preprocess_flip", "oar_image_decode", "oar_image_free", "oar_host_approx_poly_dp", "oar_host_perimeter", "oar_host_unclip_poly", "oar_host_offset_ring", "oar_host_ring_outline", "oar_host_sort_poly_boxes",
 ]
 
 
@@ -192,6 +192,7 @@ def lib():
     L.oar_dev_synchronize.argtypes = [C.c_int32]
     L.oar_k_normalize.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), f32p, f32p, C.c_int32, vp]
     L.oar_k_rec_preprocess.argtypes = [u8pp, u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, u32p]
+    L.oar_k_rec_preprocess_flip.argtypes = [u8pp, u32p, u32p, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, u32p]
     L.oar_k_resize_triangle.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     L.oar_k_threshold.argtypes = [vp, C.c_size_t, C.c_float, vp]
     L.oar_k_ctc_argmax.argtypes = [vp, C.c_size_t, C.c_size_t, vp, vp]
@@ -1150,12 +1151,14 @@ def k_normalize(rgb, alpha, beta, src=(0, 1, 2), layout="chw"):
     return out
 
 
-def k_rec_preprocess(crops, img_h=48, img_w=320, max_img_w=3200):
+def k_rec_preprocess(crops, img_h=48, img_w=320, max_img_w=3200, flips=None):
+    """flips[i] truthy: crop i is packed as its rotate180 (text-line orientation class 1) without a rotated copy."""
     imgs, ptrs, ws, hs = _img_arrays(crops)
     tw = C.c_uint32(0)
-    _check(lib().oar_k_rec_preprocess(ptrs, ws, hs, len(imgs), img_h, img_w, max_img_w, None, C.byref(tw)))
+    fl = None if flips is None else np.ascontiguousarray(np.asarray(flips, bool).astype(np.uint8))
+    _check(lib().oar_k_rec_preprocess_flip(ptrs, ws, hs, None if fl is None else _p(fl), len(imgs), img_h, img_w, max_img_w, None, C.byref(tw)))
     out = np.empty((len(imgs), 3, img_h, tw.value), np.float32)
-    _check(lib().oar_k_rec_preprocess(ptrs, ws, hs, len(imgs), img_h, img_w, max_img_w, _p(out), C.byref(tw)))
+    _check(lib().oar_k_rec_preprocess_flip(ptrs, ws, hs, None if fl is None else _p(fl), len(imgs), img_h, img_w, max_img_w, _p(out), C.byref(tw)))
     return out
 
 

@@ -708,6 +708,11 @@ oar_status oar_k_normalize(const uint8_t* rgb, uint32_t w, uint32_t h, const int
 
 oar_status oar_k_rec_preprocess(const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights, uint32_t n, uint32_t img_h,
                                 uint32_t img_w, uint32_t max_img_w, float* out_nchw, uint32_t* tensor_width) {
+    return oar_k_rec_preprocess_flip(rgb, widths, heights, nullptr, n, img_h, img_w, max_img_w, out_nchw, tensor_width);
+}
+
+oar_status oar_k_rec_preprocess_flip(const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights, const uint8_t* flips, uint32_t n,
+                                     uint32_t img_h, uint32_t img_w, uint32_t max_img_w, float* out_nchw, uint32_t* tensor_width) {
     return guard([&] {
         OAR_CHECK(tensor_width && (n == 0 || (rgb && widths && heights)), OAR_INVALID_INPUT, "oar_k_rec_preprocess: bad arguments");
         require_device();
@@ -726,7 +731,7 @@ oar_status oar_k_rec_preprocess(const uint8_t* const* rgb, const uint32_t* width
         for (uint32_t i = 0; i < n; ++i) {
             size_t bytes = (size_t)ws[i] * hs[i] * 3;
             OAR_HIP(hipMemcpy(dc.as<uint8_t>() + off, rgb[i], bytes, hipMemcpyHostToDevice));
-            descs[i].src = dc.as<uint8_t>() + off; descs[i].w = (int)ws[i]; descs[i].h = (int)hs[i]; descs[i].rw = rws[i]; descs[i].pad = 0;
+            descs[i].src = dc.as<uint8_t>() + off; descs[i].w = (int)ws[i]; descs[i].h = (int)hs[i]; descs[i].rw = rws[i]; descs[i].flip = flips && flips[i] ? 1 : 0;
             off += (bytes + 63) & ~(size_t)63;
         }
         OAR_HIP(hipMemcpy(dd.p, descs.data(), n * sizeof(pp::CropDesc), hipMemcpyHostToDevice));

@@ -977,7 +977,7 @@ const float* Recognizer::pack(const std::vector<Crop>& crops, int& Wt, bool nchw
             d = crops_dev_.as<uint8_t>() + off;
             off += (bytes + 63) & ~(size_t)63;
         }
-        dh[i].src = d; dh[i].w = (int)crops[i].w; dh[i].h = (int)crops[i].h; dh[i].rw = rws[i]; dh[i].pad = 0;
+        dh[i].src = d; dh[i].w = (int)crops[i].w; dh[i].h = (int)crops[i].h; dh[i].rw = rws[i]; dh[i].flip = crops[i].flip ? 1 : 0;
     }
     if (stage) OAR_HIP(hipMemcpyAsync(crops_dev_.as<uint8_t>() + stage_slot, stage_host_.as<uint8_t>() + stage_slot, stage, hipMemcpyHostToDevice, s));
     OAR_HIP(hipMemcpyAsync(dd, dh, (size_t)n * sizeof(pp::CropDesc), hipMemcpyHostToDevice, s));
@@ -1022,7 +1022,7 @@ const pp::ResizedImg* Recognizer::pack_u8(const std::vector<Crop>& crops, int& W
             d = crops_dev_.as<uint8_t>() + off;
             off += (bytes + 63) & ~(size_t)63;
         }
-        dh[i].src = d; dh[i].w = (int)crops[i].w; dh[i].h = (int)crops[i].h; dh[i].rw = rws[i]; dh[i].pad = 0;
+        dh[i].src = d; dh[i].w = (int)crops[i].w; dh[i].h = (int)crops[i].h; dh[i].rw = rws[i]; dh[i].flip = crops[i].flip ? 1 : 0;
         ih[i].ptr = in_buf.as<uint8_t>() + roff; ih[i].w = rws[i]; ih[i].pad = 0;
         roff += ((size_t)img_h * rws[i] * 3 + 63) & ~(size_t)63;
     }
@@ -1328,6 +1328,55 @@ void Rectifier::run_device_locked(const uint8_t* src, uint32_t w, uint32_t h, ui
     if (back) pp::resize_triangle(s, o8, (int)ow, (int)oh, dst, (int)w, (int)h);
 }
 
+// All pages of a call in sub-batches of `kSub`: per page only the two Triangle resizes and the byte conversion are separate launches;
+// normalisation and the network run once per sub-batch ([n,3,th,tw]).  The reference rectifies page by page
+// (src/oarocr/preprocess.rs:59-97 inside the serial loop of ocr.rs:544-548); UVDoc has no cross-image op, so the batched graph
+// computes the same per-page values.  Pages whose size cannot be batched (no fixed target size) take run_device_locked.
+void Rectifier::run_device_batch(const std::vector<Page>& pages) {
+    std::lock_guard<std::mutex> lk(mu_);
+    const uint32_t th = cfg_.target_h, tw = cfg_.target_w;
+    if (th == 0 || tw == 0 || pages.size() < 2) {
+        for (const Page& p : pages) run_device_locked(p.src, p.w, p.h, p.dst);
+        return;
+    }
+    OAR_HIP(hipSetDevice(eng_->device()));
+    hipStream_t s = eng_->stream();
+    constexpr size_t kSub = 8;
+    const size_t plane = (size_t)tw * th;
+    const size_t nsub = std::min(kSub, pages.size());
+    if (plane * 3 * nsub > resized_dev_.cap || plane * 12 * nsub > input_f32_.cap) {
+        OAR_HIP(hipStreamSynchronize(s));
+        resized_dev_.reserve(plane * 3 * nsub); input_f32_.reserve(plane * 12 * nsub);
+    }
+    const int srcc[3] = {2, 1, 0};
+    const float alpha[3] = {1.0f / 255.0f, 1.0f / 255.0f, 1.0f / 255.0f}, beta[3] = {-0.0f, -0.0f, -0.0f};
+    for (size_t i0 = 0; i0 < pages.size(); i0 += kSub) {
+        const size_t n = std::min(kSub, pages.size() - i0);
+        for (size_t i = 0; i < n; ++i) {
+            const Page& p = pages[i0 + i];
+            OAR_CHECK(p.w > 0 && p.h > 0 && p.src && p.dst, OAR_INVALID_INPUT, "rectifier: empty image");
+            uint8_t* r = resized_dev_.as<uint8_t>() + i * plane * 3;
+            if (p.w != tw || p.h != th) pp::resize_triangle(s, p.src, (int)p.w, (int)p.h, r, (int)tw, (int)th);     // uvdoc.rs:88-101
+            else OAR_HIP(hipMemcpyAsync(r, p.src, plane * 3, hipMemcpyDeviceToDevice, s));
+        }
+        pp::normalize(s, resized_dev_.as<uint8_t>(), input_f32_.as<float>(), (int64_t)n, (int64_t)plane, srcc, alpha, beta, 1);
+        const Plan& plan = eng_->run(input_f32_.as<float>(), {(int64_t)n, 3, (int64_t)th, (int64_t)tw}, true);
+        OAR_CHECK(!plan.outputs.empty(), OAR_INTERNAL, "UVDoc: no output returned from inference");
+        const PlanOutput& po = plan.outputs[0];
+        OAR_CHECK(po.dims.size() == 4 && po.dims[0] == (int64_t)n && po.dims[1] == 3, OAR_SHAPE_MISMATCH, "UVDoc: expected a [n,3,h,w] output");
+        const uint32_t oh = (uint32_t)po.dims[2], ow = (uint32_t)po.dims[3];
+        const size_t oplane = (size_t)oh * ow;
+        if (oplane * 3 * n > out_u8_.cap) { OAR_HIP(hipStreamSynchronize(s)); out_u8_.reserve(oplane * 3 * nsub); }
+        for (size_t i = 0; i < n; ++i) {
+            const Page& p = pages[i0 + i];
+            const bool back = ow != p.w || oh != p.h;                               // uvdoc.rs:188-203
+            uint8_t* o8 = back ? out_u8_.as<uint8_t>() + i * oplane * 3 : p.dst;
+            pp::bgr_planes_to_rgb(s, eng_->out_ptr(po.loc) + i * 3 * oplane, (int64_t)oplane, 255.0f, o8);
+            if (back) pp::resize_triangle(s, o8, (int)ow, (int)oh, p.dst, (int)p.w, (int)p.h);
+        }
+    }
+}
+
 void Rectifier::run_host(const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst) {
     // ONE lock across upload, run and read-back: io_dev_ is shared staging, a second caller (or its reserve()) must not
     // get in between
@@ -1408,13 +1457,15 @@ void Ocr::preprocess_pages(const std::vector<PageRef>& pages, std::vector<PageRe
     }
     OAR_HIP(hipStreamSynchronize(s));
     if (rect_) {
+        std::vector<Rectifier::Page> rp(n);
         for (int i = 0; i < n; ++i) {
             uint8_t* d = pre_pages_.as<uint8_t>() + poff;
-            rect_->run_device(cur[i].dev, cur[i].w, cur[i].h, d);
+            rp[i].src = cur[i].dev; rp[i].w = cur[i].w; rp[i].h = cur[i].h; rp[i].dst = d;
             poff += ((size_t)cur[i].w * cur[i].h * 3 + 255) & ~(size_t)255;
             cur[i].dev = d;
             meta_[i].rectified = true;
         }
+        rect_->run_device_batch(rp);
         OAR_HIP(hipStreamSynchronize(rect_->engine().stream()));
     }
 }
@@ -1460,7 +1511,7 @@ void Ocr::predict_core(const std::vector<PageRef>& pages, std::vector<std::vecto
     PhaseTimer timer;
     g_timer = &timer;
     struct TimerReset { ~TimerReset() { g_timer = nullptr; } } timer_reset;
-    struct PoolItem { int img; int det_index; uint32_t w, h; float wh_ratio; size_t off; const uint8_t* rot = nullptr; };
+    struct PoolItem { int img; int det_index; uint32_t w, h; float wh_ratio; size_t off; bool flip = false; };
     struct Slot { bool filled = false; OcrRegion r; };
     std::vector<std::vector<Slot>> per_image(n);
     std::vector<PoolItem> pool;
@@ -1477,23 +1528,16 @@ void Ocr::predict_core(const std::vector<PageRef>& pages, std::vector<std::vecto
             for (size_t i = 0; i < pool.size(); ++i) { imgs[i].dev = crop_pool_.as<uint8_t>() + pool[i].off; imgs[i].w = pool[i].w; imgs[i].h = pool[i].h; }
             ClsOut co;
             line_cls_->run(imgs, co);
-            size_t need = 0;
-            for (size_t i = 0; i < pool.size(); ++i)
-                if (co.ids[i * co.topk] == 1) need += ((size_t)pool[i].w * pool[i].h * 3 + 63) & ~(size_t)63;
-            if (need > rot_crops_.cap) rot_crops_.reserve(need);
-            size_t roff = 0;
+            // class 1 => the recognizer reads the crop as its rotate180 (CropDesc::flip): the resize walks the stored crop backwards,
+            // tap for tap what resizing a rotated copy would read, so no rotated crop is ever written (round 2 launched one
+            // rotate kernel per such crop: 526 launches per step on BASELINE config 5)
             for (size_t i = 0; i < pool.size(); ++i) {
                 const int c = co.ids[i * co.topk];
                 if (c < 0) continue;
                 line_angle[i] = (float)c * 180.0f;
                 per_image[pool[i].img][pool[i].det_index].r.line_angle = line_angle[i];
-                if (c != 1) continue;
-                uint8_t* d = rot_crops_.as<uint8_t>() + roff;
-                pp::rotate_rgb(s, crop_pool_.as<uint8_t>() + pool[i].off, (int)pool[i].w, (int)pool[i].h, 2, d);
-                roff += ((size_t)pool[i].w * pool[i].h * 3 + 63) & ~(size_t)63;
-                pool[i].rot = d;
+                pool[i].flip = c == 1;
             }
-            OAR_HIP(hipStreamSynchronize(s));
         }
         std::vector<PoolItem> sorted = pool;
         std::stable_sort(sorted.begin(), sorted.end(), [](const PoolItem& a, const PoolItem& b) { return a.wh_ratio < b.wh_ratio; });
@@ -1506,7 +1550,7 @@ void Ocr::predict_core(const std::vector<PageRef>& pages, std::vector<std::vecto
             float cm = base_ratio;
             for (size_t i = c0; i < c1; ++i) {
                 Recognizer::Crop c;
-                c.dev = sorted[i].rot ? sorted[i].rot : crop_pool_.as<uint8_t>() + sorted[i].off; c.w = sorted[i].w; c.h = sorted[i].h;
+                c.dev = crop_pool_.as<uint8_t>() + sorted[i].off; c.w = sorted[i].w; c.h = sorted[i].h; c.flip = sorted[i].flip;
                 crops.push_back(c);
                 if (sorted[i].wh_ratio > cm) cm = sorted[i].wh_ratio;
             }

@@ -142,7 +142,7 @@ struct RecOut {
 class Recognizer {
    public:
     Recognizer(const uint8_t* onnx, size_t len, const oar_rec_cfg& cfg);
-    struct Crop { const uint8_t* host = nullptr; const uint8_t* dev = nullptr; uint32_t w = 0, h = 0; };
+    struct Crop { const uint8_t* host = nullptr; const uint8_t* dev = nullptr; uint32_t w = 0, h = 0; bool flip = false; };   // flip: recognise rotate180 of the crop
     void run(const std::vector<Crop>& crops, RecOut& out);
     // Several recognition batches back to back on the engine stream with ONE synchronisation at the end
     // (the reference runs them serially under the session lock, src/oarocr/ocr.rs:827-841).
@@ -206,6 +206,8 @@ class Rectifier {
     // src: device u8 HWC (w x h); dst: device u8 HWC of the SAME size (caller-allocated).  Enqueued on stream(), not synchronised.
     void run_device(const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst);
     void run_host(const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst);
+    struct Page { const uint8_t* src = nullptr; uint32_t w = 0, h = 0; uint8_t* dst = nullptr; };
+    void run_device_batch(const std::vector<Page>& pages);   // same as run_device per page, the network batched over pages
     Engine& engine() { return *eng_; }
 
    private:
@@ -250,7 +252,7 @@ class Ocr {
     Rectifier* rect_ = nullptr;
     Classifier* line_cls_ = nullptr;
     std::vector<PageMeta> meta_;
-    DevBuf pre_pages_, rot_crops_;   // corrected pages / rotated crops (device)
+    DevBuf pre_pages_;               // corrected pages (device)
     DevBuf upload_pages_;
     PinBuf warp_descs_host_;
     std::mutex mu_;

@@ -19,7 +19,7 @@ struct CropDesc {          // one recognizer input crop (device-resident u8 HWC)
     const uint8_t* src;
     int32_t w, h;          // source crop size
     int32_t rw;            // resized width (<= tensor width)
-    int32_t pad;
+    int32_t flip;          // 1: the crop is read as its imageops::rotate180 (text-line orientation class 1, src/oarocr/ocr.rs:785-788)
 };
 // a16 models/recognition/crnn.rs:98-121 + simd.rs:248-308: Triangle resize to (rw x img_h), BGR (v/255-0.5)/0.5,
 // zero padding to Wt.  out layout: NHWC [n][img_h][Wt][3] (channel c = source channel 2-c) or NCHW when nchw != 0.

@@ -119,10 +119,10 @@ __device__ __forceinline__ Taps make_taps(int o, int in, int out) {
 __device__ __forceinline__ float tap_w(const Taps& t, int i) { return tri(((float)i - t.center) / t.sratio) / t.sum; }
 
 // Vertical pass value (f32, unrounded) of source column x for output row described by tv.
-__device__ __forceinline__ void vertical_sum(const uint8_t* src, int w, int x, const Taps& tv, float& r, float& g, float& b) {
+__device__ __forceinline__ void vertical_sum(const uint8_t* src, int w, int x, const Taps& tv, float& r, float& g, float& b, long sgn = 1) {
     float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
     for (int j = tv.left; j < tv.right; ++j) {
-        const uint8_t* p = src + ((long)j * w + x) * 3;
+        const uint8_t* p = src + sgn * ((long)j * w + x) * 3;
         float wv = tap_w(tv, j);
         t0 += (float)p[0] * wv; t1 += (float)p[1] * wv; t2 += (float)p[2] * wv;
     }
@@ -130,9 +130,14 @@ __device__ __forceinline__ void vertical_sum(const uint8_t* src, int w, int x, c
 }
 __device__ __forceinline__ uint8_t to_u8_round(float v) { return (uint8_t)roundf(fminf(fmaxf(v, 0.0f), 255.0f)); }
 
-__device__ __forceinline__ void resize_pixel(const uint8_t* src, int w, int h, int nw, int nh, int ox, int oy, uint8_t out[3]) {
+// flip != 0: the image read is imageops::rotate180 of (src, w, h) -- pixel (x, y) of the rotated image is pixel
+// (w - 1 - x, h - 1 - y) of the source, i.e. the source walked backwards from its last pixel: same taps, same order, same
+// values as resizing a materialised rotated copy (src/oarocr/ocr.rs:785-788 followed by crnn.rs:104-109).
+__device__ __forceinline__ void resize_pixel(const uint8_t* src, int w, int h, int nw, int nh, int ox, int oy, uint8_t out[3], int flip = 0) {
+    const long sgn = flip ? -1 : 1;
+    if (flip) src += ((long)w * h - 1) * 3;
     if (nw == w && nh == h) {
-        const uint8_t* p = src + ((long)oy * w + ox) * 3;
+        const uint8_t* p = src + sgn * ((long)oy * w + ox) * 3;
         out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
         return;
     }
@@ -148,10 +153,10 @@ __device__ __forceinline__ void resize_pixel(const uint8_t* src, int w, int h, i
         for (int j = 0; j < MAXT; ++j) wv[j] = j < nv ? tap_w(tv, tv.left + j) : 0.0f;
         for (int i = th.left; i < th.right; ++i) {
             float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
-            const uint8_t* p = src + ((long)tv.left * w + i) * 3;
+            const uint8_t* p = src + sgn * ((long)tv.left * w + i) * 3;
 #pragma unroll
             for (int j = 0; j < MAXT; ++j) {
-                if (j < nv) { t0 += (float)p[0] * wv[j]; t1 += (float)p[1] * wv[j]; t2 += (float)p[2] * wv[j]; p += (long)w * 3; }
+                if (j < nv) { t0 += (float)p[0] * wv[j]; t1 += (float)p[1] * wv[j]; t2 += (float)p[2] * wv[j]; p += sgn * (long)w * 3; }
             }
             float wh = tap_w(th, i);
             a0 += t0 * wh; a1 += t1 * wh; a2 += t2 * wh;
@@ -159,7 +164,7 @@ __device__ __forceinline__ void resize_pixel(const uint8_t* src, int w, int h, i
     } else {
         for (int i = th.left; i < th.right; ++i) {
             float r, g, b;
-            vertical_sum(src, w, i, tv, r, g, b);
+            vertical_sum(src, w, i, tv, r, g, b, sgn);
             float wh = tap_w(th, i);
             a0 += r * wh; a1 += g * wh; a2 += b * wh;
         }
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(256) void rec_pack_kernel(const CropDesc* descs, in
         float v[3] = {0.0f, 0.0f, 0.0f};
         if (ox < d.rw) {
             uint8_t px[3];
-            resize_pixel(d.src, d.w, d.h, d.rw, img_h, ox, oy, px);
+            resize_pixel(d.src, d.w, d.h, d.rw, img_h, ox, oy, px, d.flip);
 #pragma unroll
             for (int c = 0; c < 3; ++c) v[c] = ((float)px[2 - c] / 255.0f - 0.5f) / 0.5f;
         }
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(256) void rec_resize_u8_kernel(const CropDesc* desc
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (long)gridDim.x * blockDim.x) {
         const int ox = (int)(i % d.rw), oy = (int)(i / d.rw);
         uint8_t px[3];
-        resize_pixel(d.src, d.w, d.h, d.rw, img_h, ox, oy, px);
+        resize_pixel(d.src, d.w, d.h, d.rw, img_h, ox, oy, px, d.flip);
         out[i * 3] = px[0]; out[i * 3 + 1] = px[1]; out[i * 3 + 2] = px[2];
     }
 }

@@ -101,3 +101,78 @@ def test_ocr_with_rectifier_runs_in_rectified_space(nets):
     assert len(got[0].text_regions) == len(ref[0])
     for t, s in zip(got[0].text_regions, ref[0]):
         assert np.abs(np.asarray(t.bounding_box) - s["box"]).max() <= 2.0
+
+
+def test_rec_preprocess_flip_equals_packing_the_rotated_crop():
+    """CropDesc::flip (round 3): a class-1 text line is recognised from its rotate180 (src/oarocr/ocr.rs:785-788); the resize reads the
+    stored crop backwards instead of a rotated copy -- bit-identical to packing the materialised rotation."""
+    rng = np.random.default_rng(11)
+    crops = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for (w, h) in [(120, 30), (400, 41), (64, 64), (33, 20), (900, 25), (320, 48), (17, 96)]]
+    flips = [True, False, True, True, False, True, True]
+    want = R.rec_preprocess([R.rotate_rgb(c, 2) if f else c for c, f in zip(crops, flips)])
+    assert np.array_equal(api.k_rec_preprocess(crops, flips=flips), want)
+    assert np.array_equal(api.k_rec_preprocess(crops, flips=[False] * len(crops)), R.rec_preprocess(crops))
+
+
+def _c5_pages(n, seed0):
+    rng = np.random.default_rng(seed0)
+    return [R.rotate_rgb(pages.make_page(seed0 + i, (960, 960), lines=int(rng.integers(20, 41))), int(rng.integers(0, 4))) for i in range(n)]
+
+
+def test_config5_at_baseline_shape_orientation_stages_bit_exact(nets):
+    """BASELINE C5 shape (batch = 16 pages of 960 x 960) with document orientation + text-line orientation attached: every stage whose
+    arithmetic is byte / index work stays bit-exact (rotations, crops, the flipped recognizer input), so the whole result obeys the
+    det + rec contract: boxes bit-exact after rotate_back_to_original, scores within 1e-3."""
+    det, rec, chars = nets
+    doc, _ = models.build_cls(4, seed=5)
+    line, _ = models.build_cls(2, seed=9)
+    imgs = _c5_pages(16, 700)
+    ocr = (api.OAROCRBuilder(det, rec, chars).text_detection_config(api.TextDetectionConfig(0.3, 0.6, 1.5)).image_batch_size(16).region_batch_size(256)
+           .with_document_image_orientation_classification(doc).with_text_line_orientation_classification(line).build())
+    got = ocr.predict(imgs)
+    ocr.close()
+    oc = pipeline_ref.OracleOCR(det, rec, chars, 0.3, 0.6, 1.5, image_batch_size=16, region_batch_size=256, doc_orientation=doc, line_orientation=line)
+    ref = oc.predict(imgs)
+    assert sum(len(r) for r in ref) > 300
+    angles = set()
+    for g, r, (angle, rect) in zip(got, ref, oc.page_meta):
+        assert g.orientation_angle == angle and g.rectified == rect
+        rep = pipeline_ref.compare_results(g, r)
+        assert rep["ok"], rep
+        assert [t.orientation_angle for t in g.text_regions] == [s.get("line_angle") for s in r]
+        angles.update(s.get("line_angle") for s in r)
+    assert 180.0 in angles, angles      # class 1 occurred: the flipped-read path (CropDesc::flip) was exercised end to end
+
+
+def test_config5_at_baseline_shape_all_stages(nets):
+    """BASELINE C5 as stated: 16 pages of 960 x 960, document orientation + UVDoc rectification + text-line orientation all attached,
+    random page rotations, one predict.  A rectified page may differ from the oracle's by one grey level in a few pixels (the (v * 255)
+    truncation after UVDoc, test_rectifier_adapter_matches_oracle), so the detector sees a marginally different page: the rule of
+    tools/parity_fuzz.py applies -- per page the same regions within one threshold-marginal region, boxes within 2 px, in
+    rectified space (never mapped back)."""
+    det, rec, chars = nets
+    doc, _ = models.build_cls(4, seed=5)
+    line, _ = models.build_cls(2, seed=9)
+    uv, _ = models.build_uvdoc(seed=6)
+    imgs = _c5_pages(16, 900)
+    ocr = (api.OAROCRBuilder(det, rec, chars).text_detection_config(api.TextDetectionConfig(0.3, 0.6, 1.5)).image_batch_size(16).region_batch_size(256)
+           .with_document_image_orientation_classification(doc).with_document_image_rectification(uv)
+           .with_text_line_orientation_classification(line).build())
+    got = ocr.predict(imgs)
+    ocr.close()
+    oc = pipeline_ref.OracleOCR(det, rec, chars, 0.3, 0.6, 1.5, image_batch_size=16, region_batch_size=256, doc_orientation=doc, rectifier=uv,
+                                line_orientation=line)
+    ref = oc.predict(imgs)
+    assert sum(len(r) for r in ref) > 200
+    exact = 0
+    for g, r, (angle, rect) in zip(got, ref, oc.page_meta):
+        assert g.rectified and rect and g.orientation_angle == angle
+        rep = pipeline_ref.compare_results(g, r)
+        if rep["ok"]:
+            exact += 1
+            continue
+        assert abs(len(g.text_regions) - len(r)) <= 1, rep
+        if len(g.text_regions) == len(r):
+            for t, s in zip(g.text_regions, r):
+                assert np.abs(np.asarray(t.bounding_box) - s["box"]).max() <= 2.0
+    print("config 5, all stages: pages identical to the oracle:", exact, "of", len(imgs))

@@ -14,3 +14,20 @@ def test_random_pages_match_oracle():
     r = subprocess.run([sys.executable, str(root / "tools" / "parity_fuzz.py"), "8", "7"], cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "8/8 cases identical" in r.stdout
+
+
+def _fuzz(n, seed, mode):
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / "tools" / "parity_fuzz.py"), str(n), str(seed), mode], cwd=root, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert f"{n}/{n} cases identical" in r.stdout, r.stdout[-2000:]
+
+
+def test_random_pages_with_optional_stages_match_oracle():
+    """document orientation / UVDoc / text-line orientation randomly attached, pages randomly rotated"""
+    _fuzz(8, 21, "stages")
+
+
+def test_random_seal_pages_match_oracle():
+    """text_type "seal": polygon boxes, sort_poly_boxes, bounding-rectangle crops"""
+    _fuzz(4, 5, "seal")
