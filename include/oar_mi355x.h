@@ -306,6 +306,26 @@ void oar_ocr_result_free(oar_ocr_result* r);
  * (OAROCR::recognize_global's scatter, src/oarocr/ocr.rs:840-891). */
 oar_status oar_ocr_decode(const oar_ctc_dict* dict, const oar_ocr_result* res, float score_threshold, oar_text_result* out);
 
+/* Word (character) boxes, row a21: OAROCR::ctc_word_boxes (src/oarocr/ocr.rs:949-1020) -- the line box's extent cut at the
+ * CTC columns: effective columns = T * (wh_ratio / max_wh_ratio), cell = width / effective, centres (col + 0.5) * cell; a CJK
+ * character (is_cjk, ocr.rs:1075-1082) gets an average-width box around its centre, any other character the span between the
+ * midpoints to its neighbours; all clamped to the line.  A box = BoundingBox::from_coords = 4 points (x1,y1)(x2,y1)(x2,y2)(x1,y2)
+ * = 8 floats.  f32 arithmetic in the reference's order.  boxes may be NULL (count query); cap_boxes in boxes of 8 floats. */
+oar_status oar_ctc_word_boxes(const float* line_pts_xy, uint32_t n_points, const char* text_utf8, size_t text_len, const uint32_t* col_indices,
+                              uint32_t n_cols, uint32_t seq_len, float wh_ratio, float max_wh_ratio, float* boxes, uint32_t cap_boxes, uint32_t* n_boxes);
+/* OAROCR::char_positions_to_word_boxes (ocr.rs:1036-1072): the fallback when a recogniser reports positions but no columns */
+oar_status oar_char_positions_to_word_boxes(const float* line_pts_xy, uint32_t n_points, const float* char_positions, uint32_t n_positions,
+                                            uint32_t char_count, float* boxes, uint32_t cap_boxes, uint32_t* n_boxes);
+/* return_word_box for a whole pipeline result (ocr.rs:860-877): region k owns boxes [box_offsets[k], box_offsets[k+1]) (none when
+ * its text was filtered out or it has no characters); wh_ratio = crop w / h (ocr.rs:739), max_wh_ratio = res->max_wh_ratio. */
+typedef struct {
+    uint32_t n_regions;
+    uint64_t* box_offsets;   /* n_regions + 1 */
+    float* boxes;            /* box_offsets[n_regions] * 8 */
+} oar_word_boxes;
+oar_status oar_ocr_word_boxes(const oar_ocr_result* res, const oar_text_result* txt, oar_word_boxes* out);
+void oar_word_boxes_free(oar_word_boxes* w);
+
 /* ------------------------------------------------------------------------------------------------ Seam B: config-5 stages
  * PP-LCNet classifier adapters: DocumentOrientationAdapter / TextLineOrientationAdapter ->
  * PPLCNetModel::forward_refs (oar-ocr-core/src/models/classification/pp_lcnet.rs:139-330): Triangle resize

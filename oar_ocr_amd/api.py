@@ -111,6 +111,10 @@ class TextResult(C.Structure):
                 ("seq_len", C.POINTER(C.c_uint32)), ("kept", C.POINTER(C.c_uint8))]
 
 
+class WordBoxes(C.Structure):
+    _fields_ = [("n_regions", C.c_uint32), ("box_offsets", C.POINTER(C.c_uint64)), ("boxes", C.POINTER(C.c_float))]
+
+
 class ProfEntry(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double), ("alg_bytes", C.c_double), ("alg_flops", C.c_double)]
 
@@ -127,7 +131,7 @@ EXPORTS = [
     "oar_rect_run", "oar_ocr_attach", "oar_k_rotate_rgb", "oar_k_bgr_planes_to_rgb", "oar_host_rotate_back_points",
     "oar_engine_cache_stats", "oar_onnx_inspect", "oar_host_contours", "oar_ctc_dict_create", "oar_ctc_dict_destroy", "oar_ctc_dict_classes",
     "oar_ctc_decode", "oar_ocr_decode", "oar_text_result_free", "oar_db_postprocess_ex", "oar_k_dilate", "oar_k_poly_scores", "oar_debug_inject_failure", "oar_k_contours", "oar_host_contours_bits",
-    "oar_k_unclip", "oar_k_rec_preprocess_flip", "oar_image_decode", "oar_image_free", "oar_host_approx_poly_dp", "oar_host_perimeter", "oar_host_unclip_poly", "oar_host_offset_ring", "oar_host_ring_outline", "oar_host_sort_poly_boxes",
+    "oar_k_unclip", "oar_k_rec_preprocess_flip", "oar_ctc_word_boxes", "oar_char_positions_to_word_boxes", "oar_ocr_word_boxes", "oar_word_boxes_free", "oar_image_decode", "oar_image_free", "oar_host_approx_poly_dp", "oar_host_perimeter", "oar_host_unclip_poly", "oar_host_offset_ring", "oar_host_ring_outline", "oar_host_sort_poly_boxes",
 ]
 
 
@@ -192,6 +196,11 @@ def lib():
     L.oar_dev_synchronize.argtypes = [C.c_int32]
     L.oar_k_normalize.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), f32p, f32p, C.c_int32, vp]
     L.oar_k_rec_preprocess.argtypes = [u8pp, u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, u32p]
+    L.oar_ctc_word_boxes.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_size_t, vp, C.c_uint32, C.c_uint32, C.c_float, C.c_float, vp, C.c_uint32, u32p]
+    L.oar_char_positions_to_word_boxes.argtypes = [vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, u32p]
+    L.oar_ocr_word_boxes.argtypes = [vp, vp, vp]
+    L.oar_word_boxes_free.argtypes = [vp]
+    L.oar_word_boxes_free.restype = None
     L.oar_k_rec_preprocess_flip.argtypes = [u8pp, u32p, u32p, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, u32p]
     L.oar_k_resize_triangle.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     L.oar_k_threshold.argtypes = [vp, C.c_size_t, C.c_float, vp]
@@ -555,6 +564,7 @@ class DecodedTexts:
     kept: np.ndarray                # [n] bool: score >= threshold
     utf8: bytes = b""               # the concatenated texts as the library produced them
     text_offsets: Optional[np.ndarray] = None
+    word_boxes: Optional[list] = None   # per region: list of [4, 2] boxes or None (oar_ocr_word_boxes; only when asked for)
 
 
 class CtcDict:
@@ -602,10 +612,22 @@ class CtcDict:
         lib().oar_text_result_free(C.byref(res))
         return out
 
-    def decode_ocr(self, res: "OcrResult", score_threshold: float = 0.0, want_positions: bool = True) -> DecodedTexts:
+    def decode_ocr(self, res: "OcrResult", score_threshold: float = 0.0, want_positions: bool = True, word_boxes: bool = False) -> DecodedTexts:
+        """word_boxes: also run oar_ocr_word_boxes (return_word_box, src/oarocr/ocr.rs:860-877) on the decoded texts; the per-region
+        lists of [4, 2] boxes (None where the reference yields none) are returned as DecodedTexts.word_boxes."""
         tr = TextResult()
         _check(lib().oar_ocr_decode(self._h, C.byref(res), C.c_float(score_threshold), C.byref(tr)))
         out = self._unpack(tr, want_positions)
+        if word_boxes:
+            wb = WordBoxes()
+            try:
+                _check(lib().oar_ocr_word_boxes(C.byref(res), C.byref(tr), C.byref(wb)))
+                n = int(wb.n_regions)
+                offs = np.ctypeslib.as_array(wb.box_offsets, shape=(n + 1,)).copy()
+                flat = np.ctypeslib.as_array(wb.boxes, shape=(max(int(offs[n]), 1) * 8,)).copy()[:int(offs[n]) * 8].reshape(-1, 4, 2)
+                out.word_boxes = [[b for b in flat[offs[k]:offs[k + 1]]] if offs[k + 1] > offs[k] else None for k in range(n)]
+            finally:
+                lib().oar_word_boxes_free(C.byref(wb))
         lib().oar_text_result_free(C.byref(tr))
         return out
 
@@ -817,12 +839,6 @@ class TextRecognitionPredictor:
 
 
 # ------------------------------------------------------------------------------------------------ pipeline
-def _is_cjk(ch: str) -> bool:
-    """src/oarocr/ocr.rs:1075-1082"""
-    u = ord(ch)
-    return (0x4E00 <= u <= 0x9FFF) or (0x3400 <= u <= 0x4DBF) or (0x20000 <= u <= 0x2A6DF) or (0x2A700 <= u <= 0x2B73F) or (0x2B740 <= u <= 0x2B81F)
-
-
 class OAROCRBuilder:
     """src/oarocr/ocr.rs:105-417"""
 
@@ -1003,17 +1019,14 @@ class OAROCR:
         sl = np.ctypeslib.as_array(res.seq_len, shape=(nr,)).copy()
         mwh = np.ctypeslib.as_array(res.max_wh_ratio, shape=(nr,)).copy()
         lang = np.ctypeslib.as_array(res.line_angle, shape=(nr,)).copy()
-        dec = self.ctc.decode_ocr(res, self.score_threshold)   # collapse + text + score filter inside the library
+        dec = self.ctc.decode_ocr(res, self.score_threshold, word_boxes=self.return_word_box)   # collapse + text + score filter (+ word boxes) inside the library
         results = []
         for i in range(n):
             regions = []
             for k in range(offs[i], offs[i + 1]):
                 T = int(sl[k])
                 text, score, col = dec.texts[k], float(dec.scores[k]), dec.char_cols[k]
-                wb = None
-                if self.return_word_box and len(col) and T > 0:
-                    wh = np.float32(cwh[k, 0]) / np.float32(max(int(cwh[k, 1]), 1))
-                    wb = ctc_word_boxes(pts[k], text, [int(c) for c in col], T, float(wh), float(mwh[k]))
+                wb = dec.word_boxes[k] if self.return_word_box else None   # oar_ocr_word_boxes (row a21)
                 regions.append(TextRegion(pts[k].copy(), text, score, pts[k].copy(), pts[k].copy(), wb, float(dsc[k]), (int(cwh[k, 0]), int(cwh[k, 1])),
                                           float(lang[k]) if lang[k] >= 0 else None, float(mwh[k]), T))
             results.append(OAROCRResult(f"image_{i}", i, regions, **page_kw[i]))
@@ -1064,34 +1077,30 @@ class PackedPages:
 
 
 def ctc_word_boxes(line_bbox: np.ndarray, text: str, col_indices, seq_len: int, wh_ratio: float, max_wh_ratio: float):
-    """src/oarocr/ocr.rs:949-1020 (f32 arithmetic, same operation order)."""
-    if not col_indices or seq_len == 0 or not text:
-        return []
-    f = np.float32
-    EPS = f(1.1920929e-7)
-    eff = f(f(seq_len) * f(f(wh_ratio) / f(max_wh_ratio)))
-    if eff <= EPS:
-        return []
-    xs, ys = np.asarray(line_bbox, np.float32)[:, 0], np.asarray(line_bbox, np.float32)[:, 1]
-    x_min, y_min, x_max, y_max = f(xs.min()), f(ys.min()), f(xs.max()), f(ys.max())
-    width = f(x_max - x_min)
-    cell = f(width / max(eff, EPS))
-    chars = list(text)
-    avg_w = f(width / f(max(len(chars), 1)))
-    centers = [f(x_min + f(f(f(i) + f(0.5)) * cell)) for i in col_indices]
-    boxes = []
-    n = len(col_indices)
-    for i in range(n):
-        ch = chars[i] if i < len(chars) else "?"
-        c = centers[i]
-        if _is_cjk(ch):
-            half = f(avg_w / f(2.0))
-            l, r = max(f(c - half), x_min), min(f(c + half), x_max)
-        else:
-            l = max(x_min if i == 0 else f(f(centers[i - 1] + c) / f(2.0)), x_min)
-            r = min(x_max if i == n - 1 else f(f(c + centers[i + 1]) / f(2.0)), x_max)
-        boxes.append(np.array([[l, y_min], [r, y_min], [r, y_max], [l, y_max]], np.float32))
-    return boxes
+    """OAROCR::ctc_word_boxes (src/oarocr/ocr.rs:949-1020) through the C ABI (oar_ctc_word_boxes): one [4, 2] box per character."""
+    pts = np.ascontiguousarray(line_bbox, np.float32).reshape(-1, 2)
+    cols = np.ascontiguousarray(col_indices, np.uint32)
+    raw = text.encode("utf-8")
+    n = C.c_uint32(0)
+    args = (_p(pts) if pts.size else None, pts.shape[0], raw, len(raw), _p(cols) if cols.size else None, cols.size, int(seq_len), C.c_float(wh_ratio), C.c_float(max_wh_ratio))
+    _check(lib().oar_ctc_word_boxes(*args, None, 0, C.byref(n)))
+    out = np.empty((n.value, 4, 2), np.float32)
+    if n.value:
+        _check(lib().oar_ctc_word_boxes(*args, _p(out), n.value, C.byref(n)))
+    return [b for b in out]
+
+
+def char_positions_to_word_boxes(line_bbox: np.ndarray, char_positions, char_count: int):
+    """OAROCR::char_positions_to_word_boxes (src/oarocr/ocr.rs:1036-1072) through the C ABI."""
+    pts = np.ascontiguousarray(line_bbox, np.float32).reshape(-1, 2)
+    pos = np.ascontiguousarray(char_positions, np.float32)
+    n = C.c_uint32(0)
+    args = (_p(pts) if pts.size else None, pts.shape[0], _p(pos) if pos.size else None, pos.size, int(char_count))
+    _check(lib().oar_char_positions_to_word_boxes(*args, None, 0, C.byref(n)))
+    out = np.empty((n.value, 4, 2), np.float32)
+    if n.value:
+        _check(lib().oar_char_positions_to_word_boxes(*args, _p(out), n.value, C.byref(n)))
+    return [b for b in out]
 
 
 # ------------------------------------------------------------------------------------------------ device buffers / profiling

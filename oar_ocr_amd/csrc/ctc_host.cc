@@ -85,6 +85,78 @@ void pack(const std::vector<Decoded>& seqs, const std::vector<uint32_t>& Ts, flo
     out->utf8[b] = 0;
 }
 
+// decodes one UTF-8 scalar value starting at s (Rust `char`); malformed input yields the lead byte itself
+uint32_t utf8_scalar(const unsigned char* s, size_t avail, size_t& used) {
+    used = utf8_len(s, avail);
+    if (used == 1) return s[0];
+    uint32_t c = used == 2 ? (s[0] & 0x1Fu) : used == 3 ? (s[0] & 0x0Fu) : (s[0] & 0x07u);
+    for (size_t i = 1; i < used; ++i) c = (c << 6) | (s[i] & 0x3Fu);
+    return c;
+}
+// OAROCR::is_cjk (src/oarocr/ocr.rs:1075-1082)
+bool is_cjk(uint32_t u) {
+    return (u >= 0x4E00 && u <= 0x9FFF) || (u >= 0x3400 && u <= 0x4DBF) || (u >= 0x20000 && u <= 0x2A6DF) || (u >= 0x2A700 && u <= 0x2B73F) ||
+           (u >= 0x2B740 && u <= 0x2B81F);
+}
+struct Extent { float x_min, y_min, x_max, y_max; };
+// BoundingBox::x_min / y_min / x_max / y_max: f32 fold over the points
+Extent extent_of(const float* pts_xy, uint32_t n_points) {
+    Extent e{pts_xy[0], pts_xy[1], pts_xy[0], pts_xy[1]};
+    for (uint32_t i = 1; i < n_points; ++i) {
+        const float x = pts_xy[2 * i], y = pts_xy[2 * i + 1];
+        e.x_min = x < e.x_min ? x : e.x_min; e.x_max = x > e.x_max ? x : e.x_max;
+        e.y_min = y < e.y_min ? y : e.y_min; e.y_max = y > e.y_max ? y : e.y_max;
+    }
+    return e;
+}
+void push_box(std::vector<float>& out, float x1, float y1, float x2, float y2) {   // BoundingBox::from_coords (geometry.rs:98-106)
+    const float b[8] = {x1, y1, x2, y1, x2, y2, x1, y2};
+    out.insert(out.end(), b, b + 8);
+}
+// OAROCR::ctc_word_boxes (src/oarocr/ocr.rs:949-1020), f32 arithmetic in the reference's operation order
+void ctc_word_boxes(const float* pts_xy, uint32_t n_points, const char* text, size_t text_len, const uint32_t* cols, uint32_t n_cols, uint32_t seq_len,
+                    float wh_ratio, float max_wh_ratio, std::vector<float>& out) {
+    if (n_cols == 0 || seq_len == 0 || text_len == 0 || n_points == 0) return;
+    const float EPS = 1.1920929e-7f;
+    const float eff = (float)seq_len * (wh_ratio / max_wh_ratio);
+    if (eff <= EPS) return;
+    const Extent e = extent_of(pts_xy, n_points);
+    const float width = e.x_max - e.x_min;
+    const float cell = width / (eff > EPS ? eff : EPS);
+    std::vector<uint32_t> chars;
+    for (size_t b = 0; b < text_len;) { size_t used; chars.push_back(utf8_scalar((const unsigned char*)text + b, text_len - b, used)); b += used; }
+    const float avg = width / (float)(chars.size() ? chars.size() : 1);
+    std::vector<float> centers(n_cols);
+    for (uint32_t i = 0; i < n_cols; ++i) centers[i] = e.x_min + ((float)cols[i] + 0.5f) * cell;
+    for (uint32_t i = 0; i < n_cols; ++i) {
+        const uint32_t ch = i < chars.size() ? chars[i] : (uint32_t)'?';
+        const float c = centers[i];
+        float l, r;
+        if (is_cjk(ch)) {
+            const float half = avg / 2.0f;
+            l = c - half; l = l > e.x_min ? l : e.x_min;
+            r = c + half; r = r < e.x_max ? r : e.x_max;
+        } else {
+            l = i == 0 ? e.x_min : (centers[i - 1] + c) / 2.0f; l = l > e.x_min ? l : e.x_min;
+            r = i == n_cols - 1 ? e.x_max : (c + centers[i + 1]) / 2.0f; r = r < e.x_max ? r : e.x_max;
+        }
+        push_box(out, l, e.y_min, r, e.y_max);
+    }
+}
+// OAROCR::char_positions_to_word_boxes (src/oarocr/ocr.rs:1036-1072): the fallback when no column indices exist
+void positions_word_boxes(const float* pts_xy, uint32_t n_points, const float* pos, uint32_t n_pos, uint32_t char_count, std::vector<float>& out) {
+    if (n_pos == 0 || char_count == 0 || n_points == 0) return;
+    const Extent e = extent_of(pts_xy, n_points);
+    const float width = e.x_max - e.x_min;
+    const float cw = width / (float)char_count;
+    for (uint32_t i = 0; i < n_pos; ++i) {
+        const float c = e.x_min + (pos[i] * width);
+        float l = c - cw / 2.0f; l = l > e.x_min ? l : e.x_min;
+        float r = c + cw / 2.0f; r = r < e.x_max ? r : e.x_max;
+        push_box(out, l, e.y_min, r, e.y_max);
+    }
+}
+
 template <typename F>
 oar_status guarded(F&& f) {
     try { f(); return OAR_OK; }
@@ -149,6 +221,68 @@ oar_status oar_ocr_decode(const oar_ctc_dict* dict, const oar_ocr_result* res, f
         }
         pack(seqs, Ts, score_threshold, out);
     });
+}
+
+oar_status oar_ctc_word_boxes(const float* line_pts_xy, uint32_t n_points, const char* text_utf8, size_t text_len, const uint32_t* col_indices,
+                              uint32_t n_cols, uint32_t seq_len, float wh_ratio, float max_wh_ratio, float* boxes, uint32_t cap_boxes, uint32_t* n_boxes) {
+    return guarded([&] {
+        OAR_CHECK(n_boxes && (n_points == 0 || line_pts_xy) && (text_len == 0 || text_utf8) && (n_cols == 0 || col_indices), OAR_INVALID_INPUT,
+                  "oar_ctc_word_boxes: bad arguments");
+        std::vector<float> out;
+        ctc_word_boxes(line_pts_xy, n_points, text_utf8, text_len, col_indices, n_cols, seq_len, wh_ratio, max_wh_ratio, out);
+        *n_boxes = (uint32_t)(out.size() / 8);
+        if (boxes) {
+            OAR_CHECK(cap_boxes >= *n_boxes, OAR_INVALID_INPUT, "oar_ctc_word_boxes: output buffer too small");
+            std::memcpy(boxes, out.data(), out.size() * sizeof(float));
+        }
+    });
+}
+
+oar_status oar_ocr_word_boxes(const oar_ocr_result* res, const oar_text_result* txt, oar_word_boxes* out) {
+    return guarded([&] {
+        OAR_CHECK(res && txt && out && res->n_regions == txt->n, OAR_INVALID_INPUT, "oar_ocr_word_boxes: result / text mismatch");
+        std::memset(out, 0, sizeof *out);
+        const uint32_t n = res->n_regions;
+        std::vector<float> all;
+        std::vector<uint64_t> offs(n + 1, 0);
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t p0 = res->point_offsets ? res->point_offsets[k] : 4 * k, p1 = res->point_offsets ? res->point_offsets[k + 1] : 4 * k + 4;
+            const float* pts = res->points + (size_t)p0 * 2;
+            const uint64_t c0 = txt->char_offsets[k], c1 = txt->char_offsets[k + 1];
+            const uint64_t t0 = txt->text_offsets[k], t1 = txt->text_offsets[k + 1];
+            const uint32_t cw = res->crop_wh[2 * k], ch = res->crop_wh[2 * k + 1];
+            const float wh = (float)cw / (float)(ch > 1 ? ch : 1);   // PooledRegion::wh_ratio (ocr.rs:739)
+            // ocr.rs:860-877: column indices when there are any (and T > 0), else the normalised positions, else none
+            if (c1 > c0 && txt->seq_len[k] > 0)
+                ctc_word_boxes(pts, p1 - p0, txt->utf8 + t0, (size_t)(t1 - t0), txt->char_cols + c0, (uint32_t)(c1 - c0), txt->seq_len[k], wh, res->max_wh_ratio[k], all);
+            offs[k + 1] = all.size() / 8;
+        }
+        out->n_regions = n;
+        out->box_offsets = cm<uint64_t>(n + 1);
+        std::memcpy(out->box_offsets, offs.data(), (n + 1) * sizeof(uint64_t));
+        out->boxes = cm<float>(all.size());
+        std::memcpy(out->boxes, all.data(), all.size() * sizeof(float));
+    });
+}
+
+oar_status oar_char_positions_to_word_boxes(const float* line_pts_xy, uint32_t n_points, const float* char_positions, uint32_t n_positions,
+                                            uint32_t char_count, float* boxes, uint32_t cap_boxes, uint32_t* n_boxes) {
+    return guarded([&] {
+        OAR_CHECK(n_boxes && (n_points == 0 || line_pts_xy) && (n_positions == 0 || char_positions), OAR_INVALID_INPUT, "oar_char_positions_to_word_boxes: bad arguments");
+        std::vector<float> out;
+        positions_word_boxes(line_pts_xy, n_points, char_positions, n_positions, char_count, out);
+        *n_boxes = (uint32_t)(out.size() / 8);
+        if (boxes) {
+            OAR_CHECK(cap_boxes >= *n_boxes, OAR_INVALID_INPUT, "oar_char_positions_to_word_boxes: output buffer too small");
+            std::memcpy(boxes, out.data(), out.size() * sizeof(float));
+        }
+    });
+}
+
+void oar_word_boxes_free(oar_word_boxes* w) {
+    if (!w) return;
+    std::free(w->box_offsets); std::free(w->boxes);
+    std::memset(w, 0, sizeof *w);
 }
 
 void oar_text_result_free(oar_text_result* r) {

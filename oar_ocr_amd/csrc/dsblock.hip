@@ -43,14 +43,61 @@ DsPlanShape ds_shape(const DsBlockP& p) {
     r.ok = best_tiles > 0;
     return r;
 }
+
+// The wave-autonomous kernel (dsblock_wa.inc, round 3): 3x3, stride 1, any C / Cout whose fragment count has an instantiation.
+struct WaShape { int nf, P; long tiles; int tiles_x, tiles_y; size_t lds; bool ok; };
+WaShape wa_shape(const DsBlockP& p) {
+    WaShape r{};
+    const char* e = getenv("OAR_DSBLOCK_WA");   // read per call (plan time + launch): tests A/B the two kernels inside one process
+    if ((e && atoi(e) == 0) || p.ks != 3 || p.sh != 1 || p.sw != 1) return r;
+    if (p.C <= 0 || (p.C & 3) || p.Cout <= 0 || (p.Cout & 3) || (p.y_ld & 3) || p.N <= 0 || p.Ho <= 0 || p.Wo <= 0) return r;
+    if (p.pt < 0 || p.pl < 0 || p.pt > 2 || p.pl > 2) return r;
+    if ((long)p.H * p.W * p.C * 4 >= (1L << 31)) return r;   // 32-bit tile-relative source offsets
+    r.nf = (p.Cout + 15) / 16;
+    if (!(r.nf <= 6 || r.nf == 8 || r.nf == 12)) return r;
+    r.P = r.nf == 12 ? 1 : 2;
+    const int TR = 4 * r.P, in_px = (TR + 2) * 18, nj = (in_px * 8 + 63) / 64;
+    r.tiles_x = (p.Wo + 15) / 16; r.tiles_y = (p.Ho + TR - 1) / TR;
+    r.tiles = (long)p.N * r.tiles_x * r.tiles_y;
+    r.lds = (size_t)kWaRing * nj * 1024 + (size_t)((p.C + 31) / 32) * 1280;
+    r.ok = true;
+    return r;
+}
+
+void dsblock_wa(hipStream_t s, const DsBlockP& b, const WaShape& sh) {
+    DsP p{};
+    p.x = b.x; p.y = b.y; p.wd = b.wd; p.bd = b.bd; p.wp = reinterpret_cast<const uint4*>(b.wp); p.bp = b.bp; p.res = b.residual; p.se = b.se;
+    p.N = b.N; p.H = b.H; p.W = b.W; p.C = b.C; p.Ho = b.Ho; p.Wo = b.Wo; p.Cout = b.Cout;
+    p.sh = b.sh; p.sw = b.sw; p.pt = b.pt; p.pl = b.pl;
+    p.act1 = b.act1.kind; p.a1 = b.act1.alpha; p.b1 = b.act1.beta;
+    p.act2 = b.act2.kind; p.a2 = b.act2.alpha; p.b2 = b.act2.beta;
+    p.TR = 4 * sh.P; p.TC = 16; p.IR = p.TR + 2; p.IC = 18; p.tiles_x = sh.tiles_x; p.tiles_y = sh.tiles_y; p.tiles = sh.tiles;
+    p.KC = (b.C + 31) / 32; p.NF = sh.nf; p.y_ld = b.y_ld;
+    { const char* e = getenv("OAR_DSB_DBG"); p.dbg = e ? atoi(e) : 0; }
+    const int per_cu = (int)std::min<size_t>(4, (160 * 1024) / sh.lds);
+    long grid = std::min<long>(sh.tiles, 256L * per_cu);
+    grid = std::max<long>(8, (grid + 7) / 8 * 8);
+    const double px_in = (double)b.N * b.H * b.W, px_out = (double)b.N * b.Ho * b.Wo;
+    const double bytes = 4.0 * (px_in * b.C + px_out * b.Cout * (b.residual ? 2 : 1)) + 4.0 * b.ks * b.ks * b.C + 6.0 * b.C * b.Cout;
+    const double flops = 2.0 * px_out * b.C * (b.ks * b.ks + (double)b.Cout);
+    char pname[96];
+    const char* cls = "dsblock";
+    if (Profiler::get().detail) { snprintf(pname, sizeof pname, "dsblock px=%ld C=%d N=%d k3 s1x1 wa%d", (long)px_out, b.C, b.Cout, sh.P); cls = pname; }
+    ProfScope ps(s, cls, bytes, flops, true);
+    if (sh.nf <= 4) dsblock_wa_launch_a(s, p, sh.nf, (int)grid, sh.lds, ps.start(), ps.stop());
+    else dsblock_wa_launch_b(s, p, sh.nf, (int)grid, sh.lds, ps.start(), ps.stop());
+}
 }  // namespace
 
 bool dsblock_eligible(const DsBlockP& p) {
-    static const bool on = [] { const char* e = getenv("OAR_FUSE_DSBLOCK"); return !e || atoi(e) != 0; }();
-    return on && ds_shape(p).ok;
+    const char* e = getenv("OAR_FUSE_DSBLOCK");
+    const bool on = !e || atoi(e) != 0;
+    return on && (wa_shape(p).ok || ds_shape(p).ok);
 }
 
 void dsblock(hipStream_t s, const DsBlockP& b) {
+    const WaShape wa = wa_shape(b);
+    if (wa.ok) { dsblock_wa(s, b, wa); return; }
     const DsPlanShape sh = ds_shape(b);
     OAR_CHECK(sh.ok, OAR_INTERNAL, "dsblock: called on an ineligible block");
     DsP p{};

@@ -23,6 +23,7 @@ struct DsP {
     int tiles_x, tiles_y;
     long tiles;
     int KC, NF, y_ld;
+    int dbg;   // dsblock_wa timing ablations (OAR_DSB_DBG; wrong results, for tools/dsblock_bench.py only)
 };
 
 // one translation unit per (kernel size, column stride): each instantiates the eight (NFW, PFW) wave layouts
@@ -30,6 +31,18 @@ void dsblock_launch_k3s1(hipStream_t s, const DsP& p, int nfw, int pfw, int grid
 void dsblock_launch_k3s2(hipStream_t s, const DsP& p, int nfw, int pfw, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1);
 void dsblock_launch_k5s1(hipStream_t s, const DsP& p, int nfw, int pfw, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1);
 void dsblock_launch_k5s2(hipStream_t s, const DsP& p, int nfw, int pfw, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1);
+
+// wave-autonomous variant (dsblock_wa.inc; 3x3, stride 1): one translation unit per group of cout-fragment counts
+constexpr int kWaRing = 3;       // tile buffers in the LDS ring: 2 = one step of prefetch, 3 = two
+constexpr int kWaThreads = 320;  // 4 consumer waves + 1 producer wave
+void dsblock_wa_launch_a(hipStream_t s, const DsP& p, int nf, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1);   // NF 1..4 (P = 2)
+void dsblock_wa_launch_b(hipStream_t s, const DsP& p, int nf, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1);   // NF 5, 6, 8 (P = 2), 12 (P = 1)
+template <int NF, int P, typename K>
+static void dsblock_wa_one(K kernel, hipStream_t s, const DsP& p, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1) {
+    static const bool once = [kernel] { OAR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); return true; }();
+    (void)once;
+    hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(kWaThreads), lds, s, e0, e1, 0, p);
+}
 
 #define OAR_DSBLOCK_INSTANTIATE(NAME, KS, SW)                                                                                                  \
     template <int NFW, int PFW>                                                                                                                \

@@ -442,3 +442,59 @@ def uvdoc_postprocess(pred_chw: np.ndarray, orig_wh) -> np.ndarray:
     if ow and oh and (ow, oh) != (w, h):
         out = resize_triangle(out, ow, oh)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ a21 word boxes
+def _is_cjk(ch: str) -> bool:
+    """OAROCR::is_cjk (src/oarocr/ocr.rs:1075-1082)"""
+    u = ord(ch)
+    return (0x4E00 <= u <= 0x9FFF) or (0x3400 <= u <= 0x4DBF) or (0x20000 <= u <= 0x2A6DF) or (0x2A700 <= u <= 0x2B73F) or (0x2B740 <= u <= 0x2B81F)
+
+
+def ctc_word_boxes(line_bbox: np.ndarray, text: str, col_indices, seq_len: int, wh_ratio: float, max_wh_ratio: float):
+    """OAROCR::ctc_word_boxes, src/oarocr/ocr.rs:949-1020 (f32 arithmetic, same operation order); checker for oar_ctc_word_boxes."""
+    if not col_indices or seq_len == 0 or not text:
+        return []
+    f = np.float32
+    EPS = f(1.1920929e-7)
+    eff = f(f(seq_len) * f(f(wh_ratio) / f(max_wh_ratio)))
+    if eff <= EPS:
+        return []
+    xs, ys = np.asarray(line_bbox, np.float32)[:, 0], np.asarray(line_bbox, np.float32)[:, 1]
+    x_min, y_min, x_max, y_max = f(xs.min()), f(ys.min()), f(xs.max()), f(ys.max())
+    width = f(x_max - x_min)
+    cell = f(width / max(eff, EPS))
+    chars = list(text)
+    avg_w = f(width / f(max(len(chars), 1)))
+    centers = [f(x_min + f(f(f(i) + f(0.5)) * cell)) for i in col_indices]
+    boxes = []
+    n = len(col_indices)
+    for i in range(n):
+        ch = chars[i] if i < len(chars) else "?"
+        c = centers[i]
+        if _is_cjk(ch):
+            half = f(avg_w / f(2.0))
+            l, r = max(f(c - half), x_min), min(f(c + half), x_max)
+        else:
+            l = max(x_min if i == 0 else f(f(centers[i - 1] + c) / f(2.0)), x_min)
+            r = min(x_max if i == n - 1 else f(f(c + centers[i + 1]) / f(2.0)), x_max)
+        boxes.append(np.array([[l, y_min], [r, y_min], [r, y_max], [l, y_max]], np.float32))
+    return boxes
+
+
+
+def char_positions_to_word_boxes(line_bbox: np.ndarray, char_positions, char_count: int):
+    """OAROCR::char_positions_to_word_boxes, src/oarocr/ocr.rs:1036-1072."""
+    if len(char_positions) == 0 or char_count == 0:
+        return []
+    f = np.float32
+    xs, ys = np.asarray(line_bbox, np.float32)[:, 0], np.asarray(line_bbox, np.float32)[:, 1]
+    x_min, y_min, x_max, y_max = f(xs.min()), f(ys.min()), f(xs.max()), f(ys.max())
+    width = f(x_max - x_min)
+    cw = f(width / f(char_count))
+    boxes = []
+    for pos in char_positions:
+        c = f(x_min + f(f(pos) * width))
+        l, r = max(f(c - f(cw / f(2.0))), x_min), min(f(c + f(cw / f(2.0))), x_max)
+        boxes.append(np.array([[l, y_min], [r, y_min], [r, y_max], [l, y_max]], np.float32))
+    return boxes

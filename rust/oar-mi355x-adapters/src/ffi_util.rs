@@ -2,6 +2,7 @@
 
 use image::RgbImage;
 use oar_ocr_core::core::OCRError;
+use oar_ocr_core::core::config::{OrtExecutionProvider, OrtSessionConfig};
 use oar_ocr_core::core::inference::ModelSource;
 use std::path::PathBuf;
 use std::sync::Arc;
@@ -66,4 +67,20 @@ pub unsafe fn slice_or_empty<'a, T>(ptr: *const T, len: usize) -> &'a [T] {
         // SAFETY: guaranteed by the caller.
         unsafe { std::slice::from_raw_parts(ptr, len) }
     }
+}
+
+/// What an `OrtSessionConfig` means to this backend (`OrtConfigurable::with_ort_config`, core/traits/adapter.rs:126-129).
+/// The reference's generic construction path hands every adapter builder the pipeline's session configuration
+/// (`build_optional_adapter`, src/oarocr/builder_utils.rs:60-80; `OAROCRBuilder::build`, src/oarocr/ocr.rs:311,393).  Of
+/// that configuration only the DEVICE is meaningful here: the first execution provider that names a device id (CUDA,
+/// TensorRT, DirectML -- the accelerator entries a caller already has in its config) selects the MI355X with the same
+/// ordinal; thread counts, arena / optimisation levels and provider options configure ONNX Runtime and are ignored.
+/// `None`: the config names no device (CPU-only / OpenVINO / CoreML / WebGPU lists, or no list) -- the builder keeps its own.
+pub fn device_id_from_ort_config(config: &OrtSessionConfig) -> Option<i32> {
+    config.execution_providers.as_ref()?.iter().find_map(|ep| match ep {
+        OrtExecutionProvider::CUDA { device_id, .. }
+        | OrtExecutionProvider::TensorRT { device_id, .. }
+        | OrtExecutionProvider::DirectML { device_id } => Some(device_id.unwrap_or(0)),
+        _ => None,
+    })
 }

@@ -9,13 +9,14 @@
 //! `with_document_image_rectification`, `with_text_line_orientation_classification`).
 
 use crate::error::{Mi355xError, check};
-use crate::ffi_util::{ImageBatch, model_bytes, slice_or_empty};
+use crate::ffi_util::{ImageBatch, device_id_from_ort_config, model_bytes, slice_or_empty};
 use crate::orientation::{ClsHandle, Mi355xDocumentOrientationAdapter, Mi355xTextLineOrientationAdapter};
 use crate::rectification::RectHandle;
 use crate::text_recognition::{DictHandle, TextResultGuard};
 use image::RgbImage;
 use oar_mi355x_sys as sys;
 use oar_ocr_core::core::OCRError;
+use oar_ocr_core::core::config::OrtSessionConfig;
 use oar_ocr_core::core::inference::ModelSource;
 use oar_ocr_core::domain::TextRegion;
 use oar_ocr_core::processors::{BoundingBox, Point};
@@ -68,6 +69,14 @@ pub struct Mi355xOcrPage {
     pub rectified: bool,
 }
 
+struct WordBoxesGuard(sys::oar_word_boxes);
+impl Drop for WordBoxesGuard {
+    fn drop(&mut self) {
+        // SAFETY: filled by oar_ocr_word_boxes or all-NULL.
+        unsafe { sys::oar_word_boxes_free(&mut self.0) }
+    }
+}
+
 /// Builder with the surface of `OAROCRBuilder` (src/oarocr/ocr.rs:105-417) for the stages of the hot path.
 #[derive(Clone)]
 pub struct Mi355xOcrBuilder {
@@ -87,6 +96,7 @@ pub struct Mi355xOcrBuilder {
     device_id: i32,
     text_type: Option<String>,
     explicit_det_thresholds: bool,
+    return_word_box: bool,
 }
 
 impl Mi355xOcrBuilder {
@@ -110,6 +120,7 @@ impl Mi355xOcrBuilder {
             device_id: 0,
             text_type: None,
             explicit_det_thresholds: false,
+            return_word_box: false,
         }
     }
 
@@ -175,6 +186,21 @@ impl Mi355xOcrBuilder {
 
     pub fn device_id(mut self, device_id: i32) -> Self {
         self.device_id = device_id;
+        self
+    }
+
+    /// `OAROCRBuilder::ort_session` (src/oarocr/ocr.rs:135-141): the session configuration of every model of the pipeline.
+    /// Here it selects the device (see `device_id_from_ort_config`); the ONNX Runtime knobs do not apply.
+    pub fn ort_session(mut self, config: OrtSessionConfig) -> Self {
+        if let Some(device_id) = device_id_from_ort_config(&config) {
+            self.device_id = device_id;
+        }
+        self
+    }
+
+    /// `OAROCRBuilder::return_word_box` (src/oarocr/ocr.rs): fill `TextRegion::word_boxes` (row a21, `oar_ocr_word_boxes`).
+    pub fn return_word_box(mut self, enable: bool) -> Self {
+        self.return_word_box = enable;
         self
     }
 
@@ -287,6 +313,7 @@ impl Mi355xOcrBuilder {
             handle,
             dict,
             rec_score_thresh: self.rec_score_thresh,
+            return_word_box: self.return_word_box,
             _doc_orientation: doc_orientation,
             _rectifier: rectifier,
             _line_orientation: line_orientation,
@@ -301,6 +328,7 @@ pub struct Mi355xOcr {
     handle: OcrHandle,
     dict: DictHandle,
     rec_score_thresh: f32,
+    return_word_box: bool,
     _doc_orientation: Option<ClsHandle>,
     _rectifier: Option<RectHandle>,
     _line_orientation: Option<ClsHandle>,
@@ -333,6 +361,13 @@ impl Mi355xOcr {
         let status = unsafe { sys::oar_ocr_decode(self.dict.0.as_ptr(), &res.0, self.rec_score_thresh, &mut texts.0) };
         check(status).map_err(|e| e.into_adapter_error("OAROCR", "decode".to_string()))?;
         let decoded = texts.to_output(true);
+        // return_word_box (ocr.rs:860-877): OAROCR::ctc_word_boxes of every region, inside the library (row a21)
+        let mut word_boxes = WordBoxesGuard(sys::oar_word_boxes { n_regions: 0, box_offsets: std::ptr::null_mut(), boxes: std::ptr::null_mut() });
+        if self.return_word_box {
+            // SAFETY: res / texts were filled by the two calls above and describe the same regions; word_boxes is a valid out-parameter.
+            let status = unsafe { sys::oar_ocr_word_boxes(&res.0, &texts.0, &mut word_boxes.0) };
+            check(status).map_err(|e| e.into_adapter_error("OAROCR", "word boxes".to_string()))?;
+        }
 
         let r = &res.0;
         let (n, nr) = (r.n_images as usize, r.n_regions as usize);
@@ -352,6 +387,12 @@ impl Mi355xOcr {
                 if r.point_offsets.is_null() { None } else { Some(slice_or_empty(r.point_offsets, nr + 1)) },
             )
         };
+        // SAFETY: lengths as documented for oar_word_boxes (both arrays NULL when word boxes were not requested).
+        let (wb_offsets, wb_boxes) = unsafe {
+            let offs = slice_or_empty(word_boxes.0.box_offsets, if self.return_word_box { nr + 1 } else { 0 });
+            let total = offs.last().copied().unwrap_or(0) as usize;
+            (offs, slice_or_empty(word_boxes.0.boxes, total * 8))
+        };
         let mut pages = Vec::with_capacity(n);
         for i in 0..n {
             let (lo, hi) = (offsets[i] as usize, offsets[i + 1] as usize);
@@ -369,7 +410,16 @@ impl Mi355xOcr {
                     text: Some(Arc::from(decoded.texts[k].as_str())),
                     confidence: Some(decoded.scores[k]),
                     orientation_angle: if line_angle[k] >= 0.0 { Some(line_angle[k]) } else { None },
-                    word_boxes: None,
+                    // Some(..) exactly when the reference's branch at ocr.rs:860 is taken: word boxes requested and the region has characters
+                    word_boxes: if self.return_word_box && wb_offsets[k + 1] > wb_offsets[k] {
+                        Some(
+                            (wb_offsets[k] as usize..wb_offsets[k + 1] as usize)
+                                .map(|b| BoundingBox::new((0..4).map(|q| Point::new(wb_boxes[b * 8 + q * 2], wb_boxes[b * 8 + q * 2 + 1])).collect()))
+                                .collect(),
+                        )
+                    } else {
+                        None
+                    },
                     label: None,
                 };
                 regions.push(Mi355xOcrRegion {

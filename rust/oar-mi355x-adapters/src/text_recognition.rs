@@ -8,11 +8,13 @@
 
 use crate::error::{Mi355xError, check};
 use crate::ffi_util::{ImageBatch, model_bytes, slice_or_empty};
+use crate::ffi_util::device_id_from_ort_config;
 use oar_mi355x_sys as sys;
 use oar_ocr_core::core::OCRError;
 use oar_ocr_core::core::config::ConfigValidator;
 use oar_ocr_core::core::inference::ModelSource;
-use oar_ocr_core::core::traits::adapter::{AdapterBuilder, AdapterInfo, ModelAdapter};
+use oar_ocr_core::core::config::OrtSessionConfig;
+use oar_ocr_core::core::traits::adapter::{AdapterBuilder, AdapterInfo, ModelAdapter, OrtConfigurable};
 use oar_ocr_core::core::traits::task::{Task, TaskType};
 use oar_ocr_core::domain::tasks::{TextRecognitionConfig, TextRecognitionOutput, TextRecognitionTask};
 use std::ptr::NonNull;
@@ -356,5 +358,17 @@ impl AdapterBuilder for Mi355xTextRecognitionAdapterBuilder {
 
     fn adapter_type(&self) -> &str {
         "text_recognition"
+    }
+}
+
+/// `OrtConfigurable` (core/traits/adapter.rs:126-129): lets the reference's generic construction path
+/// (`build_optional_adapter`, src/oarocr/builder_utils.rs:60-80; `OAROCRBuilder::build`, src/oarocr/ocr.rs:311,393) configure
+/// this builder unchanged.  Only the device ordinal of the session configuration applies (see `device_id_from_ort_config`).
+impl OrtConfigurable for Mi355xTextRecognitionAdapterBuilder {
+    fn with_ort_config(mut self, config: OrtSessionConfig) -> Self {
+        if let Some(device_id) = device_id_from_ort_config(&config) {
+            self.device_id = device_id;
+        }
+        self
     }
 }

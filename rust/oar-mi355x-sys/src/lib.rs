@@ -210,6 +210,14 @@ pub struct oar_ocr_result {
 
 #[repr(C)]
 #[derive(Debug, Clone, Copy)]
+pub struct oar_word_boxes {
+    pub n_regions: u32,
+    pub box_offsets: *mut u64,
+    pub boxes: *mut f32,
+}
+
+#[repr(C)]
+#[derive(Debug, Clone, Copy)]
 pub struct oar_cls_cfg {
     pub device_id: i32,
     pub input_h: u32,
@@ -284,6 +292,10 @@ unsafe extern "C" {
     pub fn oar_ocr_predict_device(o: *mut oar_ocr, d_rgb: *const *const u8, widths: *const u32, heights: *const u32, n_images: u32, out: *mut oar_ocr_result) -> oar_status;
     pub fn oar_ocr_result_free(r: *mut oar_ocr_result);
     pub fn oar_ocr_decode(dict: *const oar_ctc_dict, res: *const oar_ocr_result, score_threshold: f32, out: *mut oar_text_result) -> oar_status;
+    pub fn oar_ctc_word_boxes(line_pts_xy: *const f32, n_points: u32, text_utf8: *const c_char, text_len: usize, col_indices: *const u32, n_cols: u32, seq_len: u32, wh_ratio: f32, max_wh_ratio: f32, boxes: *mut f32, cap_boxes: u32, n_boxes: *mut u32) -> oar_status;
+    pub fn oar_char_positions_to_word_boxes(line_pts_xy: *const f32, n_points: u32, char_positions: *const f32, n_positions: u32, char_count: u32, boxes: *mut f32, cap_boxes: u32, n_boxes: *mut u32) -> oar_status;
+    pub fn oar_ocr_word_boxes(res: *const oar_ocr_result, txt: *const oar_text_result, out: *mut oar_word_boxes) -> oar_status;
+    pub fn oar_word_boxes_free(w: *mut oar_word_boxes);
     pub fn oar_cls_create(onnx: *const u8, onnx_len: usize, cfg: *const oar_cls_cfg, out: *mut *mut oar_cls) -> oar_status;
     pub fn oar_cls_destroy(c: *mut oar_cls);
     pub fn oar_cls_run(c: *mut oar_cls, rgb: *const *const u8, widths: *const u32, heights: *const u32, n_images: u32, out: *mut oar_cls_result) -> oar_status;
@@ -304,6 +316,7 @@ unsafe extern "C" {
     /// fixed-length arrays: src_channels: [i32; 3], alpha: [f32; 3], beta: [f32; 3]
     pub fn oar_k_normalize(rgb: *const u8, w: u32, h: u32, src_channels: *const i32, alpha: *const f32, beta: *const f32, hwc_layout: i32, out: *mut f32) -> oar_status;
     pub fn oar_k_rec_preprocess(rgb: *const *const u8, widths: *const u32, heights: *const u32, n: u32, img_h: u32, img_w: u32, max_img_w: u32, out_nchw: *mut f32, tensor_width: *mut u32) -> oar_status;
+    pub fn oar_k_rec_preprocess_flip(rgb: *const *const u8, widths: *const u32, heights: *const u32, flips: *const u8, n: u32, img_h: u32, img_w: u32, max_img_w: u32, out_nchw: *mut f32, tensor_width: *mut u32) -> oar_status;
     pub fn oar_k_resize_triangle(rgb: *const u8, w: u32, h: u32, nw: u32, nh: u32, out: *mut u8) -> oar_status;
     pub fn oar_k_threshold(pred: *const f32, n: usize, thresh: f32, mask: *mut u8) -> oar_status;
     pub fn oar_k_dilate(mask: *const u8, height: u32, width: u32, out: *mut u8) -> oar_status;

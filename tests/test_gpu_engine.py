@@ -500,6 +500,11 @@ DS_CASES = [  # (C, Cout, k, stride, N, H, W, act, residual)
     (48, 96, 3, (2, 1), 2, 24, 50, "hswish", False), (96, 192, 3, (1, 2), 2, 12, 64, "hswish", False), (192, 192, 5, (1, 1), 3, 12, 40, "hswish", False),
     (64, 128, 5, (2, 2), 2, 30, 46, "hswish", False), (128, 128, 5, (1, 1), 2, 15, 23, "hswish", True), (32, 64, 3, (2, 2), 1, 37, 61, "relu", False),
     (192, 256, 5, (2, 1), 2, 12, 40, "swish", False), (8, 16, 3, (1, 1), 1, 9, 17, "hswish", False), (72, 40, 5, (1, 1), 1, 20, 36, None, False),
+    # round 3, the wave-autonomous kernel (dsblock_wa.inc: 3x3 stride 1): every instantiated fragment count, partial channel chunks, image
+    # borders on all four sides, many tiles per XCD band, the generic activation path, residual
+    (96, 96, 3, (1, 1), 2, 12, 160, "hswish", False), (64, 64, 3, (1, 1), 2, 30, 30, "hswish", True), (80, 80, 3, (1, 1), 1, 17, 35, "relu", False),
+    (32, 128, 3, (1, 1), 1, 21, 50, "hswish", False), (96, 192, 3, (1, 1), 2, 12, 70, "hswish", False), (20, 12, 3, (1, 1), 1, 40, 19, "swish", False),
+    (16, 24, 3, (1, 1), 3, 120, 136, "hswish", False), (48, 48, 3, (1, 1), 1, 3, 5, None, False),
 ]
 
 
@@ -526,6 +531,12 @@ def test_fused_dsblock_matches_oracle(case, monkeypatch):
     monkeypatch.setenv("OAR_FUSE_DSBLOCK", "0")
     plain = api.OrtInfer(m).infer(x)[0][1]
     assert np.abs(plain - got[0][1]).max() <= 2e-4 * max(1.0, float(np.abs(plain).max()))
+    monkeypatch.delenv("OAR_FUSE_DSBLOCK")
+    if k == 3 and stride == (1, 1):
+        # the two fused kernels share their arithmetic (FMA chain, exact bf16 split, order of the six products): bit-identical
+        monkeypatch.setenv("OAR_DSBLOCK_WA", "0")
+        old = api.OrtInfer(m).infer(x)[0][1]
+        assert np.array_equal(old, got[0][1])
 
 
 @pytest.mark.parametrize("case", ["fpn", "fallbacks"])

@@ -253,9 +253,10 @@ def test_gpu_contours_text_page_and_host_fallback():
     _same_contours(m5)
 
 
-def test_gpu_unclip_equals_the_host_routine_on_random_boxes():
-    """a11 as a HIP kernel (pp::unclip_quads, run next to the box scores): vertex for vertex what host::unclip -- and therefore the
-    oracle -- produces, on 20 000 random rectangles of every orientation, size and winding, at several ratios; degenerate boxes are
+def test_gpu_unclip_equals_the_oracle_on_random_boxes():
+    """a11 as a HIP kernel (pp::unclip_quads, run next to the box scores): vertex for vertex what the ORACLE's unclip (oracle/oar_oracle.c,
+    the restatement of db_bitmap.rs:279-368) produces -- compared directly, not through the product's own host routine
+    -- on 20 000 random rectangles of every orientation, size and winding, at several ratios; degenerate boxes are
     dropped by both."""
     rng = np.random.default_rng(77)
     n = 20000
@@ -276,7 +277,7 @@ def test_gpu_unclip_equals_the_host_routine_on_random_boxes():
         got = api.k_unclip(boxes, ratio)
         bad = 0
         for i in range(n):
-            ref = api.host_unclip(boxes[i], ratio)
+            ref = R.unclip(boxes[i], ratio)
             g = got[i]
             assert g is not None
             if g.shape != ref.shape or not np.array_equal(g, ref):
