@@ -216,8 +216,11 @@ def main():
 
     gathered = {"pages": 0, "regions": 0, "bytes": 0}
 
+    passes = {"n": 0}   # every oar_ocr_predict pass of this process (discovery + warm-up + timed): the divisor of a rocprofv3 --stats summary
+
     def step():
         """host pages -> boxes + texts + scores on the host of rank 0"""
+        passes["n"] += 1
         packed = eng.predict_packed(host_pages)
         if world == 1:
             gathered.update(pages=len(packed.region_offsets) - 1, regions=len(packed.scores), bytes=len(packed.utf8))
@@ -266,6 +269,8 @@ def main():
     if not stub:
         api.prof_sampling(1, 0)
     roof = None
+    from oar_ocr_amd.build import csrc_fingerprint
+    csrc_now = csrc_fingerprint()
     if dominant:
         snap = {e["name"]: e for e in api.prof_snapshot()}
         api.prof_enable(False)
@@ -282,12 +287,18 @@ def main():
                 ach, peak, unit, bound = e["alg_bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
             # HBM bytes per launch of this kernel class from the committed PMC passes (rocprofv3 cannot run inside the timed
             # region; tools/make_profile_summaries.py writes the file from separate --pmc FETCH_SIZE / WRITE_SIZE passes)
+            # The file carries the fingerprint of the csrc/ it was measured on: when the sources have changed since, the counters
+            # describe other kernels -- `traffic` is then null and traffic_source says why.
             traffic, traffic_src = None, None
             for tf in sorted(ROOT.glob("profiles/r*/pmc_traffic.json"), reverse=True):
                 try:
-                    t = json.loads(tf.read_text()).get(dominant)
+                    doc = json.loads(tf.read_text())
+                    t = doc.get(dominant)
                     if t:
-                        traffic, traffic_src = t["hbm_bytes_per_launch"], str(tf.relative_to(ROOT))
+                        fresh = doc.get("_csrc_fingerprint") == csrc_now
+                        traffic = t["hbm_bytes_per_launch"] if fresh else None
+                        traffic_src = (f"{tf.relative_to(ROOT)} (csrc fingerprint {csrc_now}: matches the timed build)" if fresh else
+                                       f"none: {tf.relative_to(ROOT)} was measured on csrc {doc.get('_csrc_fingerprint', 'unrecorded')}, this build is {csrc_now} -- re-run tools/profile_round.sh")
                         break
                 except Exception:
                     pass
@@ -305,6 +316,9 @@ def main():
         for mf in sorted(ROOT.glob("profiles/r*/mfma_util.json"), reverse=True):
             try:
                 m = json.loads(mf.read_text())
+                if m.get("_csrc_fingerprint") != csrc_now:
+                    mfma_util = {"classes": None, "source": f"none: {mf.relative_to(ROOT)} was measured on csrc {m.get('_csrc_fingerprint', 'unrecorded')}, this build is {csrc_now}"}
+                    break
                 mfma_util = {"unit": "% of the dense MFMA peak of the class's dtype (bf16 2500 / f32 157.3 TFLOP/s), time-weighted per class",
                              "source": str(mf.relative_to(ROOT)),
                              "classes": {k: v["pct_of_dense_peak"] for k, v in m.items() if isinstance(v, dict) and "pct_of_dense_peak" in v}}
@@ -343,17 +357,31 @@ def main():
         if args.cpu_pages > 0 and world == 1 and not stub:   # the CPU baseline is timed on rank 0 of the single-GPU run only
             from oracle import pipeline_ref
             torch.set_num_threads(min(os.cpu_count() or 1, 64))
+            # SURVEY 8d "ORT-CPU stand-in": only possible when onnxruntime AND operator-supplied weights exist on this box -- say which oracle ran
+            try:
+                import onnxruntime  # noqa: F401
+                have_ort = True
+            except Exception:
+                have_ort = False
+            real = sorted(str(q.relative_to(ROOT)) for q in (ROOT / "models").glob("*.onnx")) if (ROOT / "models").is_dir() else []
+            ort_note = ("not run: " + ("onnxruntime is not importable on this box" if not have_ort else "onnxruntime present") +
+                        ("; no models/*.onnx supplied (synthetic-weight graphs only)" if not real else f"; models present: {real}") +
+                        " -- the timed oracle is the torch-CPU port")
             sample = host_pages[:args.cpu_pages]
             stages = dict(doc_orientation=models.build_cls(4, seed=5)[0], rectifier=models.build_uvdoc(seed=6)[0],
                           line_orientation=models.build_cls(2, seed=9)[0]) if args.config == 4 else {}
-            oc = pipeline_ref.OracleOCR(det, rec, chars, 0.3, 0.6, 1.5, image_batch_size=1, region_batch_size=16, **stages)  # reference CPU policy (builder_utils.rs:111-125)
+            cpu_threads = torch.get_num_threads()
+            oc = pipeline_ref.OracleOCR(det, rec, chars, 0.3, 0.6, 1.5, image_batch_size=1, region_batch_size=16, threads=cpu_threads, **stages)  # reference CPU policy (builder_utils.rs:111-125)
             oc.predict(sample[:1])  # warm
             c0 = time.perf_counter()
             oc.predict(sample)
             cdt = time.perf_counter() - c0
-            cpu = {"value": round(len(sample) / cdt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            cpu = {"value": round(len(sample) / cdt, 3), "unit": "images/sec", "cores": cpu_threads, "kind": "port",
+                   "parallel": f"thread pool of {cpu_threads} over the crops of a page / of a recognition batch (where the reference's rayon pool fans out: "
+                               "processors.rs:113-131, crnn.rs:98-121) + torch-CPU intra-op threads for the networks; contour tracing / unclip serial per page as in the reference",
+                   "ort_cpu_standin": ort_note,
                    "sample": f"{len(sample)} of the same {size}x{size} synthetic pages, det batch 1 / rec batch 16 (reference CPU defaults); "
-                             "oracle = C restatement of pre/post (1 thread) + torch-CPU fp32 network (threads above); the reference's own "
+                             "oracle = C restatement of pre/post + torch-CPU fp32 network; the reference's own "
                              "published CPU figure is 34 ms/image (docs/FAQ.md:22, i9-13900KF, real weights)"}
         line = {
             "metric": "images/sec end-to-end PP-OCRv6 det+rec", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
@@ -370,7 +398,7 @@ def main():
                        "pages_per_gpu_per_step": n_pages, "image_batch_size": image_batch, "region_batch_size": args.region_batch,
                        "regions_per_step": gathered["regions"], "text_bytes_per_step": gathered["bytes"], "pages_gathered_per_step": gathered["pages"],
                        "parallelism": f"image-parallel x{world}", "host_cores_per_rank": cores},
-            "roofline": roof, "cpu_baseline": cpu, "device_resident": dev_res, "conv_mfma_util": mfma_util, "kernel_ms_per_step_untimed_pass": breakdown,
+            "roofline": roof, "cpu_baseline": cpu, "device_resident": dev_res, "conv_mfma_util": mfma_util, "kernel_ms_per_step_untimed_pass": breakdown, "predict_passes_total": passes["n"], "csrc_fingerprint": csrc_now,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

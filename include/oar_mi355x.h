@@ -266,6 +266,9 @@ typedef struct {
     uint32_t image_batch_size; /* 0 => adapter recommended 8  (text_detection_adapter.rs:85-87)   */
     uint32_t region_batch_size;/* 0 => this backend's recommended 256 (reference adapter: 64, text_recognition_adapter.rs:117-127) */
     uint32_t max_pooled_crops; /* 0 => 4096 (src/oarocr/ocr.rs:603)                            */
+    int32_t box_sort;          /* OAROCR::sort_detection_boxes keys on text_type, NOT on the detector's box type (ocr.rs:699-716):
+                                * 0 = derive from det.box_type (Poly -> sort_poly_boxes, Quad -> sort_quad_boxes: what text_type "seal" /
+                                * anything else gives when it configured both), 1 = sort_quad_boxes, 2 = sort_poly_boxes            */
 } oar_ocr_cfg;
 
 /* One entry per detected region, grouped per image in sorted (reading) order; regions whose crop failed

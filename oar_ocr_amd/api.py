@@ -79,7 +79,7 @@ class RecResult(C.Structure):
 
 class OcrCfg(C.Structure):
     _fields_ = [("det", DetCfg), ("rec", RecCfg), ("det_thresh", C.c_float), ("det_box_thresh", C.c_float), ("det_unclip_ratio", C.c_float),
-                ("image_batch_size", C.c_uint32), ("region_batch_size", C.c_uint32), ("max_pooled_crops", C.c_uint32)]
+                ("image_batch_size", C.c_uint32), ("region_batch_size", C.c_uint32), ("max_pooled_crops", C.c_uint32), ("box_sort", C.c_int32)]
 
 
 class OcrResult(C.Structure):
@@ -929,6 +929,8 @@ class OAROCRBuilder:
         cfg.image_batch_size = self._image_bs or 0      # accelerator: adapter defaults 8 / 64 (builder_utils.rs:86-102)
         cfg.region_batch_size = self._region_bs or 0
         cfg.max_pooled_crops = 0
+        # sort_detection_boxes keys on the text type (ocr.rs:699-716): 2 = sort_poly_boxes for "seal", 1 = sort_quad_boxes otherwise
+        cfg.box_sort = 2 if (self._text_type or "").lower() == "seal" else 1
         ocr = OAROCR(self._det, self._rec, self._dict, cfg, self._score_thr)
         if self._doc_ori or self._rectifier or self._line_ori:
             ocr.attach(ImageClassifier(self._doc_ori, device_id=self._device) if self._doc_ori else None,

@@ -61,6 +61,18 @@ def build_lib(force: bool = False, verbose: bool = False) -> Path:
     return LIB
 
 
+def csrc_fingerprint() -> str:
+    """sha256 over the kernel / host sources (csrc/*, sorted by name): recorded next to every committed counter summary
+    (profiles/r*/pmc_traffic.json, mfma_util.json) so that bench.py can tell when the code it is timing is no longer the code that
+    was profiled and refuse to echo stale counters."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(CSRC.iterdir()):
+        if f.suffix in (".hip", ".inc", ".cc", ".h"):
+            h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 if __name__ == "__main__":
     p = build_lib(force="--force" in sys.argv, verbose=True)
     print(p, p.stat().st_size)

@@ -52,6 +52,8 @@ WaShape wa_shape(const DsBlockP& p) {
     if ((e && atoi(e) == 0) || p.ks != 3 || p.sh != 1 || p.sw != 1) return r;
     if (p.C <= 0 || (p.C & 3) || p.Cout <= 0 || (p.Cout & 3) || (p.y_ld & 3) || p.N <= 0 || p.Ho <= 0 || p.Wo <= 0) return r;
     if (p.pt < 0 || p.pl < 0 || p.pt > 2 || p.pl > 2) return r;
+    auto plain = [](const Act& a) { return a.kind == ACT_NONE || a.kind == ACT_RELU || a.kind == ACT_HSWISH; };
+    if (!plain(p.act1) || !plain(p.act2)) return r;   // the rarely used activations stay with dsblock.inc (their exp / div paths cost this kernel registers)
     if ((long)p.H * p.W * p.C * 4 >= (1L << 31)) return r;   // 32-bit tile-relative source offsets
     r.nf = (p.Cout + 15) / 16;
     if (!(r.nf <= 6 || r.nf == 8 || r.nf == 12)) return r;
@@ -59,7 +61,7 @@ WaShape wa_shape(const DsBlockP& p) {
     const int TR = 4 * r.P, in_px = (TR + 2) * 18, nj = (in_px * 8 + 63) / 64;
     r.tiles_x = (p.Wo + 15) / 16; r.tiles_y = (p.Ho + TR - 1) / TR;
     r.tiles = (long)p.N * r.tiles_x * r.tiles_y;
-    r.lds = (size_t)kWaRing * nj * 1024 + (size_t)((p.C + 31) / 32) * 1280;
+    r.lds = (size_t)kWaRing * nj * 1024 + (size_t)((p.C + 31) / 32) * 1280 + (size_t)r.nf * 64;
     r.ok = true;
     return r;
 }

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_ext.h>
 
+#include <type_traits>
+
 #include "igemm_dev.h"
 #include "dsblock.h"
 
@@ -33,8 +35,8 @@ void dsblock_launch_k5s1(hipStream_t s, const DsP& p, int nfw, int pfw, int grid
 void dsblock_launch_k5s2(hipStream_t s, const DsP& p, int nfw, int pfw, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1);
 
 // wave-autonomous variant (dsblock_wa.inc; 3x3, stride 1): one translation unit per group of cout-fragment counts
-constexpr int kWaRing = 3;       // tile buffers in the LDS ring: 2 = one step of prefetch, 3 = two
-constexpr int kWaThreads = 320;  // 4 consumer waves + 1 producer wave
+constexpr int kWaRing = 2;       // tile buffers in LDS (the host sizes the allocation)
+constexpr int kWaThreads = 256;
 void dsblock_wa_launch_a(hipStream_t s, const DsP& p, int nf, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1);   // NF 1..4 (P = 2)
 void dsblock_wa_launch_b(hipStream_t s, const DsP& p, int nf, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1);   // NF 5, 6, 8 (P = 2), 12 (P = 1)
 template <int NF, int P, typename K>

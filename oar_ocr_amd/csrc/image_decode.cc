@@ -176,18 +176,46 @@ void decode_png(const uint8_t* b, size_t n, std::vector<uint8_t>& rgb, uint32_t&
     auto pass_h = [&](int p) { return hd.interlace ? (hd.h > (uint32_t)y0[p] ? (hd.h - y0[p] + dy[p] - 1) / dy[p] : 0u) : hd.h; };
     size_t raw_len = 0;
     for (int p = 0; p < passes; ++p) if (pass_w(p) && pass_h(p)) raw_len += (size_t)pass_h(p) * (1 + hd.row_bytes(pass_w(p)));
-    std::vector<uint8_t> raw(raw_len);
+    // Allocation budget of image::Limits::default() (max_alloc = 512 MiB, image 0.25 ImageReader): a forged IHDR must not make the
+    // library reserve gigabytes before a single IDAT byte has been looked at.  Distinct error, as the crate's LimitError is.
+    constexpr uint64_t kMaxAlloc = 512ull << 20;
+    OAR_CHECK((uint64_t)raw_len + (uint64_t)hd.w * hd.h * 3 <= kMaxAlloc, OAR_INVALID_INPUT,
+              "image load: PNG needs more than the 512 MiB allocation limit (image::Limits::default)");
+    // inflate in 32-bit-safe slices, and grow `raw` with the bytes actually produced: the allocation follows the data, not the header
+    std::vector<uint8_t> raw;
     {
         z_stream zs;
         std::memset(&zs, 0, sizeof zs);
         OAR_CHECK(inflateInit(&zs) == Z_OK, OAR_INTERNAL, "image load: zlib inflateInit failed");
-        zs.next_in = idat.data(); zs.avail_in = (uInt)std::min<size_t>(idat.size(), 0xffffffffu);
-        zs.next_out = raw.data(); zs.avail_out = (uInt)std::min<size_t>(raw.size(), 0xffffffffu);
-        const int rc = inflate(&zs, Z_FINISH);
-        const size_t got = zs.total_out;
+        size_t in_at = 0;
+        int rc = Z_OK;
+        while (rc != Z_STREAM_END) {
+            if (zs.avail_in == 0 && in_at < idat.size()) {
+                const size_t take = std::min<size_t>(idat.size() - in_at, 1u << 30);
+                zs.next_in = idat.data() + in_at; zs.avail_in = (uInt)take; in_at += take;
+            }
+            const size_t have = raw.size();
+            if (have == raw_len) {   // the stream may hold nothing more than its end marker / checksum now
+                uint8_t extra;
+                zs.next_out = &extra; zs.avail_out = 1;
+                rc = inflate(&zs, Z_NO_FLUSH);
+                if (rc == Z_STREAM_END && zs.avail_out == 1) break;
+                inflateEnd(&zs);
+                oar::fail(OAR_INVALID_INPUT, "image load: corrupt or truncated PNG image data");
+            }
+            const size_t grow = std::min<size_t>(raw_len - have, std::max<size_t>(have, 1u << 20));   // doubling, at least 1 MiB
+            raw.resize(have + grow);
+            zs.next_out = raw.data() + have; zs.avail_out = (uInt)grow;
+            rc = inflate(&zs, Z_NO_FLUSH);
+            raw.resize(have + (grow - zs.avail_out));
+            if (rc == Z_STREAM_END) break;
+            if (rc != Z_OK || (zs.avail_out != 0 && zs.avail_in == 0 && in_at >= idat.size())) {   // error, or input exhausted before the stream ended
+                inflateEnd(&zs);
+                oar::fail(OAR_INVALID_INPUT, "image load: corrupt or truncated PNG image data");
+            }
+        }
         inflateEnd(&zs);
-        OAR_CHECK((rc == Z_STREAM_END || (rc == Z_BUF_ERROR && got == raw.size()) || rc == Z_OK) && got == raw.size(), OAR_INVALID_INPUT,
-                  "image load: corrupt or truncated PNG image data");
+        OAR_CHECK(raw.size() == raw_len, OAR_INVALID_INPUT, "image load: corrupt or truncated PNG image data");
     }
     width = hd.w; height = hd.h;
     rgb.assign((size_t)hd.w * hd.h * 3, 0);

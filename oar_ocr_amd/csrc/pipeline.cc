@@ -1397,6 +1397,7 @@ Ocr::Ocr(const uint8_t* det, size_t det_len, const uint8_t* rec, size_t rec_len,
     // launch/latency-bound at 64 crops on 256 CUs; a drop-in adapter may report a larger recommended_batch_size.
     if (cfg_.region_batch_size == 0) cfg_.region_batch_size = 256;
     if (cfg_.max_pooled_crops == 0) cfg_.max_pooled_crops = 4096;  // src/oarocr/ocr.rs:603
+    OAR_CHECK(cfg_.box_sort >= 0 && cfg_.box_sort <= 2, OAR_INVALID_INPUT, "box_sort must be 0 (by box type), 1 (sort_quad_boxes) or 2 (sort_poly_boxes)");
     OAR_CHECK(cfg_.image_batch_size <= 4096 && cfg_.region_batch_size <= 4096, OAR_INVALID_INPUT,
               "batch sizes must be in 1..=4096");                  // src/oarocr/ocr.rs:250-255,419-430
     det_.reset(new Detector(det, det_len, cfg_.det));
@@ -1591,15 +1592,38 @@ void Ocr::predict_core(const std::vector<PageRef>& pages, std::vector<std::vecto
             std::vector<Planned> planned;
             for (int li = first; li < first + count; ++li) {
                 const int img = start + li;
-                const bool poly = cfg_.det.box_type == 1;   // seal text: polygons, sort_poly_boxes (ocr.rs:699-716)
+                const bool poly = cfg_.det.box_type == 1;   // BoxType::Poly (seal text): variable-size polygons
+                // sort_detection_boxes (ocr.rs:699-716) keys on text_type == "seal", the detector's box type is a separate setting:
+                // cfg_.box_sort 1 / 2 force sort_quad_boxes / sort_poly_boxes, 0 follows the box type (what text_type sets together)
+                const bool poly_sort = cfg_.box_sort == 2 || (cfg_.box_sort == 0 && poly);
                 std::vector<uint32_t> poly_off;
                 std::vector<int> order;
                 if (poly) {
                     poly_off.assign(boxes[li].counts.size() + 1, 0);
                     for (size_t b = 0; b < boxes[li].counts.size(); ++b) poly_off[b + 1] = poly_off[b] + boxes[li].counts[b];
+                } else if (poly_sort) {
+                    const size_t nb = boxes[li].pts.size() / 8;
+                    poly_off.resize(nb + 1);
+                    for (size_t b = 0; b <= nb; ++b) poly_off[b] = (uint32_t)(4 * b);
+                }
+                if (poly_sort) {
                     order = host::sort_poly_boxes(boxes[li].pts, poly_off);
-                } else {
+                } else if (!poly) {
                     order = host::sort_quad_boxes(boxes[li].pts);
+                } else {
+                    // sort_quad_boxes on polygons: the reference's routine only reads each box's y_min / x_min (sorting.rs:35-84); feed it the
+                    // polygons' axis-aligned corner boxes
+                    std::vector<float> aabb(boxes[li].counts.size() * 8);
+                    for (size_t b = 0; b < boxes[li].counts.size(); ++b) {
+                        float x0 = 3.4e38f, y0 = 3.4e38f, x1 = -3.4e38f, y1 = -3.4e38f;
+                        for (uint32_t q = poly_off[b]; q < poly_off[b + 1]; ++q) {
+                            const float x = boxes[li].pts[2 * q], y = boxes[li].pts[2 * q + 1];
+                            x0 = std::min(x0, x); x1 = std::max(x1, x); y0 = std::min(y0, y); y1 = std::max(y1, y);
+                        }
+                        const float q8[8] = {x0, y0, x1, y0, x1, y1, x0, y1};
+                        std::memcpy(aabb.data() + b * 8, q8, sizeof q8);
+                    }
+                    order = host::sort_quad_boxes(aabb);
                 }
                 per_image[img].resize(order.size());
                 for (size_t k = 0; k < order.size(); ++k) {

@@ -169,7 +169,7 @@ def rec_tensor_width(sizes, img_h=48, img_w=320, max_img_w=3200):
     return tw, rw
 
 
-def rec_preprocess(crops, img_h=48, img_w=320, max_img_w=3200, batch_max_wh_ratio=None) -> np.ndarray:
+def rec_preprocess(crops, img_h=48, img_w=320, max_img_w=3200, batch_max_wh_ratio=None, pool=None) -> np.ndarray:
     """models/recognition/crnn.rs:71-125. crops: list of [h,w,3] u8. Returns [n,3,img_h,Wt] f32.
     batch_max_wh_ratio: the crops are PART of a larger batch whose widest member has this w/h ratio (the tensor width of a
     batch is set by its widest crop, crnn.rs:80-87) -- used to check a few pages of a big pooled run."""
@@ -180,9 +180,14 @@ def rec_preprocess(crops, img_h=48, img_w=320, max_img_w=3200, batch_max_wh_rati
         tw = min(int(np.float32(img_h) * np.float32(batch_max_wh_ratio)), max_img_w)   # `(img_h as f32 * max_wh) as usize` (crnn.rs:87)
         rws = np.array([min(int(np.ceil(np.float32(img_h) * (np.float32(c.shape[1]) / np.float32(c.shape[0])))), tw) for c in crops], np.int32)
     out = np.zeros((len(crops), 3, img_h, tw), np.float32)
-    for i, c in enumerate(crops):
-        r = resize_triangle(c, int(rws[i]), img_h)
-        out[i] = crnn_normalize(r, tw)
+
+    def one(i):
+        out[i] = crnn_normalize(resize_triangle(crops[i], int(rws[i]), img_h), tw)
+    if pool is not None:   # the reference resizes / normalises the crops of a batch on its rayon pool (crnn.rs:98-121); ctypes calls release the GIL
+        list(pool.map(one, range(len(crops))))
+    else:
+        for i in range(len(crops)):
+            one(i)
     return out
 
 

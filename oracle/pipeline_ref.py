@@ -57,8 +57,10 @@ class OracleRecognizer:
         self.shape = rec_image_shape
         self.max_img_w = max_img_w
 
+    pool = None   # optional concurrent.futures executor: per-crop preprocessing in parallel (bench.py's cpu_baseline leg)
+
     def probs(self, crops, batch_max_wh_ratio=None):
-        x = R.rec_preprocess(crops, self.shape[1], self.shape[2], self.max_img_w, batch_max_wh_ratio)
+        x = R.rec_preprocess(crops, self.shape[1], self.shape[2], self.max_img_w, batch_max_wh_ratio, pool=self.pool)
         return onnx_ref.run(self.model, {self.input: x})[0], x
 
     def recognize(self, crops, batch_max_wh_ratio=None):
@@ -107,7 +109,10 @@ class OracleRectifier:
 
 class OracleOCR:
     def __init__(self, det, rec, character_list, thresh=0.3, box_thresh=0.6, unclip=2.0, image_batch_size=8, region_batch_size=64,
-                 max_pooled_crops=4096, doc_orientation=None, rectifier=None, line_orientation=None, **det_kw):
+                 max_pooled_crops=4096, doc_orientation=None, rectifier=None, line_orientation=None, threads=0, **det_kw):
+        """threads > 0: crops are cut and recognizer inputs packed on a thread pool of that size -- the places where the reference's own CPU
+        path fans out over its rayon pool (TextCroppingProcessor >= 16 boxes, src/oarocr/processors.rs:113-131; CRNN preprocess per crop,
+        crnn.rs:98-121).  Results are identical; only bench.py's cpu_baseline leg sets it."""
         self.det = OracleDetector(det, **det_kw)
         self.rec = OracleRecognizer(rec, character_list)
         self.p = (thresh, box_thresh, unclip)
@@ -117,6 +122,11 @@ class OracleOCR:
         self.rect = OracleRectifier(rectifier) if rectifier else None
         self.line_ori = OracleClassifier(line_orientation, (80, 160), None) if line_orientation else None
         self.page_meta = []
+        self.pool = None
+        if threads > 0:
+            from concurrent.futures import ThreadPoolExecutor
+            self.pool = ThreadPoolExecutor(max_workers=threads)
+            self.rec.pool = self.pool
 
     def preprocess(self, image):
         """DocumentPreprocessor::preprocess (src/oarocr/preprocess.rs:59-97): (image, angle | None, rotation | None, rectified)."""
@@ -156,11 +166,14 @@ class OracleOCR:
             else:
                 order = R.sort_quad_boxes(boxes)
             slots = []
-            for k, o in enumerate(order):
+
+            def cut(o, img_idx=img_idx, boxes=boxes):
                 if self.det.seal and len(boxes[o]) != 4:
-                    crop = poly_ref.crop_bounding_box(images[img_idx], boxes[o])
-                else:
-                    crop = R.rotate_crop(images[img_idx], boxes[o])
+                    return poly_ref.crop_bounding_box(images[img_idx], boxes[o])
+                return R.rotate_crop(images[img_idx], boxes[o])
+            crops = list(self.pool.map(cut, order)) if self.pool is not None and len(order) >= 16 else [cut(o) for o in order]
+            for k, o in enumerate(order):
+                crop = crops[k]
                 slots.append({"box": boxes[o].copy(), "det_score": float(scores[o]), "filled": False})
                 if crop is None:
                     continue

@@ -185,6 +185,7 @@ pub struct oar_ocr_cfg {
     pub image_batch_size: u32,
     pub region_batch_size: u32,
     pub max_pooled_crops: u32,
+    pub box_sort: i32,
 }
 
 #[repr(C)]

@@ -176,3 +176,32 @@ def test_decoded_page_goes_straight_into_the_pipeline_types():
     a = np.random.default_rng(1).integers(0, 256, (8, 8, 3))
     img = api.load_image_from_memory(encode_png(a, 2, 8))
     assert img.flags["C_CONTIGUOUS"] and img.dtype == np.uint8 and img.shape == (8, 8, 3)
+
+
+def test_forged_header_is_rejected_before_any_allocation():
+    """a 33-byte IHDR claiming 32768 x 32768 x RGBA16 (8 GiB of filtered data) used to make the decoder reserve the
+    buffers before it had looked at IDAT.  Now it is refused by the 512 MiB allocation budget of image::Limits::default(), quickly."""
+    import struct, time, zlib
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    ihdr = struct.pack(">IIBBBBB", 32768, 32768, 16, 6, 0, 0, 0)
+    blob = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b"")
+    t0 = time.time()
+    with pytest.raises(api.OCRError) as e:
+        api.load_image_from_memory(blob)
+    assert time.time() - t0 < 1.0
+    assert "512 MiB allocation limit" in str(e.value)
+
+
+def test_header_larger_than_the_stream_is_corrupt_not_oom():
+    """IHDR within the budget but an IDAT stream that ends early: `raw` grows with the inflated bytes only, the error is 'corrupt'."""
+    import struct, zlib
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    ihdr = struct.pack(">IIBBBBB", 8000, 8000, 8, 2, 0, 0, 0)     # 192 MB of RGB
+    blob = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(b"\0" * 4096)) + chunk(b"IEND", b"")
+    with pytest.raises(api.OCRError) as e:
+        api.load_image_from_memory(blob)
+    assert "corrupt or truncated" in str(e.value)

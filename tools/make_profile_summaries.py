@@ -9,11 +9,16 @@ usage: python tools/make_profile_summaries.py <tag> <steps_in_stats_run> [round_
 import csv, collections, json, shutil, subprocess, sys
 from pathlib import Path
 
-tag, steps = sys.argv[1], sys.argv[2]
+sys.path.insert(0, ".")
+from oar_ocr_amd.build import csrc_fingerprint
+
+tag, steps = sys.argv[1], sys.argv[2]   # steps: "auto" = the pass count the bench line of the stats run reports (gpurun_out/prof_<tag>.log)
 out = Path(sys.argv[3] if len(sys.argv) > 3 else "profiles/r2")
 out.mkdir(parents=True, exist_ok=True)
 src = Path("gpurun_out")
 shutil.copy(src / f"prof_{tag}" / f"{tag}_kernel_stats.csv", out / f"{tag}_kernel_stats.csv")
+if steps == "auto":
+    steps = "log:" + str(src / f"prof_{tag}.log")
 txt = subprocess.run([sys.executable, "tools/stats_summary.py", str(src / f"prof_{tag}" / f"{tag}_kernel_stats.csv"), steps, "40"], capture_output=True, text=True).stdout
 (out / f"{tag}_kernel_stats.txt").write_text(txt)
 txt = subprocess.run([sys.executable, "tools/pmc_summary.py", str(src), "40"], capture_output=True, text=True).stdout
@@ -39,7 +44,7 @@ f = per_class(src / "pmc_FETCH_SIZE" / "p_counter_collection.csv", "FETCH_SIZE")
 w = per_class(src / "pmc_WRITE_SIZE" / "p_counter_collection.csv", "WRITE_SIZE")
 res = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 2 --warmup 1 --cpu-pages 0 --no-prof`; "
                 "counters are in KiB; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md (HBM section); bytes are averages per launch of the class",
-       "_source_tag": tag}
+       "_source_tag": tag, "_csrc_fingerprint": csrc_fingerprint()}
 for c in f:
     fb = f[c][0] * 1024 * 2 / max(f[c][1], 1)
     wb = w.get(c, (0, 1))[0] * 1024 / max(w.get(c, (0, 1))[1], 1)
@@ -58,6 +63,7 @@ for (name, grid), m in mf.items():
         d = by[c]; d["us"] += m["us"] * m["n"]; d["n"] += m["n"]; d["busy"] += m["util"] * m["us"] * m["n"]; d["bf16"] += m["tf_bf16"] * m["us"] * m["n"]; d["f32"] += m["tf_f32"] * m["us"] * m["n"]
 util = {c: {"launches": d["n"], "avg_us": round(d["us"] / d["n"], 1), "mfma_busy_pct": round(d["busy"] / d["us"], 1), "bf16_tflops": round(d["bf16"] / d["us"], 1),
             "f32_tflops": round(d["f32"] / d["us"], 1), "pct_of_dense_peak": round(100 * (d["bf16"] / d["us"] / 2500.0 + d["f32"] / d["us"] / 157.3), 1)} for c, d in by.items()}
+util["_csrc_fingerprint"] = csrc_fingerprint()
 util["_note"] = ("time-weighted over the launches of each class; mfma_busy_pct = SQ_VALU_MFMA_BUSY_CYCLES / (4 x 256 x GRBM_GUI_ACTIVE) (rocprofv3 MfmaUtil); "
                  "tflops = SQ_INSTS_VALU_MFMA_MOPS_* x 512 / duration; dense peaks 2500 (bf16) / 157.3 (f32) TFLOP/s; calibration run in the pmc summary")
 (out / "mfma_util.json").write_text(json.dumps(util, indent=1) + "\n")
