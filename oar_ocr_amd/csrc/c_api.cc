@@ -18,6 +18,7 @@ struct oar_ocr { std::unique_ptr<Ocr> o; };
 struct oar_cls { std::unique_ptr<Classifier> c; };
 struct oar_rect { std::unique_ptr<Rectifier> r; };
 
+#include "jpeg_decode.h"
 namespace oar { namespace img {
 bool is_png(const uint8_t* b, size_t n);
 const char* sniff(const uint8_t* b, size_t n);
@@ -992,9 +993,19 @@ oar_status oar_image_decode(const uint8_t* bytes, size_t len, uint8_t** rgb, uin
     return guard([&] {
         OAR_CHECK(bytes && rgb && width && height, OAR_INVALID_INPUT, "oar_image_decode: bad arguments");
         *rgb = nullptr; *width = *height = 0;
+        if (img::is_jpeg(bytes, len)) {   // baseline / progressive Huffman JPEG (jpeg_decode.cc); pixel half on the host for this host-output entry
+            img::JpegImage ji;
+            img::jpeg_entropy_decode(bytes, len, ji);
+            std::vector<uint8_t> px;
+            img::jpeg_render_host(ji, px);
+            uint8_t* out = cmalloc<uint8_t>(px.size());
+            std::memcpy(out, px.data(), px.size());
+            *rgb = out; *width = ji.w; *height = ji.h;
+            return;
+        }
         if (!img::is_png(bytes, len)) {
             const char* what = img::sniff(bytes, len);
-            if (what) fail(OAR_UNSUPPORTED_OP, std::string("image load: ") + what + " is not decoded by this library (PNG is); use the reference's loader for it");
+            if (what) fail(OAR_UNSUPPORTED_OP, std::string("image load: ") + what + " is not decoded by this library (PNG and JPEG are); use the reference's loader for it");
             fail(OAR_INVALID_INPUT, "image load: unrecognised image format");
         }
         std::vector<uint8_t> px;

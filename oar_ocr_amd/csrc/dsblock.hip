@@ -57,6 +57,11 @@ WaShape wa_shape(const DsBlockP& p) {
     if ((long)p.H * p.W * p.C * 4 >= (1L << 31)) return r;   // 32-bit tile-relative source offsets
     r.nf = (p.Cout + 15) / 16;
     if (!(r.nf <= 6 || r.nf == 8 || r.nf == 12)) return r;
+    // Measured per layer at the bench shapes (tools/dsblock_bench.py, this kernel vs dsblock.inc): 16 -> 24 120 vs 149 us, 48 -> 48 135 vs
+    // 147, 24 -> 48 92 vs 91, 48 -> 48 @ 240^2 69 vs 80, 32 -> 32 33 vs 41, 64 -> 64 32 vs 33; 96 -> 96 212 vs 165: with 6+ cout fragments
+    // per wave the weight fragments (L1) and 176+ registers (2 waves / SIMD) cost more than the LDS operand round trip they replace.
+    // OAR_DSBLOCK_WA=2 takes every instantiated shape (A/B runs).
+    if (r.nf > 4 && !(e && atoi(e) == 2)) return r;
     r.P = r.nf == 12 ? 1 : 2;
     const int TR = 4 * r.P, in_px = (TR + 2) * 18, nj = (in_px * 8 + 63) / 64;
     r.tiles_x = (p.Wo + 15) / 16; r.tiles_y = (p.Ho + TR - 1) / TR;
