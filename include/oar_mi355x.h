@@ -437,14 +437,23 @@ oar_status oar_k_rotate_crop(const uint8_t* rgb, uint32_t w, uint32_t h, const f
 
 /* ------------------------------------------------------------------------------------------------ image decode
  * load_image_from_memory (oar-ocr-core/src/utils/image.rs:65-68: image::load_from_memory + DynamicImage::to_rgb8) for the
- * formats this library decodes itself: PNG, every colour type / bit depth / interlace mode, to the bytes the image crate
- * yields (palette and low-bit grey expanded, alpha dropped, 16-bit -> 8-bit as (v + 128) / 257).  *rgb receives width * height * 3
+ * formats this library decodes itself.  PNG: every colour type / bit depth / interlace mode, to the bytes the image crate
+ * yields (palette and low-bit grey expanded, alpha dropped, 16-bit -> 8-bit as (v + 128) / 257).  JPEG: baseline / extended
+ * sequential / progressive Huffman, 8-bit, grey or 3 components at any integral sampling ratio, restart intervals (jpeg_decode.cc):
+ * JPEG decoding is not bit-specified, so the bytes are those of the de-facto standard -- libjpeg(-turbo)'s default path (islow IDCT,
+ * fancy upsampling, its colour tables), exactly PIL's output -- and UNPINNED against zune-jpeg, the crate the reference links
+ * (expected agreement +-1..2 levels at chroma edges).  *rgb receives width * height * 3
  * bytes owned by the library (release with oar_image_free).  Errors: OAR_INVALID_INPUT = OCRError::ImageLoad (corrupt /
- * truncated data, CRC mismatch); OAR_UNSUPPORTED_OP = a format of the image crate that is not decoded here (JPEG, BMP, ...; the
+ * truncated data, CRC mismatch); OAR_UNSUPPORTED_OP = a format of the image crate that is not decoded here (BMP, GIF, WebP, ..., arithmetic-coded / 12-bit / CMYK JPEG; the
  * message names it) -- keep the reference's loader for those.  Thread-safe, no lock: decode a batch from as many threads as the
  * reference's rayon pool would use (utils/image.rs:299-345). */
 oar_status oar_image_decode(const uint8_t* bytes, size_t len, uint8_t** rgb, uint32_t* width, uint32_t* height);
 void oar_image_free(uint8_t* rgb);
+/* The same image decoded INTO HBM: *dev_rgb = width * height * 3 bytes on device_id (release with oar_dev_free), ready for
+ * oar_ocr_predict_device / oar_det_run_device.  For JPEG only the Huffman stream is decoded on the host; dequantisation, IDCT,
+ * chroma upsampling and colour conversion run as HIP kernels (jpeg.hip), bit-identical to oar_image_decode's host arithmetic.
+ * Other decoded formats (PNG) are decoded on the host and uploaded. */
+oar_status oar_image_decode_device(const uint8_t* bytes, size_t len, int32_t device_id, void** dev_rgb, uint32_t* width, uint32_t* height);
 
 /* ------------------------------------------------------------------------------------------------ host-side geometry hooks
  * The serial per-contour stages of DB post-processing and crop planning run on the host.

@@ -131,7 +131,7 @@ EXPORTS = [
     "oar_rect_run", "oar_ocr_attach", "oar_k_rotate_rgb", "oar_k_bgr_planes_to_rgb", "oar_host_rotate_back_points",
     "oar_engine_cache_stats", "oar_onnx_inspect", "oar_host_contours", "oar_ctc_dict_create", "oar_ctc_dict_destroy", "oar_ctc_dict_classes",
     "oar_ctc_decode", "oar_ocr_decode", "oar_text_result_free", "oar_db_postprocess_ex", "oar_k_dilate", "oar_k_poly_scores", "oar_debug_inject_failure", "oar_k_contours", "oar_host_contours_bits",
-    "oar_k_unclip", "oar_k_rec_preprocess_flip", "oar_ctc_word_boxes", "oar_char_positions_to_word_boxes", "oar_ocr_word_boxes", "oar_word_boxes_free", "oar_image_decode", "oar_image_free", "oar_host_approx_poly_dp", "oar_host_perimeter", "oar_host_unclip_poly", "oar_host_offset_ring", "oar_host_ring_outline", "oar_host_sort_poly_boxes",
+    "oar_k_unclip", "oar_k_rec_preprocess_flip", "oar_image_decode_device", "oar_ctc_word_boxes", "oar_char_positions_to_word_boxes", "oar_ocr_word_boxes", "oar_word_boxes_free", "oar_image_decode", "oar_image_free", "oar_host_approx_poly_dp", "oar_host_perimeter", "oar_host_unclip_poly", "oar_host_offset_ring", "oar_host_ring_outline", "oar_host_sort_poly_boxes",
 ]
 
 
@@ -209,6 +209,7 @@ def lib():
     L.oar_k_unclip.argtypes = [vp, C.c_uint32, C.c_float, vp, vp, C.c_uint32]
     L.oar_image_decode.argtypes = [vp, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.oar_image_free.argtypes = [C.POINTER(C.c_uint8)]
+    L.oar_image_decode_device.argtypes = [vp, C.c_size_t, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.oar_image_free.restype = None
     L.oar_k_rotate_crop.argtypes = [vp, C.c_uint32, C.c_uint32, f32p, vp, C.c_size_t, u32p, u32p]
     L.oar_host_candidates.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, vp, C.c_int32]
@@ -285,7 +286,8 @@ DEFAULT_PARALLEL_THRESHOLD = 4   # core/constants.rs:18
 
 def load_image_from_memory(data: bytes) -> np.ndarray:
     """utils/image.rs:65-68: encoded bytes -> [H, W, 3] u8 (RgbImage).  PNG is decoded by the library to the bytes image 0.25.6
-    yields; other formats raise OCRError with OAR_UNSUPPORTED_OP (the message names the format)."""
+    yields, JPEG to libjpeg's default-path bytes (= PIL's; unpinned against zune-jpeg); other formats raise OCRError with
+    OAR_UNSUPPORTED_OP (the message names the format)."""
     buf = (C.c_char * len(data)).from_buffer_copy(data) if len(data) else (C.c_char * 1)()
     out = C.POINTER(C.c_uint8)()
     w, h = C.c_uint32(0), C.c_uint32(0)
@@ -294,6 +296,18 @@ def load_image_from_memory(data: bytes) -> np.ndarray:
         return np.ctypeslib.as_array(out, shape=(h.value, w.value, 3)).copy()
     finally:
         lib().oar_image_free(out)
+
+
+def load_image_to_device(data: bytes, device_id: int = 0):
+    """oar_image_decode_device: the decoded page in HBM (JPEG: Huffman on the host, IDCT / upsampling / colour as HIP kernels).
+    Returns (DeviceBuffer-like pointer holder, width, height); pass .ptr to predict_device, free() when done."""
+    buf = (C.c_char * len(data)).from_buffer_copy(data) if len(data) else (C.c_char * 1)()
+    ptr = C.c_void_p()
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    _check(lib().oar_image_decode_device(C.cast(buf, C.c_void_p), len(data), device_id, C.byref(ptr), C.byref(w), C.byref(h)))
+    holder = DeviceBuffer.__new__(DeviceBuffer)
+    holder.ptr, holder.nbytes = ptr, w.value * h.value * 3
+    return holder, w.value, h.value
 
 
 def load_image(path) -> np.ndarray:

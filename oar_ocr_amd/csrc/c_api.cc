@@ -19,6 +19,7 @@ struct oar_cls { std::unique_ptr<Classifier> c; };
 struct oar_rect { std::unique_ptr<Rectifier> r; };
 
 #include "jpeg_decode.h"
+#include "jpeg_dev.h"
 namespace oar { namespace img {
 bool is_png(const uint8_t* b, size_t n);
 const char* sniff(const uint8_t* b, size_t n);
@@ -1017,6 +1018,58 @@ oar_status oar_image_decode(const uint8_t* bytes, size_t len, uint8_t** rgb, uin
     });
 }
 void oar_image_free(uint8_t* rgb) { std::free(rgb); }
+
+oar_status oar_image_decode_device(const uint8_t* bytes, size_t len, int32_t device_id, void** dev_rgb, uint32_t* width, uint32_t* height) {
+    return guard([&] {
+        OAR_CHECK(bytes && dev_rgb && width && height, OAR_INVALID_INPUT, "oar_image_decode_device: bad arguments");
+        *dev_rgb = nullptr; *width = *height = 0;
+        require_device();
+        OAR_HIP(hipSetDevice(device_id));
+        if (img::is_jpeg(bytes, len)) {
+            // entropy decoding on the host (serial by nature), the arithmetic on the GPU: coefficient planes up, RGB page born in HBM
+            img::JpegImage ji;
+            img::jpeg_entropy_decode(bytes, len, ji);
+            pp::JpegDevPlan plan{};
+            plan.ncomp = ji.ncomp; plan.hmax = ji.hmax; plan.vmax = ji.vmax; plan.color = ji.color; plan.w = ji.w; plan.h = ji.h;
+            size_t coef_bytes = 0, plane_bytes = 0;
+            for (int c = 0; c < ji.ncomp; ++c) { coef_bytes += ji.comp[c].coef.size() * 2; plane_bytes += (size_t)ji.comp[c].bw * ji.comp[c].bh * 64; }
+            DevBuf work;   // [coefficients][planes][quantisation tables]
+            work.reserve(coef_bytes + plane_bytes + 3 * 64 * 2 + 256);
+            uint8_t* base = work.as<uint8_t>();
+            size_t co = 0, po = coef_bytes;
+            uint16_t qh[3 * 64] = {0};
+            for (int c = 0; c < ji.ncomp; ++c) {
+                const img::JpegComp& k = ji.comp[c];
+                OAR_HIP(hipMemcpyAsync(base + co, k.coef.data(), k.coef.size() * 2, hipMemcpyHostToDevice, nullptr));
+                plan.comp[c] = pp::JpegDevComp{reinterpret_cast<const int16_t*>(base + co), base + po, k.h, k.v, k.bw, k.bh, k.dw, k.dh};
+                plan.total_blocks += (long)k.bw * k.bh;
+                co += k.coef.size() * 2; po += (size_t)k.bw * k.bh * 64;
+                std::memcpy(qh + c * 64, k.q, 128);
+            }
+            const size_t qo = (po + 127) & ~(size_t)127;
+            OAR_HIP(hipMemcpyAsync(base + qo, qh, sizeof qh, hipMemcpyHostToDevice, nullptr));
+            plan.q = reinterpret_cast<const uint16_t*>(base + qo);
+            void* out = nullptr;
+            OAR_HIP(hipMalloc(&out, (size_t)ji.w * ji.h * 3));
+            pp::jpeg_render(nullptr, plan, static_cast<uint8_t*>(out));
+            const hipError_t e = hipStreamSynchronize(nullptr);
+            if (e != hipSuccess) { (void)hipFree(out); fail(OAR_DEVICE, std::string("oar_image_decode_device: ") + hipGetErrorString(e)); }
+            *dev_rgb = out; *width = ji.w; *height = ji.h;
+            return;
+        }
+        // every other decoded format: host decode, one upload
+        uint8_t* host = nullptr;
+        uint32_t w = 0, h = 0;
+        const oar_status st = oar_image_decode(bytes, len, &host, &w, &h);
+        if (st != OAR_OK) { char msg[512]; oar_last_error(msg, sizeof msg); fail(st, msg); }
+        void* out = nullptr;
+        const hipError_t e1 = hipMalloc(&out, (size_t)w * h * 3);
+        const hipError_t e2 = e1 == hipSuccess ? hipMemcpy(out, host, (size_t)w * h * 3, hipMemcpyHostToDevice) : e1;
+        std::free(host);
+        if (e2 != hipSuccess) { if (out) (void)hipFree(out); fail(OAR_DEVICE, std::string("oar_image_decode_device: ") + hipGetErrorString(e2)); }
+        *dev_rgb = out; *width = w; *height = h;
+    });
+}
 
 int32_t oar_host_approx_poly_dp(const float* xy, int32_t n_points, float epsilon, float* out_xy, int32_t cap_points) {
     try {

@@ -330,6 +330,7 @@ unsafe extern "C" {
     pub fn oar_k_rotate_crop(rgb: *const u8, w: u32, h: u32, box_: *const f32, out: *mut u8, cap: usize, out_w: *mut u32, out_h: *mut u32) -> oar_status;
     pub fn oar_image_decode(bytes: *const u8, len: usize, rgb: *mut *mut u8, width: *mut u32, height: *mut u32) -> oar_status;
     pub fn oar_image_free(rgb: *mut u8);
+    pub fn oar_image_decode_device(bytes: *const u8, len: usize, device_id: i32, dev_rgb: *mut *mut c_void, width: *mut u32, height: *mut u32) -> oar_status;
     pub fn oar_host_candidates(mask: *const u8, width: u32, height: u32, max_candidates: u32, max_bands: i32, boxes8: *mut f32, cap: i32) -> i32;
     pub fn oar_host_contours(mask: *const u8, width: u32, height: u32, max_contours: u32, max_bands: i32, offsets: *mut i64, pts_xy: *mut i32, types: *mut i32, cap_points: i64) -> i32;
     pub fn oar_host_contours_bits(mask: *const u8, width: u32, height: u32, max_contours: u32, max_bands: i32, offsets: *mut i64, pts_xy: *mut i32, types: *mut i32, cap_points: i64) -> i32;

@@ -144,7 +144,7 @@ def test_damaged_files_are_image_load_errors_not_pixels():
 
 
 def test_formats_of_the_image_crate_that_are_not_decoded_here_say_so():
-    for name, head in (("JPEG", b"\xff\xd8\xff\xe0\x00\x10JFIF"), ("BMP", b"BM" + b"\0" * 30), ("GIF", b"GIF89a" + b"\0" * 20), ("WebP", b"RIFF\0\0\0\0WEBPVP8 "),
+    for name, head in (("BMP", b"BM" + b"\0" * 30), ("GIF", b"GIF89a" + b"\0" * 20), ("WebP", b"RIFF\0\0\0\0WEBPVP8 "),
                        ("TIFF", b"II*\0" + b"\0" * 20), ("PNM", b"P6\n1 1\n255\n\0\0\0")):
         with pytest.raises(api.OCRError) as e:
             api.load_image_from_memory(head)
@@ -205,3 +205,107 @@ def test_header_larger_than_the_stream_is_corrupt_not_oom():
     with pytest.raises(api.OCRError) as e:
         api.load_image_from_memory(blob)
     assert "corrupt or truncated" in str(e.value)
+
+
+# ------------------------------------------------------------------------------------------------ JPEG (round 3)
+def _jpeg_bytes(arr, **kw):
+    import io
+    from PIL import Image
+    bio = io.BytesIO()
+    Image.fromarray(arr).save(bio, "JPEG", **kw)
+    return bio.getvalue()
+
+
+def _pil_rgb(data):
+    import io
+    from PIL import Image
+    return np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+
+
+def _test_image(h, w, seed=0):
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    a = np.stack([(x * 3 + y) % 256, (x + y * 2) % 256, (x * y // 7) % 256], -1).astype(np.uint8)
+    a[h // 4:h // 2, w // 4:w // 2] = rng.integers(0, 256, (h // 2 - h // 4, w // 2 - w // 4, 3))
+    return a
+
+
+JPEG_SIZES = [(16, 16), (17, 23), (64, 48), (100, 133), (7, 5), (1, 1), (33, 129), (2, 300)]
+
+
+@pytest.mark.parametrize("progressive", [False, True], ids=["baseline", "progressive"])
+@pytest.mark.parametrize("subsampling", [0, 1, 2, "4:1:1", "4:4:0"], ids=["444", "422", "420", "411", "440"])
+def test_jpeg_equals_libjpeg_turbo_bit_for_bit(subsampling, progressive):
+    """JPEG decoding is not bit-specified; this decoder restates libjpeg's default path (islow IDCT, fancy h2v1 / h2v2 / h1v2 upsampling,
+    replication elsewhere, ycc_rgb tables).  PIL decodes through libjpeg-turbo with those defaults: EXACT equality on every size /
+    subsampling / mode / quality here, including partial MCUs, 1-pixel images and components too narrow for the fancy filters."""
+    for (h, w) in JPEG_SIZES:
+        for q in (35, 90, 100):
+            try:
+                data = _jpeg_bytes(_test_image(h, w, h * w + q), quality=q, subsampling=subsampling, progressive=progressive, optimize=(q == 90))
+            except (ValueError, TypeError, KeyError):
+                pytest.skip("this Pillow cannot write the subsampling")
+            got = api.load_image_from_memory(data)
+            assert np.array_equal(got, _pil_rgb(data)), (h, w, q)
+
+
+def test_jpeg_grey_restart_intervals_and_large_image():
+    from PIL import Image
+    for (h, w) in JPEG_SIZES:
+        g = _test_image(h, w, 3)[:, :, 0]
+        for prog in (False, True):
+            data = _jpeg_bytes(g, quality=80, progressive=prog)
+            assert np.array_equal(api.load_image_from_memory(data), _pil_rgb(data))
+    a = _test_image(240, 333, 5)
+    for kw in (dict(restart_marker_blocks=3), dict(restart_marker_rows=1), dict(restart_marker_blocks=1, progressive=True)):
+        try:
+            data = _jpeg_bytes(a, quality=75, subsampling=2, **kw)
+        except TypeError:
+            continue
+        assert b"\xff\xdd" in data                    # a DRI segment was really written
+        assert np.array_equal(api.load_image_from_memory(data), _pil_rgb(data)), kw
+    big = _test_image(960, 1280, 11)
+    data = _jpeg_bytes(big, quality=85, subsampling=2)
+    got = api.load_image_from_memory(data)
+    assert np.array_equal(got, _pil_rgb(data))
+    assert np.abs(got.astype(np.int32) - big).mean() < 40    # and it IS the picture (the test pattern is deliberately busy)
+
+
+def test_jpeg_damage_and_undecoded_processes():
+    a = _test_image(64, 80, 1)
+    good = _jpeg_bytes(a, quality=80)
+    for blob in (good[:200], good[:2], good[:-2][:len(good) // 2]):
+        with pytest.raises(api.OCRError) as e:
+            api.load_image_from_memory(blob)
+        assert e.value.code == api.OAR_INVALID_INPUT
+    from PIL import Image
+    import io
+    bio = io.BytesIO()
+    Image.fromarray(a).convert("CMYK").save(bio, "JPEG")
+    with pytest.raises(api.OCRError) as e:
+        api.load_image_from_memory(bio.getvalue())
+    assert e.value.code == api.OAR_UNSUPPORTED_OP and "CMYK" in e.value.message
+    sof = good.index(b"\xff\xc0")
+    arith = good[:sof] + b"\xff\xc9" + good[sof + 2:]          # SOF9: arithmetic coding
+    with pytest.raises(api.OCRError) as e:
+        api.load_image_from_memory(arith)
+    assert e.value.code == api.OAR_UNSUPPORTED_OP and "arithmetic" in e.value.message
+    huge = good[:sof + 5] + b"\xff\xff\xff\xff" + good[sof + 9:]     # 65535 x 65535: refused by the allocation budget, not attempted
+    with pytest.raises(api.OCRError) as e:
+        api.load_image_from_memory(huge)
+    assert "512 MiB allocation limit" in e.value.message
+
+
+def test_load_images_mixed_png_and_jpeg(tmp_path):
+    """load_images (utils/image.rs:299-345) over a directory of both formats, sequential and parallel: same pages either way"""
+    from PIL import Image
+    want, paths = [], []
+    for i in range(12):
+        a = _test_image(40 + 3 * i, 60 + i, i)
+        p = tmp_path / (f"p{i}.png" if i % 2 else f"p{i}.jpg")
+        Image.fromarray(a).save(p, **({} if i % 2 else dict(quality=90, subsampling=i % 3, progressive=bool(i % 4))))
+        paths.append(str(p))
+        want.append(a if i % 2 else np.asarray(Image.open(p).convert("RGB")))
+    for thr in (100, 2):
+        got = api.load_images(paths, parallel_threshold=thr)
+        assert all(np.array_equal(g, w) for g, w in zip(got, want))
