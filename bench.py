@@ -51,6 +51,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-pages", type=int, default=3, help="pages in the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--no-device-resident", action="store_true", help="skip the second, device-resident timing")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the third timing (two calls in flight through oar_ocr_predict_async)")
     ap.add_argument("--config", type=int, default=1, choices=(1, 2, 3, 4),
                     help="BASELINE.json configs index: 1 = v6-tiny det+rec on 32 x 960^2 pages per GPU (the metric's configuration, default); "
                          "2 = server-size det + SVTR rec (V=18710) on 64 x 1280^2 pages; 3 = v6-tiny, 1024 pages block-partitioned over the ranks; "
@@ -351,6 +352,28 @@ def main():
         for b in dev_pages:
             b.free()
 
+    # -- third figure: two calls in flight on one handle (oar_ocr_predict_async, oar_ocr_cfg.lanes = 2): call k + 1 uploads and detects
+    # while call k recognises.  Same pages, same per-call results (tests/test_gpu_async.py); reported next to the synchronous headline.
+    pipelined = None
+    if not stub and not args.no_pipelined and world == 1:
+        eng.close()
+        ocr2 = builder.lanes(2).build()
+        for _ in range(max(2, args.warmup)):
+            ocr2.wait_packed(ocr2.submit_packed(h_ptrs, h_ws, h_hs, n_pages), n_pages)
+        torch.cuda.synchronize()
+        p0 = time.perf_counter()
+        tickets = [ocr2.submit_packed(h_ptrs, h_ws, h_hs, n_pages)]
+        for i in range(args.steps):
+            if i + 1 < args.steps:
+                tickets.append(ocr2.submit_packed(h_ptrs, h_ws, h_hs, n_pages))
+            ocr2.wait_packed(tickets[i], n_pages)
+        torch.cuda.synchronize()
+        pdt = time.perf_counter() - p0
+        pipelined = {"value": round(n_pages * args.steps / pdt, 2), "unit": "images/sec", "ms_per_step": round(pdt / args.steps * 1e3, 3), "calls_in_flight": 2,
+                     "what": "the same host-entry step through oar_ocr_predict_async / oar_ocr_wait with oar_ocr_cfg.lanes = 2: every call is still one "
+                             "OAROCR::predict (crops pooled over its own pages), two are in flight"}
+        ocr2.close()
+
     if rank == 0:
         value = total_pages * args.steps / tmax
         cpu = None
@@ -398,7 +421,7 @@ def main():
                        "pages_per_gpu_per_step": n_pages, "image_batch_size": image_batch, "region_batch_size": args.region_batch,
                        "regions_per_step": gathered["regions"], "text_bytes_per_step": gathered["bytes"], "pages_gathered_per_step": gathered["pages"],
                        "parallelism": f"image-parallel x{world}", "host_cores_per_rank": cores},
-            "roofline": roof, "cpu_baseline": cpu, "device_resident": dev_res, "conv_mfma_util": mfma_util, "kernel_ms_per_step_untimed_pass": breakdown, "predict_passes_total": passes["n"], "csrc_fingerprint": csrc_now,
+            "roofline": roof, "cpu_baseline": cpu, "device_resident": dev_res, "pipelined": pipelined, "conv_mfma_util": mfma_util, "kernel_ms_per_step_untimed_pass": breakdown, "predict_passes_total": passes["n"], "csrc_fingerprint": csrc_now,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -269,6 +269,8 @@ typedef struct {
     int32_t box_sort;          /* OAROCR::sort_detection_boxes keys on text_type, NOT on the detector's box type (ocr.rs:699-716):
                                 * 0 = derive from det.box_type (Poly -> sort_poly_boxes, Quad -> sort_quad_boxes: what text_type "seal" /
                                 * anything else gives when it configured both), 1 = sort_quad_boxes, 2 = sort_poly_boxes            */
+    uint32_t lanes;            /* 0 / 1 => one pipeline; n (<= 8) => n complete pipelines behind the handle (own engines, streams,
+                                * staging; the geometry threads are split between them) for oar_ocr_predict_async            */
 } oar_ocr_cfg;
 
 /* One entry per detected region, grouped per image in sorted (reading) order; regions whose crop failed
@@ -305,6 +307,16 @@ oar_status oar_ocr_predict(oar_ocr* o, const uint8_t* const* rgb, const uint32_t
 oar_status oar_ocr_predict_device(oar_ocr* o, const uint8_t* const* d_rgb, const uint32_t* widths,
                                   const uint32_t* heights, uint32_t n_images, oar_ocr_result* out);
 void oar_ocr_result_free(oar_ocr_result* r);
+/* Calls in flight.  oar_ocr_predict_async queues one OAROCR::predict (same arguments; device_pages != 0: the pointers are device
+ * memory, as for oar_ocr_predict_device) on the next lane of the handle and returns a ticket at once; oar_ocr_wait blocks until
+ * that call has finished and hands over its result (or its error: status + oar_last_error).  With oar_ocr_cfg.lanes = 2, call
+ * k + 1 uploads and detects while call k recognises -- the GPU time a single synchronous predict cannot fill (its recogniser
+ * must wait for the last page's boxes: crops are pooled over the pages of one call, src/oarocr/ocr.rs:594-634).  Every call is
+ * still one predict on one lane, so its result is exactly the synchronous one.  The page buffers must stay valid until the
+ * ticket has been waited for; every ticket must be waited for exactly once.  Thread-safe. */
+oar_status oar_ocr_predict_async(oar_ocr* o, const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights, uint32_t n_images,
+                                 int32_t device_pages, uint64_t* ticket);
+oar_status oar_ocr_wait(oar_ocr* o, uint64_t ticket, oar_ocr_result* out);
 /* Texts / scores / character columns of every region of a pipeline result, region order = res's
  * (OAROCR::recognize_global's scatter, src/oarocr/ocr.rs:840-891). */
 oar_status oar_ocr_decode(const oar_ctc_dict* dict, const oar_ocr_result* res, float score_threshold, oar_text_result* out);

@@ -79,7 +79,7 @@ class RecResult(C.Structure):
 
 class OcrCfg(C.Structure):
     _fields_ = [("det", DetCfg), ("rec", RecCfg), ("det_thresh", C.c_float), ("det_box_thresh", C.c_float), ("det_unclip_ratio", C.c_float),
-                ("image_batch_size", C.c_uint32), ("region_batch_size", C.c_uint32), ("max_pooled_crops", C.c_uint32), ("box_sort", C.c_int32)]
+                ("image_batch_size", C.c_uint32), ("region_batch_size", C.c_uint32), ("max_pooled_crops", C.c_uint32), ("box_sort", C.c_int32), ("lanes", C.c_uint32)]
 
 
 class OcrResult(C.Structure):
@@ -131,7 +131,7 @@ EXPORTS = [
     "oar_rect_run", "oar_ocr_attach", "oar_k_rotate_rgb", "oar_k_bgr_planes_to_rgb", "oar_host_rotate_back_points",
     "oar_engine_cache_stats", "oar_onnx_inspect", "oar_host_contours", "oar_ctc_dict_create", "oar_ctc_dict_destroy", "oar_ctc_dict_classes",
     "oar_ctc_decode", "oar_ocr_decode", "oar_text_result_free", "oar_db_postprocess_ex", "oar_k_dilate", "oar_k_poly_scores", "oar_debug_inject_failure", "oar_k_contours", "oar_host_contours_bits",
-    "oar_k_unclip", "oar_k_rec_preprocess_flip", "oar_image_decode_device", "oar_ctc_word_boxes", "oar_char_positions_to_word_boxes", "oar_ocr_word_boxes", "oar_word_boxes_free", "oar_image_decode", "oar_image_free", "oar_host_approx_poly_dp", "oar_host_perimeter", "oar_host_unclip_poly", "oar_host_offset_ring", "oar_host_ring_outline", "oar_host_sort_poly_boxes",
+    "oar_k_unclip", "oar_k_rec_preprocess_flip", "oar_image_decode_device", "oar_ocr_predict_async", "oar_ocr_wait", "oar_ctc_word_boxes", "oar_char_positions_to_word_boxes", "oar_ocr_word_boxes", "oar_word_boxes_free", "oar_image_decode", "oar_image_free", "oar_host_approx_poly_dp", "oar_host_perimeter", "oar_host_unclip_poly", "oar_host_offset_ring", "oar_host_ring_outline", "oar_host_sort_poly_boxes",
 ]
 
 
@@ -209,6 +209,8 @@ def lib():
     L.oar_k_unclip.argtypes = [vp, C.c_uint32, C.c_float, vp, vp, C.c_uint32]
     L.oar_image_decode.argtypes = [vp, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.oar_image_free.argtypes = [C.POINTER(C.c_uint8)]
+    L.oar_ocr_predict_async.argtypes = [vp, u8pp, u32p, u32p, C.c_uint32, C.c_int32, C.POINTER(C.c_uint64)]
+    L.oar_ocr_wait.argtypes = [vp, C.c_uint64, vp]
     L.oar_image_decode_device.argtypes = [vp, C.c_size_t, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.oar_image_free.restype = None
     L.oar_k_rotate_crop.argtypes = [vp, C.c_uint32, C.c_uint32, f32p, vp, C.c_size_t, u32p, u32p]
@@ -860,6 +862,7 @@ class OAROCRBuilder:
         self._det, self._rec, self._dict = det_model, rec_model, list(character_dict)
         self._image_bs = None
         self._region_bs = None
+        self._lanes = 0
         self._det_cfg: Optional[TextDetectionConfig] = None
         self._score_thr = 0.0
         self._device = 0
@@ -894,6 +897,11 @@ class OAROCRBuilder:
 
     def region_batch_size(self, n: int):
         self._region_bs = n
+        return self
+
+    def lanes(self, n: int):
+        """This backend's addition: n complete pipelines behind the handle for submit() / wait() (oar_ocr_cfg.lanes)."""
+        self._lanes = int(n)
         return self
 
     def text_detection_config(self, cfg: TextDetectionConfig):
@@ -945,6 +953,7 @@ class OAROCRBuilder:
         cfg.max_pooled_crops = 0
         # sort_detection_boxes keys on the text type (ocr.rs:699-716): 2 = sort_poly_boxes for "seal", 1 = sort_quad_boxes otherwise
         cfg.box_sort = 2 if (self._text_type or "").lower() == "seal" else 1
+        cfg.lanes = self._lanes
         ocr = OAROCR(self._det, self._rec, self._dict, cfg, self._score_thr)
         if self._doc_ori or self._rectifier or self._line_ori:
             ocr.attach(ImageClassifier(self._doc_ori, device_id=self._device) if self._doc_ori else None,
@@ -1015,6 +1024,42 @@ class OAROCR:
         finally:
             lib().oar_ocr_result_free(C.byref(res))
         return PackedPages(offs, pts, d.scores, d.utf8, d.text_offsets)
+
+    # ---- calls in flight (oar_ocr_predict_async / oar_ocr_wait; oar_ocr_cfg.lanes)
+    def submit_packed(self, ptrs, ws, hs, n: int, device: bool = False) -> int:
+        """Queues one predict on the next lane and returns its ticket (the page buffers must stay alive until wait_packed)."""
+        t = C.c_uint64(0)
+        _check(lib().oar_ocr_predict_async(self._h, ptrs, ws, hs, n, int(device), C.byref(t)))
+        return int(t.value)
+
+    def wait_packed(self, ticket: int, n: int) -> "PackedPages":
+        res = OcrResult()
+        _check(lib().oar_ocr_wait(self._h, C.c_uint64(ticket), C.byref(res)))
+        try:
+            d = self.ctc.decode_ocr(res, self.score_threshold, want_positions=False)
+            nr = int(res.n_regions)
+            offs = np.ctypeslib.as_array(res.region_offsets, shape=(n + 1,)).copy()
+            pts = np.ctypeslib.as_array(res.points, shape=(max(nr, 1) * 8,)).copy()[:nr * 8].reshape(nr, 4, 2)
+        finally:
+            lib().oar_ocr_result_free(C.byref(res))
+        return PackedPages(offs, pts, d.scores, d.utf8, d.text_offsets)
+
+    def submit(self, images: Sequence[np.ndarray]) -> int:
+        """OAROCR::predict queued on the next lane; wait(ticket) returns what predict(images) would."""
+        imgs, ptrs, ws, hs = _img_arrays(images)
+        t = self.submit_packed(ptrs, ws, hs, len(imgs))
+        self._inflight = getattr(self, "_inflight", {})
+        self._inflight[t] = (imgs, ptrs, ws, hs)   # keeps the page buffers alive
+        return t
+
+    def wait(self, ticket: int) -> List[OAROCRResult]:
+        res = OcrResult()
+        try:
+            _check(lib().oar_ocr_wait(self._h, C.c_uint64(ticket), C.byref(res)))
+            return self._assemble(res)
+        finally:
+            getattr(self, "_inflight", {}).pop(ticket, None)
+            lib().oar_ocr_result_free(C.byref(res))
 
     def _assemble(self, res: OcrResult) -> List[OAROCRResult]:
         n, nr = res.n_images, res.n_regions

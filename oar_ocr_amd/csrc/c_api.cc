@@ -1,6 +1,11 @@
 // c_api.cc -- extern "C" boundary (include/oar_mi355x.h). No exception crosses it.
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <thread>
 
 #include "engine.h"
 #include "pipeline.h"
@@ -14,7 +19,44 @@ using namespace oar;
 struct oar_engine { std::unique_ptr<Engine> e; PinBuf view; };   // view: staging for oar_engine_run_first_f32
 struct oar_det { std::unique_ptr<Detector> d; };
 struct oar_rec { std::unique_ptr<Recognizer> r; };
-struct oar_ocr { std::unique_ptr<Ocr> o; };
+// One pipeline handle = `lanes` complete pipelines (own engines, streams, staging, geometry pool) over the same model bytes.  Lane 0 serves
+// the synchronous oar_ocr_predict; oar_ocr_predict_async hands a call to the next lane's worker thread, so call k + 1's upload and
+// detection run while call k recognises (the ~15 % of the GPU a synchronous predict leaves idle).  A call is still one
+// OAROCR::predict on one lane: crops are pooled across the pages of THAT call only (ocr.rs:594-634), results are those of the
+// synchronous call.
+struct OcrLane {
+    std::unique_ptr<Ocr> o;
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    struct Job {
+        uint64_t ticket = 0;
+        std::vector<PageRef> pages;
+        bool done = false;
+        oar_status status = OAR_OK;
+        std::string error;
+        std::vector<std::vector<OcrRegion>> res;
+        std::vector<Ocr::PageMeta> meta;
+    };
+    std::deque<std::shared_ptr<Job>> queue;
+    bool stop = false;
+};
+struct oar_ocr {
+    std::unique_ptr<Ocr> o;                         // lane 0
+    std::vector<std::unique_ptr<OcrLane>> lanes;    // all lanes (lanes[0]->o is null: it borrows `o`)
+    std::mutex mu;                                  // tickets / job table
+    std::condition_variable done_cv;
+    uint64_t next_ticket = 1;
+    std::map<uint64_t, std::shared_ptr<OcrLane::Job>> jobs;
+    Ocr& lane_ocr(size_t i) { return i == 0 ? *o : *lanes[i]->o; }
+    ~oar_ocr() {
+        for (auto& l : lanes) {
+            { std::lock_guard<std::mutex> lk(l->mu); l->stop = true; }
+            l->cv.notify_all();
+            if (l->worker.joinable()) l->worker.join();
+        }
+    }
+};
 struct oar_cls { std::unique_ptr<Classifier> c; };
 struct oar_rect { std::unique_ptr<Rectifier> r; };
 
@@ -452,8 +494,45 @@ oar_status oar_ocr_create(const uint8_t* det_onnx, size_t det_len, const uint8_t
         if (c.det_thresh == 0.f && c.det_box_thresh == 0.f && c.det_unclip_ratio == 0.f) {
             c.det_thresh = 0.3f; c.det_box_thresh = 0.6f; c.det_unclip_ratio = 2.0f;  // builder defaults, ocr.rs:319-366
         }
+        OAR_CHECK(c.lanes <= 8, OAR_INVALID_INPUT, "oar_ocr_cfg.lanes must be in 0..=8");
+        const uint32_t n_lanes = c.lanes ? c.lanes : 1;
+        if (n_lanes > 1) {   // the lanes share the host: split the geometry pool (16 polling threads per lane would fight)
+            int total = c.det.host_threads;
+            if (total <= 0) { const char* e = getenv("OAR_HOST_THREADS"); total = e ? atoi(e) : 0; }
+            if (total <= 0) total = std::min<int>(ThreadPool::available_cpus(), 16);
+            c.det.host_threads = std::max(2, total / (int)n_lanes);
+        }
         std::unique_ptr<oar_ocr> h(new oar_ocr());
         h->o.reset(new Ocr(det_onnx, det_len, rec_onnx, rec_len, c));
+        for (uint32_t i = 0; i < n_lanes; ++i) {
+            std::unique_ptr<OcrLane> l(new OcrLane());
+            if (i > 0) l->o.reset(new Ocr(det_onnx, det_len, rec_onnx, rec_len, c));
+            h->lanes.push_back(std::move(l));
+        }
+        oar_ocr* raw = h.get();
+        for (uint32_t i = 0; i < n_lanes; ++i) {
+            OcrLane* l = raw->lanes[i].get();
+            l->worker = std::thread([raw, l, i] {
+                for (;;) {
+                    std::shared_ptr<OcrLane::Job> job;
+                    {
+                        std::unique_lock<std::mutex> lk(l->mu);
+                        l->cv.wait(lk, [&] { return l->stop || !l->queue.empty(); });
+                        if (l->queue.empty()) return;   // stop requested and nothing left to run
+                        job = l->queue.front();
+                        l->queue.pop_front();
+                    }
+                    try {
+                        raw->lane_ocr(i).predict(job->pages, job->res, &job->meta);
+                    } catch (const Error& e) { job->status = e.code; job->error = e.what(); }
+                    catch (const std::bad_alloc&) { job->status = OAR_OOM; job->error = "host allocation failed"; }
+                    catch (const std::exception& e) { job->status = OAR_INTERNAL; job->error = e.what(); }
+                    catch (...) { job->status = OAR_INTERNAL; job->error = "unknown error"; }
+                    { std::lock_guard<std::mutex> lk(raw->mu); job->done = true; }
+                    raw->done_cv.notify_all();
+                }
+            });
+        }
         if (c.det.profile || c.rec.profile) Profiler::get().enabled = true;
         *out = h.release();
     });
@@ -529,6 +608,48 @@ static oar_status ocr_predict_impl(oar_ocr* o, const uint8_t* const* rgb, const 
         fill_ocr_result(res, meta, out);
     });
 }
+oar_status oar_ocr_predict_async(oar_ocr* o, const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights, uint32_t n_images,
+                                 int32_t device_pages, uint64_t* ticket) {
+    return guard([&] {
+        OAR_CHECK(o && ticket, OAR_INVALID_INPUT, "oar_ocr_predict_async: bad arguments");
+        OAR_CHECK(n_images > 0 && rgb && widths && heights, OAR_INVALID_INPUT, "OCR Pipeline: images must be a non-empty slice");
+        auto job = std::make_shared<OcrLane::Job>();
+        job->pages.resize(n_images);
+        for (uint32_t i = 0; i < n_images; ++i) {
+            if (device_pages) job->pages[i].dev = rgb[i]; else job->pages[i].host = rgb[i];
+            job->pages[i].w = widths[i]; job->pages[i].h = heights[i];
+        }
+        size_t lane;
+        {
+            std::lock_guard<std::mutex> lk(o->mu);
+            job->ticket = o->next_ticket++;
+            lane = (size_t)(job->ticket % o->lanes.size());   // round robin: consecutive calls land on different lanes
+            o->jobs[job->ticket] = job;
+        }
+        OcrLane* l = o->lanes[lane].get();
+        { std::lock_guard<std::mutex> lk(l->mu); l->queue.push_back(job); }
+        l->cv.notify_one();
+        *ticket = job->ticket;
+    });
+}
+
+oar_status oar_ocr_wait(oar_ocr* o, uint64_t ticket, oar_ocr_result* out) {
+    std::shared_ptr<OcrLane::Job> job;
+    oar_status st = guard([&] {
+        OAR_CHECK(o && out, OAR_INVALID_INPUT, "oar_ocr_wait: bad arguments");
+        std::memset(out, 0, sizeof *out);
+        std::unique_lock<std::mutex> lk(o->mu);
+        auto it = o->jobs.find(ticket);
+        OAR_CHECK(it != o->jobs.end(), OAR_INVALID_INPUT, "oar_ocr_wait: unknown (or already collected) ticket");
+        job = it->second;
+        o->done_cv.wait(lk, [&] { return job->done; });
+        o->jobs.erase(it);
+    });
+    if (st != OAR_OK) return st;
+    if (job->status != OAR_OK) { oar::set_last_error(job->error); return job->status; }
+    return guard([&] { fill_ocr_result(job->res, job->meta, out); });
+}
+
 oar_status oar_ocr_predict(oar_ocr* o, const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights, uint32_t n_images,
                            oar_ocr_result* out) {
     return ocr_predict_impl(o, rgb, widths, heights, n_images, false, out);
@@ -621,8 +742,10 @@ oar_status oar_rect_run(oar_rect* r, const uint8_t* rgb, uint32_t width, uint32_
 oar_status oar_ocr_attach(oar_ocr* o, oar_cls* doc_orientation, oar_rect* rectifier, oar_cls* line_orientation) {
     return guard([&] {
         OAR_CHECK(o, OAR_INVALID_INPUT, "oar_ocr_attach: pipeline handle is null");
-        o->o->attach(doc_orientation ? doc_orientation->c.get() : nullptr, rectifier ? rectifier->r.get() : nullptr,
-                     line_orientation ? line_orientation->c.get() : nullptr);
+        // the stage handles lock internally (Classifier / Rectifier own a mutex): every lane may borrow the same ones
+        for (size_t i = 0; i < std::max<size_t>(o->lanes.size(), 1); ++i)
+            o->lane_ocr(i).attach(doc_orientation ? doc_orientation->c.get() : nullptr, rectifier ? rectifier->r.get() : nullptr,
+                                  line_orientation ? line_orientation->c.get() : nullptr);
     });
 }
 

@@ -251,6 +251,7 @@ impl Mi355xOcrBuilder {
             max_pooled_crops: 0,
             // sort_detection_boxes keys on the text type, not on the detector's box type (ocr.rs:699-716)
             box_sort: if is_seal_text { 2 } else { 1 },
+            lanes: 0,
         };
         let (det_bytes, det_shown) = model_bytes(&self.det_model)?;
         let (rec_bytes, _rec_shown) = model_bytes(&self.rec_model)?;

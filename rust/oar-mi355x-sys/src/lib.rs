@@ -186,6 +186,7 @@ pub struct oar_ocr_cfg {
     pub region_batch_size: u32,
     pub max_pooled_crops: u32,
     pub box_sort: i32,
+    pub lanes: u32,
 }
 
 #[repr(C)]
@@ -292,6 +293,8 @@ unsafe extern "C" {
     pub fn oar_ocr_predict(o: *mut oar_ocr, rgb: *const *const u8, widths: *const u32, heights: *const u32, n_images: u32, out: *mut oar_ocr_result) -> oar_status;
     pub fn oar_ocr_predict_device(o: *mut oar_ocr, d_rgb: *const *const u8, widths: *const u32, heights: *const u32, n_images: u32, out: *mut oar_ocr_result) -> oar_status;
     pub fn oar_ocr_result_free(r: *mut oar_ocr_result);
+    pub fn oar_ocr_predict_async(o: *mut oar_ocr, rgb: *const *const u8, widths: *const u32, heights: *const u32, n_images: u32, device_pages: i32, ticket: *mut u64) -> oar_status;
+    pub fn oar_ocr_wait(o: *mut oar_ocr, ticket: u64, out: *mut oar_ocr_result) -> oar_status;
     pub fn oar_ocr_decode(dict: *const oar_ctc_dict, res: *const oar_ocr_result, score_threshold: f32, out: *mut oar_text_result) -> oar_status;
     pub fn oar_ctc_word_boxes(line_pts_xy: *const f32, n_points: u32, text_utf8: *const c_char, text_len: usize, col_indices: *const u32, n_cols: u32, seq_len: u32, wh_ratio: f32, max_wh_ratio: f32, boxes: *mut f32, cap_boxes: u32, n_boxes: *mut u32) -> oar_status;
     pub fn oar_char_positions_to_word_boxes(line_pts_xy: *const f32, n_points: u32, char_positions: *const f32, n_positions: u32, char_count: u32, boxes: *mut f32, cap_boxes: u32, n_boxes: *mut u32) -> oar_status;

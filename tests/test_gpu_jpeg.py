@@ -37,7 +37,10 @@ def test_device_decode_equals_host_decode_and_pil(progressive):
                 kw = dict(quality=85, progressive=progressive)
                 if src.ndim == 3:
                     kw["subsampling"] = sub
-                data = _jpeg(src, **kw)
+                try:
+                    data = _jpeg(src, **kw)
+                except (TypeError, ValueError, KeyError):
+                    continue   # this Pillow cannot write the subsampling
                 buf, dw, dh = api.load_image_to_device(data)
                 got = _download(buf, dw, dh)
                 buf.free()
