@@ -399,6 +399,48 @@ oar_status oar_k_bgr_planes_to_rgb(const float* planes, uint64_t plane, float sc
 /* BoundingBox::rotate_back_to_original (processors/geometry.rs:848-889), in place on n (x, y) pairs */
 oar_status oar_host_rotate_back_points(float* pts, uint32_t n_points, float angle, uint32_t rotated_w, uint32_t rotated_h);
 
+/* ------------------------------------------------------------------------------------------------ Seam B: layout detection
+ * LayoutDetectionAdapter's model half (oar-ocr-core/src/domain/adapters/layout_detection_adapter.rs:1121-1197): PicoDet / RT-DETR /
+ * PP-DocLayout graphs through ScaleAwareDetectorModel::forward (models/detection/scale_aware_detector.rs:169-440: resize_exact to
+ * the model's image_shape with the model's filter, NormalizeImage, graph inputs "image" + "scale_factor" [+ "im_shape"]) and
+ * LayoutPostProcess::apply (processors/layout_postprocess.rs:60-634: row parsing in the three column orders, score filter,
+ * normalised / absolute coordinate conversion, class-aware greedy NMS, max_detections, PP-DocLayoutV2 reading order).  Resize,
+ * normalisation, the network and the post-processing are HIP kernels; per image the result is LayoutPostprocessOutput's
+ * (boxes, class ids, scores).  What the adapter does ABOVE that with configuration only -- class labels, per-class thresholds,
+ * max_elements -- stays with the caller (rust/oar-mi355x-adapters/src/layout_detection.rs, api.LayoutDetectionPredictor).       */
+typedef struct oar_layout oar_layout;
+typedef struct {
+    int32_t device_id;
+    uint32_t input_h, input_w;   /* image_shape: 0,0 => 800 x 608 (PicoDet); PP-DocLayout 800 x 800                       */
+    int32_t resize_filter;       /* 0 Triangle, 1 CatmullRom (PP-DocLayout), 2 Lanczos3 (PicoDet): scale_aware_detector.rs:49-75 */
+    int32_t color_bgr;           /* 1: BGR tensor (PicoDet), 0: RGB (PP-DocLayout)                                          */
+    float scale;                 /* 0 => 1/255                                                                              */
+    float mean[3], std[3];       /* RGB statistics; std all 0 => ImageNet (0.485.. / 0.229..)                               */
+    uint32_t num_classes;
+    int32_t model_type;          /* 0 "picodet" (and any other name: process_standard), 1 "rtdetr", 2 "pp-doclayout"        */
+    float score_threshold;       /* LayoutPostProcess::score_threshold                                                      */
+    float nms_threshold;
+    uint32_t max_detections;     /* 0 => 100                                                                                */
+} oar_layout_cfg;
+typedef struct {
+    uint32_t n_images, n_boxes;
+    uint32_t* box_offsets;       /* n_images + 1                                                                            */
+    float* boxes;                /* n_boxes * 4: x1 y1 x2 y2 in original-image pixels (BoundingBox = (x1,y1)(x2,y1)(x2,y2)(x1,y2)) */
+    int32_t* classes;            /* n_boxes                                                                                 */
+    float* scores;               /* n_boxes                                                                                 */
+    uint32_t feature_dim;        /* columns of the graph's prediction rows: 7 / 8 => is_reading_order_sorted (adapter :1186-1192) */
+} oar_layout_result;
+oar_status oar_layout_create(const uint8_t* onnx, size_t onnx_len, const oar_layout_cfg* cfg, oar_layout** out);
+void oar_layout_destroy(oar_layout* l);
+oar_status oar_layout_run(oar_layout* l, const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights, uint32_t n_images, oar_layout_result* out);
+void oar_layout_result_free(oar_layout_result* r);
+/* parity hooks: the preprocessed tensor of one image ([3, input_h, input_w] f32); the filtered resize alone; LayoutPostProcess alone on
+ * a caller-supplied prediction tensor [n_images, rows, feat] (src_wh: n_images x (width, height)) */
+oar_status oar_layout_preprocess(oar_layout* l, const uint8_t* rgb, uint32_t width, uint32_t height, float* out_chw);
+oar_status oar_k_resize_filter(const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, int32_t filter, uint8_t* out);
+oar_status oar_k_layout_postprocess(const float* pred, uint32_t n_images, uint32_t rows, uint32_t feat, const float* src_wh, uint32_t num_classes, int32_t model_type,
+                                    float score_threshold, float nms_threshold, uint32_t max_detections, oar_layout_result* out);
+
 /* ------------------------------------------------------------------------------------------------ device helpers */
 oar_status oar_dev_alloc(int32_t device_id, size_t bytes, void** out);
 oar_status oar_dev_upload(void* dst, const void* src, size_t bytes);

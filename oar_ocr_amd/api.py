@@ -115,6 +115,17 @@ class WordBoxes(C.Structure):
     _fields_ = [("n_regions", C.c_uint32), ("box_offsets", C.POINTER(C.c_uint64)), ("boxes", C.POINTER(C.c_float))]
 
 
+class LayoutCfg(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("input_h", C.c_uint32), ("input_w", C.c_uint32), ("resize_filter", C.c_int32), ("color_bgr", C.c_int32), ("scale", C.c_float),
+                ("mean", C.c_float * 3), ("std", C.c_float * 3), ("num_classes", C.c_uint32), ("model_type", C.c_int32), ("score_threshold", C.c_float),
+                ("nms_threshold", C.c_float), ("max_detections", C.c_uint32)]
+
+
+class LayoutResult(C.Structure):
+    _fields_ = [("n_images", C.c_uint32), ("n_boxes", C.c_uint32), ("box_offsets", C.POINTER(C.c_uint32)), ("boxes", C.POINTER(C.c_float)),
+                ("classes", C.POINTER(C.c_int32)), ("scores", C.POINTER(C.c_float)), ("feature_dim", C.c_uint32)]
+
+
 class ProfEntry(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double), ("alg_bytes", C.c_double), ("alg_flops", C.c_double)]
 
@@ -131,7 +142,7 @@ EXPORTS = [
     "oar_rect_run", "oar_ocr_attach", "oar_k_rotate_rgb", "oar_k_bgr_planes_to_rgb", "oar_host_rotate_back_points",
     "oar_engine_cache_stats", "oar_onnx_inspect", "oar_host_contours", "oar_ctc_dict_create", "oar_ctc_dict_destroy", "oar_ctc_dict_classes",
     "oar_ctc_decode", "oar_ocr_decode", "oar_text_result_free", "oar_db_postprocess_ex", "oar_k_dilate", "oar_k_poly_scores", "oar_debug_inject_failure", "oar_k_contours", "oar_host_contours_bits",
-    "oar_k_unclip", "oar_k_rec_preprocess_flip", "oar_image_decode_device", "oar_ocr_predict_async", "oar_ocr_wait", "oar_ctc_word_boxes", "oar_char_positions_to_word_boxes", "oar_ocr_word_boxes", "oar_word_boxes_free", "oar_image_decode", "oar_image_free", "oar_host_approx_poly_dp", "oar_host_perimeter", "oar_host_unclip_poly", "oar_host_offset_ring", "oar_host_ring_outline", "oar_host_sort_poly_boxes",
+    "oar_k_unclip", "oar_k_rec_preprocess_flip", "oar_layout_create", "oar_layout_destroy", "oar_layout_run", "oar_layout_result_free", "oar_layout_preprocess", "oar_k_resize_filter", "oar_k_layout_postprocess", "oar_image_decode_device", "oar_ocr_predict_async", "oar_ocr_wait", "oar_ctc_word_boxes", "oar_char_positions_to_word_boxes", "oar_ocr_word_boxes", "oar_word_boxes_free", "oar_image_decode", "oar_image_free", "oar_host_approx_poly_dp", "oar_host_perimeter", "oar_host_unclip_poly", "oar_host_offset_ring", "oar_host_ring_outline", "oar_host_sort_poly_boxes",
 ]
 
 
@@ -209,6 +220,15 @@ def lib():
     L.oar_k_unclip.argtypes = [vp, C.c_uint32, C.c_float, vp, vp, C.c_uint32]
     L.oar_image_decode.argtypes = [vp, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.oar_image_free.argtypes = [C.POINTER(C.c_uint8)]
+    L.oar_layout_create.argtypes = [vp, C.c_size_t, vp, C.POINTER(C.c_void_p)]
+    L.oar_layout_destroy.argtypes = [vp]
+    L.oar_layout_destroy.restype = None
+    L.oar_layout_run.argtypes = [vp, u8pp, u32p, u32p, C.c_uint32, vp]
+    L.oar_layout_result_free.argtypes = [vp]
+    L.oar_layout_result_free.restype = None
+    L.oar_layout_preprocess.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp]
+    L.oar_k_resize_filter.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, vp]
+    L.oar_k_layout_postprocess.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_int32, C.c_float, C.c_float, C.c_uint32, vp]
     L.oar_ocr_predict_async.argtypes = [vp, u8pp, u32p, u32p, C.c_uint32, C.c_int32, C.POINTER(C.c_uint64)]
     L.oar_ocr_wait.argtypes = [vp, C.c_uint64, vp]
     L.oar_image_decode_device.argtypes = [vp, C.c_size_t, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -1162,6 +1182,175 @@ def char_positions_to_word_boxes(line_bbox: np.ndarray, char_positions, char_cou
     if n.value:
         _check(lib().oar_char_positions_to_word_boxes(*args, _p(out), n.value, C.byref(n)))
     return [b for b in out]
+
+
+# ------------------------------------------------------------------------------------------------ layout detection
+LAYOUT_FILTERS = {"triangle": 0, "catmullrom": 1, "lanczos3": 2}
+LAYOUT_MODEL_TYPES = {"picodet": 0, "rtdetr": 1, "pp-doclayout": 2}
+
+
+@dataclass
+class LayoutModelConfig:
+    """domain/adapters/layout_detection_adapter.rs:38-52 + the model's ScaleAwareDetectorPreprocessConfig (scale_aware_detector.rs:49-75)"""
+    model_name: str
+    num_classes: int
+    class_labels: dict
+    model_type: str = "picodet"
+    input_size: Optional[tuple] = (800, 608)
+
+    @staticmethod
+    def picodet_layout_1x():                       # layout_detection_adapter.rs:56-71
+        return LayoutModelConfig("picodet_layout_1x", 5, {0: "text", 1: "title", 2: "list", 3: "table", 4: "figure"}, "picodet", (800, 608))
+
+    @staticmethod
+    def picodet_layout_1x_table():                 # :74-85
+        return LayoutModelConfig("picodet_layout_1x_table", 1, {0: "table"}, "picodet", (800, 608))
+
+    def preprocess(self):
+        """(filter, bgr, mean, std) of the model family"""
+        if self.model_type == "pp-doclayout":
+            return "catmullrom", False, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)
+        return "lanczos3", True, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+@dataclass
+class LayoutDetectionConfig:
+    """domain/tasks/layout_detection.rs:47-78 (class_merge_modes is not carried by this mirror)"""
+    score_threshold: float = 0.5
+    max_elements: int = 100
+    class_thresholds: Optional[dict] = None
+    nms_threshold: float = 0.5
+    layout_unclip_ratio: Optional[object] = None    # float | (w, h) | {class_id: (w, h)}
+
+    def get_class_threshold(self, name: str) -> float:   # :287-292
+        return (self.class_thresholds or {}).get(name, self.score_threshold)
+
+
+@dataclass
+class LayoutDetectionElement:
+    bbox: np.ndarray          # [4, 2]
+    element_type: str
+    score: float
+
+
+def unclip_boxes(boxes: np.ndarray, classes, ratio) -> np.ndarray:
+    """processors/layout_postprocess.rs:636-690 on [k, 4] x1 y1 x2 y2 boxes (f32, the reference's operation order)"""
+    f = np.float32
+    out = np.asarray(boxes, np.float32).copy()
+    for i, c in enumerate(classes):
+        if isinstance(ratio, dict):
+            wr, hr = ratio.get(int(c), (1.0, 1.0))
+        elif isinstance(ratio, (tuple, list)):
+            wr, hr = ratio
+        else:
+            wr = hr = ratio
+        wr, hr = f(wr), f(hr)
+        if abs(wr - f(1.0)) < f(1e-6) and abs(hr - f(1.0)) < f(1e-6):
+            continue
+        x0, y0, x1, y1 = out[i]
+        w, h = f(x1 - x0), f(y1 - y0)
+        cx, cy = f(x0 + f(w * f(0.5))), f(y0 + f(h * f(0.5)))
+        hw, hh = f(f(w * wr) * f(0.5)), f(f(h * hr) * f(0.5))
+        out[i] = [f(cx - hw), f(cy - hh), f(cx + hw), f(cy + hh)]
+    return out
+
+
+class LayoutDetectionPredictor:
+    """LayoutDetectionAdapter (domain/adapters/layout_detection_adapter.rs) for the PicoDet / RT-DETR families: the model half
+    (resize, normalise, graph, LayoutPostProcess) is ONE C call into HBM-resident kernels (oar_layout_run); class labels, per-class
+    thresholds, layout_unclip_ratio and max_elements are applied here as the adapter's postprocess does (:540-629)."""
+
+    def __init__(self, onnx_bytes: bytes, model_config: Optional[LayoutModelConfig] = None, config: Optional[LayoutDetectionConfig] = None, device_id: int = 0):
+        self.model_config = model_config or LayoutModelConfig.picodet_layout_1x()
+        self.config = config or LayoutDetectionConfig()
+        filt, bgr, mean, std = self.model_config.preprocess()
+        c = LayoutCfg()
+        c.device_id = device_id
+        c.input_h, c.input_w = self.model_config.input_size or (800, 800)
+        c.resize_filter, c.color_bgr, c.scale = LAYOUT_FILTERS[filt], int(bgr), 1.0 / 255.0
+        c.mean, c.std = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+        c.num_classes, c.model_type = self.model_config.num_classes, LAYOUT_MODEL_TYPES.get(self.model_config.model_type, 0)
+        c.score_threshold, c.nms_threshold, c.max_detections = self.config.score_threshold, self.config.nms_threshold, self.config.max_elements
+        buf = (C.c_char * len(onnx_bytes)).from_buffer_copy(onnx_bytes)
+        self._h = C.c_void_p()
+        _check(lib().oar_layout_create(C.cast(buf, C.c_void_p), len(onnx_bytes), C.byref(c), C.byref(self._h)))
+        self.input_hw = (int(c.input_h), int(c.input_w))
+
+    def preprocess(self, image: np.ndarray) -> np.ndarray:
+        img = np.ascontiguousarray(image, np.uint8)
+        out = np.empty((3, self.input_hw[0], self.input_hw[1]), np.float32)
+        _check(lib().oar_layout_preprocess(self._h, _p(img), img.shape[1], img.shape[0], _p(out)))
+        return out
+
+    def detect_raw(self, images: Sequence[np.ndarray]):
+        """LayoutPostProcess::apply's output: per image (boxes [k, 4], classes [k], scores [k]); plus the prediction width"""
+        imgs, ptrs, ws, hs = _img_arrays(images)
+        res = LayoutResult()
+        _check(lib().oar_layout_run(self._h, ptrs, ws, hs, len(imgs), C.byref(res)))
+        try:
+            return _unpack_layout(res), int(res.feature_dim)
+        finally:
+            lib().oar_layout_result_free(C.byref(res))
+
+    def predict(self, images: Sequence[np.ndarray], config: Optional[LayoutDetectionConfig] = None):
+        cfg = config or self.config
+        per_image, feat = self.detect_raw(images)
+        out = []
+        for boxes, classes, scores in per_image:
+            if cfg.layout_unclip_ratio is not None:
+                boxes = unclip_boxes(boxes, classes, cfg.layout_unclip_ratio)
+            els = []
+            for b, c, s in zip(boxes, classes, scores):
+                name = self.model_config.class_labels.get(int(c), "unknown")
+                if s >= np.float32(cfg.get_class_threshold(name)):
+                    els.append(LayoutDetectionElement(np.array([[b[0], b[1]], [b[2], b[1]], [b[2], b[3]], [b[0], b[3]]], np.float32), name, float(s)))
+                    if len(els) >= cfg.max_elements:
+                        break
+            out.append(els)
+        self.is_reading_order_sorted = feat in (7, 8)
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.oar_layout_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _unpack_layout(res: "LayoutResult"):
+    n, nb = int(res.n_images), int(res.n_boxes)
+    offs = np.ctypeslib.as_array(res.box_offsets, shape=(n + 1,)).copy()
+    boxes = np.ctypeslib.as_array(res.boxes, shape=(max(nb, 1) * 4,)).copy()[:nb * 4].reshape(nb, 4)
+    cls = np.ctypeslib.as_array(res.classes, shape=(max(nb, 1),)).copy()[:nb]
+    sc = np.ctypeslib.as_array(res.scores, shape=(max(nb, 1),)).copy()[:nb]
+    return [(boxes[offs[i]:offs[i + 1]], cls[offs[i]:offs[i + 1]], sc[offs[i]:offs[i + 1]]) for i in range(n)]
+
+
+def k_resize_filter(rgb, nw, nh, filter="lanczos3"):
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w, _ = rgb.shape
+    out = np.empty((nh, nw, 3), np.uint8)
+    _check(lib().oar_k_resize_filter(_p(rgb), w, h, nw, nh, LAYOUT_FILTERS[filter], _p(out)))
+    return out
+
+
+def k_layout_postprocess(pred, src_wh, num_classes, score_threshold=0.5, nms_threshold=0.5, max_detections=100, model_type="picodet"):
+    """pred: [n_images, rows, feat]; src_wh: [n_images, 2] (width, height).  The HIP LayoutPostProcess on caller-supplied predictions."""
+    pred = np.ascontiguousarray(pred, np.float32)
+    n, rows, feat = pred.shape
+    wh = np.ascontiguousarray(src_wh, np.float32).reshape(n, 2)
+    res = LayoutResult()
+    _check(lib().oar_k_layout_postprocess(_p(pred) if pred.size else None, n, rows, feat, _p(wh), num_classes, LAYOUT_MODEL_TYPES.get(model_type, 0), C.c_float(score_threshold),
+                                          C.c_float(nms_threshold), max_detections, C.byref(res)))
+    try:
+        return _unpack_layout(res)
+    finally:
+        lib().oar_layout_result_free(C.byref(res))
 
 
 # ------------------------------------------------------------------------------------------------ device buffers / profiling

@@ -8,6 +8,7 @@
 #include <thread>
 
 #include "engine.h"
+#include "layout.h"
 #include "pipeline.h"
 
 namespace oar {
@@ -59,6 +60,7 @@ struct oar_ocr {
 };
 struct oar_cls { std::unique_ptr<Classifier> c; };
 struct oar_rect { std::unique_ptr<Rectifier> r; };
+struct oar_layout { std::unique_ptr<LayoutDetector> l; };
 
 #include "jpeg_decode.h"
 #include "jpeg_dev.h"
@@ -716,6 +718,142 @@ oar_status oar_cls_preprocess(oar_cls* c, const uint8_t* const* rgb, const uint3
         std::vector<float> v;
         c->c->pack_only(cls_images(rgb, widths, heights, n_images), v);
         std::memcpy(out_nchw, v.data(), v.size() * sizeof(float));
+    });
+}
+
+// ---------------------------------------------------------------------------------------------- layout detection
+static LayoutCfg layout_cfg_from(const oar_layout_cfg* cfg) {
+    LayoutCfg c;
+    if (!cfg) return c;
+    c.device_id = cfg->device_id;
+    if (cfg->input_h && cfg->input_w) { c.input_h = cfg->input_h; c.input_w = cfg->input_w; }
+    c.filter = cfg->resize_filter;
+    c.bgr = cfg->color_bgr != 0;
+    if (cfg->scale > 0.0f) c.scale = cfg->scale;
+    if (cfg->std[0] != 0.0f || cfg->std[1] != 0.0f || cfg->std[2] != 0.0f)
+        for (int k = 0; k < 3; ++k) { c.mean[k] = cfg->mean[k]; c.stdv[k] = cfg->std[k]; }
+    if (cfg->num_classes) c.num_classes = cfg->num_classes;
+    c.model_type = cfg->model_type;
+    c.score_threshold = cfg->score_threshold;
+    c.nms_threshold = cfg->nms_threshold;
+    if (cfg->max_detections) c.max_detections = cfg->max_detections;
+    return c;
+}
+static void fill_layout_result(const LayoutOut& lo, oar_layout_result* out) {
+    std::memset(out, 0, sizeof *out);
+    out->n_images = (uint32_t)(lo.offsets.size() - 1); out->n_boxes = (uint32_t)lo.scores.size(); out->feature_dim = lo.feature_dim;
+    out->box_offsets = cmalloc<uint32_t>(lo.offsets.size());
+    std::memcpy(out->box_offsets, lo.offsets.data(), lo.offsets.size() * 4);
+    out->boxes = cmalloc<float>(lo.boxes.size()); out->classes = cmalloc<int32_t>(lo.classes.size()); out->scores = cmalloc<float>(lo.scores.size());
+    std::memcpy(out->boxes, lo.boxes.data(), lo.boxes.size() * 4);
+    std::memcpy(out->classes, lo.classes.data(), lo.classes.size() * 4);
+    std::memcpy(out->scores, lo.scores.data(), lo.scores.size() * 4);
+}
+oar_status oar_layout_create(const uint8_t* onnx, size_t onnx_len, const oar_layout_cfg* cfg, oar_layout** out) {
+    return guard([&] {
+        OAR_CHECK(out, OAR_INVALID_INPUT, "oar_layout_create: out is null");
+        *out = nullptr;
+        std::unique_ptr<oar_layout> h(new oar_layout());
+        h->l.reset(new LayoutDetector(onnx, onnx_len, layout_cfg_from(cfg)));
+        *out = h.release();
+    });
+}
+void oar_layout_destroy(oar_layout* l) { delete l; }
+oar_status oar_layout_run(oar_layout* l, const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights, uint32_t n_images, oar_layout_result* out) {
+    return guard([&] {
+        OAR_CHECK(l && out && (n_images == 0 || (rgb && widths && heights)), OAR_INVALID_INPUT, "oar_layout_run: bad arguments");
+        std::vector<LayoutDetector::Image> imgs(n_images);
+        for (uint32_t i = 0; i < n_images; ++i) { imgs[i].host = rgb[i]; imgs[i].w = widths[i]; imgs[i].h = heights[i]; }
+        LayoutOut lo;
+        l->l->run(imgs, lo);
+        fill_layout_result(lo, out);
+    });
+}
+void oar_layout_result_free(oar_layout_result* r) {
+    if (!r) return;
+    std::free(r->box_offsets); std::free(r->boxes); std::free(r->classes); std::free(r->scores);
+    std::memset(r, 0, sizeof *r);
+}
+oar_status oar_layout_preprocess(oar_layout* l, const uint8_t* rgb, uint32_t width, uint32_t height, float* out_chw) {
+    return guard([&] {
+        OAR_CHECK(l && rgb && out_chw, OAR_INVALID_INPUT, "oar_layout_preprocess: bad arguments");
+        LayoutDetector::Image im;
+        im.host = rgb; im.w = width; im.h = height;
+        std::vector<float> t;
+        l->l->preprocess_only(im, t);
+        std::memcpy(out_chw, t.data(), t.size() * 4);
+    });
+}
+oar_status oar_k_resize_filter(const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, int32_t filter, uint8_t* out) {
+    return guard([&] {
+        OAR_CHECK(rgb && out && w && h && nw && nh && filter >= 0 && filter <= 2, OAR_INVALID_INPUT, "oar_k_resize_filter: bad arguments");
+        require_device();
+        if (nw == w && nh == h) { std::memcpy(out, rgb, (size_t)w * h * 3); return; }
+        std::vector<pp::FilterTaps> tv, th;
+        std::vector<float> wv, wh;
+        const int mv = host::filter_taps(filter, (int)h, (int)nh, tv, wv), mh = host::filter_taps(filter, (int)w, (int)nw, th, wh);
+        DevBuf din, dout, dtmp, dtv, dwv, dth, dwh;
+        din.reserve((size_t)w * h * 3); dout.reserve((size_t)nw * nh * 3); dtmp.reserve((size_t)nh * w * 12);
+        dtv.reserve(tv.size() * sizeof(pp::FilterTaps)); dwv.reserve(wv.size() * 4); dth.reserve(th.size() * sizeof(pp::FilterTaps)); dwh.reserve(wh.size() * 4);
+        OAR_HIP(hipMemcpy(din.p, rgb, (size_t)w * h * 3, hipMemcpyHostToDevice));
+        OAR_HIP(hipMemcpy(dtv.p, tv.data(), tv.size() * sizeof(pp::FilterTaps), hipMemcpyHostToDevice));
+        OAR_HIP(hipMemcpy(dwv.p, wv.data(), wv.size() * 4, hipMemcpyHostToDevice));
+        OAR_HIP(hipMemcpy(dth.p, th.data(), th.size() * sizeof(pp::FilterTaps), hipMemcpyHostToDevice));
+        OAR_HIP(hipMemcpy(dwh.p, wh.data(), wh.size() * 4, hipMemcpyHostToDevice));
+        pp::resize_filter(nullptr, din.as<uint8_t>(), (int)w, (int)h, dout.as<uint8_t>(), (int)nw, (int)nh, dtv.as<pp::FilterTaps>(), dwv.as<float>(), mv, dth.as<pp::FilterTaps>(),
+                          dwh.as<float>(), mh, dtmp.as<float>());
+        OAR_HIP(hipDeviceSynchronize());
+        OAR_HIP(hipMemcpy(out, dout.p, (size_t)nw * nh * 3, hipMemcpyDeviceToHost));
+    });
+}
+oar_status oar_k_layout_postprocess(const float* pred, uint32_t n_images, uint32_t rows, uint32_t feat, const float* src_wh, uint32_t num_classes, int32_t model_type,
+                                    float score_threshold, float nms_threshold, uint32_t max_detections, oar_layout_result* out) {
+    return guard([&] {
+        OAR_CHECK(out && (n_images == 0 || (src_wh && (rows == 0 || feat == 0 || pred))) && max_detections > 0 && max_detections <= 4096 && rows <= 65536, OAR_INVALID_INPUT,
+                  "oar_k_layout_postprocess: bad arguments");
+        require_device();
+        LayoutOut lo;
+        lo.offsets.assign(1, 0);
+        lo.feature_dim = feat;
+        if (n_images == 0 || rows == 0 || feat == 0) { for (uint32_t i = 0; i < n_images; ++i) lo.offsets.push_back(0); fill_layout_result(lo, out); return; }
+        DevBuf dpred, dwh, dcand, dsorted, dkeep;
+        const size_t np = (size_t)n_images * rows * feat;
+        dpred.reserve(np * 4); dwh.reserve((size_t)n_images * 8); dcand.reserve((size_t)n_images * rows * 32); dsorted.reserve((size_t)n_images * rows * 4);
+        dkeep.reserve((size_t)n_images * (max_detections + 1) * 4);
+        OAR_HIP(hipMemcpy(dpred.p, pred, np * 4, hipMemcpyHostToDevice));
+        OAR_HIP(hipMemcpy(dwh.p, src_wh, (size_t)n_images * 8, hipMemcpyHostToDevice));
+        pp::LayoutPostP p{};
+        p.pred = dpred.as<float>(); p.rows = (int)rows; p.feat = (int)feat; p.num_classes = (int)num_classes; p.model_type = model_type; p.max_det = (int)max_detections;
+        p.score_thr = score_threshold; p.nms_thr = nms_threshold; p.src_wh = dwh.as<float>();
+        p.cand = dcand.as<float>(); p.sorted = dsorted.as<int>(); p.keep = dkeep.as<int>(); p.n_keep = dkeep.as<int>() + (size_t)n_images * max_detections;
+        pp::layout_postprocess(nullptr, p, (int)n_images);
+        OAR_HIP(hipDeviceSynchronize());
+        std::vector<int> keep((size_t)n_images * (max_detections + 1));
+        std::vector<float> cand((size_t)n_images * rows * 8);
+        OAR_HIP(hipMemcpy(keep.data(), dkeep.p, keep.size() * 4, hipMemcpyDeviceToHost));
+        OAR_HIP(hipMemcpy(cand.data(), dcand.p, cand.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n_images; ++i) {
+            const int nk = keep[(size_t)n_images * max_detections + i];
+            std::vector<int> rk(keep.begin() + (long)((size_t)i * max_detections), keep.begin() + (long)((size_t)i * max_detections) + nk);
+            if (model_type == 2 && feat == 8 && nk > 1) {
+                auto key = [](float v) { int32_t b; std::memcpy(&b, &v, 4); return b ^ (int32_t)(((uint32_t)(b >> 31)) >> 1); };
+                const float* pr = pred + (size_t)i * rows * feat;
+                std::stable_sort(rk.begin(), rk.end(), [&](int a, int b) {
+                    const int32_t ca = key(pr[(size_t)a * feat + 6]), cb = key(pr[(size_t)b * feat + 6]);
+                    if (ca != cb) return ca < cb;
+                    return key(pr[(size_t)a * feat + 7]) < key(pr[(size_t)b * feat + 7]);
+                });
+            }
+            for (int r : rk) {
+                const float* c8 = cand.data() + ((size_t)i * rows + (size_t)r) * 8;
+                lo.boxes.insert(lo.boxes.end(), c8, c8 + 4);
+                lo.scores.push_back(c8[4]);
+                int32_t cls; std::memcpy(&cls, &c8[5], 4);
+                lo.classes.push_back(cls);
+            }
+            lo.offsets.push_back((uint32_t)lo.scores.size());
+        }
+        fill_layout_result(lo, out);
     });
 }
 

@@ -478,3 +478,64 @@ def build_multi_io_fixture(seed=5, c=16, vocab=29):
     g.add_output("ids", ["N", "T"], elem_type=7)
     g.add_output("dims", [4], elem_type=7)
     return g.model(), {"params": g.n_params}
+
+
+# ---------------------------------------------------------------------------------------------- f4: layout detector graphs
+def build_layout(kind="picodet", n_classes=5, seed=11, image_shape=(800, 608), feat=None):
+    """A PicoDet / PP-DocLayout-shaped layout detector with synthetic weights.
+    Inputs as the exported Paddle detection graphs declare them (models/detection/scale_aware_detector.rs:248-290): "image"
+    [N,3,H,W], "scale_factor" [N,2] = (resized_h / orig_h, resized_w / orig_w), and for kind "pp-doclayout" also "im_shape" [N,2].
+    Output: ONE 2-D tensor [N * K, feat] of rows (class_id, score, x1, y1, x2, y2[, col, row]) in ORIGINAL-image pixels -- what the
+    reference reshapes to [N, K, 1, feat] (:325-339); K = anchors of the stride-32 and stride-16 grids.  The box decode inside the graph is
+    the detectors' own: anchor centre -/+ stride * softplus-like distances, divided by the scale factor.  No NMS node: the suppression is
+    LayoutPostProcess's (the reference runs its own NMS on whatever the graph returns, layout_postprocess.rs:482-548)."""
+    feat = feat or (8 if kind == "pp-doclayout" else 6)
+    H, W = image_shape
+    n = _Net(f"synth_layout_{kind}", seed, decomposed_hswish=False)
+    g = n.g
+    g.add_input("image", ["N", 3, H, W])
+    g.add_input("scale_factor", ["N", 2])
+    if kind == "pp-doclayout":
+        g.add_input("im_shape", ["N", 2])
+    c1, c2, c3, c4, c5 = 16, 24, 48, 96, 128
+    x = n.conv("image", 3, c1, 3, 2, act="hswish")
+    x = n.ds_block(x, c1, c2, 3, 2)
+    x = n.ds_block(x, c2, c3, 3, 2)
+    x = n.ds_block(x, c3, c3, 3, 1)
+    f16 = n.ds_block(x, c3, c4, 3, 2)                                  # stride 16
+    f16 = n.ds_block(f16, c4, c4, 5, 1)
+    f32_ = n.ds_block(f16, c4, c5, 5, 2, use_se=True)                  # stride 32
+    f32_ = n.ds_block(f32_, c5, c5, 5, 1, use_se=True)
+    rows = []
+    for ft, cin, stride in ((f16, c4, 16), (f32_, c5, 32)):
+        h, w = H // stride, W // stride
+        k = h * w
+        t = n.conv(ft, cin, 64, 3, act="hswish")
+        cls = n.conv(t, 64, n_classes, 1, w=n._w((n_classes, 64, 1, 1), 64, gain=24.0), b=(n._b(n_classes) - 2.0).astype(np.float32))   # sparse confident anchors
+        reg = n.conv(t, 64, 4, 1, w=n._w((4, 64, 1, 1), 64, gain=6.0), b=(n._b(4) + 1.0).astype(np.float32))
+        cls = g.op("Reshape", [g.op("Transpose", [cls], perm=[0, 2, 3, 1]), g.init(np.array([0, k, n_classes], np.int64), "shape")])     # [N, K, C]
+        reg = g.op("Reshape", [g.op("Transpose", [reg], perm=[0, 2, 3, 1]), g.init(np.array([0, k, 4], np.int64), "shape")])             # [N, K, 4]
+        prob = g.op("Sigmoid", [cls])
+        score = g.op("ReduceMax", [prob], axes=[2], keepdims=1)                                                                         # [N, K, 1]
+        cid = g.op("Cast", [g.op("ArgMax", [prob], axis=2, keepdims=1)], to=1)
+        dist = g.op("Mul", [g.op("Softplus", [reg]), g.init(np.array(float(stride) * 1.5, np.float32), "stride")])                      # l, t, r, b in resized pixels
+        ys, xs = np.mgrid[0:h, 0:w]
+        ctr = np.stack([(xs + 0.5) * stride, (ys + 0.5) * stride, (xs + 0.5) * stride, (ys + 0.5) * stride], -1).reshape(1, k, 4).astype(np.float32)
+        sign = np.array([-1, -1, 1, 1], np.float32).reshape(1, 1, 4)
+        box = g.op("Add", [g.init(ctr, "centres"), g.op("Mul", [dist, g.init(sign, "sign")])])                                          # x1 y1 x2 y2, resized pixels
+        # / (scale_x, scale_y, scale_x, scale_y): scale_factor is (scale_y, scale_x)
+        ax1 = g.init(np.array([1], np.int64), "axes")
+        sy = g.op("Slice", ["scale_factor", g.init(np.array([0], np.int64), "starts"), g.init(np.array([1], np.int64), "ends"), ax1])    # [N, 1]
+        sx = g.op("Slice", ["scale_factor", g.init(np.array([1], np.int64), "starts"), g.init(np.array([2], np.int64), "ends"), ax1])
+        sf = g.op("Concat", [sx, sy, sx, sy], axis=1)                                                                                    # [N, 4]
+        sf = g.op("Unsqueeze", [sf, g.init(np.array([1], np.int64), "axes")])                                                           # [N, 1, 4]
+        box = g.op("Div", [box, sf])
+        cols = [cid, score, box]
+        if feat == 8:   # PP-DocLayoutV2's reading-order columns: (col, row) of the anchor grid cell, coarse
+            order = np.stack([(xs // max(w // 2, 1)).astype(np.float32), ys.astype(np.float32) * w + xs], -1).reshape(1, k, 2).astype(np.float32)
+            cols.append(g.op("Add", [g.op("Mul", [score, g.init(np.zeros((1, 1, 2), np.float32), "zero")]), g.init(order, "order")]))     # broadcast to [N, K, 2]
+        rows.append(g.op("Concat", cols, axis=2))
+    allr = g.op("Concat", rows, axis=1)                                                                                                  # [N, K, feat]
+    g.nodes.append(node("Reshape", [allr, g.init(np.array([-1, feat], np.int64), "shape")], ["boxes"]))
+    g.add_output("boxes", ["M", feat])
+    return g.model(), {"params": g.n_params, "kind": kind, "classes": n_classes, "anchors": (H // 16) * (W // 16) + (H // 32) * (W // 32), "feat": feat}

@@ -503,3 +503,60 @@ def char_positions_to_word_boxes(line_bbox: np.ndarray, char_positions, char_cou
         l, r = max(f(c - f(cw / f(2.0))), x_min), min(f(c + f(cw / f(2.0))), x_max)
         boxes.append(np.array([[l, y_min], [r, y_min], [r, y_max], [l, y_max]], np.float32))
     return boxes
+
+
+# ------------------------------------------------------------------------------------------------ f4 layout detection
+FILTERS = {"triangle": 0, "catmullrom": 1, "lanczos3": 2}
+
+
+def resize_filter(rgb: np.ndarray, nw: int, nh: int, filter="lanczos3") -> np.ndarray:
+    """image 0.25.6 imageops::resize with FilterType::{Triangle, CatmullRom, Lanczos3} (DetResizeForTest::with_filter,
+    processors/resize_detection.rs:104-108 -> resize_exact, :362)."""
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w, _ = rgb.shape
+    out = np.empty((nh, nw, 3), np.uint8)
+    lib().orc_resize_filter_rgb(_p(rgb), w, h, nw, nh, FILTERS[filter], _p(out))
+    return out
+
+
+def layout_preprocess(rgb: np.ndarray, image_shape=(800, 608), filter="lanczos3", scale=1.0 / 255.0, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225),
+                      bgr=True):
+    """ScaleAwareDetectorModel::preprocess (models/detection/scale_aware_detector.rs:169-199): DetResizeForTest Type1 (keep_ratio = false:
+    resize_exact to image_shape, resize_detection.rs:337-365; pages with h + w < 64 are padded to >= 32 x 32 first, :174-176) and
+    NormalizeImage::with_color_order_from_rgb_stats (normalization.rs:241-273: the RGB statistics are permuted into the output
+    channel order).  Returns (tensor [3, H, W], (src_h, src_w, ratio_h, ratio_w), (resized_h, resized_w))."""
+    src_h, src_w = rgb.shape[:2]
+    img = rgb
+    if src_h + src_w < 64:
+        ph, pw = max(32, src_h), max(32, src_w)
+        pad = np.zeros((ph, pw, 3), np.uint8)
+        pad[:src_h, :src_w] = rgb
+        img = pad
+    h, w = img.shape[:2]
+    th, tw = image_shape
+    if (th, tw) == (h, w):
+        res, rh, rw = img, np.float32(1.0), np.float32(1.0)
+    else:
+        rh, rw = np.float32(th) / np.float32(h), np.float32(tw) / np.float32(w)
+        res = resize_filter(img, tw, th, filter)
+    m = [mean[2], mean[1], mean[0]] if bgr else list(mean)
+    s = [std[2], std[1], std[0]] if bgr else list(std)
+    alpha, beta = alpha_beta(scale, m, s)
+    t = normalize(res, alpha, beta, src=(2, 1, 0) if bgr else (0, 1, 2), layout="chw")
+    return t, (np.float32(src_h), np.float32(src_w), rh, rw), (res.shape[0], res.shape[1])
+
+
+MODEL_TYPES = {"picodet": 0, "standard": 0, "rtdetr": 1, "pp-doclayout": 2}
+
+
+def layout_postprocess(pred: np.ndarray, src_w, src_h, num_classes, score_threshold=0.5, nms_threshold=0.5, max_detections=100, model_type="picodet"):
+    """LayoutPostProcess::apply for one image (processors/layout_postprocess.rs:60-634).  pred: [rows, feat] (the image's slab of the
+    [batch, boxes, 1, feat] prediction tensor).  Returns (boxes [k, 4] x1 y1 x2 y2, classes [k], scores [k])."""
+    pred = np.ascontiguousarray(pred, np.float32).reshape(-1, pred.shape[-1]) if pred.size else np.zeros((0, max(pred.shape[-1], 1)), np.float32)
+    rows, feat = pred.shape
+    ob, oc, os_ = np.zeros((max(rows, 1), 4), np.float32), np.zeros(max(rows, 1), np.int32), np.zeros(max(rows, 1), np.float32)
+    L = lib()
+    L.orc_layout_postprocess.restype = C.c_int
+    n = L.orc_layout_postprocess(_p(pred), rows, feat, C.c_float(src_w), C.c_float(src_h), int(num_classes), C.c_float(score_threshold), C.c_float(nms_threshold),
+                                 int(max_detections), MODEL_TYPES[model_type], _p(ob), _p(oc), _p(os_))
+    return ob[:n].copy(), oc[:n].copy(), os_[:n].copy()

@@ -952,3 +952,205 @@ void orc_bgr_planes_to_rgb(const float* c0, const float* c1, const float* c2, lo
         }
     }
 }
+
+/* ============================================================ f4: layout detection
+ * Resize with the other two filters the layout detectors use  [third-party: image 0.25.6 imageops::sample]:
+ *   FilterType::CatmullRom = bc_cubic_spline(x, 0, 0.5), support 2 (PP-DocLayout, scale_aware_detector.rs:63-75);
+ *   FilterType::Lanczos3   = sinc(x) sinc(x / 3), support 3       (PicoDet, scale_aware_detector.rs:49-61).
+ * Same two passes as Triangle (vertical into f32, horizontal with clamp + round), only kernel and support differ.
+ * filter: 0 Triangle, 1 CatmullRom, 2 Lanczos3.  UNPINNED against the crate, as Triangle is. */
+static inline float orc_sinc(float t) { float a = t * 3.14159274f; return t == 0.0f ? 1.0f : sinf(a) / a; }
+static inline float orc_filter_kernel(int filter, float x) {
+    if (filter == 0) return tri_kernel(x);
+    if (filter == 2) return fabsf(x) < 3.0f ? orc_sinc(x) * orc_sinc(x / 3.0f) : 0.0f;
+    float a = fabsf(x), k;   /* bc_cubic_spline(x, b = 0, c = 0.5): coefficients are exact small integers in f32 */
+    if (a < 1.0f) k = 9.0f * (a * a * a) + -15.0f * (a * a) + 6.0f;
+    else if (a < 2.0f) k = -3.0f * (a * a * a) + 15.0f * (a * a) + -24.0f * a + 12.0f;
+    else k = 0.0f;
+    return k / 6.0f;
+}
+static inline float orc_filter_support(int filter) { return filter == 0 ? 1.0f : filter == 1 ? 2.0f : 3.0f; }
+
+/* taps of one output coordinate: returns n, writes left and the normalised weights (image's sample loop) */
+int orc_filter_taps(int filter, int in_len, int out_len, int o, int* left_out, float* ws) {
+    float ratio = (float)in_len / (float)out_len;
+    float sratio = ratio < 1.0f ? 1.0f : ratio;
+    float support = orc_filter_support(filter) * sratio;
+    float in = ((float)o + 0.5f) * ratio;
+    int64_t left = clampi64((int64_t)floorf(in - support), 0, (int64_t)in_len - 1);
+    int64_t right = clampi64((int64_t)ceilf(in + support), left + 1, (int64_t)in_len);
+    in = in - 0.5f;
+    int n = 0; float sum = 0.0f;
+    for (int64_t i = left; i < right; ++i) { float wv = orc_filter_kernel(filter, ((float)i - in) / sratio); ws[n++] = wv; sum += wv; }
+    for (int i = 0; i < n; ++i) ws[i] /= sum;
+    *left_out = (int)left;
+    return n;
+}
+
+void orc_resize_filter_rgb(const uint8_t* src, int w, int h, int nw, int nh, int filter, uint8_t* dst) {
+    if (w == 0 || h == 0) { memset(dst, 0, (size_t)nw * nh * 3); return; }
+    if (nw == w && nh == h) { memcpy(dst, src, (size_t)w * h * 3); return; }
+    float* tmp = (float*)malloc(sizeof(float) * (size_t)w * nh * 3);
+    float* ws = (float*)malloc(sizeof(float) * (size_t)((w > h ? w : h) + 8));
+    for (int oy = 0; oy < nh; ++oy) {
+        int left; int n = orc_filter_taps(filter, h, nh, oy, &left, ws);
+        for (int x = 0; x < w; ++x) {
+            float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+            for (int i = 0; i < n; ++i) {
+                const uint8_t* p = src + ((size_t)(left + i) * w + x) * 3;
+                float wv = ws[i];
+                t0 += (float)p[0] * wv; t1 += (float)p[1] * wv; t2 += (float)p[2] * wv;
+            }
+            float* o = tmp + ((size_t)oy * w + x) * 3; o[0] = t0; o[1] = t1; o[2] = t2;
+        }
+    }
+    for (int ox = 0; ox < nw; ++ox) {
+        int left; int n = orc_filter_taps(filter, w, nw, ox, &left, ws);
+        for (int y = 0; y < nh; ++y) {
+            float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+            for (int i = 0; i < n; ++i) {
+                const float* p = tmp + ((size_t)y * w + (left + i)) * 3;
+                float wv = ws[i];
+                t0 += p[0] * wv; t1 += p[1] * wv; t2 += p[2] * wv;
+            }
+            uint8_t* o = dst + ((size_t)y * nw + ox) * 3;
+            o[0] = (uint8_t)roundf(clampf(t0, 0.0f, 255.0f));
+            o[1] = (uint8_t)roundf(clampf(t1, 0.0f, 255.0f));
+            o[2] = (uint8_t)roundf(clampf(t2, 0.0f, 255.0f));
+        }
+    }
+    free(tmp); free(ws);
+}
+
+/* LayoutPostProcess (processors/layout_postprocess.rs:21-634) for ONE image.
+ * pred: rows x feat floats (the [num_boxes, 1, feat] or [rows, cols, feat] slab of one batch entry, row-major).
+ * model_type: 0 "picodet" / standard, 1 "rtdetr", 2 "pp-doclayout".  Outputs: boxes (x1,y1,x2,y2), classes, scores, in the
+ * reference's order (NMS keep order = descending score, stable; pp-doclayout 8-dim: then sorted by (col, row)).  Returns the count. */
+static int lp_valid_score(float s) { return isfinite(s) && s >= 0.0f && s <= 1.0f + 1.1920929e-7f; }          /* :460-462 */
+static int lp_valid_class(float raw, int num_classes) {                                                       /* :464-470 */
+    if (!isfinite(raw)) return 0;
+    int c = (int)roundf(raw);
+    return c >= 0 && c < num_classes + 5;
+}
+static void lp_convert(float x1, float y1, float x2, float y2, float ow, float oh, float* o) {                /* :423-454 */
+    int normalized = x2 <= 1.05f && y2 <= 1.05f && x1 >= -0.05f && y1 >= -0.05f && ow > 0.0f && oh > 0.0f;
+    if (normalized) { o[0] = clampf(x1, 0.0f, 1.0f) * ow; o[1] = clampf(y1, 0.0f, 1.0f) * oh; o[2] = clampf(x2, 0.0f, 1.0f) * ow; o[3] = clampf(y2, 0.0f, 1.0f) * oh; }
+    else { o[0] = clampf(x1, 0.0f, ow); o[1] = clampf(y1, 0.0f, oh); o[2] = clampf(x2, 0.0f, ow); o[3] = clampf(y2, 0.0f, oh); }
+}
+static int lp_valid_box(const float* b) { return b[2] > b[0] && b[3] > b[1] && isfinite(b[0]) && isfinite(b[1]) && isfinite(b[2]) && isfinite(b[3]); }
+/* parse_compact_prediction (:372-421): three column orders tried in turn */
+static int lp_parse_compact(const float* row, int num_classes, int rtdetr, int* cls, float* score, float* xyxy) {
+    const int order[3][6] = {{0, 1, 2, 3, 4, 5}, {5, 4, 0, 1, 2, 3}, {1, 0, 2, 3, 4, 5}};   /* class, score, x1, y1, x2, y2 column of each format */
+    for (int f = 0; f < 3; ++f) {
+        float s = row[order[f][1]], c = row[order[f][0]];
+        int sv = rtdetr ? isfinite(s) : lp_valid_score(s);
+        if (sv && lp_valid_class(c, num_classes)) {
+            int ci = (int)roundf(c);
+            if (ci >= 0) {
+                *cls = ci; *score = rtdetr ? clampf(s, 0.0f, 1.0f) : s;
+                xyxy[0] = row[order[f][2]]; xyxy[1] = row[order[f][3]]; xyxy[2] = row[order[f][4]]; xyxy[3] = row[order[f][5]];
+                return 1;
+            }
+        }
+    }
+    return 0;
+}
+/* compute_nms_keep_indices (:482-548): stable sort by score descending (partial_cmp, incomparable = equal), greedy, same class only */
+static int lp_nms(const float* boxes, const int* classes, const float* scores, int n, float nms_thr, int max_det, int* keep) {
+    int* idx = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; ++i) idx[i] = i;
+    for (int i = 1; i < n; ++i) {   /* insertion sort = stable; a before b iff scores[b] < scores[a] */
+        int v = idx[i], j = i - 1;
+        while (j >= 0 && scores[idx[j]] < scores[v]) { idx[j + 1] = idx[j]; --j; }
+        idx[j + 1] = v;
+    }
+    char* sup = (char*)calloc((size_t)(n > 0 ? n : 1), 1);
+    int nk = 0;
+    for (int pos = 0; pos < n; ++pos) {
+        int i = idx[pos];
+        if (sup[i]) continue;
+        keep[nk++] = i;
+        if (nk >= max_det) break;
+        const float* bi = boxes + 4 * i;
+        float area_i = (bi[2] - bi[0]) * (bi[3] - bi[1]);
+        for (int q = pos + 1; q < n; ++q) {
+            int j = idx[q];
+            if (sup[j] || classes[j] != classes[i]) continue;
+            const float* bj = boxes + 4 * j;
+            float ix0 = bi[0] > bj[0] ? bi[0] : bj[0], iy0 = bi[1] > bj[1] ? bi[1] : bj[1];
+            float ix1 = bi[2] < bj[2] ? bi[2] : bj[2], iy1 = bi[3] < bj[3] ? bi[3] : bj[3];
+            if (ix0 >= ix1 || iy0 >= iy1) continue;
+            float inter = (ix1 - ix0) * (iy1 - iy0);
+            float area_j = (bj[2] - bj[0]) * (bj[3] - bj[1]);
+            float uni = area_i + area_j - inter;
+            if (uni > 0.0f && inter / uni > nms_thr) sup[j] = 1;
+        }
+    }
+    free(idx); free(sup);
+    return nk;
+}
+int orc_layout_postprocess(const float* pred, int rows, int feat, float src_w, float src_h, int num_classes, float score_thr, float nms_thr,
+                           int max_det, int model_type, float* out_boxes, int* out_classes, float* out_scores) {
+    if (rows <= 0 || feat <= 0) return 0;
+    float* boxes = (float*)malloc(sizeof(float) * 4 * (size_t)rows);
+    int* classes = (int*)malloc(sizeof(int) * (size_t)rows);
+    float* scores = (float*)malloc(sizeof(float) * (size_t)rows);
+    float* order = (float*)malloc(sizeof(float) * 2 * (size_t)rows);
+    int n = 0;
+    if (model_type == 2) {                       /* process_pp_doclayout (:232-333) */
+        if (feat < 6) { free(boxes); free(classes); free(scores); free(order); return 0; }
+        for (int r = 0; r < rows; ++r) {
+            const float* row = pred + (size_t)r * feat;
+            float cf = row[0];
+            int ci = isnan(cf) ? 0 : cf >= 2147483648.0f ? 2147483647 : cf <= -2147483648.0f ? (-2147483647 - 1) : (int)cf;   /* `as i32`: truncation, saturating, NaN -> 0 */
+            float s = row[1];
+            if (s < score_thr || ci < 0 || ci >= num_classes) continue;
+            float b[4];
+            lp_convert(row[2], row[3], row[4], row[5], src_w, src_h, b);
+            if (!lp_valid_box(b)) continue;
+            memcpy(boxes + 4 * n, b, sizeof b); classes[n] = ci; scores[n] = s;
+            order[2 * n] = feat == 8 ? row[6] : 0.0f; order[2 * n + 1] = feat == 8 ? row[7] : (float)r;
+            ++n;
+        }
+    } else {                                     /* process_picodet (:99-211); rtdetr / standard share it */
+        for (int r = 0; r < rows; ++r) {
+            const float* row = pred + (size_t)r * feat;
+            float b[4];
+            if (feat == 4 + num_classes) {
+                int best = 0; float bs = -INFINITY;
+                for (int c = 0; c < num_classes; ++c) if (row[4 + c] > bs) { bs = row[4 + c]; best = c; }
+                if (bs < score_thr) continue;
+                lp_convert(row[0], row[1], row[2], row[3], src_w, src_h, b);
+                if (!lp_valid_box(b)) continue;
+                memcpy(boxes + 4 * n, b, sizeof b); classes[n] = best; scores[n] = bs; ++n;
+            } else if (feat >= 6) {
+                int ci; float s, x[4];
+                if (!lp_parse_compact(row, num_classes, model_type == 1, &ci, &s, x)) continue;
+                if (s < score_thr || ci >= num_classes) continue;
+                lp_convert(x[0], x[1], x[2], x[3], src_w, src_h, b);
+                if (!lp_valid_box(b)) continue;
+                memcpy(boxes + 4 * n, b, sizeof b); classes[n] = ci; scores[n] = s; ++n;
+            }
+        }
+    }
+    int* keep = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    int nk = lp_nms(boxes, classes, scores, n, nms_thr, max_det, keep);
+    if (model_type == 2 && feat == 8 && nk > 1) {   /* reading order: (col, row) ascending by total_cmp, stable (:309-320) */
+        for (int i = 1; i < nk; ++i) {
+            int v = keep[i], j = i - 1;
+            while (j >= 0) {
+                float ca = order[2 * keep[j]], ra = order[2 * keep[j] + 1], cb = order[2 * v], rb = order[2 * v + 1];
+                int32_t ia, ib; memcpy(&ia, &ca, 4); memcpy(&ib, &cb, 4);
+                ia ^= (int32_t)(((uint32_t)(ia >> 31)) >> 1); ib ^= (int32_t)(((uint32_t)(ib >> 31)) >> 1);   /* f32::total_cmp key */
+                int gt = ia > ib;
+                if (ia == ib) { int32_t ja, jb; memcpy(&ja, &ra, 4); memcpy(&jb, &rb, 4); ja ^= (int32_t)(((uint32_t)(ja >> 31)) >> 1); jb ^= (int32_t)(((uint32_t)(jb >> 31)) >> 1); gt = ja > jb; }
+                if (!gt) break;
+                keep[j + 1] = keep[j]; --j;
+            }
+            keep[j + 1] = v;
+        }
+    }
+    for (int i = 0; i < nk; ++i) { memcpy(out_boxes + 4 * i, boxes + 4 * keep[i], 16); out_classes[i] = classes[keep[i]]; out_scores[i] = scores[keep[i]]; }
+    free(boxes); free(classes); free(scores); free(order); free(keep);
+    return nk;
+}

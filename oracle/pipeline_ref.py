@@ -107,6 +107,35 @@ class OracleRectifier:
         return out
 
 
+class OracleLayoutDetector:
+    """LayoutDetectionAdapter's model half for the PicoDet / RT-DETR / PP-DocLayout graphs: ScaleAwareDetectorModel::forward
+    (models/detection/scale_aware_detector.rs:169-440) + LayoutPostProcess::apply (processors/layout_postprocess.rs:60-97)."""
+
+    def __init__(self, onnx_bytes, num_classes=5, model_type="picodet", image_shape=(800, 608), score_threshold=0.5, nms_threshold=0.5, max_detections=100):
+        self.model = onnx_ref.parse_model(onnx_bytes)
+        self.inputs = self.model["inputs"]
+        self.kw = dict(filter="catmullrom", bgr=False, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0)) if model_type == "pp-doclayout" else dict(filter="lanczos3", bgr=True)
+        self.image_shape, self.num_classes, self.model_type = image_shape, num_classes, model_type
+        self.post = (score_threshold, nms_threshold, max_detections)
+
+    def preprocess(self, image):
+        return R.layout_preprocess(image, self.image_shape, **self.kw)
+
+    def predictions(self, images):
+        pre = [self.preprocess(im) for im in images]
+        x = np.stack([p[0] for p in pre])
+        feeds = {"image": x, "scale_factor": np.array([[np.float32(p[2][0]) / np.float32(im.shape[0]), np.float32(p[2][1]) / np.float32(im.shape[1])] for p, im in zip(pre, images)], np.float32)}
+        if "im_shape" in self.inputs:
+            feeds["im_shape"] = np.array([[p[2][0], p[2][1]] for p in pre], np.float32)
+        y = onnx_ref.run(self.model, feeds)[0]
+        n = len(images)
+        return y.reshape(n, -1, y.shape[-1])            # [n, boxes, feat] (the reference's [n, boxes, 1, feat])
+
+    def detect(self, images):
+        y = self.predictions(images)
+        return [R.layout_postprocess(y[i], images[i].shape[1], images[i].shape[0], self.num_classes, *self.post, model_type=self.model_type) for i in range(len(images))], y
+
+
 class OracleOCR:
     def __init__(self, det, rec, character_list, thresh=0.3, box_thresh=0.6, unclip=2.0, image_batch_size=8, region_batch_size=64,
                  max_pooled_crops=4096, doc_orientation=None, rectifier=None, line_orientation=None, threads=0, **det_kw):

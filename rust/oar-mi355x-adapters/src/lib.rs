@@ -14,6 +14,7 @@
 //! | `document_orientation_adapter.rs`                            | [`Mi355xDocumentOrientationAdapter`]| `oar_cls_*`               |
 //! | `text_line_orientation_adapter.rs`                           | [`Mi355xTextLineOrientationAdapter`]| `oar_cls_*`               |
 //! | `document_rectification_adapter.rs` `UVDocRectifierAdapter`  | [`Mi355xRectifierAdapter`]          | `oar_rect_*`              |
+//! | `layout_detection_adapter.rs` `LayoutDetectionAdapter` (PicoDet / RT-DETR) | [`Mi355xLayoutDetectionAdapter`]   | `oar_layout_*`            |
 //! | `core/inference/ort_infer_execution.rs` `OrtInfer` (Seam A)  | [`Mi355xInfer`]                     | `oar_engine_*`            |
 //! | `src/oarocr/ocr.rs` `OAROCR::predict`                        | [`Mi355xOcr`]                       | `oar_ocr_*`               |
 //!
@@ -23,6 +24,7 @@
 pub mod error;
 pub mod ffi_util;
 pub mod infer;
+pub mod layout_detection;
 pub mod orientation;
 pub mod pipeline;
 pub mod rectification;
@@ -32,6 +34,7 @@ pub mod text_recognition;
 
 pub use error::{Mi355xError, check};
 pub use infer::Mi355xInfer;
+pub use layout_detection::{Mi355xLayoutDetectionAdapter, Mi355xLayoutDetectionAdapterBuilder};
 pub use orientation::{
     Mi355xDocumentOrientationAdapter, Mi355xDocumentOrientationAdapterBuilder,
     Mi355xTextLineOrientationAdapter, Mi355xTextLineOrientationAdapterBuilder,

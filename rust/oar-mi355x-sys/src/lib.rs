@@ -67,6 +67,12 @@ pub struct oar_rect {
     _marker: core::marker::PhantomData<(*mut u8, core::marker::PhantomPinned)>,
 }
 
+#[repr(C)]
+pub struct oar_layout {
+    _private: [u8; 0],
+    _marker: core::marker::PhantomData<(*mut u8, core::marker::PhantomPinned)>,
+}
+
 pub type oar_output_view_fn = Option<unsafe extern "C" fn(user: *mut c_void, dims: *const i64, rank: i32, data: *const f32) -> i32>;
 
 #[repr(C)]
@@ -249,6 +255,36 @@ pub struct oar_rect_cfg {
 
 #[repr(C)]
 #[derive(Debug, Clone, Copy)]
+pub struct oar_layout_cfg {
+    pub device_id: i32,
+    pub input_h: u32,
+    pub input_w: u32,
+    pub resize_filter: i32,
+    pub color_bgr: i32,
+    pub scale: f32,
+    pub mean: [f32; 3],
+    pub std: [f32; 3],
+    pub num_classes: u32,
+    pub model_type: i32,
+    pub score_threshold: f32,
+    pub nms_threshold: f32,
+    pub max_detections: u32,
+}
+
+#[repr(C)]
+#[derive(Debug, Clone, Copy)]
+pub struct oar_layout_result {
+    pub n_images: u32,
+    pub n_boxes: u32,
+    pub box_offsets: *mut u32,
+    pub boxes: *mut f32,
+    pub classes: *mut i32,
+    pub scores: *mut f32,
+    pub feature_dim: u32,
+}
+
+#[repr(C)]
+#[derive(Debug, Clone, Copy)]
 pub struct oar_prof_entry {
     pub name: [c_char; 48],
     pub launches: u64,
@@ -312,6 +348,13 @@ unsafe extern "C" {
     pub fn oar_k_rotate_rgb(rgb: *const u8, w: u32, h: u32, quarter: i32, out: *mut u8) -> oar_status;
     pub fn oar_k_bgr_planes_to_rgb(planes: *const f32, plane: u64, scale: f32, out: *mut u8) -> oar_status;
     pub fn oar_host_rotate_back_points(pts: *mut f32, n_points: u32, angle: f32, rotated_w: u32, rotated_h: u32) -> oar_status;
+    pub fn oar_layout_create(onnx: *const u8, onnx_len: usize, cfg: *const oar_layout_cfg, out: *mut *mut oar_layout) -> oar_status;
+    pub fn oar_layout_destroy(l: *mut oar_layout);
+    pub fn oar_layout_run(l: *mut oar_layout, rgb: *const *const u8, widths: *const u32, heights: *const u32, n_images: u32, out: *mut oar_layout_result) -> oar_status;
+    pub fn oar_layout_result_free(r: *mut oar_layout_result);
+    pub fn oar_layout_preprocess(l: *mut oar_layout, rgb: *const u8, width: u32, height: u32, out_chw: *mut f32) -> oar_status;
+    pub fn oar_k_resize_filter(rgb: *const u8, w: u32, h: u32, nw: u32, nh: u32, filter: i32, out: *mut u8) -> oar_status;
+    pub fn oar_k_layout_postprocess(pred: *const f32, n_images: u32, rows: u32, feat: u32, src_wh: *const f32, num_classes: u32, model_type: i32, score_threshold: f32, nms_threshold: f32, max_detections: u32, out: *mut oar_layout_result) -> oar_status;
     pub fn oar_dev_alloc(device_id: i32, bytes: usize, out: *mut *mut c_void) -> oar_status;
     pub fn oar_dev_upload(dst: *mut c_void, src: *const c_void, bytes: usize) -> oar_status;
     pub fn oar_dev_download(dst: *mut c_void, src: *const c_void, bytes: usize) -> oar_status;

@@ -184,7 +184,7 @@ def test_adapters_crate_only_uses_what_the_sys_crate_declares(header):
             "oar_engine_create", "oar_engine_run_named", "oar_engine_run_first_f32", "oar_engine_io"} <= used_funcs
 
 
-@pytest.mark.parametrize("fn,adapters", [("text_detection.rs", 1), ("text_recognition.rs", 1), ("orientation.rs", 2), ("rectification.rs", 1)])
+@pytest.mark.parametrize("fn,adapters", [("text_detection.rs", 1), ("text_recognition.rs", 1), ("orientation.rs", 2), ("rectification.rs", 1), ("layout_detection.rs", 1)])
 def test_every_adapter_implements_the_reference_traits(fn, adapters):
     """ModelAdapter { type Task; info; execute; supports_batching; recommended_batch_size } and
     AdapterBuilder { type Config; type Adapter; build; with_config; adapter_type } (core/traits/adapter.rs:42-110)."""
