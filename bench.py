@@ -189,11 +189,9 @@ def main():
                    .region_batch_size(args.region_batch).device(dev))
         if world > 1:
             builder = builder.host_threads(max(2, min(16, cores)))   # this rank's geometry pool stays inside its CPU budget
-            if cores < 6:
-                # too few CPUs per rank for the host border follower to keep up with the detector: follow the mask borders on
-                # the GPU instead (oar_det_cfg.gpu_contours; identical boxes)
-                cfg.gpu_contours = True
-                builder = builder.text_detection_config(cfg)
+            # (round 2 switched to the GPU border follower below 6 cores per rank; measured in round 3, profiles/r3/gpu_contours_breakeven.txt:
+            # the host tracer wins at EVERY pool size -- 1 thread 1002 vs 903 images/s, 2 threads 1301 vs 958, 4 threads 1635 vs 967 -- so
+            # the switch is gone; oar_det_cfg.gpu_contours / OAR_GPU_CONTOURS remain as a knob)
         if args.config == 4:
             builder = (builder.with_document_image_orientation_classification(models.build_cls(4, seed=5)[0])
                        .with_document_image_rectification(models.build_uvdoc(seed=6)[0])
