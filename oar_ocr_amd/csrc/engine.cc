@@ -660,6 +660,304 @@ struct Planner {
     void step(std::function<void(const RunCtx&)> f, double flops = 0, double bytes = 0) {
         P.steps.push_back(std::move(f));
         P.flops += flops; P.bytes += bytes; P.n_kernels++;
+        step_chain.push_back(-1);
+        step_node.push_back(cur);
+    }
+
+    // ------------------------------------------------------------------ sample-local chains (csrc/chain.hip)
+    // Operators that only read rows of their own sample (1 x k convolutions over H == 1 maps, Linear, LayerNorm, the fused SVTR
+    // attention, row copies of a channel concat) record a ChainRec next to their step.  While the newest step is such an operator,
+    // build() releases nothing (every tensor a run touches stays allocated until the run ends, so no two of them share arena bytes
+    // and the samples of a fused run may advance at different paces); fuse_chains() then replaces each run by ONE chain_run step.
+    struct ChainRec {
+        k::ChainOpD d;
+        Loc in, out, res;
+        int64_t rows = 0;                 // rows of the operator's tensors (all samples)
+        int64_t fix_n = 0, fix_T = 0;     // > 0: the operator fixes the partition (n samples of T rows); 0: any partition of its rows
+        std::function<std::vector<float>()> make_w;   // GEMM weights as [N][K] f32 (host), built only when a chain is really formed
+        const float* dev_bias = nullptr;  // GEMM bias / LN beta (device constant of N floats)
+        const float* dev_gamma = nullptr; // LN gamma
+        double flops = 0, bytes = 0;
+        int node = 0;                     // graph node the operator belongs to
+        std::string out_root;             // storage root of the tensor it writes (liveness: is it read after the run?)
+    };
+    std::vector<int> step_chain;          // parallel to P.steps: index into chain_recs, -1 = not chainable
+    std::vector<int> step_node;           // parallel to P.steps: the graph node that emitted the step
+    std::vector<ChainRec> chain_recs;
+    bool chain_on = [] { const char* e = getenv("OAR_FUSE_CHAIN"); return !e || atoi(e) != 0; }();
+    static bool chain_loc_ok(const Loc& l) { return l.kind == Loc::ARENA || l.kind == Loc::INPUT || (l.kind == Loc::CONST && l.cptr); }
+    static k::ChainRef chain_ref(const Loc& l) {
+        k::ChainRef r;
+        if (l.kind == Loc::ARENA) { r.kind = 1; r.v = (unsigned long long)l.off; }
+        else if (l.kind == Loc::INPUT) { r.kind = 2; r.v = (unsigned long long)l.off; }
+        else if (l.kind == Loc::CONST) { r.kind = 0; r.v = (unsigned long long)reinterpret_cast<uintptr_t>(l.cptr); }
+        return r;
+    }
+    void step_chainable(std::function<void(const RunCtx&)> f, ChainRec rec, double flops, double bytes) {
+        step(std::move(f), flops, bytes);
+        if (!chain_on) return;
+        rec.flops = flops; rec.bytes = bytes; rec.node = cur;
+        step_chain.back() = (int)chain_recs.size();
+        chain_recs.push_back(std::move(rec));
+    }
+    bool chain_run_open() const { return chain_on && !step_chain.empty() && step_chain.back() >= 0; }
+    static std::vector<float> chain_weight_conv(const HostTensor& W) {   // [Cout][Cin][1][kw] -> [Cout][kw * Cin]
+        const int64_t Co = W.dims[0], Ci = W.dims[1], kw = W.dims[3], K = kw * Ci;
+        std::vector<float> w((size_t)Co * K);
+        for (int64_t co = 0; co < Co; ++co)
+            for (int64_t ci = 0; ci < Ci; ++ci)
+                for (int64_t b = 0; b < kw; ++b) w[(size_t)co * K + b * Ci + ci] = W.f[(size_t)((co * Ci + ci) * kw + b)];
+        return w;
+    }
+    static std::vector<float> chain_weight_linear(const HostTensor& B, bool transB) {   // -> [N][K]
+        const int64_t K = transB ? B.dims[1] : B.dims[0], N = transB ? B.dims[0] : B.dims[1];
+        std::vector<float> w((size_t)N * K);
+        for (int64_t kk = 0; kk < K; ++kk)
+            for (int64_t nn = 0; nn < N; ++nn) w[(size_t)nn * K + kk] = transB ? B.f[(size_t)(nn * K + kk)] : B.f[(size_t)(kk * N + nn)];
+        return w;
+    }
+    static constexpr int kMinChain = 3;
+    bool chain_live_after(const std::string& root, int last_node) const {   // is the tensor read by a node after `last_node` (or a graph output)?
+        if (root == "\x01stage") return false;   // a staging copy of fuse_chains: lives inside the run by construction
+        auto it = last_use.find(root);
+        return root.empty() || it == last_use.end() || it->second > last_node;
+    }
+    // Tensors a chain writes and nobody reads after it live in the workgroup's LDS (one sample's rows, each row padded by 4 floats so
+    // that the 16 rows of a B operand start in different banks): the operators' references are rewritten to LDS offsets (ChainRef
+    // kind 3) and their row strides to the padded one.  Liveness-based first-fit over the operator order; when the budget is
+    // exceeded the largest tensor goes back to the arena and the placement is redone.  Returns the dynamic LDS size of the launch.
+    size_t chain_place_in_lds(std::vector<k::ChainOpD>& ops, const std::vector<std::string>& out_roots, int last_node, int64_t n, int64_t T, size_t scratch, size_t budget) {
+        static const bool lds_on = [] { const char* e = getenv("OAR_CHAIN_LDS"); return !e || atoi(e) != 0; }();
+        if (!lds_on || scratch >= budget) return scratch;
+        struct Use { int op; int which; int64_t off; int ld; int width; };   // which: 0 in, 1 out, 2 res; width: columns the view covers
+        std::vector<Use> uses;
+        for (int j = 0; j < (int)ops.size(); ++j) {
+            const k::ChainOpD& d = ops[(size_t)j];
+            const int win = d.type == k::CH_GEMM ? d.cin : d.type == k::CH_ATTN ? 3 * d.heads * d.hd : d.N;
+            if (d.in.kind == 1) uses.push_back({j, 0, (int64_t)d.in.v, d.in_ld, win});
+            if (d.out.kind == 1) uses.push_back({j, 1, (int64_t)d.out.v, d.out_ld, d.N});
+            if (d.res.kind == 1) uses.push_back({j, 2, (int64_t)d.res.v, d.res_ld, d.N});
+        }
+        struct Root { int64_t base, end; int ld; bool bad = false, written = false, live_out = false, in_lds = false; int first = 1 << 30, last = -1; size_t bytes = 0, off = 0; };
+        std::vector<Root> roots;
+        std::vector<int> order(uses.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return uses[(size_t)a].off < uses[(size_t)b].off; });
+        std::vector<int> root_of(uses.size(), -1);
+        for (int ui : order) {
+            const Use& u = uses[(size_t)ui];
+            const int64_t end = u.off + ((n * T - 1) * u.ld + u.width) * 4;
+            if (roots.empty() || u.off >= roots.back().end) { Root r; r.base = u.off; r.end = end; r.ld = u.ld; roots.push_back(r); }
+            Root& r = roots.back();
+            r.end = std::max(r.end, end);
+            if (u.ld != r.ld || u.off - r.base >= (int64_t)r.ld * 4) r.bad = true;
+            root_of[(size_t)ui] = (int)roots.size() - 1;
+        }
+        for (size_t ui = 0; ui < uses.size(); ++ui) {
+            Root& r = roots[(size_t)root_of[ui]];
+            const Use& u = uses[ui];
+            r.first = std::min(r.first, u.op); r.last = std::max(r.last, u.op);
+            if (u.which == 1) {
+                r.written = true;
+                if (chain_live_after(out_roots[(size_t)u.op], last_node)) r.live_out = true;
+            }
+        }
+        for (Root& r : roots) {
+            r.bytes = (size_t)T * (size_t)(r.ld + 4) * 4;
+            r.in_lds = r.written && !r.live_out && !r.bad;
+            // a tensor written in the run must be written before it is read there (it is: the planner emits in dependency order)
+        }
+        size_t peak = 0;
+        for (;;) {
+            // first-fit by first definition; a slot is reusable by an operator's OUTPUT only when its tensor's last use is an earlier operator
+            std::vector<int> idx;
+            for (int i = 0; i < (int)roots.size(); ++i) if (roots[(size_t)i].in_lds) idx.push_back(i);
+            std::sort(idx.begin(), idx.end(), [&](int a, int b) { return roots[(size_t)a].first < roots[(size_t)b].first; });
+            std::vector<int> active;
+            peak = 0;
+            for (int i : idx) {
+                Root& r = roots[(size_t)i];
+                std::vector<int> keep;
+                for (int a : active) if (roots[(size_t)a].last >= r.first) keep.push_back(a);
+                active.swap(keep);
+                std::sort(active.begin(), active.end(), [&](int a, int b) { return roots[(size_t)a].off < roots[(size_t)b].off; });
+                size_t off = 0;
+                for (int a : active) { if (off + r.bytes <= roots[(size_t)a].off) break; off = std::max(off, roots[(size_t)a].off + roots[(size_t)a].bytes); }
+                r.off = off;
+                peak = std::max(peak, off + r.bytes);
+                active.push_back(i);
+            }
+            if (scratch + peak <= budget || idx.empty()) break;
+            int big = idx[0];
+            for (int i : idx) if (roots[(size_t)i].bytes > roots[(size_t)big].bytes) big = i;
+            roots[(size_t)big].in_lds = false;
+        }
+        for (size_t ui = 0; ui < uses.size(); ++ui) {
+            const Root& r = roots[(size_t)root_of[ui]];
+            if (!r.in_lds) continue;
+            const Use& u = uses[ui];
+            k::ChainOpD& d = ops[(size_t)u.op];
+            k::ChainRef ref; ref.kind = 3; ref.v = (unsigned long long)(scratch + r.off + (size_t)(u.off - r.base));
+            if (u.which == 0) { d.in = ref; d.in_ld = r.ld + 4; }
+            else if (u.which == 1) { d.out = ref; d.out_ld = r.ld + 4; }
+            else { d.res = ref; d.res_ld = r.ld + 4; }
+        }
+        return scratch + peak;
+    }
+    void fuse_chains() {
+        if (!chain_on || chain_recs.empty()) return;
+        const int ns = (int)P.steps.size();
+        std::vector<std::function<void(const RunCtx&)>> out;
+        int fused_away = 0;
+        int a = 0;
+        auto keep = [&](int i) { out.push_back(std::move(P.steps[(size_t)i])); };
+        while (a < ns) {
+            if (step_chain[(size_t)a] < 0) { keep(a++); continue; }
+            int b = a;
+            while (b < ns && step_chain[(size_t)b] >= 0) ++b;
+            // run [a, b): chains grow around each operator that fixes the partition
+            int i = a;
+            while (i < b) {
+                int kf = i;
+                while (kf < b && chain_recs[(size_t)step_chain[(size_t)kf]].fix_n == 0) ++kf;
+                if (kf == b) break;
+                const int64_t n = chain_recs[(size_t)step_chain[(size_t)kf]].fix_n, T = chain_recs[(size_t)step_chain[(size_t)kf]].fix_T;
+                auto compat = [&](int j) {
+                    const ChainRec& r = chain_recs[(size_t)step_chain[(size_t)j]];
+                    return r.fix_n ? (r.fix_n == n && r.fix_T == T) : (r.rows == n * T);
+                };
+                if (n <= 0 || T <= 0 || T > 4096 || !compat(kf)) { for (int j = i; j <= kf; ++j) keep(j); i = kf + 1; continue; }
+                int lo = kf, hi = kf + 1;
+                while (lo > i && compat(lo - 1)) --lo;
+                while (hi < b && compat(hi)) ++hi;
+                for (int j = i; j < lo; ++j) keep(j);
+                if (hi - lo < kMinChain) { for (int j = lo; j < hi; ++j) keep(j); i = hi; continue; }
+                std::vector<k::ChainOpD> ops;
+                std::vector<std::string> out_roots;
+                std::vector<const ChainRec*> recs;
+                double flops = 0, bytes = 0;
+                int max_hd = 0;
+                int last_node = chain_recs[(size_t)step_chain[(size_t)(hi - 1)]].node;
+                if ((size_t)hi < step_node.size() && step_node[(size_t)hi] == last_node) --last_node;   // the run was cut inside a node: that node's tensors stay in the arena
+                for (int j = lo; j < hi; ++j) {
+                    ChainRec& r = chain_recs[(size_t)step_chain[(size_t)j]];
+                    k::ChainOpD d = r.d;
+                    d.in = chain_ref(r.in); d.out = chain_ref(r.out); d.res = chain_ref(r.res);
+                    if (d.type == k::CH_ATTN) max_hd = std::max(max_hd, d.hd);
+                    flops += r.flops; bytes += r.bytes;
+                    ops.push_back(d); out_roots.push_back(r.out_root); recs.push_back(&r);
+                }
+                // copy elision: a Concat input produced inside the run by one operator and read by nothing else is written where the copy
+                // would have put it (the producer gets the copy's destination view) and the copy disappears
+                for (int j = 0; j < (int)ops.size();) {
+                    const k::ChainOpD& cp = ops[(size_t)j];
+                    int prod = -1, readers = 0;
+                    if (cp.type == k::CH_COPY && cp.in.kind == 1) {
+                        for (int q = 0; q < (int)ops.size(); ++q) {
+                            const k::ChainOpD& o = ops[(size_t)q];
+                            if (q < j && o.out.kind == 1 && o.out.v == cp.in.v && o.out_ld == cp.in_ld && o.N == cp.N && o.type != k::CH_COPY) prod = q;
+                            if (q != j && ((o.in.kind == 1 && o.in.v == cp.in.v) || (o.res.kind == 1 && o.res.v == cp.in.v))) ++readers;
+                        }
+                    }
+                    if (prod >= 0 && readers == 0 && !chain_live_after(out_roots[(size_t)prod], last_node)) {
+                        ops[(size_t)prod].out = cp.out; ops[(size_t)prod].out_ld = cp.out_ld;
+                        out_roots[(size_t)prod] = out_roots[(size_t)j];
+                        ops.erase(ops.begin() + j); out_roots.erase(out_roots.begin() + j); recs.erase(recs.begin() + j);
+                        continue;
+                    }
+                    ++j;
+                }
+                // the chain's constants in one allocation: biases / LayerNorm affine vectors first (the kernel keeps them in LDS), then weights
+                std::vector<float> blob;
+                auto fetch = [&](const float* dev, int cnt) {   // a device constant back to the host (plan time only)
+                    const int at = (int)blob.size();
+                    blob.resize((size_t)at + (size_t)((cnt + 3) & ~3), 0.f);
+                    OAR_HIP(hipMemcpy(blob.data() + at, dev, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+                    return at;
+                };
+                for (size_t q = 0; q < ops.size(); ++q) {
+                    if (recs[q]->dev_bias && ops[q].type != k::CH_COPY) ops[q].bias_l = fetch(recs[q]->dev_bias, ops[q].N);
+                    if (recs[q]->dev_gamma && ops[q].type == k::CH_LN) ops[q].w_l = fetch(recs[q]->dev_gamma, ops[q].N);
+                }
+                const int small = (int)blob.size();
+                // a product whose tokens come from HBM (the run's input) gets them staged into LDS first: a row copy in front of it, its
+                // destination a transient LDS tensor (a made-up arena address far above the real arena names it for the placement below)
+                const unsigned long long kStageBase = 1ull << 50;
+                for (size_t q = 0; q < ops.size(); ++q) {
+                    if (ops[q].type != k::CH_GEMM || (ops[q].in.kind != 1 && ops[q].in.kind != 2)) continue;
+                    bool produced_here = false;   // (tensors written earlier in the run are placed in LDS as they are)
+                    for (size_t e = 0; e < q && ops[q].in.kind == 1; ++e) {
+                        if (ops[e].out.kind != 1) continue;
+                        const unsigned long long a0 = ops[q].in.v, a1 = a0 + (unsigned long long)(((n * T - 1) * ops[q].in_ld + ops[q].cin) * 4);
+                        const unsigned long long b0 = ops[e].out.v, b1 = b0 + (unsigned long long)(((n * T - 1) * ops[e].out_ld + ops[e].N) * 4);
+                        produced_here = produced_here || (a0 < b1 && b0 < a1);
+                    }
+                    if (produced_here) continue;
+                    k::ChainOpD cp;
+                    cp.type = k::CH_COPY; cp.N = ops[q].in_ld; cp.in_ld = ops[q].in_ld; cp.out_ld = ops[q].in_ld;
+                    cp.in = ops[q].in;
+                    cp.out.kind = 1; cp.out.v = kStageBase + ((unsigned long long)q << 40);
+                    ops[q].in = cp.out;
+                    ops.insert(ops.begin() + (long)q, cp); out_roots.insert(out_roots.begin() + (long)q, std::string("\x01stage")); recs.insert(recs.begin() + (long)q, nullptr);
+                    ++q;
+                }
+                const int MT = (int)((T + 15) / 16);
+                std::vector<size_t> w_at(ops.size(), 0);
+                size_t scratch = 0;
+                for (size_t q = 0; q < ops.size(); ++q) {
+                    k::ChainOpD& d = ops[q];
+                    if (d.type != k::CH_GEMM) continue;
+                    blob.resize((blob.size() + 63) & ~(size_t)63, 0.f);
+                    w_at[q] = blob.size();
+                    const std::vector<float> w = recs[q]->make_w();
+                    OAR_CHECK(w.size() == (size_t)d.N * (size_t)d.K, OAR_INTERNAL, "chain: weight size");
+                    blob.insert(blob.end(), w.begin(), w.end());
+                    // work items = channel tiles x token groups (mb tiles each) x K slices: enough of them for the 16 waves, partials <= 24 KB
+                    d.mb = MT <= 3 ? MT : (MT % 3 == 0 ? 3 : (MT % 2 == 0 ? 2 : 3));
+                    const int MG = (MT + d.mb - 1) / d.mb, NT = d.N / 16, KB = d.K / 16;
+                    int ks = 1;
+                    while (NT * MG * ks < 16 && KB / (ks * 2) >= 2 && NT * MG * d.mb * ks * 2 <= 24) ks *= 2;
+                    d.ksplit = ks;
+                    scratch = std::max(scratch, k::chain_lds_bytes(d, (int)T));
+                }
+                auto consts = std::make_shared<DevBuf>();
+                consts->reserve(blob.size() * 4 + 256);
+                OAR_HIP(hipMemcpy(consts->p, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
+                for (size_t q = 0; q < ops.size(); ++q) if (ops[q].type == k::CH_GEMM) ops[q].w = consts->as<float>() + w_at[q];
+                scratch = (scratch + 255) & ~(size_t)255;
+                const size_t small_bytes = (((size_t)small * 4 + 255) & ~(size_t)255) + ((ops.size() * sizeof(k::ChainOpD) + 255) & ~(size_t)255);   // + the table copy
+                const size_t tens_end = chain_place_in_lds(ops, out_roots, last_node, n, T, scratch, k::kChainLdsBudget - small_bytes);
+                for (size_t q = 0; q + 1 < ops.size();) {   // a staging copy that found no room: drop it, the product reads HBM (slow path)
+                    if (ops[q].type == k::CH_COPY && ops[q].out.kind == 1 && ops[q].out.v >= kStageBase) {
+                        ops[q + 1].in = ops[q].in; ops[q + 1].in_ld = ops[q].in_ld;
+                        ops.erase(ops.begin() + (long)q); out_roots.erase(out_roots.begin() + (long)q); recs.erase(recs.begin() + (long)q); w_at.erase(w_at.begin() + (long)q);
+                        continue;
+                    }
+                    ++q;
+                }
+                const int small_l = (int)(((tens_end + 255) & ~(size_t)255) / 4);
+                for (auto& d : ops) { if (d.bias_l >= 0) d.bias_l += small_l; if (d.w_l >= 0) d.w_l += small_l; }
+                auto table = std::make_shared<DevBuf>();
+                table->reserve(ops.size() * sizeof(k::ChainOpD));
+                OAR_HIP(hipMemcpy(table->p, ops.data(), ops.size() * sizeof(k::ChainOpD), hipMemcpyHostToDevice));
+                k::ChainLaunch L;
+                L.ops = table->as<k::ChainOpD>(); L.n_ops = (int)ops.size(); L.n_samples = (int)n; L.T = (int)T; L.max_hd = max_hd;
+                L.lds = (size_t)small_l * 4 + small_bytes;
+                L.tab_l = small_l + (int)((((size_t)small * 4 + 255) & ~(size_t)255) / 4);
+                L.consts = consts->as<float>(); L.small = small; L.total_consts = (int)blob.size(); L.small_l = small_l;
+                L.bytes = bytes; L.flops = flops;
+                const int n_ops = hi - lo;
+                out.push_back([L, table, consts](const RunCtx& c) { k::chain_run(c.s, L, c.arena, reinterpret_cast<const char*>(c.input)); });
+                fused_away += n_ops - 1;
+                i = hi;
+            }
+            for (int j = i; j < b; ++j) keep(j);
+            a = b;
+        }
+        P.steps.swap(out);
+        P.n_kernels -= fused_away;
+        step_chain.assign(P.steps.size(), -1);
+        step_node.assign(P.steps.size(), -1);
     }
 
     // ------------------------------------------------------------------ layout conversions
@@ -913,13 +1211,29 @@ struct Planner {
         bool has_res = res.kind != Loc::NONE;
         double flops = 2.0 * N * Ho * Wo * Cout * (Cin / g) * kh * kw;
         double bytes = 4.0 * (N * H * Wd * Cin + N * Ho * Wo * Cout * (has_res ? 2 : 1) + numel(W.dims));
-        step([=](const RunCtx& c) {
+        auto run = [=](const RunCtx& c) {
             k::ConvP q = p;
             q.x = c.at(xin); q.y = c.mut(yl); q.residual = has_res ? c.at(res) : nullptr;
             if (kind == 0) k::conv_igemm(c.s, q);
             else if (kind == 1) k::conv_dw(c.s, q);
             else k::conv_direct(c.s, q);
-        }, flops, bytes);
+        };
+        // a 1 x k convolution over a one-row map is a product over the rows of each sample: chainable (chain.hip)
+        if (kind == 0 && H == 1 && Ho == 1 && kh == 1 && pt == 0 && pb == 0 && sw == 1 && dw == 1 && Wo == Wd && Cin % 16 == 0 && Cout % 16 == 0 &&
+            chain_loc_ok(xin) && (!has_res || chain_loc_ok(res))) {
+            ChainRec r;
+            r.d.type = k::CH_GEMM; r.d.K = (int)(kw * Cin); r.d.N = (int)Cout; r.d.cin = (int)Cin; r.d.pad = (int)pl;
+            r.d.in_ld = (int)Cin; r.d.out_ld = (int)Cout; r.d.res_ld = (int)Cout;
+            r.d.act = n.act.kind; r.d.alpha = n.act.alpha; r.d.beta = n.act.beta; r.dev_bias = bias;
+            r.in = xin; r.out = yl; if (has_res) r.res = res;
+            r.rows = N * Wd; r.out_root = n.out[0];
+            if (kw > 1) { r.fix_n = N; r.fix_T = Wd; }
+            const HostTensor* Wp = &W;
+            r.make_w = [Wp]() { return chain_weight_conv(*Wp); };
+            step_chainable(run, std::move(r), flops, bytes);
+            return;
+        }
+        step(run, flops, bytes);
     }
 
     // fused depthwise-separable block (rewrite pass 7)
@@ -1728,7 +2042,7 @@ struct Planner {
                     run_resize(*peek_pending(n.in[i]), yl, off, (int)total);
                     pending_resize.erase(n.in[i]);
                 } else {
-                    step([=](const RunCtx& c) { k::copy2d(c.s, c.at(il), c.mut(yl) + off, outer, (int)w, (int)w, (int)total); }, 0, 8.0 * outer * w);
+                    concat_copy_step(il, yl, off, outer, w, total, n.out[0]);
                 }
                 coff += w;
             }
@@ -1746,8 +2060,20 @@ struct Planner {
             int64_t w = xs[i].dims[axis] * inner;
             Loc il = ins[i];
             int64_t off = coff;
-            step([=](const RunCtx& c) { k::copy2d(c.s, c.at(il), c.mut(yl) + off, outer, (int)w, (int)w, (int)total); }, 0, 8.0 * outer * w);
+            concat_copy_step(il, yl, off, outer, w, total, n.out[0]);
             coff += w;
+        }
+    }
+    // one input of a Concat: `outer` rows of w floats into columns [off, off + w) of rows of `total` floats
+    void concat_copy_step(Loc il, Loc yl, int64_t off, int64_t outer, int64_t w, int64_t total, const std::string& out_name) {
+        auto run = [=](const RunCtx& c) { k::copy2d(c.s, c.at(il), c.mut(yl) + off, outer, (int)w, (int)w, (int)total); };
+        if ((w & 3) == 0 && (total & 3) == 0 && (off & 3) == 0 && chain_loc_ok(il) && yl.kind == Loc::ARENA) {
+            ChainRec r;
+            r.d.type = k::CH_COPY; r.d.N = (int)w; r.d.in_ld = (int)w; r.d.out_ld = (int)total;
+            r.in = il; r.out = yl; r.out.off += off * 4; r.rows = outer; r.out_root = out_name;
+            step_chainable(run, std::move(r), 0, 8.0 * outer * w);
+        } else {
+            step(run, 0, 8.0 * outer * w);
         }
     }
 
@@ -2011,7 +2337,20 @@ struct Planner {
             p.ctc_valid = P.logits_valid;
             p.N = 1; p.H = 1; p.W = (int)M; p.Cin = (int)K; p.Ho = 1; p.Wo = (int)M; p.Cout = (int)N;
             p.kh = p.kw = p.sh = p.sw = p.dh = p.dw = 1; p.groups = 1; p.act = act; p.w = w; p.bias = bias; p.y_ld = (int)N;
-            step([=](const RunCtx& c) { k::ConvP q = p; q.x = c.at(ain); q.y = c.mut(yl); q.residual = has_res ? c.at(res) : nullptr; q.ctc_part = has_part ? c.mut(part) : nullptr; k::conv_igemm(c.s, q); }, flops, bytes);
+            auto run = [=](const RunCtx& c) { k::ConvP q = p; q.x = c.at(ain); q.y = c.mut(yl); q.residual = has_res ? c.at(res) : nullptr; q.ctc_part = has_part ? c.mut(part) : nullptr; k::conv_igemm(c.s, q); };
+            if (!has_part && P.logits_valid == 0 && K % 16 == 0 && N % 16 == 0 && chain_loc_ok(ain) && (!has_res || chain_loc_ok(res))) {
+                ChainRec r;   // rows x K times K x N: any partition of the rows into samples will do
+                r.d.type = k::CH_GEMM; r.d.K = (int)K; r.d.N = (int)N; r.d.cin = (int)K; r.d.pad = 0;
+                r.d.in_ld = (int)K; r.d.out_ld = (int)N; r.d.res_ld = (int)N;
+                r.d.act = act.kind; r.d.alpha = act.alpha; r.d.beta = act.beta; r.dev_bias = bias;
+                r.in = ain; r.out = yl; if (has_res) r.res = res;
+                r.rows = M; r.out_root = n.out[0];
+                const HostTensor* Bp = bt.ht;
+                r.make_w = [Bp, transB]() { return chain_weight_linear(*Bp, transB); };
+                step_chainable(run, std::move(r), flops, bytes);
+            } else {
+                step(run, flops, bytes);
+            }
         } else {
             const float* w = bt.loc.cptr;
             k::GemmP g{};
@@ -2070,8 +2409,17 @@ struct Planner {
         TInfo& y = new_out(n.out[0], {N, T, h * d}, Layout::NATIVE);
         Loc yl = y.loc;
         const float scale = n.af("scale", 1.0f);
-        step([=](const RunCtx& c) { k::attention(c.s, c.at(xin), c.mut(yl), (int)N, (int)T, (int)h, (int)d, scale); },
-             4.0 * N * h * T * T * d, 4.0 * N * T * 4 * h * d);
+        auto run = [=](const RunCtx& c) { k::attention(c.s, c.at(xin), c.mut(yl), (int)N, (int)T, (int)h, (int)d, scale); };
+        const double flops = 4.0 * N * h * T * T * d, bytes = 4.0 * N * T * 4 * h * d;
+        if (d <= k::kChainMaxHd && d % 4 == 0 && chain_loc_ok(xin)) {
+            ChainRec r;
+            r.d.type = k::CH_ATTN; r.d.heads = (int)h; r.d.hd = (int)d; r.d.scale = scale; r.d.N = (int)(h * d);
+            r.d.in_ld = (int)(3 * h * d); r.d.out_ld = (int)(h * d);
+            r.in = xin; r.out = yl; r.rows = N * T; r.fix_n = N; r.fix_T = T; r.out_root = n.out[0];
+            step_chainable(run, std::move(r), flops, bytes);
+        } else {
+            step(run, flops, bytes);
+        }
     }
     bool E_opset13() const { return opset >= 13 || opset == 0; }
     int64_t opset = 17;
@@ -2089,7 +2437,15 @@ struct Planner {
         float eps = n.af("epsilon", 1e-5f);
         TInfo& y = new_out(n.out[0], x.dims, Layout::NATIVE);
         Loc yl = y.loc;
-        step([=](const RunCtx& c) { k::layernorm(c.s, c.at(xin), g, b, c.mut(yl), rows, (int)C, eps); }, 8.0 * rows * C, 8.0 * rows * C);
+        auto run = [=](const RunCtx& c) { k::layernorm(c.s, c.at(xin), g, b, c.mut(yl), rows, (int)C, eps); };
+        if (chain_loc_ok(xin) && C > 0) {
+            ChainRec r;
+            r.d.type = k::CH_LN; r.d.N = (int)C; r.d.in_ld = (int)C; r.d.out_ld = (int)C; r.d.eps = eps; r.dev_gamma = g; r.dev_bias = b;
+            r.in = xin; r.out = yl; r.rows = rows; r.out_root = n.out[0];
+            step_chainable(run, std::move(r), 8.0 * rows * C, 8.0 * rows * C);
+        } else {
+            step(run, 8.0 * rows * C, 8.0 * rows * C);
+        }
     }
 
     void op_host_arith(const GNode& n, int op) {
@@ -2193,7 +2549,7 @@ struct Planner {
                 }
             }
             dispatch(n);
-            release_dead(i);
+            if (!chain_run_open()) release_dead(i);   // an open run of chainable operators keeps its tensors (see ChainRec)
         }
         for (size_t oi = 0; oi < E.output_names_.size(); ++oi) {
             const std::string& on = E.output_names_[oi];
@@ -2224,6 +2580,7 @@ struct Planner {
             P.outputs.push_back(po);
         }
         P.arena_bytes = std::max<size_t>(P.arena_bytes, 256);
+        fuse_chains();
     }
 
     void dispatch(const GNode& n) {

@@ -132,6 +132,37 @@ void where(hipStream_t s, const float* cond, const float* a, const float* b, flo
 void grid_sample(hipStream_t s, const float* x, const float* grid, float* y, int N, int H, int W, int C, int Ho, int Wo, int mode, int padding, int align_corners);
 // softmax(scale * q k^T) v per (image, head); qkv [n][T][3][heads][hd] row-major, out [n][T][heads][hd]; hd <= 64
 void attention(hipStream_t s, const float* qkv, float* out, int n, int T, int heads, int hd, float scale);
+// A run of sample-local operators as one launch (chain.hip): one workgroup per sample walks the table.  Every tensor is a row-major
+// [n_samples * T rows][ld floats] view; sample s owns rows [s * T, (s + 1) * T).
+enum ChainType : int { CH_GEMM = 0, CH_LN = 1, CH_ATTN = 2, CH_COPY = 3 };
+struct ChainRef { unsigned long long v = 0; int kind = -1; };   // kind: -1 none, 0 absolute device pointer, 1 arena-relative byte offset, 2 primary-input-relative
+struct ChainOpD {
+    int type = 0;
+    int K = 0, N = 0;            // GEMM: reduction length (taps * cin) / output channels; LN, COPY: N = row length
+    int cin = 0, pad = 0;        // GEMM over a 1 x k convolution: k = K / cin taps, input row t + tap - pad (zero outside the sample)
+    int ksplit = 1;              // GEMM: K slices reduced through LDS
+    int mb = 1;                  // GEMM: token tiles (of 16 rows) one work item covers, 1..3 (4 would spill)
+    int in_ld = 0, out_ld = 0, res_ld = 0;
+    int act = 0; float alpha = 0.f, beta = 0.f;
+    float eps = 0.f, scale = 0.f;   // LN epsilon / attention scale
+    int heads = 0, hd = 0;
+    ChainRef in, out, res;
+    const float* w = nullptr;    // GEMM: [N][K] f32, K index = tap * cin + c (inside the chain's constant blob)
+    int bias_l = -1;             // GEMM bias [N] / LN beta: float offset in LDS (the kernel copies the small constants there), -1 = none
+    int w_l = -1;                // LN gamma: float offset in LDS, -1 = none
+};
+static_assert(sizeof(ChainOpD) % 4 == 0, "ChainOpD is copied to LDS word by word");
+struct ChainLaunch {
+    const ChainOpD* ops = nullptr; int n_ops = 0, n_samples = 0, T = 0, max_hd = 0;
+    size_t lds = 0;              // dynamic LDS: split-K scratch | resident tensors | small constants | operator table
+    const float* consts = nullptr; int small = 0, total_consts = 0, small_l = 0;   // constant blob (floats): [0, small) -> LDS at float offset small_l
+    int tab_l = 0;               // float offset in LDS of the operator table copy
+    double bytes = 0, flops = 0;
+};
+constexpr size_t kChainLdsBudget = 159 * 1024;   // LDS a chain may plan with (the launch adds 640 bytes of debug stamps)
+constexpr int kChainMaxHd = 16;   // attention head size the chain kernel is instantiated for (a 32-wide variant spills: wider heads stay unfused)
+size_t chain_lds_bytes(const ChainOpD& op, int T);
+void chain_run(hipStream_t s, const ChainLaunch& L, char* arena, const char* input);
 // softmax over the last dim fused with CTC argmax (last max index wins) -- see kernels.hip
 // CTC head without logits: conv_igemm with ConvP::ctc_part set writes {max, sum exp, last arg max} per (row, cout tile
 // of 128 columns); ctc_combine merges the tiles of each row into the arg max index and its softmax probability.
