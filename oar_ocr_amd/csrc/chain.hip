@@ -79,308 +79,325 @@ __device__ __forceinline__ float ch_row16_sum(float v) {
 __device__ __forceinline__ float ch_quad_sum(float v) { v += ch_dpp<0xB1>(v); v += ch_dpp<0x4E>(v); return v; }
 __device__ __forceinline__ float ch_quad_max(float v) { v = fmaxf(v, ch_dpp<0xB1>(v)); v = fmaxf(v, ch_dpp<0x4E>(v)); return v; }
 
+// the activations a chained product may carry (the planner leaves operators with any other one unfused): apply_act's formulas, the
+// switch outside the four elements -- every extra case is inlined into each epilogue of a kernel that has to stay cache-sized
+__device__ __forceinline__ f32x4 ch_act4(f32x4 v, int kind, float alpha, float beta) {
+    switch (kind) {
+        case ACT_RELU:
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+            break;
+        case ACT_HSWISH:
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = v[i] * fminf(fmaxf(v[i] * (1.0f / 6.0f) + 0.5f, 0.f), 1.f);
+            break;
+        case ACT_HSIGMOID:
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fminf(fmaxf(v[i] * alpha + beta, 0.f), 1.f);
+            break;
+        case ACT_SIGMOID:
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = 1.0f / (1.0f + expf(-v[i]));
+            break;
+        case ACT_SWISH:
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = v[i] * (1.0f / (1.0f + expf(-v[i])));
+            break;
+        default: break;
+    }
+    return v;
+}
+
 // out[t][n] = act(bias[n] + sum_{tap, c} in[t + tap - pad][c] * w[n][tap * cin + c]) (+ res[t][n]),  t in [0, T)
+struct ChEpi { const ChainOpD& op; const ChView& out; const ChView& res; bool has_res; int T; unsigned lbase; int r, q, MT; };
+__device__ __forceinline__ void ch_epilogue(const ChEpi& e, f32x4 acc, int nt, int mtile) {
+    const int t = mtile * 16 + e.r, n0 = nt * 16 + 4 * e.q;
+    if (mtile >= e.MT || t >= e.T) return;
+    if (e.op.bias_l >= 0) { const f32x4 b = CH_LDS(ch_lf4, e.lbase + 4u * (unsigned)(e.op.bias_l + n0)); acc += b; }
+    acc = ch_act4(acc, e.op.act, e.op.alpha, e.op.beta);
+    if (e.has_res) { const float4 v = ch_ld4(e.res, t * e.res.ld + n0); acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w; }
+    ch_st4(e.out, t * e.out.ld + n0, make_float4(acc[0], acc[1], acc[2], acc[3]));
+}
+
 // General path (tokens in HBM: only when the planner could not stage them in LDS): one work item = one 16 x 16 output tile over one
-// K slice; K walks in groups of four 16-wide steps, the next group's operands in flight while the current group's 16 MFMAs issue.
-__device__ __forceinline__ void ch_gemm_slow(const ChainOpD& op, const ChView& in, const ChView& out, const ChView& res, bool has_res, int T, unsigned lbase, int wave, int lane, unsigned ph) {
+// K slice, one 16-wide K step at a time.  Compact on purpose -- it is the fallback, and the kernel's code has to stay cache-sized.
+__device__ __forceinline__ void ch_gemm_slow(const ChainOpD& op, const ChView& in, const ChView& out, const ChView& res, bool has_res, int T, unsigned lbase, int wave, int lane) {
     const int MT = (T + 15) >> 4, NT = op.N >> 4, KB = op.K >> 4, KS = op.ksplit;
     const int kper = (KB + KS - 1) / KS, tiles = NT * MT, items = tiles * KS;
     const int r = lane & 15, q = lane >> 4;
-    auto epilogue = [&](f32x4 acc, int tile) __attribute__((always_inline)) {
-        const int nt = tile / MT, mt = tile - nt * MT;
-        const int t = mt * 16 + r, n0 = nt * 16 + 4 * q;
-        if (t >= T) return;
-        if (op.bias_l >= 0) { const float4 b = ch_f4(CH_LDS(ch_lf4, lbase + 4u * (unsigned)(op.bias_l + n0))); acc[0] += b.x; acc[1] += b.y; acc[2] += b.z; acc[3] += b.w; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = apply_act(acc[i], op.act, op.alpha, op.beta);
-        if (has_res) { const float4 v = ch_ld4(res, t * res.ld + n0); acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w; }
-        ch_st4(out, t * out.ld + n0, make_float4(acc[0], acc[1], acc[2], acc[3]));
-    };
-    if (ph && threadIdx.x == 0) CH_LDS(__attribute__((address_space(3))) unsigned long long, ph) = clock64();
+    const ChEpi epi{op, out, res, has_res, T, lbase, r, q, MT};
     for (int it = wave; it < items; it += kWaves) {
-        const int tile = it / KS, ks = it - tile * KS;
-        const int nt = tile / MT, mt = tile - nt * MT;
+        const int tile = it / KS, ks = it - tile * KS, nt = tile / MT, mt = tile - nt * MT;
         const int t = mt * 16 + r;
-        ch_gf* wrow = (ch_gf*)(unsigned long long)reinterpret_cast<unsigned long long>(op.w) + (long)(nt * 16 + r) * op.K + 4 * q;
+        ch_gf* wrow = (ch_gf*)reinterpret_cast<unsigned long long>(op.w) + (long)(nt * 16 + r) * op.K + 4 * q;
         const int kb0 = ks * kper, kb1 = min(KB, kb0 + kper);
-        int kb = kb0;                                        // the next step to LOAD
-        int tap = (kb * 16) / op.cin, c0 = kb * 16 - tap * op.cin;
-        float4 a[4], b[4], an[4], bn[4];
-        auto load_group = [&](float4 (&A)[4], float4 (&B)[4]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                A[u] = make_float4(0.f, 0.f, 0.f, 0.f); B[u] = A[u];
-                if (kb < kb1) {
-                    A[u] = ch_f4(*reinterpret_cast<ch_gf4*>(wrow + kb * 16));
-                    const int row = t + tap - op.pad;
-                    if (row >= 0 && row < T) B[u] = ch_ld4(in, row * in.ld + c0 + 4 * q);
-                    ++kb; c0 += 16;
-                    if (c0 == op.cin) { c0 = 0; ++tap; }
-                }
-            }
-        };
+        int tap = (kb0 * 16) / op.cin, c0 = kb0 * 16 - tap * op.cin;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        load_group(a, b);
-        if (ph && threadIdx.x == 0 && it == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); CH_LDS(__attribute__((address_space(3))) unsigned long long, ph + 8) = clock64(); }
-        for (int g = kb0; g < kb1; g += 4) {
-            const bool more = g + 4 < kb1;
-            if (more) load_group(an, bn);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u].w, acc, 0, 0, 0);
-            }
-            if (more) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { a[u] = an[u]; b[u] = bn[u]; }
-            }
+#pragma nounroll
+        for (int kb = kb0; kb < kb1; ++kb) {
+            const float4 a = ch_f4(*reinterpret_cast<ch_gf4*>(wrow + kb * 16));
+            const int row = t + tap - op.pad;
+            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row >= 0 && row < T) b = ch_ld4(in, row * in.ld + c0 + 4 * q);
+            c0 += 16;
+            if (c0 == op.cin) { c0 = 0; ++tap; }
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
         }
-        if (ph && threadIdx.x == 0 && it == 0) { asm volatile("s_nop 0" : "+v"(acc)); CH_LDS(__attribute__((address_space(3))) unsigned long long, ph + 16) = clock64(); }
-        if (KS == 1) epilogue(acc, tile);
+        if (KS == 1) ch_epilogue(epi, acc, nt, mt);
         else CH_LDS(ch_lf4, lbase + 16u * (unsigned)(it * 64 + lane)) = acc;
     }
     if (KS > 1) {
         __syncthreads();
         for (int tile = wave; tile < tiles; tile += kWaves) {
             f32x4 acc = CH_LDS(ch_lf4, lbase + 16u * (unsigned)(tile * KS * 64 + lane));
-            for (int ks = 1; ks < KS; ++ks) { const f32x4 v = CH_LDS(ch_lf4, lbase + 16u * (unsigned)((tile * KS + ks) * 64 + lane)); acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3]; }
-            epilogue(acc, tile);
+            for (int ks = 1; ks < KS; ++ks) acc += CH_LDS(ch_lf4, lbase + 16u * (unsigned)((tile * KS + ks) * 64 + lane));
+            ch_epilogue(epi, acc, tile / MT, tile % MT);
         }
     }
-    if (ph && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); CH_LDS(__attribute__((address_space(3))) unsigned long long, ph + 24) = clock64(); }
 }
 
-// weights of a work item's first K group (4 steps x float4 per lane), zero beyond the item's K slice: issued one operator ahead
-__device__ __forceinline__ void ch_load_a(const ChainOpD& op, int T, int it, int lane, float4 (&A)[4]) {
-    const int MT = (T + 15) >> 4, MB = op.mb, MG = (MT + MB - 1) / MB, KB = op.K >> 4, KS = op.ksplit, kper = (KB + KS - 1) / KS;
-    const int ks = it % KS, nt = (it / KS) / MG;
-    const int kb0 = ks * kper, kb1 = min(KB, kb0 + kper);
-    ch_gf* wrow = (ch_gf*)reinterpret_cast<unsigned long long>(op.w) + (long)(nt * 16 + (lane & 15)) * op.K + 4 * (lane >> 4);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        A[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kb0 + u < kb1) A[u] = ch_f4(*reinterpret_cast<ch_gf4*>(wrow + (kb0 + u) * 16));
-    }
-}
-
-// Fast path: tokens in LDS.  One work item = 16 output channels x MB token tiles (the weights of a K step are loaded once for all of
-// them) over one K slice; items = channel tiles x token groups x K slices, chosen by the planner to occupy the 16 waves.  The first
-// weight group of a wave's first item arrives in `pa` (loaded while the previous operator ran).
-template <int MB>
-__device__ __forceinline__ void ch_gemm_lds(const ChainOpD& op, const ChView& in, const ChView& out, const ChView& res, bool has_res, int T, unsigned lbase, int wave, int lane,
-                                            const float4 (&pa)[4], bool have_pa) {
-    const int MT = (T + 15) >> 4, MG = (MT + MB - 1) / MB, NT = op.N >> 4, KB = op.K >> 4, KS = op.ksplit;
+// Fast path: tokens in LDS.  One work item = 16 output channels x mb (<= 3) token tiles (the weights of a K step are loaded once for
+// all of them) over one K slice; items = channel tiles x token groups x K slices, chosen by the planner to occupy the 16 waves in one
+// round.  (Requesting the next operator's first weights one operator ahead was tried: the 32 registers it holds across the
+// operator push this 1024-thread kernel over its 128 and the spills cost more than the L2 round trip they hide.)
+template <int MBX>
+__device__ __forceinline__ void ch_gemm_lds(const ChainOpD& op, const ChView& in, const ChView& out, const ChView& res, bool has_res, int T, unsigned lbase, int wave, int lane) {
+    const int MB = op.mb, MT = (T + 15) >> 4, MG = (MT + MB - 1) / MB, NT = op.N >> 4, KB = op.K >> 4, KS = op.ksplit;
     const int kper = (KB + KS - 1) / KS, items = NT * MG * KS;
     const int r = lane & 15, q = lane >> 4;
-    auto epilogue = [&](f32x4 acc, int nt, int mtile) __attribute__((always_inline)) {
-        const int t = mtile * 16 + r, n0 = nt * 16 + 4 * q;
-        if (mtile >= MT || t >= T) return;
-        if (op.bias_l >= 0) { const float4 b = ch_f4(CH_LDS(ch_lf4, lbase + 4u * (unsigned)(op.bias_l + n0))); acc[0] += b.x; acc[1] += b.y; acc[2] += b.z; acc[3] += b.w; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = apply_act(acc[i], op.act, op.alpha, op.beta);
-        if (has_res) { const float4 v = ch_ld4(res, t * res.ld + n0); acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w; }
-        ch_st4(out, t * out.ld + n0, make_float4(acc[0], acc[1], acc[2], acc[3]));
-    };
+    const ChEpi epi{op, out, res, has_res, T, lbase, r, q, MT};
+    const bool lin = op.cin == op.K && op.pad == 0;   // a plain product: row t of every K step (rows past T clamp to the last one: computed, never stored)
     for (int it = wave; it < items; it += kWaves) {
         const int ks = it % KS, rest = it / KS, mg = rest % MG, nt = rest / MG;
         const int kb0 = ks * kper, kb1 = min(KB, kb0 + kper);
         ch_gf* wrow = (ch_gf*)reinterpret_cast<unsigned long long>(op.w) + (long)(nt * 16 + r) * op.K + 4 * q;
         int tap = (kb0 * 16) / op.cin, c0 = kb0 * 16 - tap * op.cin;
-        float4 a[4], an[4];
-        if (it == wave && have_pa) {
+        f32x4 a[4], an[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] = pa[u];
-        } else {
+        for (int u = 0; u < 4; ++u) { a[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; if (kb0 + u < kb1) a[u] = *reinterpret_cast<ch_gf4*>(wrow + (kb0 + u) * 16); }
+        int trow[MBX];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { a[u] = make_float4(0.f, 0.f, 0.f, 0.f); if (kb0 + u < kb1) a[u] = ch_f4(*reinterpret_cast<ch_gf4*>(wrow + (kb0 + u) * 16)); }
-        }
-        f32x4 acc[MB];
+        for (int m = 0; m < MBX; ++m) { trow[m] = (mg * MB + m) * 16 + r; if (lin) trow[m] = min(trow[m], T - 1); }
+        f32x4 acc[MBX];
 #pragma unroll
-        for (int m = 0; m < MB; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < MBX; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const unsigned inb = in.l + 16u * (unsigned)q;
+#pragma nounroll
         for (int g = kb0; g < kb1; g += 4) {
-            if (g + 4 < kb1) {
+            const bool more = g + 4 < kb1;
+            if (more) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { an[u] = make_float4(0.f, 0.f, 0.f, 0.f); if (g + 4 + u < kb1) an[u] = ch_f4(*reinterpret_cast<ch_gf4*>(wrow + (g + 4 + u) * 16)); }
+                for (int u = 0; u < 4; ++u) { an[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; if (g + 4 + u < kb1) an[u] = *reinterpret_cast<ch_gf4*>(wrow + (g + 4 + u) * 16); }
             }
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                if (g + 2 * half >= kb1) break;
-                f32x4 b[2][MB];
+            for (int u = 0; u < 4; ++u) {
+                if (g + u < kb1) {
+                    f32x4 b[MBX];
+                    const int dt = tap - op.pad;
 #pragma unroll
-                for (int uu = 0; uu < 2; ++uu) {
-                    const bool on = g + 2 * half + uu < kb1;
-#pragma unroll
-                    for (int m = 0; m < MB; ++m) {
-                        const int row = (mg * MB + m) * 16 + r + tap - op.pad;
-                        b[uu][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        if (on && row >= 0 && row < T) b[uu][m] = CH_LDS(ch_lf4, inb + 4u * (unsigned)(row * in.ld + c0));
+                    for (int m = 0; m < MBX; ++m) {
+                        const int row = trow[m] + dt;
+                        b[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (m < MB && (unsigned)row < (unsigned)T) b[m] = CH_LDS(ch_lf4, inb + 4u * (unsigned)(row * in.ld + c0));
                     }
-                    if (on) { c0 += 16; if (c0 == op.cin) { c0 = 0; ++tap; } }
-                }
+                    c0 += 16;
+                    if (c0 == op.cin) { c0 = 0; ++tap; }
 #pragma unroll
-                for (int uu = 0; uu < 2; ++uu) {
-                    const float4 av = a[2 * half + uu];
-#pragma unroll
-                    for (int m = 0; m < MB; ++m) {
-                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b[uu][m][0], acc[m], 0, 0, 0);
-                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b[uu][m][1], acc[m], 0, 0, 0);
-                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b[uu][m][2], acc[m], 0, 0, 0);
-                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b[uu][m][3], acc[m], 0, 0, 0);
-                    }
+                    for (int m = 0; m < MBX; ++m)
+                        if (m < MB) {
+                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][0], b[m][0], acc[m], 0, 0, 0);
+                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][1], b[m][1], acc[m], 0, 0, 0);
+                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][2], b[m][2], acc[m], 0, 0, 0);
+                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][3], b[m][3], acc[m], 0, 0, 0);
+                        }
                 }
+                __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler hoists all 12 token loads of the group: 48 registers, spills)
             }
-            if (g + 4 < kb1) {
+            if (more) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) a[u] = an[u];
             }
         }
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            if (KS == 1) epilogue(acc[m], nt, mg * MB + m);
-            else CH_LDS(ch_lf4, lbase + 16u * (unsigned)(((((nt * MG + mg) * MB + m) * KS) + ks) * 64 + lane)) = acc[m];
-        }
+        for (int m = 0; m < MBX; ++m)
+            if (m < MB) {
+                if (KS == 1) ch_epilogue(epi, acc[m], nt, mg * MB + m);
+                else CH_LDS(ch_lf4, lbase + 16u * (unsigned)(((((nt * MG + mg) * MB + m) * KS) + ks) * 64 + lane)) = acc[m];
+                __builtin_amdgcn_sched_barrier(0);   // one tile's epilogue at a time (interleaved, their exp sequences spill)
+            }
     }
     if (KS > 1) {
         __syncthreads();
         const int tiles = NT * MG * MB;
         for (int tile = wave; tile < tiles; tile += kWaves) {
             f32x4 acc = CH_LDS(ch_lf4, lbase + 16u * (unsigned)(tile * KS * 64 + lane));
-            for (int ks = 1; ks < KS; ++ks) { const f32x4 v = CH_LDS(ch_lf4, lbase + 16u * (unsigned)((tile * KS + ks) * 64 + lane)); acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3]; }
+            for (int ks = 1; ks < KS; ++ks) acc += CH_LDS(ch_lf4, lbase + 16u * (unsigned)((tile * KS + ks) * 64 + lane));
             const int m = tile % MB, rest = tile / MB, mg = rest % MG, nt = rest / MG;
-            epilogue(acc, nt, mg * MB + m);
+            ch_epilogue(epi, acc, nt, mg * MB + m);
         }
     }
 }
 
-// LayerNorm over rows of C floats: 16 lanes per row (4 rows per wave at a time), the row in registers (C <= 256: 16 per lane) or
-// re-read (wider rows); mean, then the variance of the centred values, the 16 partial sums combined by DPP rotations
+// LayerNorm over rows of C floats: 16 lanes per row (4 rows per wave at a time), each lane float4s of the row (C <= 256 and a
+// multiple of 4: the row stays in registers) or single floats (any C, re-read per pass); mean, then the variance of the centred
+// values, the 16 partial sums combined by DPP rotations
 __device__ __forceinline__ void ch_layernorm(const ChainOpD& op, const ChView& x, const ChView& y, int T, unsigned lbase, int wave, int lane) {
     const int C = op.N, sub = lane & 15;
     const float rc = 1.0f / (float)C;
     for (int row = wave * 4 + (lane >> 4); row < T + 3; row += kWaves * 4) {   // (+3: the lanes of a wave stay together for the DPP steps)
         const bool live = row < T;
         const int xr = (live ? row : T - 1) * x.ld;
-        if (C <= 256) {
-            float xv[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { xv[j] = 0.f; if (16 * j + sub < C) xv[j] = ch_ld1(x, xr + 16 * j + sub); }
+        if (C <= 256 && (C & 3) == 0) {
+            float4 xv[4];
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) s += xv[j];
+            for (int j = 0; j < 4; ++j) {
+                xv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (64 * j + 4 * sub < C) xv[j] = ch_ld4(x, xr + 64 * j + 4 * sub);
+                s += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
+            }
             const float mean = ch_row16_sum(s) * rc;
             float v = 0.f;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) if (16 * j + sub < C) { const float d = xv[j] - mean; v += d * d; }
+            for (int j = 0; j < 4; ++j)
+                if (64 * j + 4 * sub < C) {
+                    const float d0 = xv[j].x - mean, d1 = xv[j].y - mean, d2 = xv[j].z - mean, d3 = xv[j].w - mean;
+                    v += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
             const float inv = 1.0f / sqrtf(ch_row16_sum(v) * rc + op.eps);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int i = 16 * j + sub;
+            for (int j = 0; j < 4; ++j) {
+                const int i = 64 * j + 4 * sub;
                 if (live && i < C) {
-                    float t = (xv[j] - mean) * inv;
-                    if (op.w_l >= 0) t *= CH_LDS(ch_lf, lbase + 4u * (unsigned)(op.w_l + i));
-                    if (op.bias_l >= 0) t += CH_LDS(ch_lf, lbase + 4u * (unsigned)(op.bias_l + i));
-                    ch_st1(y, row * y.ld + i, t);
+                    f32x4 t = {(xv[j].x - mean) * inv, (xv[j].y - mean) * inv, (xv[j].z - mean) * inv, (xv[j].w - mean) * inv};
+                    if (op.w_l >= 0) t *= CH_LDS(ch_lf4, lbase + 4u * (unsigned)(op.w_l + i));
+                    if (op.bias_l >= 0) t += CH_LDS(ch_lf4, lbase + 4u * (unsigned)(op.bias_l + i));
+                    ch_st4(y, row * y.ld + i, ch_f4(t));
                 }
             }
         } else {
             float s = 0.f;
+#pragma nounroll
             for (int i = sub; i < C; i += 16) s += ch_ld1(x, xr + i);
             const float mean = ch_row16_sum(s) * rc;
             float v = 0.f;
+#pragma nounroll
             for (int i = sub; i < C; i += 16) { const float d = ch_ld1(x, xr + i) - mean; v += d * d; }
             const float inv = 1.0f / sqrtf(ch_row16_sum(v) * rc + op.eps);
-            if (live)
+            if (live) {
+#pragma nounroll
                 for (int i = sub; i < C; i += 16) {
                     float t = (ch_ld1(x, xr + i) - mean) * inv;
                     if (op.w_l >= 0) t *= CH_LDS(ch_lf, lbase + 4u * (unsigned)(op.w_l + i));
                     if (op.bias_l >= 0) t += CH_LDS(ch_lf, lbase + 4u * (unsigned)(op.bias_l + i));
                     ch_st1(y, row * y.ld + i, t);
                 }
+            }
         }
     }
 }
 
-// softmax(scale * q k^T) v per head: a quad of lanes owns one (head, query row), each lane every fourth key; two passes over its
-// keys (maximum, then exp / sum / weighted V, the scores recomputed), the quad's partial maxima / sums / outputs combined by DPP,
-// lane s of the quad storing output channels [4 s, 4 s + 4) -- K and V are read where the QKV projection left them.
-template <int HD>
-__device__ __forceinline__ void ch_attention(const ChainOpD& op, const ChView& qkv, const ChView& out, int T) {
-    constexpr int H4 = HD / 4;
-    const int heads = op.heads, hd = op.hd, dim = heads * hd, h4 = hd >> 2;
-    const int total = heads * T * 4;
-    for (int i0 = 0; i0 < total; i0 += kChainThreads) {
-        const int i = i0 + (int)threadIdx.x;
-        const bool live = i < total;
-        const int ic = live ? i : total - 1;
-        const int sl = ic & 3, ht = ic >> 2, h = ht / T, t = ht - h * T;
-        const int qb = t * qkv.ld + h * hd;
-        float qv[HD];
+// softmax(scale * q k^T) v on the matrix pipe (T <= 64): one wave per (head, tile of 16 query rows).  Scores transposed, S^T = K (Q
+// scale)^T: keys are the A rows, queries the B columns, so a lane ends up with the scores of keys {16 jt + 4 q + i} for ITS query
+// r -- the softmax over keys is 4 JT registers plus two cross-row exchanges, and the probabilities are already laid out as the B
+// operand of O^T = V^T P (K index = the lane group's key), whose result is 4 consecutive output channels of one query: one float4.
+__device__ __forceinline__ void ch_attention_mfma(const ChainOpD& op, const ChView& qkv, const ChView& out, int T, int wave, int lane) {
+    constexpr int JX = 4;
+    const int heads = op.heads, hd = op.hd, dim = heads * hd, MT = (T + 15) >> 4;
+    const int r = lane & 15, q = lane >> 4;
+    const bool dq = 4 * q < hd;
+    for (int u = wave; u < heads * MT; u += kWaves) {
+        const int h = u / MT, tt = u - h * MT;
+        const int tq = min(tt * 16 + r, T - 1);
+        float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dq) qv = ch_ld4(qkv, tq * qkv.ld + h * hd + 4 * q);
+        qv.x *= op.scale; qv.y *= op.scale; qv.z *= op.scale; qv.w *= op.scale;
+        f32x4 sc[JX];
+        float m = -3.402823466e38f;
 #pragma unroll
-        for (int d4 = 0; d4 < H4; ++d4) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (d4 < h4) v = ch_ld4(qkv, qb + 4 * d4);
-            qv[4 * d4] = v.x * op.scale; qv[4 * d4 + 1] = v.y * op.scale; qv[4 * d4 + 2] = v.z * op.scale; qv[4 * d4 + 3] = v.w * op.scale;
-        }
-        auto score = [&](int j) __attribute__((always_inline)) {   // four independent partial sums (one per float4 of the head), then their sum
-            float a[H4];
-            const int kb = j * qkv.ld + dim + h * hd;
+        for (int jt = 0; jt < JX; ++jt) {
+            sc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (jt < MT) {
+                float4 kv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (dq) kv = ch_ld4(qkv, min(jt * 16 + r, T - 1) * qkv.ld + dim + h * hd + 4 * q);
+                sc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.x, qv.x, sc[jt], 0, 0, 0);
+                sc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.y, qv.y, sc[jt], 0, 0, 0);
+                sc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.z, qv.z, sc[jt], 0, 0, 0);
+                sc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.w, qv.w, sc[jt], 0, 0, 0);
 #pragma unroll
-            for (int d4 = 0; d4 < H4; ++d4) {
-                a[d4] = 0.f;
-                if (d4 < h4) {
-                    const float4 kk = ch_ld4(qkv, kb + 4 * d4);
-                    a[d4] = fmaf(qv[4 * d4 + 3], kk.w, fmaf(qv[4 * d4 + 2], kk.z, fmaf(qv[4 * d4 + 1], kk.y, qv[4 * d4] * kk.x)));
+                for (int i = 0; i < 4; ++i) {
+                    if (jt * 16 + 4 * q + i >= T) sc[jt][i] = -3.402823466e38f;
+                    m = fmaxf(m, sc[jt][i]);
                 }
             }
-            float sum = a[0];
-#pragma unroll
-            for (int d4 = 1; d4 < H4; ++d4) sum += a[d4];
-            return sum;
-        };
-        constexpr int kKeep = 16;               // scores of a lane's keys stay in registers when T <= 64
-        const bool keep = T <= 4 * kKeep;
-        float sc[kKeep];
-        float m = -3.402823466e38f;
-        if (keep) {
-#pragma unroll
-            for (int jj = 0; jj < kKeep; ++jj) { sc[jj] = -3.402823466e38f; if (sl + 4 * jj < T) { sc[jj] = score(sl + 4 * jj); m = fmaxf(m, sc[jj]); } }
-        } else {
-            for (int j = sl; j < T; j += 4) m = fmaxf(m, score(j));
         }
-        m = ch_quad_max(m);
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
         float l = 0.f;
-        float o[HD];
 #pragma unroll
-        for (int d = 0; d < HD; ++d) o[d] = 0.f;
-        auto weigh = [&](int j, float sj) __attribute__((always_inline)) {
-            const float p = expf(sj - m);
-            l += p;
-            const int vb = j * qkv.ld + 2 * dim + h * hd;
+        for (int jt = 0; jt < JX; ++jt)
+            if (jt < MT) {
 #pragma unroll
-            for (int d4 = 0; d4 < H4; ++d4)
-                if (d4 < h4) {
-                    const float4 vv = ch_ld4(qkv, vb + 4 * d4);
-                    o[4 * d4] = fmaf(p, vv.x, o[4 * d4]); o[4 * d4 + 1] = fmaf(p, vv.y, o[4 * d4 + 1]);
-                    o[4 * d4 + 2] = fmaf(p, vv.z, o[4 * d4 + 2]); o[4 * d4 + 3] = fmaf(p, vv.w, o[4 * d4 + 3]);
+                for (int i = 0; i < 4; ++i) {
+                    const float p = jt * 16 + 4 * q + i < T ? expf(sc[jt][i] - m) : 0.f;
+                    sc[jt][i] = p;
+                    l += p;
                 }
-        };
-        if (keep) {
+            }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int jj = 0; jj < kKeep; ++jj) if (sl + 4 * jj < T) weigh(sl + 4 * jj, sc[jj]);
-        } else {
-            for (int j = sl; j < T; j += 4) weigh(j, score(j));
+        for (int jt = 0; jt < JX; ++jt)
+            if (jt < MT) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int j = jt * 16 + 4 * q + i;
+                    float vv = 0.f;
+                    if (j < T && r < hd) vv = ch_ld1(qkv, j * qkv.ld + 2 * dim + h * hd + r);
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, sc[jt][i], o, 0, 0, 0);
+                }
+            }
+        const int t = tt * 16 + r;
+        if (t < T && dq) {
+            const float rl = 1.0f / l;
+            ch_st4(out, t * out.ld + h * hd + 4 * q, make_float4(o[0] * rl, o[1] * rl, o[2] * rl, o[3] * rl));
         }
-        l = ch_quad_sum(l);
+    }
+}
+
+// any T: one thread per (head, query row), two passes over the keys (maximum, then exp / sum / weighted V) -- attention_kernel's
+// statement sequence (kernels.hip), K and V read where the QKV projection left them; compact, not fast
+template <int HD>
+__device__ __forceinline__ void ch_attention_any(const ChainOpD& op, const ChView& qkv, const ChView& out, int T) {
+    const int heads = op.heads, hd = op.hd, dim = heads * hd;
+    for (int i = threadIdx.x; i < heads * T; i += kChainThreads) {
+        const int h = i / T, t = i - h * T;
+        float qv[HD], o[HD];
 #pragma unroll
-        for (int d = 0; d < HD; ++d) o[d] = ch_quad_sum(o[d]);
-        const float rl = 1.0f / l;
+        for (int d = 0; d < HD; ++d) { qv[d] = d < hd ? ch_ld1(qkv, t * qkv.ld + h * hd + d) * op.scale : 0.f; o[d] = 0.f; }
+        auto score = [&](int j) __attribute__((always_inline)) {
+            float a = 0.f;
 #pragma unroll
-        for (int d4 = 0; d4 < H4; ++d4)
-            if (live && d4 == sl && d4 < h4)
-                ch_st4(out, t * out.ld + h * hd + 4 * d4, make_float4(o[4 * d4] * rl, o[4 * d4 + 1] * rl, o[4 * d4 + 2] * rl, o[4 * d4 + 3] * rl));
+            for (int d = 0; d < HD; ++d) if (d < hd) a = fmaf(qv[d], ch_ld1(qkv, j * qkv.ld + dim + h * hd + d), a);
+            return a;
+        };
+        float m = -3.402823466e38f;
+#pragma nounroll
+        for (int j = 0; j < T; ++j) m = fmaxf(m, score(j));
+        float l = 0.f;
+#pragma nounroll
+        for (int j = 0; j < T; ++j) {
+            const float p = expf(score(j) - m);
+            l += p;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) if (d < hd) o[d] = fmaf(p, ch_ld1(qkv, j * qkv.ld + 2 * dim + h * hd + d), o[d]);
+        }
+#pragma unroll
+        for (int d = 0; d < HD; ++d) if (d < hd) ch_st1(out, t * out.ld + h * hd + d, o[d] / l);
     }
 }
 
@@ -426,47 +443,27 @@ __global__ __launch_bounds__(kChainThreads) void chain_kernel(const ChainOpD* __
         __builtin_memcpy(&op, w, sizeof op);
         return op;
     };
-    float4 pa[4];
-    bool have_pa = false;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) pa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    ChainOpD op = read_op(0);
     for (int i = 0; i < n_ops; ++i) {
-        // the next product's first weights start their trip now (they do not depend on this operator's result)
-        ChainOpD nxt = op;
-        float4 pn[4];
-        bool have_pn = false;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) pn[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i + 1 < n_ops) {
-            nxt = read_op(i + 1);
-            if (nxt.type == CH_GEMM && nxt.in.kind == 3) {
-                const int MTn = (T + 15) >> 4, items = (nxt.N >> 4) * ((MTn + nxt.mb - 1) / nxt.mb) * nxt.ksplit;
-                if (wave < items) ch_load_a(nxt, T, wave, lane, pn);
-                have_pn = true;
-            }
-        }
+        const ChainOpD op = read_op(i);
         const ChView in = ch_view(op.in, op.in_ld, row0, arena, input, lbase), out = ch_view(op.out, op.out_ld, row0, arena, input, lbase);
         switch (op.type) {
             case CH_GEMM: {
                 const bool has_res = op.res.kind >= 0;
                 const ChView res = ch_view(op.res, op.res_ld, row0, arena, input, lbase);
-                if (!in.lds) ch_gemm_slow(op, in, out, res, has_res, T, lbase, wave, lane, 0u);
-                else if (op.mb == 1) ch_gemm_lds<1>(op, in, out, res, has_res, T, lbase, wave, lane, pa, have_pa);
-                else if (op.mb == 2) ch_gemm_lds<2>(op, in, out, res, has_res, T, lbase, wave, lane, pa, have_pa);
-                else ch_gemm_lds<3>(op, in, out, res, has_res, T, lbase, wave, lane, pa, have_pa);
+                if (in.lds && op.mb == 1) ch_gemm_lds<1>(op, in, out, res, has_res, T, lbase, wave, lane);
+                else if (in.lds) ch_gemm_lds<3>(op, in, out, res, has_res, T, lbase, wave, lane);
+                else ch_gemm_slow(op, in, out, res, has_res, T, lbase, wave, lane);
                 break;
             }
             case CH_LN: ch_layernorm(op, in, out, T, lbase, wave, lane); break;
-            case CH_ATTN: ch_attention<HD>(op, in, out, T); break;
+            case CH_ATTN:
+                if (T <= 64 && (op.hd & 3) == 0) ch_attention_mfma(op, in, out, T, wave, lane);
+                else ch_attention_any<HD>(op, in, out, T);
+                break;
             default: ch_copy(op, in, out, T); break;
         }
         __syncthreads();   // workgroup-scope release / acquire: the next operator reads what this one stored (LDS, or HBM through this CU's L1)
         if (dbg && threadIdx.x == 0 && i < 70) CH_LDS(__attribute__((address_space(3))) unsigned long long, stamps + 8u * (unsigned)(i + 1)) = wall_clock64();
-        op = nxt;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) pa[u] = pn[u];
-        have_pa = have_pn;
     }
     if (dbg && blockIdx.x == 0 && threadIdx.x == 0)
     {

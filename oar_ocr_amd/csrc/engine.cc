@@ -727,7 +727,8 @@ struct Planner {
     // kind 3) and their row strides to the padded one.  Liveness-based first-fit over the operator order; when the budget is
     // exceeded the largest tensor goes back to the arena and the placement is redone.  Returns the dynamic LDS size of the launch.
     size_t chain_place_in_lds(std::vector<k::ChainOpD>& ops, const std::vector<std::string>& out_roots, int last_node, int64_t n, int64_t T, size_t scratch, size_t budget) {
-        static const bool lds_on = [] { const char* e = getenv("OAR_CHAIN_LDS"); return !e || atoi(e) != 0; }();
+        const char* lds_env = getenv("OAR_CHAIN_LDS");   // read per plan: tests A/B the placements inside one process
+        const bool lds_on = !lds_env || atoi(lds_env) != 0;
         if (!lds_on || scratch >= budget) return scratch;
         struct Use { int op; int which; int64_t off; int ld; int width; };   // which: 0 in, 1 out, 2 res; width: columns the view covers
         std::vector<Use> uses;
@@ -913,8 +914,11 @@ struct Planner {
                     OAR_CHECK(w.size() == (size_t)d.N * (size_t)d.K, OAR_INTERNAL, "chain: weight size");
                     blob.insert(blob.end(), w.begin(), w.end());
                     // work items = channel tiles x token groups (mb tiles each) x K slices: enough of them for the 16 waves, partials <= 24 KB
-                    d.mb = MT <= 3 ? MT : (MT % 3 == 0 ? 3 : (MT % 2 == 0 ? 2 : 3));
-                    const int MG = (MT + d.mb - 1) / d.mb, NT = d.N / 16, KB = d.K / 16;
+                    // narrow products whose 16 x 16 tiles fit one round of the 16 waves take one tile per item (shortest dependent chain);
+                    // the others share each weight load between up to 3 token tiles
+                    const int NT = d.N / 16, KB = d.K / 16;
+                    d.mb = (NT * MT <= 16 && KB <= 8) ? 1 : (MT <= 3 ? MT : (MT % 3 == 0 ? 3 : (MT % 2 == 0 ? 2 : 3)));
+                    const int MG = (MT + d.mb - 1) / d.mb;
                     int ks = 1;
                     while (NT * MG * ks < 16 && KB / (ks * 2) >= 2 && NT * MG * d.mb * ks * 2 <= 24) ks *= 2;
                     d.ksplit = ks;
@@ -1219,7 +1223,7 @@ struct Planner {
             else k::conv_direct(c.s, q);
         };
         // a 1 x k convolution over a one-row map is a product over the rows of each sample: chainable (chain.hip)
-        if (kind == 0 && H == 1 && Ho == 1 && kh == 1 && pt == 0 && pb == 0 && sw == 1 && dw == 1 && Wo == Wd && Cin % 16 == 0 && Cout % 16 == 0 &&
+        if (kind == 0 && H == 1 && Ho == 1 && kh == 1 && pt == 0 && pb == 0 && sw == 1 && dw == 1 && Wo == Wd && Cin % 16 == 0 && Cout % 16 == 0 && k::chain_act_ok(n.act.kind) &&
             chain_loc_ok(xin) && (!has_res || chain_loc_ok(res))) {
             ChainRec r;
             r.d.type = k::CH_GEMM; r.d.K = (int)(kw * Cin); r.d.N = (int)Cout; r.d.cin = (int)Cin; r.d.pad = (int)pl;
@@ -2338,7 +2342,7 @@ struct Planner {
             p.N = 1; p.H = 1; p.W = (int)M; p.Cin = (int)K; p.Ho = 1; p.Wo = (int)M; p.Cout = (int)N;
             p.kh = p.kw = p.sh = p.sw = p.dh = p.dw = 1; p.groups = 1; p.act = act; p.w = w; p.bias = bias; p.y_ld = (int)N;
             auto run = [=](const RunCtx& c) { k::ConvP q = p; q.x = c.at(ain); q.y = c.mut(yl); q.residual = has_res ? c.at(res) : nullptr; q.ctc_part = has_part ? c.mut(part) : nullptr; k::conv_igemm(c.s, q); };
-            if (!has_part && P.logits_valid == 0 && K % 16 == 0 && N % 16 == 0 && chain_loc_ok(ain) && (!has_res || chain_loc_ok(res))) {
+            if (!has_part && P.logits_valid == 0 && K % 16 == 0 && N % 16 == 0 && k::chain_act_ok(act.kind) && chain_loc_ok(ain) && (!has_res || chain_loc_ok(res))) {
                 ChainRec r;   // rows x K times K x N: any partition of the rows into samples will do
                 r.d.type = k::CH_GEMM; r.d.K = (int)K; r.d.N = (int)N; r.d.cin = (int)K; r.d.pad = 0;
                 r.d.in_ld = (int)K; r.d.out_ld = (int)N; r.d.res_ld = (int)N;

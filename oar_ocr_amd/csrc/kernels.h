@@ -161,6 +161,7 @@ struct ChainLaunch {
 };
 constexpr size_t kChainLdsBudget = 159 * 1024;   // LDS a chain may plan with (the launch adds 640 bytes of debug stamps)
 constexpr int kChainMaxHd = 16;   // attention head size the chain kernel is instantiated for (a 32-wide variant spills: wider heads stay unfused)
+inline bool chain_act_ok(int kind) { return kind == ACT_NONE || kind == ACT_RELU || kind == ACT_HSWISH || kind == ACT_HSIGMOID || kind == ACT_SIGMOID || kind == ACT_SWISH; }
 size_t chain_lds_bytes(const ChainOpD& op, int T);
 void chain_run(hipStream_t s, const ChainLaunch& L, char* arena, const char* input);
 // softmax over the last dim fused with CTC argmax (last max index wins) -- see kernels.hip

@@ -619,3 +619,31 @@ def test_stacked_convtranspose_pair_is_one_kernel(case):
     names = {e["name"]: e["launches"] for e in api.prof_snapshot()}
     api.prof_enable(False)
     assert names.get("convt_pair", 0) == (1 if c1 != 12 else 0), names
+
+
+@pytest.mark.parametrize("n,W", [(5, 320), (3, 184), (1, 8), (2, 520), (2, 1100)])
+@pytest.mark.parametrize("mode", ["lds", "arena"])
+def test_sample_local_chain_matches_oracle_and_the_unfused_path(n, W, mode, monkeypatch):
+    """The recognizer's SVTR neck (1 x 3 conv, 1 x 1 convs, LayerNorm, QKV / attention / projection, FFN, concat) runs as ONE launch
+    (csrc/chain.hip: a workgroup per text line walks the operator table; Planner::fuse_chains).  Same numbers as the torch oracle
+    and, to f32 rounding, as the operator-by-operator path (OAR_FUSE_CHAIN=0); argmax identical.  T = W / 8 covers one to three token
+    tiles (matrix-pipe attention), T = 65 (two token groups, attention on the any-T path, tensors that no longer all fit LDS) and
+    T = 137; `arena` keeps every tensor in HBM (OAR_CHAIN_LDS=0: the general product path)."""
+    rec, _ = models.build_rec("tiny", vocab=6906, seed=1)
+    x = np.random.default_rng(n * 1000 + W).standard_normal((n, 3, 48, W)).astype(np.float32)
+    monkeypatch.setenv("OAR_FUSE_CHAIN", "0")
+    plain_eng = api.OrtInfer(rec, profile=True)
+    plain = plain_eng.infer(x)[0][1]
+    monkeypatch.setenv("OAR_FUSE_CHAIN", "1")
+    if mode == "arena":
+        monkeypatch.setenv("OAR_CHAIN_LDS", "0")
+    eng = api.OrtInfer(rec, profile=True)
+    api.prof_enable(True); api.prof_reset()
+    got = eng.infer(x)[0][1]
+    snap = {e["name"]: e["launches"] for e in api.prof_snapshot()}
+    api.prof_enable(False)
+    assert snap.get("chain", 0) == 1 and not snap.get("attention", 0) and not snap.get("layernorm", 0), snap
+    ref = onnx_ref.run(rec, {eng.input_name(): x})[0]
+    assert np.abs(got - ref).max() <= TOL
+    assert np.abs(got - plain).max() <= 5e-5
+    assert np.array_equal(got.argmax(-1), plain.argmax(-1)) and np.array_equal(got.argmax(-1), ref.argmax(-1))

@@ -8,7 +8,8 @@ from oar_ocr_amd.synth import models, pages
 what = sys.argv[1] if len(sys.argv) > 1 else "rec"
 if what == "rec":
     m, _ = models.build_rec("tiny", vocab=6906, seed=1)
-    x = np.random.default_rng(0).standard_normal((256, 3, 48, 320)).astype(np.float32)
+    import os
+    x = np.random.default_rng(0).standard_normal((int(os.environ.get("REC_N", "256")), 3, 48, 320)).astype(np.float32)
 else:
     m, _ = models.build_det("tiny", seed=0)
     x = np.random.default_rng(0).standard_normal((8, 3, 960, 960)).astype(np.float32)
