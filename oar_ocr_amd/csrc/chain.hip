@@ -4,15 +4,15 @@
 // FC1 -> FC2 + residual] -> LN -> 1x1 conv -> concat -> 1x3 conv -> 1x1 conv) touches, per text line, T <= a few dozen tokens of
 // <= 512 channels: every operator is a [T x K] x [K x N] product, a row normalisation, a T x T attention or a row copy that only
 // reads rows of its OWN sample.  As separate launches that is 22 kernels of 5-30 us each whose grids cannot fill 256 CUs; here ONE
-// workgroup (16 waves) owns a sample and walks the operator table, a workgroup barrier between operators, the intermediate
-// tensors in the planner's arena (they are KBs per sample: L2 / L1 hits).  The planner (engine.cc, Planner::fuse_chains) records the
-// operators, keeps every tensor of the run allocated until the run ends (no two of them alias, so samples may run at
-// different paces) and replaces the run by one `chain_run` step.
+// workgroup (16 waves) owns a sample and walks the operator table, a workgroup barrier between operators.  The planner (engine.cc,
+// Planner::fuse_chains) records the operators, keeps every tensor of the run allocated until the run ends (no two of them alias,
+// so samples may run at different paces), places the run's internal tensors in LDS, packs its constants into one blob and
+// replaces the run by one `chain_run` step.  DESIGN.md 4.12 has the per-operator timings and what was tried.
 //
 // Arithmetic: products on v_mfma_f32_16x16x4_f32 (exact f32 multiply-add, weights as the A operand, tokens as B: a lane ends up
 // with 4 consecutive output channels of one token = one float4 store); split-K partials, when a product has too few tiles for 16
-// waves, are reduced through LDS in a fixed order (deterministic).  LayerNorm and attention are the statement sequences of
-// layernorm_kernel / attention_kernel (kernels.hip), so those results are bit-identical to the unfused path given equal inputs.
+// waves, are reduced through LDS in a fixed order (deterministic).  Attention for T <= 64 runs on the matrix pipe too.  Summation
+// orders differ from the operator-by-operator kernels: equal to them to f32 rounding (<= 5e-5 in the tests), not bit for bit.
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 #include <algorithm>
