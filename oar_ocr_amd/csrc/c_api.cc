@@ -1,6 +1,7 @@
 // c_api.cc -- extern "C" boundary (include/oar_mi355x.h). No exception crosses it.
 #include <condition_variable>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -228,8 +229,19 @@ void fetch_outputs(Engine& E, const Plan& p, oar_tensor* outs, int32_t max_out, 
         for (int i = 0; i < max_out; ++i) oar_tensor_free(&outs[i]);
         throw;
     }
+    // integer outputs live on the device as f32: exact up to 2^24, beyond that the value the graph meant is gone -- fail instead of
+    // handing back a rounded neighbour (index-valued outputs, ArgMax and friends, are far below that)
+    bool lossy = false;
     for (auto& q : pend)
-        for (int64_t k = 0; k < q.n; ++k) q.t->data_i64[k] = (int64_t)std::llround((double)q.tmp[(size_t)k]);
+        for (int64_t k = 0; k < q.n; ++k) {
+            const float v = q.tmp[(size_t)k];
+            lossy = lossy || !(std::fabs(v) <= 16777216.0f);
+            q.t->data_i64[k] = (int64_t)std::llround((double)v);
+        }
+    if (lossy) {
+        for (int i = 0; i < max_out; ++i) oar_tensor_free(&outs[i]);
+        fail(OAR_UNSUPPORTED_OP, "an integer graph output exceeds 2^24 (or is not finite): it cannot be represented by the engine's f32 device tensors");
+    }
     *n_out = (int32_t)p.outputs.size();
 }
 
@@ -250,6 +262,9 @@ const Plan& run_named(Engine& E, const oar_input* inputs, int32_t n_in, std::vec
         else for (size_t k = 0; k < infos.size(); ++k) if (infos[k].name == in.name) slot = k;
         OAR_CHECK(slot < infos.size(), OAR_INVALID_INPUT, std::string("the model has no input named '") + (in.name ? in.name : "") + "'");
         OAR_CHECK(ptrs[slot] == nullptr, OAR_INVALID_INPUT, "input '" + infos[slot].name + "' given twice");
+        // oar_input carries f32 only: a model that declares an integer / double / half input would be fed reinterpreted floats
+        OAR_CHECK(infos[slot].elem_type == 0 || infos[slot].elem_type == 1, OAR_UNSUPPORTED_OP,
+                  "input '" + infos[slot].name + "' is declared with ONNX element type " + std::to_string(infos[slot].elem_type) + "; only f32 inputs can be bound");
         int64_t cnt = 1;
         for (int32_t k = 0; k < in.rank; ++k) { OAR_CHECK(in.dims[k] >= 0, OAR_INVALID_INPUT, "negative dimension"); cnt *= in.dims[k]; }
         dims[slot].assign(in.dims, in.dims + in.rank);

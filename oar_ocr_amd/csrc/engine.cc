@@ -1629,6 +1629,7 @@ struct Planner {
             if (t.dtype == DType::F32) v = t.f.empty() ? 0.0 : t.f[0];
             else { v = t.i.empty() ? 0.0 : (double)t.i[0]; is_f = false; }
         }
+        for (auto d : sh.hv) OAR_CHECK(d >= 0 && d <= (int64_t)1 << 28, OAR_SHAPE_MISMATCH, "ConstantOfShape: negative or unreasonable dimension");   // (two negative dims would multiply to a plausible count)
         const int64_t cnt = numel(sh.hv);
         OAR_CHECK(cnt >= 0 && cnt <= (int64_t)1 << 28, OAR_SHAPE_MISMATCH, "ConstantOfShape: unreasonable element count");
         if (!is_f || cnt <= 64) {   // shape plumbing stays on the host
@@ -1796,6 +1797,8 @@ struct Planner {
         if (op == "Tile") {
             if (!(in[0].dims.size() <= 1 && in[1].hv.size() == 1 && in[1].host_int)) return false;   // real data: device path
             std::vector<double> v = host_values(in[0]), out;
+            // (a shape-arithmetic vector: the repeat count comes from the model file -- bounded, and never negative)
+            OAR_CHECK(in[1].hv[0] >= 0 && in[1].hv[0] * (int64_t)std::max<size_t>(v.size(), 1) <= 4096, OAR_MODEL_LOAD, "Tile: unreasonable repeat count of a host vector at " + n.out[0]);
             for (int64_t k = 0; k < in[1].hv[0]; ++k) out.insert(out.end(), v.begin(), v.end());
             set_host(n.out[0], {(int64_t)out.size()}, out, float_like(in[0]));
             return true;

@@ -1580,6 +1580,7 @@ void Ocr::predict_core(const std::vector<PageRef>& pages, std::vector<std::vecto
     };
 
     int flush_count = 0;
+    bool planning_failed = false;   // an error from the crop-planning callback (not from the detector): no per-image retry for those
     auto run_chunk = [&](int start, int end) {
         std::vector<PageRef> chunk(pages.begin() + start, pages.begin() + end);
         std::vector<DetBoxes> boxes;
@@ -1701,7 +1702,10 @@ void Ocr::predict_core(const std::vector<PageRef>& pages, std::vector<std::vecto
                 if (pool.size() >= cfg_.max_pooled_crops) { flush(); ++flush_count; desc_used = 0; }
             }
         };
-        det_->run(chunk, cfg_.det_thresh, cfg_.det_box_thresh, cfg_.det_unclip_ratio, boxes, &dev_pages, plan_pages);
+        auto guarded_plan = [&](int first, int count) {
+            try { plan_pages(first, count); } catch (...) { planning_failed = true; throw; }
+        };
+        det_->run(chunk, cfg_.det_thresh, cfg_.det_box_thresh, cfg_.det_unclip_ratio, boxes, &dev_pages, guarded_plan);
         // the detector's page staging buffer is reused by the next chunk: crops must be done first
         OAR_HIP(hipStreamSynchronize(s));
         tmark("crop_sync");
@@ -1715,7 +1719,10 @@ void Ocr::predict_core(const std::vector<PageRef>& pages, std::vector<std::vecto
         } catch (const Error& err) {
             // "Batched text detection failed; falling back to per-image detection" (src/oarocr/ocr.rs:576-588): the chunk is
             // redone page by page; a page that fails on its own fails the call, as the reference's `?` does.
-            if (end - start <= 1) throw;
+            // only a DETECTOR failure is retried page by page; an error raised while planning / warping / recognising crops (a flush may
+            // already have mixed this chunk's crops into batches with earlier pages) fails the call, as any error after detection does
+            // in the reference (ocr.rs:590-640: `?` on everything behind the detection fallback)
+            if (end - start <= 1 || planning_failed) throw;
             fprintf(stderr, "[oar] batched text detection failed (%s); falling back to per-image detection for pages %d..%d\n", err.what(), start, end);
             (void)hipStreamSynchronize(s);
             (void)hipGetLastError();

@@ -126,8 +126,8 @@ class GraphBuilder:
         self._uid += 1
         return f"{prefix}_{self._uid}"
 
-    def add_input(self, name, shape):
-        self.inputs.append(value_info(name, shape))
+    def add_input(self, name, shape, elem_type: int = FLOAT):
+        self.inputs.append(value_info(name, shape, elem_type))
 
     def add_output(self, name, shape, elem_type: int = FLOAT):
         self.outputs.append(value_info(name, shape, elem_type))

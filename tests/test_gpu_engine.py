@@ -647,3 +647,27 @@ def test_sample_local_chain_matches_oracle_and_the_unfused_path(n, W, mode, monk
     assert np.abs(got - ref).max() <= TOL
     assert np.abs(got - plain).max() <= 5e-5
     assert np.array_equal(got.argmax(-1), plain.argmax(-1)) and np.array_equal(got.argmax(-1), ref.argmax(-1))
+
+
+def test_non_f32_declared_inputs_and_oversized_integer_outputs_are_errors():
+    """oar_input binds f32 only: a model that declares an int64 secondary input is refused instead of being fed reinterpreted floats;
+    an integer-typed output whose value does not fit the engine's f32 device tensors (> 2^24) fails instead of coming back rounded."""
+    g = GraphBuilder("i64_in")
+    g.add_input("x", ["N", 4])
+    g.add_input("idx", ["N", 4], elem_type=7)
+    y = g.op("Add", ["x", g.op("Cast", ["idx"], to=1)])
+    g.add_output(y, ["N", 4])
+    eng = api.OrtInfer(g.model())
+    with pytest.raises(api.OCRError, match="only f32 inputs"):
+        eng.infer([("x", np.zeros((1, 4), np.float32)), ("idx", np.zeros((1, 4), np.float32))])
+    eng.close()
+    g = GraphBuilder("big_int_out")
+    g.add_input("x", ["N", 4])
+    big = g.op("Floor", [g.op("Mul", ["x", g.init(np.array(3.0e7, np.float32))])])
+    g.add_output(big, ["N", 4], elem_type=7)      # declared int64: comes back as TensorOutput::I64
+    eng = api.OrtInfer(g.model())
+    with pytest.raises(api.OCRError, match="2\\^24"):
+        eng.infer(np.ones((1, 4), np.float32))
+    small = eng.infer(np.full((1, 4), 1e-4, np.float32))[0][1]     # 3000: exact
+    assert small.dtype == np.int64 and np.all(small == 3000)
+    eng.close()
