@@ -486,6 +486,40 @@ void Engine::rewrite_graph(OnnxModel& m) {
         for (int i = 0; i < (int)nodes.size(); ++i) if (!dead[i]) keep.push_back(std::move(nodes[i]));
         nodes.swap(keep);
     }
+    // ---- pass 8: squeeze-excite scale into the pointwise conv behind it: Mul(x, SEGate(...)) whose only reader is a plain 1x1 Conv
+    // becomes that Conv with the gate as a 4th input (csrc/igemm_ws_x6.hip multiplies it into the pixels as they are loaded: the scaled
+    // feature map is never written or re-read).  Shapes / kernel choice are plan-time matters: op_conv runs the Mul after all when the
+    // bf16x6 weight-stationary kernel does not take the layer.  OAR_FUSE_SE_SCALE=0 keeps the Mul.
+    {
+        const char* fe = getenv("OAR_FUSE_SE_SCALE");
+        const bool fuse = !fe || atoi(fe) != 0;
+        auto cons = consumers(nodes);
+        std::map<std::string, int> producer;
+        for (int i = 0; i < (int)nodes.size(); ++i) for (auto& o : nodes[i].out) producer[o] = i;
+        std::vector<bool> dead(nodes.size(), false);
+        for (int i = 0; fuse && i < (int)nodes.size(); ++i) {
+            const GNode& m = nodes[i];
+            if (m.op != "Mul" || m.in.size() != 2 || m.act.kind != k::ACT_NONE || !m.residual.empty() || graph_outs.count(m.out[0])) continue;
+            int gi = -1;
+            for (int t = 0; t < 2; ++t) { auto pit = producer.find(m.in[t]); if (pit != producer.end() && nodes[pit->second].op == "SEGate") gi = t; }
+            if (gi < 0 || cons[m.out[0]].size() != 1) continue;
+            GNode& c = nodes[cons[m.out[0]][0]];
+            if (c.op != "Conv" || c.in.size() < 2 || c.in.size() > 3 || c.in[0] != m.out[0] || !is_init(c.in[1]) || c.ai("group", 1) != 1) continue;
+            const HostTensor& w = inits_[c.in[1]];
+            if (w.dims.size() != 4 || w.dims[2] != 1 || w.dims[3] != 1) continue;
+            bool plain = c.as("auto_pad", "NOTSET") == "NOTSET";
+            for (auto v : c.ais("strides")) plain = plain && v == 1;
+            for (auto v : c.ais("pads")) plain = plain && v == 0;
+            if (!plain) continue;
+            c.in.resize(4);
+            c.in[0] = m.in[1 - gi];
+            c.in[3] = m.in[gi];
+            dead[i] = true;
+        }
+        std::vector<GNode> keep;
+        for (int i = 0; i < (int)nodes.size(); ++i) if (!dead[i]) keep.push_back(std::move(nodes[i]));
+        nodes.swap(keep);
+    }
     for (int i = 0; i < (int)nodes.size(); ++i) nodes[i].id = i;
     nodes_ = std::move(nodes);
 }
@@ -1145,6 +1179,26 @@ struct Planner {
     }
 
     void op_conv(const GNode& n) {
+        if (n.in.size() > 3 && !n.in[3].empty()) {   // rewrite pass 8: a squeeze-excite gate rides on this 1x1 conv
+            TInfo xg = get(n.in[0]), gt = get(n.in[3]);
+            const TInfo& wg = get(n.in[1]);
+            bool ok = xg.dims.size() == 4 && !xg.host_int && !gt.host_int && wg.ht && wg.ht->dims.size() == 4 && gt.loc.kind != Loc::NONE && n.residual.empty();
+            if (ok) {
+                const int64_t N = xg.dims[0], C = xg.dims[1], HW = xg.dims[2] * xg.dims[3];
+                ok = numel(gt.dims) == N * C && gt.dims.size() >= 2 && gt.dims[0] == N && gt.dims[1] == C && wg.ht->dims[1] == C && C % 8 == 0 &&
+                     k::conv_igemm_se_ok(N * HW, (int)C, (int)wg.ht->dims[0], (int)HW);
+            }
+            if (!ok) {   // the Mul after all, then the plain conv
+                GNode mul;
+                mul.op = "Mul"; mul.in = {n.in[0], n.in[3]}; mul.out = {n.out[0] + "::se"};
+                op_binary(mul, 2);
+                GNode c2 = n;
+                c2.in.resize(3);
+                c2.in[0] = mul.out[0];
+                op_conv(c2);
+                return;
+            }
+        }
         TInfo x = get(n.in[0]);
         OAR_CHECK(x.dims.size() == 4, OAR_UNSUPPORTED_OP, "Conv: only 2-D convolutions are supported");
         const TInfo& wt = get(n.in[1]);
@@ -1213,17 +1267,23 @@ struct Planner {
         else { kind = 2; p.w = conv_weight_direct(n, W); }
         Loc yl = y.loc;
         bool has_res = res.kind != Loc::NONE;
+        Loc gate;   // [N][Cin] squeeze-excite gate folded into the load (checked above)
+        if (n.in.size() > 3 && !n.in[3].empty()) {
+            OAR_CHECK(kind == 0 && p.w_fmt == k::IGEMM_W_X6, OAR_INTERNAL, "Conv: gate on a layer that is not on the bf16x6 kernel");
+            gate = get(n.in[3]).loc;
+        }
+        const bool has_gate = gate.kind != Loc::NONE;
         double flops = 2.0 * N * Ho * Wo * Cout * (Cin / g) * kh * kw;
         double bytes = 4.0 * (N * H * Wd * Cin + N * Ho * Wo * Cout * (has_res ? 2 : 1) + numel(W.dims));
         auto run = [=](const RunCtx& c) {
             k::ConvP q = p;
-            q.x = c.at(xin); q.y = c.mut(yl); q.residual = has_res ? c.at(res) : nullptr;
+            q.x = c.at(xin); q.y = c.mut(yl); q.residual = has_res ? c.at(res) : nullptr; q.se = has_gate ? c.at(gate) : nullptr;
             if (kind == 0) k::conv_igemm(c.s, q);
             else if (kind == 1) k::conv_dw(c.s, q);
             else k::conv_direct(c.s, q);
         };
         // a 1 x k convolution over a one-row map is a product over the rows of each sample: chainable (chain.hip)
-        if (kind == 0 && H == 1 && Ho == 1 && kh == 1 && pt == 0 && pb == 0 && sw == 1 && dw == 1 && Wo == Wd && Cin % 16 == 0 && Cout % 16 == 0 && k::chain_act_ok(n.act.kind) &&
+        if (kind == 0 && !has_gate && H == 1 && Ho == 1 && kh == 1 && pt == 0 && pb == 0 && sw == 1 && dw == 1 && Wo == Wd && Cin % 16 == 0 && Cout % 16 == 0 && k::chain_act_ok(n.act.kind) &&
             chain_loc_ok(xin) && (!has_res || chain_loc_ok(res))) {
             ChainRec r;
             r.d.type = k::CH_GEMM; r.d.K = (int)(kw * Cin); r.d.N = (int)Cout; r.d.cin = (int)Cin; r.d.pad = (int)pl;

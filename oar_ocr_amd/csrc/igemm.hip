@@ -248,6 +248,17 @@ int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin) {
     return IGEMM_W_K16;
 }
 
+int ws_x6_se_rows(long M, int ny, int hw);   // igemm_ws_x6.hip
+bool conv_igemm_se_ok(long M, int K, int N, int hw) {
+    static const bool on = [] { const char* e = getenv("OAR_FUSE_SE_SCALE"); return !e || atoi(e) != 0; }();
+    if (!on || hw <= 0 || igemm_weight_format(M, K, N, true) != IGEMM_W_X6) return false;
+    const int nfrag = (N + 15) / 16, nt = ws_x6_tile(K, nfrag);
+    if (nt == 0 || os_mode() == 2) return false;   // (the output-stationary kernel has no gate path)
+    const int ny = (nfrag + nt - 1) / nt;
+    const size_t lds = (size_t)nt * ((K + 31) / 32) * 3072 + (size_t)nt * 64 + 16 + (size_t)ws_x6_se_rows(M, ny, hw) * K * 4;
+    return lds <= 160 * 1024;
+}
+
 void conv_igemm(hipStream_t s, const ConvP& c) {
     IgemmP p;
     p.x = c.x; p.w = c.w; p.bias = c.bias; p.res = c.residual; p.y = c.y;
@@ -256,6 +267,7 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     p.act = c.act.kind; p.alpha = c.act.alpha; p.beta = c.act.beta;
     p.convt = c.convt2x2; p.Cout = c.Cout;
     p.ctc_part = c.ctc_part; p.ctc_valid = c.ctc_valid;
+    p.se = c.se; p.se_hw = c.Ho * c.Wo;
     if (c.convt2x2) {
         p.Ho = c.H; p.Wo = c.W;  // GEMM columns are INPUT pixels
         p.M = (long)c.N * c.H * c.W; p.K = c.Cin; p.gemm_cout = 4 * c.Cout;
@@ -336,12 +348,14 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
         else if (PF == 2) LAUNCH2(NTV, 2);           \
         else LAUNCH2(NTV, 1);                        \
     } while (0)
+    OAR_CHECK(!c.se || x6, OAR_INTERNAL, "conv_igemm: gate on a non-x6 layer (conv_igemm_se_ok should have said no)");
     if (ws3) {
         conv_igemm_ws3(s, p, nfrag);
     } else if (x6) {
         const int nt = c.ctc_part ? 8 : is1x1 ? ws_x6_tile(p.K, nfrag) : 0;
         OAR_CHECK(((p.Cout & 3) == 0) && ((p.y_ld & 3) == 0) && !c.convt2x2, OAR_INTERNAL, "conv_igemm: bf16x6 weights on an ineligible layer");
         const bool os = !c.ctc_part && (nt == 0 || (os_mode() == 2 && os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin)));
+        OAR_CHECK(!c.se || (!os && !c.ctc_part && is1x1), OAR_INTERNAL, "conv_igemm: gate on a layer the weight-stationary x6 kernel does not take");
         if (os) {
             OAR_CHECK(os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin), OAR_INTERNAL, "conv_igemm: bf16x6 weights on a layer neither x6 kernel takes");
             conv_igemm_os_x6(s, p, nfrag, is1x1);

@@ -47,6 +47,8 @@ struct IgemmP {
     float alpha, beta;
     float* ctc_part;     // != null (weight-stationary f32 kernel only): no logits are stored; per (row, cout tile) the
     int ctc_valid;       // softmax partials {max, sum exp(x - max), last arg max} over the tile's valid columns go here
+    const float* se;     // != null (bf16x6 weight-stationary kernel only): gate [image][K] multiplied into x on load
+    int se_hw;           // pixels per image (se row of pixel m = m / se_hw)
 };
 
 __device__ __forceinline__ void igemm_store(const IgemmP& p, f32x4 v, bool valid, long obase, int c, bool vec_ok, bool add_bias = true) {

@@ -21,6 +21,7 @@ struct IgemmWsX6P {
     int groups;         // teams per XCD; team t handles cout tiles t, t+groups, ...
     long wt_per_xcd;    // wave tiles (16 pixels) per XCD band
     long wt_total;      // ceil(M / 16)
+    int se_cap;         // SE variant: gate rows (images) the LDS region after the counter can hold
 };
 
 __device__ __forceinline__ void split3(const f32x4& a, const f32x4& b, uint4& h, uint4& m, uint4& l) {
@@ -41,7 +42,10 @@ __device__ __forceinline__ void split3(const f32x4& a, const f32x4& b, uint4& h,
     l = make_uint4((ll[0] >> 16) | ll[1], (ll[2] >> 16) | ll[3], (ll[4] >> 16) | ll[5], (ll[6] >> 16) | ll[7]);
 }
 
-template <int NT, bool CTC = false>   // CTC: the CTC-head variant (softmax partials instead of logits), its own instantiation so that
+// SE: the input is multiplied by a squeeze-excite gate [image][K] as it is loaded (the Mul between the gate and this conv never runs:
+// one read + one write of the whole feature map less).  The gate rows of the images this workgroup's tile range touches sit in LDS
+// behind the counter; x * gate is the same v_mul_f32 the stand-alone Mul would have done, so the result is bit-identical to it.
+template <int NT, bool CTC = false, bool SE = false>   // CTC: the CTC-head variant (softmax partials instead of logits), its own instantiation so that
 __global__ __launch_bounds__(1024) void conv_igemm_ws_x6_kernel(IgemmWsX6P q) {   // the plain kernels keep their register budget
     extern __shared__ uint4 wx_lds[];   // [kc][nf][plane][lane] weights | [nf][16] bias | counter
     const IgemmP& p = q.g;
@@ -53,12 +57,20 @@ __global__ __launch_bounds__(1024) void conv_igemm_ws_x6_kernel(IgemmWsX6P q) { 
     const int team = j % q.groups, member = j / q.groups, team_size = (per_xcd - team + q.groups - 1) / q.groups;
     float* lds_bias = reinterpret_cast<float*>(wx_lds + (long)NT * p.KC * 3 * 64);
     unsigned* ws_ctr = reinterpret_cast<unsigned*>(lds_bias + NT * 16);
+    float* se_lds = reinterpret_cast<float*>(ws_ctr + 4);   // SE: [image - se_first][K]
     long wt_begin, wt_count;
     {
         const long x0 = (long)xcd * q.wt_per_xcd, x1 = min(q.wt_total, x0 + q.wt_per_xcd);
         const long n_x = max(0L, x1 - x0), share = (n_x + team_size - 1) / team_size;
         wt_begin = x0 + (long)member * share;
         wt_count = max(0L, min(share, x1 - wt_begin));
+    }
+    int se_first = 0;
+    if (SE && wt_count > 0) {
+        se_first = (int)((wt_begin * 16) / p.se_hw);
+        const int se_last = (int)(min(p.M - 1, (wt_begin + wt_count) * 16 - 1) / p.se_hw);
+        const int cnt = min(se_last - se_first + 1, q.se_cap) * p.K;
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) se_lds[i] = p.se[(long)se_first * p.K + i];   // (visible after the barrier below)
     }
     constexpr int NL = 2;   // vector-memory loads per chunk: two float4 of one pixel fragment
     auto issue = [](f32x4& dst, const float* src) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src)); };
@@ -119,6 +131,8 @@ __global__ __launch_bounds__(1024) void conv_igemm_ws_x6_kernel(IgemmWsX6P q) { 
 
         const uint4* wl = wx_lds + lane;
         auto run_tile = [&]() {
+            const float* se_row = nullptr;
+            if (SE) se_row = se_lds + (long)((int)(min(m0 + pl_, p.M - 1) / p.se_hw) - se_first) * p.K;
             f32x4 acc[NT][1];
 #pragma clang loop unroll(full)
             for (int nf = 0; nf < NT; ++nf) {
@@ -141,6 +155,11 @@ __global__ __launch_bounds__(1024) void conv_igemm_ws_x6_kernel(IgemmWsX6P q) { 
                     issue(ns.a, ap); issue(ns.b, ap + 4);
                 }
                 uint4 xs[3];
+                if (SE) {
+                    const float* sp = se_row + min(kc * 32 + 8 * g, p.K - 8);
+                    const f32x4 ga = *reinterpret_cast<const f32x4*>(sp), gb = *reinterpret_cast<const f32x4*>(sp + 4);
+                    split3(cs.a * ga, cs.b * gb, xs[0], xs[1], xs[2]);
+                } else
                 split3(cs.a, cs.b, xs[0], xs[1], xs[2]);
                 const int k1 = min(kc + 1, p.KC - 1);
 #pragma clang loop unroll(full)
@@ -203,10 +222,19 @@ __global__ __launch_bounds__(1024) void conv_igemm_ws_x6_kernel(IgemmWsX6P q) { 
     }
 }
 
-template <int NT, bool CTC = false>
+// gate rows (images) one workgroup's tile range can touch, for the launch geometry below
+int ws_x6_se_rows(long M, int ny, int hw) {
+    const int per_xcd = 32;
+    const long wt_total = (M + 15) / 16, wt_per_xcd = (wt_total + 7) / 8;
+    const int groups = ny < per_xcd ? ny : per_xcd, team_min = per_xcd / groups;   // the smallest team has floor(32 / groups) members
+    const long share = (wt_per_xcd + team_min - 1) / team_min;
+    return (int)((share * 16 + hw - 1) / hw) + 1;
+}
+
+template <int NT, bool CTC = false, bool SE = false>
 static void launch_ws_x6(hipStream_t s, const IgemmP& p, int ny, size_t lds) {
     static const bool once = [] {
-        OAR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws_x6_kernel<NT, CTC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        OAR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws_x6_kernel<NT, CTC, SE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         return true;
     }();
     (void)once;
@@ -216,11 +244,25 @@ static void launch_ws_x6(hipStream_t s, const IgemmP& p, int ny, size_t lds) {
     q.wt_total = (p.M + 15) / 16;
     q.wt_per_xcd = (q.wt_total + 7) / 8;
     q.groups = ny < per_xcd ? ny : per_xcd;
-    hipLaunchKernelGGL((conv_igemm_ws_x6_kernel<NT, CTC>), dim3(per_xcd * 8), dim3(1024), lds, s, q);
+    q.se_cap = 0;
+    if (SE) {
+        q.se_cap = ws_x6_se_rows(p.M, ny, p.se_hw);
+        lds += (size_t)q.se_cap * p.K * 4;
+        OAR_CHECK(lds <= 160 * 1024, OAR_INTERNAL, "conv_igemm_ws_x6: the gate rows do not fit LDS (conv_igemm_se_ok should have said no)");
+    }
+    hipLaunchKernelGGL((conv_igemm_ws_x6_kernel<NT, CTC, SE>), dim3(per_xcd * 8), dim3(1024), lds, s, q);
 }
 
 void conv_igemm_ws_x6(hipStream_t s, const IgemmP& p, int ws_nt, int ny, size_t lds) {
     if (p.ctc_part) { launch_ws_x6<8, true>(s, p, ny, lds); return; }   // conv_igemm passes ws_nt = 8 for CTC heads
+    if (p.se) {
+        switch (ws_nt) {
+            case 8: launch_ws_x6<8, false, true>(s, p, ny, lds); break;
+            case 6: launch_ws_x6<6, false, true>(s, p, ny, lds); break;
+            default: launch_ws_x6<4, false, true>(s, p, ny, lds); break;
+        }
+        return;
+    }
     switch (ws_nt) {
         case 8: launch_ws_x6<8>(s, p, ny, lds); break;
         case 6: launch_ws_x6<6>(s, p, ny, lds); break;

@@ -30,6 +30,7 @@ struct ConvP {
     int w_fmt;              // igemm only: weight fragment layout, one of IGEMM_W_* (chosen by igemm_weight_format)
     float* ctc_part;        // igemm only, Linear feeding the fused CTC tail: softmax partials [rows][ctc_tiles()] float4
     int ctc_valid;          //   instead of logits (y is not written); ctc_valid = number of real classes
+    const float* se;        // igemm only (bf16x6 weight-stationary 1x1): squeeze-excite gate [N][Cin] multiplied into the input on load
 };
 enum : int { IGEMM_W_K16 = 0, IGEMM_W_X6 = 1 };
 
@@ -40,7 +41,9 @@ enum : int { IGEMM_W_K16 = 0, IGEMM_W_X6 = 1 };
 // Rows are padded to 64 couts, K to the chunk size, with zeros.
 void conv_igemm(hipStream_t s, const ConvP& p);
 // chosen per layer AND input shape at plan time: M = GEMM rows (pixels), N = couts
-int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin = 0);   // Cin: input channels of a k x k conv (0: treat as not eligible for the x6 path)
+int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin = 0);
+// may a 1x1 conv of this shape take ConvP::se (the gate of a squeeze-excite block folded into its input load)?  hw = pixels per image
+bool conv_igemm_se_ok(long M, int K, int N, int hw);   // Cin: input channels of a k x k conv (0: treat as not eligible for the x6 path)
 // Depthwise conv. w: [kh][kw][C]. C % 4 == 0.
 void conv_dw(hipStream_t s, const ConvP& p);
 // Direct conv for everything else (small Cin, odd channels, grouped). w: [kh][kw][Cin/g][Cout].

@@ -671,3 +671,27 @@ def test_non_f32_declared_inputs_and_oversized_integer_outputs_are_errors():
     small = eng.infer(np.full((1, 4), 1e-4, np.float32))[0][1]     # 3000: exact
     assert small.dtype == np.int64 and np.all(small == 3000)
     eng.close()
+
+
+def test_squeeze_excite_scale_rides_on_the_pointwise_conv(monkeypatch):
+    """Mul(x, SEGate) -> Conv 1x1 (the tail of a PP-LCNet squeeze-excite block): on layers the bf16x6 weight-stationary kernel takes,
+    the gate is multiplied into the pixels as they are loaded (engine.cc pass 8, igemm_ws_x6.hip SE variant) -- no `binary` launch, the
+    scaled map never reaches HBM -- and the result is BIT-identical to running the Mul (same v_mul_f32, then the same split); layers
+    the kernel does not take (the detector's 30 x 30 maps) run the Mul after all.  Both against the torch oracle."""
+    rec, _ = models.build_rec("tiny", vocab=6906, seed=1)
+    # 160 lines of 48 x 200: 300 pixels per image at the gated layers (not a multiple of the 16-pixel tile: tiles straddle images)
+    x = np.random.default_rng(77).standard_normal((160, 3, 48, 200)).astype(np.float32)
+    monkeypatch.setenv("OAR_FUSE_SE_SCALE", "0")
+    plain = api.OrtInfer(rec).infer(x)[0][1]
+    monkeypatch.delenv("OAR_FUSE_SE_SCALE")
+    eng = api.OrtInfer(rec, profile=True)
+    api.prof_enable(True); api.prof_reset()
+    got = eng.infer(x)[0][1]
+    snap = {e["name"]: e["launches"] for e in api.prof_snapshot()}
+    api.prof_enable(False)
+    assert not snap.get("binary", 0), snap
+    assert np.array_equal(got, plain)
+    ref = onnx_ref.run(rec, {eng.input_name(): x})[0]
+    assert np.abs(got - ref).max() <= TOL
+    det, _ = models.build_det("tiny", seed=0)
+    _check(det, np.random.default_rng(5).standard_normal((2, 3, 320, 480)).astype(np.float32))
