@@ -866,7 +866,12 @@ struct Planner {
                 while (lo > i && compat(lo - 1)) --lo;
                 while (hi < b && compat(hi)) ++hi;
                 for (int j = i; j < lo; ++j) keep(j);
-                if (hi - lo < kMinChain) { for (int j = lo; j < hi; ++j) keep(j); i = hi; continue; }
+                // one workgroup (one CU's f32 matrix pipe: 0.6 TFLOP/s) per sample: beyond ~32 MFLOP per sample the operator-by-operator
+                // kernels, which spread every product over the whole chip, win again (a server-size SVTR neck is ~120 MFLOP per line)
+                double run_flops = 0;
+                for (int j = lo; j < hi; ++j) run_flops += chain_recs[(size_t)step_chain[(size_t)j]].flops;
+                static const double max_mflop = [] { const char* e = getenv("OAR_CHAIN_MAX_MFLOP"); return e ? atof(e) : 32.0; }();
+                if (hi - lo < kMinChain || run_flops / (double)n > max_mflop * 1e6) { for (int j = lo; j < hi; ++j) keep(j); i = hi; continue; }
                 std::vector<k::ChainOpD> ops;
                 std::vector<std::string> out_roots;
                 std::vector<const ChainRec*> recs;
