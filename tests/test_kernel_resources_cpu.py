@@ -51,7 +51,19 @@ def test_weight_stationary_kernels_fit_their_budget():
         for name, r in ks.items():
             assert r["vgprs"] <= 128, (name, r)     # 1024-thread workgroups: 4 waves per SIMD only inside 128 registers
             ctc_variant = "ILi8ELb1E" in name      # the CTC-head instantiation of the x6 kernel (softmax-partial epilogue): 164 B today
-            assert r["scratch"] <= (200 if ctc_variant else 160), (name, r)   # today: 148 B (x6, 8 fragments) / 84 / 28 / 12 (3x3) of cold-path spill; a regression shows up as KBs
+            se_variant = "ELb0ELb1E" in name       # round 3: the squeeze-excite-gate instantiations (8 more live registers per chunk): 208 B at 8 fragments
+            assert r["scratch"] <= (240 if se_variant else 200 if ctc_variant else 160), (name, r)   # today: 148 B (x6, 8 fragments) / 84 / 28 / 12 (3x3) of cold-path spill; a regression shows up as KBs
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
+def test_chain_kernel_fits_its_1024_thread_workgroup():
+    """chain.hip: one 1024-thread workgroup per text line = 4 waves per SIMD = 128 registers; today 128 with 88 B of spill of
+    loop-invariant values (stored once in the prologue); its code has to stay inside the 64 KB instruction cache (46 KB today --
+    a 95 KB build of this kernel ran every operator at instruction-fetch speed)."""
+    ks = {k: v for k, v in _resources("chain.hip").items() if "chain_kernel" in k}
+    assert len(ks) == 1
+    for name, r in ks.items():
+        assert r["vgprs"] <= 128 and r["scratch"] <= 160, (name, r)
 
 
 @pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
