@@ -201,7 +201,7 @@ def main():
 
         class HipEngine:
             def predict_packed(self, pages):
-                return ocr.predict_packed(h_ptrs, h_ws, h_hs, n_pages)
+                return ocr.predict_packed(h_ptrs, h_ws, h_hs, n_pages, want_blob=world > 1)   # N > 1: the rank's blob comes from oar_ocr_pack
 
             def close(self):
                 ocr.close()
@@ -224,11 +224,10 @@ def main():
         if world == 1:
             gathered.update(pages=len(packed.region_offsets) - 1, regions=len(packed.scores), bytes=len(packed.utf8))
             return packed
-        blobs = oard.gather_bytes(packed.to_bytes(), 0, comm_dev)
+        blobs = oard.gather_bytes(getattr(packed, "blob", None) or packed.to_bytes(), 0, comm_dev)   # oar_ocr_pack's wire format
         if rank == 0:
-            parts = [api.PackedPages.from_bytes(b) for b in blobs]   # block partition => concatenation restores page order
-            gathered.update(pages=sum(len(p.region_offsets) - 1 for p in parts), regions=sum(len(p.scores) for p in parts),
-                            bytes=sum(len(p.utf8) for p in parts))
+            merged = api.PackedPages.merge(blobs)   # oar_packed_merge: block partition => concatenation in rank order restores page order
+            gathered.update(pages=len(merged.region_offsets) - 1, regions=len(merged.scores), bytes=len(merged.utf8))
         return packed
 
     # -- untimed: discover the dominant kernel class with every class instrumented

@@ -341,6 +341,31 @@ typedef struct {
 oar_status oar_ocr_word_boxes(const oar_ocr_result* res, const oar_text_result* txt, oar_word_boxes* out);
 void oar_word_boxes_free(oar_word_boxes* w);
 
+/* ------------------------------------------------------------------------------------------------ multi-process hosts
+ * One process per GPU, image-parallel: pages are independent units, the crop pool is per shard (ocr.rs:594-634 pools within one
+ * predict call), and there is no collective on the data path -- only the final results travel.  The library ships no transport:
+ * a rank packs the results of its block of pages into ONE contiguous blob, the host moves blobs with what it has (RCCL / MPI /
+ * sockets: bench.py uses torch.distributed's gather), and rank 0 merges them in rank order.  Host-only, no GPU involved.
+ *   oar_shard_range : static block partition, rank r owns items [begin, end) = [r n / G, (r + 1) n / G) with the remainder spread
+ *                     over the first ranks (SURVEY 8e "Partitioning")
+ *   oar_ocr_pack    : (pipeline result, decoded texts) -> blob.  Wire format v1, little-endian, no padding:
+ *                     int64 n_images, n_regions, utf8_bytes | u32 region_offsets[n_images + 1] | f32 points[n_regions * 8] |
+ *                     f32 scores[n_regions] (the text scores) | u64 text_offsets[n_regions + 1] | utf8.  Quad boxes only.
+ *   oar_packed_merge: blobs in rank order -> one flat result (offsets rebased; a block partition makes concatenation = page order) */
+typedef struct {
+    uint32_t n_images, n_regions;
+    uint32_t* region_offsets;  /* n_images + 1 */
+    float* points;             /* n_regions * 8 */
+    float* scores;             /* n_regions */
+    uint64_t* text_offsets;    /* n_regions + 1 */
+    char* utf8;                /* text_offsets[n_regions] bytes (+ one NUL) */
+} oar_packed_pages;
+oar_status oar_shard_range(uint64_t n_items, uint32_t world_size, uint32_t rank, uint64_t* begin, uint64_t* end);
+oar_status oar_ocr_pack(const oar_ocr_result* res, const oar_text_result* txt, uint8_t** blob, size_t* len);
+void oar_blob_free(uint8_t* blob);
+oar_status oar_packed_merge(const uint8_t* const* blobs, const size_t* lens, uint32_t n_blobs, oar_packed_pages* out);
+void oar_packed_pages_free(oar_packed_pages* p);
+
 /* ------------------------------------------------------------------------------------------------ Seam B: config-5 stages
  * PP-LCNet classifier adapters: DocumentOrientationAdapter / TextLineOrientationAdapter ->
  * PPLCNetModel::forward_refs (oar-ocr-core/src/models/classification/pp_lcnet.rs:139-330): Triangle resize

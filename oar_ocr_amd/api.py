@@ -648,7 +648,7 @@ class CtcDict:
         lib().oar_text_result_free(C.byref(res))
         return out
 
-    def decode_ocr(self, res: "OcrResult", score_threshold: float = 0.0, want_positions: bool = True, word_boxes: bool = False) -> DecodedTexts:
+    def decode_ocr(self, res: "OcrResult", score_threshold: float = 0.0, want_positions: bool = True, word_boxes: bool = False, want_blob: bool = False) -> DecodedTexts:
         """word_boxes: also run oar_ocr_word_boxes (return_word_box, src/oarocr/ocr.rs:860-877) on the decoded texts; the per-region
         lists of [4, 2] boxes (None where the reference yields none) are returned as DecodedTexts.word_boxes."""
         tr = TextResult()
@@ -664,6 +664,13 @@ class CtcDict:
                 out.word_boxes = [[b for b in flat[offs[k]:offs[k + 1]]] if offs[k + 1] > offs[k] else None for k in range(n)]
             finally:
                 lib().oar_word_boxes_free(C.byref(wb))
+        if want_blob:   # oar_ocr_pack: the rank's final results as one blob for the host's transport (header: "multi-process hosts")
+            blob, ln = C.POINTER(C.c_uint8)(), C.c_size_t(0)
+            try:
+                _check(lib().oar_ocr_pack(C.byref(res), C.byref(tr), C.byref(blob), C.byref(ln)))
+                out.blob = C.string_at(blob, ln.value)
+            finally:
+                lib().oar_blob_free(blob)
         lib().oar_text_result_free(C.byref(tr))
         return out
 
@@ -1027,7 +1034,7 @@ class OAROCR:
         lib().oar_ocr_result_free(C.byref(res))
         return out
 
-    def predict_packed(self, ptrs, ws, hs, n: int, device: bool = False) -> "PackedPages":
+    def predict_packed(self, ptrs, ws, hs, n: int, device: bool = False, want_blob: bool = False) -> "PackedPages":
         """The metric path of bench.py (u8 pages in host memory -> sorted boxes + texts + scores on the host):
         ONE oar_ocr_predict + ONE oar_ocr_decode, results as flat arrays (no per-region Python objects).  ptrs / ws / hs are
         prepared ctypes arrays (the caller owns the page buffers, as the Rust caller owns its `RgbImage`s)."""
@@ -1035,15 +1042,17 @@ class OAROCR:
         fn = lib().oar_ocr_predict_device if device else lib().oar_ocr_predict
         _check(fn(self._h, ptrs, ws, hs, n, C.byref(res)))
         try:
-            d = self.ctc.decode_ocr(res, self.score_threshold, want_positions=False)
-            nr = int(res.n_regions)
             if res.point_offsets:
                 raise OCRError(OAR_INVALID_INPUT, "predict_packed carries quad boxes only: use predict() for seal text")
+            d = self.ctc.decode_ocr(res, self.score_threshold, want_positions=False, want_blob=want_blob)
+            nr = int(res.n_regions)
             offs = np.ctypeslib.as_array(res.region_offsets, shape=(n + 1,)).copy()
             pts = np.ctypeslib.as_array(res.points, shape=(max(nr, 1) * 8,)).copy()[:nr * 8].reshape(nr, 4, 2)
         finally:
             lib().oar_ocr_result_free(C.byref(res))
-        return PackedPages(offs, pts, d.scores, d.utf8, d.text_offsets)
+        pk = PackedPages(offs, pts, d.scores, d.utf8, d.text_offsets)
+        pk.blob = getattr(d, "blob", None)   # want_blob: oar_ocr_pack's wire format (== to_bytes())
+        return pk
 
     # ---- calls in flight (oar_ocr_predict_async / oar_ocr_wait; oar_ocr_cfg.lanes)
     def submit_packed(self, ptrs, ws, hs, n: int, device: bool = False) -> int:
@@ -1126,6 +1135,20 @@ class OAROCR:
             pass
 
 
+class PackedPagesC(C.Structure):   # oar_packed_pages
+    _fields_ = [("n_images", C.c_uint32), ("n_regions", C.c_uint32), ("region_offsets", C.POINTER(C.c_uint32)), ("points", C.POINTER(C.c_float)),
+                ("scores", C.POINTER(C.c_float)), ("text_offsets", C.POINTER(C.c_uint64)), ("utf8", C.c_void_p)]
+
+
+def shard_range(n_items: int, world_size: int, rank: int):
+    """oar_shard_range: the static block partition of SURVEY 8e (rank r owns items [begin, end))"""
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    if world_size <= 0 or rank < 0:
+        raise OCRError(OAR_INVALID_INPUT, "oar_shard_range: bad world_size / rank")
+    _check(lib().oar_shard_range(C.c_uint64(n_items), C.c_uint32(world_size), C.c_uint32(rank), C.byref(a), C.byref(b)))
+    return int(a.value), int(b.value)
+
+
 @dataclass
 class PackedPages:
     """Flat result of OAROCR.predict_packed: page i owns regions [region_offsets[i], region_offsets[i+1]) in reading order;
@@ -1135,6 +1158,7 @@ class PackedPages:
     scores: np.ndarray
     utf8: bytes
     text_offsets: np.ndarray
+    blob: Optional[bytes] = None   # predict_packed(want_blob=True): oar_ocr_pack's blob of these arrays
 
     def text(self, k: int) -> str:
         return self.utf8[self.text_offsets[k]:self.text_offsets[k + 1]].decode("utf-8", errors="replace")
@@ -1145,6 +1169,26 @@ class PackedPages:
         head = np.array([n, nr, len(self.utf8)], np.int64)
         return b"".join([head.tobytes(), self.region_offsets.astype(np.uint32).tobytes(), self.points.astype(np.float32).tobytes(),
                          self.scores.astype(np.float32).tobytes(), self.text_offsets.astype(np.uint64).tobytes(), self.utf8])
+
+    @classmethod
+    def merge(cls, blobs: Sequence[bytes]) -> "PackedPages":
+        """oar_packed_merge: the ranks' blobs, in rank order, as one flat result (a block partition makes that page order)"""
+        n = len(blobs)
+        keep = [C.create_string_buffer(b, len(b)) for b in blobs]
+        ptrs = (C.POINTER(C.c_uint8) * max(n, 1))(*[C.cast(k, C.POINTER(C.c_uint8)) for k in keep])
+        lens = (C.c_size_t * max(n, 1))(*[len(b) for b in blobs])
+        out = PackedPagesC()
+        _check(lib().oar_packed_merge(ptrs, lens, n, C.byref(out)))
+        try:
+            ni, nr = int(out.n_images), int(out.n_regions)
+            ro = np.ctypeslib.as_array(out.region_offsets, shape=(ni + 1,)).copy()
+            pts = np.ctypeslib.as_array(out.points, shape=(max(nr, 1) * 8,)).copy()[:nr * 8].reshape(nr, 4, 2)
+            sc = np.ctypeslib.as_array(out.scores, shape=(max(nr, 1),)).copy()[:nr]
+            to = np.ctypeslib.as_array(out.text_offsets, shape=(nr + 1,)).copy()
+            utf8 = C.string_at(out.utf8, int(to[nr]))
+        finally:
+            lib().oar_packed_pages_free(C.byref(out))
+        return cls(ro, pts, sc, utf8, to)
 
     @classmethod
     def from_bytes(cls, blob: bytes) -> "PackedPages":

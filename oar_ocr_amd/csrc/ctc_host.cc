@@ -4,6 +4,7 @@
 // (domain/adapters/text_recognition_adapter.rs:60-102).  It is a few microseconds of integer work per region; the
 // Python mirror (api.CTCLabelDecode) needed ~10 ms per 1000 regions, which is why it lives here as well.
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -277,6 +278,101 @@ oar_status oar_char_positions_to_word_boxes(const float* line_pts_xy, uint32_t n
             std::memcpy(boxes, out.data(), out.size() * sizeof(float));
         }
     });
+}
+
+// ---- multi-process hosts (header: "multi-process hosts"): block partition + the wire format of a rank's final results
+oar_status oar_shard_range(uint64_t n_items, uint32_t world_size, uint32_t rank, uint64_t* begin, uint64_t* end) {
+    return guarded([&] {
+        OAR_CHECK(begin && end && world_size > 0 && rank < world_size, OAR_INVALID_INPUT, "oar_shard_range: bad world_size / rank");
+        const uint64_t base = n_items / world_size, rem = n_items % world_size;
+        *begin = (uint64_t)rank * base + std::min<uint64_t>(rank, rem);
+        *end = *begin + base + (rank < rem ? 1 : 0);
+    });
+}
+
+oar_status oar_ocr_pack(const oar_ocr_result* res, const oar_text_result* txt, uint8_t** blob, size_t* len) {
+    return guarded([&] {
+        OAR_CHECK(res && txt && blob && len, OAR_INVALID_INPUT, "oar_ocr_pack: bad arguments");
+        OAR_CHECK(txt->n == res->n_regions, OAR_SHAPE_MISMATCH, "oar_ocr_pack: the texts do not belong to this result");
+        OAR_CHECK(!res->point_offsets, OAR_INVALID_INPUT, "oar_ocr_pack carries quad boxes only");
+        const uint64_t n = res->n_images, nr = res->n_regions, nb = nr ? txt->text_offsets[nr] : 0;
+        const size_t total = 24 + 4 * (n + 1) + 32 * nr + 4 * nr + 8 * (nr + 1) + nb;
+        uint8_t* b = static_cast<uint8_t*>(std::malloc(total ? total : 1));
+        OAR_CHECK(b, OAR_DEVICE, "oar_ocr_pack: out of memory");
+        uint8_t* w = b;
+        auto put = [&](const void* src, size_t bytes) { if (bytes) std::memcpy(w, src, bytes); w += bytes; };
+        const int64_t head[3] = {(int64_t)n, (int64_t)nr, (int64_t)nb};
+        put(head, 24);
+        if (res->region_offsets) put(res->region_offsets, 4 * (n + 1));
+        else { const uint32_t z = 0; for (uint64_t i = 0; i <= n; ++i) put(&z, 4); }
+        put(res->points, 32 * nr);
+        put(txt->scores, 4 * nr);
+        if (txt->text_offsets) put(txt->text_offsets, 8 * (nr + 1));
+        else { const uint64_t z = 0; put(&z, 8); }
+        put(txt->utf8, nb);
+        *blob = b; *len = total;
+    });
+}
+
+void oar_blob_free(uint8_t* blob) { std::free(blob); }
+
+oar_status oar_packed_merge(const uint8_t* const* blobs, const size_t* lens, uint32_t n_blobs, oar_packed_pages* out) {
+    return guarded([&] {
+        OAR_CHECK(out && (n_blobs == 0 || (blobs && lens)), OAR_INVALID_INPUT, "oar_packed_merge: bad arguments");
+        std::memset(out, 0, sizeof *out);
+        uint64_t n = 0, nr = 0, nb = 0;
+        for (uint32_t i = 0; i < n_blobs; ++i) {   // validate every header against its blob's length before anything is copied
+            OAR_CHECK(blobs[i] && lens[i] >= 24, OAR_INVALID_INPUT, "oar_packed_merge: blob " + std::to_string(i) + " is too short");
+            int64_t h[3];
+            std::memcpy(h, blobs[i], 24);
+            OAR_CHECK(h[0] >= 0 && h[1] >= 0 && h[2] >= 0 && h[0] < (1ll << 31) && h[1] < (1ll << 31) && h[2] < (1ll << 40), OAR_INVALID_INPUT, "oar_packed_merge: corrupt header in blob " + std::to_string(i));
+            const uint64_t need = 24 + 4 * ((uint64_t)h[0] + 1) + 36 * (uint64_t)h[1] + 8 * ((uint64_t)h[1] + 1) + (uint64_t)h[2];
+            OAR_CHECK(need == lens[i], OAR_INVALID_INPUT, "oar_packed_merge: blob " + std::to_string(i) + " has " + std::to_string(lens[i]) + " bytes, its header says " + std::to_string(need));
+            n += (uint64_t)h[0]; nr += (uint64_t)h[1]; nb += (uint64_t)h[2];
+        }
+        OAR_CHECK(n < (1ull << 31) && nr < (1ull << 31), OAR_INVALID_INPUT, "oar_packed_merge: too many pages / regions");
+        out->n_images = (uint32_t)n; out->n_regions = (uint32_t)nr;
+        out->region_offsets = cm<uint32_t>(n + 1);
+        out->points = cm<float>(nr * 8 + 1);
+        out->scores = cm<float>(nr + 1);
+        out->text_offsets = cm<uint64_t>(nr + 1);
+        out->utf8 = cm<char>(nb + 1);
+        uint64_t pi = 0, ri = 0, bi = 0;
+        out->region_offsets[0] = 0; out->text_offsets[0] = 0;
+        try {
+        for (uint32_t i = 0; i < n_blobs; ++i) {
+            int64_t h[3];
+            std::memcpy(h, blobs[i], 24);
+            const uint64_t bn = (uint64_t)h[0], bnr = (uint64_t)h[1], bnb = (uint64_t)h[2];
+            const uint8_t* r = blobs[i] + 24;
+            for (uint64_t k = 0; k <= bn; ++k) {
+                uint32_t v;
+                std::memcpy(&v, r + 4 * k, 4);
+                OAR_CHECK(v <= bnr && (k == 0 ? v == 0 : true), OAR_INVALID_INPUT, "oar_packed_merge: region offsets out of range in blob " + std::to_string(i));
+                if (k) out->region_offsets[pi + k] = (uint32_t)(ri + v);
+            }
+            r += 4 * (bn + 1);
+            std::memcpy(out->points + ri * 8, r, 32 * bnr); r += 32 * bnr;
+            std::memcpy(out->scores + ri, r, 4 * bnr); r += 4 * bnr;
+            for (uint64_t k = 0; k <= bnr; ++k) {
+                uint64_t v;
+                std::memcpy(&v, r + 8 * k, 8);
+                OAR_CHECK(v <= bnb, OAR_INVALID_INPUT, "oar_packed_merge: text offsets out of range in blob " + std::to_string(i));
+                if (k) out->text_offsets[ri + k] = bi + v;
+            }
+            r += 8 * (bnr + 1);
+            std::memcpy(out->utf8 + bi, r, bnb);
+            pi += bn; ri += bnr; bi += bnb;
+        }
+        } catch (...) { oar_packed_pages_free(out); throw; }
+        out->utf8[nb] = 0;
+    });
+}
+
+void oar_packed_pages_free(oar_packed_pages* p) {
+    if (!p) return;
+    std::free(p->region_offsets); std::free(p->points); std::free(p->scores); std::free(p->text_offsets); std::free(p->utf8);
+    std::memset(p, 0, sizeof *p);
 }
 
 void oar_word_boxes_free(oar_word_boxes* w) {

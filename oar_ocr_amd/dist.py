@@ -17,9 +17,8 @@ def shard_range(n_items: int, world_size: int, rank: int) -> Tuple[int, int]:
     """Static block partition: rank r gets [r*n/G, (r+1)*n/G) with the remainder spread over the first ranks."""
     if world_size <= 0 or not (0 <= rank < world_size):
         raise ValueError("bad world_size/rank")
-    base, rem = divmod(n_items, world_size)
-    start = rank * base + min(rank, rem)
-    return start, start + base + (1 if rank < rem else 0)
+    from . import api   # oar_shard_range (C ABI: the same partition for a Rust / C host)
+    return api.shard_range(n_items, world_size, rank)
 
 
 def init_from_env(backend: str | None = None):

@@ -17,6 +17,7 @@
 //! | `layout_detection_adapter.rs` `LayoutDetectionAdapter` (PicoDet / RT-DETR) | [`Mi355xLayoutDetectionAdapter`]   | `oar_layout_*`            |
 //! | `core/inference/ort_infer_execution.rs` `OrtInfer` (Seam A)  | [`Mi355xInfer`]                     | `oar_engine_*`            |
 //! | `src/oarocr/ocr.rs` `OAROCR::predict`                        | [`Mi355xOcr`]                       | `oar_ocr_*`               |
+//! | (no counterpart: one process per GPU)             | [`shard`]                           | `oar_shard_range`, `oar_ocr_pack`, `oar_packed_merge` |
 //!
 //! The build image of the backend repository has no Rust toolchain: this crate is source-only there, checked
 //! lexically against the `-sys` crate (every `sys::` item it names exists) by `tests/test_rust_bindings_cpu.py`.
@@ -29,6 +30,7 @@ pub mod orientation;
 pub mod pipeline;
 pub mod rectification;
 pub mod seal_text_detection;
+pub mod shard;
 pub mod text_detection;
 pub mod text_recognition;
 
@@ -42,6 +44,7 @@ pub use orientation::{
 pub use pipeline::{Mi355xOcr, Mi355xOcrBuilder, Mi355xOcrPage, Mi355xOcrRegion};
 pub use rectification::{Mi355xRectifierAdapter, Mi355xRectifierAdapterBuilder};
 pub use seal_text_detection::{Mi355xSealTextDetectionAdapter, Mi355xSealTextDetectionAdapterBuilder};
+pub use shard::{PackedPages, merge_packed, shard_range};
 pub use text_detection::{Mi355xTextDetectionAdapter, Mi355xTextDetectionAdapterBuilder};
 pub use text_recognition::{Mi355xTextRecognitionAdapter, Mi355xTextRecognitionAdapterBuilder};
 

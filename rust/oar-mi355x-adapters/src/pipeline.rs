@@ -338,6 +338,34 @@ pub struct Mi355xOcr {
 }
 
 impl Mi355xOcr {
+    /// One rank's share of a multi-process job (`crate::shard`): `predict` + decode on `images`, the final results (boxes, text
+    /// scores, texts) as ONE blob in `oar_ocr_pack`'s wire format -- what the host ships to rank 0 for `shard::merge_packed`.
+    pub fn predict_packed_blob(&self, images: &[Arc<RgbImage>]) -> Result<Vec<u8>, OCRError> {
+        let batch = ImageBatch::new(images.iter().map(AsRef::as_ref));
+        // SAFETY: an all-zero oar_ocr_result (NULL arrays, zero counts) is a valid "empty" value for the free function.
+        let mut res = OcrResultGuard(unsafe { std::mem::zeroed() });
+        if !batch.is_empty() {
+            // SAFETY: three arrays of batch.len() entries; page buffers outlive the call.
+            let status = unsafe {
+                sys::oar_ocr_predict(self.handle.0.as_ptr(), batch.ptrs.as_ptr(), batch.widths.as_ptr(), batch.heights.as_ptr(), batch.len() as u32, &mut res.0)
+            };
+            check(status).map_err(|e| e.into_adapter_error("OAROCR", format!("predict (pages={})", batch.len())))?;
+        }
+        let mut texts = TextResultGuard::empty();
+        // SAFETY: res is empty or was filled by oar_ocr_predict; texts is a valid out-parameter.
+        let status = unsafe { sys::oar_ocr_decode(self.dict.0.as_ptr(), &res.0, self.rec_score_thresh, &mut texts.0) };
+        check(status).map_err(|e| e.into_adapter_error("OAROCR", "decode".to_string()))?;
+        let (mut blob, mut len) = (std::ptr::null_mut::<u8>(), 0usize);
+        // SAFETY: res / texts describe the same regions; blob / len are valid out-parameters.
+        let status = unsafe { sys::oar_ocr_pack(&res.0, &texts.0, &mut blob, &mut len) };
+        check(status).map_err(|e| e.into_adapter_error("OAROCR", "pack".to_string()))?;
+        // SAFETY: oar_ocr_pack returned len bytes at blob; copied out before the library's buffer is released.
+        let out = unsafe { crate::ffi_util::slice_or_empty(blob as *const u8, len) }.to_vec();
+        // SAFETY: blob came from oar_ocr_pack (or is NULL).
+        unsafe { sys::oar_blob_free(blob) };
+        Ok(out)
+    }
+
     /// `OAROCR::predict(images)` (ocr.rs:518-659): one entry per input page, regions in reading order.
     pub fn predict(&self, images: &[Arc<RgbImage>]) -> Result<Vec<Mi355xOcrPage>, OCRError> {
         if images.is_empty() {

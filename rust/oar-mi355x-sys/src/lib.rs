@@ -226,6 +226,18 @@ pub struct oar_word_boxes {
 
 #[repr(C)]
 #[derive(Debug, Clone, Copy)]
+pub struct oar_packed_pages {
+    pub n_images: u32,
+    pub n_regions: u32,
+    pub region_offsets: *mut u32,
+    pub points: *mut f32,
+    pub scores: *mut f32,
+    pub text_offsets: *mut u64,
+    pub utf8: *mut c_char,
+}
+
+#[repr(C)]
+#[derive(Debug, Clone, Copy)]
 pub struct oar_cls_cfg {
     pub device_id: i32,
     pub input_h: u32,
@@ -336,6 +348,11 @@ unsafe extern "C" {
     pub fn oar_char_positions_to_word_boxes(line_pts_xy: *const f32, n_points: u32, char_positions: *const f32, n_positions: u32, char_count: u32, boxes: *mut f32, cap_boxes: u32, n_boxes: *mut u32) -> oar_status;
     pub fn oar_ocr_word_boxes(res: *const oar_ocr_result, txt: *const oar_text_result, out: *mut oar_word_boxes) -> oar_status;
     pub fn oar_word_boxes_free(w: *mut oar_word_boxes);
+    pub fn oar_shard_range(n_items: u64, world_size: u32, rank: u32, begin: *mut u64, end: *mut u64) -> oar_status;
+    pub fn oar_ocr_pack(res: *const oar_ocr_result, txt: *const oar_text_result, blob: *mut *mut u8, len: *mut usize) -> oar_status;
+    pub fn oar_blob_free(blob: *mut u8);
+    pub fn oar_packed_merge(blobs: *const *const u8, lens: *const usize, n_blobs: u32, out: *mut oar_packed_pages) -> oar_status;
+    pub fn oar_packed_pages_free(p: *mut oar_packed_pages);
     pub fn oar_cls_create(onnx: *const u8, onnx_len: usize, cfg: *const oar_cls_cfg, out: *mut *mut oar_cls) -> oar_status;
     pub fn oar_cls_destroy(c: *mut oar_cls);
     pub fn oar_cls_run(c: *mut oar_cls, rgb: *const *const u8, widths: *const u32, heights: *const u32, n_images: u32, out: *mut oar_cls_result) -> oar_status;
