@@ -520,6 +520,32 @@ void Engine::rewrite_graph(OnnxModel& m) {
         for (int i = 0; i < (int)nodes.size(); ++i) if (!dead[i]) keep.push_back(std::move(nodes[i]));
         nodes.swap(keep);
     }
+    // ---- pass 9: the squeeze of a squeeze-excite block from the depthwise conv's own epilogue: GlobalAveragePool(dw conv output) is
+    // dropped and its output becomes a second output of the conv node (conv_dw_tiled_kernel<..., GAP> writes per-tile sums,
+    // global_avgpool_finish reduces them: the feature map is not read a second time).  op_conv pools separately when the launched
+    // depthwise variant has no pooled form.  OAR_FUSE_SE_POOL=0 keeps the GlobalAveragePool.
+    {
+        const char* fe = getenv("OAR_FUSE_SE_POOL");
+        const bool fuse = !fe || atoi(fe) != 0;
+        std::map<std::string, int> producer;
+        for (int i = 0; i < (int)nodes.size(); ++i) for (auto& o : nodes[i].out) producer[o] = i;
+        std::vector<bool> dead(nodes.size(), false);
+        for (int i = 0; fuse && i < (int)nodes.size(); ++i) {
+            const GNode& gp = nodes[i];
+            if (gp.op != "GlobalAveragePool" || gp.in.size() != 1 || graph_outs.count(gp.out[0])) continue;
+            auto pit = producer.find(gp.in[0]);
+            if (pit == producer.end() || pit->second > i) continue;
+            GNode& d = nodes[pit->second];
+            if (d.op != "Conv" || d.out.size() != 1 || d.in.size() < 2 || d.in.size() > 3 || !is_init(d.in[1]) || !d.residual.empty()) continue;
+            const HostTensor& wd = inits_[d.in[1]];
+            if (wd.dims.size() != 4 || wd.dims[1] != 1 || d.ai("group", 1) != wd.dims[0] || wd.dims[0] < 8) continue;   // depthwise
+            d.out.push_back(gp.out[0]);
+            dead[i] = true;
+        }
+        std::vector<GNode> keep;
+        for (int i = 0; i < (int)nodes.size(); ++i) if (!dead[i]) keep.push_back(std::move(nodes[i]));
+        nodes.swap(keep);
+    }
     for (int i = 0; i < (int)nodes.size(); ++i) nodes[i].id = i;
     nodes_ = std::move(nodes);
 }
@@ -1280,12 +1306,33 @@ struct Planner {
         const bool has_gate = gate.kind != Loc::NONE;
         double flops = 2.0 * N * Ho * Wo * Cout * (Cin / g) * kh * kw;
         double bytes = 4.0 * (N * H * Wd * Cin + N * Ho * Wo * Cout * (has_res ? 2 : 1) + numel(W.dims));
+        if (n.out.size() > 1) {   // rewrite pass 9: out[1] = GlobalAveragePool(out[0])
+            const int tiles = kind == 1 ? k::conv_dw_gap_tiles(p) : 0;
+            if (tiles > 0 && Cout <= 1024) {
+                TInfo& gy = new_out(n.out[1], {N, Cout, 1, 1}, Layout::CLAST);
+                const Loc gl = gy.loc, part = alloc_temp((size_t)N * tiles * Cout * sizeof(float));
+                const int hw = (int)(Ho * Wo);
+                step([=](const RunCtx& c) {
+                    k::ConvP q = p;
+                    q.x = c.at(xin); q.y = c.mut(yl); q.residual = has_res ? c.at(res) : nullptr; q.gap_part = c.mut(part);
+                    k::conv_dw(c.s, q);
+                }, flops, bytes + 4.0 * N * tiles * Cout);
+                step([=](const RunCtx& c) { k::global_avgpool_finish(c.s, c.at(part), c.mut(gl), (int)N, tiles, (int)Cout, hw); }, 0, 4.0 * N * tiles * Cout);
+                return;
+            }
+        }
         auto run = [=](const RunCtx& c) {
             k::ConvP q = p;
             q.x = c.at(xin); q.y = c.mut(yl); q.residual = has_res ? c.at(res) : nullptr; q.se = has_gate ? c.at(gate) : nullptr;
             if (kind == 0) k::conv_igemm(c.s, q);
             else if (kind == 1) k::conv_dw(c.s, q);
             else k::conv_direct(c.s, q);
+        };
+        auto pool_after = [&]() {   // the pooled output without a pooled kernel variant: an ordinary GlobalAveragePool of out[0]
+            if (n.out.size() < 2) return;
+            GNode gp;
+            gp.op = "GlobalAveragePool"; gp.in = {n.out[0]}; gp.out = {n.out[1]};
+            op_gap(gp);
         };
         // a 1 x k convolution over a one-row map is a product over the rows of each sample: chainable (chain.hip)
         if (kind == 0 && !has_gate && H == 1 && Ho == 1 && kh == 1 && pt == 0 && pb == 0 && sw == 1 && dw == 1 && Wo == Wd && Cin % 16 == 0 && Cout % 16 == 0 && k::chain_act_ok(n.act.kind) &&
@@ -1300,9 +1347,11 @@ struct Planner {
             const HostTensor* Wp = &W;
             r.make_w = [Wp]() { return chain_weight_conv(*Wp); };
             step_chainable(run, std::move(r), flops, bytes);
+            pool_after();
             return;
         }
         step(run, flops, bytes);
+        pool_after();
     }
 
     // fused depthwise-separable block (rewrite pass 7)

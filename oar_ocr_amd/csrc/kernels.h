@@ -31,6 +31,8 @@ struct ConvP {
     float* ctc_part;        // igemm only, Linear feeding the fused CTC tail: softmax partials [rows][ctc_tiles()] float4
     int ctc_valid;          //   instead of logits (y is not written); ctc_valid = number of real classes
     const float* se;        // igemm only (bf16x6 weight-stationary 1x1): squeeze-excite gate [N][Cin] multiplied into the input on load
+    float* gap_part;        // depthwise only (conv_dw_gap_tiles(p) > 0): per-tile sums of the activated output, [N][tiles][Cout] -- the squeeze of an
+                            // SE block without a second read of the feature map (global_avgpool_finish reduces them)
 };
 enum : int { IGEMM_W_K16 = 0, IGEMM_W_X6 = 1 };
 
@@ -46,6 +48,10 @@ int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin = 0);
 bool conv_igemm_se_ok(long M, int K, int N, int hw);   // Cin: input channels of a k x k conv (0: treat as not eligible for the x6 path)
 // Depthwise conv. w: [kh][kw][C]. C % 4 == 0.
 void conv_dw(hipStream_t s, const ConvP& p);
+// tiles per image of the variant conv_dw will launch for p when it can also emit ConvP::gap_part (0: it cannot -- pool separately)
+int conv_dw_gap_tiles(const ConvP& p);
+// mean over the feature map from conv_dw's per-tile sums: y[n][c] = (sum over tiles of part[n][t][c]) / hw, fixed order
+void global_avgpool_finish(hipStream_t s, const float* part, float* y, int N, int tiles, int C, int hw);
 // Direct conv for everything else (small Cin, odd channels, grouped). w: [kh][kw][Cin/g][Cout].
 void conv_direct(hipStream_t s, const ConvP& p);
 // RGB stem with the page normalisation folded in: the stem reads the u8 HWC pages themselves and computes

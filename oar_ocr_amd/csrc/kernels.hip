@@ -25,7 +25,7 @@ namespace k {
 // the window is loaded once ((TW-1)*S + K float4s) and reused by all TW outputs, cutting the load count per output
 // from K*K to K*((TW-1)*S+K)/TW.  Lanes run along channels first, so a wave reads/writes whole 16-byte-per-lane
 // contiguous NHWC segments.  Weights [kh][kw][C].
-template <int K, int SH, int S, int TW, int TH>
+template <int K, int SH, int S, int TW, int TH, bool GAP = false>
 __global__ __launch_bounds__(256) void conv_dw_tiled_kernel(ConvP p) {
     // One thread = 4 channels x TH output rows x TW output columns.  Every input row of the (TH-1)*SH+K row window is
     // loaded once ((TW-1)*S+K float4s) and feeds every output row it overlaps; the K*K*C weights sit in LDS (their own
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void conv_dw_tiled_kernel(ConvP p) {
                 }
             }
         }
+        float4 tsum = make_float4(0.f, 0.f, 0.f, 0.f);   // GAP: this tile's sum of the activated outputs (rows, then columns: fixed order)
 #pragma unroll
         for (int tr = 0; tr < TH; ++tr) {
             if (oh0 + tr >= p.Ho) break;
@@ -97,8 +98,10 @@ __global__ __launch_bounds__(256) void conv_dw_tiled_kernel(ConvP p) {
                 v.x = apply_act(v.x, p.act.kind, p.act.alpha, p.act.beta); v.y = apply_act(v.y, p.act.kind, p.act.alpha, p.act.beta);
                 v.z = apply_act(v.z, p.act.kind, p.act.alpha, p.act.beta); v.w = apply_act(v.w, p.act.kind, p.act.alpha, p.act.beta);
                 *reinterpret_cast<float4*>(p.y + o) = v;
+                if (GAP) { tsum.x += v.x; tsum.y += v.y; tsum.z += v.z; tsum.w += v.w; }
             }
         }
+        if (GAP) reinterpret_cast<float4*>(p.gap_part)[((n * htiles + ht) * (long)wtiles + wt) * C4 + c4] = tsum;
     }
 }
 
@@ -142,9 +145,30 @@ static inline unsigned grid_for(long work, int block = 256, long cap = 256L * 32
     return (unsigned)g;
 }
 
+namespace {
+constexpr int kDwTW = 4;
+// output rows per thread: the tallest tile that still leaves >= 4 resident workgroups' worth of threads per CU
+int dw_tile_rows(const ConvP& p) {
+    auto threads_for = [&](int th) { return (long)p.N * ((p.Ho + th - 1) / th) * ((p.Wo + kDwTW - 1) / kDwTW) * (p.Cout / 4); };
+    return threads_for(2) >= 256L * 256 * 4 ? 2 : 1;   // (4 rows per thread measured slower on the 5x5 layers: 134 vs 112 us)
+}
+bool dw_tiled_shape(const ConvP& p) {
+    const bool sq = p.kh == p.kw && p.dh == 1 && p.dw == 1;
+    return sq && (p.kh == 3 || p.kh == 5) && (p.sh == 1 || p.sh == 2) && (p.sw == 1 || p.sw == 2) && (size_t)p.kh * p.kw * p.Cout * sizeof(float) <= 96 * 1024;
+}
+}  // namespace
+
+// the pooled variant is instantiated for the 5 x 5 kernels (where PP-LCNet puts its squeeze-excite blocks)
+int conv_dw_gap_tiles(const ConvP& p) {
+    if (!dw_tiled_shape(p) || p.kh != 5 || (p.Cout & 3) || p.N <= 0 || p.Ho <= 0 || p.Wo <= 0) return 0;
+    const int th = dw_tile_rows(p);
+    return ((p.Ho + th - 1) / th) * ((p.Wo + kDwTW - 1) / kDwTW);
+}
+
 void conv_dw(hipStream_t s, const ConvP& p) {
     long total = (long)p.N * p.Ho * p.Wo * (p.Cout / 4);
     if (total == 0) return;
+    OAR_CHECK(!p.gap_part || conv_dw_gap_tiles(p) > 0, OAR_INTERNAL, "conv_dw: pooled output on a shape without that variant");
     double bytes = 4.0 * ((double)p.N * p.H * p.W * p.Cin + (double)p.N * p.Ho * p.Wo * p.Cout + (double)p.kh * p.kw * p.Cout);
     double flops = 2.0 * (double)p.N * p.Ho * p.Wo * p.Cout * p.kh * p.kw;
     char pname[96];
@@ -152,12 +176,9 @@ void conv_dw(hipStream_t s, const ConvP& p) {
     if (Profiler::get().detail) { snprintf(pname, sizeof pname, "conv_dw px=%ld C=%d k%d s%d", (long)p.N * p.Ho * p.Wo, p.Cout, p.kh, p.sh); cls = pname; }
     ProfScope ps(s, cls, bytes, flops, /*single_launch=*/true);
     const bool sq = p.kh == p.kw && p.dh == 1 && p.dw == 1;
-    constexpr int TW = 4;
-    // output rows per thread: the tallest tile that still leaves >= 4 resident workgroups' worth of threads per CU
+    constexpr int TW = kDwTW;
     auto threads_for = [&](int th) { return (long)p.N * ((p.Ho + th - 1) / th) * ((p.Wo + TW - 1) / TW) * (p.Cout / 4); };
-    const long want = 256L * 256 * 4;
-    int TH = 1;
-    if (threads_for(2) >= want) TH = 2;   // (4 rows per thread measured slower on the 5x5 layers: 134 vs 112 us)
+    const int TH = dw_tile_rows(p);
     long tiled = threads_for(TH);
     dim3 g((grid_for(tiled) + 7) / 8 * 8), b(256);
     const size_t lds = (size_t)p.kh * p.kw * p.Cout * sizeof(float);
@@ -175,11 +196,33 @@ void conv_dw(hipStream_t s, const ConvP& p) {
         }                                                                                                                                                   \
         hipExtLaunchKernelGGL((conv_dw_tiled_kernel<KV, SHV, SWV, TW, THV>), g, b, lds, s, ps.start(), ps.stop(), 0, p);                                    \
     } while (0)
+#define DW2G(KV, SHV, SWV, THV)                                                                                                                             \
+    do {                                                                                                                                                    \
+        if (lds > 64 * 1024) {                                                                                                                              \
+            static const bool once = [] {                                                                                                                   \
+                OAR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dw_tiled_kernel<KV, SHV, SWV, TW, THV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); \
+                return true;                                                                                                                                \
+            }();                                                                                                                                            \
+            (void)once;                                                                                                                                     \
+        }                                                                                                                                                   \
+        hipExtLaunchKernelGGL((conv_dw_tiled_kernel<KV, SHV, SWV, TW, THV, true>), g, b, lds, s, ps.start(), ps.stop(), 0, p);                              \
+    } while (0)
+#define DWG(KV, SHV, SWV)                                  \
+    do {                                                   \
+        if (TH == 2) DW2G(KV, SHV, SWV, 2);                \
+        else DW2G(KV, SHV, SWV, 1);                        \
+    } while (0)
 #define DW(KV, SHV, SWV)                                   \
     do {                                                   \
         if (TH == 2) DW2(KV, SHV, SWV, 2);                 \
         else DW2(KV, SHV, SWV, 1);                         \
     } while (0)
+    if (p.gap_part) {   // (conv_dw_gap_tiles said yes: 5 x 5, strides 1 / 2)
+        if (p.sh == 1 && p.sw == 1) DWG(5, 1, 1);
+        else if (p.sh == 2 && p.sw == 2) DWG(5, 2, 2);
+        else if (p.sh == 2 && p.sw == 1) DWG(5, 2, 1);
+        else DWG(5, 1, 2);
+    } else
     if (fits && sq && p.kh == 3 && p.sh == 1 && p.sw == 1) DW(3, 1, 1);
     else if (fits && sq && p.kh == 3 && p.sh == 2 && p.sw == 2) DW(3, 2, 2);
     else if (fits && sq && p.kh == 3 && p.sh == 2 && p.sw == 1) DW(3, 2, 1);
@@ -191,6 +234,8 @@ void conv_dw(hipStream_t s, const ConvP& p) {
     else hipExtLaunchKernelGGL(conv_dw_kernel, dim3(grid_for(total)), b, 0, s, ps.start(), ps.stop(), 0, p);
 #undef DW2
 #undef DW
+#undef DW2G
+#undef DWG
 }
 
 // ------------------------------------------------------------------------------------------ small-Cin conv (network stems)
@@ -568,6 +613,14 @@ void global_avgpool(hipStream_t s, const float* x, float* y, int N, int HW, int 
     } else {
         hipLaunchKernelGGL(global_avgpool_scalar_kernel, dim3((C + 255) / 256, N), dim3(256), 0, s, x, y, HW, C);
     }
+}
+
+void global_avgpool_finish(hipStream_t s, const float* part, float* y, int N, int tiles, int C, int hw) {
+    if (N == 0 || C == 0) return;
+    OAR_CHECK((C & 3) == 0 && C <= 1024 && tiles > 0, OAR_INTERNAL, "global_avgpool_finish: channel count");
+    ProfScope ps(s, "global_avgpool", 4.0 * ((double)N * tiles * C + (double)N * C), (double)N * tiles * C);
+    const int C4 = C >> 2, parts = std::max(1, 256 / C4);
+    hipLaunchKernelGGL(global_avgpool_kernel, dim3(N), dim3(256), (size_t)parts * C4 * sizeof(float4), s, part, y, tiles, C, 1, (float)hw);
 }
 
 // ------------------------------------------------------------------------------------------ resize

@@ -695,3 +695,49 @@ def test_squeeze_excite_scale_rides_on_the_pointwise_conv(monkeypatch):
     assert np.abs(got - ref).max() <= TOL
     det, _ = models.build_det("tiny", seed=0)
     _check(det, np.random.default_rng(5).standard_normal((2, 3, 320, 480)).astype(np.float32))
+
+
+def test_squeeze_excite_pool_comes_from_the_depthwise_epilogue(monkeypatch):
+    """GlobalAveragePool(depthwise conv) (the squeeze of an SE block): the 5 x 5 depthwise kernel writes per-tile sums of its activated
+    output and `global_avgpool_finish` reduces them (engine.cc pass 9) -- the feature map is not read a second time.  Same numbers as the
+    oracle, equal to the separate pool to f32 rounding (another summation order: tile sums first), argmax unchanged; 3 x 3 depthwise
+    convs (no pooled variant) pool separately."""
+    rec, _ = models.build_rec("tiny", vocab=6906, seed=1)
+    x = np.random.default_rng(78).standard_normal((160, 3, 48, 200)).astype(np.float32)
+    monkeypatch.setenv("OAR_FUSE_SE_POOL", "0")
+    plain_eng = api.OrtInfer(rec, profile=True)
+    api.prof_enable(True); api.prof_reset()
+    plain = plain_eng.infer(x)[0][1]
+    before = {e["name"]: e["launches"] for e in api.prof_snapshot()}
+    monkeypatch.delenv("OAR_FUSE_SE_POOL")
+    eng = api.OrtInfer(rec, profile=True)
+    api.prof_reset()
+    got = eng.infer(x)[0][1]
+    snap = {e["name"]: e["launches"] for e in api.prof_snapshot()}
+    api.prof_enable(False)
+    assert snap.get("global_avgpool", 0) == before.get("global_avgpool", 0) and snap.get("conv_dw", 0) == before.get("conv_dw", 0), (before, snap)   # (the finish pass keeps the class name)
+    assert np.abs(got - plain).max() <= 2e-5 and np.array_equal(got.argmax(-1), plain.argmax(-1))
+    ref = onnx_ref.run(rec, {eng.input_name(): x})[0]
+    assert np.abs(got - ref).max() <= TOL
+    # a 3 x 3 depthwise conv under a pool: no pooled kernel variant, the planner pools separately
+    rng = np.random.default_rng(12)
+
+    def build(g):
+        g.add_input("x", ["N", 16, "H", "W"])
+        d = g.op("Conv", ["x", g.init(rng.standard_normal((16, 1, 3, 3)).astype(np.float32) * 0.3), g.init(rng.standard_normal(16).astype(np.float32) * 0.1)],
+                 kernel_shape=[3, 3], strides=[1, 1], pads=[1, 1, 1, 1], group=16, dilations=[1, 1])
+        d = g.op("Relu", [d])
+        p = g.op("GlobalAveragePool", [d])
+        return g.op("Mul", [d, p]), ["N", 16, "H", "W"]
+
+    _check(_single_op_graph(build), rng.standard_normal((3, 16, 20, 28)).astype(np.float32))
+    # and a 5 x 5 one, stride 2, odd sizes (partial tiles at the right / bottom edge)
+    def build5(g):
+        g.add_input("x", ["N", 24, "H", "W"])
+        d = g.op("Conv", ["x", g.init(rng.standard_normal((24, 1, 5, 5)).astype(np.float32) * 0.2), g.init(rng.standard_normal(24).astype(np.float32) * 0.1)],
+                 kernel_shape=[5, 5], strides=[2, 2], pads=[2, 2, 2, 2], group=24, dilations=[1, 1])
+        d = g.op("HardSwish", [d])
+        p = g.op("GlobalAveragePool", [d])
+        return g.op("Mul", [d, p]), ["N", 24, "H", "W"]
+
+    _check(_single_op_graph(build5), rng.standard_normal((5, 24, 37, 51)).astype(np.float32))
