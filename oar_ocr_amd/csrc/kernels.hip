@@ -292,10 +292,11 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvP p) {
 
 // The same kernel fed by u8 pages (StemU8, kernels.h): tap value = (float)byte * alpha + beta, two separate f32 operations
 // exactly as pp::normalize computes them; out-of-image taps contribute nothing (the conv zero-pads the NORMALISED tensor).
-template <bool CRNN>
+template <bool CRNN, bool K3>
 __global__ __launch_bounds__(256) void conv_smallcin_u8_kernel(ConvP p, StemU8 st) {
     __shared__ float ws[128 * 16];
     __shared__ float lut[CRNN ? 256 : 1];
+    __shared__ float ot[4 * 64 * 17];   // per-wave output transposition slabs (see the store below)
     const int K = p.kh * p.kw * 3;
     const int co0 = blockIdx.y * 16;
     for (int i = threadIdx.x; i < K * 16; i += 256) {
@@ -311,35 +312,44 @@ __global__ __launch_bounds__(256) void conv_smallcin_u8_kernel(ConvP p, StemU8 s
     const int n = blockIdx.z;
     const uint8_t* __restrict__ pg = CRNN ? st.dev[n].ptr : st.pages[n];
     const int img_w = CRNN ? st.dev[n].w : p.W;   // the image's own row length: taps past it are padding
-    for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < per_image; pix += (long)gridDim.x * blockDim.x) {
-        const int ow = (int)(pix % p.Wo), oh = (int)(pix / p.Wo);
+    // (the loop condition is the WAVE's first pixel: a wave stays together for the LDS transposition of its stores; lanes past the
+    // image's last pixel compute the last pixel again and store nothing)
+    for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix - (threadIdx.x & 63) < per_image; pix += (long)gridDim.x * blockDim.x) {
+        const bool live = pix < per_image;
+        const long pixc = live ? pix : per_image - 1;
+        const int ow = (int)(pixc % p.Wo), oh = (int)(pixc / p.Wo);
         float acc[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) acc[c] = (p.bias && co0 + c < p.Cout) ? p.bias[co0 + c] : 0.f;
-        for (int a = 0; a < p.kh; ++a) {
-            const int ih = oh * p.sh - p.pt + a * p.dh;
-            if (ih < 0 || ih >= p.H) continue;
-            for (int b = 0; b < p.kw; ++b) {
-                const int iw = ow * p.sw - p.pl + b * p.dw;
-                if (iw < 0 || iw >= img_w) continue;
-                const uint8_t* xp = pg + ((long)ih * img_w + iw) * 3;
-                const float* wp = ws + (a * p.kw + b) * 3 * 16;
-                float x0, x1, x2;
-                if (CRNN) {
-                    x0 = lut[xp[s0]]; x1 = lut[xp[s1]]; x2 = lut[xp[s2]];
-                } else {
-                    const float t0 = (float)xp[s0] * a0, t1 = (float)xp[s1] * a1, t2 = (float)xp[s2] * a2;
-                    x0 = t0 + b0; x1 = t1 + b1; x2 = t2 + b2;
-                }
-#pragma unroll
-                for (int c = 0; c < 16; ++c) acc[c] = fmaf(x0, wp[c], acc[c]);
-#pragma unroll
-                for (int c = 0; c < 16; ++c) acc[c] = fmaf(x1, wp[16 + c], acc[c]);
-#pragma unroll
-                for (int c = 0; c < 16; ++c) acc[c] = fmaf(x2, wp[32 + c], acc[c]);
+        auto tap = [&](int a, int b, int kw) __attribute__((always_inline)) {
+            const int ih = oh * p.sh - p.pt + a * p.dh, iw = ow * p.sw - p.pl + b * p.dw;
+            if (ih < 0 || ih >= p.H || iw < 0 || iw >= img_w) return;
+            const uint8_t* xp = pg + ((long)ih * img_w + iw) * 3;
+            const float* wp = ws + (a * kw + b) * 3 * 16;
+            float x0, x1, x2;
+            if (CRNN) {
+                x0 = lut[xp[s0]]; x1 = lut[xp[s1]]; x2 = lut[xp[s2]];
+            } else {
+                const float t0 = (float)xp[s0] * a0, t1 = (float)xp[s1] * a1, t2 = (float)xp[s2] * a2;
+                x0 = t0 + b0; x1 = t1 + b1; x2 = t2 + b2;
             }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[c] = fmaf(x0, wp[c], acc[c]);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[c] = fmaf(x1, wp[16 + c], acc[c]);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[c] = fmaf(x2, wp[32 + c], acc[c]);
+        };
+        if (K3) {   // the 3 x 3 stems of both networks: compile-time trip counts (the nine taps' loads can all be in flight; same order of the FMAs)
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) tap(a, b, 3);
+        } else {
+            for (int a = 0; a < p.kh; ++a)
+                for (int b = 0; b < p.kw; ++b) tap(a, b, p.kw);
         }
-        const long opix = (long)n * per_image + pix;
+        const long opix = (long)n * per_image + pixc;
         float* o = p.y + opix * p.y_ld + co0;
         const bool vec = (co0 + 16 <= p.Cout) && ((p.y_ld & 3) == 0);
 #pragma unroll
@@ -348,9 +358,27 @@ __global__ __launch_bounds__(256) void conv_smallcin_u8_kernel(ConvP p, StemU8 s
             acc[c] = apply_act(acc[c], p.act.kind, p.act.alpha, p.act.beta);
         }
         if (vec) {
+            // A lane's 16 channels are 64 contiguous bytes, but lane-by-lane that is four store instructions of 16 bytes at a 64-byte
+            // stride: every one of them touches all 32 cache lines of the wave's 4 KB partially.  The wave's 64 pixels are consecutive,
+            // so its 256 float4s go through LDS (a wave's own 64 x 17-float slab: no barrier, the LDS unit serves a wave's accesses in
+            // order) and leave as four fully coalesced 1 KB stores.
+            float* slab = ot + (threadIdx.x >> 6) * (64 * 17);
+            const int lane = threadIdx.x & 63;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(o + q * 4) = make_float4(acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]);
-        } else {
+            for (int c = 0; c < 16; ++c) slab[lane * 17 + c] = acc[c];
+            __builtin_amdgcn_wave_barrier();
+            const long pix_w0 = pix - lane;                               // the wave's first pixel (its lanes hold pix_w0 .. pix_w0 + 63)
+            float* ow_ = p.y + ((long)n * per_image + pix_w0) * p.y_ld + co0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = j * 64 + lane, px = e >> 2, qd = e & 3;
+                if (pix_w0 + px < per_image) {
+                    const float* sp = slab + px * 17 + qd * 4;
+                    *reinterpret_cast<float4*>(ow_ + (long)px * p.y_ld + qd * 4) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else if (live) {
             for (int c = 0; c < 16 && co0 + c < p.Cout; ++c) o[c] = acc[c];
         }
     }
@@ -362,8 +390,9 @@ void conv_smallcin_u8(hipStream_t s, const ConvP& p, const StemU8& st) {
     const double total = (double)p.N * per_image * p.Cout;
     ProfScope ps(s, "conv_smallcin", 3.0 * (double)p.N * p.H * p.W + 4.0 * total, 2.0 * total * p.kh * p.kw * 3);
     const dim3 grid(grid_for(per_image, 256, 256L * 4), (p.Cout + 15) / 16, p.N);
-    if (st.dev) hipLaunchKernelGGL(conv_smallcin_u8_kernel<true>, grid, dim3(256), 0, s, p, st);
-    else hipLaunchKernelGGL(conv_smallcin_u8_kernel<false>, grid, dim3(256), 0, s, p, st);
+    const bool k3 = p.kh == 3 && p.kw == 3;
+    if (st.dev) { if (k3) hipLaunchKernelGGL((conv_smallcin_u8_kernel<true, true>), grid, dim3(256), 0, s, p, st); else hipLaunchKernelGGL((conv_smallcin_u8_kernel<true, false>), grid, dim3(256), 0, s, p, st); }
+    else { if (k3) hipLaunchKernelGGL((conv_smallcin_u8_kernel<false, true>), grid, dim3(256), 0, s, p, st); else hipLaunchKernelGGL((conv_smallcin_u8_kernel<false, false>), grid, dim3(256), 0, s, p, st); }
 }
 
 // ------------------------------------------------------------------------------------------ direct conv (fallback)

@@ -635,6 +635,7 @@ def test_sample_local_chain_matches_oracle_and_the_unfused_path(n, W, mode, monk
     plain_eng = api.OrtInfer(rec, profile=True)
     plain = plain_eng.infer(x)[0][1]
     monkeypatch.setenv("OAR_FUSE_CHAIN", "1")
+    monkeypatch.setenv("OAR_CHAIN_MAX_MFLOP", "1000")   # (the planner's default cap of 32 MFLOP per line would leave the T = 137 case unfused)
     if mode == "arena":
         monkeypatch.setenv("OAR_CHAIN_LDS", "0")
     eng = api.OrtInfer(rec, profile=True)
