@@ -1268,7 +1268,24 @@ struct Planner {
         Loc xin = to_clast_loc(x);
         const float* bias = has_input(n, 2) ? get(n.in[2]).loc.cptr : nullptr;
         Loc res;
+        int res_up = 0;
         if (!n.residual.empty()) {
+            // the other operand of the folded Add is a deferred nearest upsampling by an integer factor (the top-down path of an FPN): the
+            // conv's epilogue reads the low-resolution tensor through the index map -- the upsampled tensor is never written or re-read
+            const char* up_env = getenv("OAR_FUSE_RES_UP");   // (read per plan: the test compares both forms in one process)
+            const bool up_on = !up_env || atoi(up_env) != 0;
+            if (const PendingResize* pr = peek_pending(n.residual)) {
+                const bool f32_tile = g == 1 && Cin % 4 == 0 && Cout % 4 == 0 &&
+                                      k::igemm_weight_format((long)(N * Ho * Wo), (int)(kh * kw * Cin), (int)Cout, kh == 1 && kw == 1 && sh == 1 && sw == 1 && pt == 0 && pl == 0, (int)Cin) == k::IGEMM_W_K16;
+                if (up_on && f32_tile && pr->fh > 1 && pr->fh == pr->fw && pr->N == N && pr->C == Cout && pr->Ho == Ho && pr->Wo == Wo && Ho % pr->fh == 0 && Wo % pr->fw == 0 &&
+                    pr->H * pr->fh == Ho && pr->W * pr->fw == Wo && N * Ho * Wo < ((int64_t)1 << 31)) {
+                    res = pr->xin;
+                    res_up = pr->fh;
+                    pending_resize.erase(n.residual);
+                }
+            }
+        }
+        if (!n.residual.empty() && res_up == 0) {
             TInfo r = get(n.residual);
             if (r.host_int || r.dims != std::vector<int64_t>{N, Cout, Ho, Wo}) {
                 // the folded Add broadcasts: plan the conv and the add separately after all
@@ -1287,7 +1304,7 @@ struct Planner {
         k::ConvP p{};
         p.N = (int)N; p.H = (int)H; p.W = (int)Wd; p.Cin = (int)Cin; p.Ho = (int)Ho; p.Wo = (int)Wo; p.Cout = (int)Cout;
         p.kh = (int)kh; p.kw = (int)kw; p.sh = (int)sh; p.sw = (int)sw; p.pt = (int)pt; p.pl = (int)pl; p.dh = (int)dh; p.dw = (int)dw;
-        p.groups = (int)g; p.act = n.act; p.bias = bias; p.y_ld = (int)Cout; p.convt2x2 = 0;
+        p.groups = (int)g; p.act = n.act; p.bias = bias; p.y_ld = (int)Cout; p.convt2x2 = 0; p.res_up = res_up;
         int kind;  // 0 igemm, 1 dw, 2 direct
         if (g == 1 && Cin % 4 == 0) {
             kind = 0;

@@ -268,6 +268,7 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     p.convt = c.convt2x2; p.Cout = c.Cout;
     p.ctc_part = c.ctc_part; p.ctc_valid = c.ctc_valid;
     p.se = c.se; p.se_hw = c.Ho * c.Wo;
+    p.res_up = c.residual ? c.res_up : 0;
     if (c.convt2x2) {
         p.Ho = c.H; p.Wo = c.W;  // GEMM columns are INPUT pixels
         p.M = (long)c.N * c.H * c.W; p.K = c.Cin; p.gemm_cout = 4 * c.Cout;
@@ -308,7 +309,9 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     // on the long-K 3x3 convs; small-M / tiny-K layers stay on the per-tile kernel
     const long wave_tile_passes = ((p.M + 15) / 16) * ((nfrag + 7) / 8);   // (16-pixel tile, 128-cout tile) pairs
     const bool ws_auto = (p.gemm_cout >= ws_min_n && wave_tile_passes >= 4096) || (p.K >= 512 && p.M >= 262144);
-    if (!x6 && vec_ok && p.KC >= 2 && ws_mode != 0 && (ws_mode == 1 || ws_auto)) {
+    const bool res_up = p.res_up > 1;   // the upsampled residual lives in the per-tile kernels' epilogue only
+    OAR_CHECK(!res_up || (!x6 && !c.convt2x2 && p.M < (1L << 31) && c.Ho % p.res_up == 0 && c.Wo % p.res_up == 0), OAR_INTERNAL, "conv_igemm: upsampled residual on an ineligible layer");
+    if (!x6 && !res_up && vec_ok && p.KC >= 2 && ws_mode != 0 && (ws_mode == 1 || ws_auto)) {
         static const int max_nt = [] { const char* e = getenv("OAR_IGEMM_WS_MAXNT"); return e ? atoi(e) : 8; }();
         const int cand[6] = {8, 6, 4, 3, 2, 1};
         int best = 1 << 30;
@@ -322,7 +325,7 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
         OAR_CHECK(vec_ok && is1x1 && (x6 ? ctc_partials_supported_x6(p.K) : ctc_partials_supported(p.K)), OAR_INTERNAL, "conv_igemm: CTC partials on an ineligible layer");
         ws_nt = 8;
     }
-    const bool ws3 = !x6 && !c.ctc_part && conv_igemm_ws3_eligible(p, nfrag);
+    const bool ws3 = !x6 && !res_up && !c.ctc_part && conv_igemm_ws3_eligible(p, nfrag);
     const bool ws = ws_nt > 0 || ws3;
     // launches of at most `small_max` wave tiles are latency-bound: the deep-prefetch variant (OAR_IGEMM_SMALL=0 disables)
     static const long small_max = [] { const char* e = getenv("OAR_IGEMM_SMALL"); return e ? atol(e) : 4096L; }();

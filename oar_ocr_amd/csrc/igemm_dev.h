@@ -47,9 +47,19 @@ struct IgemmP {
     float alpha, beta;
     float* ctc_part;     // != null (weight-stationary f32 kernel only): no logits are stored; per (row, cout tile) the
     int ctc_valid;       // softmax partials {max, sum exp(x - max), last arg max} over the tile's valid columns go here
+    int res_up;          // > 1 (per-tile f32 kernels only): res is the low-resolution operand of an FPN sum, read at (h / res_up, w / res_up)
     const float* se;     // != null (bf16x6 weight-stationary kernel only): gate [image][K] multiplied into x on load
     int se_hw;           // pixels per image (se row of pixel m = m / se_hw)
 };
+
+// element offset of the residual for output pixel `opix`, channel co: the same pixel, or -- res_up > 1 -- pixel (h / f, w / f) of the
+// [N][Ho / f][Wo / f][Cout] low-resolution tensor (M < 2^31 checked by the host: 32-bit divisions)
+__device__ __forceinline__ long igemm_res_off(const IgemmP& p, long opix, int co) {
+    if (p.res_up <= 1) return opix * p.y_ld + co;
+    const unsigned hw = (unsigned)(p.Ho * p.Wo), m = (unsigned)opix, f = (unsigned)p.res_up;
+    const unsigned n = m / hw, r = m - n * hw, h = r / (unsigned)p.Wo, w = r - h * (unsigned)p.Wo;
+    return (((long)n * (p.Ho / p.res_up) + h / f) * (long)(p.Wo / p.res_up) + w / f) * p.Cout + co;
+}
 
 __device__ __forceinline__ void igemm_store(const IgemmP& p, f32x4 v, bool valid, long obase, int c, bool vec_ok, bool add_bias = true) {
     if (!valid || c >= p.gemm_cout) return;
@@ -59,7 +69,7 @@ __device__ __forceinline__ void igemm_store(const IgemmP& p, f32x4 v, bool valid
         if (p.convt) { int ab = c / p.Cout; co = c - ab * p.Cout; opix = obase + (long)(ab >> 1) * (2L * p.Wo) + (ab & 1); }
         if (p.bias && add_bias) { float4 bv = *reinterpret_cast<const float4*>(p.bias + co); o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w; }
         float* dst = p.y + opix * p.y_ld + co;
-        if (p.res) { float4 rv = *reinterpret_cast<const float4*>(p.res + opix * p.y_ld + co); o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w; }
+        if (p.res) { float4 rv = *reinterpret_cast<const float4*>(p.res + igemm_res_off(p, opix, co)); o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w; }
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = apply_act(o[r], p.act, p.alpha, p.beta);
         *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
@@ -72,7 +82,7 @@ __device__ __forceinline__ void igemm_store(const IgemmP& p, f32x4 v, bool valid
             if (p.convt) { int ab = cc / p.Cout; co = cc - ab * p.Cout; opix = obase + (long)(ab >> 1) * (2L * p.Wo) + (ab & 1); }
             float t = o[r];
             if (p.bias && add_bias) t += p.bias[co];
-            if (p.res) t += p.res[opix * p.y_ld + co];
+            if (p.res) t += p.res[igemm_res_off(p, opix, co)];
             p.y[opix * p.y_ld + co] = apply_act(t, p.act, p.alpha, p.beta);
         }
     }
@@ -130,7 +140,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[NT]
 #pragma clang loop unroll(full)
         for (int nf = 0; nf < NT; ++nf)
 #pragma clang loop unroll(full)
-            for (int pf = 0; pf < PF; ++pf) { bool cv; int co; rv[nf][pf] = *reinterpret_cast<const float4*>(p.res + coff(nf, pf, cv, co)); }
+            for (int pf = 0; pf < PF; ++pf) {
+                bool cv; int co;
+                long ro = coff(nf, pf, cv, co);
+                if constexpr (!VEC_ONLY) { if (p.res_up > 1) ro = igemm_res_off(p, obase[pf], co); }   // (only the per-tile kernels take an upsampled residual)
+                rv[nf][pf] = *reinterpret_cast<const float4*>(p.res + ro);
+            }
 #pragma clang loop unroll(full)
         for (int nf = 0; nf < NT; ++nf)
 #pragma clang loop unroll(full)

@@ -31,6 +31,8 @@ struct ConvP {
     float* ctc_part;        // igemm only, Linear feeding the fused CTC tail: softmax partials [rows][ctc_tiles()] float4
     int ctc_valid;          //   instead of logits (y is not written); ctc_valid = number of real classes
     const float* se;        // igemm only (bf16x6 weight-stationary 1x1): squeeze-excite gate [N][Cin] multiplied into the input on load
+    int res_up;             // igemm only (f32 per-tile kernels): f > 1 => `residual` is [N][Ho / f][Wo / f][Cout], added through the nearest index map (h / f, w / f)
+                            // -- the top-down sum of an FPN without materialising the upsampled tensor
     float* gap_part;        // depthwise only (conv_dw_gap_tiles(p) > 0): per-tile sums of the activated output, [N][tiles][Cout] -- the squeeze of an
                             // SE block without a second read of the feature map (global_avgpool_finish reduces them)
 };

@@ -742,3 +742,26 @@ def test_squeeze_excite_pool_comes_from_the_depthwise_epilogue(monkeypatch):
         return g.op("Mul", [d, p]), ["N", 24, "H", "W"]
 
     _check(_single_op_graph(build5), rng.standard_normal((5, 24, 37, 51)).astype(np.float32))
+
+
+def test_fpn_sum_reads_the_low_resolution_operand_in_the_conv_epilogue(monkeypatch):
+    """lateral 1 x 1 conv + nearest-upsampled top-down tensor (FPN): the folded Add's other operand is a deferred integer-factor Resize,
+    so the conv's epilogue reads the LOW-resolution tensor at (h / f, w / f) (igemm_res_off; engine.cc op_conv) -- the upsampled tensor
+    is never materialised.  Bit-identical to materialising it (the same f32 add), equal to the oracle; no `resize` launch for the sums."""
+    det, _ = models.build_det("tiny", seed=0)
+    x = np.random.default_rng(3).standard_normal((3, 3, 320, 480)).astype(np.float32)
+    monkeypatch.setenv("OAR_FUSE_RES_UP", "0")
+    e0 = api.OrtInfer(det, profile=True)
+    api.prof_enable(True); api.prof_reset()
+    plain = e0.infer(x)[0][1]
+    before = {e["name"]: e["launches"] for e in api.prof_snapshot()}
+    monkeypatch.delenv("OAR_FUSE_RES_UP")
+    e1 = api.OrtInfer(det, profile=True)
+    api.prof_reset()
+    got = e1.infer(x)[0][1]
+    after = {e["name"]: e["launches"] for e in api.prof_snapshot()}
+    api.prof_enable(False)
+    assert np.array_equal(got, plain)
+    assert after.get("resize", 0) == before.get("resize", 0) - 3, (before, after)     # the three top-down sums
+    ref = onnx_ref.run(det, {e1.input_name(): x})[0]
+    assert np.abs(got - ref).max() <= TOL
