@@ -128,6 +128,13 @@ void Profiler::flush() {
     pending_base += pending.size();
     pending.clear();
 }
+void Profiler::drop_events() {
+    flush();
+    std::lock_guard<std::mutex> lk(mu);
+    for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+    pool.clear();
+    (void)hipGetLastError();   // (results deliberately ignored above: do not leave their error state behind)
+}
 void Profiler::reset() {
     flush();
     std::lock_guard<std::mutex> lk(mu);

@@ -58,8 +58,10 @@ Engine::~Engine() {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     clear_graphs();
+    Profiler::get().drop_events();   // no pooled event may outlive the stream it was recorded on
     for (void* p : dev_allocs_) (void)hipFree(p);
     if (stream_) (void)hipStreamDestroy(stream_);
+    (void)hipGetLastError();
 }
 
 const float* Engine::upload_const(const std::string& key, const std::vector<float>& v) {
@@ -722,6 +724,11 @@ struct Planner {
         P.flops += flops; P.bytes += bytes; P.n_kernels++;
         step_chain.push_back(-1);
         step_node.push_back(cur);
+        static const bool dbg_steps = [] { const char* e = getenv("OAR_DEBUG_STEPS"); return e && atoi(e) != 0; }();
+        if (dbg_steps) {
+            const GNode* g = cur >= 0 && cur < (int)E.nodes_.size() ? &E.nodes_[(size_t)cur] : nullptr;
+            P.step_ops.push_back(g ? g->op + " -> " + (g->out.empty() ? std::string("?") : g->out[0]) : std::string("?"));
+        }
     }
 
     // ------------------------------------------------------------------ sample-local chains (csrc/chain.hip)
@@ -871,7 +878,9 @@ struct Planner {
         std::vector<std::function<void(const RunCtx&)>> out;
         int fused_away = 0;
         int a = 0;
-        auto keep = [&](int i) { out.push_back(std::move(P.steps[(size_t)i])); };
+        std::vector<std::string> out_ops;
+        const bool names = P.step_ops.size() == P.steps.size();
+        auto keep = [&](int i) { out.push_back(std::move(P.steps[(size_t)i])); if (names) out_ops.push_back(P.step_ops[(size_t)i]); };
         while (a < ns) {
             if (step_chain[(size_t)a] < 0) { keep(a++); continue; }
             int b = a;
@@ -1018,6 +1027,7 @@ struct Planner {
                 L.bytes = bytes; L.flops = flops;
                 const int n_ops = hi - lo;
                 out.push_back([L, table, consts](const RunCtx& c) { k::chain_run(c.s, L, c.arena, reinterpret_cast<const char*>(c.input)); });
+                if (names) out_ops.push_back("chain of " + std::to_string(hi - lo) + " steps from " + P.step_ops[(size_t)lo]);
                 fused_away += n_ops - 1;
                 i = hi;
             }
@@ -1025,6 +1035,7 @@ struct Planner {
             a = b;
         }
         P.steps.swap(out);
+        if (names) P.step_ops.swap(out_ops);
         P.n_kernels -= fused_away;
         step_chain.assign(P.steps.size(), -1);
         step_node.assign(P.steps.size(), -1);
@@ -2984,7 +2995,15 @@ const Plan& Engine::run(const float* d_in, const std::vector<int64_t>& dims, boo
     RunCtx c{stream_, d_in, arena_.as<char>()};
     last_input_ = d_in;
     if (!replay(p, c)) {
-        for (auto& st : p.steps) st(c);
+        if (!p.step_ops.empty() && p.step_ops.size() == p.steps.size()) {   // OAR_DEBUG_STEPS=1 (and no chain fusion re-indexing): which step leaves a HIP error behind?
+            for (size_t i = 0; i < p.steps.size(); ++i) {
+                p.steps[i](c);
+                const hipError_t e = hipGetLastError();
+                if (e != hipSuccess) fail(OAR_DEVICE, "HIP error after step " + std::to_string(i) + " (" + p.step_ops[i] + "): " + hipGetErrorString(e));
+            }
+        } else {
+            for (auto& st : p.steps) st(c);
+        }
         ++p.runs;
     }
     OAR_HIP(hipGetLastError());

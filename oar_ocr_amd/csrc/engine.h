@@ -73,6 +73,7 @@ struct PlanOutput {
 
 struct Plan {
     std::vector<std::function<void(const RunCtx&)>> steps;
+    std::vector<std::string> step_ops;   // OAR_DEBUG_STEPS=1: the graph node (op -> first output) behind each step, for error attribution
     size_t arena_bytes = 0;
     std::vector<PlanOutput> outputs;
     double flops = 0, bytes = 0;

@@ -203,6 +203,7 @@ Detector::Detector(const uint8_t* onnx, size_t len, const oar_det_cfg& cfg) : cf
     OAR_HIP(hipEventCreateWithFlags(&stage_free_, hipEventDisableTiming));
 }
 Detector::~Detector() {
+    Profiler::get().drop_events();   // (see Profiler::drop_events: pooled events must not outlive the streams they were recorded on)
     if (copy_stream_) { (void)hipStreamSynchronize(copy_stream_); (void)hipStreamDestroy(copy_stream_); }
     if (score_stream_) { (void)hipStreamSynchronize(score_stream_); (void)hipStreamDestroy(score_stream_); }
     if (upload_stream_) { (void)hipStreamSynchronize(upload_stream_); (void)hipStreamDestroy(upload_stream_); }
