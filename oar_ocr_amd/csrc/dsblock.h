@@ -20,6 +20,7 @@ struct DsBlockP {
     const float* wp;           // pointwise weights in bf16x6 fragment order (IGEMM_W_X6)
     const float* bp;           // may be null
     const float* residual;     // may be null, shape of y
+    bool has_res;              // plan time (pointers not known yet): the block ends in + residual
     const float* se;           // may be null: [N][C] gate applied to the depthwise output after act1
     float* y;
     int y_ld;
@@ -27,6 +28,9 @@ struct DsBlockP {
 // true when dsblock() can run the block (shape / stride / channel limits); the planner keeps the two convolutions otherwise
 bool dsblock_eligible(const DsBlockP& p);
 void dsblock(hipStream_t s, const DsBlockP& p);
+// fragment layout dsblock() expects p.wp in for this block (IGEMM_W_X6 for the bf16x6 kernels, IGEMM_W_K16 for the f32 row-streaming kernel);
+// depends on the shape only (not on the pointers)
+int dsblock_wp_format(const DsBlockP& p);
 
 }  // namespace k
 }  // namespace oar

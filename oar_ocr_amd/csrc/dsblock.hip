@@ -1,5 +1,6 @@
 // dsblock.hip -- host side of the fused depthwise-separable block: tile shape, wave layout, launch (kernel: dsblock.inc).
 #include "dsblock_dev.h"
+#include "dsblock_rs.h"
 
 namespace oar {
 namespace k {
@@ -94,15 +95,93 @@ void dsblock_wa(hipStream_t s, const DsBlockP& b, const WaShape& sh) {
     if (sh.nf <= 4) dsblock_wa_launch_a(s, p, sh.nf, (int)grid, sh.lds, ps.start(), ps.stop());
     else dsblock_wa_launch_b(s, p, sh.nf, (int)grid, sh.lds, ps.start(), ps.stop());
 }
+
+// The row-streaming kernel (dsblock_rs.inc, round 4): 3x3, strides 1 / 2, pointwise on the f32 matrix pipe, per-wave LDS-DMA rings.
+struct RsShape { int nch, nf, wpw, NR, R, segs, tiles_x, items; unsigned lds_dw, lds_pw, lds_pb; size_t lds; bool ok; };
+RsShape rs_shape(const DsBlockP& p) {
+    RsShape r{};
+    const char* e = getenv("OAR_DSBLOCK_RS");   // 0: never; 2: wherever an instantiation exists (A/B runs)
+    const int mode = e ? atoi(e) : 1;
+    if (mode == 0 || p.ks != 3 || !(p.sh == 1 || p.sh == 2) || !(p.sw == 1 || p.sw == 2)) return r;
+    if (p.C < 4 || (p.C & 3) || p.Cout <= 0 || (p.Cout & 3) || (p.y_ld & 3) || p.N <= 0 || p.Ho <= 0 || p.Wo <= 0) return r;
+    if (p.pt < 0 || p.pl < 0 || p.pt > 2 || p.pl > 2 || p.has_res || p.residual || p.se) return r;
+    auto plain = [](const Act& a) { return a.kind == ACT_NONE || a.kind == ACT_RELU || a.kind == ACT_HSWISH; };
+    if (!plain(p.act1) || !plain(p.act2)) return r;
+    if ((long)p.H * p.W * p.C * 4 >= (1L << 29)) return r;            // 32-bit image-relative DMA offsets, out-of-range marker 2^30
+    if ((long)p.N * p.Ho * p.Wo >= (1L << 31) / 4) return r;
+    r.nch = (p.C + 15) / 16; r.nf = (p.Cout + 15) / 16;
+    const int IW = 15 * p.sw + 3, NJ = (r.nch * IW * 64 + 1023) / 1024, SLOT = NJ * 1024, NSET = 2 / p.sh + 1;
+    const size_t tables = (size_t)10 * r.nch * 64 + (size_t)r.nf * r.nch * 1024 + (size_t)r.nf * 64;
+    // waves per workgroup (one workgroup per CU): 12 when the ring still gets SH + 2 row slots per wave, else 8
+    r.wpw = 0;
+    for (int wpw : {12, 8}) {
+        if (!dsblock_rs_has(r.nch, wpw)) continue;
+        if (tables + (size_t)wpw * SLOT * (p.sh + 1) > 160 * 1024) continue;
+        const int nr = (int)std::min<size_t>(p.sh + 7, (160 * 1024 - tables) / ((size_t)wpw * SLOT));
+        if (r.wpw == 0 || (r.NR < p.sh + 2 && nr > r.NR)) { r.wpw = wpw; r.NR = nr; }
+    }
+    if (r.wpw == 0) return r;
+    { const char* f = getenv("OAR_DSB_RS_NR"); if (f && atoi(f) >= p.sh + 1 && atoi(f) <= r.NR) r.NR = atoi(f); }
+    // The f32 matrix pipe bounds the wide blocks (NF * NCH * 4 MFMAs of 32 cycles per 16 pixels): where that exceeds what the
+    // bf16x6 kernels need they keep the block (measured per layer, tools/dsblock_bench.py)
+    if (mode != 2 && r.nf * r.nch > 36) return r;
+    r.tiles_x = (p.Wo + 15) / 16;
+    // rows per item: the fewest wave rounds, then the least warm-up overhead (each item re-reads NSET - 1 rows of halo)
+    const long waves = 256L * r.wpw;
+    double best = 1e30;
+    for (int R = std::min(p.Ho, 4); R <= p.Ho; ++R) {
+        const int segs = (p.Ho + R - 1) / R;
+        const long items = (long)p.N * segs * r.tiles_x;
+        const long rounds = (items + waves - 1) / waves;
+        const double cost = (double)rounds * (R + (NSET - 1) * 0.7 + 0.5);
+        if (cost < best - 1e-9) { best = cost; r.R = R; r.segs = segs; r.items = (int)items; }
+        if (R >= 64 && rounds == 1) break;
+    }
+    { const char* f = getenv("OAR_DSB_RS_R"); if (f && atoi(f) > 0) { r.R = std::min(p.Ho, atoi(f)); r.segs = (p.Ho + r.R - 1) / r.R; r.items = p.N * r.segs * r.tiles_x; } }
+    const size_t rings = (size_t)r.wpw * r.NR * SLOT;
+    r.lds_dw = (unsigned)rings; r.lds_pw = r.lds_dw + 10u * r.nch * 64u; r.lds_pb = r.lds_pw + (unsigned)(r.nf * r.nch * 1024);
+    r.lds = r.lds_pb + (size_t)r.nf * 64;
+    r.ok = r.lds <= 160 * 1024;
+    return r;
+}
+
+void dsblock_rs(hipStream_t s, const DsBlockP& b, const RsShape& sh) {
+    DsRsP p{};
+    p.x = b.x; p.y = b.y; p.wd = b.wd; p.bd = b.bd; p.wp = reinterpret_cast<const float4*>(b.wp); p.bp = b.bp;
+    p.N = b.N; p.H = b.H; p.W = b.W; p.C = b.C; p.Ho = b.Ho; p.Wo = b.Wo; p.Cout = b.Cout; p.y_ld = b.y_ld;
+    p.pt = b.pt; p.pl = b.pl; p.act1 = b.act1.kind; p.act2 = b.act2.kind;
+    p.R = sh.R; p.segs = sh.segs; p.tiles_x = sh.tiles_x; p.items = sh.items; p.per_xcd = (sh.items + 7) / 8;
+    p.NF = sh.nf; p.NR = sh.NR; p.lds_dw = sh.lds_dw; p.lds_pw = sh.lds_pw; p.lds_pb = sh.lds_pb;
+    p.img_bytes = (unsigned)((long)b.H * b.W * b.C * 4);
+    { const char* e = getenv("OAR_DSB_DBG"); p.dbg = e ? atoi(e) : 0; }
+    const int grid = 256;   // one persistent workgroup per CU (a multiple of the 8 XCDs: workgroup i runs on XCD i % 8 and walks that XCD's band)
+    const double px_in = (double)b.N * b.H * b.W, px_out = (double)b.N * b.Ho * b.Wo;
+    const double bytes = 4.0 * (px_in * b.C + px_out * b.Cout) + 4.0 * b.ks * b.ks * b.C + 4.0 * b.C * b.Cout;
+    const double flops = 2.0 * px_out * b.C * (b.ks * b.ks + (double)b.Cout);
+    char pname[96];
+    const char* cls = "dsblock";
+    if (Profiler::get().detail) { snprintf(pname, sizeof pname, "dsblock px=%ld C=%d N=%d k3 s%dx%d rs R%d", (long)px_out, b.C, b.Cout, b.sh, b.sw, sh.R); cls = pname; }
+    ProfScope ps(s, cls, bytes, flops, true);
+    if (b.sh == 1 && b.sw == 1) dsblock_rs_launch_k3s11(s, p, sh.nch, sh.wpw, grid, sh.lds, ps.start(), ps.stop());
+    else if (b.sh == 2 && b.sw == 1) dsblock_rs_launch_k3s21(s, p, sh.nch, sh.wpw, grid, sh.lds, ps.start(), ps.stop());
+    else if (b.sh == 1) dsblock_rs_launch_k3s12(s, p, sh.nch, sh.wpw, grid, sh.lds, ps.start(), ps.stop());
+    else dsblock_rs_launch_k3s22(s, p, sh.nch, sh.wpw, grid, sh.lds, ps.start(), ps.stop());
+}
 }  // namespace
+
+bool dsblock_rs_has(int nch, int wpw) { return (wpw == 8 && (nch == 1 || nch == 2 || nch == 3 || nch == 4 || nch == 6)) || (wpw == 12 && nch >= 1 && nch <= 3); }
+
+int dsblock_wp_format(const DsBlockP& p) { return rs_shape(p).ok ? IGEMM_W_K16 : IGEMM_W_X6; }
 
 bool dsblock_eligible(const DsBlockP& p) {
     const char* e = getenv("OAR_FUSE_DSBLOCK");
     const bool on = !e || atoi(e) != 0;
-    return on && (wa_shape(p).ok || ds_shape(p).ok);
+    return on && (rs_shape(p).ok || wa_shape(p).ok || ds_shape(p).ok);
 }
 
 void dsblock(hipStream_t s, const DsBlockP& b) {
+    const RsShape rs = rs_shape(b);
+    if (rs.ok) { dsblock_rs(s, b, rs); return; }
     const WaShape wa = wa_shape(b);
     if (wa.ok) { dsblock_wa(s, b, wa); return; }
     const DsPlanShape sh = ds_shape(b);

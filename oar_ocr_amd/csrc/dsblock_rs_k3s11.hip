@@ -1,0 +1,8 @@
+// dsblock_rs_k3s11.hip -- row-streaming fused depthwise-separable block, 3x3, stride (1, 1) (see dsblock_rs.inc)
+#include "dsblock_rs.h"
+namespace oar {
+namespace k {
+#include "dsblock_rs.inc"
+OAR_DSBLOCK_RS_INSTANTIATE(dsblock_rs_launch_k3s11, 3, 1, 1)
+}  // namespace k
+}  // namespace oar

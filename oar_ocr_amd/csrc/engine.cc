@@ -1410,6 +1410,7 @@ struct Planner {
         p.N = (int)N; p.H = (int)H; p.W = (int)W; p.C = (int)C; p.Ho = (int)Ho; p.Wo = (int)Wo; p.Cout = (int)Cout;
         p.ks = (int)ks; p.sh = (int)sh; p.sw = (int)sw; p.pt = (int)pt; p.pl = (int)pl;
         p.act1 = dwn.act; p.act2 = n.act; p.y_ld = (int)Cout;
+        p.has_res = !n.residual.empty();
         Loc res;
         if (!n.residual.empty()) {
             TInfo r = get(n.residual);
@@ -1420,7 +1421,7 @@ struct Planner {
         Loc xin = to_clast_loc(x);
         p.wd = conv_weight_dw(dwn, WD);
         p.bd = n.in[2].empty() ? nullptr : get(n.in[2]).loc.cptr;
-        p.wp = conv_weight_igemm(pwn, WP, k::IGEMM_W_X6);
+        p.wp = conv_weight_igemm(pwn, WP, k::dsblock_wp_format(p));
         p.bp = n.in[4].empty() ? nullptr : get(n.in[4]).loc.cptr;
         if (!n.in[2].empty()) OAR_CHECK((int64_t)get(n.in[2]).ht->f.size() == C, OAR_MODEL_LOAD, "DSBlock: depthwise bias size");
         if (!n.in[4].empty()) OAR_CHECK((int64_t)get(n.in[4]).ht->f.size() == Cout, OAR_MODEL_LOAD, "DSBlock: pointwise bias size");
