@@ -97,7 +97,7 @@ void dsblock_wa(hipStream_t s, const DsBlockP& b, const WaShape& sh) {
 }
 
 // The row-streaming kernel (dsblock_rs.inc, round 4): 3x3, strides 1 / 2, pointwise on the f32 matrix pipe, per-wave LDS-DMA rings.
-struct RsShape { int nch, nf, wpw, NR, R, segs, tiles_x, items; unsigned lds_dw, lds_pw, lds_pb; size_t lds; bool ok; };
+struct RsShape { int nch, nf, nft, wpw, NR, R, segs, tiles_x, items; unsigned lds_dw, lds_pw, lds_pb; size_t lds; bool ok; };
 RsShape rs_shape(const DsBlockP& p) {
     RsShape r{};
     const char* e = getenv("OAR_DSBLOCK_RS");   // 0: never; 2: wherever an instantiation exists (A/B runs)
@@ -114,8 +114,13 @@ RsShape rs_shape(const DsBlockP& p) {
     const size_t tables = (size_t)10 * r.nch * 64 + (size_t)r.nf * r.nch * 1024 + (size_t)r.nf * 64;
     // waves per workgroup (one workgroup per CU): 12 when the ring still gets SH + 2 row slots per wave, else 8
     r.wpw = 0;
-    for (int wpw : {12, 8}) {
-        if (!dsblock_rs_has(r.nch, wpw)) continue;
+    const char* fw = getenv("OAR_DSB_RS_WPW");
+    { const char* fg = getenv("OAR_DSB_RS_GENERIC"); r.nft = (fg && atoi(fg)) ? 0 : r.nf; }   // 0: the run-time fragment loop (A/B)
+    bool any = false;
+    for (int wpw : {16, 12, 8, 4}) any = any || dsblock_rs_has(p.sh, p.sw, r.nch, r.nft, wpw);
+    if (!any) r.nft = 0;
+    for (int wpw : {12, 8, 16, 4}) {
+        if (!dsblock_rs_has(p.sh, p.sw, r.nch, r.nft, wpw) || (fw && atoi(fw) != wpw) || (!fw && (wpw == 16 || wpw == 4))) continue;
         if (tables + (size_t)wpw * SLOT * (p.sh + 1) > 160 * 1024) continue;
         const int nr = (int)std::min<size_t>(p.sh + 7, (160 * 1024 - tables) / ((size_t)wpw * SLOT));
         if (r.wpw == 0 || (r.NR < p.sh + 2 && nr > r.NR)) { r.wpw = wpw; r.NR = nr; }
@@ -154,6 +159,12 @@ void dsblock_rs(hipStream_t s, const DsBlockP& b, const RsShape& sh) {
     p.NF = sh.nf; p.NR = sh.NR; p.lds_dw = sh.lds_dw; p.lds_pw = sh.lds_pw; p.lds_pb = sh.lds_pb;
     p.img_bytes = (unsigned)((long)b.H * b.W * b.C * 4);
     { const char* e = getenv("OAR_DSB_DBG"); p.dbg = e ? atoi(e) : 0; }
+    static unsigned long long* dbgbuf = nullptr;
+    if (p.dbg & 64) {
+        if (!dbgbuf) { OAR_HIP(hipMalloc(&dbgbuf, 64)); }
+        OAR_HIP(hipMemsetAsync(dbgbuf, 0, 64, s));
+        p.dbgbuf = dbgbuf;
+    }
     const int grid = 256;   // one persistent workgroup per CU (a multiple of the 8 XCDs: workgroup i runs on XCD i % 8 and walks that XCD's band)
     const double px_in = (double)b.N * b.H * b.W, px_out = (double)b.N * b.Ho * b.Wo;
     const double bytes = 4.0 * (px_in * b.C + px_out * b.Cout) + 4.0 * b.ks * b.ks * b.C + 4.0 * b.C * b.Cout;
@@ -162,14 +173,26 @@ void dsblock_rs(hipStream_t s, const DsBlockP& b, const RsShape& sh) {
     const char* cls = "dsblock";
     if (Profiler::get().detail) { snprintf(pname, sizeof pname, "dsblock px=%ld C=%d N=%d k3 s%dx%d rs R%d", (long)px_out, b.C, b.Cout, b.sh, b.sw, sh.R); cls = pname; }
     ProfScope ps(s, cls, bytes, flops, true);
-    if (b.sh == 1 && b.sw == 1) dsblock_rs_launch_k3s11(s, p, sh.nch, sh.wpw, grid, sh.lds, ps.start(), ps.stop());
-    else if (b.sh == 2 && b.sw == 1) dsblock_rs_launch_k3s21(s, p, sh.nch, sh.wpw, grid, sh.lds, ps.start(), ps.stop());
-    else if (b.sh == 1) dsblock_rs_launch_k3s12(s, p, sh.nch, sh.wpw, grid, sh.lds, ps.start(), ps.stop());
-    else dsblock_rs_launch_k3s22(s, p, sh.nch, sh.wpw, grid, sh.lds, ps.start(), ps.stop());
+    if (b.sh == 1 && b.sw == 1) dsblock_rs_launch_k3s11(s, p, sh.nch, sh.nft, sh.wpw, grid, sh.lds, ps.start(), ps.stop());
+    else if (b.sh == 2 && b.sw == 1) dsblock_rs_launch_k3s21(s, p, sh.nch, sh.nft, sh.wpw, grid, sh.lds, ps.start(), ps.stop());
+    else if (b.sh == 1) dsblock_rs_launch_k3s12(s, p, sh.nch, sh.nft, sh.wpw, grid, sh.lds, ps.start(), ps.stop());
+    else dsblock_rs_launch_k3s22(s, p, sh.nch, sh.nft, sh.wpw, grid, sh.lds, ps.start(), ps.stop());
+    if (p.dbg & 64) {
+        unsigned long long h[8] = {0};
+        OAR_HIP(hipStreamSynchronize(s));
+        OAR_HIP(hipMemcpy(h, dbgbuf, 48, hipMemcpyDeviceToHost));
+        const double n = h[5] ? (double)h[5] : 1.0;
+        fprintf(stderr, "dsblock_rs wg0/wave0: %llu live iterations; clocks per iteration: wait %.0f  depthwise %.0f  dma-issue %.0f  act %.0f  pointwise+stores %.0f  (wpw %d NR %d R %d)\n",
+                h[5], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, sh.wpw, sh.NR, sh.R);
+    }
 }
 }  // namespace
 
-bool dsblock_rs_has(int nch, int wpw) { return (wpw == 8 && (nch == 1 || nch == 2 || nch == 3 || nch == 4 || nch == 6)) || (wpw == 12 && nch >= 1 && nch <= 3); }
+bool dsblock_rs_has(int sh, int sw, int nch, int nft, int wpw) {
+    static const int T[][5] = {{1,1,1,2,8},{1,1,1,2,12},{1,1,1,2,16},{1,1,1,1,8},{1,1,1,1,12},{1,1,1,1,16},{1,1,2,2,8},{1,1,2,2,12},{1,1,2,2,16},{1,1,2,3,8},{1,1,2,3,12},{1,1,2,3,16},{1,1,3,3,8},{1,1,3,3,12},{1,1,3,3,16},{1,1,4,4,8},{1,1,4,4,12},{1,1,6,6,4},{1,1,6,6,8},{1,1,1,0,8},{1,1,1,0,12},{1,1,1,0,16},{1,1,2,0,8},{1,1,2,0,12},{1,1,2,0,16},{1,1,3,0,8},{1,1,3,0,12},{1,1,3,0,16},{1,1,4,0,8},{1,1,4,0,12},{1,1,6,0,4},{1,1,6,0,8},{2,1,3,6,8},{2,1,3,6,12},{2,1,1,0,8},{2,1,1,0,12},{2,1,1,0,16},{2,1,2,0,8},{2,1,2,0,12},{2,1,2,0,16},{2,1,3,0,8},{2,1,3,0,12},{2,1,3,0,16},{2,1,4,0,8},{2,1,4,0,12},{2,1,6,0,4},{2,1,6,0,8},{1,2,1,0,8},{1,2,1,0,12},{1,2,1,0,16},{1,2,2,0,8},{1,2,2,0,12},{1,2,2,0,16},{1,2,3,0,8},{1,2,3,0,12},{1,2,3,0,16},{1,2,4,0,8},{1,2,4,0,12},{2,2,2,2,8},{2,2,2,2,12},{2,2,2,2,16},{2,2,2,4,8},{2,2,2,4,12},{2,2,2,4,16},{2,2,4,8,8},{2,2,4,8,12},{2,2,1,0,8},{2,2,1,0,12},{2,2,1,0,16},{2,2,2,0,8},{2,2,2,0,12},{2,2,2,0,16},{2,2,3,0,8},{2,2,3,0,12},{2,2,3,0,16},{2,2,4,0,8},{2,2,4,0,12}};   // generated with the instantiation units (dsblock_rs_k3s*.hip)
+    for (const auto& t : T) if (t[0] == sh && t[1] == sw && t[2] == nch && t[3] == nft && t[4] == wpw) return true;
+    return false;
+}
 
 int dsblock_wp_format(const DsBlockP& p) { return rs_shape(p).ok ? IGEMM_W_K16 : IGEMM_W_X6; }
 

@@ -14,11 +14,14 @@ namespace k {
 #include "dsblock_rs_p.inc"
 
 // one translation unit per stride combination (3x3): NCH = channel chunks of 16, wpw = waves per workgroup (8 or 12)
-void dsblock_rs_launch_k3s11(hipStream_t s, const DsRsP& p, int nch, int wpw, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1);
-void dsblock_rs_launch_k3s21(hipStream_t s, const DsRsP& p, int nch, int wpw, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1);
-void dsblock_rs_launch_k3s12(hipStream_t s, const DsRsP& p, int nch, int wpw, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1);
-void dsblock_rs_launch_k3s22(hipStream_t s, const DsRsP& p, int nch, int wpw, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1);
-bool dsblock_rs_has(int nch, int wpw);
+// one translation unit per stride combination (3x3): nch = channel chunks of 16, nf = cout fragments of 16 (0: the generic kernel that
+// loops over fragment pairs at run time), wpw = waves per workgroup
+void dsblock_rs_launch_k3s11(hipStream_t s, const DsRsP& p, int nch, int nft, int wpw, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1);
+void dsblock_rs_launch_k3s21(hipStream_t s, const DsRsP& p, int nch, int nft, int wpw, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1);
+void dsblock_rs_launch_k3s12(hipStream_t s, const DsRsP& p, int nch, int nft, int wpw, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1);
+void dsblock_rs_launch_k3s22(hipStream_t s, const DsRsP& p, int nch, int nft, int wpw, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1);
+// which (nch, nft, wpw) the unit of stride (sh, sw) instantiates
+bool dsblock_rs_has(int sh, int sw, int nch, int nft, int wpw);
 
 template <typename K>
 static void dsblock_rs_one(K kernel, int wpw, hipStream_t s, const DsRsP& p, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1) {
@@ -27,20 +30,8 @@ static void dsblock_rs_one(K kernel, int wpw, hipStream_t s, const DsRsP& p, int
     hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(wpw * 64), lds, s, e0, e1, 0, p);
 }
 
-#define OAR_DSBLOCK_RS_INSTANTIATE(NAME, KS, SH, SW)                                                                                           \
-    void NAME(hipStream_t s, const DsRsP& p, int nch, int wpw, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1) {                           \
-        switch (nch * 100 + wpw) {                                                                                                             \
-            case 108: dsblock_rs_one(dsblock_rs_kernel<KS, SH, SW, 1, 8>, 8, s, p, grid, lds, e0, e1); break;                                  \
-            case 112: dsblock_rs_one(dsblock_rs_kernel<KS, SH, SW, 1, 12>, 12, s, p, grid, lds, e0, e1); break;                                \
-            case 208: dsblock_rs_one(dsblock_rs_kernel<KS, SH, SW, 2, 8>, 8, s, p, grid, lds, e0, e1); break;                                  \
-            case 212: dsblock_rs_one(dsblock_rs_kernel<KS, SH, SW, 2, 12>, 12, s, p, grid, lds, e0, e1); break;                                \
-            case 308: dsblock_rs_one(dsblock_rs_kernel<KS, SH, SW, 3, 8>, 8, s, p, grid, lds, e0, e1); break;                                  \
-            case 312: dsblock_rs_one(dsblock_rs_kernel<KS, SH, SW, 3, 12>, 12, s, p, grid, lds, e0, e1); break;                                \
-            case 408: dsblock_rs_one(dsblock_rs_kernel<KS, SH, SW, 4, 8>, 8, s, p, grid, lds, e0, e1); break;                                  \
-            case 608: dsblock_rs_one(dsblock_rs_kernel<KS, SH, SW, 6, 8>, 8, s, p, grid, lds, e0, e1); break;                                  \
-            default: ::oar::fail(OAR_INTERNAL, "dsblock_rs: no kernel for this shape");                                                        \
-        }                                                                                                                                      \
-    }
+#define OAR_RS_CASE(KS, SH, SW, NCH, NFT, WPW) \
+    case (NCH) * 10000 + (NFT) * 100 + (WPW): dsblock_rs_one(dsblock_rs_kernel<KS, SH, SW, NCH, NFT, WPW>, WPW, s, p, grid, lds, e0, e1); break;
 
 }  // namespace k
 }  // namespace oar
