@@ -97,39 +97,26 @@ void dsblock_wa(hipStream_t s, const DsBlockP& b, const WaShape& sh) {
 }
 
 // The row-streaming kernel (dsblock_rs.inc, round 4): 3x3, strides 1 / 2, pointwise on the f32 matrix pipe, per-wave LDS-DMA rings.
-struct RsShape { int nch, nf, nft, wpw, NR, R, segs, tiles_x, items; unsigned lds_dw, lds_pw, lds_pb; size_t lds; bool ok; };
+struct RsShape { int nch, nf, acts, wpw, NR, R, segs, tiles_x, items; unsigned lds_dw, lds_pw; size_t lds; bool ok; };
 RsShape rs_shape(const DsBlockP& p) {
     RsShape r{};
-    const char* e = getenv("OAR_DSBLOCK_RS");   // 0: never; 2: wherever an instantiation exists (A/B runs)
-    const int mode = e ? atoi(e) : 1;
-    if (mode == 0 || p.ks != 3 || !(p.sh == 1 || p.sh == 2) || !(p.sw == 1 || p.sw == 2)) return r;
+    const char* e = getenv("OAR_DSBLOCK_RS");   // 0: never (A/B runs against dsblock / dsblock_wa)
+    if ((e && atoi(e) == 0) || p.ks != 3 || !(p.sh == 1 || p.sh == 2) || !(p.sw == 1 || p.sw == 2)) return r;
     if (p.C < 4 || (p.C & 3) || p.Cout <= 0 || (p.Cout & 3) || (p.y_ld & 3) || p.N <= 0 || p.Ho <= 0 || p.Wo <= 0) return r;
     if (p.pt < 0 || p.pl < 0 || p.pt > 2 || p.pl > 2 || p.has_res || p.residual || p.se) return r;
     auto plain = [](const Act& a) { return a.kind == ACT_NONE || a.kind == ACT_RELU || a.kind == ACT_HSWISH; };
     if (!plain(p.act1) || !plain(p.act2)) return r;
-    if ((long)p.H * p.W * p.C * 4 >= (1L << 29)) return r;            // 32-bit image-relative DMA offsets, out-of-range marker 2^30
-    if ((long)p.N * p.Ho * p.Wo >= (1L << 31) / 4) return r;
+    if ((long)p.H * p.W * p.C * 4 >= (1L << 29)) return r;                       // 32-bit image-relative DMA offsets, out-of-range marker 2^30
+    if ((long)p.N * p.Ho * p.Wo * p.y_ld * 4 >= (1L << 31)) return r;            // 32-bit store offsets, out-of-range marker 2^31
     r.nch = (p.C + 15) / 16; r.nf = (p.Cout + 15) / 16;
-    const int IW = 15 * p.sw + 3, NJ = (r.nch * IW * 64 + 1023) / 1024, SLOT = NJ * 1024, NSET = 2 / p.sh + 1;
-    const size_t tables = (size_t)10 * r.nch * 64 + (size_t)r.nf * r.nch * 1024 + (size_t)r.nf * 64;
-    // waves per workgroup (one workgroup per CU): 12 when the ring still gets SH + 2 row slots per wave, else 8
-    r.wpw = 0;
-    const char* fw = getenv("OAR_DSB_RS_WPW");
-    { const char* fg = getenv("OAR_DSB_RS_GENERIC"); r.nft = (fg && atoi(fg)) ? 0 : r.nf; }   // 0: the run-time fragment loop (A/B)
-    bool any = false;
-    for (int wpw : {16, 12, 8, 4}) any = any || dsblock_rs_has(p.sh, p.sw, r.nch, r.nft, wpw);
-    if (!any) r.nft = 0;
-    for (int wpw : {12, 8, 16, 4}) {
-        if (!dsblock_rs_has(p.sh, p.sw, r.nch, r.nft, wpw) || (fw && atoi(fw) != wpw) || (!fw && (wpw == 16 || wpw == 4))) continue;
-        if (tables + (size_t)wpw * SLOT * (p.sh + 1) > 160 * 1024) continue;
-        const int nr = (int)std::min<size_t>(p.sh + 7, (160 * 1024 - tables) / ((size_t)wpw * SLOT));
-        if (r.wpw == 0 || (r.NR < p.sh + 2 && nr > r.NR)) { r.wpw = wpw; r.NR = nr; }
-    }
+    r.wpw = dsblock_rs_wpw(p.sh, p.sw, r.nch, r.nf);
     if (r.wpw == 0) return r;
-    { const char* f = getenv("OAR_DSB_RS_NR"); if (f && atoi(f) >= p.sh + 1 && atoi(f) <= r.NR) r.NR = atoi(f); }
-    // The f32 matrix pipe bounds the wide blocks (NF * NCH * 4 MFMAs of 32 cycles per 16 pixels): where that exceeds what the
-    // bf16x6 kernels need they keep the block (measured per layer, tools/dsblock_bench.py)
-    if (mode != 2 && r.nf * r.nch > 36) return r;
+    r.acts = (p.act1.kind == ACT_HSWISH && p.act2.kind == ACT_HSWISH) ? 1 : 0;
+    const int IW = 15 * p.sw + 3, NJ = (r.nch * IW * 64 + 1023) / 1024, SLOT = NJ * 1024, NSET = 2 / p.sh + 1;
+    const bool pwreg = r.nf * r.nch <= 12;
+    const size_t tables = (size_t)10 * r.nch * 64 + (pwreg ? 0 : (size_t)r.nf * r.nch * 1024);
+    if (tables + (size_t)r.wpw * SLOT * (p.sh + 1) > 160 * 1024) return r;
+    r.NR = tables + (size_t)r.wpw * SLOT * (p.sh + 2) <= 160 * 1024 ? p.sh + 2 : p.sh + 1;   // the kernel computes the same (constexpr NR): one or two rows beyond the SH being consumed (deeper rings measured equal)
     r.tiles_x = (p.Wo + 15) / 16;
     // rows per item: the fewest wave rounds, then the least warm-up overhead (each item re-reads NSET - 1 rows of halo)
     const long waves = 256L * r.wpw;
@@ -144,8 +131,8 @@ RsShape rs_shape(const DsBlockP& p) {
     }
     { const char* f = getenv("OAR_DSB_RS_R"); if (f && atoi(f) > 0) { r.R = std::min(p.Ho, atoi(f)); r.segs = (p.Ho + r.R - 1) / r.R; r.items = p.N * r.segs * r.tiles_x; } }
     const size_t rings = (size_t)r.wpw * r.NR * SLOT;
-    r.lds_dw = (unsigned)rings; r.lds_pw = r.lds_dw + 10u * r.nch * 64u; r.lds_pb = r.lds_pw + (unsigned)(r.nf * r.nch * 1024);
-    r.lds = r.lds_pb + (size_t)r.nf * 64;
+    r.lds_dw = (unsigned)rings; r.lds_pw = r.lds_dw + 10u * r.nch * 64u;
+    r.lds = rings + tables;
     r.ok = r.lds <= 160 * 1024;
     return r;
 }
@@ -156,15 +143,9 @@ void dsblock_rs(hipStream_t s, const DsBlockP& b, const RsShape& sh) {
     p.N = b.N; p.H = b.H; p.W = b.W; p.C = b.C; p.Ho = b.Ho; p.Wo = b.Wo; p.Cout = b.Cout; p.y_ld = b.y_ld;
     p.pt = b.pt; p.pl = b.pl; p.act1 = b.act1.kind; p.act2 = b.act2.kind;
     p.R = sh.R; p.segs = sh.segs; p.tiles_x = sh.tiles_x; p.items = sh.items; p.per_xcd = (sh.items + 7) / 8;
-    p.NF = sh.nf; p.NR = sh.NR; p.lds_dw = sh.lds_dw; p.lds_pw = sh.lds_pw; p.lds_pb = sh.lds_pb;
+    p.NF = sh.nf; p.NR = sh.NR; p.lds_dw = sh.lds_dw; p.lds_pw = sh.lds_pw; p.lds_pb = 0;
     p.img_bytes = (unsigned)((long)b.H * b.W * b.C * 4);
-    { const char* e = getenv("OAR_DSB_DBG"); p.dbg = e ? atoi(e) : 0; }
-    static unsigned long long* dbgbuf = nullptr;
-    if (p.dbg & 64) {
-        if (!dbgbuf) { OAR_HIP(hipMalloc(&dbgbuf, 64)); }
-        OAR_HIP(hipMemsetAsync(dbgbuf, 0, 64, s));
-        p.dbgbuf = dbgbuf;
-    }
+    p.y_bytes = (unsigned)((long)b.N * b.Ho * b.Wo * b.y_ld * 4);
     const int grid = 256;   // one persistent workgroup per CU (a multiple of the 8 XCDs: workgroup i runs on XCD i % 8 and walks that XCD's band)
     const double px_in = (double)b.N * b.H * b.W, px_out = (double)b.N * b.Ho * b.Wo;
     const double bytes = 4.0 * (px_in * b.C + px_out * b.Cout) + 4.0 * b.ks * b.ks * b.C + 4.0 * b.C * b.Cout;
@@ -173,25 +154,19 @@ void dsblock_rs(hipStream_t s, const DsBlockP& b, const RsShape& sh) {
     const char* cls = "dsblock";
     if (Profiler::get().detail) { snprintf(pname, sizeof pname, "dsblock px=%ld C=%d N=%d k3 s%dx%d rs R%d", (long)px_out, b.C, b.Cout, b.sh, b.sw, sh.R); cls = pname; }
     ProfScope ps(s, cls, bytes, flops, true);
-    if (b.sh == 1 && b.sw == 1) dsblock_rs_launch_k3s11(s, p, sh.nch, sh.nft, sh.wpw, grid, sh.lds, ps.start(), ps.stop());
-    else if (b.sh == 2 && b.sw == 1) dsblock_rs_launch_k3s21(s, p, sh.nch, sh.nft, sh.wpw, grid, sh.lds, ps.start(), ps.stop());
-    else if (b.sh == 1) dsblock_rs_launch_k3s12(s, p, sh.nch, sh.nft, sh.wpw, grid, sh.lds, ps.start(), ps.stop());
-    else dsblock_rs_launch_k3s22(s, p, sh.nch, sh.nft, sh.wpw, grid, sh.lds, ps.start(), ps.stop());
-    if (p.dbg & 64) {
-        unsigned long long h[8] = {0};
-        OAR_HIP(hipStreamSynchronize(s));
-        OAR_HIP(hipMemcpy(h, dbgbuf, 48, hipMemcpyDeviceToHost));
-        const double n = h[5] ? (double)h[5] : 1.0;
-        fprintf(stderr, "dsblock_rs wg0/wave0: %llu live iterations; clocks per iteration: wait %.0f  depthwise %.0f  dma-issue %.0f  act %.0f  pointwise+stores %.0f  (wpw %d NR %d R %d)\n",
-                h[5], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, sh.wpw, sh.NR, sh.R);
-    }
+    const char* de = getenv("OAR_DSB_DBG");
+    if (de && atoi(de) > 0 && b.sh == 1 && b.sw == 1 && sh.nch == 3 && sh.nf == 3 && sh.acts == 1) dsblock_rs_launch_dbg(s, p, atoi(de), grid, sh.lds, ps.start(), ps.stop());
+    else if (b.sh == 1 && b.sw == 1) dsblock_rs_launch_k3s11(s, p, sh.nch, sh.nf, sh.acts, grid, sh.lds, ps.start(), ps.stop());
+    else if (b.sh == 2 && b.sw == 1) dsblock_rs_launch_k3s21(s, p, sh.nch, sh.nf, sh.acts, grid, sh.lds, ps.start(), ps.stop());
+    else if (b.sh == 1) dsblock_rs_launch_k3s12(s, p, sh.nch, sh.nf, sh.acts, grid, sh.lds, ps.start(), ps.stop());
+    else dsblock_rs_launch_k3s22(s, p, sh.nch, sh.nf, sh.acts, grid, sh.lds, ps.start(), ps.stop());
 }
 }  // namespace
 
-bool dsblock_rs_has(int sh, int sw, int nch, int nft, int wpw) {
-    static const int T[][5] = {{1,1,1,2,8},{1,1,1,2,12},{1,1,1,2,16},{1,1,1,1,8},{1,1,1,1,12},{1,1,1,1,16},{1,1,2,2,8},{1,1,2,2,12},{1,1,2,2,16},{1,1,2,3,8},{1,1,2,3,12},{1,1,2,3,16},{1,1,3,3,8},{1,1,3,3,12},{1,1,3,3,16},{1,1,4,4,8},{1,1,4,4,12},{1,1,6,6,4},{1,1,6,6,8},{1,1,1,0,8},{1,1,1,0,12},{1,1,1,0,16},{1,1,2,0,8},{1,1,2,0,12},{1,1,2,0,16},{1,1,3,0,8},{1,1,3,0,12},{1,1,3,0,16},{1,1,4,0,8},{1,1,4,0,12},{1,1,6,0,4},{1,1,6,0,8},{2,1,3,6,8},{2,1,3,6,12},{2,1,1,0,8},{2,1,1,0,12},{2,1,1,0,16},{2,1,2,0,8},{2,1,2,0,12},{2,1,2,0,16},{2,1,3,0,8},{2,1,3,0,12},{2,1,3,0,16},{2,1,4,0,8},{2,1,4,0,12},{2,1,6,0,4},{2,1,6,0,8},{1,2,1,0,8},{1,2,1,0,12},{1,2,1,0,16},{1,2,2,0,8},{1,2,2,0,12},{1,2,2,0,16},{1,2,3,0,8},{1,2,3,0,12},{1,2,3,0,16},{1,2,4,0,8},{1,2,4,0,12},{2,2,2,2,8},{2,2,2,2,12},{2,2,2,2,16},{2,2,2,4,8},{2,2,2,4,12},{2,2,2,4,16},{2,2,4,8,8},{2,2,4,8,12},{2,2,1,0,8},{2,2,1,0,12},{2,2,1,0,16},{2,2,2,0,8},{2,2,2,0,12},{2,2,2,0,16},{2,2,3,0,8},{2,2,3,0,12},{2,2,3,0,16},{2,2,4,0,8},{2,2,4,0,12}};   // generated with the instantiation units (dsblock_rs_k3s*.hip)
-    for (const auto& t : T) if (t[0] == sh && t[1] == sw && t[2] == nch && t[3] == nft && t[4] == wpw) return true;
-    return false;
+int dsblock_rs_wpw(int sh, int sw, int nch, int nft) {
+    static const int T[][5] = {{1,1,1,1,12},{1,1,1,2,12},{1,1,2,2,12},{1,1,2,3,12},{1,1,2,4,12},{1,1,3,3,12},{1,1,3,6,8},{1,1,4,4,8},{1,1,4,8,8},{1,1,5,5,8},{1,1,6,6,8},{1,1,2,8,8},{2,1,3,6,8},{2,1,2,4,12},{2,1,1,2,12},{2,1,4,8,8},{1,2,1,2,12},{1,2,2,4,12},{1,2,3,6,8},{2,2,2,2,8},{2,2,2,4,8},{2,2,1,2,12}};   // generated with the instantiation units (dsblock_rs_k3s*.hip)
+    for (const auto& t : T) if (t[0] == sh && t[1] == sw && t[2] == nch && t[3] == nft) return t[4];
+    return 0;
 }
 
 int dsblock_wp_format(const DsBlockP& p) { return rs_shape(p).ok ? IGEMM_W_K16 : IGEMM_W_X6; }

@@ -3,19 +3,11 @@
 namespace oar {
 namespace k {
 #include "dsblock_rs.inc"
-void dsblock_rs_launch_k3s12(hipStream_t s, const DsRsP& p, int nch, int nft, int wpw, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1) {
-    switch (nch * 10000 + nft * 100 + wpw) {
-        OAR_RS_CASE(3, 1, 2, 1, 0, 8)
-        OAR_RS_CASE(3, 1, 2, 1, 0, 12)
-        OAR_RS_CASE(3, 1, 2, 1, 0, 16)
-        OAR_RS_CASE(3, 1, 2, 2, 0, 8)
-        OAR_RS_CASE(3, 1, 2, 2, 0, 12)
-        OAR_RS_CASE(3, 1, 2, 2, 0, 16)
-        OAR_RS_CASE(3, 1, 2, 3, 0, 8)
-        OAR_RS_CASE(3, 1, 2, 3, 0, 12)
-        OAR_RS_CASE(3, 1, 2, 3, 0, 16)
-        OAR_RS_CASE(3, 1, 2, 4, 0, 8)
-        OAR_RS_CASE(3, 1, 2, 4, 0, 12)
+void dsblock_rs_launch_k3s12(hipStream_t s, const DsRsP& p, int nch, int nft, int acts, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1) {
+    switch (nch * 1000 + nft * 10 + acts) {
+        OAR_RS_CASE(3, 1, 2, 1, 2, 12)
+        OAR_RS_CASE(3, 1, 2, 2, 4, 12)
+        OAR_RS_CASE(3, 1, 2, 3, 6, 8)
         default: ::oar::fail(OAR_INTERNAL, "dsblock_rs: no kernel for this shape");
     }
 }

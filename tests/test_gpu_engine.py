@@ -510,8 +510,8 @@ DS_CASES = [  # (C, Cout, k, stride, N, H, W, act, residual)
 
 @pytest.mark.parametrize("case", DS_CASES, ids=[f"C{c[0]}-N{c[1]}-k{c[2]}-s{c[3][0]}{c[3][1]}" for c in DS_CASES])
 def test_fused_dsblock_matches_oracle(case, monkeypatch):
-    """Conv(depthwise k x k) + act -> Conv(1 x 1) + act (+ residual) runs as one kernel (csrc/dsblock.inc: depthwise on the
-    VALU pipe into LDS operand fragments, pointwise as bf16x6 MFMAs).  Every wave layout, both kernel sizes, all four
+    """Conv(depthwise k x k) + act -> Conv(1 x 1) + act (+ residual) runs as one kernel (csrc/dsblock_rs.inc: rolling depthwise sums in
+    registers feeding the f32 matrix pipe; csrc/dsblock.inc / dsblock_wa.inc: depthwise into bf16x6 MFMA operand fragments).  Every wave layout, both kernel sizes, all four
     stride combinations, partial edge tiles and channel counts that are not multiples of 32 / 16 -- against the torch-CPU
     interpreter, and against the same graph with the fusion switched off (OAR_FUSE_DSBLOCK=0)."""
     C, Cout, k, stride, N, H, W, act, residual = case
@@ -532,11 +532,16 @@ def test_fused_dsblock_matches_oracle(case, monkeypatch):
     plain = api.OrtInfer(m).infer(x)[0][1]
     assert np.abs(plain - got[0][1]).max() <= 2e-4 * max(1.0, float(np.abs(plain).max()))
     monkeypatch.delenv("OAR_FUSE_DSBLOCK")
+    # round 4: the row-streaming kernel (dsblock_rs.inc, f32 matrix pipe) takes the 3x3 blocks it has an instantiation for; the bf16x6
+    # kernels it replaced must still agree with the oracle on the same graph (they keep the shapes it does not take)
+    monkeypatch.setenv("OAR_DSBLOCK_RS", "0")
+    wa = api.OrtInfer(m).infer(x)[0][1]
+    assert np.abs(wa - ref[0]).max() <= 2e-4 * max(1.0, float(np.abs(ref[0]).max()))
     if k == 3 and stride == (1, 1):
-        # the two fused kernels share their arithmetic (FMA chain, exact bf16 split, order of the six products): bit-identical
+        # dsblock_wa and dsblock share their arithmetic (FMA chain, exact bf16 split, order of the six products): bit-identical
         monkeypatch.setenv("OAR_DSBLOCK_WA", "0")
         old = api.OrtInfer(m).infer(x)[0][1]
-        assert np.array_equal(old, got[0][1])
+        assert np.array_equal(old, wa)
 
 
 @pytest.mark.parametrize("case", ["fpn", "fallbacks"])
