@@ -1,5 +1,5 @@
-// dsblock_rs_dbg.hip -- timing ablations of the row-streaming block at its flagship shape (48 -> 48, 3x3 stride 1, hard swish): OAR_DSB_DBG=1..5
-// selects a variant that leaves one ingredient out (WRONG results; tools/dsblock_bench.py only).  See DBG in dsblock_rs.inc.
+// dsblock_rs_dbg.hip -- timing ablations of the row-streaming block at its flagship shape (48 -> 48, 3x3 stride 1, hard swish): OAR_DSB_DBG=<mask>
+// selects a variant that leaves ingredients out (WRONG results; tools/dsblock_bench.py only).  See DBG in dsblock_rs.inc.
 #include "dsblock_rs.h"
 namespace oar {
 namespace k {
@@ -9,8 +9,34 @@ void dsblock_rs_launch_dbg(hipStream_t s, const DsRsP& p, int dbg, int grid, siz
         case 1: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 1>, 12, s, p, grid, lds, e0, e1); break;
         case 2: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 2>, 12, s, p, grid, lds, e0, e1); break;
         case 3: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 3>, 12, s, p, grid, lds, e0, e1); break;
-        case 4: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 4>, 12, s, p, grid, lds, e0, e1); break;
-        default: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 5>, 12, s, p, grid, lds, e0, e1); break;
+        case 7: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 7>, 12, s, p, grid, lds, e0, e1); break;
+        case 8: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 8>, 12, s, p, grid, lds, e0, e1); break;
+        case 9: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 9>, 12, s, p, grid, lds, e0, e1); break;
+        case 10: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 10>, 12, s, p, grid, lds, e0, e1); break;
+        case 11: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 11>, 12, s, p, grid, lds, e0, e1); break;
+        case 15: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 15>, 12, s, p, grid, lds, e0, e1); break;
+        case 16: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 16>, 12, s, p, grid, lds, e0, e1); break;
+        case 19: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 19>, 12, s, p, grid, lds, e0, e1); break;
+        case 23: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 23>, 12, s, p, grid, lds, e0, e1); break;
+        case 32: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 32>, 12, s, p, grid, lds, e0, e1); break;
+        case 64: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 64>, 12, s, p, grid, lds, e0, e1); break;
+        case 67: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 67>, 12, s, p, grid, lds, e0, e1); break;
+        case 71: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 71>, 12, s, p, grid, lds, e0, e1); break;
+        case 72: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 72>, 12, s, p, grid, lds, e0, e1); break;
+        case 79: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 79>, 12, s, p, grid, lds, e0, e1); break;
+        case 135: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 135>, 12, s, p, grid, lds, e0, e1); break;
+        case 143: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 143>, 12, s, p, grid, lds, e0, e1); break;
+        case 87: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 87>, 12, s, p, grid, lds, e0, e1); break;
+        case 207: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 207>, 12, s, p, grid, lds, e0, e1); break;
+        case 256: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 256>, 12, s, p, grid, lds, e0, e1); break;
+        case 512: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 512>, 12, s, p, grid, lds, e0, e1); break;
+        case 768: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 768>, 12, s, p, grid, lds, e0, e1); break;
+        case 328: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 328>, 12, s, p, grid, lds, e0, e1); break;
+        case 584: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 584>, 12, s, p, grid, lds, e0, e1); break;
+        case 840: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 840>, 12, s, p, grid, lds, e0, e1); break;
+        case 264: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 264>, 12, s, p, grid, lds, e0, e1); break;
+        case 520: dsblock_rs_one(dsblock_rs_kernel<3, 1, 1, 3, 3, 12, 1, 520>, 12, s, p, grid, lds, e0, e1); break;
+        default: ::oar::fail(OAR_INTERNAL, "dsblock_rs_dbg: this mask is not instantiated");
     }
 }
 }  // namespace k
