@@ -97,7 +97,7 @@ void dsblock_wa(hipStream_t s, const DsBlockP& b, const WaShape& sh) {
 }
 
 // The row-streaming kernel (dsblock_rs.inc, round 4): 3x3, strides 1 / 2, pointwise on the f32 matrix pipe, per-wave LDS-DMA rings.
-struct RsShape { int nch, nf, acts, wpw, NR, R, segs, tiles_x, items; unsigned lds_dw, lds_pw; size_t lds; bool ok; };
+struct RsShape { int nch, nf, acts, x6, wpw, NR, R, segs, tiles_x, items; unsigned lds_dw, lds_pw; size_t lds; bool ok; };
 RsShape rs_shape(const DsBlockP& p) {
     RsShape r{};
     const char* e = getenv("OAR_DSBLOCK_RS");   // 0: never (A/B runs against dsblock / dsblock_wa)
@@ -109,12 +109,16 @@ RsShape rs_shape(const DsBlockP& p) {
     if ((long)p.H * p.W * p.C * 4 >= (1L << 29)) return r;                       // 32-bit image-relative DMA offsets, out-of-range marker 2^30
     if ((long)p.N * p.Ho * p.Wo * p.y_ld * 4 >= (1L << 31)) return r;            // 32-bit store offsets, out-of-range marker 2^31
     r.nch = (p.C + 15) / 16; r.nf = (p.Cout + 15) / 16;
-    r.wpw = dsblock_rs_wpw(p.sh, p.sw, r.nch, r.nf);
+    // pointwise on the f32 matrix instruction or as bf16x6 (dsblock_rs.inc, PWX6).  Measured per layer (tools/dsblock_bench.py, OAR_DSB_RS_X6=0|1):
+    // the f32 instruction blocks its SIMD for 32 cycles each, so it only pays where the product is tiny
+    { const char* f = getenv("OAR_DSB_RS_X6"); r.x6 = f ? (atoi(f) != 0) : (r.nf * r.nch >= 6); }
+    r.wpw = dsblock_rs_wpw(p.sh, p.sw, r.nch, r.nf, r.x6);
+    if (r.wpw == 0) { r.x6 = !r.x6; r.wpw = dsblock_rs_wpw(p.sh, p.sw, r.nch, r.nf, r.x6); }
     if (r.wpw == 0) return r;
     r.acts = (p.act1.kind == ACT_HSWISH && p.act2.kind == ACT_HSWISH) ? 1 : 0;
-    const int IW = 15 * p.sw + 3, NJ = (r.nch * IW * 64 + 1023) / 1024, SLOT = NJ * 1024, NSET = 2 / p.sh + 1;
-    const bool pwreg = r.nf * r.nch <= 12;
-    const size_t tables = (size_t)10 * r.nch * 64 + (pwreg ? 0 : (size_t)r.nf * r.nch * 1024);
+    const int IW = 15 * p.sw + 3, SLOT = r.nch * IW * 64, NSET = 2 / p.sh + 1, ncp = (r.nch + 1) / 2;   // (ring slots are packed: one row each)
+    const bool pwreg = !r.x6 && r.nf * r.nch <= 12;
+    const size_t tables = (size_t)10 * r.nch * 64 + (r.x6 ? (size_t)r.nf * ncp * 3 * 1024 : pwreg ? 0 : (size_t)r.nf * r.nch * 1024);
     if (tables + (size_t)r.wpw * SLOT * (p.sh + 1) > 160 * 1024) return r;
     r.NR = tables + (size_t)r.wpw * SLOT * (p.sh + 2) <= 160 * 1024 ? p.sh + 2 : p.sh + 1;   // the kernel computes the same (constexpr NR): one or two rows beyond the SH being consumed (deeper rings measured equal)
     r.tiles_x = (p.Wo + 15) / 16;
@@ -155,21 +159,21 @@ void dsblock_rs(hipStream_t s, const DsBlockP& b, const RsShape& sh) {
     if (Profiler::get().detail) { snprintf(pname, sizeof pname, "dsblock px=%ld C=%d N=%d k3 s%dx%d rs R%d", (long)px_out, b.C, b.Cout, b.sh, b.sw, sh.R); cls = pname; }
     ProfScope ps(s, cls, bytes, flops, true);
     const char* de = getenv("OAR_DSB_DBG");
-    if (de && atoi(de) > 0 && b.sh == 1 && b.sw == 1 && sh.nch == 3 && sh.nf == 3 && sh.acts == 1) dsblock_rs_launch_dbg(s, p, atoi(de), grid, sh.lds, ps.start(), ps.stop());
-    else if (b.sh == 1 && b.sw == 1) dsblock_rs_launch_k3s11(s, p, sh.nch, sh.nf, sh.acts, grid, sh.lds, ps.start(), ps.stop());
-    else if (b.sh == 2 && b.sw == 1) dsblock_rs_launch_k3s21(s, p, sh.nch, sh.nf, sh.acts, grid, sh.lds, ps.start(), ps.stop());
-    else if (b.sh == 1) dsblock_rs_launch_k3s12(s, p, sh.nch, sh.nf, sh.acts, grid, sh.lds, ps.start(), ps.stop());
-    else dsblock_rs_launch_k3s22(s, p, sh.nch, sh.nf, sh.acts, grid, sh.lds, ps.start(), ps.stop());
+    if (de && atoi(de) > 0 && b.sh == 1 && b.sw == 1 && sh.nch == 3 && sh.nf == 3 && sh.acts == 1 && !sh.x6) dsblock_rs_launch_dbg(s, p, atoi(de), grid, sh.lds, ps.start(), ps.stop());
+    else if (b.sh == 1 && b.sw == 1) dsblock_rs_launch_k3s11(s, p, sh.nch, sh.nf, sh.x6, sh.acts, grid, sh.lds, ps.start(), ps.stop());
+    else if (b.sh == 2 && b.sw == 1) dsblock_rs_launch_k3s21(s, p, sh.nch, sh.nf, sh.x6, sh.acts, grid, sh.lds, ps.start(), ps.stop());
+    else if (b.sh == 1) dsblock_rs_launch_k3s12(s, p, sh.nch, sh.nf, sh.x6, sh.acts, grid, sh.lds, ps.start(), ps.stop());
+    else dsblock_rs_launch_k3s22(s, p, sh.nch, sh.nf, sh.x6, sh.acts, grid, sh.lds, ps.start(), ps.stop());
 }
 }  // namespace
 
-int dsblock_rs_wpw(int sh, int sw, int nch, int nft) {
-    static const int T[][5] = {{1,1,1,1,12},{1,1,1,2,12},{1,1,2,2,12},{1,1,2,3,12},{1,1,2,4,12},{1,1,3,3,12},{1,1,3,6,8},{1,1,4,4,8},{1,1,4,8,8},{1,1,5,5,8},{1,1,6,6,8},{1,1,2,8,8},{2,1,3,6,8},{2,1,2,4,12},{2,1,1,2,12},{2,1,4,8,8},{1,2,1,2,12},{1,2,2,4,12},{1,2,3,6,8},{2,2,2,2,8},{2,2,2,4,8},{2,2,1,2,12}};   // generated with the instantiation units (dsblock_rs_k3s*.hip)
-    for (const auto& t : T) if (t[0] == sh && t[1] == sw && t[2] == nch && t[3] == nft) return t[4];
+int dsblock_rs_wpw(int sh, int sw, int nch, int nft, int x6) {
+    static const int T[][6] = {{1,1,1,1,0,12},{1,1,1,2,0,12},{1,1,2,2,0,12},{1,1,2,3,0,12},{1,1,2,3,1,12},{1,1,2,4,0,12},{1,1,2,4,1,12},{1,1,3,3,0,12},{1,1,3,3,1,12},{1,1,3,6,0,12},{1,1,3,6,1,12},{1,1,4,4,0,8},{1,1,4,4,1,8},{1,1,4,8,0,8},{1,1,4,8,1,8},{1,1,5,5,0,8},{1,1,5,5,1,8},{1,1,6,6,0,8},{1,1,6,6,1,6},{1,1,2,8,0,12},{2,1,3,6,0,12},{2,1,3,6,1,12},{2,1,2,4,0,12},{2,1,2,4,1,12},{2,1,1,2,0,12},{2,1,4,8,0,8},{2,1,4,8,1,8},{1,2,1,2,0,12},{1,2,2,4,0,12},{1,2,2,4,1,12},{1,2,3,6,0,8},{1,2,3,6,1,8},{1,2,4,8,0,6},{1,2,4,8,1,6},{2,2,2,2,0,12},{2,2,2,4,0,12},{2,2,2,4,1,8},{2,2,4,8,0,4},{2,2,4,8,1,4},{2,2,1,2,0,12},{2,2,3,6,0,6},{2,2,3,6,1,6}};   // generated with the instantiation units (dsblock_rs_k3s*.hip): sh, sw, nch, nft, x6, waves
+    for (const auto& t : T) if (t[0] == sh && t[1] == sw && t[2] == nch && t[3] == nft && t[4] == x6) return t[5];
     return 0;
 }
 
-int dsblock_wp_format(const DsBlockP& p) { return rs_shape(p).ok ? IGEMM_W_K16 : IGEMM_W_X6; }
+int dsblock_wp_format(const DsBlockP& p) { const RsShape r = rs_shape(p); return !r.ok ? IGEMM_W_X6 : r.x6 ? IGEMM_W_X6RS : IGEMM_W_K16; }
 
 bool dsblock_eligible(const DsBlockP& p) {
     const char* e = getenv("OAR_FUSE_DSBLOCK");

@@ -3,11 +3,16 @@
 namespace oar {
 namespace k {
 #include "dsblock_rs.inc"
-void dsblock_rs_launch_k3s22(hipStream_t s, const DsRsP& p, int nch, int nft, int acts, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1) {
-    switch (nch * 1000 + nft * 10 + acts) {
-        OAR_RS_CASE(3, 2, 2, 2, 2, 8)
-        OAR_RS_CASE(3, 2, 2, 2, 4, 8)
-        OAR_RS_CASE(3, 2, 2, 1, 2, 12)
+void dsblock_rs_launch_k3s22(hipStream_t s, const DsRsP& p, int nch, int nft, int x6, int acts, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1) {
+    switch (nch * 10000 + nft * 100 + x6 * 10 + acts) {
+        OAR_RS_CASE(3, 2, 2, 2, 2, 12, 0)
+        OAR_RS_CASE(3, 2, 2, 2, 4, 12, 0)
+        OAR_RS_CASE(3, 2, 2, 2, 4, 8, 1)
+        OAR_RS_CASE(3, 2, 2, 4, 8, 4, 0)
+        OAR_RS_CASE(3, 2, 2, 4, 8, 4, 1)
+        OAR_RS_CASE(3, 2, 2, 1, 2, 12, 0)
+        OAR_RS_CASE(3, 2, 2, 3, 6, 6, 0)
+        OAR_RS_CASE(3, 2, 2, 3, 6, 6, 1)
         default: ::oar::fail(OAR_INTERNAL, "dsblock_rs: no kernel for this shape");
     }
 }

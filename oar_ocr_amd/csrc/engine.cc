@@ -1127,7 +1127,37 @@ struct Planner {
         std::memcpy(out.data(), f.data(), f.size() * 2);
         return out;
     }
+    // [rows][K] f32 GEMM weights -> the bf16x6 fragments of the row-streaming separable block (dsblock_rs.inc): Wr[rows/16][KP][3 planes][lane][8 bf16],
+    // KP = ceil(ceil(K/16)/2) k-steps of two 16-channel chunks; lane = (row & 15) + 16 * g holds, for e = 0..3, k = 32*kp + 4*g + e (first chunk) and,
+    // for e = 4..7, k = 32*kp + 16 + 4*g + (e - 4) (second chunk) -- the order in which that kernel's lanes hold the depthwise outputs
+    static std::vector<float> to_fragment_x6_rs(const std::vector<float>& w, int64_t rows, int64_t K) {
+        int64_t Rp = (rows + 63) / 64 * 64, KP = ((K + 15) / 16 + 1) / 2;
+        std::vector<uint16_t> f((size_t)Rp * KP * 32 * 3, 0);
+        for (int64_t r = 0; r < rows; ++r)
+            for (int64_t k = 0; k < K; ++k) {
+                float x = w[(size_t)r * K + k];
+                uint32_t u, um, ul;
+                std::memcpy(&u, &x, 4);
+                uint32_t uh = u & 0xFFFF0000u;
+                float fh; std::memcpy(&fh, &uh, 4);
+                float r1 = x - fh;
+                std::memcpy(&um, &r1, 4); um &= 0xFFFF0000u;
+                float fm; std::memcpy(&fm, &um, 4);
+                float r2 = r1 - fm;
+                std::memcpy(&ul, &r2, 4); ul &= 0xFFFF0000u;
+                int64_t nf = r / 16, c = r % 16, kp = k / 32, half = (k % 32) / 16, g = (k % 16) / 4, e = half * 4 + k % 4;
+                size_t lane = (size_t)(c + 16 * g);
+                size_t base = (size_t)((nf * KP + kp) * 3) * 64 * 8;
+                f[base + (0 * 64 + lane) * 8 + e] = (uint16_t)(uh >> 16);
+                f[base + (1 * 64 + lane) * 8 + e] = (uint16_t)(um >> 16);
+                f[base + (2 * 64 + lane) * 8 + e] = (uint16_t)(ul >> 16);
+            }
+        std::vector<float> out(f.size() / 2);
+        std::memcpy(out.data(), f.data(), f.size() * 2);
+        return out;
+    }
     static std::vector<float> to_fragments(int fmt, const std::vector<float>& w, int64_t rows, int64_t K) {
+        if (fmt == k::IGEMM_W_X6RS) return to_fragment_x6_rs(w, rows, K);
         return fmt == k::IGEMM_W_X6 ? to_fragment_x6(w, rows, K) : to_fragment_order(w, rows, K);
     }
     const float* conv_weight_igemm(const GNode& n, const HostTensor& W, int fmt) {
