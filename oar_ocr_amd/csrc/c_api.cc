@@ -660,7 +660,8 @@ oar_status oar_ocr_wait(oar_ocr* o, uint64_t ticket, oar_ocr_result* out) {
         OAR_CHECK(it != o->jobs.end(), OAR_INVALID_INPUT, "oar_ocr_wait: unknown (or already collected) ticket");
         job = it->second;
         o->done_cv.wait(lk, [&] { return job->done; });
-        o->jobs.erase(it);
+        // (the wait released the lock: another thread waiting on the same ticket may have collected it -- `it` is not to be trusted)
+        OAR_CHECK(o->jobs.erase(ticket) == 1, OAR_INVALID_INPUT, "oar_ocr_wait: ticket collected by another waiter");
     });
     if (st != OAR_OK) return st;
     if (job->status != OAR_OK) { oar::set_last_error(job->error); return job->status; }
@@ -824,8 +825,11 @@ oar_status oar_k_resize_filter(const uint8_t* rgb, uint32_t w, uint32_t h, uint3
 oar_status oar_k_layout_postprocess(const float* pred, uint32_t n_images, uint32_t rows, uint32_t feat, const float* src_wh, uint32_t num_classes, int32_t model_type,
                                     float score_threshold, float nms_threshold, uint32_t max_detections, oar_layout_result* out) {
     return guard([&] {
-        OAR_CHECK(out && (n_images == 0 || (src_wh && (rows == 0 || feat == 0 || pred))) && max_detections > 0 && max_detections <= 4096 && rows <= 65536, OAR_INVALID_INPUT,
+        OAR_CHECK(out && (n_images == 0 || (src_wh && (rows == 0 || feat == 0 || pred))) && max_detections > 0 && max_detections <= 4096 && rows <= 16384, OAR_INVALID_INPUT,
                   "oar_k_layout_postprocess: bad arguments");
+        // the row formats the kernel parses: 6 / 7 / 8 compact columns, or 4 box columns + one score per class
+        OAR_CHECK(feat == 0 || (feat >= 6 && feat <= 8) || (num_classes > 0 && feat == 4 + num_classes), OAR_INVALID_INPUT,
+                  "oar_k_layout_postprocess: feat must be 6, 7, 8 or 4 + num_classes");
         require_device();
         LayoutOut lo;
         lo.offsets.assign(1, 0);
@@ -1325,12 +1329,17 @@ oar_status oar_image_decode_device(const uint8_t* bytes, size_t len, int32_t dev
             const size_t qo = (po + 127) & ~(size_t)127;
             OAR_HIP(hipMemcpyAsync(base + qo, qh, sizeof qh, hipMemcpyHostToDevice, nullptr));
             plan.q = reinterpret_cast<const uint16_t*>(base + qo);
-            void* out = nullptr;
-            OAR_HIP(hipMalloc(&out, (size_t)ji.w * ji.h * 3));
-            pp::jpeg_render(nullptr, plan, static_cast<uint8_t*>(out));
+            // the page buffer is owned by a guard until it is handed to the caller: jpeg_render / the profiler scope may throw, and the
+            // pageable sources of the copies above (ji, qh) must outlive them on every path -- so the stream is drained before unwinding
+            struct PageGuard {
+                void* p = nullptr;
+                ~PageGuard() { (void)hipStreamSynchronize(nullptr); if (p) (void)hipFree(p); (void)hipGetLastError(); }
+            } page;
+            OAR_HIP(hipMalloc(&page.p, (size_t)ji.w * ji.h * 3));
+            pp::jpeg_render(nullptr, plan, static_cast<uint8_t*>(page.p));
             const hipError_t e = hipStreamSynchronize(nullptr);
-            if (e != hipSuccess) { (void)hipFree(out); fail(OAR_DEVICE, std::string("oar_image_decode_device: ") + hipGetErrorString(e)); }
-            *dev_rgb = out; *width = ji.w; *height = ji.h;
+            if (e != hipSuccess) fail(OAR_DEVICE, std::string("oar_image_decode_device: ") + hipGetErrorString(e));
+            *dev_rgb = page.p; page.p = nullptr; *width = ji.w; *height = ji.h;
             return;
         }
         // every other decoded format: host decode, one upload

@@ -69,7 +69,8 @@ __global__ __launch_bounds__(1024) void conv_igemm_ws_x6_kernel(IgemmWsX6P q) { 
     if (SE && wt_count > 0) {
         se_first = (int)((wt_begin * 16) / p.se_hw);
         const int se_last = (int)(min(p.M - 1, (wt_begin + wt_count) * 16 - 1) / p.se_hw);
-        const int cnt = min(se_last - se_first + 1, q.se_cap) * p.K;
+        if (se_last - se_first + 1 > q.se_cap) __builtin_trap();   // the host's bound (ws_x6_se_rows) undercounts this workgroup's images: fail loudly, never read unstaged gates
+        const int cnt = (se_last - se_first + 1) * p.K;
         for (int i = threadIdx.x; i < cnt; i += blockDim.x) se_lds[i] = p.se[(long)se_first * p.K + i];   // (visible after the barrier below)
     }
     constexpr int NL = 2;   // vector-memory loads per chunk: two float4 of one pixel fragment

@@ -195,14 +195,8 @@ void decode_png(const uint8_t* b, size_t n, std::vector<uint8_t>& rgb, uint32_t&
                 zs.next_in = idat.data() + in_at; zs.avail_in = (uInt)take; in_at += take;
             }
             const size_t have = raw.size();
-            if (have == raw_len) {   // the stream may hold nothing more than its end marker / checksum now
-                uint8_t extra;
-                zs.next_out = &extra; zs.avail_out = 1;
-                rc = inflate(&zs, Z_NO_FLUSH);
-                if (rc == Z_STREAM_END && zs.avail_out == 1) break;
-                inflateEnd(&zs);
-                oar::fail(OAR_INVALID_INPUT, "image load: corrupt or truncated PNG image data");
-            }
+            if (have == raw_len) break;   // the image is complete: whatever follows in the stream (end marker, adler32, excess IDAT bytes) is not
+                                          // looked at -- the png crate behind image 0.25 stops at the last scanline too
             const size_t grow = std::min<size_t>(raw_len - have, std::max<size_t>(have, 1u << 20));   // doubling, at least 1 MiB
             raw.resize(have + grow);
             zs.next_out = raw.data() + have; zs.avail_out = (uInt)grow;

@@ -77,6 +77,7 @@ struct BitReader {
     const uint8_t* p; const uint8_t* end;
     uint64_t buf = 0; int cnt = 0;
     int marker = 0;          // a marker met inside the entropy-coded segment (feeding stops, zeros follow)
+    long pad = 0;            // zero bits fed behind a marker / the end of the data (a scan that CONSUMES them has run out of data)
     void fill() {
         while (cnt <= 56) {
             int byte = 0;
@@ -90,6 +91,7 @@ struct BitReader {
             } else if (!marker) {
                 marker = 0xD9;   // ran off the data: behave as at EOI
             }
+            if (marker) pad += 8;
             buf |= (uint64_t)byte << (56 - cnt);
             cnt += 8;
         }
@@ -98,7 +100,9 @@ struct BitReader {
     inline void skip(int n) { buf <<= n; cnt -= n; }
     inline int get(int n) { if (n == 0) return 0; const int v = peek(n); skip(n); return v; }
     inline int bit() { return get(1); }
-    void align_reset() { buf = 0; cnt = 0; }
+    void align_reset() { buf = 0; cnt = 0; pad = 0; }
+    // padding bits already consumed: the bits still in the buffer are the most recently fed ones
+    long starved() const { return pad > cnt ? pad - cnt : 0; }
     int decode(const Huff& h) {
         if (cnt < 16) fill();
         const int look = (int)(buf >> 55);   // 9 bits
@@ -124,6 +128,10 @@ void jpeg_entropy_decode(const uint8_t* b, size_t n, JpegImage& im) {
     uint16_t qt[4][64];
     bool qdef[4] = {false, false, false, false};
     bool have_sof = false, progressive = false, jfif = false, seen_scan = false;
+    // untrusted input: a progressive file may carry any number of scans, each walking every block.  Legitimate encoders emit ~10 (libjpeg's
+    // default script) to a few dozen; the total work is capped as libjpeg-turbo / zune-jpeg cap it (scan count, block visits)
+    int n_scans = 0;
+    long long block_visits = 0, block_budget = 0;
     int adobe_transform = -1, restart_interval = 0;
     uint8_t comp_id[3] = {0, 0, 0};
     int comp_tq[3] = {0, 0, 0};
@@ -212,6 +220,13 @@ void jpeg_entropy_decode(const uint8_t* b, size_t n, JpegImage& im) {
             OAR_CHECK(have_sof && dl >= 1, OAR_INVALID_INPUT, "image load: JPEG scan before the frame header");
             const int ns = d[0];
             OAR_CHECK(ns >= 1 && ns <= im.ncomp && dl >= 1 + (size_t)ns * 2 + 3, OAR_INVALID_INPUT, "image load: bad JPEG SOS");
+            // an interleaved scan over a SUBSET of the components has its own MCU geometry (T.81 A.2.3); no encoder in use writes one
+            OAR_CHECK(ns == 1 || ns == im.ncomp, OAR_UNSUPPORTED_OP, "image load: JPEG scan interleaves a subset of the components (unsupported)");
+            OAR_CHECK(++n_scans <= 256, OAR_INVALID_INPUT, "image load: JPEG with more than 256 scans");
+            if (block_budget == 0) {
+                for (int k = 0; k < im.ncomp; ++k) block_budget += (long long)im.comp[k].bw * im.comp[k].bh;
+                block_budget = block_budget * 48 + 4096;   // every block visited 48 times: DC + 13 refinements of it, the AC bands and theirs, with room
+            }
             int sc[3], td[3], ta[3];
             for (int i = 0; i < ns; ++i) {
                 int c = -1;
@@ -236,6 +251,8 @@ void jpeg_entropy_decode(const uint8_t* b, size_t n, JpegImage& im) {
             int eobrun = 0;
             // one block of one component; (bx, by) in blocks
             auto block = [&](int i, int bx, int by) {
+                OAR_CHECK(++block_visits <= block_budget, OAR_INVALID_INPUT, "image load: JPEG scans exceed the decoding budget (too many passes over the image)");
+                OAR_CHECK(br.starved() <= 64, OAR_INVALID_INPUT, "image load: truncated JPEG (the entropy-coded data ends before the scan does)");
                 JpegComp& k = im.comp[sc[i]];
                 int16_t* cf = k.coef.data() + ((size_t)by * k.bw + bx) * 64;
                 if (!progressive) {

@@ -234,7 +234,7 @@ void LayoutDetector::run(const std::vector<Image>& images, LayoutOut& out) {
         }
         out.feature_dim = (uint32_t)feat;
         if (rows == 0 || feat == 0) { for (size_t i = 0; i < n; ++i) out.offsets.push_back((uint32_t)out.scores.size()); continue; }
-        OAR_CHECK(rows <= 65536, OAR_UNSUPPORTED_OP, "layout: more than 65536 candidate rows per image");
+        OAR_CHECK(rows <= 16384, OAR_UNSUPPORTED_OP, "layout: more than 16384 candidate rows per image");   // (one workgroup ranks an image: O(rows^2); rows bytes of LDS)
         cand_dev_.reserve((size_t)n * rows * 8 * 4); sorted_dev_.reserve((size_t)n * rows * 4); keep_dev_.reserve((size_t)n * (cfg_.max_detections + 1) * 4);
         pp::LayoutPostP p{};
         p.pred = eng_->out_ptr(po.loc); p.rows = rows; p.feat = feat; p.num_classes = (int)cfg_.num_classes; p.model_type = cfg_.model_type; p.max_det = (int)cfg_.max_detections;

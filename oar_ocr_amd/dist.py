@@ -15,10 +15,15 @@ from typing import List, Sequence, Tuple
 
 def shard_range(n_items: int, world_size: int, rank: int) -> Tuple[int, int]:
     """Static block partition: rank r gets [r*n/G, (r+1)*n/G) with the remainder spread over the first ranks."""
-    if world_size <= 0 or not (0 <= rank < world_size):
-        raise ValueError("bad world_size/rank")
-    from . import api   # oar_shard_range (C ABI: the same partition for a Rust / C host)
-    return api.shard_range(n_items, world_size, rank)
+    if world_size <= 0 or not (0 <= rank < world_size) or n_items < 0:
+        raise ValueError("bad n_items/world_size/rank")
+    try:
+        from . import api   # oar_shard_range (C ABI: the same partition for a Rust / C host)
+        return api.shard_range(n_items, world_size, rank)
+    except (OSError, ImportError):   # library not built on this host: the same arithmetic (oar_shard_range, ctc_host.cc)
+        base, rem = divmod(n_items, world_size)
+        lo = rank * base + min(rank, rem)
+        return lo, lo + base + (1 if rank < rem else 0)
 
 
 def init_from_env(backend: str | None = None):

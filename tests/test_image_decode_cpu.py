@@ -296,6 +296,50 @@ def test_jpeg_damage_and_undecoded_processes():
     assert "512 MiB allocation limit" in e.value.message
 
 
+def test_jpeg_scan_bomb_and_subset_scan_are_refused_quickly():
+    """untrusted progressive files -- every extra SOS walks all blocks again and a reader that feeds zeros past the data never
+    stops.  A file whose scans are repeated hundreds of times is refused by the scan cap / block budget in bounded time; data that ends
+    before its scan does is a truncation error; an interleaved scan over a subset of the components (own MCU geometry, T.81 A.2.3) is named
+    as unsupported rather than decoded with the frame's geometry."""
+    import time
+    a = _test_image(96, 128, 3)
+    prog = _jpeg_bytes(a, quality=85, progressive=True)
+    assert np.array_equal(api.load_image_from_memory(prog), _pil_rgb(prog))
+    # the scans of the file: (offset of FF DA, Ss, Ah)
+    scans, pos = [], 0
+    while True:
+        pos = prog.find(b"\xff\xda", pos)
+        if pos < 0:
+            break
+        ns = prog[pos + 4]
+        scans.append((pos, prog[pos + 5 + 2 * ns], prog[pos + 7 + 2 * ns] >> 4))
+        pos += 2
+    first = scans[0][0]
+    eoi = prog.rindex(b"\xff\xd9")
+    k = next(i for i, (_, ss, ah) in enumerate(scans) if ss == 0 and ah > 0)          # a DC refinement scan: legal to repeat (it ORs one bit)
+    end = scans[k + 1][0] if k + 1 < len(scans) else eoi
+    one_scan = prog[scans[k][0]:end]
+    bomb = prog[:eoi] + one_scan * 400 + b"\xff\xd9"
+    t0 = time.time()
+    with pytest.raises(api.OCRError) as e:
+        api.load_image_from_memory(bomb)
+    assert e.value.code == api.OAR_INVALID_INPUT and ("scans" in e.value.message or "budget" in e.value.message), e.value.message
+    assert time.time() - t0 < 5.0
+    assert np.array_equal(api.load_image_from_memory(prog[:eoi] + one_scan * 3 + b"\xff\xd9"), _pil_rgb(prog))   # a few repeats are just a longer file
+    # entropy-coded data cut inside the first scan, EOI appended: the scan would run on zeros
+    cut = prog[:first + 40] + b"\xff\xd9"
+    with pytest.raises(api.OCRError) as e:
+        api.load_image_from_memory(cut)
+    assert e.value.code == api.OAR_INVALID_INPUT
+    base = _jpeg_bytes(a, quality=85)
+    sos = base.index(b"\xff\xda")
+    assert base[sos + 4] == 3
+    subset = base[:sos + 2] + struct.pack(">H", 10) + bytes([2]) + base[sos + 5:sos + 9] + base[sos + 11:]
+    with pytest.raises(api.OCRError) as e:
+        api.load_image_from_memory(subset)
+    assert e.value.code == api.OAR_UNSUPPORTED_OP and "subset" in e.value.message
+
+
 def test_load_images_mixed_png_and_jpeg(tmp_path):
     """load_images (utils/image.rs:299-345) over a directory of both formats, sequential and parallel: same pages either way"""
     from PIL import Image
