@@ -465,6 +465,27 @@ oar_status oar_layout_preprocess(oar_layout* l, const uint8_t* rgb, uint32_t wid
 oar_status oar_k_resize_filter(const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, int32_t filter, uint8_t* out);
 oar_status oar_k_layout_postprocess(const float* pred, uint32_t n_images, uint32_t rows, uint32_t feat, const float* src_wh, uint32_t num_classes, int32_t model_type,
                                     float score_threshold, float nms_threshold, uint32_t max_detections, oar_layout_result* out);
+/* PP-DocLayout: the adapter's own PaddleX-style post-processing (LayoutDetectionAdapter::postprocess_pp_doclayout, layout_detection_adapter.rs:631-846)
+ * replaces LayoutPostProcess for model_type "pp-doclayout": per-class thresholds, paddlex_layout_nms (:884-935), filter_large_image_boxes (:955-995),
+ * apply_paddlex_merge_modes (:997-1100) and the reading-order sort, as one HIP kernel on the raw prediction rows (layout.hip ppdoc_post_kernel).
+ * Above the ABI stay: class labels, layout_unclip_ratio, max_elements.                                                                              */
+typedef struct {
+    float score_threshold;              /* LayoutDetectionConfig::score_threshold (clamped at 0 as the adapter does)                                 */
+    const float* class_thresholds;      /* [num_classes] by class id, NaN = not configured; NULL = none configured                                   */
+    int32_t layout_nms;                 /* LayoutDetectionConfig::layout_nms                                                                         */
+    int32_t image_class_id;             /* id of the label "image" or -1                                                                             */
+    int32_t formula_class_id;           /* id of the label "formula" or -1                                                                           */
+    const int32_t* class_merge_modes;   /* [num_classes] by class id: -1 not configured, 0 Large, 1 Union, 2 Small (MergeBboxMode); NULL = none      */
+} oar_ppdoc_cfg;
+oar_status oar_layout_run_ppdoc(oar_layout* l, const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights, uint32_t n_images, const oar_ppdoc_cfg* cfg,
+                                oar_layout_result* out);
+oar_status oar_k_ppdoc_postprocess(const float* pred, uint32_t n_images, uint32_t rows, uint32_t feat, const float* src_wh, uint32_t num_classes, const oar_ppdoc_cfg* cfg,
+                                   oar_layout_result* out);
+/* class_merge_modes of the PicoDet / RT-DETR adapters: apply_nms_with_merge (processors/layout_postprocess.rs:692-841) on one image's kept boxes
+ * (host code: a greedy, order-dependent merge of a few dozen boxes).  mode_of_class: [num_classes] 0 Large (the default of an unlisted class), 1 Union,
+ * 2 Small.  out_*: room for n entries; returns the number written.                                                                                  */
+int32_t oar_host_nms_with_merge(const float* boxes, const int32_t* classes, const float* scores, uint32_t n, const int32_t* mode_of_class, uint32_t num_classes,
+                                float nms_threshold, uint32_t max_detections, float* out_boxes, int32_t* out_classes, float* out_scores);
 
 /* ------------------------------------------------------------------------------------------------ device helpers */
 oar_status oar_dev_alloc(int32_t device_id, size_t bytes, void** out);

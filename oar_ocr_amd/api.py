@@ -142,7 +142,7 @@ EXPORTS = [
     "oar_rect_run", "oar_ocr_attach", "oar_k_rotate_rgb", "oar_k_bgr_planes_to_rgb", "oar_host_rotate_back_points",
     "oar_engine_cache_stats", "oar_onnx_inspect", "oar_host_contours", "oar_ctc_dict_create", "oar_ctc_dict_destroy", "oar_ctc_dict_classes",
     "oar_ctc_decode", "oar_ocr_decode", "oar_text_result_free", "oar_db_postprocess_ex", "oar_k_dilate", "oar_k_poly_scores", "oar_debug_inject_failure", "oar_k_contours", "oar_host_contours_bits",
-    "oar_k_unclip", "oar_k_rec_preprocess_flip", "oar_layout_create", "oar_layout_destroy", "oar_layout_run", "oar_layout_result_free", "oar_layout_preprocess", "oar_k_resize_filter", "oar_k_layout_postprocess", "oar_image_decode_device", "oar_ocr_predict_async", "oar_ocr_wait", "oar_ctc_word_boxes", "oar_char_positions_to_word_boxes", "oar_ocr_word_boxes", "oar_word_boxes_free", "oar_image_decode", "oar_image_free", "oar_host_approx_poly_dp", "oar_host_perimeter", "oar_host_unclip_poly", "oar_host_offset_ring", "oar_host_ring_outline", "oar_host_sort_poly_boxes",
+    "oar_k_unclip", "oar_k_rec_preprocess_flip", "oar_layout_create", "oar_layout_destroy", "oar_layout_run", "oar_layout_result_free", "oar_layout_preprocess", "oar_k_resize_filter", "oar_k_layout_postprocess", "oar_layout_run_ppdoc", "oar_k_ppdoc_postprocess", "oar_host_nms_with_merge", "oar_image_decode_device", "oar_ocr_predict_async", "oar_ocr_wait", "oar_ctc_word_boxes", "oar_char_positions_to_word_boxes", "oar_ocr_word_boxes", "oar_word_boxes_free", "oar_image_decode", "oar_image_free", "oar_host_approx_poly_dp", "oar_host_perimeter", "oar_host_unclip_poly", "oar_host_offset_ring", "oar_host_ring_outline", "oar_host_sort_poly_boxes",
 ]
 
 
@@ -1229,6 +1229,41 @@ def char_positions_to_word_boxes(line_bbox: np.ndarray, char_positions, char_cou
 
 
 # ------------------------------------------------------------------------------------------------ layout detection
+class PpDocCfg(C.Structure):
+    _fields_ = [("score_threshold", C.c_float), ("class_thresholds", C.POINTER(C.c_float)), ("layout_nms", C.c_int32), ("image_class_id", C.c_int32),
+                ("formula_class_id", C.c_int32), ("class_merge_modes", C.POINTER(C.c_int32))]
+
+
+MERGE_MODES = {"large": 0, "union": 1, "small": 2}   # MergeBboxMode (domain/tasks/layout_detection.rs:17-25)
+
+
+def _ppdoc_cfg(num_classes, class_labels, score_threshold, class_thresholds, layout_nms, class_merge_modes):
+    """LayoutDetectionConfig + LayoutModelConfig -> oar_ppdoc_cfg (label-keyed maps become class-id-indexed arrays, as the adapter builds them, :645-675).
+    Returns (cfg, keepalive)."""
+    cfg = PpDocCfg()
+    cfg.score_threshold = score_threshold
+    cfg.layout_nms = int(bool(layout_nms))
+    by_label = {v: k for k, v in class_labels.items()}
+    cfg.image_class_id = by_label.get("image", -1)
+    cfg.formula_class_id = by_label.get("formula", -1)
+    keep = []
+    if class_thresholds:
+        thr = np.full(max(num_classes, 1), np.nan, np.float32)
+        for cid, label in class_labels.items():
+            if label in class_thresholds and 0 <= cid < num_classes:
+                thr[cid] = class_thresholds[label]
+        keep.append(thr)
+        cfg.class_thresholds = thr.ctypes.data_as(C.POINTER(C.c_float))
+    if class_merge_modes:
+        mm = np.full(max(num_classes, 1), -1, np.int32)
+        for cid, label in class_labels.items():
+            if label in class_merge_modes and 0 <= cid < num_classes:
+                mm[cid] = MERGE_MODES[class_merge_modes[label]]
+        keep.append(mm)
+        cfg.class_merge_modes = mm.ctypes.data_as(C.POINTER(C.c_int32))
+    return cfg, keep
+
+
 LAYOUT_FILTERS = {"triangle": 0, "catmullrom": 1, "lanczos3": 2}
 LAYOUT_MODEL_TYPES = {"picodet": 0, "rtdetr": 1, "pp-doclayout": 2}
 
@@ -1250,6 +1285,20 @@ class LayoutModelConfig:
     def picodet_layout_1x_table():                 # :74-85
         return LayoutModelConfig("picodet_layout_1x_table", 1, {0: "table"}, "picodet", (800, 608))
 
+    _PPDOC23 = ["paragraph_title", "image", "text", "number", "abstract", "content", "figure_title", "formula", "table", "table_title", "reference", "doc_title",
+                "footnote", "header", "algorithm", "footer", "seal", "chart_title", "chart", "formula_number", "header_image", "footer_image", "aside_text"]
+    _PPDOCV2 = ["abstract", "algorithm", "aside_text", "chart", "content", "display_formula", "doc_title", "figure_title", "footer", "footer_image", "footnote",
+                "formula_number", "header", "header_image", "image", "inline_formula", "number", "paragraph_title", "reference", "reference_content", "seal", "table",
+                "text", "vertical_text", "vision_footnote"]
+
+    @staticmethod
+    def pp_doclayout_s():                          # layout_detection_adapter.rs:242-275 (23 classes, 480 x 480)
+        return LayoutModelConfig("pp-doclayout-s", 23, dict(enumerate(LayoutModelConfig._PPDOC23)), "pp-doclayout", (480, 480))
+
+    @staticmethod
+    def pp_doclayoutv2():                          # :383-418 (25 classes, 800 x 800; rows carry (col, row) reading-order columns)
+        return LayoutModelConfig("pp-doclayoutv2", 25, dict(enumerate(LayoutModelConfig._PPDOCV2)), "pp-doclayout", (800, 800))
+
     def preprocess(self):
         """(filter, bgr, mean, std) of the model family"""
         if self.model_type == "pp-doclayout":
@@ -1259,15 +1308,26 @@ class LayoutModelConfig:
 
 @dataclass
 class LayoutDetectionConfig:
-    """domain/tasks/layout_detection.rs:47-78 (class_merge_modes is not carried by this mirror)"""
+    """domain/tasks/layout_detection.rs:47-78"""
     score_threshold: float = 0.5
     max_elements: int = 100
     class_thresholds: Optional[dict] = None
     nms_threshold: float = 0.5
     layout_unclip_ratio: Optional[object] = None    # float | (w, h) | {class_id: (w, h)}
+    class_merge_modes: Optional[dict] = None        # {label: "large" | "union" | "small"}
+    layout_nms: bool = True
 
     def get_class_threshold(self, name: str) -> float:   # :287-292
         return (self.class_thresholds or {}).get(name, self.score_threshold)
+
+    @staticmethod
+    def with_pp_doclayoutv2_defaults():                  # domain/tasks/layout_detection.rs:140-205
+        low = {"display_formula", "doc_title", "inline_formula", "paragraph_title", "text", "vertical_text"}
+        large = {"chart", "display_formula", "doc_title", "inline_formula", "paragraph_title"}
+        thr = {n: (0.45 if n == "seal" else 0.4 if n in low else 0.5) for n in LayoutModelConfig._PPDOCV2}
+        modes = {n: ("large" if n in large else "union") for n in LayoutModelConfig._PPDOCV2}
+        return LayoutDetectionConfig(score_threshold=0.4, max_elements=100, class_thresholds=thr, nms_threshold=0.5, layout_unclip_ratio=(1.0, 1.0),
+                                     class_merge_modes=modes, layout_nms=True)
 
 
 @dataclass
@@ -1336,13 +1396,43 @@ class LayoutDetectionPredictor:
         finally:
             lib().oar_layout_result_free(C.byref(res))
 
+    def detect_raw_ppdoc(self, images: Sequence[np.ndarray], cfg: "LayoutDetectionConfig"):
+        """postprocess_pp_doclayout up to the reading-order sort (oar_layout_run_ppdoc): per image (boxes, classes, scores) in final order"""
+        imgs, ptrs, ws, hs = _img_arrays(images)
+        pc, keep = _ppdoc_cfg(self.model_config.num_classes, self.model_config.class_labels, cfg.score_threshold, cfg.class_thresholds, cfg.layout_nms, cfg.class_merge_modes)
+        res = LayoutResult()
+        _check(lib().oar_layout_run_ppdoc(self._h, ptrs, ws, hs, len(imgs), C.byref(pc), C.byref(res)))
+        del keep
+        try:
+            return _unpack_layout(res), int(res.feature_dim)
+        finally:
+            lib().oar_layout_result_free(C.byref(res))
+
     def predict(self, images: Sequence[np.ndarray], config: Optional[LayoutDetectionConfig] = None):
         cfg = config or self.config
+        if self.model_config.model_type == "pp-doclayout":        # layout_detection_adapter.rs:545-547: the adapter's own post-processing
+            per_image, feat = self.detect_raw_ppdoc(images, cfg)
+            out = []
+            for boxes, classes, scores in per_image:
+                if cfg.layout_unclip_ratio is not None:
+                    boxes = unclip_boxes(boxes, classes, cfg.layout_unclip_ratio)
+                els = []
+                for b, c, s in zip(boxes, classes, scores):          # (no second threshold here: :813-831)
+                    name = self.model_config.class_labels.get(int(c), "unknown")
+                    els.append(LayoutDetectionElement(np.array([[b[0], b[1]], [b[2], b[1]], [b[2], b[3]], [b[0], b[3]]], np.float32), name, float(s)))
+                    if len(els) >= cfg.max_elements:
+                        break
+                out.append(els)
+            self.is_reading_order_sorted = feat in (7, 8)
+            return out
         per_image, feat = self.detect_raw(images)
         out = []
         for boxes, classes, scores in per_image:
             if cfg.layout_unclip_ratio is not None:
                 boxes = unclip_boxes(boxes, classes, cfg.layout_unclip_ratio)
+            if cfg.class_merge_modes is not None:                # apply_nms_with_merge (:577-587)
+                modes = [cfg.class_merge_modes.get(self.model_config.class_labels.get(c, "unknown"), "large") for c in range(self.model_config.num_classes)]
+                boxes, classes, scores = host_nms_with_merge(boxes, classes, scores, modes, cfg.nms_threshold, cfg.max_elements)
             els = []
             for b, c, s in zip(boxes, classes, scores):
                 name = self.model_config.class_labels.get(int(c), "unknown")
@@ -1373,6 +1463,37 @@ def _unpack_layout(res: "LayoutResult"):
     cls = np.ctypeslib.as_array(res.classes, shape=(max(nb, 1),)).copy()[:nb]
     sc = np.ctypeslib.as_array(res.scores, shape=(max(nb, 1),)).copy()[:nb]
     return [(boxes[offs[i]:offs[i + 1]], cls[offs[i]:offs[i + 1]], sc[offs[i]:offs[i + 1]]) for i in range(n)]
+
+
+def k_ppdoc_postprocess(pred, src_wh, num_classes, class_labels, score_threshold=0.5, class_thresholds=None, layout_nms=True, class_merge_modes=None):
+    """pred: [n_images, rows, feat]; the HIP PP-DocLayout post-processing on caller-supplied predictions (oar_k_ppdoc_postprocess)."""
+    pred = np.ascontiguousarray(pred, np.float32)
+    n, rows, feat = pred.shape
+    wh = np.ascontiguousarray(src_wh, np.float32).reshape(n, 2)
+    pc, keep = _ppdoc_cfg(num_classes, class_labels, score_threshold, class_thresholds, layout_nms, class_merge_modes)
+    res = LayoutResult()
+    _check(lib().oar_k_ppdoc_postprocess(_p(pred) if pred.size else None, n, rows, feat, _p(wh), num_classes, C.byref(pc), C.byref(res)))
+    del keep
+    try:
+        return _unpack_layout(res)
+    finally:
+        lib().oar_layout_result_free(C.byref(res))
+
+
+def host_nms_with_merge(boxes, classes, scores, mode_of_class, nms_threshold=0.5, max_detections=100):
+    """apply_nms_with_merge (processors/layout_postprocess.rs:743-841) through the C ABI; mode_of_class: per class id "large" | "union" | "small"."""
+    b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 4)
+    c = np.ascontiguousarray(classes, np.int32)
+    s = np.ascontiguousarray(scores, np.float32)
+    modes = np.ascontiguousarray([MERGE_MODES[m] for m in mode_of_class], np.int32)
+    n = len(s)
+    ob, oc, os_ = np.zeros((max(n, 1), 4), np.float32), np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float32)
+    L = lib()
+    L.oar_host_nms_with_merge.restype = C.c_int32
+    k = L.oar_host_nms_with_merge(_p(b), _p(c), _p(s), n, _p(modes), len(modes), C.c_float(nms_threshold), int(max_detections), _p(ob), _p(oc), _p(os_))
+    if k < 0:
+        raise OCRError(OAR_INVALID_INPUT, "oar_host_nms_with_merge failed")
+    return ob[:k].copy(), oc[:k].copy(), os_[:k].copy()
 
 
 def k_resize_filter(rgb, nw, nh, filter="lanczos3"):

@@ -785,6 +785,20 @@ oar_status oar_layout_run(oar_layout* l, const uint8_t* const* rgb, const uint32
         fill_layout_result(lo, out);
     });
 }
+oar_status oar_layout_run_ppdoc(oar_layout* l, const uint8_t* const* rgb, const uint32_t* widths, const uint32_t* heights, uint32_t n_images, const oar_ppdoc_cfg* cfg,
+                                oar_layout_result* out) {
+    return guard([&] {
+        OAR_CHECK(l && out && cfg && (n_images == 0 || (rgb && widths && heights)), OAR_INVALID_INPUT, "oar_layout_run_ppdoc: bad arguments");
+        std::vector<LayoutDetector::Image> imgs(n_images);
+        for (uint32_t i = 0; i < n_images; ++i) { imgs[i].host = rgb[i]; imgs[i].w = widths[i]; imgs[i].h = heights[i]; }
+        LayoutDetector::PpDocCfg pc;
+        pc.score_threshold = cfg->score_threshold; pc.class_thr = cfg->class_thresholds; pc.layout_nms = cfg->layout_nms != 0;
+        pc.image_class = cfg->image_class_id; pc.formula_class = cfg->formula_class_id; pc.merge_mode = cfg->class_merge_modes;
+        LayoutOut lo;
+        l->l->run_ppdoc(imgs, pc, lo);
+        fill_layout_result(lo, out);
+    });
+}
 void oar_layout_result_free(oar_layout_result* r) {
     if (!r) return;
     std::free(r->box_offsets); std::free(r->boxes); std::free(r->classes); std::free(r->scores);
@@ -827,9 +841,9 @@ oar_status oar_k_layout_postprocess(const float* pred, uint32_t n_images, uint32
     return guard([&] {
         OAR_CHECK(out && (n_images == 0 || (src_wh && (rows == 0 || feat == 0 || pred))) && max_detections > 0 && max_detections <= 4096 && rows <= 16384, OAR_INVALID_INPUT,
                   "oar_k_layout_postprocess: bad arguments");
-        // the row formats the kernel parses: 6 / 7 / 8 compact columns, or 4 box columns + one score per class
-        OAR_CHECK(feat == 0 || (feat >= 6 && feat <= 8) || (num_classes > 0 && feat == 4 + num_classes), OAR_INVALID_INPUT,
-                  "oar_k_layout_postprocess: feat must be 6, 7, 8 or 4 + num_classes");
+        // the row formats the kernel parses: 6 / 7 / 8 compact columns, or 4 box columns + one score per class; any other width yields no detections, as
+        // the reference's row parser does (layout_postprocess.rs:277-340) -- every read stays inside the row, so only the size is bounded here
+        OAR_CHECK(feat <= 4 + 4096 && num_classes <= 4096, OAR_INVALID_INPUT, "oar_k_layout_postprocess: feat / num_classes out of range");
         require_device();
         LayoutOut lo;
         lo.offsets.assign(1, 0);
@@ -1356,6 +1370,58 @@ oar_status oar_image_decode_device(const uint8_t* bytes, size_t len, int32_t dev
     });
 }
 
+oar_status oar_k_ppdoc_postprocess(const float* pred, uint32_t n_images, uint32_t rows, uint32_t feat, const float* src_wh, uint32_t num_classes, const oar_ppdoc_cfg* cfg,
+                                   oar_layout_result* out) {
+    return guard([&] {
+        OAR_CHECK(out && cfg && (n_images == 0 || (src_wh && (rows == 0 || pred))) && rows <= 16384 && num_classes > 0 && num_classes <= 4096, OAR_INVALID_INPUT,
+                  "oar_k_ppdoc_postprocess: bad arguments");
+        OAR_CHECK(rows == 0 || (feat >= 6 && feat <= 8), OAR_INVALID_INPUT, "oar_k_ppdoc_postprocess: feat must be 6, 7 or 8");
+        require_device();
+        LayoutOut lo;
+        lo.offsets.assign(1, 0);
+        lo.feature_dim = feat;
+        if (n_images == 0 || rows == 0) { for (uint32_t i = 0; i < n_images; ++i) lo.offsets.push_back(0); fill_layout_result(lo, out); return; }
+        DevBuf dpred, dwh, dcand, dsorted, dkeep, dcfg;
+        const size_t np = (size_t)n_images * rows * feat;
+        dpred.reserve(np * 4); dwh.reserve((size_t)n_images * 8); dcand.reserve((size_t)n_images * rows * 32); dsorted.reserve((size_t)n_images * rows * 4);
+        dkeep.reserve((size_t)n_images * (rows + 1) * 4); dcfg.reserve((size_t)num_classes * 8 + 16);
+        OAR_HIP(hipMemcpy(dpred.p, pred, np * 4, hipMemcpyHostToDevice));
+        OAR_HIP(hipMemcpy(dwh.p, src_wh, (size_t)n_images * 8, hipMemcpyHostToDevice));
+        if (cfg->class_thresholds) OAR_HIP(hipMemcpy(dcfg.p, cfg->class_thresholds, (size_t)num_classes * 4, hipMemcpyHostToDevice));
+        if (cfg->class_merge_modes) OAR_HIP(hipMemcpy(dcfg.as<uint8_t>() + (size_t)num_classes * 4, cfg->class_merge_modes, (size_t)num_classes * 4, hipMemcpyHostToDevice));
+        pp::PpDocPostP q{};
+        q.pred = dpred.as<float>(); q.rows = (int)rows; q.feat = (int)feat; q.num_classes = (int)num_classes; q.score_thr = cfg->score_threshold;
+        q.class_thr = cfg->class_thresholds ? dcfg.as<float>() : nullptr; q.layout_nms = cfg->layout_nms ? 1 : 0; q.image_class = cfg->image_class_id; q.formula_class = cfg->formula_class_id;
+        q.merge_mode = cfg->class_merge_modes ? reinterpret_cast<const int*>(dcfg.as<uint8_t>() + (size_t)num_classes * 4) : nullptr;
+        q.src_wh = dwh.as<float>(); q.cand = dcand.as<float>(); q.sorted = dsorted.as<int>(); q.keep = dkeep.as<int>(); q.n_keep = dkeep.as<int>() + (size_t)n_images * rows;
+        pp::ppdoc_postprocess(nullptr, q, (int)n_images);
+        OAR_HIP(hipDeviceSynchronize());
+        std::vector<int> keep((size_t)n_images * (rows + 1));
+        std::vector<float> cand((size_t)n_images * rows * 8);
+        OAR_HIP(hipMemcpy(keep.data(), dkeep.p, keep.size() * 4, hipMemcpyDeviceToHost));
+        OAR_HIP(hipMemcpy(cand.data(), dcand.p, cand.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n_images; ++i) {
+            const int nk = keep[(size_t)n_images * rows + i];
+            for (int k = 0; k < nk; ++k) {
+                const float* c8 = cand.data() + ((size_t)i * rows + (size_t)keep[(size_t)i * rows + k]) * 8;
+                lo.boxes.insert(lo.boxes.end(), c8, c8 + 4);
+                lo.scores.push_back(c8[4]);
+                int32_t cls; std::memcpy(&cls, &c8[5], 4);
+                lo.classes.push_back(cls);
+            }
+            lo.offsets.push_back((uint32_t)lo.scores.size());
+        }
+        fill_layout_result(lo, out);
+    });
+}
+int32_t oar_host_nms_with_merge(const float* boxes, const int32_t* classes, const float* scores, uint32_t n, const int32_t* mode_of_class, uint32_t num_classes,
+                                float nms_threshold, uint32_t max_detections, float* out_boxes, int32_t* out_classes, float* out_scores) {
+    try {
+        if (n == 0) return 0;
+        if (!boxes || !classes || !scores || !mode_of_class || !out_boxes || !out_classes || !out_scores) return -1;
+        return host::nms_with_merge(boxes, classes, scores, (int)n, mode_of_class, (int)num_classes, nms_threshold, (int)max_detections, out_boxes, out_classes, out_scores);
+    } catch (...) { return -1; }
+}
 int32_t oar_host_approx_poly_dp(const float* xy, int32_t n_points, float epsilon, float* out_xy, int32_t cap_points) {
     try {
         std::vector<host::Pt> p(n_points > 0 ? n_points : 0);

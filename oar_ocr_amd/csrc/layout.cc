@@ -185,7 +185,10 @@ void LayoutDetector::preprocess_only(const Image& im, std::vector<float>& chw) {
     OAR_HIP(hipStreamSynchronize(eng_->stream()));
 }
 
-void LayoutDetector::run(const std::vector<Image>& images, LayoutOut& out) {
+void LayoutDetector::run(const std::vector<Image>& images, LayoutOut& out) { run_impl(images, nullptr, out); }
+void LayoutDetector::run_ppdoc(const std::vector<Image>& images, const PpDocCfg& pc, LayoutOut& out) { run_impl(images, &pc, out); }
+
+void LayoutDetector::run_impl(const std::vector<Image>& images, const PpDocCfg* pc, LayoutOut& out) {
     std::lock_guard<std::mutex> lk(mu_);
     OAR_HIP(hipSetDevice(eng_->device()));
     hipStream_t s = eng_->stream();
@@ -235,6 +238,39 @@ void LayoutDetector::run(const std::vector<Image>& images, LayoutOut& out) {
         out.feature_dim = (uint32_t)feat;
         if (rows == 0 || feat == 0) { for (size_t i = 0; i < n; ++i) out.offsets.push_back((uint32_t)out.scores.size()); continue; }
         OAR_CHECK(rows <= 16384, OAR_UNSUPPORTED_OP, "layout: more than 16384 candidate rows per image");   // (one workgroup ranks an image: O(rows^2); rows bytes of LDS)
+        if (pc) {
+            // ---- the PP-DocLayout adapter's post-processing (layout.hip ppdoc_post_kernel): the kept rows come back in their final order
+            OAR_CHECK(feat >= 6 && feat <= 8, OAR_INVALID_INPUT, "pp-doclayout: expected 6, 7 or 8 prediction columns, got " + std::to_string(feat));
+            cand_dev_.reserve((size_t)n * rows * 8 * 4); sorted_dev_.reserve((size_t)n * rows * 4); keep_dev_.reserve((size_t)n * (rows + 1) * 4);
+            const size_t nc = cfg_.num_classes;
+            DevBuf cfg_dev;
+            cfg_dev.reserve(nc * 8 + 16);
+            if (pc->class_thr) OAR_HIP(hipMemcpyAsync(cfg_dev.p, pc->class_thr, nc * 4, hipMemcpyHostToDevice, s));
+            if (pc->merge_mode) OAR_HIP(hipMemcpyAsync(cfg_dev.as<uint8_t>() + nc * 4, pc->merge_mode, nc * 4, hipMemcpyHostToDevice, s));
+            pp::PpDocPostP q{};
+            q.pred = eng_->out_ptr(po.loc); q.rows = rows; q.feat = feat; q.num_classes = (int)nc; q.score_thr = pc->score_threshold;
+            q.class_thr = pc->class_thr ? cfg_dev.as<float>() : nullptr; q.layout_nms = pc->layout_nms ? 1 : 0; q.image_class = pc->image_class; q.formula_class = pc->formula_class;
+            q.merge_mode = pc->merge_mode ? reinterpret_cast<const int*>(cfg_dev.as<uint8_t>() + nc * 4) : nullptr;
+            q.src_wh = d_wh; q.cand = cand_dev_.as<float>(); q.sorted = sorted_dev_.as<int>(); q.keep = keep_dev_.as<int>(); q.n_keep = keep_dev_.as<int>() + (size_t)n * rows;
+            pp::ppdoc_postprocess(s, q, (int)n);
+            std::vector<int> keep((size_t)n * (rows + 1));
+            std::vector<float> cand((size_t)n * rows * 8);
+            OAR_HIP(hipMemcpyAsync(keep.data(), keep_dev_.p, keep.size() * 4, hipMemcpyDeviceToHost, s));
+            OAR_HIP(hipMemcpyAsync(cand.data(), cand_dev_.p, cand.size() * 4, hipMemcpyDeviceToHost, s));
+            OAR_HIP(hipStreamSynchronize(s));   // (also: the configuration copies have left their host sources)
+            for (size_t i = 0; i < n; ++i) {
+                const int nk = keep[(size_t)n * rows + i];
+                for (int k = 0; k < nk; ++k) {
+                    const float* c8 = cand.data() + (i * (size_t)rows + (size_t)keep[i * (size_t)rows + k]) * 8;
+                    out.boxes.insert(out.boxes.end(), c8, c8 + 4);
+                    out.scores.push_back(c8[4]);
+                    int32_t cls; std::memcpy(&cls, &c8[5], 4);
+                    out.classes.push_back(cls);
+                }
+                out.offsets.push_back((uint32_t)out.scores.size());
+            }
+            continue;
+        }
         cand_dev_.reserve((size_t)n * rows * 8 * 4); sorted_dev_.reserve((size_t)n * rows * 4); keep_dev_.reserve((size_t)n * (cfg_.max_detections + 1) * 4);
         pp::LayoutPostP p{};
         p.pred = eng_->out_ptr(po.loc); p.rows = rows; p.feat = feat; p.num_classes = (int)cfg_.num_classes; p.model_type = cfg_.model_type; p.max_det = (int)cfg_.max_detections;
@@ -272,5 +308,50 @@ void LayoutDetector::run(const std::vector<Image>& images, LayoutOut& out) {
     }
     if (Profiler::get().enabled) Profiler::get().flush();
 }
+
+
+namespace host {
+// apply_nms_with_merge: groups grow greedily in score order -- a seed box absorbs every later-ranked box of its class that overlaps the GROWING merged box
+// by more than the threshold; the group's box is merged per the class's mode, its score is the group maximum, its place the earliest input index.
+int nms_with_merge(const float* boxes, const int32_t* classes, const float* scores, int n, const int32_t* mode_of_class, int num_classes, float nms_thr, int max_det,
+                   float* out_boxes, int32_t* out_classes, float* out_scores) {
+    if (n <= 0) return 0;
+    struct Group { float b[4]; int32_t cls; float score; int first; };
+    std::vector<int> order((size_t)n);
+    for (int i = 0; i < n; ++i) order[(size_t)i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return scores[b] < scores[a]; });   // descending; unordered pairs stay put
+    std::vector<char> used((size_t)n, 0);
+    std::vector<Group> groups;
+    auto area = [](const float* b) { return (b[2] - b[0]) * (b[3] - b[1]); };
+    auto iou = [&](const float* a, const float* b) {
+        const float x0 = std::max(a[0], b[0]), y0 = std::max(a[1], b[1]), x1 = std::min(a[2], b[2]), y1 = std::min(a[3], b[3]);
+        if (x1 <= x0 || y1 <= y0) return 0.0f;
+        const float inter = (x1 - x0) * (y1 - y0), uni = area(a) + area(b) - inter;
+        return uni > 0.0f ? inter / uni : 0.0f;
+    };
+    for (int seed : order) {
+        if (used[(size_t)seed]) continue;
+        used[(size_t)seed] = 1;
+        Group gq;
+        std::memcpy(gq.b, boxes + 4 * (size_t)seed, 16); gq.cls = classes[seed]; gq.score = scores[seed]; gq.first = seed;
+        const int mode = gq.cls >= 0 && gq.cls < num_classes ? mode_of_class[gq.cls] : 0;
+        for (int other : order) {
+            if (other == seed || used[(size_t)other] || classes[other] != gq.cls) continue;
+            const float* ob = boxes + 4 * (size_t)other;
+            if (!(iou(gq.b, ob) > nms_thr)) continue;
+            if (mode == 1) { gq.b[0] = std::min(gq.b[0], ob[0]); gq.b[1] = std::min(gq.b[1], ob[1]); gq.b[2] = std::max(gq.b[2], ob[2]); gq.b[3] = std::max(gq.b[3], ob[3]); }
+            else if (mode == 2 ? !(area(gq.b) <= area(ob)) : !(area(gq.b) >= area(ob))) std::memcpy(gq.b, ob, 16);
+            gq.score = std::max(gq.score, scores[other]);
+            gq.first = std::min(gq.first, other);
+            used[(size_t)other] = 1;
+        }
+        groups.push_back(gq);
+    }
+    if ((int)groups.size() > max_det) groups.resize((size_t)std::max(max_det, 0));   // the groups are in score order: the best max_det survive
+    std::stable_sort(groups.begin(), groups.end(), [](const Group& a, const Group& b) { return a.first < b.first; });
+    for (size_t i = 0; i < groups.size(); ++i) { std::memcpy(out_boxes + 4 * i, groups[i].b, 16); out_classes[i] = groups[i].cls; out_scores[i] = groups[i].score; }
+    return (int)groups.size();
+}
+}  // namespace host
 
 }  // namespace oar

@@ -53,11 +53,28 @@ struct LayoutPostP {
     int* keep;               // out [n_images][max_det] candidate rows in keep order
     int* n_keep;             // out [n_images]
 };
+struct PpDocPostP {           // the PP-DocLayout adapter's own post-processing (layout.hip ppdoc_post_kernel)
+    const float* pred;       // [n_images][rows][feat], feat 6 | 7 | 8
+    int rows, feat, num_classes;
+    float score_thr;
+    const float* class_thr;  // [num_classes] per-class threshold, NaN = not configured; may be null
+    int layout_nms, image_class, formula_class;
+    const int* merge_mode;   // [num_classes]: -1 not configured, 0 Large, 1 Union, 2 Small; may be null
+    const float* src_wh;     // [n_images][2]
+    float* cand;             // scratch [n_images][rows][8]: x1 y1 x2 y2 score class order0 order1
+    int* sorted;             // scratch [n_images][rows]
+    int* keep;               // out [n_images][rows]: candidate rows in final order
+    int* n_keep;             // out [n_images]
+};
+void ppdoc_postprocess(hipStream_t s, const PpDocPostP& p, int n_images);
 // LayoutPostProcess for every image of a batch: one workgroup per image (parse -> stable rank by score -> greedy class-aware NMS)
 void layout_postprocess(hipStream_t s, const LayoutPostP& p, int n_images);
 }  // namespace pp
 
 namespace host {
+// apply_nms_with_merge (processors/layout_postprocess.rs:743-841); returns the number of boxes written
+int nms_with_merge(const float* boxes, const int32_t* classes, const float* scores, int n, const int32_t* mode_of_class, int num_classes, float nms_thr, int max_det,
+                   float* out_boxes, int32_t* out_classes, float* out_scores);
 // taps of one axis: image's sample loop (same statements as the oracle, kept in C++ for the product); returns max taps
 int filter_taps(int filter, int in_len, int out_len, std::vector<pp::FilterTaps>& taps, std::vector<float>& weights);
 }  // namespace host
@@ -67,12 +84,16 @@ class LayoutDetector {
     LayoutDetector(const uint8_t* onnx, size_t len, const LayoutCfg& cfg);
     struct Image { const uint8_t* host = nullptr; const uint8_t* dev = nullptr; uint32_t w = 0, h = 0; };
     void run(const std::vector<Image>& images, LayoutOut& out);
+    // PP-DocLayout: the adapter's post-processing instead of LayoutPostProcess (host arrays are copied to the device per call)
+    struct PpDocCfg { float score_threshold = 0.5f; const float* class_thr = nullptr; bool layout_nms = true; int image_class = -1, formula_class = -1; const int32_t* merge_mode = nullptr; };
+    void run_ppdoc(const std::vector<Image>& images, const PpDocCfg& pc, LayoutOut& out);
     // the preprocessed tensor of ONE image, [3, H, W] f32 on the host (parity tests)
     void preprocess_only(const Image& im, std::vector<float>& chw);
     Engine& engine() { return *eng_; }
 
    private:
     const float* preprocess(const std::vector<Image>& images, size_t i0, size_t n, std::vector<float>& scale_factor, std::vector<float>& src_wh);
+    void run_impl(const std::vector<Image>& images, const PpDocCfg* pc, LayoutOut& out);
     std::unique_ptr<Engine> eng_;
     LayoutCfg cfg_;
     bool wants_im_shape_ = false;

@@ -174,6 +174,195 @@ __global__ __launch_bounds__(256) void layout_post_kernel(LayoutPostP p) {
     __syncthreads();
     if (tid == 0) p.n_keep[img] = s_nkeep;
 }
+
+// ------------------------------------------------------------------------------------------ PP-DocLayout adapter post-processing
+// LayoutDetectionAdapter::postprocess_pp_doclayout (domain/adapters/layout_detection_adapter.rs:631-846) up to and including the reading-order
+// sort, one workgroup per image, every list operation as a parallel predicate over the candidate rows instead of the reference's Vec rebuilds:
+//   A  parse + per-class threshold + coordinate conversion + validity                       (:683-732)      one row per thread
+//   B  paddlex_layout_nms (:884-935): stable descending rank by counting, then the in-place marking form of the reference (a lane per later
+//      candidate tests the selected box; same-class IoU >= 0.6 or cross-class >= 0.98 suppresses; IoU is paddlex_iou's "+ 1" form, :937-953)
+//   C  filter_large_image_boxes (:955-995): page-sized "image" boxes dropped unless nothing else is left
+//   D  apply_paddlex_merge_modes (:997-1100): per configured class, containment (>= 0.9 of the inner box's area) against the list as it was
+//      before the step; Large drops the contained, Small drops a container that is not itself contained
+//   E  reading order (:785-811): stable rank by f32::total_cmp on the order column(s), by counting
+// List state = one byte per candidate row in LDS (bit 0 candidate, bit 1 alive); positions are recomputed by counting when an order is needed.
+__device__ __forceinline__ float ppd_iou(const float* a, const float* b) {
+    const float iw = fmaxf(fminf(a[2], b[2]) - fmaxf(a[0], b[0]) + 1.0f, 0.0f), ih = fmaxf(fminf(a[3], b[3]) - fmaxf(a[1], b[1]) + 1.0f, 0.0f);
+    const float inter = iw * ih;
+    const float uni = (a[2] - a[0] + 1.0f) * (a[3] - a[1] + 1.0f) + (b[2] - b[0] + 1.0f) * (b[3] - b[1] + 1.0f) - inter;
+    return uni > 0.0f ? inter / uni : 0.0f;
+}
+__device__ __forceinline__ bool ppd_contained(const float* in, const float* out) {
+    const float area = (in[2] - in[0]) * (in[3] - in[1]);
+    if (area <= 0.0f) return false;
+    const float iw = fmaxf(fminf(in[2], out[2]) - fmaxf(in[0], out[0]), 0.0f), ih = fmaxf(fminf(in[3], out[3]) - fmaxf(in[1], out[1]), 0.0f);
+    return (iw * ih) / area >= 0.9f;
+}
+__device__ __forceinline__ int ppd_key(float v) { const int b = __float_as_int(v); return b ^ (int)(((unsigned)(b >> 31)) >> 1); }   // f32::total_cmp
+
+__global__ __launch_bounds__(256) void ppdoc_post_kernel(PpDocPostP p) {
+    extern __shared__ unsigned char pd_lds[];
+    unsigned char* st = pd_lds;                       // [rows]: bit 0 candidate (survived A), bit 1 alive, bit 2 scratch
+    __shared__ int s_n, s_go, s_cur, s_any;
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const float* pred = p.pred + (long)img * p.rows * p.feat;
+    float* cand = p.cand + (long)img * p.rows * 8;
+    int* sorted = p.sorted + (long)img * p.rows;
+    int* keep = p.keep + (long)img * p.rows;
+    const float ow = p.src_wh[img * 2], oh = p.src_wh[img * 2 + 1];
+    if (tid == 0) { s_n = 0; s_any = 0; }
+    // ---- A
+    for (int r = tid; r < p.rows; r += 256) {
+        const float* row = pred + (long)r * p.feat;
+        float b[4] = {0.f, 0.f, 0.f, 0.f};
+        const float cf = row[0], score = row[1];
+        const int ci = cf != cf ? 0 : cf >= 2147483648.0f ? 2147483647 : cf <= -2147483648.0f ? (-2147483647 - 1) : (int)cf;   // `as i32`
+        bool ok = false;
+        if (ci >= 0 && ci < p.num_classes) {
+            float thr = fmaxf(p.score_thr, 0.0f);
+            if (p.class_thr) { const float t = p.class_thr[ci]; if (t == t) thr = t; }
+            if (!(score < thr)) { convert(row[2], row[3], row[4], row[5], ow, oh, b); ok = valid_box(b); }
+        }
+        float* c8 = cand + (long)r * 8;
+        c8[0] = b[0]; c8[1] = b[1]; c8[2] = b[2]; c8[3] = b[3]; c8[4] = score; c8[5] = __int_as_float(ci);
+        c8[6] = p.feat >= 7 ? row[6] : 0.0f; c8[7] = p.feat >= 8 ? row[7] : 0.0f;
+        st[r] = ok ? 3 : 0;
+    }
+    __syncthreads();
+    // ---- B
+    if (p.layout_nms) {
+        for (int i = tid; i < p.rows; i += 256) {
+            if (!(st[i] & 1)) continue;
+            const float si = cand[(long)i * 8 + 4];
+            int rank = 0;
+            for (int j = 0; j < p.rows; ++j) {
+                if (!(st[j] & 1)) continue;
+                const float sj = cand[(long)j * 8 + 4];
+                if (si < sj || (!(sj < si) && j < i)) ++rank;      // j sorts before i (unordered pairs keep row order)
+            }
+            sorted[rank] = i;
+            atomicAdd(&s_n, 1);
+        }
+        __syncthreads();
+        const int nv = s_n;
+        for (int pos = 0; pos < nv; ++pos) {
+            if (tid == 0) { s_cur = sorted[pos]; s_go = (st[s_cur] & 2) ? 1 : 0; }
+            __syncthreads();
+            if (s_go) {
+                const int i = s_cur;
+                const float* bi = cand + (long)i * 8;
+                const int ic = __float_as_int(bi[5]);
+                for (int q = pos + 1 + tid; q < nv; q += 256) {
+                    const int j = sorted[q];
+                    if (!(st[j] & 2)) continue;
+                    const float* bj = cand + (long)j * 8;
+                    const float iou = ppd_iou(bi, bj), thr = __float_as_int(bj[5]) == ic ? 0.6f : 0.98f;
+                    if (iou >= thr || iou != iou) st[j] &= ~2;
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        // selection order = row order
+        for (int i = tid; i < p.rows; i += 256) {
+            if (!(st[i] & 1)) continue;
+            int rank = 0;
+            for (int j = 0; j < i; ++j) rank += st[j] & 1;
+            sorted[rank] = i;
+            atomicAdd(&s_n, 1);
+        }
+        __syncthreads();
+    }
+    const int nv = s_n;
+    __syncthreads();
+    // ---- C (list = alive entries of sorted[0 .. nv))
+    if (p.image_class >= 0) {
+        if (tid == 0) { s_go = 0; s_cur = 0; }
+        __syncthreads();
+        const float thr = ow > oh ? 0.82f : 0.93f, img_area = ow * oh;
+        int alive = 0, kept = 0;
+        for (int q = tid; q < nv; q += 256) {
+            const int i = sorted[q];
+            if (!(st[i] & 2)) continue;
+            ++alive;
+            const float* b = cand + (long)i * 8;
+            bool k = true;
+            if (__float_as_int(b[5]) == p.image_class) {
+                const float xmin = fmaxf(b[0], 0.0f), ymin = fmaxf(b[1], 0.0f), xmax = fminf(b[2], ow), ymax = fminf(b[3], oh);
+                k = (xmax - xmin) * (ymax - ymin) <= thr * img_area;
+            }
+            if (k) { ++kept; st[i] |= 4; } else st[i] &= ~4;
+        }
+        atomicAdd(&s_go, alive); atomicAdd(&s_cur, kept);
+        __syncthreads();
+        if (s_go > 1 && s_cur > 0) {
+            for (int q = tid; q < nv; q += 256) { const int i = sorted[q]; if ((st[i] & 2) && !(st[i] & 4)) st[i] &= ~2; }
+        }
+        __syncthreads();
+    }
+    // ---- D
+    if (p.merge_mode) {
+        for (int q = tid; q < nv; q += 256) { const int i = sorted[q]; st[i] = (st[i] & ~4) | ((st[i] & 2) ? 4 : 0); }   // bit 2 = the list before this step
+        __syncthreads();
+        for (int q = tid; q < nv; q += 256) {
+            const int x = sorted[q];
+            if (!(st[x] & 4)) continue;
+            const float* bx = cand + (long)x * 8;
+            const int cx = __float_as_int(bx[5]);
+            bool drop = false;
+            for (int c = 0; c < p.num_classes && !drop; ++c) {
+                const int mode = p.merge_mode[c];
+                if (mode != 0 && mode != 2) continue;                      // Union / not configured
+                bool contained = false, contains = false;
+                for (int r = 0; r < nv; ++r) {
+                    const int y = sorted[r];
+                    if (y == x || !(st[y] & 4)) continue;
+                    const float* by = cand + (long)y * 8;
+                    const int cy = __float_as_int(by[5]);
+                    // pair (i = x, j = y): is x contained by y?   pair (i = y, j = x): does x contain y?
+                    const bool skip_xy = p.formula_class >= 0 && cx == p.formula_class && cy != p.formula_class;
+                    const bool skip_yx = p.formula_class >= 0 && cy == p.formula_class && cx != p.formula_class;
+                    if (mode == 0) {
+                        if (!skip_xy && cy == c && ppd_contained(bx, by)) contained = true;
+                        if (!skip_yx && cx == c && ppd_contained(by, bx)) contains = true;
+                    } else {
+                        if (!skip_xy && cx == c && ppd_contained(bx, by)) contained = true;
+                        if (!skip_yx && cy == c && ppd_contained(by, bx)) contains = true;
+                    }
+                }
+                if (mode == 0) drop = contained;
+                else drop = !(!contains || contained);
+            }
+            if (drop) st[x] &= ~2;
+        }
+        __syncthreads();
+    }
+    // ---- E: final order.  Position among the alive entries of the selection order, or the stable rank by the order column(s)
+    if (tid == 0) s_go = 0;
+    __syncthreads();
+    for (int q = tid; q < nv; q += 256) {
+        const int i = sorted[q];
+        if (!(st[i] & 2)) continue;
+        int rank = 0;
+        if (p.feat == 7 || p.feat == 8) {
+            const int ki = ppd_key(cand[(long)i * 8 + 6]), ri = ppd_key(cand[(long)i * 8 + 7]);
+            for (int r = 0; r < nv; ++r) {
+                const int j = sorted[r];
+                if (!(st[j] & 2) || j == i) continue;
+                const int kj = ppd_key(cand[(long)j * 8 + 6]), rj = ppd_key(cand[(long)j * 8 + 7]);
+                const bool less = kj < ki || (kj == ki && p.feat == 8 && rj < ri);
+                const bool equal = kj == ki && (p.feat != 8 || rj == ri);
+                if (less || (equal && r < q)) ++rank;
+            }
+        } else {
+            for (int r = 0; r < q; ++r) rank += (st[sorted[r]] & 2) ? 1 : 0;
+        }
+        keep[rank] = i;
+        atomicAdd(&s_go, 1);
+    }
+    __syncthreads();
+    if (tid == 0) p.n_keep[img] = s_go;
+}
 }  // namespace
 
 void resize_filter(hipStream_t s, const uint8_t* src, int w, int h, uint8_t* dst, int nw, int nh, const FilterTaps* tv, const float* wv, int max_tv,
@@ -189,6 +378,12 @@ void layout_postprocess(hipStream_t s, const LayoutPostP& p, int n_images) {
     if (n_images == 0) return;
     ProfScope ps(s, "layout_post", 4.0 * (double)n_images * p.rows * p.feat, 0.0);
     hipLaunchKernelGGL(layout_post_kernel, dim3(n_images), dim3(256), (size_t)((p.rows + 15) & ~15), s, p);
+}
+
+void ppdoc_postprocess(hipStream_t s, const PpDocPostP& p, int n_images) {
+    if (n_images == 0) return;
+    ProfScope ps(s, "layout_post", 4.0 * (double)n_images * p.rows * p.feat, 0.0);
+    hipLaunchKernelGGL(ppdoc_post_kernel, dim3(n_images), dim3(256), (size_t)((p.rows + 15) & ~15), s, p);
 }
 
 }  // namespace pp

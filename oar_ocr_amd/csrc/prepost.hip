@@ -387,7 +387,26 @@ __global__ __launch_bounds__(256) void box_scores_kernel(const float* pred, int 
                     unsigned x1 = f2u(fmaxf(xs[c], (float)start_x)), x2 = f2u(fminf(xs[c + 1], (float)end_x));
                     if (x1 < x2 && x1 >= start_x && x2 <= end_x) {
                         unsigned xe = x2 < (unsigned)width ? x2 : (unsigned)width;
-                        if (x1 < xe) { for (unsigned x = x1; x < xe; ++x) line += row[x]; lp += xe - x1; }
+                        if (x1 < xe) {
+                            // the reference's sequential `+=` along the row -- but the LOADS are independent: 16 in flight per lane, then the adds in
+                            // order (a load-then-add loop pays one L2 round trip per pixel: 78 us per launch in round 3)
+                            unsigned x = x1;
+                            for (; x + 16 <= xe; x += 16) {
+                                float v[16];
+#pragma unroll
+                                for (int k = 0; k < 16; ++k) v[k] = row[x + k];
+#pragma unroll
+                                for (int k = 0; k < 16; ++k) line += v[k];
+                            }
+                            {
+                                float v[16];
+#pragma unroll
+                                for (int k = 0; k < 16; ++k) v[k] = x + k < xe ? row[x + k] : 0.0f;
+#pragma unroll
+                                for (int k = 0; k < 16; ++k) if (x + k < xe) line += v[k];
+                            }
+                            lp += xe - x1;
+                        }
                     }
                 }
             }
@@ -558,7 +577,26 @@ __global__ __launch_bounds__(256) void poly_scores_kernel(const float* pred, int
                     const unsigned x1 = f2u(fmaxf(open_x, (float)start_x)), x2 = f2u(fminf(bx, (float)end_x));
                     if (x1 < x2 && x1 >= start_x && x2 <= end_x) {
                         const unsigned xe = x2 < (unsigned)width ? x2 : (unsigned)width;
-                        if (x1 < xe) { for (unsigned x = x1; x < xe; ++x) line += row[x]; lp += xe - x1; }
+                        if (x1 < xe) {
+                            // the reference's sequential `+=` along the row -- but the LOADS are independent: 16 in flight per lane, then the adds in
+                            // order (a load-then-add loop pays one L2 round trip per pixel: 78 us per launch in round 3)
+                            unsigned x = x1;
+                            for (; x + 16 <= xe; x += 16) {
+                                float v[16];
+#pragma unroll
+                                for (int k = 0; k < 16; ++k) v[k] = row[x + k];
+#pragma unroll
+                                for (int k = 0; k < 16; ++k) line += v[k];
+                            }
+                            {
+                                float v[16];
+#pragma unroll
+                                for (int k = 0; k < 16; ++k) v[k] = x + k < xe ? row[x + k] : 0.0f;
+#pragma unroll
+                                for (int k = 0; k < 16; ++k) if (x + k < xe) line += v[k];
+                            }
+                            lp += xe - x1;
+                        }
                     }
                 }
             }

@@ -560,3 +560,56 @@ def layout_postprocess(pred: np.ndarray, src_w, src_h, num_classes, score_thresh
     n = L.orc_layout_postprocess(_p(pred), rows, feat, C.c_float(src_w), C.c_float(src_h), int(num_classes), C.c_float(score_threshold), C.c_float(nms_threshold),
                                  int(max_detections), MODEL_TYPES[model_type], _p(ob), _p(oc), _p(os_))
     return ob[:n].copy(), oc[:n].copy(), os_[:n].copy()
+
+
+MERGE_MODES = {"large": 0, "union": 1, "small": 2}
+
+
+def paddlex_layout_nms(boxes, classes, scores):
+    """LayoutDetectionAdapter::paddlex_layout_nms (layout_detection_adapter.rs:884-935) on [n, 4] accessor values (x_min, y_min, x_max, y_max):
+    indices of the selected boxes in selection order.  Restated in the compacting form of the reference's own test (:1668-1697)."""
+    b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 4)
+    c = np.ascontiguousarray(classes, np.int32)
+    s = np.ascontiguousarray(scores, np.float32)
+    sel = np.zeros(max(len(s), 1), np.int32)
+    L = lib()
+    L.orc_paddlex_layout_nms.restype = C.c_int
+    n = L.orc_paddlex_layout_nms(_p(b), _p(c), _p(s), len(s), _p(sel))
+    return sel[:n].copy()
+
+
+def pp_doclayout_postprocess(pred, src_w, src_h, num_classes, score_threshold=0.5, class_thresholds=None, layout_nms=True, image_class=-1, formula_class=-1,
+                             merge_modes=None):
+    """LayoutDetectionAdapter::postprocess_pp_doclayout (:631-846) for one image, up to and including the reading-order sort (labels,
+    layout_unclip_ratio and max_elements are the caller's).  class_thresholds / merge_modes: {class_id: value}; modes "large" | "union" | "small"."""
+    pred = np.ascontiguousarray(pred, np.float32).reshape(-1, pred.shape[-1]) if pred.size else np.zeros((0, max(pred.shape[-1], 1)), np.float32)
+    rows, feat = pred.shape
+    thr = np.full(max(num_classes, 1), np.nan, np.float32)
+    for k, v in (class_thresholds or {}).items():
+        if 0 <= int(k) < num_classes:
+            thr[int(k)] = v
+    mm = np.full(max(num_classes, 1), -1, np.int32)
+    for k, v in (merge_modes or {}).items():
+        if 0 <= int(k) < num_classes:
+            mm[int(k)] = MERGE_MODES[v]
+    ob, oc, os_ = np.zeros((max(rows, 1), 4), np.float32), np.zeros(max(rows, 1), np.int32), np.zeros(max(rows, 1), np.float32)
+    L = lib()
+    L.orc_pp_doclayout_postprocess.restype = C.c_int
+    n = L.orc_pp_doclayout_postprocess(_p(pred), rows, feat, C.c_float(src_w), C.c_float(src_h), int(num_classes), C.c_float(score_threshold),
+                                       _p(thr) if class_thresholds else None, int(bool(layout_nms)), int(image_class), int(formula_class),
+                                       _p(mm) if merge_modes else None, _p(ob), _p(oc), _p(os_))
+    return ob[:n].copy(), oc[:n].copy(), os_[:n].copy()
+
+
+def apply_nms_with_merge(boxes, classes, scores, mode_of_class, nms_threshold=0.5, max_detections=100):
+    """processors/layout_postprocess.rs:743-841 (class_merge_modes of the PicoDet / RT-DETR adapters).  mode_of_class: per class id "large" | "union" | "small"."""
+    b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 4)
+    c = np.ascontiguousarray(classes, np.int32)
+    s = np.ascontiguousarray(scores, np.float32)
+    modes = np.ascontiguousarray([MERGE_MODES[m] for m in mode_of_class], np.int32)
+    n = len(s)
+    ob, oc, os_ = np.zeros((max(n, 1), 4), np.float32), np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float32)
+    L = lib()
+    L.orc_apply_nms_with_merge.restype = C.c_int
+    k = L.orc_apply_nms_with_merge(_p(b), _p(c), _p(s), n, _p(modes), len(modes), C.c_float(nms_threshold), int(max_detections), _p(ob), _p(oc), _p(os_))
+    return ob[:k].copy(), oc[:k].copy(), os_[:k].copy()

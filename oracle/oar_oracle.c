@@ -1154,3 +1154,184 @@ int orc_layout_postprocess(const float* pred, int rows, int feat, float src_w, f
     free(boxes); free(classes); free(scores); free(order); free(keep);
     return nk;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------------------------
+ * LayoutDetectionAdapter::postprocess_pp_doclayout (oar-ocr-core/src/domain/adapters/layout_detection_adapter.rs:631-846) and its helpers:
+ * paddlex_layout_nms (:884-935; restated in the COMPACTING form the reference's own test keeps as `compacting_nms_reference`, :1668-1697),
+ * paddlex_iou (:937-953), filter_large_image_boxes (:955-995), apply_paddlex_merge_modes / check_containment / is_contained (:997-1100).
+ * Everything up to and including the reading-order sort; class labels, layout_unclip_ratio and max_elements are applied by the caller.
+ * class_thr[c]: per-class threshold or NaN (not configured); merge_mode[c]: -1 not configured, 0 Large, 1 Union, 2 Small (MergeBboxMode);
+ * image_class / formula_class: the ids of the labels "image" / "formula" or -1.  Test infrastructure: see the header of this file. */
+static float ppd_iou(const float* a, const float* b) {
+    /* Rust's f32::min / f32::max return the other operand when one is NaN -- so do C's fminf / fmaxf */
+    float iw = fmaxf(fminf(a[2], b[2]) - fmaxf(a[0], b[0]) + 1.0f, 0.0f);
+    float ih = fmaxf(fminf(a[3], b[3]) - fmaxf(a[1], b[1]) + 1.0f, 0.0f);
+    float inter = iw * ih;
+    float a1 = (a[2] - a[0] + 1.0f) * (a[3] - a[1] + 1.0f), a2 = (b[2] - b[0] + 1.0f) * (b[3] - b[1] + 1.0f);
+    float uni = a1 + a2 - inter;
+    return uni > 0.0f ? inter / uni : 0.0f;
+}
+int orc_paddlex_layout_nms(const float* boxes, const int* classes, const float* scores, int n, int* selected) {
+    int* idx = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; ++i) idx[i] = i;
+    /* stable, descending by score; an unordered pair compares Equal (partial_cmp(..).unwrap_or(Equal)) */
+    for (int i = 1; i < n; ++i) {
+        int v = idx[i], j = i - 1;
+        while (j >= 0 && scores[idx[j]] < scores[v]) { idx[j + 1] = idx[j]; --j; }
+        idx[j + 1] = v;
+    }
+    int m = n, ns = 0;
+    while (m > 0) {                                   /* compacting form: take the head, keep the tail entries whose IoU is below the threshold */
+        int cur = idx[0], w = 0;
+        selected[ns++] = cur;
+        for (int k = 1; k < m; ++k) {
+            float thr = classes[idx[k]] == classes[cur] ? 0.6f : 0.98f;
+            float iou = ppd_iou(boxes + 4 * cur, boxes + 4 * idx[k]);
+            if (iou < thr) idx[w++] = idx[k];
+        }
+        m = w;
+    }
+    free(idx);
+    return ns;
+}
+static int ppd_contained(const float* in, const float* out) {
+    float area = (in[2] - in[0]) * (in[3] - in[1]);
+    if (area <= 0.0f) return 0;
+    float xi1 = fmaxf(in[0], out[0]), yi1 = fmaxf(in[1], out[1]), xi2 = fminf(in[2], out[2]), yi2 = fminf(in[3], out[3]);
+    float iw = fmaxf(xi2 - xi1, 0.0f), ih = fmaxf(yi2 - yi1, 0.0f);
+    return (iw * ih) / area >= 0.9f;
+}
+static int32_t ppd_total_key(float v) { int32_t b; memcpy(&b, &v, 4); return b ^ (int32_t)(((uint32_t)(b >> 31)) >> 1); }
+int orc_pp_doclayout_postprocess(const float* pred, int rows, int feat, float src_w, float src_h, int num_classes, float score_thr, const float* class_thr,
+                                 int layout_nms, int image_class, int formula_class, const int* merge_mode,
+                                 float* out_boxes, int* out_classes, float* out_scores) {
+    if (rows <= 0 || feat < 6) return 0;
+    float* boxes = (float*)malloc(sizeof(float) * 4 * (size_t)rows);
+    int* classes = (int*)malloc(sizeof(int) * (size_t)rows);
+    float* scores = (float*)malloc(sizeof(float) * (size_t)rows);
+    float* order = (float*)malloc(sizeof(float) * 2 * (size_t)rows);
+    int* sel = (int*)malloc(sizeof(int) * (size_t)rows);
+    int n = 0;
+    for (int r = 0; r < rows; ++r) {
+        const float* row = pred + (size_t)r * feat;
+        float cf = row[0];
+        int ci = isnan(cf) ? 0 : cf >= 2147483648.0f ? 2147483647 : cf <= -2147483648.0f ? (-2147483647 - 1) : (int)cf;
+        float s = row[1];
+        if (ci < 0 || ci >= num_classes) continue;
+        float thr = (class_thr && !isnan(class_thr[ci])) ? class_thr[ci] : (score_thr > 0.0f ? score_thr : 0.0f);   /* config.score_threshold.max(0.0) */
+        if (s < thr) continue;
+        float b[4];
+        lp_convert(row[2], row[3], row[4], row[5], src_w, src_h, b);
+        if (!lp_valid_box(b)) continue;
+        memcpy(boxes + 4 * n, b, 16); classes[n] = ci; scores[n] = s;
+        order[2 * n] = feat == 8 || feat == 7 ? row[6] : 0.0f; order[2 * n + 1] = feat == 8 ? row[7] : 0.0f;
+        ++n;
+    }
+    int m = n;
+    for (int i = 0; i < n; ++i) sel[i] = i;
+    if (layout_nms && n > 0) m = orc_paddlex_layout_nms(boxes, classes, scores, n, sel);
+    if (image_class >= 0 && m > 1) {                  /* filter_large_image_boxes: drop page-sized "image" boxes unless nothing would be left */
+        float thr = src_w > src_h ? 0.82f : 0.93f, img_area = src_w * src_h;
+        int* k2 = (int*)malloc(sizeof(int) * (size_t)m); int w = 0;
+        for (int i = 0; i < m; ++i) {
+            const float* b = boxes + 4 * sel[i];
+            if (classes[sel[i]] != image_class) { k2[w++] = sel[i]; continue; }
+            float xmin = fmaxf(b[0], 0.0f), ymin = fmaxf(b[1], 0.0f), xmax = fminf(b[2], src_w), ymax = fminf(b[3], src_h);
+            if ((xmax - xmin) * (ymax - ymin) <= thr * img_area) k2[w++] = sel[i];
+        }
+        if (w > 0) { memcpy(sel, k2, sizeof(int) * (size_t)w); m = w; }
+        free(k2);
+    }
+    int any_mode = 0;
+    if (merge_mode) for (int c = 0; c < num_classes; ++c) any_mode |= merge_mode[c] >= 0;
+    if (any_mode && m > 0) {                          /* apply_paddlex_merge_modes */
+        char* keep = (char*)malloc((size_t)m); memset(keep, 1, (size_t)m);
+        int* contains = (int*)malloc(sizeof(int) * (size_t)m); int* contained = (int*)malloc(sizeof(int) * (size_t)m);
+        for (int c = 0; c < num_classes; ++c) {
+            int mode = merge_mode[c];
+            if (mode != 0 && mode != 2) continue;     /* Union / not configured: nothing */
+            memset(contains, 0, sizeof(int) * (size_t)m); memset(contained, 0, sizeof(int) * (size_t)m);
+            for (int i = 0; i < m; ++i)
+                for (int j = 0; j < m; ++j) {
+                    if (i == j) continue;
+                    if (formula_class >= 0 && classes[sel[i]] == formula_class && classes[sel[j]] != formula_class) continue;
+                    int hit = mode == 0 ? (classes[sel[j]] == c && ppd_contained(boxes + 4 * sel[i], boxes + 4 * sel[j]))
+                                        : (classes[sel[i]] == c && ppd_contained(boxes + 4 * sel[i], boxes + 4 * sel[j]));
+                    if (hit) { contained[i] = 1; contains[j] = 1; }
+                }
+            for (int i = 0; i < m; ++i) {
+                if (mode == 0) { if (contained[i] == 1) keep[i] = 0; }
+                else if (!(contains[i] == 0 || contained[i] == 1)) keep[i] = 0;
+            }
+        }
+        int w = 0;
+        for (int i = 0; i < m; ++i) if (keep[i]) sel[w++] = sel[i];
+        m = w;
+        free(keep); free(contains); free(contained);
+    }
+    if ((feat == 7 || feat == 8) && m > 0) {          /* reading order: stable, by total_cmp on (col[, row]) */
+        for (int i = 1; i < m; ++i) {
+            int v = sel[i], j = i - 1;
+            while (j >= 0) {
+                int32_t ca = ppd_total_key(order[2 * sel[j]]), cb = ppd_total_key(order[2 * v]);
+                int gt = ca > cb;
+                if (ca == cb && feat == 8) gt = ppd_total_key(order[2 * sel[j] + 1]) > ppd_total_key(order[2 * v + 1]);
+                if (!gt) break;
+                sel[j + 1] = sel[j]; --j;
+            }
+            sel[j + 1] = v;
+        }
+    }
+    for (int i = 0; i < m; ++i) { memcpy(out_boxes + 4 * i, boxes + 4 * sel[i], 16); out_classes[i] = classes[sel[i]]; out_scores[i] = scores[sel[i]]; }
+    free(boxes); free(classes); free(scores); free(order); free(sel);
+    return m;
+}
+
+/* processors/layout_postprocess.rs:692-841: merge_boxes + apply_nms_with_merge (the non-PP-DocLayout adapters' class_merge_modes path).
+ * mode_of_class[c]: 0 Large (also the default of an unlisted class), 1 Union, 2 Small.  Output in the reference's final order. */
+static float nm_iou(const float* a, const float* b) {
+    float x0 = fmaxf(a[0], b[0]), y0 = fmaxf(a[1], b[1]), x1 = fminf(a[2], b[2]), y1 = fminf(a[3], b[3]);
+    if (x1 <= x0 || y1 <= y0) return 0.0f;
+    float inter = (x1 - x0) * (y1 - y0), a1 = (a[2] - a[0]) * (a[3] - a[1]), a2 = (b[2] - b[0]) * (b[3] - b[1]), uni = a1 + a2 - inter;
+    return uni > 0.0f ? inter / uni : 0.0f;
+}
+int orc_apply_nms_with_merge(const float* boxes, const int* classes, const float* scores, int n, const int* mode_of_class, int num_classes, float nms_thr, int max_det,
+                             float* out_boxes, int* out_classes, float* out_scores) {
+    if (n <= 0) return 0;
+    int* idx = (int*)malloc(sizeof(int) * (size_t)n); char* done = (char*)calloc((size_t)n, 1);
+    float* rb = (float*)malloc(sizeof(float) * 4 * (size_t)n); int* rc = (int*)malloc(sizeof(int) * (size_t)n); float* rs = (float*)malloc(sizeof(float) * (size_t)n);
+    int* ro = (int*)malloc(sizeof(int) * (size_t)n);
+    for (int i = 0; i < n; ++i) idx[i] = i;
+    for (int i = 1; i < n; ++i) { int v = idx[i], j = i - 1; while (j >= 0 && scores[idx[j]] < scores[v]) { idx[j + 1] = idx[j]; --j; } idx[j + 1] = v; }
+    int nr = 0;
+    for (int a = 0; a < n; ++a) {
+        int i = idx[a];
+        if (done[i]) continue;
+        done[i] = 1;
+        int mode = classes[i] >= 0 && classes[i] < num_classes ? mode_of_class[classes[i]] : 0;
+        float mb[4]; memcpy(mb, boxes + 4 * i, 16);
+        float best = scores[i]; int ord = i;
+        for (int b = 0; b < n; ++b) {
+            int j = idx[b];
+            if (i == j || done[j] || classes[i] != classes[j]) continue;
+            if (nm_iou(mb, boxes + 4 * j) > nms_thr) {
+                const float* o = boxes + 4 * j;
+                float a1 = (mb[2] - mb[0]) * (mb[3] - mb[1]), a2 = (o[2] - o[0]) * (o[3] - o[1]);
+                if (mode == 0) { if (!(a1 >= a2)) memcpy(mb, o, 16); }
+                else if (mode == 2) { if (!(a1 <= a2)) memcpy(mb, o, 16); }
+                else { mb[0] = fminf(mb[0], o[0]); mb[1] = fminf(mb[1], o[1]); mb[2] = fmaxf(mb[2], o[2]); mb[3] = fmaxf(mb[3], o[3]); }
+                best = fmaxf(best, scores[j]);
+                if (j < ord) ord = j;
+                done[j] = 1;
+            }
+        }
+        memcpy(rb + 4 * nr, mb, 16); rc[nr] = classes[i]; rs[nr] = best; ro[nr] = ord; ++nr;
+    }
+    int take = nr < max_det ? nr : max_det;
+    int* p = (int*)malloc(sizeof(int) * (size_t)(take > 0 ? take : 1));
+    for (int i = 0; i < take; ++i) p[i] = i;
+    for (int i = 1; i < take; ++i) { int v = p[i], j = i - 1; while (j >= 0 && ro[p[j]] > ro[v]) { p[j + 1] = p[j]; --j; } p[j + 1] = v; }   /* sort_by_key: stable */
+    for (int i = 0; i < take; ++i) { memcpy(out_boxes + 4 * i, rb + 4 * p[i], 16); out_classes[i] = rc[p[i]]; out_scores[i] = rs[p[i]]; }
+    free(idx); free(done); free(rb); free(rc); free(rs); free(ro); free(p);
+    return take;
+}

@@ -8,9 +8,10 @@
 //! whose stages are HIP kernels; the configuration pass stays here, in the reference's own words (`unclip_boxes` is the
 //! reference's function, called as the reference calls it).
 //!
-//! Not carried: `class_merge_modes` (`apply_nms_with_merge`) and the PP-DocLayout adapter's PaddleX-style post-processing
-//! (`postprocess_pp_doclayout`, :631-846) -- a `LayoutModelConfig` of type "pp-doclayout" is refused at build time; the
-//! processor-level `LayoutPostProcess` of all three model types IS behind `oar_layout_run` (parity-tested through the C ABI).
+//! Round 4: a `LayoutModelConfig` of type "pp-doclayout" takes the adapter's own PaddleX-style post-processing
+//! (`postprocess_pp_doclayout`, :631-846: per-class thresholds, `paddlex_layout_nms`, `filter_large_image_boxes`,
+//! `apply_paddlex_merge_modes`, reading-order sort) as ONE HIP kernel behind `oar_layout_run_ppdoc`; `class_merge_modes` of the
+//! other families (`apply_nms_with_merge`, processors/layout_postprocess.rs:743-841) goes through `oar_host_nms_with_merge`.
 //! Source-only, never compiled here (no Rust toolchain in the backend's build image): checked lexically by
 //! tests/test_rust_bindings_cpu.py.
 
@@ -23,7 +24,7 @@ use oar_ocr_core::core::inference::ModelSource;
 use oar_ocr_core::core::traits::adapter::{AdapterBuilder, AdapterInfo, ModelAdapter, OrtConfigurable};
 use oar_ocr_core::core::traits::task::{Task, TaskType};
 use oar_ocr_core::domain::adapters::LayoutModelConfig;
-use oar_ocr_core::domain::tasks::{LayoutDetectionConfig, LayoutDetectionElement, LayoutDetectionOutput, LayoutDetectionTask, UnclipRatio};
+use oar_ocr_core::domain::tasks::{LayoutDetectionConfig, LayoutDetectionElement, LayoutDetectionOutput, LayoutDetectionTask, MergeBboxMode, UnclipRatio};
 use oar_ocr_core::processors::{BoundingBox, unclip_boxes};
 use std::ptr::NonNull;
 
@@ -85,16 +86,39 @@ impl ModelAdapter for Mi355xLayoutDetectionAdapter {
             scores: std::ptr::null_mut(),
             feature_dim: 0,
         });
-        // SAFETY: three arrays of batch.len() entries; page buffers outlive the call; result is a valid out-parameter.
+        let is_ppdoc = self.model_config.model_type == "pp-doclayout";
+        // label-keyed maps -> class-id-indexed arrays, as postprocess_pp_doclayout builds them (:645-675)
+        let num_classes = self.model_config.num_classes;
+        let class_thresholds: Option<Vec<f32>> = effective_config.class_thresholds.as_ref().map(|t| {
+            (0..num_classes).map(|c| self.model_config.class_labels.get(&c).and_then(|l| t.get(l)).copied().unwrap_or(f32::NAN)).collect()
+        });
+        let merge_code = |m: MergeBboxMode| match m { MergeBboxMode::Large => 0i32, MergeBboxMode::Union => 1, MergeBboxMode::Small => 2 };
+        let class_merge_modes: Option<Vec<i32>> = effective_config.class_merge_modes.as_ref().map(|m| {
+            (0..num_classes).map(|c| self.model_config.class_labels.get(&c).and_then(|l| m.get(l)).map(|v| merge_code(*v)).unwrap_or(-1)).collect()
+        });
+        let label_id = |name: &str| self.model_config.class_labels.iter().find_map(|(id, l)| (l == name).then_some(*id as i32)).unwrap_or(-1);
+        let ppdoc_cfg = sys::oar_ppdoc_cfg {
+            score_threshold: effective_config.score_threshold,
+            class_thresholds: class_thresholds.as_ref().map_or(std::ptr::null(), |v| v.as_ptr()),
+            layout_nms: effective_config.layout_nms as i32,
+            image_class_id: label_id("image"),
+            formula_class_id: label_id("formula"),
+            class_merge_modes: if is_ppdoc { class_merge_modes.as_ref().map_or(std::ptr::null(), |v| v.as_ptr()) } else { std::ptr::null() },
+        };
+        // SAFETY: three arrays of batch.len() entries; page buffers and the configuration arrays outlive the call; result is a valid out-parameter.
         let status = unsafe {
-            sys::oar_layout_run(
-                self.handle.0.as_ptr(),
-                batch.ptrs.as_ptr(),
-                batch.widths.as_ptr(),
-                batch.heights.as_ptr(),
-                batch.len() as u32,
-                &mut result.0,
-            )
+            if is_ppdoc {
+                sys::oar_layout_run_ppdoc(self.handle.0.as_ptr(), batch.ptrs.as_ptr(), batch.widths.as_ptr(), batch.heights.as_ptr(), batch.len() as u32, &ppdoc_cfg, &mut result.0)
+            } else {
+                sys::oar_layout_run(
+                    self.handle.0.as_ptr(),
+                    batch.ptrs.as_ptr(),
+                    batch.widths.as_ptr(),
+                    batch.heights.as_ptr(),
+                    batch.len() as u32,
+                    &mut result.0,
+                )
+            }
         };
         check(status).map_err(|e| {
             e.into_adapter_error("LayoutDetectionAdapter", format!("PicoDet forward (batch_size={batch_len})"))
@@ -112,7 +136,8 @@ impl ModelAdapter for Mi355xLayoutDetectionAdapter {
             let (lo, hi) = (offsets[i] as usize, offsets[i + 1] as usize);
             let mut img_boxes: Vec<BoundingBox> =
                 (lo..hi).map(|b| BoundingBox::from_coords(boxes[b * 4], boxes[b * 4 + 1], boxes[b * 4 + 2], boxes[b * 4 + 3])).collect();
-            let img_classes: Vec<usize> = (lo..hi).map(|b| classes[b].max(0) as usize).collect();
+            let mut img_classes: Vec<usize> = (lo..hi).map(|b| classes[b].max(0) as usize).collect();
+            let mut img_scores: Vec<f32> = (lo..hi).map(|b| scores[b]).collect();
             if let Some(ref unclip_ratio) = effective_config.layout_unclip_ratio {
                 let (width_ratio, height_ratio, per_class_ratios) = match unclip_ratio {
                     UnclipRatio::Uniform(r) => (*r, *r, None),
@@ -121,12 +146,35 @@ impl ModelAdapter for Mi355xLayoutDetectionAdapter {
                 };
                 img_boxes = unclip_boxes(&img_boxes, &img_classes, width_ratio, height_ratio, per_class_ratios);
             }
+            // class_merge_modes of the PicoDet / RT-DETR families: apply_nms_with_merge (:577-587) on this image's boxes
+            if let (false, Some(modes)) = (is_ppdoc, effective_config.class_merge_modes.as_ref()) {
+                let mode_of_class: Vec<i32> = (0..num_classes)
+                    .map(|c| self.model_config.class_labels.get(&c).and_then(|l| modes.get(l)).map(|v| merge_code(*v)).unwrap_or(0))
+                    .collect();
+                let flat: Vec<f32> = img_boxes.iter().flat_map(|b| { let (x0, y0, x1, y1) = b.aabb(); [x0, y0, x1, y1] }).collect();
+                let cls32: Vec<i32> = img_classes.iter().map(|&c| c as i32).collect();
+                let k = img_boxes.len();
+                let (mut ob, mut oc, mut os) = (vec![0f32; k * 4], vec![0i32; k], vec![0f32; k]);
+                // SAFETY: input arrays hold k entries, output arrays have room for k
+                let m = unsafe {
+                    sys::oar_host_nms_with_merge(flat.as_ptr(), cls32.as_ptr(), img_scores.as_ptr(), k as u32, mode_of_class.as_ptr(), num_classes as u32,
+                                                 effective_config.nms_threshold, effective_config.max_elements as u32, ob.as_mut_ptr(), oc.as_mut_ptr(), os.as_mut_ptr())
+                };
+                if m < 0 {
+                    return Err(OCRError::InvalidInput { message: "oar_host_nms_with_merge failed".to_string() });
+                }
+                let m = m as usize;
+                img_boxes = (0..m).map(|b| BoundingBox::from_coords(ob[b * 4], ob[b * 4 + 1], ob[b * 4 + 2], ob[b * 4 + 3])).collect();
+                img_classes = oc[..m].iter().map(|&c| c.max(0) as usize).collect();
+                img_scores = os[..m].to_vec();
+            }
             let mut img_elements = Vec::new();
             for (k, bbox) in img_boxes.iter().enumerate() {
-                let score = scores[lo + k];
+                let score = img_scores[k];
                 let element_type =
                     self.model_config.class_labels.get(&img_classes[k]).cloned().unwrap_or_else(|| "unknown".to_string());
-                if score >= effective_config.get_class_threshold(&element_type) {
+                // PP-DocLayout applied its per-class thresholds inside the kernel (:700-706) and has no second filter here (:813-831)
+                if is_ppdoc || score >= effective_config.get_class_threshold(&element_type) {
                     img_elements.push(LayoutDetectionElement { bbox: bbox.clone(), element_type, score });
                     if img_elements.len() >= effective_config.max_elements {
                         break;
@@ -201,18 +249,15 @@ impl AdapterBuilder for Mi355xLayoutDetectionAdapterBuilder {
 
     fn build(self, model_source: impl Into<ModelSource>) -> Result<Self::Adapter, OCRError> {
         let model_config = self.model_config.unwrap_or_else(LayoutModelConfig::picodet_layout_1x);
-        if self.config.class_merge_modes.is_some() {
-            return Err(OCRError::ConfigError {
-                message: "Mi355xLayoutDetectionAdapter: class_merge_modes (apply_nms_with_merge) is not carried by this backend".to_string(),
-            });
-        }
         // ScaleAwareDetectorPreprocessConfig of the family (scale_aware_detector.rs:49-75) and the processor's model type
         let (model_type, resize_filter, color_bgr, mean, std) = match model_config.model_type.as_str() {
             "picodet" => (0, 2, 1, [0.485f32, 0.456, 0.406], [0.229f32, 0.224, 0.225]),
             "rtdetr" => (1, 2, 1, [0.485f32, 0.456, 0.406], [0.229f32, 0.224, 0.225]),
+            // PPDocLayoutModel: CatmullRom resize, RGB tensor, no mean / std (scale_aware_detector.rs:62-75)
+            "pp-doclayout" => (2, 1, 0, [0.0f32, 0.0, 0.0], [1.0f32, 1.0, 1.0]),
             other => {
                 return Err(OCRError::InvalidInput {
-                    message: format!("Mi355xLayoutDetectionAdapter: model type '{other}' is not carried by this backend (picodet, rtdetr are)"),
+                    message: format!("Mi355xLayoutDetectionAdapter: model type '{other}' is not carried by this backend (picodet, rtdetr, pp-doclayout are)"),
                 });
             }
         };

@@ -297,6 +297,17 @@ pub struct oar_layout_result {
 
 #[repr(C)]
 #[derive(Debug, Clone, Copy)]
+pub struct oar_ppdoc_cfg {
+    pub score_threshold: f32,
+    pub class_thresholds: *const f32,
+    pub layout_nms: i32,
+    pub image_class_id: i32,
+    pub formula_class_id: i32,
+    pub class_merge_modes: *const i32,
+}
+
+#[repr(C)]
+#[derive(Debug, Clone, Copy)]
 pub struct oar_prof_entry {
     pub name: [c_char; 48],
     pub launches: u64,
@@ -372,6 +383,9 @@ unsafe extern "C" {
     pub fn oar_layout_preprocess(l: *mut oar_layout, rgb: *const u8, width: u32, height: u32, out_chw: *mut f32) -> oar_status;
     pub fn oar_k_resize_filter(rgb: *const u8, w: u32, h: u32, nw: u32, nh: u32, filter: i32, out: *mut u8) -> oar_status;
     pub fn oar_k_layout_postprocess(pred: *const f32, n_images: u32, rows: u32, feat: u32, src_wh: *const f32, num_classes: u32, model_type: i32, score_threshold: f32, nms_threshold: f32, max_detections: u32, out: *mut oar_layout_result) -> oar_status;
+    pub fn oar_layout_run_ppdoc(l: *mut oar_layout, rgb: *const *const u8, widths: *const u32, heights: *const u32, n_images: u32, cfg: *const oar_ppdoc_cfg, out: *mut oar_layout_result) -> oar_status;
+    pub fn oar_k_ppdoc_postprocess(pred: *const f32, n_images: u32, rows: u32, feat: u32, src_wh: *const f32, num_classes: u32, cfg: *const oar_ppdoc_cfg, out: *mut oar_layout_result) -> oar_status;
+    pub fn oar_host_nms_with_merge(boxes: *const f32, classes: *const i32, scores: *const f32, n: u32, mode_of_class: *const i32, num_classes: u32, nms_threshold: f32, max_detections: u32, out_boxes: *mut f32, out_classes: *mut i32, out_scores: *mut f32) -> i32;
     pub fn oar_dev_alloc(device_id: i32, bytes: usize, out: *mut *mut c_void) -> oar_status;
     pub fn oar_dev_upload(dst: *mut c_void, src: *const c_void, bytes: usize) -> oar_status;
     pub fn oar_dev_download(dst: *mut c_void, src: *const c_void, bytes: usize) -> oar_status;

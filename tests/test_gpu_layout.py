@@ -113,7 +113,64 @@ def test_layout_adapter_matches_oracle(kind, shape):
             assert np.abs(ref[i][0] - rb).max() <= 5e-2 and np.array_equal(ref[i][1], rc)
     assert total > (20 if kind == "picodet" else 0), total
     els = pred.predict(imgs)
-    assert [len(e) for e in els] == [len(r[0]) for r in raw] and all(e.element_type.startswith("c") for p_ in els for e in p_)
+    if kind == "pp-doclayout":
+        # model_type "pp-doclayout" takes the adapter's own post-processing (postprocess_pp_doclayout, layout_detection_adapter.rs:631-846) instead of
+        # LayoutPostProcess: the elements are the oracle's restatement of it applied to the same rows
+        for i, im in enumerate(imgs):
+            rb, rc, rs = R.pp_doclayout_postprocess(y[i], im.shape[1], im.shape[0], 5, thr)
+            assert len(els[i]) == min(len(rb), 60)
+            for e, b, c, sc in zip(els[i], rb, rc, rs):
+                assert e.element_type == f"c{c}" and e.score == float(sc) and np.array_equal(e.bbox[0], b[:2]) and np.array_equal(e.bbox[2], b[2:])
+    else:
+        assert [len(e) for e in els] == [len(r[0]) for r in raw]
+    assert all(e.element_type.startswith("c") for p_ in els for e in p_)
     assert pred.is_reading_order_sorted == (feat in (7, 8))
     pred.close()
     eng.close()
+
+
+@pytest.mark.parametrize("feat", [6, 7, 8])
+def test_pp_doclayout_adapter_postprocess_kernel_equals_the_oracle(feat):
+    """LayoutDetectionAdapter::postprocess_pp_doclayout as one HIP kernel (layout.hip ppdoc_post_kernel) against the oracle's restatement on identical
+    prediction rows: per-class thresholds, paddlex_layout_nms (the '+ 1' IoU, 0.6 same class / 0.98 across), filter_large_image_boxes,
+    apply_paddlex_merge_modes (Large / Small / Union, the formula rule), reading-order sort by total_cmp -- with score ties, page-sized image boxes,
+    normalised coordinates, nested boxes, infinite scores, every switch on and off."""
+    rng = np.random.default_rng(90 + feat)
+    labels = {0: "text", 1: "image", 2: "formula", 3: "table", 4: "chart", 5: "title"}
+    nc = len(labels)
+    for trial, (n, rows) in enumerate([(3, 300), (2, 40), (1, 1), (2, 700), (1, 0)]):
+        pred = _random_predictions(rng, n, rows, feat, nc, "csb", nan_ok=False) if rows else np.zeros((n, 0, feat), np.float32)
+        wh = np.stack([rng.integers(300, 700, n), rng.integers(300, 900, n)], -1).astype(np.float32)
+        if rows >= 40:
+            for i in range(n):
+                # nested boxes (containment >= 0.9) of assorted classes, and page-sized image boxes
+                for k in range(0, rows // 4, 2):
+                    x0, y0 = rng.uniform(0, 250), rng.uniform(0, 400)
+                    w, h = rng.uniform(60, 200), rng.uniform(60, 200)
+                    pred[i, k, 2:6] = [x0, y0, x0 + w, y0 + h]
+                    pred[i, k + 1, 2:6] = [x0 + 0.02 * w, y0 + 0.02 * h, x0 + rng.uniform(0.5, 0.99) * w, y0 + rng.uniform(0.5, 0.99) * h]
+                    pred[i, k, 0], pred[i, k + 1, 0] = rng.integers(0, nc), rng.integers(0, nc)
+                    pred[i, k, 1], pred[i, k + 1, 1] = np.round(rng.uniform(0.3, 1.0, 2), 2)
+                pred[i, rows // 2, :6] = [1, 0.9, 0, 0, wh[i, 0], wh[i, 1]]
+                pred[i, rows // 2 + 1, :6] = [1, 0.8, 2, 2, wh[i, 0] * 0.5, wh[i, 1] * 0.5]
+        variants = [
+            dict(),
+            dict(class_thresholds={"text": 0.4, "table": 0.75, "title": 0.0}),
+            dict(layout_nms=False),
+            dict(class_merge_modes={"text": "large", "image": "union", "table": "small", "chart": "large"}),
+            dict(class_merge_modes={k: "small" for k in labels.values()}, class_thresholds={"formula": 0.2}),
+            dict(class_merge_modes={"formula": "large", "title": "small"}, layout_nms=False),
+        ]
+        for kw in variants:
+            thr = 0.5 if trial % 2 == 0 else 0.3
+            got = api.k_ppdoc_postprocess(pred, wh, nc, labels, thr, kw.get("class_thresholds"), kw.get("layout_nms", True), kw.get("class_merge_modes"))
+            by = {v: k for k, v in labels.items()}
+            kept = 0
+            for i in range(n):
+                rb, rc, rs = R.pp_doclayout_postprocess(pred[i], wh[i, 0], wh[i, 1], nc, thr, {by[k]: v for k, v in kw.get("class_thresholds", {}).items()} or None,
+                                                        kw.get("layout_nms", True), by["image"], by["formula"], {by[k]: v for k, v in kw.get("class_merge_modes", {}).items()} or None)
+                gb, gc, gs = got[i]
+                assert np.array_equal(gc, rc) and np.array_equal(gs, rs) and np.array_equal(gb, rb), (feat, trial, kw, i, len(gc), len(rc))
+                kept += len(rb)
+            if rows >= 300:
+                assert kept > 10

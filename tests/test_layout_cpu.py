@@ -66,3 +66,103 @@ def test_adapter_level_helpers():
     assert np.allclose(out, [[5, 30, 35, 50], [-2.5, 2.5, 12.5, 7.5]])
     assert np.array_equal(api.unclip_boxes(boxes, [0, 1], 1.0), boxes)
     assert np.allclose(api.unclip_boxes(boxes, [0, 1], {1: (2.0, 2.0)}), [[10, 20, 30, 60], [-5, -5, 15, 15]])
+
+
+def test_reference_inline_test_of_paddlex_layout_nms():
+    """layout_detection_adapter.rs:1699-1724 `paddlex_layout_nms_matches_compacting_reference_on_dense_input`: 256 boxes on a 37 / 53 lattice plus one
+    whose x1 is NaN, classes i % 7, scores (97 i mod 1000) / 1000.  The reference checks its in-place marking form against a compacting form; the oracle
+    restates the compacting form, so the in-place form is written out here (python, f32) and must select the same indices in the same order."""
+    f = np.float32
+    boxes = []
+    for i in range(256):
+        x, y, size = f((i * 37) % 80), f((i * 53) % 80), f(18.0 + (i % 11))
+        boxes.append([x, y, x + size, y + size])
+    boxes.append([10, 0, 10, 10])       # from_coords(NaN, 0, 10, 10): BoundingBox::x_min / x_max skip a NaN point (geometry.rs:179-190, :569-580)
+    boxes = np.array(boxes, np.float32)
+    classes = np.array([i % 7 for i in range(257)], np.int32)
+    scores = np.array([f((i * 97) % 1000) / f(1000.0) for i in range(257)], np.float32)
+    sel = R.paddlex_layout_nms(boxes, classes, scores)
+
+    def iou(a, b):
+        iw = max(f(min(a[2], b[2]) - max(a[0], b[0]) + f(1)), f(0)); ih = max(f(min(a[3], b[3]) - max(a[1], b[1]) + f(1)), f(0))
+        inter = f(iw * ih)
+        u = f(f(f(f(a[2] - a[0] + f(1)) * f(a[3] - a[1] + f(1))) + f(f(b[2] - b[0] + f(1)) * f(b[3] - b[1] + f(1)))) - inter)
+        return f(inter / u) if u > 0 else f(0)
+    idx = sorted(range(257), key=lambda i: -scores[i])
+    sup, out = [False] * 257, []
+    for p in range(257):
+        if sup[p]:
+            continue
+        cur = idx[p]
+        out.append(cur)
+        for q in range(p + 1, 257):
+            if not sup[q]:
+                v = iou(boxes[cur], boxes[idx[q]])
+                if v >= (f(0.6) if classes[idx[q]] == classes[cur] else f(0.98)) or np.isnan(v):
+                    sup[q] = True
+    assert list(sel) == out
+    # a denser variant of the same lattice does suppress
+    boxes2 = boxes.copy(); boxes2[:, :2] = np.floor(boxes2[:, :2] / 3); boxes2[:, 2:] = boxes2[:, :2] + 25
+    assert len(R.paddlex_layout_nms(boxes2, classes, scores)) < 120
+
+
+def test_pp_doclayout_adapter_postprocess_rules():
+    """postprocess_pp_doclayout (:631-846), each rule on a hand-made row set (rows: class, score, x1, y1, x2, y2[, col, row])."""
+    W, H = 400.0, 600.0
+    rows = np.array([
+        [0, 0.90, 10, 10, 110, 60, 1, 0],      # text
+        [0, 0.85, 12, 12, 108, 58, 0, 5],      # text inside the first (IoU('+1' form) > 0.6): suppressed by NMS
+        [1, 0.95, 0, 0, 400, 600, 0, 1],       # page-sized image
+        [2, 0.70, 200, 200, 300, 260, 0, 0],   # formula
+        [0, 0.45, 205, 205, 295, 255, 2, 2],   # text inside the formula, below 0.5
+        [3, 0.80, 50, 300, 350, 500, 1, 1],    # table
+        [0, 0.60, 60, 310, 200, 400, 0, 2],    # text inside the table
+        [9, 0.99, 0, 0, 10, 10, 0, 0],         # class out of range
+        [0, 0.99, 50, 50, 40, 60, 0, 0],       # x2 < x1
+    ], np.float32)
+    b, c, s = R.pp_doclayout_postprocess(rows[:, :6], W, H, 4, 0.5)
+    assert list(c) == [1, 0, 3, 2, 0] and list(s) == [np.float32(v) for v in (0.95, 0.90, 0.80, 0.70, 0.60)]          # score order, NMS dropped row 1
+    b, c, s = R.pp_doclayout_postprocess(rows[:, :6], W, H, 4, 0.5, image_class=1)
+    assert list(c) == [0, 3, 2, 0]                                                                                     # the page-sized image is gone
+    b, c, s = R.pp_doclayout_postprocess(rows[:, :6], W, H, 4, 0.5, class_thresholds={0: 0.4}, layout_nms=False)
+    assert list(s) == [np.float32(v) for v in (0.90, 0.85, 0.95, 0.70, 0.45, 0.80, 0.60)]                              # row order, per-class threshold
+    # Large on "table": what a table contains goes; Small on "text": a text that contains another box goes unless it is itself contained
+    b, c, s = R.pp_doclayout_postprocess(rows[:, :6], W, H, 4, 0.5, image_class=1, merge_modes={3: "large"})
+    assert list(zip(c, s)) == [(0, np.float32(0.90)), (3, np.float32(0.80)), (2, np.float32(0.70))]
+    b, c, s = R.pp_doclayout_postprocess(rows[:, :6], W, H, 4, 0.4, image_class=1, formula_class=2, merge_modes={2: "large"})
+    assert (0, np.float32(0.45)) not in list(zip(c, s))                                                               # text inside the formula: contained by class 2
+    b, c, s = R.pp_doclayout_postprocess(rows[:, :6], W, H, 4, 0.4, image_class=1, formula_class=2, merge_modes={0: "large"})
+    assert (2, np.float32(0.70)) in list(zip(c, s))                                                                   # (formula, non-formula) pairs are skipped
+    # reading order: V2 (col, row), V3 (single key); ties keep selection order
+    b, c, s = R.pp_doclayout_postprocess(rows, W, H, 4, 0.5)
+    assert list(s) == [np.float32(v) for v in (0.70, 0.95, 0.60, 0.90, 0.80)]
+    b, c, s = R.pp_doclayout_postprocess(rows[:, :7], W, H, 4, 0.5)
+    assert list(s) == [np.float32(v) for v in (0.95, 0.70, 0.60, 0.90, 0.80)]
+
+
+def test_nms_with_merge_product_equals_the_oracle():
+    """apply_nms_with_merge (processors/layout_postprocess.rs:743-841, class_merge_modes of the PicoDet / RT-DETR adapters): the library's host routine
+    (oar_host_nms_with_merge, no GPU involved) against the oracle's restatement, hand cases and 200 random box sets."""
+    from oar_ocr_amd import api
+    f = np.float32
+    boxes = np.array([[0, 0, 100, 100], [10, 10, 90, 90], [200, 200, 260, 260], [5, 5, 120, 110], [0, 0, 100, 100]], f)
+    classes = np.array([0, 0, 1, 0, 1], np.int32)
+    scores = np.array([0.9, 0.95, 0.5, 0.7, 0.6], f)
+    for modes, expect in ((["union", "large"], [[0, 0, 120, 110], [200, 200, 260, 260], [0, 0, 100, 100]]), (["large", "large"], [[5, 5, 120, 110], [200, 200, 260, 260], [0, 0, 100, 100]]),
+                          (["small", "large"], [[10, 10, 90, 90], [200, 200, 260, 260], [0, 0, 100, 100]])):
+        rb, rc, rs = R.apply_nms_with_merge(boxes, classes, scores, modes, 0.5, 100)
+        assert rb.tolist() == expect and list(rc) == [0, 1, 1] and list(rs) == [f(0.95), f(0.5), f(0.6)]
+        gb, gc, gs = api.host_nms_with_merge(boxes, classes, scores, modes, 0.5, 100)
+        assert np.array_equal(gb, rb) and np.array_equal(gc, rc) and np.array_equal(gs, rs)
+    rng = np.random.default_rng(3)
+    for t in range(200):
+        n = int(rng.integers(0, 60))
+        xy = rng.uniform(0, 200, (n, 2)); wh = rng.uniform(5, 120, (n, 2))
+        b = np.concatenate([xy, xy + wh], 1).astype(f)
+        c = rng.integers(0, 4, n).astype(np.int32)
+        s = np.round(rng.uniform(0, 1, n), 1).astype(f)
+        modes = list(rng.choice(["large", "union", "small"], 4))
+        thr, cap = float(rng.choice([0.1, 0.3, 0.5])), int(rng.choice([3, 10, 100]))
+        rb, rc, rs = R.apply_nms_with_merge(b, c, s, modes, thr, cap)
+        gb, gc, gs = api.host_nms_with_merge(b, c, s, modes, thr, cap)
+        assert np.array_equal(gb, rb) and np.array_equal(gc, rc) and np.array_equal(gs, rs), t
