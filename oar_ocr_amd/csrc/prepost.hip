@@ -344,6 +344,32 @@ void ctc_argmax(hipStream_t s, const float* probs, int64_t rows, int vocab, int6
 // ------------------------------------------------------------------------------------------ a10 box score
 // One workgroup per box. Rows are summed left-to-right by one lane each (the reference's sequential `+=`),
 // then lane 0 adds the row sums in row order -- exactly the reference's summation tree (db_score.rs:86-132).
+// The reference's sequential `+=` along a scanline span (db_score.rs:118-124): the ADDS keep that order, the LOADS do not have to.  A
+// load-then-add loop pays one L2 round trip per pixel (78 us per launch in round 3; 16 single loads in flight: 33 us).  Here a lane keeps 128 pixels
+// in flight as 32 four-pixel loads (rows are only 4-byte aligned: f4u), then 32, then a clamped tail.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+template <int NV>
+__device__ __forceinline__ float span_batch(const float* p, float line) {
+    f4u v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const f4u*>(p + i * 4);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { line += v[i].x; line += v[i].y; line += v[i].z; line += v[i].w; }
+    return line;
+}
+__device__ __forceinline__ float span_sum(const float* row, unsigned x1, unsigned xe, float line) {
+    unsigned x = x1;
+    for (; x + 128 <= xe; x += 128) line = span_batch<32>(row + x, line);
+    for (; x + 32 <= xe; x += 32) line = span_batch<8>(row + x, line);
+    if (x < xe) {
+        float v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = row[x + k < xe ? x + k : xe - 1];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) if (x + k < xe) line += v[k];
+    }
+    return line;
+}
 __device__ __forceinline__ unsigned f2u(float v) { return v > 0.0f ? (v >= 4294967296.0f ? 0xFFFFFFFFu : (unsigned)v) : 0u; }
 __global__ __launch_bounds__(256) void box_scores_kernel(const float* pred, int height, int width, const ScoreBox* boxes, float* scores) {
     __shared__ float rsum[256];
@@ -388,23 +414,7 @@ __global__ __launch_bounds__(256) void box_scores_kernel(const float* pred, int 
                     if (x1 < x2 && x1 >= start_x && x2 <= end_x) {
                         unsigned xe = x2 < (unsigned)width ? x2 : (unsigned)width;
                         if (x1 < xe) {
-                            // the reference's sequential `+=` along the row -- but the LOADS are independent: 16 in flight per lane, then the adds in
-                            // order (a load-then-add loop pays one L2 round trip per pixel: 78 us per launch in round 3)
-                            unsigned x = x1;
-                            for (; x + 16 <= xe; x += 16) {
-                                float v[16];
-#pragma unroll
-                                for (int k = 0; k < 16; ++k) v[k] = row[x + k];
-#pragma unroll
-                                for (int k = 0; k < 16; ++k) line += v[k];
-                            }
-                            {
-                                float v[16];
-#pragma unroll
-                                for (int k = 0; k < 16; ++k) v[k] = x + k < xe ? row[x + k] : 0.0f;
-#pragma unroll
-                                for (int k = 0; k < 16; ++k) if (x + k < xe) line += v[k];
-                            }
+                            line = span_sum(row, x1, xe, line);
                             lp += xe - x1;
                         }
                     }
@@ -578,23 +588,7 @@ __global__ __launch_bounds__(256) void poly_scores_kernel(const float* pred, int
                     if (x1 < x2 && x1 >= start_x && x2 <= end_x) {
                         const unsigned xe = x2 < (unsigned)width ? x2 : (unsigned)width;
                         if (x1 < xe) {
-                            // the reference's sequential `+=` along the row -- but the LOADS are independent: 16 in flight per lane, then the adds in
-                            // order (a load-then-add loop pays one L2 round trip per pixel: 78 us per launch in round 3)
-                            unsigned x = x1;
-                            for (; x + 16 <= xe; x += 16) {
-                                float v[16];
-#pragma unroll
-                                for (int k = 0; k < 16; ++k) v[k] = row[x + k];
-#pragma unroll
-                                for (int k = 0; k < 16; ++k) line += v[k];
-                            }
-                            {
-                                float v[16];
-#pragma unroll
-                                for (int k = 0; k < 16; ++k) v[k] = x + k < xe ? row[x + k] : 0.0f;
-#pragma unroll
-                                for (int k = 0; k < 16; ++k) if (x + k < xe) line += v[k];
-                            }
+                            line = span_sum(row, x1, xe, line);
                             lp += xe - x1;
                         }
                     }

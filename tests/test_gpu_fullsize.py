@@ -4,8 +4,9 @@ C3 had only Seam-A graph checks at 256x320).
 C2  PP-OCRv6-tiny-class det+rec, ONE predict of 32 pages of 960x960 (image batch 32, region batch 256: the bench's
     workload, with its 8/9-page detector sub-batches, the M >= 100 k kernel selections and ~1100 pooled crops);
     4 pages -- one from each detector sub-batch -- are checked against the oracle.
-C3  PP-OCRv5-server-class det + SVTR rec (V = 18710) through OAROCR.predict on 1280x1280 pages with limit_side_len = 1280
-    (the reference needs that setting to really run 1280^2, src/oarocr/ocr.rs:351-363), every page checked.
+C3  PP-OCRv5-server-class det + SVTR rec (V = 18710) through OAROCR.predict, 64 pages of 1280x1280 in one call with limit_side_len = 1280
+    (the reference needs that setting to really run 1280^2, src/oarocr/ocr.rs:351-363), 3 pages checked.
+C4  rank 0 of 8's shard of the 1024-page list (128 pages, 2 host threads) through predict_packed -> oar_ocr_pack -> oar_packed_merge.
 
 Bar: boxes bit-exact, region order identical, recognition scores within 1e-3, texts equal unless the oracle's own top-2
 probabilities tie within 1e-5 at some time step."""
@@ -109,11 +110,48 @@ def test_c3_server_graphs_on_1280x1280_pages():
     det, _ = models.build_det("server", seed=0)
     rec, _ = models.build_rec("server", vocab=18710, seed=1)
     chars = api.read_dict(models.synth_dict(18708))
-    imgs = [pages.make_page(100 + i, (1280, 1280), 40) for i in range(3)]
+    imgs = [pages.make_page(100 + i, (1280, 1280), 40) for i in range(64)]     # BASELINE C3 as stated: batch = 64 pages in ONE predict
     cfg = api.TextDetectionConfig(score_threshold=0.3, box_threshold=0.6, unclip_ratio=1.5, limit_side_len=1280)
     ocr = api.OAROCRBuilder(det, rec, chars).text_detection_config(cfg).image_batch_size(64).region_batch_size(64).build()
     got = ocr.predict(imgs)
-    assert sum(len(g.text_regions) for g in got) > 60
-    n, ties = _check_pages_against_oracle(got, imgs, [0, 1, 2], det, rec, chars, dict(limit_side_len=1280), (0.3, 0.6, 1.5))
+    assert len(got) == 64 and sum(len(g.text_regions) for g in got) > 1500
+    n, ties = _check_pages_against_oracle(got, imgs, [0, 30, 63], det, rec, chars, dict(limit_side_len=1280), (0.3, 0.6, 1.5))
     assert n > 60 and ties <= 2
+    ocr.close()
+
+
+def test_c4_rank_0_of_8_shard_of_the_1024_page_list():
+    """BASELINE C4 (1024 pages image-parallel over 8 GPUs) as ONE rank sees it: oar_shard_range(1024, 8, 0) = pages [0, 128), image_batch_size 32,
+    a 2-thread geometry pool (the rank's share of the host), ONE predict over the whole shard, the result leaving as oar_ocr_pack's blob and meeting the
+    other ranks' blobs in oar_packed_merge.  Four pages of the shard are checked against the oracle, every page against the object-returning entry."""
+    a, b = api.shard_range(1024, 8, 0)
+    assert (a, b) == (0, 128) and api.shard_range(1024, 8, 7) == (896, 1024)
+    det, _ = models.build_det("tiny", seed=0)
+    rec, _ = models.build_rec("tiny", vocab=6906, seed=1)
+    chars = api.read_dict(models.synth_dict(6904))
+    imgs = [pages.make_page(a + i, (960, 960), 40) for i in range(b - a)]                 # bench.py --config 3 seeds its pages the same way
+    cfg = api.TextDetectionConfig(score_threshold=0.3, box_threshold=0.6, unclip_ratio=1.5)
+    ocr = api.OAROCRBuilder(det, rec, chars).text_detection_config(cfg).image_batch_size(32).region_batch_size(256).host_threads(2).build()
+    _, ptrs, ws, hs = api._img_arrays(imgs)
+    packed = ocr.predict_packed(ptrs, ws, hs, len(imgs), want_blob=True)
+    assert len(packed.region_offsets) == 129 and packed.region_offsets[-1] > 3600 and packed.blob == packed.to_bytes()
+    got = ocr.predict(imgs)
+    assert packed.region_offsets.tolist() == np.concatenate([[0], np.cumsum([len(g.text_regions) for g in got])]).tolist()
+    k = 0
+    for g in got:
+        for t in g.text_regions:
+            assert np.array_equal(packed.points[k], t.bounding_box) and packed.text(k) == t.text and packed.scores[k] == np.float32(t.confidence)
+            k += 1
+    n, ties = _check_pages_against_oracle(got, imgs, [0, 41, 86, 127], det, rec, chars, {}, (0.3, 0.6, 1.5))
+    assert n > 100 and ties <= 2
+    # rank 0's blob + a second rank's (two pages of ITS shard) through the merge the host runs after its gather
+    a1, _ = api.shard_range(1024, 8, 1)
+    tail = [pages.make_page(a1 + i, (960, 960), 40) for i in range(2)]
+    _, p1, w1, h1 = api._img_arrays(tail)
+    other = ocr.predict_packed(p1, w1, h1, 2, want_blob=True)
+    merged = api.PackedPages.merge([packed.blob, other.blob])
+    nr = int(packed.region_offsets[-1])
+    assert merged.region_offsets.tolist() == packed.region_offsets.tolist() + [nr + int(v) for v in other.region_offsets[1:]]
+    assert np.array_equal(merged.points[:nr], packed.points) and np.array_equal(merged.points[nr:], other.points)
+    assert np.array_equal(merged.scores, np.concatenate([packed.scores, other.scores])) and merged.utf8 == packed.utf8 + other.utf8
     ocr.close()
