@@ -17,7 +17,7 @@ struct DsBlockP {
     const float* x;
     const float* wd;           // depthwise weights [ks*ks][C]
     const float* bd;           // may be null
-    const float* wp;           // pointwise weights in bf16x6 fragment order (IGEMM_W_X6)
+    const float* wp;           // pointwise weights in the order dsblock_wp_format() names (IGEMM_W_X6CS: whole weight blocks, wd / bd unused)
     const float* bp;           // may be null
     const float* residual;     // may be null, shape of y
     bool has_res;              // plan time (pointers not known yet): the block ends in + residual
@@ -31,6 +31,8 @@ void dsblock(hipStream_t s, const DsBlockP& p);
 // fragment layout dsblock() expects p.wp in for this block (IGEMM_W_X6 for the bf16x6 kernels, IGEMM_W_K16 for the f32 row-streaming kernel);
 // depends on the shape only (not on the pointers)
 int dsblock_wp_format(const DsBlockP& p);
+// IGEMM_W_X6CS: bytes of one channel chunk's weight block (dsblock_cs.inc: [taps | bias] rounded to 1 KB, then 1536 B per cout fragment, rounded to 1 KB)
+size_t dsblock_cs_block_bytes(int ks, int nft);
 
 }  // namespace k
 }  // namespace oar

@@ -1,6 +1,7 @@
 // dsblock.hip -- host side of the fused depthwise-separable block: tile shape, wave layout, launch (kernel: dsblock.inc).
 #include "dsblock_dev.h"
 #include "dsblock_rs.h"
+#include "dsblock_cs.h"
 
 namespace oar {
 namespace k {
@@ -165,6 +166,59 @@ void dsblock_rs(hipStream_t s, const DsBlockP& b, const RsShape& sh) {
     else if (b.sh == 1) dsblock_rs_launch_k3s12(s, p, sh.nch, sh.nf, sh.x6, sh.acts, grid, sh.lds, ps.start(), ps.stop());
     else dsblock_rs_launch_k3s22(s, p, sh.nch, sh.nf, sh.x6, sh.acts, grid, sh.lds, ps.start(), ps.stop());
 }
+
+// The chunk-streamed kernel (dsblock_cs.inc, round 4): the wide blocks (C / Cout up to 192, 3x3 and 5x5) whose tables do not fit dsblock_rs's LDS plan.
+struct CsShape { int nch, nf, acts, segs, tiles_x, items, iters, grid; size_t lds; bool ok, forced; };
+CsShape cs_shape(const DsBlockP& p) {
+    CsShape r{};
+    const char* e = getenv("OAR_DSBLOCK_CS");   // 0: never; 2: wherever an instantiation exists (A/B runs against dsblock_rs / dsblock)
+    if (e && atoi(e) == 0) return r;
+    r.forced = e && atoi(e) == 2;
+    if (!(p.ks == 3 || p.ks == 5) || p.C <= 0 || (p.C & 15) || p.Cout <= 0 || (p.Cout & 15) || (p.y_ld & 3) || p.N <= 0 || p.Ho <= 0 || p.Wo <= 0) return r;
+    if (p.pt < 0 || p.pl < 0 || p.pt >= p.ks || p.pl >= p.ks || p.has_res || p.residual || p.se) return r;
+    auto plain = [](const Act& a) { return a.kind == ACT_NONE || a.kind == ACT_RELU || a.kind == ACT_HSWISH; };
+    if (!plain(p.act1) || !plain(p.act2)) return r;
+    if ((long)p.H * p.W * p.C * 4 >= (1L << 29) || (long)p.N * p.Ho * p.Wo * p.y_ld * 4 >= (1L << 31)) return r;
+    r.nch = p.C / 16; r.nf = p.Cout / 16;
+    r.lds = dsblock_cs_lds(p.ks, p.sh, p.sw, r.nch, r.nf);
+    if (r.lds == 0) return r;
+    r.acts = (p.act1.kind == ACT_HSWISH && p.act2.kind == ACT_HSWISH) ? 1 : 0;
+    r.segs = (p.Ho + kCsRows - 1) / kCsRows; r.tiles_x = (p.Wo + 15) / 16;
+    const long items = (long)p.N * r.segs * r.tiles_x;
+    if (items >= (1L << 30)) return r;
+    r.items = (int)items;
+    r.grid = (int)std::min<long>(256, ((items + 3) / 4 + 7) / 8 * 8);      // four waves = four items per workgroup and step; a multiple of the 8 XCDs
+    r.iters = (int)((items + 4L * r.grid - 1) / (4L * r.grid));
+    r.ok = true;
+    return r;
+}
+void dsblock_cs(hipStream_t s, const DsBlockP& b, const CsShape& sh) {
+    DsCsP p{};
+    p.x = b.x; p.y = b.y; p.wb = reinterpret_cast<const float4*>(b.wp);
+    p.bp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(b.wp) + (size_t)sh.nch * dsblock_cs_block_bytes(b.ks, sh.nf));   // the pointwise bias follows the blocks
+    p.N = b.N; p.H = b.H; p.W = b.W; p.C = b.C; p.Ho = b.Ho; p.Wo = b.Wo; p.Cout = b.Cout; p.y_ld = b.y_ld;
+    p.pt = b.pt; p.pl = b.pl; p.act1 = b.act1.kind; p.act2 = b.act2.kind;
+    p.segs = sh.segs; p.tiles_x = sh.tiles_x; p.items = sh.items; p.iters = sh.iters;
+    p.img_bytes = (unsigned)((long)b.H * b.W * b.C * 4);
+    p.y_bytes = (unsigned)((long)b.N * b.Ho * b.Wo * b.y_ld * 4);
+    const double px_in = (double)b.N * b.H * b.W, px_out = (double)b.N * b.Ho * b.Wo;
+    const double bytes = 4.0 * (px_in * b.C + px_out * b.Cout) + 4.0 * b.ks * b.ks * b.C + 6.0 * b.C * b.Cout;
+    const double flops = 2.0 * px_out * b.C * (b.ks * b.ks + (double)b.Cout);
+    char pname[96];
+    const char* cls = "dsblock";
+    if (Profiler::get().detail) { snprintf(pname, sizeof pname, "dsblock px=%ld C=%d N=%d k%d s%dx%d cs", (long)px_out, b.C, b.Cout, b.ks, b.sh, b.sw); cls = pname; }
+    ProfScope ps(s, cls, bytes, flops, true);
+    dsblock_cs_launch(s, p, b.ks, b.sh, b.sw, sh.nch, sh.nf, sh.acts, sh.grid, sh.lds, ps.start(), ps.stop());
+}
+// which kernel runs the block: 0 row-streaming, 1 wave-autonomous, 2 chunk-streamed, 3 dsblock.inc, -1 none
+int ds_pick(const DsBlockP& p) {
+    const CsShape cs = cs_shape(p);
+    if (cs.ok && cs.forced) return 2;
+    if (rs_shape(p).ok) return 0;
+    if (wa_shape(p).ok) return 1;
+    if (cs.ok) return 2;
+    return ds_shape(p).ok ? 3 : -1;
+}
 }  // namespace
 
 int dsblock_rs_wpw(int sh, int sw, int nch, int nft, int x6) {
@@ -173,19 +227,24 @@ int dsblock_rs_wpw(int sh, int sw, int nch, int nft, int x6) {
     return 0;
 }
 
-int dsblock_wp_format(const DsBlockP& p) { const RsShape r = rs_shape(p); return !r.ok ? IGEMM_W_X6 : r.x6 ? IGEMM_W_X6RS : IGEMM_W_K16; }
+int dsblock_wp_format(const DsBlockP& p) {
+    const int k = ds_pick(p);
+    if (k == 2) return IGEMM_W_X6CS;
+    if (k != 0) return IGEMM_W_X6;
+    return rs_shape(p).x6 ? IGEMM_W_X6RS : IGEMM_W_K16;
+}
 
 bool dsblock_eligible(const DsBlockP& p) {
     const char* e = getenv("OAR_FUSE_DSBLOCK");
     const bool on = !e || atoi(e) != 0;
-    return on && (rs_shape(p).ok || wa_shape(p).ok || ds_shape(p).ok);
+    return on && ds_pick(p) >= 0;
 }
 
 void dsblock(hipStream_t s, const DsBlockP& b) {
-    const RsShape rs = rs_shape(b);
-    if (rs.ok) { dsblock_rs(s, b, rs); return; }
-    const WaShape wa = wa_shape(b);
-    if (wa.ok) { dsblock_wa(s, b, wa); return; }
+    const int pick = ds_pick(b);
+    if (pick == 0) { dsblock_rs(s, b, rs_shape(b)); return; }
+    if (pick == 1) { dsblock_wa(s, b, wa_shape(b)); return; }
+    if (pick == 2) { dsblock_cs(s, b, cs_shape(b)); return; }
     const DsPlanShape sh = ds_shape(b);
     OAR_CHECK(sh.ok, OAR_INTERNAL, "dsblock: called on an ineligible block");
     DsP p{};

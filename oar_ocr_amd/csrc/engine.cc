@@ -1176,6 +1176,54 @@ struct Planner {
         w.resize((size_t)Co * K);
         return E.upload_const(key, to_fragments(fmt, w, Co, K));
     }
+    // IGEMM_W_X6CS (dsblock_cs.inc): one block per 16-channel chunk c --
+    //   [tap t = 0 .. ks*ks-1 | bias][g = 0..3] float4 = depthwise weights / bias of channels 16 c + 4 g .. + 3        (rounded up to 1 KB)
+    //   per cout fragment f: lane (g, m = cout 16 f + m) -> 8 bytes w_l, 8 bytes w_h  (1 KB), then 8 bytes w_m (512 B)   (rounded up to 1 KB)
+    // and after the last block the pointwise bias [Cout]
+    // where w_h / w_m / w_l are the bf16 truncation pieces of W_pw[16 f + m][16 c + 4 g + e], e = 0..3
+    const float* conv_weight_cs(const GNode& dwn, const GNode& pwn, const HostTensor& WD, const HostTensor& WP, const std::vector<float>* bias_dw, const std::vector<float>* bias_pw) {
+        std::string key = "dscs:" + dwn.in[1] + ":" + pwn.in[1];
+        auto it = E.dev_consts_.find(key);
+        if (it != E.dev_consts_.end()) return it->second;
+        const int64_t C = WD.dims[0], ks = WD.dims[2], Co = WP.dims[0], nch = C / 16, nft = Co / 16;
+        const size_t blk = k::dsblock_cs_block_bytes((int)ks, (int)nft), dwb = (size_t)(((ks * ks + 1) * 64 + 1023) / 1024 * 1024);
+        std::vector<float> out(blk * (size_t)nch / 4 + (size_t)Co, 0.f);   // + the pointwise bias [Cout] (zeros when the block has none)
+        if (bias_pw) std::copy(bias_pw->begin(), bias_pw->begin() + Co, out.begin() + (ptrdiff_t)(blk * (size_t)nch / 4));
+        auto split = [](float x, uint16_t& h, uint16_t& m, uint16_t& l) {
+            uint32_t u, um, ul;
+            std::memcpy(&u, &x, 4);
+            const uint32_t uh = u & 0xFFFF0000u;
+            float fh; std::memcpy(&fh, &uh, 4);
+            const float r1 = x - fh;
+            std::memcpy(&um, &r1, 4); um &= 0xFFFF0000u;
+            float fm; std::memcpy(&fm, &um, 4);
+            const float r2 = r1 - fm;
+            std::memcpy(&ul, &r2, 4);
+            h = (uint16_t)(uh >> 16); m = (uint16_t)(um >> 16); l = (uint16_t)(ul >> 16);
+        };
+        for (int64_t c = 0; c < nch; ++c) {
+            char* b = reinterpret_cast<char*>(out.data()) + (size_t)c * blk;
+            float* dw = reinterpret_cast<float*>(b);
+            for (int64_t t = 0; t <= ks * ks; ++t)
+                for (int64_t q = 0; q < 16; ++q) {
+                    const int64_t ch = c * 16 + q;
+                    dw[t * 16 + q] = t < ks * ks ? WD.f[(size_t)(ch * ks * ks + t)] : (bias_dw ? (*bias_dw)[(size_t)ch] : 0.f);
+                }
+            for (int64_t f = 0; f < nft; ++f) {
+                uint16_t* lh = reinterpret_cast<uint16_t*>(b + dwb + (size_t)f * 1536);
+                uint16_t* md = reinterpret_cast<uint16_t*>(b + dwb + (size_t)f * 1536 + 1024);
+                for (int64_t g = 0; g < 4; ++g)
+                    for (int64_t m = 0; m < 16; ++m)
+                        for (int64_t e = 0; e < 4; ++e) {
+                            uint16_t h, mm, l;
+                            split(WP.f[(size_t)((f * 16 + m) * C + c * 16 + g * 4 + e)], h, mm, l);
+                            const size_t lane = (size_t)(g * 16 + m);
+                            lh[lane * 8 + e] = l; lh[lane * 8 + 4 + e] = h; md[lane * 4 + e] = mm;
+                        }
+            }
+        }
+        return E.upload_const(key, out);
+    }
     const float* conv_weight_dw(const GNode& n, const HostTensor& W) {
         std::string key = "dw:" + n.in[1];
         auto it = E.dev_consts_.find(key);
@@ -1449,12 +1497,13 @@ struct Planner {
         if (Ho <= 0 || Wo <= 0 || !k::dsblock_eligible(p)) return unfused();
         if (!n.residual.empty()) res = to_clast_loc(get(n.residual));
         Loc xin = to_clast_loc(x);
-        p.wd = conv_weight_dw(dwn, WD);
-        p.bd = n.in[2].empty() ? nullptr : get(n.in[2]).loc.cptr;
-        p.wp = conv_weight_igemm(pwn, WP, k::dsblock_wp_format(p));
-        p.bp = n.in[4].empty() ? nullptr : get(n.in[4]).loc.cptr;
         if (!n.in[2].empty()) OAR_CHECK((int64_t)get(n.in[2]).ht->f.size() == C, OAR_MODEL_LOAD, "DSBlock: depthwise bias size");
         if (!n.in[4].empty()) OAR_CHECK((int64_t)get(n.in[4]).ht->f.size() == Cout, OAR_MODEL_LOAD, "DSBlock: pointwise bias size");
+        p.wd = conv_weight_dw(dwn, WD);
+        p.bd = n.in[2].empty() ? nullptr : get(n.in[2]).loc.cptr;
+        const int wfmt = k::dsblock_wp_format(p);
+        p.wp = wfmt == k::IGEMM_W_X6CS ? conv_weight_cs(dwn, pwn, WD, WP, n.in[2].empty() ? nullptr : &get(n.in[2]).ht->f, n.in[4].empty() ? nullptr : &get(n.in[4]).ht->f) : conv_weight_igemm(pwn, WP, wfmt);
+        p.bp = n.in[4].empty() ? nullptr : get(n.in[4]).loc.cptr;
         TInfo& y = new_out(n.out[0], {N, Cout, Ho, Wo}, Layout::CLAST);
         Loc yl = y.loc;
         const bool has_res = res.kind != Loc::NONE;

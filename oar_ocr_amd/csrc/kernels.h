@@ -36,7 +36,8 @@ struct ConvP {
     float* gap_part;        // depthwise only (conv_dw_gap_tiles(p) > 0): per-tile sums of the activated output, [N][tiles][Cout] -- the squeeze of an
                             // SE block without a second read of the feature map (global_avgpool_finish reduces them)
 };
-enum : int { IGEMM_W_K16 = 0, IGEMM_W_X6 = 1, IGEMM_W_X6RS = 2 };   // X6RS: the bf16x6 fragments of dsblock_rs.inc (k-step = two 16-channel chunks)
+enum : int { IGEMM_W_K16 = 0, IGEMM_W_X6 = 1, IGEMM_W_X6RS = 2, IGEMM_W_X6CS = 3 };   // X6CS: per-chunk weight blocks of dsblock_cs.inc (depthwise taps + bias + pointwise pieces)
+//   // X6RS: the bf16x6 fragments of dsblock_rs.inc (k-step = two 16-channel chunks)
 
 // Implicit-GEMM conv on the matrix cores. groups == 1, Cin % 4 == 0. Weight layouts (ConvP::w_fmt):
 //   K16: f32 fragments  Wf[cout/16][K/16][lane][4 f32]              -> v_mfma_f32_16x16x4_f32 (exact f32 FMA chain)

@@ -505,6 +505,9 @@ DS_CASES = [  # (C, Cout, k, stride, N, H, W, act, residual)
     (96, 96, 3, (1, 1), 2, 12, 160, "hswish", False), (64, 64, 3, (1, 1), 2, 30, 30, "hswish", True), (80, 80, 3, (1, 1), 1, 17, 35, "relu", False),
     (32, 128, 3, (1, 1), 1, 21, 50, "hswish", False), (96, 192, 3, (1, 1), 2, 12, 70, "hswish", False), (20, 12, 3, (1, 1), 1, 40, 19, "swish", False),
     (16, 24, 3, (1, 1), 3, 120, 136, "hswish", False), (48, 48, 3, (1, 1), 1, 3, 5, None, False),
+    # round 4, the chunk-streamed kernel (dsblock_cs.inc: the wide blocks): ragged rows / columns, more items than one round of waves, run-time activations
+    (192, 192, 5, (1, 1), 5, 13, 50, "hswish", False), (96, 192, 3, (1, 2), 3, 12, 161, "relu", False), (128, 128, 5, (1, 1), 2, 15, 23, "hswish", False),
+    (192, 192, 5, (1, 1), 40, 12, 80, None, False),
 ]
 
 
@@ -542,6 +545,14 @@ def test_fused_dsblock_matches_oracle(case, monkeypatch):
         monkeypatch.setenv("OAR_DSBLOCK_WA", "0")
         old = api.OrtInfer(m).infer(x)[0][1]
         assert np.array_equal(old, wa)
+        monkeypatch.delenv("OAR_DSBLOCK_WA")
+    # the chunk-streamed kernel wherever it has an instantiation (OAR_DSBLOCK_CS=2), and the build without it (=0: the wide 5x5 blocks fall back to two
+    # convolutions, 96 -> 192 stride (1, 2) to dsblock.inc)
+    monkeypatch.delenv("OAR_DSBLOCK_RS")
+    for v in ("2", "0"):
+        monkeypatch.setenv("OAR_DSBLOCK_CS", v)
+        alt = api.OrtInfer(m).infer(x)[0][1]
+        assert np.abs(alt - ref[0]).max() <= 2e-4 * max(1.0, float(np.abs(ref[0]).max())), v
 
 
 @pytest.mark.parametrize("case", ["fpn", "fallbacks"])
