@@ -387,21 +387,58 @@ def main():
             ort_note = ("not run: " + ("onnxruntime is not importable on this box" if not have_ort else "onnxruntime present") +
                         ("; no models/*.onnx supplied (synthetic-weight graphs only)" if not real else f"; models present: {real}") +
                         " -- the timed oracle is the torch-CPU port")
-            sample = host_pages[:args.cpu_pages]
-            stages = dict(doc_orientation=models.build_cls(4, seed=5)[0], rectifier=models.build_uvdoc(seed=6)[0],
-                          line_orientation=models.build_cls(2, seed=9)[0]) if args.config == 4 else {}
-            cpu_threads = torch.get_num_threads()
-            oc = pipeline_ref.OracleOCR(det, rec, chars, 0.3, 0.6, 1.5, image_batch_size=1, region_batch_size=16, threads=cpu_threads, **stages)  # reference CPU policy (builder_utils.rs:111-125)
-            oc.predict(sample[:1])  # warm
-            c0 = time.perf_counter()
-            oc.predict(sample)
-            cdt = time.perf_counter() - c0
-            cpu = {"value": round(len(sample) / cdt, 3), "unit": "images/sec", "cores": cpu_threads, "kind": "port",
-                   "parallel": f"thread pool of {cpu_threads} over the crops of a page / of a recognition batch (where the reference's rayon pool fans out: "
-                               "processors.rs:113-131, crnn.rs:98-121) + torch-CPU intra-op threads for the networks; contour tracing / unclip serial per page as in the reference",
+            # Two deployments of the same port, each timed on a bounded sample (oracle/cpu_baseline_worker.py; every worker is warmed before the
+            # common start signal):  (a) ONE pipeline with all intra-op threads -- the reference's default CPU deployment;  (b) W pipelines of T
+            # threads side by side (W x T = the cores): what fills a 64-core host when pages queue up.  `value` is the better of the two.
+            ncpu = min(os.cpu_count() or 1, 64)
+            cfg_id = {1: 1, 2: 2, 3: 1, 4: 4}[args.config]
+
+            def run_workers(W, Tn, pages_each):
+                env = dict(os.environ, OMP_NUM_THREADS=str(Tn), MKL_NUM_THREADS=str(Tn))
+                procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_baseline_worker", "--threads", str(Tn), "--pages", str(pages_each), "--seed0", str(1000 + 17 * w),
+                                           "--size", str(size), "--lines", str(args.lines), "--config", str(cfg_id)], cwd=str(ROOT), env=env,
+                                          stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for w in range(W)]
+                try:
+                    for q in procs:
+                        while True:
+                            ln = q.stdout.readline()
+                            if not ln:
+                                raise RuntimeError("cpu_baseline worker died during warm-up")
+                            if ln.startswith("READY"):
+                                break
+                    c0 = time.perf_counter()
+                    for q in procs:
+                        q.stdin.write("GO\n"); q.stdin.flush()
+                    outs = [json.loads(q.stdout.readline()) for q in procs]
+                    wall = time.perf_counter() - c0
+                finally:
+                    for q in procs:
+                        try:
+                            q.stdin.close()
+                        except Exception:
+                            pass
+                        q.wait(timeout=60)
+                stage = {}
+                for o in outs:
+                    for k, v in o["stage_ms_per_page"].items():
+                        stage[k] = stage.get(k, 0.0) + v / len(outs)
+                return {"workers": W, "threads_each": Tn, "pages": W * pages_each, "images_per_sec": round(W * pages_each / wall, 3), "wall_s": round(wall, 2),
+                        "stage_ms_per_page": {k: round(v, 1) for k, v in sorted(stage.items(), key=lambda kv: -kv[1])}}
+            single = run_workers(1, ncpu, args.cpu_pages)
+            Wn = max(1, ncpu // 8)
+            multi = run_workers(Wn, max(1, ncpu // Wn), max(2, args.cpu_pages - 1)) if Wn > 1 else single
+            best = max((single, multi), key=lambda r: r["images_per_sec"])
+            cpu = {"value": best["images_per_sec"], "unit": "images/sec", "cores": best["workers"] * best["threads_each"], "kind": "port",
+                   "deployment": f"{best['workers']} pipeline(s) x {best['threads_each']} torch threads",
+                   "one_pipeline": single, "pipelines_side_by_side": multi,
+                   "parallel": "per pipeline: thread pool over the crops of a page / of a recognition batch (where the reference's rayon pool fans out: "
+                               "processors.rs:113-131, crnn.rs:98-121) + torch-CPU intra-op threads for the networks (channels_last convolutions); "
+                               "contour tracing / unclip serial per page as in the reference",
                    "ort_cpu_standin": ort_note,
-                   "sample": f"{len(sample)} of the same {size}x{size} synthetic pages, det batch 1 / rec batch 16 (reference CPU defaults); "
-                             "oracle = C restatement of pre/post + torch-CPU fp32 network; the reference's own "
+                   "why_not_29": "stage_ms_per_page: the two networks are > 90 % of a page on the CPU and run in the torch eager interpreter (one ATen call per ONNX node, "
+                                 "no graph fusion, oneDNN depthwise kernels); ONNX Runtime's fused graph on the published i9-13900KF is what reaches 34 ms/image",
+                   "sample": f"{best['pages']} {size}x{size} synthetic pages (same generator as the GPU workload), one predict per page, det batch 1 / rec batch 16 "
+                             "(reference CPU defaults); oracle = C restatement of pre/post + torch-CPU fp32 network; the reference's own "
                              "published CPU figure is 34 ms/image (docs/FAQ.md:22, i9-13900KF, real weights)"}
         line = {
             "metric": "images/sec end-to-end PP-OCRv6 det+rec", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
