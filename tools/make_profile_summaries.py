@@ -25,7 +25,7 @@ txt = subprocess.run([sys.executable, "tools/pmc_summary.py", str(src), "40"], c
 (out / f"{tag}_pmc_summary.txt").write_text(txt)
 
 def klass(name):   # kernel name -> profiler class used by the in-library profiler / bench.py
-    for k in ("dsblock", "conv_igemm_ws_x6", "conv_igemm_ws", "conv_igemm", "conv_dw", "conv_smallcin", "softmax_argmax", "rec_pack", "global_avgpool", "binary", "resize", "copy2d", "normalize", "gemm_batched", "permute"):
+    for k in ("dsblock_cs", "dsblock", "conv_igemm_ws_x6", "conv_igemm_ws", "conv_igemm", "conv_dw", "conv_smallcin", "softmax_argmax", "rec_pack", "global_avgpool", "binary", "resize", "copy2d", "normalize", "gemm_batched", "permute"):
         if k in name:
             return k
     return None
