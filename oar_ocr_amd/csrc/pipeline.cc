@@ -197,8 +197,19 @@ Detector::Detector(const uint8_t* onnx, size_t len, const oar_det_cfg& cfg) : cf
     eng_.reset(new Engine(onnx, len, cfg_.device_id));
     pool_.reset(new ThreadPool(cfg_.host_threads));
     OAR_HIP(hipSetDevice(eng_->device()));
-    OAR_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
-    OAR_HIP(hipStreamCreateWithFlags(&score_stream_, hipStreamNonBlocking));
+    // OAR_CONTOUR_CUS=n (experiment): the streams that carry the border follower / unclip / box scores are confined to n CUs spread over
+    // the XCDs (hipExtStreamCreateWithCUMask).  The network's stream keeps all CUs -- its persistent kernels are sized for 256 -- so this reserves nothing;
+    // measured in profiles/r4/gpu_contours_cu_mask.txt
+    static const int contour_cus = [] { const char* e = getenv("OAR_CONTOUR_CUS"); return e ? atoi(e) : 0; }();
+    if (contour_cus > 0 && contour_cus <= 256) {
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < contour_cus; ++i) { const int cu = (int)((long)i * 256 / contour_cus); mask[cu >> 5] |= 1u << (cu & 31); }
+        OAR_HIP(hipExtStreamCreateWithCUMask(&copy_stream_, 8, mask));
+        OAR_HIP(hipExtStreamCreateWithCUMask(&score_stream_, 8, mask));
+    } else {
+        OAR_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+        OAR_HIP(hipStreamCreateWithFlags(&score_stream_, hipStreamNonBlocking));
+    }
     OAR_HIP(hipStreamCreateWithFlags(&upload_stream_, hipStreamNonBlocking));
     OAR_HIP(hipEventCreateWithFlags(&stage_free_, hipEventDisableTiming));
 }
