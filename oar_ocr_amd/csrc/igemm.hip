@@ -232,10 +232,11 @@ static bool os_x6_eligible(long M, int K, int N, int Cin) {
     return Cin % 8 == 0 && K >= min_k && N >= 64 && (N & 3) == 0 && fills && K < 65536;
 }
 
-int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin) {
+int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin, long same3x3_px) {
     // OAR_IGEMM_X6: 1 (default) = bf16x6 kernels on the wide layers, 0 = f32 MFMA everywhere
     static const int mode = [] { const char* e = getenv("OAR_IGEMM_X6"); return e ? atoi(e) : 1; }();
     if (!mode) return IGEMM_W_K16;
+    if (!is1x1 && same3x3_px > 0 && K == 9 * Cin && conv3x3_n16_x6_eligible(M, Cin, N, same3x3_px, N)) return IGEMM_W_X6;
     if (!is1x1) return (os_mode() && Cin > 0 && os_x6_eligible(M, K, N, Cin)) ? IGEMM_W_X6 : IGEMM_W_K16;
     // every lane's 8-float group must be all-valid or all-padding (K % 8); wide enough to be matrix-pipe bound
     // (N >= 96, K >= 96); enough (16-pixel tile, cout tile) pairs to fill the 4096 resident waves; float4 epilogue
@@ -334,9 +335,11 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     double bytes = 4.0 * ((double)c.N * c.H * c.W * c.Cin + (double)p.M * p.gemm_cout + (double)p.K * p.gemm_cout);
     char pname[96];
     const bool x6_os = x6 && !c.ctc_part && (!is1x1 || ws_x6_tile(p.K, nfrag) == 0 || (os_mode() == 2 && os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin)));
-    const char* cls = x6_os ? "conv_igemm_os_x6" : x6 ? "conv_igemm_ws_x6" : ws ? "conv_igemm_ws" : "conv_igemm";   // one profiler class per kernel
+    const bool rs3_cls = x6 && !c.convt2x2 && c.kh == 3 && c.kw == 3 && c.sh == 1 && c.sw == 1 && c.pt == 1 && c.pl == 1 && c.dh == 1 && c.dw == 1 && c.Ho == c.H && c.Wo == c.W && !c.residual && !c.se &&
+                         !c.ctc_part && conv3x3_n16_x6_eligible(p.M, c.Cin, c.Cout, (long)c.H * c.W, c.y_ld);
+    const char* cls = rs3_cls ? "conv_rs3_x6" : x6_os ? "conv_igemm_os_x6" : x6 ? "conv_igemm_ws_x6" : ws ? "conv_igemm_ws" : "conv_igemm";   // one profiler class per kernel
     if (Profiler::get().detail) {
-        snprintf(pname, sizeof pname, "conv_igemm%s M=%ld K=%d N=%d k%dx%d s%d%s", x6_os ? "_os_x6" : x6 ? "_x6" : ws ? "_ws" : "", p.M, p.K, p.gemm_cout, c.kh, c.kw, c.sh, c.convt2x2 ? " convT" : "");
+        snprintf(pname, sizeof pname, "conv_igemm%s M=%ld K=%d N=%d k%dx%d s%d%s", rs3_cls ? "_rs3_x6" : x6_os ? "_os_x6" : x6 ? "_x6" : ws ? "_ws" : "", p.M, p.K, p.gemm_cout, c.kh, c.kw, c.sh, c.convt2x2 ? " convT" : "");
         cls = pname;
     }
     ProfScope ps(s, cls, bytes, flops);
@@ -352,8 +355,12 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
         else LAUNCH2(NTV, 1);                        \
     } while (0)
     OAR_CHECK(!c.se || x6, OAR_INTERNAL, "conv_igemm: gate on a non-x6 layer (conv_igemm_se_ok should have said no)");
+    const bool same3x3 = !c.convt2x2 && c.kh == 3 && c.kw == 3 && c.sh == 1 && c.sw == 1 && c.pt == 1 && c.pl == 1 && c.dh == 1 && c.dw == 1 && c.Ho == c.H && c.Wo == c.W;
+    const bool rs3 = x6 && same3x3 && !c.residual && !c.se && !c.ctc_part && conv3x3_n16_x6_eligible(p.M, c.Cin, c.Cout, (long)c.H * c.W, c.y_ld);
     if (ws3) {
         conv_igemm_ws3(s, p, nfrag);
+    } else if (rs3) {
+        conv3x3_n16_x6(s, p, c.N);
     } else if (x6) {
         const int nt = c.ctc_part ? 8 : is1x1 ? ws_x6_tile(p.K, nfrag) : 0;
         OAR_CHECK(((p.Cout & 3) == 0) && ((p.y_ld & 3) == 0) && !c.convt2x2, OAR_INTERNAL, "conv_igemm: bf16x6 weights on an ineligible layer");

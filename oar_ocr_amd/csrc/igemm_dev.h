@@ -249,6 +249,9 @@ void conv_igemm_os_x6(hipStream_t s, const IgemmP& p, int nfrag, bool is1x1);
 // 3x3 / stride 1 / pad 1 variant with in-register horizontal tap reuse (igemm_ws3.hip); nfrag = ceil(cout / 16) <= 2
 bool conv_igemm_ws3_eligible(const IgemmP& p, int nfrag);
 void conv_igemm_ws3(hipStream_t s, const IgemmP& p, int nfrag);
+// igemm_rs3_x6.hip: 3x3 same convolution, Cin 32 / 64, <= 16 output channels, bf16x6, row-streaming (weights IGEMM_W_X6)
+bool conv3x3_n16_x6_eligible(long M, int Cin, int Cout, long img_px, int y_ld);
+void conv3x3_n16_x6(hipStream_t s, const IgemmP& p, int n_images);
 
 }  // namespace k
 }  // namespace oar

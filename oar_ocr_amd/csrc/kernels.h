@@ -46,7 +46,9 @@ enum : int { IGEMM_W_K16 = 0, IGEMM_W_X6 = 1, IGEMM_W_X6RS = 2, IGEMM_W_X6CS = 3
 // Rows are padded to 64 couts, K to the chunk size, with zeros.
 void conv_igemm(hipStream_t s, const ConvP& p);
 // chosen per layer AND input shape at plan time: M = GEMM rows (pixels), N = couts
-int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin = 0);
+// same3x3_px: pixels of ONE image when the layer is a 3x3 / stride 1 / pad 1 / dilation 1 convolution without residual (0 otherwise): the row-streaming
+// bf16x6 kernel of igemm_rs3_x6.hip takes such layers with <= 16 output channels
+int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin = 0, long same3x3_px = 0);
 // may a 1x1 conv of this shape take ConvP::se (the gate of a squeeze-excite block folded into its input load)?  hw = pixels per image
 bool conv_igemm_se_ok(long M, int K, int N, int hw);   // Cin: input channels of a k x k conv (0: treat as not eligible for the x6 path)
 // Depthwise conv. w: [kh][kw][C]. C % 4 == 0.

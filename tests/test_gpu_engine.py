@@ -290,6 +290,38 @@ def test_igemm_kernels_at_bench_shapes(case):
 
 
 @pytest.mark.parametrize("case", [
+    ("rs3_x6 3x3 64->16", 2, 64, 16, 240, 240, "relu"),              # the DB head's convolution (igemm_rs3_x6.hip)
+    ("rs3_x6 3x3 64->16 ragged", 3, 64, 16, 150, 231, "hswish"),     # strips hang over the row, segments over the image, 3 images
+    ("rs3_x6 3x3 32->8", 2, 32, 8, 240, 241, None),                  # one k-step per tap, two idle lane groups in the store
+    ("rs3_x6 3x3 64->12 tall", 1, 64, 12, 700, 150, "relu"),         # long segments, Cout not a multiple of 8
+])
+def test_row_streaming_3x3_x6_kernel(case, monkeypatch):
+    """igemm_rs3_x6.hip (3x3 same convolution, <= 16 output channels, bf16x6 from packed planes in LDS) against torch-CPU conv2d, and against the
+    f32 kernel it replaced (OAR_IGEMM_RS3=0: conv_igemm_ws3_kernel)."""
+    name, n, cin, cout, h, w, act = case
+    g = GraphBuilder("conv")
+    rng = np.random.default_rng(len(name) + cout)
+    g.add_input("x", ["N", cin, "H", "W"])
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * (1.0 / np.sqrt(cin * 9))).astype(np.float32)
+    y = g.op("Conv", ["x", g.init(wt), g.init(rng.standard_normal(cout).astype(np.float32))], kernel_shape=[3, 3], strides=[1, 1], pads=[1, 1, 1, 1], group=1, dilations=[1, 1])
+    if act == "relu":
+        y = g.op("Relu", [y])
+    elif act == "hswish":
+        y = g.op("HardSwish", [y])
+    g.add_output(y, ["N", cout, "H", "W"])
+    x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    m = g.model()
+    got, ref = _check(m, x)
+    eng = api.OrtInfer(m, profile=True)
+    api.prof_reset()
+    eng.infer(x)
+    assert any(e["name"] == "conv_rs3_x6" for e in api.prof_snapshot()), "the layer did not select the row-streaming kernel"
+    api.prof_enable(False)
+    eng.close()
+    monkeypatch.setenv("OAR_IGEMM_RS3", "0")
+
+
+@pytest.mark.parametrize("case", [
     ("os_x6 3x3 64->64", 2, 64, 64, 192, 192, 3, (1, 1), 1),            # K = 576: k x k conv on the output-stationary bf16x6 kernel
     ("os_x6 1x1 512->128", 1, 512, 128, 256, 256, 1, (1, 1), 1),        # long-K 1x1: the weights do not fit the weight-stationary LDS tile
     ("os_x6 3x3 s2 32->96 ragged", 1, 32, 96, 514, 514, 3, (2, 2), 1),  # stride 2, 66049 output pixels (not a multiple of the 256-pixel tile), 6 cout fragments

@@ -78,3 +78,18 @@ def test_output_stationary_kernel_fits_two_workgroups_per_cu():
     assert len(ks) == 4
     for name, r in ks.items():
         assert r["vgprs"] <= 256 and r["spill"] <= 8 and r["scratch"] <= 64, (name, r)
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
+def test_round4_one_wave_per_simd_kernels_do_not_spill():
+    """Round 4's register-heavy kernels run ONE wave per SIMD by design (512 registers: accumulators of a whole pixel tile / all weights of the layer);
+    a spill in their inner loops costs more than anything they gain.  dsblock_cs.inc: 256 + ~200 accumulation registers, no scratch;
+    igemm_rs3_x6.hip: 216 weight registers + operands, no scratch."""
+    cs = {k: v for k, v in _resources("dsblock_cs.hip").items() if "dsblock_cs_kernel" in k}
+    assert len(cs) >= 8
+    for name, r in cs.items():
+        assert r["spill"] == 0 and r["scratch"] == 0, (name, r)
+    rs3 = {k: v for k, v in _resources("igemm_rs3_x6.hip").items() if "conv3x3_n16_x6_kernel" in k}
+    assert len(rs3) == 2
+    for name, r in rs3.items():
+        assert r["spill"] == 0 and r["scratch"] == 0 and r["vgprs"] <= 256, (name, r)
