@@ -8,8 +8,8 @@
 //     PACKED bf16 PLANES ([plane h / m / l][pixel][channel], 144 B per pixel so that the 16 pixels of a 16-byte-per-lane read hit distinct banks):
 //     a new input row is loaded f32 (buffer loads: pixels / rows outside the image read as zeros), split, written to the slot of the row that died;
 //   * the B operand of tap (kh, kw), channel chunk c, piece p is then ONE ds_read_b128 at (row kh, pixel n + kw): the column shift is an address;
-//   * the weights (K = 9 Cin: 18 k-steps x 3 pieces x 16 B per lane at Cin = 64) stay in REGISTERS for the whole launch -- 216 VGPRs, one wave
-//     per SIMD, nothing shared between waves, no barrier;
+//   * the weights' h and m pieces (K = 9 Cin: 18 k-steps x 2 pieces x 16 B per lane at Cin = 64) stay in REGISTERS for the whole launch -- 144
+//     VGPRs, one wave per SIMD; the l pieces sit in an 18 KB LDS table; no barrier after the table is filled;
 //   * six accumulators, one per product class (mm, lh, hl, mh, hm, hh): consecutive MFMAs never depend on each other, and the classes are added
 //     smallest first at the end.
 // Work item = (image, segment of R rows, strip), dealt in XCD bands as dsblock_rs.inc does.  Algorithmic bytes: 4 (M Cin + M Cout).
@@ -57,14 +57,20 @@ __global__ __launch_bounds__(kR3Waves * 64, 1) void conv3x3_n16_x6_kernel(Rs3P p
     const unsigned ring0 = (unsigned)(wave * 3 * kR3RowB);
 
     // ---- this lane's weight pieces: A operands of all 9 * CC32 k-steps (IGEMM_W_X6: [kc][piece][lane] 16 bytes)
-    r3_u32x4 wreg[KC][3];
+    // (the h and m pieces: 144 registers at Cin = 64.  With the l pieces as well the kernel needed more than the 256 registers vector instructions
+    // can address and shuttled weights through accumulation registers before every MFMA; the l piece feeds one product in six and is read from an
+    // LDS table shared by the four waves instead)
+    r3_u32x4 wreg[KC][2];
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
+        for (int s = 0; s < 2; ++s) {
             const float4 v = p.w[(kc * 3 + s) * 64 + lane];
             wreg[kc][s] = (r3_u32x4){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
         }
+    constexpr unsigned kWl = (unsigned)(kR3Waves * 3 * kR3RowB);   // [kc][lane] 16 bytes, behind the rings
+    for (int i = tid; i < KC * 64; i += kR3Waves * 64) r3_lds[(kWl >> 4) + i] = p.w[((i >> 6) * 3 + 2) * 64 + (i & 63)];
+    __syncthreads();
     const float4 bq = (p.bias && g * 4 < p.Cout) ? *reinterpret_cast<const float4*>(p.bias + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 
     const int xcd = (int)(blockIdx.x & 7), wgx = (int)(blockIdx.x >> 3), wgs = (int)(gridDim.x >> 3);
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 1) void conv3x3_n16_x6_kernel(Rs3P p
             dst[u] = q < NU ? (unsigned)(px * kR3PxB + cq * 8) : 0xFFFFFFFFu;
         }
         r3_u32x4 in[NJ];
-        auto load_row = [&](int y) __attribute__((always_inline)) {
+        auto load_row = [&](int y, r3_u32x4 (&in)[NJ]) __attribute__((always_inline)) {
             const bool rok = (unsigned)y < (unsigned)p.H;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ximg, 0, rok ? (int)p.img_bytes : 0, 0x00020000);
             const int so = rok ? y * row_bytes : 0;
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 1) void conv3x3_n16_x6_kernel(Rs3P p
             for (int u = 0; u < NJ; ++u) in[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)src[u], so, 0);
         };
         // exact three-way bf16 split of the loaded quads -> the three planes of ring slot `slot`
-        auto put_row = [&](unsigned slot) __attribute__((always_inline)) {
+        auto put_row = [&](unsigned slot, const r3_u32x4 (&in)[NJ]) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < NJ; ++u) {
                 unsigned hb[4], mb[4], lb[4];
@@ -119,10 +125,14 @@ __global__ __launch_bounds__(kR3Waves * 64, 1) void conv3x3_n16_x6_kernel(Rs3P p
             }
         };
         // ---- warm-up: input rows o_begin - 1, o_begin, o_begin + 1 into slots 0, 1, 2
-#pragma unroll 1
-        for (int k = 0; k < 3; ++k) {
-            load_row(o_begin - 1 + k);
-            put_row(ring0 + (unsigned)(k * kR3RowB));
+        {   // (the three rows are requested together: one memory latency per item, not three)
+            r3_u32x4 in1[NJ], in2[NJ];
+            load_row(o_begin - 1, in);
+            load_row(o_begin, in1);
+            load_row(o_begin + 1, in2);
+            put_row(ring0, in);
+            put_row(ring0 + (unsigned)kR3RowB, in1);
+            put_row(ring0 + (unsigned)(2 * kR3RowB), in2);
         }
         int s0 = 0;   // ring slot of the row above the output row
         const int ox = tx * 16 + n;
@@ -130,7 +140,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 1) void conv3x3_n16_x6_kernel(Rs3P p
         unsigned st_row = (unsigned)((img * p.H + o_begin) * orow_bytes);
 #pragma unroll 1
         for (int r = o_begin; r < o_end; ++r) {
-            load_row(r + 2);                                   // lands while this row is multiplied
+            load_row(r + 2, in);                               // lands while this row is multiplied
             f32x4 acc[6];                                      // one accumulator per product class: six independent MFMA chains
             acc[5] = (f32x4){bq.x, bq.y, bq.z, bq.w};
             acc[0] = acc[1] = acc[2] = acc[3] = acc[4] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -138,24 +148,26 @@ __global__ __launch_bounds__(kR3Waves * 64, 1) void conv3x3_n16_x6_kernel(Rs3P p
             unsigned slot_of[3];
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) slot_of[kh] = (unsigned)((s0 + kh >= 3 ? s0 + kh - 3 : s0 + kh) * kR3RowB);
-            // k-step kc = (kh, kw, c): its three pieces are read while k-step kc - 1 is multiplied; the reads of kc + 1 are ordered behind the DATA of
-            // kc - 1 (an empty asm, not volatile: a dependence, not a scheduling barrier), so at most two k-steps of operands are ever in flight
-            r3_u32x4 xs[2][3];
-            auto fetch = [&](int kc, r3_u32x4 (&dstv)[3]) __attribute__((always_inline)) {
+            // k-step kc = (kh, kw, c): its three pieces are read two k-steps ahead; the reads of kc + 3 are ordered behind the DATA of kc (an empty asm,
+            // not volatile: a dependence, not a scheduling barrier), so at most three k-steps of operands are ever in flight
+            r3_u32x4 xs[3][4];   // x pieces h, m, l and the weights' l piece
+            auto fetch = [&](int kc, r3_u32x4 (&dstv)[4]) __attribute__((always_inline)) {
                 const int kh = kc / (3 * CC32), kw = (kc / CC32) % 3, c = kc % CC32;
 #pragma unroll
                 for (int s_ = 0; s_ < 3; ++s_) dstv[s_] = r3_lds4(rd + slot_of[kh] + (unsigned)(s_ * kR3PlB + kw * kR3PxB + c * 64));
+                dstv[3] = r3_lds4(rd - rd_lane - ring0 + kWl + (unsigned)(kc * 1024 + lane * 16));
             };
             fetch(0, xs[0]);
+            fetch(1, xs[1]);
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
-                if (kc + 1 < KC) fetch(kc + 1, xs[(kc + 1) & 1]);
+                if (kc + 2 < KC) fetch(kc + 2, xs[(kc + 2) % 3]);
                 // six products, smallest first: (w piece, x piece) = mm, lh, hl, mh, hm, hh
                 constexpr int WPL[6] = {1, 2, 0, 1, 0, 0}, XPL[6] = {1, 0, 2, 0, 1, 0};
 #pragma unroll
                 for (int t = 0; t < 6; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(r3_bf16x8, wreg[kc][WPL[t]]), __builtin_bit_cast(r3_bf16x8, xs[kc & 1][XPL[t]]), acc[t], 0, 0, 0);
-                asm("" : "+v"(rd) : "v"(xs[kc & 1][2]));
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(r3_bf16x8, WPL[t] == 2 ? xs[kc % 3][3] : wreg[kc][WPL[t] == 2 ? 0 : WPL[t]]), __builtin_bit_cast(r3_bf16x8, xs[kc % 3][XPL[t]]), acc[t], 0, 0, 0);
+                asm("" : "+v"(rd) : "v"(xs[kc % 3][2]));
             }
             f32x4 o = ((((acc[0] + acc[1]) + acc[2]) + acc[3]) + acc[4]) + acc[5];   // smallest classes first
             r3_u32x4 v;
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 1) void conv3x3_n16_x6_kernel(Rs3P p
             for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(apply_act(o[e], p.act, p.alpha, p.beta));
             // every read of the oldest row has returned (its data fed the MFMAs above): its slot takes row r + 2
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            put_row(ring0 + (unsigned)(s0 * kR3RowB));
+            put_row(ring0 + (unsigned)(s0 * kR3RowB), in);
             __builtin_amdgcn_raw_buffer_store_b128(v, ysrc, (int)(st_lane + st_row), 0, 0);
             st_row += (unsigned)orow_bytes;
             s0 = s0 + 1 == 3 ? 0 : s0 + 1;
@@ -196,7 +208,7 @@ void conv3x3_n16_x6(hipStream_t s, const IgemmP& g, int n_images) {
     p.per_xcd = (p.items + 7) / 8;
     p.img_bytes = (unsigned)((long)g.H * g.W * g.Cin * 4);
     p.y_bytes = (unsigned)((long)n_images * g.H * g.W * g.y_ld * 4);
-    const size_t lds = (size_t)kR3Waves * 3 * kR3RowB;
+    const size_t lds = (size_t)kR3Waves * 3 * kR3RowB + (size_t)9 * (g.Cin / 32) * 1024;   // rings + the weights' l pieces
     auto launch = [&](auto kernel) {
         static const bool once = [kernel] { OAR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); return true; }();
         (void)once;
