@@ -44,7 +44,8 @@ __device__ __forceinline__ void r3_lds_w2(unsigned off, r3_u32x2 v) {
 }
 
 // CC32 = Cin / 32 (k-steps per tap)
-template <int CC32>
+// DBG (timing ablations, wrong results; OAR_RS3_DBG): 1 no MFMA, 2 no split / ring writes, 4 no operand reads, 8 no stores, 16 no row loads
+template <int CC32, int DBG = 0>
 __global__ __launch_bounds__(kR3Waves * 64, 1) void conv3x3_n16_x6_kernel(Rs3P p) {
     constexpr int QPP = CC32 * 8;                           // float4 quads per pixel
     constexpr int NU = kR3IW * QPP;                         // quads of one strip row
@@ -100,12 +101,13 @@ __global__ __launch_bounds__(kR3Waves * 64, 1) void conv3x3_n16_x6_kernel(Rs3P p
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ximg, 0, rok ? (int)p.img_bytes : 0, 0x00020000);
             const int so = rok ? y * row_bytes : 0;
 #pragma unroll
-            for (int u = 0; u < NJ; ++u) in[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)src[u], so, 0);
+            for (int u = 0; u < NJ; ++u) in[u] = (DBG & 16) ? (r3_u32x4){(unsigned)y, 1u, 2u, 3u} : __builtin_amdgcn_raw_buffer_load_b128(rs, (int)src[u], so, 0);
         };
         // exact three-way bf16 split of the loaded quads -> the three planes of ring slot `slot`
         auto put_row = [&](unsigned slot, const r3_u32x4 (&in)[NJ]) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < NJ; ++u) {
+                if constexpr ((DBG & 2) != 0) { if (in[u][0] == 0x12345u) r3_lds_w2(slot, (r3_u32x2){in[u][1], in[u][2]}); continue; }
                 unsigned hb[4], mb[4], lb[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -153,6 +155,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 1) void conv3x3_n16_x6_kernel(Rs3P p
             r3_u32x4 xs[3][4];   // x pieces h, m, l and the weights' l piece
             auto fetch = [&](int kc, r3_u32x4 (&dstv)[4]) __attribute__((always_inline)) {
                 const int kh = kc / (3 * CC32), kw = (kc / CC32) % 3, c = kc % CC32;
+                if constexpr ((DBG & 4) != 0) { for (int s_ = 0; s_ < 4; ++s_) dstv[s_] = (r3_u32x4){rd + kc, 1u, 2u, (unsigned)s_}; return; }
 #pragma unroll
                 for (int s_ = 0; s_ < 3; ++s_) dstv[s_] = r3_lds4(rd + slot_of[kh] + (unsigned)(s_ * kR3PlB + kw * kR3PxB + c * 64));
                 dstv[3] = r3_lds4(rd - rd_lane - ring0 + kWl + (unsigned)(kc * 1024 + lane * 16));
@@ -166,7 +169,8 @@ __global__ __launch_bounds__(kR3Waves * 64, 1) void conv3x3_n16_x6_kernel(Rs3P p
                 constexpr int WPL[6] = {1, 2, 0, 1, 0, 0}, XPL[6] = {1, 0, 2, 0, 1, 0};
 #pragma unroll
                 for (int t = 0; t < 6; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(r3_bf16x8, WPL[t] == 2 ? xs[kc % 3][3] : wreg[kc][WPL[t] == 2 ? 0 : WPL[t]]), __builtin_bit_cast(r3_bf16x8, xs[kc % 3][XPL[t]]), acc[t], 0, 0, 0);
+                    if constexpr ((DBG & 1) != 0) acc[t][0] += __uint_as_float(xs[kc % 3][XPL[t]][0] ^ wreg[kc][0][t & 3]);
+                    else acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(r3_bf16x8, WPL[t] == 2 ? xs[kc % 3][3] : wreg[kc][WPL[t] == 2 ? 0 : WPL[t]]), __builtin_bit_cast(r3_bf16x8, xs[kc % 3][XPL[t]]), acc[t], 0, 0, 0);
                 asm("" : "+v"(rd) : "v"(xs[kc % 3][2]));
             }
             f32x4 o = ((((acc[0] + acc[1]) + acc[2]) + acc[3]) + acc[4]) + acc[5];   // smallest classes first
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 1) void conv3x3_n16_x6_kernel(Rs3P p
             // every read of the oldest row has returned (its data fed the MFMAs above): its slot takes row r + 2
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             put_row(ring0 + (unsigned)(s0 * kR3RowB), in);
-            __builtin_amdgcn_raw_buffer_store_b128(v, ysrc, (int)(st_lane + st_row), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(v, ysrc, (int)(((DBG & 8) && v[0] != 0x12345u) ? kR3OobSt : st_lane + st_row), 0, 0);
             st_row += (unsigned)orow_bytes;
             s0 = s0 + 1 == 3 ? 0 : s0 + 1;
         }
@@ -214,6 +218,21 @@ void conv3x3_n16_x6(hipStream_t s, const IgemmP& g, int n_images) {
         (void)once;
         hipLaunchKernelGGL(kernel, dim3(256), dim3(kR3Waves * 64), lds, s, p);
     };
+    static const int dbg = [] { const char* e = getenv("OAR_RS3_DBG"); return e ? atoi(e) : 0; }();
+    if (dbg && g.Cin == 64) {
+        switch (dbg) {
+            case 1: launch(conv3x3_n16_x6_kernel<2, 1>); return;
+            case 2: launch(conv3x3_n16_x6_kernel<2, 2>); return;
+            case 4: launch(conv3x3_n16_x6_kernel<2, 4>); return;
+            case 8: launch(conv3x3_n16_x6_kernel<2, 8>); return;
+            case 16: launch(conv3x3_n16_x6_kernel<2, 16>); return;
+            case 24: launch(conv3x3_n16_x6_kernel<2, 24>); return;
+            case 26: launch(conv3x3_n16_x6_kernel<2, 26>); return;
+            case 27: launch(conv3x3_n16_x6_kernel<2, 27>); return;
+            case 31: launch(conv3x3_n16_x6_kernel<2, 31>); return;
+            default: break;
+        }
+    }
     if (g.Cin == 64) launch(conv3x3_n16_x6_kernel<2>);
     else launch(conv3x3_n16_x6_kernel<1>);
 }
