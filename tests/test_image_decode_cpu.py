@@ -144,8 +144,8 @@ def test_damaged_files_are_image_load_errors_not_pixels():
 
 
 def test_formats_of_the_image_crate_that_are_not_decoded_here_say_so():
-    for name, head in (("BMP", b"BM" + b"\0" * 30), ("GIF", b"GIF89a" + b"\0" * 20), ("WebP", b"RIFF\0\0\0\0WEBPVP8 "),
-                       ("TIFF", b"II*\0" + b"\0" * 20), ("PNM", b"P6\n1 1\n255\n\0\0\0")):
+    for name, head in (("WebP", b"RIFF\0\0\0\0WEBPVP8 "), ("TIFF", b"II*\0" + b"\0" * 20), ("PNM", b"P7\nWIDTH 1\nHEIGHT 1\nDEPTH 3\nMAXVAL 255\nENDHDR\n\0\0\0"),
+                       ("PNM", b"P6\n1 1\n1023\n\0\0\0\0\0\0"), ("BMP", b"BM" + struct.pack("<IHHI", 70, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, 2, 2, 1, 24, 4, 16, 0, 0, 0, 0) + b"\0" * 16)):
         with pytest.raises(api.OCRError) as e:
             api.load_image_from_memory(head)
         assert e.value.code == api.OAR_UNSUPPORTED_OP and name in e.value.message
@@ -353,3 +353,122 @@ def test_load_images_mixed_png_and_jpeg(tmp_path):
     for thr in (100, 2):
         got = api.load_images(paths, parallel_threshold=thr)
         assert all(np.array_equal(g, w) for g, w in zip(got, want))
+
+
+def _pil():
+    return pytest.importorskip("PIL.Image")
+
+
+def test_bmp_pnm_gif_equal_pil_on_files_pil_wrote():
+    """The small formats of image_misc_decode.cc (round 4) against PIL's decoder on files PIL encoded: BMP 1 / 8 (palette) / 24 / 32 bits, binary PNM
+    (P4 / P5 / P6), GIF with global palettes (interlaced too) -- every pixel equal to Image.open(...).convert("RGB")."""
+    import io
+    Image = _pil()
+    rng = np.random.default_rng(5)
+    cases = []
+    for (h, w) in ((1, 1), (7, 13), (33, 64), (50, 31)):
+        rgbx = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        grey = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        pal = Image.fromarray(rgbx).quantize(colors=min(256, max(2, h * w)))
+        bits = Image.fromarray((grey > 127).astype(np.uint8) * 255).convert("1")
+        rgba = Image.fromarray(np.concatenate([rgbx, grey[..., None]], -1), "RGBA")
+        cases += [("BMP", Image.fromarray(rgbx), {}), ("BMP", Image.fromarray(grey), {}), ("BMP", pal, {}), ("BMP", bits, {}), ("BMP", rgba, {}),
+                  ("PPM", Image.fromarray(rgbx), {}), ("PPM", Image.fromarray(grey), {}), ("PPM", bits, {}),
+                  ("GIF", pal, {}), ("GIF", Image.fromarray(grey), {}), ("GIF", pal, {"interlace": True}), ("GIF", bits, {})]
+    for fmt, im, kw in cases:
+        buf = io.BytesIO()
+        im.save(buf, format=fmt, **kw)
+        data = buf.getvalue()
+        want = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+        got = api.load_image_from_memory(data)
+        assert got.shape == want.shape and np.array_equal(got, want), (fmt, im.mode, im.size, kw)
+
+
+def test_bmp_variants_pil_cannot_write():
+    """Hand-built BMP files: 16-bit 5-5-5 and 5-6-5 (BI_BITFIELDS), top-down 24-bit, 4-bit palette, OS/2 core header, RLE8 with every escape --
+    against PIL's decoder where PIL reads the variant, else against the pixels the file was built from."""
+    import io
+    Image = _pil()
+    rng = np.random.default_rng(6)
+    h, w = 5, 7
+
+    def bmp(info, body, palette=b""):
+        off = 14 + len(info) + len(palette)
+        return b"BM" + struct.pack("<IHHI", off + len(body), 0, 0, off) + info + palette + body
+
+    def rows(arr, bpp_bytes):   # bottom-up rows padded to 4 bytes
+        out = b""
+        for y in range(arr.shape[0] - 1, -1, -1):
+            r = arr[y].tobytes()
+            out += r + b"\0" * (-len(r) % 4)
+        return out
+    px = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    # 5-5-5 (BI_RGB) and 5-6-5 (BI_BITFIELDS)
+    for masks, comp in (((0x7C00, 0x03E0, 0x001F), 0), ((0xF800, 0x07E0, 0x001F), 3)):
+        bits = [bin(m).count("1") for m in masks]
+        shifts = [(m & -m).bit_length() - 1 for m in masks]
+        q = [(px[..., c].astype(np.uint32) >> (8 - bits[c])) for c in range(3)]
+        v = ((q[0] << shifts[0]) | (q[1] << shifts[1]) | (q[2] << shifts[2])).astype("<u2")
+        info = struct.pack("<IiiHHIIiiII", 40, w, h, 1, 16, comp, 0, 0, 0, 0, 0) + (struct.pack("<III", *masks) if comp == 3 else b"")
+        data = bmp(info, rows(v, 2))
+        want = np.stack([np.round(q[c] * 255.0 / ((1 << bits[c]) - 1)).astype(np.uint8) for c in range(3)], -1)
+        got = api.load_image_from_memory(data)
+        assert np.array_equal(got, want), masks
+        assert np.abs(got.astype(int) - np.asarray(Image.open(io.BytesIO(data)).convert("RGB")).astype(int)).max() <= 1   # (PIL widens by bit replication)
+    # top-down 24-bit
+    info = struct.pack("<IiiHHIIiiII", 40, w, -h, 1, 24, 0, 0, 0, 0, 0, 0)
+    body = b"".join(px[y, :, ::-1].tobytes() + b"\0" * (-3 * w % 4) for y in range(h))
+    data = bmp(info, body)
+    assert np.array_equal(api.load_image_from_memory(data), px) and np.array_equal(np.asarray(Image.open(io.BytesIO(data)).convert("RGB")), px)
+    # 4-bit palette, OS/2 core header (3-byte palette entries)
+    palette = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+    idx = rng.integers(0, 16, (h, w), dtype=np.uint8)
+    packed = b""
+    for y in range(h - 1, -1, -1):
+        r = bytearray((w + 1) // 2)
+        for x in range(w):
+            r[x // 2] |= int(idx[y, x]) << (4 if x % 2 == 0 else 0)
+        packed += bytes(r) + b"\0" * (-len(r) % 4)
+    for core in (False, True):
+        info = struct.pack("<IHHHH", 12, w, h, 1, 4) if core else struct.pack("<IiiHHIIiiII", 40, w, h, 1, 4, 0, 0, 0, 0, 16, 0)
+        pal_bytes = b"".join(bytes(c[::-1]) + (b"" if core else b"\0") for c in palette)
+        data = bmp(info, packed, pal_bytes)
+        want = palette[idx]
+        assert np.array_equal(api.load_image_from_memory(data), want), core
+        assert np.array_equal(np.asarray(Image.open(io.BytesIO(data)).convert("RGB")), want)
+    # RLE8: encoded runs, an absolute run (odd length: padded), a delta, end of line, end of bitmap before the last rows (left at palette entry 0 ... black)
+    palette = rng.integers(0, 256, (256, 3), dtype=np.uint8)
+    palette[0] = 0
+    want_idx = np.zeros((4, 8), np.uint8)
+    stream = bytearray()
+    stream += bytes([3, 9, 0, 3, 5, 6, 7, 0, 2, 11, 0, 0]); want_idx[3] = [9, 9, 9, 5, 6, 7, 11, 11]     # file row 0 = image row 3
+    stream += bytes([0, 2, 2, 1, 4, 200, 0, 0]); want_idx[1, 2:6] = 200                                     # delta (+2, +1) from the start of file row 1 -> row 2
+    stream += bytes([8, 77, 0, 1]); want_idx[0] = 77
+    info = struct.pack("<IiiHHIIiiII", 40, 8, 4, 1, 8, 1, len(stream), 0, 0, 256, 0)
+    data = bmp(info, bytes(stream), b"".join(bytes(c[::-1]) + b"\0" for c in palette))
+    got = api.load_image_from_memory(data)
+    assert np.array_equal(got, palette[want_idx])
+    assert np.array_equal(np.asarray(Image.open(io.BytesIO(data)).convert("RGB")), got)
+
+
+def test_ascii_pnm_and_gif_frame_inside_the_screen():
+    import io
+    Image = _pil()
+    assert np.array_equal(api.load_image_from_memory(b"P3\n# a comment\n2 2\n255\n255 0 0  0 255 0\n0 0 255  9 8 7\n"), np.array([[[255, 0, 0], [0, 255, 0]], [[0, 0, 255], [9, 8, 7]]], np.uint8))
+    assert np.array_equal(api.load_image_from_memory(b"P2 3 1 255 0 128 255"), np.array([[[0] * 3, [128] * 3, [255] * 3]], np.uint8))
+    assert np.array_equal(api.load_image_from_memory(b"P1\n4 1\n1001"), np.array([[[0] * 3, [255] * 3, [255] * 3, [0] * 3]], np.uint8))
+    # a GIF whose first frame covers only part of the logical screen: the rest is the transparent canvas -> black after to_rgb8
+    frame = Image.fromarray(np.random.default_rng(2).integers(0, 256, (3, 4, 3), dtype=np.uint8)).quantize(colors=8)
+    buf = io.BytesIO(); frame.save(buf, format="GIF"); g = bytearray(buf.getvalue())
+    assert struct.unpack("<HH", g[6:10]) == (4, 3)
+    g[6:10] = struct.pack("<HH", 9, 8)                               # logical screen 9 x 8
+    at = g.index(b"\x2c")                                            # image descriptor
+    g[at + 1:at + 5] = struct.pack("<HH", 2, 1)                      # frame at (2, 1)
+    got = api.load_image_from_memory(bytes(g))
+    want = np.zeros((8, 9, 3), np.uint8)
+    want[1:4, 2:6] = np.asarray(frame.convert("RGB"))
+    assert np.array_equal(got, want)
+    for bad in (bytes(g[:at + 12]), b"BM" + struct.pack("<IHHI", 70, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, 4, 4, 1, 24, 0, 0, 0, 0, 0, 0) + b"\0" * 16, b"P6\n2 2\n255\n\0", b"GIF89a" + b"\0" * 20):
+        with pytest.raises(api.OCRError) as e:
+            api.load_image_from_memory(bad)
+        assert e.value.code == api.OAR_INVALID_INPUT, bad[:8]
