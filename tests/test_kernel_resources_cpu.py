@@ -90,6 +90,7 @@ def test_round4_one_wave_per_simd_kernels_do_not_spill():
     for name, r in cs.items():
         assert r["spill"] == 0 and r["scratch"] == 0, (name, r)
     rs3 = {k: v for k, v in _resources("igemm_rs3_x6.hip").items() if "conv3x3_n16_x6_kernel" in k}
+    rs3 = {k: v for k, v in rs3.items() if k.endswith("ELi0EEEvNS0_4Rs3PE")}     # the product instantiations (DBG = 0), not the timing ablations
     assert len(rs3) == 2
     for name, r in rs3.items():
         assert r["spill"] == 0 and r["scratch"] == 0 and r["vgprs"] <= 256, (name, r)
