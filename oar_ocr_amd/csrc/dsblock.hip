@@ -222,7 +222,7 @@ int ds_pick(const DsBlockP& p) {
 }  // namespace
 
 int dsblock_rs_wpw(int sh, int sw, int nch, int nft, int x6) {
-    static const int T[][6] = {{1,1,1,1,0,12},{1,1,1,2,0,12},{1,1,2,2,0,12},{1,1,2,3,0,12},{1,1,2,3,1,12},{1,1,2,4,0,12},{1,1,2,4,1,12},{1,1,3,3,0,12},{1,1,3,3,1,12},{1,1,3,6,0,12},{1,1,3,6,1,12},{1,1,4,4,0,8},{1,1,4,4,1,8},{1,1,4,8,0,8},{1,1,4,8,1,8},{1,1,5,5,0,8},{1,1,5,5,1,8},{1,1,6,6,0,8},{1,1,6,6,1,6},{1,1,2,8,0,12},{2,1,3,6,0,12},{2,1,3,6,1,12},{2,1,2,4,0,12},{2,1,2,4,1,12},{2,1,1,2,0,12},{2,1,4,8,0,8},{2,1,4,8,1,8},{1,2,1,2,0,12},{1,2,2,4,0,12},{1,2,2,4,1,12},{1,2,3,6,0,8},{1,2,3,6,1,8},{1,2,4,8,0,6},{1,2,4,8,1,6},{2,2,2,2,0,12},{2,2,2,4,0,12},{2,2,2,4,1,8},{2,2,4,8,0,4},{2,2,4,8,1,4},{2,2,1,2,0,12},{2,2,3,6,0,6},{2,2,3,6,1,6}};   // generated with the instantiation units (dsblock_rs_k3s*.hip): sh, sw, nch, nft, x6, waves
+    static const int T[][6] = {{1,1,1,1,0,12},{1,1,1,2,0,16},{1,1,2,2,0,12},{1,1,2,3,0,12},{1,1,2,3,1,16},{1,1,2,4,0,12},{1,1,2,4,1,12},{1,1,3,3,0,12},{1,1,3,3,1,12},{1,1,3,6,0,12},{1,1,3,6,1,12},{1,1,4,4,0,8},{1,1,4,4,1,8},{1,1,4,8,0,8},{1,1,4,8,1,8},{1,1,5,5,0,8},{1,1,5,5,1,8},{1,1,6,6,0,8},{1,1,6,6,1,6},{1,1,2,8,0,12},{2,1,3,6,0,12},{2,1,3,6,1,12},{2,1,2,4,0,12},{2,1,2,4,1,12},{2,1,1,2,0,12},{2,1,4,8,0,8},{2,1,4,8,1,8},{1,2,1,2,0,12},{1,2,2,4,0,12},{1,2,2,4,1,12},{1,2,3,6,0,8},{1,2,3,6,1,8},{1,2,4,8,0,6},{1,2,4,8,1,6},{2,2,2,2,0,12},{2,2,2,4,0,12},{2,2,2,4,1,8},{2,2,4,8,0,4},{2,2,4,8,1,4},{2,2,1,2,0,12},{2,2,3,6,0,6},{2,2,3,6,1,6}};   // generated with the instantiation units (dsblock_rs_k3s*.hip): sh, sw, nch, nft, x6, waves
     for (const auto& t : T) if (t[0] == sh && t[1] == sw && t[2] == nch && t[3] == nft && t[4] == x6) return t[5];
     return 0;
 }

@@ -6,10 +6,10 @@ namespace k {
 void dsblock_rs_launch_k3s11(hipStream_t s, const DsRsP& p, int nch, int nft, int x6, int acts, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1) {
     switch (nch * 10000 + nft * 100 + x6 * 10 + acts) {
         OAR_RS_CASE(3, 1, 1, 1, 1, 12, 0)
-        OAR_RS_CASE(3, 1, 1, 1, 2, 12, 0)
+        OAR_RS_CASE(3, 1, 1, 1, 2, 16, 0)
         OAR_RS_CASE(3, 1, 1, 2, 2, 12, 0)
         OAR_RS_CASE(3, 1, 1, 2, 3, 12, 0)
-        OAR_RS_CASE(3, 1, 1, 2, 3, 12, 1)
+        OAR_RS_CASE(3, 1, 1, 2, 3, 16, 1)
         OAR_RS_CASE(3, 1, 1, 2, 4, 12, 0)
         OAR_RS_CASE(3, 1, 1, 2, 4, 12, 1)
         OAR_RS_CASE(3, 1, 1, 3, 3, 12, 0)
