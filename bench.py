@@ -36,7 +36,7 @@ MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA peak; the bf16x6 kernels spend 6 
 
 def mfma_peak_for(kernel):
     """Peak in f32-equivalent TFLOP/s (2*M*K*N per product) of the matrix pipe the kernel class runs on."""
-    return (MFMA_BF16_PEAK_TF / 6.0, "bf16 dense peak / 6 (three-way split, six MFMAs per product)") if ("_x6" in kernel or kernel == "dsblock_cs") else (MFMA_F32_PEAK_TF, "f32-input MFMA dense peak")
+    return (MFMA_BF16_PEAK_TF / 6.0, "bf16 dense peak / 6 (three-way split, six MFMAs per product)") if ("_x6" in kernel or kernel.startswith("dsblock")) else (MFMA_F32_PEAK_TF, "f32-input MFMA dense peak")
 
 
 def parse_args(argv=None):

@@ -205,7 +205,7 @@ void dsblock_cs(hipStream_t s, const DsBlockP& b, const CsShape& sh) {
     const double bytes = 4.0 * (px_in * b.C + px_out * b.Cout) + 4.0 * b.ks * b.ks * b.C + 6.0 * b.C * b.Cout;
     const double flops = 2.0 * px_out * b.C * (b.ks * b.ks + (double)b.Cout);
     char pname[96];
-    const char* cls = "dsblock_cs";   // its own profiler class: bounded by its matrix + vector instruction streams, not by HBM like the row-streaming kernels
+    const char* cls = "dsblock";   // one profiler class for every fused separable-block kernel (rocprofv3 groups them by the dsblock* prefix too); per-kernel figures: DESIGN 4.13 / 4.14
     if (Profiler::get().detail) { snprintf(pname, sizeof pname, "dsblock px=%ld C=%d N=%d k%d s%dx%d cs", (long)px_out, b.C, b.Cout, b.ks, b.sh, b.sw); cls = pname; }
     ProfScope ps(s, cls, bytes, flops, true);
     dsblock_cs_launch(s, p, b.ks, b.sh, b.sw, sh.nch, sh.nf, sh.acts, sh.grid, sh.lds, ps.start(), ps.stop());
