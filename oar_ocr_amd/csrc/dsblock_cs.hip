@@ -6,7 +6,7 @@ namespace k {
 
 namespace {
 struct CsInst { int ks, sh, sw, nch, nft; };
-constexpr CsInst kInst[] = {{5, 1, 1, 12, 12}, {3, 1, 2, 6, 12}, {3, 1, 1, 6, 6}, {5, 1, 1, 8, 8}};
+constexpr CsInst kInst[] = {{5, 1, 1, 12, 12}, {3, 1, 2, 6, 12}, {3, 1, 1, 6, 6}, {5, 1, 1, 8, 8}, {3, 1, 1, 8, 8}};
 constexpr size_t block_bytes(int ks, int nft) { return (size_t)(((ks * ks + 1) * 64 + 1023) / 1024 * 1024 + (nft * 1536 + 1023) / 1024 * 1024); }
 constexpr size_t lds_bytes(int ks, int sh, int sw, int nft) {
     const int iw = 15 * sw + ks, ir = (kCsRows - 1) * sh + ks, nj = (ir * iw * 4 + 63) / 64;
@@ -46,6 +46,7 @@ void dsblock_cs_launch(hipStream_t s, const DsCsP& p, int ks, int sh, int sw, in
     OAR_CS_CASE(3, 1, 2, 6, 12)
     OAR_CS_CASE(3, 1, 1, 6, 6)
     OAR_CS_CASE(5, 1, 1, 8, 8)
+    OAR_CS_CASE(3, 1, 1, 8, 8)
     ::oar::fail(OAR_INTERNAL, "dsblock_cs: no kernel for this shape");
 }
 }  // namespace k
