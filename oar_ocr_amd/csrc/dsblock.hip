@@ -183,7 +183,8 @@ CsShape cs_shape(const DsBlockP& p) {
     r.lds = dsblock_cs_lds(p.ks, p.sh, p.sw, r.nch, r.nf);
     if (r.lds == 0) return r;
     r.acts = (p.act1.kind == ACT_HSWISH && p.act2.kind == ACT_HSWISH) ? 1 : 0;
-    r.segs = (p.Ho + kCsRows - 1) / kCsRows; r.tiles_x = (p.Wo + 15) / 16;
+    const int rows = dsblock_cs_rows(p.ks, p.sh, p.sw, r.nch, r.nf);
+    r.segs = (p.Ho + rows - 1) / rows; r.tiles_x = (p.Wo + 15) / 16;
     const long items = (long)p.N * r.segs * r.tiles_x;
     if (items >= (1L << 30)) return r;
     r.items = (int)items;

@@ -12,10 +12,10 @@ namespace k {
 
 #include "dsblock_cs_p.inc"
 
-constexpr int kCsRows = 4;   // output rows of a tile (R)
 // bytes of one weight block / of the kernel's LDS for the (ks, sh, sw, nch, nft) instantiation; 0 = not instantiated
 size_t dsblock_cs_block_bytes(int ks, int nft);
 size_t dsblock_cs_lds(int ks, int sh, int sw, int nch, int nft);
+int dsblock_cs_rows(int ks, int sh, int sw, int nch, int nft);   // output rows of a tile (R) of that instantiation
 void dsblock_cs_launch(hipStream_t s, const DsCsP& p, int ks, int sh, int sw, int nch, int nft, int acts, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1);
 
 }  // namespace k

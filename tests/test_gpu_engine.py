@@ -540,6 +540,7 @@ DS_CASES = [  # (C, Cout, k, stride, N, H, W, act, residual)
     # round 4, the chunk-streamed kernel (dsblock_cs.inc: the wide blocks): ragged rows / columns, more items than one round of waves, run-time activations
     (192, 192, 5, (1, 1), 5, 13, 50, "hswish", False), (96, 192, 3, (1, 2), 3, 12, 161, "relu", False), (128, 128, 5, (1, 1), 2, 15, 23, "hswish", False),
     (192, 192, 5, (1, 1), 40, 12, 80, None, False), (128, 128, 3, (1, 1), 3, 13, 50, "hswish", False),
+    (256, 256, 3, (1, 1), 3, 11, 37, "hswish", False), (128, 256, 3, (2, 2), 2, 25, 61, "relu", False),   # two-row tiles (16 cout fragments), stride 2 both ways
 ]
 
 

@@ -9,7 +9,7 @@ from oar_ocr_amd.synth import models
 CASES = {  # name: (C, Cout, k, stride, N, H, W)
     "rec192": (192, 192, 5, (1, 1), 256, 12, 80), "rec96": (96, 96, 3, (1, 1), 256, 12, 160), "rec96s": (96, 192, 3, (1, 2), 256, 12, 160),
     "rec48": (48, 48, 3, (1, 1), 256, 24, 160), "rec48s": (48, 96, 3, (2, 1), 256, 24, 160), "rec24": (24, 48, 3, (1, 1), 256, 24, 160),
-    "det16": (16, 24, 3, (1, 1), 9, 480, 480), "det48": (48, 48, 3, (1, 1), 9, 240, 240), "det32": (32, 32, 3, (1, 1), 9, 240, 240), "det64": (64, 64, 3, (1, 1), 9, 120, 120), "det24s": (24, 32, 3, (2, 2), 9, 480, 480), "det128": (128, 128, 5, (1, 1), 9, 60, 60), "srv128": (128, 128, 3, (1, 1), 64, 24, 400), "srv256": (256, 256, 3, (1, 1), 64, 12, 200),
+    "det16": (16, 24, 3, (1, 1), 9, 480, 480), "det48": (48, 48, 3, (1, 1), 9, 240, 240), "det32": (32, 32, 3, (1, 1), 9, 240, 240), "det64": (64, 64, 3, (1, 1), 9, 120, 120), "det24s": (24, 32, 3, (2, 2), 9, 480, 480), "det128": (128, 128, 5, (1, 1), 9, 60, 60), "srv128": (128, 128, 3, (1, 1), 64, 24, 400), "srv256": (256, 256, 3, (1, 1), 64, 12, 200), "srv128s": (128, 256, 3, (2, 2), 64, 24, 400),
 }
 for name in (sys.argv[1:] or list(CASES)):
     C, Cout, k, stride, N, H, W = CASES[name]
