@@ -9,7 +9,8 @@
 //     a new input row is loaded f32 (buffer loads: pixels / rows outside the image read as zeros), split, written to the slot of the row that died;
 //   * the B operand of tap (kh, kw), channel chunk c, piece p is then ONE ds_read_b128 at (row kh, pixel n + kw): the column shift is an address;
 //   * the weights' h and m pieces (K = 9 Cin: 18 k-steps x 2 pieces x 16 B per lane at Cin = 64) stay in REGISTERS for the whole launch -- 144
-//     VGPRs, one wave per SIMD; the l pieces sit in an 18 KB LDS table; no barrier after the table is filled;
+//     VGPRs, 241 in all: two waves fit a SIMD, and six waves a workgroup (three 23 KB rings more would not fit LDS); the l pieces sit in an
+//     18 KB LDS table; no barrier after the table is filled;
 //   * six accumulators, one per product class (mm, lh, hl, mh, hm, hh): consecutive MFMAs never depend on each other, and the classes are added
 //     smallest first at the end.
 // Work item = (image, segment of R rows, strip), dealt in XCD bands as dsblock_rs.inc does.  Algorithmic bytes: 4 (M Cin + M Cout).
@@ -34,7 +35,7 @@ struct Rs3P {
 
 namespace {
 constexpr unsigned kR3Oob = 0x40000000u, kR3OobSt = 0x80000000u;
-constexpr int kR3IW = 18, kR3PxB = 144, kR3PlB = kR3IW * kR3PxB, kR3RowB = 3 * kR3PlB, kR3Waves = 4;
+constexpr int kR3IW = 18, kR3PxB = 144, kR3PlB = kR3IW * kR3PxB, kR3RowB = 3 * kR3PlB, kR3Waves = 6;
 
 __device__ __forceinline__ r3_u32x4 r3_lds4(unsigned off) {
     return *reinterpret_cast<const __attribute__((address_space(3))) r3_u32x4*>((__attribute__((address_space(3))) const char*)nullptr + off);
@@ -46,7 +47,7 @@ __device__ __forceinline__ void r3_lds_w2(unsigned off, r3_u32x2 v) {
 // CC32 = Cin / 32 (k-steps per tap)
 // DBG (timing ablations, wrong results; OAR_RS3_DBG): 1 no MFMA, 2 no split / ring writes, 4 no operand reads, 8 no stores, 16 no row loads
 template <int CC32, int DBG = 0>
-__global__ __launch_bounds__(kR3Waves * 64, 1) void conv3x3_n16_x6_kernel(Rs3P p) {
+__global__ __launch_bounds__(kR3Waves * 64, 2) void conv3x3_n16_x6_kernel(Rs3P p) {
     constexpr int QPP = CC32 * 8;                           // float4 quads per pixel
     constexpr int NU = kR3IW * QPP;                         // quads of one strip row
     constexpr int NJ = (NU + 63) / 64;                      // loads per lane and row
