@@ -35,6 +35,22 @@ def test_detector_graph_matches_oracle():
     assert g.min() >= 0.0 and g.max() <= 1.0          # ScoreValidator range (utils/validation.rs:51-53)
 
 
+def test_engine_matches_the_torch_free_oracle_too():
+    """The same two graphs against oracle/onnx_np.py (numpy / float64, no torch kernel): the engine is not only close to ONE evaluator."""
+    from oracle import onnx_np
+    det, _ = models.build_det("tiny", seed=0)
+    x, _ = R.det_preprocess(pages.make_page(5, (96, 160), lines=2))
+    got = api.OrtInfer(det).infer(x[None])[0][1]
+    ref = onnx_np.run(det, {"x": x[None]})[0]
+    assert got.shape == ref.shape and np.abs(got - ref).max() <= TOL
+    rec, _ = models.build_rec("tiny", vocab=301, seed=1)
+    xr = R.rec_preprocess([pages.make_crop(i, w, 48) for i, w in enumerate((200, 131, 96))])
+    eng = api.OrtInfer(rec)
+    got = eng.infer(xr)[0][1]
+    ref = onnx_np.run(rec, {eng.input_name(): xr})[0]
+    assert got.shape == ref.shape and np.abs(got - ref).max() <= TOL and np.array_equal(got.argmax(-1), ref.argmax(-1))
+
+
 def test_detector_batch_and_shapes():
     det, _ = models.build_det("tiny", seed=0)
     rng = np.random.default_rng(0)
