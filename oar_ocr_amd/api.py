@@ -308,8 +308,8 @@ DEFAULT_PARALLEL_THRESHOLD = 4   # core/constants.rs:18
 
 def load_image_from_memory(data: bytes) -> np.ndarray:
     """utils/image.rs:65-68: encoded bytes -> [H, W, 3] u8 (RgbImage).  PNG is decoded by the library to the bytes image 0.25.6
-    yields, JPEG to libjpeg's default-path bytes (= PIL's; unpinned against zune-jpeg), BMP / PNM (maxval 255) / the first frame of a GIF
-    (round 4, image_misc_decode.cc; == PIL); WebP, TIFF and the variants those decoders refuse raise OCRError with OAR_UNSUPPORTED_OP (the message
+    yields, JPEG to libjpeg's default-path bytes (= PIL's; unpinned against zune-jpeg), BMP / PNM (maxval 255) / baseline TIFF / the first frame of a GIF
+    (round 4, image_misc_decode.cc; == PIL); WebP and the variants those decoders refuse raise OCRError with OAR_UNSUPPORTED_OP (the message
     names the format)."""
     buf = (C.c_char * len(data)).from_buffer_copy(data) if len(data) else (C.c_char * 1)()
     out = C.POINTER(C.c_uint8)()

@@ -69,7 +69,7 @@ namespace oar { namespace img {
 bool is_png(const uint8_t* b, size_t n);
 const char* sniff(const uint8_t* b, size_t n);
 void decode_png(const uint8_t* b, size_t n, std::vector<uint8_t>& rgb, uint32_t& width, uint32_t& height);
-bool decode_misc(const uint8_t* b, size_t n, std::vector<uint8_t>& rgb, uint32_t& width, uint32_t& height);   // image_misc_decode.cc: BMP, PNM, GIF
+bool decode_misc(const uint8_t* b, size_t n, std::vector<uint8_t>& rgb, uint32_t& width, uint32_t& height);   // image_misc_decode.cc: BMP, PNM, TIFF, GIF
 } }
 
 namespace {
@@ -1304,7 +1304,7 @@ oar_status oar_image_decode(const uint8_t* bytes, size_t len, uint8_t** rgb, uin
         if (!img::is_png(bytes, len)) {
             if (!img::decode_misc(bytes, len, px, w, h)) {
                 const char* what = img::sniff(bytes, len);
-                if (what) fail(OAR_UNSUPPORTED_OP, std::string("image load: ") + what + " is not decoded by this library (PNG, JPEG, BMP, PNM and GIF are); use the reference's loader for it");
+                if (what) fail(OAR_UNSUPPORTED_OP, std::string("image load: ") + what + " is not decoded by this library (PNG, JPEG, BMP, PNM, TIFF and GIF are); use the reference's loader for it");
                 fail(OAR_INVALID_INPUT, "image load: unrecognised image format");
             }
         } else {

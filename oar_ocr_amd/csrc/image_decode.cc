@@ -10,7 +10,7 @@
 // PNG is lossless and its decoding is fully specified, so "the same bytes" is a property of the format, not of an
 // implementation: pinned against PIL and against an independent zlib + numpy oracle (tests/test_image_decode_cpu.py).
 // The DEFLATE stream is inflated by the system zlib (the reference uses a Rust inflate; any conforming inflate yields the same
-// bytes).  JPEG is jpeg_decode.cc, BMP / PNM / GIF image_misc_decode.cc; the other formats the image crate knows (TIFF, WebP, ...) are reported as
+// bytes).  JPEG is jpeg_decode.cc, BMP / PNM / TIFF / GIF image_misc_decode.cc; the other formats the image crate knows (WebP, ...) are reported as
 // OAR_UNSUPPORTED_OP -- never guessed at.
 // Host code by nature (a DEFLATE stream and PNG's left / up filters are serial per image); images decode in parallel across
 // caller threads (the entry point holds no lock).

@@ -1,20 +1,27 @@
 // image_misc_decode.cc -- the small formats behind `load_image_from_memory` (oar-ocr-core/src/utils/image.rs:65-68: image::load_from_memory +
-// DynamicImage::to_rgb8): BMP, binary / ASCII PNM, and the first frame of a GIF (round 4; VERDICT r3 "missing" #3).
+// DynamicImage::to_rgb8): BMP, binary / ASCII PNM, baseline TIFF, and the first frame of a GIF (round 4; VERDICT r3 "missing" #3).
 //
 // Only the parts of each format whose result does not depend on a decoder's choices are taken; anything else is refused with OAR_UNSUPPORTED_OP
 // (never guessed at) and stays with the reference's loader:
 //   BMP   BITMAPCOREHEADER / INFOHEADER / V4 / V5; BI_RGB 1, 4, 8 (palette), 16 (5-5-5), 24, 32 bits; BI_BITFIELDS 16 / 32 bits (any contiguous
 //         masks, an n-bit channel widened as round(v * 255 / (2^n - 1))); BI_RLE8 / BI_RLE4; bottom-up and top-down.  Alpha is dropped (to_rgb8).
 //   PNM   P1 / P4 (1 = black), P2 / P5, P3 / P6 with maxval 255 (other maxvals need the crate's scaling rule: refused).
+//   TIFF  first image of the file, strips, chunky planes; compression none / LZW / PackBits / Deflate (with or without the horizontal predictor);
+//         8- or 16-bit samples (16 -> 8 as (v + 128) / 257, DynamicImage::to_rgb8's rule); BlackIsZero, WhiteIsZero (inverted, as the tiff crate
+//         does), RGB, RGB + extra samples (dropped).  Palette, 1-bit, CMYK / YCbCr, tiles, separate planes, fax codings: refused (the image crate's
+//         TiffDecoder accepts only the L / LA / RGB / RGBA 8- and 16-bit colour types as well).
 //   GIF   87a / 89a, first frame, global or local palette, interlaced or not.  image's GifDecoder composes the frame on a transparent canvas and
 //         to_rgb8 drops alpha: pixels outside the frame come out as (0, 0, 0); a pixel with the transparent index keeps its palette colour
 //         (the gif crate's RGBA output writes the colour with alpha 0).
 // Limits as image_decode.cc: width, height <= 65535 px and <= 512 MiB of output.
 // Unpinned against the image crate itself (no cargo here): tests compare with PIL on files PIL wrote and on hand-built headers.
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <string>
 #include <vector>
+
+#include <zlib.h>
 
 #include "common.h"
 
@@ -222,6 +229,155 @@ void decode_pnm(const uint8_t* bytes, size_t len, std::vector<uint8_t>& rgb, uin
     width = W; height = H;
 }
 
+// ------------------------------------------------------------------------------------------------ TIFF
+struct Tf {
+    const uint8_t* b; size_t n; bool be;
+    uint32_t u16(size_t o) const { OAR_CHECK(o + 2 <= n, OAR_INVALID_INPUT, "image load: truncated TIFF"); return be ? ((uint32_t)b[o] << 8) | b[o + 1] : ((uint32_t)b[o + 1] << 8) | b[o]; }
+    uint32_t u32(size_t o) const { return be ? (u16(o) << 16) | u16(o + 2) : (u16(o + 2) << 16) | u16(o); }
+};
+struct TfEntry { uint32_t type = 0, count = 0; size_t at = 0; bool present = false; };
+
+// TIFF LZW: MSB-first codes, 9 .. 12 bits, Clear = 256, EOI = 257, the code width grows one code EARLY
+void tiff_lzw(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t want) {
+    std::vector<uint16_t> prefix(4096);
+    std::vector<uint8_t> suffix(4096), stack(4096);
+    uint32_t width = 9, next = 258, prev = 0xFFFF, first = 0;
+    uint64_t acc = 0;
+    uint32_t nbits = 0;
+    size_t p = 0;
+    for (uint32_t i = 0; i < 256; ++i) { prefix[i] = 0xFFFF; suffix[i] = (uint8_t)i; }
+    while (out.size() < want) {
+        while (nbits < width && p < n) { acc = (acc << 8) | src[p++]; nbits += 8; }
+        if (nbits < width) break;
+        const uint32_t code = (uint32_t)((acc >> (nbits - width)) & ((1u << width) - 1));
+        nbits -= width;
+        if (code == 256) { width = 9; next = 258; prev = 0xFFFF; continue; }
+        if (code == 257) break;
+        uint32_t sp = 0, c = code;
+        if (prev == 0xFFFF) { OAR_CHECK(code < 256, OAR_INVALID_INPUT, "image load: corrupt TIFF LZW stream"); }
+        else if (code >= next) { OAR_CHECK(code == next, OAR_INVALID_INPUT, "image load: corrupt TIFF LZW stream"); stack[sp++] = (uint8_t)first; c = prev; }
+        while (c >= 258) { OAR_CHECK(sp < 4095, OAR_INVALID_INPUT, "image load: corrupt TIFF LZW stream"); stack[sp++] = suffix[c]; c = prefix[c]; }
+        OAR_CHECK(c < 256, OAR_INVALID_INPUT, "image load: corrupt TIFF LZW stream");
+        stack[sp++] = (uint8_t)c;
+        first = c;
+        if (prev != 0xFFFF && next < 4096) { prefix[next] = (uint16_t)prev; suffix[next] = (uint8_t)first; ++next; }
+        if (next + 1 >= (1u << width) && width < 12) ++width;   // "early change"
+        prev = code;
+        while (sp && out.size() < want) out.push_back(stack[--sp]);
+    }
+}
+
+void decode_tiff(const uint8_t* bytes, size_t len, std::vector<uint8_t>& rgb, uint32_t& width, uint32_t& height) {
+    OAR_CHECK(len >= 8, OAR_INVALID_INPUT, "image load: truncated TIFF header");
+    Tf t{bytes, len, bytes[0] == 'M'};
+    const size_t ifd = t.u32(4);
+    const uint32_t n_ent = t.u16(ifd);
+    OAR_CHECK(ifd + 2 + (size_t)n_ent * 12 <= len, OAR_INVALID_INPUT, "image load: truncated TIFF directory");
+    static const uint32_t tsz[14] = {0, 1, 1, 2, 4, 8, 1, 1, 2, 4, 8, 4, 8, 4};
+    auto find = [&](uint32_t tag) {
+        TfEntry e;
+        for (uint32_t i = 0; i < n_ent; ++i) {
+            const size_t at = ifd + 2 + (size_t)i * 12;
+            if (t.u16(at) != tag) continue;
+            e.type = t.u16(at + 2); e.count = t.u32(at + 4);
+            OAR_CHECK(e.type >= 1 && e.type <= 13, OAR_INVALID_INPUT, "image load: TIFF field type");
+            const size_t bytes_total = (size_t)tsz[e.type] * e.count;
+            e.at = bytes_total <= 4 ? at + 8 : t.u32(at + 8);
+            OAR_CHECK(e.at + bytes_total <= len, OAR_INVALID_INPUT, "image load: TIFF field beyond the file");
+            e.present = true;
+            break;
+        }
+        return e;
+    };
+    auto value = [&](const TfEntry& e, uint32_t i) -> uint32_t {   // BYTE / SHORT / LONG arrays
+        OAR_CHECK(i < e.count, OAR_INVALID_INPUT, "image load: TIFF field index");
+        if (e.type == 3) return t.u16(e.at + 2 * i);
+        if (e.type == 4) return t.u32(e.at + 4 * i);
+        if (e.type == 1) return bytes[e.at + i];
+        fail(OAR_INVALID_INPUT, "image load: TIFF field is not an integer");
+        return 0;
+    };
+    auto scalar = [&](uint32_t tag, uint32_t dflt) { const TfEntry e = find(tag); return e.present ? value(e, 0) : dflt; };
+    const uint32_t W = scalar(256, 0), H = scalar(257, 0);
+    check_dims(W, H);
+    const uint32_t comp = scalar(259, 1), photo = scalar(262, 0xFFFF), spp = scalar(277, 1), planar = scalar(284, 1), predictor = scalar(317, 1);
+    const TfEntry bps_e = find(258);
+    const uint32_t bps = bps_e.present ? value(bps_e, 0) : 1;
+    if (bps_e.present) for (uint32_t i = 1; i < bps_e.count; ++i) OAR_CHECK(value(bps_e, i) == bps, OAR_UNSUPPORTED_OP, "image load: TIFF with mixed sample widths is not decoded");
+    OAR_CHECK(!find(322).present && !find(324).present, OAR_UNSUPPORTED_OP, "image load: tiled TIFF is not decoded by this library");
+    OAR_CHECK(bps == 8 || bps == 16, OAR_UNSUPPORTED_OP, "image load: TIFF with " + std::to_string(bps) + "-bit samples is not decoded by this library");
+    OAR_CHECK(comp == 1 || comp == 5 || comp == 8 || comp == 32946 || comp == 32773, OAR_UNSUPPORTED_OP, "image load: TIFF compression " + std::to_string(comp) + " is not decoded by this library");
+    OAR_CHECK((photo == 0 || photo == 1) ? spp >= 1 : photo == 2 ? spp >= 3 : false, OAR_UNSUPPORTED_OP,
+              "image load: TIFF photometric interpretation " + std::to_string(photo) + " is not decoded by this library");
+    OAR_CHECK(spp <= 8 && (planar == 1 || spp == 1), OAR_UNSUPPORTED_OP, "image load: TIFF with separate sample planes is not decoded");
+    OAR_CHECK(predictor == 1 || predictor == 2, OAR_UNSUPPORTED_OP, "image load: TIFF predictor " + std::to_string(predictor) + " is not decoded");
+    const uint32_t rps = std::min(scalar(278, H), H);
+    OAR_CHECK(rps > 0, OAR_INVALID_INPUT, "image load: TIFF rows per strip");
+    const TfEntry offs = find(273), cnts = find(279);
+    const uint32_t n_strips = (H + rps - 1) / rps;
+    OAR_CHECK(offs.present && cnts.present && offs.count >= n_strips && cnts.count >= n_strips, OAR_INVALID_INPUT, "image load: TIFF strip table");
+    const size_t bpp = (size_t)spp * (bps / 8), row_bytes = (size_t)W * bpp;
+    rgb.assign((size_t)W * H * 3, 0);
+    std::vector<uint8_t> buf;
+    for (uint32_t si = 0; si < n_strips; ++si) {
+        const uint32_t rows = std::min(rps, H - si * rps);
+        const size_t want = row_bytes * rows, off = value(offs, si), cnt = value(cnts, si);
+        OAR_CHECK(off + cnt <= len, OAR_INVALID_INPUT, "image load: TIFF strip beyond the file");
+        buf.clear();
+        if (comp == 1) {
+            OAR_CHECK(cnt >= want, OAR_INVALID_INPUT, "image load: truncated TIFF strip");
+            buf.assign(bytes + off, bytes + off + want);
+        } else if (comp == 5) {
+            buf.reserve(want);
+            tiff_lzw(bytes + off, cnt, buf, want);
+        } else if (comp == 32773) {   // PackBits
+            size_t p = off;
+            while (buf.size() < want && p < off + cnt) {
+                const int8_t c = (int8_t)bytes[p++];
+                if (c >= 0) { const size_t k = (size_t)c + 1; OAR_CHECK(p + k <= off + cnt, OAR_INVALID_INPUT, "image load: corrupt TIFF PackBits strip"); buf.insert(buf.end(), bytes + p, bytes + p + k); p += k; }
+                else if (c != -128) { OAR_CHECK(p < off + cnt, OAR_INVALID_INPUT, "image load: corrupt TIFF PackBits strip"); buf.insert(buf.end(), (size_t)(1 - c), bytes[p++]); }
+            }
+            if (buf.size() > want) buf.resize(want);
+        } else {
+            buf.resize(want);
+            uLongf got = (uLongf)want;
+            const int rc = uncompress(buf.data(), &got, bytes + off, (uLong)cnt);
+            OAR_CHECK((rc == Z_OK || rc == Z_BUF_ERROR) && got == want, OAR_INVALID_INPUT, "image load: corrupt TIFF Deflate strip");
+        }
+        OAR_CHECK(buf.size() == want, OAR_INVALID_INPUT, "image load: TIFF strip decodes to too few bytes");
+        for (uint32_t r = 0; r < rows; ++r) {
+            uint8_t* row = buf.data() + row_bytes * r;
+            if (predictor == 2) {   // horizontal differencing per sample, in the file's sample width
+                if (bps == 8) { for (size_t i = bpp; i < row_bytes; ++i) row[i] = (uint8_t)(row[i] + row[i - bpp]); }
+                else {
+                    for (size_t i = spp; i < (size_t)W * spp; ++i) {
+                        const size_t a = 2 * i, b0 = 2 * (i - spp);
+                        const uint32_t cur = t.be ? ((uint32_t)row[a] << 8 | row[a + 1]) : ((uint32_t)row[a + 1] << 8 | row[a]);
+                        const uint32_t prv = t.be ? ((uint32_t)row[b0] << 8 | row[b0 + 1]) : ((uint32_t)row[b0 + 1] << 8 | row[b0]);
+                        const uint32_t v = (cur + prv) & 0xFFFF;
+                        if (t.be) { row[a] = (uint8_t)(v >> 8); row[a + 1] = (uint8_t)v; } else { row[a] = (uint8_t)v; row[a + 1] = (uint8_t)(v >> 8); }
+                    }
+                }
+            }
+            uint8_t* o = rgb.data() + ((size_t)(si * rps + r) * W) * 3;
+            for (uint32_t x = 0; x < W; ++x, o += 3) {
+                uint32_t smp[3];
+                const uint32_t ns = photo == 2 ? 3 : 1;
+                for (uint32_t c = 0; c < ns; ++c) {
+                    const size_t at = (size_t)x * bpp + (size_t)c * (bps / 8);
+                    uint32_t v;
+                    if (bps == 8) v = row[at];
+                    else { const uint32_t w16 = t.be ? ((uint32_t)row[at] << 8 | row[at + 1]) : ((uint32_t)row[at + 1] << 8 | row[at]); v = (w16 + 128) / 257; }
+                    smp[c] = v;
+                }
+                if (photo == 2) { o[0] = (uint8_t)smp[0]; o[1] = (uint8_t)smp[1]; o[2] = (uint8_t)smp[2]; }
+                else { const uint8_t v = (uint8_t)(photo == 0 ? 255 - smp[0] : smp[0]); o[0] = o[1] = o[2] = v; }
+            }
+        }
+    }
+    width = W; height = H;
+}
+
 // ------------------------------------------------------------------------------------------------ GIF (first frame)
 void decode_gif(const uint8_t* bytes, size_t len, std::vector<uint8_t>& rgb, uint32_t& width, uint32_t& height) {
     Rd r{bytes, len};
@@ -337,6 +493,7 @@ bool decode_misc(const uint8_t* b, size_t n, std::vector<uint8_t>& rgb, uint32_t
     if (n >= 2 && b[0] == 'B' && b[1] == 'M') { decode_bmp(b, n, rgb, width, height); return true; }
     if (n >= 2 && b[0] == 'P' && b[1] >= '1' && b[1] <= '6') { decode_pnm(b, n, rgb, width, height); return true; }
     if (n >= 6 && (!std::memcmp(b, "GIF87a", 6) || !std::memcmp(b, "GIF89a", 6))) { decode_gif(b, n, rgb, width, height); return true; }
+    if (n >= 4 && (!std::memcmp(b, "II*\0", 4) || !std::memcmp(b, "MM\0*", 4))) { decode_tiff(b, n, rgb, width, height); return true; }
     return false;
 }
 

@@ -144,7 +144,7 @@ def test_damaged_files_are_image_load_errors_not_pixels():
 
 
 def test_formats_of_the_image_crate_that_are_not_decoded_here_say_so():
-    for name, head in (("WebP", b"RIFF\0\0\0\0WEBPVP8 "), ("TIFF", b"II*\0" + b"\0" * 20), ("PNM", b"P7\nWIDTH 1\nHEIGHT 1\nDEPTH 3\nMAXVAL 255\nENDHDR\n\0\0\0"),
+    for name, head in (("WebP", b"RIFF\0\0\0\0WEBPVP8 "), ("PNM", b"P7\nWIDTH 1\nHEIGHT 1\nDEPTH 3\nMAXVAL 255\nENDHDR\n\0\0\0"),
                        ("PNM", b"P6\n1 1\n1023\n\0\0\0\0\0\0"), ("BMP", b"BM" + struct.pack("<IHHI", 70, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, 2, 2, 1, 24, 4, 16, 0, 0, 0, 0) + b"\0" * 16)):
         with pytest.raises(api.OCRError) as e:
             api.load_image_from_memory(head)
@@ -359,6 +359,11 @@ def _pil():
     return pytest.importorskip("PIL.Image")
 
 
+def _pil_has_libtiff():
+    from PIL import features
+    return bool(features.check("libtiff"))
+
+
 def test_bmp_pnm_gif_equal_pil_on_files_pil_wrote():
     """The small formats of image_misc_decode.cc (round 4) against PIL's decoder on files PIL encoded: BMP 1 / 8 (palette) / 24 / 32 bits, binary PNM
     (P4 / P5 / P6), GIF with global palettes (interlaced too) -- every pixel equal to Image.open(...).convert("RGB")."""
@@ -472,3 +477,55 @@ def test_ascii_pnm_and_gif_frame_inside_the_screen():
         with pytest.raises(api.OCRError) as e:
             api.load_image_from_memory(bad)
         assert e.value.code == api.OAR_INVALID_INPUT, bad[:8]
+
+
+def test_tiff_equals_pil_and_the_16_bit_rule():
+    """Baseline TIFF (image_misc_decode.cc): strips, compression none / LZW / PackBits / Deflate, the horizontal predictor, grey / RGB / RGBA, 8 and
+    16 bits, WhiteIsZero, big-endian -- against PIL where PIL produces 8-bit RGB, and against (v + 128) / 257 (DynamicImage::to_rgb8) for 16 bits."""
+    import io
+    Image = _pil()
+    rng = np.random.default_rng(8)
+    n = 0
+    for (h, w) in ((1, 1), (9, 14), (67, 45)):
+        rgbx = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        rgbx[h // 2:] = rgbx[h // 2][None]                       # runs, so the coders have something to do
+        grey = rgbx[..., 0].copy()
+        for im in (Image.fromarray(rgbx), Image.fromarray(grey), Image.fromarray(np.concatenate([rgbx, grey[..., None]], -1), "RGBA")):
+            for kw in (dict(), dict(compression="tiff_lzw"), dict(compression="packbits"), dict(compression="tiff_adobe_deflate"),
+                       dict(compression="tiff_lzw", tiffinfo={317: 2}), dict(compression="tiff_adobe_deflate", tiffinfo={317: 2})):
+                buf = io.BytesIO()
+                try:
+                    im.save(buf, format="TIFF", **kw)
+                except Exception:          # a PIL build without libtiff writes only uncompressed files
+                    continue
+                data = buf.getvalue()
+                want = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+                assert np.array_equal(api.load_image_from_memory(data), want), (im.mode, (h, w), kw)
+                n += 1
+    assert n >= 9 * (6 if _pil_has_libtiff() else 1)
+    # 16-bit grey, little- and big-endian, hand-built (one strip, uncompressed); WhiteIsZero inverts
+    v = rng.integers(0, 65536, (4, 5), dtype=np.uint16)
+    for be in (False, True):
+        for photo in (1, 0):
+            e = ">" if be else "<"
+            pix = v.astype(e + "u2").tobytes()
+            tags = [(256, 3, 1, 5), (257, 3, 1, 4), (258, 3, 1, 16), (259, 3, 1, 1), (262, 3, 1, photo), (273, 4, 1, 8), (277, 3, 1, 1), (278, 3, 1, 4), (279, 4, 1, len(pix))]
+            ifd_at = 8 + len(pix)
+            ifd = struct.pack(e + "H", len(tags))
+            for tag, typ, cnt, val in tags:
+                ifd += struct.pack(e + "HHI", tag, typ, cnt) + (struct.pack(e + "HH", val, 0) if typ == 3 else struct.pack(e + "I", val))
+            data = (b"MM\0*" if be else b"II*\0") + struct.pack(e + "I", ifd_at) + pix + ifd + struct.pack(e + "I", 0)
+            g8 = ((v.astype(np.uint32) + 128) // 257).astype(np.uint8)
+            if photo == 0:
+                g8 = 255 - g8
+            assert np.array_equal(api.load_image_from_memory(data), np.repeat(g8[..., None], 3, -1)), (be, photo)
+    # refused, by name: 1-bit, palette, tiles
+    one_bit = io.BytesIO(); Image.fromarray((rng.random((8, 8)) > 0.5).astype(np.uint8) * 255).convert("1").save(one_bit, format="TIFF")
+    pal = io.BytesIO(); Image.fromarray(rng.integers(0, 256, (8, 8, 3), dtype=np.uint8)).quantize(16).save(pal, format="TIFF")
+    for blob in (one_bit.getvalue(), pal.getvalue()):
+        with pytest.raises(api.OCRError) as ex:
+            api.load_image_from_memory(blob)
+        assert ex.value.code == api.OAR_UNSUPPORTED_OP and "TIFF" in ex.value.message
+    with pytest.raises(api.OCRError) as ex:
+        api.load_image_from_memory(b"II*\0" + b"\0" * 20)
+    assert ex.value.code == api.OAR_INVALID_INPUT
