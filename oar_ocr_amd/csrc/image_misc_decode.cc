@@ -322,6 +322,7 @@ void decode_tiff(const uint8_t* bytes, size_t len, std::vector<uint8_t>& rgb, ui
     for (uint32_t si = 0; si < n_strips; ++si) {
         const uint32_t rows = std::min(rps, H - si * rps);
         const size_t want = row_bytes * rows, off = value(offs, si), cnt = value(cnts, si);
+        OAR_CHECK(want <= kMaxOut, OAR_UNSUPPORTED_OP, "image load: TIFF strip larger than the 512 MiB decoding budget");   // (a header alone must not make the decoder allocate gigabytes)
         OAR_CHECK(off + cnt <= len, OAR_INVALID_INPUT, "image load: TIFF strip beyond the file");
         buf.clear();
         if (comp == 1) {
