@@ -292,17 +292,23 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvP p) {
 
 // The same kernel fed by u8 pages (StemU8, kernels.h): tap value = (float)byte * alpha + beta, two separate f32 operations
 // exactly as pp::normalize computes them; out-of-image taps contribute nothing (the conv zero-pads the NORMALISED tensor).
-template <bool CRNN, bool K3>
+// SW: the 16 output channels of the group all exist, so a tap's 16 weights are 64 contiguous bytes at a wave-uniform address -- they
+// are read through the scalar cache straight into SGPRs (the FMAs take them as their scalar operand) instead of 108 broadcast
+// ds_read_b128 per pixel, which kept the CU's one LDS pipe busier than its four SIMDs' FMAs.  Same products, same order.
+typedef const __attribute__((address_space(4))) float sfloat;
+template <bool CRNN, bool K3, bool SW>
 __global__ __launch_bounds__(256) void conv_smallcin_u8_kernel(ConvP p, StemU8 st) {
-    __shared__ float ws[128 * 16];
+    __shared__ float ws[SW ? 1 : 128 * 16];
     __shared__ float lut[CRNN ? 256 : 1];
     __shared__ float ot[4 * 64 * 17];   // per-wave output transposition slabs (see the store below)
     const int K = p.kh * p.kw * 3;
     const int co0 = blockIdx.y * 16;
-    for (int i = threadIdx.x; i < K * 16; i += 256) {
-        int k = i >> 4, c = i & 15;
-        ws[i] = (co0 + c < p.Cout) ? p.w[(long)k * p.Cout + co0 + c] : 0.f;
-    }
+    if (!SW)
+        for (int i = threadIdx.x; i < K * 16; i += 256) {
+            int k = i >> 4, c = i & 15;
+            ws[i] = (co0 + c < p.Cout) ? p.w[(long)k * p.Cout + co0 + c] : 0.f;
+        }
+    sfloat* wsc = (sfloat*)(uintptr_t)(p.w + co0);
     if (CRNN) lut[threadIdx.x] = ((float)threadIdx.x / 255.0f - 0.5f) / 0.5f;   // pp::rec_pack's expression, once per byte value
     __syncthreads();
     const long per_image = (long)p.Ho * p.Wo;
@@ -325,7 +331,6 @@ __global__ __launch_bounds__(256) void conv_smallcin_u8_kernel(ConvP p, StemU8 s
             const int ih = oh * p.sh - p.pt + a * p.dh, iw = ow * p.sw - p.pl + b * p.dw;
             if (ih < 0 || ih >= p.H || iw < 0 || iw >= img_w) return;
             const uint8_t* xp = pg + ((long)ih * img_w + iw) * 3;
-            const float* wp = ws + (a * kw + b) * 3 * 16;
             float x0, x1, x2;
             if (CRNN) {
                 x0 = lut[xp[s0]]; x1 = lut[xp[s1]]; x2 = lut[xp[s2]];
@@ -333,12 +338,23 @@ __global__ __launch_bounds__(256) void conv_smallcin_u8_kernel(ConvP p, StemU8 s
                 const float t0 = (float)xp[s0] * a0, t1 = (float)xp[s1] * a1, t2 = (float)xp[s2] * a2;
                 x0 = t0 + b0; x1 = t1 + b1; x2 = t2 + b2;
             }
+            if (SW) {
+                sfloat* wp = wsc + (long)(a * kw + b) * 3 * p.Cout;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) acc[c] = fmaf(x0, wp[c], acc[c]);
+                for (int c = 0; c < 16; ++c) acc[c] = fmaf(x0, wp[c], acc[c]);
 #pragma unroll
-            for (int c = 0; c < 16; ++c) acc[c] = fmaf(x1, wp[16 + c], acc[c]);
+                for (int c = 0; c < 16; ++c) acc[c] = fmaf(x1, wp[p.Cout + c], acc[c]);
 #pragma unroll
-            for (int c = 0; c < 16; ++c) acc[c] = fmaf(x2, wp[32 + c], acc[c]);
+                for (int c = 0; c < 16; ++c) acc[c] = fmaf(x2, wp[2 * p.Cout + c], acc[c]);
+            } else {
+                const float* wp = ws + (a * kw + b) * 3 * 16;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) acc[c] = fmaf(x0, wp[c], acc[c]);
+#pragma unroll
+                for (int c = 0; c < 16; ++c) acc[c] = fmaf(x1, wp[16 + c], acc[c]);
+#pragma unroll
+                for (int c = 0; c < 16; ++c) acc[c] = fmaf(x2, wp[32 + c], acc[c]);
+            }
         };
         if (K3) {   // the 3 x 3 stems of both networks: compile-time trip counts (the nine taps' loads can all be in flight; same order of the FMAs)
 #pragma unroll
@@ -391,8 +407,17 @@ void conv_smallcin_u8(hipStream_t s, const ConvP& p, const StemU8& st) {
     ProfScope ps(s, "conv_smallcin", 3.0 * (double)p.N * p.H * p.W + 4.0 * total, 2.0 * total * p.kh * p.kw * 3);
     const dim3 grid(grid_for(per_image, 256, 256L * 4), (p.Cout + 15) / 16, p.N);
     const bool k3 = p.kh == 3 && p.kw == 3;
-    if (st.dev) { if (k3) hipLaunchKernelGGL((conv_smallcin_u8_kernel<true, true>), grid, dim3(256), 0, s, p, st); else hipLaunchKernelGGL((conv_smallcin_u8_kernel<true, false>), grid, dim3(256), 0, s, p, st); }
-    else { if (k3) hipLaunchKernelGGL((conv_smallcin_u8_kernel<false, true>), grid, dim3(256), 0, s, p, st); else hipLaunchKernelGGL((conv_smallcin_u8_kernel<false, false>), grid, dim3(256), 0, s, p, st); }
+    static const bool sw_off = [] { const char* e = getenv("OAR_STEM_SW"); return e && e[0] == '0'; }();
+    const bool sw = k3 && p.Cout % 16 == 0 && !sw_off;   // (Cout % 16: every group is full and its 64 weight bytes are dword aligned)
+    if (st.dev) {
+        if (sw) hipLaunchKernelGGL((conv_smallcin_u8_kernel<true, true, true>), grid, dim3(256), 0, s, p, st);
+        else if (k3) hipLaunchKernelGGL((conv_smallcin_u8_kernel<true, true, false>), grid, dim3(256), 0, s, p, st);
+        else hipLaunchKernelGGL((conv_smallcin_u8_kernel<true, false, false>), grid, dim3(256), 0, s, p, st);
+    } else {
+        if (sw) hipLaunchKernelGGL((conv_smallcin_u8_kernel<false, true, true>), grid, dim3(256), 0, s, p, st);
+        else if (k3) hipLaunchKernelGGL((conv_smallcin_u8_kernel<false, true, false>), grid, dim3(256), 0, s, p, st);
+        else hipLaunchKernelGGL((conv_smallcin_u8_kernel<false, false, false>), grid, dim3(256), 0, s, p, st);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ direct conv (fallback)

@@ -107,8 +107,9 @@ def test_rec_preprocess_flip_equals_packing_the_rotated_crop():
     """CropDesc::flip (round 3): a class-1 text line is recognised from its rotate180 (src/oarocr/ocr.rs:785-788); the resize reads the
     stored crop backwards instead of a rotated copy -- bit-identical to packing the materialised rotation."""
     rng = np.random.default_rng(11)
-    crops = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for (w, h) in [(120, 30), (400, 41), (64, 64), (33, 20), (900, 25), (320, 48), (17, 96)]]
-    flips = [True, False, True, True, False, True, True]
+    crops = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for (w, h) in [(120, 30), (400, 41), (64, 64), (33, 20), (900, 25), (320, 48), (17, 96),
+                                                                                  (300, 230), (2000, 40), (150, 260)]]   # the last three: tap sets wider than the strip kernel's 8
+    flips = [True, False, True, True, False, True, True, True, False, False]
     want = R.rec_preprocess([R.rotate_rgb(c, 2) if f else c for c, f in zip(crops, flips)])
     assert np.array_equal(api.k_rec_preprocess(crops, flips=flips), want)
     assert np.array_equal(api.k_rec_preprocess(crops, flips=[False] * len(crops)), R.rec_preprocess(crops))

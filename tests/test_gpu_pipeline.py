@@ -144,10 +144,10 @@ def test_fused_recognizer_stem_matches_the_packed_tensor_path(nets, monkeypatch)
     order, so indices AND probabilities are identical, for mixed widths, very narrow crops, a taller-than-48 crop
     (down-scaling) and a batch of one."""
     _, rec, chars = nets
-    shapes = [(320, 48), (260, 40), (500, 44), (150, 30), (24, 20), (900, 61), (48, 48), (40, 16)]
+    shapes = [(320, 48), (260, 40), (500, 44), (150, 30), (24, 20), (900, 61), (48, 48), (40, 16), (700, 230)]   # 230 rows: > 8 vertical taps
     crops = [pages.make_crop(60 + i, w, h) for i, (w, h) in enumerate(shapes)]
     pred = api.TextRecognitionPredictor(rec, chars)
-    for batch in (crops, crops[:1], crops[4:6]):
+    for batch in (crops, crops[:1], crops[4:6], crops[7:]):
         fused = pred.predict(batch)
         monkeypatch.setenv("OAR_REC_FUSE_STEM", "0")
         plain = pred.predict(batch)
