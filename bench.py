@@ -320,6 +320,14 @@ def main():
                 mfma_util = {"unit": "% of the dense MFMA peak of the class's dtype (bf16 2500 / f32 157.3 TFLOP/s), time-weighted per class",
                              "source": str(mf.relative_to(ROOT)),
                              "classes": {k: v["pct_of_dense_peak"] for k, v in m.items() if isinstance(v, dict) and "pct_of_dense_peak" in v}}
+                # the other bound of the same classes: counter-measured HBM bytes per launch / launch duration / 8 TB/s (same session's
+                # FETCH_SIZE / WRITE_SIZE passes), so that each conv class shows how far it is from BOTH of its roofs
+                tf = mf.with_name("pmc_traffic.json")
+                if tf.exists():
+                    t = json.loads(tf.read_text())
+                    if t.get("_csrc_fingerprint") == csrc_now:
+                        mfma_util["hbm_frac"] = {k: t[k]["hbm_frac"] for k in mfma_util["classes"] if isinstance(t.get(k), dict) and t[k].get("hbm_frac") is not None}
+                        mfma_util["hbm_frac_source"] = str(tf.relative_to(ROOT))
                 break
             except Exception:
                 pass

@@ -33,24 +33,29 @@ def klass(name):   # kernel name -> profiler class used by the in-library profil
     return None
 
 def per_class(path, counter):
-    tot = collections.defaultdict(float); disp = collections.defaultdict(set)
+    tot = collections.defaultdict(float); disp = collections.defaultdict(set); ns = collections.defaultdict(float)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
         c = klass(r["Kernel_Name"])
         if c:
-            tot[c] += float(r["Counter_Value"]); disp[c].add(r["Dispatch_Id"])
-    return {c: (tot[c], len(disp[c])) for c in tot}
+            tot[c] += float(r["Counter_Value"])
+            if r["Dispatch_Id"] not in disp[c]:
+                disp[c].add(r["Dispatch_Id"]); ns[c] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    return {c: (tot[c], len(disp[c]), ns[c]) for c in tot}
 
 f = per_class(src / "pmc_FETCH_SIZE" / "p_counter_collection.csv", "FETCH_SIZE")
 w = per_class(src / "pmc_WRITE_SIZE" / "p_counter_collection.csv", "WRITE_SIZE")
 res = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 2 --warmup 1 --cpu-pages 0 --no-prof`; "
-                "counters are in KiB; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md (HBM section); bytes are averages per launch of the class",
+                "counters are in KiB; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md (HBM section); bytes are averages per launch of the class; "
+                "hbm_frac = counter bytes per launch / average launch duration in the same pass / 8 TB/s",
        "_source_tag": tag, "_csrc_fingerprint": csrc_fingerprint()}
 for c in f:
     fb = f[c][0] * 1024 * 2 / max(f[c][1], 1)
-    wb = w.get(c, (0, 1))[0] * 1024 / max(w.get(c, (0, 1))[1], 1)
-    res[c] = {"fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb), "hbm_bytes_per_launch": round(fb + wb), "launches_sampled": f[c][1]}
+    wb = w.get(c, (0, 1, 0))[0] * 1024 / max(w.get(c, (0, 1, 0))[1], 1)
+    us = f[c][2] / max(f[c][1], 1) / 1e3   # average launch of the class in the FETCH_SIZE pass (the launches the bytes were counted on)
+    res[c] = {"fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb), "hbm_bytes_per_launch": round(fb + wb), "launches_sampled": f[c][1],
+              "avg_us": round(us, 1), "hbm_frac": round((fb + wb) / (us * 1e-6) / 8e12, 3) if us > 0 else None}
 (out / "pmc_traffic.json").write_text(json.dumps(res, indent=1) + "\n")
 print(json.dumps({k: v for k, v in res.items() if not k.startswith("_")}, indent=1)[:1500])
 

@@ -18,7 +18,7 @@ def load(path):
         return agg, dur, n
     seen = set()
     for r in csv.DictReader(open(path)):
-        k = (r["Kernel_Name"].split("(")[0][-64:], int(r["Grid_Size"]))
+        k = (r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][-64:], int(r["Grid_Size"]))
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         d = (k, r["Dispatch_Id"])
         if d not in seen:
@@ -57,7 +57,7 @@ if __name__ == "__main__":
         wr = w[k]["WRITE_SIZE"] / max(wn[k], 1) * 1024 / 1e6
         m = mf.get(k)
         tail = f"{m['util']:10.1f} {m['tf_bf16']:8.1f} {m['tf_f32']:7.1f} {m['frac_peak']:6.1f} {m['wait']:12.1f}" if m else ""
-        print(f"{k[0]:66s} {k[1]:8d} {n:3d} {us:7.1f} {fe:9.1f} {wr:8.1f} {(fe + wr) / us * 1e3 / 1e3:6.0f} | {tail}")
+        print(f"{k[0]:66s} {k[1]:8d} {n:3d} {us:7.1f} {fe:9.1f} {wr:8.1f} {(fe + wr) / us * 1e3:6.0f} | {tail}")
     cal = mfma_rows(base, "pmc_MFMA_peak")
     if cal:
         print("\ncalibration: tools/mfma_peak under the same counters (a kernel at the MFMA issue peak)")
