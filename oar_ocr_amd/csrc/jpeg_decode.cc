@@ -387,39 +387,39 @@ void jpeg_idct_block(const int16_t* cf, const uint16_t* q, uint8_t* out, int str
     // jidctint.c jpeg_idct_islow (CONST_BITS 13, PASS1_BITS 2)
     constexpr int F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633, F1501 = 12299, F1847 = 15137, F1961 = 16069, F2053 = 16819,
                   F2562 = 20995, F3072 = 25172;
-    int ws[64];
+    W32 ws[64];
     for (int x = 0; x < 8; ++x) {
-        const int i0 = cf[x] * q[x], i1 = cf[8 + x] * q[8 + x], i2 = cf[16 + x] * q[16 + x], i3 = cf[24 + x] * q[24 + x], i4 = cf[32 + x] * q[32 + x], i5 = cf[40 + x] * q[40 + x],
-                  i6 = cf[48 + x] * q[48 + x], i7 = cf[56 + x] * q[56 + x];
-        int z1 = (i2 + i6) * F0541;
-        const int t2 = z1 + i6 * (-F1847), t3 = z1 + i2 * F0765;
-        const int t0 = (int)((unsigned)(i0 + i4) << 13), t1 = (int)((unsigned)(i0 - i4) << 13);
-        const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
-        int o0 = i7, o1 = i5, o2 = i3, o3 = i1;
-        z1 = o0 + o3; int z2 = o1 + o2, z3 = o0 + o2, z4 = o1 + o3;
-        const int z5 = (z3 + z4) * F1175;
+        const W32 i0 = cf[x] * q[x], i1 = cf[8 + x] * q[8 + x], i2 = cf[16 + x] * q[16 + x], i3 = cf[24 + x] * q[24 + x], i4 = cf[32 + x] * q[32 + x], i5 = cf[40 + x] * q[40 + x],
+                  i6 = cf[48 + x] * q[48 + x], i7 = cf[56 + x] * q[56 + x];   // |int16 x uint16| < 2^31
+        W32 z1 = (i2 + i6) * F0541;
+        const W32 t2 = z1 + i6 * (-F1847), t3 = z1 + i2 * F0765;
+        const W32 t0 = (i0 + i4).shl(13), t1 = (i0 - i4).shl(13);
+        const W32 t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+        W32 o0 = i7, o1 = i5, o2 = i3, o3 = i1;
+        z1 = o0 + o3; W32 z2 = o1 + o2, z3 = o0 + o2, z4 = o1 + o3;
+        const W32 z5 = (z3 + z4) * F1175;
         o0 *= F0298; o1 *= F2053; o2 *= F3072; o3 *= F1501;
         z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
         z3 += z5; z4 += z5;
         o0 += z1 + z3; o1 += z2 + z4; o2 += z2 + z3; o3 += z1 + z4;
-        auto ds = [](int v) { return (v + (1 << 10)) >> 11; };
+        auto ds = [](W32 v) { return W32((v + (1 << 10)).sra(11)); };
         ws[x] = ds(t10 + o3); ws[56 + x] = ds(t10 - o3); ws[8 + x] = ds(t11 + o2); ws[48 + x] = ds(t11 - o2);
         ws[16 + x] = ds(t12 + o1); ws[40 + x] = ds(t12 - o1); ws[24 + x] = ds(t13 + o0); ws[32 + x] = ds(t13 - o0);
     }
     for (int y = 0; y < 8; ++y) {
-        const int* w = ws + y * 8;
-        int z1 = (w[2] + w[6]) * F0541;
-        const int t2 = z1 + w[6] * (-F1847), t3 = z1 + w[2] * F0765;
-        const int t0 = (int)((unsigned)(w[0] + w[4]) << 13), t1 = (int)((unsigned)(w[0] - w[4]) << 13);
-        const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
-        int o0 = w[7], o1 = w[5], o2 = w[3], o3 = w[1];
-        z1 = o0 + o3; int z2 = o1 + o2, z3 = o0 + o2, z4 = o1 + o3;
-        const int z5 = (z3 + z4) * F1175;
+        const W32* w = ws + y * 8;
+        W32 z1 = (w[2] + w[6]) * F0541;
+        const W32 t2 = z1 + w[6] * (-F1847), t3 = z1 + w[2] * F0765;
+        const W32 t0 = (w[0] + w[4]).shl(13), t1 = (w[0] - w[4]).shl(13);
+        const W32 t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+        W32 o0 = w[7], o1 = w[5], o2 = w[3], o3 = w[1];
+        z1 = o0 + o3; W32 z2 = o1 + o2, z3 = o0 + o2, z4 = o1 + o3;
+        const W32 z5 = (z3 + z4) * F1175;
         o0 *= F0298; o1 *= F2053; o2 *= F3072; o3 *= F1501;
         z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
         z3 += z5; z4 += z5;
         o0 += z1 + z3; o1 += z2 + z4; o2 += z2 + z3; o3 += z1 + z4;
-        auto rl = [](int v) { v = ((v + (1 << 17)) >> 18) + 128; return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); };
+        auto rl = [](W32 x) { const int v = (x + (1 << 17)).sra(18) + 128; return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); };
         uint8_t* o = out + (size_t)y * stride;
         o[0] = rl(t10 + o3); o[7] = rl(t10 - o3); o[1] = rl(t11 + o2); o[6] = rl(t11 - o2);
         o[2] = rl(t12 + o1); o[5] = rl(t12 - o1); o[3] = rl(t13 + o0); o[4] = rl(t13 - o0);

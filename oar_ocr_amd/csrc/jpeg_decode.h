@@ -7,6 +7,30 @@
 namespace oar {
 namespace img {
 
+#if defined(__HIPCC__)
+#define OAR_JPEG_HD __host__ __device__
+#else
+#define OAR_JPEG_HD
+#endif
+// The inverse DCT's 32-bit arithmetic.  On a valid stream no intermediate leaves int32 (jidctint.c's own range analysis); coefficients
+// of a corrupt one can, and there libjpeg's arithmetic wraps.  An int that overflows is undefined in C++, so the sums and products are
+// carried in uint32 (defined wrap-around, the same bits) and only the shifts look at the value as signed.  Host renderer and device
+// kernel share the type, so they also agree on garbage.
+struct W32 {
+    uint32_t u;
+    W32() = default;
+    OAR_JPEG_HD constexpr W32(int v) : u((uint32_t)v) {}
+    OAR_JPEG_HD static constexpr W32 raw(uint32_t x) { W32 r(0); r.u = x; return r; }
+    OAR_JPEG_HD constexpr int s() const { return (int)u; }
+    OAR_JPEG_HD friend constexpr W32 operator+(W32 a, W32 b) { return raw(a.u + b.u); }
+    OAR_JPEG_HD friend constexpr W32 operator-(W32 a, W32 b) { return raw(a.u - b.u); }
+    OAR_JPEG_HD friend constexpr W32 operator*(W32 a, W32 b) { return raw(a.u * b.u); }
+    OAR_JPEG_HD W32& operator+=(W32 b) { u += b.u; return *this; }
+    OAR_JPEG_HD W32& operator*=(W32 b) { u *= b.u; return *this; }
+    OAR_JPEG_HD constexpr W32 shl(int n) const { return raw(u << n); }
+    OAR_JPEG_HD constexpr int sra(int n) const { return (int)u >> n; }   // arithmetic shift of the two's-complement value
+};
+
 struct JpegComp {
     int h = 1, v = 1;            // sampling factors
     int bw = 0, bh = 0;          // blocks per row / column of the coefficient plane (padded to whole MCUs)
