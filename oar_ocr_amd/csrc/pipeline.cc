@@ -599,7 +599,8 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
     std::vector<int> sb_off{0};
     {
         const int base = std::min(B, kSub);
-        const int last = B > base ? std::max(1, base / 2) : 0;
+        static const int last_env = [] { const char* e = getenv("OAR_DET_LAST"); return e ? atoi(e) : 0; }();   // (A/B knob: pages in the last sub-batch)
+        const int last = B > base ? (last_env > 0 ? std::min(last_env, base) : std::max(1, base / 2)) : 0;
         const int first = (first_half && host_pages && B - last > base) ? std::max(1, base / 2) : 0;
         int rest = B - last - first;
         if (first) sb_off.push_back(first);
