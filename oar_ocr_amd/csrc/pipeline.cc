@@ -17,7 +17,7 @@ struct PhaseTimer {  // OAR_TIMING=1: prints host-side phase times of each predi
     std::chrono::steady_clock::time_point t0;
     std::vector<std::pair<const char*, double>> marks;
     PhaseTimer() {
-        static const bool en = [] { const char* e = getenv("OAR_TIMING"); return e && e[0] == '1'; }();
+        static const bool en = [] { const char* e = getenv("OAR_TIMING"); return e && (e[0] == '1' || e[0] == '2'); }();
         on = en;
         t0 = std::chrono::steady_clock::now();
     }
@@ -29,6 +29,12 @@ struct PhaseTimer {  // OAR_TIMING=1: prints host-side phase times of each predi
     }
     void dump(const char* title) {
         if (!on) return;
+        static const bool seq = [] { const char* e = getenv("OAR_TIMING"); return e && e[0] == '2'; }();   // 2: the marks in order, not summed by name
+        if (seq) {
+            fprintf(stderr, "[timing] %s (sequence):", title);
+            for (auto& m : marks) fprintf(stderr, " %s=%.2f", m.first, m.second);
+            fprintf(stderr, "\n");
+        }
         std::map<std::string, double> agg;
         std::vector<std::string> order;
         for (auto& m : marks) { if (!agg.count(m.first)) order.push_back(m.first); agg[m.first] += m.second; }
@@ -436,36 +442,44 @@ void subbatch_candidates_traced(ThreadPool& pool, const uint32_t* ctrl, const pp
 }
 
 // `gpu_unclip` (optional): the candidates' unclipped polygons as pp::unclip_quads left them (n_pts -1: not handled there)
+// a11-a12 for ONE candidate: score gate -> unclip -> second mini box -> min side -> scale / round / clamp (db_bitmap.rs:255-277); false = dropped
+bool finish_one_box(const Candidate& cd, float score, float box_thresh, float unclip_ratio, float wscale, float hscale, float dwf, float dhf,
+                    const pp::UnclipOut* gpu_unclip, float* pts8) {
+    if (score < box_thresh) return false;
+    std::vector<host::Pt> un;
+    if (gpu_unclip && gpu_unclip->n_pts >= 0) {
+        const pp::UnclipOut& u = *gpu_unclip;
+        un.resize((size_t)u.n_pts);
+        for (int k = 0; k < u.n_pts; ++k) un[k] = {u.pts[k * 2], u.pts[k * 2 + 1]};
+    } else {
+        host::Pt mb[4];
+        for (int k = 0; k < 4; ++k) mb[k] = {cd.pts[k * 2], cd.pts[k * 2 + 1]};
+        un = host::unclip(mb, unclip_ratio);
+    }
+    if (un.empty()) return false;
+    host::Pt bp[4];
+    float sside = 0.f;
+    if (!host::mini_box(un, bp, sside)) return false;
+    if (sside < 3.0f + 2.0f) return false;
+    for (int k = 0; k < 4; ++k) {
+        float x = std::round(bp[k].x * wscale), y = std::round(bp[k].y * hscale);
+        x = x < 0.0f ? 0.0f : (x > dwf ? dwf : x);
+        y = y < 0.0f ? 0.0f : (y > dhf ? dhf : y);
+        pts8[k * 2] = x; pts8[k * 2 + 1] = y;
+    }
+    return true;
+}
+
 void finish_boxes(const std::vector<Candidate>& cands, const float* scores, int H, int W, uint32_t src_w, uint32_t src_h, float box_thresh,
                   float unclip_ratio, DetBoxes& out, const pp::UnclipOut* gpu_unclip = nullptr) {
     out.pts.clear(); out.scores.clear();
     const float wscale = (float)src_w / (float)W, hscale = (float)src_h / (float)H;
     const float dwf = (float)src_w, dhf = (float)src_h;
-    std::vector<host::Pt> un;
     for (size_t i = 0; i < cands.size(); ++i) {
-        float score = scores[i];
-        if (score < box_thresh) continue;
-        if (gpu_unclip && gpu_unclip[i].n_pts >= 0) {
-            const pp::UnclipOut& u = gpu_unclip[i];
-            un.resize((size_t)u.n_pts);
-            for (int k = 0; k < u.n_pts; ++k) un[k] = {u.pts[k * 2], u.pts[k * 2 + 1]};
-        } else {
-            host::Pt mb[4];
-            for (int k = 0; k < 4; ++k) mb[k] = {cands[i].pts[k * 2], cands[i].pts[k * 2 + 1]};
-            un = host::unclip(mb, unclip_ratio);
-        }
-        if (un.empty()) continue;
-        host::Pt bp[4];
-        float sside = 0.f;
-        if (!host::mini_box(un, bp, sside)) continue;
-        if (sside < 3.0f + 2.0f) continue;
-        for (int k = 0; k < 4; ++k) {
-            float x = std::round(bp[k].x * wscale), y = std::round(bp[k].y * hscale);
-            x = x < 0.0f ? 0.0f : (x > dwf ? dwf : x);
-            y = y < 0.0f ? 0.0f : (y > dhf ? dhf : y);
-            out.pts.push_back(x); out.pts.push_back(y);
-        }
-        out.scores.push_back(score);
+        float p8[8];
+        if (!finish_one_box(cands[i], scores[i], box_thresh, unclip_ratio, wscale, hscale, dwf, dhf, gpu_unclip ? gpu_unclip + i : nullptr, p8)) continue;
+        out.pts.insert(out.pts.end(), p8, p8 + 8);
+        out.scores.push_back(scores[i]);
     }
 }
 
@@ -760,17 +774,60 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
         if (sl.total) OAR_HIP(hipEventSynchronize(score_done_[sb]));
         tmark("box_scores_wait");
         const float* sc = sl.scores_host.as<float>();
-        pool_->parallel_for(nb, [&](int k) {
-            const PageRef& pg = pages[idx[b0 + k]];
-            if (cfg_.box_type == 1) finish_polys(cands[b0 + k], sc + sl.base[k], H, W, pg.w, pg.h, box_thresh, unclip, out[idx[b0 + k]]);
-            else finish_boxes(cands[b0 + k], sc + sl.base[k], H, W, pg.w, pg.h, box_thresh, unclip, out[idx[b0 + k]],
-                              sl.unclipped ? sl.unclip_host.as<pp::UnclipOut>() + sl.base[k] : nullptr);
-        });
+        static const bool chunked = [] { const char* e = getenv("OAR_FINISH_CHUNKS"); return !e || atoi(e) != 0; }();   // 0: one task per page (A/B)
+        if (cfg_.box_type == 1 || !chunked) {
+            pool_->parallel_for(nb, [&](int k) {
+                const PageRef& pg = pages[idx[b0 + k]];
+                if (cfg_.box_type == 1) finish_polys(cands[b0 + k], sc + sl.base[k], H, W, pg.w, pg.h, box_thresh, unclip, out[idx[b0 + k]]);
+                else finish_boxes(cands[b0 + k], sc + sl.base[k], H, W, pg.w, pg.h, box_thresh, unclip, out[idx[b0 + k]],
+                                  sl.unclipped ? sl.unclip_host.as<pp::UnclipOut>() + sl.base[k] : nullptr);
+            });
+        } else {
+            // quads: chunks of 8 candidates over the whole pool (a sub-batch is 4-8 pages: one task per page left most workers idle while the
+            // GPU waited for the detection phase's host side); kept candidates are gathered in discovery order afterwards
+            struct Chunk { int k; size_t c0, c1; };
+            std::vector<Chunk> chunks;
+            for (int k = 0; k < nb; ++k)
+                for (size_t c0 = 0; c0 < cands[b0 + k].size(); c0 += 8) chunks.push_back({k, c0, std::min(cands[b0 + k].size(), c0 + 8)});
+            finish_pts_.resize(sl.total * 8); finish_ok_.assign(sl.total, 0);
+            const pp::UnclipOut* gu = sl.unclipped ? sl.unclip_host.as<pp::UnclipOut>() : nullptr;
+            pool_->parallel_for((int)chunks.size(), [&](int ci) {
+                const Chunk& ch = chunks[ci];
+                const PageRef& pg = pages[idx[b0 + ch.k]];
+                const float wscale = (float)pg.w / (float)W, hscale = (float)pg.h / (float)H;
+                for (size_t c = ch.c0; c < ch.c1; ++c) {
+                    const size_t g = sl.base[ch.k] + c;
+                    finish_ok_[g] = finish_one_box(cands[b0 + ch.k][c], sc[g], box_thresh, unclip, wscale, hscale, (float)pg.w, (float)pg.h, gu ? gu + g : nullptr,
+                                                   finish_pts_.data() + g * 8) ? 1 : 0;
+                }
+            });
+            for (int k = 0; k < nb; ++k) {
+                DetBoxes& o = out[idx[b0 + k]];
+                o.pts.clear(); o.scores.clear();
+                for (size_t c = 0; c < cands[b0 + k].size(); ++c) {
+                    const size_t g = sl.base[k] + c;
+                    if (!finish_ok_[g]) continue;
+                    o.pts.insert(o.pts.end(), finish_pts_.data() + g * 8, finish_pts_.data() + g * 8 + 8);
+                    o.scores.push_back(sc[g]);
+                }
+            }
+        }
         tmark("host_unclip");
         if (on_ready) { on_ready(idx[b0], nb); tmark("crop_plan+warp"); }
     };
     auto host_stage = [&](int sb) {
         const int b0 = sb_off[sb], nb = sb_off[sb + 1] - b0;
+        // OAR_DET_FINISH_EARLY=1 (experiment, off): finish(sb - 1) -- scores back, unclip, crop planning of the previous sub-batch -- goes FIRST
+        // when the GPU is still working on this sub-batch's network.  Measured on the bench workload, four alternations on one box
+        // (profiles/r4/host_finish_ab.txt): +3 % twice, -5 % twice -- the detection phase is host-bound there (det_gpu_wait = 0 from the
+        // third sub-batch on), so the order of host work matters less than its amount; what did pay is the chunk-parallel finish() below.
+        static const bool finish_early = [] { const char* e = getenv("OAR_DET_FINISH_EARLY"); return e && atoi(e) != 0; }();
+        bool finished_prev = false;
+        if (sb > 0 && finish_early) {
+            const hipError_t q = hipEventQuery(sub_events_[sb]);
+            if (q == hipErrorNotReady) { (void)hipGetLastError(); finish(sb - 1); finished_prev = true; }   // ("not ready" must not stay behind as the thread's last error)
+            else if (q != hipSuccess) OAR_HIP(q);
+        }
         OAR_HIP(hipEventSynchronize(sub_events_[sb]));
         tmark("det_gpu_wait");
         // BoxType::Poly scores the approximated polygon with box_score_fast whatever score_mode says (db_bitmap.rs:49)
@@ -843,7 +900,7 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
             OAR_HIP(hipEventRecord(score_done_[sb], score_stream_));
         }
         tmark("box_scores_enqueue");
-        if (sb > 0) finish(sb - 1);   // its scores were enqueued one contour pass ago
+        if (sb > 0 && !finished_prev) finish(sb - 1);   // its scores were enqueued one contour pass ago
     };
     // `depth` sub-batches are queued ahead of the one the host works on (OAR_DET_DEPTH, default 1; every buffer a sub-batch's GPU
     // work touches is either per page or used in stream order, so any depth is safe)

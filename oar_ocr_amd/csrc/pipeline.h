@@ -118,6 +118,8 @@ class Detector {
         PinBuf unclip_host; DevBuf unclip_dev; bool unclipped = false;              // a11 on the GPU: pp::UnclipOut per candidate
     };
     std::vector<std::unique_ptr<ScoreSlot>> score_slots_;
+    std::vector<float> finish_pts_;       // finish(): per-candidate results of the chunk-parallel unclip / second mini box
+    std::vector<uint8_t> finish_ok_;
     // mask read-back runs on its own stream: a D2H copy is a blit KERNEL on the queue it is issued to (150 us per 9-page
     // sub-batch over PCIe), which on the engine stream held up the next sub-batch's network
     hipStream_t copy_stream_ = nullptr;

@@ -1,5 +1,7 @@
 """Randomised end-to-end parity sweep: OAROCR (HIP, through the C ABI) against the oracle pipeline on random page sizes,
-line counts, thresholds and batch sizes.  usage: python tools/parity_fuzz.py [n_cases] [seed] [stages|server|seal]"""
+line counts, thresholds and batch sizes.  usage: python tools/parity_fuzz.py [n_cases] [seed] [stages|server|seal|plain] [only_case]
+(only_case: replay that one case of the seeded sequence -- the random draws of the earlier cases are made, nothing is computed for them --
+and print the regions whose boxes differ; also dumps the pages to gpurun_out/fuzz_case_<n>.npz)"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -18,6 +20,7 @@ det, _ = models.build_det("server" if server else "tiny", seed=2 if server else 
 rec, _ = models.build_rec("server" if server else "tiny", vocab=18710 if server else 6906, seed=3 if server else 1)
 chars = api.read_dict(models.synth_dict(18708 if server else 6904))
 max_side = 640 if server else 1100
+only_case = int(sys.argv[4]) if len(sys.argv) > 4 else None
 bad = 0
 t0 = time.time()
 for case in range(n_cases):
@@ -48,6 +51,8 @@ for case in range(n_cases):
             b = b.with_document_image_rectification(uvdoc); stages["rectifier"] = uvdoc
         if rng.random() < 0.6:
             b = b.with_text_line_orientation_classification(cls2); stages["line_orientation"] = cls2
+    if only_case is not None and case != only_case:
+        continue
     ocr = b.build()
     got = ocr.predict(imgs)
     ref = pipeline_ref.OracleOCR(det, rec, chars, thr, bthr, unclip, image_batch_size=ibs, region_batch_size=rbs, **stages, **({"text_type": "seal"} if seal else {})).predict(imgs)
@@ -63,6 +68,16 @@ for case in range(n_cases):
         ok = ok and rep["ok"]
         if not rep["ok"]:
             print("  MISMATCH", rep)
+            if only_case is not None:
+                import os
+                os.makedirs("gpurun_out", exist_ok=True)
+                np.savez_compressed(f"gpurun_out/fuzz_case_{case}.npz", **{f"page{i}": im for i, im in enumerate(imgs)})
+                for q, (gr, rr) in enumerate(zip(g.text_regions, r)):
+                    gb, rb = np.asarray(gr.bounding_box, np.float32), np.asarray(rr["box"], np.float32)
+                    if gb.shape != rb.shape or not np.array_equal(gb, rb):
+                        print(f"  region {q}: product {gb.shape} oracle {rb.shape}")
+                        print("   product", gb.reshape(-1).tolist())
+                        print("   oracle ", rb.reshape(-1).tolist())
     nreg = sum(len(r) for r in ref)
     print(f"case {case}: stages={sorted(stages)} {n_img} pages {[im.shape[:2] for im in imgs]} thr={thr} box={bthr} unclip={unclip} ibs={ibs} rbs={rbs} regions={nreg} {'ok' if ok else 'FAIL'}", flush=True)
     bad += 0 if ok else 1
