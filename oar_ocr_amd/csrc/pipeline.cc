@@ -325,6 +325,7 @@ void contours_to_candidates(ThreadPool& pool, std::vector<std::vector<host::Cont
 void subbatch_candidates(ThreadPool& pool, const uint8_t* masks, size_t hw, int H, int W, int nb, uint32_t max_candidates,
                          std::vector<Candidate>* out /* [nb] */, int keep_contour = kCandFast) {
     const int row_bytes = (W + 7) / 8;
+    const auto t_entry = std::chrono::steady_clock::now();
     // stage 1: contour tracing, parallel over (page, row band) -- bands are cut at fully-blank rows
     struct Band { int page, y0, y1; };
     std::vector<Band> bands;
@@ -355,9 +356,10 @@ void subbatch_candidates(ThreadPool& pool, const uint8_t* masks, size_t hw, int 
         auto tc = std::chrono::steady_clock::now();
         double mx = 0, sum = 0;
         for (double t : tpage) { mx = std::max(mx, t); sum += t; }
-        fprintf(stderr, "[timing]   subbatch nb=%d setup=%.2fms stage1=%.2fms (per-band max %.2f avg %.2f, %zu bands) stage2=%.2fms\n", nb,
+        fprintf(stderr, "[timing]   subbatch nb=%d setup=%.2fms stage1=%.2fms (per-band max %.2f avg %.2f, %zu bands) stage2=%.2fms total=%.2fms\n", nb,
                 std::chrono::duration<double, std::milli>(ta - t_setup).count(), std::chrono::duration<double, std::milli>(tb - ta).count(), mx,
-                sum / std::max<size_t>(tpage.size(), 1), tpage.size(), std::chrono::duration<double, std::milli>(tc - tb).count());
+                sum / std::max<size_t>(tpage.size(), 1), tpage.size(), std::chrono::duration<double, std::milli>(tc - tb).count(),
+                std::chrono::duration<double, std::milli>(tc - t_entry).count());
     }
 }
 
@@ -905,13 +907,46 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
     // `depth` sub-batches are queued ahead of the one the host works on (OAR_DET_DEPTH, default 1; every buffer a sub-batch's GPU
     // work touches is either per page or used in stream order, so any depth is safe)
     static const int depth = [] { const char* e = getenv("OAR_DET_DEPTH"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : v > 8 ? 8 : v; }();
-    int queued = 0;
-    for (; queued < std::min(depth, nsub); ++queued) enqueue(queued);
-    for (int sb = 0; sb < nsub; ++sb) {
-        if (queued < nsub) enqueue(queued++);
-        host_stage(sb);
+    // OAR_DET_ENQ_THREAD (default 1): with three or more sub-batches their GPU work is enqueued by a helper thread, all of it as soon as the
+    // uploads allow (nothing a sub-batch's launches touch depends on the host's results for an earlier one), and this thread only does the
+    // host stages.  The ~100 launches of a sub-batch cost the launching thread 0.13 ms -- 0.5 ms for the first two, which wait for their
+    // pages -- and OAR_TIMING=2 showed the detection phase bounded by this thread (det_gpu_wait = 0 from the third sub-batch on), not by the GPU.
+    static const bool enq_thread = [] { const char* e = getenv("OAR_DET_ENQ_THREAD"); return !e || atoi(e) != 0; }();
+    if (enq_thread && nsub >= 3) {
+        struct Enqueuer {   // declared last: joined before anything its thread refers to goes out of scope
+            std::thread th;
+            std::atomic<int> done{0};
+            std::atomic<bool> failed{false};
+            std::exception_ptr err;
+            ~Enqueuer() { if (th.joinable()) th.join(); }
+        } enq;
+        const int device = eng_->device();
+        enq.th = std::thread([&, device] {
+            try {
+                OAR_HIP(hipSetDevice(device));
+                for (int q = 0; q < nsub; ++q) { enqueue(q); enq.done.store(q + 1, std::memory_order_release); }
+            } catch (...) {
+                enq.err = std::current_exception();
+                enq.failed.store(true, std::memory_order_release);
+            }
+        });
+        for (int sb = 0; sb < nsub; ++sb) {
+            while (enq.done.load(std::memory_order_acquire) <= sb && !enq.failed.load(std::memory_order_acquire)) cpu_relax();   // (an event must be recorded before it is waited for)
+            if (enq.failed.load(std::memory_order_acquire)) { enq.th.join(); std::rethrow_exception(enq.err); }
+            host_stage(sb);
+        }
+        finish(nsub - 1);
+        enq.th.join();
+        if (enq.failed.load(std::memory_order_acquire)) std::rethrow_exception(enq.err);
+    } else {
+        int queued = 0;
+        for (; queued < std::min(depth, nsub); ++queued) enqueue(queued);
+        for (int sb = 0; sb < nsub; ++sb) {
+            if (queued < nsub) enqueue(queued++);
+            host_stage(sb);
+        }
+        finish(nsub - 1);
     }
-    finish(nsub - 1);
     if (Profiler::get().enabled) Profiler::get().flush();
 }
 

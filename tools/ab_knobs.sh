@@ -8,9 +8,9 @@ print("$name", d["value"], d["ms_per_step"], "frac", d["roofline"]["frac"], "us"
 P
 }
 for i in 1 2 3 4; do
-run old$i OAR_FINISH_CHUNKS=0 OAR_DET_FINISH_EARLY=0
-run chunks$i OAR_FINISH_CHUNKS=1 OAR_DET_FINISH_EARLY=0
-run early$i OAR_FINISH_CHUNKS=0 OAR_DET_FINISH_EARLY=1
-run both$i X=1
-run both_last2_$i OAR_DET_LAST=2
+run base$i X=1
+run early$i OAR_DET_FINISH_EARLY=1
+run sub6_$i OAR_DET_SUB=6
+run sub4_$i OAR_DET_SUB=4
+run last2_$i OAR_DET_LAST=2
 done
