@@ -217,6 +217,7 @@ Detector::Detector(const uint8_t* onnx, size_t len, const oar_det_cfg& cfg) : cf
         OAR_HIP(hipStreamCreateWithFlags(&score_stream_, hipStreamNonBlocking));
     }
     OAR_HIP(hipStreamCreateWithFlags(&upload_stream_, hipStreamNonBlocking));
+    OAR_HIP(hipStreamCreateWithFlags(&upload_stream2_, hipStreamNonBlocking));
     OAR_HIP(hipEventCreateWithFlags(&stage_free_, hipEventDisableTiming));
 }
 Detector::~Detector() {
@@ -224,8 +225,10 @@ Detector::~Detector() {
     if (copy_stream_) { (void)hipStreamSynchronize(copy_stream_); (void)hipStreamDestroy(copy_stream_); }
     if (score_stream_) { (void)hipStreamSynchronize(score_stream_); (void)hipStreamDestroy(score_stream_); }
     if (upload_stream_) { (void)hipStreamSynchronize(upload_stream_); (void)hipStreamDestroy(upload_stream_); }
+    if (upload_stream2_) { (void)hipStreamSynchronize(upload_stream2_); (void)hipStreamDestroy(upload_stream2_); }
     if (stage_free_) (void)hipEventDestroy(stage_free_);
     for (hipEvent_t e : upload_done_) (void)hipEventDestroy(e);
+    for (hipEvent_t e : upload_done2_) (void)hipEventDestroy(e);
     for (hipEvent_t e : sub_events_) (void)hipEventDestroy(e);
     for (hipEvent_t e : mask_ready_) (void)hipEventDestroy(e);
     for (hipEvent_t e : score_done_) (void)hipEventDestroy(e);
@@ -535,11 +538,12 @@ void Detector::run(const std::vector<PageRef>& pages, float thresh, float box_th
         OAR_CHECK(p.w > 0 && p.h > 0 && (p.host || p.dev), OAR_INVALID_INPUT, "detector: empty page");
         if (!p.dev) total += ((size_t)p.w * p.h * 3 + 255) & ~(size_t)255;
     }
-    if (total > pages_dev_.cap) { OAR_HIP(hipStreamSynchronize(s)); OAR_HIP(hipStreamSynchronize(upload_stream_)); pages_dev_.reserve(total); }
+    if (total > pages_dev_.cap) { OAR_HIP(hipStreamSynchronize(s)); OAR_HIP(hipStreamSynchronize(upload_stream_)); OAR_HIP(hipStreamSynchronize(upload_stream2_)); pages_dev_.reserve(total); }
     // whatever still reads the staging area on the engine stream (the previous call's crop kernels) must be done before
     // this call's uploads overwrite it
     OAR_HIP(hipEventRecord(stage_free_, s));
     OAR_HIP(hipStreamWaitEvent(upload_stream_, stage_free_, 0));
+    OAR_HIP(hipStreamWaitEvent(upload_stream2_, stage_free_, 0));
     page_ptrs_.assign(n, nullptr);
     upload_src_.assign(n, nullptr);
     size_t off = 0;
@@ -667,35 +671,44 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
     // hipMemcpyAsync occupies its CALLING thread for the whole copy (~0.7 ms per 8 pages of 960^2), so the copies are issued
     // from a helper thread while this one keeps the kernel queue full; `issued` counts the sub-batches whose upload (and
     // the event that follows it) has been submitted -- an event must be recorded before a stream can wait on it.
+    // OAR_UPLOAD_THREADS (1 or 2, default 1): with 2, two helper threads on two streams take alternate pages of every sub-batch (one thread's
+    // staged copy runs at ~31 GB/s, barely ahead of the detector -- 11 pages / ms against 8 -- and the first sub-batch's upload is exposed).
+    // Measured on the bench workload, five alternations on one box: 2198 images/s against 2221 with one thread -- no gain, stays off.
+    static const int n_up = [] { const char* e = getenv("OAR_UPLOAD_THREADS"); const int v = e ? atoi(e) : 1; return v >= 2 ? 2 : 1; }();
+    while ((int)upload_done2_.size() < nsub) { hipEvent_t e; OAR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); upload_done2_.push_back(e); }
     struct Uploader {
-        std::thread th;
-        std::atomic<int> issued{0};
+        std::thread th[2];
+        std::atomic<int> issued[2];
         std::atomic<bool> failed{false};
+        std::mutex mu;
         std::string error;
-        ~Uploader() { if (th.joinable()) th.join(); }
+        Uploader() { issued[0].store(0); issued[1].store(0); }
+        ~Uploader() { for (auto& t : th) if (t.joinable()) t.join(); }
     } up;
     bool any_upload = false;
     for (int b = 0; b < B; ++b) any_upload = any_upload || upload_src_[idx[b]] != nullptr;
     if (any_upload) {
         const int device = eng_->device();
-        up.th = std::thread([&, device] {
-            try {
-                OAR_HIP(hipSetDevice(device));
-                for (int sb = 0; sb < nsub; ++sb) {
-                    for (int k = sb_off[sb]; k < sb_off[sb + 1]; ++k) {
-                        const int pi = idx[k];
-                        if (!upload_src_[pi]) continue;
-                        OAR_HIP(hipMemcpyAsync(const_cast<uint8_t*>(page_ptrs_[pi]), upload_src_[pi], (size_t)pages[pi].w * pages[pi].h * 3, hipMemcpyHostToDevice, upload_stream_));
-                        upload_src_[pi] = nullptr;
+        for (int t = 0; t < n_up; ++t)
+            up.th[t] = std::thread([&, device, t] {
+                try {
+                    OAR_HIP(hipSetDevice(device));
+                    hipStream_t us = t == 0 ? upload_stream_ : upload_stream2_;
+                    for (int sb = 0; sb < nsub; ++sb) {
+                        for (int k = sb_off[sb] + t; k < sb_off[sb + 1]; k += n_up) {
+                            const int pi = idx[k];
+                            if (!upload_src_[pi]) continue;
+                            OAR_HIP(hipMemcpyAsync(const_cast<uint8_t*>(page_ptrs_[pi]), upload_src_[pi], (size_t)pages[pi].w * pages[pi].h * 3, hipMemcpyHostToDevice, us));
+                            upload_src_[pi] = nullptr;
+                        }
+                        OAR_HIP(hipEventRecord(t == 0 ? upload_done_[sb] : upload_done2_[sb], us));
+                        up.issued[t].store(sb + 1, std::memory_order_release);
                     }
-                    OAR_HIP(hipEventRecord(upload_done_[sb], upload_stream_));
-                    up.issued.store(sb + 1, std::memory_order_release);
+                } catch (const std::exception& e) {
+                    { std::lock_guard<std::mutex> lk(up.mu); up.error = e.what(); }
+                    up.failed.store(true, std::memory_order_release);
                 }
-            } catch (const std::exception& e) {
-                up.error = e.what();
-                up.failed.store(true, std::memory_order_release);
-            }
-        });
+            });
     }
 
     size_t rs_off = 0;
@@ -704,9 +717,11 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
         const int b0 = sb_off[sb], nb = sb_off[sb + 1] - b0;
         const uint8_t* srcs[32];
         if (any_upload) {
-            while (up.issued.load(std::memory_order_acquire) <= sb && !up.failed.load(std::memory_order_acquire)) cpu_relax();
-            if (up.failed.load(std::memory_order_acquire)) fail(OAR_DEVICE, "page upload failed: " + up.error);
+            for (int t = 0; t < n_up; ++t)
+                while (up.issued[t].load(std::memory_order_acquire) <= sb && !up.failed.load(std::memory_order_acquire)) cpu_relax();
+            if (up.failed.load(std::memory_order_acquire)) { std::lock_guard<std::mutex> lk(up.mu); fail(OAR_DEVICE, "page upload failed: " + up.error); }
             OAR_HIP(hipStreamWaitEvent(s, upload_done_[sb], 0));
+            if (n_up > 1) OAR_HIP(hipStreamWaitEvent(s, upload_done2_[sb], 0));
         }
         for (int k = 0; k < nb; ++k) {
             const int pi = idx[b0 + k];
@@ -770,6 +785,8 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
     const uint32_t maxc = cfg_.max_candidates;
     while ((int)score_slots_.size() < nsub) score_slots_.emplace_back(new ScoreSlot());
     while ((int)score_done_.size() < nsub) { hipEvent_t e; OAR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); score_done_.push_back(e); }
+    static const bool enq_thread = [] { const char* e = getenv("OAR_DET_ENQ_THREAD"); return !e || atoi(e) != 0; }();
+    const bool helper_enqueues = enq_thread && nsub >= 3;
     auto finish = [&](int sb) {
         const int b0 = sb_off[sb], nb = sb_off[sb + 1] - b0;
         ScoreSlot& sl = *score_slots_[sb];
@@ -819,11 +836,14 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
     };
     auto host_stage = [&](int sb) {
         const int b0 = sb_off[sb], nb = sb_off[sb + 1] - b0;
-        // OAR_DET_FINISH_EARLY=1 (experiment, off): finish(sb - 1) -- scores back, unclip, crop planning of the previous sub-batch -- goes FIRST
-        // when the GPU is still working on this sub-batch's network.  Measured on the bench workload, four alternations on one box
-        // (profiles/r4/host_finish_ab.txt): +3 % twice, -5 % twice -- the detection phase is host-bound there (det_gpu_wait = 0 from the
-        // third sub-batch on), so the order of host work matters less than its amount; what did pay is the chunk-parallel finish() below.
-        static const bool finish_early = [] { const char* e = getenv("OAR_DET_FINISH_EARLY"); return e && atoi(e) != 0; }();
+        // finish(sb - 1) -- scores back, unclip, crop planning of the previous sub-batch -- goes FIRST when the GPU is still working on this
+        // sub-batch's network.  With the helper thread enqueueing (below) the host stages never hold the GPU up, so the order only matters
+        // after the LAST sub-batch, where everything this thread still has to do is exposed between detector and recognizer (1.0-1.4 ms of
+        // idle queue per step in the rocprofv3 kernel trace): whatever can be done before that network ends should be.  On by default with the
+        // helper thread (+0.9 % over four A/B pairs, profiles/r4/host_finish_ab.txt); without it -- the calling thread then also has to
+        // enqueue -- it measured +3 / +3 / -5 / -5 % and stays off.  OAR_DET_FINISH_EARLY=0|1 overrides.
+        static const int finish_early_env = [] { const char* e = getenv("OAR_DET_FINISH_EARLY"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+        const bool finish_early = finish_early_env >= 0 ? finish_early_env == 1 : helper_enqueues;
         bool finished_prev = false;
         if (sb > 0 && finish_early) {
             const hipError_t q = hipEventQuery(sub_events_[sb]);
@@ -911,8 +931,7 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
     // uploads allow (nothing a sub-batch's launches touch depends on the host's results for an earlier one), and this thread only does the
     // host stages.  The ~100 launches of a sub-batch cost the launching thread 0.13 ms -- 0.5 ms for the first two, which wait for their
     // pages -- and OAR_TIMING=2 showed the detection phase bounded by this thread (det_gpu_wait = 0 from the third sub-batch on), not by the GPU.
-    static const bool enq_thread = [] { const char* e = getenv("OAR_DET_ENQ_THREAD"); return !e || atoi(e) != 0; }();
-    if (enq_thread && nsub >= 3) {
+    if (helper_enqueues) {
         struct Enqueuer {   // declared last: joined before anything its thread refers to goes out of scope
             std::thread th;
             std::atomic<int> done{0};

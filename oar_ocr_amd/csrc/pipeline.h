@@ -123,9 +123,10 @@ class Detector {
     // mask read-back runs on its own stream: a D2H copy is a blit KERNEL on the queue it is issued to (150 us per 9-page
     // sub-batch over PCIe), which on the engine stream held up the next sub-batch's network
     hipStream_t copy_stream_ = nullptr;
+    hipStream_t upload_stream2_ = nullptr; // second uploader thread's stream (alternate pages of a sub-batch)
     hipStream_t upload_stream_ = nullptr;  // host pages -> HBM, one sub-batch ahead of the network
     hipEvent_t stage_free_ = nullptr;
-    std::vector<hipEvent_t> upload_done_;
+    std::vector<hipEvent_t> upload_done_, upload_done2_;
     std::vector<const uint8_t*> upload_src_;   // per page: host source still to be uploaded (nullptr = resident)
     hipStream_t score_stream_ = nullptr;   // box-score round trips (not behind the queued mask copies of later sub-batches)
     PinBuf mask_host_;

@@ -7,10 +7,9 @@ d=json.load(open("gpurun_out/s4/ab_$name.json"))
 print("$name", d["value"], d["ms_per_step"], "frac", d["roofline"]["frac"], "us", d["roofline"]["avg_launch_us"], "devres", (d.get("device_resident") or {}).get("value"))
 P
 }
-for i in 1 2 3 4; do
+for i in 1 2 3 4 5; do
 run base$i X=1
-run early$i OAR_DET_FINISH_EARLY=1
-run sub6_$i OAR_DET_SUB=6
-run sub4_$i OAR_DET_SUB=4
 run last2_$i OAR_DET_LAST=2
+run last3_$i OAR_DET_LAST=3
+run spin$i OAR_POOL_SPIN_MS=5
 done
