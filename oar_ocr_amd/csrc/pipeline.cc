@@ -342,8 +342,13 @@ void subbatch_candidates(ThreadPool& pool, const uint8_t* masks, size_t hw, int 
     std::vector<std::vector<host::Contour>> band_cs(bands.size());
     std::vector<double> tpage(bands.size(), 0.0);
     auto ta = std::chrono::steady_clock::now();
-    pool.parallel_for((int)bands.size(), [&](int i) {
+    // tallest bands first: the pool hands out indices in order, and a tall band claimed last would be the whole tail of the stage
+    std::vector<int> by_rows(bands.size());
+    for (size_t i = 0; i < bands.size(); ++i) by_rows[i] = (int)i;
+    std::stable_sort(by_rows.begin(), by_rows.end(), [&](int a, int b) { return bands[a].y1 - bands[a].y0 > bands[b].y1 - bands[b].y0; });
+    pool.parallel_for((int)bands.size(), [&](int slot) {
         auto t0 = std::chrono::steady_clock::now();
+        const int i = by_rows[slot];
         const Band& bd = bands[i];
         band_cs[i] = host::find_contours_band_bits(masks + (size_t)bd.page * hw, row_bytes, W, bd.y0, bd.y1, max_candidates);
         tpage[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

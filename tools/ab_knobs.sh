@@ -7,9 +7,8 @@ d=json.load(open("gpurun_out/s4/ab_$name.json"))
 print("$name", d["value"], d["ms_per_step"], "frac", d["roofline"]["frac"], "us", d["roofline"]["avg_launch_us"], "devres", (d.get("device_resident") or {}).get("value"))
 P
 }
-for i in 1 2 3 4 5; do
+for i in 1 2 3; do
 run base$i X=1
-run last2_$i OAR_DET_LAST=2
-run last3_$i OAR_DET_LAST=3
-run spin$i OAR_POOL_SPIN_MS=5
+run bands3_$i OAR_BANDS_MULT=3
 done
+OAR_TIMING=2 python tools/host_entry_breakdown.py 2>&1 | grep -E "subbatch" | tail -5
