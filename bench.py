@@ -98,7 +98,10 @@ def cgroup_cpu_quota():
 def pin_rank_to_its_cores(local_rank: int, local_world: int) -> int:
     """One process per GPU shares the host: give each rank a contiguous slice of the cores BEFORE its geometry pool is
     created (threads inherit the affinity), so that N spinning pools never compete for a core.  Returns the rank's CPU
-    budget = min(slice size, its share of the container's CPU quota)."""
+    budget = min(slice size, its share of the container's CPU quota).  (Tried at the end of round 4 and dropped: pinning a rank
+    whose quota share is smaller than its slice to `budget` cores from inside the process -- 1855-2037 images/s against 2108-2190
+    floating on the 1-GPU box, although `taskset -c 0-15 python bench.py` from outside measures 2246-2330:
+    profiles/r4/host_cores_sweep.txt.)"""
     quota = cgroup_cpu_quota()
     if not hasattr(os, "sched_getaffinity"):
         per = max(1, (os.cpu_count() or 1) // max(local_world, 1))
@@ -188,7 +191,13 @@ def main():
         builder = (api.OAROCRBuilder(det, rec, chars).text_detection_config(cfg).image_batch_size(image_batch)
                    .region_batch_size(args.region_batch).device(dev))
         if world > 1:
-            builder = builder.host_threads(max(2, min(16, cores)))   # this rank's geometry pool stays inside its CPU budget
+            # this rank's geometry pool stays inside its CPU budget, and on a slice of six or more pinned cores it leaves two of them to the call's
+            # uploader / enqueuer threads (profiles/r4/host_cores_sweep.txt: 8 pinned cores 1600-1750 images/s with a pool of 8, 2165-2177 with 6)
+            ht = max(2, min(16, cores))
+            aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 0
+            if aff >= 6 and ht > aff - 2:
+                ht = aff - 2
+            builder = builder.host_threads(ht)
             # (round 2 switched to the GPU border follower below 6 cores per rank; measured in round 3, profiles/r3/gpu_contours_breakeven.txt:
             # the host tracer wins at EVERY pool size -- 1 thread 1002 vs 903 images/s, 2 threads 1301 vs 958, 4 threads 1635 vs 967 -- so
             # the switch is gone; oar_det_cfg.gpu_contours / OAR_GPU_CONTOURS remain as a knob)

@@ -70,7 +70,19 @@ int ThreadPool::available_cpus() {
 
 ThreadPool::ThreadPool(int n) {
     if (n <= 0) { const char* e = getenv("OAR_HOST_THREADS"); n = e ? atoi(e) : 0; }
-    if (n <= 0) n = std::min<int>(available_cpus(), 16);
+    // default: the CPUs this process may use (affinity mask and container quota), at most 16 -- and at most the affinity mask minus two when
+    // that mask has six or more CPUs: a predict() also runs an uploader and an enqueuer thread next to the caller, and on a rank PINNED to
+    // its slice of the host, polling workers on every core of the slice starve them.  Measured with taskset on the bench workload
+    // (profiles/r4/host_cores_sweep.txt): 8 cores 1600-1750 images/s with a pool of 8, 2165-2177 with 6; 16 cores 1650-1990 with 16, 2167-2310
+    // with 14; 4 cores 1757-1778 with 4 = 1752-1763 with 3; 2 cores 1359-1417 with 2, 1075-1093 with 1.  (A CPU-time quota alone -- 16 CPUs
+    // of a 256-thread host on the 1-GPU bench box -- does not have the problem: threads float, 16 measured >= 14 there.)
+    if (n <= 0) {
+        n = std::min<int>(available_cpus(), 16);
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        const int aff = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : 0;
+        if (aff >= 6 && n > aff - 2) n = aff - 2;
+    }
     if (n <= 0) n = 1;
     if (n > 64) n = 64;
     for (int i = 0; i < n - 1; ++i) workers_.emplace_back([this] { loop(); });
@@ -87,6 +99,16 @@ static inline void cpu_relax() {
 #if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
 #endif
+}
+// Wait for another THREAD of this call (uploader / enqueuer): poll briefly, then give the core away on every round -- on a rank with two
+// or four cores the thread waited for may not be running at all while this one spins (measured with taskset: device-resident throughput
+// fell by 30 % at 2 cores when the waits only polled).
+template <typename Pred>
+static inline void wait_for_thread(Pred done) {
+    for (int spins = 0; !done(); ++spins) {
+        if (spins < 256) cpu_relax();
+        else std::this_thread::yield();
+    }
 }
 void ThreadPool::loop() {
     // OAR_POOL_SPIN_MS: how long an idle worker keeps polling before it parks (default 25 ms ~ one predict() of the
@@ -723,7 +745,7 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
         const uint8_t* srcs[32];
         if (any_upload) {
             for (int t = 0; t < n_up; ++t)
-                while (up.issued[t].load(std::memory_order_acquire) <= sb && !up.failed.load(std::memory_order_acquire)) cpu_relax();
+                wait_for_thread([&] { return up.issued[t].load(std::memory_order_acquire) > sb || up.failed.load(std::memory_order_acquire); });
             if (up.failed.load(std::memory_order_acquire)) { std::lock_guard<std::mutex> lk(up.mu); fail(OAR_DEVICE, "page upload failed: " + up.error); }
             OAR_HIP(hipStreamWaitEvent(s, upload_done_[sb], 0));
             if (n_up > 1) OAR_HIP(hipStreamWaitEvent(s, upload_done2_[sb], 0));
@@ -955,7 +977,7 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
             }
         });
         for (int sb = 0; sb < nsub; ++sb) {
-            while (enq.done.load(std::memory_order_acquire) <= sb && !enq.failed.load(std::memory_order_acquire)) cpu_relax();   // (an event must be recorded before it is waited for)
+            wait_for_thread([&] { return enq.done.load(std::memory_order_acquire) > sb || enq.failed.load(std::memory_order_acquire); });   // (an event must be recorded before it is waited for)
             if (enq.failed.load(std::memory_order_acquire)) { enq.th.join(); std::rethrow_exception(enq.err); }
             host_stage(sb);
         }
