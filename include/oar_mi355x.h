@@ -145,7 +145,9 @@ typedef struct {
     uint32_t max_candidates;   /* default 1000 (processors/db_postprocess.rs:79)                        */
     int32_t use_hip_graph;
     int32_t profile;
-    int32_t host_threads;      /* worker threads for the serial contour/geometry stage (0 = hw conc.)   */
+    int32_t host_threads;      /* threads of the contour / geometry pool, the caller included (0 = the CPUs this process may use --
+                                * affinity mask and container quota --, at most 16, and at most the affinity mask minus 2 when it has
+                                * >= 6 CPUs: a call also runs one uploader and one enqueuer thread)                                  */
     /* DBPostProcess options the adapter exposes (processors/db_postprocess.rs:60-98, processors/types.rs):          */
     int32_t box_type;          /* 0 = BoxType::Quad (default), 1 = BoxType::Poly (seal / curved text: polygons_from_bitmap, db_bitmap.rs:16-82;
                                   results carry point_offsets) */
