@@ -1,4 +1,14 @@
+# A/B of run-time knobs on the bench workload: alternating runs on one box.  usage: bash tools/ab_knobs.sh  (writes gpurun_out/s4/ab_*.json)
 mkdir -p gpurun_out/s4
-for i in 1 2; do python bench.py --cpu-pages 0 --steps 20 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('default:', d['value'], d['ms_per_step'], (d.get('device_resident') or {}).get('value'), (d.get('pipelined') or {}).get('value'))"; done
-OAR_DIST_BACKEND=gloo python bench.py --gpus 2 --cpu-pages 0 --steps 10 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('2 ranks on one GPU (gloo):', d['value'], d['ms_per_step'], d['config'].get('host_cores_per_rank'))"
-OAR_DIST_BACKEND=gloo python bench.py --gpus 8 --config 3 --cpu-pages 0 --steps 2 --warmup 1 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('8 ranks on one GPU (gloo), config 3:', d['value'], d['ms_per_step'], d['config'].get('host_cores_per_rank'), d['scaling'])"
+B="python bench.py --cpu-pages 0 --steps 20"
+run() { name=$1; shift; env "$@" $B > gpurun_out/s4/ab_$name.json 2> gpurun_out/s4/ab_$name.err; python - <<P
+import json
+d=json.load(open("gpurun_out/s4/ab_$name.json"))
+print("$name", d["value"], d["ms_per_step"], "devres", (d.get("device_resident") or {}).get("value"), "pipelined", (d.get("pipelined") or {}).get("value"))
+P
+}
+for i in 1 2 3 4; do
+run new_$i X=1
+run nothread_$i OAR_DET_ENQ_THREAD=0
+run old_$i OAR_DET_ENQ_THREAD=0 OAR_DET_FINISH_EARLY=0 OAR_FINISH_CHUNKS=0
+done
