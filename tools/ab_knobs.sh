@@ -1,14 +1,15 @@
-# A/B of run-time knobs on the bench workload: alternating runs on one box.  usage: bash tools/ab_knobs.sh  (writes gpurun_out/s4/ab_*.json)
+# where the caller's threads run: floating / taskset from outside / affinity set in-process BEFORE anything touches the HIP runtime
 mkdir -p gpurun_out/s4
-B="python bench.py --cpu-pages 0 --steps 20"
-run() { name=$1; shift; env "$@" $B > gpurun_out/s4/ab_$name.json 2> gpurun_out/s4/ab_$name.err; python - <<P
+ARGS="--cpu-pages 0 --no-pipelined --steps 20"
+show() { python - <<P
 import json
-d=json.load(open("gpurun_out/s4/ab_$name.json"))
-print("$name", d["value"], d["ms_per_step"], "devres", (d.get("device_resident") or {}).get("value"), "pipelined", (d.get("pipelined") or {}).get("value"))
+d=json.load(open("gpurun_out/s4/ab_$1.json"))
+print("$1", d["value"], d["ms_per_step"], "devres", (d.get("device_resident") or {}).get("value"))
 P
 }
-for i in 1 2 3 4; do
-run new_$i X=1
-run nothread_$i OAR_DET_ENQ_THREAD=0
-run old_$i OAR_DET_ENQ_THREAD=0 OAR_DET_FINISH_EARLY=0 OAR_FINISH_CHUNKS=0
+for i in 1 2 3; do
+python bench.py $ARGS > gpurun_out/s4/ab_free_$i.json 2>/dev/null; show free_$i
+taskset -c 0-15 python bench.py $ARGS > gpurun_out/s4/ab_taskset_$i.json 2>/dev/null; show taskset_$i
+python -c "import os, sys, runpy; os.sched_setaffinity(0, range(16)); sys.argv = ['bench.py'] + '$ARGS'.split(); runpy.run_path('bench.py', run_name='__main__')" > gpurun_out/s4/ab_early_inproc_$i.json 2>/dev/null; show early_inproc_$i
+OAR_HOST_THREADS=14 python bench.py $ARGS > gpurun_out/s4/ab_free_ht14_$i.json 2>/dev/null; show free_ht14_$i
 done
