@@ -39,6 +39,9 @@ int dsblock_cs_rows(int ks, int sh, int sw, int nch, int nft) {
     }
 #define OAR_CS_DBG(D) case D: launch_one(dsblock_cs_kernel<5, 1, 1, 12, 12, 4, 1, D>, s, p, grid, lds, e0, e1); return;
 void dsblock_cs_launch(hipStream_t s, const DsCsP& p, int ks, int sh, int sw, int nch, int nft, int acts, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1) {
+    // producer / consumer form (dsblock_pc.inc, round 5) wherever it is instantiated; OAR_DSB_PC=0 keeps the one-wave-per-SIMD kernel (A/B runs)
+    static const bool pc_on = [] { const char* e = getenv("OAR_DSB_PC"); return !e || atoi(e) != 0; }();
+    if (pc_on && dsblock_pc_launch(s, p, ks, sh, sw, nch, nft, acts, grid, e0, e1)) return;
     static const int dbg = [] { const char* e = getenv("OAR_DSB_CS_DBG"); return e ? atoi(e) : 0; }();   // timing ablations of the 192 -> 192 5x5 instantiation (wrong results)
     if (dbg && ks == 5 && nch == 12 && nft == 12 && acts) {
         switch (dbg) {

@@ -3017,8 +3017,7 @@ bool Engine::replay(const Plan& p, const RunCtx& c) {
     // 21.9-23.0 ms without.  The rocprofv3 kernel trace explains it: dependent kernels enqueued one by one already start
     // back to back (median gap 0.00 us), so a graph of kernel nodes has no dispatch gap left to remove; with external
     // event-record nodes (profiler on) replay is 6 % slower.
-    static const bool env_on = [] { const char* e = getenv("OAR_HIP_GRAPH"); return e && atoi(e) != 0; }();
-    if (!env_on || !graphs_ok_ || p.runs == 0) return false;
+    if (!graphs_requested() || !graphs_ok_ || p.runs == 0) return false;
     Profiler& prof = Profiler::get();
     const auto key = std::make_tuple(&p, (const void*)c.input, (const void*)c.arena);
     auto it = graphs_.find(key);

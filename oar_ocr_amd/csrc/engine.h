@@ -3,6 +3,7 @@
 // input, all graph outputs.  Feature maps live in HBM as NHWC ("channels-last"); the ONNX (NCHW) view is
 // only materialised at the boundary.
 #pragma once
+#include <cstdlib>
 #include <functional>
 #include <map>
 #include <memory>
@@ -108,6 +109,10 @@ class Engine {
     // The graph input feeds exactly one node, an RGB stem convolution: the detector may hand the engine its u8 pages
     // (run_stem) and skip the normalised f32 input tensor altogether.
     bool stem_fusable() const { return stem_fusable_; }
+    // true while plans may be captured / replayed as hipGraphs on stream(): capture is a property of the STREAM, so no other thread may
+    // submit to it meanwhile (Detector::run keeps its helper enqueue thread off in that mode)
+    static bool graphs_requested() { static const bool on = [] { const char* e = getenv("OAR_HIP_GRAPH"); return e && atoi(e) != 0; }(); return on; }
+    bool graphs_enabled() const { return graphs_requested() && graphs_ok_; }
     // dims = {n, 3, H, W}; st.pages[0..n) are device pointers to H x W x 3 u8 pages; st.src / alpha / beta as pp::normalize
     // st.dev (device table of per-image pointers / widths, kernels.h): the recognizer's form, any n
     const Plan& run_stem(const k::StemU8& st, const std::vector<int64_t>& dims, bool skip_final_softmax = false);

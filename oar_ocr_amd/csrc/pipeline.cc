@@ -813,7 +813,10 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
     while ((int)score_slots_.size() < nsub) score_slots_.emplace_back(new ScoreSlot());
     while ((int)score_done_.size() < nsub) { hipEvent_t e; OAR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); score_done_.push_back(e); }
     static const bool enq_thread = [] { const char* e = getenv("OAR_DET_ENQ_THREAD"); return !e || atoi(e) != 0; }();
-    const bool helper_enqueues = enq_thread && nsub >= 3;
+    // (with hipGraph replay the engine CAPTURES on the detector stream: the calling thread's crop launches / copies / synchronisations on that
+    // stream would be recorded into -- or invalidate -- the helper's capture, so the helper thread stays off and enqueue / host stages interleave
+    // on one thread as before)
+    const bool helper_enqueues = enq_thread && nsub >= 3 && !eng_->graphs_enabled();
     auto finish = [&](int sb) {
         const int b0 = sb_off[sb], nb = sb_off[sb + 1] - b0;
         ScoreSlot& sl = *score_slots_[sb];

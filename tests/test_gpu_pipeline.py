@@ -262,3 +262,20 @@ def test_soft_probability_maps_boxes_within_the_float_budget():
         near += 1
     assert boxes >= 30 and marginal_px >= 20, (boxes, marginal_px)   # the regime is really exercised
     print(f"soft maps: {exact} pages bit-identical, {near} within the float budget, {boxes} boxes, {marginal_px} pixels within 1e-4 of the threshold")
+
+
+def test_graph_replay_with_three_sub_batches_gives_the_same_pages():
+    """OAR_HIP_GRAPH=1 captures plans on the detector stream; with >= 3 sub-batches the helper enqueue thread would share that stream with the
+    calling thread's crop launches.  Three predicts (plain, capture, replay) in each mode must agree region for region."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    outs = []
+    for graph in ("0", "1"):
+        env = dict(os.environ, OAR_HIP_GRAPH=graph)
+        r = subprocess.run([sys.executable, str(root / "tools" / "graph_check.py")], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l.split()[2:] for l in r.stdout.splitlines() if l.startswith("DIGEST")])
+    assert len(outs[0]) == 3 and outs[0] == outs[1] and len({tuple(d) for d in outs[0]}) == 1 and int(outs[0][0][0]) > 200, outs
