@@ -111,7 +111,18 @@ struct Profiler {
     std::atomic<int> sample_stride{1}, sample_phase{0};
     std::atomic<long> sample_counter{0};
     bool detail = false;  // OAR_PROF_DETAIL=1: split conv classes by shape
-    std::string filter;  // when non-empty only this kernel class is instrumented
+    std::string filter;  // when non-empty only these kernel classes are instrumented: one name, or several separated by commas
+    bool filter_match(const char* name) const {
+        if (filter.empty()) return true;
+        const size_t n = strlen(name);
+        for (size_t pos = 0; pos <= filter.size();) {
+            size_t e = filter.find(',', pos);
+            if (e == std::string::npos) e = filter.size();
+            if (e - pos == n && filter.compare(pos, n, name) == 0) return true;
+            pos = e + 1;
+        }
+        return false;
+    }
     std::vector<std::string> names;
     std::map<std::string, int> index;
     std::vector<oar_prof_entry> totals;
@@ -150,7 +161,7 @@ struct ProfScope {
     // hipExtLaunchKernelGGL (null events = a plain launch).
     ProfScope(hipStream_t s_, const char* name, double bytes, double flops, bool single_launch = false) : s(s_) {
         Profiler& p = Profiler::get();
-        on = p.enabled && (p.filter.empty() || p.filter == name);
+        on = p.enabled && p.filter_match(name);
         if (on && !Profiler::capturing) {   // (a captured graph keeps every event node: sampling cannot vary per replay)
             const int stride = p.sample_stride.load(std::memory_order_relaxed), phase = p.sample_phase.load(std::memory_order_relaxed);
             if (phase < 0) on = false;

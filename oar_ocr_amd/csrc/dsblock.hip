@@ -90,7 +90,7 @@ void dsblock_wa(hipStream_t s, const DsBlockP& b, const WaShape& sh) {
     const double bytes = 4.0 * (px_in * b.C + px_out * b.Cout * (b.residual ? 2 : 1)) + 4.0 * b.ks * b.ks * b.C + 6.0 * b.C * b.Cout;
     const double flops = 2.0 * px_out * b.C * (b.ks * b.ks + (double)b.Cout);
     char pname[96];
-    const char* cls = "dsblock";
+    const char* cls = "dsblock_wa";   // one profiler class per kernel FAMILY (row-streaming: HBM-bound; chunk-streamed: instruction-bound; bench.py roofline.by_family)
     if (Profiler::get().detail) { snprintf(pname, sizeof pname, "dsblock px=%ld C=%d N=%d k3 s1x1 wa%d", (long)px_out, b.C, b.Cout, sh.P); cls = pname; }
     ProfScope ps(s, cls, bytes, flops, true);
     if (sh.nf <= 4) dsblock_wa_launch_a(s, p, sh.nf, (int)grid, sh.lds, ps.start(), ps.stop());
@@ -156,7 +156,7 @@ void dsblock_rs(hipStream_t s, const DsBlockP& b, const RsShape& sh) {
     const double bytes = 4.0 * (px_in * b.C + px_out * b.Cout) + 4.0 * b.ks * b.ks * b.C + 4.0 * b.C * b.Cout;
     const double flops = 2.0 * px_out * b.C * (b.ks * b.ks + (double)b.Cout);
     char pname[96];
-    const char* cls = "dsblock";
+    const char* cls = "dsblock_rs";   // one profiler class per kernel FAMILY (row-streaming: HBM-bound; chunk-streamed: instruction-bound; bench.py roofline.by_family)
     if (Profiler::get().detail) { snprintf(pname, sizeof pname, "dsblock px=%ld C=%d N=%d k3 s%dx%d rs R%d", (long)px_out, b.C, b.Cout, b.sh, b.sw, sh.R); cls = pname; }
     ProfScope ps(s, cls, bytes, flops, true);
     const char* de = getenv("OAR_DSB_DBG");
@@ -206,7 +206,7 @@ void dsblock_cs(hipStream_t s, const DsBlockP& b, const CsShape& sh) {
     const double bytes = 4.0 * (px_in * b.C + px_out * b.Cout) + 4.0 * b.ks * b.ks * b.C + 6.0 * b.C * b.Cout;
     const double flops = 2.0 * px_out * b.C * (b.ks * b.ks + (double)b.Cout);
     char pname[96];
-    const char* cls = "dsblock";   // one profiler class for every fused separable-block kernel (rocprofv3 groups them by the dsblock* prefix too); per-kernel figures: DESIGN 4.13 / 4.14
+    const char* cls = "dsblock_cs";   // one profiler class per kernel FAMILY (row-streaming: HBM-bound; chunk-streamed: instruction-bound; bench.py roofline.by_family)
     if (Profiler::get().detail) { snprintf(pname, sizeof pname, "dsblock px=%ld C=%d N=%d k%d s%dx%d cs", (long)px_out, b.C, b.Cout, b.ks, b.sh, b.sw); cls = pname; }
     ProfScope ps(s, cls, bytes, flops, true);
     dsblock_cs_launch(s, p, b.ks, b.sh, b.sw, sh.nch, sh.nf, sh.acts, sh.grid, sh.lds, ps.start(), ps.stop());
@@ -264,7 +264,7 @@ void dsblock(hipStream_t s, const DsBlockP& b) {
     const double bytes = 4.0 * (px_in * b.C + px_out * b.Cout * (b.residual ? 2 : 1)) + 4.0 * b.ks * b.ks * b.C + 6.0 * b.C * b.Cout;
     const double flops = 2.0 * px_out * b.C * (b.ks * b.ks + (double)b.Cout);
     char pname[96];
-    const char* cls = "dsblock";
+    const char* cls = "dsblock";   // one profiler class per kernel FAMILY (row-streaming: HBM-bound; chunk-streamed: instruction-bound; bench.py roofline.by_family)
     if (Profiler::get().detail) { snprintf(pname, sizeof pname, "dsblock px=%ld C=%d N=%d k%d s%dx%d t%dx%d", (long)px_out, b.C, b.Cout, b.ks, b.sh, b.sw, sh.TR, sh.TC); cls = pname; }
     ProfScope ps(s, cls, bytes, flops, true);
     if (b.ks == 3 && b.sw == 1) dsblock_launch_k3s1(s, p, sh.nfw, sh.pfw, (int)grid, sh.lds, ps.start(), ps.stop());

@@ -236,7 +236,9 @@ int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin, long same3x3_
     // OAR_IGEMM_X6: 1 (default) = bf16x6 kernels on the wide layers, 0 = f32 MFMA everywhere
     static const int mode = [] { const char* e = getenv("OAR_IGEMM_X6"); return e ? atoi(e) : 1; }();
     if (!mode) return IGEMM_W_K16;
-    if (!is1x1 && same3x3_px > 0 && K == 9 * Cin && conv3x3_n16_x6_eligible(M, Cin, N, same3x3_px, N)) return IGEMM_W_X6;
+    // (decided before the output's leading dimension is final -- a Concat may place the layer in a wider buffer: the 2^31-byte bound of the kernel's
+    // output descriptor is checked here for up to four equal branches; launch time re-checks with the real y_ld and fails loudly, never falls through)
+    if (!is1x1 && same3x3_px > 0 && K == 9 * Cin && conv3x3_n16_x6_eligible(M, Cin, N, same3x3_px, 4 * N)) return IGEMM_W_X6;
     if (!is1x1) return (os_mode() && Cin > 0 && os_x6_eligible(M, K, N, Cin)) ? IGEMM_W_X6 : IGEMM_W_K16;
     // every lane's 8-float group must be all-valid or all-padding (K % 8); wide enough to be matrix-pipe bound
     // (N >= 96, K >= 96); enough (16-pixel tile, cout tile) pairs to fill the 4096 resident waves; float4 epilogue
@@ -357,6 +359,8 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     OAR_CHECK(!c.se || x6, OAR_INTERNAL, "conv_igemm: gate on a non-x6 layer (conv_igemm_se_ok should have said no)");
     const bool same3x3 = !c.convt2x2 && c.kh == 3 && c.kw == 3 && c.sh == 1 && c.sw == 1 && c.pt == 1 && c.pl == 1 && c.dh == 1 && c.dw == 1 && c.Ho == c.H && c.Wo == c.W;
     const bool rs3 = x6 && same3x3 && !c.residual && !c.se && !c.ctc_part && conv3x3_n16_x6_eligible(p.M, c.Cin, c.Cout, (long)c.H * c.W, c.y_ld);
+    // a layer whose weights were laid out for the row-streaming 3x3 kernel (Cout <= 16: no other bf16x6 kernel takes it) must reach that kernel
+    OAR_CHECK(!(x6 && same3x3 && c.Cout <= 16) || rs3, OAR_INTERNAL, "conv_igemm: 3x3 / Cout <= 16 bf16x6 weights but the row-streaming kernel's launch-time conditions do not hold (y_ld / output size / residual / gate changed after planning)");
     if (ws3) {
         conv_igemm_ws3(s, p, nfrag);
     } else if (rs3) {

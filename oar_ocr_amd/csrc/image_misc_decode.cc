@@ -103,6 +103,12 @@ void decode_bmp(const uint8_t* bytes, size_t len, std::vector<uint8_t>& rgb, uin
         mr = mask_of(rm, "red"); mg = mask_of(gm, "green"); mb = mask_of(bm, "blue");
     }
     OAR_CHECK(data_off <= len, OAR_INVALID_INPUT, "image load: BMP pixel offset beyond the file");
+    {   // the file must be able to hold the raster BEFORE the output is allocated: rows of the uncompressed forms, and for RLE at least one
+        // two-byte run per 255 pixels
+        const size_t stride_chk = (((size_t)W * bpp + 31) / 32) * 4;
+        const size_t need = rle ? ((size_t)W * H + 254) / 255 * 2 : stride_chk * H;
+        OAR_CHECK(need <= len - data_off, OAR_INVALID_INPUT, "image load: truncated BMP pixel data");
+    }
     rgb.assign((size_t)W * H * 3, 0);
     auto put_idx = [&](uint32_t x, uint32_t yfile, uint32_t idx) {
         const uint32_t y = top_down ? yfile : H - 1 - yfile;
@@ -187,6 +193,12 @@ void decode_pnm(const uint8_t* bytes, size_t len, std::vector<uint8_t>& rgb, uin
         maxval = t.number();
         OAR_CHECK(maxval >= 1 && maxval <= 65535, OAR_INVALID_INPUT, "image load: PNM maxval out of range");
         OAR_CHECK(maxval == 255, OAR_UNSUPPORTED_OP, "image load: PNM with maxval " + std::to_string(maxval) + " is not decoded by this library (255 is)");
+    }
+    {   // the file must be able to hold the raster BEFORE the output is allocated (a 20-byte header must not cost 512 MiB)
+        const size_t samples = (size_t)W * H * (colour ? 3 : 1);
+        const size_t need = ascii ? (bitmap ? samples : 2 * samples - 1)                      // one digit per bit; one digit + one separator per sample
+                                  : (bitmap ? (size_t)((W + 7) / 8) * H : samples) + 1;      // + the single white-space byte behind the header
+        OAR_CHECK(t.p <= len && need <= len - t.p, OAR_INVALID_INPUT, "image load: truncated PNM raster");
     }
     rgb.assign((size_t)W * H * 3, 0);
     const size_t px = (size_t)W * H;
@@ -317,6 +329,13 @@ void decode_tiff(const uint8_t* bytes, size_t len, std::vector<uint8_t>& rgb, ui
     const uint32_t n_strips = (H + rps - 1) / rps;
     OAR_CHECK(offs.present && cnts.present && offs.count >= n_strips && cnts.count >= n_strips, OAR_INVALID_INPUT, "image load: TIFF strip table");
     const size_t bpp = (size_t)spp * (bps / 8), row_bytes = (size_t)W * bpp;
+    for (uint32_t si = 0; si < n_strips; ++si) {   // every strip must be able to hold its rows BEFORE anything is allocated from header fields alone
+        const size_t want = row_bytes * std::min(rps, H - si * rps), off = value(offs, si), cnt = value(cnts, si);
+        OAR_CHECK(off <= len && cnt <= len - off, OAR_INVALID_INPUT, "image load: TIFF strip beyond the file");
+        // densest encodings: raw 1 : 1; PackBits 2 bytes -> 128; Deflate ~1 : 1032; LZW one 9-bit code -> at most 4094 bytes
+        const size_t ratio = comp == 1 ? 1 : comp == 32773 ? 64 : comp == 5 ? 3640 : 1040;
+        OAR_CHECK(want <= kMaxOut && (want + ratio - 1) / ratio <= cnt + 16, OAR_INVALID_INPUT, "image load: TIFF strip too short for its rows");
+    }
     rgb.assign((size_t)W * H * 3, 0);
     std::vector<uint8_t> buf;
     for (uint32_t si = 0; si < n_strips; ++si) {
@@ -329,8 +348,7 @@ void decode_tiff(const uint8_t* bytes, size_t len, std::vector<uint8_t>& rgb, ui
             OAR_CHECK(cnt >= want, OAR_INVALID_INPUT, "image load: truncated TIFF strip");
             buf.assign(bytes + off, bytes + off + want);
         } else if (comp == 5) {
-            buf.reserve(want);
-            tiff_lzw(bytes + off, cnt, buf, want);
+            tiff_lzw(bytes + off, cnt, buf, want);   // (grows with the decoded data: no reserve from header fields)
         } else if (comp == 32773) {   // PackBits
             size_t p = off;
             while (buf.size() < want && p < off + cnt) {

@@ -220,7 +220,9 @@ void jpeg_entropy_decode(const uint8_t* b, size_t n, JpegImage& im) {
             OAR_CHECK(have_sof && dl >= 1, OAR_INVALID_INPUT, "image load: JPEG scan before the frame header");
             const int ns = d[0];
             OAR_CHECK(ns >= 1 && ns <= im.ncomp && dl >= 1 + (size_t)ns * 2 + 3, OAR_INVALID_INPUT, "image load: bad JPEG SOS");
-            // an interleaved scan over a SUBSET of the components has its own MCU geometry (T.81 A.2.3); no encoder in use writes one
+            // KNOWN LIMITATION: an interleaved scan over a SUBSET of the components has its own MCU geometry (T.81 A.2.3), which this decoder does not
+            // implement.  libjpeg-turbo / PIL never write one, but mozjpeg -dc-scan-opt 2 and jpgcrush scripts emit a Cb + Cr interleaved DC scan: such a
+            // file is refused here (OAR_UNSUPPORTED_OP, never mis-decoded) where the reference's image crate decodes it.  README "Image formats".
             OAR_CHECK(ns == 1 || ns == im.ncomp, OAR_UNSUPPORTED_OP, "image load: JPEG scan interleaves a subset of the components (unsupported)");
             OAR_CHECK(++n_scans <= 256, OAR_INVALID_INPUT, "image load: JPEG with more than 256 scans");
             if (block_budget == 0) {

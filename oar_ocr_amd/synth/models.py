@@ -142,6 +142,9 @@ def build_det(size="tiny", seed=0, soft=False):
     cfg = {
         #        stem  c2   c3   c4    c5   neck  p
         "tiny": (16, 24, 32, 64, 128, 256, 64, 16),
+        # the same topology widened to the parameter count of the file it stands for: pp-ocrv6_tiny_det.onnx is 1 780 590 bytes ~ 0.445 M f32 parameters
+        # (reference registry.rs:83); "tiny" above has 0.288 M.  447 089 parameters.  bench.py reports both (VERDICT r4 #7b).
+        "tiny_full": (16, 32, 48, 80, 160, 320, 96, 16),
         "server": (32, 64, 128, 256, 512, 1024, 256, 64),
     }[size]
     stem, b2, c2, c3, c4, c5, nk, pc = cfg

@@ -149,7 +149,11 @@ impl ModelAdapter for Mi355xLayoutDetectionAdapter {
             // class_merge_modes of the PicoDet / RT-DETR families: apply_nms_with_merge (:577-587) on this image's boxes
             if let (false, Some(modes)) = (is_ppdoc, effective_config.class_merge_modes.as_ref()) {
                 let mode_of_class: Vec<i32> = (0..num_classes)
-                    .map(|c| self.model_config.class_labels.get(&c).and_then(|l| modes.get(l)).map(|v| merge_code(*v)).unwrap_or(0))
+                    // a class id without a label is looked up as "unknown", as the reference does (layout_postprocess.rs:771-779) and api.py's .get(c, "unknown")
+                    .map(|c| {
+                        let label = self.model_config.class_labels.get(&c).map(|s| s.as_str()).unwrap_or("unknown");
+                        modes.get(label).map(|v| merge_code(*v)).unwrap_or(0)
+                    })
                     .collect();
                 let flat: Vec<f32> = img_boxes.iter().flat_map(|b| { let (x0, y0, x1, y1) = b.aabb(); [x0, y0, x1, y1] }).collect();
                 let cls32: Vec<i32> = img_classes.iter().map(|&c| c as i32).collect();

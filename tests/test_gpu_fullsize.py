@@ -155,3 +155,52 @@ def test_c4_rank_0_of_8_shard_of_the_1024_page_list():
     assert np.array_equal(merged.points[:nr], packed.points) and np.array_equal(merged.points[nr:], other.points)
     assert np.array_equal(merged.scores, np.concatenate([packed.scores, other.scores])) and merged.utf8 == packed.utf8 + other.utf8
     ocr.close()
+
+
+def test_c4_all_eight_shards_of_the_1024_page_list_on_one_gpu():
+    """BASELINE C4 at FULL size, sequentially on one GPU (VERDICT r4 #7a): the eight oar_shard_range(1024, 8, r) shards each go through ONE
+    predict_packed(want_blob=True) as rank r would run it, the eight blobs meet in oar_packed_merge in rank order -> 1024 pages in list order.
+    Region counts, boxes, texts and scores of the merged result equal the per-shard results; sampled pages of shards 3 and 7 equal the
+    object-returning entry point; shard 7's last page is checked against the oracle."""
+    det, _ = models.build_det("tiny", seed=0)
+    rec, _ = models.build_rec("tiny", vocab=6906, seed=1)
+    chars = api.read_dict(models.synth_dict(6904))
+    cfg = api.TextDetectionConfig(score_threshold=0.3, box_threshold=0.6, unclip_ratio=1.5)
+    ocr = api.OAROCRBuilder(det, rec, chars).text_detection_config(cfg).image_batch_size(32).region_batch_size(256).build()
+    blobs, shards = [], []
+    covered = 0
+    for r in range(8):
+        a, b = api.shard_range(1024, 8, r)
+        assert a == covered and b - a == 128
+        covered = b
+        imgs = [pages.make_page(a + i, (960, 960), 40) for i in range(b - a)]
+        _, ptrs, ws, hs = api._img_arrays(imgs)
+        packed = ocr.predict_packed(ptrs, ws, hs, len(imgs), want_blob=True)
+        assert len(packed.region_offsets) == 129 and packed.region_offsets[-1] > 3600
+        blobs.append(packed.blob)
+        shards.append(packed)
+        if r in (3, 7):   # a few pages of the shard through OAROCR.predict (its own call: crops pooled over these pages only -> same boxes, texts may differ only by batch padding)
+            sub = [0, 64, 127]
+            got = ocr.predict([imgs[i] for i in sub])
+            for j, i in enumerate(sub):
+                k0, k1 = int(packed.region_offsets[i]), int(packed.region_offsets[i + 1])
+                assert k1 - k0 == len(got[j].text_regions)
+                for k, t in zip(range(k0, k1), got[j].text_regions):
+                    assert np.array_equal(packed.points[k], t.bounding_box) and abs(float(packed.scores[k]) - t.confidence) <= 1e-3
+        if r == 7:
+            got_all = ocr.predict(imgs[96:])   # the last recognition batches of the list, object form, against the oracle
+            n, ties = _check_pages_against_oracle(got_all, imgs[96:], [31], det, rec, chars, {}, (0.3, 0.6, 1.5))
+            assert n > 20 and ties <= 2
+        del imgs
+    assert covered == 1024
+    merged = api.PackedPages.merge(blobs)
+    assert len(merged.region_offsets) == 1025
+    base = 0
+    for r, sh in enumerate(shards):
+        nr = int(sh.region_offsets[-1])
+        assert merged.region_offsets[r * 128:(r + 1) * 128 + 1].tolist() == [base + int(v) for v in sh.region_offsets]
+        assert np.array_equal(merged.points[base:base + nr], sh.points) and np.array_equal(merged.scores[base:base + nr], sh.scores)
+        assert merged.text(base) == sh.text(0) and merged.text(base + nr - 1) == sh.text(nr - 1)
+        base += nr
+    assert base == len(merged.scores) and merged.utf8 == b"".join(sh.utf8 for sh in shards)
+    ocr.close()
