@@ -2548,7 +2548,10 @@ struct Planner {
         Act act = n.act;
         double flops = 2.0 * M * N * K, bytes = 4.0 * (M * K + M * N * (has_res ? 2 : 1) + K * N);
         if (K % 4 == 0 && alpha == 1.0f) {
-            const int fmt = has_res ? 0 : k::igemm_weight_format((long)M, (int)K, (int)Np, true);
+            // (a CTC head with a short K runs on the output-stationary bf16x6 kernel, ctc_head_x6.hip: bf16x6 fragments whatever igemm_weight_format says)
+            const bool ctc_head = P.logits_valid > 0 && od.back() == Np && n.act.kind == k::ACT_NONE && !has_res && k::ctc_head_x6_supported((long)M, (int)K, (int)Np) &&
+                                  k::ctc_partials_supported_x6((int)K) && [] { const char* e = getenv("OAR_CTC_PARTIALS"); return !e || atoi(e) != 0; }();
+            const int fmt = has_res ? 0 : ctc_head ? k::IGEMM_W_X6 : k::igemm_weight_format((long)M, (int)K, (int)Np, true);
             const float* w = linear_weight(n.in[1], *bt.ht, transB, fmt);
             k::ConvP p{};
             p.w_fmt = fmt;

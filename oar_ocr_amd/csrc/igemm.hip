@@ -324,6 +324,10 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
             if (padded < best) { best = padded; ws_nt = t; }
         }
     }
+    if (c.ctc_part && x6 && is1x1 && !c.residual && !c.se && c.act.kind == ACT_NONE && ctc_head_x6_supported(p.M, p.K, p.gemm_cout)) {
+        ctc_head_x6(s, c.x, c.w, c.bias, c.ctc_part, p.M, p.K, p.gemm_cout, c.ctc_valid);   // short K: output-stationary, the weights streamed once per 256 rows
+        return;
+    }
     if (c.ctc_part) {   // the partial-softmax epilogue lives in the weight-stationary kernels (f32 and bf16x6), 8 fragments per tile
         OAR_CHECK(vec_ok && is1x1 && (x6 ? ctc_partials_supported_x6(p.K) : ctc_partials_supported(p.K)), OAR_INTERNAL, "conv_igemm: CTC partials on an ineligible layer");
         ws_nt = 8;

@@ -185,6 +185,9 @@ int ctc_tiles(int n_padded);   // cout tiles per row for a (16-padded) class cou
 bool ctc_partials_supported(int K);
 bool ctc_partials_supported_x6(int K);
 void ctc_combine(hipStream_t s, const float* part, int64_t rows, int tiles, int64_t* idx, float* prob);
+// ctc_head_x6.hip: the CTC head as an output-stationary bf16x6 kernel (K = 32 / 64; IGEMM_W_X6 weights; same partials as above)
+bool ctc_head_x6_supported(long M, int K, int n_padded);
+void ctc_head_x6(hipStream_t s, const float* x, const float* w_x6, const float* bias, float* part, long M, int K, int n_padded, int valid);
 void softmax_argmax(hipStream_t s, const float* logits, int64_t rows, int C, int ld, int64_t* idx, float* prob);   // ld = row stride
 
 }  // namespace k
