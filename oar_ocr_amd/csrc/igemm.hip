@@ -325,7 +325,7 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
         }
     }
     if (c.ctc_part && x6 && is1x1 && !c.residual && !c.se && c.act.kind == ACT_NONE && ctc_head_x6_supported(p.M, p.K, p.gemm_cout)) {
-        ctc_head_x6(s, c.x, c.w, c.bias, c.ctc_part, p.M, p.K, p.gemm_cout, c.ctc_valid);   // short K: output-stationary, the weights streamed once per 256 rows
+        ctc_head_x6(s, c.x, c.w, c.bias, c.ctc_part, p.M, p.K, p.gemm_cout, c.ctc_valid);   // short K: output-stationary, the weights streamed once per 384 rows
         return;
     }
     if (c.ctc_part) {   // the partial-softmax epilogue lives in the weight-stationary kernels (f32 and bf16x6), 8 fragments per tile
