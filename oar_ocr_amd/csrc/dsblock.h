@@ -31,6 +31,10 @@ void dsblock(hipStream_t s, const DsBlockP& p);
 // fragment layout dsblock() expects p.wp in for this block (IGEMM_W_X6 for the bf16x6 kernels, IGEMM_W_K16 for the f32 row-streaming kernel);
 // depends on the shape only (not on the pointers)
 int dsblock_wp_format(const DsBlockP& p);
+// Two consecutive blocks (a: x -> t, b: t -> y; both 3x3 / stride 1 / pad 1, no residual, no gate) as ONE launch whose intermediate tensor never reaches HBM
+// (dsblock_rs2.inc).  Both pointwise tables must be in IGEMM_W_X6RS order; a.y and b.x are unused.  OAR_DSBLOCK_RS2=0 turns it off.
+bool dsblock2_eligible(const DsBlockP& a, const DsBlockP& b);
+void dsblock2(hipStream_t s, const DsBlockP& a, const DsBlockP& b);
 // IGEMM_W_X6CS: bytes of one channel chunk's weight block (dsblock_cs.inc: [taps | bias] rounded to 1 KB, then 1536 B per cout fragment, rounded to 1 KB)
 size_t dsblock_cs_block_bytes(int ks, int nft);
 

@@ -2,6 +2,7 @@
 #include "dsblock_dev.h"
 #include "dsblock_rs.h"
 #include "dsblock_cs.h"
+#include "dsblock_rs2.h"
 
 namespace oar {
 namespace k {
@@ -211,6 +212,79 @@ void dsblock_cs(hipStream_t s, const DsBlockP& b, const CsShape& sh) {
     ProfScope ps(s, cls, bytes, flops, true);
     dsblock_cs_launch(s, p, b.ks, b.sh, b.sw, sh.nch, sh.nf, sh.acts, sh.grid, sh.lds, ps.start(), ps.stop());
 }
+// The two-block row-streaming kernel (dsblock_rs2.inc, round 5): block a's output feeds block b through a per-wave LDS ring.
+struct Rs2Shape { int nch1, nf1, nf2, acts, wpw, R, segs, tiles_x, items; unsigned lds_ring2, lds_dw1, lds_pw1, lds_dw2, lds_pw2; size_t lds; bool ok; };
+Rs2Shape rs2_shape(const DsBlockP& a, const DsBlockP& b) {
+    Rs2Shape r{};
+    const char* e = getenv("OAR_DSBLOCK_RS2");
+    if (e && atoi(e) == 0) return r;
+    auto plain = [](const Act& x) { return x.kind == ACT_NONE || x.kind == ACT_RELU || x.kind == ACT_HSWISH; };
+    auto simple = [&](const DsBlockP& p) {
+        return p.ks == 3 && p.sh == 1 && p.sw == 1 && p.pt == 1 && p.pl == 1 && p.Ho == p.H && p.Wo == p.W && !p.has_res && !p.residual && !p.se && plain(p.act1) && plain(p.act2) &&
+               p.C >= 4 && (p.C & 3) == 0 && p.Cout >= 4 && (p.Cout & 3) == 0;
+    };
+    if (!simple(a) || !simple(b) || a.Cout != b.C || a.N != b.N || a.H != b.H || a.W != b.W || a.N <= 0 || a.H <= 0 || a.W <= 0 || (b.y_ld & 3)) return r;
+    if ((long)a.H * a.W * a.C * 4 >= (1L << 29) || (long)b.N * b.H * b.W * b.y_ld * 4 >= (1L << 31)) return r;
+    r.nch1 = (a.C + 15) / 16; r.nf1 = (a.Cout + 15) / 16; r.nf2 = (b.Cout + 15) / 16;
+    r.wpw = dsblock_rs2_wpw(r.nch1, r.nf1, r.nf2);
+    if (r.wpw == 0) return r;
+    const bool hs = a.act1.kind == ACT_HSWISH && a.act2.kind == ACT_HSWISH && b.act1.kind == ACT_HSWISH && b.act2.kind == ACT_HSWISH;
+    r.acts = hs ? 1 : 0;
+    const int nch2 = r.nf1, ncp1 = (r.nch1 + 1) / 2, ncp2 = (nch2 + 1) / 2;
+    const size_t slot1 = (size_t)r.nch1 * 18 * 64, slot2 = (size_t)nch2 * 18 * 64;
+    const size_t rings1 = (size_t)r.wpw * 3 * slot1, rings2 = (size_t)r.wpw * 2 * slot2;
+    r.lds_ring2 = (unsigned)rings1;
+    r.lds_dw1 = (unsigned)(rings1 + rings2);
+    r.lds_pw1 = r.lds_dw1 + 10u * r.nch1 * 64u;
+    r.lds_dw2 = r.lds_pw1 + (unsigned)(r.nf1 * ncp1 * 3 * 1024);
+    r.lds_pw2 = r.lds_dw2 + 10u * nch2 * 64u;
+    r.lds = (size_t)r.lds_pw2 + (size_t)r.nf2 * ncp2 * 3 * 1024;
+    if (r.lds > 160 * 1024) return r;
+    r.tiles_x = (a.W + 13) / 14;
+    // rows per item: the fewest wave rounds, then the least pipeline fill (an item of R rows takes R + 5 iterations)
+    const long waves = 256L * r.wpw;
+    double best = 1e30;
+    for (int R = std::min(a.H, 4); R <= a.H; ++R) {
+        const int segs = (a.H + R - 1) / R;
+        const long items = (long)a.N * segs * r.tiles_x;
+        if (items >= (1L << 30)) continue;
+        const long rounds = (items + waves - 1) / waves;
+        const double cost = (double)rounds * (R + 5);
+        if (cost < best - 1e-9) { best = cost; r.R = R; r.segs = segs; r.items = (int)items; }
+        if (R >= 64 && rounds == 1) break;
+    }
+    r.ok = r.R > 0;
+    return r;
+}
+}  // namespace
+bool dsblock2_eligible(const DsBlockP& a, const DsBlockP& b) {
+    const char* e = getenv("OAR_FUSE_DSBLOCK");
+    const bool on = !e || atoi(e) != 0;
+    return on && rs2_shape(a, b).ok;
+}
+void dsblock2(hipStream_t s, const DsBlockP& a, const DsBlockP& b) {
+    const Rs2Shape sh = rs2_shape(a, b);
+    OAR_CHECK(sh.ok, OAR_INTERNAL, "dsblock2: called on an ineligible pair of blocks");
+    DsRs2P p{};
+    p.x = a.x; p.y = b.y;
+    p.wd1 = a.wd; p.bd1 = a.bd; p.wp1 = reinterpret_cast<const float4*>(a.wp); p.bp1 = a.bp;
+    p.wd2 = b.wd; p.bd2 = b.bd; p.wp2 = reinterpret_cast<const float4*>(b.wp); p.bp2 = b.bp;
+    p.N = a.N; p.H = a.H; p.W = a.W; p.C1 = a.C; p.C2 = a.Cout; p.C3 = b.Cout; p.y_ld = b.y_ld;
+    p.act11 = a.act1.kind; p.act12 = a.act2.kind; p.act21 = b.act1.kind; p.act22 = b.act2.kind;
+    p.R = sh.R; p.segs = sh.segs; p.tiles_x = sh.tiles_x; p.items = sh.items; p.per_xcd = (sh.items + 7) / 8;
+    p.lds_ring2 = sh.lds_ring2; p.lds_dw1 = sh.lds_dw1; p.lds_pw1 = sh.lds_pw1; p.lds_dw2 = sh.lds_dw2; p.lds_pw2 = sh.lds_pw2;
+    p.img_bytes = (unsigned)((long)a.H * a.W * a.C * 4);
+    p.y_bytes = (unsigned)((long)b.N * b.H * b.W * b.y_ld * 4);
+    const double px = (double)a.N * a.H * a.W;
+    const double bytes = 4.0 * px * (a.C + b.Cout) + 4.0 * 9 * (a.C + b.C) + 4.0 * ((double)a.C * a.Cout + (double)b.C * b.Cout);   // the intermediate tensor moves no bytes
+    const double flops = 2.0 * px * (a.C * (9.0 + a.Cout) + b.C * (9.0 + b.Cout));
+    char pname[96];
+    const char* cls = "dsblock_rs2";
+    if (Profiler::get().detail) { snprintf(pname, sizeof pname, "dsblock2 px=%ld C=%d-%d-%d rs2 R%d", (long)px, a.C, a.Cout, b.Cout, sh.R); cls = pname; }
+    ProfScope ps(s, cls, bytes, flops, true);
+    dsblock_rs2_launch(s, p, sh.nch1, sh.nf1, sh.nf2, sh.acts, 256, sh.lds, ps.start(), ps.stop());
+}
+namespace {
 // which kernel runs the block: 0 row-streaming, 1 wave-autonomous, 2 chunk-streamed, 3 dsblock.inc, -1 none
 int ds_pick(const DsBlockP& p) {
     const CsShape cs = cs_shape(p);

@@ -1463,8 +1463,92 @@ struct Planner {
     }
 
     // fused depthwise-separable block (rewrite pass 7)
+    // shape part of a DSBlock node's parameters for an [N, C, H, W] input; false when the node is not a plain block
+    bool dsblock_shape(const GNode& n, int64_t N, int64_t C, int64_t H, int64_t W, k::DsBlockP& p) {
+        const TInfo &wdt = get(n.in[1]), &wpt = get(n.in[3]);
+        if (!wdt.ht || !wpt.ht) return false;
+        const HostTensor &WD = *wdt.ht, &WP = *wpt.ht;
+        const int64_t ks = WD.dims[2], Cout = WP.dims[0];
+        if (WD.dims[0] != C || WP.dims[1] != C) return false;
+        auto st = n.ais("strides");
+        const int64_t sh = st.size() == 2 ? st[0] : 1, sw = st.size() == 2 ? st[1] : 1;
+        int64_t pt, pl, pb, pr;
+        get_pads(n, H, W, ks, ks, sh, sw, 1, 1, pt, pl, pb, pr);
+        const int64_t Ho = (H + pt + pb - (ks - 1) - 1) / sh + 1, Wo = (W + pl + pr - (ks - 1) - 1) / sw + 1;
+        p = k::DsBlockP{};
+        p.N = (int)N; p.H = (int)H; p.W = (int)W; p.C = (int)C; p.Ho = (int)Ho; p.Wo = (int)Wo; p.Cout = (int)Cout;
+        p.ks = (int)ks; p.sh = (int)sh; p.sw = (int)sw; p.pt = (int)pt; p.pl = (int)pl;
+        p.act1.kind = (int)n.ai("act1", 0); p.act1.alpha = n.af("act1_alpha", 0.f); p.act1.beta = n.af("act1_beta", 0.f);
+        p.act2 = n.act; p.y_ld = (int)Cout;
+        p.has_res = !n.residual.empty();
+        return Ho > 0 && Wo > 0;
+    }
+    // DSBlock n followed by a DSBlock that is the ONLY reader of its output: one launch, the tensor between them never exists (csrc/dsblock_rs2.inc).
+    // Decided here, at plan time, because eligibility depends on the shapes; the second node is then skipped by build().
+    bool try_dsblock_pair(const GNode& n, const TInfo& x) {
+        if (cur + 1 >= (int)E.nodes_.size() || !n.residual.empty() || x.dims.size() != 4 || x.host_int) return false;
+        const GNode& m = E.nodes_[cur + 1];
+        if (m.op != "DSBlock" || m.in.empty() || m.in[0] != n.out[0] || !m.residual.empty()) return false;
+        for (auto& o : E.output_names_) if (o == n.out[0]) return false;
+        for (int i = 0; i < (int)E.nodes_.size(); ++i) {   // nobody else reads the intermediate tensor
+            if (i == cur + 1) continue;
+            const GNode& q = E.nodes_[i];
+            for (auto& s : q.in) if (s == n.out[0]) return false;
+            if (q.residual == n.out[0]) return false;
+        }
+        for (size_t i = 1; i < m.in.size(); ++i) if (m.in[i] == n.out[0]) return false;
+        k::DsBlockP pa, pb;
+        const int64_t N = x.dims[0], C = x.dims[1], H = x.dims[2], W = x.dims[3];
+        if (!dsblock_shape(n, N, C, H, W, pa) || !dsblock_shape(m, N, pa.Cout, pa.Ho, pa.Wo, pb) || !k::dsblock2_eligible(pa, pb)) return false;
+        // a chain a -> b -> c can fuse only one of its two pairs: the one whose intermediate tensor is wider saves more traffic (OAR_DSBLOCK_RS2_FIRST=1: always the first)
+        static const bool first = [] { const char* e = getenv("OAR_DSBLOCK_RS2_FIRST"); return e && atoi(e) != 0; }();
+        if (!first && cur + 2 < (int)E.nodes_.size()) {
+            const GNode& q = E.nodes_[cur + 2];
+            k::DsBlockP pc;
+            if (q.op == "DSBlock" && !q.in.empty() && q.in[0] == m.out[0] && q.residual.empty() && get(q.in[1]).ht && get(q.in[3]).ht &&
+                dsblock_shape(q, N, pb.Cout, pb.Ho, pb.Wo, pc) && k::dsblock2_eligible(pb, pc) && pb.Cout > pa.Cout) {
+                bool sole = true;
+                for (auto& o : E.output_names_) sole = sole && o != m.out[0];
+                for (int i = 0; sole && i < (int)E.nodes_.size(); ++i) {
+                    if (i == cur + 2) continue;
+                    for (auto& t : E.nodes_[i].in) sole = sole && t != m.out[0];
+                    sole = sole && E.nodes_[i].residual != m.out[0];
+                }
+                if (sole) return false;   // b -> c will be fused when b is planned
+            }
+        }
+        auto weights = [&](const GNode& d, k::DsBlockP& p) {
+            const HostTensor &WD = *get(d.in[1]).ht, &WP = *get(d.in[3]).ht;
+            GNode dwn, pwn;
+            dwn.op = "Conv"; dwn.in = {d.in[0], d.in[1]};
+            pwn.op = "Conv"; pwn.in = {d.out[0] + "::dw", d.in[3]};
+            if (!d.in[2].empty()) OAR_CHECK((int64_t)get(d.in[2]).ht->f.size() == p.C, OAR_MODEL_LOAD, "DSBlock: depthwise bias size");
+            if (!d.in[4].empty()) OAR_CHECK((int64_t)get(d.in[4]).ht->f.size() == p.Cout, OAR_MODEL_LOAD, "DSBlock: pointwise bias size");
+            p.wd = conv_weight_dw(dwn, WD);
+            p.bd = d.in[2].empty() ? nullptr : get(d.in[2]).loc.cptr;
+            p.wp = conv_weight_igemm(pwn, WP, k::IGEMM_W_X6RS);
+            p.bp = d.in[4].empty() ? nullptr : get(d.in[4]).loc.cptr;
+        };
+        weights(n, pa);
+        weights(m, pb);
+        Loc xin = to_clast_loc(x);
+        TInfo& y = new_out(m.out[0], {N, (int64_t)pb.Cout, (int64_t)pb.Ho, (int64_t)pb.Wo}, Layout::CLAST);
+        Loc yl = y.loc;
+        const double px = (double)N * H * W;
+        const double flops = 2.0 * px * (pa.C * (9.0 + pa.Cout) + pb.C * (9.0 + pb.Cout));
+        const double bytes = 4.0 * px * (pa.C + pb.Cout);
+        step([=](const RunCtx& c) {
+            k::DsBlockP qa = pa, qb = pb;
+            qa.x = c.at(xin); qb.y = c.mut(yl);
+            k::dsblock2(c.s, qa, qb);
+        }, flops, bytes);
+        fused_into_prev.insert(cur + 1);
+        return true;
+    }
+
     void op_dsblock(const GNode& n) {
         TInfo x = get(n.in[0]);
+        if (try_dsblock_pair(n, x)) return;
         const TInfo &wdt = get(n.in[1]), &wpt = get(n.in[3]);
         OAR_CHECK(wdt.ht && wpt.ht, OAR_UNSUPPORTED_OP, "DSBlock: weights must be initializers");
         const HostTensor &WD = *wdt.ht, &WP = *wpt.ht;
@@ -2748,6 +2832,7 @@ struct Planner {
     }
 
     bool skip_final_softmax = false;
+    std::set<int> fused_into_prev;   // node indices whose work was planned by their predecessor
     bool stem_u8 = false;
     void build(const std::vector<int64_t>& in_dims, bool in_clast, const std::vector<std::vector<int64_t>>* extra_dims) {
         compute_last_use();
@@ -2770,6 +2855,7 @@ struct Planner {
         for (int i = 0; i < (int)E.nodes_.size(); ++i) {
             const GNode& n = E.nodes_[i];
             cur = i;
+            if (fused_into_prev.count(i)) { release_dead(i); continue; }   // planned together with the node before it (op_dsblock: two blocks, one launch)
             if (skip_final_softmax && n.op == "Softmax" && !n.out.empty() && n.out[0] == E.output_names_[0]) {
                 TInfo x = get(n.in[0]);
                 int r = (int)x.dims.size();

@@ -560,6 +560,37 @@ DS_CASES = [  # (C, Cout, k, stride, N, H, W, act, residual)
 ]
 
 
+DS2_CASES = [  # (C1, C2, C3, N, H, W, act): two consecutive 3x3 / stride-1 blocks -> one launch (csrc/dsblock_rs2.inc)
+    (24, 48, 48, 3, 24, 50, "hswish"), (24, 48, 48, 2, 24, 14, "relu"), (24, 48, 48, 1, 1, 5, "hswish"), (24, 48, 48, 2, 70, 29, None),
+    (16, 24, 48, 3, 13, 33, "hswish"), (16, 24, 48, 1, 24, 160, "hswish"), (16, 24, 48, 40, 24, 43, "relu"),
+]
+
+
+@pytest.mark.parametrize("case", DS2_CASES, ids=[f"C{c[0]}-{c[1]}-{c[2]}-H{c[4]}W{c[5]}" for c in DS2_CASES])
+def test_two_fused_dsblocks_match_oracle_and_the_two_launch_path(case, monkeypatch):
+    """Block -> block with the tensor between them never written (dsblock_rs2.inc): strips of 14 columns with one recomputed halo column per side,
+    intermediate rows / columns outside the image zeroed (block 2's padding), pipeline fill and drain per item, ragged last strip, one-row images,
+    several row segments, run-time activations -- against the torch-CPU interpreter and against the same graph as two launches (OAR_DSBLOCK_RS2=0)."""
+    C1, C2, C3, N, H, W, act = case
+    net = models._Net("ds2", seed=C1 * 5 + C3 + H, decomposed_hswish=False)
+    g = net.g
+    g.add_input("x", ["N", C1, "H", "W"])
+    t = net.ds_block("x", C1, C2, 3, 1, act=act)
+    z = net.ds_block(t, C2, C3, 3, 1, act=act)
+    g.nodes.append(models.node("Identity", [z], ["out"]))
+    g.add_output("out", ["N", C3, "H", "W"])
+    m = g.model()
+    x = np.random.default_rng(2).standard_normal((N, C1, H, W)).astype(np.float32)
+    api.prof_enable(True); api.prof_reset()
+    got, ref = _check(m, x, tol=2e-4)
+    names = {e["name"] for e in api.prof_snapshot() if e["launches"]}
+    api.prof_enable(False)
+    assert "dsblock_rs2" in names, names            # the pair really ran as one launch
+    monkeypatch.setenv("OAR_DSBLOCK_RS2", "0")
+    two = api.OrtInfer(m).infer(x)[0][1]
+    assert np.abs(two - got[0][1]).max() <= 2e-4 * max(1.0, float(np.abs(two).max()))
+
+
 @pytest.mark.parametrize("case", DS_CASES, ids=[f"C{c[0]}-N{c[1]}-k{c[2]}-s{c[3][0]}{c[3][1]}" for c in DS_CASES])
 def test_fused_dsblock_matches_oracle(case, monkeypatch):
     """Conv(depthwise k x k) + act -> Conv(1 x 1) + act (+ residual) runs as one kernel (csrc/dsblock_rs.inc: rolling depthwise sums in
