@@ -8,7 +8,7 @@
 # PMC passes never carry --kernel-trace / --stats (gpurun refuses the combination).  Then: python tools/make_profile_summaries.py <tag> auto profiles/r4   (auto: the pass count the stats run's bench line reports)
 TAG=${1:-r2a}
 R=$PWD; cd /tmp; export TMPDIR=/tmp
-BENCH="python $R/bench.py --cpu-pages 0 --no-device-resident --no-pipelined"
+BENCH="python $R/bench.py --cpu-pages 0 --no-device-resident --no-pipelined --no-real-size"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o $TAG -- $BENCH --steps 5 --warmup 2 > $R/gpurun_out/prof_$TAG.log 2>&1 < /dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_$c
