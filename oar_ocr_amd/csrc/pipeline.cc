@@ -782,11 +782,17 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
             traced = mask_dil_.as<uint8_t>() + (size_t)b0 * hw;
         }
         OAR_HIP(hipEventRecord(mask_ready_[sb], s));
-        OAR_HIP(hipStreamWaitEvent(copy_stream_, mask_ready_[sb], 0));
+        // OAR_GPU_CONTOURS_INLINE=1 (experiment, round 5; default 0): the border follower ON the detector's stream, between this sub-batch's network and the
+        // next one's.  Measured (profiles/r5/gpu_follower_inline.txt): 35.6 ms per step against 31.3 on its own stream and 14-25 with the host tracer -- the
+        // follower's launch time is not queueing behind the network but its own serial work: one wave per mask segment, ~0.5 us per border pixel, so a launch
+        // lasts as long as its longest segment (a 900-pixel text line: ~1.5 ms), alone on the GPU as well.
+        static const bool trace_inline = [] { const char* e = getenv("OAR_GPU_CONTOURS_INLINE"); return e && atoi(e) != 0; }();
+        hipStream_t ts = (gpu_contours && trace_inline) ? s : copy_stream_;
+        if (ts != s) OAR_HIP(hipStreamWaitEvent(copy_stream_, mask_ready_[sb], 0));
         if (gpu_contours) {
-            // a8 on the GPU, on the copy stream (concurrent with the next sub-batch's network): only the border chains cross PCIe
+            // a8 on the GPU: only the border chains cross PCIe
             const uint32_t tcap = (uint32_t)nb * ContourBufs::kSegsPerPage;
-            pp::trace_contours(copy_stream_, traced, nb, H, W, trace_.rows.as<uint8_t>(), trace_.band_y.as<int32_t>(), trace_.n_bands.as<int32_t>(),
+            pp::trace_contours(ts, traced, nb, H, W, trace_.rows.as<uint8_t>(), trace_.band_y.as<int32_t>(), trace_.n_bands.as<int32_t>(),
                                trace_.lists.as<uint32_t>(), tcap, trace_.scratch.as<uint32_t>(), trace_.packed.as<uint32_t>() + (size_t)b0 * trace_.packed_words_per_page,
                                (uint32_t)std::min<size_t>((size_t)nb * trace_.packed_words_per_page, 0xffffffffu),
                                trace_.ctrl.as<uint32_t>() + (size_t)sb * pp::kTraceCtlWords, trace_.ctrl_host.as<uint32_t>() + (size_t)sb * pp::kTraceCtlWords,
@@ -797,7 +803,7 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
             OAR_HIP(hipMemcpyAsync(mask_host_.as<uint8_t>() + (size_t)b0 * hbits, mask_bits_.as<uint8_t>() + (size_t)b0 * hbits, (size_t)nb * hbits,
                                    hipMemcpyDeviceToHost, copy_stream_));
         }
-        OAR_HIP(hipEventRecord(sub_events_[sb], copy_stream_));
+        OAR_HIP(hipEventRecord(sub_events_[sb], ts));
         tmark("det_enqueue");
     };
 
