@@ -33,7 +33,7 @@ bool dsblock_pc_launch(hipStream_t s, const DsCsP& p, int ks, int sh, int sw, in
     static const int dbg = [] { const char* e = getenv("OAR_DSB_PC_DBG"); return e ? atoi(e) : 0; }();   // timing ablations of the 192 -> 192 5x5 instantiation (wrong results)
     if (dbg && ks == 5 && nch == 12 && nft == 12 && acts) {
         switch (dbg) {
-            OAR_PC_DBG(1) OAR_PC_DBG(2) OAR_PC_DBG(4) OAR_PC_DBG(8) OAR_PC_DBG(12) OAR_PC_DBG(32) OAR_PC_DBG(64) OAR_PC_DBG(128) OAR_PC_DBG(256) OAR_PC_DBG(28) OAR_PC_DBG(29) OAR_PC_DBG(30) OAR_PC_DBG(512) OAR_PC_DBG(640) OAR_PC_DBG(768) OAR_PC_DBG(8192) OAR_PC_DBG(8704)
+            OAR_PC_DBG(1) OAR_PC_DBG(2) OAR_PC_DBG(4) OAR_PC_DBG(8) OAR_PC_DBG(12) OAR_PC_DBG(32) OAR_PC_DBG(64) OAR_PC_DBG(128) OAR_PC_DBG(256) OAR_PC_DBG(28) OAR_PC_DBG(29) OAR_PC_DBG(30) OAR_PC_DBG(512) OAR_PC_DBG(640) OAR_PC_DBG(768) OAR_PC_DBG(16384) OAR_PC_DBG(16896)
             default: break;
         }
     }
