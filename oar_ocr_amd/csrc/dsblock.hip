@@ -279,7 +279,7 @@ void dsblock2(hipStream_t s, const DsBlockP& a, const DsBlockP& b) {
     const double bytes = 4.0 * px * (a.C + b.Cout) + 4.0 * 9 * (a.C + b.C) + 4.0 * ((double)a.C * a.Cout + (double)b.C * b.Cout);   // the intermediate tensor moves no bytes
     const double flops = 2.0 * px * (a.C * (9.0 + a.Cout) + b.C * (9.0 + b.Cout));
     char pname[96];
-    const char* cls = "dsblock_rs2";
+    const char* cls = "dsblock_rs";   // the row-streaming family (one launch, two blocks: its algorithmic bytes are the first block's input + the second's output)
     if (Profiler::get().detail) { snprintf(pname, sizeof pname, "dsblock2 px=%ld C=%d-%d-%d rs2 R%d", (long)px, a.C, a.Cout, b.Cout, sh.R); cls = pname; }
     ProfScope ps(s, cls, bytes, flops, true);
     dsblock_rs2_launch(s, p, sh.nch1, sh.nf1, sh.nf2, sh.acts, 256, sh.lds, ps.start(), ps.stop());

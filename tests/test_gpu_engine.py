@@ -583,9 +583,9 @@ def test_two_fused_dsblocks_match_oracle_and_the_two_launch_path(case, monkeypat
     x = np.random.default_rng(2).standard_normal((N, C1, H, W)).astype(np.float32)
     api.prof_enable(True); api.prof_reset()
     got, ref = _check(m, x, tol=2e-4)
-    names = {e["name"] for e in api.prof_snapshot() if e["launches"]}
+    launches = {e["name"]: e["launches"] for e in api.prof_snapshot() if e["launches"]}
     api.prof_enable(False)
-    assert "dsblock_rs2" in names, names            # the pair really ran as one launch
+    assert launches.get("dsblock_rs") == 1 and not any("conv" in n for n in launches), launches   # the pair ran as ONE launch of the row-streaming family
     monkeypatch.setenv("OAR_DSBLOCK_RS2", "0")
     two = api.OrtInfer(m).infer(x)[0][1]
     assert np.abs(two - got[0][1]).max() <= 2e-4 * max(1.0, float(np.abs(two).max()))

@@ -27,7 +27,7 @@ txt = subprocess.run([sys.executable, "tools/pmc_summary.py", str(src), "40"], c
 def klass(name):   # kernel name -> profiler class used by the in-library profiler / bench.py
     if "conv3x3_n16_x6" in name:
         return "conv_rs3_x6"
-    for pre, k in (("dsblock_rs2_kernel", "dsblock_rs2"), ("ctc_head_x6_kernel", "ctc_head_x6"), ("dsblock_rs_kernel", "dsblock_rs"), ("dsblock_cs_kernel", "dsblock_cs"), ("dsblock_pc_kernel", "dsblock_cs"), ("dsblock_wa_kernel", "dsblock_wa")):   # one class per dsblock family
+    for pre, k in (("dsblock_rs2_kernel", "dsblock_rs"), ("ctc_head_x6_kernel", "ctc_head_x6"), ("dsblock_rs_kernel", "dsblock_rs"), ("dsblock_cs_kernel", "dsblock_cs"), ("dsblock_pc_kernel", "dsblock_cs"), ("dsblock_wa_kernel", "dsblock_wa")):   # one class per dsblock family
         if pre in name:
             return k
     for k in ("dsblock", "conv_igemm_ws_x6", "conv_igemm_ws", "conv_igemm", "conv_dw", "conv_smallcin", "softmax_argmax", "rec_pack", "global_avgpool", "binary", "resize", "copy2d", "normalize", "gemm_batched", "permute"):
