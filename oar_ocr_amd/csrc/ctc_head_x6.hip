@@ -28,7 +28,7 @@ typedef __bf16 ch_bf16x8 __attribute__((ext_vector_type(8)));
 
 struct CtcHeadP {
     const float* x; const float4* w; const float* bias; float* part;
-    long M; int K; int valid; int ny; int tiles_per_wg; unsigned w_bytes;
+    long M; int K; int valid; int ny; int tiles_per_wg; unsigned w_bytes; int n_padded;
 };
 
 __device__ __forceinline__ void ch_dma(unsigned voff, ch_u32x4 rsrc, unsigned soff, unsigned lds_dst) {
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kChWaves * 64, 1) void ctc_head_x6_kernel(CtcHeadP 
     request(t0, 0);
     // bias of the workgroup's columns (zeros past the padded width never matter: those columns are not valid)
     for (int i = tid; i < (t1 - t0) * 128; i += kChWaves * 64)
-        reinterpret_cast<float*>(reinterpret_cast<char*>(ch_lds) + BIAS0)[i] = p.bias ? p.bias[t0 * 128 + i] : 0.f;
+        reinterpret_cast<float*>(reinterpret_cast<char*>(ch_lds) + BIAS0)[i] = (p.bias && t0 * 128 + i < p.n_padded) ? p.bias[t0 * 128 + i] : 0.f;   // (the last tile may reach past the padded width)
     // ---- this wave's rows: lane (g, pl) holds k = 32 kc + 8 g .. + 7 of row pl, split exactly into three bf16 pieces (B operands)
     ch_u32x4 B[kChRT][KC][3];
 #pragma unroll
@@ -181,7 +181,7 @@ bool ctc_head_x6_supported(long M, int K, int n_padded) {
 void ctc_head_x6(hipStream_t s, const float* x, const float* w_x6, const float* bias, float* part, long M, int K, int n_padded, int valid) {
     CtcHeadP p{};
     p.x = x; p.w = reinterpret_cast<const float4*>(w_x6); p.bias = bias; p.part = part;
-    p.M = M; p.K = K; p.valid = valid; p.ny = ctc_tiles(n_padded);
+    p.M = M; p.K = K; p.valid = valid; p.ny = ctc_tiles(n_padded); p.n_padded = n_padded;
     const int KC = K / 32;
     const long rows64 = ((long)n_padded + 63) / 64 * 64;   // engine.cc to_fragment_x6 pads the rows (couts) to 64
     p.w_bytes = (unsigned)(rows64 / 16 * KC * 3 * 1024);

@@ -137,6 +137,27 @@ def test_fused_ctc_tail_matches_unfused(nets):
     np.testing.assert_allclose(got.probs.reshape(-1), pr, rtol=1e-5, atol=0)
 
 
+@pytest.mark.parametrize("vocab", [1100, 3001, 6906])
+def test_ctc_head_kernel_on_ragged_vocabularies(vocab, monkeypatch):
+    """csrc/ctc_head_x6.hip (round 5): the output-stationary CTC head with padded widths that are not multiples of its 128-column tile (1100 -> 1104, 3001 -> 3008: the last
+    tile reads weights / bias past the matrix; the fused tail is only used above 1024 classes), and at the bench's 6906 -- indices equal to the
+    logits + stand-alone arg max path, probabilities to a few ulp, and equal to the weight-stationary kernels it replaced (OAR_CTC_HEAD_OS=0 needs a fresh
+    process for its cached switch, so that comparison is on values: both must match the unfused tail)."""
+    rec, _ = models.build_rec("tiny", vocab=vocab, seed=3)
+    chars = api.read_dict(models.synth_dict(vocab - 2))
+    crops = [pages.make_crop(70 + i, w, h) for i, (w, h) in enumerate([(320, 48), (200, 40), (640, 48), (90, 30), (33, 48)])]
+    api.prof_enable(True); api.prof_reset()
+    got = api.TextRecognitionPredictor(rec, chars).predict(crops)
+    names = {e["name"] for e in api.prof_snapshot() if e["launches"]}
+    api.prof_enable(False)
+    assert "ctc_head_x6" in names, names
+    x = api.k_rec_preprocess(crops)
+    (name, probs), = api.OrtInfer(rec).infer(x)
+    idx, pr = api.k_ctc_argmax(probs)
+    assert np.array_equal(got.indices.reshape(-1), idx)
+    np.testing.assert_allclose(got.probs.reshape(-1), pr, rtol=2e-5, atol=0)
+
+
 def test_fused_recognizer_stem_matches_the_packed_tensor_path(nets, monkeypatch):
     """The recognizer reads u8 crops resized to their own width and normalises + pads inside its first convolution
     (k::StemU8::dev) instead of going through the f32 tensor pp::rec_pack writes (OAR_REC_FUSE_STEM=0): the same input values
