@@ -94,3 +94,23 @@ def test_round4_one_wave_per_simd_kernels_do_not_spill():
     assert len(rs3) == 2
     for name, r in rs3.items():
         assert r["spill"] == 0 and r["scratch"] == 0 and r["vgprs"] <= 256, (name, r)
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
+def test_round5_kernels_fit_their_wave_budgets():
+    """dsblock_pc.inc: 512 threads = one producer + one consumer per SIMD = 256 registers each; the consumer's hand-written fragment step pins
+    v[208:251], so a spill would mean the compiler ran out of the rest.  dsblock_rs2.inc: 8 waves (24 -> 48 -> 48, stage-1 taps in registers: <= 256) or
+    16 waves (16 -> 24 -> 48: <= 128).  ctc_head_x6.hip: 12 waves x 2 row tiles = three waves per SIMD (<= 168 registers).  None may touch scratch."""
+    pc = {k: v for k, v in _resources("dsblock_pc.hip").items() if "dsblock_pc_kernel" in k}
+    assert len(pc) == 2
+    for name, r in pc.items():
+        assert r["vgprs"] <= 256 and r["spill"] == 0 and r["scratch"] == 0 and r["occupancy"] >= 2, (name, r)
+    rs2 = {k: v for k, v in _resources("dsblock_rs2.hip").items() if "dsblock_rs2_kernel" in k}
+    assert len(rs2) == 6
+    for name, r in rs2.items():
+        cap = 128 if "ILi1ELi2ELi3ELi16E" in name else 256
+        assert r["vgprs"] <= cap and r["spill"] == 0 and r["scratch"] == 0, (name, r)
+    ch = {k: v for k, v in _resources("ctc_head_x6.hip").items() if "ctc_head_x6_kernel" in k}
+    assert len(ch) == 2
+    for name, r in ch.items():
+        assert r["vgprs"] <= 168 and r["spill"] == 0 and r["scratch"] == 0 and r["occupancy"] >= 3, (name, r)
