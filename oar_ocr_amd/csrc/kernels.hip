@@ -1163,28 +1163,33 @@ void softmax_argmax(hipStream_t s, const float* logits, int64_t rows, int C, int
     hipLaunchKernelGGL(softmax_argmax_kernel, dim3((unsigned)rows), dim3(256), (size_t)C * sizeof(float), s, logits, C, ld, idx, prob);
 }
 
-// merges the per-tile softmax partials of conv_igemm's CTC epilogue: one thread per row
+// merges the per-tile softmax partials of the CTC heads' epilogues: 16 lanes per row (round 5: one thread per row left 40 workgroups walking 54 tiles
+// each, 21 us per batch; lane l takes tiles l, l + 16, ..., then a fixed xor tree: the result does not depend on the launch geometry)
 __global__ __launch_bounds__(256) void ctc_combine_kernel(const float4* part, long rows, int tiles, int64_t* idx, float* prob) {
-    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= rows) return;
-    const float4* pr = part + row * tiles;
+    const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15;
+    const bool live = row < rows;
+    const float4* pr = part + (live ? row : 0) * tiles;
     float M = -3.402823466e38f;
-    for (int t = 0; t < tiles; ++t) M = fmaxf(M, pr[t].x);
+    if (live) for (int t = l; t < tiles; t += 16) M = fmaxf(M, pr[t].x);
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) M = fmaxf(M, __shfl_xor(M, o, 16));
     float S = 0.f;
-    int last = 0;
-    for (int t = 0; t < tiles; ++t) {
+    int last = -1;
+    if (live) for (int t = l; t < tiles; t += 16) {
         const float4 v = pr[t];
         const float e = expf(v.x - M);
         S += v.y * e;
-        if (e == 1.0f && __float_as_int(v.z) >= 0) last = __float_as_int(v.z);   // tiles ascend in column order
+        if (e == 1.0f && __float_as_int(v.z) >= 0) last = max(last, __float_as_int(v.z));   // columns ascend with the tile index: the largest hit is the last
     }
-    idx[row] = last;
-    prob[row] = 1.0f / S;
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) { S += __shfl_xor(S, o, 16); last = max(last, __shfl_xor(last, o, 16)); }
+    if (live && l == 0) { idx[row] = last < 0 ? 0 : last; prob[row] = 1.0f / S; }
 }
 void ctc_combine(hipStream_t s, const float* part, int64_t rows, int tiles, int64_t* idx, float* prob) {
     if (rows == 0) return;
     ProfScope ps(s, "ctc_combine", 16.0 * (double)rows * tiles, 0.0);
-    hipLaunchKernelGGL(ctc_combine_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(part), (long)rows, tiles, idx, prob);
+    hipLaunchKernelGGL(ctc_combine_kernel, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(part), (long)rows, tiles, idx, prob);
 }
 
 void softmax_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C) {
