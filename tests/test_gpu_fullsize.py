@@ -3,9 +3,9 @@ C3 had only Seam-A graph checks at 256x320).
 
 C2  PP-OCRv6-tiny-class det+rec, ONE predict of 32 pages of 960x960 (image batch 32, region batch 256: the bench's
     workload, with its 8/9-page detector sub-batches, the M >= 100 k kernel selections and ~1100 pooled crops);
-    4 pages -- one from each detector sub-batch -- are checked against the oracle.
+    8 pages -- at least one from each detector sub-batch -- are checked against the oracle (round 5: 4 -> 8; C3 3 -> 5; C4 rank 4 -> 6).
 C3  PP-OCRv5-server-class det + SVTR rec (V = 18710) through OAROCR.predict, 64 pages of 1280x1280 in one call with limit_side_len = 1280
-    (the reference needs that setting to really run 1280^2, src/oarocr/ocr.rs:351-363), 3 pages checked.
+    (the reference needs that setting to really run 1280^2, src/oarocr/ocr.rs:351-363), 5 pages checked.
 C4  rank 0 of 8's shard of the 1024-page list (128 pages, 2 host threads) through predict_packed -> oar_ocr_pack -> oar_packed_merge.
 
 Bar: boxes bit-exact, region order identical, recognition scores within 1e-3, texts equal unless the oracle's own top-2
@@ -92,8 +92,8 @@ def test_c2_32_pages_of_960x960_in_one_predict():
     total = sum(len(g.text_regions) for g in got)
     assert total > 900                                            # ~1090 regions: several 256-crop recognition batches
     assert len({round(t.rec_max_wh_ratio, 4) for g in got for t in g.text_regions}) >= 3
-    n, ties = _check_pages_against_oracle(got, imgs, [0, 9, 20, 31], det, rec, chars, {}, (0.3, 0.6, 1.5))
-    assert n > 100 and ties <= 2
+    n, ties = _check_pages_against_oracle(got, imgs, [0, 3, 9, 14, 20, 25, 28, 31], det, rec, chars, {}, (0.3, 0.6, 1.5))
+    assert n > 200 and ties <= 3
     # the packed metric path of bench.py returns the same boxes / texts / scores
     _, ptrs, ws, hs = api._img_arrays(imgs)
     packed = ocr.predict_packed(ptrs, ws, hs, 32)
@@ -115,7 +115,7 @@ def test_c3_server_graphs_on_1280x1280_pages():
     ocr = api.OAROCRBuilder(det, rec, chars).text_detection_config(cfg).image_batch_size(64).region_batch_size(64).build()
     got = ocr.predict(imgs)
     assert len(got) == 64 and sum(len(g.text_regions) for g in got) > 1500
-    n, ties = _check_pages_against_oracle(got, imgs, [0, 30, 63], det, rec, chars, dict(limit_side_len=1280), (0.3, 0.6, 1.5))
+    n, ties = _check_pages_against_oracle(got, imgs, [0, 17, 30, 46, 63], det, rec, chars, dict(limit_side_len=1280), (0.3, 0.6, 1.5))
     assert n > 60 and ties <= 2
     ocr.close()
 
@@ -123,7 +123,7 @@ def test_c3_server_graphs_on_1280x1280_pages():
 def test_c4_rank_0_of_8_shard_of_the_1024_page_list():
     """BASELINE C4 (1024 pages image-parallel over 8 GPUs) as ONE rank sees it: oar_shard_range(1024, 8, 0) = pages [0, 128), image_batch_size 32,
     a 2-thread geometry pool (the rank's share of the host), ONE predict over the whole shard, the result leaving as oar_ocr_pack's blob and meeting the
-    other ranks' blobs in oar_packed_merge.  Four pages of the shard are checked against the oracle, every page against the object-returning entry."""
+    other ranks' blobs in oar_packed_merge.  Six pages of the shard are checked against the oracle, every page against the object-returning entry."""
     a, b = api.shard_range(1024, 8, 0)
     assert (a, b) == (0, 128) and api.shard_range(1024, 8, 7) == (896, 1024)
     det, _ = models.build_det("tiny", seed=0)
@@ -142,7 +142,7 @@ def test_c4_rank_0_of_8_shard_of_the_1024_page_list():
         for t in g.text_regions:
             assert np.array_equal(packed.points[k], t.bounding_box) and packed.text(k) == t.text and packed.scores[k] == np.float32(t.confidence)
             k += 1
-    n, ties = _check_pages_against_oracle(got, imgs, [0, 41, 86, 127], det, rec, chars, {}, (0.3, 0.6, 1.5))
+    n, ties = _check_pages_against_oracle(got, imgs, [0, 23, 41, 64, 86, 127], det, rec, chars, {}, (0.3, 0.6, 1.5))
     assert n > 100 and ties <= 2
     # rank 0's blob + a second rank's (two pages of ITS shard) through the merge the host runs after its gather
     a1, _ = api.shard_range(1024, 8, 1)
