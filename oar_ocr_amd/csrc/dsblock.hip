@@ -232,7 +232,8 @@ Rs2Shape rs2_shape(const DsBlockP& a, const DsBlockP& b) {
     r.acts = hs ? 1 : 0;
     const int nch2 = r.nf1, ncp1 = (r.nch1 + 1) / 2, ncp2 = (nch2 + 1) / 2;
     const size_t slot1 = (size_t)r.nch1 * 18 * 64, slot2 = (size_t)nch2 * 18 * 64;
-    const size_t rings1 = (size_t)r.wpw * 3 * slot1, rings2 = (size_t)r.wpw * 2 * slot2;
+    const int lag = dsblock_rs2_lag(r.nch1, r.nf1, r.nf2);
+    const size_t rings1 = (size_t)r.wpw * 3 * slot1, rings2 = (size_t)r.wpw * (lag ? 2 : 1) * slot2;
     r.lds_ring2 = (unsigned)rings1;
     r.lds_dw1 = (unsigned)(rings1 + rings2);
     r.lds_pw1 = r.lds_dw1 + 10u * r.nch1 * 64u;
@@ -249,7 +250,7 @@ Rs2Shape rs2_shape(const DsBlockP& a, const DsBlockP& b) {
         const long items = (long)a.N * segs * r.tiles_x;
         if (items >= (1L << 30)) continue;
         const long rounds = (items + waves - 1) / waves;
-        const double cost = (double)rounds * (R + 5);
+        const double cost = (double)rounds * (R + (lag ? 5 : 4));
         if (cost < best - 1e-9) { best = cost; r.R = R; r.segs = segs; r.items = (int)items; }
         if (R >= 64 && rounds == 1) break;
     }
