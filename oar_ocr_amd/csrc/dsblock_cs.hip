@@ -42,6 +42,7 @@ void dsblock_cs_launch(hipStream_t s, const DsCsP& p, int ks, int sh, int sw, in
     // producer / consumer form (dsblock_pc.inc, round 5) wherever it is instantiated; OAR_DSB_PC=0 keeps the one-wave-per-SIMD kernel (A/B runs)
     static const bool pc_on = [] { const char* e = getenv("OAR_DSB_PC"); return !e || atoi(e) != 0; }();
     if (pc_on && dsblock_pc_launch(s, p, ks, sh, sw, nch, nft, acts, grid, e0, e1)) return;
+#ifdef OAR_DSB_ABLATIONS
     static const int dbg = [] { const char* e = getenv("OAR_DSB_CS_DBG"); return e ? atoi(e) : 0; }();   // timing ablations of the 192 -> 192 5x5 instantiation (wrong results)
     if (dbg && ks == 5 && nch == 12 && nft == 12 && acts) {
         switch (dbg) {
@@ -49,6 +50,7 @@ void dsblock_cs_launch(hipStream_t s, const DsCsP& p, int ks, int sh, int sw, in
             default: break;
         }
     }
+#endif
     OAR_CS_CASE(5, 1, 1, 12, 12, 4)
     OAR_CS_CASE(3, 1, 2, 6, 12, 4)
     OAR_CS_CASE(3, 1, 1, 6, 6, 4)

@@ -1,8 +1,15 @@
 // dsblock_rs_dbg.hip -- timing ablations of the row-streaming block at its flagship shape (48 -> 48, 3x3 stride 1, hard swish): OAR_DSB_DBG=<mask>
 // selects a variant that leaves ingredients out (WRONG results; tools/dsblock_bench.py only).  See DBG in dsblock_rs.inc.
+// Built only with OAR_DSB_ABLATIONS=1 in the environment of oar_ocr_amd/build.py (wrong-result kernels are a build option, not product code);
+// the product build gets a stub that fails loudly.
 #include "dsblock_rs.h"
 namespace oar {
 namespace k {
+#ifndef OAR_DSB_ABLATIONS
+void dsblock_rs_launch_dbg(hipStream_t, const DsRsP&, int, int, size_t, hipEvent_t, hipEvent_t) {
+    ::oar::fail(OAR_INTERNAL, "OAR_DSB_DBG needs a library built with OAR_DSB_ABLATIONS=1");
+}
+#else
 #include "dsblock_rs.inc"
 void dsblock_rs_launch_dbg(hipStream_t s, const DsRsP& p, int dbg, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1) {
     switch (dbg) {
@@ -42,5 +49,6 @@ void dsblock_rs_launch_dbg(hipStream_t s, const DsRsP& p, int dbg, int grid, siz
         default: ::oar::fail(OAR_INTERNAL, "dsblock_rs_dbg: this mask is not instantiated");
     }
 }
+#endif
 }  // namespace k
 }  // namespace oar
