@@ -1176,20 +1176,23 @@ oar_status oar_k_rotate_crop(const uint8_t* rgb, uint32_t w, uint32_t h, const f
 int32_t oar_host_candidates(const uint8_t* mask, uint32_t width, uint32_t height, uint32_t max_candidates, int32_t max_bands,
                             float* boxes8, int32_t cap) {
     try {
-        std::vector<int32_t> scratch((size_t)width * height);
-        std::vector<int> cuts = host::blank_row_bands(mask, (int)width, (int)height, max_bands < 1 ? 1 : max_bands);
+        // the detector's own route: the mask as a bit plane, row bands cut at blank rows, corner points only (pipeline.cc subbatch_candidates)
+        const int row_bytes = ((int)width + 7) / 8;
+        std::vector<uint8_t> bits((size_t)row_bytes * height, 0);
+        for (uint32_t y = 0; y < height; ++y)
+            for (uint32_t x = 0; x < width; ++x)
+                if (mask[(size_t)y * width + x]) bits[(size_t)y * row_bytes + (x >> 3)] |= (uint8_t)(1u << (x & 7));
+        std::vector<int> cuts = host::blank_row_bands_bits(bits.data(), row_bytes, (int)height, max_bands < 1 ? 1 : max_bands);
         std::vector<host::Contour> cs;
         for (size_t i = 0; i + 1 < cuts.size(); ++i) {
-            auto part = host::find_contours_band(mask, (int)width, (int)height, cuts[i], cuts[i + 1], max_candidates, scratch.data());
+            auto part = host::find_contours_band_bits(bits.data(), row_bytes, (int)width, cuts[i], cuts[i + 1], max_candidates, true);
             for (auto& c : part) { if (cs.size() >= max_candidates) break; cs.push_back(std::move(c)); }
         }
         int32_t n = 0;
         for (auto& c : cs) {
-            std::vector<host::Pt> simp = host::simplify_chain(c.pts);
             host::Pt mb[4];
             float ms = 0.f;
-            bool ok = simp.size() >= 3 ? host::mini_box(simp, mb, ms) : host::mini_box(c.pts, mb, ms);
-            if (!ok || ms < 3.0f) continue;
+            if (!host::contour_mini_box(c, mb, ms) || ms < 3.0f) continue;
             if (n < cap) for (int k = 0; k < 4; ++k) { boxes8[n * 8 + k * 2] = mb[k].x; boxes8[n * 8 + k * 2 + 1] = mb[k].y; }
             ++n;
         }

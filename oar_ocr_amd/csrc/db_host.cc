@@ -170,24 +170,220 @@ std::vector<Contour> find_contours_band(const uint8_t* mask, int width, int heig
     });
 }
 
-// The same from a bit-packed mask (pp::pack_mask_bits: pixel x of row y is bit x & 7 of byte bits[y * row_bytes + (x >> 3)])
-std::vector<Contour> find_contours_band_bits(const uint8_t* bits, int row_bytes, int width, int band_y0, int band_y1, size_t max_contours) {
-    return follow_band(width, band_y0, band_y1, max_contours, [&](int r, uint8_t* dst) {
-        const uint8_t* b = bits + (size_t)(band_y0 + r) * row_bytes;
-        int x = 0;
-        for (; x + 8 <= width; x += 8) {
-            // one mask byte -> eight 0 / 1 flag bytes: spread the bits to the byte lanes' low bits
-            const uint64_t v = b[x >> 3];
-            // bits 0..6: the seven shifted copies v7 << 7i put bit i of v7 on bit 8i and never overlap (j + 7i is a bijection
-            // for j in 0..6), so there are no carries; bit 7 separately
-            uint64_t flags = ((v & 0x7full) * 0x0002040810204081ull) & 0x0001010101010101ull;
-            flags |= (uint64_t)((v >> 7) & 1u) << 56;
-            std::memcpy(dst + x, &flags, 8);
+// ---- the same border following straight from a bit-packed mask (pp::pack_mask_bits: pixel x of row y is bit x & 7 of byte
+// bits[y * row_bytes + (x >> 3)]), without ever expanding it to a byte per pixel.
+// What the byte version spends its time on is not the walk: it is writing the 0.9 MB state plane of a 960^2 page and reading it back
+// to find the run ends.  Here the foreground stays a bit plane (framed by one background bit on every side, so the walk has no
+// bounds checks), the state "0 / unmarked / marked positive / marked negative" becomes two more bit planes that start out zero
+// (`marked`, `neg`: the three predicates of follow_band read exactly these), run starts / ends come out of 64-bit word arithmetic
+// (w & ~(w << 1), w & ~(w >> 1)), and a step of the walk reads the 3 x 3 neighbourhood with three 16-bit loads: a 512-entry table turns it
+// into the 8 neighbour flags in direction order, a rotate + count-leading-zeros replaces the search loop.
+// `corners_only`: DBPostProcess (Quad boxes, fast score) only ever looks at a contour through simplify_chain; whether a point survives that
+// (the step into it differs from the step out of it, db_bitmap.rs:207-239) is known while walking, so only those points are stored and the
+// contour is marked `simplified`.  A chain with fewer than three such points is kept whole, as simplify_chain does.
+namespace {
+struct StepTable {
+    uint8_t nb[512];        // 3 x 3 window -> neighbour flags in direction order w, nw, n, ne, e, se, s, sw
+    uint8_t step[8 * 512];  // (front, window) -> d4 | right_edge << 3 | (dx + 1) << 4 | (dy + 1) << 6
+    StepTable() {
+        static const int DX[8] = {-1, -1, 0, 1, 1, 1, 0, -1};
+        static const int DY[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+        // window index: bits 0..2 = row above (x - 1, x, x + 1), 3..5 = the pixel's row, 6..8 = row below
+        for (int i = 0; i < 512; ++i) {
+            const int a = i & 7, m = (i >> 3) & 7, b = i >> 6;
+            nb[i] = (uint8_t)(((m >> 0) & 1) | ((a & 1) << 1) | (((a >> 1) & 1) << 2) | (((a >> 2) & 1) << 3) | (((m >> 2) & 1) << 4) |
+                              (((b >> 2) & 1) << 5) | (((b >> 1) & 1) << 6) | ((b & 1) << 7));
         }
-        for (; x < width; ++x) dst[x] = (b[x >> 3] >> (x & 7)) & 1u;
-    });
+        for (int front = 0; front < 8; ++front)
+            for (int i = 0; i < 512; ++i) {
+                // counter-clockwise search starting next to the previous pixel: bit k of r is direction (front + k) & 7, the search runs
+                // k = 7 .. 0 and stops at the first foreground one (bit 0, the previous pixel, always is inside a walk); east was examined on
+                // the way iff its k is larger
+                const unsigned n = nb[i], r = ((n >> front) | (n << (8 - front))) & 0xffu;
+                if (!r) { step[front * 512 + i] = 0; continue; }
+                const int k4 = 31 - __builtin_clz(r);
+                const int d4 = (front + k4) & 7;
+                const int right_edge = ((4 - front) & 7) > k4;
+                step[front * 512 + i] = (uint8_t)(d4 | (right_edge << 3) | ((DX[d4] + 1) << 4) | ((DY[d4] + 1) << 6));
+            }
+    }
+};
+const StepTable kStep;
+
+struct BitFollower {
+    int width, band_y0, stride;            // stride: bytes per framed row (a multiple of 8; 8 spare bytes on either side of the pixels for the unaligned loads)
+    uint8_t *fg, *marked, *neg;            // framed planes (pointing past a row's left spare bytes): pixel x of band row r is bit (x + 1) of row (r + 1)
+    std::vector<Contour>* out;
+    size_t max_contours;
+    bool corners_only, full = false;
+    std::vector<Pt> pts;
+
+    inline unsigned window(int X, int Y) const {   // framed coordinates
+        const uint8_t* r = fg + (size_t)Y * stride + ((X - 1) >> 3);
+        const int sh = (X - 1) & 7;
+        uint16_t a, m, b;
+        std::memcpy(&a, r - stride, 2); std::memcpy(&m, r, 2); std::memcpy(&b, r + stride, 2);
+        return ((a >> sh) & 7) | (((m >> sh) & 7) << 3) | (((b >> sh) & 7) << 6);
+    }
+
+    // one border from (x, y) [band-local row]; `first`: direction of the background neighbour that triggered it.  keep_all: every point,
+    // otherwise only the points simplify_chain keeps (returns false, with nothing stored, when those are fewer than three)
+    template <bool kKeepAll>
+    bool walk(int x, int y, int first) {
+        static const int DX[8] = {-1, -1, 0, 1, 1, 1, 0, -1};
+        static const int DY[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+        pts.clear();
+        const int X0 = x + 1, Y0 = y + 1;
+        const unsigned n0 = kStep.nb[window(X0, Y0)];
+        if (n0 == 0) {
+            pts.push_back({(float)x, (float)(y + band_y0)});
+            const size_t o = (size_t)Y0 * stride + (X0 >> 3);
+            marked[o] |= (uint8_t)(1u << (X0 & 7)); neg[o] |= (uint8_t)(1u << (X0 & 7));
+            return true;
+        }
+        const int d1 = (first + __builtin_ctz(((n0 >> first) | (n0 << (8 - first))) & 0xffu)) & 7;   // clockwise from the trigger
+        const int X1 = X0 + DX[d1], Y1 = Y0 + DY[d1];
+        int X = X0, Y = Y0, front = d1;   // front: direction from the current pixel to the previous one
+        size_t n_pts = 0;
+        for (;;) {
+            const unsigned e = kStep.step[front * 512 + window(X, Y)];
+            const int d4 = e & 7;
+            const size_t o = (size_t)Y * stride + (X >> 3);
+            const uint8_t bit = (uint8_t)(1u << (X & 7));
+            marked[o] |= bit;
+            if (X == width || (e & 8)) neg[o] |= bit;
+            ++n_pts;
+            if (kKeepAll || (front ^ 4) != d4) pts.push_back({(float)(X - 1), (float)(Y - 1 + band_y0)});   // the step in differs from the step out
+            const int X4 = X + (int)((e >> 4) & 3) - 1, Y4 = Y + (int)(e >> 6) - 1;
+            if (X4 == X0 && Y4 == Y0 && X == X1 && Y == Y1) break;
+            X = X4; Y = Y4; front = d4 ^ 4;
+            // Four steps in five run straight along a horizontal edge (a text line's top and bottom): a pixel entered from the west leaves
+            // to the east iff its east neighbour is foreground and sw, s, se are background -- then east was not examined (no negative mark)
+            // and the step in equals the step out (not a simplify_chain point); mirrored (ne, n, nw) for a pixel entered from the east.
+            // Whole runs of such pixels are taken from 64-bit windows of the two rows involved: one ctz / clz, one OR into `marked`.
+            if (d4 == 4) {
+                for (;;) {
+                    const size_t ob = (size_t)Y * stride + ((X - 1) >> 3);
+                    const int sh = (X - 1) & 7;
+                    uint64_t c, b;
+                    std::memcpy(&c, fg + ob, 8); std::memcpy(&b, fg + ob + stride, 8);
+                    c >>= sh; b >>= sh;   // bit i = pixel X - 1 + i; 64 - sh >= 57 bits are real
+                    const uint64_t go = (c >> 2) & ~b & ~(b >> 1) & ~(b >> 2);   // bit i: pixel X + i continues east
+                    int L = __builtin_ctzll(~go | (1ull << 54));
+                    if (Y == Y1 && X1 >= X && X1 < X + L) L = X1 - X;   // the walk may end at p1 -> p0: p1 takes an ordinary step
+                    if (L == 0) break;
+                    uint64_t mk;
+                    std::memcpy(&mk, marked + ob, 8);
+                    mk |= ((1ull << L) - 1) << (sh + 1);
+                    std::memcpy(marked + ob, &mk, 8);
+                    n_pts += (size_t)L;
+                    if (kKeepAll) for (int i = 0; i < L; ++i) pts.push_back({(float)(X - 1 + i), (float)(Y - 1 + band_y0)});
+                    X += L;
+                    if (L < 54) break;
+                }
+            } else if (d4 == 0) {
+                for (;;) {
+                    const int top = X + 1;                                   // the word's last pixel
+                    const ptrdiff_t ob = (ptrdiff_t)Y * stride + (top >> 3) - 7;   // may reach into the row's left spare bytes (zero)
+                    const int up = 7 - (top & 7);
+                    uint64_t c, a;
+                    std::memcpy(&c, fg + ob, 8); std::memcpy(&a, fg + ob - stride, 8);
+                    c <<= up; a <<= up;   // bit 63 - i = pixel X + 1 - i; 64 - up >= 57 bits are real
+                    const uint64_t go = (c << 2) & ~a & ~(a << 1) & ~(a << 2);   // bit 63 - i: pixel X - i continues west
+                    int L = __builtin_clzll(~go | (1ull << 9));
+                    if (Y == Y1 && X1 <= X && X1 > X - L) L = X - X1;
+                    if (L == 0) break;
+                    uint64_t mk;
+                    std::memcpy(&mk, marked + ob, 8);
+                    mk |= (((1ull << L) - 1) << (63 - L)) >> up;   // pixels X - L + 1 .. X: bits 63 - L .. 62 before the shift back
+                    std::memcpy(marked + ob, &mk, 8);
+                    n_pts += (size_t)L;
+                    if (kKeepAll) for (int i = 0; i < L; ++i) pts.push_back({(float)(X - 1 - i), (float)(Y - 1 + band_y0)});
+                    X -= L;
+                    if (L < 54) break;
+                }
+            }
+        }
+        return kKeepAll || (n_pts > 2 && pts.size() >= 3);
+    }
+
+    void follow(int x, int y, int first, bool hole) {
+        Contour c;
+        c.hole = hole;
+        if (corners_only && walk<false>(x, y, first)) c.simplified = pts.size() >= 3;   // a lone pixel comes back as itself
+        else walk<true>(x, y, first);   // (again: the marks it leaves are the same) a chain simplify_chain would hand back whole
+        c.pts.assign(pts.begin(), pts.end());
+        out->push_back(std::move(c));
+        if (out->size() >= max_contours) full = true;
+    }
+};
+}  // namespace
+
+std::vector<Contour> find_contours_band_bits(const uint8_t* bits, int row_bytes, int width, int band_y0, int band_y1, size_t max_contours, bool corners_only) {
+    std::vector<Contour> out;
+    const int rows = band_y1 - band_y0;
+    if (rows <= 0 || width <= 0) return out;
+    const int words = (width + 2 + 63) / 64;
+    const int stride = words * 8 + 16;
+    static thread_local std::vector<uint8_t> planes;
+    const size_t plane_bytes = (size_t)(rows + 2) * stride;
+    planes.assign(plane_bytes * 3 + 8, 0);
+    BitFollower bf;
+    bf.width = width; bf.band_y0 = band_y0; bf.stride = stride;
+    bf.fg = planes.data() + 8; bf.marked = bf.fg + plane_bytes; bf.neg = bf.marked + plane_bytes;
+    bf.out = &out; bf.max_contours = max_contours; bf.corners_only = corners_only;
+    // framed foreground: the source row shifted up by one bit
+    const int src_words = (row_bytes + 7) / 8;
+    for (int r = 0; r < rows; ++r) {
+        const uint8_t* src = bits + (size_t)(band_y0 + r) * row_bytes;
+        uint8_t* dst = bf.fg + (size_t)(r + 1) * stride;
+        uint64_t carry = 0;
+        for (int j = 0; j < words; ++j) {
+            uint64_t w = 0;
+            if (j < src_words) std::memcpy(&w, src + (size_t)j * 8, (size_t)std::min(8, row_bytes - j * 8));
+            const uint64_t o = (w << 1) | carry;
+            carry = w >> 63;
+            std::memcpy(dst + (size_t)j * 8, &o, 8);
+        }
+    }
+    // raster scan: only the first / last pixel of a foreground run can start a border (imageproc's loop body, see follow_band::visit): an
+    // outer one where the run starts (x > 0, pixel not yet on a followed border), else a hole border where it ends (x + 1 < width, pixel not
+    // marked negative).  A followed border only ever ADDS marks, so the words are simply re-read after each one.
+    const int last_word = (width >> 6), last_bit = width & 63;   // framed position of pixel width - 1
+    for (int y = 0; y < rows && !bf.full; ++y) {
+        const size_t ro = (size_t)(y + 1) * stride;
+        uint64_t prev_msb = 0, w;
+        std::memcpy(&w, bf.fg + ro, 8);
+        for (int j = 0; j < words && !bf.full; ++j) {
+            uint64_t next = 0;
+            if (j + 1 < words) std::memcpy(&next, bf.fg + ro + (size_t)(j + 1) * 8, 8);
+            if (w) {
+                uint64_t starts = w & ~((w << 1) | prev_msb);
+                uint64_t ends = w & ~((w >> 1) | (next << 63));
+                if (j == 0) starts &= ~2ull;                                   // x == 0 never starts an outer border
+                if (j == last_word) ends &= ~(1ull << last_bit);               // x == width - 1 never starts a hole border
+                uint64_t done = 0;                                             // positions already visited in this word
+                for (;;) {
+                    uint64_t mk, ng;
+                    std::memcpy(&mk, bf.marked + ro + (size_t)j * 8, 8);
+                    std::memcpy(&ng, bf.neg + ro + (size_t)j * 8, 8);
+                    const uint64_t outer = starts & ~mk, hole = ends & ~ng & ~outer;
+                    const uint64_t cand = (outer | hole) & ~done;
+                    if (!cand) break;
+                    const int b = __builtin_ctzll(cand);
+                    done |= (2ull << b) - 1;                                   // (b == 63: 2 << 63 wraps to 0, - 1 = all ones)
+                    bf.follow(j * 64 + b - 1, y, ((outer >> b) & 1) ? 0 : 4, !((outer >> b) & 1));
+                    if (bf.full) break;
+                }
+            }
+            prev_msb = w >> 63;
+            w = next;
+        }
+    }
+    return out;
 }
 
+// blank_row_bands for a bit-packed mask
 std::vector<int> blank_row_bands_bits(const uint8_t* bits, int row_bytes, int height, int max_bands) {
     std::vector<uint8_t> occupied(height, 0);
     int fg_rows = 0;
@@ -216,29 +412,65 @@ std::vector<int> blank_row_bands_bits(const uint8_t* bits, int row_bytes, int he
 // ------------------------------------------------------------------------------------------ hull / min-area rect
 std::vector<Pt> convex_hull(const std::vector<Pt>& src) {
     if (src.size() < 3) return src;
-    std::vector<Pt> pts = src;
+    const size_t n = src.size();
     size_t si = 0;
-    for (size_t i = 1; i < pts.size(); ++i)
-        if (pts[i].y < pts[si].y || (pts[i].y == pts[si].y && pts[i].x < pts[si].x)) si = i;
-    std::swap(pts[0], pts[si]);
-    const Pt s = pts[0];
-    // the comparator of the reference (atan2 total_cmp, then squared distance) is a pure function of each point:
-    // evaluate it once per point instead of once per comparison (identical ordering, ~10x fewer libm calls)
-    struct Keyed { int32_t ang, dist; Pt p; };
-    std::vector<Keyed> keyed(pts.size() - 1);
-    for (size_t i = 1; i < pts.size(); ++i) {
-        const Pt& a = pts[i];
-        float d = (a.x - s.x) * (a.x - s.x) + (a.y - s.y) * (a.y - s.y);
-        keyed[i - 1] = {total_order_key(std::atan2(a.y - s.y, a.x - s.x)), total_order_key(d), a};
+    float mnx = src[0].x, mxx = src[0].x, mny = src[0].y, mxy = src[0].y;
+    bool integral = true;
+    for (size_t i = 0; i < n; ++i) {
+        const Pt& q = src[i];
+        if (q.y < src[si].y || (q.y == src[si].y && q.x < src[si].x)) si = i;
+        mnx = std::min(mnx, q.x); mxx = std::max(mxx, q.x); mny = std::min(mny, q.y); mxy = std::max(mxy, q.y);
+        integral = integral && q.x == std::floor(q.x) && q.y == std::floor(q.y);
     }
-    std::stable_sort(keyed.begin(), keyed.end(), [](const Keyed& a, const Keyed& b) {
+    const Pt s = src[si];
+    // The points that enter the sort.  The reference sorts ALL of them (geometry.rs:226-271: Graham scan, keys atan2f then squared
+    // distance, stable).  For border pixels -- integer coordinates -- inside a box whose diagonal is at most 1000 px every quantity of
+    // the scan is exact: two directions from s that differ at all differ by >= 1 / (|p| |q|) >= 1e-6 rad, four ulps of an angle in
+    // (0, pi], so the atan2f keys (glibc: < 1 ulp, and a function of the float quotient y / x, hence equal along a ray) order the
+    // points exactly by angle; the squared distances and the cross products are integers below 2^24.  An exact Graham scan returns the
+    // strict hull vertices counter-clockwise from s whatever else was in its input, and a strict hull vertex is the leftmost or the
+    // rightmost point of its row -- so only those (at most two per row) are sorted: a text line's few hundred corner points become
+    // a few dozen, and the atan2f calls with them.  Anything else (non-integer points: unclipped polygons; larger boxes) takes the
+    // reference's route point for point.
+    static thread_local std::vector<Pt> cand;
+    cand.clear();
+    cand.push_back(s);
+    const float ex = mxx - mnx, ey = mxy - mny;
+    if (integral && n > 12 && ex * ex + ey * ey <= 1.0e6f && std::isfinite(ex) && std::isfinite(ey)) {
+        const int R = (int)ey + 1, y0 = (int)mny;
+        static thread_local std::vector<float> lo, hi;
+        lo.assign((size_t)R, INFINITY); hi.assign((size_t)R, -INFINITY);
+        for (const Pt& q : src) {
+            const int r = (int)q.y - y0;
+            lo[r] = std::min(lo[r], q.x); hi[r] = std::max(hi[r], q.x);
+        }
+        for (int r = 0; r < R; ++r) {
+            if (lo[r] > hi[r]) continue;   // a row without points
+            const float y = (float)(y0 + r);
+            if (!(r == 0 && lo[r] == s.x)) cand.push_back({lo[r], y});
+            if (hi[r] != lo[r]) cand.push_back({hi[r], y});
+        }
+    } else {
+        for (size_t i = 0; i < n; ++i) if (i != si) cand.push_back(src[i]);
+    }
+    // the comparator of the reference (atan2 total_cmp, then squared distance) is a pure function of each point: evaluate it once
+    // per point instead of once per comparison; the index as the last key makes std::sort the reference's stable sort
+    struct Keyed { int32_t ang, dist; uint32_t idx; };
+    static thread_local std::vector<Keyed> keyed;
+    keyed.resize(cand.size() - 1);
+    for (size_t i = 1; i < cand.size(); ++i) {
+        const Pt& a = cand[i];
+        float d = (a.x - s.x) * (a.x - s.x) + (a.y - s.y) * (a.y - s.y);
+        keyed[i - 1] = {total_order_key(std::atan2(a.y - s.y, a.x - s.x)), total_order_key(d), (uint32_t)i};
+    }
+    std::sort(keyed.begin(), keyed.end(), [](const Keyed& a, const Keyed& b) {
         if (a.ang != b.ang) return a.ang < b.ang;
-        return a.dist < b.dist;
+        if (a.dist != b.dist) return a.dist < b.dist;
+        return a.idx < b.idx;
     });
-    for (size_t i = 1; i < pts.size(); ++i) pts[i] = keyed[i - 1].p;
     std::vector<Pt> hull;
-    hull.reserve(pts.size());
-    for (const Pt& p : pts) {
+    hull.reserve(std::min<size_t>(cand.size(), 64));
+    auto feed = [&](const Pt& p) {
         while (hull.size() > 1) {
             const Pt &a = hull[hull.size() - 2], &b = hull[hull.size() - 1];
             float cr = (b.x - a.x) * (p.y - a.y) - (b.y - a.y) * (p.x - a.x);
@@ -246,7 +478,9 @@ std::vector<Pt> convex_hull(const std::vector<Pt>& src) {
             else break;
         }
         hull.push_back(p);
-    }
+    };
+    feed(s);
+    for (const Keyed& k : keyed) feed(cand[k.idx]);
     return hull;
 }
 
@@ -336,6 +570,12 @@ bool mini_box(const std::vector<Pt>& pts, Pt out[4], float& min_side) {
     out[0] = raw[i1]; out[1] = raw[i2]; out[2] = raw[i3]; out[3] = raw[i4];
     min_side = ms;
     return true;
+}
+
+bool contour_mini_box(const Contour& c, Pt out[4], float& min_side) {
+    if (c.simplified) return mini_box(c.pts, out, min_side);   // the tracer already kept simplify_chain's points (>= 3 of them)
+    std::vector<Pt> simp = simplify_chain(c.pts);
+    return simp.size() >= 3 ? mini_box(simp, out, min_side) : mini_box(c.pts, out, min_side);
 }
 
 // ------------------------------------------------------------------------------------------ unclip (Clipper2 offset)

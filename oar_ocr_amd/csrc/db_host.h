@@ -13,6 +13,7 @@ struct Pt { float x, y; };
 
 struct Contour {
     std::vector<Pt> pts;   // border pixels in tracing order
+    bool simplified = false;   // pts already is simplify_chain(border pixels) (find_contours_band_bits with corners_only)
     bool hole = false;
     int parent = -1;
 };
@@ -27,7 +28,9 @@ std::vector<Contour> find_contours(const uint8_t* mask, int width, int height, s
 std::vector<Contour> find_contours_band(const uint8_t* mask, int width, int height, int y0, int y1, size_t max_contours, int32_t* scratch);
 // The same two helpers on a bit-packed mask (what the detector reads back: 8x less PCIe traffic than the byte mask): pixel x of
 // row y is bit (x & 7) of byte bits[y * row_bytes + (x >> 3)]; bits past `width` in a row's last byte must be zero.
-std::vector<Contour> find_contours_band_bits(const uint8_t* bits, int row_bytes, int width, int y0, int y1, size_t max_contours);
+// corners_only: a contour whose simplify_chain keeps >= 3 points is returned as those points (`simplified`), which is all the
+// Quad / fast-score candidate stage reads; the others whole.
+std::vector<Contour> find_contours_band_bits(const uint8_t* bits, int row_bytes, int width, int y0, int y1, size_t max_contours, bool corners_only = false);
 std::vector<int> blank_row_bands_bits(const uint8_t* bits, int row_bytes, int height, int max_bands);
 // Row cuts for find_contours_band: returns band boundaries (first = 0, last = height); every interior boundary is a
 // row whose pixels are all zero; at most max_bands bands of roughly equal foreground-row count.
@@ -39,6 +42,8 @@ MinAreaRect min_area_rect(const std::vector<Pt>& src);                   // proc
 std::vector<Pt> simplify_chain(const std::vector<Pt>& p);                // processors/db_bitmap.rs:207-239
 // processors/db_bitmap.rs:164-205,253-277: ordered mini box + min side; false when rejected.
 bool mini_box(const std::vector<Pt>& pts, Pt out[4], float& min_side);
+// db_bitmap.rs:153-162: simplify the border chain, mini box of what is left (of the whole chain when fewer than 3 points are)
+bool contour_mini_box(const Contour& c, Pt out[4], float& min_side);
 // processors/db_bitmap.rs:279-368 (clipper2 inflate, Round join, precision 2)
 std::vector<Pt> unclip(const Pt box[4], float ratio);
 // processors/sorting.rs:35-84: returns the permutation

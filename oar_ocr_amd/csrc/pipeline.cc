@@ -303,11 +303,9 @@ bool contour_candidate(const host::Contour& c, Candidate& cd, int keep_contour =
         cd.contour = host::approx_poly_dp(c.pts, epsilon);
         return cd.contour.size() >= 4;
     }
-    std::vector<host::Pt> simp = host::simplify_chain(c.pts);
     host::Pt mb[4];
     float min_side = 0.f;
-    bool ok = simp.size() >= 3 ? host::mini_box(simp, mb, min_side) : host::mini_box(c.pts, mb, min_side);
-    if (!ok) return false;
+    if (!host::contour_mini_box(c, mb, min_side)) return false;
     if (min_side < 3.0f) return false;  // DBPostProcess::min_size (db_postprocess.rs:83)
     for (int i = 0; i < 4; ++i) { cd.pts[i * 2] = mb[i].x; cd.pts[i * 2 + 1] = mb[i].y; }
     if (keep_contour) cd.contour = c.pts;
@@ -372,7 +370,7 @@ void subbatch_candidates(ThreadPool& pool, const uint8_t* masks, size_t hw, int 
         auto t0 = std::chrono::steady_clock::now();
         const int i = by_rows[slot];
         const Band& bd = bands[i];
-        band_cs[i] = host::find_contours_band_bits(masks + (size_t)bd.page * hw, row_bytes, W, bd.y0, bd.y1, max_candidates);
+        band_cs[i] = host::find_contours_band_bits(masks + (size_t)bd.page * hw, row_bytes, W, bd.y0, bd.y1, max_candidates, keep_contour == kCandFast);
         tpage[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     });
     std::vector<std::vector<host::Contour>> cs(nb);

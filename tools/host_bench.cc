@@ -1,14 +1,43 @@
+// Host-side DB post-processing microbenchmark on real masks (gpurun_out/masks8.bin: 8 x 960 x 960 bytes, the oracle's
+// thresholded probability maps of bench pages 0..7; made by tools/make_mask.py --oracle).  One thread, per-page figures.
+//   /opt/rocm/bin/hipcc -O3 -std=c++17 -ffp-contract=off -x c++ -Ioar_ocr_amd/csrc tools/host_bench.cc oar_ocr_amd/csrc/db_host.cc -o /tmp/host_bench
 #include "db_host.h"
 #include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 using namespace oar::host;
-int main(){
-  std::vector<uint8_t> m(960*960); FILE*f=fopen("gpurun_out/mask.bin","rb"); fread(m.data(),1,m.size(),f); fclose(f);
-  auto t0=std::chrono::steady_clock::now();
-  std::vector<Contour> cs; for(int r=0;r<20;++r) cs=find_contours(m.data(),960,960,1000);
-  auto t1=std::chrono::steady_clock::now();
-  int nb=0; for(int r=0;r<20;++r){ nb=0; for(auto&c:cs){ auto s=simplify_chain(c.pts); Pt mb[4]; float ms; bool ok = s.size()>=3? mini_box(s,mb,ms):mini_box(c.pts,mb,ms); if(ok&&ms>=3) nb++; } }
-  auto t2=std::chrono::steady_clock::now();
-  printf("contours=%zu boxes=%d find=%.3f ms minibox=%.3f ms\n", cs.size(), nb, std::chrono::duration<double,std::milli>(t1-t0).count()/20, std::chrono::duration<double,std::milli>(t2-t1).count()/20);
+using clk = std::chrono::steady_clock;
+static double ms(clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); }
+int main(int argc, char** argv) {
+    const int W = 960, H = 960, N = 8, REP = 20;
+    std::vector<uint8_t> m((size_t)N * W * H);
+    FILE* f = fopen(argc > 1 ? argv[1] : "gpurun_out/masks8.bin", "rb");
+    if (!f || fread(m.data(), 1, m.size(), f) != m.size()) { fprintf(stderr, "no masks\n"); return 1; }
+    fclose(f);
+    const int rb = (W + 7) / 8;
+    std::vector<uint8_t> bits((size_t)N * H * rb, 0);
+    for (int k = 0; k < N; ++k)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x)
+                if (m[((size_t)k * H + y) * W + x]) bits[((size_t)k * H + y) * rb + (x >> 3)] |= 1u << (x & 7);
+    double t_find = 0, t_mb = 0;
+    size_t n_c = 0, n_pts = 0, n_box = 0;
+    for (int r = 0; r < REP; ++r) {
+        for (int k = 0; k < N; ++k) {
+            auto t0 = clk::now();
+            std::vector<Contour> cs = find_contours_band_bits(bits.data() + (size_t)k * H * rb, rb, W, 0, H, 1000, true);
+            auto t1 = clk::now();
+            for (auto& c : cs) {
+                Pt mb[4]; float msd;
+                bool ok = contour_mini_box(c, mb, msd);
+                if (r == 0) { n_pts += c.pts.size(); if (ok && msd >= 3) n_box++; }
+            }
+            auto t2 = clk::now();
+            if (r == 0) n_c += cs.size();
+            t_find += ms(t0, t1); t_mb += ms(t1, t2);
+        }
+    }
+    printf("per page: contours=%.1f kept_points=%.0f boxes=%.1f | find=%.3f ms minibox=%.3f ms\n", (double)n_c / N, (double)n_pts / N,
+           (double)n_box / N, t_find / (REP * N), t_mb / (REP * N));
 }
