@@ -2,8 +2,12 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#endif
 
 namespace oar {
 namespace host {
@@ -25,6 +29,8 @@ inline int32_t total_order_key(float f) {  // f32::total_cmp
     i ^= (int32_t)(((uint32_t)(i >> 31)) >> 1);
     return i;
 }
+// OAR_HOST_FAST=0: the round-4 host route (byte state plane, every point through simplify_chain and the sort) for A/B timing; same results
+inline bool host_fast() { static const bool v = [] { const char* e = getenv("OAR_HOST_FAST"); return !(e && e[0] == '0'); }(); return v; }
 inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 }  // namespace
 
@@ -320,6 +326,18 @@ struct BitFollower {
 }  // namespace
 
 std::vector<Contour> find_contours_band_bits(const uint8_t* bits, int row_bytes, int width, int band_y0, int band_y1, size_t max_contours, bool corners_only) {
+    if (!host_fast())
+        return follow_band(width, band_y0, band_y1, max_contours, [&](int r, uint8_t* dst) {
+            const uint8_t* b = bits + (size_t)(band_y0 + r) * row_bytes;
+            int x = 0;
+            for (; x + 8 <= width; x += 8) {   // one mask byte -> eight 0 / 1 flag bytes (bits 0..6 by a carry-free multiply, bit 7 apart)
+                const uint64_t v = b[x >> 3];
+                uint64_t flags = ((v & 0x7full) * 0x0002040810204081ull) & 0x0001010101010101ull;
+                flags |= (uint64_t)((v >> 7) & 1u) << 56;
+                std::memcpy(dst + x, &flags, 8);
+            }
+            for (; x < width; ++x) dst[x] = (b[x >> 3] >> (x & 7)) & 1u;
+        });
     std::vector<Contour> out;
     const int rows = band_y1 - band_y0;
     if (rows <= 0 || width <= 0) return out;
@@ -436,7 +454,7 @@ std::vector<Pt> convex_hull(const std::vector<Pt>& src) {
     cand.clear();
     cand.push_back(s);
     const float ex = mxx - mnx, ey = mxy - mny;
-    if (integral && n > 12 && ex * ex + ey * ey <= 1.0e6f && std::isfinite(ex) && std::isfinite(ey)) {
+    if (host_fast() && integral && n > 12 && ex * ex + ey * ey <= 1.0e6f && std::isfinite(ex) && std::isfinite(ey)) {
         const int R = (int)ey + 1, y0 = (int)mny;
         static thread_local std::vector<float> lo, hi;
         lo.assign((size_t)R, INFINITY); hi.assign((size_t)R, -INFINITY);
@@ -484,6 +502,69 @@ std::vector<Pt> convex_hull(const std::vector<Pt>& src) {
     return hull;
 }
 
+// The inner loop of the reference's min-area rectangle (geometry.rs:381-409: every hull edge against every hull vertex, h^2 projections --
+// 3 000 for the 56-gon an unclipped text line is): pn = nx dx + ny dy, pp = -ny dx + nx dy with their running minima / maxima.  Each lane
+// of the vector forms performs the scalar statement sequence (separate multiplies and adds, `v < m ? v : m` as min, `v > m ? v : m` as max),
+// and a minimum / maximum does not depend on the order it is taken in, so the four numbers are the scalar loop's (up to the sign of a
+// zero, which nothing downstream can see: the extents enter as differences and sums).
+namespace {
+using ExtentsFn = void (*)(const float*, const float*, size_t, float, float, float, float, float*);
+void extents_scalar(const float* xs, const float* ys, size_t n, float hix, float hiy, float nx, float ny, float* ext) {
+    const float px = -ny, py = nx;
+    float mnn = std::numeric_limits<float>::max(), mxn = std::numeric_limits<float>::lowest();
+    float mnp = mnn, mxp = mxn;
+    for (size_t k = 0; k < n; ++k) {
+        float dx = xs[k] - hix, dy = ys[k] - hiy;
+        float pn = nx * dx + ny * dy, pp = px * dx + py * dy;
+        if (pn < mnn) mnn = pn;
+        if (pn > mxn) mxn = pn;
+        if (pp < mnp) mnp = pp;
+        if (pp > mxp) mxp = pp;
+    }
+    ext[0] = mnn; ext[1] = mxn; ext[2] = mnp; ext[3] = mxp;
+}
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+void extents_sse2(const float* xs, const float* ys, size_t n, float hix, float hiy, float nx, float ny, float* ext) {   // n % 4 == 0
+    const __m128 vhx = _mm_set1_ps(hix), vhy = _mm_set1_ps(hiy), vnx = _mm_set1_ps(nx), vny = _mm_set1_ps(ny), vpx = _mm_set1_ps(-ny);
+    __m128 mnn = _mm_set1_ps(std::numeric_limits<float>::max()), mxn = _mm_set1_ps(std::numeric_limits<float>::lowest()), mnp = mnn, mxp = mxn;
+    for (size_t k = 0; k < n; k += 4) {
+        const __m128 dx = _mm_sub_ps(_mm_loadu_ps(xs + k), vhx), dy = _mm_sub_ps(_mm_loadu_ps(ys + k), vhy);
+        const __m128 pn = _mm_add_ps(_mm_mul_ps(vnx, dx), _mm_mul_ps(vny, dy)), pp = _mm_add_ps(_mm_mul_ps(vpx, dx), _mm_mul_ps(vnx, dy));
+        mnn = _mm_min_ps(pn, mnn); mxn = _mm_max_ps(pn, mxn); mnp = _mm_min_ps(pp, mnp); mxp = _mm_max_ps(pp, mxp);
+    }
+    float a[4], b[4], c[4], d[4];
+    _mm_storeu_ps(a, mnn); _mm_storeu_ps(b, mxn); _mm_storeu_ps(c, mnp); _mm_storeu_ps(d, mxp);
+    ext[0] = std::min(std::min(a[0], a[1]), std::min(a[2], a[3])); ext[1] = std::max(std::max(b[0], b[1]), std::max(b[2], b[3]));
+    ext[2] = std::min(std::min(c[0], c[1]), std::min(c[2], c[3])); ext[3] = std::max(std::max(d[0], d[1]), std::max(d[2], d[3]));
+}
+__attribute__((target("avx"))) void extents_avx(const float* xs, const float* ys, size_t n, float hix, float hiy, float nx, float ny, float* ext) {   // n % 8 == 0
+    const __m256 vhx = _mm256_set1_ps(hix), vhy = _mm256_set1_ps(hiy), vnx = _mm256_set1_ps(nx), vny = _mm256_set1_ps(ny), vpx = _mm256_set1_ps(-ny);
+    __m256 mnn = _mm256_set1_ps(std::numeric_limits<float>::max()), mxn = _mm256_set1_ps(std::numeric_limits<float>::lowest()), mnp = mnn, mxp = mxn;
+    for (size_t k = 0; k < n; k += 8) {
+        const __m256 dx = _mm256_sub_ps(_mm256_loadu_ps(xs + k), vhx), dy = _mm256_sub_ps(_mm256_loadu_ps(ys + k), vhy);
+        const __m256 pn = _mm256_add_ps(_mm256_mul_ps(vnx, dx), _mm256_mul_ps(vny, dy)), pp = _mm256_add_ps(_mm256_mul_ps(vpx, dx), _mm256_mul_ps(vnx, dy));
+        mnn = _mm256_min_ps(pn, mnn); mxn = _mm256_max_ps(pn, mxn); mnp = _mm256_min_ps(pp, mnp); mxp = _mm256_max_ps(pp, mxp);
+    }
+    // lanes -> one number each, in registers (eight lanes of four accumulators through memory cost as much as the loop of a 56-gon)
+    __m128 a = _mm_min_ps(_mm256_castps256_ps128(mnn), _mm256_extractf128_ps(mnn, 1)), b = _mm_max_ps(_mm256_castps256_ps128(mxn), _mm256_extractf128_ps(mxn, 1));
+    __m128 c = _mm_min_ps(_mm256_castps256_ps128(mnp), _mm256_extractf128_ps(mnp, 1)), d = _mm_max_ps(_mm256_castps256_ps128(mxp), _mm256_extractf128_ps(mxp, 1));
+    a = _mm_min_ps(a, _mm_movehl_ps(a, a)); b = _mm_max_ps(b, _mm_movehl_ps(b, b)); c = _mm_min_ps(c, _mm_movehl_ps(c, c)); d = _mm_max_ps(d, _mm_movehl_ps(d, d));
+    a = _mm_min_ss(a, _mm_shuffle_ps(a, a, 1)); b = _mm_max_ss(b, _mm_shuffle_ps(b, b, 1)); c = _mm_min_ss(c, _mm_shuffle_ps(c, c, 1)); d = _mm_max_ss(d, _mm_shuffle_ps(d, d, 1));
+    ext[0] = _mm_cvtss_f32(a); ext[1] = _mm_cvtss_f32(b); ext[2] = _mm_cvtss_f32(c); ext[3] = _mm_cvtss_f32(d);
+}
+#endif
+ExtentsFn pick_extents() {
+    if (!host_fast()) return nullptr;
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    __builtin_cpu_init();
+    return __builtin_cpu_supports("avx") ? extents_avx : extents_sse2;
+#else
+    return extents_scalar;
+#endif
+}
+const ExtentsFn g_extents = pick_extents();
+}  // namespace
+
 MinAreaRect min_area_rect(const std::vector<Pt>& src) {
     MinAreaRect zero{0, 0, 0, 0, 0};
     if (src.size() < 3) return zero;
@@ -502,6 +583,11 @@ MinAreaRect min_area_rect(const std::vector<Pt>& src) {
     float min_area = std::numeric_limits<float>::max();
     MinAreaRect best = zero;
     const size_t n = hp.size();
+    // the hull as x / y arrays, padded to a multiple of 8 with copies of the last vertex (a duplicate changes no minimum / maximum)
+    static thread_local std::vector<float> xs, ys;
+    const size_t np = (n + 7) & ~(size_t)7;
+    xs.resize(np); ys.resize(np);
+    for (size_t i = 0; i < np; ++i) { const Pt& q = hp[i < n ? i : n - 1]; xs[i] = q.x; ys[i] = q.y; }
     for (size_t i = 0; i < n; ++i) {
         size_t j = (i + 1) % n;
         float ex = hp[j].x - hp[i].x, ey = hp[j].y - hp[i].y;
@@ -510,16 +596,22 @@ MinAreaRect min_area_rect(const std::vector<Pt>& src) {
         float inv = 1.0f / std::sqrt(el2);
         float nx = ex * inv, ny = ey * inv, px = -ny, py = nx;
         float hix = hp[i].x, hiy = hp[i].y;
-        float mnn = std::numeric_limits<float>::max(), mxn = std::numeric_limits<float>::lowest();
-        float mnp = mnn, mxp = mxn;
-        for (const Pt& q : hp) {
-            float dx = q.x - hix, dy = q.y - hiy;
-            float pn = nx * dx + ny * dy, pp = px * dx + py * dy;
-            if (pn < mnn) mnn = pn;
-            if (pn > mxn) mxn = pn;
-            if (pp < mnp) mnp = pp;
-            if (pp > mxp) mxp = pp;
+        float ext[4];   // min / max of the projections on the edge direction, min / max on its normal
+        if (g_extents) g_extents(xs.data(), ys.data(), np, hix, hiy, nx, ny, ext);
+        else {   // OAR_HOST_FAST=0: the loop as round 4 had it
+            float mnn = std::numeric_limits<float>::max(), mxn = std::numeric_limits<float>::lowest();
+            float mnp = mnn, mxp = mxn;
+            for (const Pt& q : hp) {
+                float dx = q.x - hix, dy = q.y - hiy;
+                float pn = nx * dx + ny * dy, pp = px * dx + py * dy;
+                if (pn < mnn) mnn = pn;
+                if (pn > mxn) mxn = pn;
+                if (pp < mnp) mnp = pp;
+                if (pp > mxp) mxp = pp;
+            }
+            ext[0] = mnn; ext[1] = mxn; ext[2] = mnp; ext[3] = mxp;
         }
+        const float mnn = ext[0], mxn = ext[1], mnp = ext[2], mxp = ext[3];
         float w = mxn - mnn, h = mxp - mnp, area = w * h;
         if (area < min_area) {
             min_area = area;

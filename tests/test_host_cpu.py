@@ -105,3 +105,80 @@ def test_thread_pool_back_to_back_jobs():
     L.oar_host_pool_selftest.restype = C.c_int32
     for threads in (2, 7, 16, 48):
         assert L.oar_host_pool_selftest(threads, 20000) == 0
+
+
+# ---------------------------------------------------------------------------------------------- round 5: bit-plane border follower
+def _stress_masks():
+    rng = np.random.default_rng(55)
+    out = []
+    for w in (1, 2, 7, 8, 9, 62, 63, 64, 65, 66, 126, 127, 128, 129, 190, 200):       # word / byte boundaries of the framed bit plane
+        for dens in (0.15, 0.5, 0.85):
+            out.append(((rng.random((1 + int(rng.integers(1, 40)), w)) < dens) * 255).astype(np.uint8))
+    for _ in range(12):                                                                  # blobs with long straight edges (run skipping)
+        h, w = int(rng.integers(20, 80)), int(rng.integers(100, 400))
+        m = np.zeros((h, w), np.uint8)
+        for _ in range(int(rng.integers(1, 6))):
+            y0, x0 = int(rng.integers(0, h - 3)), int(rng.integers(0, w - 10))
+            m[y0:y0 + int(rng.integers(1, 12)), x0:x0 + int(rng.integers(3, 300))] = 255
+        m ^= ((rng.random(m.shape) < 0.01) * 255).astype(np.uint8)
+        out.append(m)
+    for _ in range(8):                                                                   # one-pixel strokes in all 8 directions
+        h, w = 60, 130
+        m = np.zeros((h, w), np.uint8)
+        for _ in range(10):
+            x, y, dx, dy = int(rng.integers(0, w)), int(rng.integers(0, h)), int(rng.integers(-1, 2)), int(rng.integers(-1, 2))
+            for i in range(int(rng.integers(2, 60))):
+                xx, yy = x + i * dx, y + i * dy
+                if 0 <= xx < w and 0 <= yy < h:
+                    m[yy, xx] = 255
+        out.append(m)
+    return out
+
+
+def test_bit_plane_follower_matches_oracle_chain_for_chain():
+    """find_contours_band_bits (word-level run ends, table-driven steps, whole horizontal runs per ctz / clz) against the oracle's
+    restatement of imageproc's find_contours: same borders, same order, same points -- and the candidates that come out of its
+    corner-only mode (the detector's route) against simplify_chain + mini_box of the oracle."""
+    n_c = 0
+    for m in _stress_masks():
+        ref = R.find_contours(m)
+        for bands in (1, 3):
+            got = api.host_contours(m, 100000, bands, bits=True)
+            assert len(got) == len(ref)
+            for (gp, gt), (rp, rt, _) in zip(got, ref):
+                assert gt == rt and np.array_equal(gp, rp)
+        n_c += len(ref)
+        assert np.array_equal(api.host_candidates(m, 100000, 2), oracle_candidates(m, 100000))
+        k = max(1, len(ref) // 2)                                                        # take(max_candidates) mid-band
+        assert np.array_equal(api.host_candidates(m, k, 1), oracle_candidates(m, k))
+    assert n_c > 3000
+
+
+def test_host_fast_route_equals_the_round4_route():
+    """OAR_HOST_FAST=0 keeps the round-4 host route (byte state plane, every point through simplify_chain and the Graham sort, scalar
+    min-area-rectangle loop) for A/B timing: both routes must give the same candidates, unclipped polygons and second mini boxes."""
+    import os, subprocess, sys
+    code = r'''
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+from oar_ocr_amd import api
+sys.path.insert(0, %r)
+from test_host_cpu import blob_mask, _stress_masks
+h = hashlib.sha256()
+n = 0
+for m in [blob_mask(s, (960, 960), 40) for s in (11, 12)] + _stress_masks():
+    c = api.host_candidates(m, 1000, 4)
+    h.update(c.tobytes())
+    for b in c[:40]:
+        u = api.host_unclip(b, 1.5)
+        h.update(u.tobytes())
+        if len(u) >= 3:
+            mb = api.host_mini_box(u)
+            h.update(repr(None if mb is None else (mb[0].tobytes(), float(mb[1]))).encode())
+            n += 1
+print(n, h.hexdigest())
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    outs = [subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OAR_HOST_FAST=v), capture_output=True, text=True, timeout=600) for v in ("0", "1")]
+    assert all(o.returncode == 0 for o in outs), outs[0].stderr[-2000:] + outs[1].stderr[-2000:]
+    assert outs[0].stdout == outs[1].stdout and int(outs[0].stdout.split()[0]) > 100

@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <array>
 #include <vector>
 using namespace oar::host;
 using clk = std::chrono::steady_clock;
@@ -21,23 +22,34 @@ int main(int argc, char** argv) {
         for (int y = 0; y < H; ++y)
             for (int x = 0; x < W; ++x)
                 if (m[((size_t)k * H + y) * W + x]) bits[((size_t)k * H + y) * rb + (x >> 3)] |= 1u << (x & 7);
-    double t_find = 0, t_mb = 0;
+    double t_find = 0, t_mb = 0, t_fin = 0;
+    size_t n_un = 0, n_fin = 0;
     size_t n_c = 0, n_pts = 0, n_box = 0;
     for (int r = 0; r < REP; ++r) {
         for (int k = 0; k < N; ++k) {
             auto t0 = clk::now();
             std::vector<Contour> cs = find_contours_band_bits(bits.data() + (size_t)k * H * rb, rb, W, 0, H, 1000, true);
             auto t1 = clk::now();
+            std::vector<std::array<Pt, 4>> boxes;
             for (auto& c : cs) {
                 Pt mb[4]; float msd;
                 bool ok = contour_mini_box(c, mb, msd);
                 if (r == 0) { n_pts += c.pts.size(); if (ok && msd >= 3) n_box++; }
+                if (ok && msd >= 3) boxes.push_back({mb[0], mb[1], mb[2], mb[3]});
             }
             auto t2 = clk::now();
+            for (auto& bx : boxes) {   // a11-a12 for every candidate (the pipeline only does it for those that pass the score gate)
+                std::vector<Pt> un = unclip(bx.data(), 1.5f);
+                Pt bp[4]; float ss;
+                bool ok2 = !un.empty() && mini_box(un, bp, ss);
+                if (r == 0) { n_un += un.size(); n_fin += ok2; }
+            }
+            auto t3 = clk::now();
+            t_fin += ms(t2, t3);
             if (r == 0) n_c += cs.size();
             t_find += ms(t0, t1); t_mb += ms(t1, t2);
         }
     }
-    printf("per page: contours=%.1f kept_points=%.0f boxes=%.1f | find=%.3f ms minibox=%.3f ms\n", (double)n_c / N, (double)n_pts / N,
-           (double)n_box / N, t_find / (REP * N), t_mb / (REP * N));
+    printf("per page: contours=%.1f kept_points=%.0f boxes=%.1f | find=%.3f ms minibox=%.3f ms | unclip + second mini box=%.3f ms (%.0f vertices per box)\n", (double)n_c / N, (double)n_pts / N,
+           (double)n_box / N, t_find / (REP * N), t_mb / (REP * N), t_fin / (REP * N), (double)n_un / std::max<size_t>(n_fin, 1));
 }
