@@ -274,6 +274,7 @@ def main():
     S = min(5, max(args.steps, 1))
     balanced = S * (args.steps // S)
     barrier()
+    cpu0 = os.times()
     t0 = time.perf_counter()
     for i in range(args.steps):
         if dominant:
@@ -281,6 +282,9 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    cpu1 = os.times()
+    # CPU time of this rank's process (every thread: caller, geometry pool, uploader, enqueuer, HIP runtime) per timed step -- what a rank costs its host
+    host_cpu_ms = ((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / max(args.steps, 1) * 1e3
     if not stub:
         api.prof_sampling(1, 0)
     roof = None
@@ -512,7 +516,7 @@ def main():
                                    f"sorted boxes + texts + scores on the host{' of rank 0 (RCCL gather inside the region)' if world > 1 else ''}",
                        "pages_per_gpu_per_step": n_pages, "image_batch_size": image_batch, "region_batch_size": args.region_batch,
                        "regions_per_step": gathered["regions"], "text_bytes_per_step": gathered["bytes"], "pages_gathered_per_step": gathered["pages"],
-                       "parallelism": f"image-parallel x{world}", "host_cores_per_rank": cores},
+                       "parallelism": f"image-parallel x{world}", "host_cores_per_rank": cores, "host_cpu_ms_per_step": round(host_cpu_ms, 2)},
             "roofline": roof, "cpu_baseline": cpu, "device_resident": dev_res, "pipelined": pipelined, "det_real_size": real_size, "conv_mfma_util": mfma_util, "kernel_ms_per_step_untimed_pass": breakdown, "predict_passes_total": passes["n"], "csrc_fingerprint": csrc_now,
         }
         print(json.dumps(line), flush=True)

@@ -366,11 +366,49 @@ void subbatch_candidates(ThreadPool& pool, const uint8_t* masks, size_t hw, int 
     std::vector<int> by_rows(bands.size());
     for (size_t i = 0; i < bands.size(); ++i) by_rows[i] = (int)i;
     std::stable_sort(by_rows.begin(), by_rows.end(), [&](int a, int b) { return bands[a].y1 - bands[a].y0 > bands[b].y1 - bands[b].y0; });
+    if (keep_contour == kCandFast) {
+        // Quad boxes, fast score (the hot path): a band's worker turns its contours into candidates right away -- the mini box of a contour
+        // costs about what following it does since round 5, so the bands still balance -- and the few hundred border chains of a band are
+        // released by the thread that allocated them: handing 2 600 small vectors per sub-batch back to the caller cost it 0.3 ms of
+        // cross-thread frees after the two stages had taken 0.3 ms together.  `take(max_candidates)` counts CONTOURS in discovery order, so
+        // every contour keeps its slot (ok = 0: no candidate) until the bands of a page are concatenated.
+        struct BandOut { std::vector<Candidate> cand; std::vector<uint8_t> ok; };
+        std::vector<BandOut> bo(bands.size());
+        pool.parallel_for((int)bands.size(), [&](int slot) {
+            auto t0 = std::chrono::steady_clock::now();
+            const int i = by_rows[slot];
+            const Band& bd = bands[i];
+            std::vector<host::Contour> cs = host::find_contours_band_bits(masks + (size_t)bd.page * hw, row_bytes, W, bd.y0, bd.y1, max_candidates, true);
+            BandOut& o = bo[i];
+            o.ok.assign(cs.size(), 0);
+            o.cand.reserve(cs.size() / 4 + 4);
+            for (size_t c = 0; c < cs.size(); ++c) {
+                Candidate cd;
+                if (contour_candidate(cs[c], cd, kCandFast)) { o.ok[c] = 1; o.cand.push_back(std::move(cd)); }
+            }
+            tpage[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        });
+        std::vector<size_t> taken(nb, 0);
+        for (int k = 0; k < nb; ++k) out[k].clear();
+        for (size_t i = 0; i < bands.size(); ++i) {   // band order == raster discovery order
+            const int k = bands[i].page;
+            size_t next = 0;
+            for (size_t c = 0; c < bo[i].ok.size() && taken[k] < max_candidates; ++c, ++taken[k])
+                if (bo[i].ok[c]) out[k].push_back(std::move(bo[i].cand[next++]));
+        }
+        if (g_timer && g_timer->on) {
+            double mx = 0, sum = 0;
+            for (double t : tpage) { mx = std::max(mx, t); sum += t; }
+            fprintf(stderr, "[timing]   subbatch nb=%d bands=%zu (contours + mini boxes per band: max %.2f avg %.2f ms) total=%.2fms\n", nb, bands.size(), mx,
+                    sum / std::max<size_t>(tpage.size(), 1), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count());
+        }
+        return;
+    }
     pool.parallel_for((int)bands.size(), [&](int slot) {
         auto t0 = std::chrono::steady_clock::now();
         const int i = by_rows[slot];
         const Band& bd = bands[i];
-        band_cs[i] = host::find_contours_band_bits(masks + (size_t)bd.page * hw, row_bytes, W, bd.y0, bd.y1, max_candidates, keep_contour == kCandFast);
+        band_cs[i] = host::find_contours_band_bits(masks + (size_t)bd.page * hw, row_bytes, W, bd.y0, bd.y1, max_candidates, false);
         tpage[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     });
     std::vector<std::vector<host::Contour>> cs(nb);

@@ -54,6 +54,24 @@ def test_detection_adapter_matches_oracle(nets, gpu_contours):
         pred.predict([])
 
 
+def test_detection_max_candidates_cuts_contours_in_discovery_order(nets):
+    """`take(max_candidates)` counts contours (not boxes) in raster discovery order; the detector follows a page band by band on the pool and
+    turns each band's contours into candidates where they were followed, so the cut has to be made when the bands are concatenated."""
+    det, _, _ = nets
+    imgs = [pages.make_page(31, (960, 960), lines=40), pages.make_page(32, (640, 960), lines=24)]
+    for maxc in (25, 120):
+        got = api.TextDetectionPredictor(det, api.TextDetectionConfig(0.3, 0.6, 1.5, max_candidates=maxc)).predict(imgs)
+        ref = pipeline_ref.OracleDetector(det, max_candidates=maxc).detect(imgs, 0.3, 0.6, 1.5)
+        full = pipeline_ref.OracleDetector(det).detect(imgs, 0.3, 0.6, 1.5)
+        for g, (rb, rs, prob), (fb, _, _) in zip(got, ref, full):
+            assert len(rb) < len(fb)                                   # the cut really removes something
+            gb = np.stack([d.bbox for d in g]) if g else np.zeros((0, 4, 2), np.float32)
+            if int((np.abs(prob - 0.3) < 1e-4).sum()) == 0:
+                assert np.array_equal(gb, rb)
+            else:
+                assert len(gb) == len(rb) and np.abs(gb - rb).max() <= 2.0
+
+
 def test_recognition_adapter_matches_oracle(nets):
     _, rec, chars = nets
     crops = [pages.make_crop(i, w, h) for i, (w, h) in enumerate([(320, 48), (200, 30), (411, 52), (90, 40), (640, 36)])]

@@ -6,7 +6,7 @@ ARGS="--cpu-pages 0 --no-pipelined --no-real-size --no-device-resident --no-prof
 show() { python - <<P
 import json
 try:
-    d=json.loads(open("gpurun_out/hab/$1.json").read().strip().splitlines()[-1]); print("$1", d["value"], d["ms_per_step"])
+    d=json.loads(open("gpurun_out/hab/$1.json").read().strip().splitlines()[-1]); print("$1", d["value"], d["ms_per_step"], "host cpu ms/step", d["config"].get("host_cpu_ms_per_step"))
 except Exception as e: print("$1 failed", e)
 P
 }
