@@ -110,10 +110,26 @@ static inline void wait_for_thread(Pred done) {
         else std::this_thread::yield();
     }
 }
+// Wait for a GPU event inside the detection phase, where the other threads of the call (pool workers, uploader, enqueuer) have work: the
+// runtime's own wait polls without ever giving the core away, which on a rank with two or four cores is time taken from them.
+// OAR_EVENT_YIELD=0 restores hipEventSynchronize.
+static void wait_event_yielding(hipEvent_t ev) {
+    static const bool on = [] { const char* e = getenv("OAR_EVENT_YIELD"); return !(e && e[0] == '0'); }();
+    if (!on) { OAR_HIP(hipEventSynchronize(ev)); return; }
+    for (int spins = 0;; ++spins) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) return;
+        if (q != hipErrorNotReady) OAR_HIP(q);
+        (void)hipGetLastError();   // "not ready" must not stay behind as the thread's last error
+        if (spins < 64) cpu_relax();
+        else std::this_thread::yield();
+    }
+}
 void ThreadPool::loop() {
     // OAR_POOL_SPIN_MS: how long an idle worker keeps polling before it parks (default 25 ms ~ one predict() of the
     // bench workload, so workers stay hot across the recognition phase of continuous serving)
     static const int spin_ms = [] { const char* e = getenv("OAR_POOL_SPIN_MS"); int v = e ? atoi(e) : 25; return v < 0 ? 0 : v; }();
+    static const bool pool_yield = [] { const char* e = getenv("OAR_POOL_YIELD"); return !(e && e[0] == '0'); }();   // A/B knob
     int seen = 0;
     while (!stop_.load(std::memory_order_acquire)) {
         // wait for a new generation: poll while the pool is active (and for at most spin_ms), else park
@@ -122,7 +138,10 @@ void ThreadPool::loop() {
             auto t0 = std::chrono::steady_clock::now();
             int spins = 0;
             while ((g = gen_.load(std::memory_order_acquire)) == seen && !stop_.load(std::memory_order_acquire)) {
-                cpu_relax();
+                // poll; after ~50 us without work give the core away on every round (a no-op while nobody else wants it): on a rank with two or
+                // four cores the uploader / enqueuer threads of the call are what a polling worker would otherwise be running instead of
+                if (spins < 2048 || !pool_yield) cpu_relax();
+                else std::this_thread::yield();
                 const bool idle = active_.load(std::memory_order_acquire) == 0;
                 if (idle || ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(spin_ms))) {
                     std::unique_lock<std::mutex> lk(mu_);
@@ -862,7 +881,7 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
     auto finish = [&](int sb) {
         const int b0 = sb_off[sb], nb = sb_off[sb + 1] - b0;
         ScoreSlot& sl = *score_slots_[sb];
-        if (sl.total) OAR_HIP(hipEventSynchronize(score_done_[sb]));
+        if (sl.total) wait_event_yielding(score_done_[sb]);
         tmark("box_scores_wait");
         const float* sc = sl.scores_host.as<float>();
         static const bool chunked = [] { const char* e = getenv("OAR_FINISH_CHUNKS"); return !e || atoi(e) != 0; }();   // 0: one task per page (A/B)
@@ -922,7 +941,7 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
             if (q == hipErrorNotReady) { (void)hipGetLastError(); finish(sb - 1); finished_prev = true; }   // ("not ready" must not stay behind as the thread's last error)
             else if (q != hipSuccess) OAR_HIP(q);
         }
-        OAR_HIP(hipEventSynchronize(sub_events_[sb]));
+        wait_event_yielding(sub_events_[sb]);
         tmark("det_gpu_wait");
         // BoxType::Poly scores the approximated polygon with box_score_fast whatever score_mode says (db_bitmap.rs:49)
         const bool poly = cfg_.box_type == 1;
@@ -1125,7 +1144,7 @@ Recognizer::Recognizer(const uint8_t* onnx, size_t len, const oar_rec_cfg& cfg) 
     // OAR_REC_LANES (default 1): with 2 lanes bench.py gains 4-5 % (1447-1500 vs 1393-1421 images/s), but the kernels of
     // the two streams then share the GPU and their individual durations (the roofline accounting, the rocprof averages)
     // stop being comparable with the isolated numbers -- opt-in until the profiler separates lanes
-    static const int n_lanes = [] { const char* e = getenv("OAR_REC_LANES"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : v > 4 ? 4 : v; }();
+    const int n_lanes = [] { const char* e = getenv("OAR_REC_LANES"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : v > 4 ? 4 : v; }();   // read per handle: bench.py times both
     for (int i = 1; i < n_lanes; ++i) {
         lanes_.emplace_back(new Engine(onnx, len, cfg_.device_id));
         lane_in_.emplace_back(new DevBuf());

@@ -1,5 +1,5 @@
 // Host-side DB post-processing microbenchmark on real masks (gpurun_out/masks8.bin: 8 x 960 x 960 bytes, the oracle's
-// thresholded probability maps of bench pages 0..7; made by tools/make_mask.py --oracle).  One thread, per-page figures.
+// thresholded probability maps of bench pages 0..7; made by `python tools/make_mask.py --oracle 8`).  One thread, per-page figures.
 //   /opt/rocm/bin/hipcc -O3 -std=c++17 -ffp-contract=off -x c++ -Ioar_ocr_amd/csrc tools/host_bench.cc oar_ocr_amd/csrc/db_host.cc -o /tmp/host_bench
 #include "db_host.h"
 #include <chrono>
