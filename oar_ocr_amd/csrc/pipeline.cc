@@ -110,21 +110,6 @@ static inline void wait_for_thread(Pred done) {
         else std::this_thread::yield();
     }
 }
-// Wait for a GPU event inside the detection phase, where the other threads of the call (pool workers, uploader, enqueuer) have work: the
-// runtime's own wait polls without ever giving the core away, which on a rank with two or four cores is time taken from them.
-// OAR_EVENT_YIELD=0 restores hipEventSynchronize.
-static void wait_event_yielding(hipEvent_t ev) {
-    static const bool on = [] { const char* e = getenv("OAR_EVENT_YIELD"); return !(e && e[0] == '0'); }();
-    if (!on) { OAR_HIP(hipEventSynchronize(ev)); return; }
-    for (int spins = 0;; ++spins) {
-        const hipError_t q = hipEventQuery(ev);
-        if (q == hipSuccess) return;
-        if (q != hipErrorNotReady) OAR_HIP(q);
-        (void)hipGetLastError();   // "not ready" must not stay behind as the thread's last error
-        if (spins < 64) cpu_relax();
-        else std::this_thread::yield();
-    }
-}
 void ThreadPool::loop() {
     // OAR_POOL_SPIN_MS: how long an idle worker keeps polling before it parks (default 25 ms ~ one predict() of the
     // bench workload, so workers stay hot across the recognition phase of continuous serving)
@@ -881,7 +866,7 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
     auto finish = [&](int sb) {
         const int b0 = sb_off[sb], nb = sb_off[sb + 1] - b0;
         ScoreSlot& sl = *score_slots_[sb];
-        if (sl.total) wait_event_yielding(score_done_[sb]);
+        if (sl.total) OAR_HIP(hipEventSynchronize(score_done_[sb]));
         tmark("box_scores_wait");
         const float* sc = sl.scores_host.as<float>();
         static const bool chunked = [] { const char* e = getenv("OAR_FINISH_CHUNKS"); return !e || atoi(e) != 0; }();   // 0: one task per page (A/B)
@@ -941,7 +926,7 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
             if (q == hipErrorNotReady) { (void)hipGetLastError(); finish(sb - 1); finished_prev = true; }   // ("not ready" must not stay behind as the thread's last error)
             else if (q != hipSuccess) OAR_HIP(q);
         }
-        wait_event_yielding(sub_events_[sb]);
+        OAR_HIP(hipEventSynchronize(sub_events_[sb]));
         tmark("det_gpu_wait");
         // BoxType::Poly scores the approximated polygon with box_score_fast whatever score_mode says (db_bitmap.rs:49)
         const bool poly = cfg_.box_type == 1;
