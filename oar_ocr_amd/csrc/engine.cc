@@ -543,6 +543,16 @@ void Engine::rewrite_graph(OnnxModel& m) {
             if (wd.dims.size() != 4 || wd.dims[1] != 1 || d.ai("group", 1) != wd.dims[0] || wd.dims[0] < 8) continue;   // depthwise
             d.out.push_back(gp.out[0]);
             dead[i] = true;
+            // round 5: when the pooled vector only feeds a fused squeeze-excite gate the conv hands over its per-tile sums as they are and
+            // se_fc reduces them (no global_avgpool_finish launch: 4 fewer 6 us kernels and kernel boundaries per recognition batch).
+            // OAR_FUSE_SE_POOL=1 keeps the finishing launch.
+            int readers = 0, gate = -1;
+            for (int j = 0; j < (int)nodes.size(); ++j) {
+                if (dead[j]) continue;
+                for (size_t q = 0; q < nodes[j].in.size(); ++q) if (nodes[j].in[q] == gp.out[0]) { ++readers; if (nodes[j].op == "SEGate" && q == 0) gate = j; }
+                if (nodes[j].residual == gp.out[0]) ++readers;
+            }
+            if (readers == 1 && gate >= 0 && !(fe && atoi(fe) == 1)) { Attr a; a.kind = Attr::I; a.i = 1; d.attrs["gap_raw"] = a; }
         }
         std::vector<GNode> keep;
         for (int i = 0; i < (int)nodes.size(); ++i) if (!dead[i]) keep.push_back(std::move(nodes[i]));
@@ -567,6 +577,7 @@ struct TInfo {
     bool is_int = false;             // device tensor whose f32 values are integers by construction (ArgMax, integer Cast of one)
     bool u8_stem = false;            // the graph input of a run_stem plan: u8 pages read by the fused stem, no f32 tensor behind it
     std::string root;                // storage root (for liveness)
+    int gap_tiles = 0, gap_hw = 0;   // [n, tiles * C, 1, 1]: per-tile channel sums of a pooling depthwise conv, still to be reduced and divided by gap_hw (SEGate does)
     size_t bytes() const { return (size_t)std::max<int64_t>(numel(dims), 1) * 4; }
 };
 
@@ -1416,6 +1427,17 @@ struct Planner {
         double bytes = 4.0 * (N * H * Wd * Cin + N * Ho * Wo * Cout * (has_res ? 2 : 1) + numel(W.dims));
         if (n.out.size() > 1) {   // rewrite pass 9: out[1] = GlobalAveragePool(out[0])
             const int tiles = kind == 1 ? k::conv_dw_gap_tiles(p) : 0;
+            if (tiles > 0 && Cout <= 1024 && n.ai("gap_raw", 0) != 0) {   // the only reader is an SEGate: it reduces the tile sums itself
+                TInfo& gy = new_out(n.out[1], {N, (int64_t)tiles * Cout, 1, 1}, Layout::CLAST);
+                gy.gap_tiles = tiles; gy.gap_hw = (int)(Ho * Wo);
+                const Loc part = gy.loc;
+                step([=](const RunCtx& c) {
+                    k::ConvP q = p;
+                    q.x = c.at(xin); q.y = c.mut(yl); q.residual = has_res ? c.at(res) : nullptr; q.gap_part = c.mut(part);
+                    k::conv_dw(c.s, q);
+                }, flops, bytes + 4.0 * N * tiles * Cout);
+                return;
+            }
             if (tiles > 0 && Cout <= 1024) {
                 TInfo& gy = new_out(n.out[1], {N, Cout, 1, 1}, Layout::CLAST);
                 const Loc gl = gy.loc, part = alloc_temp((size_t)N * tiles * Cout * sizeof(float));
@@ -2155,7 +2177,8 @@ struct Planner {
         OAR_CHECK(x.dims.size() == 4 && x.dims[2] == 1 && x.dims[3] == 1, OAR_SHAPE_MISMATCH, "SEGate: input must be [n, C, 1, 1]");
         const TInfo &w1 = get(n.in[1]), &w2 = get(n.in[3]);
         OAR_CHECK(w1.ht && w2.ht, OAR_UNSUPPORTED_OP, "SEGate: weights must be initializers");
-        const int64_t N = x.dims[0], C = x.dims[1], Cmid = w1.ht->dims[0], Cout = w2.ht->dims[0];
+        const int tiles = x.gap_tiles, gap_hw = x.gap_hw;   // > 0: the input still is the producing conv's tile sums
+        const int64_t N = x.dims[0], C = tiles > 0 ? x.dims[1] / tiles : x.dims[1], Cmid = w1.ht->dims[0], Cout = w2.ht->dims[0];
         OAR_CHECK(w1.ht->dims[1] == C && w2.ht->dims[1] == Cmid, OAR_SHAPE_MISMATCH, "SEGate: weight shapes");
         const float* b1 = has_input(n, 2) ? get(n.in[2]).loc.cptr : nullptr;
         const float* b2 = has_input(n, 4) ? get(n.in[4]).loc.cptr : nullptr;
@@ -2169,7 +2192,7 @@ struct Planner {
         Loc xin = x.loc;   // [n, C, 1, 1]: the same bytes in either layout
         TInfo& y = new_out(n.out[0], {N, Cout, 1, 1}, Layout::CLAST);
         Loc yl = y.loc;
-        step([=](const RunCtx& c) { k::se_fc(c.s, c.at(xin), w1p, b1, a1, w2p, b2, a2, c.mut(yl), (int)N, (int)C, (int)Cmid, (int)Cout); },
+        step([=](const RunCtx& c) { k::se_fc(c.s, c.at(xin), w1p, b1, a1, w2p, b2, a2, c.mut(yl), (int)N, (int)C, (int)Cmid, (int)Cout, tiles, gap_hw); },
              2.0 * N * Cmid * (C + Cout), 4.0 * (N * (C + Cout) + Cmid * (C + Cout)));
     }
 

@@ -130,8 +130,10 @@ void gemm_batched(hipStream_t s, const GemmP& p);
 void layernorm(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C, float eps);
 void softmax_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int C);
 // squeeze-excite gate on a pooled vector: y[n] = act2(W2 act1(W1 x[n] + b1) + b2); w1 = W1 [Cmid][C], w2 = W2 TRANSPOSED [Cmid][Cout]
+// tiles > 0: x is not the pooled vector but the per-tile channel sums a pooling depthwise conv left ([N][tiles][C], conv_dw with gap_part);
+// the kernel reduces them itself, in global_avgpool_finish's order, and divides by hw -- the squeeze costs no launch of its own
 void se_fc(hipStream_t s, const float* x, const float* w1, const float* b1, Act act1, const float* w2, const float* b2, Act act2, float* y, int N, int C,
-           int Cmid, int Cout);
+           int Cmid, int Cout, int tiles = 0, int hw = 0);
 // ONNX Pad on a contiguous tensor of rank <= 6: out_dims[d] = in_dims[d] + before[d] + after[d] (negative = crop);
 // mode 0 constant (value), 1 reflect, 2 edge
 void pad_nd(hipStream_t s, const float* x, float* y, int rank, const int64_t* in_dims, const int64_t* out_dims, const int64_t* before, int mode, float value);

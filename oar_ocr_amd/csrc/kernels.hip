@@ -1211,14 +1211,38 @@ void softmax_lastdim(hipStream_t s, const float* x, float* y, int64_t rows, int 
 // workgroups share an image, each recomputing the cheap hidden vector and producing its slice of the outputs.
 __global__ __launch_bounds__(1024) void se_fc_kernel(const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1, Act a1,
                                                      const float* __restrict__ w2, const float* __restrict__ b2, Act a2, float* __restrict__ y, int C, int Cmid, int Cout,
-                                                     int slice, int parts) {
-    extern __shared__ float se_lds[];   // pooled [C] | hidden [Cmid] | partial [parts][slice]
+                                                     int slice, int parts, int tiles, float hw) {
+    extern __shared__ float se_lds[];   // pooled [C] | hidden [Cmid] | partial [parts][slice] (first: the tile sums' partial reduction [gparts][C])
     float* pooled = se_lds;
     float* hidden = se_lds + C;
     float* partial = hidden + Cmid;
     const long n = blockIdx.x;
     const int c_lo = blockIdx.y * slice, c_hi = min(c_lo + slice, Cout);
-    for (int c = threadIdx.x; c < C; c += blockDim.x) pooled[c] = x[n * C + c];
+    if (tiles > 0) {
+        // x = [N][tiles][C] channel sums of the producing depthwise conv's tiles: the reduction global_avgpool_kernel would do over them as a
+        // launch of its own (HW = tiles, one split), term for term -- gparts groups stride over the tiles four at a time as (a + b) + (c + d),
+        // the groups are added in order, the total is divided by the pixel count
+        const int C4 = C >> 2, gparts = 256 / C4 > 0 ? 256 / C4 : 1;
+        float* red = partial;   // [gparts][C]: gparts * C <= 1024 floats (the host sizes the LDS for it)
+        const float* xb = x + n * (long)tiles * C;
+        for (int t = threadIdx.x; t < gparts * C; t += blockDim.x) {
+            const int c = t % C, part = t / C;
+            float acc = 0.f;
+            int i = part;
+            for (; i + 3 * gparts < tiles; i += 4 * gparts)
+                acc += (xb[(long)i * C + c] + xb[(long)(i + gparts) * C + c]) + (xb[(long)(i + 2 * gparts) * C + c] + xb[(long)(i + 3 * gparts) * C + c]);
+            for (; i < tiles; i += gparts) acc += xb[(long)i * C + c];
+            red[part * C + c] = acc;
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            float t = red[c];
+            for (int q = 1; q < gparts; ++q) t += red[q * C + c];
+            pooled[c] = t / hw;
+        }
+    } else {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) pooled[c] = x[n * C + c];
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     for (int jb = wave * 4; jb < Cmid; jb += nwaves * 4) {   // four hidden units per wave per pass: their weight rows load together
@@ -1276,8 +1300,9 @@ __global__ __launch_bounds__(1024) void se_fc_kernel(const float* __restrict__ x
     }
 }
 void se_fc(hipStream_t s, const float* x, const float* w1, const float* b1, Act act1, const float* w2, const float* b2, Act act2, float* y, int N, int C,
-           int Cmid, int Cout) {
+           int Cmid, int Cout, int tiles, int hw) {
     if (N == 0) return;
+    OAR_CHECK(tiles == 0 || ((C & 3) == 0 && C <= 1024 && hw > 0), OAR_INTERNAL, "se_fc: tile sums need C % 4 == 0, C <= 1024");
     // G workgroups per image when the images alone leave most of the chip idle; a slice is a multiple of 64 outputs, <= 1024
     int G = 1;
     if (N < 128) G = std::max(1, std::min(std::min(8, 256 / N), (Cout + 63) / 64));
@@ -1285,10 +1310,11 @@ void se_fc(hipStream_t s, const float* x, const float* w1, const float* b1, Act 
     while (slice > 1024) { ++G; slice = ((Cout + G - 1) / G + 63) / 64 * 64; }
     G = (Cout + slice - 1) / slice;
     const int parts = std::max(1, std::min(std::min(8, 1024 / slice), (Cmid + 7) / 8));
-    const size_t lds = (size_t)(C + Cmid + parts * slice) * sizeof(float);
+    const int gparts = tiles > 0 ? std::max(1, 256 / (C >> 2)) : 0;
+    const size_t lds = (size_t)(C + Cmid + std::max(parts * slice, gparts * C)) * sizeof(float);
     OAR_CHECK(lds <= 64 * 1024, OAR_UNSUPPORTED_OP, "se_fc: vectors exceed LDS");
-    ProfScope ps(s, "se_fc", 4.0 * ((double)N * (C + Cout) + (double)Cmid * (C + Cout)), 2.0 * N * (double)Cmid * (C + Cout));
-    hipLaunchKernelGGL(se_fc_kernel, dim3((unsigned)N, (unsigned)G), dim3(1024), lds, s, x, w1, b1, act1, w2, b2, act2, y, C, Cmid, Cout, slice, parts);
+    ProfScope ps(s, "se_fc", 4.0 * ((double)N * ((double)C * std::max(tiles, 1) + Cout) + (double)Cmid * (C + Cout)), 2.0 * N * (double)Cmid * (C + Cout));
+    hipLaunchKernelGGL(se_fc_kernel, dim3((unsigned)N, (unsigned)G), dim3(1024), lds, s, x, w1, b1, act1, w2, b2, act2, y, C, Cmid, Cout, slice, parts, tiles, (float)hw);
 }
 
 // ------------------------------------------------------------------------------------------ ReduceMean (last axis)

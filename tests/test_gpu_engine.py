@@ -796,7 +796,8 @@ def test_squeeze_excite_scale_rides_on_the_pointwise_conv(monkeypatch):
 
 def test_squeeze_excite_pool_comes_from_the_depthwise_epilogue(monkeypatch):
     """GlobalAveragePool(depthwise conv) (the squeeze of an SE block): the 5 x 5 depthwise kernel writes per-tile sums of its activated
-    output and `global_avgpool_finish` reduces them (engine.cc pass 9) -- the feature map is not read a second time.  Same numbers as the
+    output and `global_avgpool_finish` -- since round 5 the squeeze-excite gate kernel itself, when the pooled vector feeds nothing else --
+    reduces them (engine.cc pass 9): the feature map is not read a second time.  Same numbers as the
     oracle, equal to the separate pool to f32 rounding (another summation order: tile sums first), argmax unchanged; 3 x 3 depthwise
     convs (no pooled variant) pool separately."""
     rec, _ = models.build_rec("tiny", vocab=6906, seed=1)
@@ -806,13 +807,21 @@ def test_squeeze_excite_pool_comes_from_the_depthwise_epilogue(monkeypatch):
     api.prof_enable(True); api.prof_reset()
     plain = plain_eng.infer(x)[0][1]
     before = {e["name"]: e["launches"] for e in api.prof_snapshot()}
+    monkeypatch.setenv("OAR_FUSE_SE_POOL", "1")                       # round 4: tile sums + a finishing launch of the pool kernel
+    fin_eng = api.OrtInfer(rec, profile=True)
+    api.prof_reset()
+    fin = fin_eng.infer(x)[0][1]
+    mid = {e["name"]: e["launches"] for e in api.prof_snapshot()}
     monkeypatch.delenv("OAR_FUSE_SE_POOL")
-    eng = api.OrtInfer(rec, profile=True)
+    eng = api.OrtInfer(rec, profile=True)                             # round 5 default: the SE gate kernel reduces the tile sums itself
     api.prof_reset()
     got = eng.infer(x)[0][1]
     snap = {e["name"]: e["launches"] for e in api.prof_snapshot()}
     api.prof_enable(False)
-    assert snap.get("global_avgpool", 0) == before.get("global_avgpool", 0) and snap.get("conv_dw", 0) == before.get("conv_dw", 0), (before, snap)   # (the finish pass keeps the class name)
+    assert mid.get("global_avgpool", 0) == before.get("global_avgpool", 0) and mid.get("conv_dw", 0) == before.get("conv_dw", 0), (before, mid)   # (the finish pass keeps the class name)
+    assert snap.get("conv_dw", 0) == before.get("conv_dw", 0) and snap.get("se_fc", 0) == before.get("se_fc", 0) > 0
+    assert snap.get("global_avgpool", 0) == before.get("global_avgpool", 0) - snap["se_fc"], (before, snap)   # every squeeze of this graph feeds a gate: no pool launch left for them
+    assert np.array_equal(got, fin)                                   # same reduction order inside se_fc as in the finishing launch
     assert np.abs(got - plain).max() <= 2e-5 and np.array_equal(got.argmax(-1), plain.argmax(-1))
     ref = onnx_ref.run(rec, {eng.input_name(): x})[0]
     assert np.abs(got - ref).max() <= TOL
