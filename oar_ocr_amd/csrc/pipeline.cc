@@ -814,9 +814,16 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
         OAR_CHECK(po.dims.size() == 4 && po.dims[0] == nb && po.dims[1] == C && po.dims[2] == H && po.dims[3] == W, OAR_SHAPE_MISMATCH,
                   "DB: inconsistent output shape across sub-batches");
         // only channel 0 is used (processors/db_postprocess.rs:122-123); keep it past the next sub-batch's arena reuse
-        k::copy2d(s, eng_->out_ptr(po.loc), probs + (size_t)b0 * hw, nb, (int)hw, (int)(hw * C), (int)hw);
-        pp::threshold(s, probs + (size_t)b0 * hw, mask_dev_.as<uint8_t>() + (size_t)b0 * hw, (int64_t)nb * hw, thresh);
+        // OAR_DB_FINISH_FUSED=0 restores copy2d + threshold (+ pack_mask_bits on the copy stream)
+        static const bool fused_finish_env = [] { const char* e = getenv("OAR_DB_FINISH_FUSED"); return !(e && e[0] == '0'); }();
+        const bool fused_finish = fused_finish_env && !gpu_contours && !cfg_.use_dilation;   // nothing else reads the byte mask then
         const uint8_t* traced = mask_dev_.as<uint8_t>() + (size_t)b0 * hw;
+        if (fused_finish) {
+            pp::db_keep_and_pack(s, eng_->out_ptr(po.loc), (int64_t)(hw * C), probs + (size_t)b0 * hw, mask_bits_.as<uint8_t>() + (size_t)b0 * hbits, nb, H, W, thresh);
+        } else {
+            k::copy2d(s, eng_->out_ptr(po.loc), probs + (size_t)b0 * hw, nb, (int)hw, (int)(hw * C), (int)hw);
+            pp::threshold(s, probs + (size_t)b0 * hw, mask_dev_.as<uint8_t>() + (size_t)b0 * hw, (int64_t)nb * hw, thresh);
+        }
         if (cfg_.use_dilation) {   // db_postprocess.rs:163-168: the contours are traced on the dilated mask, the scores still read pred
             pp::dilate3x3(s, traced, mask_dil_.as<uint8_t>() + (size_t)b0 * hw, nb, H, W);
             traced = mask_dil_.as<uint8_t>() + (size_t)b0 * hw;
@@ -839,7 +846,7 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
                                trace_.table_dev.as<pp::SegRec>(), trace_.table.as<pp::SegRec>() + (size_t)b0 * ContourBufs::kSegsPerPage, tcap);
         } else {
             // the mask crosses PCIe as a bit plane: 8x less traffic for the blit kernel that shares the GPU with the next network
-            pp::pack_mask_bits(copy_stream_, traced, mask_bits_.as<uint8_t>() + (size_t)b0 * hbits, nb, H, W);
+            if (!fused_finish) pp::pack_mask_bits(copy_stream_, traced, mask_bits_.as<uint8_t>() + (size_t)b0 * hbits, nb, H, W);
             OAR_HIP(hipMemcpyAsync(mask_host_.as<uint8_t>() + (size_t)b0 * hbits, mask_bits_.as<uint8_t>() + (size_t)b0 * hbits, (size_t)nb * hbits,
                                    hipMemcpyDeviceToHost, copy_stream_));
         }

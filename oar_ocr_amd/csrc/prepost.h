@@ -39,6 +39,9 @@ void threshold(hipStream_t s, const float* pred, uint8_t* mask, int64_t n, float
 // n_images masks of height x width bytes -> bit planes of ceil(width / 8) bytes per row (pixel x = bit x & 7 of byte x >> 3): the
 // form in which a mask is read back by the host border follower (8x less PCIe traffic; db_host.h find_contours_band_bits)
 void pack_mask_bits(hipStream_t s, const uint8_t* mask, uint8_t* bits, int n_images, int height, int width);
+// a7 for the default detector route in ONE launch: net_out = [n][C][H][W] (image stride img_stride floats), channel 0 -> probs [n][H][W] and its
+// threshold as a bit plane (same bits as threshold + pack_mask_bits)
+void db_keep_and_pack(hipStream_t s, const float* net_out, int64_t img_stride, float* probs, uint8_t* bits, int n_images, int height, int width, float thresh);
 
 // DBPostProcess::dilate_mask_img (processors/db_mask.rs:11: imageproc morphology::dilate, Norm::LInf, k = 1) on n_images
 // masks of height x width each: a pixel becomes 255 when any pixel of its 3 x 3 neighbourhood inside the image is non-zero.

@@ -278,6 +278,39 @@ void pack_mask_bits(hipStream_t s, const uint8_t* mask, uint8_t* bits, int n_ima
     hipLaunchKernelGGL(pack_mask_bits_kernel, dim3(grid_for(rows * row_bytes)), dim3(256), 0, s, mask, bits, rows, width, row_bytes);
 }
 
+// ------------------------------------------------------------------------------------------ a7 in one pass over the detector's output
+// What a detector sub-batch needs of its network output when the host follows the borders (the default): channel 0 kept in `probs` (the box
+// scores read it after the arena has been reused) and the thresholded mask as a bit plane for the read-back.  copy2d + threshold + pack_mask_bits
+// did that in three launches over two streams; here one thread takes 8 pixels of a row: two float4 loads, two float4 stores, one byte of
+// bits (bit k = pred[x0 + k] > thresh, the predicate threshold_kernel writes as 255 and pack_mask_bits reads as != 0).
+__global__ __launch_bounds__(256) void db_keep_and_pack_kernel(const float* __restrict__ net_out, long img_stride, float* __restrict__ probs, uint8_t* __restrict__ bits,
+                                                              long rows, int H, int W, int row_bytes, float thresh) {
+    const long total = rows * row_bytes;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / row_bytes, img = r / H;
+        const int bx = (int)(i - r * row_bytes), x0 = bx * 8;
+        const float* src = net_out + img * img_stride + (r - img * H) * (long)W + x0;
+        float* dst = probs + r * (long)W + x0;
+        unsigned v = 0;
+        if (x0 + 8 <= W && ((((size_t)src) | ((size_t)dst)) & 15) == 0) {
+            const float4 a = reinterpret_cast<const float4*>(src)[0], b = reinterpret_cast<const float4*>(src)[1];
+            reinterpret_cast<float4*>(dst)[0] = a; reinterpret_cast<float4*>(dst)[1] = b;
+            v = (a.x > thresh ? 1u : 0u) | (a.y > thresh ? 2u : 0u) | (a.z > thresh ? 4u : 0u) | (a.w > thresh ? 8u : 0u) |
+                (b.x > thresh ? 16u : 0u) | (b.y > thresh ? 32u : 0u) | (b.z > thresh ? 64u : 0u) | (b.w > thresh ? 128u : 0u);
+        } else {
+            for (int k = 0; k < 8 && x0 + k < W; ++k) { const float p = src[k]; dst[k] = p; v |= p > thresh ? (1u << k) : 0u; }
+        }
+        bits[i] = (uint8_t)v;
+    }
+}
+void db_keep_and_pack(hipStream_t s, const float* net_out, int64_t img_stride, float* probs, uint8_t* bits, int n_images, int height, int width, float thresh) {
+    const long rows = (long)n_images * height;
+    if (rows == 0 || width == 0) return;
+    const int row_bytes = (width + 7) / 8;
+    ProfScope ps(s, "threshold", 8.0 * (double)rows * width + (double)rows * row_bytes, 0.0);
+    hipLaunchKernelGGL(db_keep_and_pack_kernel, dim3(grid_for(rows * row_bytes)), dim3(256), 0, s, net_out, (long)img_stride, probs, bits, rows, height, width, row_bytes, thresh);
+}
+
 // ------------------------------------------------------------------------------------------ mask dilation (use_dilation)
 __global__ __launch_bounds__(256) void dilate3x3_kernel(const uint8_t* __restrict__ mask, uint8_t* __restrict__ out, int height, int width) {
     const long plane = (long)height * width;
