@@ -2372,6 +2372,37 @@ struct Planner {
             TInfo& y = new_out(n.out[0], od, Layout::CLAST);
             Loc yl = y.loc;
             int64_t coff = 0, total = pod[pax] * inner;
+            // round 5: every absorbed resize an integer-factor nearest upsampling (the DB neck: up8 / up4 / up2 of three pyramid levels next to
+            // the finest one) -> the whole concat is ONE gather launch instead of one launch per input.  OAR_CONCAT_GATHER=0 restores those.
+            if (absorb && r == 4 && inner == 1 && xs.size() <= 8) {
+                static const bool gather_on = [] { const char* e = getenv("OAR_CONCAT_GATHER"); return !(e && e[0] == '0'); }();
+                bool ok = gather_on;
+                for (size_t i = 0; ok && i < xs.size(); ++i) {
+                    const PendingResize* pr = peek_pending(n.in[i]);
+                    if (pr) ok = pr->fh > 0 && pr->fw > 0 && pr->imode == 0 && pr->Ho == od[2] && pr->Wo == od[3] && pr->H * pr->fh == pr->Ho && pr->W * pr->fw == pr->Wo && pr->N == od[0];
+                    else ok = xs[i].dims[0] == od[0] && xs[i].dims[2] == od[2] && xs[i].dims[3] == od[3];
+                }
+                if (ok) {
+                    k::ConcatGatherP gp{};
+                    std::vector<Loc> src(xs.size());
+                    gp.n_src = (int)xs.size(); gp.N = (int)od[0]; gp.Ho = (int)od[2]; gp.Wo = (int)od[3]; gp.C = (int)od[1];
+                    double bytes = 4.0 * (double)numel(od);
+                    for (size_t i = 0; i < xs.size(); ++i) {
+                        const PendingResize* pr = peek_pending(n.in[i]);
+                        src[i] = pr ? pr->xin : ins[i];
+                        gp.c[i] = (int)xs[i].dims[1]; gp.off[i] = (int)coff; gp.fh[i] = pr ? pr->fh : 1; gp.fw[i] = pr ? pr->fw : 1;
+                        bytes += 4.0 * (double)numel(xs[i].dims) / (gp.fh[i] * gp.fw[i]);
+                        coff += xs[i].dims[1];
+                    }
+                    for (auto& nm : n.in) pending_resize.erase(nm);
+                    step([=](const RunCtx& c) {
+                        k::ConcatGatherP q = gp;
+                        for (int i = 0; i < q.n_src; ++i) q.x[i] = c.at(src[(size_t)i]);
+                        k::concat_gather(c.s, q, c.mut(yl));
+                    }, 0, bytes);
+                    return;
+                }
+            }
             for (size_t i = 0; i < xs.size(); ++i) {
                 int64_t w = xs[i].dims[axis] * inner;
                 Loc il = ins[i];

@@ -103,6 +103,11 @@ int resize_nearest_index(int o, float scale, int in, int out, int ctm, int neare
 void binary_upsampled(hipStream_t s, const float* a, const float* b, float* y, int N, int Ho, int Wo, int C, int fh, int fw, int op);
 void resize(hipStream_t s, const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, float scale_h,
             float scale_w, int mode, int ctm, int nearest_mode, int y_ld);
+// Channel concat of channels-last maps in ONE launch: source i contributes c[i] channels (c[i] % 4 == 0) at channel offset off[i], read at
+// pixel (oh / fh[i], ow / fw[i]) of its [N][Ho / fh][Wo / fw][c] map (integer-factor nearest upsampling with coordinate mode asymmetric /
+// floor; f = 1: a plain copy).  The DB neck's Concat(up8(p5), up4(p4), up2(p3), p2) was three resize launches and a copy.
+struct ConcatGatherP { const float* x[8]; int c[8], off[8], fh[8], fw[8]; int n_src, N, Ho, Wo, C; };
+void concat_gather(hipStream_t s, const ConcatGatherP& p, float* y);
 
 void unary(hipStream_t s, const float* x, float* y, int64_t n, Act act);
 // y = op(a, b) with numpy broadcasting over up to 6 dims. op: 0 add, 1 sub, 2 mul, 3 div, 4 pow, 5 prelu, 6 max, 7 min,

@@ -741,6 +741,35 @@ void resize(hipStream_t s, const float* x, float* y, int N, int H, int W, int C,
     hipLaunchKernelGGL(resize_kernel, dim3(grid_for(work)), dim3(256), 0, s, x, y, N, H, W, C, Ho, Wo, scale_h, scale_w, mode, ctm, nearest_mode, y_ld);
 }
 
+__global__ __launch_bounds__(256) void concat_gather_kernel(ConcatGatherP p, float* __restrict__ y) {
+    const int C4 = p.C >> 2;
+    const long total = (long)p.N * p.Ho * p.Wo * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const long pix = i / C4;
+        const int ow = (int)(pix % p.Wo);
+        const long t = pix / p.Wo;
+        const int oh = (int)(t % p.Ho);
+        const long n = t / p.Ho;
+        int sidx = 0;
+#pragma unroll
+        for (int q = 1; q < 8; ++q) if (q < p.n_src && c4 * 4 >= p.off[q]) sidx = q;
+        const int cs = p.c[sidx], fh = p.fh[sidx], fw = p.fw[sidx];
+        const int Hs = p.Ho / fh, Ws = p.Wo / fw;
+        const float* src = p.x[sidx] + ((n * Hs + oh / fh) * (long)Ws + ow / fw) * cs + (c4 * 4 - p.off[sidx]);
+        reinterpret_cast<float4*>(y)[i] = *reinterpret_cast<const float4*>(src);
+    }
+}
+void concat_gather(hipStream_t s, const ConcatGatherP& p, float* y) {
+    const long total = (long)p.N * p.Ho * p.Wo * p.C;
+    if (total == 0) return;
+    OAR_CHECK(p.n_src >= 1 && p.n_src <= 8 && (p.C & 3) == 0, OAR_INTERNAL, "concat_gather: sources / channels");
+    double rd = 0;
+    for (int i = 0; i < p.n_src; ++i) rd += (double)p.N * (p.Ho / p.fh[i]) * (p.Wo / p.fw[i]) * p.c[i];
+    ProfScope ps(s, "resize", 4.0 * (rd + (double)total), 0.0);
+    hipLaunchKernelGGL(concat_gather_kernel, dim3(grid_for(total / 4)), dim3(256), 0, s, p, y);
+}
+
 // ------------------------------------------------------------------------------------------ elementwise
 __global__ __launch_bounds__(256) void unary_kernel(const float* x, float* y, long n, int kind, float alpha, float beta) {
     long n4 = n >> 2;
