@@ -1419,7 +1419,7 @@ struct Planner {
         bool has_res = res.kind != Loc::NONE;
         Loc gate;   // [N][Cin] squeeze-excite gate folded into the load (checked above)
         if (n.in.size() > 3 && !n.in[3].empty()) {
-            OAR_CHECK(kind == 0 && p.w_fmt == k::IGEMM_W_X6, OAR_INTERNAL, "Conv: gate on a layer that is not on the bf16x6 kernel");
+            OAR_CHECK(kind == 0 && (p.w_fmt == k::IGEMM_W_X6 || p.w_fmt == k::IGEMM_W_K16), OAR_INTERNAL, "Conv: gate on a layer that is on neither gated kernel");
             gate = get(n.in[3]).loc;
         }
         const bool has_gate = gate.kind != Loc::NONE;

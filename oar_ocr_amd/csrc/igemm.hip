@@ -126,7 +126,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmP p) {  // 2 wa
 // coarse FPN levels: a few hundred wave tiles).  The per-tile kernel above keeps one chunk in flight, so such a launch
 // costs ~(KC + 1) load round trips (8 us at K = 64, 15 us at K = 256, whatever M is); here D = 4 chunks are in flight
 // per wave (a register ring; D * (NT + 1) float4s), the arithmetic and the epilogue are the same.
-template <int NT, bool IS1X1>
+// SE (1x1 only): p.se = squeeze-excite gate [image][K], multiplied into the pixel fragment before it is used -- the same v_mul_f32 the
+// separate Mul launch did (round 5: the detector's two gated pointwise convs are too small for the bf16x6 kernel that folds the gate)
+template <int NT, bool IS1X1, bool SE = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_small_kernel(IgemmP p) {
     constexpr int D = 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -154,13 +156,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_small_kernel(IgemmP p) {
     const bool bias_in_acc = igemm_init_acc<NT, 1>(p, acc, g, nf0);
     const float4* wf = reinterpret_cast<const float4*>(p.w) + ((long)nf0 * p.KC) * 64 + lane;
 
-    float4 xs[D], ws[D][NT];
+    float4 xs[D], ws[D][NT], gs[SE ? D : 1];
     bool ok[D];
+    const float* se_row = SE ? p.se + (min(m0 + pl_, p.M - 1) / p.se_hw) * (long)p.K : nullptr;
     auto request = [&](int kc_, int d) {
         const int kc = min(kc_, p.KC - 1);   // past the end: a harmless re-read keeps every load unconditional
         const int k = min(kc * 16 + 4 * g, p.K - 4);
         if (IS1X1) {
             xs[d] = *reinterpret_cast<const float4*>(p.x + pix_base + k);
+            if (SE) gs[d] = *reinterpret_cast<const float4*>(se_row + k);
             ok[d] = true;
         } else {
             const int tap = (int)__umulhi((unsigned)k, p.cin_magic), ci = k - tap * p.Cin;
@@ -177,6 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_small_kernel(IgemmP p) {
     auto consume = [&](int d) {
         float4 v = xs[d];
         if (!IS1X1) { v.x = ok[d] ? v.x : 0.f; v.y = ok[d] ? v.y : 0.f; v.z = ok[d] ? v.z : 0.f; v.w = ok[d] ? v.w : 0.f; }
+        if (SE) { const float4 gq = gs[d]; v.x *= gq.x; v.y *= gq.y; v.z *= gq.z; v.w *= gq.w; }
 #pragma clang loop unroll(full)
         for (int j = 0; j < 4; ++j)
 #pragma clang loop unroll(full)
@@ -252,9 +257,29 @@ int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin, long same3x3_
 }
 
 int ws_x6_se_rows(long M, int ny, int hw);   // igemm_ws_x6.hip
+// the f32 kernel choice of conv_igemm for a plain 1x1 layer (no residual, no CTC partials): does it land on the latency variant?
+static bool f32_1x1_goes_small(long M, int K, int N) {
+    static const int ws_mode = [] { const char* e = getenv("OAR_IGEMM_WS"); return e ? atoi(e) : -1; }();
+    static const int ws_min_n = [] { const char* e = getenv("OAR_IGEMM_WS_MIN_N"); return e ? atoi(e) : 96; }();
+    static const long small_max = [] { const char* e = getenv("OAR_IGEMM_SMALL"); return e ? atol(e) : 4096L; }();
+    const int nfrag = (N + 15) / 16, KC = (K + 15) / 16;
+    int NT = 1, best = 1 << 30;
+    for (int t = 4; t >= 1; --t) { int padded = (nfrag + t - 1) / t * t; if (padded < best) { best = padded; NT = t; } }
+    const long ny = (nfrag + NT - 1) / NT;
+    const long wave_tile_passes = ((M + 15) / 16) * ((nfrag + 7) / 8);
+    const bool ws_auto = (N >= ws_min_n && wave_tile_passes >= 4096) || (K >= 512 && M >= 262144);
+    const bool ws = (N & 3) == 0 && KC >= 2 && ws_mode != 0 && (ws_mode == 1 || ws_auto);
+    return !ws && ((M + 15) / 16) * ny <= small_max;
+}
 bool conv_igemm_se_ok(long M, int K, int N, int hw) {
     static const bool on = [] { const char* e = getenv("OAR_FUSE_SE_SCALE"); return !e || atoi(e) != 0; }();
-    if (!on || hw <= 0 || igemm_weight_format(M, K, N, true) != IGEMM_W_X6) return false;
+    if (!on || hw <= 0) return false;
+    if (igemm_weight_format(M, K, N, true) == IGEMM_W_K16) {   // round 5: the latency variant of the f32 kernel multiplies the gate in as well
+        const char* e = getenv("OAR_FUSE_SE_SCALE_SMALL");   // (plan-time question: read per call, a test flips it within one process)
+        const bool small_se = !(e && e[0] == '0');
+        return small_se && (K & 3) == 0 && (N & 3) == 0 && f32_1x1_goes_small(M, K, N);
+    }
+    if (igemm_weight_format(M, K, N, true) != IGEMM_W_X6) return false;
     const int nfrag = (N + 15) / 16, nt = ws_x6_tile(K, nfrag);
     if (nt == 0 || os_mode() == 2) return false;   // (the output-stationary kernel has no gate path)
     const int ny = (nfrag + nt - 1) / nt;
@@ -360,7 +385,7 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
         else if (PF == 2) LAUNCH2(NTV, 2);           \
         else LAUNCH2(NTV, 1);                        \
     } while (0)
-    OAR_CHECK(!c.se || x6, OAR_INTERNAL, "conv_igemm: gate on a non-x6 layer (conv_igemm_se_ok should have said no)");
+    OAR_CHECK(!c.se || x6 || (small && is1x1 && !c.residual && !c.convt2x2), OAR_INTERNAL, "conv_igemm: gate on a layer neither gated kernel takes (conv_igemm_se_ok should have said no)");
     const bool same3x3 = !c.convt2x2 && c.kh == 3 && c.kw == 3 && c.sh == 1 && c.sw == 1 && c.pt == 1 && c.pl == 1 && c.dh == 1 && c.dw == 1 && c.Ho == c.H && c.Wo == c.W;
     const bool rs3 = x6 && same3x3 && !c.residual && !c.se && !c.ctc_part && conv3x3_n16_x6_eligible(p.M, c.Cin, c.Cout, (long)c.H * c.W, c.y_ld);
     // a layer whose weights were laid out for the row-streaming 3x3 kernel (Cout <= 16: no other bf16x6 kernel takes it) must reach that kernel
@@ -389,7 +414,8 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
         const dim3 sgrid((unsigned)(((p.M + 63) / 64) * ny));
 #define LAUNCH_SMALL(NTV)                                                                                          \
     do {                                                                                                          \
-        if (is1x1) hipLaunchKernelGGL((conv_igemm_small_kernel<NTV, true>), sgrid, dim3(256), 0, s, p);        \
+        if (is1x1 && p.se) hipLaunchKernelGGL((conv_igemm_small_kernel<NTV, true, true>), sgrid, dim3(256), 0, s, p); \
+        else if (is1x1) hipLaunchKernelGGL((conv_igemm_small_kernel<NTV, true>), sgrid, dim3(256), 0, s, p);   \
         else hipLaunchKernelGGL((conv_igemm_small_kernel<NTV, false>), sgrid, dim3(256), 0, s, p);             \
     } while (0)
         if (NT == 4) LAUNCH_SMALL(4);
