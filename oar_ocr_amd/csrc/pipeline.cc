@@ -676,7 +676,12 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
     float alpha[3], beta[3];
     for (int c = 0; c < 3; ++c) { alpha[c] = scale / stdv[c]; beta[c] = -mean[c] / stdv[c]; }
-    static const int kSub = [] { const char* e = getenv("OAR_DET_SUB"); int v = e ? atoi(e) : 8; return v > 0 ? v : 8; }();
+    // pages per sub-batch.  Round 5: 16 (8 / 16 / 8 for a 32-page call) now that the host stages of a sub-batch cost a third of what they did --
+    // 96 instead of 160 detector launches per call, each with its ~5 us boundary: +3.9 % and +4.7 % images/s over three alternating pairs each
+    // (8: 2350 / 2409 / 2406, 16: 2527 / 2457 / 2462; profiles/r5/det_sub_ab.txt), 4 pinned cores +3 %.  A rank with two cores is host-bound in this
+    // phase and prefers the finer grain (8: 1988, 16: 1927): a pool of <= 2 threads keeps 8.
+    static const int sub_env = [] { const char* e = getenv("OAR_DET_SUB"); int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+    const int kSub = sub_env > 0 ? sub_env : (pool_->size() <= 1 ? 8 : 16);   // size() = workers next to the calling thread
     // sub-batch sizes: the LAST one is half-size (its contour tracing is the only host work the GPU cannot overlap); when the
     // pages still have to be uploaded the FIRST one is half-size too (the GPU idles until its pages have crossed PCIe:
     // 0.9 ms for ten 960^2 pages, OAR_DET_FIRST=0 disables); the others share the rest evenly
