@@ -39,6 +39,7 @@ struct Decoded {   // one sequence
 // CTCLabelDecode::decode_argmax_with_positions (decode.rs:549-614) for one sequence
 void decode_one(const oar_ctc_dict& d, const int64_t* idx, const float* prob, uint32_t T, Decoded& out) {
     out.text.clear(); out.cols.clear();
+    out.text.reserve((size_t)T * 3); out.cols.reserve(T);   // (one allocation each instead of a growth series per text line)
     const int64_t n_chars = (int64_t)d.chars.size();
     int64_t prev = 0;               // blank_index
     float sum = 0.0f;               // filtered_prob.iter().sum::<f32>(): sequential f32

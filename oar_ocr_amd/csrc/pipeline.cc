@@ -693,7 +693,7 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
         const int base = std::min(B, kSub);
         static const int last_env = [] { const char* e = getenv("OAR_DET_LAST"); return e ? atoi(e) : 0; }();   // (A/B knob: pages in the last sub-batch)
         const int last = B > base ? (last_env > 0 ? std::min(last_env, base) : std::max(1, base / 2)) : 0;
-        const int first = (first_half && host_pages && B - last > base) ? std::max(1, base / 2) : 0;
+        const int first = (first_half && host_pages && B - last > base) ? (first_half >= 2 ? std::min(first_half, base) : std::max(1, base / 2)) : 0;   // (OAR_DET_FIRST >= 2: that many pages)
         int rest = B - last - first;
         if (first) sb_off.push_back(first);
         int left = (rest + base - 1) / base;
