@@ -212,16 +212,59 @@ oar_status oar_ctc_decode(const oar_ctc_dict* dict, const int64_t* indices, cons
 oar_status oar_ocr_decode(const oar_ctc_dict* dict, const oar_ocr_result* res, float score_threshold, oar_text_result* out) {
     return guarded([&] {
         OAR_CHECK(dict && res && out, OAR_INVALID_INPUT, "oar_ocr_decode: bad arguments");
+        // A call's thousand text lines decoded into flat buffers sized from the totals (decode_one + pack gave every line a string and a
+        // vector of its own: ~2 200 allocations per call, a third of the 0.3 ms this took); same statements per time step, same outputs.
         const uint32_t n = res->n_regions;
-        std::vector<Decoded> seqs(n);
-        std::vector<uint32_t> Ts(n, 0);
+        const oar_ctc_dict& d = *dict;
+        const int64_t n_chars = (int64_t)d.chars.size();
+        size_t total_T = 0, max_char = 1;
         for (uint32_t k = 0; k < n; ++k) {
             const uint64_t a = res->ctc_offsets[k], b = res->ctc_offsets[k + 1];
-            Ts[k] = res->seq_len[k];
-            OAR_CHECK(b - a == 0 || b - a == Ts[k], OAR_INTERNAL, "oar_ocr_decode: region CTC length differs from its seq_len");
-            if (b > a) decode_one(*dict, res->ctc_indices + a, res->ctc_probs + a, (uint32_t)(b - a), seqs[k]);
+            OAR_CHECK(b - a == 0 || b - a == res->seq_len[k], OAR_INTERNAL, "oar_ocr_decode: region CTC length differs from its seq_len");
+            total_T += (size_t)(b - a);
         }
-        pack(seqs, Ts, score_threshold, out);
+        for (const std::string& c : d.chars) max_char = std::max(max_char, c.size());
+        std::memset(out, 0, sizeof *out);
+        out->n = n;
+        out->text_offsets = cm<uint64_t>((size_t)n + 1);
+        out->scores = cm<float>(n);
+        out->char_offsets = cm<uint64_t>((size_t)n + 1);
+        out->seq_len = cm<uint32_t>(n);
+        out->kept = cm<uint8_t>(n);
+        out->utf8 = cm<char>(total_T * max_char + 1);            // upper bounds: every time step a character
+        out->char_cols = cm<uint32_t>(total_T);
+        out->char_positions = cm<float>(total_T);
+        size_t bpos = 0, cpos = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint64_t a = res->ctc_offsets[k], b = res->ctc_offsets[k + 1];
+            const uint32_t T = (uint32_t)(b - a), Tk = res->seq_len[k];
+            const int64_t* idx = res->ctc_indices + a;
+            const float* prob = res->ctc_probs + a;
+            const size_t b0 = bpos, c0 = cpos;
+            int64_t prev = 0;               // blank_index
+            float sum = 0.0f;               // filtered_prob.iter().sum::<f32>(): sequential f32 (decode.rs:549-614, as decode_one)
+            for (uint32_t t = 0; t < T; ++t) {
+                const int64_t i = idx[t];
+                if (i != 0 && i != prev && i >= 0 && i < n_chars) {
+                    const std::string& ch = d.chars[(size_t)i];
+                    std::memcpy(out->utf8 + bpos, ch.data(), ch.size());
+                    bpos += ch.size();
+                    sum += prob[t];
+                    out->char_cols[cpos++] = t;
+                }
+                prev = i;
+            }
+            const size_t nc = cpos - c0;
+            const float score = nc == 0 ? 0.0f : sum / (float)nc;
+            const bool keep = score >= score_threshold;   // the adapter keeps the slot and the score, drops text / positions
+            out->text_offsets[k] = b0; out->char_offsets[k] = c0;
+            out->scores[k] = score; out->seq_len[k] = Tk; out->kept[k] = keep ? 1 : 0;
+            if (!keep) { bpos = b0; cpos = c0; continue; }
+            const float fT = (float)Tk;
+            for (size_t c = c0; c < cpos; ++c) out->char_positions[c] = (float)out->char_cols[c] / fT;
+        }
+        out->text_offsets[n] = bpos; out->char_offsets[n] = cpos;
+        out->utf8[bpos] = 0;
     });
 }
 

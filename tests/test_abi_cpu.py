@@ -188,3 +188,41 @@ def test_c_ctc_decode_matches_the_python_mirror_and_the_oracle(L):
         assert [c.tolist() for c in r.char_cols] == cols
         ot, osc, ocols = cpu_ref.ctc_decode(idx.astype(np.int64), pr, n, T, charset)[:3]
         assert r.texts == list(ot) and np.array_equal(r.scores, np.asarray(osc, np.float32))
+
+
+def test_c_ocr_decode_on_a_ragged_result_equals_the_per_batch_decoder(L):
+    """oar_ocr_decode (round 5: one pass into flat buffers) over a hand-built oar_ocr_result -- regions of different lengths, empty
+    regions, out-of-table classes, a score threshold that drops some -- against oar_ctc_decode run region by region."""
+    rng = np.random.default_rng(3)
+    entries = [chr(0x4E00 + i) for i in range(200)] + list("abcdefghij") + ["\U0001F600"]          # 1-, 3- and 4-byte characters
+    d = api.CtcDict.from_entries(entries)
+    Ts = [0, 1, 7, 40, 0, 133, 40, 2, 64]
+    idx_l, pr_l = [], []
+    for T in Ts:
+        i = rng.integers(0, d.classes + 3, T)
+        i[rng.random(T) < 0.5] = 0
+        for t in range(1, T):
+            if rng.random() < 0.3:
+                i[t] = i[t - 1]
+        idx_l.append(i.astype(np.int64)); pr_l.append(rng.random(T).astype(np.float32))
+    offs = np.concatenate([[0], np.cumsum(Ts)]).astype(np.uint64)
+    idx = np.concatenate(idx_l) if sum(Ts) else np.zeros(0, np.int64)
+    pr = np.concatenate(pr_l) if sum(Ts) else np.zeros(0, np.float32)
+    seq = np.array(Ts, np.uint32)
+    res = api.OcrResult()
+    res.n_images, res.n_regions = 1, len(Ts)
+    res.ctc_offsets = offs.ctypes.data_as(api.C.POINTER(api.C.c_uint64))
+    res.ctc_indices = idx.ctypes.data_as(api.C.POINTER(api.C.c_int64))
+    res.ctc_probs = pr.ctypes.data_as(api.C.POINTER(api.C.c_float))
+    res.seq_len = seq.ctypes.data_as(api.C.POINTER(api.C.c_uint32))
+    for thr in (0.0, 0.5):
+        got = d.decode_ocr(res, thr)
+        for k, T in enumerate(Ts):
+            if T == 0:
+                assert got.texts[k] == "" and got.scores[k] == 0.0 and len(got.char_cols[k]) == 0 and got.seq_len[k] == 0
+                continue
+            ref = d.decode(idx_l[k][None], pr_l[k][None], 1, T, score_threshold=thr)
+            assert got.texts[k] == ref.texts[0] and got.scores[k] == ref.scores[0] and bool(got.kept[k]) == bool(ref.kept[0])
+            assert np.array_equal(got.char_cols[k], ref.char_cols[0]) and np.array_equal(got.char_positions[k], ref.char_positions[0])
+            assert got.seq_len[k] == T
+        assert any(got.kept) and (thr == 0.0 or not all(got.kept))

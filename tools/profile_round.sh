@@ -5,7 +5,7 @@
 #   3. rocprofv3 --pmc <matrix-pipe counters>      -> gpurun_out/pmc_MFMA   (SQ_VALU_MFMA_BUSY_CYCLES, MOPS, GRBM_GUI_ACTIVE, ...)
 #   4. the same matrix-pipe counters over tools/mfma_peak (a kernel that IS at the bf16 / f32 MFMA peak): calibrates the
 #      utilisation formula used by tools/pmc_summary.py
-# PMC passes never carry --kernel-trace / --stats (gpurun refuses the combination).  Then: python tools/make_profile_summaries.py <tag> auto profiles/r4   (auto: the pass count the stats run's bench line reports)
+# PMC passes never carry --kernel-trace / --stats (gpurun refuses the combination).  Then: python tools/make_profile_summaries.py <tag> auto profiles/r5   (auto: the pass count the stats run's bench line reports)
 TAG=${1:-r2a}
 R=$PWD; cd /tmp; export TMPDIR=/tmp
 BENCH="python $R/bench.py --cpu-pages 0 --no-device-resident --no-pipelined --no-real-size"
