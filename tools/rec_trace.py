@@ -11,7 +11,7 @@ if what == "rec":
     import os
     x = np.random.default_rng(0).standard_normal((int(os.environ.get("REC_N", "256")), 3, 48, 320)).astype(np.float32)
 else:
-    m, _ = models.build_det("tiny", seed=0)
+    m, _ = models.build_det(__import__("os").environ.get("DET_SIZE", "tiny"), seed=0)
     x = np.random.default_rng(0).standard_normal((8, 3, 960, 960)).astype(np.float32)
 eng = api.OrtInfer(m, profile=True)
 eng.infer(x)
