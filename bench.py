@@ -271,7 +271,7 @@ def main():
     # An event-bracketed kernel costs ~11 us of idle queue around it (rocprofv3 kernel trace).  So each
     # step times 1 launch in S, with the phase rotating over the steps: every launch POSITION of the class is timed in exactly
     # `balanced / S` of the timed steps, which gives the same average as timing all of them at 1/S of the overhead.
-    S = min(10, max(args.steps, 1))   # (round 5: 1 in 10, was 1 in 5: ~10 instead of ~21 bracketed launches per step)
+    S = min(20, max(args.steps, 1))   # (round 5: 1 in min(20, steps), was 1 in 5: ~5 instead of ~21 bracketed launches per step; every position still timed at least once)
     balanced = S * (args.steps // S)
     barrier()
     cpu0 = os.times()
