@@ -409,6 +409,31 @@ __device__ __forceinline__ void ch_copy(const ChainOpD& op, const ChView& x, con
     }
 }
 
+// AveragePool whose window spans the whole height and `kw` columns per token (the recognizer's [6, 2] pool in front of the SVTR neck): the
+// sample's [kh][Wp][C] map (Wp = op.pad >= kw * T: a last odd column is dropped, as the pool does) -> T rows of C, pool2d_kernel's statement
+// order (rows outside, columns inside, one division at the end).  The window's loads are issued six at a time, then added in that order.
+__device__ __forceinline__ void ch_pool(const ChainOpD& op, const ChView& x, const ChView& y, int T) {
+    const int c4 = op.N >> 2, kh = op.K, kw = op.cin, Wp = op.pad, win = kh * kw;
+    ch_gf* xs = x.g + ((long)blockIdx.x * ((long)kh * Wp - T)) * x.ld;   // x.g is base + sample * T * ld; the sample's map starts at row sample * kh * Wp
+    const float div = (float)win;
+    for (int i = threadIdx.x; i < T * c4; i += kChainThreads) {
+        const int t = i / c4, c = i - t * c4;
+        ch_gf* px = xs + ((long)t * kw) * x.ld + 4 * c;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int q0 = 0; q0 < win; q0 += 6) {
+            f32x4 v[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int q = min(q0 + u, win - 1), a = q / kw, b = q - a * kw;
+                v[u] = *reinterpret_cast<ch_gf4*>(px + ((long)a * Wp + b) * x.ld);
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) if (q0 + u < win) acc += v[u];
+        }
+        ch_st4(y, t * y.ld + 4 * c, make_float4(acc[0] / div, acc[1] / div, acc[2] / div, acc[3] / div));
+    }
+}
+
 // consts: the chain's constants in one allocation -- [0, small) floats = biases / LayerNorm affine vectors (copied into LDS at
 // `small_l`), the rest = the products' weights.  Before the first operator each workgroup pulls its share of the weights towards
 // its XCD's L2 (workgroup b runs on XCD b % 8: the 32 workgroups of an XCD split the blob), so that the operators find them there
@@ -460,6 +485,7 @@ __global__ __launch_bounds__(kChainThreads) void chain_kernel(const ChainOpD* __
                 if (T <= 64 && (op.hd & 3) == 0) ch_attention_mfma(op, in, out, T, wave, lane);
                 else ch_attention_any<HD>(op, in, out, T);
                 break;
+            case CH_POOL: ch_pool(op, in, out, T); break;
             default: ch_copy(op, in, out, T); break;
         }
         __syncthreads();   // workgroup-scope release / acquire: the next operator reads what this one stored (LDS, or HBM through this CU's L1)

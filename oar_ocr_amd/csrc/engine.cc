@@ -813,7 +813,7 @@ struct Planner {
         for (int j = 0; j < (int)ops.size(); ++j) {
             const k::ChainOpD& d = ops[(size_t)j];
             const int win = d.type == k::CH_GEMM ? d.cin : d.type == k::CH_ATTN ? 3 * d.heads * d.hd : d.N;
-            if (d.in.kind == 1) uses.push_back({j, 0, (int64_t)d.in.v, d.in_ld, win});
+            if (d.in.kind == 1 && d.type != k::CH_POOL) uses.push_back({j, 0, (int64_t)d.in.v, d.in_ld, win});   // (a pool reads the sample's whole map from HBM: not a [n T][ld] tensor of the run)
             if (d.out.kind == 1) uses.push_back({j, 1, (int64_t)d.out.v, d.out_ld, d.N});
             if (d.res.kind == 1) uses.push_back({j, 2, (int64_t)d.res.v, d.res_ld, d.N});
         }
@@ -2268,7 +2268,20 @@ struct Planner {
         p.kh = (int)kh; p.kw = (int)kw; p.sh = (int)sh; p.sw = (int)sw; p.pt = (int)pt; p.pl = (int)pl;
         p.is_max = is_max; p.count_include_pad = (int)n.ai("count_include_pad", 0);
         Loc yl = y.loc;
-        step([=](const RunCtx& c) { k::PoolP q = p; q.x = c.at(xin); q.y = c.mut(yl); k::pool2d(c.s, q); }, 0, 4.0 * (numel(x.dims) + numel(y.dims)));
+        auto run = [=](const RunCtx& c) { k::PoolP q = p; q.x = c.at(xin); q.y = c.mut(yl); k::pool2d(c.s, q); };
+        const double bytes = 4.0 * (numel(x.dims) + numel(y.dims));
+        // round 5: an average pool that leaves ONE row of tokens per sample (the recognizer's [6, 2] pool in front of the SVTR neck) only
+        // reads its own sample: as the first operator of a sample-local chain (chain.hip CH_POOL) it costs no launch.  OAR_CHAIN_POOL=0 keeps it apart.
+        const char* cpe = getenv("OAR_CHAIN_POOL");
+        if (!(cpe && cpe[0] == '0') && !is_max && !ceil_mode && Ho == 1 && kh == x.dims[2] && kw == sw && kw * Wo <= x.dims[3] && x.dims[3] - kw * Wo < kw && pt == 0 && pl == 0 && pb == 0 && pr == 0 &&
+            (p.C & 3) == 0 && kh * kw <= 64 && chain_loc_ok(xin)) {
+            ChainRec r;
+            r.d.type = k::CH_POOL; r.d.K = (int)kh; r.d.cin = (int)kw; r.d.pad = (int)x.dims[3]; r.d.N = p.C; r.d.in_ld = p.C; r.d.out_ld = p.C;
+            r.in = xin; r.out = yl; r.rows = x.dims[0] * Wo; r.fix_n = x.dims[0]; r.fix_T = Wo; r.out_root = n.out[0];
+            step_chainable(run, std::move(r), 0, bytes);
+        } else {
+            step(run, 0, bytes);
+        }
     }
 
     void op_resize(const GNode& n) {

@@ -155,7 +155,7 @@ void grid_sample(hipStream_t s, const float* x, const float* grid, float* y, int
 void attention(hipStream_t s, const float* qkv, float* out, int n, int T, int heads, int hd, float scale);
 // A run of sample-local operators as one launch (chain.hip): one workgroup per sample walks the table.  Every tensor is a row-major
 // [n_samples * T rows][ld floats] view; sample s owns rows [s * T, (s + 1) * T).
-enum ChainType : int { CH_GEMM = 0, CH_LN = 1, CH_ATTN = 2, CH_COPY = 3 };
+enum ChainType : int { CH_GEMM = 0, CH_LN = 1, CH_ATTN = 2, CH_COPY = 3, CH_POOL = 4 };   // CH_POOL: AveragePool K x cin (rows x columns per token) that leaves one row: in = the sample's [K][pad][N] map, pad = its width >= cin * T
 struct ChainRef { unsigned long long v = 0; int kind = -1; };   // kind: -1 none, 0 absolute device pointer, 1 arena-relative byte offset, 2 primary-input-relative
 struct ChainOpD {
     int type = 0;
