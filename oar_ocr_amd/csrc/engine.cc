@@ -804,7 +804,12 @@ struct Planner {
     // that the 16 rows of a B operand start in different banks): the operators' references are rewritten to LDS offsets (ChainRef
     // kind 3) and their row strides to the padded one.  Liveness-based first-fit over the operator order; when the budget is
     // exceeded the largest tensor goes back to the arena and the placement is redone.  Returns the dynamic LDS size of the launch.
-    size_t chain_place_in_lds(std::vector<k::ChainOpD>& ops, const std::vector<std::string>& out_roots, int last_node, int64_t n, int64_t T, size_t scratch, size_t budget) {
+    // Split-K partials live at LDS offset 0, but only DURING their operator: `op_scratch[j]` bytes are reserved for operator j alone (a pseudo tensor
+    // pinned at offset 0 with the lifetime [j, j]), so a tensor that is dead by then -- or born later -- may occupy the same bytes (round 5: with the pooling
+    // operator inside the chain its 40 KB output pushed the 80 KB concat back to the arena while 24 KB of partials that no operator near it uses sat idle).
+    size_t chain_place_in_lds(std::vector<k::ChainOpD>& ops, const std::vector<std::string>& out_roots, int last_node, int64_t n, int64_t T, const std::vector<size_t>& op_scratch, size_t budget) {
+        size_t scratch = 0;
+        for (size_t b : op_scratch) scratch = std::max(scratch, b);
         const char* lds_env = getenv("OAR_CHAIN_LDS");   // read per plan: tests A/B the placements inside one process
         const bool lds_on = !lds_env || atoi(lds_env) != 0;
         if (!lds_on || scratch >= budget) return scratch;
@@ -848,25 +853,29 @@ struct Planner {
         }
         size_t peak = 0;
         for (;;) {
-            // first-fit by first definition; a slot is reusable by an operator's OUTPUT only when its tensor's last use is an earlier operator
+            // first-fit by first definition; a slot is reusable by an operator's OUTPUT only when its tensor's last use is an earlier operator.
+            // Candidates a tensor must avoid: every tensor placed before it whose life reaches its first operator, and the partials of every
+            // operator inside its own life.
             std::vector<int> idx;
             for (int i = 0; i < (int)roots.size(); ++i) if (roots[(size_t)i].in_lds) idx.push_back(i);
             std::sort(idx.begin(), idx.end(), [&](int a, int b) { return roots[(size_t)a].first < roots[(size_t)b].first; });
-            std::vector<int> active;
-            peak = 0;
+            std::vector<int> placed;
+            peak = scratch;
             for (int i : idx) {
                 Root& r = roots[(size_t)i];
-                std::vector<int> keep;
-                for (int a : active) if (roots[(size_t)a].last >= r.first) keep.push_back(a);
-                active.swap(keep);
-                std::sort(active.begin(), active.end(), [&](int a, int b) { return roots[(size_t)a].off < roots[(size_t)b].off; });
+                std::vector<std::pair<size_t, size_t>> busy;   // [begin, end) byte ranges taken while r lives
+                for (int a : placed) if (roots[(size_t)a].last >= r.first) busy.push_back({roots[(size_t)a].off, roots[(size_t)a].off + roots[(size_t)a].bytes});
+                size_t part = 0;
+                for (int j = std::max(0, r.first); j <= r.last && j < (int)op_scratch.size(); ++j) part = std::max(part, op_scratch[(size_t)j]);
+                if (part) busy.push_back({0, part});
+                std::sort(busy.begin(), busy.end());
                 size_t off = 0;
-                for (int a : active) { if (off + r.bytes <= roots[(size_t)a].off) break; off = std::max(off, roots[(size_t)a].off + roots[(size_t)a].bytes); }
+                for (auto& b : busy) { if (off + r.bytes <= b.first) break; off = std::max(off, b.second); }
                 r.off = off;
                 peak = std::max(peak, off + r.bytes);
-                active.push_back(i);
+                placed.push_back(i);
             }
-            if (scratch + peak <= budget || idx.empty()) break;
+            if (peak <= budget || idx.empty()) break;
             int big = idx[0];
             for (int i : idx) if (roots[(size_t)i].bytes > roots[(size_t)big].bytes) big = i;
             roots[(size_t)big].in_lds = false;
@@ -876,12 +885,12 @@ struct Planner {
             if (!r.in_lds) continue;
             const Use& u = uses[ui];
             k::ChainOpD& d = ops[(size_t)u.op];
-            k::ChainRef ref; ref.kind = 3; ref.v = (unsigned long long)(scratch + r.off + (size_t)(u.off - r.base));
+            k::ChainRef ref; ref.kind = 3; ref.v = (unsigned long long)(r.off + (size_t)(u.off - r.base));
             if (u.which == 0) { d.in = ref; d.in_ld = r.ld + 4; }
             else if (u.which == 1) { d.out = ref; d.out_ld = r.ld + 4; }
             else { d.res = ref; d.res_ld = r.ld + 4; }
         }
-        return scratch + peak;
+        return peak;
     }
     void fuse_chains() {
         if (!chain_on || chain_recs.empty()) return;
@@ -990,7 +999,6 @@ struct Planner {
                 }
                 const int MT = (int)((T + 15) / 16);
                 std::vector<size_t> w_at(ops.size(), 0);
-                size_t scratch = 0;
                 for (size_t q = 0; q < ops.size(); ++q) {
                     k::ChainOpD& d = ops[q];
                     if (d.type != k::CH_GEMM) continue;
@@ -1005,18 +1013,20 @@ struct Planner {
                     const int NT = d.N / 16, KB = d.K / 16;
                     d.mb = (NT * MT <= 16 && KB <= 8) ? 1 : (MT <= 3 ? MT : (MT % 3 == 0 ? 3 : (MT % 2 == 0 ? 2 : 3)));
                     const int MG = (MT + d.mb - 1) / d.mb;
+                    // (a 48 KB cap -- 16 items instead of 8 for the two long products K = 768 / 1536 -> 32 -- was measured: no faster per product, and the
+                    // partials then push the 80 KB concat out of LDS: profiles/r5/chain_lds_scratch.txt)
                     int ks = 1;
                     while (NT * MG * ks < 16 && KB / (ks * 2) >= 2 && NT * MG * d.mb * ks * 2 <= 24) ks *= 2;
                     d.ksplit = ks;
-                    scratch = std::max(scratch, k::chain_lds_bytes(d, (int)T));
                 }
+                std::vector<size_t> op_scratch(ops.size(), 0);
+                for (size_t q = 0; q < ops.size(); ++q) op_scratch[q] = (k::chain_lds_bytes(ops[q], (int)T) + 255) & ~(size_t)255;
                 auto consts = std::make_shared<DevBuf>();
                 consts->reserve(blob.size() * 4 + 256);
                 OAR_HIP(hipMemcpy(consts->p, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
                 for (size_t q = 0; q < ops.size(); ++q) if (ops[q].type == k::CH_GEMM) ops[q].w = consts->as<float>() + w_at[q];
-                scratch = (scratch + 255) & ~(size_t)255;
                 const size_t small_bytes = (((size_t)small * 4 + 255) & ~(size_t)255) + ((ops.size() * sizeof(k::ChainOpD) + 255) & ~(size_t)255);   // + the table copy
-                const size_t tens_end = chain_place_in_lds(ops, out_roots, last_node, n, T, scratch, k::kChainLdsBudget - small_bytes);
+                const size_t tens_end = chain_place_in_lds(ops, out_roots, last_node, n, T, op_scratch, k::kChainLdsBudget - small_bytes);
                 for (size_t q = 0; q + 1 < ops.size();) {   // a staging copy that found no room: drop it, the product reads HBM (slow path)
                     if (ops[q].type == k::CH_COPY && ops[q].out.kind == 1 && ops[q].out.v >= kStageBase) {
                         ops[q + 1].in = ops[q].in; ops[q + 1].in_ld = ops[q].in_ld;
