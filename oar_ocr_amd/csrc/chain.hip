@@ -159,13 +159,99 @@ __device__ __forceinline__ void ch_gemm_slow(const ChainOpD& op, const ChView& i
     }
 }
 
-// Fast path: tokens in LDS.  One work item = 16 output channels x mb (<= 3) token tiles (the weights of a K step are loaded once for
+// Fast path: tokens in LDS.  One work item = 16 output channels x MB (<= 3) token tiles (the weights of a K step are loaded once for
 // all of them) over one K slice; items = channel tiles x token groups x K slices, chosen by the planner to occupy the 16 waves in one
 // round.  (Requesting the next operator's first weights one operator ahead was tried: the 32 registers it holds across the
 // operator push this 1024-thread kernel over its 128 and the spills cost more than the L2 round trip they hide.)
-template <int MBX>
+// The K loop is BRANCH-FREE (end of round 5): MB is a template parameter, a K step past the slice loads a clamped (valid) weight address and
+// is zeroed by a select, a token row outside the sample reads row 0 and is zeroed by a select.  With `if (m < op.mb)` / `if (g + u < kb1)`
+// as run-time branches around loads and MFMAs the compiler split the unrolled body into ~20 blocks, shuffled the accumulators between
+// them with v_mov chains and waited vmcnt(0) -- i.e. for the NEXT group's weights, the prefetch -- in front of every MFMA quartet.
+template <int MB>
 __device__ __forceinline__ void ch_gemm_lds(const ChainOpD& op, const ChView& in, const ChView& out, const ChView& res, bool has_res, int T, unsigned lbase, int wave, int lane) {
-    const int MB = op.mb, MT = (T + 15) >> 4, MG = (MT + MB - 1) / MB, NT = op.N >> 4, KB = op.K >> 4, KS = op.ksplit;
+    const int MT = (T + 15) >> 4, MG = (MT + MB - 1) / MB, NT = op.N >> 4, KB = op.K >> 4, KS = op.ksplit;
+    const int kper = (KB + KS - 1) / KS, items = NT * MG * KS;
+    const int r = lane & 15, q = lane >> 4;
+    const ChEpi epi{op, out, res, has_res, T, lbase, r, q, MT};
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int it = wave; it < items; it += kWaves) {
+        const int ks = it % KS, rest = it / KS, mg = rest % MG, nt = rest / MG;
+        const int kb0 = ks * kper, kb1 = min(KB, kb0 + kper), klast = max(kb1 - 1, 0);
+        ch_gf* wrow = (ch_gf*)reinterpret_cast<unsigned long long>(op.w) + (long)(nt * 16 + r) * op.K + 4 * q;
+        int tap = (kb0 * 16) / op.cin, c0 = kb0 * 16 - tap * op.cin;
+        f32x4 a[4], an[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) an[u] = *reinterpret_cast<ch_gf4*>(wrow + min(kb0 + u, klast) * 16);
+        int trow[MB];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) trow[m] = (mg * MB + m) * 16 + r;
+        f32x4 acc[MB];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) acc[m] = zero4;
+        const unsigned inb = in.l + 16u * (unsigned)q;
+#pragma nounroll
+        for (int g = kb0; g < kb1; g += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool live = g + u < kb1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[u][e] = live ? an[u][e] : 0.f;
+            }
+            if (g + 4 < kb1) {   // the next group (a branch around the four loads only: a request nobody consumes would still be waited for before its registers are reused)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) an[u] = *reinterpret_cast<ch_gf4*>(wrow + min(g + 4 + u, klast) * 16);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                f32x4 b[MB];
+                const int dt = tap - op.pad;
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    const int row = trow[m] + dt;
+                    const bool ok = (unsigned)row < (unsigned)T;   // outside the sample: the convolution's zero padding / a tile row past T (computed, never stored)
+                    const f32x4 v = CH_LDS(ch_lf4, inb + 4u * (unsigned)((ok ? row : 0) * in.ld + c0));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[m][e] = ok ? v[e] : 0.f;
+                }
+                c0 += 16;
+                const bool wrap = c0 >= op.cin;
+                c0 = wrap ? 0 : c0;
+                tap += wrap ? 1 : 0;
+                // (requesting step u + 1's token tiles before the MFMAs of step u -- two register stages -- was measured: no faster, 13 registers more)
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][0], b[m][0], acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][1], b[m][1], acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][2], b[m][2], acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][3], b[m][3], acc[m], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler hoists all 12 token loads of the group: 48 registers, spills)
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            if (KS == 1) ch_epilogue(epi, acc[m], nt, mg * MB + m);
+            else CH_LDS(ch_lf4, lbase + 16u * (unsigned)(((((nt * MG + mg) * MB + m) * KS) + ks) * 64 + lane)) = acc[m];
+            __builtin_amdgcn_sched_barrier(0);   // one tile's epilogue at a time (interleaved, their exp sequences spill)
+        }
+    }
+    if (KS > 1) {
+        __syncthreads();
+        const int tiles = NT * MG * MB;
+        for (int tile = wave; tile < tiles; tile += kWaves) {
+            f32x4 acc = CH_LDS(ch_lf4, lbase + 16u * (unsigned)(tile * KS * 64 + lane));
+            for (int ks = 1; ks < KS; ++ks) acc += CH_LDS(ch_lf4, lbase + 16u * (unsigned)((tile * KS + ks) * 64 + lane));
+            const int m = tile % MB, rest = tile / MB, mg = rest % MG, nt = rest / MG;
+            ch_epilogue(epi, acc, nt, mg * MB + m);
+        }
+    }
+}
+
+// One token tile per item and a K slice shorter than one group of four steps (the 32 -> 64 convolutions, the K = 64 projections split in two): the
+// guarded loop of rounds 3-4 -- skipping the missing steps costs less here than multiplying zeros (3.2 / 4.4 us against 3.9 / 5.3 per product).
+__device__ __forceinline__ void ch_gemm_lds_short(const ChainOpD& op, const ChView& in, const ChView& out, const ChView& res, bool has_res, int T, unsigned lbase, int wave, int lane) {
+    constexpr int MBX = 1, MB = 1;
+    const int MT = (T + 15) >> 4, MG = (MT + MB - 1) / MB, NT = op.N >> 4, KB = op.K >> 4, KS = op.ksplit;
     const int kper = (KB + KS - 1) / KS, items = NT * MG * KS;
     const int r = lane & 15, q = lane >> 4;
     const ChEpi epi{op, out, res, has_res, T, lbase, r, q, MT};
@@ -475,7 +561,9 @@ __global__ __launch_bounds__(kChainThreads) void chain_kernel(const ChainOpD* __
             case CH_GEMM: {
                 const bool has_res = op.res.kind >= 0;
                 const ChView res = ch_view(op.res, op.res_ld, row0, arena, input, lbase);
-                if (in.lds && op.mb == 1) ch_gemm_lds<1>(op, in, out, res, has_res, T, lbase, wave, lane);
+                if (in.lds && op.mb == 1 && ((op.K >> 4) + op.ksplit - 1) / op.ksplit < 4) ch_gemm_lds_short(op, in, out, res, has_res, T, lbase, wave, lane);
+                else if (in.lds && op.mb == 1) ch_gemm_lds<1>(op, in, out, res, has_res, T, lbase, wave, lane);
+                else if (in.lds && op.mb == 2) ch_gemm_lds<2>(op, in, out, res, has_res, T, lbase, wave, lane);
                 else if (in.lds) ch_gemm_lds<3>(op, in, out, res, has_res, T, lbase, wave, lane);
                 else ch_gemm_slow(op, in, out, res, has_res, T, lbase, wave, lane);
                 break;

@@ -1014,7 +1014,7 @@ struct Planner {
                     d.mb = (NT * MT <= 16 && KB <= 8) ? 1 : (MT <= 3 ? MT : (MT % 3 == 0 ? 3 : (MT % 2 == 0 ? 2 : 3)));
                     const int MG = (MT + d.mb - 1) / d.mb;
                     // (a 48 KB cap -- 16 items instead of 8 for the two long products K = 768 / 1536 -> 32 -- was measured: no faster per product, and the
-                    // partials then push the 80 KB concat out of LDS: profiles/r5/chain_lds_scratch.txt)
+                    // partials then push the 80 KB concat out of LDS: profiles/r5/chain_r5_endgame.txt)
                     int ks = 1;
                     while (NT * MG * ks < 16 && KB / (ks * 2) >= 2 && NT * MG * d.mb * ks * 2 <= 24) ks *= 2;
                     d.ksplit = ks;
