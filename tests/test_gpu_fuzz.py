@@ -11,9 +11,9 @@ pytestmark = pytest.mark.gpu
 
 def test_random_pages_match_oracle():
     root = Path(__file__).resolve().parents[1]
-    r = subprocess.run([sys.executable, str(root / "tools" / "parity_fuzz.py"), "8", "7"], cwd=root, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, str(root / "tools" / "parity_fuzz.py"), "24", "7"], cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "8/8 cases identical" in r.stdout
+    assert "24/24 cases identical" in r.stdout   # (8 cases until the end of round 5; the first 64 of this seed are identical on the final build, 2 x 64 checked)
 
 
 def _fuzz(n, seed, mode):
@@ -25,7 +25,7 @@ def _fuzz(n, seed, mode):
 
 def test_random_pages_with_optional_stages_match_oracle():
     """document orientation / UVDoc / text-line orientation randomly attached, pages randomly rotated"""
-    _fuzz(8, 21, "stages")
+    _fuzz(12, 21, "stages")
 
 
 def test_random_seal_pages_match_oracle():
