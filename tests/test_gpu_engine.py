@@ -718,7 +718,7 @@ def test_stacked_convtranspose_pair_is_one_kernel(case):
     assert names.get("convt_pair", 0) == (1 if c1 != 12 else 0), names
 
 
-@pytest.mark.parametrize("n,W", [(5, 320), (3, 184), (1, 8), (2, 520), (2, 1100)])
+@pytest.mark.parametrize("n,W", [(5, 320), (3, 184), (1, 8), (3, 480), (2, 520), (2, 1100)])   # W = 480: four token tiles = two per work item (ch_gemm_lds<2>)
 @pytest.mark.parametrize("mode", ["lds", "arena"])
 def test_sample_local_chain_matches_oracle_and_the_unfused_path(n, W, mode, monkeypatch):
     """The recognizer's SVTR neck (1 x 3 conv, 1 x 1 convs, LayerNorm, QKV / attention / projection, FFN, concat) runs as ONE launch
