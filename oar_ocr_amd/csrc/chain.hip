@@ -390,9 +390,10 @@ __device__ __forceinline__ void ch_layernorm(const ChainOpD& op, const ChView& x
 // scale)^T: keys are the A rows, queries the B columns, so a lane ends up with the scores of keys {16 jt + 4 q + i} for ITS query
 // r -- the softmax over keys is 4 JT registers plus two cross-row exchanges, and the probabilities are already laid out as the B
 // operand of O^T = V^T P (K index = the lane group's key), whose result is 4 consecutive output channels of one query: one float4.
+template <int MT>   // token tiles, 1..4 (a template parameter: `jt < MT` tested at run time around the MFMAs splits the unrolled body into blocks, see ch_gemm_lds)
 __device__ __forceinline__ void ch_attention_mfma(const ChainOpD& op, const ChView& qkv, const ChView& out, int T, int wave, int lane) {
-    constexpr int JX = 4;
-    const int heads = op.heads, hd = op.hd, dim = heads * hd, MT = (T + 15) >> 4;
+    constexpr int JX = MT;
+    const int heads = op.heads, hd = op.hd, dim = heads * hd;
     const int r = lane & 15, q = lane >> 4;
     const bool dq = 4 * q < hd;
     for (int u = wave; u < heads * MT; u += kWaves) {
@@ -570,8 +571,12 @@ __global__ __launch_bounds__(kChainThreads) void chain_kernel(const ChainOpD* __
             }
             case CH_LN: ch_layernorm(op, in, out, T, lbase, wave, lane); break;
             case CH_ATTN:
-                if (T <= 64 && (op.hd & 3) == 0) ch_attention_mfma(op, in, out, T, wave, lane);
-                else ch_attention_any<HD>(op, in, out, T);
+                if (T <= 64 && (op.hd & 3) == 0) {
+                    if (T <= 16) ch_attention_mfma<1>(op, in, out, T, wave, lane);
+                    else if (T <= 32) ch_attention_mfma<2>(op, in, out, T, wave, lane);
+                    else if (T <= 48) ch_attention_mfma<3>(op, in, out, T, wave, lane);
+                    else ch_attention_mfma<4>(op, in, out, T, wave, lane);
+                } else ch_attention_any<HD>(op, in, out, T);
                 break;
             case CH_POOL: ch_pool(op, in, out, T); break;
             default: ch_copy(op, in, out, T); break;
