@@ -80,7 +80,7 @@ const float* Engine::upload_const(const std::string& key, const std::vector<floa
 // as a stand-alone element-wise kernel (apply_unary): every extra case in apply_act costs registers in each conv epilogue --
 // with all of them in, the depthwise kernel lost a wave per SIMD and a quarter of its bandwidth.
 static bool is_fusable_act(const std::string& op) {
-    return op == "Relu" || op == "HardSwish" || op == "HardSigmoid" || op == "Sigmoid" || op == "LeakyRelu" || op == "Tanh";
+    return op == "Relu" || op == "HardSwish" || op == "HardSigmoid" || op == "Sigmoid" || op == "LeakyRelu" || op == "Tanh" || op == "Gelu";
 }
 static bool is_unary_act(const std::string& op) {
     return op == "Relu" || op == "HardSwish" || op == "HardSigmoid" || op == "Sigmoid" || op == "LeakyRelu" || op == "Tanh" || op == "Erf" ||
@@ -224,6 +224,72 @@ void Engine::rewrite_graph(OnnxModel& m) {
         nodes.swap(keep);
     }
 
+    // ---- pass 2b: GELU as exporters below opset 20 spell it (SVTRv2's MLPs and conv stem): x * 0.5 * (1 + erf(x / sqrt(2))), in either association
+    //   Mul(Mul(x, Add(Erf(Div(x, 1.41421)), 1)), 0.5)   or   Mul(Mul(x, 0.5), Add(Erf(..), 1));  x / sqrt(2) may also be Mul(x, 0.70711)
+    // becomes ONE Gelu node (5 element-wise launches over the widest tensor of the block -> an epilogue of the producing Linear / Conv, pass 3).
+    // OAR_FUSE_GELU=0 keeps the op-by-op path.
+    {
+        const char* fe = getenv("OAR_FUSE_GELU");
+        const bool fuse = !fe || atoi(fe) != 0;
+        auto cons = consumers(nodes);
+        std::map<std::string, int> producer;
+        for (int i = 0; i < (int)nodes.size(); ++i) for (auto& o : nodes[i].out) producer[o] = i;
+        std::vector<bool> dead(nodes.size(), false);
+        auto scalar_of = [&](const std::string& v, float& out) {
+            auto it = inits_.find(v);
+            if (it == inits_.end() || it->second.dtype != DType::F32 || it->second.f.size() != 1) return false;
+            out = it->second.f[0];
+            return true;
+        };
+        auto single_use = [&](const std::string& v) { return cons[v].size() == 1 && !graph_outs.count(v); };
+        // node `i` is op(x, c) or op(c, x) with a scalar constant close to `want`: returns x's name
+        auto scaled = [&](int i, const char* op, float want, bool commutes, std::string& x) {
+            const GNode& q = nodes[i];
+            if (q.op != op || q.in.size() != 2) return false;
+            float c;
+            if (scalar_of(q.in[1], c) && std::fabs(c - want) <= 1e-4f * std::fabs(want)) { x = q.in[0]; return true; }
+            if (commutes && scalar_of(q.in[0], c) && std::fabs(c - want) <= 1e-4f * std::fabs(want)) { x = q.in[1]; return true; }
+            return false;
+        };
+        for (int i = 0; fuse && i < (int)nodes.size(); ++i) {
+            if (nodes[i].op != "Erf" || dead[i] || !single_use(nodes[i].out[0])) continue;
+            auto pit = producer.find(nodes[i].in[0]);
+            if (pit == producer.end() || dead[pit->second] || !single_use(nodes[i].in[0])) continue;
+            const int pre = pit->second;
+            std::string x;
+            if (!scaled(pre, "Div", 1.41421356f, false, x) && !scaled(pre, "Mul", 0.70710678f, true, x)) continue;
+            const int add = cons[nodes[i].out[0]][0];
+            std::string e1;
+            if (dead[add] || !scaled(add, "Add", 1.0f, true, e1) || e1 != nodes[i].out[0] || !single_use(nodes[add].out[0])) continue;
+            const int m1 = cons[nodes[add].out[0]][0];
+            if (dead[m1] || nodes[m1].op != "Mul" || nodes[m1].in.size() != 2) continue;
+            const std::string other = nodes[m1].in[0] == nodes[add].out[0] ? nodes[m1].in[1] : nodes[m1].in[0];
+            int last = -1, half = -1;
+            if (other == x) {   // (x * (1 + erf)) * 0.5
+                if (!single_use(nodes[m1].out[0])) continue;
+                const int m2 = cons[nodes[m1].out[0]][0];
+                std::string t;
+                if (dead[m2] || !scaled(m2, "Mul", 0.5f, true, t) || t != nodes[m1].out[0]) continue;
+                last = m2;
+            } else {            // (x * 0.5) * (1 + erf)
+                auto hit = producer.find(other);
+                std::string t;
+                if (hit == producer.end() || dead[hit->second] || !single_use(other) || !scaled(hit->second, "Mul", 0.5f, true, t) || t != x) continue;
+                half = hit->second;
+                last = m1;
+            }
+            GNode ge;
+            ge.op = "Gelu"; ge.in = {x}; ge.out = {nodes[last].out[0]};
+            for (int d : {pre, i, add, m1}) dead[d] = true;
+            if (half >= 0) dead[half] = true;
+            dead[last] = false;
+            nodes[last] = std::move(ge);   // the last node of the pattern: every reader comes after it
+        }
+        std::vector<GNode> keep;
+        for (int i = 0; i < (int)nodes.size(); ++i) if (!dead[i]) keep.push_back(std::move(nodes[i]));
+        nodes.swap(keep);
+    }
+
     // ---- pass 3: fuse activations into Conv / ConvTranspose / Linear / Gemm / Add
     {
         bool changed = true;
@@ -238,7 +304,8 @@ void Engine::rewrite_graph(OnnxModel& m) {
                 const std::string& y = p.out[0];
                 if (graph_outs.count(y)) continue;
                 auto& cs = cons[y];
-                if (cs.size() == 1 && is_fusable_act(nodes[cs[0]].op) && !dead[cs[0]]) {
+                if (cs.size() == 1 && is_fusable_act(nodes[cs[0]].op) && !dead[cs[0]] &&
+                    !(nodes[cs[0]].op == "Gelu" && nodes[cs[0]].as("approximate", "none") == "tanh")) {   // (the tanh form only exists in the stand-alone kernel)
                     GNode& a = nodes[cs[0]];
                     p.act = act_of(a);
                     p.out[0] = a.out[0];
@@ -1879,7 +1946,23 @@ struct Planner {
         }
         bool trailing = !axes.empty();
         for (size_t i = 0; i < axes.size(); ++i) trailing = trailing && axes[i] == r - (int64_t)axes.size() + (int64_t)i;
-        OAR_CHECK(trailing, OAR_UNSUPPORTED_OP, n.op + ": only the trailing axes (or H, W of an NCHW tensor for ReduceMean) are supported");
+        if (!trailing && (mode == 0 || mode == 2) && r == 4 && axes.size() == 1 && (axes[0] == 2 || axes[0] == 3) && !x.host_int) {
+            // mean / max over ONE spatial axis of a feature map (SVTRv2's `x.mean(2)` in front of its CTC head): a pooling window as tall (wide)
+            // as the map, on the channels-last tensor where it lies; keepdims = 0 is then a Squeeze of a channels-last view
+            GNode pl;
+            pl.op = mode == 0 ? "AveragePool" : "MaxPool"; pl.in = {n.in[0]}; pl.out = {keep ? n.out[0] : n.out[0] + "::kept"};
+            Attr ks; ks.kind = Attr::IS; ks.is = axes[0] == 2 ? std::vector<int64_t>{x.dims[2], 1} : std::vector<int64_t>{1, x.dims[3]};
+            pl.attrs["kernel_shape"] = ks; pl.attrs["strides"] = ks;
+            op_pool(pl, mode == 2);
+            if (!keep) {
+                GNode sq;
+                sq.op = "Squeeze"; sq.in = {pl.out[0]}; sq.out = {n.out[0]};
+                Attr ax; ax.kind = Attr::IS; ax.is = {axes[0]}; sq.attrs["axes"] = ax;
+                op_squeeze(sq);
+            }
+            return;
+        }
+        OAR_CHECK(trailing, OAR_UNSUPPORTED_OP, n.op + ": only the trailing axes (or H, W / one of them for ReduceMean / ReduceMax of an NCHW tensor) are supported");
         Loc xin = to_native_loc(x);
         int64_t C = 1;
         for (auto a : axes) C *= x.dims[a];
@@ -2799,7 +2882,7 @@ struct Planner {
         const int64_t h = n.ai("heads", 1), d = n.ai("head_dim", 1);
         OAR_CHECK(x.dims.size() == 3 && x.dims[2] == 3 * h * d, OAR_SHAPE_MISMATCH, "Attention: input must be [n, T, 3*heads*head_dim]");
         const int64_t N = x.dims[0], T = x.dims[1];
-        OAR_CHECK(2 * T * d * 4 <= 150 * 1024, OAR_UNSUPPORTED_OP, "Attention: K and V of one head must fit LDS");
+        OAR_CHECK(k::attention_fits((int)T, (int)h, (int)d), OAR_UNSUPPORTED_OP, "Attention: K and V of one head must fit LDS (or head_dim == 32 for the streaming kernel)");
         Loc xin = to_native_loc(x);
         TInfo& y = new_out(n.out[0], {N, T, h * d}, Layout::NATIVE);
         Loc yl = y.loc;

@@ -153,6 +153,11 @@ void where(hipStream_t s, const float* cond, const float* a, const float* b, flo
 void grid_sample(hipStream_t s, const float* x, const float* grid, float* y, int N, int H, int W, int C, int Ho, int Wo, int mode, int padding, int align_corners);
 // softmax(scale * q k^T) v per (image, head); qkv [n][T][3][heads][hd] row-major, out [n][T][heads][hd]; hd <= 64
 void attention(hipStream_t s, const float* qkv, float* out, int n, int T, int heads, int hd, float scale);
+// attention_x6.hip: the same operator flash-style on the bf16 matrix pipe (bf16x6 products), any T, head dim 32 -- what `attention` launches for
+// hd == 32 unless OAR_ATTN_X6=0; attention_fits(T, hd): can `attention` run this shape at all (either kernel)?
+bool attention_x6_supported(int T, int heads, int hd);
+void attention_x6(hipStream_t s, const float* qkv, float* out, int n, int T, int heads, int hd, float scale);
+bool attention_fits(int T, int heads, int hd);
 // A run of sample-local operators as one launch (chain.hip): one workgroup per sample walks the table.  Every tensor is a row-major
 // [n_samples * T rows][ld floats] view; sample s owns rows [s * T, (s + 1) * T).
 enum ChainType : int { CH_GEMM = 0, CH_LN = 1, CH_ATTN = 2, CH_COPY = 3, CH_POOL = 4 };   // CH_POOL: AveragePool K x cin (rows x columns per token) that leaves one row: in = the sample's [K][pad][N] map, pad = its width >= cin * T

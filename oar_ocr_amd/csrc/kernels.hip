@@ -1558,9 +1558,17 @@ static void launch_attention(hipStream_t s, const float* qkv, float* out, int n,
     hipLaunchKernelGGL((attention_kernel<HD>), dim3((unsigned)(n * heads)), dim3(threads), lds, s, qkv, out, T, heads, hd, scale);
 }
 
+static bool attention_x6_on() { static const bool on = [] { const char* e = getenv("OAR_ATTN_X6"); return !e || atoi(e) != 0; }(); return on; }
+bool attention_fits(int T, int heads, int hd) {
+    if (hd < 1 || hd > 64) return false;
+    if (attention_x6_on() && attention_x6_supported(T, heads, hd)) return true;
+    const int HD = hd <= 16 ? 16 : hd <= 32 ? 32 : 64;
+    return (size_t)2 * T * HD * sizeof(float) <= 150 * 1024;
+}
 void attention(hipStream_t s, const float* qkv, float* out, int n, int T, int heads, int hd, float scale) {
     if (n == 0 || T == 0) return;
     OAR_CHECK(hd >= 1 && hd <= 64, OAR_UNSUPPORTED_OP, "attention: head_dim must be in 1..=64");
+    if (attention_x6_on() && attention_x6_supported(T, heads, hd) && T > 32) return attention_x6(s, qkv, out, n, T, heads, hd, scale);
     const double nh = (double)n * heads;
     ProfScope ps(s, "attention", 4.0 * nh * T * 4.0 * hd, 4.0 * nh * T * T * hd);
     if (hd <= 16) launch_attention<16>(s, qkv, out, n, T, heads, hd, scale);

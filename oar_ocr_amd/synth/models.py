@@ -59,23 +59,33 @@ class _Net:
         if kind == "swish":
             s = g.op("Sigmoid", [x])
             return g.op("Mul", [x, s])
+        if kind == "gelu":   # the erf form exporters below opset 20 write: x * 0.5 * (1 + erf(x / sqrt(2)))
+            e = g.op("Erf", [g.op("Div", [x, g.init(np.array(np.sqrt(2.0), np.float32), "c")])])
+            t = g.op("Add", [e, g.init(np.array(1.0, np.float32), "c")])
+            return g.op("Mul", [g.op("Mul", [x, t]), g.init(np.array(0.5, np.float32), "c")])
         raise ValueError(kind)
 
     # ------------------------------------------------------------------ layers
-    def conv(self, x, cin, cout, k, stride=1, groups=1, act=None, ink=None, pad=None, bias=True, w=None, b=None):
-        """ink: None | 'pass' (out0 <- box-filter of in0) | 'zero' (out0 == 0) for the channel-0 ink path."""
+    def conv(self, x, cin, cout, k, stride=1, groups=1, act=None, ink=None, pad=None, bias=True, w=None, b=None, pads4=None, gain=2.0):
+        """ink: None | 'pass' (out0 <- box-filter of in0) | 'center' (out0 <- in0 through the centre tap: large kernels would blur the
+        ink away) | 'zero' (out0 == 0) for the channel-0 ink path.  pads4: ONNX pads [top, left, bottom, right] when they are not symmetric
+        (the "SAME" padding of an even kernel pads bottom / right only)."""
         kh, kw = (k, k) if isinstance(k, int) else k
         sh, sw = (stride, stride) if isinstance(stride, int) else stride
         if pad is None:
             pad = (kh // 2, kw // 2)
         cpg = cin // groups
         if w is None:
-            w = self._w((cout, cpg, kh, kw), cpg * kh * kw)
+            w = self._w((cout, cpg, kh, kw), cpg * kh * kw, gain)
         if b is None:
             b = self._b(cout)
         if ink == "pass":
             w[0] = 0.0
             w[0, 0] = 1.0 / (kh * kw)
+            b[0] = 0.0
+        elif ink == "center":
+            w[0] = 0.0
+            w[0, 0, kh // 2, kw // 2] = 1.0
             b[0] = 0.0
         elif ink == "zero":
             w[0] = 0.0
@@ -83,7 +93,7 @@ class _Net:
         ins = [x, self.g.init(w)]
         if bias:
             ins.append(self.g.init(b, "b"))
-        y = self.g.op("Conv", ins, kernel_shape=[kh, kw], strides=[sh, sw], pads=[pad[0], pad[1], pad[0], pad[1]],
+        y = self.g.op("Conv", ins, kernel_shape=[kh, kw], strides=[sh, sw], pads=list(pads4) if pads4 is not None else [pad[0], pad[1], pad[0], pad[1]],
                       group=groups, dilations=[1, 1])
         return self.act(y, act)
 
@@ -138,7 +148,10 @@ class _Net:
 def build_det(size="tiny", seed=0, soft=False):
     """DB text detector.  Returns (onnx_bytes, info).  soft: a shallow final gain and 30x the weight on the random channels -- the probability
     map is no longer near-binary (thousands of pixels within 0.05 of the 0.3 threshold, blob borders that depend on the random-weight
-    channels): the regime real PP-OCR weights put the post-processing in (VERDICT r2 weak #2)."""
+    channels): the regime real PP-OCR weights put the post-processing in.
+    size "server_hgnet" (and its narrow test twin "hgnet_small"): the PP-OCRv5 server detector's family, see build_det_hgnet."""
+    if size in _HGNET_CFG:
+        return build_det_hgnet(size, seed=seed, soft=soft)
     cfg = {
         #        stem  c2   c3   c4    c5   neck  p
         "tiny": (16, 24, 32, 64, 128, 256, 64, 16),
@@ -208,7 +221,10 @@ def build_det(size="tiny", seed=0, soft=False):
 
 
 def build_rec(size="tiny", vocab=6906, seed=1):
-    """CRNN/SVTR CTC recognizer: in [n,3,48,W] -> out [n, W/8, vocab] softmax probabilities."""
+    """CRNN/SVTR CTC recognizer: in [n,3,48,W] -> out [n, W/8, vocab] softmax probabilities.
+    size "svtrv2" (and its narrow test twin "svtrv2_small"): the SVTRv2 server recognizer's family, see build_rec_svtrv2 (T = W/4)."""
+    if size in _SVTRV2_CFG:
+        return build_rec_svtrv2(size, vocab=vocab, seed=seed)
     cfg = {
         #        stem b2  b3  b4   b5   b6   svtr_dim heads out
         "tiny": (16, 24, 48, 96, 192, 256, 64, 4, 64),
@@ -282,6 +298,220 @@ def build_rec(size="tiny", vocab=6906, seed=1):
     z = g.op("Squeeze", [z, g.init(np.array([2], np.int64), "axes")])
     z = g.op("Transpose", [z], perm=[0, 2, 1])                           # [n, T, outc]
     logits = linear(z, outc, vocab, gain=float(outc) * 4.0)               # spread logits: distinct argmax
+    g.nodes.append(node("Softmax", [logits], ["probs"], axis=2))
+    g.add_output("probs", ["N", "T", vocab])
+    return g.model(), {"params": g.n_params, "size": size, "vocab": vocab}
+
+
+# ---------------------------------------------------------------------------------------------- BASELINE C3: the server graphs
+# pp-ocrv5_server_det.onnx is 88 116 836 bytes ~ 22.0 M f32 parameters (reference registry.rs:77): PP-HGNetV2-B4 backbone (stem with a 2x2 side
+# branch, four stages of HG blocks -- a run of `layers` convolutions whose outputs are ALL concatenated with the block input and aggregated by two
+# 1x1 convolutions; stages 1-2 use dense 3x3 convolutions, stages 3-4 the "light" form 1x1 + depthwise 5x5), LK-PAN neck (1x1 laterals to 256
+# channels, top-down adds, 9x9 convolutions 256 -> 64 on every level, a bottom-up path of 3x3 stride-2 convolutions, 9x9 convolutions 64 -> 64,
+# concat at stride 4) and the DB head.  Channel / depth numbers are PaddleOCR's published configuration of that detector [NOT in the reference: the
+# reference only pins the file's byte size]; weights are random apart from the ink path.  An effective-squeeze-excite gate (GlobalAveragePool ->
+# 1x1 -> Sigmoid -> Mul; PP-HGNet v1's, SURVEY Appendix B names it) closes the two dense stages: 0.28 M parameters (on all four stages its C x C
+# weights would be 5.5 M and put the graph 25 % over the file it stands for).
+_HGNET_CFG = {
+    #                 stem (c1, c2a, c3, c4)   stages: (mid, out, blocks, light, k, layers)                                              neck  pan
+    "server_hgnet": ((32, 16, 32, 48), ((48, 128, 1, False, 3, 6), (96, 512, 1, False, 3, 6), (192, 1024, 3, True, 5, 6), (384, 2048, 1, True, 5, 6)), 256, 64),
+    # the same topology at 1/4 of the widths (1.4 M parameters): what the CPU oracle can run on several pages inside a test
+    "hgnet_small": ((16, 8, 16, 16), ((16, 32, 1, False, 3, 6), (24, 128, 1, False, 3, 6), (48, 256, 3, True, 5, 6), (96, 512, 1, True, 5, 6)), 64, 16),
+}
+
+
+def build_det_hgnet(size="server_hgnet", seed=0, soft=False, ese=True):
+    """PP-OCRv5-server-class DB detector (see the comment above).  Returns (onnx_bytes, info)."""
+    (s1, s2a, s3, s4), stages, nk, pc = _HGNET_CFG[size]
+    n = _Net(f"synth_db_{size}", seed)
+    g = n.g
+    g.add_input("x", ["N", 3, "H", "W"])
+    same2 = [0, 0, 1, 1]   # "SAME" padding of a 2x2 kernel: bottom / right
+    # ---- stem (stride 4).  Channel 0 carries the ink signal as in build_det
+    w = n._w((s1, 3, 3, 3), 27)
+    b = n._b(s1)
+    for c in range(3):
+        w[0, c] = -INK_AMPL * DB_STD[c] / 27.0
+    b[0] = INK_AMPL * (1.0 - float(DB_MEAN.mean()))
+    x1 = n.conv("x", 3, s1, 3, 2, act="relu", w=w, b=b)
+    x2 = n.conv(x1, s1, s2a, 2, 1, act="relu", ink="pass", pads4=same2)
+    x2 = n.conv(x2, s2a, s1, 2, 1, act="relu", ink="pass", pads4=same2)
+    xp = g.op("MaxPool", [x1], kernel_shape=[2, 2], strides=[1, 1], pads=same2)
+    x = g.op("Concat", [xp, x2], axis=1)
+    x = n.conv(x, 2 * s1, s3, 3, 2, act="relu", ink="pass")
+    x = n.conv(x, s3, s4, 1, 1, act="relu", ink="pass")
+
+    def hg_block(x, cin, mid, cout, k, layers, light, identity, ink):
+        outs = [x]
+        t, c = x, cin
+        for _ in range(layers):
+            if light:   # LightConvBNAct: 1x1 without activation, then depthwise k x k with ReLU
+                t = n.conv(t, c, mid, 1, 1, gain=1.0)       # (no activation behind it: a variance-preserving draw, there is no BatchNorm to rescale)
+                t = n.conv(t, mid, mid, k, 1, groups=mid, act="relu")
+            else:
+                t = n.conv(t, c, mid, k, 1, act="relu")
+            outs.append(t)
+            c = mid
+        total = cin + layers * mid
+        y = g.op("Concat", outs, axis=1)
+        y = n.conv(y, total, cout // 2, 1, 1, act="relu", ink=ink)     # aggregation squeeze: concat channel 0 is the block input's channel 0
+        y = n.conv(y, cout // 2, cout, 1, 1, act="relu", ink=ink)      # aggregation excitation
+        if identity:
+            y = g.op("Add", [y, x])
+        return y
+
+    def ese_gate(x, c, ink):
+        p = g.op("GlobalAveragePool", [x])
+        w, b = n._w((c, c, 1, 1), c, gain=1.0), n._b(c)
+        if ink:   # sigmoid(12) = 1 - 6e-6: the ink channel passes the gate unscaled
+            w[0] = 0.0
+            b[0] = 12.0
+        h = g.op("Conv", [p, g.init(w), g.init(b, "b")], kernel_shape=[1, 1], strides=[1, 1], pads=[0, 0, 0, 0], group=1, dilations=[1, 1])
+        return g.op("Mul", [x, g.op("Sigmoid", [h])])
+
+    feats = []
+    cin = s4
+    for si, (mid, cout, blocks, light, k, layers) in enumerate(stages):
+        ink = "pass" if si == 0 else None
+        if si > 0:   # downsample: depthwise 3x3 stride 2 without activation
+            x = n.conv(x, cin, cin, 3, 2, groups=cin, gain=1.0)
+        for bi in range(blocks):
+            x = hg_block(x, cin if bi == 0 else cout, mid, cout, k, layers, light, identity=bi > 0, ink=ink)
+        if ese and not light:
+            x = ese_gate(x, cout, ink=si == 0)
+        feats.append((x, cout))
+        cin = cout
+    (f2, c2), (f3, c3), (f4, c4), (f5, c5) = feats
+    # ---- LK-PAN
+    in5 = n.conv(f5, c5, nk, 1, ink="zero", bias=False, gain=0.5)
+    in4 = n.conv(f4, c4, nk, 1, ink="zero", bias=False, gain=0.5)
+    in3 = n.conv(f3, c3, nk, 1, ink="zero", bias=False, gain=0.5)
+    in2 = n.conv(f2, c2, nk, 1, ink="pass", bias=False, gain=0.5)
+
+    def up(t, s):
+        return g.op("Resize", [t, "", g.init(np.array([1, 1, s, s], np.float32), "scales")], mode="nearest",
+                    coordinate_transformation_mode="asymmetric", nearest_mode="floor")
+
+    out4 = g.op("Add", [in4, up(in5, 2)])
+    out3 = g.op("Add", [in3, up(out4, 2)])
+    out2 = g.op("Add", [in2, up(out3, 2)])
+    q5 = n.conv(in5, nk, pc, 9, bias=False, gain=0.5)
+    q4 = n.conv(out4, nk, pc, 9, bias=False, gain=0.5)
+    q3 = n.conv(out3, nk, pc, 9, bias=False, gain=0.5)
+    q2 = n.conv(out2, nk, pc, 9, ink="center", bias=False, gain=0.5)
+    pan3 = g.op("Add", [q3, n.conv(q2, pc, pc, 3, 2, bias=False, gain=0.5)])
+    pan4 = g.op("Add", [q4, n.conv(pan3, pc, pc, 3, 2, bias=False, gain=0.5)])
+    pan5 = g.op("Add", [q5, n.conv(pan4, pc, pc, 3, 2, bias=False, gain=0.5)])
+    p2 = n.conv(q2, pc, pc, 9, ink="center", bias=False, gain=0.5)
+    p3 = n.conv(pan3, pc, pc, 9, bias=False, gain=0.5)
+    p4 = n.conv(pan4, pc, pc, 9, bias=False, gain=0.5)
+    p5 = n.conv(pan5, pc, pc, 9, bias=False, gain=0.5)
+    fuse = g.op("Concat", [up(p5, 8), up(p4, 4), up(p3, 2), p2], axis=1)
+    # ---- DB head; the ink channel is concat index 3 * pc
+    hc = nk // 4
+    w = n._w((hc, 4 * pc, 3, 3), 4 * pc * 9)
+    b = n._b(hc)
+    w[0] = 0.0
+    w[0, 3 * pc] = 1.0 / 9.0
+    b[0] = 0.0
+    x = n.conv(fuse, 4 * pc, hc, 3, w=w, b=b, bias=True)
+    x = n.bn(x, hc, ink=True)
+    x = g.op("Relu", [x])
+    x = n.conv_transpose2x2(x, hc, hc, ink_gain=1.0)
+    x = n.bn(x, hc, ink=True)
+    x = g.op("Relu", [x])
+    x = n.conv_transpose2x2(x, hc, 1, ink_gain=1.2, ink_bias=-4.0, noise=0.4) if soft else n.conv_transpose2x2(x, hc, 1, ink_gain=2.0, ink_bias=-7.0, noise=0.01)
+    y = g.op("Sigmoid", [x])
+    g.nodes.append(node("Identity", [y], ["prob"]))
+    g.add_output("prob", ["N", 1, "H", "W"])
+    return g.model(), {"params": g.n_params, "size": size}
+
+
+# ch_svtrv2_rec.onnx is 84 196 641 bytes ~ 21.0 M f32 parameters (reference registry.rs:25); it is used with ppocr_keys_v1.txt (6623 lines ->
+# V = 6625).  SVTRv2-B as OpenOCR publishes it [NOT in the reference]: conv stem (two 3x3 stride-2 convolutions, GELU) to [n, 128, 12, W/4]; three
+# stages of six mixing blocks at dims 128 / 256 / 384 -- "Conv" blocks (5x5 grouped convolution, groups = heads, post-norm, MLP ratio 4) in stage 1 and
+# the first two blocks of stage 2, global self-attention blocks (heads 8 / 12, head dim 32) everywhere else -- with a 3x3 stride-(2,1) convolution +
+# LayerNorm between stages; mean over the 3 remaining rows -> [n, W/4, 384] -> Linear -> Softmax.  T = W/4: the pipeline reads T from the output.
+_SVTRV2_CFG = {
+    #            dims              depths     heads       mixers per stage (C = conv, G = global)
+    "svtrv2": ((128, 256, 384), (6, 6, 6), (4, 8, 12), ("CCCCCC", "CCGGGG", "GGGGGG")),
+    "svtrv2_small": ((32, 64, 96), (2, 3, 2), (2, 4, 6), ("CC", "CGG", "GG")),
+}
+
+
+def build_rec_svtrv2(size="svtrv2", vocab=6625, seed=1):
+    """SVTRv2-class CTC recognizer: in [n,3,48,W] (W % 4 == 0) -> out [n, W/4, vocab] softmax probabilities (see the comment above)."""
+    dims, depths, heads, mixers = _SVTRV2_CFG[size]
+    n = _Net(f"synth_rec_{size}", seed, decomposed_hswish=False)
+    g = n.g
+    i64 = np.int64
+    g.add_input("x", ["N", 3, 48, "W"])
+    x = n.conv("x", 3, dims[0] // 2, 3, 2, act="gelu")
+    x = n.conv(x, dims[0] // 2, dims[0], 3, 2, act="gelu")                      # [n, d0, 12, W/4]
+
+    def linear(t, cin, cout, gain=1.0):
+        w = n._w((cin, cout), cin, gain)
+        t = g.op("MatMul", [t, g.init(w)])
+        return g.op("Add", [t, g.init(n._b(cout), "b")])
+
+    def layernorm(t, c):
+        gamma = (1.0 + 0.1 * n.rng.standard_normal(c)).astype(np.float32)
+        beta = (0.05 * n.rng.standard_normal(c)).astype(np.float32)
+        return g.op("LayerNormalization", [t, g.init(gamma), g.init(beta)], axis=-1, epsilon=1e-6)
+
+    def to_tokens(m, c):      # [n, c, h, w] -> [n, h*w, c]
+        t = g.op("Reshape", [m, g.init(np.array([0, c, -1], i64), "shape")])
+        return g.op("Transpose", [t], perm=[0, 2, 1])
+
+    def to_map(t, c, h):      # [n, h*w, c] -> [n, c, h, w]
+        m = g.op("Transpose", [t], perm=[0, 2, 1])
+        return g.op("Reshape", [m, g.init(np.array([0, c, h, -1], i64), "shape")])
+
+    def mlp(t, c):
+        y = linear(t, c, 4 * c)
+        y = n.act(y, "gelu")
+        return linear(y, 4 * c, c, gain=0.5)
+
+    def conv_block(t, c, h, nh):
+        m = n.conv(to_map(t, c, h), c, c, 5, 1, groups=nh)
+        t = layernorm(g.op("Add", [t, to_tokens(m, c)]), c)
+        return layernorm(g.op("Add", [t, mlp(t, c)]), c)
+
+    def global_block(t, c, nh):
+        hd = c // nh
+        qkv = linear(t, c, 3 * c)
+        qkv = g.op("Reshape", [qkv, g.init(np.array([0, -1, 3, nh, hd], i64), "shape")])
+        qkv = g.op("Transpose", [qkv], perm=[2, 0, 3, 1, 4])
+        q, k, v = g.op("Split", [qkv], n_out=3, axis=0)
+        ax0 = g.init(np.array([0], i64), "axes")
+        q = g.op("Squeeze", [q, ax0])
+        k = g.op("Squeeze", [k, ax0])
+        v = g.op("Squeeze", [v, ax0])
+        q = g.op("Mul", [q, g.init(np.array(hd ** -0.5, np.float32), "scale")])
+        att = g.op("MatMul", [q, g.op("Transpose", [k], perm=[0, 1, 3, 2])])
+        att = g.op("Softmax", [att], axis=-1)
+        o = g.op("MatMul", [att, v])
+        o = g.op("Transpose", [o], perm=[0, 2, 1, 3])
+        o = g.op("Reshape", [o, g.init(np.array([0, -1, c], i64), "shape")])
+        o = linear(o, c, c, gain=0.5)
+        t = layernorm(g.op("Add", [t, o]), c)
+        return layernorm(g.op("Add", [t, mlp(t, c)]), c)
+
+    h = 12
+    t = to_tokens(x, dims[0])
+    for si in range(3):
+        c = dims[si]
+        for kind in mixers[si][:depths[si]]:
+            t = conv_block(t, c, h, heads[si]) if kind == "C" else global_block(t, c, heads[si])
+        if si < 2:   # sub-sampling: 3x3 convolution, stride (2, 1), then LayerNorm over the channels
+            m = n.conv(to_map(t, c, h), c, dims[si + 1], 3, (2, 1))
+            h //= 2
+            t = layernorm(to_tokens(m, dims[si + 1]), dims[si + 1])
+    c = dims[2]
+    m = to_map(t, c, h)                                                          # [n, c, 3, W/4]
+    m = g.op("ReduceMean", [m], axes=[2], keepdims=0)                            # [n, c, W/4]
+    z = g.op("Transpose", [m], perm=[0, 2, 1])                                   # [n, T, c]
+    logits = linear(z, c, vocab, gain=float(c) * 4.0)                             # spread logits: distinct argmax
     g.nodes.append(node("Softmax", [logits], ["probs"], axis=2))
     g.add_output("probs", ["N", "T", vocab])
     return g.model(), {"params": g.n_params, "size": size, "vocab": vocab}

@@ -312,6 +312,8 @@ def run(model, feeds: dict, want=None):
                 cm = bool(a.get("ceil_mode", 0))
                 if op == "AveragePool":
                     y = F.avg_pool2d(x[0], k, s, (pads[0], pads[1]), ceil_mode=cm, count_include_pad=bool(a.get("count_include_pad", 0)))
+                elif pads[0] != pads[2] or pads[1] != pads[3]:   # e.g. the "SAME" padding of a 2x2 / stride-1 pool: bottom / right only
+                    y = F.max_pool2d(F.pad(x[0], (pads[1], pads[3], pads[0], pads[2]), value=float("-inf")), k, s, 0, ceil_mode=cm)
                 else:
                     y = F.max_pool2d(x[0], k, s, (pads[0], pads[1]), ceil_mode=cm)
             elif op == "Resize":

@@ -1,0 +1,133 @@
+"""BASELINE C3 on graphs of the size and kind it names: the PP-HGNetV2 / LK-PAN detector (21.7 M parameters, dense 3x3 and
+9x9 convolutions) and the SVTRv2 recognizer (20.5 M parameters, grouped 5x5 mixing + global attention over 480 ... 2400 tokens) of
+oar_ocr_amd/synth/models.py, against the torch-CPU oracle; plus the two pieces the engine grew for them: the streaming bf16x6 attention kernel
+(csrc/attention_x6.hip) and the decomposed-GELU rewrite (engine.cc pass 2b).  Tolerance as in test_gpu_engine.py: 2e-4 (north_star allows 1e-3)."""
+import numpy as np
+import pytest
+
+from oar_ocr_amd import api
+from oar_ocr_amd.synth import models, pages
+from oar_ocr_amd.synth.onnx_writer import GraphBuilder
+from oracle import cpu_ref as R
+from oracle import onnx_ref, pipeline_ref
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+def _check(model_bytes, x, tol=TOL):
+    eng = api.OrtInfer(model_bytes)
+    got = eng.infer(x)
+    ref = onnx_ref.run(model_bytes, {eng.input_name(): x})
+    assert len(got) == len(ref)
+    for (name, g), r in zip(got, ref):
+        assert g.shape == r.shape, (name, g.shape, r.shape)
+        d = np.abs(g - r).max() if g.size else 0.0
+        scale = max(1.0, float(np.abs(r).max())) if r.size else 1.0
+        assert d <= tol * scale, (name, d, scale)
+    return got, ref
+
+
+def _attention_graph(dim, heads, seed, gain=1.0):
+    g = GraphBuilder("attn")
+    rng = np.random.default_rng(seed)
+    hd = dim // heads
+    g.add_input("x", ["N", "T", dim])
+    w = (gain * rng.standard_normal((dim, 3 * dim)) / np.sqrt(dim)).astype(np.float32)
+    qkv = g.op("MatMul", ["x", g.init(w)])
+    qkv = g.op("Add", [qkv, g.init((0.1 * rng.standard_normal(3 * dim)).astype(np.float32))])
+    qkv = g.op("Reshape", [qkv, g.init(np.array([0, -1, 3, heads, hd], np.int64), "shape")])
+    qkv = g.op("Transpose", [qkv], perm=[2, 0, 3, 1, 4])
+    q, k, v = g.op("Split", [qkv], n_out=3, axis=0)
+    ax0 = g.init(np.array([0], np.int64), "axes")
+    q, k, v = g.op("Squeeze", [q, ax0]), g.op("Squeeze", [k, ax0]), g.op("Squeeze", [v, ax0])
+    q = g.op("Mul", [q, g.init(np.array(hd ** -0.5, np.float32), "scale")])
+    att = g.op("Softmax", [g.op("MatMul", [q, g.op("Transpose", [k], perm=[0, 1, 3, 2])])], axis=-1)
+    o = g.op("Transpose", [g.op("MatMul", [att, v])], perm=[0, 2, 1, 3])
+    o = g.op("Reshape", [o, g.init(np.array([0, -1, dim], np.int64), "shape")])
+    g.add_output(o, ["N", "T", dim])
+    return g.model()
+
+
+@pytest.mark.parametrize("case", [
+    ("one block and a bit", 64, 2, 3, 33, 1.0),
+    ("one query tile", 64, 2, 2, 128, 1.0),
+    ("svtrv2 stage 2 at W = 320", 256, 8, 2, 480, 1.0),
+    ("svtrv2 stage 3, ragged tails", 384, 12, 1, 1001, 1.0),
+    ("wide crop, peaked soft-max", 64, 2, 1, 2400, 4.0),     # scores of +-40: the running maximum moves block after block
+])
+def test_streaming_attention_matches_oracle(case):
+    """head dim 32 -> attention_x6.hip (K and V of a head no longer have to fit LDS: T = 2400 is 600 KB of them)."""
+    name, dim, heads, n, T, gain = case
+    model = _attention_graph(dim, heads, seed=len(name), gain=gain)
+    x = np.random.default_rng(n + T).standard_normal((n, T, dim)).astype(np.float32)
+    api.prof_enable(True); api.prof_reset()
+    _check(model, x)
+    snap = {e["name"]: e["launches"] for e in api.prof_snapshot()}
+    api.prof_enable(False)
+    assert snap.get("attention_x6", 0) >= 1, snap
+
+
+@pytest.mark.parametrize("form", ["(x * (1 + erf)) * 0.5", "(x * 0.5) * (1 + erf)", "x * 0.70711 inside"])
+def test_decomposed_gelu_is_one_epilogue(form):
+    """Pass 2b: Div / Erf / Add / Mul / Mul behind a Linear -> the Linear's activation; same numbers as the op-by-op oracle."""
+    g = GraphBuilder("gelu")
+    rng = np.random.default_rng(len(form))
+    c = 64
+    g.add_input("x", ["N", "T", c])
+    f32 = np.float32
+    y = g.op("Add", [g.op("MatMul", ["x", g.init((rng.standard_normal((c, 2 * c)) / 8).astype(f32))]), g.init((0.1 * rng.standard_normal(2 * c)).astype(f32))])
+    pre = g.op("Mul", [y, g.init(np.array(0.70710678, f32))]) if "0.70711" in form else g.op("Div", [y, g.init(np.array(np.sqrt(2.0), f32))])
+    t = g.op("Add", [g.op("Erf", [pre]), g.init(np.array(1.0, f32))])
+    if form.startswith("(x * 0.5)"):
+        o = g.op("Mul", [g.op("Mul", [y, g.init(np.array(0.5, f32))]), t])
+    else:
+        o = g.op("Mul", [g.op("Mul", [y, t]), g.init(np.array(0.5, f32))])
+    o = g.op("Add", [g.op("MatMul", [o, g.init((rng.standard_normal((2 * c, c)) / 11).astype(f32))]), g.init((0.1 * rng.standard_normal(c)).astype(f32))])
+    g.add_output(o, ["N", "T", c])
+    m = g.model()
+    x = rng.standard_normal((2, 50, c)).astype(f32)
+    _check(m, x)
+    assert api.OrtInfer(m).cost((2, 50, c))[2] <= 3       # two Linears (+ output copy); seven launches op by op
+
+
+def test_hgnet_detector_graph_matches_oracle():
+    """The narrow twin of the C3 detector (same topology: 2x2 stem branch with bottom / right padding, MaxPool, HG blocks with 7-way concats,
+    light blocks, ESE gates, LK-PAN 9x9 convolutions, bottom-up path) on two page shapes."""
+    det, info = models.build_det("hgnet_small", seed=0)
+    for seed, hw in ((1, (160, 224)), (2, (96, 320))):
+        x, _ = R.det_preprocess(pages.make_page(seed, hw, lines=3))
+        (name, g), = _check(det, x[None])[0]
+        assert g.shape == (1, 1) + hw and g.min() >= 0.0 and g.max() <= 1.0
+    _check(det, np.random.default_rng(0).standard_normal((3, 3, 64, 96)).astype(np.float32))
+
+
+def test_svtrv2_recognizer_graph_matches_oracle():
+    """The narrow twin of the C3 recognizer: conv stem with GELU, grouped 5x5 mixing blocks, sub-sampling convolutions, global attention
+    (head dim 16: the LDS-resident kernel) -- at three widths, T = W / 4."""
+    rec, _ = models.build_rec("svtrv2_small", vocab=97, seed=1)
+    for ws in ((320, 200, 96), (640,)):
+        xr = R.rec_preprocess([pages.make_crop(i, w, 48) for i, w in enumerate(ws)])
+        (name, g), = _check(rec, xr)[0]
+        assert g.shape == (len(ws), xr.shape[3] // 4, 97)
+        ref = onnx_ref.run(rec, {"x": xr})[0]
+        assert np.array_equal(g.argmax(-1), ref.argmax(-1))
+
+
+def test_server_graphs_full_width_on_a_small_page():
+    """The 21.7 M / 20.5 M parameter graphs themselves (bench.py --config 2) through OAROCR::predict on one 320 x 480 page and on a page
+    with a 1000-pixel line (Wt = 1600 -> 2400 tokens in stage 2): boxes bit-exact, texts equal, scores within 1e-3 of the oracle."""
+    det, di = models.build_det("server_hgnet", seed=0)
+    rec, ri = models.build_rec("svtrv2", vocab=6625, seed=1)
+    assert 21.0e6 < di["params"] < 22.5e6 and 20.0e6 < ri["params"] < 21.5e6
+    chars = api.read_dict(models.synth_dict(6623))
+    imgs = [pages.make_page(0, (320, 480), lines=6), pages.make_page(3, (256, 1280), lines=4)]
+    cfg = api.TextDetectionConfig(score_threshold=0.3, box_threshold=0.6, unclip_ratio=1.5, limit_side_len=1280)
+    ocr = api.OAROCRBuilder(det, rec, chars).text_detection_config(cfg).image_batch_size(2).region_batch_size(8).build()
+    got = ocr.predict(imgs)
+    oracle = pipeline_ref.OracleOCR(det, rec, chars, thresh=0.3, box_thresh=0.6, unclip=1.5, region_batch_size=8, limit_side_len=1280)
+    ref = oracle.predict(imgs)
+    for g, r in zip(got, ref):
+        rep = pipeline_ref.compare_results(g, r)
+        assert rep["ok"] and rep["n_regions"][0] >= 3 and rep["text_equal"] >= rep["n_regions"][0] - 1, rep
+    ocr.close()

@@ -3,8 +3,12 @@ sys.path.insert(0,'.')
 import numpy as np
 from oar_ocr_amd import api
 from oar_ocr_amd.synth import models, pages
-SERVER = len(sys.argv) > 1 and sys.argv[1] == 'server'     # BASELINE C3: server-size det + SVTR rec (V = 18710), 1280^2 pages
-if SERVER:
+SERVER = len(sys.argv) > 1 and sys.argv[1] == 'server'     # round-1..5 stand-in for C3: widened LCNet det + SVTR-neck rec (V = 18710), 1280^2 pages
+C3 = len(sys.argv) > 1 and sys.argv[1] == 'c3'             # BASELINE C3 on the graphs it names: PP-HGNetV2 / LK-PAN detector + SVTRv2 recognizer
+if C3:
+    det,_=models.build_det('server_hgnet', seed=0); rec,_=models.build_rec('svtrv2', vocab=6625, seed=1)
+    chars=api.read_dict(models.synth_dict(6623)); S=1280; NP=int(sys.argv[2]) if len(sys.argv) > 2 else 16
+elif SERVER:
     det,_=models.build_det('server', seed=0); rec,_=models.build_rec('server', vocab=18710, seed=1)
     chars=api.read_dict(models.synth_dict(18708)); S=1280; NP=16
 else:
