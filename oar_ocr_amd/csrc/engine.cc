@@ -1482,8 +1482,29 @@ struct Planner {
         p.N = (int)N; p.H = (int)H; p.W = (int)Wd; p.Cin = (int)Cin; p.Ho = (int)Ho; p.Wo = (int)Wo; p.Cout = (int)Cout;
         p.kh = (int)kh; p.kw = (int)kw; p.sh = (int)sh; p.sw = (int)sw; p.pt = (int)pt; p.pl = (int)pl; p.dh = (int)dh; p.dw = (int)dw;
         p.groups = (int)g; p.act = n.act; p.bias = bias; p.y_ld = (int)Cout; p.convt2x2 = 0; p.res_up = res_up;
-        int kind;  // 0 igemm, 1 dw, 2 direct
-        if (g == 1 && Cin % 4 == 0) {
+        int kind;  // 0 igemm, 1 dw, 2 direct, 3 grouped igemm
+        // a grouped k x k convolution with wide groups (SVTRv2's local mixing: 5x5, 32 channels per group) is one implicit GEMM per group on the
+        // output-stationary bf16x6 kernel, which reads its Cin / g channels out of the full tensor (ConvP::x_ld) and writes its Cout / g channels
+        // into the full output (y_ld); the direct kernel it ran on before took 5.3 ms per layer (6.7 TFLOP/s).  OAR_GROUPED_X6=0 restores that
+        const int64_t cg = Cin / g, og = Cout / g;
+        const char* gx_env = getenv("OAR_GROUPED_X6");
+        const bool grouped_x6 = g > 1 && g < Cin && cg % 8 == 0 && og % 4 == 0 && !(n.in.size() > 3 && !n.in[3].empty()) && res_up == 0 && !(gx_env && gx_env[0] == '0') &&
+                                k::conv_grouped_x6_ok((long)(N * Ho * Wo), (int)(kh * kw * cg), (int)og, (int)cg);
+        std::vector<const float*> wgrp;
+        if (grouped_x6) {
+            kind = 3;
+            p.w_fmt = k::IGEMM_W_X6;
+            const size_t per = (size_t)(og * cg * kh * kw);
+            for (int64_t gi = 0; gi < g; ++gi) {
+                HostTensor Wg;
+                Wg.dtype = DType::F32; Wg.dims = {og, cg, kh, kw};
+                Wg.f.assign(W.f.begin() + (ptrdiff_t)(gi * per), W.f.begin() + (ptrdiff_t)((gi + 1) * per));
+                GNode gn = n;
+                gn.in[1] = n.in[1] + "::group" + std::to_string(gi);
+                wgrp.push_back(conv_weight_igemm(gn, Wg, k::IGEMM_W_X6));
+            }
+        }
+        else if (g == 1 && Cin % 4 == 0) {
             kind = 0;
             const bool is1x1 = kh == 1 && kw == 1 && sh == 1 && sw == 1 && pt == 0 && pl == 0;
             const bool same3x3 = kh == 3 && kw == 3 && sh == 1 && sw == 1 && pt == 1 && pl == 1 && dh == 1 && dw == 1 && Ho == H && Wo == Wd && n.residual.empty();
@@ -1531,6 +1552,18 @@ struct Planner {
         auto run = [=](const RunCtx& c) {
             k::ConvP q = p;
             q.x = c.at(xin); q.y = c.mut(yl); q.residual = has_res ? c.at(res) : nullptr; q.se = has_gate ? c.at(gate) : nullptr;
+            if (kind == 3) {
+                const int ng = p.groups, cgi = p.Cin / ng, ogi = p.Cout / ng;
+                for (int gi = 0; gi < ng; ++gi) {
+                    k::ConvP r = q;
+                    r.groups = 1; r.Cin = cgi; r.Cout = ogi; r.x_ld = p.Cin;
+                    r.x = q.x + (size_t)gi * cgi; r.y = q.y + (size_t)gi * ogi; r.w = wgrp[(size_t)gi];
+                    r.bias = q.bias ? q.bias + (size_t)gi * ogi : nullptr;
+                    r.residual = q.residual ? q.residual + (size_t)gi * ogi : nullptr;
+                    k::conv_igemm(c.s, r);
+                }
+                return;
+            }
             if (kind == 0) k::conv_igemm(c.s, q);
             else if (kind == 1) k::conv_dw(c.s, q);
             else k::conv_direct(c.s, q);
@@ -2559,6 +2592,9 @@ struct Planner {
             int r = (int)x.dims.size();
             int64_t sp = 1;
             for (int i = 2; i < r; ++i) sp *= x.dims[i];
+            // [n, C, spatial...] -> [n, C, other spatial grouping] (SVTRv2's map <-> token moves: Reshape [n,C,H,W] -> [n,C,H*W] in front of a
+            // Transpose to [n,H*W,C], and back): channels-last keeps the spatial positions in row-major order whatever their grouping -- a view
+            if (od.size() >= 3 && od[0] == x.dims[0] && od[1] == x.dims[1] && !x.ht) { alias_out(n.out[0], x, od, Layout::CLAST); return; }
             if (x.dims[1] != 1 && sp != 1) {  // genuine transpose needed
                 TInfo& y = new_out(n.out[0], od, Layout::NATIVE);
                 to_native_loc(x, y.loc);
@@ -2795,7 +2831,7 @@ struct Planner {
             // (a CTC head with a short K runs on the output-stationary bf16x6 kernel, ctc_head_x6.hip: bf16x6 fragments whatever igemm_weight_format says)
             const bool ctc_head = P.logits_valid > 0 && od.back() == Np && n.act.kind == k::ACT_NONE && !has_res && k::ctc_head_x6_supported((long)M, (int)K, (int)Np) &&
                                   k::ctc_partials_supported_x6((int)K) && [] { const char* e = getenv("OAR_CTC_PARTIALS"); return !e || atoi(e) != 0; }();
-            const int fmt = has_res ? 0 : ctc_head ? k::IGEMM_W_X6 : k::igemm_weight_format((long)M, (int)K, (int)Np, true);
+            const int fmt = ctc_head ? k::IGEMM_W_X6 : k::igemm_weight_format((long)M, (int)K, (int)Np, true);
             const float* w = linear_weight(n.in[1], *bt.ht, transB, fmt);
             k::ConvP p{};
             p.w_fmt = fmt;

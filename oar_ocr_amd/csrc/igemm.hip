@@ -230,12 +230,14 @@ bool ctc_partials_supported_x6(int K) { return K % 8 == 0 && K >= 32 && (size_t)
 static int os_mode() { static const int m = [] { const char* e = getenv("OAR_IGEMM_OS"); return e ? atoi(e) : 1; }(); return m; }
 // layers the output-stationary x6 kernel takes: every lane's 8-float group inside one tap and all-valid or all-padding
 // (Cin % 8), wide and long enough to be matrix-pipe work, enough 256-pixel tiles to fill the chip, float4 epilogue
-static bool os_x6_eligible(long M, int K, int N, int Cin) {
+static bool os_x6_eligible(long M, int K, int N, int Cin, bool grouped = false) {
     static const int min_k = [] { const char* e = getenv("OAR_IGEMM_OS_MINK"); return e ? atoi(e) : 256; }();
     // enough (256-pixel, 128-cout) tiles for the 512 workgroup slots of the chip: many pixels, or fewer pixels under a wide layer
     const bool fills = M >= 65536 || (M >= 8192 && ((M + 255) / 256) * ((N + 127) / 128) >= 256);
-    return Cin % 8 == 0 && K >= min_k && N >= 64 && (N & 3) == 0 && fills && K < 65536;
+    return Cin % 8 == 0 && K >= min_k && N >= (grouped ? 32 : 64) && (N & 3) == 0 && fills && K < 65536;
 }
+
+bool conv_grouped_x6_ok(long M, int K, int N, int Cin) { return os_mode() != 0 && os_x6_eligible(M, K, N, Cin, true); }
 
 int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin, long same3x3_px) {
     // OAR_IGEMM_X6: 1 (default) = bf16x6 kernels on the wide layers, 0 = f32 MFMA everywhere
@@ -296,6 +298,7 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     p.convt = c.convt2x2; p.Cout = c.Cout;
     p.ctc_part = c.ctc_part; p.ctc_valid = c.ctc_valid;
     p.se = c.se; p.se_hw = c.Ho * c.Wo;
+    p.x_ld = c.x_ld > 0 ? c.x_ld : c.Cin;
     p.res_up = c.residual ? c.res_up : 0;
     if (c.convt2x2) {
         p.Ho = c.H; p.Wo = c.W;  // GEMM columns are INPUT pixels
@@ -305,6 +308,7 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
         p.M = (long)c.N * c.Ho * c.Wo; p.K = c.kh * c.kw * c.Cin; p.gemm_cout = c.Cout;
     }
     const bool x6 = c.w_fmt == IGEMM_W_X6;
+    const bool grouped = p.x_ld != c.Cin;   // one group of a grouped convolution: output-stationary bf16x6 kernel only (the one that reads x with x_ld)
     p.KC = x6 ? (p.K + 31) / 32 : (p.K + 15) / 16;
     if (p.M == 0) return;
     const bool is1x1 = c.convt2x2 || (c.kh == 1 && c.kw == 1 && c.sh == 1 && c.sw == 1 && c.pt == 0 && c.pl == 0);
@@ -390,6 +394,7 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     const bool rs3 = x6 && same3x3 && !c.residual && !c.se && !c.ctc_part && conv3x3_n16_x6_eligible(p.M, c.Cin, c.Cout, (long)c.H * c.W, c.y_ld);
     // a layer whose weights were laid out for the row-streaming 3x3 kernel (Cout <= 16: no other bf16x6 kernel takes it) must reach that kernel
     OAR_CHECK(!(x6 && same3x3 && c.Cout <= 16) || rs3, OAR_INTERNAL, "conv_igemm: 3x3 / Cout <= 16 bf16x6 weights but the row-streaming kernel's launch-time conditions do not hold (y_ld / output size / residual / gate changed after planning)");
+    OAR_CHECK(!grouped || (x6 && !is1x1 && !c.ctc_part && !c.se && !c.convt2x2 && !(x6 && same3x3 && c.Cout <= 16)), OAR_INTERNAL, "conv_igemm: x_ld on a layer that does not run on the output-stationary bf16x6 kernel");
     if (ws3) {
         conv_igemm_ws3(s, p, nfrag);
     } else if (rs3) {
@@ -400,7 +405,7 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
         const bool os = !c.ctc_part && (nt == 0 || (os_mode() == 2 && os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin)));
         OAR_CHECK(!c.se || (!os && !c.ctc_part && is1x1), OAR_INTERNAL, "conv_igemm: gate on a layer the weight-stationary x6 kernel does not take");
         if (os) {
-            OAR_CHECK(os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin), OAR_INTERNAL, "conv_igemm: bf16x6 weights on a layer neither x6 kernel takes");
+            OAR_CHECK(os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin, grouped), OAR_INTERNAL, "conv_igemm: bf16x6 weights on a layer neither x6 kernel takes");
             conv_igemm_os_x6(s, p, nfrag, is1x1);
         } else {
             conv_igemm_ws_x6(s, p, nt, (nfrag + nt - 1) / nt, (size_t)nt * p.KC * 3072 + (size_t)nt * 64 + 16);

@@ -50,6 +50,8 @@ struct IgemmP {
     int res_up;          // > 1 (per-tile f32 kernels only): res is the low-resolution operand of an FPN sum, read at (h / res_up, w / res_up)
     const float* se;     // != null (bf16x6 weight-stationary kernel only): gate [image][K] multiplied into x on load
     int se_hw;           // pixels per image (se row of pixel m = m / se_hw)
+    int x_ld;            // output-stationary bf16x6 kernel only: floats between two pixels of x (>= Cin; > Cin for one group of a grouped convolution,
+                         // whose x points at the group's first channel).  Every other kernel reads x with stride Cin
 };
 
 // element offset of the residual for output pixel `opix`, channel co: the same pixel, or -- res_up > 1 -- pixel (h / f, w / f) of the

@@ -80,12 +80,12 @@ __global__ __launch_bounds__(kOsThreads, 2) void conv_igemm_os_x6_kernel(IgemmOs
 #pragma clang loop unroll(full)
     for (int pf = 0; pf < PF; ++pf) {
         const long m = min(m0 + pf * 16 + pl_, p.M - 1);   // clamped rows compute garbage that is never stored
-        if (IS1X1) { pix_base[pf] = m * (long)p.Cin; ih0[pf] = 0; iw0[pf] = 0; }
+        if (IS1X1) { pix_base[pf] = m * (long)p.x_ld; ih0[pf] = 0; iw0[pf] = 0; }
         else {
             const long hw = (long)p.Ho * p.Wo;
             const long n = m / hw, r = m - n * hw;
             const int oh = (int)(r / p.Wo), ow = (int)(r - (long)oh * p.Wo);
-            pix_base[pf] = n * (long)p.H * p.W * p.Cin;
+            pix_base[pf] = n * (long)p.H * p.W * p.x_ld;
             ih0[pf] = oh * p.sh - p.pt; iw0[pf] = ow * p.sw - p.pl;
         }
     }
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kOsThreads, 2) void conv_igemm_os_x6_kernel(IgemmOs
                 const int ih = ih0[pf] + tap_h * p.dh, iw = iw0[pf] + tap_w * p.dw;
                 const bool ok = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
                 const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
-                src = p.x + pix_base[pf] + ((long)ihc * p.W + iwc) * p.Cin + ci;
+                src = p.x + pix_base[pf] + ((long)ihc * p.W + iwc) * p.x_ld + ci;
                 st.okmask |= (ok ? 1u : 0u) << pf;
             }
             issue(st.a[pf], src); issue(st.b[pf], src + 4);
@@ -233,16 +233,19 @@ static void launch_os_x6(hipStream_t s, const IgemmP& p, int nfrag, int nfrag_al
     else hipLaunchKernelGGL((conv_igemm_os_x6_kernel<BNF, false>), grid, dim3(kOsThreads), lds, s, q);
 }
 
-// cout fragments per workgroup tile: the one with less padded (wasted) MFMA work, 8 on ties
+// cout fragments per workgroup tile: the one with less padded (wasted) MFMA work, 8 on ties; 2 for the 32-channel groups of a grouped convolution
 int igemm_os_x6_tile(int nfrag) {
+    if (nfrag <= 2) return 2;
     const int p8 = (nfrag + 7) / 8 * 8, p4 = (nfrag + 3) / 4 * 4;
     return p4 < p8 ? 4 : 8;
 }
 
 void conv_igemm_os_x6(hipStream_t s, const IgemmP& p, int nfrag, bool is1x1) {
     const int nfrag_alloc = (p.gemm_cout + 63) / 64 * 4;
-    if (igemm_os_x6_tile(nfrag) == 8) launch_os_x6<8>(s, p, nfrag, nfrag_alloc, is1x1);
-    else launch_os_x6<4>(s, p, nfrag, nfrag_alloc, is1x1);
+    const int tile = igemm_os_x6_tile(nfrag);
+    if (tile == 8) launch_os_x6<8>(s, p, nfrag, nfrag_alloc, is1x1);
+    else if (tile == 4) launch_os_x6<4>(s, p, nfrag, nfrag_alloc, is1x1);
+    else launch_os_x6<2>(s, p, nfrag, nfrag_alloc, is1x1);
 }
 
 }  // namespace k
