@@ -54,11 +54,15 @@ def parse_args(argv=None):
     ap.add_argument("--no-pipelined", action="store_true", help="skip the third timing (two calls in flight through oar_ocr_predict_async)")
     ap.add_argument("--config", type=int, default=1, choices=(1, 2, 3, 4),
                     help="BASELINE.json configs index: 1 = v6-tiny det+rec on 32 x 960^2 pages per GPU (the metric's configuration, default); "
-                         "2 = server-size det + SVTR rec (V=18710) on 64 x 1280^2 pages; 3 = v6-tiny, 1024 pages block-partitioned over the ranks; "
+                         "2 = PP-OCRv5-server-class detector (PP-HGNetV2 / LK-PAN, 21.7 M parameters) + SVTRv2-class recognizer (20.5 M, V = 6625) on 64 x 1280^2 pages, "
+                         "detector at 1280 (limit_side_len = 1280); 3 = v6-tiny, 1024 pages block-partitioned over the ranks; "
                          "4 = full pipeline (doc orientation + UVDoc + det + rec + text-line orientation) on 16 x 960^2 pages")
     ap.add_argument("--det-params", choices=("class", "real-size"), default="class",
                     help="config 1 / 3 detector: 'class' = the round-1 v6-tiny-class graph (0.288 M parameters); 'real-size' = the same topology widened to the "
                          "0.445 M parameters of the file it stands for (registry.rs:83).  The default line times 'class' and reports 'real-size' beside it")
+    ap.add_argument("--c3-graphs", choices=("named", "standin"), default="named",
+                    help="config 2: 'named' = graphs of the size and kind BASELINE C3 names (synth/models.py build_det_hgnet / build_rec_svtrv2); 'standin' = the "
+                         "widened LCNet detector (4.3 M) + SVTR-neck recognizer (7.3 M, V = 18710) rounds 1-5 ran config 2 on, detector input at the default 960")
     ap.add_argument("--no-real-size", action="store_true", help="skip the extra timing of the real-size detector (config 1, one GPU)")
     ap.add_argument("--stub-engine", action="store_true", help=argparse.SUPPRESS)   # tests/test_bench_cpu.py: control flow without a GPU
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py starts its own ranks (0 = pick a free one)")
@@ -175,6 +179,10 @@ def main():
     # ---- workload
     size_name, vocab = ("server", 18710) if args.config == 2 else ("tiny", 6906)
     det_name = "tiny_full" if (size_name == "tiny" and args.det_params == "real-size") else size_name
+    rec_name = size_name
+    c3_named = args.config == 2 and args.c3_graphs == "named"
+    if c3_named:   # ch_svtrv2_rec.onnx is used with ppocr_keys_v1.txt: 6623 lines -> V = 6625
+        det_name, rec_name, vocab = "server_hgnet", "svtrv2", 6625
     size = args.size or (1280 if args.config == 2 else 960)
     if args.config == 3:      # BASELINE configs[3]: 1024 pages over the ranks (block partition, 128 per GPU at N = 8)
         total_pages = args.pages or 1024
@@ -190,9 +198,11 @@ def main():
         eng, det_info, rec_info = StubEngine(rank), {"params": 0}, {"params": 0}
     else:
         det, det_info = models.build_det(det_name, seed=0)
-        rec, rec_info = models.build_rec(size_name, vocab=vocab, seed=1)
+        rec, rec_info = models.build_rec(rec_name, vocab=vocab, seed=1)
         chars = api.read_dict(models.synth_dict(vocab - 2))
         cfg = api.TextDetectionConfig(score_threshold=0.3, box_threshold=0.6, unclip_ratio=1.5)   # examples/ocr.rs:119-133 set
+        if c3_named:   # "batch=64 1280x1280": the default limit (960 / Max, src/oarocr/ocr.rs:351-363) would Triangle-downscale the pages to 960^2 first
+            cfg = api.TextDetectionConfig(score_threshold=0.3, box_threshold=0.6, unclip_ratio=1.5, limit_side_len=size)
         builder = (api.OAROCRBuilder(det, rec, chars).text_detection_config(cfg).image_batch_size(image_batch)
                    .region_batch_size(args.region_batch).device(dev))
         if world > 1:
@@ -480,7 +490,7 @@ def main():
             def run_workers(W, Tn, pages_each):
                 env = dict(os.environ, OMP_NUM_THREADS=str(Tn), MKL_NUM_THREADS=str(Tn))
                 procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_baseline_worker", "--threads", str(Tn), "--pages", str(pages_each), "--seed0", str(1000 + 17 * w),
-                                           "--size", str(size), "--lines", str(args.lines), "--config", str(cfg_id)], cwd=str(ROOT), env=env,
+                                           "--size", str(size), "--lines", str(args.lines), "--config", str(cfg_id), "--c3-graphs", args.c3_graphs], cwd=str(ROOT), env=env,
                                           stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for w in range(W)]
                 try:
                     for q in procs:
@@ -529,7 +539,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(tmax / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"baseline_config": args.config,
-                       "workload": f"{'PP-OCRv5-server-class det + SVTR rec' if args.config == 2 else 'PP-OCRv6-tiny-class det+rec'}"
+                       "workload": f"{('PP-OCRv5-server-class det (PP-HGNetV2 + LK-PAN, input 1280) + SVTRv2-class rec' if c3_named else 'server-size LCNet det + SVTR-neck rec (rounds 1-5 stand-in, detector input 960)') if args.config == 2 else 'PP-OCRv6-tiny-class det+rec'}"
                                    f"{' + doc orientation + UVDoc + text-line orientation' if args.config == 4 else ''} "
                                    f"(synthetic-weight graphs: det {det_info['params']} params, rec {rec_info['params']} params, V={vocab}), "
                                    + (f"{total_pages} synthetic {size}x{size} pages block-partitioned over {world} GPU(s)" if args.config == 3 else

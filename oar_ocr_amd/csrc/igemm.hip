@@ -233,7 +233,10 @@ static int os_mode() { static const int m = [] { const char* e = getenv("OAR_IGE
 static bool os_x6_eligible(long M, int K, int N, int Cin, bool grouped = false) {
     static const int min_k = [] { const char* e = getenv("OAR_IGEMM_OS_MINK"); return e ? atoi(e) : 256; }();
     // enough (256-pixel, 128-cout) tiles for the 512 workgroup slots of the chip: many pixels, or fewer pixels under a wide layer
-    const bool fills = M >= 65536 || (M >= 8192 && ((M + 255) / 256) * ((N + 127) / 128) >= 256);
+    // (round 6: a group of a grouped convolution has no other matrix-pipe kernel -- any launch of >= 4096 pixels beats the direct kernel; a very long K
+    // (the 9x9 LK-PAN convolutions, K = 20736) pays for half-filled CUs as well: 72 -> ~110 TFLOP/s at 200 tiles)
+    const long tiles = ((M + 255) / 256) * ((N + 127) / 128);
+    const bool fills = M >= 65536 || (M >= 8192 && tiles >= 256) || (grouped && M >= 4096) || (K >= 2048 && M >= 8192 && tiles >= 128);
     return Cin % 8 == 0 && K >= min_k && N >= (grouped ? 32 : 64) && (N & 3) == 0 && fills && K < 65536;
 }
 

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--lines", type=int, default=40)
     ap.add_argument("--config", type=int, default=1)
     ap.add_argument("--fast", type=int, default=1)
+    ap.add_argument("--c3-graphs", default="named", help="config 2: 'named' = PP-HGNetV2 / LK-PAN detector + SVTRv2 recognizer (V = 6625), 'standin' = the rounds 1-5 graphs")
     a = ap.parse_args()
     os.environ["OMP_NUM_THREADS"] = str(a.threads)
     import torch
@@ -55,12 +56,15 @@ def main():
     for n in ("det_preprocess", "db_postprocess", "rotate_crop", "rec_preprocess", "argmax_rows", "ctc_decode"):
         wrap(R, n)
     size_name, vocab = ("server", 18710) if a.config == 2 else ("tiny", 6906)
-    det, _ = models.build_det(size_name, seed=0)
-    rec, _ = models.build_rec(size_name, vocab=vocab, seed=1)
+    det_name = rec_name = size_name
+    if a.config == 2 and a.c3_graphs == "named":
+        det_name, rec_name, vocab = "server_hgnet", "svtrv2", 6625
+    det, _ = models.build_det(det_name, seed=0)
+    rec, _ = models.build_rec(rec_name, vocab=vocab, seed=1)
     chars = api.read_dict(models.synth_dict(vocab - 2))
     stages = dict(doc_orientation=models.build_cls(4, seed=5)[0], rectifier=models.build_uvdoc(seed=6)[0],
                   line_orientation=models.build_cls(2, seed=9)[0]) if a.config == 4 else {}
-    kw = dict(limit_side_len=a.size) if a.config == 2 else {}
+    kw = dict(limit_side_len=a.size) if (a.config == 2 and a.c3_graphs == "named") else {}
     oc = pipeline_ref.OracleOCR(det, rec, chars, 0.3, 0.6, 1.5, image_batch_size=1, region_batch_size=16, threads=a.threads, **stages, **kw)
     # network time by graph: the detector's and the recognizer's interpreter runs are told apart by their model dict
     run = onnx_ref.run

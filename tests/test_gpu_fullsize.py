@@ -120,6 +120,24 @@ def test_c3_server_graphs_on_1280x1280_pages():
     ocr.close()
 
 
+def test_c3_named_graphs_on_1280x1280_pages():
+    """BASELINE C3 on graphs of the size and kind it names (VERDICT r5 next #1a): PP-HGNetV2 / LK-PAN detector (21.7 M parameters) at 1280 x 1280
+    (limit_side_len = 1280, src/oarocr/ocr.rs:351-363) + SVTRv2 recognizer (20.5 M, V = 6625), 64 pages in ONE predict; five pages against the oracle
+    (boxes bit-exact, texts, scores <= 1e-3)."""
+    det, di = models.build_det("server_hgnet", seed=0)
+    rec, ri = models.build_rec("svtrv2", vocab=6625, seed=1)
+    assert di["params"] > 21e6 and ri["params"] > 20e6
+    chars = api.read_dict(models.synth_dict(6623))
+    imgs = [pages.make_page(100 + i, (1280, 1280), 40) for i in range(64)]
+    cfg = api.TextDetectionConfig(score_threshold=0.3, box_threshold=0.6, unclip_ratio=1.5, limit_side_len=1280)
+    ocr = api.OAROCRBuilder(det, rec, chars).text_detection_config(cfg).image_batch_size(64).region_batch_size(256).build()
+    got = ocr.predict(imgs)
+    assert len(got) == 64 and sum(len(g.text_regions) for g in got) > 1500
+    n, ties = _check_pages_against_oracle(got, imgs, [0, 17, 30, 46, 63], det, rec, chars, dict(limit_side_len=1280), (0.3, 0.6, 1.5))
+    assert n > 60 and ties <= 2
+    ocr.close()
+
+
 def test_c4_rank_0_of_8_shard_of_the_1024_page_list():
     """BASELINE C4 (1024 pages image-parallel over 8 GPUs) as ONE rank sees it: oar_shard_range(1024, 8, 0) = pages [0, 128), image_batch_size 32,
     a 2-thread geometry pool (the rank's share of the host), ONE predict over the whole shard, the result leaving as oar_ocr_pack's blob and meeting the
