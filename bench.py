@@ -57,9 +57,10 @@ def parse_args(argv=None):
                          "2 = PP-OCRv5-server-class detector (PP-HGNetV2 / LK-PAN, 21.7 M parameters) + SVTRv2-class recognizer (20.5 M, V = 6625) on 64 x 1280^2 pages, "
                          "detector at 1280 (limit_side_len = 1280); 3 = v6-tiny, 1024 pages block-partitioned over the ranks; "
                          "4 = full pipeline (doc orientation + UVDoc + det + rec + text-line orientation) on 16 x 960^2 pages")
-    ap.add_argument("--det-params", choices=("class", "real-size"), default="class",
-                    help="config 1 / 3 detector: 'class' = the round-1 v6-tiny-class graph (0.288 M parameters); 'real-size' = the same topology widened to the "
-                         "0.445 M parameters of the file it stands for (registry.rs:83).  The default line times 'class' and reports 'real-size' beside it")
+    ap.add_argument("--det-params", choices=("class", "real-size"), default="real-size",
+                    help="config 1 / 3 / 4 graphs: 'real-size' (default since round 6) = detector and recognizer at the parameter counts of the files they stand for "
+                         "(pp-ocrv6_tiny_det.onnx 0.445 M, pp-ocrv6_tiny_rec.onnx 1.116 M: registry.rs:83-84 -> synth 'tiny_full': 0.447 M / 1.103 M); 'class' = the lighter "
+                         "graphs of rounds 1-5 (0.288 M / 0.914 M).  The default line times 'real-size' and reports 'class' beside it")
     ap.add_argument("--c3-graphs", choices=("named", "standin"), default="named",
                     help="config 2: 'named' = graphs of the size and kind BASELINE C3 names (synth/models.py build_det_hgnet / build_rec_svtrv2); 'standin' = the "
                          "widened LCNet detector (4.3 M) + SVTR-neck recognizer (7.3 M, V = 18710) rounds 1-5 ran config 2 on, detector input at the default 960")
@@ -179,7 +180,7 @@ def main():
     # ---- workload
     size_name, vocab = ("server", 18710) if args.config == 2 else ("tiny", 6906)
     det_name = "tiny_full" if (size_name == "tiny" and args.det_params == "real-size") else size_name
-    rec_name = size_name
+    rec_name = det_name if size_name == "tiny" else size_name
     c3_named = args.config == 2 and args.c3_graphs == "named"
     if c3_named:   # ch_svtrv2_rec.onnx is used with ppocr_keys_v1.txt: 6623 lines -> V = 6625
         det_name, rec_name, vocab = "server_hgnet", "svtrv2", 6625
@@ -424,11 +425,13 @@ def main():
                              "OAROCR::predict (crops pooled over its own pages), two are in flight"}
         ocr2.close()
 
-    # -- fourth figure (config 1, one GPU): the same step with the detector at the parameter count of the file it stands for (VERDICT r4 #7b)
+    # -- fourth figure (config 1, one GPU): the same step on the lighter graphs rounds 1-5 quoted their headline on (the file sizes
+    # pin 0.445 M / 1.116 M parameters; since round 6 the headline runs graphs of that size and the lighter ones are the side figure)
     real_size = None
-    if not stub and world == 1 and args.config == 1 and det_name == "tiny" and not args.no_real_size:
-        det_full, det_full_info = models.build_det("tiny_full", seed=0)
-        ocr3 = (api.OAROCRBuilder(det_full, rec, chars).text_detection_config(cfg).image_batch_size(image_batch).region_batch_size(args.region_batch).device(dev)).build()
+    if not stub and world == 1 and args.config == 1 and det_name == "tiny_full" and not args.no_real_size:
+        det_cls, det_cls_info = models.build_det("tiny", seed=0)
+        rec_cls, rec_cls_info = models.build_rec("tiny", vocab=vocab, seed=1)
+        ocr3 = (api.OAROCRBuilder(det_cls, rec_cls, chars).text_detection_config(cfg).image_batch_size(image_batch).region_batch_size(args.region_batch).device(dev)).build()
         for _ in range(max(2, args.warmup)):
             r3 = ocr3.predict_packed(h_ptrs, h_ws, h_hs, n_pages)
         torch.cuda.synchronize()
@@ -438,9 +441,9 @@ def main():
         torch.cuda.synchronize()
         qdt = time.perf_counter() - q0
         real_size = {"value": round(n_pages * args.steps / qdt, 2), "unit": "images/sec", "ms_per_step": round(qdt / args.steps * 1e3, 3),
-                     "det_params": det_full_info["params"], "regions_per_step": len(r3.scores),
-                     "what": "the headline step (same pages, same recognizer, same entry point) with the detector widened to the 0.445 M parameters of "
-                             "pp-ocrv6_tiny_det.onnx (registry.rs:83): synth models.build_det('tiny_full'); `value` above is the 0.288 M-parameter graph of rounds 1-4"}
+                     "det_params": det_cls_info["params"], "rec_params": rec_cls_info["params"], "regions_per_step": len(r3.scores),
+                     "what": "the same step (same pages, same entry point) on the LIGHTER graphs rounds 1-5 quoted as their headline: synth models.build_det('tiny') 0.288 M + "
+                             "build_rec('tiny') 0.914 M parameters.  `value` above is on graphs of the size of the files it names (0.447 M / 1.103 M)"}
         ocr3.close()
 
     # -- fifth figure: the recognizer's batches alternating over two streams (OAR_REC_LANES=2: a second engine instance, same weights).  The
@@ -549,7 +552,7 @@ def main():
                        "pages_per_gpu_per_step": n_pages, "image_batch_size": image_batch, "region_batch_size": args.region_batch,
                        "regions_per_step": gathered["regions"], "text_bytes_per_step": gathered["bytes"], "pages_gathered_per_step": gathered["pages"],
                        "parallelism": f"image-parallel x{world}", "host_cores_per_rank": cores, "host_cpu_ms_per_step": round(host_cpu_ms, 2)},
-            "roofline": roof, "cpu_baseline": cpu, "device_resident": dev_res, "pipelined": pipelined, "det_real_size": real_size, "rec_two_streams": rec_two, "conv_mfma_util": mfma_util, "kernel_ms_per_step_untimed_pass": breakdown, "predict_passes_total": passes["n"], "csrc_fingerprint": csrc_now,
+            "roofline": roof, "cpu_baseline": cpu, "device_resident": dev_res, "pipelined": pipelined, "lighter_graphs_r1_r5": real_size, "rec_two_streams": rec_two, "conv_mfma_util": mfma_util, "kernel_ms_per_step_untimed_pass": breakdown, "predict_passes_total": passes["n"], "csrc_fingerprint": csrc_now,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

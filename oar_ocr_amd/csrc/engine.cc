@@ -1491,6 +1491,7 @@ struct Planner {
         const bool grouped_x6 = g > 1 && g < Cin && cg % 8 == 0 && og % 4 == 0 && !(n.in.size() > 3 && !n.in[3].empty()) && res_up == 0 && !(gx_env && gx_env[0] == '0') &&
                                 k::conv_grouped_x6_ok((long)(N * Ho * Wo), (int)(kh * kw * cg), (int)og, (int)cg);
         std::vector<const float*> wgrp;
+        std::vector<int> slices3;
         if (grouped_x6) {
             kind = 3;
             p.w_fmt = k::IGEMM_W_X6;
@@ -1502,6 +1503,26 @@ struct Planner {
                 GNode gn = n;
                 gn.in[1] = n.in[1] + "::group" + std::to_string(gi);
                 wgrp.push_back(conv_weight_igemm(gn, Wg, k::IGEMM_W_X6));
+            }
+        }
+        else if (g == 1 && Cout <= 16 && Cin > 64 && kh == 3 && kw == 3 && sh == 1 && sw == 1 && pt == 1 && pl == 1 && dh == 1 && dw == 1 && Ho == H && Wo == Wd && n.residual.empty() &&
+                 !(n.in.size() > 3 && !n.in[3].empty()) && !(slices3 = k::conv3x3_n16_slices((long)(N * Ho * Wo), (int)Cin, (int)Cout, (long)(H * Wd), (int)(4 * Cout))).empty()) {
+            // the row-streaming bf16x6 kernel keeps a slice's weights in registers: 96 ... 256 input channels run as passes over 64- / 32-channel slices, every pass
+            // after the first adding to the partial sums in y (the 0.445 M-parameter detector's neck: 96 -> 16 at quarter resolution ran on the f32 kernel, 201 us per 8 pages)
+            kind = 4;
+            p.w_fmt = k::IGEMM_W_X6;
+            int64_t c0 = 0;
+            for (int cs : slices3) {
+                HostTensor Ws;
+                Ws.dtype = DType::F32; Ws.dims = {Cout, (int64_t)cs, kh, kw};
+                Ws.f.resize((size_t)(Cout * cs * 9));
+                for (int64_t co = 0; co < Cout; ++co)
+                    for (int64_t ci = 0; ci < cs; ++ci)
+                        for (int64_t t = 0; t < 9; ++t) Ws.f[(size_t)((co * cs + ci) * 9 + t)] = W.f[(size_t)((co * Cin + c0 + ci) * 9 + t)];
+                GNode gn = n;
+                gn.in[1] = n.in[1] + "::slice" + std::to_string(c0);
+                wgrp.push_back(conv_weight_igemm(gn, Ws, k::IGEMM_W_X6));
+                c0 += cs;
             }
         }
         else if (g == 1 && Cin % 4 == 0) {
@@ -1561,6 +1582,18 @@ struct Planner {
                     r.bias = q.bias ? q.bias + (size_t)gi * ogi : nullptr;
                     r.residual = q.residual ? q.residual + (size_t)gi * ogi : nullptr;
                     k::conv_igemm(c.s, r);
+                }
+                return;
+            }
+            if (kind == 4) {
+                int c0 = 0;
+                for (size_t i = 0; i < slices3.size(); ++i) {
+                    k::ConvP r = q;
+                    r.Cin = slices3[i]; r.x_ld = p.Cin; r.x = q.x + c0; r.w = wgrp[i]; r.accum = i > 0 ? 1 : 0;
+                    if (i > 0) r.bias = nullptr;
+                    if (i + 1 < slices3.size()) r.act = k::Act{};
+                    k::conv_igemm(c.s, r);
+                    c0 += slices3[i];
                 }
                 return;
             }

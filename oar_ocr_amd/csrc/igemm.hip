@@ -240,6 +240,7 @@ static bool os_x6_eligible(long M, int K, int N, int Cin, bool grouped = false) 
     return Cin % 8 == 0 && K >= min_k && N >= (grouped ? 32 : 64) && (N & 3) == 0 && fills && K < 65536;
 }
 
+std::vector<int> conv3x3_n16_slices(long M, int Cin, int Cout, long img_px, int y_ld) { return conv3x3_n16_x6_slices(M, Cin, Cout, img_px, y_ld); }
 bool conv_grouped_x6_ok(long M, int K, int N, int Cin) { return os_mode() != 0 && os_x6_eligible(M, K, N, Cin, true); }
 
 int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin, long same3x3_px) {
@@ -301,7 +302,7 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     p.convt = c.convt2x2; p.Cout = c.Cout;
     p.ctc_part = c.ctc_part; p.ctc_valid = c.ctc_valid;
     p.se = c.se; p.se_hw = c.Ho * c.Wo;
-    p.x_ld = c.x_ld > 0 ? c.x_ld : c.Cin;
+    p.x_ld = c.x_ld > 0 ? c.x_ld : c.Cin; p.accum = c.accum;
     p.res_up = c.residual ? c.res_up : 0;
     if (c.convt2x2) {
         p.Ho = c.H; p.Wo = c.W;  // GEMM columns are INPUT pixels
@@ -397,7 +398,8 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     const bool rs3 = x6 && same3x3 && !c.residual && !c.se && !c.ctc_part && conv3x3_n16_x6_eligible(p.M, c.Cin, c.Cout, (long)c.H * c.W, c.y_ld);
     // a layer whose weights were laid out for the row-streaming 3x3 kernel (Cout <= 16: no other bf16x6 kernel takes it) must reach that kernel
     OAR_CHECK(!(x6 && same3x3 && c.Cout <= 16) || rs3, OAR_INTERNAL, "conv_igemm: 3x3 / Cout <= 16 bf16x6 weights but the row-streaming kernel's launch-time conditions do not hold (y_ld / output size / residual / gate changed after planning)");
-    OAR_CHECK(!grouped || (x6 && !is1x1 && !c.ctc_part && !c.se && !c.convt2x2 && !(x6 && same3x3 && c.Cout <= 16)), OAR_INTERNAL, "conv_igemm: x_ld on a layer that does not run on the output-stationary bf16x6 kernel");
+    OAR_CHECK(!grouped || (x6 && !is1x1 && !c.ctc_part && !c.se && !c.convt2x2 && (rs3 || !(same3x3 && c.Cout <= 16))), OAR_INTERNAL, "conv_igemm: x_ld on a layer that runs on neither kernel that reads x with a stride of its own");
+    OAR_CHECK(!c.accum || rs3, OAR_INTERNAL, "conv_igemm: accumulate flag on a layer that does not run on the row-streaming 3x3 kernel");
     if (ws3) {
         conv_igemm_ws3(s, p, nfrag);
     } else if (rs3) {

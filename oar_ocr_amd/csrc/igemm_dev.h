@@ -50,7 +50,8 @@ struct IgemmP {
     int res_up;          // > 1 (per-tile f32 kernels only): res is the low-resolution operand of an FPN sum, read at (h / res_up, w / res_up)
     const float* se;     // != null (bf16x6 weight-stationary kernel only): gate [image][K] multiplied into x on load
     int se_hw;           // pixels per image (se row of pixel m = m / se_hw)
-    int x_ld;            // output-stationary bf16x6 kernel only: floats between two pixels of x (>= Cin; > Cin for one group of a grouped convolution,
+    int accum;           // row-streaming 3x3 kernel only (igemm_rs3_x6.hip): add to what y holds (a later pass over a channel slice of the input)
+    int x_ld;            // output-stationary bf16x6 kernel and igemm_rs3_x6.hip: floats between two pixels of x (>= Cin; > Cin for one group of a grouped convolution,
                          // whose x points at the group's first channel).  Every other kernel reads x with stride Cin
 };
 
@@ -253,6 +254,7 @@ bool conv_igemm_ws3_eligible(const IgemmP& p, int nfrag);
 void conv_igemm_ws3(hipStream_t s, const IgemmP& p, int nfrag);
 // igemm_rs3_x6.hip: 3x3 same convolution, Cin 32 / 64, <= 16 output channels, bf16x6, row-streaming (weights IGEMM_W_X6)
 bool conv3x3_n16_x6_eligible(long M, int Cin, int Cout, long img_px, int y_ld);
+std::vector<int> conv3x3_n16_x6_slices(long M, int Cin, int Cout, long img_px, int y_ld);
 void conv3x3_n16_x6(hipStream_t s, const IgemmP& p, int n_images);
 
 }  // namespace k

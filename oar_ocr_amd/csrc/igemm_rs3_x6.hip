@@ -28,6 +28,8 @@ typedef __bf16 r3_bf16x8 __attribute__((ext_vector_type(8)));
 struct Rs3P {
     const float* x; float* y; const float4* w; const float* bias;
     int N, H, W, Cin, Cout, y_ld;
+    int x_ld;            // floats between two pixels of x (>= Cin): a pass over a 64- or 32-channel slice of a wider tensor (round 6: Cin = 96 ... 256 as several passes)
+    int accum;           // 1: this pass adds its sum to what y already holds (the previous passes' partial sums); bias / activation belong to the first / last pass (host)
     int act; float alpha, beta;
     int R, segs, tiles_x, items, per_xcd;
     unsigned img_bytes, y_bytes;
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 2) void conv3x3_n16_x6_kernel(Rs3P p
     const int xcd = (int)(blockIdx.x & 7), wgx = (int)(blockIdx.x >> 3), wgs = (int)(gridDim.x >> 3);
     const int b0 = xcd * p.per_xcd, b1 = min(p.items, b0 + p.per_xcd);
     const int J = wgs * kR3Waves, j0 = wgx * kR3Waves + wave;
-    const int row_bytes = p.W * p.Cin * 4, orow_bytes = p.W * p.y_ld * 4;
+    const int row_bytes = p.W * p.x_ld * 4, orow_bytes = p.W * p.y_ld * 4;
     const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
     const unsigned rd_lane = (unsigned)(n * kR3PxB + g * 16);   // + row slot + piece * kR3PlB + kw * kR3PxB + c * 64
 
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 2) void conv3x3_n16_x6_kernel(Rs3P p
         for (int u = 0; u < NJ; ++u) {
             const int q = u * 64 + lane, px = q / QPP, cq = q - px * QPP;
             const bool ok = q < NU && (unsigned)(x0 + px) < (unsigned)p.W;
-            src[u] = ok ? (unsigned)(((x0 + px) * p.Cin + cq * 4) * 4) : kR3Oob;
+            src[u] = ok ? (unsigned)(((x0 + px) * p.x_ld + cq * 4) * 4) : kR3Oob;
             dst[u] = q < NU ? (unsigned)(px * kR3PxB + cq * 8) : 0xFFFFFFFFu;
         }
         r3_u32x4 in[NJ];
@@ -144,6 +146,8 @@ __global__ __launch_bounds__(kR3Waves * 64, 2) void conv3x3_n16_x6_kernel(Rs3P p
 #pragma unroll 1
         for (int r = o_begin; r < o_end; ++r) {
             load_row(r + 2, in);                               // lands while this row is multiplied
+            r3_u32x4 prev = (r3_u32x4){0u, 0u, 0u, 0u};       // partial sums of the earlier channel slices (out-of-range lanes read zeros)
+            if (p.accum) prev = __builtin_amdgcn_raw_buffer_load_b128(ysrc, (int)(st_lane + st_row), 0, 0);
             f32x4 acc[6];                                      // one accumulator per product class: six independent MFMA chains
             acc[5] = (f32x4){bq.x, bq.y, bq.z, bq.w};
             acc[0] = acc[1] = acc[2] = acc[3] = acc[4] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 2) void conv3x3_n16_x6_kernel(Rs3P p
             f32x4 o = ((((acc[0] + acc[1]) + acc[2]) + acc[3]) + acc[4]) + acc[5];   // smallest classes first
             r3_u32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(apply_act(o[e], p.act, p.alpha, p.beta));
+            for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(apply_act(o[e] + __uint_as_float(prev[e]), p.act, p.alpha, p.beta));
             // every read of the oldest row has returned (its data fed the MFMAs above): its slot takes row r + 2
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             put_row(ring0 + (unsigned)(s0 * kR3RowB), in);
@@ -193,11 +197,19 @@ bool conv3x3_n16_x6_eligible(long M, int Cin, int Cout, long img_px, int y_ld) {
     static const bool on = [] { const char* e = getenv("OAR_IGEMM_RS3"); return !e || atoi(e) != 0; }();
     return on && (Cin == 32 || Cin == 64) && Cout >= 4 && Cout <= 16 && (Cout & 3) == 0 && (y_ld & 3) == 0 && M >= 100000 && img_px * Cin * 4 < (1L << 29) && M * y_ld * 4 < (1L << 31);
 }
+// wider inputs as passes over 64- / 32-channel slices (each pass: weights' h and m pieces in registers): the slice widths, empty when not eligible
+std::vector<int> conv3x3_n16_x6_slices(long M, int Cin, int Cout, long img_px, int y_ld) {
+    std::vector<int> v;
+    if (Cin <= 64 || Cin > 256 || Cin % 32 != 0 || img_px * Cin * 4 >= (1L << 29) || !conv3x3_n16_x6_eligible(M, 64, Cout, img_px, y_ld)) return v;
+    for (int c = 0; c < Cin; c += 64) v.push_back(std::min(64, Cin - c));
+    return v;
+}
 
 void conv3x3_n16_x6(hipStream_t s, const IgemmP& g, int n_images) {
     Rs3P p{};
     p.x = g.x; p.y = g.y; p.w = reinterpret_cast<const float4*>(g.w); p.bias = g.bias;
     p.N = n_images; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.Cout = g.Cout; p.y_ld = g.y_ld;
+    p.x_ld = g.x_ld > 0 ? g.x_ld : g.Cin; p.accum = g.accum;
     p.act = g.act; p.alpha = g.alpha; p.beta = g.beta;
     p.tiles_x = (g.W + 15) / 16;
     // rows per item: the fewest wave rounds, then the least warm-up (three rows per item)
@@ -211,7 +223,7 @@ void conv3x3_n16_x6(hipStream_t s, const IgemmP& g, int n_images) {
         if (cost < best - 1e-9) { best = cost; p.R = R; p.segs = segs; p.items = (int)items; }
     }
     p.per_xcd = (p.items + 7) / 8;
-    p.img_bytes = (unsigned)((long)g.H * g.W * g.Cin * 4);
+    p.img_bytes = (unsigned)((long)g.H * g.W * p.x_ld * 4);
     p.y_bytes = (unsigned)((long)n_images * g.H * g.W * g.y_ld * 4);
     const size_t lds = (size_t)kR3Waves * 3 * kR3RowB + (size_t)9 * (g.Cin / 32) * 1024;   // rings + the weights' l pieces
     auto launch = [&](auto kernel) {

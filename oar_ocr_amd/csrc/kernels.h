@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <vector>
 
 namespace oar {
 namespace k {
@@ -33,7 +34,8 @@ struct ConvP {
     const float* se;        // igemm only (bf16x6 weight-stationary 1x1): squeeze-excite gate [N][Cin] multiplied into the input on load
     int res_up;             // igemm only (f32 per-tile kernels): f > 1 => `residual` is [N][Ho / f][Wo / f][Cout], added through the nearest index map (h / f, w / f)
                             // -- the top-down sum of an FPN without materialising the upsampled tensor
-    int x_ld;               // igemm only, output-stationary bf16x6 kernel: floats between two pixels of x when that is not Cin (0 = Cin): one group of a
+    int accum;              // igemm only, row-streaming 3x3 kernel: 1 = add to what y already holds (a later pass over a channel slice of the input, ConvP::x_ld)
+    int x_ld;               // igemm only, output-stationary bf16x6 kernel / row-streaming 3x3 kernel: floats between two pixels of x when that is not Cin (0 = Cin): one group of a
                             // grouped convolution reads its Cin channels out of the full tensor
     float* gap_part;        // depthwise only (conv_dw_gap_tiles(p) > 0): per-tile sums of the activated output, [N][tiles][Cout] -- the squeeze of an
                             // SE block without a second read of the feature map (global_avgpool_finish reduces them)
@@ -53,6 +55,9 @@ void conv_igemm(hipStream_t s, const ConvP& p);
 int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin = 0, long same3x3_px = 0);
 // one group of a grouped k x k convolution (ConvP::x_ld) as its own implicit GEMM on the output-stationary bf16x6 kernel: M pixels, K = kh * kw * Cin_g, N = Cout_g >= 32
 bool conv_grouped_x6_ok(long M, int K, int N, int Cin);
+// a 3x3 / stride 1 / pad 1 convolution with <= 16 output channels and 96 ... 256 input channels as passes of the row-streaming bf16x6 kernel over 64- / 32-channel
+// slices of the input (ConvP::x_ld, ConvP::accum): the slice widths, empty when the layer is not eligible.  img_px = pixels of one image
+std::vector<int> conv3x3_n16_slices(long M, int Cin, int Cout, long img_px, int y_ld);
 // may a 1x1 conv of this shape take ConvP::se (the gate of a squeeze-excite block folded into its input load)?  hw = pixels per image
 bool conv_igemm_se_ok(long M, int K, int N, int hw);   // Cin: input channels of a k x k conv (0: treat as not eligible for the x6 path)
 // Depthwise conv. w: [kh][kw][C]. C % 4 == 0.

@@ -228,8 +228,13 @@ def build_rec(size="tiny", vocab=6906, seed=1):
     cfg = {
         #        stem b2  b3  b4   b5   b6   svtr_dim heads out
         "tiny": (16, 24, 48, 96, 192, 256, 64, 4, 64),
+        # the same widths, deepened to the parameter count of the file it stands for: pp-ocrv6_tiny_rec.onnx is 4 462 639 bytes ~ 1.116 M f32 parameters
+        # (reference registry.rs:84); "tiny" above has 0.914 M.  Two more 5x5 blocks at 192 channels and one more squeeze-excite block at 256 (LCNetV3
+        # backbones carry more blocks in exactly these stages): 1 103 284 parameters
+        "tiny_full": (16, 24, 48, 96, 192, 256, 64, 4, 64),
         "server": (32, 64, 128, 256, 512, 768, 192, 6, 192),
     }[size]
+    extra_b5, extra_b6 = (2, 1) if size == "tiny_full" else (0, 0)
     stem, b2, b3, b4, b5, b6, dim, heads, outc = cfg
     n = _Net(f"synth_rec_{size}", seed, decomposed_hswish=False)
     g = n.g
@@ -243,8 +248,12 @@ def build_rec(size="tiny", vocab=6906, seed=1):
     x = n.ds_block(x, b4, b5, 3, (1, 2))                               # 12 x W/4
     x = n.ds_block(x, b5, b5, 5, 1)
     x = n.ds_block(x, b5, b5, 5, 1)
+    for _ in range(extra_b5):
+        x = n.ds_block(x, b5, b5, 5, 1)
     x = n.ds_block(x, b5, b6, 5, (2, 1), use_se=True)                  # 6 x W/4
     x = n.ds_block(x, b6, b6, 5, 1, use_se=True)
+    for _ in range(extra_b6):
+        x = n.ds_block(x, b6, b6, 5, 1, use_se=True)
     x = g.op("AveragePool", [x], kernel_shape=[6, 2], strides=[6, 2], pads=[0, 0, 0, 0])   # 1 x W/8
     # SVTR neck (EncoderWithSVTR)
     h = x

@@ -57,6 +57,8 @@ def main():
         wrap(R, n)
     size_name, vocab = ("server", 18710) if a.config == 2 else ("tiny", 6906)
     det_name = rec_name = size_name
+    if size_name == "tiny":   # graphs of the size of the files they stand for (bench.py --det-params real-size, the default since round 6)
+        det_name = rec_name = "tiny_full"
     if a.config == 2 and a.c3_graphs == "named":
         det_name, rec_name, vocab = "server_hgnet", "svtrv2", 6625
     det, _ = models.build_det(det_name, seed=0)

@@ -310,6 +310,8 @@ def test_igemm_kernels_at_bench_shapes(case):
     ("rs3_x6 3x3 64->16 ragged", 3, 64, 16, 150, 231, "hswish"),     # strips hang over the row, segments over the image, 3 images
     ("rs3_x6 3x3 32->8", 2, 32, 8, 240, 241, None),                  # one k-step per tap, two idle lane groups in the store
     ("rs3_x6 3x3 64->12 tall", 1, 64, 12, 700, 150, "relu"),         # long segments, Cout not a multiple of 8
+    ("rs3_x6 3x3 96->16 two passes", 2, 96, 16, 240, 240, "hswish"), # round 6: slices of 64 + 32 channels, the second pass adds to y (the 0.447 M detector's neck)
+    ("rs3_x6 3x3 160->8 three passes", 1, 160, 8, 400, 260, None),   # 64 + 64 + 32, bias in the first pass only
 ])
 def test_row_streaming_3x3_x6_kernel(case, monkeypatch):
     """igemm_rs3_x6.hip (3x3 same convolution, <= 16 output channels, bf16x6 from packed planes in LDS) against torch-CPU conv2d, and against the

@@ -106,6 +106,23 @@ def test_c2_32_pages_of_960x960_in_one_predict():
     ocr.close()
 
 
+def test_c2_32_pages_on_graphs_of_the_files_sizes():
+    """BASELINE C2 on the graphs bench.py times by default since round 6: detector 447 089 parameters (pp-ocrv6_tiny_det.onnx:
+    1 780 590 bytes), recognizer 1 103 284 (pp-ocrv6_tiny_rec.onnx: 4 462 639 bytes) -- 32 pages of 960 x 960 in one predict, eight against the oracle."""
+    det, di = models.build_det("tiny_full", seed=0)
+    rec, ri = models.build_rec("tiny_full", vocab=6906, seed=1)
+    assert abs(di["params"] * 4 / 1780590 - 1) < 0.02 and abs(ri["params"] * 4 / 4462639 - 1) < 0.02
+    chars = api.read_dict(models.synth_dict(6904))
+    imgs = [pages.make_page(i, (960, 960), 40) for i in range(32)]
+    cfg = api.TextDetectionConfig(score_threshold=0.3, box_threshold=0.6, unclip_ratio=1.5)
+    ocr = api.OAROCRBuilder(det, rec, chars).text_detection_config(cfg).image_batch_size(32).region_batch_size(256).build()
+    got = ocr.predict(imgs)
+    assert len(got) == 32 and sum(len(g.text_regions) for g in got) > 900
+    n, ties = _check_pages_against_oracle(got, imgs, [0, 3, 9, 14, 20, 25, 28, 31], det, rec, chars, {}, (0.3, 0.6, 1.5))
+    assert n > 200 and ties <= 3
+    ocr.close()
+
+
 def test_c3_server_graphs_on_1280x1280_pages():
     det, _ = models.build_det("server", seed=0)
     rec, _ = models.build_rec("server", vocab=18710, seed=1)

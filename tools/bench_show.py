@@ -2,7 +2,7 @@
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print("value", d["value"], "ms/step", d["ms_per_step"], "| device_resident", (d.get("device_resident") or {}).get("value"), "| pipelined", (d.get("pipelined") or {}).get("value"),
-      "| det_real_size", {k: v for k, v in (d.get("det_real_size") or {}).items() if k != "what"})
+      "| lighter graphs (r1-r5)", {k: v for k, v in (d.get("lighter_graphs_r1_r5") or d.get("det_real_size") or {}).items() if k != "what"})
 r = d.get("roofline") or {}
 print("roofline", {k: r.get(k) for k in ("kernel", "bound", "frac", "avg_launch_us", "share_of_step", "traffic")})
 for k, v in (r.get("by_family") or {}).items():
