@@ -64,6 +64,10 @@ def parse_args(argv=None):
     ap.add_argument("--c3-graphs", choices=("named", "standin"), default="named",
                     help="config 2: 'named' = graphs of the size and kind BASELINE C3 names (synth/models.py build_det_hgnet / build_rec_svtrv2); 'standin' = the "
                          "widened LCNet detector (4.3 M) + SVTR-neck recognizer (7.3 M, V = 18710) rounds 1-5 ran config 2 on, detector input at the default 960")
+    ap.add_argument("--models-dir", default="", help="real-weights mode (SURVEY 8d mode i): a directory holding the config's three files under their registry names "
+                    "(config 1: pp-ocrv6_tiny_det.onnx, pp-ocrv6_tiny_rec.onnx, ppocrv6_tiny_dict.txt; config 2: pp-ocrv5_server_det.onnx, ch_svtrv2_rec.onnx, ppocr_keys_v1.txt). "
+                    "Every file's size and SHA-256 is checked against the reference's registry (oar_ocr_amd/weights.py); a mismatch refuses the run.  With onnxruntime importable, "
+                    "the CPU leg becomes the ORT-CPU stand-in and a network-level parity report (max |dprob|, threshold-marginal pixels) is added")
     ap.add_argument("--no-real-size", action="store_true", help="skip the extra timing of the real-size detector (config 1, one GPU)")
     ap.add_argument("--stub-engine", action="store_true", help=argparse.SUPPRESS)   # tests/test_bench_cpu.py: control flow without a GPU
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py starts its own ranks (0 = pick a free one)")
@@ -153,6 +157,15 @@ class StubEngine:
 
 def main():
     args = parse_args()
+    real_weights = None
+    if args.models_dir:   # verified before anything runs (or any rank starts): a file that is not the registry's is refused, never silently replaced by a synthetic graph
+        from oar_ocr_amd import weights
+        try:
+            rw_det, rw_rec, rw_chars, rw_report = weights.load_config(args.models_dir, args.config)
+        except weights.WeightsError as e:
+            print(f"bench.py --models-dir {args.models_dir}: refused -- {e}", file=sys.stderr, flush=True)
+            sys.exit(3)
+        real_weights = {"dir": args.models_dir, "files": rw_report}
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 
@@ -198,9 +211,13 @@ def main():
     if stub:
         eng, det_info, rec_info = StubEngine(rank), {"params": 0}, {"params": 0}
     else:
-        det, det_info = models.build_det(det_name, seed=0)
-        rec, rec_info = models.build_rec(rec_name, vocab=vocab, seed=1)
-        chars = api.read_dict(models.synth_dict(vocab - 2))
+        if real_weights:
+            det, rec, chars = rw_det, rw_rec, rw_chars
+            det_info, rec_info, vocab = {"params": len(det) // 4}, {"params": len(rec) // 4}, len(chars) + 2     # (file bytes / 4: the files are almost all f32 initializers)
+        else:
+            det, det_info = models.build_det(det_name, seed=0)
+            rec, rec_info = models.build_rec(rec_name, vocab=vocab, seed=1)
+            chars = api.read_dict(models.synth_dict(vocab - 2))
         cfg = api.TextDetectionConfig(score_threshold=0.3, box_threshold=0.6, unclip_ratio=1.5)   # examples/ocr.rs:119-133 set
         if c3_named:   # "batch=64 1280x1280": the default limit (960 / Max, src/oarocr/ocr.rs:351-363) would Triangle-downscale the pages to 960^2 first
             cfg = api.TextDetectionConfig(score_threshold=0.3, box_threshold=0.6, unclip_ratio=1.5, limit_side_len=size)
@@ -481,6 +498,11 @@ def main():
             except Exception:
                 have_ort = False
             real = sorted(str(q.relative_to(ROOT)) for q in (ROOT / "models").glob("*.onnx")) if (ROOT / "models").is_dir() else []
+            ort_standin = None
+            if have_ort and real_weights:   # SURVEY 8d plan (1): the closest stand-in for the reference's CPU path -- ORT CPU EP on the SAME files, this repo's CPU pre / post around it
+                from oracle import ort_standin as ort_mod
+                ort_standin = ort_mod.time_and_compare(rw_det, rw_rec, rw_chars, host_pages[:max(1, args.cpu_pages)], api, limit_side_len=(size if c3_named else None),
+                                                       threads=min(os.cpu_count() or 1, 64))
             ort_note = ("not run: " + ("onnxruntime is not importable on this box" if not have_ort else "onnxruntime present") +
                         ("; no models/*.onnx supplied (synthetic-weight graphs only)" if not real else f"; models present: {real}") +
                         " -- the timed oracle is the torch-CPU port")
@@ -537,10 +559,13 @@ def main():
                    "sample": f"{best['pages']} {size}x{size} synthetic pages (same generator as the GPU workload), one predict per page, det batch 1 / rec batch 16 "
                              "(reference CPU defaults); oracle = C restatement of pre/post + torch-CPU fp32 network; the reference's own "
                              "published CPU figure is 34 ms/image (docs/FAQ.md:22, i9-13900KF, real weights)"}
+            if ort_standin:   # real weights + onnxruntime: the stand-in IS the baseline, the torch port stays beside it
+                cpu = {"value": ort_standin["images_per_sec"], "unit": "images/sec", "cores": ort_standin["threads"], "kind": "ort-standin", "sample": ort_standin["sample"],
+                       "network_parity": ort_standin["parity"], "torch_port": cpu}
         line = {
             "metric": "images/sec end-to-end PP-OCRv6 det+rec", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(tmax / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic pages, real weights (registry-verified files)" if real_weights else "synthetic",
             "config": {"baseline_config": args.config,
                        "workload": f"{('PP-OCRv5-server-class det (PP-HGNetV2 + LK-PAN, input 1280) + SVTRv2-class rec' if c3_named else 'server-size LCNet det + SVTR-neck rec (rounds 1-5 stand-in, detector input 960)') if args.config == 2 else 'PP-OCRv6-tiny-class det+rec'}"
                                    f"{' + doc orientation + UVDoc + text-line orientation' if args.config == 4 else ''} "
@@ -552,7 +577,7 @@ def main():
                        "pages_per_gpu_per_step": n_pages, "image_batch_size": image_batch, "region_batch_size": args.region_batch,
                        "regions_per_step": gathered["regions"], "text_bytes_per_step": gathered["bytes"], "pages_gathered_per_step": gathered["pages"],
                        "parallelism": f"image-parallel x{world}", "host_cores_per_rank": cores, "host_cpu_ms_per_step": round(host_cpu_ms, 2)},
-            "roofline": roof, "cpu_baseline": cpu, "device_resident": dev_res, "pipelined": pipelined, "lighter_graphs_r1_r5": real_size, "rec_two_streams": rec_two, "conv_mfma_util": mfma_util, "kernel_ms_per_step_untimed_pass": breakdown, "predict_passes_total": passes["n"], "csrc_fingerprint": csrc_now,
+            "real_weights": real_weights, "roofline": roof, "cpu_baseline": cpu, "device_resident": dev_res, "pipelined": pipelined, "lighter_graphs_r1_r5": real_size, "rec_two_streams": rec_two, "conv_mfma_util": mfma_util, "kernel_ms_per_step_untimed_pass": breakdown, "predict_passes_total": passes["n"], "csrc_fingerprint": csrc_now,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -51,11 +51,22 @@ int oar_device_count(void);
  */
 typedef struct oar_engine oar_engine;
 
+/* Arithmetic mode of the network kernels (SURVEY 8b "Device selection": OarEngineCfg{device_id, precision, stream}; the reference's seam is
+ * OrtSessionConfig, core/config/onnx.rs:88-178).  OAR_PRECISION_F32 is the only mode the library implements: every product is either an f32
+ * FMA / f32-input MFMA or "bf16x6" -- both operands split exactly into three bf16 pieces, the six significant products accumulated in f32,
+ * relative error of a product ~2^-24 like an f32 multiply.  Narrower modes (bf16x3, 16-bit activations) would not be the reference's arithmetic;
+ * any other value is refused with OAR_INVALID_INPUT instead of being silently widened or narrowed. */
+typedef enum { OAR_PRECISION_F32 = 0 } oar_precision;
+
 typedef struct {
     int32_t device_id;      /* HIP device ordinal                                                    */
     int32_t use_hip_graph;  /* 1: capture each (shape-specialised) plan into a hipGraph and replay    */
     int32_t profile;        /* 1: record hipEvents around kernels (see oar_prof_*)                   */
-    int32_t reserved;
+    int32_t precision;      /* oar_precision; 0 = OAR_PRECISION_F32 (was `reserved`, always 0)       */
+    void* stream;           /* hipStream_t of the caller on `device_id`, or NULL: the engine creates its own non-blocking stream.  With a caller's
+                             * stream every copy and kernel of oar_engine_run is enqueued on it (in order with the caller's own work) and the call
+                             * still returns after the outputs have reached the host.  The stream must outlive the engine; the engine never
+                             * destroys it.                                                          */
 } oar_engine_cfg;
 
 /* TensorOutput::{F32, I64} (core/inference/tensor_output.rs:16-21) */
@@ -593,6 +604,10 @@ int32_t oar_host_ring_outline(const int64_t* xy, int32_t n_points, int32_t negat
 void oar_host_sort_poly_boxes(const float* pts_xy, const uint32_t* offsets, int32_t n, int32_t* order);
 /* a9 mini box of an arbitrary point set (db_bitmap.rs:164-205): returns 1 and fills box8/min_side, or 0. */
 int32_t oar_host_mini_box(const float* xy, int32_t n_points, float box8[8], float* min_side);
+/* convex_hull (processors/geometry.rs:226-271: Graham scan from the lowest-then-leftmost point, atan2 / squared-distance keys, pop on cross <= 0) of
+ * n_points (x, y) pairs -> hull vertices in scan order; returns their count, -1 on bad arguments or cap_points too small.  A test entry: the product's
+ * row-extreme pre-filter for integer border pixels (db_host.cc) is checked through it against an exact integer-arithmetic scan. */
+int32_t oar_host_convex_hull(const float* xy, int32_t n_points, float* out_xy, int32_t cap_points);
 /* a13 processors/sorting.rs:35-84: permutation that sorts n quad boxes into reading order. */
 void oar_host_sort_quad_boxes(const float* boxes8, int32_t n, int32_t* order);
 /* Self-test of the geometry thread pool: `jobs` back-to-back parallel loops of varying length on `threads` workers;

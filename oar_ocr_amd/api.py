@@ -36,7 +36,10 @@ class OCRError(RuntimeError):
 
 
 class EngineCfg(C.Structure):
-    _fields_ = [("device_id", C.c_int32), ("use_hip_graph", C.c_int32), ("profile", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("device_id", C.c_int32), ("use_hip_graph", C.c_int32), ("profile", C.c_int32), ("precision", C.c_int32), ("stream", C.c_void_p)]
+
+
+PRECISION_F32 = 0   # oar_precision: the only arithmetic mode (f32 FMA / f32 MFMA / bf16x6); anything else is refused by oar_engine_create
 
 
 class Tensor(C.Structure):
@@ -137,7 +140,7 @@ EXPORTS = [
     "oar_ocr_predict", "oar_ocr_predict_device", "oar_ocr_result_free", "oar_dev_alloc", "oar_dev_upload", "oar_dev_download",
     "oar_dev_free", "oar_dev_synchronize", "oar_k_normalize", "oar_k_rec_preprocess", "oar_k_resize_triangle", "oar_k_threshold",
     "oar_k_ctc_argmax", "oar_k_box_scores", "oar_k_rotate_crop", "oar_prof_reset", "oar_prof_enable", "oar_prof_filter", "oar_prof_sampling", "oar_prof_snapshot",
-    "oar_host_candidates", "oar_host_unclip", "oar_host_mini_box", "oar_host_sort_quad_boxes", "oar_host_pool_selftest", "oar_host_plan_crop",
+    "oar_host_candidates", "oar_host_unclip", "oar_host_mini_box", "oar_host_convex_hull", "oar_host_sort_quad_boxes", "oar_host_pool_selftest", "oar_host_plan_crop",
     "oar_cls_create", "oar_cls_destroy", "oar_cls_run", "oar_cls_result_free", "oar_cls_preprocess", "oar_rect_create", "oar_rect_destroy",
     "oar_rect_run", "oar_ocr_attach", "oar_k_rotate_rgb", "oar_k_bgr_planes_to_rgb", "oar_host_rotate_back_points",
     "oar_engine_cache_stats", "oar_onnx_inspect", "oar_host_contours", "oar_ctc_dict_create", "oar_ctc_dict_destroy", "oar_ctc_dict_classes",
@@ -254,6 +257,8 @@ def lib():
     L.oar_host_sort_poly_boxes.restype = None
     L.oar_host_mini_box.argtypes = [vp, C.c_int32, vp, f32p]
     L.oar_host_mini_box.restype = C.c_int32
+    L.oar_host_convex_hull.argtypes = [vp, C.c_int32, vp, C.c_int32]
+    L.oar_host_convex_hull.restype = C.c_int32
     L.oar_host_sort_quad_boxes.argtypes = [vp, C.c_int32, vp]
     L.oar_host_sort_quad_boxes.restype = None
     L.oar_host_plan_crop.argtypes = [C.c_uint32, C.c_uint32, vp, vp, vp]
@@ -394,9 +399,11 @@ def _img_arrays(images: Sequence[np.ndarray]):
 class OrtInfer:
     """Drop-in for `OrtInfer` (core/inference/mod.rs:31-115): `.onnx` bytes in, f32 tensors in/out."""
 
-    def __init__(self, model: bytes, device_id: int = 0, profile: bool = False):
+    def __init__(self, model: bytes, device_id: int = 0, profile: bool = False, precision: int = PRECISION_F32, stream: Optional[int] = None):
+        """stream: a hipStream_t of the caller (integer handle, e.g. torch.cuda.Stream().cuda_stream) on `device_id`; every copy and kernel of
+        `infer` is then enqueued on it.  None: the engine creates its own stream."""
         self._h = C.c_void_p()
-        cfg = EngineCfg(device_id, 0, int(profile), 0)
+        cfg = EngineCfg(device_id, 0, int(profile), int(precision), C.c_void_p(stream) if stream else None)
         buf = (C.c_char * len(model)).from_buffer_copy(model)
         _check(lib().oar_engine_create(C.cast(buf, C.c_void_p), len(model), C.byref(cfg), C.byref(self._h)))
 
@@ -1769,6 +1776,16 @@ def host_mini_box(points):
     ms = C.c_float(0)
     ok = lib().oar_host_mini_box(_p(pts), pts.shape[0], _p(out), C.byref(ms))
     return (out, float(ms.value)) if ok == 1 else None
+
+
+def host_convex_hull(points):
+    """convex_hull (processors/geometry.rs:226-271) of [n, 2] points through the C ABI (oar_host_convex_hull): hull vertices in scan order."""
+    pts = np.ascontiguousarray(points, np.float32).reshape(-1, 2)
+    out = np.zeros((max(pts.shape[0], 1), 2), np.float32)
+    n = lib().oar_host_convex_hull(_p(pts), pts.shape[0], _p(out), out.shape[0])
+    if n < 0:
+        raise OCRError(1, "oar_host_convex_hull failed")
+    return out[:n].copy()
 
 
 def host_sort_quad_boxes(boxes):

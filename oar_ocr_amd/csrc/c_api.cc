@@ -174,7 +174,8 @@ oar_status oar_engine_create(const uint8_t* onnx, size_t onnx_len, const oar_eng
         OAR_CHECK(out, OAR_INVALID_INPUT, "oar_engine_create: out is null");
         *out = nullptr;
         std::unique_ptr<oar_engine> h(new oar_engine());
-        h->e.reset(new Engine(onnx, onnx_len, cfg ? cfg->device_id : 0));
+        OAR_CHECK(!cfg || cfg->precision == OAR_PRECISION_F32, OAR_INVALID_INPUT, "oar_engine_create: unsupported precision (only OAR_PRECISION_F32 = 0 exists: f32 / bf16x6 arithmetic)");
+        h->e.reset(new Engine(onnx, onnx_len, cfg ? cfg->device_id : 0, cfg ? static_cast<hipStream_t>(cfg->stream) : nullptr));
         if (cfg && cfg->profile) Profiler::get().enabled = true;
         *out = h.release();
     });
@@ -1479,6 +1480,17 @@ int32_t oar_host_mini_box(const float* xy, int32_t n_points, float box8[8], floa
         for (int k = 0; k < 4; ++k) { box8[k * 2] = mb[k].x; box8[k * 2 + 1] = mb[k].y; }
         if (min_side) *min_side = ms;
         return 1;
+    } catch (...) { return -1; }
+}
+int32_t oar_host_convex_hull(const float* xy, int32_t n_points, float* out_xy, int32_t cap_points) {
+    try {
+        if (!xy || n_points < 0 || !out_xy) return -1;
+        std::vector<host::Pt> p((size_t)n_points);
+        for (int i = 0; i < n_points; ++i) p[(size_t)i] = {xy[i * 2], xy[i * 2 + 1]};
+        const std::vector<host::Pt> h = host::convex_hull(p);
+        if ((int64_t)h.size() > cap_points) return -1;
+        for (size_t k = 0; k < h.size(); ++k) { out_xy[k * 2] = h[k].x; out_xy[k * 2 + 1] = h[k].y; }
+        return (int32_t)h.size();
     } catch (...) { return -1; }
 }
 int32_t oar_host_pool_selftest(int32_t threads, int32_t jobs) {

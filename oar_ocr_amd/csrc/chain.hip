@@ -601,11 +601,7 @@ size_t chain_lds_bytes(const ChainOpD& op, int T) {   // scratch at the bottom o
 void chain_run(hipStream_t s, const ChainLaunch& L, char* arena, const char* input) {
     if (L.n_samples <= 0 || L.T <= 0 || L.n_ops <= 0) return;
     OAR_CHECK(L.lds + 640 <= 160 * 1024 && L.max_hd <= kChainMaxHd, OAR_INTERNAL, "chain: LDS / head size beyond what the planner may fuse");
-    static const bool once = [] {
-        OAR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<kChainMaxHd>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        return true;
-    }();
-    (void)once;
+    OAR_MAX_LDS_ONCE(chain_kernel<kChainMaxHd>, 160 * 1024);
     ProfScope ps(s, "chain", L.bytes, L.flops, true);
     // OAR_CHAIN_DBG=1: per-operator wall-clock stamps of workgroup 0 (100 MHz constant clock), printed after a synchronising read-back
     static const bool dbg_on = [] { const char* e = getenv("OAR_CHAIN_DBG"); return e && atoi(e) != 0; }();

@@ -33,6 +33,22 @@ struct Error : std::runtime_error {
                             std::to_string(__LINE__) + ")");                                                \
     } while (0)
 
+// Opt a kernel in to more than 64 KB of dynamic LDS.  The attribute belongs to the (function, DEVICE) pair, so it is set once per device the calling thread
+// has current -- a process-wide once-flag would leave an Engine created later on another device_id launching with > 64 KB and no opt-in.
+// One flag word per call site (per template instantiation inside a function template), one bit per device ordinal.
+#define OAR_MAX_LDS_ONCE(kernel_expr, bytes)                                                                                     \
+    do {                                                                                                                          \
+        static std::atomic<unsigned long long> oar_lds_done_{0};                                                                  \
+        int oar_lds_dev_ = 0;                                                                                                     \
+        (void)hipGetDevice(&oar_lds_dev_);                                                                                        \
+        const unsigned long long oar_lds_bit_ = 1ull << (oar_lds_dev_ & 63);                                                      \
+        if (!(oar_lds_done_.load(std::memory_order_acquire) & oar_lds_bit_)) {                                                    \
+            OAR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_expr), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes))); \
+            oar_lds_done_.fetch_or(oar_lds_bit_, std::memory_order_release);                                                      \
+        }                                                                                                                         \
+    } while (0)
+
+
 #define OAR_CHECK(cond, code, msg)                \
     do {                                          \
         if (!(cond)) ::oar::fail((code), (msg));  \

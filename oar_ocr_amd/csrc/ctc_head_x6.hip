@@ -166,8 +166,7 @@ __global__ __launch_bounds__(kChWaves * 64, 1) void ctc_head_x6_kernel(CtcHeadP 
 
 template <typename K>
 void launch_ch(K kernel, hipStream_t s, const CtcHeadP& p, dim3 grid, size_t lds, hipEvent_t e0, hipEvent_t e1) {
-    static const bool once = [kernel] { OAR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); return true; }();
-    (void)once;
+    OAR_MAX_LDS_ONCE(kernel, 160 * 1024);
     hipExtLaunchKernelGGL(kernel, grid, dim3(kChWaves * 64), lds, s, e0, e1, 0, p);
 }
 }  // namespace

@@ -15,8 +15,7 @@ constexpr size_t lds_bytes(int ks, int sh, int sw, int nft, int rows) {
 }
 template <typename K>
 void launch_one(K kernel, hipStream_t s, const DsCsP& p, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1) {
-    static const bool once = [kernel] { OAR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); return true; }();
-    (void)once;
+    OAR_MAX_LDS_ONCE(kernel, 160 * 1024);
     hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, s, e0, e1, 0, p);
 }
 }  // namespace

@@ -8,8 +8,7 @@ namespace k {
 namespace {
 template <typename K>
 void launch_rs2(K kernel, int wpw, hipStream_t s, const DsRs2P& p, int grid, size_t lds, hipEvent_t e0, hipEvent_t e1) {
-    static const bool once = [kernel] { OAR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); return true; }();
-    (void)once;
+    OAR_MAX_LDS_ONCE(kernel, 160 * 1024);
     hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(wpw * 64), lds, s, e0, e1, 0, p);
 }
 struct Rs2Inst { int nch1, nf1, nf2, wpw; };

@@ -21,13 +21,14 @@ static int64_t numel(const std::vector<int64_t>& d) {
     return n;
 }
 
-Engine::Engine(const uint8_t* onnx, size_t len, int device_id) : device_(device_id) {
+Engine::Engine(const uint8_t* onnx, size_t len, int device_id, hipStream_t caller_stream) : device_(device_id) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         fail(OAR_DEVICE, "no HIP device visible: libOarMi355x has no CPU fallback");
     OAR_CHECK(device_id >= 0 && device_id < ndev, OAR_DEVICE, "device_id out of range");
     OAR_HIP(hipSetDevice(device_));
-    OAR_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    if (caller_stream) { stream_ = caller_stream; owns_stream_ = false; }   // oar_engine_cfg.stream: the caller's stream, never destroyed here
+    else OAR_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     OnnxModel m = parse_onnx(onnx, len);
     validate_model(m);
     input_name_ = m.inputs[0];
@@ -60,7 +61,7 @@ Engine::~Engine() {
     clear_graphs();
     Profiler::get().drop_events();   // no pooled event may outlive the stream it was recorded on
     for (void* p : dev_allocs_) (void)hipFree(p);
-    if (stream_) (void)hipStreamDestroy(stream_);
+    if (stream_ && owns_stream_) (void)hipStreamDestroy(stream_);
     (void)hipGetLastError();
 }
 
@@ -619,7 +620,8 @@ void Engine::rewrite_graph(OnnxModel& m) {
                 for (size_t q = 0; q < nodes[j].in.size(); ++q) if (nodes[j].in[q] == gp.out[0]) { ++readers; if (nodes[j].op == "SEGate" && q == 0) gate = j; }
                 if (nodes[j].residual == gp.out[0]) ++readers;
             }
-            if (readers == 1 && gate >= 0 && !(fe && atoi(fe) == 1)) { Attr a; a.kind = Attr::I; a.i = 1; d.attrs["gap_raw"] = a; }
+            // (a pooled vector that is ALSO a graph output must exist as [N, C, 1, 1] means, not as raw tile sums: ADVICE r5)
+            if (readers == 1 && gate >= 0 && !graph_outs.count(gp.out[0]) && !(fe && atoi(fe) == 1)) { Attr a; a.kind = Attr::I; a.i = 1; d.attrs["gap_raw"] = a; }
         }
         std::vector<GNode> keep;
         for (int i = 0; i < (int)nodes.size(); ++i) if (!dead[i]) keep.push_back(std::move(nodes[i]));
@@ -1650,38 +1652,66 @@ struct Planner {
     }
     // DSBlock n followed by a DSBlock that is the ONLY reader of its output: one launch, the tensor between them never exists (csrc/dsblock_rs2.inc).
     // Decided here, at plan time, because eligibility depends on the shapes; the second node is then skipped by build().
-    bool try_dsblock_pair(const GNode& n, const TInfo& x) {
-        if (cur + 1 >= (int)E.nodes_.size() || !n.residual.empty() || x.dims.size() != 4 || x.host_int) return false;
-        const GNode& m = E.nodes_[cur + 1];
-        if (m.op != "DSBlock" || m.in.empty() || m.in[0] != n.out[0] || !m.residual.empty()) return false;
+    // May DSBlock node i be fused with node i + 1 as far as the GRAPH is concerned: i + 1 is a DSBlock reading i's output as its data input and nothing else does.
+    bool dsblock_link_ok(int i) {
+        if (i + 1 >= (int)E.nodes_.size()) return false;
+        const GNode &n = E.nodes_[i], &m = E.nodes_[i + 1];
+        if (n.op != "DSBlock" || m.op != "DSBlock" || !n.residual.empty() || !m.residual.empty() || m.in.empty() || m.in[0] != n.out[0]) return false;
         for (auto& o : E.output_names_) if (o == n.out[0]) return false;
-        for (int i = 0; i < (int)E.nodes_.size(); ++i) {   // nobody else reads the intermediate tensor
-            if (i == cur + 1) continue;
-            const GNode& q = E.nodes_[i];
+        for (int j = 0; j < (int)E.nodes_.size(); ++j) {   // nobody else reads the intermediate tensor
+            if (j == i + 1) continue;
+            const GNode& q = E.nodes_[j];
             for (auto& s : q.in) if (s == n.out[0]) return false;
             if (q.residual == n.out[0]) return false;
         }
-        for (size_t i = 1; i < m.in.size(); ++i) if (m.in[i] == n.out[0]) return false;
+        for (size_t k = 1; k < m.in.size(); ++k) if (m.in[k] == n.out[0]) return false;
+        return true;
+    }
+    // The pairing of a maximal run of chained DSBlocks, decided ONCE when its first block is planned (the round-5 rule decided per node --
+    // "defer when the next pair is wider" -- and in a run of four or more blocks of growing width every block deferred, so only the last pair fused):
+    // the set of disjoint adjacent pairs that keeps the most intermediate-tensor elements out of HBM (a three-line dynamic programme over the run).
+    // OAR_DSBLOCK_RS2_FIRST=1: greedy from the front instead.
+    std::map<int, bool> dsblock_pair_plan;   // node index -> fuse with the next node
+    void plan_dsblock_run(int first, const TInfo& x) {
+        std::vector<k::DsBlockP> ps;
+        std::vector<bool> link;
+        int64_t N = x.dims[0], C = x.dims[1], H = x.dims[2], W = x.dims[3];
+        for (int i = first; i < (int)E.nodes_.size(); ++i) {
+            const GNode& q = E.nodes_[i];
+            k::DsBlockP p;
+            if (q.op != "DSBlock" || q.in.size() < 5 || !dsblock_shape(q, N, C, H, W, p)) break;
+            ps.push_back(p);
+            C = p.Cout; H = p.Ho; W = p.Wo;
+            const bool ok = dsblock_link_ok(i);
+            link.push_back(ok);
+            if (!ok) break;
+        }
+        const int R = (int)ps.size();
+        std::vector<double> w(std::max(R - 1, 0), -1.0);   // elements of the tensor between block j and j + 1 when that pair can fuse
+        for (int j = 0; j + 1 < R; ++j)
+            if (link[j] && k::dsblock2_eligible(ps[j], ps[j + 1])) w[j] = (double)N * ps[j].Cout * ps[j].Ho * ps[j].Wo;
+        static const bool greedy_first = [] { const char* e = getenv("OAR_DSBLOCK_RS2_FIRST"); return e && atoi(e) != 0; }();
+        std::vector<bool> take(std::max(R - 1, 0), false);
+        if (greedy_first) {
+            for (int j = 0; j + 1 < R; ++j) if (w[j] > 0) { take[j] = true; ++j; }
+        } else {
+            std::vector<double> best(R + 1, 0.0);   // best[j]: blocks j.. of the run
+            for (int j = R - 2; j >= 0; --j) best[j] = std::max(best[j + 1], w[j] > 0 ? w[j] + best[std::min(j + 2, R)] : 0.0);
+            for (int j = 0; j + 1 < R;) {
+                if (w[j] > 0 && w[j] + best[std::min(j + 2, R)] >= best[j + 1]) { take[j] = true; j += 2; }
+                else ++j;
+            }
+        }
+        for (int j = 0; j < R; ++j) dsblock_pair_plan[first + j] = j + 1 < R && take[j];
+    }
+    bool try_dsblock_pair(const GNode& n, const TInfo& x) {
+        if (cur + 1 >= (int)E.nodes_.size() || !n.residual.empty() || x.dims.size() != 4 || x.host_int) return false;
+        if (!dsblock_pair_plan.count(cur)) plan_dsblock_run(cur, x);
+        if (!dsblock_pair_plan[cur]) return false;
+        const GNode& m = E.nodes_[cur + 1];
         k::DsBlockP pa, pb;
         const int64_t N = x.dims[0], C = x.dims[1], H = x.dims[2], W = x.dims[3];
         if (!dsblock_shape(n, N, C, H, W, pa) || !dsblock_shape(m, N, pa.Cout, pa.Ho, pa.Wo, pb) || !k::dsblock2_eligible(pa, pb)) return false;
-        // a chain a -> b -> c can fuse only one of its two pairs: the one whose intermediate tensor is wider saves more traffic (OAR_DSBLOCK_RS2_FIRST=1: always the first)
-        static const bool first = [] { const char* e = getenv("OAR_DSBLOCK_RS2_FIRST"); return e && atoi(e) != 0; }();
-        if (!first && cur + 2 < (int)E.nodes_.size()) {
-            const GNode& q = E.nodes_[cur + 2];
-            k::DsBlockP pc;
-            if (q.op == "DSBlock" && !q.in.empty() && q.in[0] == m.out[0] && q.residual.empty() && get(q.in[1]).ht && get(q.in[3]).ht &&
-                dsblock_shape(q, N, pb.Cout, pb.Ho, pb.Wo, pc) && k::dsblock2_eligible(pb, pc) && pb.Cout > pa.Cout) {
-                bool sole = true;
-                for (auto& o : E.output_names_) sole = sole && o != m.out[0];
-                for (int i = 0; sole && i < (int)E.nodes_.size(); ++i) {
-                    if (i == cur + 2) continue;
-                    for (auto& t : E.nodes_[i].in) sole = sole && t != m.out[0];
-                    sole = sole && E.nodes_[i].residual != m.out[0];
-                }
-                if (sole) return false;   // b -> c will be fused when b is planned
-            }
-        }
         auto weights = [&](const GNode& d, k::DsBlockP& p) {
             const HostTensor &WD = *get(d.in[1]).ht, &WP = *get(d.in[3]).ht;
             GNode dwn, pwn;

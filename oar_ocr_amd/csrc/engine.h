@@ -89,7 +89,7 @@ struct Plan {
 
 class Engine {
    public:
-    Engine(const uint8_t* onnx, size_t len, int device_id);
+    Engine(const uint8_t* onnx, size_t len, int device_id, hipStream_t caller_stream = nullptr);   // caller_stream: oar_engine_cfg.stream (null = own stream)
     ~Engine();
     const std::string& input_name() const { return input_name_; }
     // declared graph inputs (initializers excluded) / outputs, with the shapes the model file declares (-1 = dynamic):
@@ -135,6 +135,7 @@ class Engine {
     int device_ = 0;
     int64_t opset_ = 17;
     hipStream_t stream_ = nullptr;
+    bool owns_stream_ = true;   // false: oar_engine_cfg.stream (the caller's)
     std::string input_name_;
     std::vector<std::string> output_names_;
     std::vector<ValueInfo> input_infos_, output_infos_;

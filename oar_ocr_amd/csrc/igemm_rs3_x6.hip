@@ -227,8 +227,7 @@ void conv3x3_n16_x6(hipStream_t s, const IgemmP& g, int n_images) {
     p.y_bytes = (unsigned)((long)n_images * g.H * g.W * g.y_ld * 4);
     const size_t lds = (size_t)kR3Waves * 3 * kR3RowB + (size_t)9 * (g.Cin / 32) * 1024;   // rings + the weights' l pieces
     auto launch = [&](auto kernel) {
-        static const bool once = [kernel] { OAR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); return true; }();
-        (void)once;
+        OAR_MAX_LDS_ONCE(kernel, 160 * 1024);
         hipLaunchKernelGGL(kernel, dim3(256), dim3(kR3Waves * 64), lds, s, p);
     };
     static const int dbg = [] { const char* e = getenv("OAR_RS3_DBG"); return e ? atoi(e) : 0; }();

@@ -249,11 +249,7 @@ bool conv_igemm_ws3_eligible(const IgemmP& p, int nfrag) {
 
 template <int NT>
 static void launch_ws3(hipStream_t s, const IgemmP& p, size_t lds) {
-    static const bool once = [] {
-        OAR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws3_kernel<NT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        return true;
-    }();
-    (void)once;
+    OAR_MAX_LDS_ONCE((conv_igemm_ws3_kernel<NT, 2>), 160 * 1024);
     IgemmWs3P q;
     q.g = p; q.ny = 1; q.groups = 1;
     q.wt_total = (p.M + 31) / 32;

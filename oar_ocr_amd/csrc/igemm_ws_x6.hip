@@ -234,11 +234,7 @@ int ws_x6_se_rows(long M, int ny, int hw) {
 
 template <int NT, bool CTC = false, bool SE = false>
 static void launch_ws_x6(hipStream_t s, const IgemmP& p, int ny, size_t lds) {
-    static const bool once = [] {
-        OAR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_ws_x6_kernel<NT, CTC, SE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        return true;
-    }();
-    (void)once;
+    OAR_MAX_LDS_ONCE((conv_igemm_ws_x6_kernel<NT, CTC, SE>), 160 * 1024);
     IgemmWsX6P q;
     q.g = p; q.ny = ny;
     const int per_xcd = 32;

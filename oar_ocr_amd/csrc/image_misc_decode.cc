@@ -103,10 +103,11 @@ void decode_bmp(const uint8_t* bytes, size_t len, std::vector<uint8_t>& rgb, uin
         mr = mask_of(rm, "red"); mg = mask_of(gm, "green"); mb = mask_of(bm, "blue");
     }
     OAR_CHECK(data_off <= len, OAR_INVALID_INPUT, "image load: BMP pixel offset beyond the file");
-    {   // the file must be able to hold the raster BEFORE the output is allocated: rows of the uncompressed forms, and for RLE at least one
-        // two-byte run per 255 pixels
+    {   // the file must be able to hold the raster BEFORE the output is allocated: rows of the uncompressed forms.  An RLE stream may SKIP pixels
+        // (end-of-line, delta and end-of-bitmap escapes leave them at zero, as the image crate does), so a sparse page can be far shorter than one
+        // run per 255 pixels: all it must contain is the two-byte end-of-bitmap marker; the output stays bounded by kMaxOut (dims check)
         const size_t stride_chk = (((size_t)W * bpp + 31) / 32) * 4;
-        const size_t need = rle ? ((size_t)W * H + 254) / 255 * 2 : stride_chk * H;
+        const size_t need = rle ? 2 : stride_chk * H;
         OAR_CHECK(need <= len - data_off, OAR_INVALID_INPUT, "image load: truncated BMP pixel data");
     }
     rgb.assign((size_t)W * H * 3, 0);

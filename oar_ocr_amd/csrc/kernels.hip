@@ -188,22 +188,14 @@ void conv_dw(hipStream_t s, const ConvP& p) {
 #define DW2(KV, SHV, SWV, THV)                                                                                                                              \
     do {                                                                                                                                                    \
         if (lds > 64 * 1024) {                                                                                                                              \
-            static const bool once = [] {                                                                                                                   \
-                OAR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dw_tiled_kernel<KV, SHV, SWV, TW, THV>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); \
-                return true;                                                                                                                                \
-            }();                                                                                                                                            \
-            (void)once;                                                                                                                                     \
+            OAR_MAX_LDS_ONCE((conv_dw_tiled_kernel<KV, SHV, SWV, TW, THV>), 96 * 1024);                    \
         }                                                                                                                                                   \
         hipExtLaunchKernelGGL((conv_dw_tiled_kernel<KV, SHV, SWV, TW, THV>), g, b, lds, s, ps.start(), ps.stop(), 0, p);                                    \
     } while (0)
 #define DW2G(KV, SHV, SWV, THV)                                                                                                                             \
     do {                                                                                                                                                    \
         if (lds > 64 * 1024) {                                                                                                                              \
-            static const bool once = [] {                                                                                                                   \
-                OAR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dw_tiled_kernel<KV, SHV, SWV, TW, THV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); \
-                return true;                                                                                                                                \
-            }();                                                                                                                                            \
-            (void)once;                                                                                                                                     \
+            OAR_MAX_LDS_ONCE((conv_dw_tiled_kernel<KV, SHV, SWV, TW, THV, true>), 96 * 1024);                    \
         }                                                                                                                                                   \
         hipExtLaunchKernelGGL((conv_dw_tiled_kernel<KV, SHV, SWV, TW, THV, true>), g, b, lds, s, ps.start(), ps.stop(), 0, p);                              \
     } while (0)
@@ -1547,11 +1539,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 
 template <int HD>
 static void launch_attention(hipStream_t s, const float* qkv, float* out, int n, int T, int heads, int hd, float scale) {
-    static const bool once = [] {
-        OAR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        return true;
-    }();
-    (void)once;
+    OAR_MAX_LDS_ONCE(attention_kernel<HD>, 160 * 1024);
     const size_t lds = (size_t)2 * T * HD * sizeof(float);
     OAR_CHECK(lds <= 150 * 1024, OAR_UNSUPPORTED_OP, "attention: K and V of one head exceed the LDS staging buffer");
     const int threads = std::min(256, (T + 63) / 64 * 64);

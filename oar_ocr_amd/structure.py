@@ -1,7 +1,9 @@
 """Overall OCR of OARStructure -- the second caller of the text-detection / text-recognition adapters
 (SURVEY 8f rank 1).
 
-Mirrors `OARStructure::run_overall_ocr` (src/oarocr/structure.rs:2208-2540) and
+Mirrors `OARStructure::run_overall_ocr` (src/oarocr/structure.rs:2208-2540),
+`precompute_overall_ocr_across_pages` (src/oarocr/structure.rs:2859-3260: detection batched over the pages of a document, the crops of ALL pages in
+one width-sorted recognition queue, per-page results scattered back) and
 `refine_overall_ocr_with_layout` (src/oarocr/structure.rs:1438-1660): formula masking, text detection on the masked
 page, splitting of text boxes that span several layout containers, reading-order sort, cropping from the unmasked
 page, optional text-line orientation, width-sorted recognition batches, then the two layout-guided refinements
@@ -43,6 +45,18 @@ class LayoutElement:
 @dataclass
 class RegionBlock:
     bbox: np.ndarray
+
+
+@dataclass
+class PreparedPage:
+    """The fields of the reference's PreparedPage that the overall OCR reads and writes (src/oarocr/structure.rs: current_image, layout_elements,
+    detected_region_blocks, precomputed_text_regions).  `error` stands for the page's slot holding Err(..): such pages are skipped, and a page whose
+    own detection / cropping / refinement fails gets its error recorded here instead of aborting the document."""
+    current_image: np.ndarray
+    layout_elements: Sequence[LayoutElement]
+    detected_region_blocks: Optional[Sequence[RegionBlock]] = None
+    precomputed_text_regions: Optional[List["api.TextRegion"]] = None
+    error: Optional[Exception] = None
 
 
 def from_coords(x1, y1, x2, y2) -> np.ndarray:
@@ -162,10 +176,13 @@ class OverallOCR:
     `api.ImageClassifier(input_hw=(80, 160), resize_short=0)`; `formula_recognition` says whether the structure pipeline
     has a formula recogniser attached (only then are formula regions masked before detection, structure.rs:2228-2241)."""
 
-    def __init__(self, det, rec, text_line_orientation=None, region_batch_size: Optional[int] = None, formula_recognition: bool = False):
+    def __init__(self, det, rec, text_line_orientation=None, region_batch_size: Optional[int] = None, formula_recognition: bool = False,
+                 image_batch_size: Optional[int] = None, seal_text_detection: bool = False):
         self.det, self.rec, self.line_ori = det, rec, text_line_orientation
         self.region_batch_size = region_batch_size
         self.formula_recognition = formula_recognition
+        self.image_batch_size = image_batch_size          # pipeline.image_batch_size (cross-page detection batches)
+        self.seal_text_detection = seal_text_detection    # a seal detector is attached: the cross-page path stands down (structure.rs:2874-2878)
 
     def _batch_size(self) -> int:
         return max(self.region_batch_size if self.region_batch_size is not None else self.rec.recommended_batch_size(), 1)
@@ -226,6 +243,108 @@ class OverallOCR:
                         regions.append(api.TextRegion(bounding_box=boxes[i], text=rec[0], confidence=rec[1], dt_poly=boxes[i], rec_poly=boxes[i]))
         self._refine(regions, layout_elements, page)
         return regions
+
+    # ------------------------------------------------------------------ the cross-page path
+    def _masked(self, pg: PreparedPage) -> np.ndarray:
+        """The image text detection sees: formula regions painted white when a formula recogniser is attached (structure.rs:2917-2928)."""
+        img = np.ascontiguousarray(pg.current_image, np.uint8)
+        if self.formula_recognition:
+            masks = [e.bbox for e in pg.layout_elements if e.element_type in FORMULA_TYPES]
+            if masks:
+                img = img.copy()
+                mask_regions(img, masks)
+        return img
+
+    def precompute_across_pages(self, prepared_pages: Sequence[PreparedPage]) -> bool:
+        """`precompute_overall_ocr_across_pages` (src/oarocr/structure.rs:2859-3260): fills `precomputed_text_regions` of every page it can.
+        Returns False when the path stands down (seal-enabled pipeline) and nothing was touched.
+
+        Detection runs over the pages in batches of `image_batch_size` (a failed batch falls back to per-page detection of its pages); every page's
+        boxes are split by its containers, sorted and cropped from the unmasked page; the crops of ALL pages form one queue, stably sorted by
+        width / height and recognised in batches of `region_batch_size`; texts go back to (page, detection index); each page is then refined against
+        its own layout.  A page whose own step fails carries the error; the others are unaffected."""
+        if self.seal_text_detection:
+            return False
+        n = len(prepared_pages)
+        live = [i for i, pg in enumerate(prepared_pages) if pg.error is None]
+        det_bs = max(self.image_batch_size if self.image_batch_size is not None else self.det.recommended_batch_size(), 1)
+        # 1. batched detection on the masked pages
+        page_boxes: List[Optional[List[np.ndarray]]] = [None] * n
+        seen = {i: self._masked(prepared_pages[i]) for i in live}
+        for s in range(0, len(live), det_bs):
+            idx = live[s:s + det_bs]
+            try:
+                dets = self.det.predict([seen[i] for i in idx])
+            except api.OCRError:
+                continue                                               # these pages are detected one by one below
+            for i, d in zip(idx, dets):
+                page_boxes[i] = [q.bbox for q in d]
+        # 2. per page: containers, reading order, crops into the document-wide queue
+        boxes_of: List[Optional[List[np.ndarray]]] = [None] * n
+        recognized: List[Optional[list]] = [None] * n
+        queue = []                                                     # (page, detection index, wh ratio, crop)
+        for i in live:
+            pg = prepared_pages[i]
+            boxes = page_boxes[i]
+            if boxes is None:
+                try:
+                    boxes = [q.bbox for q in self.det.predict([seen[i]])[0]]
+                except api.OCRError as e:
+                    pg.error = e
+                    continue
+            if boxes:
+                if pg.detected_region_blocks is not None:
+                    containers = [r.bbox for r in pg.detected_region_blocks]
+                else:
+                    containers = [e.bbox for e in pg.layout_elements if e.element_type in SPLIT_CONTAINER_TYPES]
+                boxes = split_boxes_by_containers(boxes, containers)
+                order = api.host_sort_quad_boxes(np.stack(boxes))
+                boxes = [boxes[k] for k in order]
+            page = np.ascontiguousarray(pg.current_image, np.uint8)
+            try:
+                for k, b in enumerate(boxes):
+                    c = api.k_rotate_crop(page, b) if np.asarray(b).reshape(-1, 2).shape[0] == 4 else crop_bounding_box(page, b)
+                    if c is not None:
+                        queue.append((i, k, F(c.shape[1]) / F(max(c.shape[0], 1)), c))
+            except api.OCRError as e:
+                pg.error = e
+                queue = [q for q in queue if q[0] != i]
+                continue
+            boxes_of[i], recognized[i] = boxes, [None] * len(boxes)
+        # 3. one queue for the whole document: optional line orientation, stable sort by ratio, recognition batches
+        if queue:
+            if self.line_ori is not None:
+                try:
+                    for k, cls in enumerate(self.line_ori.predict([q[3] for q in queue])):
+                        if cls and cls[0].class_id == 1:
+                            queue[k] = queue[k][:3] + (api.k_rotate_rgb(queue[k][3], 2),)
+                except api.OCRError:
+                    pass                                               # "proceeding without rotation"
+            queue.sort(key=lambda q: q[2])
+            bs = self._batch_size()
+            for s in range(0, len(queue), bs):
+                chunk = queue[s:s + bs]
+                try:
+                    r = self.rec.predict([q[3] for q in chunk])
+                except api.OCRError:
+                    continue                                           # the batch is skipped, its slots stay empty
+                for (i, k, _, _), text, score in zip(chunk, r.texts, r.scores):
+                    if text and recognized[i] is not None:
+                        recognized[i][k] = (text, float(score))
+        # 4. per page: regions in detection order, layout-guided refinement
+        for i in live:
+            pg = prepared_pages[i]
+            if pg.error is not None or recognized[i] is None:
+                continue
+            regions = [api.TextRegion(bounding_box=boxes_of[i][k], text=t[0], confidence=t[1], dt_poly=boxes_of[i][k], rec_poly=boxes_of[i][k])
+                       for k, t in enumerate(recognized[i]) if t is not None]
+            try:
+                self._refine(regions, pg.layout_elements, np.ascontiguousarray(pg.current_image, np.uint8))
+            except api.OCRError as e:
+                pg.error = e
+                continue
+            pg.precomputed_text_regions = regions
+        return True
 
     def _refine(self, regions: List[api.TextRegion], layout_elements: Sequence[LayoutElement], page: np.ndarray) -> None:
         """refine_overall_ocr_with_layout (src/oarocr/structure.rs:1438-1660)."""

@@ -231,10 +231,13 @@ class OracleOCR:
         for c0 in range(0, len(order), self.region_bs):
             chunk = [pool[i] for i in order[c0:c0 + self.region_bs]]
             r = self.rec.recognize([c[2] for c in chunk])
-            for j, (img_idx, k, _, _) in enumerate(chunk):
+            # chunk_max_wh_ratio as ocr.rs:828-831 folds it: from the recognizer's base ratio (rec_image_shape w / h) over the chunk's crops, in f32
+            base = np.float32(self.rec.shape[2]) / np.float32(self.rec.shape[1])
+            chunk_max = max([base] + [c[3] for c in chunk])
+            for j, (img_idx, k, _, wh) in enumerate(chunk):
                 s = per_image[img_idx][k]
                 s.update(filled=True, text=r["texts"][j], score=r["scores"][j], idx=r["idx"][j], prob=r["prob"][j],
-                         probs_full=r["probs_full"][j])
+                         probs_full=r["probs_full"][j], cols=r["cols"][j], wh_ratio=wh, max_wh_ratio=chunk_max)
 
 
 def compare_results(got, ref, prob_tol=1e-3, tie_tol=1e-5):

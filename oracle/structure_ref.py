@@ -1,4 +1,6 @@
-"""Oracle for OARStructure's overall OCR: `run_overall_ocr` (src/oarocr/structure.rs:2208-2540) and
+"""Oracle for OARStructure's overall OCR: `run_overall_ocr` (src/oarocr/structure.rs:2208-2540),
+`precompute_overall_ocr_across_pages` (src/oarocr/structure.rs:2859-3260; `precompute` below, written from the Rust statement by statement -- its
+PageOcrState / RecItem records, its four phases -- not from oar_ocr_amd/structure.py) and
 `refine_overall_ocr_with_layout` (src/oarocr/structure.rs:1438-1660) restated over the CPU oracle components
 (C restatement of pre/post + torch-CPU network interpreter).
 
@@ -162,6 +164,129 @@ class OracleOverallOCR:
                             found[i] = (text, float(score))
                 out = [{"box": boxes[i], "text": found[i][0], "score": found[i][1]} for i in range(len(boxes)) if i in found]
         self.refine(out, layout, page)
+        return out
+
+    def precompute(self, prepared_pages, image_batch_size=8, seal_enabled=False):
+        """structure.rs:2859-3260.  prepared_pages: list of dicts {"image", "layout", "region_blocks" (None or list of boxes)} or None for a page
+        whose slot already holds Err.  Returns a list, per page None (Err / not precomputed) or its regions -- or None altogether when the path
+        stands down (:2874-2878, seal detector attached)."""
+        if seal_enabled:                                                        # :2874-2878
+            return None
+        image_batch_size = max(image_batch_size, 1)                             # :2880-2884
+        n_pages = len(prepared_pages)
+        page_states = [None] * n_pages                                          # Vec<Option<PageOcrState>>  :2901-2902
+        rec_items = []                                                          # Vec<RecItem>: dicts page_idx / det_idx / wh_ratio / image
+        batched_detection_boxes = [None] * n_pages                              # :2905-2906
+        out = [None] * n_pages
+
+        def ocr_image_of(prepared):                                             # :2916-2928 (and again :2969-2981)
+            img = np.ascontiguousarray(prepared["image"], np.uint8)
+            if self.formula:
+                mask_bboxes = [b for b, t in prepared["layout"] if t in ("formula", "formula_number")]
+                if mask_bboxes:
+                    img = img.copy()
+                    paint(img, mask_bboxes)
+            return img
+
+        # phase 1 (:2908-2961): detection over chunks of image_batch_size pages
+        det_page_indices, det_images = [], []
+        for page_idx, prepared in enumerate(prepared_pages):
+            if prepared is None:
+                continue
+            det_page_indices.append(page_idx)
+            det_images.append(ocr_image_of(prepared))
+        for start in range(0, len(det_page_indices), image_batch_size):
+            batch_page_indices = det_page_indices[start:start + image_batch_size]
+            det_result = self.det.detect(det_images[start:start + image_batch_size], *self.p)
+            for offset, (boxes, _scores, _prob) in enumerate(det_result):
+                batched_detection_boxes[batch_page_indices[offset]] = [np.asarray(b, np.float32).reshape(4, 2) for b in boxes]
+
+        # phase 2 (:2963-3128): per page -- split by containers, sort, crop; crops join the document's RecItem list
+        for page_idx in range(n_pages):
+            prepared = prepared_pages[page_idx]
+            if prepared is None:
+                continue
+            detection_boxes = batched_detection_boxes[page_idx]
+            batched_detection_boxes[page_idx] = None                            # .take()
+            if detection_boxes is None:                                         # per-page fallback of a failed batch (:2968-3007)
+                boxes, _, _ = self.det.detect([ocr_image_of(prepared)], *self.p)[0]
+                detection_boxes = [np.asarray(b, np.float32).reshape(4, 2) for b in boxes]
+            if detection_boxes:                                                 # :3009-3092
+                split_boxes = []
+                if prepared.get("region_blocks") is not None:
+                    container_boxes = list(prepared["region_blocks"])
+                else:
+                    container_boxes = [b for b, t in prepared["layout"] if t in TEXTUAL]
+                if container_boxes:
+                    for bbox in detection_boxes:
+                        intersections = []
+                        self_area = shoelace(bbox)
+                        if self_area <= 0:
+                            split_boxes.append(bbox)
+                            continue
+                        b0, b1, b2, b3 = extent(bbox)
+                        for container in container_boxes:
+                            c0, c1, c2, c3 = extent(container)
+                            ix0, iy0, ix1, iy1 = max(b0, c0), max(b1, c1), min(b2, c2), min(b3, c3)
+                            if f32(ix1 - ix0) <= 2 or f32(iy1 - iy0) <= 2:
+                                continue
+                            inter_bbox = rect(ix0, iy0, ix1, iy1)
+                            inter_area = shoelace(inter_bbox)
+                            if inter_area <= 0:
+                                continue
+                            if f32(inter_area / self_area) >= SPLIT_IOA:
+                                intersections.append(inter_bbox)
+                        if len(intersections) >= 2:
+                            split_boxes.extend(intersections)
+                        else:
+                            split_boxes.append(bbox)
+                    detection_boxes = split_boxes
+            if detection_boxes:                                                 # :3094-3096
+                detection_boxes = [detection_boxes[i] for i in R.sort_quad_boxes(np.stack(detection_boxes))]
+            state = {"recognized": [None] * len(detection_boxes), "detection_boxes": detection_boxes}   # :3098-3101
+            if state["detection_boxes"]:                                        # :3103-3126, TextCroppingProcessor::new(true) on the UNMASKED page
+                page = np.ascontiguousarray(prepared["image"], np.uint8)
+                for det_idx, bbox in enumerate(state["detection_boxes"]):
+                    img = R.rotate_crop(page, bbox)
+                    if img is None:
+                        continue
+                    wh_ratio = f32(img.shape[1]) / f32(max(img.shape[0], 1))
+                    rec_items.append({"page_idx": page_idx, "det_idx": det_idx, "wh_ratio": wh_ratio, "image": img})
+            page_states[page_idx] = state
+
+        # phase 3 (:3131-3210): text-line orientation over ALL items, stable sort by wh_ratio, recognition chunks
+        if rec_items:
+            if self.line is not None:
+                for item, (ids, _) in zip(rec_items, self.line.classify([it["image"] for it in rec_items])):
+                    if int(ids[0]) == 1:
+                        item["image"] = R.rotate_rgb(item["image"], 2)
+            rec_items.sort(key=lambda it: it["wh_ratio"])                       # sort_by(partial_cmp): stable
+            start = 0
+            while start < len(rec_items):
+                end = min(start + self.bs, len(rec_items))
+                chunk = rec_items[start:end]
+                rec_result = self.rec.recognize([it["image"] for it in chunk])
+                for i, item in enumerate(chunk):
+                    text = rec_result["texts"][i]
+                    if text == "":
+                        continue
+                    page_states[item["page_idx"]]["recognized"][item["det_idx"]] = (text, float(rec_result["scores"][i]))
+                start = end
+
+        # phase 4 (:3218-3262): regions in detection order, refined against the page's own layout
+        for page_idx in range(n_pages):
+            state = page_states[page_idx]
+            page_states[page_idx] = None
+            if state is None or prepared_pages[page_idx] is None:
+                continue
+            prepared = prepared_pages[page_idx]
+            text_regions = []
+            for det_idx, rec in enumerate(state["recognized"]):
+                if rec is None:
+                    continue
+                text_regions.append({"box": state["detection_boxes"][det_idx], "text": rec[0], "score": rec[1]})
+            self.refine(text_regions, prepared["layout"], np.ascontiguousarray(prepared["image"], np.uint8))
+            out[page_idx] = text_regions
         return out
 
     def refine(self, regions, layout, page):

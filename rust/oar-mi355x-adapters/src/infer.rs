@@ -66,7 +66,7 @@ impl Mi355xInfer {
     pub fn new(model_source: impl Into<ModelSource>, input_name: Option<&str>, device_id: i32) -> Result<Self, OCRError> {
         let source: ModelSource = model_source.into();
         let (bytes, shown) = model_bytes(&source)?;
-        let cfg = sys::oar_engine_cfg { device_id, use_hip_graph: 0, profile: 0, reserved: 0 };
+        let cfg = sys::oar_engine_cfg { device_id, use_hip_graph: 0, profile: 0, precision: sys::OAR_PRECISION_F32 as i32, stream: std::ptr::null_mut() };
         let mut raw: *mut sys::oar_engine = std::ptr::null_mut();
         // SAFETY: bytes valid for bytes.len(); cfg / raw valid for the call.
         let status = unsafe { sys::oar_engine_create(bytes.as_ptr(), bytes.len(), &cfg, &mut raw) };

@@ -19,6 +19,9 @@ pub const OAR_DEVICE: oar_status = 5;
 pub const OAR_OOM: oar_status = 6;
 pub const OAR_INTERNAL: oar_status = 7;
 
+pub type oar_precision = c_int;
+pub const OAR_PRECISION_F32: oar_precision = 0;
+
 pub type oar_dtype = c_int;
 pub const OAR_DTYPE_F32: oar_dtype = 1;
 pub const OAR_DTYPE_I64: oar_dtype = 7;
@@ -81,7 +84,8 @@ pub struct oar_engine_cfg {
     pub device_id: i32,
     pub use_hip_graph: i32,
     pub profile: i32,
-    pub reserved: i32,
+    pub precision: i32,
+    pub stream: *mut c_void,
 }
 
 #[repr(C)]
@@ -421,6 +425,7 @@ unsafe extern "C" {
     pub fn oar_host_sort_poly_boxes(pts_xy: *const f32, offsets: *const u32, n: i32, order: *mut i32);
     /// fixed-length arrays: box8: [f32; 8]
     pub fn oar_host_mini_box(xy: *const f32, n_points: i32, box8: *mut f32, min_side: *mut f32) -> i32;
+    pub fn oar_host_convex_hull(xy: *const f32, n_points: i32, out_xy: *mut f32, cap_points: i32) -> i32;
     pub fn oar_host_sort_quad_boxes(boxes8: *const f32, n: i32, order: *mut i32);
     pub fn oar_host_pool_selftest(threads: i32, jobs: i32) -> i32;
     /// fixed-length arrays: box8: [f32; 8], plan: [i32; 8], inv: [f32; 9]

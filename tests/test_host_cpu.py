@@ -182,3 +182,82 @@ print(n, h.hexdigest())
     outs = [subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OAR_HOST_FAST=v), capture_output=True, text=True, timeout=600) for v in ("0", "1")]
     assert all(o.returncode == 0 for o in outs), outs[0].stderr[-2000:] + outs[1].stderr[-2000:]
     assert outs[0].stdout == outs[1].stdout and int(outs[0].stdout.split()[0]) > 100
+
+
+def test_convex_hull_fast_path_equals_an_exact_integer_graham_scan():
+    """db_host.cc's convex_hull keeps only each row's leftmost / rightmost point before the Graham sort when the points are integer border
+    pixels inside a <= 1000 px diagonal, on the argument that every float quantity of the scan is then exact.  Checked here against a scan in exact
+    integer arithmetic (Python ints: angle order by cross-product sign, ties by squared distance, pop on cross <= 0 -- geometry.rs:226-271 with no
+    rounding anywhere) instead of only against the library's own slow route: blobs, thin diagonals (many collinear points), duplicates, full rows."""
+    from functools import cmp_to_key
+    rng = np.random.default_rng(11)
+
+    def exact_hull(pts):
+        pts = [(int(x), int(y)) for x, y in pts]
+        si = min(range(len(pts)), key=lambda i: (pts[i][1], pts[i][0]))      # first of the lowest-then-leftmost points (strict < in the scan for the start)
+        s = pts[si]
+        rest = [(i, p) for i, p in enumerate(pts) if i != si]
+
+        def cmp(a, b):
+            (ia, pa), (ib, pb) = a, b
+            ax, ay, bx, by = pa[0] - s[0], pa[1] - s[1], pb[0] - s[0], pb[1] - s[1]
+            # all points have y >= s.y: angles lie in [0, pi]; (0, 0) has atan2 = 0 like the +x ray
+            cr = ax * by - ay * bx
+            za, zb = (ax == 0 and ay == 0), (bx == 0 and by == 0)
+            if za or zb:
+                ka = 0 if (za or (ay == 0 and ax > 0)) else 1
+                kb = 0 if (zb or (by == 0 and bx > 0)) else 1
+                if ka != kb:
+                    return -1 if ka < kb else 1
+                if ka == 1:
+                    return 0 if ia == ib else (-1 if ia < ib else 1)
+            elif cr != 0:
+                return -1 if cr > 0 else 1
+            elif ax * bx + ay * by < 0:                                      # opposite rays on the start row: angle 0 before angle pi
+                return -1 if ax > 0 else 1
+            da, db = ax * ax + ay * ay, bx * bx + by * by
+            if da != db:
+                return -1 if da < db else 1
+            return -1 if ia < ib else (1 if ia > ib else 0)
+        rest.sort(key=cmp_to_key(cmp))
+        hull = []
+        for p in [s] + [p for _, p in rest]:
+            while len(hull) > 1:
+                a, b = hull[-2], hull[-1]
+                if (b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0]) <= 0:
+                    hull.pop()
+                else:
+                    break
+            hull.append(p)
+        return np.asarray(hull, np.float32)
+
+    n_cases = 0
+    for case in range(400):
+        kind = case % 4
+        if kind == 0:      # a filled blob's pixels
+            w, h = int(rng.integers(8, 300)), int(rng.integers(4, 60))
+            n = int(rng.integers(13, 400))
+            pts = np.stack([rng.integers(0, w, n), rng.integers(0, h, n)], 1)
+        elif kind == 1:    # a thin diagonal band: long collinear runs
+            n = int(rng.integers(13, 200))
+            t = rng.integers(0, 300, n)
+            pts = np.stack([t * 2 + rng.integers(0, 2, n), t + rng.integers(0, 2, n)], 1)
+        elif kind == 2:    # a rectangle border with duplicates
+            w, h = int(rng.integers(5, 400)), int(rng.integers(3, 50))
+            xs = np.concatenate([np.arange(w), np.full(h, w - 1), np.arange(w)[::-1], np.zeros(h, int)])
+            ys = np.concatenate([np.zeros(w, int), np.arange(h), np.full(w, h - 1), np.arange(h)[::-1]])
+            pts = np.stack([xs, ys], 1)
+            pts = np.concatenate([pts, pts[rng.integers(0, len(pts), 10)]])
+        else:              # a rotated text-line outline
+            ang = rng.uniform(-0.5, 0.5)
+            L, H = rng.uniform(40, 600), rng.uniform(8, 40)
+            u = rng.uniform(0, 1, (200, 2)) * [L, H]
+            pts = np.round(u @ np.array([[np.cos(ang), np.sin(ang)], [-np.sin(ang), np.cos(ang)]]) + 300).astype(int)
+        pts = pts + np.array([int(rng.integers(0, 2000)), int(rng.integers(0, 2000))])
+        if np.hypot(np.ptp(pts[:, 0]), np.ptp(pts[:, 1])) > 1000 or len(pts) <= 12:
+            continue
+        got = api.host_convex_hull(pts.astype(np.float32))
+        want = exact_hull(pts)
+        assert got.shape == want.shape and np.array_equal(got, want), (case, kind, got, want)
+        n_cases += 1
+    assert n_cases > 300

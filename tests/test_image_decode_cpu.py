@@ -454,6 +454,18 @@ def test_bmp_variants_pil_cannot_write():
     got = api.load_image_from_memory(data)
     assert np.array_equal(got, palette[want_idx])
     assert np.array_equal(np.asarray(Image.open(io.BytesIO(data)).convert("RGB")), got)
+    # a SPARSE RLE8 page: 600 x 400 pixels in 18 bytes -- one run, end-of-line escapes, a delta and end-of-bitmap; every skipped pixel
+    # stays at palette entry 0.  (Round 5's pre-check wanted two bytes per 255 pixels and refused such files as truncated.)
+    sparse = bytes([5, 9, 0, 0, 0, 0, 0, 2, 10, 3, 2, 200, 0, 0, 0, 0, 0, 1])
+    want_idx = np.zeros((400, 600), np.uint8)
+    want_idx[399, 0:5] = 9
+    want_idx[399 - 2 - 3, 10:12] = 200
+    info = struct.pack("<IiiHHIIiiII", 40, 600, 400, 1, 8, 1, len(sparse), 0, 0, 256, 0)
+    data = bmp(info, sparse, b"".join(bytes(c[::-1]) + b"\0" for c in palette))
+    got = api.load_image_from_memory(data)
+    assert np.array_equal(got, palette[want_idx])                    # (PIL's own RLE decoder refuses this file as "not enough image data"; the image crate zero-fills)
+    with pytest.raises(api.OCRError):                                # a stream too short to even hold the end-of-bitmap marker
+        api.load_image_from_memory(bmp(struct.pack("<IiiHHIIiiII", 40, 600, 400, 1, 8, 1, 1, 0, 0, 256, 0), b"\0", b"".join(bytes(c[::-1]) + b"\0" for c in palette)))
 
 
 def test_ascii_pnm_and_gif_frame_inside_the_screen():

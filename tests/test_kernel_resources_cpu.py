@@ -75,7 +75,7 @@ def test_output_stationary_kernel_fits_two_workgroups_per_cu():
     """igemm_os_x6.hip: 256-thread workgroups, two per CU (they overlap each other's barrier / split phases) -- needs <= 256
     registers per lane; today 186-256 with at most 4 spilled dwords in the 8-fragment k x k variant."""
     ks = {k: v for k, v in _resources("igemm_os_x6.hip").items() if "conv_igemm_os_x6_kernel" in k}
-    assert len(ks) == 4
+    assert len(ks) == 6      # 8 / 4 / 2 cout fragments (round 6: 2 for the 32-channel groups of a grouped convolution) x {1x1, k x k}
     for name, r in ks.items():
         assert r["vgprs"] <= 256 and r["spill"] <= 8 and r["scratch"] <= 64, (name, r)
 
@@ -114,3 +114,13 @@ def test_round5_kernels_fit_their_wave_budgets():
     assert len(ch) == 2
     for name, r in ch.items():
         assert r["vgprs"] <= 168 and r["spill"] == 0 and r["scratch"] == 0 and r["occupancy"] >= 3, (name, r)
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
+def test_streaming_attention_kernel_fits_two_waves_per_simd():
+    """attention_x6.hip (round 6): query planes + two accumulator sets + one block's K / V / P fragments per wave -- no scratch, <= 256 registers so that two
+    workgroups (8 waves) share a CU and one's soft-max (VALU) phase overlaps the other's MFMA phase."""
+    ks = {k: v for k, v in _resources("attention_x6.hip").items() if "attention_x6_kernel" in k}
+    assert len(ks) == 1
+    for name, r in ks.items():
+        assert r["spill"] == 0 and r["scratch"] == 0 and r["vgprs"] <= 256 and r["occupancy"] >= 2, (name, r)

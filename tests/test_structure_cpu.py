@@ -73,3 +73,107 @@ def test_split_boxes_by_containers_matches_oracle_rule():
     assert np.array_equal(got[0], S.from_coords(20, 50, 100, 72)) and np.array_equal(got[1], S.from_coords(100, 50, 180, 72))
     assert got[2] is narrow and got[3] is sliver
     assert S.split_boxes_by_containers([wide], []) == [wide]
+
+
+# ------------------------------------------------------------------------------------------------ the cross-page control flow, no GPU
+class _Det:
+    """Stub text detector: one box per dark row band of the page's red channel; `fail_batches` makes every multi-page call raise."""
+    def __init__(self, fail_batches=False, fail_pages=()):
+        self.calls, self.fail_batches, self.fail_pages = [], fail_batches, set(fail_pages)
+
+    @staticmethod
+    def recommended_batch_size():
+        return 8
+
+    def predict(self, images):
+        from oar_ocr_amd import api
+        self.calls.append(len(images))
+        if self.fail_batches and len(images) > 1:
+            raise api.OCRError(6, "batched detection failed")
+        out = []
+        for im in images:
+            if int(im[0, 0, 2]) in self.fail_pages:
+                raise api.OCRError(6, "page detection failed")
+            rows = np.nonzero(im[:, 0, 0] == 0)[0]
+            boxes, start = [], None
+            for y in range(im.shape[0] + 1):
+                dark = y < im.shape[0] and im[y, 0, 0] == 0
+                if dark and start is None:
+                    start = y
+                if not dark and start is not None:
+                    boxes.append(type("D", (), {"bbox": S.from_coords(4, start, im.shape[1] - 4 - 10 * len(boxes), y)})())
+                    start = None
+            out.append(boxes)
+        return out
+
+
+class _Rec:
+    """Stub recognizer: text = "<w>x<h>" of the crop; the batch whose first crop is `poison` wide raises."""
+    def __init__(self, poison=None):
+        self.batches, self.poison = [], poison
+
+    @staticmethod
+    def recommended_batch_size():
+        return 64
+
+    def predict(self, crops):
+        from oar_ocr_amd import api
+        self.batches.append([c.shape[1] for c in crops])
+        if self.poison is not None and crops and crops[0].shape[1] == self.poison:
+            raise api.OCRError(6, "recognition batch failed")
+        return type("R", (), {"texts": [f"{c.shape[1]}x{c.shape[0]}" for c in crops], "scores": [0.9] * len(crops)})()
+
+
+def _banded_page(tag, w, bands):
+    im = np.full((120, w, 3), 255, np.uint8)
+    for y0, y1 in bands:
+        im[y0:y1] = 0
+    im[0, 0, 2] = tag
+    return im
+
+
+def test_cross_page_overall_ocr_control_flow(monkeypatch):
+    """precompute_overall_ocr_across_pages (structure.rs:2859-3260) over stub adapters: detection batches of image_batch_size with per-page fallback
+    after a failed batch, a page whose own detection fails carries the error alone, one document-wide queue sorted by crop ratio and cut into
+    region_batch_size chunks, a failed recognition chunk leaves its slots empty, texts return to (page, detection) slots, seal stand-down."""
+    from oar_ocr_amd import api
+    monkeypatch.setattr(api, "k_rotate_crop", lambda page, b: S.crop_bounding_box(page, b))
+    monkeypatch.setattr(api, "host_sort_quad_boxes", lambda boxes: sorted(range(len(boxes)), key=lambda i: (float(boxes[i][:, 1].min()), float(boxes[i][:, 0].min()))))
+    pages_ = [_banded_page(1, 200, [(10, 30), (50, 70)]), _banded_page(2, 300, [(20, 40)]), _banded_page(3, 100, [(5, 25), (40, 60), (80, 100)])]
+
+    def prepared():
+        return [S.PreparedPage(p, []) for p in pages_]
+
+    # plain run: one detection call of 3 pages; six crops in ONE queue sorted by ratio, chunks of 4
+    det, rec = _Det(), _Rec()
+    pp = prepared()
+    assert S.OverallOCR(det, rec, region_batch_size=4, image_batch_size=8).precompute_across_pages(pp) is True
+    assert det.calls == [3]
+    widths = [w for b in rec.batches for w in b]
+    assert len(rec.batches) == 2 and len(rec.batches[0]) == 4 and widths == sorted(widths)            # every band is 20 px tall: ratio order = width order
+    assert [[r.text for r in p.precomputed_text_regions] for p in pp] == [["192x20", "182x20"], ["292x20"], ["92x20", "82x20", "72x20"]]
+    # image_batch_size 2 -> calls of 2 + 1; a failing batch falls back to per-page calls for ITS pages only
+    det = _Det(fail_batches=True)
+    pp = prepared()
+    S.OverallOCR(det, _Rec(), region_batch_size=64, image_batch_size=2).precompute_across_pages(pp)
+    assert det.calls == [2, 1, 1, 1] and all(p.error is None and p.precomputed_text_regions for p in pp)
+    # a page whose own detection fails (after its batch failed) keeps the error; the others are complete
+    det = _Det(fail_batches=True, fail_pages=(2,))
+    pp = prepared()
+    S.OverallOCR(det, _Rec(), region_batch_size=64, image_batch_size=3).precompute_across_pages(pp)
+    assert isinstance(pp[1].error, api.OCRError) and pp[1].precomputed_text_regions is None
+    assert len(pp[0].precomputed_text_regions) == 2 and len(pp[2].precomputed_text_regions) == 3
+    # a failed recognition chunk: its crops stay unrecognised (no region), later chunks still run
+    rec = _Rec(poison=72)
+    pp = prepared()
+    S.OverallOCR(_Det(), rec, region_batch_size=2, image_batch_size=8).precompute_across_pages(pp)
+    assert [[r.text for r in p.precomputed_text_regions] for p in pp] == [["192x20", "182x20"], ["292x20"], ["92x20"]]
+    # pages already in error are skipped; seal-enabled pipelines stand down before touching anything
+    pp = prepared()
+    pp[0].error = RuntimeError("decode")
+    det = _Det()
+    S.OverallOCR(det, _Rec(), image_batch_size=8).precompute_across_pages(pp)
+    assert det.calls == [2] and pp[0].precomputed_text_regions is None
+    pp = prepared()
+    det = _Det()
+    assert S.OverallOCR(det, _Rec(), seal_text_detection=True).precompute_across_pages(pp) is False and det.calls == [] and pp[0].precomputed_text_regions is None
