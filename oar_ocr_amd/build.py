@@ -14,7 +14,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIBDIR = HERE / "lib"
 LIB = LIBDIR / "libOarMi355x.so"
-SOURCES = ["common.cc", "onnx_parse.cc", "engine.cc", "db_host.cc", "poly_host.cc", "pipeline.cc", "c_api.cc", "ctc_host.cc", "image_decode.cc", "image_misc_decode.cc", "jpeg_decode.cc", "layout.cc", "kernels.hip", "igemm.hip", "igemm_ws_1x1.hip", "igemm_ws_gen.hip", "igemm_ws_x6.hip", "igemm_os_x6.hip", "igemm_ws3.hip", "igemm_rs3_x6.hip", "prepost.hip", "contours.hip", "jpeg.hip", "layout.hip", "dsblock.hip", "dsblock_k3s1.hip", "dsblock_k3s2.hip", "dsblock_k5s1.hip", "dsblock_k5s2.hip", "dsblock_wa_a.hip", "dsblock_wa_b.hip", "dsblock_rs_k3s11.hip", "dsblock_rs_k3s21.hip", "dsblock_rs_k3s12.hip", "dsblock_rs_k3s22.hip", "dsblock_rs_dbg.hip", "dsblock_cs.hip", "dsblock_pc.hip", "dsblock_rs2.hip", "ctc_head_x6.hip", "chain.hip", "attention_x6.hip"]
+SOURCES = ["common.cc", "onnx_parse.cc", "engine.cc", "db_host.cc", "poly_host.cc", "pipeline.cc", "c_api.cc", "ctc_host.cc", "image_decode.cc", "image_misc_decode.cc", "jpeg_decode.cc", "layout.cc", "kernels.hip", "igemm.hip", "igemm_ws_1x1.hip", "igemm_ws_gen.hip", "igemm_ws_x6.hip", "igemm_os_x6.hip", "igemm_ws3.hip", "igemm_rs3_x6.hip", "prepost.hip", "contours.hip", "jpeg.hip", "layout.hip", "dsblock.hip", "dsblock_k3s1.hip", "dsblock_k3s2.hip", "dsblock_k5s1.hip", "dsblock_k5s2.hip", "dsblock_wa_a.hip", "dsblock_wa_b.hip", "dsblock_rs_k3s11.hip", "dsblock_rs_k3s21.hip", "dsblock_rs_k3s12.hip", "dsblock_rs_k3s22.hip", "dsblock_rs_dbg.hip", "dsblock_cs.hip", "dsblock_pc.hip", "dsblock_rs2.hip", "ctc_head_x6.hip", "chain.hip", "attention_x6.hip", "igemm_lk_x6.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wno-unused-result", "-Wno-pass-failed"]

@@ -1531,7 +1531,9 @@ struct Planner {
             kind = 0;
             const bool is1x1 = kh == 1 && kw == 1 && sh == 1 && sw == 1 && pt == 0 && pl == 0;
             const bool same3x3 = kh == 3 && kw == 3 && sh == 1 && sw == 1 && pt == 1 && pl == 1 && dh == 1 && dw == 1 && Ho == H && Wo == Wd && n.residual.empty();
-            p.w_fmt = k::igemm_weight_format((long)(N * Ho * Wo), (int)(kh * kw * Cin), (int)Cout, is1x1, (int)Cin, same3x3 ? (long)(H * Wd) : 0);
+            const bool lk_ok = !(n.in.size() > 3 && !n.in[3].empty()) && res_up == 0 &&
+                               k::conv_lk_x6_eligible((int)kh, (int)kw, (int)sh, (int)sw, (int)pt, (int)pl, (int)dh, (int)dw, (int)H, (int)Wd, (int)Ho, (int)Wo, (int)Cin, (int)Cout, (int)(4 * Cout), (long)(N * Ho * Wo));
+            p.w_fmt = k::igemm_weight_format((long)(N * Ho * Wo), (int)(kh * kw * Cin), (int)Cout, is1x1, (int)Cin, same3x3 ? (long)(H * Wd) : 0, lk_ok);
             p.w = conv_weight_igemm(n, W, p.w_fmt);
         }
         else if (g == Cin && g == Cout && Cout % 4 == 0) { kind = 1; p.w = conv_weight_dw(n, W); }

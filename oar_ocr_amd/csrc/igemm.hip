@@ -243,13 +243,14 @@ static bool os_x6_eligible(long M, int K, int N, int Cin, bool grouped = false) 
 std::vector<int> conv3x3_n16_slices(long M, int Cin, int Cout, long img_px, int y_ld) { return conv3x3_n16_x6_slices(M, Cin, Cout, img_px, y_ld); }
 bool conv_grouped_x6_ok(long M, int K, int N, int Cin) { return os_mode() != 0 && os_x6_eligible(M, K, N, Cin, true); }
 
-int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin, long same3x3_px) {
+int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin, long same3x3_px, bool lk_ok) {
     // OAR_IGEMM_X6: 1 (default) = bf16x6 kernels on the wide layers, 0 = f32 MFMA everywhere
     static const int mode = [] { const char* e = getenv("OAR_IGEMM_X6"); return e ? atoi(e) : 1; }();
     if (!mode) return IGEMM_W_K16;
     // (decided before the output's leading dimension is final -- a Concat may place the layer in a wider buffer: the 2^31-byte bound of the kernel's
     // output descriptor is checked here for up to four equal branches; launch time re-checks with the real y_ld and fails loudly, never falls through)
     if (!is1x1 && same3x3_px > 0 && K == 9 * Cin && conv3x3_n16_x6_eligible(M, Cin, N, same3x3_px, 4 * N)) return IGEMM_W_X6;
+    if (!is1x1 && lk_ok) return IGEMM_W_X6;   // large-kernel same convolution: LDS-tiled bf16x6 kernel, whatever the pixel count
     if (!is1x1) return (os_mode() && Cin > 0 && os_x6_eligible(M, K, N, Cin)) ? IGEMM_W_X6 : IGEMM_W_K16;
     // every lane's 8-float group must be all-valid or all-padding (K % 8); wide enough to be matrix-pipe bound
     // (N >= 96, K >= 96); enough (16-pixel tile, cout tile) pairs to fill the 4096 resident waves; float4 epilogue
@@ -373,12 +374,19 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     double flops = 2.0 * (double)p.M * p.K * p.gemm_cout;
     double bytes = 4.0 * ((double)c.N * c.H * c.W * c.Cin + (double)p.M * p.gemm_cout + (double)p.K * p.gemm_cout);
     char pname[96];
-    const bool x6_os = x6 && !c.ctc_part && (!is1x1 || ws_x6_tile(p.K, nfrag) == 0 || (os_mode() == 2 && os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin)));
+    // wide 1x1 layers whose weight-stationary tile is down to 4 cout fragments (K >= 320: 64 couts x K x 96 B of LDS) make >= 8 passes over their pixels -- each pass
+    // re-reading and re-splitting them; there the output-stationary kernel's 128-cout tiles win (SVTRv2's 384 -> 1152 projection: 130 -> 199 TFLOP/s).  OAR_IGEMM_OS_WIDE=0 off
+    static const bool os_wide = [] { const char* e = getenv("OAR_IGEMM_OS_WIDE"); return !e || atoi(e) != 0; }();
+    const bool prefer_os = os_wide && os_mode() != 0 && x6 && is1x1 && !c.convt2x2 && !c.se && !c.ctc_part && p.gemm_cout >= 512 && ws_x6_tile(p.K, nfrag) > 0 && ws_x6_tile(p.K, nfrag) <= 4 &&
+                           os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin);
+    const bool x6_os = x6 && !c.ctc_part && (!is1x1 || ws_x6_tile(p.K, nfrag) == 0 || prefer_os || (os_mode() == 2 && os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin)));
     const bool rs3_cls = x6 && !c.convt2x2 && c.kh == 3 && c.kw == 3 && c.sh == 1 && c.sw == 1 && c.pt == 1 && c.pl == 1 && c.dh == 1 && c.dw == 1 && c.Ho == c.H && c.Wo == c.W && !c.residual && !c.se &&
                          !c.ctc_part && conv3x3_n16_x6_eligible(p.M, c.Cin, c.Cout, (long)c.H * c.W, c.y_ld);
-    const char* cls = rs3_cls ? "conv_rs3_x6" : x6_os ? "conv_igemm_os_x6" : x6 ? "conv_igemm_ws_x6" : ws ? "conv_igemm_ws" : "conv_igemm";   // one profiler class per kernel
+    const bool lk = x6 && !grouped && !c.ctc_part && !c.se && !c.convt2x2 && !is1x1 &&
+                    conv_lk_x6_eligible(c.kh, c.kw, c.sh, c.sw, c.pt, c.pl, c.dh, c.dw, c.H, c.W, c.Ho, c.Wo, c.Cin, c.Cout, c.y_ld, p.M);
+    const char* cls = lk ? "conv_lk_x6" : rs3_cls ? "conv_rs3_x6" : x6_os ? "conv_igemm_os_x6" : x6 ? "conv_igemm_ws_x6" : ws ? "conv_igemm_ws" : "conv_igemm";   // one profiler class per kernel
     if (Profiler::get().detail) {
-        snprintf(pname, sizeof pname, "conv_igemm%s M=%ld K=%d N=%d k%dx%d s%d%s", rs3_cls ? "_rs3_x6" : x6_os ? "_os_x6" : x6 ? "_x6" : ws ? "_ws" : "", p.M, p.K, p.gemm_cout, c.kh, c.kw, c.sh, c.convt2x2 ? " convT" : "");
+        snprintf(pname, sizeof pname, "conv_igemm%s M=%ld K=%d N=%d k%dx%d s%d%s", lk ? "_lk_x6" : rs3_cls ? "_rs3_x6" : x6_os ? "_os_x6" : x6 ? "_x6" : ws ? "_ws" : "", p.M, p.K, p.gemm_cout, c.kh, c.kw, c.sh, c.convt2x2 ? " convT" : "");
         cls = pname;
     }
     ProfScope ps(s, cls, bytes, flops);
@@ -400,14 +408,16 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     OAR_CHECK(!(x6 && same3x3 && c.Cout <= 16) || rs3, OAR_INTERNAL, "conv_igemm: 3x3 / Cout <= 16 bf16x6 weights but the row-streaming kernel's launch-time conditions do not hold (y_ld / output size / residual / gate changed after planning)");
     OAR_CHECK(!grouped || (x6 && !is1x1 && !c.ctc_part && !c.se && !c.convt2x2 && (rs3 || !(same3x3 && c.Cout <= 16))), OAR_INTERNAL, "conv_igemm: x_ld on a layer that runs on neither kernel that reads x with a stride of its own");
     OAR_CHECK(!c.accum || rs3, OAR_INTERNAL, "conv_igemm: accumulate flag on a layer that does not run on the row-streaming 3x3 kernel");
-    if (ws3) {
+    if (lk) {
+        conv_lk_x6(s, p, c.N);
+    } else if (ws3) {
         conv_igemm_ws3(s, p, nfrag);
     } else if (rs3) {
         conv3x3_n16_x6(s, p, c.N);
     } else if (x6) {
         const int nt = c.ctc_part ? 8 : is1x1 ? ws_x6_tile(p.K, nfrag) : 0;
         OAR_CHECK(((p.Cout & 3) == 0) && ((p.y_ld & 3) == 0) && !c.convt2x2, OAR_INTERNAL, "conv_igemm: bf16x6 weights on an ineligible layer");
-        const bool os = !c.ctc_part && (nt == 0 || (os_mode() == 2 && os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin)));
+        const bool os = !c.ctc_part && (nt == 0 || prefer_os || (os_mode() == 2 && os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin)));
         OAR_CHECK(!c.se || (!os && !c.ctc_part && is1x1), OAR_INTERNAL, "conv_igemm: gate on a layer the weight-stationary x6 kernel does not take");
         if (os) {
             OAR_CHECK(os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin, grouped), OAR_INTERNAL, "conv_igemm: bf16x6 weights on a layer neither x6 kernel takes");

@@ -255,6 +255,8 @@ void conv_igemm_ws3(hipStream_t s, const IgemmP& p, int nfrag);
 // igemm_rs3_x6.hip: 3x3 same convolution, Cin 32 / 64, <= 16 output channels, bf16x6, row-streaming (weights IGEMM_W_X6)
 bool conv3x3_n16_x6_eligible(long M, int Cin, int Cout, long img_px, int y_ld);
 std::vector<int> conv3x3_n16_x6_slices(long M, int Cin, int Cout, long img_px, int y_ld);
+// igemm_lk_x6.hip: k x k same convolution from an LDS-staged halo tile (k = 9), bf16x6, weights IGEMM_W_X6
+void conv_lk_x6(hipStream_t s, const IgemmP& p, int n_images);
 void conv3x3_n16_x6(hipStream_t s, const IgemmP& p, int n_images);
 
 }  // namespace k

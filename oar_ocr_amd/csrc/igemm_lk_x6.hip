@@ -1,0 +1,246 @@
+// igemm_lk_x6.hip -- large-kernel "same" convolutions (k x k, stride 1, pad k / 2; the 9 x 9 convolutions of the LK-PAN neck: K = 81 Cin up to 20 736)
+// on the bf16 matrix pipe with f32-equivalent accuracy (bf16x6), from an LDS-STAGED im2col TILE (round 6; BASELINE C3).
+//
+// The output-stationary kernel (igemm_os_x6.hip) ran these layers at 0.41 of the bf16x6 roof: every wave fetches its pixel fragments from L2 once
+// PER TAP -- each input element 81 times -- and splits them into the three bf16 pieces 81 times: 43 B / clock / CU of L1 traffic and as many
+// vector-ALU clocks for the split as the matrix pipe needs for the products.  Here both are paid once per input element and tile:
+//
+//   * a workgroup (4 waves) owns an 8-row x 32-column output tile of one image and all (<= 64) output channels; a wave owns 2 rows = 4 pixel
+//     fragments x 4 cout fragments = 16 accumulators;
+//   * for each 32-channel chunk of the input the tile's HALO ((8 + k - 1) x (32 + k - 1) pixels; out-of-image pixels zero) is loaded ONCE, split
+//     exactly into the three bf16 planes and stored to LDS as [plane][pixel][32 channels]; the 16-byte channel group of a pixel is XOR-swizzled with
+//     bits 2..3 of the pixel index, so that the 16 lanes of a fragment read (16 consecutive pixels, one group) hit 16 distinct 16-byte bank groups;
+//   * the B operand of tap (dy, dx) is then ONE ds_read_b128 per plane at pixel + dy * halo_width + dx: the im2col column never exists anywhere;
+//   * the tap's weights (4 cout fragments x 3 planes, 12 KB, IGEMM_W_X6 order) go global -> registers -> LDS one tap ahead (double buffer, one
+//     workgroup barrier per tap), and every wave reads them once per tap for its 4 pixel fragments: 24 ds_read_b128 per 96 MFMAs.
+//     Three LDS stages: while tap t is multiplied from REGISTERS, tap t + 1 is read LDS -> registers (its reads hide behind the MFMAs instead of
+//     standing in front of them after every barrier) and tap t + 2 travels global -> registers -> LDS.
+// Per chunk and tile: 80 KB of input read, k * k * 96 MFMAs per wave.  LDS: 3 planes x 640 pixels x 64 B + 3 x 12 KB = 156 KB at k = 9.
+#include "igemm_dev.h"
+
+namespace oar {
+namespace k {
+
+typedef __bf16 lk_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned lk_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned lk_u32x2 __attribute__((ext_vector_type(2)));
+
+struct LkP {
+    IgemmP g;            // g.w in IGEMM_W_X6 order, g.KC = KS * KS * Cin / 32
+    int N;               // images
+    int tiles_x, tiles_y;
+    long tiles;          // N * tiles_y * tiles_x
+    long per_xcd;
+    int nfrag_alloc;
+};
+
+namespace {
+__device__ __forceinline__ lk_u32x4 lk_lds4(unsigned off) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) lk_u32x4*>((__attribute__((address_space(3))) const char*)nullptr + off);
+}
+__device__ __forceinline__ void lk_lds_w2(unsigned off, lk_u32x2 v) {
+    *reinterpret_cast<__attribute__((address_space(3))) lk_u32x2*>((__attribute__((address_space(3))) char*)nullptr + off) = v;
+}
+__device__ __forceinline__ void lk_lds_w4(unsigned off, lk_u32x4 v) {
+    *reinterpret_cast<__attribute__((address_space(3))) lk_u32x4*>((__attribute__((address_space(3))) char*)nullptr + off) = v;
+}
+
+constexpr int kLkTH = 8, kLkTW = 32, kLkThreads = 256;
+
+template <int KS>
+__global__ __launch_bounds__(kLkThreads, 1) void conv_lk_x6_kernel(LkP q) {
+    constexpr int PAD = KS / 2, HWD = kLkTW + KS - 1, HHT = kLkTH + KS - 1, NPX = HWD * HHT;
+    constexpr unsigned PLB = (unsigned)NPX * 64u;          // bytes of one plane of the halo tile
+    constexpr unsigned WST0 = 3u * PLB;                    // weight stages behind the planes: 3 x [4 cout fragments][3 planes][64 lanes] 16 B
+    constexpr int NQ = NPX * 8;                            // float4 quads of one chunk of the halo
+    constexpr int NSL = (NQ + kLkThreads - 1) / kLkThreads;
+    constexpr int NSH = (NSL + 1) / 2;                     // staged in two halves: NSH quads per thread in flight
+    extern __shared__ float4 lk_lds[];
+    const IgemmP& p = q.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n16 = lane & 15, g = lane >> 4;
+    const int xcd = (int)(blockIdx.x & 7);
+    const long j = (long)(blockIdx.x >> 3);
+    const long tile = (long)xcd * q.per_xcd + j;
+    if (j >= q.per_xcd || tile >= q.tiles) return;
+    const int tx = (int)(tile % q.tiles_x);
+    const long t2 = tile / q.tiles_x;
+    const int ty = (int)(t2 % q.tiles_y), img = (int)(t2 / q.tiles_y);
+    const int y0 = ty * kLkTH, x0 = tx * kLkTW;
+    const int CC = p.Cin >> 5;
+    const float* ximg = p.x + (long)img * p.H * p.W * p.Cin;
+
+    // ---- per-lane halo pixel of each of this wave's 4 pixel fragments at tap (0, 0): rows 2 wave, 2 wave + 1; columns 0..15, 16..31
+    int hp0[4];
+#pragma clang loop unroll(full)
+    for (int f = 0; f < 4; ++f) hp0[f] = (2 * wave + (f >> 1)) * HWD + (f & 1) * 16 + n16;
+
+    f32x4 acc[4][4];   // [pixel fragment][cout fragment]
+#pragma clang loop unroll(full)
+    for (int f = 0; f < 4; ++f)
+#pragma clang loop unroll(full)
+        for (int nf = 0; nf < 4; ++nf) acc[f][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // weights of (tap, chunk): thread t copies uint4 #(t + 256 u), u = 0..2, of the [4][3][64] block
+    const uint4* wsrc = reinterpret_cast<const uint4*>(p.w);
+    lk_u32x4 wreg[3];
+    auto w_request = [&](int tap, int c) {
+        const int kc = tap * CC + c;
+#pragma clang loop unroll(full)
+        for (int u = 0; u < 3; ++u) {
+            const int i = tid + kLkThreads * u;
+            const int nf = i / 192, r = i - nf * 192;
+            const int nfg = min(nf, q.nfrag_alloc - 1);
+            const uint4 v = wsrc[((long)nfg * p.KC + kc) * 192 + r];
+            wreg[u] = (lk_u32x4){v.x, v.y, v.z, v.w};
+        }
+    };
+    auto w_commit = [&](int stage) {
+#pragma clang loop unroll(full)
+        for (int u = 0; u < 3; ++u) lk_lds_w4(WST0 + (unsigned)(stage * 12288 + (tid + kLkThreads * u) * 16), wreg[u]);
+    };
+    // one chunk of the halo: global f32 -> three bf16 planes in LDS
+    auto stage_halo = [&](int c) {
+#pragma clang loop unroll(full)
+        for (int half = 0; half < 2; ++half) {
+            float4 v[NSH];
+#pragma clang loop unroll(full)
+            for (int u = 0; u < NSH; ++u) {
+                const int i = tid + kLkThreads * (half * NSH + u);
+                const int hp = i >> 3, qd = i & 7;
+                const int hy = hp / HWD, hx = hp - hy * HWD;
+                const int iy = y0 - PAD + hy, ix = x0 - PAD + hx;
+                const bool ok = (half * NSH + u) < NSL && i < NQ && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                v[u] = ok ? *reinterpret_cast<const float4*>(ximg + ((long)iy * p.W + ix) * p.Cin + c * 32 + qd * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma clang loop unroll(full)
+            for (int u = 0; u < NSH; ++u) {
+                const int i = tid + kLkThreads * (half * NSH + u);
+                if ((half * NSH + u) >= NSL || i >= NQ) continue;
+                const int hp = i >> 3, qd = i & 7;
+                const float f[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                unsigned hb[4], mb[4], lb[4];
+#pragma clang loop unroll(full)
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned ux = __float_as_uint(f[e]);
+                    const float r1 = f[e] - __uint_as_float(ux & 0xFFFF0000u);
+                    const unsigned u1 = __float_as_uint(r1);
+                    const float r2 = r1 - __uint_as_float(u1 & 0xFFFF0000u);
+                    hb[e] = ux; mb[e] = u1; lb[e] = __float_as_uint(r2);
+                }
+                const unsigned off = (unsigned)(hp * 64 + ((((qd >> 1) ^ (hp >> 2)) & 3) << 4) + (qd & 1) * 8);
+                lk_lds_w2(off, (lk_u32x2){__builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u), __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u)});
+                lk_lds_w2(off + PLB, (lk_u32x2){__builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u), __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u)});
+                lk_lds_w2(off + 2 * PLB, (lk_u32x2){__builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u), __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u)});
+            }
+        }
+    };
+
+    constexpr int WP[6] = {1, 2, 0, 1, 0, 0};   // (w plane, x plane) = mm, lh, hl, mh, hm, hh: smallest terms first
+    constexpr int XP[6] = {1, 0, 2, 0, 1, 0};
+    auto x_read = [&](lk_u32x4 (&dst)[3], int f, int tapoff) {
+        const int hp = hp0[f] + tapoff;
+        const unsigned a = (unsigned)(hp * 64 + (((g ^ (hp >> 2)) & 3) << 4));
+#pragma clang loop unroll(full)
+        for (int pl = 0; pl < 3; ++pl) dst[pl] = lk_lds4(a + (unsigned)pl * PLB);
+    };
+
+    auto w_read = [&](lk_u32x4 (&wf)[4][3], int stage) {
+        const unsigned wst = WST0 + (unsigned)(stage * 12288 + lane * 16);
+#pragma clang loop unroll(full)
+        for (int nf = 0; nf < 4; ++nf)
+#pragma clang loop unroll(full)
+            for (int pl = 0; pl < 3; ++pl) wf[nf][pl] = lk_lds4(wst + (unsigned)((nf * 3 + pl) * 1024));
+    };
+    auto tap_mfma = [&](const lk_u32x4 (&wf)[4][3], int tap) {
+        const int dy = tap / KS, dx = tap - dy * KS;
+        const int tapoff = dy * HWD + dx;
+        lk_u32x4 xf[2][3];
+        x_read(xf[0], 0, tapoff);
+#pragma clang loop unroll(full)
+        for (int f = 0; f < 4; ++f) {
+            if (f + 1 < 4) x_read(xf[(f + 1) & 1], f + 1, tapoff);   // the next fragment's reads overlap this one's 24 MFMAs
+#pragma clang loop unroll(full)
+            for (int t = 0; t < 6; ++t)
+#pragma clang loop unroll(full)
+                for (int nf = 0; nf < 4; ++nf)   // the four cout fragments alternate: no back-to-back MFMAs on one accumulator
+                    acc[f][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lk_bf16x8, wf[nf][WP[t]]), __builtin_bit_cast(lk_bf16x8, xf[f & 1][XP[t]]), acc[f][nf], 0, 0, 0);
+        }
+    };
+    constexpr int KK = KS * KS;
+    // one tap: `cur` holds its weights; `nxt` receives tap + 1's from LDS stage (tap + 1) % 3; tap + 2's go global -> registers -> stage (tap + 2) % 3
+    auto tap_step = [&](lk_u32x4 (&cur)[4][3], lk_u32x4 (&nxt)[4][3], int tap, int c) {
+        if (tap + 2 < KK) w_request(tap + 2, c);
+        if (tap + 1 < KK) w_read(nxt, (tap + 1) % 3);
+        tap_mfma(cur, tap);
+        if (tap + 2 < KK) w_commit((tap + 2) % 3);
+        __syncthreads();
+    };
+    lk_u32x4 wa[4][3], wb[4][3];
+    for (int c = 0; c < CC; ++c) {
+        // (the barrier that ended the previous chunk's last tap: every wave is done with the old halo and with all three weight stages)
+        w_request(0, c);
+        stage_halo(c);
+        w_commit(0);
+        w_request(1, c);
+        w_commit(1);
+        __syncthreads();
+        w_read(wa, 0);
+        int tap = 0;
+#pragma clang loop unroll(disable)
+        for (; tap + 1 < KK; tap += 2) {
+            tap_step(wa, wb, tap, c);
+            tap_step(wb, wa, tap + 1, c);
+        }
+        if (tap < KK) tap_step(wa, wb, tap, c);
+    }
+
+    // ---- epilogue: bias + residual + activation, one float4 per (pixel, 4 couts)
+#pragma clang loop unroll(full)
+    for (int f = 0; f < 4; ++f) {
+        const int oy = y0 + 2 * wave + (f >> 1), ox = x0 + (f & 1) * 16 + n16;
+        if (oy >= p.H || ox >= p.W) continue;
+        const long pix = ((long)img * p.H + oy) * p.W + ox;
+#pragma clang loop unroll(full)
+        for (int nf = 0; nf < 4; ++nf) {
+            const int co = nf * 16 + g * 4;
+            if (co >= p.gemm_cout) continue;
+            float o[4] = {acc[f][nf][0], acc[f][nf][1], acc[f][nf][2], acc[f][nf][3]};
+            if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + co); o[0] += b.x; o[1] += b.y; o[2] += b.z; o[3] += b.w; }
+            if (p.res) { const float4 r = *reinterpret_cast<const float4*>(p.res + pix * p.y_ld + co); o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w; }
+#pragma clang loop unroll(full)
+            for (int e = 0; e < 4; ++e) o[e] = apply_act(o[e], p.act, p.alpha, p.beta);
+            *reinterpret_cast<float4*>(p.y + pix * p.y_ld + co) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+}  // namespace
+
+// k x k / stride 1 / pad k / 2 / dilation 1 convolutions the LDS-tiled kernel takes: k = 9 (LK-PAN), 32 | Cin, Cout <= 64 in float4 groups, images of at least
+// half a tile row; OAR_IGEMM_LK=0 keeps them on the output-stationary kernel
+bool conv_lk_x6_eligible(int kh, int kw, int sh, int sw, int pt, int pl, int dh, int dw, int H, int W, int Ho, int Wo, int Cin, int Cout, int y_ld, long M) {
+    static const bool on = [] { const char* e = getenv("OAR_IGEMM_LK"); return !e || atoi(e) != 0; }();
+    return on && kh == 9 && kw == 9 && sh == 1 && sw == 1 && pt == 4 && pl == 4 && dh == 1 && dw == 1 && Ho == H && Wo == W && (Cin & 31) == 0 && Cin >= 32 &&
+           Cout <= 64 && (Cout & 3) == 0 && (y_ld & 3) == 0 && W >= 16 && H >= 4 && M >= 2048 && (long)H * W * Cin < (1L << 31) &&
+           // one workgroup per CU (156 KB of LDS): below ~half a chip of tiles the per-tile kernels, which spread a small map over every CU, are faster
+           // (8 x 40 x 40 pixels = 80 tiles: 0.73 ms here against 0.53 ms on the f32 per-tile kernel)
+           (M / ((long)H * W)) * ((H + kLkTH - 1) / kLkTH) * ((W + kLkTW - 1) / kLkTW) >= 128;
+}
+
+void conv_lk_x6(hipStream_t s, const IgemmP& p, int n_images) {
+    LkP q;
+    q.g = p;
+    q.N = n_images;
+    q.tiles_x = (p.W + kLkTW - 1) / kLkTW;
+    q.tiles_y = (p.H + kLkTH - 1) / kLkTH;
+    q.tiles = (long)n_images * q.tiles_x * q.tiles_y;
+    q.per_xcd = (q.tiles + 7) / 8;
+    q.nfrag_alloc = (p.gemm_cout + 63) / 64 * 4;
+    constexpr int KS = 9;
+    const size_t lds = (size_t)3 * (kLkTW + KS - 1) * (kLkTH + KS - 1) * 64 + 3 * 12288;
+    OAR_MAX_LDS_ONCE(conv_lk_x6_kernel<9>, 160 * 1024);
+    hipLaunchKernelGGL(conv_lk_x6_kernel<9>, dim3((unsigned)(q.per_xcd * 8)), dim3(kLkThreads), lds, s, q);
+}
+
+}  // namespace k
+}  // namespace oar

@@ -52,7 +52,9 @@ void conv_igemm(hipStream_t s, const ConvP& p);
 // chosen per layer AND input shape at plan time: M = GEMM rows (pixels), N = couts
 // same3x3_px: pixels of ONE image when the layer is a 3x3 / stride 1 / pad 1 / dilation 1 convolution without residual (0 otherwise): the row-streaming
 // bf16x6 kernel of igemm_rs3_x6.hip takes such layers with <= 16 output channels
-int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin = 0, long same3x3_px = 0);
+int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin = 0, long same3x3_px = 0, bool lk_ok = false);
+// lk_ok: conv_lk_x6_eligible said yes for this layer (large-kernel same convolution from an LDS-staged halo tile, igemm_lk_x6.hip)
+bool conv_lk_x6_eligible(int kh, int kw, int sh, int sw, int pt, int pl, int dh, int dw, int H, int W, int Ho, int Wo, int Cin, int Cout, int y_ld, long M);
 // one group of a grouped k x k convolution (ConvP::x_ld) as its own implicit GEMM on the output-stationary bf16x6 kernel: M pixels, K = kh * kw * Cin_g, N = Cout_g >= 32
 bool conv_grouped_x6_ok(long M, int K, int N, int Cin);
 // a 3x3 / stride 1 / pad 1 convolution with <= 16 output channels and 96 ... 256 input channels as passes of the row-streaming bf16x6 kernel over 64- / 32-channel

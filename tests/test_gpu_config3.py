@@ -153,3 +153,26 @@ def test_grouped_mixing_conv_runs_per_group_on_the_matrix_pipe(case):
     snap = {e["name"]: e["launches"] for e in api.prof_snapshot()}
     api.prof_enable(False)
     assert snap.get("conv_igemm_os_x6", 0) == groups and not snap.get("conv_direct", 0), snap
+
+
+@pytest.mark.parametrize("case", [("lk-pan 256 -> 64", 256, 64, 4, 80, 128, True), ("lk-pan 64 -> 64, ragged tiles", 64, 64, 8, 45, 70, False), ("48 couts, ragged", 32, 48, 6, 60, 70, False)])
+def test_large_kernel_conv_from_an_lds_staged_halo_tile(case):
+    """igemm_lk_x6.hip: the 9 x 9 convolutions of the LK-PAN neck -- halo tile split once into bf16 planes in LDS, taps as address offsets -- against
+    torch-CPU conv2d; tiles hanging over the right / bottom edge, a cout count that is not a multiple of 64, bias + activation in the epilogue."""
+    name, cin, cout, n, h, w, with_bias = case
+    g = GraphBuilder("lk")
+    rng = np.random.default_rng(len(name))
+    g.add_input("x", ["N", cin, "H", "W"])
+    wt = (rng.standard_normal((cout, cin, 9, 9)) * np.sqrt(1.0 / (81 * cin))).astype(np.float32)
+    ins = ["x", g.init(wt)] + ([g.init((0.2 * rng.standard_normal(cout)).astype(np.float32))] if with_bias else [])
+    y = g.op("Conv", ins, kernel_shape=[9, 9], strides=[1, 1], pads=[4, 4, 4, 4], group=1, dilations=[1, 1])
+    if with_bias:
+        y = g.op("Relu", [y])
+    g.add_output(y, ["N", cout, "H", "W"])
+    m = g.model()
+    x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    api.prof_enable(True); api.prof_reset()
+    _check(m, x)
+    snap = {e["name"]: e["launches"] for e in api.prof_snapshot()}
+    api.prof_enable(False)
+    assert snap.get("conv_lk_x6", 0) == 1, snap

@@ -134,7 +134,11 @@ def test_word_boxes_of_a_real_predict_result_match_the_oracle(nets):
     boxes, CTC columns, sequence lengths, crop ratios and per-batch maximum ratios -- against OAROCR::ctc_word_boxes (ocr.rs:949-1020, :860-877)
     restated in the oracle and fed with the ORACLE pipeline's values.  Lines of different widths in recognition batches of 8: most crops are padded
     (wh_ratio < chunk maximum); the dictionary mixes ASCII and CJK entries, so both the midpoint and the average-width branch run."""
-    det, rec, chars = nets
+    det, rec, _ = nets
+    # a dictionary that alternates Latin letters / digits and CJK ideographs over the recognizer's 6904 classes (the synthetic dictionary is 1 % ASCII:
+    # a random-weight recognizer would never emit a Latin character)
+    latin = [chr(c) for c in range(0x30, 0x3A)] + [chr(c) for c in range(0x41, 0x5B)] + [chr(c) for c in range(0x61, 0x7B)]
+    chars = [latin[(i // 2) % len(latin)] if i % 2 else chr(0x4E00 + i) for i in range(6904)]
     imgs = [pages.make_page(80, (480, 960), lines=12), pages.make_page(81, (640, 480), lines=14), pages.make_page(82, (320, 1280), lines=6)]
     cfg = api.TextDetectionConfig(0.3, 0.6, 1.5)
     ocr = api.OAROCRBuilder(det, rec, chars).text_detection_config(cfg).image_batch_size(4).region_batch_size(8).build()
@@ -157,7 +161,7 @@ def test_word_boxes_of_a_real_predict_result_match_the_oracle(nets):
             n_cjk += sum(1 for ch in s["text"] if ord(ch) >= 0x2E80)
             n_latin += sum(1 for ch in s["text"] if ord(ch) < 0x2E80)
             n_padded += int(np.float32(s["wh_ratio"]) < np.float32(s["max_wh_ratio"]))
-    assert n_boxes > 100 and n_cjk > 20 and n_latin > 5 and n_padded > 10, (n_boxes, n_cjk, n_latin, n_padded)
+    assert n_boxes > 60 and n_cjk > 15 and n_latin > 15 and n_padded > 10, (n_boxes, n_cjk, n_latin, n_padded)
     ocr.close()
 
 
