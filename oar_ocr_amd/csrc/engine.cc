@@ -2578,7 +2578,11 @@ struct Planner {
             int64_t coff = 0, total = pod[pax] * inner;
             // round 5: every absorbed resize an integer-factor nearest upsampling (the DB neck: up8 / up4 / up2 of three pyramid levels next to
             // the finest one) -> the whole concat is ONE gather launch instead of one launch per input.  OAR_CONCAT_GATHER=0 restores those.
-            if (absorb && r == 4 && inner == 1 && xs.size() <= 8) {
+            // round 6: the same launch for a plain channel concat of three or more maps (PP-HGNetV2's blocks concatenate seven: one gather instead of seven
+            // strided copies)
+            bool plain = !absorb && r == 4 && inner == 1 && xs.size() >= 3 && (od[1] & 3) == 0;
+            for (auto& t : xs) plain = plain && t.dims.size() == 4 && (t.dims[1] & 3) == 0;
+            if ((absorb || plain) && r == 4 && inner == 1 && xs.size() <= 8) {
                 static const bool gather_on = [] { const char* e = getenv("OAR_CONCAT_GATHER"); return !(e && e[0] == '0'); }();
                 bool ok = gather_on;
                 for (size_t i = 0; ok && i < xs.size(); ++i) {

@@ -377,7 +377,10 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     // wide 1x1 layers whose weight-stationary tile is down to 4 cout fragments (K >= 320: 64 couts x K x 96 B of LDS) make >= 8 passes over their pixels -- each pass
     // re-reading and re-splitting them; there the output-stationary kernel's 128-cout tiles win (SVTRv2's 384 -> 1152 projection: 130 -> 199 TFLOP/s).  OAR_IGEMM_OS_WIDE=0 off
     static const bool os_wide = [] { const char* e = getenv("OAR_IGEMM_OS_WIDE"); return !e || atoi(e) != 0; }();
-    const bool prefer_os = os_wide && os_mode() != 0 && x6 && is1x1 && !c.convt2x2 && !c.se && !c.ctc_part && p.gemm_cout >= 512 && ws_x6_tile(p.K, nfrag) > 0 && ws_x6_tile(p.K, nfrag) <= 4 &&
+    // (not behind an expensive activation: the output-stationary kernel's epilogue runs after its K loop with nothing to hide it -- the GELU layers 384 -> 1536 and
+    // 256 -> 1024 measured 132 / 108 TFLOP/s there against 152 / 169 on the weight-stationary kernel, whose other waves multiply meanwhile)
+    const bool cheap_act = c.act.kind == ACT_NONE || c.act.kind == ACT_RELU;
+    const bool prefer_os = os_wide && os_mode() != 0 && x6 && is1x1 && !c.convt2x2 && !c.se && !c.ctc_part && cheap_act && p.K >= 320 && p.gemm_cout >= 512 && ws_x6_tile(p.K, nfrag) > 0 && ws_x6_tile(p.K, nfrag) <= 4 &&
                            os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin);
     const bool x6_os = x6 && !c.ctc_part && (!is1x1 || ws_x6_tile(p.K, nfrag) == 0 || prefer_os || (os_mode() == 2 && os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin)));
     const bool rs3_cls = x6 && !c.convt2x2 && c.kh == 3 && c.kw == 3 && c.sh == 1 && c.sw == 1 && c.pt == 1 && c.pl == 1 && c.dh == 1 && c.dw == 1 && c.Ho == c.H && c.Wo == c.W && !c.residual && !c.se &&

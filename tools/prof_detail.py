@@ -11,6 +11,9 @@ if C3:
 elif SERVER:
     det,_=models.build_det('server', seed=0); rec,_=models.build_rec('server', vocab=18710, seed=1)
     chars=api.read_dict(models.synth_dict(18708)); S=1280; NP=16
+elif len(sys.argv) > 1 and sys.argv[1] == 'full':         # BASELINE C2 on the graphs bench.py times by default since round 6 (0.447 M / 1.103 M parameters)
+    det,_=models.build_det('tiny_full', seed=0); rec,_=models.build_rec('tiny_full', vocab=6906, seed=1)
+    chars=api.read_dict(models.synth_dict()); S=960; NP=32
 else:
     det,_=models.build_det(); rec,_=models.build_rec()
     chars=api.read_dict(models.synth_dict()); S=960; NP=32
