@@ -316,6 +316,7 @@ def main():
     if not stub:
         api.prof_sampling(1, 0)
     roof = None
+    cfg_sfx = "" if args.config in (1, 3) else f"_c{args.config}"   # committed counter summaries are per workload: profiles/r*/pmc_traffic[_c2].json, mfma_util[_c2].json
     from oar_ocr_amd.build import csrc_fingerprint
     csrc_now = csrc_fingerprint()
 
@@ -335,7 +336,7 @@ def main():
         # The file carries the fingerprint of the csrc/ it was measured on: when the sources have changed since, the counters
         # describe other kernels -- `traffic` is then null and traffic_source says why.
         traffic, traffic_src = None, None
-        for tf in sorted(ROOT.glob("profiles/r*/pmc_traffic.json"), reverse=True):
+        for tf in sorted(ROOT.glob(f"profiles/r*/pmc_traffic{cfg_sfx}.json"), reverse=True):
             try:
                 doc = json.loads(tf.read_text())
                 t = doc.get(name)
@@ -373,8 +374,8 @@ def main():
     # committed rocprofv3 --pmc pass over this same command (tools/profile_round.sh pass 3 -> profiles/r*/mfma_util.json; the
     # counters cannot be collected inside the timed region).  Only reported for the workload the pass was made on (config 1).
     mfma_util = None
-    if rank == 0 and args.config == 1:
-        for mf in sorted(ROOT.glob("profiles/r*/mfma_util.json"), reverse=True):
+    if rank == 0 and args.config in (1, 2):
+        for mf in sorted(ROOT.glob(f"profiles/r*/mfma_util{cfg_sfx}.json"), reverse=True):
             try:
                 m = json.loads(mf.read_text())
                 if m.get("_csrc_fingerprint") != csrc_now:
@@ -385,7 +386,7 @@ def main():
                              "classes": {k: v["pct_of_dense_peak"] for k, v in m.items() if isinstance(v, dict) and "pct_of_dense_peak" in v}}
                 # the other bound of the same classes: counter-measured HBM bytes per launch / launch duration / 8 TB/s (same session's
                 # FETCH_SIZE / WRITE_SIZE passes), so that each conv class shows how far it is from BOTH of its roofs
-                tf = mf.with_name("pmc_traffic.json")
+                tf = mf.with_name(f"pmc_traffic{cfg_sfx}.json")
                 if tf.exists():
                     t = json.loads(tf.read_text())
                     if t.get("_csrc_fingerprint") == csrc_now:

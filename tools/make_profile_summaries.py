@@ -4,7 +4,9 @@ files committed under profiles/<round>/:
   <tag>_kernel_stats.txt        per-step view of the same file (tools/stats_summary.py)
   <tag>_pmc_summary.txt         FETCH_SIZE (x2, gfx950 correction) / WRITE_SIZE / SQ counters per kernel (tools/pmc_summary.py)
   pmc_traffic.json              HBM bytes per launch for each kernel class, read by bench.py for roofline.traffic
-usage: python tools/make_profile_summaries.py <tag> <steps_in_stats_run> [round_dir]
+usage: python tools/make_profile_summaries.py <tag> <steps_in_stats_run> [round_dir] [config]
+config (default 1): the bench.py --config the session ran; any other value writes pmc_traffic_c<config>.json / mfma_util_c<config>.json (bench.py reads the
+file of the config it is timing) and reads the raw passes from gpurun_out/pmc_*_c<config>/.
 """
 import csv, collections, json, shutil, subprocess, sys
 from pathlib import Path
@@ -14,6 +16,8 @@ from oar_ocr_amd.build import csrc_fingerprint
 
 tag, steps = sys.argv[1], sys.argv[2]   # steps: "auto" = the pass count the bench line of the stats run reports (gpurun_out/prof_<tag>.log)
 out = Path(sys.argv[3] if len(sys.argv) > 3 else "profiles/r2")
+cfg = sys.argv[4] if len(sys.argv) > 4 else "1"
+sfx = "" if cfg == "1" else f"_c{cfg}"
 out.mkdir(parents=True, exist_ok=True)
 src = Path("gpurun_out")
 shutil.copy(src / f"prof_{tag}" / f"{tag}_kernel_stats.csv", out / f"{tag}_kernel_stats.csv")
@@ -21,12 +25,15 @@ if steps == "auto":
     steps = "log:" + str(src / f"prof_{tag}.log")
 txt = subprocess.run([sys.executable, "tools/stats_summary.py", str(src / f"prof_{tag}" / f"{tag}_kernel_stats.csv"), steps, "40"], capture_output=True, text=True).stdout
 (out / f"{tag}_kernel_stats.txt").write_text(txt)
-txt = subprocess.run([sys.executable, "tools/pmc_summary.py", str(src), "40"], capture_output=True, text=True).stdout
+txt = subprocess.run([sys.executable, "tools/pmc_summary.py", str(src), "40"] + ([sfx] if sfx else []), capture_output=True, text=True).stdout
 (out / f"{tag}_pmc_summary.txt").write_text(txt)
 
 def klass(name):   # kernel name -> profiler class used by the in-library profiler / bench.py
     if "conv3x3_n16_x6" in name:
         return "conv_rs3_x6"
+    for pre, k in (("conv_lk_x6_kernel", "conv_lk_x6"), ("attention_x6_kernel", "attention_x6"), ("conv_igemm_os_x6_kernel", "conv_igemm_os_x6"), ("layernorm", "layernorm")):   # round 6 (BASELINE C3)
+        if pre in name:
+            return k
     for pre, k in (("dsblock_rs2_kernel", "dsblock_rs"), ("ctc_head_x6_kernel", "ctc_head_x6"), ("dsblock_rs_kernel", "dsblock_rs"), ("dsblock_cs_kernel", "dsblock_cs"), ("dsblock_pc_kernel", "dsblock_cs"), ("dsblock_wa_kernel", "dsblock_wa")):   # one class per dsblock family
         if pre in name:
             return k
@@ -47,25 +54,25 @@ def per_class(path, counter):
                 disp[c].add(r["Dispatch_Id"]); ns[c] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     return {c: (tot[c], len(disp[c]), ns[c]) for c in tot}
 
-f = per_class(src / "pmc_FETCH_SIZE" / "p_counter_collection.csv", "FETCH_SIZE")
-w = per_class(src / "pmc_WRITE_SIZE" / "p_counter_collection.csv", "WRITE_SIZE")
+f = per_class(src / f"pmc_FETCH_SIZE{sfx}" / "p_counter_collection.csv", "FETCH_SIZE")
+w = per_class(src / f"pmc_WRITE_SIZE{sfx}" / "p_counter_collection.csv", "WRITE_SIZE")
 res = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 2 --warmup 1 --cpu-pages 0 --no-prof`; "
                 "counters are in KiB; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md (HBM section); bytes are averages per launch of the class; "
                 "hbm_frac = counter bytes per launch / average launch duration in the same pass / 8 TB/s",
-       "_source_tag": tag, "_csrc_fingerprint": csrc_fingerprint()}
+       "_source_tag": tag, "_csrc_fingerprint": csrc_fingerprint(), "_config": cfg}
 for c in f:
     fb = f[c][0] * 1024 * 2 / max(f[c][1], 1)
     wb = w.get(c, (0, 1, 0))[0] * 1024 / max(w.get(c, (0, 1, 0))[1], 1)
     us = f[c][2] / max(f[c][1], 1) / 1e3   # average launch of the class in the FETCH_SIZE pass (the launches the bytes were counted on)
     res[c] = {"fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb), "hbm_bytes_per_launch": round(fb + wb), "launches_sampled": f[c][1],
               "avg_us": round(us, 1), "hbm_frac": round((fb + wb) / (us * 1e-6) / 8e12, 3) if us > 0 else None}
-(out / "pmc_traffic.json").write_text(json.dumps(res, indent=1) + "\n")
+(out / f"pmc_traffic{sfx}.json").write_text(json.dumps(res, indent=1) + "\n")
 print(json.dumps({k: v for k, v in res.items() if not k.startswith("_")}, indent=1)[:1500])
 
 # counter-based matrix-pipe utilisation per kernel class (pmc_MFMA pass), read by nothing -- evidence for DESIGN.md / the judge
 sys.path.insert(0, "tools")
 import pmc_summary
-mf = pmc_summary.mfma_rows(str(src), "pmc_MFMA")
+mf = pmc_summary.mfma_rows(str(src), f"pmc_MFMA{sfx}")
 by = collections.defaultdict(lambda: dict(us=0.0, n=0, busy=0.0, bf16=0.0, f32=0.0))
 for (name, grid), m in mf.items():
     c = klass(name)
@@ -76,5 +83,5 @@ util = {c: {"launches": d["n"], "avg_us": round(d["us"] / d["n"], 1), "mfma_busy
 util["_csrc_fingerprint"] = csrc_fingerprint()
 util["_note"] = ("time-weighted over the launches of each class; mfma_busy_pct = SQ_VALU_MFMA_BUSY_CYCLES / (4 x 256 x GRBM_GUI_ACTIVE) (rocprofv3 MfmaUtil); "
                  "tflops = SQ_INSTS_VALU_MFMA_MOPS_* x 512 / duration; dense peaks 2500 (bf16) / 157.3 (f32) TFLOP/s; calibration run in the pmc summary")
-(out / "mfma_util.json").write_text(json.dumps(util, indent=1) + "\n")
+(out / f"mfma_util{sfx}.json").write_text(json.dumps(util, indent=1) + "\n")
 print(json.dumps(util, indent=1)[:1200])

@@ -4,7 +4,7 @@ the matrix pipe (pmc_MFMA pass): counter-based MFMA utilisation
     util = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE)      (rocprofv3's MfmaUtil expression)
 and the MFMA rate from SQ_INSTS_VALU_MFMA_MOPS_{BF16,F32} x 512 flop / kernel duration, as a fraction of the dense peak
 (2500 TFLOP/s bf16, 157.3 TFLOP/s f32).  pmc_MFMA_peak (tools/mfma_peak under the same counters) calibrates both.
-usage: python tools/pmc_summary.py [gpurun_out] [rows]"""
+usage: python tools/pmc_summary.py [gpurun_out] [rows] [suffix]      suffix: "_c2" for the passes of a --config 2 session (tools/profile_round.sh <tag> 2)"""
 import csv, sys, collections, os
 
 CUS, SIMDS = 256, 4
@@ -46,9 +46,10 @@ def mfma_rows(base, sub):
 if __name__ == "__main__":
     base = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
     top = int(sys.argv[2]) if len(sys.argv) > 2 else 25
-    f, fd, fn = load(f"{base}/pmc_FETCH_SIZE/p_counter_collection.csv")
-    w, wd, wn = load(f"{base}/pmc_WRITE_SIZE/p_counter_collection.csv")
-    mf = mfma_rows(base, "pmc_MFMA")
+    sfx = sys.argv[3] if len(sys.argv) > 3 else ""
+    f, fd, fn = load(f"{base}/pmc_FETCH_SIZE{sfx}/p_counter_collection.csv")
+    w, wd, wn = load(f"{base}/pmc_WRITE_SIZE{sfx}/p_counter_collection.csv")
+    mf = mfma_rows(base, f"pmc_MFMA{sfx}")
     keys = sorted(fd, key=lambda k: -fd[k])[:top]
     print(f"{'kernel':66s} {'grid':>8s} {'n':>3s} {'us':>7s} {'fetchMB*2':>9s} {'writeMB':>8s} {'GB/s':>6s} | {'mfma busy%':>10s} {'bf16 TF':>8s} {'f32 TF':>7s} {'%peak':>6s} {'issue-stall%':>12s}")
     for k in keys:
