@@ -385,7 +385,7 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     const bool x6_os = x6 && !c.ctc_part && (!is1x1 || ws_x6_tile(p.K, nfrag) == 0 || prefer_os || (os_mode() == 2 && os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin)));
     const bool rs3_cls = x6 && !c.convt2x2 && c.kh == 3 && c.kw == 3 && c.sh == 1 && c.sw == 1 && c.pt == 1 && c.pl == 1 && c.dh == 1 && c.dw == 1 && c.Ho == c.H && c.Wo == c.W && !c.residual && !c.se &&
                          !c.ctc_part && conv3x3_n16_x6_eligible(p.M, c.Cin, c.Cout, (long)c.H * c.W, c.y_ld);
-    const bool lk = x6 && !grouped && !c.ctc_part && !c.se && !c.convt2x2 && !is1x1 &&
+    const bool lk = x6 && !c.ctc_part && !c.se && !c.convt2x2 && !is1x1 &&
                     conv_lk_x6_eligible(c.kh, c.kw, c.sh, c.sw, c.pt, c.pl, c.dh, c.dw, c.H, c.W, c.Ho, c.Wo, c.Cin, c.Cout, c.y_ld, p.M);
     const char* cls = lk ? "conv_lk_x6" : rs3_cls ? "conv_rs3_x6" : x6_os ? "conv_igemm_os_x6" : x6 ? "conv_igemm_ws_x6" : ws ? "conv_igemm_ws" : "conv_igemm";   // one profiler class per kernel
     if (Profiler::get().detail) {

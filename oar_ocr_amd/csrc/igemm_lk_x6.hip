@@ -45,11 +45,16 @@ __device__ __forceinline__ void lk_lds_w4(unsigned off, lk_u32x4 v) {
     *reinterpret_cast<__attribute__((address_space(3))) lk_u32x4*>((__attribute__((address_space(3))) char*)nullptr + off) = v;
 }
 
-constexpr int kLkTH = 8, kLkTW = 32, kLkThreads = 256;
+constexpr int kLkTW = 32, kLkThreads = 256;
 
-template <int KS>
+// KS: kernel size; TH: tile rows (6 / 8 / 12: TH / 2 pixel fragments per wave, dealt round-robin over the tile's 2 TH fragments); NF: cout fragments (4, or 2 for
+// the 32-channel groups of a grouped convolution -- the 5 x 5 local mixing of SVTRv2, which reads its 32 input channels out of the full tensor through g.x_ld)
+template <int KS, int TH, int NF>
 __global__ __launch_bounds__(kLkThreads, 1) void conv_lk_x6_kernel(LkP q) {
-    constexpr int PAD = KS / 2, HWD = kLkTW + KS - 1, HHT = kLkTH + KS - 1, NPX = HWD * HHT;
+    constexpr int PAD = KS / 2, HWD = kLkTW + KS - 1, HHT = TH + KS - 1, NPX = HWD * HHT;
+    constexpr int PF = TH / 2;                             // pixel fragments per wave
+    constexpr int WSTB = NF * 3072;                        // bytes of one weight stage
+    constexpr int NWL = (NF * 192 + kLkThreads - 1) / kLkThreads;
     constexpr unsigned PLB = (unsigned)NPX * 64u;          // bytes of one plane of the halo tile
     constexpr unsigned WST0 = 3u * PLB;                    // weight stages behind the planes: 3 x [4 cout fragments][3 planes][64 lanes] 16 B
     constexpr int NQ = NPX * 8;                            // float4 quads of one chunk of the halo
@@ -66,29 +71,29 @@ __global__ __launch_bounds__(kLkThreads, 1) void conv_lk_x6_kernel(LkP q) {
     const int tx = (int)(tile % q.tiles_x);
     const long t2 = tile / q.tiles_x;
     const int ty = (int)(t2 % q.tiles_y), img = (int)(t2 / q.tiles_y);
-    const int y0 = ty * kLkTH, x0 = tx * kLkTW;
+    const int y0 = ty * TH, x0 = tx * kLkTW;
     const int CC = p.Cin >> 5;
-    const float* ximg = p.x + (long)img * p.H * p.W * p.Cin;
+    const float* ximg = p.x + (long)img * p.H * p.W * p.x_ld;
 
-    // ---- per-lane halo pixel of each of this wave's 4 pixel fragments at tap (0, 0): rows 2 wave, 2 wave + 1; columns 0..15, 16..31
-    int hp0[4];
+    // ---- per-lane halo pixel of each of this wave's PF pixel fragments at tap (0, 0): tile fragment wave + 4 f = (row, 16-column half)
+    int hp0[PF];
 #pragma clang loop unroll(full)
-    for (int f = 0; f < 4; ++f) hp0[f] = (2 * wave + (f >> 1)) * HWD + (f & 1) * 16 + n16;
+    for (int f = 0; f < PF; ++f) hp0[f] = ((wave + 4 * f) >> 1) * HWD + ((wave + 4 * f) & 1) * 16 + n16;
 
-    f32x4 acc[4][4];   // [pixel fragment][cout fragment]
+    f32x4 acc[PF][NF];   // [pixel fragment][cout fragment]
 #pragma clang loop unroll(full)
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < PF; ++f)
 #pragma clang loop unroll(full)
-        for (int nf = 0; nf < 4; ++nf) acc[f][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nf = 0; nf < NF; ++nf) acc[f][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // weights of (tap, chunk): thread t copies uint4 #(t + 256 u), u = 0..2, of the [4][3][64] block
+    // weights of (tap, chunk): thread t copies uint4 #(t + 256 u), u < NWL, of the [NF][3][64] block
     const uint4* wsrc = reinterpret_cast<const uint4*>(p.w);
-    lk_u32x4 wreg[3];
+    lk_u32x4 wreg[NWL];
     auto w_request = [&](int tap, int c) {
         const int kc = tap * CC + c;
 #pragma clang loop unroll(full)
-        for (int u = 0; u < 3; ++u) {
-            const int i = tid + kLkThreads * u;
+        for (int u = 0; u < NWL; ++u) {
+            const int i = min(tid + kLkThreads * u, NF * 192 - 1);
             const int nf = i / 192, r = i - nf * 192;
             const int nfg = min(nf, q.nfrag_alloc - 1);
             const uint4 v = wsrc[((long)nfg * p.KC + kc) * 192 + r];
@@ -97,7 +102,8 @@ __global__ __launch_bounds__(kLkThreads, 1) void conv_lk_x6_kernel(LkP q) {
     };
     auto w_commit = [&](int stage) {
 #pragma clang loop unroll(full)
-        for (int u = 0; u < 3; ++u) lk_lds_w4(WST0 + (unsigned)(stage * 12288 + (tid + kLkThreads * u) * 16), wreg[u]);
+        for (int u = 0; u < NWL; ++u)
+            if (tid + kLkThreads * u < NF * 192) lk_lds_w4(WST0 + (unsigned)(stage * WSTB + (tid + kLkThreads * u) * 16), wreg[u]);
     };
     // one chunk of the halo: global f32 -> three bf16 planes in LDS
     auto stage_halo = [&](int c) {
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(kLkThreads, 1) void conv_lk_x6_kernel(LkP q) {
                 const int hy = hp / HWD, hx = hp - hy * HWD;
                 const int iy = y0 - PAD + hy, ix = x0 - PAD + hx;
                 const bool ok = (half * NSH + u) < NSL && i < NQ && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                v[u] = ok ? *reinterpret_cast<const float4*>(ximg + ((long)iy * p.W + ix) * p.Cin + c * 32 + qd * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[u] = ok ? *reinterpret_cast<const float4*>(ximg + ((long)iy * p.W + ix) * p.x_ld + c * 32 + qd * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma clang loop unroll(full)
             for (int u = 0; u < NSH; ++u) {
@@ -145,38 +151,38 @@ __global__ __launch_bounds__(kLkThreads, 1) void conv_lk_x6_kernel(LkP q) {
         for (int pl = 0; pl < 3; ++pl) dst[pl] = lk_lds4(a + (unsigned)pl * PLB);
     };
 
-    auto w_read = [&](lk_u32x4 (&wf)[4][3], int stage) {
-        const unsigned wst = WST0 + (unsigned)(stage * 12288 + lane * 16);
+    auto w_read = [&](lk_u32x4 (&wf)[NF][3], int stage) {
+        const unsigned wst = WST0 + (unsigned)(stage * WSTB + lane * 16);
 #pragma clang loop unroll(full)
-        for (int nf = 0; nf < 4; ++nf)
+        for (int nf = 0; nf < NF; ++nf)
 #pragma clang loop unroll(full)
             for (int pl = 0; pl < 3; ++pl) wf[nf][pl] = lk_lds4(wst + (unsigned)((nf * 3 + pl) * 1024));
     };
-    auto tap_mfma = [&](const lk_u32x4 (&wf)[4][3], int tap) {
+    auto tap_mfma = [&](const lk_u32x4 (&wf)[NF][3], int tap) {
         const int dy = tap / KS, dx = tap - dy * KS;
         const int tapoff = dy * HWD + dx;
         lk_u32x4 xf[2][3];
         x_read(xf[0], 0, tapoff);
 #pragma clang loop unroll(full)
-        for (int f = 0; f < 4; ++f) {
-            if (f + 1 < 4) x_read(xf[(f + 1) & 1], f + 1, tapoff);   // the next fragment's reads overlap this one's 24 MFMAs
+        for (int f = 0; f < PF; ++f) {
+            if (f + 1 < PF) x_read(xf[(f + 1) & 1], f + 1, tapoff);   // the next fragment's reads overlap this one's 6 NF MFMAs
 #pragma clang loop unroll(full)
             for (int t = 0; t < 6; ++t)
 #pragma clang loop unroll(full)
-                for (int nf = 0; nf < 4; ++nf)   // the four cout fragments alternate: no back-to-back MFMAs on one accumulator
+                for (int nf = 0; nf < NF; ++nf)   // the cout fragments alternate: no back-to-back MFMAs on one accumulator
                     acc[f][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lk_bf16x8, wf[nf][WP[t]]), __builtin_bit_cast(lk_bf16x8, xf[f & 1][XP[t]]), acc[f][nf], 0, 0, 0);
         }
     };
     constexpr int KK = KS * KS;
     // one tap: `cur` holds its weights; `nxt` receives tap + 1's from LDS stage (tap + 1) % 3; tap + 2's go global -> registers -> stage (tap + 2) % 3
-    auto tap_step = [&](lk_u32x4 (&cur)[4][3], lk_u32x4 (&nxt)[4][3], int tap, int c) {
+    auto tap_step = [&](lk_u32x4 (&cur)[NF][3], lk_u32x4 (&nxt)[NF][3], int tap, int c) {
         if (tap + 2 < KK) w_request(tap + 2, c);
         if (tap + 1 < KK) w_read(nxt, (tap + 1) % 3);
         tap_mfma(cur, tap);
         if (tap + 2 < KK) w_commit((tap + 2) % 3);
         __syncthreads();
     };
-    lk_u32x4 wa[4][3], wb[4][3];
+    lk_u32x4 wa[NF][3], wb[NF][3];
     for (int c = 0; c < CC; ++c) {
         // (the barrier that ended the previous chunk's last tap: every wave is done with the old halo and with all three weight stages)
         w_request(0, c);
@@ -197,12 +203,12 @@ __global__ __launch_bounds__(kLkThreads, 1) void conv_lk_x6_kernel(LkP q) {
 
     // ---- epilogue: bias + residual + activation, one float4 per (pixel, 4 couts)
 #pragma clang loop unroll(full)
-    for (int f = 0; f < 4; ++f) {
-        const int oy = y0 + 2 * wave + (f >> 1), ox = x0 + (f & 1) * 16 + n16;
+    for (int f = 0; f < PF; ++f) {
+        const int oy = y0 + ((wave + 4 * f) >> 1), ox = x0 + ((wave + 4 * f) & 1) * 16 + n16;
         if (oy >= p.H || ox >= p.W) continue;
         const long pix = ((long)img * p.H + oy) * p.W + ox;
 #pragma clang loop unroll(full)
-        for (int nf = 0; nf < 4; ++nf) {
+        for (int nf = 0; nf < NF; ++nf) {
             const int co = nf * 16 + g * 4;
             if (co >= p.gemm_cout) continue;
             float o[4] = {acc[f][nf][0], acc[f][nf][1], acc[f][nf][2], acc[f][nf][3]};
@@ -216,30 +222,54 @@ __global__ __launch_bounds__(kLkThreads, 1) void conv_lk_x6_kernel(LkP q) {
 }
 }  // namespace
 
-// k x k / stride 1 / pad k / 2 / dilation 1 convolutions the LDS-tiled kernel takes: k = 9 (LK-PAN), 32 | Cin, Cout <= 64 in float4 groups, images of at least
-// half a tile row; OAR_IGEMM_LK=0 keeps them on the output-stationary kernel
+// k x k / stride 1 / pad k / 2 / dilation 1 convolutions the LDS-tiled kernel takes: k = 9 with Cout <= 64 (LK-PAN), k = 5 with Cout <= 32 (one 32-channel group
+// of SVTRv2's local mixing; Cin is then the group's 32 channels), 32 | Cin, float4 channel groups; OAR_IGEMM_LK=0 keeps them on the output-stationary kernel.
+// Tile rows: the one of 12 / 8 / 6 that wastes the fewest rows of the map (k = 9: 8, the halo of a 12-row tile would not fit LDS).
+static int lk_tile_rows(int ks, int H) {
+    if (ks == 9) return 8;
+    int best = 8, waste = 1 << 30;
+    for (int th : {12, 8, 6}) { const int w = (H + th - 1) / th * th - H; if (w < waste) { waste = w; best = th; } }
+    return best;
+}
 bool conv_lk_x6_eligible(int kh, int kw, int sh, int sw, int pt, int pl, int dh, int dw, int H, int W, int Ho, int Wo, int Cin, int Cout, int y_ld, long M) {
     static const bool on = [] { const char* e = getenv("OAR_IGEMM_LK"); return !e || atoi(e) != 0; }();
-    return on && kh == 9 && kw == 9 && sh == 1 && sw == 1 && pt == 4 && pl == 4 && dh == 1 && dw == 1 && Ho == H && Wo == W && (Cin & 31) == 0 && Cin >= 32 &&
-           Cout <= 64 && (Cout & 3) == 0 && (y_ld & 3) == 0 && W >= 16 && H >= 4 && M >= 2048 && (long)H * W * Cin < (1L << 31) &&
-           // one workgroup per CU (156 KB of LDS): below ~half a chip of tiles the per-tile kernels, which spread a small map over every CU, are faster
-           // (8 x 40 x 40 pixels = 80 tiles: 0.73 ms here against 0.53 ms on the f32 per-tile kernel)
-           (M / ((long)H * W)) * ((H + kLkTH - 1) / kLkTH) * ((W + kLkTW - 1) / kLkTW) >= 128;
+    const bool k9 = kh == 9 && kw == 9 && pt == 4 && pl == 4 && Cout <= 64;
+    // k = 5 / one 32-channel group: built and measured EQUAL to the output-stationary kernel (157 against 146-149 us per group at 319 488 pixels: 25 taps of one
+    // chunk do not amortise the halo staging of a one-workgroup-per-CU kernel the way 81 taps x 8 chunks do) -- opt-in, OAR_IGEMM_LK5=1
+    static const bool k5_on = [] { const char* e = getenv("OAR_IGEMM_LK5"); return e && atoi(e) != 0; }();
+    const bool k5 = k5_on && kh == 5 && kw == 5 && pt == 2 && pl == 2 && Cout <= 32 && Cin == 32;
+    if (!(on && (k9 || k5) && sh == 1 && sw == 1 && dh == 1 && dw == 1 && Ho == H && Wo == W && (Cin & 31) == 0 && Cin >= 32 &&
+          (Cout & 3) == 0 && (y_ld & 3) == 0 && W >= 16 && H >= 4 && M >= 2048 && (long)H * W * Cin < (1L << 31))) return false;
+    // one workgroup per CU (129 ... 156 KB of LDS): below ~half a chip of tiles the per-tile kernels, which spread a small map over every CU, are faster
+    // (8 x 40 x 40 pixels = 80 tiles of the 9 x 9 kernel: 0.73 ms here against 0.53 ms on the f32 per-tile kernel)
+    const int th = lk_tile_rows(kh, H);
+    return (M / ((long)H * W)) * ((H + th - 1) / th) * ((W + kLkTW - 1) / kLkTW) >= 128;
 }
 
-void conv_lk_x6(hipStream_t s, const IgemmP& p, int n_images) {
+template <int KS, int TH, int NF>
+static void launch_lk(hipStream_t s, const IgemmP& p, int n_images) {
     LkP q;
     q.g = p;
     q.N = n_images;
     q.tiles_x = (p.W + kLkTW - 1) / kLkTW;
-    q.tiles_y = (p.H + kLkTH - 1) / kLkTH;
+    q.tiles_y = (p.H + TH - 1) / TH;
     q.tiles = (long)n_images * q.tiles_x * q.tiles_y;
     q.per_xcd = (q.tiles + 7) / 8;
     q.nfrag_alloc = (p.gemm_cout + 63) / 64 * 4;
-    constexpr int KS = 9;
-    const size_t lds = (size_t)3 * (kLkTW + KS - 1) * (kLkTH + KS - 1) * 64 + 3 * 12288;
-    OAR_MAX_LDS_ONCE(conv_lk_x6_kernel<9>, 160 * 1024);
-    hipLaunchKernelGGL(conv_lk_x6_kernel<9>, dim3((unsigned)(q.per_xcd * 8)), dim3(kLkThreads), lds, s, q);
+    const size_t lds = (size_t)3 * (kLkTW + KS - 1) * (TH + KS - 1) * 64 + (size_t)3 * NF * 3072;
+    OAR_CHECK(lds <= 160 * 1024, OAR_INTERNAL, "conv_lk_x6: tile does not fit LDS");
+    OAR_MAX_LDS_ONCE((conv_lk_x6_kernel<KS, TH, NF>), 160 * 1024);
+    hipLaunchKernelGGL((conv_lk_x6_kernel<KS, TH, NF>), dim3((unsigned)(q.per_xcd * 8)), dim3(kLkThreads), lds, s, q);
+}
+
+void conv_lk_x6(hipStream_t s, const IgemmP& p, int n_images) {
+    if (p.kh == 9) return launch_lk<9, 8, 4>(s, p, n_images);
+    OAR_CHECK(p.kh == 5 && p.Cin == 32 && p.gemm_cout <= 32, OAR_INTERNAL, "conv_lk_x6: not a shape conv_lk_x6_eligible accepts");
+    switch (lk_tile_rows(5, p.H)) {
+        case 12: return launch_lk<5, 12, 2>(s, p, n_images);
+        case 6: return launch_lk<5, 6, 2>(s, p, n_images);
+        default: return launch_lk<5, 8, 2>(s, p, n_images);
+    }
 }
 
 }  // namespace k

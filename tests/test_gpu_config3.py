@@ -133,7 +133,7 @@ def test_server_graphs_full_width_on_a_small_page():
     ocr.close()
 
 
-@pytest.mark.parametrize("case", [("svtrv2 stage 1", 128, 4, 8, 12, 704, False), ("svtrv2 stage 2 + residual", 256, 8, 6, 6, 2000, True)])
+@pytest.mark.parametrize("case", [("svtrv2 stage 1", 128, 4, 8, 12, 704, False), ("svtrv2 stage 2 + residual", 256, 8, 6, 6, 2000, True), ("few tiles: output-stationary", 128, 4, 2, 12, 1400, False), ("10 rows: 12-row tiles hang over", 64, 2, 9, 10, 530, True)])
 def test_grouped_mixing_conv_runs_per_group_on_the_matrix_pipe(case):
     """SVTRv2's local mixing: 5 x 5 convolution, 32 channels per group.  Each group is one implicit GEMM (K = 800, N = 32) on the
     output-stationary bf16x6 kernel reading its channels out of the full tensor (ConvP::x_ld); the direct kernel it replaces ran at 6.7 TFLOP/s."""
@@ -152,7 +152,8 @@ def test_grouped_mixing_conv_runs_per_group_on_the_matrix_pipe(case):
     _check(m, x)
     snap = {e["name"]: e["launches"] for e in api.prof_snapshot()}
     api.prof_enable(False)
-    assert snap.get("conv_igemm_os_x6", 0) == groups and not snap.get("conv_direct", 0), snap
+    # (round 6, later: groups of 32 channels run on the LDS-tiled kernel of igemm_lk_x6.hip when the launch has enough tiles, else on the output-stationary one)
+    assert snap.get("conv_lk_x6", 0) + snap.get("conv_igemm_os_x6", 0) == groups and not snap.get("conv_direct", 0), snap
 
 
 @pytest.mark.parametrize("case", [("lk-pan 256 -> 64", 256, 64, 4, 80, 128, True), ("lk-pan 64 -> 64, ragged tiles", 64, 64, 8, 45, 70, False), ("48 couts, ragged", 32, 48, 6, 60, 70, False)])
