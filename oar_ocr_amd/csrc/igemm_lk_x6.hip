@@ -11,11 +11,9 @@
 //     exactly into the three bf16 planes and stored to LDS as [plane][pixel][32 channels]; the 16-byte channel group of a pixel is XOR-swizzled with
 //     bits 2..3 of the pixel index, so that the 16 lanes of a fragment read (16 consecutive pixels, one group) hit 16 distinct 16-byte bank groups;
 //   * the B operand of tap (dy, dx) is then ONE ds_read_b128 per plane at pixel + dy * halo_width + dx: the im2col column never exists anywhere;
-//   * the tap's weights (4 cout fragments x 3 planes, 12 KB, IGEMM_W_X6 order) go global -> registers -> LDS one tap ahead (double buffer, one
-//     workgroup barrier per tap), and every wave reads them once per tap for its 4 pixel fragments: 24 ds_read_b128 per 96 MFMAs.
-//     Three LDS stages: while tap t is multiplied from REGISTERS, tap t + 1 is read LDS -> registers (its reads hide behind the MFMAs instead of
-//     standing in front of them after every barrier) and tap t + 2 travels global -> registers -> LDS.
-// Per chunk and tile: 80 KB of input read, k * k * 96 MFMAs per wave.  LDS: 3 planes x 640 pixels x 64 B + 3 x 12 KB = 156 KB at k = 9.
+//   * the tap's weights (4 cout fragments x 3 planes, 12 KB, IGEMM_W_X6 order) are loaded by every wave into registers one tap ahead of their use (two
+//     register sets; L1 / L2 hits: all waves of all workgroups read the same rows); no barrier inside a chunk -- 12 ds_read_b128 per 96 MFMAs.
+// Per chunk and tile: 80 KB of input read, k * k * 96 MFMAs per wave.  LDS: 3 planes x 640 pixels x 64 B = 120 KB at k = 9.
 #include "igemm_dev.h"
 
 namespace oar {
@@ -53,10 +51,7 @@ template <int KS, int TH, int NF>
 __global__ __launch_bounds__(kLkThreads, 1) void conv_lk_x6_kernel(LkP q) {
     constexpr int PAD = KS / 2, HWD = kLkTW + KS - 1, HHT = TH + KS - 1, NPX = HWD * HHT;
     constexpr int PF = TH / 2;                             // pixel fragments per wave
-    constexpr int WSTB = NF * 3072;                        // bytes of one weight stage
-    constexpr int NWL = (NF * 192 + kLkThreads - 1) / kLkThreads;
     constexpr unsigned PLB = (unsigned)NPX * 64u;          // bytes of one plane of the halo tile
-    constexpr unsigned WST0 = 3u * PLB;                    // weight stages behind the planes: 3 x [4 cout fragments][3 planes][64 lanes] 16 B
     constexpr int NQ = NPX * 8;                            // float4 quads of one chunk of the halo
     constexpr int NSL = (NQ + kLkThreads - 1) / kLkThreads;
     constexpr int NSH = (NSL + 1) / 2;                     // staged in two halves: NSH quads per thread in flight
@@ -86,24 +81,21 @@ __global__ __launch_bounds__(kLkThreads, 1) void conv_lk_x6_kernel(LkP q) {
 #pragma clang loop unroll(full)
         for (int nf = 0; nf < NF; ++nf) acc[f][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // weights of (tap, chunk): thread t copies uint4 #(t + 256 u), u < NWL, of the [NF][3][64] block
-    const uint4* wsrc = reinterpret_cast<const uint4*>(p.w);
-    lk_u32x4 wreg[NWL];
-    auto w_request = [&](int tap, int c) {
-        const int kc = tap * CC + c;
+    // weights of (tap, chunk): every wave loads the NF x 3 fragments it multiplies with straight into registers (IGEMM_W_X6 order: one coalesced 1 KB row per
+    // fragment and plane, the same addresses for all waves and workgroups -> L1 / L2 hits), one tap ahead of their use.  (A first version passed them through a
+    // triple-buffered LDS stage with a workgroup barrier per tap: same speed to 1 %, and the barrier tied the four waves together at every tap.)
+    const uint4* wsrc = reinterpret_cast<const uint4*>(p.w) + lane;
+    auto w_load = [&](lk_u32x4 (&wf)[NF][3], int tap, int c) {
+        const long kc = (long)tap * CC + c;
 #pragma clang loop unroll(full)
-        for (int u = 0; u < NWL; ++u) {
-            const int i = min(tid + kLkThreads * u, NF * 192 - 1);
-            const int nf = i / 192, r = i - nf * 192;
+        for (int nf = 0; nf < NF; ++nf) {
             const int nfg = min(nf, q.nfrag_alloc - 1);
-            const uint4 v = wsrc[((long)nfg * p.KC + kc) * 192 + r];
-            wreg[u] = (lk_u32x4){v.x, v.y, v.z, v.w};
-        }
-    };
-    auto w_commit = [&](int stage) {
 #pragma clang loop unroll(full)
-        for (int u = 0; u < NWL; ++u)
-            if (tid + kLkThreads * u < NF * 192) lk_lds_w4(WST0 + (unsigned)(stage * WSTB + (tid + kLkThreads * u) * 16), wreg[u]);
+            for (int pl = 0; pl < 3; ++pl) {
+                const uint4 v = wsrc[((long)nfg * p.KC + kc) * 192 + pl * 64];
+                wf[nf][pl] = (lk_u32x4){v.x, v.y, v.z, v.w};
+            }
+        }
     };
     // one chunk of the halo: global f32 -> three bf16 planes in LDS
     auto stage_halo = [&](int c) {
@@ -151,13 +143,6 @@ __global__ __launch_bounds__(kLkThreads, 1) void conv_lk_x6_kernel(LkP q) {
         for (int pl = 0; pl < 3; ++pl) dst[pl] = lk_lds4(a + (unsigned)pl * PLB);
     };
 
-    auto w_read = [&](lk_u32x4 (&wf)[NF][3], int stage) {
-        const unsigned wst = WST0 + (unsigned)(stage * WSTB + lane * 16);
-#pragma clang loop unroll(full)
-        for (int nf = 0; nf < NF; ++nf)
-#pragma clang loop unroll(full)
-            for (int pl = 0; pl < 3; ++pl) wf[nf][pl] = lk_lds4(wst + (unsigned)((nf * 3 + pl) * 1024));
-    };
     auto tap_mfma = [&](const lk_u32x4 (&wf)[NF][3], int tap) {
         const int dy = tap / KS, dx = tap - dy * KS;
         const int tapoff = dy * HWD + dx;
@@ -174,31 +159,25 @@ __global__ __launch_bounds__(kLkThreads, 1) void conv_lk_x6_kernel(LkP q) {
         }
     };
     constexpr int KK = KS * KS;
-    // one tap: `cur` holds its weights; `nxt` receives tap + 1's from LDS stage (tap + 1) % 3; tap + 2's go global -> registers -> stage (tap + 2) % 3
-    auto tap_step = [&](lk_u32x4 (&cur)[NF][3], lk_u32x4 (&nxt)[NF][3], int tap, int c) {
-        if (tap + 2 < KK) w_request(tap + 2, c);
-        if (tap + 1 < KK) w_read(nxt, (tap + 1) % 3);
-        tap_mfma(cur, tap);
-        if (tap + 2 < KK) w_commit((tap + 2) % 3);
-        __syncthreads();
-    };
     lk_u32x4 wa[NF][3], wb[NF][3];
+    w_load(wa, 0, 0);
     for (int c = 0; c < CC; ++c) {
-        // (the barrier that ended the previous chunk's last tap: every wave is done with the old halo and with all three weight stages)
-        w_request(0, c);
+        if (c > 0) __syncthreads();   // every wave is done with the previous chunk's halo
         stage_halo(c);
-        w_commit(0);
-        w_request(1, c);
-        w_commit(1);
         __syncthreads();
-        w_read(wa, 0);
         int tap = 0;
 #pragma clang loop unroll(disable)
         for (; tap + 1 < KK; tap += 2) {
-            tap_step(wa, wb, tap, c);
-            tap_step(wb, wa, tap + 1, c);
+            w_load(wb, tap + 1, c);
+            tap_mfma(wa, tap);
+            if (tap + 2 < KK) w_load(wa, tap + 2, c);
+            else if (c + 1 < CC) w_load(wa, 0, c + 1);
+            tap_mfma(wb, tap + 1);
         }
-        if (tap < KK) tap_step(wa, wb, tap, c);
+        if (tap < KK) {   // odd tap count: the last tap runs from wa; the next chunk's first tap is requested behind it
+            tap_mfma(wa, tap);
+            if (c + 1 < CC) w_load(wa, 0, c + 1);
+        }
     }
 
     // ---- epilogue: bias + residual + activation, one float4 per (pixel, 4 couts)
@@ -228,15 +207,19 @@ __global__ __launch_bounds__(kLkThreads, 1) void conv_lk_x6_kernel(LkP q) {
 static int lk_tile_rows(int ks, int H) {
     if (ks == 9) return 8;
     int best = 8, waste = 1 << 30;
-    for (int th : {12, 8, 6}) { const int w = (H + th - 1) / th * th - H; if (w < waste) { waste = w; best = th; } }
+    static const int pref = [] { const char* e = getenv("OAR_IGEMM_LK5_TH"); return e ? atoi(e) : 0; }();   // (A/B knob: force 6 / 8 / 12)
+    if (pref == 6 || pref == 8 || pref == 12) return pref;
+    for (int th : {6, 8, 12}) { const int w = (H + th - 1) / th * th - H; if (w < waste) { waste = w; best = th; } }   // ties: the smaller tile (two workgroups per CU)
     return best;
 }
 bool conv_lk_x6_eligible(int kh, int kw, int sh, int sw, int pt, int pl, int dh, int dw, int H, int W, int Ho, int Wo, int Cin, int Cout, int y_ld, long M) {
     static const bool on = [] { const char* e = getenv("OAR_IGEMM_LK"); return !e || atoi(e) != 0; }();
     const bool k9 = kh == 9 && kw == 9 && pt == 4 && pl == 4 && Cout <= 64;
-    // k = 5 / one 32-channel group: built and measured EQUAL to the output-stationary kernel (157 against 146-149 us per group at 319 488 pixels: 25 taps of one
-    // chunk do not amortise the halo staging of a one-workgroup-per-CU kernel the way 81 taps x 8 chunks do) -- opt-in, OAR_IGEMM_LK5=1
-    static const bool k5_on = [] { const char* e = getenv("OAR_IGEMM_LK5"); return e && atoi(e) != 0; }();
+    // k = 5 / one 32-channel group (OAR_IGEMM_LK5=0: back to the output-stationary kernel).  With the weights through an LDS stage and 12-row tiles (one workgroup
+    // per CU) it measured EQUAL to that kernel (157 against 146-149 us per group at 319 488 pixels: 25 taps of one chunk do not amortise a halo staging nothing
+    // overlaps); with the weights in registers and 6-row tiles -- 69 KB of LDS, two workgroups per CU, one stages while the other multiplies -- 57 against 77 us
+    // at 159 744 pixels
+    static const bool k5_on = [] { const char* e = getenv("OAR_IGEMM_LK5"); return !e || atoi(e) != 0; }();
     const bool k5 = k5_on && kh == 5 && kw == 5 && pt == 2 && pl == 2 && Cout <= 32 && Cin == 32;
     if (!(on && (k9 || k5) && sh == 1 && sw == 1 && dh == 1 && dw == 1 && Ho == H && Wo == W && (Cin & 31) == 0 && Cin >= 32 &&
           (Cout & 3) == 0 && (y_ld & 3) == 0 && W >= 16 && H >= 4 && M >= 2048 && (long)H * W * Cin < (1L << 31))) return false;
@@ -256,7 +239,7 @@ static void launch_lk(hipStream_t s, const IgemmP& p, int n_images) {
     q.tiles = (long)n_images * q.tiles_x * q.tiles_y;
     q.per_xcd = (q.tiles + 7) / 8;
     q.nfrag_alloc = (p.gemm_cout + 63) / 64 * 4;
-    const size_t lds = (size_t)3 * (kLkTW + KS - 1) * (TH + KS - 1) * 64 + (size_t)3 * NF * 3072;
+    const size_t lds = (size_t)3 * (kLkTW + KS - 1) * (TH + KS - 1) * 64;
     OAR_CHECK(lds <= 160 * 1024, OAR_INTERNAL, "conv_lk_x6: tile does not fit LDS");
     OAR_MAX_LDS_ONCE((conv_lk_x6_kernel<KS, TH, NF>), 160 * 1024);
     hipLaunchKernelGGL((conv_lk_x6_kernel<KS, TH, NF>), dim3((unsigned)(q.per_xcd * 8)), dim3(kLkThreads), lds, s, q);
