@@ -71,23 +71,28 @@ __global__ __launch_bounds__(256, 2) void attention_x6_kernel(const float* __res
     const bool is_k = tid < 128;
     const int slot = tid & 127, s_tile = slot >> 6, s_lane = slot & 63, s_i = s_lane & 15, s_g = s_lane >> 4;
     float stg[8];
+    // (every load is unconditional -- out-of-range keys read key T - 1 and are zeroed afterwards: with a branch per load the compiler waited for each of the
+    // eight strided value loads before it issued the next, eight memory round trips per block where the block's products take one)
     auto stage_load = [&](int kb) {
         const int k0 = kb * kAttKB;
         if (is_k) {
             const int key = k0 + s_tile * 16 + s_i;
-            if (key < T) {
-                const float4 a = *reinterpret_cast<const float4*>(base + (long)key * row_ld + dim + 8 * s_g);
-                const float4 b = *reinterpret_cast<const float4*>(base + (long)key * row_ld + dim + 8 * s_g + 4);
-                stg[0] = a.x; stg[1] = a.y; stg[2] = a.z; stg[3] = a.w; stg[4] = b.x; stg[5] = b.y; stg[6] = b.z; stg[7] = b.w;
-            } else {
-#pragma clang loop unroll(full)
-                for (int j = 0; j < 8; ++j) stg[j] = 0.f;
-            }
+            const float* src = base + (long)min(key, T - 1) * row_ld + dim + 8 * s_g;
+            const float4 a = *reinterpret_cast<const float4*>(src);
+            const float4 b = *reinterpret_cast<const float4*>(src + 4);
+            const float z = key < T ? 1.f : 0.f;
+            stg[0] = a.x * z; stg[1] = a.y * z; stg[2] = a.z * z; stg[3] = a.w * z; stg[4] = b.x * z; stg[5] = b.y * z; stg[6] = b.z * z; stg[7] = b.w * z;
         } else {
+            float v[8];
 #pragma clang loop unroll(full)
             for (int j = 0; j < 8; ++j) {
                 const int key = k0 + (j < 4 ? 4 * s_g + j : 16 + 4 * s_g + (j - 4));
-                stg[j] = key < T ? base[(long)key * row_ld + 2 * dim + s_tile * 16 + s_i] : 0.f;
+                v[j] = base[(long)min(key, T - 1) * row_ld + 2 * dim + s_tile * 16 + s_i];
+            }
+#pragma clang loop unroll(full)
+            for (int j = 0; j < 8; ++j) {
+                const int key = k0 + (j < 4 ? 4 * s_g + j : 16 + 4 * s_g + (j - 4));
+                stg[j] = key < T ? v[j] : 0.f;
             }
         }
     };
@@ -112,6 +117,8 @@ __global__ __launch_bounds__(256, 2) void attention_x6_kernel(const float* __res
     stage_load(0);
     stage_commit(0);
     __syncthreads();
+    // (requesting the blocks TWO iterations ahead -- a second staging set, 182 registers -- was measured slower: 369 against 312 us per launch; the third wave
+    // per SIMD that 161 registers allow hides more than the longer prefetch distance does)
     for (int kb = 0; kb < n_blocks; ++kb) {
         const int st = kb & 1;
         const bool more = kb + 1 < n_blocks;
