@@ -59,8 +59,11 @@ def parse_args(argv=None):
                          "4 = full pipeline (doc orientation + UVDoc + det + rec + text-line orientation) on 16 x 960^2 pages")
     ap.add_argument("--det-params", choices=("class", "real-size"), default="real-size",
                     help="config 1 / 3 / 4 graphs: 'real-size' (default since round 6) = detector and recognizer at the parameter counts of the files they stand for "
-                         "(pp-ocrv6_tiny_det.onnx 0.445 M, pp-ocrv6_tiny_rec.onnx 1.116 M: registry.rs:83-84 -> synth 'tiny_full': 0.447 M / 1.103 M); 'class' = the lighter "
+                         "(pp-ocrv6_tiny_det.onnx 0.445 M, pp-ocrv6_tiny_rec.onnx 1.116 M: registry.rs:83-84 -> synth 'tiny_full': 0.447 M / 1.136 M); 'class' = the lighter "
                          "graphs of rounds 1-5 (0.288 M / 0.914 M).  The default line times 'real-size' and reports 'class' beside it")
+    ap.add_argument("--rec-variant", choices=("head", "deep"), default="head",
+                    help="real-size recognizer of config 1 / 3 / 4: 'head' = synth 'tiny_full' (the extra 0.2 M parameters in the CTC projection, 96 x 6906: 1.136 M); "
+                         "'deep' = synth 'tiny_deep' (two more 5x5 blocks + one SE block in the backbone: 1.103 M) -- the first form this round measured, kept for comparison")
     ap.add_argument("--c3-graphs", choices=("named", "standin"), default="named",
                     help="config 2: 'named' = graphs of the size and kind BASELINE C3 names (synth/models.py build_det_hgnet / build_rec_svtrv2); 'standin' = the "
                          "widened LCNet detector (4.3 M) + SVTR-neck recognizer (7.3 M, V = 18710) rounds 1-5 ran config 2 on, detector input at the default 960")
@@ -194,6 +197,8 @@ def main():
     size_name, vocab = ("server", 18710) if args.config == 2 else ("tiny", 6906)
     det_name = "tiny_full" if (size_name == "tiny" and args.det_params == "real-size") else size_name
     rec_name = det_name if size_name == "tiny" else size_name
+    if rec_name == "tiny_full" and args.rec_variant == "deep":
+        rec_name = "tiny_deep"
     c3_named = args.config == 2 and args.c3_graphs == "named"
     if c3_named:   # ch_svtrv2_rec.onnx is used with ppocr_keys_v1.txt: 6623 lines -> V = 6625
         det_name, rec_name, vocab = "server_hgnet", "svtrv2", 6625
@@ -461,7 +466,7 @@ def main():
         real_size = {"value": round(n_pages * args.steps / qdt, 2), "unit": "images/sec", "ms_per_step": round(qdt / args.steps * 1e3, 3),
                      "det_params": det_cls_info["params"], "rec_params": rec_cls_info["params"], "regions_per_step": len(r3.scores),
                      "what": "the same step (same pages, same entry point) on the LIGHTER graphs rounds 1-5 quoted as their headline: synth models.build_det('tiny') 0.288 M + "
-                             "build_rec('tiny') 0.914 M parameters.  `value` above is on graphs of the size of the files it names (0.447 M / 1.103 M)"}
+                             "build_rec('tiny') 0.914 M parameters.  `value` above is on graphs of the size of the files it names (0.447 M / 1.136 M)"}
         ocr3.close()
 
     # -- fifth figure: the recognizer's batches alternating over two streams (OAR_REC_LANES=2: a second engine instance, same weights).  The

@@ -171,10 +171,10 @@ void launch_ch(K kernel, hipStream_t s, const CtcHeadP& p, dim3 grid, size_t lds
 }
 }  // namespace
 
-// K a multiple of 32 up to 64 (the tile's 8 x KC x 3 KB of weights, double-buffered, must fit LDS); OAR_CTC_HEAD_OS=0 keeps the weight-stationary kernels
+// K a multiple of 32 up to 96 (the tile's 8 x KC x 3 KB of weights, double-buffered, must fit LDS: 144 KB at K = 96, round 6); OAR_CTC_HEAD_OS=0 keeps the weight-stationary kernels
 bool ctc_head_x6_supported(long M, int K, int n_padded) {
     static const bool on = [] { const char* e = getenv("OAR_CTC_HEAD_OS"); return !e || atoi(e) != 0; }();
-    return on && M > 0 && (K == 32 || K == 64) && n_padded >= 128 && (n_padded & 15) == 0 && M * (long)ctc_tiles(n_padded) * 16 < (1L << 40);
+    return on && M > 0 && (K == 32 || K == 64 || K == 96) && n_padded >= 128 && (n_padded & 15) == 0 && M * (long)ctc_tiles(n_padded) * 16 < (1L << 40);
 }
 
 void ctc_head_x6(hipStream_t s, const float* x, const float* w_x6, const float* bias, float* part, long M, int K, int n_padded, int valid) {
@@ -186,13 +186,15 @@ void ctc_head_x6(hipStream_t s, const float* x, const float* w_x6, const float* 
     p.w_bytes = (unsigned)(rows64 / 16 * KC * 3 * 1024);
     const int row_blocks = (int)((M + kChWaves * kChRT * 16 - 1) / (kChWaves * kChRT * 16));
     int splits = std::max(1, std::min(p.ny, (240 + row_blocks - 1) / row_blocks));
-    p.tiles_per_wg = std::min((p.ny + splits - 1) / splits, 96);   // (the bias range of a workgroup lives in LDS: at most 48 KB of it)
+    const int bias_cap = (int)((160 * 1024 - (size_t)2 * 8 * KC * 3 * 1024) / 512);   // the bias range of a workgroup lives in LDS behind the two weight buffers (K = 96: 32 tiles)
+    p.tiles_per_wg = std::min((p.ny + splits - 1) / splits, std::min(96, bias_cap));
     splits = (p.ny + p.tiles_per_wg - 1) / p.tiles_per_wg;
     const size_t lds = (size_t)2 * 8 * KC * 3 * 1024 + (size_t)p.tiles_per_wg * 512;
     OAR_CHECK(lds <= 160 * 1024, OAR_INTERNAL, "ctc_head_x6: the column range of a workgroup does not fit LDS");
     const double flops = 2.0 * (double)M * K * n_padded, bytes = 4.0 * (double)M * K + 6.0 * (double)K * n_padded + 16.0 * (double)M * p.ny;
     ProfScope ps(s, "ctc_head_x6", bytes, flops, true);
     if (KC == 1) launch_ch(ctc_head_x6_kernel<1>, s, p, dim3((unsigned)splits, (unsigned)row_blocks), lds, ps.start(), ps.stop());
+    else if (KC == 3) launch_ch(ctc_head_x6_kernel<3>, s, p, dim3((unsigned)splits, (unsigned)row_blocks), lds, ps.start(), ps.stop());
     else launch_ch(ctc_head_x6_kernel<2>, s, p, dim3((unsigned)splits, (unsigned)row_blocks), lds, ps.start(), ps.stop());
 }
 

@@ -108,7 +108,7 @@ def test_c2_32_pages_of_960x960_in_one_predict():
 
 def test_c2_32_pages_on_graphs_of_the_files_sizes():
     """BASELINE C2 on the graphs bench.py times by default since round 6: detector 447 089 parameters (pp-ocrv6_tiny_det.onnx:
-    1 780 590 bytes), recognizer 1 103 284 (pp-ocrv6_tiny_rec.onnx: 4 462 639 bytes) -- 32 pages of 960 x 960 in one predict, eight against the oracle."""
+    1 780 590 bytes), recognizer 1 135 700 (pp-ocrv6_tiny_rec.onnx: 4 462 639 bytes; CTC head K = 96 on ctc_head_x6_kernel<3>) -- 32 pages of 960 x 960 in one predict, eight against the oracle."""
     det, di = models.build_det("tiny_full", seed=0)
     rec, ri = models.build_rec("tiny_full", vocab=6906, seed=1)
     assert abs(di["params"] * 4 / 1780590 - 1) < 0.02 and abs(ri["params"] * 4 / 4462639 - 1) < 0.02

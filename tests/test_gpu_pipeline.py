@@ -191,13 +191,16 @@ def test_fused_ctc_tail_matches_unfused(nets):
     np.testing.assert_allclose(got.probs.reshape(-1), pr, rtol=1e-5, atol=0)
 
 
-@pytest.mark.parametrize("vocab", [1100, 3001, 6906])
+@pytest.mark.parametrize("vocab", [1100, 3001, 6906, (6906, "tiny_full")])
 def test_ctc_head_kernel_on_ragged_vocabularies(vocab, monkeypatch):
     """csrc/ctc_head_x6.hip (round 5): the output-stationary CTC head with padded widths that are not multiples of its 128-column tile (1100 -> 1104, 3001 -> 3008: the last
     tile reads weights / bias past the matrix; the fused tail is only used above 1024 classes), and at the bench's 6906 -- indices equal to the
     logits + stand-alone arg max path, probabilities to a few ulp, and equal to the weight-stationary kernels it replaced (OAR_CTC_HEAD_OS=0 needs a fresh
     process for its cached switch, so that comparison is on values: both must match the unfused tail)."""
-    rec, _ = models.build_rec("tiny", vocab=vocab, seed=3)
+    size = "tiny"
+    if isinstance(vocab, tuple):   # round 6: the real-size recognizer's head, K = 96 (ctc_head_x6_kernel<3>: 144 KB of double-buffered weights)
+        vocab, size = vocab
+    rec, _ = models.build_rec(size, vocab=vocab, seed=3)
     chars = api.read_dict(models.synth_dict(vocab - 2))
     crops = [pages.make_crop(70 + i, w, h) for i, (w, h) in enumerate([(320, 48), (200, 40), (640, 48), (90, 30), (33, 48)])]
     api.prof_enable(True); api.prof_reset()
