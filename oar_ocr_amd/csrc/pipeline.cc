@@ -681,7 +681,9 @@ void Detector::run_group(const std::vector<int>& idx, const std::vector<PageRef>
     // (8: 2350 / 2409 / 2406, 16: 2527 / 2457 / 2462; profiles/r5/det_sub_ab.txt), 4 pinned cores +3 %.  A rank with two cores is host-bound in this
     // phase and prefers the finer grain (8: 1988, 16: 1927): a pool of <= 2 threads keeps 8.
     static const int sub_env = [] { const char* e = getenv("OAR_DET_SUB"); int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
-    const int kSub = sub_env > 0 ? sub_env : (pool_->size() <= 1 ? 8 : 16);   // size() = workers next to the calling thread
+    // Round 6: 12 (6 / 10 / 10 / 6) on the real-size detector, whose sub-batch takes 1.5x as long on the GPU: +2 % over five alternating pairs
+    // (16: 2178 / 2214 / 2246 / 2283 / 2242, 12: 2278 / 2297 / 2293 / 2320 / 2288; profiles/r6/det_sub_ab.txt)
+    const int kSub = sub_env > 0 ? sub_env : (pool_->size() <= 1 ? 8 : 12);   // size() = workers next to the calling thread
     // sub-batch sizes: the LAST one is half-size (its contour tracing is the only host work the GPU cannot overlap); when the
     // pages still have to be uploaded the FIRST one is half-size too (the GPU idles until its pages have crossed PCIe:
     // 0.9 ms for ten 960^2 pages, OAR_DET_FIRST=0 disables); the others share the rest evenly
