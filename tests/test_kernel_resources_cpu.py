@@ -111,7 +111,7 @@ def test_round5_kernels_fit_their_wave_budgets():
         cap = 128 if "ILi1ELi2ELi3ELi16E" in name else 168 if "ILi2ELi3ELi3ELi12E" in name else 256
         assert r["vgprs"] <= cap and r["spill"] == 0 and r["scratch"] == 0, (name, r)
     ch = {k: v for k, v in _resources("ctc_head_x6.hip").items() if "ctc_head_x6_kernel" in k}
-    assert len(ch) == 2
+    assert len(ch) == 3      # K = 32 / 64 / 96 (round 6: the real-size recognizer's head; 72 operand registers, still three waves per SIMD)
     for name, r in ch.items():
         assert r["vgprs"] <= 168 and r["spill"] == 0 and r["scratch"] == 0 and r["occupancy"] >= 3, (name, r)
 
