@@ -16,8 +16,10 @@ cls4, cls2, uvdoc = models.build_cls(4, seed=5)[0], models.build_cls(2, seed=9)[
 server = len(sys.argv) > 3 and sys.argv[3] == "server"       # BASELINE config 3 graphs (wide layers: large-K weight-stationary kernels);
 #                                                               the torch-CPU oracle needs ~15 min per case on them: run a handful at most
 seal = len(sys.argv) > 3 and sys.argv[3] == "seal"           # text_type "seal": stamp-like pages, polygon boxes, sort_poly_boxes, bounding-rectangle crops
-det, _ = models.build_det("server" if server else "tiny", seed=2 if server else 0)
-rec, _ = models.build_rec("server" if server else "tiny", vocab=18710 if server else 6906, seed=3 if server else 1)
+import os
+tiny_name = "tiny_full" if os.environ.get("FUZZ_GRAPHS", "") == "full" else "tiny"   # FUZZ_GRAPHS=full: the real-size graphs bench.py times by default since round 6
+det, _ = models.build_det("server" if server else tiny_name, seed=2 if server else 0)
+rec, _ = models.build_rec("server" if server else tiny_name, vocab=18710 if server else 6906, seed=3 if server else 1)
 chars = api.read_dict(models.synth_dict(18708 if server else 6904))
 max_side = 640 if server else 1100
 only_case = int(sys.argv[4]) if len(sys.argv) > 4 else None
