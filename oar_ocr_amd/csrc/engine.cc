@@ -731,6 +731,33 @@ struct Planner {
     // A 2x2 / stride-2 ConvTranspose whose only consumer is another one (the DB head's tail) is held back the same way: the
     // consumer runs both as k::convt2x2_pair, anything else runs it first.
     std::map<std::string, const GNode*> pending_convt;
+    // Round 6: a plain channel concat of channels-last maps whose ONLY reader is a 1x1 convolution the output-stationary bf16x6 kernel can take (PP-HGNetV2's
+    // aggregation: seven maps, up to 3328 channels) is not written at all: the convolution reads its K dimension out of the sources (ConvP::msrc).  Anything
+    // else that asks for the value first gets the gather launch.  compute_last_use keeps the sources alive until that reader.
+    struct PendingConcat { std::vector<Loc> src; std::vector<int> c; std::vector<int64_t> dims; };
+    std::map<std::string, PendingConcat> pending_concat;
+    std::map<std::string, int> concat_consumer;   // Concat output -> index of its only consumer node
+    void emit_concat_gather(const PendingConcat& pc, Loc yl) {
+        k::ConcatGatherP gp{};
+        gp.n_src = (int)pc.src.size(); gp.N = (int)pc.dims[0]; gp.Ho = (int)pc.dims[2]; gp.Wo = (int)pc.dims[3]; gp.C = (int)pc.dims[1];
+        int off = 0;
+        for (size_t i = 0; i < pc.src.size(); ++i) { gp.c[i] = pc.c[i]; gp.off[i] = off; gp.fh[i] = 1; gp.fw[i] = 1; off += pc.c[i]; }
+        const std::vector<Loc> src = pc.src;
+        step([=](const RunCtx& c) {
+            k::ConcatGatherP q = gp;
+            for (int i = 0; i < q.n_src; ++i) q.x[i] = c.at(src[(size_t)i]);
+            k::concat_gather(c.s, q, c.mut(yl));
+        }, 0, 8.0 * (double)numel(pc.dims));
+    }
+    void materialise_concat(const std::string& name) {
+        auto it = pending_concat.find(name);
+        if (it == pending_concat.end()) return;
+        const PendingConcat pc = it->second;
+        pending_concat.erase(it);
+        vals.erase(name);
+        TInfo& y = new_out(name, pc.dims, Layout::CLAST);
+        emit_concat_gather(pc, y.loc);
+    }
     const PendingResize* peek_pending(const std::string& name) const {
         auto it = pending_resize.find(name);
         return it == pending_resize.end() ? nullptr : &it->second;
@@ -755,6 +782,7 @@ struct Planner {
     // ------------------------------------------------------------------ values
     TInfo& get(const std::string& name) {
         if (!pending_resize.empty() || !pending_convt.empty()) materialise_pending(name);
+        if (!pending_concat.empty()) materialise_concat(name);
         auto it = vals.find(name);
         if (it != vals.end()) return it->second;
         auto ii = E.inits_.find(name);
@@ -1410,6 +1438,19 @@ struct Planner {
                 return;
             }
         }
+        PendingConcat msrc;   // non-empty: the input is a deferred concat this convolution reads source by source
+        {
+            auto pit = pending_concat.find(n.in[0]);
+            if (pit != pending_concat.end()) {
+                auto wi = E.inits_.find(n.in.size() > 1 ? n.in[1] : std::string());
+                const std::vector<int64_t>& pd = pit->second.dims;
+                const bool still_ok = wi != E.inits_.end() && wi->second.dims.size() == 4 && wi->second.dims[2] == 1 && wi->second.dims[3] == 1 && n.residual.empty() &&
+                                      !(n.in.size() > 3 && !n.in[3].empty()) && n.out.size() == 1 &&
+                                      k::conv_msrc_ok((long)(pd[0] * pd[2] * pd[3]), (int)pd[1], (int)wi->second.dims[0]);
+                if (getenv("OAR_DEBUG_CONCAT")) fprintf(stderr, "  conv %s reads pending concat: still_ok=%d (w4=%d res=%d gate=%d nout=%zu)\n", n.out[0].c_str(), (int)still_ok, (int)(wi != E.inits_.end() && wi->second.dims.size() == 4), (int)!n.residual.empty(), (int)(n.in.size() > 3 && !n.in[3].empty()), n.out.size());
+                if (still_ok) { msrc = pit->second; TInfo keep = vals[n.in[0]]; pending_concat.erase(pit); vals[n.in[0]] = keep; }
+            }
+        }
         TInfo x = get(n.in[0]);
         OAR_CHECK(x.dims.size() == 4, OAR_UNSUPPORTED_OP, "Conv: only 2-D convolutions are supported");
         const TInfo& wt = get(n.in[1]);
@@ -1444,7 +1485,7 @@ struct Planner {
             }, 2.0 * N * Ho * Wo * Cout * 3 * kh * kw, 3.0 * N * H * Wd + 4.0 * N * Ho * Wo * Cout);
             return;
         }
-        Loc xin = to_clast_loc(x);
+        Loc xin = msrc.src.empty() ? to_clast_loc(x) : Loc();   // (a deferred concat has no storage of its own)
         const float* bias = has_input(n, 2) ? get(n.in[2]).loc.cptr : nullptr;
         Loc res;
         int res_up = 0;
@@ -1574,9 +1615,17 @@ struct Planner {
                 return;
             }
         }
+        const bool from_concat = !msrc.src.empty();
+        OAR_CHECK(!from_concat || (kind == 0 && p.w_fmt == k::IGEMM_W_X6), OAR_INTERNAL, "Conv: deferred concat in front of a layer that is not on the bf16x6 kernels");
         auto run = [=](const RunCtx& c) {
             k::ConvP q = p;
-            q.x = c.at(xin); q.y = c.mut(yl); q.residual = has_res ? c.at(res) : nullptr; q.se = has_gate ? c.at(gate) : nullptr;
+            q.y = c.mut(yl); q.residual = has_res ? c.at(res) : nullptr; q.se = has_gate ? c.at(gate) : nullptr;
+            if (from_concat) {
+                q.x = nullptr; q.n_msrc = (int)msrc.src.size();
+                for (int i = 0; i < q.n_msrc; ++i) { q.msrc[i] = c.at(msrc.src[(size_t)i]); q.msrc_c[i] = msrc.c[(size_t)i]; }
+            } else {
+                q.x = c.at(xin);
+            }
             if (kind == 3) {
                 const int ng = p.groups, cgi = p.Cin / ng, ogi = p.Cout / ng;
                 for (int gi = 0; gi < ng; ++gi) {
@@ -2573,8 +2622,6 @@ struct Planner {
             for (int i = pax + 1; i < r; ++i) inner *= pod[i];
             std::vector<Loc> ins;
             for (size_t i = 0; i < xs.size(); ++i) ins.push_back(absorb && peek_pending(n.in[i]) ? Loc() : to_clast_loc(xs[i]));
-            TInfo& y = new_out(n.out[0], od, Layout::CLAST);
-            Loc yl = y.loc;
             int64_t coff = 0, total = pod[pax] * inner;
             // round 5: every absorbed resize an integer-factor nearest upsampling (the DB neck: up8 / up4 / up2 of three pyramid levels next to
             // the finest one) -> the whole concat is ONE gather launch instead of one launch per input.  OAR_CONCAT_GATHER=0 restores those.
@@ -2582,6 +2629,35 @@ struct Planner {
             // strided copies)
             bool plain = !absorb && r == 4 && inner == 1 && xs.size() >= 3 && (od[1] & 3) == 0;
             for (auto& t : xs) plain = plain && t.dims.size() == 4 && (t.dims[1] & 3) == 0;
+            // (round 6, later) ... or no launch at all when the only reader is a 1x1 convolution that can read the sources itself (pending_concat above)
+            static const bool defer_on = [] { const char* e = getenv("OAR_CONCAT_DEFER"); return !(e && e[0] == '0'); }();
+            if (getenv("OAR_DEBUG_CONCAT")) fprintf(stderr, "concat %s: plain=%d absorb=%d r=%d inner=%ld n=%zu consumer=%d\n", n.out[0].c_str(), (int)plain, (int)absorb, r, (long)inner, xs.size(), concat_consumer.count(n.out[0]) ? concat_consumer[n.out[0]] : -1);
+            if (plain && defer_on && xs.size() <= 8 && concat_consumer.count(n.out[0])) {
+                const GNode& cn = E.nodes_[concat_consumer[n.out[0]]];
+                auto wi = E.inits_.find(cn.in.size() > 1 ? cn.in[1] : std::string());
+                auto attr_ok = [&](const char* a, int64_t want) { auto v = cn.ais(a); for (auto e : v) if (e != want) return false; return true; };
+                bool ok = wi != E.inits_.end() && wi->second.dims.size() == 4 && wi->second.dims[2] == 1 && wi->second.dims[3] == 1 && wi->second.dims[1] == od[1] && cn.ai("group", 1) == 1 &&
+                          attr_ok("strides", 1) && attr_ok("pads", 0) && attr_ok("dilations", 1) && cn.residual.empty() && !(cn.in.size() > 3 && !cn.in[3].empty()) &&
+                          cn.as("auto_pad", "NOTSET") == "NOTSET";
+                for (auto& t : xs) ok = ok && t.layout == Layout::CLAST && (t.dims[1] & 7) == 0 && t.dims[0] == od[0] && t.dims[2] == od[2] && t.dims[3] == od[3] && !t.host_int;   // (channels-last already: a converted copy would be a temporary of THIS node)
+                if (getenv("OAR_DEBUG_CONCAT")) {
+                    fprintf(stderr, "  ok before msrc check = %d (K=%ld N=%ld) res=%d gate=%d autopad=%s\n", (int)ok, (long)od[1], wi != E.inits_.end() ? (long)wi->second.dims[0] : -1L, (int)!cn.residual.empty(), (int)(cn.in.size() > 3 && !cn.in[3].empty()), cn.as("auto_pad", "NOTSET").c_str());
+                    for (auto& t : xs) fprintf(stderr, "    src layout=%d C=%ld host=%d\n", (int)(t.layout == Layout::CLAST), (long)t.dims[1], (int)t.host_int);
+                }
+                ok = ok && k::conv_msrc_ok((long)(od[0] * od[2] * od[3]), (int)od[1], (int)wi->second.dims[0]) && (wi->second.dims[0] & 3) == 0;
+                if (ok) {
+                    PendingConcat pc;
+                    for (size_t i = 0; i < xs.size(); ++i) { pc.src.push_back(ins[i]); pc.c.push_back((int)xs[i].dims[1]); }
+                    pc.dims = od;
+                    TInfo t;
+                    t.dims = od; t.layout = Layout::CLAST;
+                    vals[n.out[0]] = t;          // shape only: no storage unless somebody materialises it
+                    pending_concat[n.out[0]] = std::move(pc);
+                    return;
+                }
+            }
+            TInfo& y = new_out(n.out[0], od, Layout::CLAST);   // (below the deferral: a deferred concat owns no storage)
+            Loc yl = y.loc;
             if ((absorb || plain) && r == 4 && inner == 1 && xs.size() <= 8) {
                 static const bool gather_on = [] { const char* e = getenv("OAR_CONCAT_GATHER"); return !(e && e[0] == '0'); }();
                 bool ok = gather_on;
@@ -3074,6 +3150,26 @@ struct Planner {
                 l = std::max(l, u->second.second);
             }
         }
+        concat_consumer.clear();
+        {
+            std::map<std::string, std::pair<int, int>> uses;
+            for (int i = 0; i < (int)E.nodes_.size(); ++i) {
+                const GNode& n = E.nodes_[i];
+                for (auto& s : n.in) if (!s.empty()) { auto& u = uses[s]; ++u.first; u.second = i; }
+                if (!n.residual.empty()) { auto& u = uses[n.residual]; ++u.first; u.second = i; }
+            }
+            for (int i = 0; i < (int)E.nodes_.size(); ++i) {
+                const GNode& n = E.nodes_[i];
+                if (n.op != "Concat" || n.out.empty() || n.in.size() < 3) continue;
+                auto u = uses.find(n.out[0]);
+                if (u == uses.end() || u->second.first != 1) continue;
+                if (std::find(E.output_names_.begin(), E.output_names_.end(), n.out[0]) != E.output_names_.end()) continue;
+                const GNode& cn = E.nodes_[u->second.second];
+                if (cn.op != "Conv" || cn.in.empty() || cn.in[0] != n.out[0]) continue;
+                concat_consumer[n.out[0]] = u->second.second;
+                for (auto& sname : n.in) { int& l = lu[sname]; l = std::max(l, u->second.second); }   // the sources live until the convolution that reads them
+            }
+        }
         for (int i = (int)E.nodes_.size() - 1; i >= 0; --i) {
             const GNode& n = E.nodes_[i];
             if (!alias_ops.count(n.op) || n.in.empty()) continue;
@@ -3171,7 +3267,7 @@ struct Planner {
     void dispatch(const GNode& n) {
         const std::string& op = n.op;
         // shape / kind of an input without forcing a deferred Resize to run (its consumer decides that)
-        auto info = [&](const std::string& s) -> const TInfo& { return (peek_pending(s) || pending_convt.count(s)) ? vals.find(s)->second : get(s); };
+        auto info = [&](const std::string& s) -> const TInfo& { return (peek_pending(s) || pending_convt.count(s) || pending_concat.count(s)) ? vals.find(s)->second : get(s); };
         bool host_inputs = !n.in.empty();
         for (auto& s : n.in) if (!s.empty()) host_inputs = host_inputs && info(s).host_int;
         if (op == "Shape") {

@@ -241,6 +241,7 @@ static bool os_x6_eligible(long M, int K, int N, int Cin, bool grouped = false) 
 }
 
 std::vector<int> conv3x3_n16_slices(long M, int Cin, int Cout, long img_px, int y_ld) { return conv3x3_n16_x6_slices(M, Cin, Cout, img_px, y_ld); }
+bool conv_msrc_ok(long M, int K, int N) { return os_mode() != 0 && (K & 7) == 0 && os_x6_eligible(M, K, N, K); }
 bool conv_grouped_x6_ok(long M, int K, int N, int Cin) { return os_mode() != 0 && os_x6_eligible(M, K, N, Cin, true); }
 
 int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin, long same3x3_px, bool lk_ok) {
@@ -304,6 +305,8 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     p.ctc_part = c.ctc_part; p.ctc_valid = c.ctc_valid;
     p.se = c.se; p.se_hw = c.Ho * c.Wo;
     p.x_ld = c.x_ld > 0 ? c.x_ld : c.Cin; p.accum = c.accum;
+    p.n_msrc = c.n_msrc;
+    for (int i = 0; i < 8; ++i) { p.msrc[i] = i < c.n_msrc ? c.msrc[i] : nullptr; p.msrc_c[i] = i < c.n_msrc ? c.msrc_c[i] : 0; }
     p.res_up = c.residual ? c.res_up : 0;
     if (c.convt2x2) {
         p.Ho = c.H; p.Wo = c.W;  // GEMM columns are INPUT pixels
@@ -382,7 +385,7 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     const bool cheap_act = c.act.kind == ACT_NONE || c.act.kind == ACT_RELU;
     const bool prefer_os = os_wide && os_mode() != 0 && x6 && is1x1 && !c.convt2x2 && !c.se && !c.ctc_part && cheap_act && p.K >= 320 && p.gemm_cout >= 512 && ws_x6_tile(p.K, nfrag) > 0 && ws_x6_tile(p.K, nfrag) <= 4 &&
                            os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin);
-    const bool x6_os = x6 && !c.ctc_part && (!is1x1 || ws_x6_tile(p.K, nfrag) == 0 || prefer_os || (os_mode() == 2 && os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin)));
+    const bool x6_os = x6 && !c.ctc_part && (!is1x1 || ws_x6_tile(p.K, nfrag) == 0 || prefer_os || c.n_msrc > 0 || (os_mode() == 2 && os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin)));
     const bool rs3_cls = x6 && !c.convt2x2 && c.kh == 3 && c.kw == 3 && c.sh == 1 && c.sw == 1 && c.pt == 1 && c.pl == 1 && c.dh == 1 && c.dw == 1 && c.Ho == c.H && c.Wo == c.W && !c.residual && !c.se &&
                          !c.ctc_part && conv3x3_n16_x6_eligible(p.M, c.Cin, c.Cout, (long)c.H * c.W, c.y_ld);
     const bool lk = x6 && !c.ctc_part && !c.se && !c.convt2x2 && !is1x1 &&
@@ -410,6 +413,7 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     // a layer whose weights were laid out for the row-streaming 3x3 kernel (Cout <= 16: no other bf16x6 kernel takes it) must reach that kernel
     OAR_CHECK(!(x6 && same3x3 && c.Cout <= 16) || rs3, OAR_INTERNAL, "conv_igemm: 3x3 / Cout <= 16 bf16x6 weights but the row-streaming kernel's launch-time conditions do not hold (y_ld / output size / residual / gate changed after planning)");
     OAR_CHECK(!grouped || (x6 && !is1x1 && !c.ctc_part && !c.se && !c.convt2x2 && (rs3 || !(same3x3 && c.Cout <= 16))), OAR_INTERNAL, "conv_igemm: x_ld on a layer that runs on neither kernel that reads x with a stride of its own");
+    OAR_CHECK(c.n_msrc == 0 || (x6 && is1x1 && !c.convt2x2 && !c.ctc_part && !c.se && !lk), OAR_INTERNAL, "conv_igemm: multi-source input on a layer that does not run on the output-stationary bf16x6 kernel");
     OAR_CHECK(!c.accum || rs3, OAR_INTERNAL, "conv_igemm: accumulate flag on a layer that does not run on the row-streaming 3x3 kernel");
     if (lk) {
         conv_lk_x6(s, p, c.N);
@@ -420,7 +424,7 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     } else if (x6) {
         const int nt = c.ctc_part ? 8 : is1x1 ? ws_x6_tile(p.K, nfrag) : 0;
         OAR_CHECK(((p.Cout & 3) == 0) && ((p.y_ld & 3) == 0) && !c.convt2x2, OAR_INTERNAL, "conv_igemm: bf16x6 weights on an ineligible layer");
-        const bool os = !c.ctc_part && (nt == 0 || prefer_os || (os_mode() == 2 && os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin)));
+        const bool os = !c.ctc_part && (nt == 0 || prefer_os || c.n_msrc > 0 || (os_mode() == 2 && os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin)));
         OAR_CHECK(!c.se || (!os && !c.ctc_part && is1x1), OAR_INTERNAL, "conv_igemm: gate on a layer the weight-stationary x6 kernel does not take");
         if (os) {
             OAR_CHECK(os_x6_eligible(p.M, p.K, p.gemm_cout, c.Cin, grouped), OAR_INTERNAL, "conv_igemm: bf16x6 weights on a layer neither x6 kernel takes");

@@ -50,6 +50,9 @@ struct IgemmP {
     int res_up;          // > 1 (per-tile f32 kernels only): res is the low-resolution operand of an FPN sum, read at (h / res_up, w / res_up)
     const float* se;     // != null (bf16x6 weight-stationary kernel only): gate [image][K] multiplied into x on load
     int se_hw;           // pixels per image (se row of pixel m = m / se_hw)
+    int n_msrc;          // output-stationary bf16x6 kernel, 1x1 only: > 0 => x is the never-materialised channel concat of these maps (kernels.h ConvP::msrc)
+    const float* msrc[8];
+    int msrc_c[8];
     int accum;           // row-streaming 3x3 kernel only (igemm_rs3_x6.hip): add to what y holds (a later pass over a channel slice of the input)
     int x_ld;            // output-stationary bf16x6 kernel and igemm_rs3_x6.hip: floats between two pixels of x (>= Cin; > Cin for one group of a grouped convolution,
                          // whose x points at the group's first channel).  Every other kernel reads x with stride Cin

@@ -75,11 +75,12 @@ __global__ __launch_bounds__(kOsThreads, 2) void conv_igemm_os_x6_kernel(IgemmOs
     const long m0 = m_tile * (NTHR / 2) + wave * 32;
 
     // ---- this lane's two pixels
-    long pix_base[PF];
+    long pix_base[PF], mrow[PF];
     int ih0[PF], iw0[PF];
 #pragma clang loop unroll(full)
     for (int pf = 0; pf < PF; ++pf) {
         const long m = min(m0 + pf * 16 + pl_, p.M - 1);   // clamped rows compute garbage that is never stored
+        mrow[pf] = m;
         if (IS1X1) { pix_base[pf] = m * (long)p.x_ld; ih0[pf] = 0; iw0[pf] = 0; }
         else {
             const long hw = (long)p.Ho * p.Wo;
@@ -98,7 +99,22 @@ __global__ __launch_bounds__(kOsThreads, 2) void conv_igemm_os_x6_kernel(IgemmOs
 #pragma clang loop unroll(full)
         for (int pf = 0; pf < PF; ++pf) {
             const float* src;
-            if (IS1X1) { src = p.x + pix_base[pf] + k; st.okmask |= 1u << pf; }
+            if (IS1X1) {
+                if (p.n_msrc > 0) {   // the input is a channel concat that was never materialised: this lane's 8-channel group lies in ONE source (8 | every width)
+                    const float* sp = p.msrc[0];
+                    int sc = p.msrc_c[0], k0s = 0, acc_c = p.msrc_c[0];
+#pragma clang loop unroll(full)
+                    for (int qi = 1; qi < 8; ++qi) {   // (static indices into the kernel arguments: a chain of selects, no register-indexed access)
+                        const bool hit = qi < p.n_msrc && k >= acc_c;
+                        sp = hit ? p.msrc[qi] : sp; sc = hit ? p.msrc_c[qi] : sc; k0s = hit ? acc_c : k0s;
+                        acc_c += p.msrc_c[qi];
+                    }
+                    src = sp + mrow[pf] * (long)sc + (k - k0s);
+                } else {
+                    src = p.x + pix_base[pf] + k;
+                }
+                st.okmask |= 1u << pf;
+            }
             else {
                 const int tap = (int)__umulhi((unsigned)k, p.cin_magic), ci = k - tap * p.Cin;
                 const int tap_h = (int)__umulhi((unsigned)tap, p.kw_magic), tap_w = tap - tap_h * p.kw;

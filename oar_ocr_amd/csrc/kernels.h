@@ -34,6 +34,9 @@ struct ConvP {
     const float* se;        // igemm only (bf16x6 weight-stationary 1x1): squeeze-excite gate [N][Cin] multiplied into the input on load
     int res_up;             // igemm only (f32 per-tile kernels): f > 1 => `residual` is [N][Ho / f][Wo / f][Cout], added through the nearest index map (h / f, w / f)
                             // -- the top-down sum of an FPN without materialising the upsampled tensor
+    int n_msrc;             // igemm only, output-stationary bf16x6 kernel, 1x1 layers: > 0 => the input is the channel concat of n_msrc channels-last maps that was never
+    const float* msrc[8];   //   materialised (PP-HGNetV2's 7-way aggregation): source i has msrc_c[i] channels (8 | msrc_c[i]) at msrc[i], pixel stride msrc_c[i];
+    int msrc_c[8];          //   x is ignored, Cin = the sum
     int accum;              // igemm only, row-streaming 3x3 kernel: 1 = add to what y already holds (a later pass over a channel slice of the input, ConvP::x_ld)
     int x_ld;               // igemm only, output-stationary bf16x6 kernel / row-streaming 3x3 kernel: floats between two pixels of x when that is not Cin (0 = Cin): one group of a
                             // grouped convolution reads its Cin channels out of the full tensor
@@ -57,6 +60,8 @@ int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin = 0, long same
 bool conv_lk_x6_eligible(int kh, int kw, int sh, int sw, int pt, int pl, int dh, int dw, int H, int W, int Ho, int Wo, int Cin, int Cout, int y_ld, long M);
 // one group of a grouped k x k convolution (ConvP::x_ld) as its own implicit GEMM on the output-stationary bf16x6 kernel: M pixels, K = kh * kw * Cin_g, N = Cout_g >= 32
 bool conv_grouped_x6_ok(long M, int K, int N, int Cin);
+// may a 1x1 layer of this shape read a never-materialised channel concat (ConvP::msrc)?  It then runs on the output-stationary bf16x6 kernel whatever its K
+bool conv_msrc_ok(long M, int K, int N);
 // a 3x3 / stride 1 / pad 1 convolution with <= 16 output channels and 96 ... 256 input channels as passes of the row-streaming bf16x6 kernel over 64- / 32-channel
 // slices of the input (ConvP::x_ld, ConvP::accum): the slice widths, empty when the layer is not eligible.  img_px = pixels of one image
 std::vector<int> conv3x3_n16_slices(long M, int Cin, int Cout, long img_px, int y_ld);

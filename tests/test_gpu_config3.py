@@ -177,3 +177,37 @@ def test_large_kernel_conv_from_an_lds_staged_halo_tile(case):
     snap = {e["name"]: e["launches"] for e in api.prof_snapshot()}
     api.prof_enable(False)
     assert snap.get("conv_lk_x6", 0) == 1, snap
+
+
+def test_aggregation_conv_reads_a_concat_that_is_never_written():
+    """PP-HGNetV2's block: seven maps concatenated, then a 1x1 convolution.  The concat is deferred and the output-stationary bf16x6 kernel reads its K dimension
+    source by source (ConvP::msrc) -- no gather / copy launch; a second graph whose concat has TWO readers must still materialise it.  Both against torch-CPU."""
+    rng = np.random.default_rng(5)
+
+    def graph(two_readers):
+        g = GraphBuilder("agg")
+        g.add_input("x", ["N", 8, "H", "W"])
+        w0 = (rng.standard_normal((48, 8, 3, 3)) * np.sqrt(2.0 / 72)).astype(np.float32)
+        t = g.op("Relu", [g.op("Conv", ["x", g.init(w0)], kernel_shape=[3, 3], strides=[1, 1], pads=[1, 1, 1, 1], group=1, dilations=[1, 1])])   # (a channels-last producer, like the stage in front of a block)
+        outs = [t]
+        for i in range(6):
+            w = (rng.standard_normal((40, 48 if i == 0 else 40, 3, 3)) * np.sqrt(2.0 / (9 * 48))).astype(np.float32)
+            t = g.op("Relu", [g.op("Conv", [t, g.init(w)], kernel_shape=[3, 3], strides=[1, 1], pads=[1, 1, 1, 1], group=1, dilations=[1, 1])])
+            outs.append(t)
+        cat = g.op("Concat", outs, axis=1)                       # 48 + 6 * 40 = 288 channels
+        wa = (rng.standard_normal((64, 288, 1, 1)) * np.sqrt(2.0 / 288)).astype(np.float32)
+        y = g.op("Relu", [g.op("Conv", [cat, g.init(wa), g.init((0.1 * rng.standard_normal(64)).astype(np.float32))], kernel_shape=[1, 1], strides=[1, 1], pads=[0, 0, 0, 0], group=1, dilations=[1, 1])])
+        if two_readers:
+            z = g.op("GlobalAveragePool", [cat])
+            g.add_output(z, ["N", 288, 1, 1])
+        g.add_output(y, ["N", 64, "H", "W"])
+        return g.model()
+    x = rng.standard_normal((2, 8, 160, 240)).astype(np.float32)      # 76 800 pixels: the output-stationary kernel's launch is large enough
+    for two in (False, True):
+        m = graph(two)
+        api.prof_enable(True); api.prof_reset()
+        _check(m, x)
+        snap = {e["name"]: e["launches"] for e in api.prof_snapshot()}
+        api.prof_enable(False)
+        copies = snap.get("resize", 0) + snap.get("copy2d", 0)
+        assert (copies >= 1) if two else (copies == 0 and snap.get("conv_igemm_os_x6", 0) >= 1), snap
