@@ -237,7 +237,7 @@ static bool os_x6_eligible(long M, int K, int N, int Cin, bool grouped = false) 
     // (the 9x9 LK-PAN convolutions, K = 20736) pays for half-filled CUs as well: 72 -> ~110 TFLOP/s at 200 tiles)
     const long tiles = ((M + 255) / 256) * ((N + 127) / 128);
     const bool fills = M >= 65536 || (M >= 8192 && tiles >= 256) || (grouped && M >= 4096) || (K >= 2048 && M >= 8192 && tiles >= 128);
-    return Cin % 8 == 0 && K >= min_k && N >= (grouped ? 32 : 64) && (N & 3) == 0 && fills && K < 65536;
+    return Cin % 8 == 0 && K >= min_k && N >= (grouped ? 32 : 48) && (N & 3) == 0 && fills && K < 65536;   // (48: PP-HGNetV2's 48 -> 48 3x3 stage, three of a 4-fragment tile -- 98 TFLOP/s on the f32 kernel)
 }
 
 std::vector<int> conv3x3_n16_slices(long M, int Cin, int Cout, long img_px, int y_ld) { return conv3x3_n16_x6_slices(M, Cin, Cout, img_px, y_ld); }
