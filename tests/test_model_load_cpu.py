@@ -51,6 +51,21 @@ def test_good_models_pass_and_report_their_ops(L):
         assert "Conv:" in summary and "!" not in summary and "input=x" in summary
 
 
+def test_round6_graph_families_load_and_have_the_files_sizes(L):
+    """The graphs BASELINE's configs are timed on since round 6: every operator supported (host-only check: oar_onnx_inspect validates as oar_engine_create does), and
+    parameter counts within 3 % of the files they stand for (reference registry.rs:83, :84, :77, :25 -- bytes / 4)."""
+    sizes = {"det tiny_full": (models.build_det("tiny_full"), 1780590), "rec tiny_full": (models.build_rec("tiny_full", vocab=6906), 4462639),
+             "det server_hgnet": (models.build_det("server_hgnet"), 88116836), "rec svtrv2": (models.build_rec("svtrv2", vocab=6625), 84196641)}
+    for name, ((blob, info), file_bytes) in sizes.items():
+        assert abs(info["params"] * 4 / file_bytes - 1) < 0.03, (name, info["params"], file_bytes)      # (svtrv2: -2.7 %: the real file also carries BatchNorm statistics of its stem)
+        st, summary, err = inspect(L, blob)
+        assert st == api.OAR_OK and "!" not in summary, (name, err, summary)
+    _, summary, _ = inspect(L, sizes["rec svtrv2"][0][0])
+    assert "Erf:" in summary and "LayerNormalization:" in summary and "Softmax:" in summary      # GELU arrives decomposed, attention op by op: the engine's rewrite passes fuse them
+    _, summary, _ = inspect(L, sizes["det server_hgnet"][0][0])
+    assert "MaxPool:" in summary and "Concat:" in summary and "GlobalAveragePool:" in summary
+
+
 def test_unsupported_operator_is_named(L):
     m = _model([], [ow.node("NonMaxSuppression", ["x"], ["y"])])
     st, summary, err = inspect(L, m)
