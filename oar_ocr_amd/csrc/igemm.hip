@@ -241,7 +241,8 @@ static bool os_x6_eligible(long M, int K, int N, int Cin, bool grouped = false) 
 }
 
 std::vector<int> conv3x3_n16_slices(long M, int Cin, int Cout, long img_px, int y_ld) { return conv3x3_n16_x6_slices(M, Cin, Cout, img_px, y_ld); }
-bool conv_msrc_ok(long M, int K, int N) { return os_mode() != 0 && (K & 7) == 0 && os_x6_eligible(M, K, N, K); }
+// (the layer must also come out of igemm_weight_format as a bf16x6 layer -- OAR_IGEMM_X6=0 turns every layer into an f32 one --: the planner lays the weights out by that answer)
+bool conv_msrc_ok(long M, int K, int N) { return os_mode() != 0 && (K & 7) == 0 && os_x6_eligible(M, K, N, K) && igemm_weight_format(M, K, N, true, K) == IGEMM_W_X6; }
 bool conv_grouped_x6_ok(long M, int K, int N, int Cin) { return os_mode() != 0 && os_x6_eligible(M, K, N, Cin, true); }
 
 int igemm_weight_format(long M, int K, int N, bool is1x1, int Cin, long same3x3_px, bool lk_ok) {
