@@ -53,6 +53,9 @@ def test_weight_stationary_kernels_fit_their_budget():
         ks = {k: v for k, v in _resources(src).items() if needle in k}
         assert ks
         for name, r in ks.items():
+            if name.endswith("ELi2EEEvNS0_10IgemmWsX6PE"):   # round 6: the two-fragment instantiations run 512-thread workgroups (two waves per SIMD: 256 registers), no cold-path spill to speak of
+                assert r["vgprs"] <= 256 and r["scratch"] <= 16 and r["occupancy"] >= 2, (name, r)
+                continue
             assert r["vgprs"] <= 128, (name, r)     # 1024-thread workgroups: 4 waves per SIMD only inside 128 registers
             ctc_variant = "ILi8ELb1E" in name      # the CTC-head instantiation of the x6 kernel (softmax-partial epilogue): 164 B today
             se_variant = "ELb0ELb1E" in name       # round 3: the squeeze-excite-gate instantiations (8 more live registers per chunk): 208 B at 8 fragments
