@@ -127,3 +127,28 @@ def test_streaming_attention_kernel_fits_two_waves_per_simd():
     assert len(ks) == 1
     for name, r in ks.items():
         assert r["spill"] == 0 and r["scratch"] == 0 and r["vgprs"] <= 256 and r["occupancy"] >= 2, (name, r)
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
+def test_per_tile_igemm_kernels_do_not_spill():
+    """VERDICT r5 next #9 (the part that can be pinned without a GPU): conv_igemm_kernel / conv_igemm_small_kernel -- 36 instantiations of 30-60 k instructions, the
+    detector's small layers and every layer with an upsampled residual -- hold their accumulators and three load stages in registers: no spill, no scratch, and the
+    two-fragment tiles the launcher prefers (PF = 2) keep at least five waves per SIMD."""
+    ks = {k: v for k, v in _resources("igemm.hip").items() if "conv_igemm_kernel" in k or "conv_igemm_small_kernel" in k}
+    assert len(ks) == 36
+    for name, r in ks.items():
+        assert r["spill"] == 0 and r["scratch"] == 0, (name, r)
+        if "conv_igemm_kernelILi" in name and "ELi2ELb" in name:
+            assert r["occupancy"] >= 5, (name, r)
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
+def test_lds_tiled_large_kernel_conv_fits_one_wave_per_simd():
+    """igemm_lk_x6.hip (round 6): 16 accumulators + two weight register sets of 48 + two pixel-fragment sets: <= 256 registers, no scratch (one workgroup of four
+    waves per CU at k = 9; the 5 x 5 / 6-row instantiation must stay under 128 so that two workgroups fit)."""
+    ks = {k: v for k, v in _resources("igemm_lk_x6.hip").items() if "conv_lk_x6_kernel" in k}
+    assert len(ks) == 4
+    for name, r in ks.items():
+        assert r["spill"] == 0 and r["scratch"] == 0 and r["vgprs"] <= 256, (name, r)
+    small = next(v for k, v in ks.items() if "ILi5ELi6ELi2E" in k)
+    assert small["vgprs"] <= 128, small
