@@ -192,6 +192,7 @@ def main():
         torch.cuda.set_device(dev)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     cores = pin_rank_to_its_cores(local, local_world)
+    pool_threads = None   # N > 1: the geometry pool size this rank asks for (below); None = the library's default rule
 
     # ---- workload
     size_name, vocab = ("server", 18710) if args.config == 2 else ("tiny", 6906)
@@ -236,6 +237,7 @@ def main():
             if aff >= 6 and ht > aff - 2:
                 ht = aff - 2
             builder = builder.host_threads(ht)
+            pool_threads = ht
             # (round 2 switched to the GPU border follower below 6 cores per rank; measured in round 3, profiles/r3/gpu_contours_breakeven.txt:
             # the host tracer wins at EVERY pool size -- 1 thread 1002 vs 903 images/s, 2 threads 1301 vs 958, 4 threads 1635 vs 967 -- so
             # the switch is gone; oar_det_cfg.gpu_contours / OAR_GPU_CONTOURS remain as a knob)
@@ -268,6 +270,7 @@ def main():
         """host pages -> boxes + texts + scores on the host of rank 0"""
         passes["n"] += 1
         packed = eng.predict_packed(host_pages)
+        passes["regions"] = len(packed.scores)   # this rank's own regions of the step
         if world == 1:
             gathered.update(pages=len(packed.region_offsets) - 1, regions=len(packed.scores), bytes=len(packed.utf8))
             return packed
@@ -402,10 +405,19 @@ def main():
                 pass
 
     tmax = dt
+    per_rank = None
     if world > 1:
         t = torch.tensor([dt], device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         tmax = float(t.item())
+        # what each rank saw (outside the timed region): its own wall time and host CPU per step, the cores it was pinned to, the geometry pool it
+        # chose, its device and the world size the process group reports -- so that a SCALE record can be read rank by rank
+        mine = {"rank": rank, "local_rank": local, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3), "host_cpu_ms_per_step": round(host_cpu_ms, 2),
+                "host_cores": cores, "cpu_affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+                "geometry_pool_threads": pool_threads, "world_size_seen": dist.get_world_size(), "backend": dist.get_backend(),
+                "device": None if stub else torch.cuda.get_device_name(dev), "regions": int(passes.get("regions", 0))}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     # -- second figure: pages already resident in HBM, no decode (round 1's headline), same step count
     dev_res = None
@@ -587,6 +599,7 @@ def main():
                        "pages_per_gpu_per_step": n_pages, "image_batch_size": image_batch, "region_batch_size": args.region_batch,
                        "regions_per_step": gathered["regions"], "text_bytes_per_step": gathered["bytes"], "pages_gathered_per_step": gathered["pages"],
                        "parallelism": f"image-parallel x{world}", "host_cores_per_rank": cores, "host_cpu_ms_per_step": round(host_cpu_ms, 2)},
+            "per_rank": per_rank,
             "real_weights": real_weights, "roofline": roof, "cpu_baseline": cpu, "device_resident": dev_res, "pipelined": pipelined, "lighter_graphs_r1_r5": real_size, "rec_two_streams": rec_two, "conv_mfma_util": mfma_util, "kernel_ms_per_step_untimed_pass": breakdown, "predict_passes_total": passes["n"], "csrc_fingerprint": csrc_now,
         }
         print(json.dumps(line), flush=True)

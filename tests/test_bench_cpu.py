@@ -32,6 +32,11 @@ def test_bench_launches_its_own_ranks_weak_scaling():
     c = out["config"]
     assert c["pages_per_gpu_per_step"] == 5 and c["pages_gathered_per_step"] == 10 and c["regions_per_step"] == 30   # both ranks' results reached rank 0
     assert abs(out["value"] - 10 * 3 / (out["ms_per_step"] * 3 / 1e3)) / out["value"] < 1e-2               # whole-job pages / max-over-ranks time
+    # per-rank record: every rank reports what it saw, in rank order; the line's time is the slowest rank's
+    pr = out["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and all(r["world_size_seen"] == 2 and r["backend"] == "gloo" for r in pr)
+    assert all(r["regions"] == 15 and r["host_cores"] >= 1 and r["host_cpu_ms_per_step"] >= 0 for r in pr)
+    assert abs(max(r["ms_per_step"] for r in pr) - out["ms_per_step"]) < 1e-2
 
 
 def test_bench_config3_block_partitions_a_fixed_page_count():
@@ -42,7 +47,7 @@ def test_bench_config3_block_partitions_a_fixed_page_count():
 
 def test_bench_single_rank_needs_no_launcher():
     out = _run("--pages", "4")
-    assert out["n_gpus"] == 1 and out["config"]["pages_gathered_per_step"] == 4
+    assert out["n_gpus"] == 1 and out["config"]["pages_gathered_per_step"] == 4 and out["per_rank"] is None
 
 
 def test_packed_pages_roundtrip():
