@@ -82,6 +82,19 @@ def test_rec_preprocess_batch():
         assert np.all(got[i, :, :, rw:] == 0.0)
 
 
+@pytest.mark.parametrize("flip", [False, True])
+def test_rec_preprocess_over_the_scale_range(flip):
+    """The recognizer resize against the oracle, bit for bit, over the scale range a page can produce: 4x enlargement to 6x reduction, the identity copy, crops of a
+    few pixels, widths capped at the tensor width (horizontal ratio != vertical ratio), and the rotate180 read."""
+    rng = np.random.default_rng(31)
+    sizes = [(96, 48), (97, 48), (31, 48), (3, 9), (200, 12), (333, 24), (500, 61), (260, 70), (410, 100), (300, 139), (640, 150), (700, 300), (5000, 40), (3300, 96), (64, 7)]
+    crops = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for (w, h) in sizes]
+    flips = [flip] * len(crops)
+    want = R.rec_preprocess([R.rotate_rgb(c, 2) if flip else c for c in crops])
+    got = api.k_rec_preprocess(crops, flips=flips)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
 def test_box_scores():
     rng = np.random.default_rng(4)
     pred = rng.random((240, 320)).astype(np.float32)
