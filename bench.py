@@ -42,7 +42,7 @@ def mfma_peak_for(kernel):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 100 for config 1 -- ~1.4 s of GPU time, long enough for an external sampler to see; 10 for the others)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pages", type=int, default=0, help="pages per GPU per step (0 = the config's: 32 / 64 / 1024 total / 16)")
     ap.add_argument("--size", type=int, default=0)
@@ -74,7 +74,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-real-size", action="store_true", help="skip the extra timing of the real-size detector (config 1, one GPU)")
     ap.add_argument("--stub-engine", action="store_true", help=argparse.SUPPRESS)   # tests/test_bench_cpu.py: control flow without a GPU
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py starts its own ranks (0 = pick a free one)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.steps <= 0:
+        args.steps = 100 if args.config == 1 and not args.stub_engine else 10
+    return args
 
 
 def self_launch(args) -> int:
