@@ -3063,7 +3063,7 @@ struct Planner {
         const int64_t h = n.ai("heads", 1), d = n.ai("head_dim", 1);
         OAR_CHECK(x.dims.size() == 3 && x.dims[2] == 3 * h * d, OAR_SHAPE_MISMATCH, "Attention: input must be [n, T, 3*heads*head_dim]");
         const int64_t N = x.dims[0], T = x.dims[1];
-        OAR_CHECK(k::attention_fits((int)T, (int)h, (int)d), OAR_UNSUPPORTED_OP, "Attention: K and V of one head must fit LDS (or head_dim == 32 for the streaming kernel)");
+        OAR_CHECK(k::attention_fits((int)T, (int)h, (int)d), OAR_UNSUPPORTED_OP, "Attention: head_dim must be in 1..=64");
         Loc xin = to_native_loc(x);
         TInfo& y = new_out(n.out[0], {N, T, h * d}, Layout::NATIVE);
         Loc yl = y.loc;

@@ -1603,10 +1603,87 @@ static void launch_attention(hipStream_t s, const float* qkv, float* out, int n,
     hipLaunchKernelGGL((attention_kernel<HD>), dim3((unsigned)(n * heads)), dim3(threads), lds, s, qkv, out, T, heads, hd, scale);
 }
 
+// K and V of a head do not fit LDS and the head dim is not the streaming bf16x6 kernel's (32): the same one-thread-per-query arithmetic over key blocks of
+// kAttnBlock rows staged in LDS, with the running maximum / sum / output rescaled once per block (online soft-max: exp(m_old - m_new) is exact 1 when the
+// maximum did not move).  A fallback for shapes no PP-OCR graph has -- any head dim <= 64 at any T runs instead of being refused (tools/op_fuzz.py found the gap).
+constexpr int kAttnBlock = 128;
+template <int HD>
+__global__ __launch_bounds__(256) void attention_stream_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T, int heads, int hd, float scale) {
+    extern __shared__ float4 att_lds[];   // K [kAttnBlock][HD] | V [kAttnBlock][HD]
+    constexpr int H4 = HD / 4;
+    float4* Ks = att_lds;
+    float4* Vs = att_lds + kAttnBlock * H4;
+    float* Kf = reinterpret_cast<float*>(Ks);
+    float* Vf = reinterpret_cast<float*>(Vs);
+    const int n = blockIdx.x / heads, h = blockIdx.x - n * heads, dim = heads * hd;
+    const float* base = qkv + (long)n * T * 3 * dim + h * hd;
+    const int t = (int)blockIdx.y * 256 + (int)threadIdx.x;
+    const bool valid = t < T;
+    float q[HD], o[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { q[d] = (valid && d < hd) ? base[(long)t * 3 * dim + d] * scale : 0.f; o[d] = 0.f; }
+    float m = -3.402823466e38f, l = 0.f;
+    for (int j0 = 0; j0 < T; j0 += kAttnBlock) {
+        const int nj = min(kAttnBlock, T - j0);
+        __syncthreads();   // (the previous block's reads are over)
+        for (int i = threadIdx.x; i < nj * HD; i += blockDim.x) {
+            const int r = i / HD, d = i - r * HD;
+            float kv = 0.f, vv = 0.f;
+            if (d < hd) { kv = base[(long)(j0 + r) * 3 * dim + dim + d]; vv = base[(long)(j0 + r) * 3 * dim + 2 * dim + d]; }
+            Kf[i] = kv; Vf[i] = vv;
+        }
+        __syncthreads();
+        auto score = [&](int j) {
+            float a = 0.f;
+#pragma unroll
+            for (int d4 = 0; d4 < H4; ++d4) {
+                const float4 kk = Ks[j * H4 + d4];
+                a = fmaf(q[4 * d4], kk.x, a); a = fmaf(q[4 * d4 + 1], kk.y, a); a = fmaf(q[4 * d4 + 2], kk.z, a); a = fmaf(q[4 * d4 + 3], kk.w, a);
+            }
+            return a;
+        };
+        float mb = m;
+#pragma unroll 4
+        for (int j = 0; j < nj; ++j) mb = fmaxf(mb, score(j));
+        const float corr = expf(m - mb);   // first block: exp(-huge) = 0 on l = 0, o = 0
+        m = mb;
+        l *= corr;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) o[d] *= corr;
+#pragma unroll 4
+        for (int j = 0; j < nj; ++j) {
+            const float p = expf(score(j) - m);
+            l += p;
+#pragma unroll
+            for (int d4 = 0; d4 < H4; ++d4) {
+                const float4 vv = Vs[j * H4 + d4];
+                o[4 * d4] = fmaf(p, vv.x, o[4 * d4]); o[4 * d4 + 1] = fmaf(p, vv.y, o[4 * d4 + 1]);
+                o[4 * d4 + 2] = fmaf(p, vv.z, o[4 * d4 + 2]); o[4 * d4 + 3] = fmaf(p, vv.w, o[4 * d4 + 3]);
+            }
+        }
+    }
+    if (valid) {
+        float* y = out + ((long)n * T + t) * dim + h * hd;
+#pragma unroll
+        for (int d = 0; d < HD; ++d)
+            if (d < hd) y[d] = o[d] / l;
+    }
+}
+template <int HD>
+static void launch_attention_stream(hipStream_t s, const float* qkv, float* out, int n, int T, int heads, int hd, float scale) {
+    OAR_MAX_LDS_ONCE(attention_stream_kernel<HD>, 160 * 1024);
+    const size_t lds = (size_t)2 * kAttnBlock * HD * sizeof(float);
+    hipLaunchKernelGGL((attention_stream_kernel<HD>), dim3((unsigned)(n * heads), (unsigned)((T + 255) / 256)), dim3(256), lds, s, qkv, out, T, heads, hd, scale);
+}
+
 static bool attention_x6_on() { static const bool on = [] { const char* e = getenv("OAR_ATTN_X6"); return !e || atoi(e) != 0; }(); return on; }
 bool attention_fits(int T, int heads, int hd) {
     if (hd < 1 || hd > 64) return false;
     if (attention_x6_on() && attention_x6_supported(T, heads, hd)) return true;
+    (void)T; (void)heads;
+    return true;   // K and V in LDS when they fit, key blocks streamed through it when they do not (attention_stream_kernel)
+}
+static bool attention_whole_head_fits(int T, int hd) {
     const int HD = hd <= 16 ? 16 : hd <= 32 ? 32 : 64;
     return (size_t)2 * T * HD * sizeof(float) <= 150 * 1024;
 }
@@ -1616,6 +1693,12 @@ void attention(hipStream_t s, const float* qkv, float* out, int n, int T, int he
     if (attention_x6_on() && attention_x6_supported(T, heads, hd) && T > 32) return attention_x6(s, qkv, out, n, T, heads, hd, scale);
     const double nh = (double)n * heads;
     ProfScope ps(s, "attention", 4.0 * nh * T * 4.0 * hd, 4.0 * nh * T * T * hd);
+    if (!attention_whole_head_fits(T, hd)) {
+        if (hd <= 16) launch_attention_stream<16>(s, qkv, out, n, T, heads, hd, scale);
+        else if (hd <= 32) launch_attention_stream<32>(s, qkv, out, n, T, heads, hd, scale);
+        else launch_attention_stream<64>(s, qkv, out, n, T, heads, hd, scale);
+        return;
+    }
     if (hd <= 16) launch_attention<16>(s, qkv, out, n, T, heads, hd, scale);
     else if (hd <= 32) launch_attention<32>(s, qkv, out, n, T, heads, hd, scale);
     else launch_attention<64>(s, qkv, out, n, T, heads, hd, scale);

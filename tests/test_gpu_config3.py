@@ -133,6 +133,21 @@ def test_server_graphs_full_width_on_a_small_page():
     ocr.close()
 
 
+@pytest.mark.parametrize("case", [("head dim 64, K and V past LDS", 192, 3, 2, 650, 1.0), ("head dim 16, 1892 tokens", 176, 11, 1, 1892, 3.0), ("head dim 40 (padded to 64)", 80, 2, 1, 700, 1.0),
+                                  ("head dim 64, fits LDS (whole-head kernel)", 128, 2, 2, 300, 1.0)])
+def test_attention_of_any_head_dim_runs_at_any_length(case):
+    """Round 6 (found by tools/op_fuzz.py): a fused Attention whose head dim is not the streaming bf16x6 kernel's 32 and whose K / V do not fit LDS used to be REFUSED
+    at plan time; it now runs on attention_stream_kernel (key blocks of 128 rows through LDS, online soft-max).  Against torch-CPU, 2e-4."""
+    name, dim, heads, n, T, gain = case
+    model = _attention_graph(dim, heads, seed=len(name), gain=gain)
+    x = np.random.default_rng(n + T).standard_normal((n, T, dim)).astype(np.float32)
+    api.prof_enable(True); api.prof_reset()
+    _check(model, x)
+    snap = {e["name"]: e["launches"] for e in api.prof_snapshot()}
+    api.prof_enable(False)
+    assert snap.get("attention", 0) >= 1 and not snap.get("attention_x6", 0), snap
+
+
 @pytest.mark.parametrize("case", [("svtrv2 stage 1", 128, 4, 8, 12, 704, False), ("svtrv2 stage 2 + residual", 256, 8, 6, 6, 2000, True), ("few tiles: output-stationary", 128, 4, 2, 12, 1400, False), ("10 rows: 12-row tiles hang over", 64, 2, 9, 10, 530, True)])
 def test_grouped_mixing_conv_runs_per_group_on_the_matrix_pipe(case):
     """SVTRv2's local mixing: 5 x 5 convolution, 32 channels per group.  Each group is one implicit GEMM (K = 800, N = 32) on the
