@@ -61,7 +61,7 @@ def test_ctc_argmax_last_index_wins():
     assert (gi[0], gp[0]) == (0, 42.0)
 
 
-@pytest.mark.parametrize("size", [(100, 37, 64, 48), (320, 48, 320, 48), (91, 33, 200, 48), (640, 120, 213, 48), (33, 17, 33, 17)])
+@pytest.mark.parametrize("size", [(100, 37, 64, 48), (320, 48, 320, 48), (91, 33, 200, 48), (640, 120, 213, 48), (33, 17, 33, 17), (1000, 410, 200, 80), (50, 20, 333, 97), (1300, 9, 100, 3)])
 def test_resize_triangle(size):
     w, h, nw, nh = size
     rng = np.random.default_rng(w * 7 + h)

@@ -2,7 +2,7 @@
 eligibility boundary of the bf16x6 kernels (weight-stationary one- and two-fragment tiles, output-stationary, row-streaming 3x3, LDS-tiled large kernel,
 grouped, multi-source concat reads, streaming attention), random epilogues (bias, ReLU / hard-swish / GELU / none, residual).  Reports, per case, the kernel
 classes that ran and the largest |difference| relative to the output scale; the tolerance is the engine tests' 2e-4.
-usage: python tools/op_fuzz.py [n_cases] [seed] [kind]      kind: dsblock | dschain | conv1x1 | conv3x3 | convk | grouped | concat | attention | all"""
+usage: python tools/op_fuzz.py [n_cases] [seed] [kind]      kind: svtr_block | dbhead | fpn | pool | dsblock | dschain | conv1x1 | conv3x3 | convk | grouped | concat | attention | all"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -191,7 +191,121 @@ def case_dschain():
     return f"dschain {'-'.join(desc)} {n}x{h}x{w}", g.model(), (n, 8, h, w)
 
 
-KINDS = {"dsblock": case_dsblock, "dschain": case_dschain, "conv1x1": case_conv1x1, "conv3x3": case_conv3x3, "convk": case_convk, "grouped": case_grouped, "concat": case_concat, "attention": case_attention}
+def _linear(g, x, cin, cout, bias=True):
+    w = (rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    y = g.op("MatMul", [x, g.init(w)])
+    return g.op("Add", [y, g.init((0.1 * rng.standard_normal(cout)).astype(np.float32))]) if bias else y
+
+
+def _ln(g, x, dim):
+    return g.op("LayerNormalization", [x, g.init((1.0 + 0.1 * rng.standard_normal(dim)).astype(np.float32)), g.init((0.1 * rng.standard_normal(dim)).astype(np.float32))], axis=-1, epsilon=1e-5)
+
+
+def _mha(g, x, dim, heads):
+    hd = dim // heads
+    qkv = g.op("Transpose", [g.op("Reshape", [_linear(g, x, dim, 3 * dim), g.init(np.array([0, -1, 3, heads, hd], np.int64), "shape")])], perm=[2, 0, 3, 1, 4])
+    q, k, v = g.op("Split", [qkv], n_out=3, axis=0)
+    ax0 = g.init(np.array([0], np.int64), "axes")
+    q, k, v = g.op("Squeeze", [q, ax0]), g.op("Squeeze", [k, ax0]), g.op("Squeeze", [v, ax0])
+    q = g.op("Mul", [q, g.init(np.array(hd ** -0.5, np.float32), "scale")])
+    att = g.op("Softmax", [g.op("MatMul", [q, g.op("Transpose", [k], perm=[0, 1, 3, 2])])], axis=-1)
+    o = g.op("Reshape", [g.op("Transpose", [g.op("MatMul", [att, v])], perm=[0, 2, 1, 3]), g.init(np.array([0, -1, dim], np.int64), "shape")])
+    return _linear(g, o, dim, dim)
+
+
+def case_svtr_block():
+    """one or two transformer blocks on [N, T, dim] tokens: pre- or post-LayerNorm, MLP ratio 2 or 4, GELU / swish-free activations the exporters emit"""
+    heads = int(rng.integers(1, 13))
+    hd = int(rng.choice([32, 32, 16, 8, 64, 15]))
+    dim = heads * hd
+    n, T = int(rng.integers(1, 40)), int(rng.choice([int(rng.integers(1, 41)), int(rng.integers(41, 200)), int(rng.integers(200, 900))]))
+    if n * T > 12000:
+        n = max(1, 12000 // T)
+    pre, ratio, a = bool(rng.random() < 0.6), int(rng.choice([2, 4])), str(rng.choice(["gelu", "relu", "hswish"]))
+    g = GraphBuilder("f")
+    g.add_input("x", ["N", "T", dim])
+    t = "x"
+    for _ in range(int(rng.integers(1, 3))):
+        if pre:
+            t = g.op("Add", [t, _mha(g, _ln(g, t, dim), dim, heads)])
+            t = g.op("Add", [t, _linear(g, act(g, _linear(g, _ln(g, t, dim), dim, ratio * dim), a), ratio * dim, dim)])
+        else:
+            t = _ln(g, g.op("Add", [t, _mha(g, t, dim, heads)]), dim)
+            t = _ln(g, g.op("Add", [t, _linear(g, act(g, _linear(g, t, dim, ratio * dim), a), ratio * dim, dim)]), dim)
+    g.add_output(t, ["N", "T", dim])
+    return f"svtr {'pre' if pre else 'post'}-LN {heads}x{hd} mlp{ratio} {a} {n}x{T}", g.model(), (n, T, dim)
+
+
+def case_dbhead():
+    """DB head: 3x3 conv (cin -> cin / 4) + ReLU -> ConvTranspose 2x2 / 2 + ReLU -> ConvTranspose 2x2 / 2 -> Sigmoid"""
+    cin = int(rng.choice([16, 24, 64, 96, 256]))
+    mid = max(4, cin // 4)
+    n, h, w = int(rng.integers(1, 5)), int(rng.integers(4, 120)), int(rng.integers(4, 160))
+    g = GraphBuilder("f")
+    g.add_input("x", ["N", 8, "H", "W"])
+    t = g.op("Relu", [conv(g, stem(g, cin), cin, mid, 3)])
+    w1 = (rng.standard_normal((mid, mid, 2, 2)) * np.sqrt(1.0 / mid)).astype(np.float32)
+    t = g.op("Relu", [g.op("ConvTranspose", [t, g.init(w1), g.init((0.1 * rng.standard_normal(mid)).astype(np.float32))], kernel_shape=[2, 2], strides=[2, 2], pads=[0, 0, 0, 0], group=1, dilations=[1, 1])])
+    w2 = (rng.standard_normal((mid, 1, 2, 2)) * np.sqrt(1.0 / mid)).astype(np.float32)
+    t = g.op("Sigmoid", [g.op("ConvTranspose", [t, g.init(w2), g.init(np.array([0.05], np.float32))], kernel_shape=[2, 2], strides=[2, 2], pads=[0, 0, 0, 0], group=1, dilations=[1, 1])])
+    g.add_output(t, ["N", 1, "H4", "W4"])
+    return f"dbhead {cin}->{mid}->1 {n}x{h}x{w}", g.model(), (n, 8, h, w)
+
+
+def case_fpn():
+    """top-down FPN sums over three or four levels (lateral 1x1 + nearest x2 + Add), 3x3 smoothing per level, nearest x2 / x4 / x8 to the finest level, Concat"""
+    levels = int(rng.integers(3, 5))
+    chans = [int(rng.choice([16, 24, 48, 96])) * (1 << i) for i in range(levels)]
+    width = int(rng.choice([24, 48, 64, 96]))
+    outc = int(rng.choice([8, 16, 24]))
+    n = int(rng.integers(1, 4))
+    h, w = int(rng.integers(1, 12)) * (1 << (levels - 1)), int(rng.integers(1, 16)) * (1 << (levels - 1))
+    g = GraphBuilder("f")
+    g.add_input("x", ["N", 8, "H", "W"])
+    feats, t, c = [], "x", 8
+    for i in range(levels):
+        t = g.op("Relu", [conv(g, t, c, chans[i], 3, stride=1 if i == 0 else 2)])
+        c = chans[i]
+        feats.append(t)
+    scales = g.init(np.array([1, 1, 2, 2], np.float32), "scales")
+    top = conv(g, feats[-1], chans[-1], width, 1, bias=False)
+    ins = [top]
+    for i in range(levels - 2, -1, -1):
+        up = g.op("Resize", [top, "", scales], mode="nearest", nearest_mode="floor", coordinate_transformation_mode="asymmetric")
+        top = g.op("Add", [conv(g, feats[i], chans[i], width, 1, bias=False), up])
+        ins.append(top)
+    outs = []
+    for j, t in enumerate(ins):   # ins[0] is the coarsest level
+        p = conv(g, t, width, outc, 3, bias=False)
+        f = 1 << (levels - 1 - j)
+        if f > 1:
+            p = g.op("Resize", [p, "", g.init(np.array([1, 1, f, f], np.float32), "scales")], mode="nearest", nearest_mode="floor", coordinate_transformation_mode="asymmetric")
+        outs.append(p)
+    y = g.op("Concat", outs[::-1], axis=1)
+    g.add_output(y, ["N", outc * levels, "H", "W"])
+    return f"fpn {chans}->{width}->{outc} {n}x{h}x{w}", g.model(), (n, 8, h, w)
+
+
+def case_pool():
+    c = int(rng.choice([8, 16, 24, 64, 96, 192]))
+    kind = str(rng.choice(["AveragePool", "MaxPool"]))
+    kh, kw = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+    sh, sw = int(rng.integers(1, kh + 1)), int(rng.integers(1, kw + 1))
+    ph, pw = int(rng.integers(0, kh // 2 + 1)), int(rng.integers(0, kw // 2 + 1))
+    ceil_mode = int(rng.random() < 0.3)
+    n, h, w = int(rng.integers(1, 5)), int(rng.integers(kh + 1, 80)), int(rng.integers(kw + 1, 120))
+    g = GraphBuilder("f")
+    g.add_input("x", ["N", 8, "H", "W"])
+    attrs = dict(kernel_shape=[kh, kw], strides=[sh, sw], pads=[ph, pw, ph, pw], ceil_mode=ceil_mode)
+    if kind == "AveragePool":
+        attrs["count_include_pad"] = int(rng.random() < 0.5)
+    y = g.op(kind, [stem(g, c)], **attrs)
+    y = g.op("Relu", [conv(g, y, c, 16, 1)])
+    g.add_output(y, ["N", 16, "H2", "W2"])
+    return f"{kind} {kh}x{kw}/{sh}x{sw} pad {ph},{pw} ceil {ceil_mode} {attrs.get('count_include_pad', '-')} c{c} {n}x{h}x{w}", g.model(), (n, 8, h, w)
+
+
+KINDS = {"svtr_block": case_svtr_block, "dbhead": case_dbhead, "fpn": case_fpn, "pool": case_pool, "dsblock": case_dsblock, "dschain": case_dschain, "conv1x1": case_conv1x1, "conv3x3": case_conv3x3, "convk": case_convk, "grouped": case_grouped, "concat": case_concat, "attention": case_attention}
 names = list(KINDS) if only == "all" else [only]
 bad = 0
 worst = {}

@@ -21,7 +21,7 @@ tiny_name = "tiny_full" if os.environ.get("FUZZ_GRAPHS", "") == "full" else "tin
 det, _ = models.build_det("server" if server else tiny_name, seed=2 if server else 0)
 rec, _ = models.build_rec("server" if server else tiny_name, vocab=18710 if server else 6906, seed=3 if server else 1)
 chars = api.read_dict(models.synth_dict(18708 if server else 6904))
-max_side = 640 if server else 1100
+max_side = int(os.environ.get("FUZZ_MAX_SIDE", "0")) or (640 if server else 1100)   # FUZZ_MAX_SIDE=3000: pages far past limit_side_len (Triangle reduction by up to ~3x in front of the detector)
 only_case = int(sys.argv[4]) if len(sys.argv) > 4 else None
 bad = 0
 t0 = time.time()
