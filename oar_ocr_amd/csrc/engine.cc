@@ -2505,7 +2505,7 @@ struct Planner {
         TInfo& y = new_out(n.out[0], {x.dims[0], x.dims[1], Ho, Wo}, Layout::CLAST);
         k::PoolP p{};
         p.N = (int)x.dims[0]; p.H = (int)x.dims[2]; p.W = (int)x.dims[3]; p.C = (int)x.dims[1]; p.Ho = (int)Ho; p.Wo = (int)Wo;
-        p.kh = (int)kh; p.kw = (int)kw; p.sh = (int)sh; p.sw = (int)sw; p.pt = (int)pt; p.pl = (int)pl;
+        p.kh = (int)kh; p.kw = (int)kw; p.sh = (int)sh; p.sw = (int)sw; p.pt = (int)pt; p.pl = (int)pl; p.pb = (int)pb; p.pr = (int)pr;
         p.is_max = is_max; p.count_include_pad = (int)n.ai("count_include_pad", 0);
         Loc yl = y.loc;
         auto run = [=](const RunCtx& c) { k::PoolP q = p; q.x = c.at(xin); q.y = c.mut(yl); k::pool2d(c.s, q); };

@@ -102,6 +102,7 @@ void convt_direct(hipStream_t s, const ConvP& p);
 
 struct PoolP {
     int N, H, W, C, Ho, Wo, kh, kw, sh, sw, pt, pl;
+    int pb, pr;              // bottom / right padding: the divisor of count_include_pad counts padding, not the ceil_mode overhang beyond it
     int is_max, count_include_pad;
     const float* x;
     float* y;

@@ -584,7 +584,13 @@ __global__ __launch_bounds__(256) void pool2d_kernel(PoolP p) {
                 ++cnt;
             }
         }
-        if (!p.is_max) acc = acc / (float)(p.count_include_pad ? p.kh * p.kw : (cnt > 0 ? cnt : 1));
+        if (!p.is_max) {
+            // count_include_pad: the window clipped to the PADDED extent (a ceil_mode window hanging over the padding does not count the overhang: ONNX AveragePool
+            // since opset 19 / torch avg_pool2d; without ceil_mode every window lies inside the padded extent and this is kh * kw)
+            const int ih0 = oh * p.sh - p.pt, iw0 = ow * p.sw - p.pl;
+            const int full = (min(ih0 + p.kh, p.H + p.pb) - ih0) * (min(iw0 + p.kw, p.W + p.pr) - iw0);
+            acc = acc / (float)(p.count_include_pad ? (full > 0 ? full : 1) : (cnt > 0 ? cnt : 1));
+        }
         p.y[i] = acc;
     }
 }

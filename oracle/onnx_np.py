@@ -74,6 +74,11 @@ def _pool(x, a, kind):
     rnd = (lambda v: -(-v // 1)) if ceil else (lambda v: v // 1)
     ho = int(rnd((h + pt + pb - kh) / sh)) + 1 if not ceil else int(np.ceil((h + pt + pb - kh) / sh)) + 1
     wo = int(rnd((w + pl + pr - kw) / sw)) + 1 if not ceil else int(np.ceil((w + pl + pr - kw) / sw)) + 1
+    if ceil:   # a last window that would start beyond the input + leading padding is dropped (ONNX / torch output-shape rule)
+        if (ho - 1) * sh >= h + pt:
+            ho -= 1
+        if (wo - 1) * sw >= w + pl:
+            wo -= 1
     include = bool(a.get("count_include_pad", 0))
     y = np.zeros((n, c, ho, wo), F64)
     for oh in range(ho):
@@ -84,7 +89,8 @@ def _pool(x, a, kind):
             if kind == "max":
                 y[:, :, oh, ow] = win.max(axis=(2, 3))
             else:
-                cnt = kh * kw if include else (yb - ya) * (xb - xa)
+                # count_include_pad: the window clipped to the padded extent -- padding counts, a ceil_mode overhang beyond it does not (ONNX opset >= 19 reference, torch)
+                cnt = (min(y0 + kh, h + pb) - y0) * (min(x0 + kw, w + pr) - x0) if include else (yb - ya) * (xb - xa)
                 y[:, :, oh, ow] = win.sum(axis=(2, 3)) / cnt
     return y
 

@@ -129,6 +129,26 @@ def test_convtranspose_pool_resize_concat():
     _check(_single_op_graph(build), rng.standard_normal((2, 8, 10, 14)).astype(np.float32))
 
 
+def test_ceil_mode_pools_divide_by_the_window_clipped_to_the_padded_extent():
+    """Round 6 (found by tools/op_fuzz.py): AveragePool with ceil_mode = 1 and count_include_pad = 1 divided the overhanging last windows by kh * kw; the
+    divisor counts padding but not the overhang beyond it (ONNX since opset 19, torch).  Also the output-size rule that drops a window starting past the input."""
+    rng = np.random.default_rng(18)
+
+    def build(g):
+        g.add_input("x", ["N", 8, "H", "W"])
+        outs = [g.op("AveragePool", ["x"], kernel_shape=[3, 2], strides=[3, 2], pads=[0, 0, 0, 0], ceil_mode=1, count_include_pad=1),
+                g.op("AveragePool", ["x"], kernel_shape=[3, 1], strides=[2, 1], pads=[1, 0, 1, 0], ceil_mode=1, count_include_pad=1),
+                g.op("AveragePool", ["x"], kernel_shape=[4, 3], strides=[3, 2], pads=[2, 1, 2, 1], ceil_mode=1, count_include_pad=0),
+                g.op("AveragePool", ["x"], kernel_shape=[3, 3], strides=[2, 2], pads=[1, 1, 1, 1], ceil_mode=0, count_include_pad=1),
+                g.op("MaxPool", ["x"], kernel_shape=[3, 4], strides=[3, 2], pads=[0, 2, 0, 2], ceil_mode=1)]
+        for o in outs[:-1]:
+            g.add_output(o, ["N", 8, "Ho", "Wo"])
+        return outs[-1], ["N", 8, "Ho", "Wo"]
+
+    for shape in ((1, 8, 4, 49), (3, 8, 16, 113), (2, 8, 10, 14)):
+        _check(_single_op_graph(build), rng.standard_normal(shape).astype(np.float32))
+
+
 def test_sequence_ops_layernorm_attention():
     rng = np.random.default_rng(9)
     C, heads = 32, 4

@@ -76,12 +76,17 @@ def test_operator_attribute_corners(case):
         c = g.op("AveragePool", ["x"], kernel_shape=[3, 3], strides=[2, 2], pads=[1, 1, 1, 1], count_include_pad=1)
         d = g.op("AveragePool", ["x"], kernel_shape=[3, 2], strides=[2, 2], pads=[1, 0, 1, 0])
         e = g.op("MaxPool", ["x"], kernel_shape=[3, 3], strides=[2, 2], pads=[1, 1, 1, 1])
+        # ceil_mode (round 6, found by tools/op_fuzz.py): the window hanging over the padded extent -- with count_include_pad the divisor counts padding, not the overhang
+        e2 = [g.op("AveragePool", ["x"], kernel_shape=[3, 2], strides=[3, 2], pads=[0, 0, 0, 0], ceil_mode=1, count_include_pad=1),
+              g.op("AveragePool", ["x"], kernel_shape=[3, 3], strides=[2, 2], pads=[1, 1, 1, 1], ceil_mode=1, count_include_pad=1),
+              g.op("AveragePool", ["x"], kernel_shape=[4, 3], strides=[3, 2], pads=[2, 1, 2, 1], ceil_mode=1, count_include_pad=0),
+              g.op("MaxPool", ["x"], kernel_shape=[3, 4], strides=[3, 2], pads=[0, 2, 0, 2], ceil_mode=1)]
         sc = lambda fy, fx: g.init(np.array([1, 1, fy, fx], np.float32))
         r = [g.op("Resize", ["x", "", sc(2, 2)], mode="nearest", coordinate_transformation_mode="asymmetric", nearest_mode="floor"),
              g.op("Resize", ["x", "", sc(1.5, 2.5)], mode="nearest", coordinate_transformation_mode="half_pixel", nearest_mode="round_prefer_floor"),
              g.op("Resize", ["x", "", sc(2, 3)], mode="linear", coordinate_transformation_mode="half_pixel"),
              g.op("Resize", ["x", "", sc(0.5, 0.5)], mode="linear", coordinate_transformation_mode="align_corners")]
-        for o in [a, b, c, d, e] + r:
+        for o in [a, b, c, d, e] + e2 + r:
             g.add_output(o, ["N", "C", "H", "W"])
         _agree(g.model(), {"x": rng.standard_normal((2, 6, 10, 14)).astype(np.float32)})
     else:
