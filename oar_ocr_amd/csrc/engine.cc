@@ -2088,8 +2088,15 @@ struct Planner {
         const bool keep = n.ai("keepdims", 1) != 0;
         bool spatial = mode == 0 && r == 4 && axes.size() == 2 && axes[0] == 2 && axes[1] == 3;
         if (spatial) {
-            OAR_CHECK(keep, OAR_UNSUPPORTED_OP, "ReduceMean over H, W with keepdims = 0");
-            return op_gap(n);
+            if (keep) return op_gap(n);
+            GNode gp = n;   // keepdims = 0: the pooled [N, C, 1, 1] map, squeezed
+            gp.out = {n.out[0] + "::kept"};
+            op_gap(gp);
+            GNode sq;
+            sq.op = "Squeeze"; sq.in = {gp.out[0]}; sq.out = {n.out[0]};
+            Attr ax; ax.kind = Attr::IS; ax.is = {2, 3}; sq.attrs["axes"] = ax;
+            op_squeeze(sq);
+            return;
         }
         bool trailing = !axes.empty();
         for (size_t i = 0; i < axes.size(); ++i) trailing = trailing && axes[i] == r - (int64_t)axes.size() + (int64_t)i;
@@ -2107,6 +2114,27 @@ struct Planner {
                 Attr ax; ax.kind = Attr::IS; ax.is = {axes[0]}; sq.attrs["axes"] = ax;
                 op_squeeze(sq);
             }
+            return;
+        }
+        if (!trailing && !axes.empty() && !x.host_int) {
+            // any other axis set (round 6; no PP-OCR graph has one -- tools/op_fuzz.py asked): the reduced axes are moved behind the others by a Transpose, reduced as
+            // trailing axes, and keepdims = 1 is a view of the result with the ones back in place
+            std::vector<int64_t> perm, od;
+            for (int i = 0; i < r; ++i) if (!std::binary_search(axes.begin(), axes.end(), (int64_t)i)) perm.push_back(i);
+            for (auto a : axes) perm.push_back(a);
+            for (int i = 0; i < r; ++i) { if (!std::binary_search(axes.begin(), axes.end(), (int64_t)i)) od.push_back(x.dims[i]); else if (keep) od.push_back(1); }
+            GNode tr;
+            tr.op = "Transpose"; tr.in = {n.in[0]}; tr.out = {n.out[0] + "::moved"};
+            Attr pa; pa.kind = Attr::IS; pa.is = perm; tr.attrs["perm"] = pa;
+            op_transpose(tr);
+            GNode rd = n;
+            rd.in = {tr.out[0]}; rd.out = {keep ? n.out[0] + "::reduced" : n.out[0]};
+            std::vector<int64_t> tail;
+            for (size_t i = 0; i < axes.size(); ++i) tail.push_back(r - (int64_t)axes.size() + (int64_t)i);
+            Attr ta; ta.kind = Attr::IS; ta.is = tail; rd.attrs["axes"] = ta;
+            Attr kd; kd.kind = Attr::I; kd.i = 0; rd.attrs["keepdims"] = kd;
+            op_reduce(rd, mode);
+            if (keep) { GNode v; v.op = "Reshape"; v.in = {rd.out[0]}; v.out = {n.out[0]}; view_native(v, get(rd.out[0]), od); }
             return;
         }
         OAR_CHECK(trailing, OAR_UNSUPPORTED_OP, n.op + ": only the trailing axes (or H, W / one of them for ReduceMean / ReduceMax of an NCHW tensor) are supported");
@@ -3046,6 +3074,24 @@ struct Planner {
         if (axis < 0) axis += r;
         Loc xin = to_native_loc(x);
         int64_t C, rows;
+        if (E_opset13() && axis != r - 1 && !x.host_int) {
+            // an inner axis (round 6): Transpose it to the end, soft-max there, Transpose back
+            std::vector<int64_t> perm;
+            for (int i = 0; i < r; ++i) if (i != axis) perm.push_back(i);
+            perm.push_back(axis);
+            std::vector<int64_t> inv(r);
+            for (int i = 0; i < r; ++i) inv[perm[i]] = i;
+            GNode t1; t1.op = "Transpose"; t1.in = {n.in[0]}; t1.out = {n.out[0] + "::moved"};
+            Attr p1; p1.kind = Attr::IS; p1.is = perm; t1.attrs["perm"] = p1;
+            op_transpose(t1);
+            GNode sm = n; sm.in = {t1.out[0]}; sm.out = {n.out[0] + "::sm"};
+            Attr la; la.kind = Attr::I; la.i = -1; sm.attrs["axis"] = la;
+            op_softmax(sm);
+            GNode t2; t2.op = "Transpose"; t2.in = {sm.out[0]}; t2.out = {n.out[0]};
+            Attr p2; p2.kind = Attr::IS; p2.is = inv; t2.attrs["perm"] = p2;
+            op_transpose(t2);
+            return;
+        }
         if (E_opset13()) {
             OAR_CHECK(axis == r - 1, OAR_UNSUPPORTED_OP, "Softmax: only the last axis is supported");
             C = x.dims.back(); rows = numel(x.dims) / std::max<int64_t>(C, 1);

@@ -211,10 +211,32 @@ def _resize(x, node, env):
 
         return x[:, :, idx(oh, sh, h)][:, :, :, idx(ow, sw, w)]
     if mode == "linear":
-        if ctm == "align_corners":
-            return F.interpolate(x, size=(oh, ow), mode="bilinear", align_corners=True)
-        if ctm in ("half_pixel", "pytorch_half_pixel"):
-            return F.interpolate(x, size=(oh, ow), mode="bilinear", align_corners=False)
+        # ONNX Resize-13 "linear" as the specification states it (and ONNX Runtime computes it): the source coordinate comes from the SCALE the node was given
+        # (out / in only when `sizes` was given) -- F.interpolate(size=...) derives it from out / in, which differs whenever floor(in * scale) / in != scale
+        # (odd lengths halved, x1.5 of an odd length; found by tools/op_fuzz.py in round 6) --, is clamped to [0, in - 1], and the two neighbours are blended.
+        def axis(o_len, s, n_in):
+            o = np.arange(o_len, dtype=np.float64)
+            if ctm == "asymmetric":
+                x_ = o / s
+            elif ctm == "half_pixel":
+                x_ = (o + 0.5) / s - 0.5
+            elif ctm == "pytorch_half_pixel":
+                x_ = (o + 0.5) / s - 0.5 if o_len > 1 else np.zeros_like(o)
+            elif ctm == "align_corners":
+                x_ = o * (n_in - 1) / (o_len - 1) if o_len > 1 else np.zeros_like(o)
+            else:
+                raise NotImplementedError((mode, ctm))
+            x_ = np.clip(x_.astype(np.float32), 0.0, float(n_in - 1))
+            i0 = np.floor(x_).astype(np.int64)
+            i1 = np.minimum(i0 + 1, n_in - 1)
+            return torch.from_numpy(i0), torch.from_numpy(i1), torch.from_numpy((x_ - i0).astype(np.float32))
+        y0, y1, fy = axis(oh, sh, h)
+        x0, x1, fx = axis(ow, sw, w)
+        fy = fy.view(1, 1, -1, 1)
+        fx = fx.view(1, 1, 1, -1)
+        top = x[:, :, y0][:, :, :, x0] * (1 - fx) + x[:, :, y0][:, :, :, x1] * fx
+        bot = x[:, :, y1][:, :, :, x0] * (1 - fx) + x[:, :, y1][:, :, :, x1] * fx
+        return top * (1 - fy) + bot * fy
     raise NotImplementedError((mode, ctm))
 
 

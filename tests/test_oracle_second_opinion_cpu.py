@@ -85,7 +85,11 @@ def test_operator_attribute_corners(case):
         r = [g.op("Resize", ["x", "", sc(2, 2)], mode="nearest", coordinate_transformation_mode="asymmetric", nearest_mode="floor"),
              g.op("Resize", ["x", "", sc(1.5, 2.5)], mode="nearest", coordinate_transformation_mode="half_pixel", nearest_mode="round_prefer_floor"),
              g.op("Resize", ["x", "", sc(2, 3)], mode="linear", coordinate_transformation_mode="half_pixel"),
-             g.op("Resize", ["x", "", sc(0.5, 0.5)], mode="linear", coordinate_transformation_mode="align_corners")]
+             g.op("Resize", ["x", "", sc(0.5, 0.5)], mode="linear", coordinate_transformation_mode="align_corners"),
+             # scales whose floor(in * scale) / in differs from the scale (the coordinate follows the SCALE, as ONNX Runtime does), and linear + asymmetric
+             g.op("Resize", ["x", "", sc(0.7, 1.3)], mode="linear", coordinate_transformation_mode="half_pixel"),
+             g.op("Resize", ["x", "", sc(1.3, 0.45)], mode="linear", coordinate_transformation_mode="pytorch_half_pixel"),
+             g.op("Resize", ["x", "", sc(2.5, 1.7)], mode="linear", coordinate_transformation_mode="asymmetric")]
         for o in [a, b, c, d, e] + e2 + r:
             g.add_output(o, ["N", "C", "H", "W"])
         _agree(g.model(), {"x": rng.standard_normal((2, 6, 10, 14)).astype(np.float32)})

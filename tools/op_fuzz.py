@@ -2,7 +2,7 @@
 eligibility boundary of the bf16x6 kernels (weight-stationary one- and two-fragment tiles, output-stationary, row-streaming 3x3, LDS-tiled large kernel,
 grouped, multi-source concat reads, streaming attention), random epilogues (bias, ReLU / hard-swish / GELU / none, residual).  Reports, per case, the kernel
 classes that ran and the largest |difference| relative to the output scale; the tolerance is the engine tests' 2e-4.
-usage: python tools/op_fuzz.py [n_cases] [seed] [kind]      kind: svtr_block | dbhead | fpn | pool | dsblock | dschain | conv1x1 | conv3x3 | convk | grouped | concat | attention | all"""
+usage: python tools/op_fuzz.py [n_cases] [seed] [kind]      kind: eltwise | reduce | resize | shape | svtr_block | dbhead | fpn | pool | dsblock | dschain | conv1x1 | conv3x3 | convk | grouped | concat | attention | all"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -305,7 +305,137 @@ def case_pool():
     return f"{kind} {kh}x{kw}/{sh}x{sw} pad {ph},{pw} ceil {ceil_mode} {attrs.get('count_include_pad', '-')} c{c} {n}x{h}x{w}", g.model(), (n, 8, h, w)
 
 
-KINDS = {"svtr_block": case_svtr_block, "dbhead": case_dbhead, "fpn": case_fpn, "pool": case_pool, "dsblock": case_dsblock, "dschain": case_dschain, "conv1x1": case_conv1x1, "conv3x3": case_conv3x3, "convk": case_convk, "grouped": case_grouped, "concat": case_concat, "attention": case_attention}
+def case_eltwise():
+    """binary operators with ONNX broadcasting: per-channel / per-sample / per-pixel / scalar / full second operands, constants and computed tensors"""
+    c = int(rng.choice([3, 8, 16, 24, 50, 96]))
+    n, h, w = int(rng.integers(1, 5)), int(rng.integers(1, 60)), int(rng.integers(1, 90))
+    g = GraphBuilder("f")
+    g.add_input("x", ["N", 8, "H", "W"])
+    y = stem(g, c)
+    desc = []
+    for _ in range(int(rng.integers(1, 4))):
+        op = str(rng.choice(["Add", "Mul", "Sub", "Div", "Max", "Min"]))
+        form = str(rng.choice(["chan", "chan3", "scalar", "pix", "gap", "full", "row"]))
+        if form == "chan":
+            b = g.init((1.5 + 0.3 * rng.standard_normal((1, c, 1, 1))).astype(np.float32))
+        elif form == "chan3":
+            b = g.init((1.5 + 0.3 * rng.standard_normal((c, 1, 1))).astype(np.float32))
+        elif form == "scalar":
+            b = g.init(np.array(1.25, np.float32), "c")
+        elif form == "pix":    # computed [N, 1, H, W]
+            b = g.op("Add", [g.op("Sigmoid", [conv(g, y, c, 1, 1)]), g.init(np.array(1.0, np.float32), "c")])
+        elif form == "gap":    # computed [N, C, 1, 1]
+            b = g.op("Add", [g.op("Sigmoid", [g.op("GlobalAveragePool", [y])]), g.init(np.array(1.0, np.float32), "c")])
+        elif form == "row":    # constant [W]-less: [1, 1, 1, 1] degenerate
+            b = g.init(np.array([[[[2.0]]]], np.float32))
+        else:
+            b = g.op("Add", [g.op("Sigmoid", [conv(g, y, c, c, 1)]), g.init(np.array(1.0, np.float32), "c")])
+        swap = bool(rng.random() < 0.3) and op != "Div"   # (constant / activation is a division by values at and near zero: ill-conditioned, not a statement about the operator)
+        y = g.op(op, [b, y] if swap else [y, b])
+        desc.append(f"{op}:{form}{'~' if swap else ''}")
+    g.add_output(y, ["N", c, "H", "W"])
+    return f"eltwise c{c} {n}x{h}x{w} {' '.join(desc)}", g.model(), (n, 8, h, w)
+
+
+def case_reduce():
+    """ReduceMean / Sum / Max / Min over random axes of 4-D and 3-D tensors, keepdims on and off; Softmax and LayerNormalization over odd widths"""
+    g = GraphBuilder("f")
+    if rng.random() < 0.5:
+        c = int(rng.choice([4, 10, 24, 33]))
+        n, h, w = int(rng.integers(1, 4)), int(rng.integers(1, 30)), int(rng.integers(1, 50))
+        g.add_input("x", ["N", 8, "H", "W"])
+        t = stem(g, c)
+        axes = sorted(set(int(a) for a in rng.choice([1, 2, 3], size=int(rng.integers(1, 3)), replace=False)))
+        kd = int(rng.random() < 0.6)
+        op = str(rng.choice(["ReduceMean", "ReduceSum", "ReduceMax", "ReduceMin"]))
+        y = g.op(op, [t], axes=axes, keepdims=kd)
+        g.add_output(y, ["A", "B", "C", "D"][: 4 if kd else 4 - len(axes)])
+        return f"{op} axes {axes} keepdims {kd} c{c} {n}x{h}x{w}", g.model(), (n, 8, h, w)
+    dim = int(rng.choice([7, 24, 33, 96, 120, 257]))
+    n, T = int(rng.integers(1, 5)), int(rng.integers(1, 70))
+    g.add_input("x", ["N", "T", dim])
+    t = _linear(g, "x", dim, dim)
+    which = str(rng.choice(["ln", "softmax_last", "softmax_mid", "reduce_last", "reduce_mid"]))
+    if which == "ln":
+        y = _ln(g, t, dim)
+    elif which == "softmax_last":
+        y = g.op("Softmax", [t], axis=-1)
+    elif which == "softmax_mid":
+        y = g.op("Softmax", [t], axis=1)
+    elif which == "reduce_last":
+        y = g.op("ReduceMean", [t], axes=[-1], keepdims=int(rng.random() < 0.5))
+    else:
+        y = g.op("ReduceMax", [t], axes=[1], keepdims=int(rng.random() < 0.5))
+    g.add_output(y, ["A", "B", "C"])
+    return f"seq {which} dim {dim} {n}x{T}", g.model(), (n, T, dim)
+
+
+def case_resize():
+    """Resize: nearest (asymmetric / floor, half_pixel / round_prefer_floor) and linear (half_pixel, align_corners, asymmetric, pytorch_half_pixel), scales and sizes,
+    integer and fractional factors, enlargements and reductions"""
+    c = int(rng.choice([3, 8, 16, 40]))
+    n, h, w = int(rng.integers(1, 4)), int(rng.integers(2, 50)), int(rng.integers(2, 70))
+    mode = str(rng.choice(["nearest", "linear"]))
+    if mode == "nearest":
+        ctm, nm = [("asymmetric", "floor"), ("half_pixel", "round_prefer_floor"), ("asymmetric", "round_prefer_floor")][int(rng.integers(0, 3))]
+    else:
+        ctm, nm = str(rng.choice(["half_pixel", "align_corners", "asymmetric", "pytorch_half_pixel"])), None
+    fy, fx = [float(rng.choice([0.5, 1.0, 1.5, 2.0, 2.5, 3.0, 4.0])) for _ in range(2)]
+    use_sizes = bool(rng.random() < 0.4)
+    g = GraphBuilder("f")
+    g.add_input("x", ["N", 8, "H", "W"])
+    t = stem(g, c) if rng.random() < 0.6 else "x"
+    cc = c if t != "x" else 8
+    attrs = dict(mode=mode, coordinate_transformation_mode=ctm)
+    if nm:
+        attrs["nearest_mode"] = nm
+    if use_sizes:
+        oh, ow = max(1, int(h * fy)), max(1, int(w * fx))
+        y = g.op("Resize", [t, "", "", g.init(np.array([n, cc, oh, ow], np.int64), "sizes")], **attrs)
+    else:
+        y = g.op("Resize", [t, "", g.init(np.array([1, 1, fy, fx], np.float32), "scales")], **attrs)
+    y = g.op("Relu", [conv(g, y, cc, 8, 1)])
+    g.add_output(y, ["N", 8, "H2", "W2"])
+    return f"resize {mode} {ctm} {nm} x{fy},{fx} {'sizes' if use_sizes else 'scales'} c{cc} {n}x{h}x{w}", g.model(), (n, 8, h, w)
+
+
+def case_shape():
+    """layout plumbing the exporters emit around the recognizer head and the necks: Slice / Split / Concat on several axes, Transpose, Squeeze / Unsqueeze, Reshape with 0 / -1, Pad"""
+    c = int(rng.choice([8, 16, 24, 48]))
+    n, h, w = int(rng.integers(1, 4)), int(rng.integers(2, 20)), int(rng.integers(4, 60))
+    g = GraphBuilder("f")
+    g.add_input("x", ["N", 8, "H", "W"])
+    t = stem(g, c)
+    which = str(rng.choice(["slice_concat", "split_c", "rec_head", "pad", "transpose"]))
+    if which == "slice_concat":
+        a0, a1 = int(rng.integers(0, w // 2)), int(rng.integers(w // 2 + 1, w + 1))
+        s1 = g.op("Slice", [t, g.init(np.array([a0], np.int64), "i"), g.init(np.array([a1], np.int64), "i"), g.init(np.array([3], np.int64), "i")])
+        s2 = g.op("Slice", [t, g.init(np.array([0], np.int64), "i"), g.init(np.array([c // 2], np.int64), "i"), g.init(np.array([1], np.int64), "i")])
+        y1 = g.op("Concat", [s1, s1], axis=3)
+        y2 = g.op("Concat", [s2, t], axis=1)
+        g.add_output(y1, ["A", "B", "C", "D"])
+        y = y2
+    elif which == "split_c":
+        a, b = g.op("Split", [t, g.init(np.array([c // 2, c - c // 2], np.int64), "split")], n_out=2, axis=1)
+        y = g.op("Concat", [g.op("Relu", [b]), g.op("Sigmoid", [a])], axis=1)
+    elif which == "rec_head":
+        p = g.op("AveragePool", [t], kernel_shape=[h, 1], strides=[h, 1], pads=[0, 0, 0, 0])      # [N, C, 1, W]
+        sq = g.op("Squeeze", [p, g.init(np.array([2], np.int64), "axes")])                           # [N, C, W]
+        tr = g.op("Transpose", [sq], perm=[0, 2, 1])                                               # [N, W, C]
+        y = g.op("Softmax", [_linear(g, tr, c, 37)], axis=2)
+    elif which == "pad":
+        pads = [0, 0, int(rng.integers(0, 3)), int(rng.integers(0, 3)), 0, 0, int(rng.integers(0, 3)), int(rng.integers(0, 3))]
+        y = g.op("Pad", [t, g.init(np.array(pads, np.int64), "pads"), g.init(np.array(0.5, np.float32), "c")], mode="constant")
+        y = g.op("Relu", [conv(g, y, c, 8, 3)])
+    else:
+        perm = [[0, 2, 3, 1], [0, 3, 1, 2], [0, 1, 3, 2], [1, 0, 2, 3]][int(rng.integers(0, 4))]
+        y = g.op("Transpose", [t], perm=perm)
+        y = g.op("Reshape", [y, g.init(np.array([0, -1], np.int64), "shape")])
+    g.add_output(y, ["A", "B", "C", "D"])
+    return f"shape {which} c{c} {n}x{h}x{w}", g.model(), (n, 8, h, w)
+
+
+KINDS = {"eltwise": case_eltwise, "reduce": case_reduce, "resize": case_resize, "shape": case_shape, "svtr_block": case_svtr_block, "dbhead": case_dbhead, "fpn": case_fpn, "pool": case_pool, "dsblock": case_dsblock, "dschain": case_dschain, "conv1x1": case_conv1x1, "conv3x3": case_conv3x3, "convk": case_convk, "grouped": case_grouped, "concat": case_concat, "attention": case_attention}
 names = list(KINDS) if only == "all" else [only]
 bad = 0
 worst = {}
@@ -330,8 +460,13 @@ for i in range(n_cases):
         for (_, a), r in zip(got, ref):
             assert a.shape == r.shape, (a.shape, r.shape)
             if r.size:
-                err = max(err, float(np.abs(a - r).max()) / max(1.0, float(np.abs(r).max())))
-        ok = err <= TOL and all(np.isfinite(a).all() for _, a in got)
+                fin = np.isfinite(r)
+                if not fin.all():   # a division by an exact zero: the engine must be non-finite in the same places (inf of the same sign, nan where nan)
+                    same = np.array_equal(np.isnan(a), np.isnan(r)) and np.array_equal(a[np.isinf(r)], r[np.isinf(r)]) and np.isfinite(a[fin]).all()
+                    err = max(err, 0.0 if same else 1.0)
+                if fin.any():
+                    err = max(err, float(np.abs(a[fin] - r[fin]).max()) / max(1.0, float(np.abs(r[fin]).max())))
+        ok = err <= TOL
         eng.close() if hasattr(eng, "close") else None
     except Exception as e:   # an engine error on a supported graph is a failure of the sweep, not of the harness
         ok, err, classes = False, float("nan"), [f"EXC {type(e).__name__}: {str(e)[:200]}"]
