@@ -820,6 +820,16 @@ struct Planner {
         t.loc = alloc_arena(t.bytes(), name);
         return vals[name] = t;
     }
+    // A node planned as several operators leaves its result as a VIEW of a temporary (e.g. pool -> "out::kept" -> Squeeze -> "out"): the arena bytes are then booked
+    // under the temporary's name, which compute_last_use() knows nothing about -- release_dead() would free them right after the node although "out" is read later.
+    // The node's output takes the booking over (round 6; tools/op_fuzz.py found a reduce whose result was overwritten by the next node's output).
+    void adopt_root(const std::string& out, const std::string& tmp) {
+        auto it = vals.find(out);
+        if (it == vals.end() || tmp == out || it->second.root != tmp) return;
+        auto rb = root_bytes.find(tmp);
+        if (rb != root_bytes.end()) { root_bytes[out] = rb->second; root_off[out] = root_off[tmp]; root_bytes.erase(tmp); root_off.erase(tmp); }
+        it->second.root = out;
+    }
     TInfo& alias_out(const std::string& name, const TInfo& src, const std::vector<int64_t>& dims, Layout lay, int64_t byte_off = 0) {
         TInfo t;
         t.dims = dims; t.layout = lay; t.root = src.root; t.loc = src.loc; t.ht = nullptr;
@@ -1921,10 +1931,22 @@ struct Planner {
         OAR_CHECK(x.dims.size() == 4, OAR_UNSUPPORTED_OP, "ConvTranspose: only 2-D");
         const TInfo& wt = get(n.in[1]);
         OAR_CHECK(wt.ht, OAR_UNSUPPORTED_OP, "ConvTranspose: weights must be an initializer");
-        const HostTensor& W = *wt.ht;
-        OAR_CHECK(W.dims.size() == 4 && W.dims[0] == x.dims[1] && W.dims[1] > 0 && W.dims[2] > 0 && W.dims[3] > 0, OAR_MODEL_LOAD, "ConvTranspose: weight must be [Cin, Cout, kh, kw] at " + n.out[0]);
+        const HostTensor& W0 = *wt.ht;
+        OAR_CHECK(W0.dims.size() == 4 && W0.dims[0] == x.dims[1] && W0.dims[1] > 0 && W0.dims[2] > 0 && W0.dims[3] > 0, OAR_MODEL_LOAD, "ConvTranspose: weight must be [Cin, Cout / group, kh, kw] at " + n.out[0]);
+        const int64_t grp = n.ai("group", 1);
+        OAR_CHECK(grp >= 1 && x.dims[1] % grp == 0, OAR_SHAPE_MISMATCH, "ConvTranspose: group must divide Cin at " + n.out[0]);
+        // group > 1 (round 6; no PP-OCR graph has one): the weights as the block-diagonal [Cin, group * Cout / group, kh, kw] tensor of the equivalent dense layer
+        HostTensor Wg;
+        if (grp > 1) {
+            const int64_t cig = W0.dims[0] / grp, cog = W0.dims[1], kk = W0.dims[2] * W0.dims[3];
+            Wg.dtype = W0.dtype; Wg.dims = {W0.dims[0], grp * cog, W0.dims[2], W0.dims[3]};
+            Wg.f.assign((size_t)(W0.dims[0] * grp * cog * kk), 0.f);
+            for (int64_t ci = 0; ci < W0.dims[0]; ++ci)
+                for (int64_t co = 0; co < cog; ++co)
+                    for (int64_t t = 0; t < kk; ++t) Wg.f[(size_t)((ci * grp * cog + (ci / cig) * cog + co) * kk + t)] = W0.f[(size_t)((ci * cog + co) * kk + t)];
+        }
+        const HostTensor& W = grp > 1 ? Wg : W0;
         if (has_input(n, 2)) { const TInfo& bt = get(n.in[2]); OAR_CHECK(bt.ht && (int64_t)bt.ht->f.size() == W.dims[1], OAR_MODEL_LOAD, "ConvTranspose: bias must be an f32 initializer of Cout elements at " + n.out[0]); }
-        OAR_CHECK(n.ai("group", 1) == 1, OAR_UNSUPPORTED_OP, "ConvTranspose: group != 1");
         int64_t N = x.dims[0], Cin = x.dims[1], H = x.dims[2], Wd = x.dims[3];
         int64_t Cout = W.dims[1], kh = W.dims[2], kw = W.dims[3];
         auto st = n.ais("strides"), dl = n.ais("dilations"), pads = n.ais("pads"), op = n.ais("output_padding");
@@ -2096,6 +2118,7 @@ struct Planner {
             sq.op = "Squeeze"; sq.in = {gp.out[0]}; sq.out = {n.out[0]};
             Attr ax; ax.kind = Attr::IS; ax.is = {2, 3}; sq.attrs["axes"] = ax;
             op_squeeze(sq);
+            adopt_root(n.out[0], gp.out[0]);
             return;
         }
         bool trailing = !axes.empty();
@@ -2113,6 +2136,7 @@ struct Planner {
                 sq.op = "Squeeze"; sq.in = {pl.out[0]}; sq.out = {n.out[0]};
                 Attr ax; ax.kind = Attr::IS; ax.is = {axes[0]}; sq.attrs["axes"] = ax;
                 op_squeeze(sq);
+                adopt_root(n.out[0], pl.out[0]);
             }
             return;
         }
@@ -2134,7 +2158,7 @@ struct Planner {
             Attr ta; ta.kind = Attr::IS; ta.is = tail; rd.attrs["axes"] = ta;
             Attr kd; kd.kind = Attr::I; kd.i = 0; rd.attrs["keepdims"] = kd;
             op_reduce(rd, mode);
-            if (keep) { GNode v; v.op = "Reshape"; v.in = {rd.out[0]}; v.out = {n.out[0]}; view_native(v, get(rd.out[0]), od); }
+            if (keep) { GNode v; v.op = "Reshape"; v.in = {rd.out[0]}; v.out = {n.out[0]}; view_native(v, get(rd.out[0]), od); adopt_root(n.out[0], rd.out[0]); }
             return;
         }
         OAR_CHECK(trailing, OAR_UNSUPPORTED_OP, n.op + ": only the trailing axes (or H, W / one of them for ReduceMean / ReduceMax of an NCHW tensor) are supported");
@@ -2941,6 +2965,7 @@ struct Planner {
         std::vector<int64_t> od;
         for (int d = 0; d < r; ++d) if (d != axis || !idx.dims.empty()) od.push_back(d == axis ? 1 : x.dims[d]);
         alias_out(n.out[0], s, od, Layout::NATIVE);
+        adopt_root(n.out[0], tmpn);   // (when the slice was a copy: the bytes are this node's output)
     }
 
     // true when `name` is consumed by nothing but the Softmax that produces graph output 0
@@ -2970,8 +2995,14 @@ struct Planner {
         if (!n.bias.empty()) { const TInfo& bb = get(n.bias); OAR_CHECK(bb.ht && (int64_t)bb.ht->f.size() == N, OAR_MODEL_LOAD, "Linear: bias must have N elements at " + n.out[0]); bias = bb.loc.cptr; }
         if (gemm && has_input(n, 2)) {
             const TInfo& c = get(n.in[2]);
-            OAR_CHECK(c.ht && numel(c.dims) == N && n.af("beta", 1.0f) == 1.0f, OAR_UNSUPPORTED_OP, "Gemm: C must be a constant [N] with beta 1");
-            bias = c.loc.cptr;
+            OAR_CHECK(c.ht && numel(c.dims) == N, OAR_UNSUPPORTED_OP, "Gemm: C must be a constant of N elements");
+            const float beta = n.af("beta", 1.0f);
+            if (beta == 1.0f) bias = c.loc.cptr;
+            else if (beta != 0.0f) {   // beta * C folded into a constant of its own (round 6)
+                std::vector<float> bc(c.ht->f);
+                for (auto& v : bc) v *= beta;
+                bias = E.upload_const("gemm_beta_c:" + n.out[0], bc);
+            }
         }
         Loc res;
         if (!n.residual.empty()) { TInfo r = get(n.residual); OAR_CHECK(numel(r.dims) == M * N, OAR_SHAPE_MISMATCH, "Linear: residual shape"); res = to_native_loc(r); }

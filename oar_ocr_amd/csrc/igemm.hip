@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmP p) {  // 2 wa
         } else {
             // k -> (tap_h, tap_w, ci) with multiply-high divisions (exact for k < 2^16, checked at launch): no
             // loop-carried state and no branches between the MFMAs
-            const int tap = (int)__umulhi((unsigned)k, p.cin_magic), ci = k - tap * p.Cin;
-            const int tap_h = (int)__umulhi((unsigned)tap, p.kw_magic), tap_w = tap - tap_h * p.kw;
+            const int tap = igemm_div(k, p.cin_magic, p.Cin), ci = k - tap * p.Cin;
+            const int tap_h = igemm_div(tap, p.kw_magic, p.kw), tap_w = tap - tap_h * p.kw;
             const int ih = ih0[pf] + tap_h * p.dh, iw = iw0[pf] + tap_w * p.dw;
             const bool ok = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
             const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_small_kernel(IgemmP p) {
             if (SE) gs[d] = *reinterpret_cast<const float4*>(se_row + k);
             ok[d] = true;
         } else {
-            const int tap = (int)__umulhi((unsigned)k, p.cin_magic), ci = k - tap * p.Cin;
-            const int tap_h = (int)__umulhi((unsigned)tap, p.kw_magic), tap_w = tap - tap_h * p.kw;
+            const int tap = igemm_div(k, p.cin_magic, p.Cin), ci = k - tap * p.Cin;
+            const int tap_h = igemm_div(tap, p.kw_magic, p.kw), tap_w = tap - tap_h * p.kw;
             const int ih = ih0 + tap_h * p.dh, iw = iw0 + tap_w * p.dw;
             ok[d] = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
             const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);

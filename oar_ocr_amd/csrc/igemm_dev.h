@@ -58,6 +58,10 @@ struct IgemmP {
                          // whose x points at the group's first channel).  Every other kernel reads x with stride Cin
 };
 
+// n / d through the host's magic number floor(2^32 / d) + 1 (exact for n < 2^16).  d == 1 has no 32-bit magic (2^32 + 1 wraps to 1, and umulhi would return 0):
+// a k x 1 kernel (kw == 1) decoded every tap as row 0 until round 6 (tools/op_fuzz.py, "conv 7x1 ... g1": err ~1) -- the divisor 1 is answered directly.
+__device__ __forceinline__ int igemm_div(int n, unsigned magic, int d) { return d == 1 ? n : (int)__umulhi((unsigned)n, magic); }
+
 // element offset of the residual for output pixel `opix`, channel co: the same pixel, or -- res_up > 1 -- pixel (h / f, w / f) of the
 // [N][Ho / f][Wo / f][Cout] low-resolution tensor (M < 2^31 checked by the host: 32-bit divisions)
 __device__ __forceinline__ long igemm_res_off(const IgemmP& p, long opix, int co) {

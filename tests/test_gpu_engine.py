@@ -87,7 +87,9 @@ def _single_op_graph(build):
 @pytest.mark.parametrize("cfg", [
     dict(cin=8, cout=24, k=3, s=1, p=1, g=1), dict(cin=16, cout=16, k=3, s=2, p=1, g=16), dict(cin=32, cout=32, k=5, s=1, p=2, g=32),
     dict(cin=3, cout=16, k=3, s=2, p=1, g=1), dict(cin=16, cout=40, k=1, s=1, p=0, g=1), dict(cin=12, cout=20, k=3, s=1, p=1, g=4),
-    dict(cin=64, cout=100, k=3, s=(2, 1), p=1, g=1), dict(cin=20, cout=6, k=(1, 3), s=1, p=(0, 1), g=1), dict(cin=8, cout=8, k=9, s=1, p=4, g=1)])
+    dict(cin=64, cout=100, k=3, s=(2, 1), p=1, g=1), dict(cin=20, cout=6, k=(1, 3), s=1, p=(0, 1), g=1), dict(cin=8, cout=8, k=9, s=1, p=4, g=1),
+    # k x 1 kernels (round 6: the tap decode divided by kw = 1 through a magic number that does not exist for 1 -- every tap read row 0; found by tools/op_fuzz.py)
+    dict(cin=16, cout=12, k=(3, 1), s=1, p=(1, 0), g=1), dict(cin=24, cout=40, k=(7, 1), s=(2, 1), p=(3, 0), g=1), dict(cin=128, cout=128, k=(5, 1), s=1, p=(2, 0), g=1)])
 def test_conv_variants(cfg):
     rng = np.random.default_rng(7)
     kh, kw = (cfg["k"], cfg["k"]) if isinstance(cfg["k"], int) else cfg["k"]
@@ -147,6 +149,30 @@ def test_ceil_mode_pools_divide_by_the_window_clipped_to_the_padded_extent():
 
     for shape in ((1, 8, 4, 49), (3, 8, 16, 113), (2, 8, 10, 14)):
         _check(_single_op_graph(build), rng.standard_normal(shape).astype(np.float32))
+
+
+def test_reduce_and_softmax_over_any_axis():
+    """Round 6: Reduce* over axis sets that are not trailing (channels of a map, the token axis of a sequence, H and W without keepdims) and Softmax over an inner axis
+    used to be refused; they run as Transpose -> trailing kernel -> view.  Against torch-CPU."""
+    rng = np.random.default_rng(19)
+
+    def maps(g):
+        g.add_input("x", ["N", 10, "H", "W"])
+        outs = [g.op("ReduceSum", ["x"], axes=[1], keepdims=0), g.op("ReduceMin", ["x"], axes=[1, 3], keepdims=1), g.op("ReduceMax", ["x"], axes=[2], keepdims=1),
+                g.op("ReduceMean", ["x"], axes=[2, 3], keepdims=0), g.op("ReduceMean", ["x"], axes=[1, 2], keepdims=1), g.op("Softmax", ["x"], axis=1)]
+        for o in outs[:-1]:
+            g.add_output(o, ["A", "B", "C", "D"])
+        return outs[-1], ["N", 10, "H", "W"]
+
+    def seq(g):
+        g.add_input("x", ["N", "T", 24])
+        outs = [g.op("ReduceMax", ["x"], axes=[1], keepdims=0), g.op("ReduceMean", ["x"], axes=[0, 2], keepdims=1), g.op("Softmax", ["x"], axis=1)]
+        for o in outs[:-1]:
+            g.add_output(o, ["A", "B", "C"])
+        return outs[-1], ["N", "T", 24]
+
+    _check(_single_op_graph(maps), rng.standard_normal((3, 10, 7, 12)).astype(np.float32))
+    _check(_single_op_graph(seq), rng.standard_normal((4, 9, 24)).astype(np.float32))
 
 
 def test_sequence_ops_layernorm_attention():

@@ -2,7 +2,7 @@
 eligibility boundary of the bf16x6 kernels (weight-stationary one- and two-fragment tiles, output-stationary, row-streaming 3x3, LDS-tiled large kernel,
 grouped, multi-source concat reads, streaming attention), random epilogues (bias, ReLU / hard-swish / GELU / none, residual).  Reports, per case, the kernel
 classes that ran and the largest |difference| relative to the output scale; the tolerance is the engine tests' 2e-4.
-usage: python tools/op_fuzz.py [n_cases] [seed] [kind]      kind: eltwise | reduce | resize | shape | svtr_block | dbhead | fpn | pool | dsblock | dschain | conv1x1 | conv3x3 | convk | grouped | concat | attention | all"""
+usage: python tools/op_fuzz.py [n_cases] [seed] [kind]      kind: convmisc | convt | gemm | gridsample | eltwise | reduce | resize | shape | svtr_block | dbhead | fpn | pool | dsblock | dschain | conv1x1 | conv3x3 | convk | grouped | concat | attention | all"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -435,7 +435,96 @@ def case_shape():
     return f"shape {which} c{c} {n}x{h}x{w}", g.model(), (n, 8, h, w)
 
 
-KINDS = {"eltwise": case_eltwise, "reduce": case_reduce, "resize": case_resize, "shape": case_shape, "svtr_block": case_svtr_block, "dbhead": case_dbhead, "fpn": case_fpn, "pool": case_pool, "dsblock": case_dsblock, "dschain": case_dschain, "conv1x1": case_conv1x1, "conv3x3": case_conv3x3, "convk": case_convk, "grouped": case_grouped, "concat": case_concat, "attention": case_attention}
+def case_convmisc():
+    """convolutions off the beaten path: rectangular kernels, dilation, asymmetric padding, mixed strides, group counts between 1 and Cin"""
+    cin = int(rng.choice([4, 8, 16, 24, 32, 64]))
+    groups = int(rng.choice([g_ for g_ in (1, 1, 2, 4, cin) if cin % g_ == 0]))
+    cout = groups * int(rng.choice([1, 2, 3, 5, 8])) if groups == cin else groups * int(rng.choice([2, 4, 6, 12]))
+    kh, kw = int(rng.choice([1, 2, 3, 5, 7])), int(rng.choice([1, 2, 3, 5, 7]))
+    sh, sw = int(rng.choice([1, 1, 2])), int(rng.choice([1, 1, 2]))
+    dh, dw = int(rng.choice([1, 1, 2])), int(rng.choice([1, 1, 2]))
+    pads = [int(rng.integers(0, kh)), int(rng.integers(0, kw)), int(rng.integers(0, kh)), int(rng.integers(0, kw))]
+    n, h, w = int(rng.integers(1, 4)), int(rng.integers(dh * (kh - 1) + 1, 60)), int(rng.integers(dw * (kw - 1) + 1, 80))
+    a = str(rng.choice(["none", "relu", "hswish"]))
+    g = GraphBuilder("f")
+    g.add_input("x", ["N", 8, "H", "W"])
+    t = stem(g, cin)
+    wt = (rng.standard_normal((cout, cin // groups, kh, kw)) * np.sqrt(1.0 / (kh * kw * cin // groups))).astype(np.float32)
+    y = g.op("Conv", [t, g.init(wt), g.init((0.2 * rng.standard_normal(cout)).astype(np.float32))], kernel_shape=[kh, kw], strides=[sh, sw], pads=pads, group=groups, dilations=[dh, dw])
+    y = act(g, y, a)
+    g.add_output(y, ["N", cout, "H2", "W2"])
+    return f"conv {kh}x{kw}/{sh}x{sw} d{dh}x{dw} pads {pads} g{groups} {cin}->{cout} {n}x{h}x{w} {a}", g.model(), (n, 8, h, w)
+
+
+def case_convt():
+    cin = int(rng.choice([4, 8, 16, 32]))
+    groups = int(rng.choice([1, 1, 2]))
+    cout = groups * int(rng.choice([1, 2, 4, 8]))
+    k, st = int(rng.choice([2, 3, 4])), int(rng.choice([1, 2, 2]))
+    p = int(rng.integers(0, (k + 1) // 2))
+    op_ = int(rng.integers(0, st))
+    n, h, w = int(rng.integers(1, 4)), int(rng.integers(2, 40)), int(rng.integers(2, 50))
+    g = GraphBuilder("f")
+    g.add_input("x", ["N", 8, "H", "W"])
+    wt = (rng.standard_normal((cin, cout // groups, k, k)) * np.sqrt(1.0 / cin)).astype(np.float32)
+    y = g.op("ConvTranspose", [stem(g, cin), g.init(wt), g.init((0.1 * rng.standard_normal(cout)).astype(np.float32))], kernel_shape=[k, k], strides=[st, st], pads=[p] * 4,
+             output_padding=[op_, op_], group=groups, dilations=[1, 1])
+    y = g.op("Relu", [y])
+    g.add_output(y, ["N", cout, "H2", "W2"])
+    return f"convT k{k} s{st} p{p} op{op_} g{groups} {cin}->{cout} {n}x{h}x{w}", g.model(), (n, 8, h, w)
+
+
+def case_gemm():
+    which = str(rng.choice(["gemm", "matmul3", "bmm", "classifier"]))
+    g = GraphBuilder("f")
+    if which == "classifier":   # PP-LCNet tail: GAP -> 1x1 conv + hard-swish -> Flatten -> Gemm -> Softmax
+        c, hid, ncls = int(rng.choice([16, 64, 160])), int(rng.choice([32, 128, 320])), int(rng.choice([2, 4, 10]))
+        n, h, w = int(rng.integers(1, 9)), int(rng.integers(1, 30)), int(rng.integers(1, 40))
+        g.add_input("x", ["N", 8, "H", "W"])
+        t = g.op("HardSwish", [conv(g, g.op("GlobalAveragePool", [stem(g, c)]), c, hid, 1)])
+        f = g.op("Flatten", [t], axis=1)
+        wq = (rng.standard_normal((ncls, hid)) / np.sqrt(hid)).astype(np.float32)
+        y = g.op("Softmax", [g.op("Gemm", [f, g.init(wq), g.init((0.1 * rng.standard_normal(ncls)).astype(np.float32))], transB=1)], axis=1)
+        g.add_output(y, ["N", ncls])
+        return f"classifier {c}->{hid}->{ncls} {n}x{h}x{w}", g.model(), (n, 8, h, w)
+    K, M = int(rng.choice([7, 24, 64, 120, 256, 384])), int(rng.choice([5, 16, 37, 96, 257]))
+    n, T = int(rng.integers(1, 6)), int(rng.integers(1, 90))
+    g.add_input("x", ["N", "T", K])
+    if which == "gemm":
+        f = g.op("Reshape", ["x", g.init(np.array([-1, K], np.int64), "shape")])
+        tb = int(rng.random() < 0.5)
+        wq = (rng.standard_normal((M, K) if tb else (K, M)) / np.sqrt(K)).astype(np.float32)
+        al, be = float(rng.choice([1.0, 0.5])), float(rng.choice([1.0, 0.0, 2.0]))
+        y = g.op("Gemm", [f, g.init(wq), g.init((0.1 * rng.standard_normal(M)).astype(np.float32))], transB=tb, alpha=al, beta=be)
+        g.add_output(y, ["R", M])
+        return f"Gemm K{K} M{M} transB {tb} alpha {al} beta {be} rows {n * T}", g.model(), (n, T, K)
+    if which == "matmul3":
+        y = act(g, _linear(g, "x", K, M, bias=bool(rng.random() < 0.7)), str(rng.choice(["none", "relu", "gelu", "hswish"])))
+        g.add_output(y, ["N", "T", M])
+        return f"MatMul [N,T,{K}] x [{K},{M}] {n}x{T}", g.model(), (n, T, K)
+    a = _linear(g, "x", K, M)                                        # [N, T, M]
+    b = g.op("Transpose", [_linear(g, "x", K, M)], perm=[0, 2, 1])   # [N, M, T]
+    y = g.op("MatMul", [a, b])                                       # [N, T, T]
+    z = g.op("MatMul", [g.op("Softmax", [y], axis=-1), a])           # [N, T, M]
+    g.add_output(z, ["N", "T", M])
+    return f"batched MatMul T{T} M{M} K{K} n{n}", g.model(), (n, T, K)
+
+
+def case_gridsample():
+    c = int(rng.choice([3, 8, 16]))
+    n, h, w = int(rng.integers(1, 4)), int(rng.integers(2, 40)), int(rng.integers(2, 50))
+    mode, padm, ac = str(rng.choice(["bilinear", "nearest"])), str(rng.choice(["zeros", "border"])), int(rng.random() < 0.5)
+    g = GraphBuilder("f")
+    g.add_input("x", ["N", 8, "H", "W"])
+    t = stem(g, c)
+    gr = g.op("Mul", [g.op("Tanh", [conv(g, "x", 8, 2, 3)]), g.init(np.array(1.2, np.float32), "c")])   # [N, 2, H, W] in (-1.2, 1.2): some samples fall outside
+    gr = g.op("Transpose", [gr], perm=[0, 2, 3, 1])
+    y = g.op("GridSample", [t, gr], mode=mode, padding_mode=padm, align_corners=ac)
+    g.add_output(y, ["N", c, "H", "W"])
+    return f"GridSample {mode} {padm} align {ac} c{c} {n}x{h}x{w}", g.model(), (n, 8, h, w)
+
+
+KINDS = {"convmisc": case_convmisc, "convt": case_convt, "gemm": case_gemm, "gridsample": case_gridsample, "eltwise": case_eltwise, "reduce": case_reduce, "resize": case_resize, "shape": case_shape, "svtr_block": case_svtr_block, "dbhead": case_dbhead, "fpn": case_fpn, "pool": case_pool, "dsblock": case_dsblock, "dschain": case_dschain, "conv1x1": case_conv1x1, "conv3x3": case_conv3x3, "convk": case_convk, "grouped": case_grouped, "concat": case_concat, "attention": case_attention}
 names = list(KINDS) if only == "all" else [only]
 bad = 0
 worst = {}
@@ -473,6 +562,8 @@ for i in range(n_cases):
     for c in classes:
         seen[c] = seen.get(c, 0) + 1
     worst[kind] = max(worst.get(kind, 0.0), err if err == err else 1.0)
+    if os.environ.get("OP_FUZZ_VERBOSE") == "1":
+        print(f"{'ok  ' if ok else 'BAD '} case {i} [{label}] err {err:.2e} {classes}", flush=True)
     if not ok:
         bad += 1
         print(f"FAIL case {i} [{label}] err {err:.3e} classes {classes}", flush=True)
