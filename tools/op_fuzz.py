@@ -2,7 +2,7 @@
 eligibility boundary of the bf16x6 kernels (weight-stationary one- and two-fragment tiles, output-stationary, row-streaming 3x3, LDS-tiled large kernel,
 grouped, multi-source concat reads, streaming attention), random epilogues (bias, ReLU / hard-swish / GELU / none, residual).  Reports, per case, the kernel
 classes that ran and the largest |difference| relative to the output scale; the tolerance is the engine tests' 2e-4.
-usage: python tools/op_fuzz.py [n_cases] [seed] [kind]      kind: convmisc | convt | gemm | gridsample | eltwise | reduce | resize | shape | svtr_block | dbhead | fpn | pool | dsblock | dschain | conv1x1 | conv3x3 | convk | grouped | concat | attention | all"""
+usage: python tools/op_fuzz.py [n_cases] [seed] [kind]      kind: neck | net | convmisc | convt | gemm | gridsample | eltwise | reduce | resize | shape | svtr_block | dbhead | fpn | pool | dsblock | dschain | conv1x1 | conv3x3 | convk | grouped | concat | attention | all"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -37,8 +37,12 @@ def conv(g, x, cin, cout, k, stride=1, groups=1, bias=True, pad=None):
     return g.op("Conv", ins, kernel_shape=[k, k], strides=[stride, stride], pads=[pad] * 4, group=groups, dilations=[1, 1])
 
 
+g_last_c = [0]
+
+
 def stem(g, c):
     """a channels-last producer in front of the layer under test (graph inputs are NCHW)"""
+    g_last_c[0] = c
     return g.op("Relu", [conv(g, "x", 8, c, 1, bias=False)])
 
 
@@ -524,7 +528,131 @@ def case_gridsample():
     return f"GridSample {mode} {padm} align {ac} c{c} {n}x{h}x{w}", g.model(), (n, 8, h, w)
 
 
-KINDS = {"convmisc": case_convmisc, "convt": case_convt, "gemm": case_gemm, "gridsample": case_gridsample, "eltwise": case_eltwise, "reduce": case_reduce, "resize": case_resize, "shape": case_shape, "svtr_block": case_svtr_block, "dbhead": case_dbhead, "fpn": case_fpn, "pool": case_pool, "dsblock": case_dsblock, "dschain": case_dschain, "conv1x1": case_conv1x1, "conv3x3": case_conv3x3, "convk": case_convk, "grouped": case_grouped, "concat": case_concat, "attention": case_attention}
+def case_net():
+    """a random small network: a DAG of 8 - 20 operators over tensors of several resolutions -- separable / dense / strided convolutions, squeeze-excite, residual sums,
+    nearest x2 + sum (FPN), concatenations of several levels, pooling, transposed convolution -- with two or three graph outputs taken anywhere.  What it is after is the
+    planner: arena reuse across branches, deferred Resize / Concat / ConvTranspose operands meeting consumers that cannot absorb them, channels-last <-> native moves."""
+    n = int(rng.integers(1, 4))
+    lv0 = int(rng.integers(2, 4))                         # the input is 2^lv0 x the coarsest grid
+    big = 6 if os.environ.get("OP_FUZZ_BIG") == "1" else 1     # OP_FUZZ_BIG=1: maps large enough for the weight-stationary / bf16x6 kernels and the deferred concat reads
+    gh, gw = big * int(rng.integers(1, 6)), big * int(rng.integers(1, 8))
+    h, w = gh << lv0, gw << lv0
+    g = GraphBuilder("f")
+    g.add_input("x", ["N", 8, "H", "W"])
+    pool = [("x", 8, 0)]                                   # (name, channels, level: resolution = input >> level)
+    t = stem(g, int(rng.choice([16, 24, 32])))
+    pool.append((t, int(g_last_c[0]), 0))
+    desc = []
+    for _ in range(int(rng.integers(8, 21))):
+        name, c, lv = pool[int(rng.integers(1, len(pool)))]
+        op = str(rng.choice(["ds", "ds", "c3", "c1", "down", "se", "res", "up_add", "cat", "pool", "convt", "gap_mul"]))
+        if op == "ds":
+            co = int(rng.choice([c, 2 * c if c <= 96 else c, 24, 48]))
+            y = _ds(g, name, c, co, int(rng.choice([3, 5])), (1, 1), "hswish", bool(rng.random() < 0.3)); pool.append((y, co, lv))
+        elif op == "c3":
+            co = int(rng.choice([16, 32, 64]))
+            y = act(g, conv(g, name, c, co, 3), str(rng.choice(["relu", "hswish", "none"]))); pool.append((y, co, lv))
+        elif op == "c1":
+            co = int(rng.choice([8, 24, 96, 128]))
+            y = act(g, conv(g, name, c, co, 1), str(rng.choice(["relu", "none", "gelu"]))); pool.append((y, co, lv))
+        elif op == "down" and lv < lv0:
+            co = int(rng.choice([c, 2 * c if c <= 64 else c]))
+            y = g.op("Relu", [conv(g, name, c, co, 3, stride=2)]); pool.append((y, co, lv + 1))
+        elif op == "se":
+            p = g.op("GlobalAveragePool", [name])
+            f = g.op("HardSigmoid", [conv(g, g.op("Relu", [conv(g, p, c, max(4, c // 4), 1)]), max(4, c // 4), c, 1)], alpha=1.0 / 6.0, beta=0.5)
+            pool.append((g.op("Mul", [name, f]), c, lv))
+        elif op == "res":
+            same = [q for q in pool[1:] if q[1] == c and q[2] == lv and q[0] != name]
+            if same:
+                pool.append((g.op("Add", [name, same[int(rng.integers(0, len(same)))][0]]), c, lv))
+        elif op == "up_add" and lv > 0:
+            finer = [q for q in pool[1:] if q[2] == lv - 1]
+            if finer:
+                fq = finer[int(rng.integers(0, len(finer)))]
+                up = g.op("Resize", [name, "", g.init(np.array([1, 1, 2, 2], np.float32), "scales")], mode="nearest", nearest_mode="floor", coordinate_transformation_mode="asymmetric")
+                lat = conv(g, fq[0], fq[1], c, 1, bias=False)
+                pool.append((g.op("Add", [lat, up]) if rng.random() < 0.7 else g.op("Add", [up, lat]), c, lv - 1))
+        elif op == "cat":
+            parts = []
+            for q in pool[1:]:
+                if q[2] >= lv and len(parts) < 4 and rng.random() < 0.5:
+                    pq = q[0]
+                    if q[2] > lv:
+                        f = 1 << (q[2] - lv)
+                        pq = g.op("Resize", [pq, "", g.init(np.array([1, 1, f, f], np.float32), "scales")], mode="nearest", nearest_mode="floor", coordinate_transformation_mode="asymmetric")
+                    parts.append((pq, q[1]))
+            if len(parts) >= 2:
+                pool.append((g.op("Concat", [p_[0] for p_ in parts], axis=1), sum(p_[1] for p_ in parts), lv))
+        elif op == "pool" and lv < lv0:
+            kind = str(rng.choice(["AveragePool", "MaxPool"]))
+            pool.append((g.op(kind, [name], kernel_shape=[2, 2], strides=[2, 2], pads=[0, 0, 0, 0]), c, lv + 1))
+        elif op == "convt" and lv > 0 and c % 4 == 0:
+            co = int(rng.choice([8, 16, c]))
+            wt = (rng.standard_normal((c, co, 2, 2)) * np.sqrt(1.0 / c)).astype(np.float32)
+            y = g.op("Relu", [g.op("ConvTranspose", [name, g.init(wt), g.init((0.1 * rng.standard_normal(co)).astype(np.float32))], kernel_shape=[2, 2], strides=[2, 2], pads=[0, 0, 0, 0], group=1, dilations=[1, 1])])
+            pool.append((y, co, lv - 1))
+        elif op == "gap_mul":
+            pool.append((g.op("Mul", [name, g.op("Sigmoid", [g.op("GlobalAveragePool", [name])])]), c, lv))
+        else:
+            continue
+        desc.append(op)
+    outs = {len(pool) - 1}
+    for _ in range(int(rng.integers(1, 3))):
+        outs.add(int(rng.integers(1, len(pool))))
+    for i in sorted(outs):
+        g.add_output(pool[i][0], ["N", pool[i][1], "Ho", "Wo"])
+    return f"net {n}x{h}x{w} {' '.join(desc)} outs {sorted(outs)}", g.model(), (n, 8, h, w)
+
+
+def _swish(g, y):
+    return g.op("Mul", [y, g.op("Sigmoid", [y])])
+
+
+def _conv1k(g, x, cin, cout, k):
+    w = (rng.standard_normal((cout, cin, 1, k)) * np.sqrt(1.0 / (k * cin))).astype(np.float32)
+    return g.op("Conv", [x, g.init(w), g.init((0.1 * rng.standard_normal(cout)).astype(np.float32))], kernel_shape=[1, k], strides=[1, 1], pads=[0, k // 2, 0, k // 2], group=1, dilations=[1, 1])
+
+
+def case_neck():
+    """the recognizer's sample-local tail (EncoderWithSVTR) at random widths: [6, 2] pool -> 1x3 conv -> 1x1 -> tokens -> 1..3 pre-LN blocks -> LN -> 1x1 -> concat with the
+    pooled map -> 1x3 -> 1x1 -> tokens -> CTC Linear (+ Softmax): the operator run the engine fuses into one chain launch per batch (LDS placement, split-K, attention tiles)"""
+    c = int(rng.choice([64, 96, 128, 192, 256, 320, 512]))
+    heads = int(rng.choice([1, 2, 4, 8]))
+    hd = int(rng.choice([8, 15, 16, 32]))
+    dim = heads * hd
+    outc = int(rng.choice([32, 64, 96, 120]))
+    vocab = int(rng.choice([37, 97, 500, 6625]))
+    n, T = int(rng.integers(1, 70)), int(rng.choice([int(rng.integers(1, 41)), int(rng.integers(41, 81)), int(rng.integers(81, 200))]))
+    if n * T > 4000:
+        n = max(1, 4000 // T)
+    hrows = int(rng.choice([1, 2, 6]))
+    g = GraphBuilder("f")
+    g.add_input("x", ["N", 8, "H", "W"])
+    t = stem(g, c)
+    x = g.op("AveragePool", [t], kernel_shape=[hrows, 2], strides=[hrows, 2], pads=[0, 0, 0, 0]) if hrows > 1 or rng.random() < 0.5 else t
+    pooled_w = 2 if x != t else 1
+    hmap = x
+    z = _swish(g, _conv1k(g, x, c, max(8, c // 8), 3))
+    z = _swish(g, conv(g, z, max(8, c // 8), dim, 1))
+    z = g.op("Transpose", [g.op("Squeeze", [z, g.init(np.array([2], np.int64), "axes")])], perm=[0, 2, 1])
+    for _ in range(int(rng.integers(1, 4))):
+        z = g.op("Add", [z, _mha(g, _ln(g, z, dim), dim, heads)])
+        y = _linear(g, _swish(g, _linear(g, _ln(g, z, dim), dim, 2 * dim)), 2 * dim, dim)
+        z = g.op("Add", [z, y])
+    z = _ln(g, z, dim)
+    z = g.op("Unsqueeze", [g.op("Transpose", [z], perm=[0, 2, 1]), g.init(np.array([2], np.int64), "axes")])
+    z = _swish(g, conv(g, z, dim, c, 1))
+    z = g.op("Concat", [hmap, z], axis=1)
+    z = _swish(g, _conv1k(g, z, 2 * c, max(8, c // 8), 3))
+    z = _swish(g, conv(g, z, max(8, c // 8), outc, 1))
+    z = g.op("Transpose", [g.op("Squeeze", [z, g.init(np.array([2], np.int64), "axes")])], perm=[0, 2, 1])
+    y = g.op("Softmax", [_linear(g, z, outc, vocab)], axis=2)
+    g.add_output(y, ["N", "T", vocab])
+    return f"neck c{c} {heads}x{hd} out{outc} V{vocab} pool[{hrows},{pooled_w}] {n}x{T}", g.model(), (n, 8, hrows, T * pooled_w)
+
+
+KINDS = {"neck": case_neck, "net": case_net, "convmisc": case_convmisc, "convt": case_convt, "gemm": case_gemm, "gridsample": case_gridsample, "eltwise": case_eltwise, "reduce": case_reduce, "resize": case_resize, "shape": case_shape, "svtr_block": case_svtr_block, "dbhead": case_dbhead, "fpn": case_fpn, "pool": case_pool, "dsblock": case_dsblock, "dschain": case_dschain, "conv1x1": case_conv1x1, "conv3x3": case_conv3x3, "convk": case_convk, "grouped": case_grouped, "concat": case_concat, "attention": case_attention}
 names = list(KINDS) if only == "all" else [only]
 bad = 0
 worst = {}
