@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgemmP p) {  // 2 wa
         } else {
             // k -> (tap_h, tap_w, ci) with multiply-high divisions (exact for k < 2^16, checked at launch): no
             // loop-carried state and no branches between the MFMAs
-            const int tap = igemm_div(k, p.cin_magic, p.Cin), ci = k - tap * p.Cin;
-            const int tap_h = igemm_div(tap, p.kw_magic, p.kw), tap_w = tap - tap_h * p.kw;
+            const int tap = (int)__umulhi((unsigned)k, p.cin_magic), ci = k - tap * p.Cin;   // (Cin >= 4 on these kernels: the magic number exists)
+            const int tap_h = igemm_tap_h(p, tap), tap_w = tap - tap_h * p.kw;
             const int ih = ih0[pf] + tap_h * p.dh, iw = iw0[pf] + tap_w * p.dw;
             const bool ok = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
             const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_small_kernel(IgemmP p) {
             if (SE) gs[d] = *reinterpret_cast<const float4*>(se_row + k);
             ok[d] = true;
         } else {
-            const int tap = igemm_div(k, p.cin_magic, p.Cin), ci = k - tap * p.Cin;
-            const int tap_h = igemm_div(tap, p.kw_magic, p.kw), tap_w = tap - tap_h * p.kw;
+            const int tap = (int)__umulhi((unsigned)k, p.cin_magic), ci = k - tap * p.Cin;   // (Cin >= 4 on these kernels: the magic number exists)
+            const int tap_h = igemm_tap_h(p, tap), tap_w = tap - tap_h * p.kw;
             const int ih = ih0 + tap_h * p.dh, iw = iw0 + tap_w * p.dw;
             ok[d] = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
             const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
@@ -337,7 +337,8 @@ void conv_igemm(hipStream_t s, const ConvP& c) {
     p.ny = (int)ny;
     OAR_CHECK(p.K < 65536, OAR_UNSUPPORTED_OP, "conv_igemm: K = kh*kw*Cin must be < 65536");
     p.cin_magic = (unsigned)((1ull << 32) / (unsigned)c.Cin + 1);
-    p.kw_magic = (unsigned)((1ull << 32) / (unsigned)c.kw + 1);
+    p.kw_magic = (unsigned)((1ull << 32) / (unsigned)c.kw + 1);   // (kw == 1: wraps to 1, umulhi(tap, 1) == 0, and kw_one adds the tap itself)
+    p.kw_one = c.kw == 1 ? 1u : 0u;
     p.mx_per_xcd = (mx + 7) / 8;
     dim3 grid((unsigned)(p.mx_per_xcd * 8 * ny));
     // weight-stationary variant (see conv_igemm_ws_kernel): OAR_IGEMM_WS = 0 off, 1 wherever it fits, default: N >= ws_min_n

@@ -43,6 +43,7 @@ struct IgemmP {
     int act, convt;
     int ny;              // number of cout tiles (for the XCD-aware tile order)
     unsigned cin_magic, kw_magic;   // floor(2^32 / d) + 1: q = umulhi(n, magic) == n / d for n < 2^16
+    unsigned kw_one;                // kw == 1 (see igemm_tap_h)
     long mx_per_xcd;     // pixel tiles per XCD band
     float alpha, beta;
     float* ctc_part;     // != null (weight-stationary f32 kernel only): no logits are stored; per (row, cout tile) the
@@ -58,9 +59,10 @@ struct IgemmP {
                          // whose x points at the group's first channel).  Every other kernel reads x with stride Cin
 };
 
-// n / d through the host's magic number floor(2^32 / d) + 1 (exact for n < 2^16).  d == 1 has no 32-bit magic (2^32 + 1 wraps to 1, and umulhi would return 0):
-// a k x 1 kernel (kw == 1) decoded every tap as row 0 until round 6 (tools/op_fuzz.py, "conv 7x1 ... g1": err ~1) -- the divisor 1 is answered directly.
-__device__ __forceinline__ int igemm_div(int n, unsigned magic, int d) { return d == 1 ? n : (int)__umulhi((unsigned)n, magic); }
+// tap / kw through the host's magic number floor(2^32 / kw) + 1 (exact for tap < 2^16).  kw == 1 has no 32-bit magic (2^32 + 1 wraps to 1, umulhi returns 0): a k x 1
+// kernel decoded every tap as row 0 until round 6 (tools/op_fuzz.py, "conv 7x1 ... g1": err ~1).  IgemmP::kw_one is 1 for kw == 1 (the quotient is then 0 + tap), else 0 --
+// one multiply-add, no select (a select cost the two-fragment per-tile kernel a wave of occupancy: 98 registers).
+__device__ __forceinline__ int igemm_tap_h(const IgemmP& p, int tap) { return (int)(__umulhi((unsigned)tap, p.kw_magic) + (unsigned)tap * p.kw_one); }
 
 // element offset of the residual for output pixel `opix`, channel co: the same pixel, or -- res_up > 1 -- pixel (h / f, w / f) of the
 // [N][Ho / f][Wo / f][Cout] low-resolution tensor (M < 2^31 checked by the host: 32-bit divisions)

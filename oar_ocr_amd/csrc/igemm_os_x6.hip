@@ -116,8 +116,8 @@ __global__ __launch_bounds__(kOsThreads, 2) void conv_igemm_os_x6_kernel(IgemmOs
                 st.okmask |= 1u << pf;
             }
             else {
-                const int tap = igemm_div(k, p.cin_magic, p.Cin), ci = k - tap * p.Cin;
-                const int tap_h = igemm_div(tap, p.kw_magic, p.kw), tap_w = tap - tap_h * p.kw;
+                const int tap = (int)__umulhi((unsigned)k, p.cin_magic), ci = k - tap * p.Cin;   // (Cin >= 4 on these kernels: the magic number exists)
+                const int tap_h = igemm_tap_h(p, tap), tap_w = tap - tap_h * p.kw;
                 const int ih = ih0[pf] + tap_h * p.dh, iw = iw0[pf] + tap_w * p.dw;
                 const bool ok = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
                 const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
