@@ -192,11 +192,14 @@ def _resize(x, node, env):
         nm = a.get("nearest_mode", "round_prefer_floor")
 
         def idx(o, s, n_in):
-            o = np.arange(o, dtype=np.float64)
+            # float32 coordinate arithmetic, as ONNX Runtime's (and the engine's): with sizes 21 -> 3 the scale 3 / 21 rounds UP in f32 and 1 / scale lands just below 7 --
+            # the floor is 6 there and 7 in float64 (tools/op_fuzz.py, round 6: a knife edge of non-integer nearest reductions; PP-OCR graphs only enlarge by integers)
+            o = np.arange(o, dtype=np.float32)
+            s = np.float32(s)
             if ctm == "asymmetric":
                 x_ = o / s
             elif ctm in ("half_pixel", "pytorch_half_pixel"):
-                x_ = (o + 0.5) / s - 0.5
+                x_ = (o + np.float32(0.5)) / s - np.float32(0.5)
             else:
                 raise NotImplementedError(ctm)
             if nm == "floor":

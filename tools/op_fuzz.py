@@ -2,7 +2,7 @@
 eligibility boundary of the bf16x6 kernels (weight-stationary one- and two-fragment tiles, output-stationary, row-streaming 3x3, LDS-tiled large kernel,
 grouped, multi-source concat reads, streaming attention), random epilogues (bias, ReLU / hard-swish / GELU / none, residual).  Reports, per case, the kernel
 classes that ran and the largest |difference| relative to the output scale; the tolerance is the engine tests' 2e-4.
-usage: python tools/op_fuzz.py [n_cases] [seed] [kind]      kind: neck | net | convmisc | convt | gemm | gridsample | eltwise | reduce | resize | shape | svtr_block | dbhead | fpn | pool | dsblock | dschain | conv1x1 | conv3x3 | convk | grouped | concat | attention | all"""
+usage: python tools/op_fuzz.py [n_cases] [seed] [kind]      kind: p2o | neck | net | convmisc | convt | gemm | gridsample | eltwise | reduce | resize | shape | svtr_block | dbhead | fpn | pool | dsblock | dschain | conv1x1 | conv3x3 | convk | grouped | concat | attention | all"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -652,7 +652,71 @@ def case_neck():
     return f"neck c{c} {heads}x{hd} out{outc} V{vocab} pool[{hrows},{pooled_w}] {n}x{T}", g.model(), (n, 8, hrows, T * pooled_w)
 
 
-KINDS = {"neck": case_neck, "net": case_net, "convmisc": case_convmisc, "convt": case_convt, "gemm": case_gemm, "gridsample": case_gridsample, "eltwise": case_eltwise, "reduce": case_reduce, "resize": case_resize, "shape": case_shape, "svtr_block": case_svtr_block, "dbhead": case_dbhead, "fpn": case_fpn, "pool": case_pool, "dsblock": case_dsblock, "dschain": case_dschain, "conv1x1": case_conv1x1, "conv3x3": case_conv3x3, "convk": case_convk, "grouped": case_grouped, "concat": case_concat, "attention": case_attention}
+def case_p2o():
+    """shape arithmetic as the Paddle / PyTorch exporters write it: Shape -> Slice / Gather -> Concat -> Reshape / Resize(sizes) / Expand, activations and normalisations that do
+    not fold (Clip, PRelu, LeakyRelu, BatchNormalization behind an Add), ArgMax tails"""
+    c = int(rng.choice([8, 16, 24, 48]))
+    n, h, w = int(rng.integers(1, 4)), int(rng.integers(2, 24)), int(rng.integers(2, 40))
+    which = str(rng.choice(["tokens", "resize_to_ref", "flatten_math", "expand_pos", "acts", "bn_after_add", "argmax"]))
+    i64 = np.int64
+    g = GraphBuilder("f")
+    g.add_input("x", ["N", 8, "H", "W"])
+    t = stem(g, c)
+    ci = lambda v: g.init(np.array(v, i64), "i")
+    if which == "tokens":      # [N, C, H, W] -> [N, H*W, C] with the batch read from Shape
+        shp = g.op("Shape", [t])
+        nb = g.op("Slice", [shp, ci([0]), ci([1]), ci([0])])
+        tgt = g.op("Concat", [nb, ci([c]), ci([-1])], axis=0)
+        y = g.op("Transpose", [g.op("Reshape", [t, tgt])], perm=[0, 2, 1])
+        y = _ln(g, y, c)
+        g.add_output(y, ["N", "T", c])
+    elif which == "resize_to_ref":   # coarse map resized to the spatial size of a finer one, sizes = Concat(Shape(coarse)[:2], Shape(ref)[2:])
+        coarse = g.op("Relu", [conv(g, t, c, c, 3, stride=2)])
+        sizes = g.op("Concat", [g.op("Slice", [g.op("Shape", [coarse]), ci([0]), ci([2]), ci([0])]), g.op("Slice", [g.op("Shape", [t]), ci([2]), ci([4]), ci([0])])], axis=0)
+        mode = str(rng.choice(["nearest", "linear"]))
+        attrs = dict(mode=mode, coordinate_transformation_mode="asymmetric" if mode == "nearest" else "half_pixel")
+        if mode == "nearest":
+            attrs["nearest_mode"] = "floor"
+        up = g.op("Resize", [coarse, "", "", sizes], **attrs)
+        y = g.op("Add", [up, t])
+        g.add_output(y, ["N", c, "H", "W"])
+    elif which == "flatten_math":    # [N, C, H, W] -> [N, C*H*W] through Gather + Mul on shape scalars, then a Linear on a fixed-size map
+        hh, ww = 3, 5
+        p = g.op("Resize", [t, "", "", ci([n, c, hh, ww])], mode="nearest", coordinate_transformation_mode="asymmetric", nearest_mode="floor")
+        shp = g.op("Shape", [p])
+        d1 = g.op("Gather", [shp, ci(1)], axis=0)
+        d2 = g.op("Gather", [shp, ci(2)], axis=0)
+        d3 = g.op("Gather", [shp, ci(3)], axis=0)
+        tot = g.op("Unsqueeze", [g.op("Mul", [g.op("Mul", [d1, d2]), d3]), ci([0])])
+        y = g.op("Reshape", [p, g.op("Concat", [ci([-1]), tot], axis=0)])
+        y = _linear(g, y, c * hh * ww, 10)
+        g.add_output(y, ["N", 10])
+    elif which == "expand_pos":      # a learned [1, C, 1, W0] embedding resized to W, expanded over the batch and the rows, added
+        pos = g.init((0.3 * rng.standard_normal((1, c, 1, 1))).astype(np.float32))
+        shp = g.op("Shape", [t])
+        y = g.op("Add", [t, g.op("Expand", [pos, shp])])
+        y = g.op("Mul", [y, g.op("Tile", [g.init((1.0 + 0.1 * rng.standard_normal((1, c, 1, 1))).astype(np.float32)), ci([1, 1, 1, 1])])])
+        g.add_output(y, ["N", c, "H", "W"])
+    elif which == "acts":
+        y = g.op("Clip", [conv(g, t, c, c, 3), g.init(np.array(-0.5, np.float32), "c"), g.init(np.array(1.5, np.float32), "c")])
+        y = g.op("PRelu", [conv(g, y, c, c, 1), g.init((0.25 + 0.05 * rng.standard_normal((c, 1, 1))).astype(np.float32))])
+        y = g.op("LeakyRelu", [conv(g, y, c, 16, 3)], alpha=0.1)
+        y = g.op("Tanh", [y])
+        g.add_output(y, ["N", 16, "H", "W"])
+    elif which == "bn_after_add":
+        y = g.op("Add", [conv(g, t, c, c, 3), t])
+        y = g.op("BatchNormalization", [y, g.init((1.0 + 0.1 * rng.standard_normal(c)).astype(np.float32)), g.init((0.1 * rng.standard_normal(c)).astype(np.float32)),
+                                        g.init((0.1 * rng.standard_normal(c)).astype(np.float32)), g.init((1.0 + 0.2 * rng.random(c)).astype(np.float32))], epsilon=1e-5)
+        y = g.op("Relu", [y])
+        g.add_output(y, ["N", c, "H", "W"])
+    else:                              # class map: ArgMax over channels is not the last axis of an NCHW tensor -> Transpose first, as exporters do
+        y = g.op("Transpose", [conv(g, t, c, 5, 1)], perm=[0, 2, 3, 1])
+        y = g.op("Softmax", [y], axis=3)
+        g.add_output(y, ["N", "H", "W", 5])
+    return f"p2o {which} c{c} {n}x{h}x{w}", g.model(), (n, 8, h, w)
+
+
+KINDS = {"p2o": case_p2o, "neck": case_neck, "net": case_net, "convmisc": case_convmisc, "convt": case_convt, "gemm": case_gemm, "gridsample": case_gridsample, "eltwise": case_eltwise, "reduce": case_reduce, "resize": case_resize, "shape": case_shape, "svtr_block": case_svtr_block, "dbhead": case_dbhead, "fpn": case_fpn, "pool": case_pool, "dsblock": case_dsblock, "dschain": case_dschain, "conv1x1": case_conv1x1, "conv3x3": case_conv3x3, "convk": case_convk, "grouped": case_grouped, "concat": case_concat, "attention": case_attention}
 names = list(KINDS) if only == "all" else [only]
 bad = 0
 worst = {}
