@@ -174,6 +174,8 @@ class OracleOCR:
     def predict(self, images):
         """With optional stages attached: slots carry boxes mapped back to the input page unless it was rectified
         (ocr.rs:644-646, 898-925); page_meta[i] = (orientation_angle | None, rectified)."""
+        if len(images) == 0:   # ocr.rs:525-532: validation error "images must be a non-empty slice" (round 6: tools/edge_pages.py found the oracle laxer than the reference)
+            raise ValueError("OCR Pipeline: images must be a non-empty slice")
         pre = [self.preprocess(im) for im in images]
         self.page_meta = [(p[1], p[3]) for p in pre]
         res = self._predict_core([p[0] for p in pre])
