@@ -17,6 +17,8 @@ rng = np.random.default_rng(seed)
 TOL = 2e-4
 import os
 DRY = os.environ.get("OP_FUZZ_DRY") == "1"
+RESHAPE = os.environ.get("OP_FUZZ_RESHAPE") == "1"   # run every case on two input shapes through ONE engine (A, B, A again)
+RESHAPE_KINDS = {"conv1x1", "conv3x3", "convk", "grouped", "concat", "dsblock", "dschain", "net", "attention", "svtr_block", "neck", "convmisc", "eltwise", "dbhead"}
 
 
 def act(g, y, kind):
@@ -732,6 +734,20 @@ for i in range(n_cases):
         continue
     try:
         eng = api.OrtInfer(model, profile=True)
+        if RESHAPE and kind in RESHAPE_KINDS:
+            # the same engine on a second input shape, then the first again: plans, constants laid out per shape and arena offsets must not leak from one shape to the other
+            shape2 = (shape[0] + 1, 8, shape[2], 2 * shape[3]) if len(shape) == 4 else (shape[0] + 1, 2 * shape[1], shape[2])
+            x2 = rng.standard_normal(shape2).astype(np.float32)
+            first = eng.infer(x)
+            got2 = eng.infer(x2)
+            ref2 = onnx_ref.run(model, {eng.input_name(): x2})
+            for (_, a), r in zip(got2, ref2):
+                assert a.shape == r.shape, (a.shape, r.shape)
+                e2 = float(np.abs(a - r).max()) / max(1.0, float(np.abs(r).max())) if r.size else 0.0
+                assert e2 <= TOL, f"second shape {shape2}: {e2:.3e}"
+            again = eng.infer(x)
+            for (_, a), (_, b) in zip(first, again):
+                assert np.array_equal(a, b), "first shape again: not the bytes of its first run"
         api.prof_enable(True); api.prof_reset()
         got = eng.infer(x)
         classes = sorted(e["name"] for e in api.prof_snapshot() if e["launches"] > 0)
