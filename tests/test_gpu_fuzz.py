@@ -34,13 +34,13 @@ def test_random_seal_pages_match_oracle():
 
 
 def test_random_graphs_match_oracle():
-    """A seeded slice of tools/op_fuzz.py (round 6): four random graphs of each of its 22 kinds -- single layers around every kernel's eligibility boundary, blocks,
+    """A seeded slice of tools/op_fuzz.py (round 6): four random graphs of each of its 23 kinds -- single layers around every kernel's eligibility boundary, blocks,
     small networks, exporter shape arithmetic -- through the C ABI against the torch-CPU oracle at 2e-4, each on two input shapes through one engine."""
     import os
     root = Path(__file__).resolve().parents[1]
-    r = subprocess.run([sys.executable, str(root / "tools" / "op_fuzz.py"), "88", "5", "all"], cwd=root, capture_output=True, text=True, timeout=900, env=dict(os.environ, OP_FUZZ_RESHAPE="1"))
+    r = subprocess.run([sys.executable, str(root / "tools" / "op_fuzz.py"), "92", "5", "all"], cwd=root, capture_output=True, text=True, timeout=900, env=dict(os.environ, OP_FUZZ_RESHAPE="1"))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "88/88 cases within" in r.stdout, r.stdout[-1500:]
+    assert "92/92 cases within" in r.stdout, r.stdout[-1500:]
 
 
 def test_degenerate_and_extreme_pages_match_oracle():
