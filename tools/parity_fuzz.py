@@ -18,9 +18,15 @@ server = len(sys.argv) > 3 and sys.argv[3] == "server"       # BASELINE config 3
 seal = len(sys.argv) > 3 and sys.argv[3] == "seal"           # text_type "seal": stamp-like pages, polygon boxes, sort_poly_boxes, bounding-rectangle crops
 import os
 tiny_name = "tiny_full" if os.environ.get("FUZZ_GRAPHS", "") == "full" else "tiny"   # FUZZ_GRAPHS=full: the real-size graphs bench.py times by default since round 6
-det, _ = models.build_det("server" if server else tiny_name, seed=2 if server else 0)
-rec, _ = models.build_rec("server" if server else tiny_name, vocab=18710 if server else 6906, seed=3 if server else 1)
-chars = api.read_dict(models.synth_dict(18708 if server else 6904))
+c3small = os.environ.get("FUZZ_GRAPHS", "") == "c3small"   # the narrow twins of the C3 graphs (PP-HGNetV2 / LK-PAN detector, SVTRv2 recognizer): 9x9 convolutions, grouped mixing, streaming attention in the whole pipeline
+if c3small:
+    det, _ = models.build_det("hgnet_small", seed=0)
+    rec, _ = models.build_rec("svtrv2_small", vocab=6625, seed=1)
+    chars = api.read_dict(models.synth_dict(6623))
+else:
+    det, _ = models.build_det("server" if server else tiny_name, seed=2 if server else 0)
+    rec, _ = models.build_rec("server" if server else tiny_name, vocab=18710 if server else 6906, seed=3 if server else 1)
+    chars = api.read_dict(models.synth_dict(18708 if server else 6904))
 max_side = int(os.environ.get("FUZZ_MAX_SIDE", "0")) or (640 if server else 1100)   # FUZZ_MAX_SIDE=3000: pages far past limit_side_len (Triangle reduction by up to ~3x in front of the detector)
 only_case = int(sys.argv[4]) if len(sys.argv) > 4 else None
 bad = 0
